@@ -1,0 +1,151 @@
+/* oracle/ref_shim.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * A thin driver around the *unmodified* reference libFLAC (compiled in place from
+ * /root/reference by oracle/Makefile into oracle/_ref/libFLAC_ref.so).  It drives the
+ * reference exclusively through its public API (include/FLAC/stream_encoder.h:704-1896)
+ * and captures what the write callback receives, so tests and bench.py's cpu_baseline
+ * leg can (a) pin the CPU restatement in oracle/flac_oracle.c and the HIP path to the
+ * real reference bytes and (b) time the reference on the host cores.
+ *
+ * Nothing here restates reference logic; it only calls it.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "FLAC/stream_encoder.h"
+
+/* exported-but-unheadered test hooks of the reference (stream_encoder.c:1829,2249) */
+extern FLAC__bool FLAC__stream_encoder_set_do_md5(FLAC__StreamEncoder *encoder, FLAC__bool value);
+extern FLAC__bool FLAC__stream_encoder_disable_instruction_set(FLAC__StreamEncoder *encoder, int value);
+
+typedef struct {
+	uint8_t *out;
+	size_t cap, len;
+	uint32_t *frame_bytes;
+	uint32_t frame_cap, nframes;
+	uint64_t header_bytes;
+	int overflow;
+} capture_t;
+
+static FLAC__StreamEncoderWriteStatus write_cb(const FLAC__StreamEncoder *enc, const FLAC__byte buffer[], size_t bytes, uint32_t samples, uint32_t current_frame, void *client)
+{
+	capture_t *c = (capture_t *)client;
+	(void)enc; (void)current_frame;
+	if(c->out) {
+		if(c->len + bytes > c->cap) { c->overflow = 1; return FLAC__STREAM_ENCODER_WRITE_STATUS_FATAL_ERROR; }
+		memcpy(c->out + c->len, buffer, bytes);
+	}
+	c->len += bytes;
+	if(samples == 0)
+		c->header_bytes += bytes;
+	else {
+		if(c->frame_bytes && c->nframes < c->frame_cap)
+			c->frame_bytes[c->nframes] = (uint32_t)bytes;
+		c->nframes++;
+	}
+	return FLAC__STREAM_ENCODER_WRITE_STATUS_OK;
+}
+
+/* No seek/tell callbacks: the STREAMINFO block in the captured stream keeps its
+ * initial (zeroed MD5 / frame sizes) form; tests compare the audio frames, and the
+ * host layer's STREAMINFO fix-up is compared through ref_encode_file() below. */
+
+typedef struct {
+	uint32_t channels, bps, sample_rate;
+	int32_t level;            /* 0..8, applied first */
+	uint32_t blocksize;       /* 0 = keep preset default */
+	int32_t do_md5;           /* 0/1 */
+	int32_t num_threads;      /* 0/1 = single thread */
+	int32_t disable_isa_mask; /* passed to disable_instruction_set when != 0 */
+	int32_t limit_min_bitrate;/* 0/1 */
+	int32_t streamable_subset;/* 0/1 */
+	int32_t max_lpc_order;    /* -1 = keep preset */
+	int32_t qlp_precision;    /* -1 = keep preset */
+	int32_t min_partition_order, max_partition_order; /* -1 = keep preset */
+	int32_t mid_side, loose_mid_side; /* -1 = keep preset */
+	const char *apodization;  /* NULL = keep preset */
+} ref_cfg_t;
+
+static FLAC__StreamEncoder *make_encoder(const ref_cfg_t *cfg, uint64_t total_samples)
+{
+	FLAC__StreamEncoder *e = FLAC__stream_encoder_new();
+	if(!e) return 0;
+	FLAC__stream_encoder_set_channels(e, cfg->channels);
+	FLAC__stream_encoder_set_bits_per_sample(e, cfg->bps);
+	FLAC__stream_encoder_set_sample_rate(e, cfg->sample_rate);
+	FLAC__stream_encoder_set_streamable_subset(e, cfg->streamable_subset ? true : false);
+	FLAC__stream_encoder_set_compression_level(e, (uint32_t)cfg->level);
+	if(cfg->blocksize) FLAC__stream_encoder_set_blocksize(e, cfg->blocksize);
+	if(cfg->max_lpc_order >= 0) FLAC__stream_encoder_set_max_lpc_order(e, (uint32_t)cfg->max_lpc_order);
+	if(cfg->qlp_precision >= 0) FLAC__stream_encoder_set_qlp_coeff_precision(e, (uint32_t)cfg->qlp_precision);
+	if(cfg->min_partition_order >= 0) FLAC__stream_encoder_set_min_residual_partition_order(e, (uint32_t)cfg->min_partition_order);
+	if(cfg->max_partition_order >= 0) FLAC__stream_encoder_set_max_residual_partition_order(e, (uint32_t)cfg->max_partition_order);
+	if(cfg->mid_side >= 0) FLAC__stream_encoder_set_do_mid_side_stereo(e, cfg->mid_side ? true : false);
+	if(cfg->loose_mid_side >= 0) FLAC__stream_encoder_set_loose_mid_side_stereo(e, cfg->loose_mid_side ? true : false);
+	if(cfg->apodization) FLAC__stream_encoder_set_apodization(e, cfg->apodization);
+	FLAC__stream_encoder_set_limit_min_bitrate(e, cfg->limit_min_bitrate ? true : false);
+	FLAC__stream_encoder_set_do_md5(e, cfg->do_md5 ? true : false);
+	FLAC__stream_encoder_set_total_samples_estimate(e, total_samples);
+	if(cfg->num_threads > 1) FLAC__stream_encoder_set_num_threads(e, (uint32_t)cfg->num_threads);
+	if(cfg->disable_isa_mask) FLAC__stream_encoder_disable_instruction_set(e, cfg->disable_isa_mask);
+	return e;
+}
+
+/* Encode `nsamples` inter-channel samples of interleaved int32 PCM through the
+ * reference encoder (stream callbacks, write only).  Returns total bytes produced,
+ * or a negative value on error.  `out` may be NULL (measure only).
+ * `elapsed_s` (optional) receives the wall time spent inside process()+finish(). */
+int64_t ref_encode_stream(const ref_cfg_t *cfg, const int32_t *pcm_interleaved, uint64_t nsamples,
+                          uint8_t *out, uint64_t cap, uint32_t *frame_bytes, uint32_t frame_cap,
+                          uint32_t *nframes_out, uint64_t *header_bytes_out, double *elapsed_s)
+{
+	capture_t c;
+	struct timespec t0, t1;
+	FLAC__StreamEncoder *e = make_encoder(cfg, nsamples);
+	FLAC__bool ok = true;
+	uint64_t done = 0;
+	memset(&c, 0, sizeof c);
+	c.out = out; c.cap = (size_t)cap; c.frame_bytes = frame_bytes; c.frame_cap = frame_cap;
+	if(!e) return -1;
+	if(FLAC__stream_encoder_init_stream(e, write_cb, 0, 0, 0, &c) != FLAC__STREAM_ENCODER_INIT_STATUS_OK) {
+		FLAC__stream_encoder_delete(e);
+		return -2;
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	while(ok && done < nsamples) {
+		/* feed in chunks like a real client would; chunking does not change output */
+		uint64_t n = nsamples - done;
+		if(n > 1u << 20) n = 1u << 20;
+		ok = FLAC__stream_encoder_process_interleaved(e, pcm_interleaved + done * cfg->channels, (uint32_t)n);
+		done += n;
+	}
+	ok = FLAC__stream_encoder_finish(e) && ok;
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	FLAC__stream_encoder_delete(e);
+	if(elapsed_s) *elapsed_s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+	if(nframes_out) *nframes_out = c.nframes;
+	if(header_bytes_out) *header_bytes_out = c.header_bytes;
+	if(!ok || c.overflow) return -3;
+	return (int64_t)c.len;
+}
+
+/* Same, but through FLAC__stream_encoder_init_file so that the reference performs its
+ * STREAMINFO / seektable fix-up (stream_encoder.c:3139-3299); used to pin the host
+ * layer's whole-file output. Returns 0 on success. */
+int32_t ref_encode_file(const ref_cfg_t *cfg, const int32_t *pcm_interleaved, uint64_t nsamples, const char *path)
+{
+	FLAC__StreamEncoder *e = make_encoder(cfg, nsamples);
+	FLAC__bool ok;
+	if(!e) return -1;
+	if(FLAC__stream_encoder_init_file(e, path, 0, 0) != FLAC__STREAM_ENCODER_INIT_STATUS_OK) {
+		FLAC__stream_encoder_delete(e);
+		return -2;
+	}
+	ok = FLAC__stream_encoder_process_interleaved(e, pcm_interleaved, (uint32_t)nsamples);
+	ok = FLAC__stream_encoder_finish(e) && ok;
+	FLAC__stream_encoder_delete(e);
+	return ok ? 0 : -3;
+}
+
+const char *ref_vendor_string(void) { return FLAC__VENDOR_STRING; }

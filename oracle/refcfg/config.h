@@ -1,0 +1,43 @@
+/* Build configuration used when compiling the UNMODIFIED reference libFLAC sources
+ * (read in place from /root/reference) into oracle/_ref/.  This file is ours: it only
+ * states the configuration that the reference's CMake Release build selects on an
+ * x86-64 Linux host (config.cmake.h.in of the reference lists the knobs).
+ * TEST INFRASTRUCTURE ONLY. */
+#ifndef FLACGPU_REF_CONFIG_H
+#define FLACGPU_REF_CONFIG_H
+#define CPU_IS_BIG_ENDIAN 0
+#define WORDS_BIGENDIAN 0
+#define ENABLE_64_BIT_WORDS 1
+#define OGG_FOUND 0
+#define FLAC__HAS_OGG 0
+#define FLAC__HAS_X86INTRIN 1
+#define FLAC__HAS_NEONINTRIN 0
+#define FLAC__HAS_A64NEONINTRIN 0
+#define FLAC__SYS_LINUX
+#define WITH_AVX
+#define FLAC__USE_AVX
+#define HAVE_BSWAP16
+#define HAVE_BSWAP32
+#define HAVE_BYTESWAP_H
+#define HAVE_CLOCK_GETTIME
+#define HAVE_CPUID_H
+#define HAVE_FSEEKO
+#define HAVE_INTTYPES_H
+#define HAVE_LROUND 1
+#define HAVE_PTHREAD 1
+#define HAVE_STDINT_H
+#define HAVE_STDLIB_H
+#define HAVE_STRING_H
+#define HAVE_SYS_PARAM_H
+#define HAVE_SYS_STAT_H
+#define HAVE_SYS_TYPES_H
+#define HAVE_UNISTD_H
+#define HAVE_X86INTRIN_H
+#define PACKAGE_VERSION "1.5.0"
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#ifndef _FILE_OFFSET_BITS
+#define _FILE_OFFSET_BITS 64
+#endif
+#endif
