@@ -360,31 +360,53 @@ static float fixed_rbps(uint64_t err, uint32_t n)
 	return (float)(log(((double)err * M_LN2) / (double)n) * 1.4426950408889634);
 }
 /* data points at sample 4 of the block (data[-4..-1] are valid); n = blocksize-4.
- * 32-bit wrapping differences, 64-bit totals (identical to the 32-bit-total flavour whenever
- * the reference selects that one, stream_encoder.c:4098-4103). */
-uint32_t fo_fixed_best_predictor(const int32_t *data, uint32_t n, float rbps[5])
+ *
+ * narrow (wide=0): the reference dispatches to ..._intrin_ssse3 (fixed_intrin_ssse3.c:62,
+ *   selected at stream_encoder.c:1085 when bps+ilog2(17n) < 32): a 4-way split of the
+ *   block plus a scalar remainder -- exactly the plain sums of fixed.c:222 for every n.
+ * wide (wide=1): ..._wide_intrin_avx2 (fixed_intrin_avx2.c:57, selected at
+ *   stream_encoder.c:1095).  Its four 64-bit lanes each process q = n/4 samples; lane l
+ *   takes its 4-sample HISTORY from offset l*q but its DATA from offset (l*n)/4, and the
+ *   n%4 trailing samples are ignored ("Ignore the remainder").  For n%4 == 0 this is the
+ *   plain sum; otherwise lanes 2 and 3 difference across a small gap.  Restated literally:
+ *   lane l sees the virtual sequence  data[l*q-4 .. l*q-1] ++ data[(l*n)/4 .. (l*n)/4+q). */
+uint32_t fo_fixed_best_predictor_ex(const int32_t *data, uint32_t n, float rbps[5], int wide)
 {
-	uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+	uint64_t e[5] = {0, 0, 0, 0, 0};
 	uint32_t order;
-	for(int32_t i = 0; i < (int32_t)n; i++) {
-		uint32_t a = (uint32_t)data[i], b = (uint32_t)data[i - 1], c = (uint32_t)data[i - 2], d = (uint32_t)data[i - 3], e = (uint32_t)data[i - 4];
-		int32_t d0 = (int32_t)a, d1 = (int32_t)(a - b), d2 = (int32_t)(a - 2u * b + c), d3 = (int32_t)(a - 3u * b + 3u * c - d), d4 = (int32_t)(a - 4u * b + 6u * c - 4u * d + e);
-		e0 += (uint32_t)(d0 < 0 ? -(uint32_t)d0 : (uint32_t)d0);
-		e1 += (uint32_t)(d1 < 0 ? -(uint32_t)d1 : (uint32_t)d1);
-		e2 += (uint32_t)(d2 < 0 ? -(uint32_t)d2 : (uint32_t)d2);
-		e3 += (uint32_t)(d3 < 0 ? -(uint32_t)d3 : (uint32_t)d3);
-		e4 += (uint32_t)(d4 < 0 ? -(uint32_t)d4 : (uint32_t)d4);
+	if(!wide) {
+		for(int32_t i = 0; i < (int32_t)n; i++) {
+			uint32_t a = (uint32_t)data[i], b = (uint32_t)data[i - 1], c = (uint32_t)data[i - 2], d = (uint32_t)data[i - 3], f = (uint32_t)data[i - 4];
+			int32_t dd[5] = { (int32_t)a, (int32_t)(a - b), (int32_t)(a - 2u * b + c), (int32_t)(a - 3u * b + 3u * c - d), (int32_t)(a - 4u * b + 6u * c - 4u * d + f) };
+			for(int k = 0; k < 5; k++) e[k] += (uint32_t)(dd[k] < 0 ? -(uint32_t)dd[k] : (uint32_t)dd[k]);
+		}
+		for(int k = 0; k < 5; k++) e[k] = (uint32_t)e[k]; /* 32-bit totals there; cannot overflow by the selector's bound */
+	}
+	else {
+		const int32_t q = (int32_t)(n / 4);
+		for(int32_t l = 0; l < 4; l++) {
+			const int32_t hist = l * q, start = (int32_t)(((uint64_t)l * n) / 4);
+			for(int32_t i = 0; i < q; i++) {
+				int64_t v[5];
+				for(int32_t j = 0; j < 5; j++) { int32_t m = i - j; v[j] = data[m >= 0 ? start + m : hist + m]; }
+				int64_t dd[5] = { v[0], v[0] - v[1], v[0] - 2 * v[1] + v[2], v[0] - 3 * v[1] + 3 * v[2] - v[3], v[0] - 4 * v[1] + 6 * v[2] - 4 * v[3] + v[4] };
+				for(int k = 0; k < 5; k++) e[k] += (uint64_t)(dd[k] < 0 ? -dd[k] : dd[k]);
+			}
+		}
 	}
 #define MIN2(x, y) ((x) < (y) ? (x) : (y))
-	if(e0 <= MIN2(MIN2(MIN2(e1, e2), e3), e4)) order = 0;
-	else if(e1 <= MIN2(MIN2(e2, e3), e4)) order = 1;
-	else if(e2 <= MIN2(e3, e4)) order = 2;
-	else if(e3 <= e4) order = 3;
+	if(e[0] <= MIN2(MIN2(MIN2(e[1], e[2]), e[3]), e[4])) order = 0;
+	else if(e[1] <= MIN2(MIN2(e[2], e[3]), e[4])) order = 1;
+	else if(e[2] <= MIN2(e[3], e[4])) order = 2;
+	else if(e[3] <= e[4]) order = 3;
 	else order = 4;
 #undef MIN2
-	rbps[0] = fixed_rbps(e0, n); rbps[1] = fixed_rbps(e1, n); rbps[2] = fixed_rbps(e2, n);
-	rbps[3] = fixed_rbps(e3, n); rbps[4] = fixed_rbps(e4, n);
+	for(int k = 0; k < 5; k++) rbps[k] = fixed_rbps(e[k], n);
 	return order;
+}
+uint32_t fo_fixed_best_predictor(const int32_t *data, uint32_t n, float rbps[5])
+{
+	return fo_fixed_best_predictor_ex(data, n, rbps, 0);
 }
 
 /* fixed.c:470-499 (32-bit wrapping; the _wide flavour at :501 is selected only when
@@ -572,7 +594,9 @@ static void process_subframe(const fo_config *cfg, const int32_t *sig /* already
 
 	if(N > 4) {
 		float rbps[5];
-		const uint32_t guess_fixed = fo_fixed_best_predictor(sig + 4, N - 4, rbps);
+		/* selector: stream_encoder.c:4098-4103 (bps >= 28 flavours are outside this restatement) */
+		const int wide = !(subframe_bps + ilog2_u32((N - 4) * 17) < 32);
+		const uint32_t guess_fixed = fo_fixed_best_predictor_ex(sig + 4, N - 4, rbps, wide);
 		int constant = 0;
 		if(!disable_constant && rbps[1] == 0.0f) {
 			constant = 1;

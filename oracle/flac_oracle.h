@@ -96,7 +96,8 @@ void     fo_lp_coefficients(const double *autoc, uint32_t *max_order, float lp[]
 uint32_t fo_best_order(const double *err, uint32_t max_order, uint32_t total_samples, uint32_t overhead); /* lpc.c:1608 */
 double   fo_expected_bits_per_residual_sample(double lpc_error, uint32_t total_samples); /* lpc.c:1580 */
 int      fo_quantize_coefficients(const float *lp, uint32_t order, uint32_t precision, int32_t *q, int *shift); /* lpc.c:220 */
-uint32_t fo_fixed_best_predictor(const int32_t *data, uint32_t n, float rbps[5]); /* fixed.c:222/301; data[-4..n) */
+uint32_t fo_fixed_best_predictor(const int32_t *data, uint32_t n, float rbps[5]); /* fixed.c:222; data[-4..n) */
+uint32_t fo_fixed_best_predictor_ex(const int32_t *data, uint32_t n, float rbps[5], int wide); /* wide: fixed_intrin_avx2.c:57 */
 uint32_t fo_rice_search(const int32_t *residual, uint32_t residual_samples, uint32_t predictor_order,
                         uint32_t rice_limit, uint32_t min_po, uint32_t max_po, uint32_t bps,
                         uint32_t *best_po, uint32_t *params /*[1<<max_po]*/);     /* stream_encoder.c:4701 */
