@@ -1,0 +1,266 @@
+// flac_amd/csrc/flacgpu_api.cpp -- C-ABI entry points of libflacgpu.so (include/flacgpu.h).
+//
+// Host-side plumbing only: device buffers, streams, events, launches.  There is deliberately NO
+// CPU implementation behind these entry points: without a usable HIP device flacgpu_create()
+// fails with FLACGPU_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "flacgpu.h"
+#include "flacgpu_dev.h"
+
+using namespace flacgpu;
+
+struct flacgpu_ctx {
+	flacgpu_config cfg;
+	DevParams P;
+	int device;
+	hipStream_t stream;          // engine-owned stream (host-buffer entry point)
+	hipEvent_t ev[5];            // start, after analyze, after pack, after compact, spare
+	float *d_windows;            // [num_apod][blocksize]
+	float *d_tail_windows;       // [num_apod][blocksize] scratch for the short last block
+	SubDecision *d_decisions;    // [max_batch][ncand]
+	uint8_t *d_slots;            // [max_batch][slot_bytes]
+	uint32_t *d_frame_bytes;     // [max_batch]
+	uint64_t *d_offsets;         // [max_batch+1]
+	uint64_t *d_total;
+	FrameInfo *d_info;           // [max_batch]
+	int32_t *d_pcm;              // staging for the host entry point
+	uint8_t *d_out;
+	size_t d_pcm_bytes, d_out_bytes;
+	uint32_t last_nframes;
+	bool timing_valid;
+};
+
+static int ilog2u(uint32_t v) { int r = -1; while(v) { r++; v >>= 1; } return r; }
+
+extern "C" const char *flacgpu_strerror(int code)
+{
+	switch(code) {
+		case FLACGPU_OK: return "ok";
+		case FLACGPU_ERR_UNSUPPORTED: return "configuration outside the GPU engine's supported range";
+		case FLACGPU_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+		case FLACGPU_ERR_ALLOC: return "device memory allocation failed";
+		case FLACGPU_ERR_OUTPUT_TOO_SMALL: return "output buffer too small";
+		case FLACGPU_ERR_LAUNCH: return "kernel launch or execution failed";
+		case FLACGPU_ERR_BAD_ARG: return "bad argument";
+		default: return "unknown error";
+	}
+}
+
+extern "C" int flacgpu_device_count(void)
+{
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+static void free_ctx(flacgpu_ctx *c)
+{
+	if(!c) return;
+	(void)hipSetDevice(c->device);
+	if(c->d_windows) (void)hipFree(c->d_windows);
+	if(c->d_tail_windows) (void)hipFree(c->d_tail_windows);
+	if(c->d_decisions) (void)hipFree(c->d_decisions);
+	if(c->d_slots) (void)hipFree(c->d_slots);
+	if(c->d_frame_bytes) (void)hipFree(c->d_frame_bytes);
+	if(c->d_offsets) (void)hipFree(c->d_offsets);
+	if(c->d_total) (void)hipFree(c->d_total);
+	if(c->d_info) (void)hipFree(c->d_info);
+	if(c->d_pcm) (void)hipFree(c->d_pcm);
+	if(c->d_out) (void)hipFree(c->d_out);
+	for(int i = 0; i < 5; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	if(c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, flacgpu_ctx **out)
+{
+	if(!cfg || !out || cfg->abi_version != FLACGPU_ABI_VERSION) return FLACGPU_ERR_BAD_ARG;
+	*out = nullptr;
+	// ---- supported range (everything else is a documented, loud failure; no CPU fallback) ----
+	if(cfg->channels < 1 || cfg->channels > FLACGPU_MAX_CHANNELS) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->bits_per_sample < 4 || cfg->bits_per_sample > 24) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->blocksize < 16 || cfg->blocksize > 16384) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->max_lpc_order > 15) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->max_lpc_order > 0 && (cfg->qlp_coeff_precision < 5 || cfg->qlp_coeff_precision > 15)) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->max_residual_partition_order > MAX_PO) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->max_lpc_order > 0 && (cfg->num_apodizations < 1 || cfg->num_apodizations > FLACGPU_MAX_APODIZATIONS)) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->max_lpc_order > 0 && !windows) return FLACGPU_ERR_BAD_ARG;
+	if(cfg->max_batch_frames < 1) return FLACGPU_ERR_BAD_ARG;
+	for(uint32_t a = 0; a < cfg->num_apodizations && cfg->max_lpc_order > 0; a++)
+		if(cfg->apodizations[a].kind == FLACGPU_APOD_SUBDIVIDE_TUKEY && cfg->apodizations[a].parts < 2) return FLACGPU_ERR_BAD_ARG;
+
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return FLACGPU_ERR_NO_DEVICE;
+	if(hipSetDevice(cfg->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+
+	flacgpu_ctx *c = new(std::nothrow) flacgpu_ctx();
+	if(!c) return FLACGPU_ERR_ALLOC;
+	memset(c, 0, sizeof *c);
+	c->cfg = *cfg;
+	c->device = cfg->device;
+
+	DevParams &P = c->P;
+	const uint32_t C = cfg->channels, N = cfg->blocksize, bps = cfg->bits_per_sample;
+	P.channels = C; P.bps = bps; P.sample_rate = cfg->sample_rate; P.blocksize = N;
+	// stream_encoder.c:737-741: mid/side only for stereo; loose only with mid/side
+	const bool ms = cfg->do_mid_side_stereo && C == 2;
+	P.ms_mode = ms ? (cfg->loose_mid_side_stereo ? 2u : 1u) : 0u;
+	P.ncand = P.ms_mode == 1 ? 4u : C;
+	P.max_lpc_order = cfg->max_lpc_order;
+	P.precision = cfg->qlp_coeff_precision;
+	P.min_po = cfg->min_residual_partition_order;
+	P.max_po = cfg->max_residual_partition_order;
+	P.rice_limit = bps > 16 ? 31u : 15u;                       // stream_encoder.c:4076
+	P.num_apod = cfg->max_lpc_order > 0 ? cfg->num_apodizations : 0;
+	for(uint32_t a = 0; a < P.num_apod; a++) { P.apod_kind[a] = cfg->apodizations[a].kind; P.apod_parts[a] = cfg->apodizations[a].parts; }
+	// stream_encoder.c:1058-1066 on an FMA-capable x86-64 host
+	P.autoc_variant = cfg->max_lpc_order < 8 ? 8u : cfg->max_lpc_order < 12 ? 12u : 16u;
+	P.disable_constant = cfg->disable_constant_subframes; P.disable_fixed = cfg->disable_fixed_subframes;
+	P.disable_verbatim = cfg->disable_verbatim_subframes; P.limit_min_bitrate = cfg->limit_min_bitrate;
+	// worst-case frame: header + per channel (verbatim size + Rice estimate slack of N/2 bits + side info)
+	{
+		const uint64_t per_ch_bits = (uint64_t)N * (bps + 1) + N / 2 + 8 + 32 + 16 * 33 + 9 + 6 + 5 * (1u << MAX_PO);
+		uint64_t bytes = 16 + C * ((per_ch_bits + 7) / 8) + 2 + 16;
+		P.slot_bytes = (uint32_t)((bytes + 15) & ~(uint64_t)15);
+	}
+	{
+		const uint32_t maxidx = 32 + ((N + 15u) & ~15u) + 16u + 16u;
+		P.sig_bytes = ((maxidx + ((maxidx >> 4) << 1) + 8) * 4 + 15) & ~15u;
+		P.wnd_bytes = ((N + 64) * 4 + 15) & ~15u;
+	}
+	if(analyze_lds_bytes(P) > 160 * 1024 - 1024 || pack_lds_bytes(P) > 160 * 1024 - 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
+
+	bool ok = true;
+	ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+	for(int i = 0; i < 5 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+	const size_t B = cfg->max_batch_frames;
+	const size_t wbytes = (size_t)(P.num_apod ? P.num_apod : 1) * N * sizeof(float);
+	ok = ok && hipMalloc(&c->d_windows, wbytes) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_tail_windows, wbytes) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_decisions, B * P.ncand * sizeof(SubDecision)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_slots, B * P.slot_bytes) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_frame_bytes, B * sizeof(uint32_t)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_offsets, (B + 1) * sizeof(uint64_t)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_total, sizeof(uint64_t)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_info, B * sizeof(FrameInfo)) == hipSuccess;
+	if(ok && P.num_apod) ok = hipMemcpy(c->d_windows, windows, wbytes, hipMemcpyHostToDevice) == hipSuccess;
+	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
+	*out = c;
+	return FLACGPU_OK;
+}
+
+extern "C" void flacgpu_destroy(flacgpu_ctx *ctx) { free_ctx(ctx); }
+
+extern "C" size_t flacgpu_max_output_bytes(const flacgpu_ctx *ctx, uint32_t nframes)
+{
+	return ctx ? (size_t)nframes * ctx->P.slot_bytes : 0;
+}
+
+static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uint64_t first, uint32_t tail_n,
+                     const float *tail_windows_host, uint8_t *d_out, size_t out_cap, uint32_t *d_fb_out,
+                     uint64_t *d_total_out, hipStream_t s)
+{
+	if(!c || !d_pcm || !d_out || nframes == 0 || nframes > c->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
+	if(tail_n >= c->P.blocksize) tail_n = 0;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	const DevParams &P = c->P;
+	if(tail_n && P.num_apod) {
+		if(!tail_windows_host) return FLACGPU_ERR_BAD_ARG;
+		if(hipMemcpyAsync(c->d_tail_windows, tail_windows_host, (size_t)P.num_apod * tail_n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	}
+	(void)hipEventRecord(c->ev[0], s);
+	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_decisions, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	(void)hipEventRecord(c->ev[1], s);
+	if(launch_pack(P, d_pcm, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	(void)hipEventRecord(c->ev[2], s);
+	if(launch_scan(c->d_frame_bytes, nframes, c->d_offsets, c->d_total, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(launch_compact(c->d_slots, P.slot_bytes, c->d_frame_bytes, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	(void)hipEventRecord(c->ev[3], s);
+	if(d_fb_out && hipMemcpyAsync(d_fb_out, c->d_frame_bytes, nframes * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(d_total_out && hipMemcpyAsync(d_total_out, c->d_total, sizeof(uint64_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	c->last_nframes = nframes;
+	c->timing_valid = true;
+	return FLACGPU_OK;
+}
+
+extern "C" int flacgpu_encode_batch_device(flacgpu_ctx *ctx, const int32_t *d_pcm, uint32_t nframes,
+                                           uint64_t first_frame_number, uint32_t last_block_samples,
+                                           const float *tail_windows_host, uint8_t *d_out, size_t out_cap,
+                                           uint32_t *d_frame_bytes, uint64_t *d_total_bytes, void *stream)
+{
+	return run_batch(ctx, d_pcm, nframes, first_frame_number, last_block_samples, tail_windows_host, d_out, out_cap,
+	                 d_frame_bytes, d_total_bytes, stream ? (hipStream_t)stream : (ctx ? ctx->stream : nullptr));
+}
+
+extern "C" int64_t flacgpu_encode_batch(flacgpu_ctx *c, const int32_t *pcm, uint32_t nframes,
+                                        uint64_t first_frame_number, uint32_t last_block_samples,
+                                        const float *tail_windows, uint8_t *out, size_t out_cap,
+                                        uint32_t *frame_bytes)
+{
+	if(!c || !pcm || !out || !frame_bytes || nframes == 0 || nframes > c->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	const DevParams &P = c->P;
+	uint32_t tail_n = last_block_samples < P.blocksize ? last_block_samples : 0;
+	const size_t nsamp = (size_t)(nframes - 1) * P.blocksize + (tail_n ? tail_n : P.blocksize);
+	// the kernels index frames at a fixed stride of blocksize*channels; staging is sized for full frames
+	const size_t pcm_bytes = (size_t)nframes * P.blocksize * P.channels * sizeof(int32_t);
+	const size_t out_bytes = (size_t)nframes * P.slot_bytes;
+	if(c->d_pcm_bytes < pcm_bytes) {
+		if(c->d_pcm) (void)hipFree(c->d_pcm);
+		c->d_pcm = nullptr; c->d_pcm_bytes = 0;
+		if(hipMalloc(&c->d_pcm, pcm_bytes) != hipSuccess) return FLACGPU_ERR_ALLOC;
+		c->d_pcm_bytes = pcm_bytes;
+	}
+	if(c->d_out_bytes < out_bytes) {
+		if(c->d_out) (void)hipFree(c->d_out);
+		c->d_out = nullptr; c->d_out_bytes = 0;
+		if(hipMalloc(&c->d_out, out_bytes) != hipSuccess) return FLACGPU_ERR_ALLOC;
+		c->d_out_bytes = out_bytes;
+	}
+	hipStream_t s = c->stream;
+	if(hipMemcpyAsync(c->d_pcm, pcm, nsamp * P.channels * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	int r = run_batch(c, c->d_pcm, nframes, first_frame_number, tail_n, tail_windows, c->d_out, out_bytes, nullptr, nullptr, s);
+	if(r != FLACGPU_OK) return r;
+	uint64_t total = 0;
+	if(hipMemcpyAsync(frame_bytes, c->d_frame_bytes, nframes * sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipMemcpyAsync(&total, c->d_total, sizeof total, hipMemcpyDeviceToHost, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipStreamSynchronize(s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	for(uint32_t i = 0; i < nframes; i++) if(frame_bytes[i] == 0xffffffffu) return FLACGPU_ERR_LAUNCH;
+	if(total > out_cap) return FLACGPU_ERR_OUTPUT_TOO_SMALL;
+	if(hipMemcpy(out, c->d_out, total, hipMemcpyDeviceToHost) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	return (int64_t)total;
+}
+
+extern "C" int flacgpu_last_batch_info(flacgpu_ctx *c, uint32_t nframes, flacgpu_subframe_info *sub, uint8_t *channel_assignment)
+{
+	if(!c || nframes == 0 || nframes > c->last_nframes) return FLACGPU_ERR_BAD_ARG;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	FrameInfo *h = (FrameInfo *)malloc(sizeof(FrameInfo) * nframes);
+	if(!h) return FLACGPU_ERR_ALLOC;
+	if(hipMemcpy(h, c->d_info, sizeof(FrameInfo) * nframes, hipMemcpyDeviceToHost) != hipSuccess) { free(h); return FLACGPU_ERR_LAUNCH; }
+	for(uint32_t f = 0; f < nframes; f++) {
+		if(sub) for(uint32_t ch = 0; ch < c->P.channels; ch++) sub[(size_t)f * c->P.channels + ch] = h[f].sub[ch];
+		if(channel_assignment) channel_assignment[f] = h[f].channel_assignment;
+	}
+	free(h);
+	return FLACGPU_OK;
+}
+
+extern "C" int flacgpu_last_batch_kernel_ms(flacgpu_ctx *c, float *analyze_ms, float *pack_ms, float *compact_ms)
+{
+	if(!c || !c->timing_valid) return FLACGPU_ERR_BAD_ARG;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	if(hipEventSynchronize(c->ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	float a = 0, p = 0, k = 0;
+	if(hipEventElapsedTime(&a, c->ev[0], c->ev[1]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipEventElapsedTime(&p, c->ev[1], c->ev[2]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipEventElapsedTime(&k, c->ev[2], c->ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(analyze_ms) *analyze_ms = a;
+	if(pack_ms) *pack_ms = p;
+	if(compact_ms) *compact_ms = k;
+	return FLACGPU_OK;
+}

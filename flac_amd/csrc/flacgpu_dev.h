@@ -1,0 +1,67 @@
+// flac_amd/csrc/flacgpu_dev.h -- structures shared by the kernels and the C-ABI host code.
+#ifndef FLACGPU_DEV_H
+#define FLACGPU_DEV_H
+#include <stdint.h>
+#include <stddef.h>
+#include <hip/hip_runtime.h>
+#include "flacgpu.h"
+
+namespace flacgpu {
+
+constexpr int TPB = 256;        // threads per workgroup (4 wavefronts of 64)
+constexpr int CHUNK = 16;       // consecutive samples owned by one thread in FIR passes
+constexpr int MAX_ORDER = 16;   // taps kept per candidate (max_lpc_order <= 15)
+constexpr int MAX_PO = 8;       // max residual partition order (FLAC subset limit)
+
+// flattened, device-friendly copy of flacgpu_config
+struct DevParams {
+	uint32_t channels, bps, sample_rate, blocksize;
+	uint32_t ms_mode;          // 0 none, 1 full mid/side search, 2 loose
+	uint32_t ncand;            // candidate channels analysed per frame
+	uint32_t max_lpc_order, precision, min_po, max_po, rice_limit;
+	uint32_t num_apod;
+	uint32_t apod_kind[FLACGPU_MAX_APODIZATIONS], apod_parts[FLACGPU_MAX_APODIZATIONS];
+	uint32_t autoc_variant;    // 8 / 12 / 16: which compiled reference routine to follow
+	uint32_t disable_constant, disable_fixed, disable_verbatim, limit_min_bitrate;
+	uint32_t slot_bytes;       // bytes reserved per frame in the slot buffer / LDS frame image
+	uint32_t sig_bytes;        // LDS bytes of the padded signal array
+	uint32_t wnd_bytes;        // LDS bytes of the windowed-signal array
+};
+
+// analysis -> pack hand-off, one per (frame, candidate channel); 16-byte multiple
+struct SubDecision {
+	uint32_t bits;             // estimated subframe bits (selection metric)
+	uint8_t type;              // 0 CONSTANT 1 VERBATIM 2 FIXED 3 LPC
+	uint8_t order, wasted, po, rice2, precision;
+	int8_t shift;
+	uint8_t which;             // signal modelled: 0..C-1 channel, C mid, C+1 side
+	int32_t constant;
+	int32_t q[MAX_ORDER];
+	uint8_t params[1u << MAX_PO];
+};
+
+struct Candidate {
+	uint32_t order, precision;
+	int32_t shift;
+	uint32_t wide;             // 64-bit accumulate FIR (lpc.c:582) instead of 32-bit (lpc.c:321)
+	int32_t q[MAX_ORDER];
+};
+
+struct FrameInfo {
+	flacgpu_subframe_info sub[FLACGPU_MAX_CHANNELS];
+	uint8_t channel_assignment;
+	uint8_t pad[3];
+};
+
+size_t analyze_lds_bytes(const DevParams &P);
+size_t pack_lds_bytes(const DevParams &P);
+hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
+                          uint32_t nframes, uint32_t tail_n, SubDecision *dec, hipStream_t s);
+hipError_t launch_pack(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
+                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, hipStream_t s);
+hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);
+hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,
+                          uint8_t *out, uint64_t out_cap, uint32_t nframes, hipStream_t s);
+
+} // namespace flacgpu
+#endif

@@ -1,0 +1,1235 @@
+// flac_amd/csrc/flacgpu_kernels.hip -- CDNA4 (gfx950) kernels of the FLAC frame engine.
+//
+// One launch encodes a batch of thousands of independent frames (the reference encodes one frame
+// per thread-pool task, src/libFLAC/stream_encoder.c:3627-3744):
+//
+//   analyze_kernel : one workgroup per (frame, candidate channel).  Channel signal lives in LDS for
+//                    the whole model search of process_subframe_ (stream_encoder.c:4045-4290):
+//                    wasted bits (:5077), fixed-predictor sums (fixed.c:222 / fixed_intrin_avx2.c:57),
+//                    windowing + autocorrelation in the reference's compiled association order
+//                    (lpc_intrin_fma.c:46-72), Levinson-Durbin / order guess /
+//                    quantisation (lpc.c:176,1608,220) and, per candidate, an integer FIR straight
+//                    out of LDS feeding per-partition |residual| sums (LDS atomics) and the closed-form
+//                    Rice parameter / bit estimate (stream_encoder.c:4701-5075).  Emits one small
+//                    decision record; residuals never touch HBM.
+//   pack_kernel    : one workgroup per frame.  Channel-assignment argmin (stream_encoder.c:3944-3972),
+//                    recomputes only the winning residuals, per-symbol bit lengths -> workgroup prefix
+//                    sum -> bits OR-ed into an LDS frame image (stream_encoder_framing.c:245-594,
+//                    bitwriter.c:575), CRC-8 / parallel CRC-16 (crc.c:366,376), coalesced store.
+//   scan/compact   : exclusive prefix sum of frame lengths, frames packed back to back.
+//
+// Integer/byte work, HBM/LDS/VALU bound: no MFMA by design.  Compile with -ffp-contract=off: the
+// fp64 sections must round exactly like the reference binary.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "flacgpu_dev.h"
+
+namespace flacgpu {
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ilog2_u32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
+__device__ __forceinline__ uint32_t ilog2_u64(uint64_t v) { return 63u - (uint32_t)__clzll((long long)v); }
+__device__ __forceinline__ uint32_t silog2_i64(int64_t v)
+{
+	if(v == 0) return 0;
+	if(v == -1) return 2;
+	if(v < 0) v = -(v + 1);
+	return ilog2_u64((uint64_t)v) + 2;
+}
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// LDS signal layout: rows of 16 samples padded to 18 words so that the per-thread sliding window
+// (thread t owns samples [16t,16t+16)) reads conflict-free; 32 zero samples in front so that a
+// zero-padded FIR of up to 32 taps never needs a bounds check.
+__device__ __forceinline__ int sigidx(int i) { const int m = i + 32; return m + ((m >> 4) << 1); }
+
+__device__ __forceinline__ uint64_t wave_reduce_add_u64(uint64_t v)
+{
+#pragma unroll
+	for(int off = 32; off >= 1; off >>= 1) {
+		uint32_t lo = __shfl_xor((uint32_t)v, off), hi = __shfl_xor((uint32_t)(v >> 32), off);
+		v += ((uint64_t)hi << 32) | lo;
+	}
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_or_u32(uint32_t v)
+{
+#pragma unroll
+	for(int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off);
+	return v;
+}
+// workgroup reductions through a small LDS scratch (8 x u64)
+__device__ __forceinline__ uint64_t block_reduce_add_u64(uint64_t v, uint64_t *scratch, int tid)
+{
+	v = wave_reduce_add_u64(v);
+	__syncthreads();
+	if((tid & 63) == 0) scratch[tid >> 6] = v;
+	__syncthreads();
+	uint64_t r = 0;
+	for(int w = 0; w < TPB / 64; w++) r += scratch[w];
+	return r;
+}
+__device__ __forceinline__ uint32_t block_reduce_or_u32(uint32_t v, uint64_t *scratch, int tid)
+{
+	v = wave_reduce_or_u32(v);
+	__syncthreads();
+	if((tid & 63) == 0) scratch[tid >> 6] = v;
+	__syncthreads();
+	uint32_t r = 0;
+	for(int w = 0; w < TPB / 64; w++) r |= (uint32_t)scratch[w];
+	return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp64 model stages, one lane each (lpc.c:176-314,1580-1630 as compiled; see oracle/flac_oracle.c)
+// ---------------------------------------------------------------------------------------------
+__device__ double expected_bits_scaled(double lpc_error, double error_scale)
+{
+	if(lpc_error > 0.0) {
+		// 0.5*log(x)/M_LN2 folded by -freciprocal-math into log(x) * (0.5/ln 2)
+		double bps = log(error_scale * lpc_error) * 0.7213475204444817;
+		return bps >= 0.0 ? bps : 0.0;
+	}
+	if(lpc_error < 0.0) return 1e32;
+	return 0.0;
+}
+
+// Levinson-Durbin + order guess + coefficient quantisation for one analysis.
+// Returns 0 when no LPC candidate results (autoc[0]==0, estimate >= bps, quantiser failure, residual
+// would need the >32-bit "limit_residual" flavour).
+__device__ int lpc_model(const double *autoc, uint32_t max_order, uint32_t n, uint32_t sbps,
+                         uint32_t cfg_precision, Candidate *out)
+{
+	double lpc[MAX_ORDER], err_of[MAX_ORDER];
+	float coef[MAX_ORDER];          // coefficients of the guessed order, filled on the second pass
+	if(autoc[0] == 0.0) return 0;
+	// pass 1: errors for every order (lp_coeff of all orders is not kept; the chosen order's
+	// coefficients are regenerated below -- Levinson is deterministic)
+	uint32_t used = max_order;
+	{
+		double err = autoc[0];
+		for(uint32_t i = 0; i < max_order; i++) {
+			double r = -autoc[i + 1];
+			uint32_t j;
+			for(j = 0; j < i; j++) r -= lpc[j] * autoc[i - j];
+			r /= err;
+			lpc[i] = r;
+			for(j = 0; j < (i >> 1); j++) {
+				double tmp = lpc[j];
+				lpc[j] += r * lpc[i - 1 - j];
+				lpc[i - 1 - j] += r * tmp;
+			}
+			if(i & 1) lpc[j] = (r + 1.0) * lpc[j];
+			err *= (1.0 - r * r);
+			err_of[i] = err;
+			if(err == 0.0) { used = i + 1; break; }
+		}
+	}
+	// FLAC__lpc_compute_best_order (lpc.c:1608): total_samples is the full blocksize
+	uint32_t order;
+	{
+		const double scale = 0.5 / (double)n;
+		const uint32_t overhead = sbps + cfg_precision;
+		double best_bits = 4294967295.0;
+		uint32_t best = 0;
+		for(uint32_t idx = 0, o = 1; idx < used; idx++, o++) {
+			double bits = expected_bits_scaled(err_of[idx], scale) * (double)(n - o) + (double)(o * overhead);
+			if(bits < best_bits) { best = idx; best_bits = bits; }
+		}
+		order = best + 1;
+	}
+	// stream_encoder.c:4227-4229
+	if(expected_bits_scaled(err_of[order - 1], 0.5 / (double)(n - order)) >= (double)sbps) return 0;
+	// pass 2: coefficients of `order`
+	{
+		double err = autoc[0];
+		for(uint32_t i = 0; i < order; i++) {
+			double r = -autoc[i + 1];
+			uint32_t j;
+			for(j = 0; j < i; j++) r -= lpc[j] * autoc[i - j];
+			r /= err;
+			lpc[i] = r;
+			for(j = 0; j < (i >> 1); j++) {
+				double tmp = lpc[j];
+				lpc[j] += r * lpc[i - 1 - j];
+				lpc[i - 1 - j] += r * tmp;
+			}
+			if(i & 1) lpc[j] = (r + 1.0) * lpc[j];
+			err *= (1.0 - r * r);
+		}
+		for(uint32_t j = 0; j < order; j++) coef[j] = (float)(-lpc[j]);
+	}
+	// stream_encoder.c:4591-4595 then FLAC__lpc_quantize_coefficients (lpc.c:220)
+	uint32_t precision = cfg_precision;
+	if(sbps <= 17) precision = umin32(precision, 32 - sbps - ilog2_u32(order));
+	int shift;
+	{
+		const uint32_t p1 = precision - 1;
+		int32_t qmax = (int32_t)1 << p1, qmin = -qmax;
+		qmax--;
+		double cmax = 0.0;
+		for(uint32_t i = 0; i < order; i++) { double a = fabs((double)coef[i]); if(a > cmax) cmax = a; }
+		if(cmax <= 0.0) return 0;
+		int e;
+		(void)frexp(cmax, &e);
+		e--;
+		shift = (int)p1 - e - 1;
+		if(shift > 15) shift = 15;
+		else if(shift < -16) return 0;
+		double error = 0.0;
+		for(uint32_t i = 0; i < MAX_ORDER; i++) out->q[i] = 0;
+		if(shift >= 0) {
+			const float scale = (float)(1 << shift);
+			for(uint32_t i = 0; i < order; i++) {
+				error += (double)(coef[i] * scale);
+				int32_t v = (int32_t)lround(error);
+				if(v > qmax) v = qmax; else if(v < qmin) v = qmin;
+				error -= v;
+				out->q[i] = v;
+			}
+		}
+		else {
+			const float scale = (float)(1 << (-shift));
+			for(uint32_t i = 0; i < order; i++) {
+				error += (double)(coef[i] / scale);
+				int32_t v = (int32_t)lround(error);
+				if(v > qmax) v = qmax; else if(v < qmin) v = qmin;
+				error -= v;
+				out->q[i] = v;
+			}
+			shift = 0;
+		}
+	}
+	// residual kernel selector (stream_encoder.c:4601-4617, lpc.c:942-976)
+	{
+		uint32_t abs_sum = 0;
+		for(uint32_t i = 0; i < order; i++) abs_sum += (uint32_t)abs(out->q[i]);
+		const uint64_t maxabs = (uint64_t)1 << (sbps - 1);
+		const uint64_t before = maxabs * abs_sum;
+		const uint64_t after = (uint64_t)(-1 * ((-1 * (int64_t)before) >> shift));
+		if(silog2_i64((int64_t)(maxabs + after)) > 32) return 0;
+		out->wide = silog2_i64((int64_t)before) > 32;
+	}
+	out->order = order;
+	out->precision = precision;
+	out->shift = shift;
+	return 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// autocorrelation chains (one lane per (lag j, vector lane l)), SURVEY.md 5.9
+// d = windowed data in LDS, nd = data_len. Result in autoc[0..lag).
+// ---------------------------------------------------------------------------------------------
+#define DD(k) ((double)d[k])
+__device__ __forceinline__ double autoc_tail(const float *d, uint32_t i, uint32_t nd, uint32_t j, double a)
+{
+	if(nd - i >= 4) {
+		double hi = fma(DD(i + 1), DD(i + 1 - j), DD(i + 3) * DD(i + 3 - j));
+		double lo = fma(DD(i), DD(i - j), DD(i + 2) * DD(i + 2 - j));
+		a = (hi + lo) + a;
+		i += 4;
+	}
+	for(; i < nd; i++) a = fma(DD(i), DD(i - j), a);
+	return a;
+}
+
+// FMA lag-8 / lag-16 routines (lpc_intrin_fma.c:46,61)
+__device__ void autoc_fma_8_16(const float *d, uint32_t nd, uint32_t L, uint32_t lag, double *autoc, int tid)
+{
+	const uint32_t j = (uint32_t)tid >> 2, l = (uint32_t)tid & 3;
+	if(j >= ((lag + 15u) & ~15u)) return;            // whole waves of idle lanes leave; lanes sharing a wave stay for the shuffles
+	const bool live = j < lag;
+	const uint32_t jj = live ? j : 0;
+	const uint32_t nb = (nd - L) / 8;
+	double acc = 0.0;
+	uint32_t i = L + l;
+	for(uint32_t k = 0; k < nb; k++, i += 8)
+		acc += fma(DD(i), DD(i - jj), DD(i + 4) * DD(i + 4 - jj));
+	// (acc3+acc1)+(acc2+acc0) within each group of 4 lanes
+	double a_odd, a_even;
+	{
+		// lane l gets partner l^2: l=0:(0,2) l=1:(1,3)
+		uint32_t lo = __shfl_xor((uint32_t)__double2loint(acc), 2), hi = __shfl_xor((uint32_t)__double2hiint(acc), 2);
+		double partner = __hiloint2double((int)hi, (int)lo);
+		// want (acc3+acc1) and (acc2+acc0): on lane 1: partner=acc3 -> acc3+acc1 ; on lane 0: partner=acc2 -> acc2+acc0
+		double s = partner + acc;
+		uint32_t slo = __shfl_xor((uint32_t)__double2loint(s), 1), shi = __shfl_xor((uint32_t)__double2hiint(s), 1);
+		double other = __hiloint2double((int)shi, (int)slo);
+		a_even = (l & 1) ? other : s;   // (acc2+acc0)
+		a_odd = (l & 1) ? s : other;    // (acc3+acc1)
+	}
+	if(live && l == 0) {
+		double a = 0.0;
+		for(uint32_t h = jj; h < L; h++) a += DD(h) * DD(h - jj);
+		if(nb) a = (a_odd + a_even) + a;
+		autoc[jj] = autoc_tail(d, L + 8 * nb, nd, jj, a);
+	}
+}
+
+// FMA lag-12 routine (lpc_intrin_fma.c:54): 2x-unrolled body, lag 8 factored
+__device__ void autoc_fma_12(const float *d, uint32_t nd, uint32_t lag, double *autoc, int tid)
+{
+	const uint32_t L = 12;
+	const uint32_t j = (uint32_t)tid >> 2, l = (uint32_t)tid & 3;
+	if(j >= ((lag + 15u) & ~15u)) return;
+	const bool live = j < lag;
+	const uint32_t jj = live ? j : 0;
+	const uint32_t nb = (nd - L) / 8;
+	const uint32_t npairs = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
+	double acc = 0.0;
+	uint32_t i = L + l, k = 0;
+	if(jj == 8) {
+		for(uint32_t p = 0; p < npairs; p++, k += 2, i += 16) {
+			double x0 = DD(i), x1 = DD(i + 4), x2 = DD(i + 8), x3 = DD(i + 12), y0 = DD(i - 8), y1 = DD(i - 4);
+			acc += fma(x0, (y0 + x2), x1 * (y1 + x3));
+		}
+	}
+	else {
+		for(uint32_t p = 0; p < npairs; p++, k += 2, i += 16) {
+			double t0 = fma(DD(i), DD(i - jj), DD(i + 4) * DD(i + 4 - jj));
+			double t1 = fma(DD(i + 8), DD(i + 8 - jj), DD(i + 12) * DD(i + 12 - jj));
+			acc += (t1 + t0);
+		}
+	}
+	for(; k < nb; k++, i += 8)
+		acc += fma(DD(i), DD(i - jj), DD(i + 4) * DD(i + 4 - jj));
+	double a_odd, a_even;
+	{
+		uint32_t lo = __shfl_xor((uint32_t)__double2loint(acc), 2), hi = __shfl_xor((uint32_t)__double2hiint(acc), 2);
+		double s = __hiloint2double((int)hi, (int)lo) + acc;
+		uint32_t slo = __shfl_xor((uint32_t)__double2loint(s), 1), shi = __shfl_xor((uint32_t)__double2hiint(s), 1);
+		double other = __hiloint2double((int)shi, (int)slo);
+		a_even = (l & 1) ? other : s;
+		a_odd = (l & 1) ? s : other;
+	}
+	if(live && l == 0) {
+		double a = 0.0;
+		for(uint32_t h = jj; h < L; h++) a += DD(h) * DD(h - jj);
+		if(nb) a = (a_odd + a_even) + a;
+		autoc[jj] = autoc_tail(d, L + 8 * nb, nd, jj, a);
+	}
+}
+
+// lpc.c:133-157 (blocksize <= 32): sequential per lag
+__device__ void autoc_small(const float *d, uint32_t nd, uint32_t lag, double *autoc, int tid)
+{
+	if((uint32_t)tid >= lag) return;
+	const uint32_t c = (uint32_t)tid;
+	double a = 0.0;
+	for(uint32_t s = 0; s + c < nd; s++) a += DD(s) * DD(s + c);
+	autoc[c] = a;
+}
+#undef DD
+
+// ---------------------------------------------------------------------------------------------
+// shared between analyze and pack: build the candidate channel's signal in LDS
+// returns the OR of all samples (for wasted bits) reduced over the workgroup
+// ---------------------------------------------------------------------------------------------
+// which: 0..C-1 independent channel, C = mid, C+1 = side
+__device__ __forceinline__ int32_t pick_channel(const int32_t *frame_pcm, uint32_t C, uint32_t i, uint32_t which)
+{
+	if(which < C) return frame_pcm[(size_t)i * C + which];
+	const int32_t l = frame_pcm[(size_t)i * 2], r = frame_pcm[(size_t)i * 2 + 1];
+	return which == C ? ((l + r) >> 1) : (l - r);
+}
+
+__device__ void load_signal(int32_t *sig, const int32_t *frame_pcm, uint32_t C, uint32_t n, uint32_t which,
+                            uint32_t *or_out, int tid)
+{
+	uint32_t orv = 0;
+	// zero the 32-sample front pad and the tail up to the next chunk boundary + one chunk
+	if(tid < 32) sig[sigidx(tid - 32)] = 0;
+	const uint32_t nround = ((n + 15u) & ~15u) + 16u;
+	for(uint32_t i = n + (uint32_t)tid; i < nround; i += TPB) sig[sigidx((int)i)] = 0;
+	if(C == 2) {
+		const int2 *p = (const int2 *)frame_pcm;
+		for(uint32_t i = (uint32_t)tid; i < n; i += TPB) {
+			const int2 lr = p[i];
+			int32_t v = which == 0 ? lr.x : which == 1 ? lr.y : which == 2 ? ((lr.x + lr.y) >> 1) : (lr.x - lr.y);
+			sig[sigidx((int)i)] = v;
+			orv |= (uint32_t)v;
+		}
+	}
+	else {
+		for(uint32_t i = (uint32_t)tid; i < n; i += TPB) {
+			int32_t v = pick_channel(frame_pcm, C, i, which);
+			sig[sigidx((int)i)] = v;
+			orv |= (uint32_t)v;
+		}
+	}
+	*or_out = orv;
+}
+
+// residual of CHUNK consecutive samples starting at `base` with a zero-padded MAXORD-tap FIR
+// (lpc.c:321 32-bit wrapping / lpc.c:582 64-bit accumulate; fixed.c:470 is the same FIR with binomial taps)
+template <int MAXORD, bool WIDE>
+__device__ __forceinline__ void fir_chunk(const int32_t *sig, int base, const int32_t *q, int shift, int32_t *r)
+{
+	int32_t x[MAXORD + CHUNK];
+#pragma unroll
+	for(int k = 0; k < MAXORD + CHUNK; k++) x[k] = sig[sigidx(base - MAXORD + k)];
+#pragma unroll
+	for(int s = 0; s < CHUNK; s++) {
+		if(WIDE) {
+			int64_t sum = 0;
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)x[MAXORD + s - 1 - j];
+			r[s] = (int32_t)((int64_t)x[MAXORD + s] - (sum >> shift));
+		}
+		else {
+			uint32_t sum = 0;
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++) sum += (uint32_t)q[j] * (uint32_t)x[MAXORD + s - 1 - j];
+			r[s] = (int32_t)((uint32_t)x[MAXORD + s] - (uint32_t)((int32_t)sum >> shift));
+		}
+	}
+}
+
+template <int MAXORD>
+__device__ __forceinline__ void fir_chunk_dispatch(const int32_t *sig, int base, const int32_t *q, int shift, bool wide, int32_t *r)
+{
+	if(wide) fir_chunk<MAXORD, true>(sig, base, q, shift, r);
+	else fir_chunk<MAXORD, false>(sig, base, q, shift, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// analyze_kernel
+// ---------------------------------------------------------------------------------------------
+struct AnalyzeShared {
+	uint64_t sums[2u << MAX_PO];        // |residual| per partition at max_po, u64 (masked to 32 bits when the reference accumulates in 32)
+	uint64_t po_bits[MAX_PO + 1];
+	uint64_t scratch[8];
+	double autoc[MAX_ORDER + 1];
+	double root[MAX_ORDER + 1];
+	Candidate cand;
+	int cand_valid;
+	int32_t bestq[MAX_ORDER];
+	uint8_t kcand[2u << MAX_PO];
+	uint8_t kbest[1u << MAX_PO];
+	uint32_t flag;
+};
+
+// Evaluate one residual candidate (fixed or LPC) with all threads.
+// Returns the estimated residual bits (find_best_partition_order_, stream_encoder.c:4701) and leaves
+// the Rice parameters of the best partition order in sh->kcand[ koff .. ), *best_po.
+template <int MAXORD>
+__device__ uint32_t eval_candidate(AnalyzeShared *sh, const int32_t *sig, uint32_t n, uint32_t order,
+                                   const int32_t *q, int shift, bool wide, uint32_t sbps,
+                                   const DevParams &P, uint32_t frame_max_po, uint32_t frame_min_po,
+                                   uint32_t *best_po_out, uint32_t *koff_out, int tid)
+{
+	// partition order limits for this predictor order (format.c:550)
+	uint32_t max_po = frame_max_po;
+	while(max_po > 0 && (n >> max_po) <= order) max_po--;
+	const uint32_t min_po = umin32(frame_min_po, max_po);
+	const uint32_t psize = n >> max_po;
+	const uint32_t nparts = 1u << max_po;
+	const bool narrow = (sbps + 4) < (32 - ilog2_u32(psize));   // stream_encoder.c:4814-4817
+
+	int32_t qr[MAXORD];
+#pragma unroll
+	for(int j = 0; j < MAXORD; j++) qr[j] = q[j];
+	for(uint32_t p = (uint32_t)tid; p < nparts; p += TPB) sh->sums[p] = 0;
+	if(tid <= MAX_PO) sh->po_bits[tid] = 0;
+	__syncthreads();
+
+	// residual -> |r| -> partition sums
+	for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * TPB) {
+		int32_t r[CHUNK];
+		fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, wide, r);
+		uint32_t part = base / psize;
+		uint32_t next = (part + 1) * psize;
+		uint64_t run = 0;
+#pragma unroll
+		for(int s = 0; s < CHUNK; s++) {
+			const uint32_t i = base + s;
+			if(i == next) {
+				if(run) atomicAdd((unsigned long long *)&sh->sums[part], (unsigned long long)run);
+				run = 0; part++; next += psize;
+			}
+			if(i >= order && i < n) {
+				const int32_t v = r[s];
+				run += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v);
+			}
+		}
+		if(run && part < nparts) atomicAdd((unsigned long long *)&sh->sums[part], (unsigned long long)run);
+	}
+	__syncthreads();
+
+	// every (partition order, partition) node: merged sum, Rice parameter, bit estimate
+	// node numbering: orders from max_po down to min_po, each with 2^po entries (the flat tree of
+	// precompute_partition_info_sums_, stream_encoder.c:4837-4851)
+	{
+		uint32_t total_nodes = 0;
+		for(int po = (int)max_po; po >= (int)min_po; po--) total_nodes += 1u << po;
+		for(uint32_t node = (uint32_t)tid; node < total_nodes; node += TPB) {
+			uint32_t po = max_po, off = 0;
+			while(node - off >= (1u << po)) { off += 1u << po; po--; }
+			const uint32_t p = node - off;
+			const uint32_t nleaf = 1u << (max_po - po);
+			uint64_t sum = 0;
+			for(uint32_t k = 0; k < nleaf; k++) {
+				uint64_t v = sh->sums[p * nleaf + k];
+				sum += narrow ? (uint64_t)(uint32_t)v : v;
+			}
+			uint32_t ns = n >> po;
+			if(p == 0) ns -= order;
+			const uint32_t div = 0x40000u / ns;
+			uint32_t k;
+			if(sum < 2 || (((sum - 1) * div) >> 18) == 0) k = 0;
+			else k = ilog2_u64(((sum - 1) * div) >> 18) + 1;
+			if(k >= P.rice_limit) k = P.rice_limit - 1;
+			uint64_t b = 4 + (uint64_t)(1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
+			if(b > 0xffffffffull) b = 0xffffffffull;
+			sh->kcand[node] = (uint8_t)k;
+			atomicAdd((unsigned long long *)&sh->po_bits[po], (unsigned long long)b);
+		}
+	}
+	__syncthreads();
+
+	uint32_t best_bits = 0, best_po = 0, best_off = 0, off = 0;
+	for(int po = (int)max_po; po >= (int)min_po; po--) {
+		uint64_t b = 6 + sh->po_bits[po];
+		uint32_t bits = b >= 0xffffffffull ? 0xffffffffu : (uint32_t)b;
+		if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = (uint32_t)po; best_off = off; }
+		off += 1u << po;
+	}
+	*best_po_out = best_po;
+	*koff_out = best_off;
+	return best_bits;
+}
+
+__device__ __forceinline__ uint32_t sat_add_u32(uint32_t est, uint32_t rbits)
+{
+	return rbits < 0xffffffffu - est ? est + rbits : 0xffffffffu;
+}
+
+template <int MAXORD>
+__global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const int32_t *__restrict__ pcm,
+                                                      const float *__restrict__ windows,
+                                                      const float *__restrict__ tail_windows,
+                                                      uint32_t nframes, uint32_t tail_n,
+                                                      SubDecision *__restrict__ decisions)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = (int)threadIdx.x;
+	const uint32_t C = P.channels, N = P.blocksize;
+
+	// XCD-aware mapping: consecutive workgroup ids round-robin over the 8 XCDs; keep the candidate
+	// channels of one frame on one XCD so their shared PCM lines hit that XCD's L2.
+	uint32_t f, cand;
+	{
+		const uint32_t b = blockIdx.x, total = nframes * P.ncand;
+		const uint32_t per_xcd_full = (total / (8 * P.ncand)) * P.ncand;   // blocks per XCD in the evenly divisible part
+		const uint32_t head = per_xcd_full * 8;
+		uint32_t lin;
+		if(b < head) { const uint32_t x = b & 7, k = b >> 3; lin = x * per_xcd_full + k; }
+		else lin = b;
+		f = lin / P.ncand; cand = lin % P.ncand;
+		(void)total;
+	}
+	const bool is_tail = tail_n != 0 && f == nframes - 1;
+	const uint32_t n = is_tail ? tail_n : N;
+	const float *win = is_tail ? tail_windows : windows;
+	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
+
+	int32_t *sig = (int32_t *)smem;
+	float *wnd = (float *)(smem + P.sig_bytes);
+	AnalyzeShared *sh = (AnalyzeShared *)(smem + P.sig_bytes + P.wnd_bytes);
+
+	SubDecision *dec = decisions + (size_t)f * P.ncand + cand;
+
+	// ---- which signal does this workgroup model? ----------------------------------------------
+	uint32_t which = cand;          // index into {ch0..chC-1, mid, side}
+	bool skip = false;              // loose mid/side: this pair not chosen -> nothing to do (never happens: grid only has the 2 chosen)
+	if(P.ms_mode == 2) {
+		// loose mid/side (stream_encoder.c:3778-3807): both workgroups of the frame compute the decision
+		uint64_t lr = 0, ms = 0;
+		const int2 *p = (const int2 *)frame_pcm;
+		for(uint32_t i = 1 + (uint32_t)tid; i < n; i += TPB) {
+			const int2 a = p[i], b = p[i - 1];
+			const int32_t pl = a.x - b.x, pr = a.y - b.y;
+			lr += (uint64_t)(uint32_t)(abs(pl) + abs(pr));
+			ms += (uint64_t)(uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
+		}
+		lr = block_reduce_add_u64(lr, sh->scratch, tid);
+		ms = block_reduce_add_u64(ms, sh->scratch, tid);
+		if(!(lr < ms)) which = 2 + cand;   // mid, side
+	}
+	(void)skip;
+
+	// limit_min_bitrate (stream_encoder.c:3874-3879): the last independent channel (and then mid/side)
+	// may not be CONSTANT when every earlier channel is
+	bool disable_constant = P.disable_constant != 0;
+	if(P.limit_min_bitrate && !disable_constant && (P.ms_mode == 2 ? which == 1 : which >= C - 1)) {
+		// are channels 0..C-2 all constant over this block? (their best subframe is CONSTANT iff so)
+		uint32_t diff = 0;
+		for(uint32_t i = (uint32_t)tid; i < n; i += TPB)
+			for(uint32_t c = 0; c + 1 < C; c++) diff |= (uint32_t)(frame_pcm[(size_t)i * C + c] ^ frame_pcm[c]);
+		diff = block_reduce_or_u32(diff, sh->scratch, tid);
+		if(diff == 0) disable_constant = true;
+	}
+
+	// ---- signal into LDS, wasted bits (stream_encoder.c:3842-3867,5077) --------------------------
+	uint32_t orv;
+	load_signal(sig, frame_pcm, C, n, which, &orv, tid);
+	orv = block_reduce_or_u32(orv, sh->scratch, tid);
+	uint32_t wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
+	if(wasted > P.bps) wasted = P.bps;
+	if(wasted) {
+		for(uint32_t i = (uint32_t)tid; i < n; i += TPB) sig[sigidx((int)i)] >>= wasted;
+	}
+	const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
+	const uint32_t hdr = 8 + wasted;
+	__syncthreads();
+
+	// partition order limits of the frame (stream_encoder.c:3759-3761)
+	uint32_t frame_max_po = 0;
+	{ uint32_t b = n; while(!(b & 1)) { frame_max_po++; b >>= 1; } if(frame_max_po > 15) frame_max_po = 15; }
+	frame_max_po = umin32(frame_max_po, P.max_po);
+	const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
+
+	// ---- running best (uniform across the workgroup) -------------------------------------------
+	uint32_t best_type = 1, best_order = 0, best_po = 0, best_precision = 0;
+	int32_t best_shift = 0;
+	int32_t best_constant = 0;
+	uint32_t best_bits = (P.disable_verbatim && n >= 4) ? 0xffffffffu : hdr + n * sbps;
+
+	if(n > 4) {
+		// ---- fixed predictor estimate (fixed.c:222 / fixed_intrin_avx2.c:57) ----------------------
+		const uint32_t n4 = n - 4;
+		const bool fwide = !(sbps + ilog2_u32(n4 * 17) < 32);
+		uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+		{
+			const uint32_t lanes = fwide ? 4 : 1;
+			const uint32_t q = fwide ? n4 / 4 : n4;
+			for(uint32_t l = 0; l < lanes; l++) {
+				const int hist = (int)(l * q), start = (int)(((uint64_t)l * n4) / 4);
+				for(uint32_t i = (uint32_t)tid; i < q; i += TPB) {
+					int64_t v[5];
+#pragma unroll
+					for(int j = 0; j < 5; j++) { const int m = (int)i - j; v[j] = sig[sigidx(4 + (m >= 0 ? start + m : hist + m))]; }
+					int64_t d0 = v[0], d1 = v[0] - v[1], d2 = v[0] - 2 * v[1] + v[2], d3 = v[0] - 3 * v[1] + 3 * v[2] - v[3],
+					        d4 = v[0] - 4 * v[1] + 6 * v[2] - 4 * v[3] + v[4];
+					if(!fwide) { d0 = (int32_t)d0; d1 = (int32_t)d1; d2 = (int32_t)d2; d3 = (int32_t)d3; d4 = (int32_t)d4; }
+					e0 += (uint64_t)(d0 < 0 ? -d0 : d0); e1 += (uint64_t)(d1 < 0 ? -d1 : d1); e2 += (uint64_t)(d2 < 0 ? -d2 : d2);
+					e3 += (uint64_t)(d3 < 0 ? -d3 : d3); e4 += (uint64_t)(d4 < 0 ? -d4 : d4);
+				}
+			}
+		}
+		e0 = block_reduce_add_u64(e0, sh->scratch, tid);
+		e1 = block_reduce_add_u64(e1, sh->scratch, tid);
+		e2 = block_reduce_add_u64(e2, sh->scratch, tid);
+		e3 = block_reduce_add_u64(e3, sh->scratch, tid);
+		e4 = block_reduce_add_u64(e4, sh->scratch, tid);
+		uint32_t guess_fixed;
+		{
+			const uint64_t m34 = e3 < e4 ? e3 : e4, m234 = e2 < m34 ? e2 : m34, m1234 = e1 < m234 ? e1 : m234;
+			if(e0 <= m1234) guess_fixed = 0;
+			else if(e1 <= m234) guess_fixed = 1;
+			else if(e2 <= m34) guess_fixed = 2;
+			else if(e3 <= e4) guess_fixed = 3;
+			else guess_fixed = 4;
+		}
+		const uint64_t eg = guess_fixed == 0 ? e0 : guess_fixed == 1 ? e1 : guess_fixed == 2 ? e2 : guess_fixed == 3 ? e3 : e4;
+		// rbps = (float)(log(M_LN2*err/n)/M_LN2) as compiled (fixed.c:284-288)
+		const float rbps_guess = eg ? (float)(log(((double)eg * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
+		const bool rbps1_zero = e1 == 0 || (float)(log(((double)e1 * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) == 0.0f;
+
+		bool is_constant = false;
+		if(!disable_constant && rbps1_zero) {
+			uint32_t diff = 0;
+			const int32_t first = sig[sigidx(0)];
+			for(uint32_t i = (uint32_t)tid; i < n; i += TPB) diff |= (uint32_t)(sig[sigidx((int)i)] ^ first);
+			diff = block_reduce_or_u32(diff, sh->scratch, tid);
+			is_constant = diff == 0;
+		}
+		if(is_constant) {
+			const uint32_t bits = hdr + sbps;
+			if(bits < best_bits) { best_type = 0; best_constant = sig[sigidx(0)]; best_bits = bits; }
+		}
+		else {
+			// ---- FIXED candidate (stream_encoder.c:4153-4196, 4489) --------------------------------
+			if(!P.disable_fixed || (P.max_lpc_order == 0 && best_bits == 0xffffffffu)) {
+				const uint32_t order = guess_fixed;   // n > 4 so order <= n-1
+				if(!(rbps_guess >= (float)sbps)) {
+					if(tid < MAX_ORDER) {
+						int32_t c = 0;
+						if(order == 1) c = tid == 0 ? 1 : 0;
+						else if(order == 2) c = tid == 0 ? 2 : tid == 1 ? -1 : 0;
+						else if(order == 3) c = tid == 0 ? 3 : tid == 1 ? -3 : tid == 2 ? 1 : 0;
+						else if(order == 4) c = tid == 0 ? 4 : tid == 1 ? -6 : tid == 2 ? 4 : tid == 3 ? -1 : 0;
+						sh->cand.q[tid] = c;
+					}
+					__syncthreads();
+					uint32_t po, koff;
+					const uint32_t rbits = eval_candidate<MAXORD>(sh, sig, n, order, sh->cand.q, 0, false, sbps, P, frame_max_po, frame_min_po, &po, &koff, tid);
+					const uint32_t est = sat_add_u32(hdr + order * sbps, rbits);
+					if(est < best_bits) {
+						best_type = 2; best_order = order; best_po = po; best_bits = est;
+						for(uint32_t p = (uint32_t)tid; p < (1u << po); p += TPB) sh->kbest[p] = sh->kcand[koff + p];
+					}
+					__syncthreads();
+				}
+			}
+			// ---- LPC candidates: apply_apodization_ state machine (stream_encoder.c:4199-4275,4318) --
+			if(P.max_lpc_order > 0) {
+				const uint32_t max_lpc = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
+				const uint32_t variant = n <= 32 ? 0u : P.autoc_variant;
+				if(max_lpc > 0) {
+					uint32_t a = 0, b = 1, c = 0;
+					while(a < P.num_apod) {
+						const float *w = win + (size_t)a * n;
+						const uint32_t kind = P.apod_kind[a], parts = P.apod_parts[a];
+						const uint32_t lag = max_lpc + 1;
+						bool have = true;
+						if(b == 1) {
+							for(uint32_t i = (uint32_t)tid; i < n; i += TPB) wnd[i] = (float)sig[sigidx((int)i)] * w[i];
+							__syncthreads();
+							if(variant == 12) autoc_fma_12(wnd, n, lag, sh->autoc, tid);
+							else if(variant == 0) autoc_small(wnd, n, lag, sh->autoc, tid);
+							else autoc_fma_8_16(wnd, n, variant, lag, sh->autoc, tid);
+							__syncthreads();
+							if(kind == FLACGPU_APOD_SUBDIVIDE_TUKEY) {
+								if((uint32_t)tid < max_lpc) sh->root[tid] = sh->autoc[tid];   // max_order entries, not +1 (:4340)
+								b++;
+							}
+							else a++;
+						}
+						else {
+							if(n / b <= 32) have = false;
+							else if(!(c & 1)) {
+								const uint32_t part = n / b / 2, dshift = (c / 2 * n) / b, nd = n / b;
+								if(part + dshift < n) {
+									const uint32_t i0 = umin32(part, n - part - dshift);
+									for(uint32_t i = (uint32_t)tid; i <= i0 + part; i += TPB) {
+										float o;
+										bool wr = true;
+										if(i >= i0 && i < i0 + part) o = (float)sig[sigidx((int)(dshift + i))] * w[n - part + (i - i0)];
+										else if(i < part) o = (float)sig[sigidx((int)(dshift + i))] * w[i];
+										else if(i == i0 + part && i < n) o = 0.0f;
+										else { wr = false; o = 0.0f; }
+										if(wr) wnd[i] = o;
+									}
+								}
+								__syncthreads();
+								if(variant == 12) autoc_fma_12(wnd, nd, lag, sh->autoc, tid);
+								else if(variant == 0) autoc_small(wnd, nd, lag, sh->autoc, tid);
+								else autoc_fma_8_16(wnd, nd, variant, lag, sh->autoc, tid);
+							}
+							else {
+								if((uint32_t)tid < max_lpc) sh->autoc[tid] = sh->root[tid] - sh->autoc[tid];
+							}
+							// set_next_subdivide_tukey (stream_encoder.c:4293)
+							if(b == 2) { if(c == 0) c = 2; else { c = 0; b++; } }
+							else if(c < 2 * b - 1) c++;
+							else { c = 0; b++; }
+							if(b > parts) { a++; b = 1; c = 0; }
+						}
+						__syncthreads();
+						if(!have) continue;
+						if(tid == 0) sh->cand_valid = lpc_model(sh->autoc, max_lpc, n, sbps, P.precision, &sh->cand);
+						__syncthreads();
+						if(sh->cand_valid) {
+							const uint32_t order = sh->cand.order, precision = sh->cand.precision;
+							const int shift = sh->cand.shift;
+							uint32_t po, koff;
+							const uint32_t rbits = eval_candidate<MAXORD>(sh, sig, n, order, sh->cand.q, shift, sh->cand.wide != 0, sbps, P, frame_max_po, frame_min_po, &po, &koff, tid);
+							const uint32_t est = sat_add_u32(hdr + 4 + 5 + order * (precision + sbps), rbits);
+							if(est > 0 && est < best_bits) {
+								best_type = 3; best_order = order; best_po = po; best_bits = est;
+								best_precision = precision; best_shift = shift;
+								for(uint32_t p = (uint32_t)tid; p < (1u << po); p += TPB) sh->kbest[p] = sh->kcand[koff + p];
+								if(tid < MAX_ORDER) sh->bestq[tid] = sh->cand.q[tid];
+							}
+						}
+						__syncthreads();
+					}
+				}
+			}
+		}
+	}
+	if(best_bits == 0xffffffffu) { best_type = 1; best_bits = hdr + n * sbps; }   // stream_encoder.c:4281
+
+	// ---- decision record ---------------------------------------------------------------------------
+	__syncthreads();
+	uint32_t rice2 = 0;
+	if(best_type >= 2) {
+		uint32_t big = 0;
+		for(uint32_t p = (uint32_t)tid; p < (1u << best_po); p += TPB) {
+			const uint8_t k = sh->kbest[p];
+			dec->params[p] = k;
+			if(k >= 15) big = 1;
+		}
+		rice2 = block_reduce_or_u32(big, sh->scratch, tid);   // stream_encoder.c:4786-4791
+	}
+	if(tid < MAX_ORDER) dec->q[tid] = best_type == 3 ? sh->bestq[tid] : 0;
+	if(tid == 0) {
+		dec->bits = best_bits;
+		dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
+		dec->po = (uint8_t)best_po; dec->rice2 = (uint8_t)rice2; dec->precision = (uint8_t)best_precision;
+		dec->shift = (int8_t)best_shift; dec->which = (uint8_t)which;
+		dec->constant = best_constant;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack_kernel
+// ---------------------------------------------------------------------------------------------
+// Frame image in LDS as 32-bit words holding the stream MSB first (word = big-endian view).
+__device__ __forceinline__ void put_bits(uint32_t *buf, uint32_t cap_words, uint32_t pos, uint32_t v, uint32_t len)
+{
+	if(len == 0) return;
+	const uint32_t w = pos >> 5, o = pos & 31;
+	const uint64_t val = (uint64_t)(len == 32 ? v : (v & ((1u << len) - 1u))) << (64 - len - o);
+	const uint32_t hi = (uint32_t)(val >> 32), lo = (uint32_t)val;
+	if(hi && w < cap_words) atomicOr(&buf[w], hi);
+	if(lo && w + 1 < cap_words) atomicOr(&buf[w + 1], lo);
+}
+
+__device__ __forceinline__ uint32_t crc16_step_byte(uint32_t c, uint32_t byte)
+{
+	c ^= byte << 8;
+#pragma unroll
+	for(int b = 0; b < 8; b++) c = (c & 0x8000u) ? ((c << 1) ^ 0x8005u) & 0xffffu : (c << 1) & 0xffffu;
+	return c;
+}
+// multiply two GF(2) polynomials of degree < 16 modulo x^16+x^15+x^2+1
+__device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
+{
+	uint32_t r = 0;
+#pragma unroll
+	for(int i = 0; i < 16; i++) {
+		if(b & 0x8000u) r ^= a;       // process b from its top bit: r = r*x + (bit? a : 0) done below
+		b <<= 1;
+		if(i != 15) r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu;
+	}
+	return r;
+}
+// x^(8*nbytes) mod P
+__device__ uint32_t gf16_xpow8(uint32_t nbytes)
+{
+	uint32_t result = 1, base = 0x0100u;    // x^8
+	while(nbytes) {
+		if(nbytes & 1) result = gf16_mul(result, base);
+		base = gf16_mul(base, base);
+		nbytes >>= 1;
+	}
+	return result;
+}
+
+struct PackShared {
+	uint64_t scratch[8];
+	uint8_t params[1u << MAX_PO];
+	uint32_t scan[TPB / 64 + 1];
+	uint32_t ca, left, right;
+	uint32_t crc_parts[TPB];
+	uint32_t bitpos;
+	uint32_t overflow;
+};
+
+template <int MAXORD>
+__global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int32_t *__restrict__ pcm,
+                                                   uint32_t nframes, uint32_t tail_n, uint64_t first_frame_number,
+                                                   const SubDecision *__restrict__ decisions,
+                                                   uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
+                                                   FrameInfo *__restrict__ info)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = (int)threadIdx.x;
+	const uint32_t C = P.channels, N = P.blocksize;
+	const uint32_t f = blockIdx.x;
+	const bool is_tail = tail_n != 0 && f == nframes - 1;
+	const uint32_t n = is_tail ? tail_n : N;
+	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
+	const SubDecision *dec = decisions + (size_t)f * P.ncand;
+
+	int32_t *sig = (int32_t *)smem;
+	uint32_t *img = (uint32_t *)(smem + P.sig_bytes);
+	PackShared *sh = (PackShared *)(smem + P.sig_bytes + P.slot_bytes);
+	const uint32_t cap_words = P.slot_bytes / 4;
+
+	for(uint32_t w = (uint32_t)tid; w < cap_words; w += TPB) img[w] = 0;
+	if(tid == 0) {
+		// channel assignment (stream_encoder.c:3944-3972)
+		uint32_t ca = 0, left = 0, right = 1;
+		if(P.ms_mode == 1) {
+			const uint32_t b0 = dec[0].bits + dec[1].bits, b1 = dec[0].bits + dec[3].bits,
+			               b2 = dec[1].bits + dec[3].bits, b3 = dec[2].bits + dec[3].bits;
+			uint32_t mn = b0;
+			if(b1 < mn) { mn = b1; ca = 1; }
+			if(b2 < mn) { mn = b2; ca = 2; }
+			if(b3 < mn) { mn = b3; ca = 3; }
+			left = ca == 2 ? 3 : ca == 3 ? 2 : 0;
+			right = ca == 0 ? 1 : ca == 2 ? 1 : 3;
+		}
+		else if(P.ms_mode == 2) {
+			ca = dec[0].which >= 2 ? 3 : 0;
+		}
+		sh->ca = ca; sh->left = left; sh->right = right; sh->overflow = 0;
+	}
+	__syncthreads();
+	const uint32_t ca = sh->ca;
+
+	// ---- frame header (stream_encoder_framing.c:245-391), one lane -------------------------------
+	if(tid == 0) {
+		uint8_t hb[16];
+		uint32_t nb = 0;
+		uint32_t bs_code, bs_hint = 0, sr_code, sr_hint = 0;
+		switch(n) {
+			case 192: bs_code = 1; break; case 576: bs_code = 2; break; case 1152: bs_code = 3; break;
+			case 2304: bs_code = 4; break; case 4608: bs_code = 5; break; case 256: bs_code = 8; break;
+			case 512: bs_code = 9; break; case 1024: bs_code = 10; break; case 2048: bs_code = 11; break;
+			case 4096: bs_code = 12; break; case 8192: bs_code = 13; break; case 16384: bs_code = 14; break;
+			case 32768: bs_code = 15; break;
+			default: bs_hint = bs_code = (n <= 0x100) ? 6 : 7; break;
+		}
+		const uint32_t sr = P.sample_rate;
+		switch(sr) {
+			case 88200: sr_code = 1; break; case 176400: sr_code = 2; break; case 192000: sr_code = 3; break;
+			case 8000: sr_code = 4; break; case 16000: sr_code = 5; break; case 22050: sr_code = 6; break;
+			case 24000: sr_code = 7; break; case 32000: sr_code = 8; break; case 44100: sr_code = 9; break;
+			case 48000: sr_code = 10; break; case 96000: sr_code = 11; break;
+			default:
+				if(sr <= 255000 && sr % 1000 == 0) sr_hint = sr_code = 12;
+				else if(sr <= 655350 && sr % 10 == 0) sr_hint = sr_code = 14;
+				else if(sr <= 0xffff) sr_hint = sr_code = 13;
+				else sr_code = 0;
+				break;
+		}
+		uint32_t bps_code;
+		switch(P.bps) {
+			case 8: bps_code = 1; break; case 12: bps_code = 2; break; case 16: bps_code = 4; break;
+			case 20: bps_code = 5; break; case 24: bps_code = 6; break; case 32: bps_code = 7; break;
+			default: bps_code = 0; break;
+		}
+		hb[nb++] = 0xff; hb[nb++] = 0xf8;
+		hb[nb++] = (uint8_t)((bs_code << 4) | sr_code);
+		hb[nb++] = (uint8_t)(((ca == 0 ? C - 1 : 7 + ca) << 4) | (bps_code << 1));
+		{
+			const uint32_t v = (uint32_t)(first_frame_number + f);   // bitwriter.c:832
+			if(v < 0x80) hb[nb++] = (uint8_t)v;
+			else if(v < 0x800) { hb[nb++] = (uint8_t)(0xC0 | (v >> 6)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+			else if(v < 0x10000) { hb[nb++] = (uint8_t)(0xE0 | (v >> 12)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+			else if(v < 0x200000) { hb[nb++] = (uint8_t)(0xF0 | (v >> 18)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+			else if(v < 0x4000000) { hb[nb++] = (uint8_t)(0xF8 | (v >> 24)); hb[nb++] = (uint8_t)(0x80 | ((v >> 18) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+			else { hb[nb++] = (uint8_t)(0xFC | (v >> 30)); hb[nb++] = (uint8_t)(0x80 | ((v >> 24) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 18) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+		}
+		if(bs_hint == 6) hb[nb++] = (uint8_t)(n - 1);
+		else if(bs_hint == 7) { hb[nb++] = (uint8_t)((n - 1) >> 8); hb[nb++] = (uint8_t)(n - 1); }
+		if(sr_hint == 12) hb[nb++] = (uint8_t)(sr / 1000);
+		else if(sr_hint == 13) { hb[nb++] = (uint8_t)(sr >> 8); hb[nb++] = (uint8_t)sr; }
+		else if(sr_hint == 14) { hb[nb++] = (uint8_t)((sr / 10) >> 8); hb[nb++] = (uint8_t)(sr / 10); }
+		uint32_t crc = 0;
+		for(uint32_t k = 0; k < nb; k++) {
+			crc ^= hb[k];
+			for(int b = 0; b < 8; b++) crc = (crc & 0x80u) ? ((crc << 1) ^ 0x07u) & 0xffu : (crc << 1) & 0xffu;
+		}
+		hb[nb++] = (uint8_t)crc;
+		for(uint32_t k = 0; k < nb; k++) put_bits(img, cap_words, 8 * k, hb[k], 8);
+		sh->bitpos = 8 * nb;
+	}
+	__syncthreads();
+
+	// ---- subframes (stream_encoder_framing.c:393-594) -------------------------------------------
+	const uint32_t nsub = C;
+	for(uint32_t s = 0; s < nsub; s++) {
+		uint32_t di;   // decision index
+		if(P.ms_mode == 1) di = s == 0 ? sh->left : sh->right;
+		else di = s;
+		const SubDecision *d = dec + di;
+		const uint32_t which = d->which, type = d->type, order = d->order, wasted = d->wasted;
+		const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
+		uint32_t pos = sh->bitpos;
+		__syncthreads();
+
+		uint32_t orv;
+		load_signal(sig, frame_pcm, C, n, which, &orv, tid);
+		__syncthreads();
+		if(wasted) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) sig[sigidx((int)i)] >>= wasted;
+		__syncthreads();
+
+		// subframe header byte (+ unary wasted bits)
+		uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : type == 2 ? (0x10u | (order << 1)) : (0x40u | ((order - 1) << 1));
+		if(tid == 0) {
+			put_bits(img, cap_words, pos, type_bits | (wasted ? 1u : 0u), 8);
+			if(wasted) put_bits(img, cap_words, pos + 8 + (wasted - 1), 1, 1);
+		}
+		pos += 8 + wasted;
+
+		if(type == 0) {
+			if(tid == 0) put_bits(img, cap_words, pos, (uint32_t)d->constant, sbps);
+			pos += sbps;
+		}
+		else if(type == 1) {
+			for(uint32_t i = (uint32_t)tid; i < n; i += TPB) put_bits(img, cap_words, pos + i * sbps, (uint32_t)sig[sigidx((int)i)], sbps);
+			pos += n * sbps;
+		}
+		else {
+			// warm-up, (precision, shift, coefficients), entropy coding header
+			if((uint32_t)tid < order) put_bits(img, cap_words, pos + (uint32_t)tid * sbps, (uint32_t)sig[sigidx(tid)], sbps);
+			pos += order * sbps;
+			const int shift = type == 3 ? d->shift : 0;
+			bool wide = false;
+			if(type == 3) {
+				const uint32_t precision = d->precision;
+				if(tid == 0) {
+					put_bits(img, cap_words, pos, precision - 1, 4);
+					put_bits(img, cap_words, pos + 4, (uint32_t)shift, 5);
+				}
+				if((uint32_t)tid < order) put_bits(img, cap_words, pos + 9 + (uint32_t)tid * precision, (uint32_t)d->q[tid], precision);
+				pos += 9 + order * precision;
+				uint32_t abs_sum = 0;
+				for(uint32_t i = 0; i < order; i++) abs_sum += (uint32_t)abs(d->q[i]);
+				wide = silog2_i64((int64_t)(((uint64_t)1 << (sbps - 1)) * abs_sum)) > 32;
+			}
+			const uint32_t po = d->po, plen = d->rice2 ? 5u : 4u;
+			if(tid == 0) {
+				put_bits(img, cap_words, pos, d->rice2 ? 1u : 0u, 2);
+				put_bits(img, cap_words, pos + 2, po, 4);
+			}
+			pos += 6;
+			// taps
+			int32_t q[MAXORD];
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++) {
+				int32_t c = 0;
+				if(type == 3) c = j < MAX_ORDER ? d->q[j] : 0;
+				else if(order == 1) c = j == 0 ? 1 : 0;
+				else if(order == 2) c = j == 0 ? 2 : j == 1 ? -1 : 0;
+				else if(order == 3) c = j == 0 ? 3 : j == 1 ? -3 : j == 2 ? 1 : 0;
+				else if(order == 4) c = j == 0 ? 4 : j == 1 ? -6 : j == 2 ? 4 : j == 3 ? -1 : 0;
+				q[j] = c;
+			}
+			const uint32_t psize = n >> po;
+			for(uint32_t p = (uint32_t)tid; p < (1u << po); p += TPB) sh->params[p] = d->params[p];
+			__syncthreads();
+			// residual bits: per-thread chunk lengths -> exclusive scan -> write
+			for(uint32_t pass = 0; pass < n; pass += CHUNK * TPB) {
+				const uint32_t base = pass + CHUNK * (uint32_t)tid;
+				int32_t r[CHUNK];
+				uint32_t mybits = 0;
+				if(base < n) {
+					fir_chunk_dispatch<MAXORD>(sig, (int)base, q, shift, wide, r);
+					uint32_t part = base / psize, next = (part + 1) * psize;
+					uint32_t k = sh->params[part];
+#pragma unroll
+					for(int t = 0; t < CHUNK; t++) {
+						const uint32_t i = base + t;
+						if(i == next) { part++; next += psize; if(i < n) k = sh->params[part]; }
+						if(i < n && i >= order) {
+							if(i == (part == 0 ? order : part * psize)) mybits += plen;
+							const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
+							mybits += (u >> k) + 1 + k;
+						}
+					}
+				}
+				// workgroup exclusive scan of mybits
+				uint32_t incl = mybits;
+#pragma unroll
+				for(int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if((tid & 63) >= off) incl += t; }
+				__syncthreads();
+				if((tid & 63) == 63) sh->scan[tid >> 6] = incl;
+				__syncthreads();
+				uint32_t wave_off = 0, total = 0;
+				for(int w = 0; w < TPB / 64; w++) { if(w < (tid >> 6)) wave_off += sh->scan[w]; total += sh->scan[w]; }
+				uint32_t p = pos + wave_off + incl - mybits;
+				if(base < n) {
+					uint32_t part = base / psize, next = (part + 1) * psize;
+					uint32_t k = sh->params[part];
+#pragma unroll
+					for(int t = 0; t < CHUNK; t++) {
+						const uint32_t i = base + t;
+						if(i == next) { part++; next += psize; if(i < n) k = sh->params[part]; }
+						if(i < n && i >= order) {
+							if(i == (part == 0 ? order : part * psize)) { put_bits(img, cap_words, p, k, plen); p += plen; }
+							const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
+							const uint32_t msbs = u >> k;
+							put_bits(img, cap_words, p + msbs, (1u << k) | (u & ((1u << k) - 1u)), k + 1);
+							p += msbs + 1 + k;
+						}
+					}
+				}
+				pos += total;
+				__syncthreads();
+			}
+		}
+		if(tid == 0) {
+			sh->bitpos = pos;
+			if(info) {
+				flacgpu_subframe_info *si = &info[f].sub[s];
+				si->type = (uint8_t)type; si->order = (uint8_t)order; si->wasted_bits = (uint8_t)wasted;
+				si->partition_order = d->po; si->rice2 = d->rice2; si->precision = d->precision; si->shift = d->shift;
+				si->pad = 0; si->bits = d->bits;
+			}
+		}
+		__syncthreads();
+	}
+
+	// ---- zero-pad to a byte, CRC-16 over the whole frame, footer (stream_encoder.c:3720-3734) --------
+	const uint32_t body_bytes = (sh->bitpos + 7) >> 3;
+	const uint32_t total_bytes = body_bytes + 2;
+	if(total_bytes > P.slot_bytes) { if(tid == 0) { sh->overflow = 1; } }
+	__syncthreads();
+	{
+		// each thread CRCs a contiguous span, then spans are combined: crc(A||B) = crc(A)*x^(8|B|) + crc(B)
+		const uint32_t span = (body_bytes + TPB - 1) / TPB;
+		const uint32_t lo = umin32((uint32_t)tid * span, body_bytes), hi = umin32(lo + span, body_bytes);
+		uint32_t c = 0;
+		for(uint32_t k = lo; k < hi; k++) c = crc16_step_byte(c, (img[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu);
+		c = gf16_mul(c, gf16_xpow8(body_bytes - hi));
+		// xor-reduce
+#pragma unroll
+		for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
+		if((tid & 63) == 0) sh->crc_parts[tid >> 6] = c;
+		__syncthreads();
+		if(tid == 0) {
+			uint32_t crc = 0;
+			for(int w = 0; w < TPB / 64; w++) crc ^= sh->crc_parts[w];
+			put_bits(img, cap_words, body_bytes * 8, crc, 16);
+		}
+		__syncthreads();
+	}
+	// ---- store: image words are big-endian views, slots are byte arrays ---------------------------
+	{
+		uint32_t *dst = (uint32_t *)(slots + (size_t)f * P.slot_bytes);
+		const uint32_t words = (umin32(total_bytes, P.slot_bytes) + 3) >> 2;
+		for(uint32_t w = (uint32_t)tid; w < words; w += TPB) dst[w] = __builtin_bswap32(img[w]);
+		if(tid == 0) {
+			frame_bytes[f] = sh->overflow ? 0xffffffffu : total_bytes;
+			if(info) info[f].channel_assignment = (uint8_t)ca;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan + compaction
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t *__restrict__ frame_bytes, uint32_t nframes,
+                                                    uint64_t *__restrict__ offsets, uint64_t *__restrict__ total)
+{
+	__shared__ uint64_t wave_tot[16];
+	__shared__ uint64_t carry;
+	const int tid = (int)threadIdx.x;
+	if(tid == 0) carry = 0;
+	__syncthreads();
+	for(uint32_t base = 0; base < nframes; base += 1024) {
+		const uint32_t i = base + (uint32_t)tid;
+		uint64_t v = i < nframes ? (frame_bytes[i] == 0xffffffffu ? 0 : frame_bytes[i]) : 0, incl = v;
+#pragma unroll
+		for(int off = 1; off < 64; off <<= 1) {
+			uint32_t lo = __shfl_up((uint32_t)incl, off), hi = __shfl_up((uint32_t)(incl >> 32), off);
+			if((tid & 63) >= off) incl += ((uint64_t)hi << 32) | lo;
+		}
+		if((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+		__syncthreads();
+		uint64_t woff = 0, tot = 0;
+		for(int w = 0; w < 16; w++) { if(w < (tid >> 6)) woff += wave_tot[w]; tot += wave_tot[w]; }
+		if(i < nframes) offsets[i] = carry + woff + incl - v;
+		__syncthreads();
+		if(tid == 0) carry += tot;
+		__syncthreads();
+	}
+	if(tid == 0) { offsets[nframes] = carry; *total = carry; }
+}
+
+__global__ __launch_bounds__(TPB) void compact_kernel(const uint8_t *__restrict__ slots, uint32_t slot_bytes,
+                                                      const uint32_t *__restrict__ frame_bytes,
+                                                      const uint64_t *__restrict__ offsets,
+                                                      uint8_t *__restrict__ out, uint64_t out_cap)
+{
+	const uint32_t f = blockIdx.x;
+	const uint32_t nb = frame_bytes[f];
+	if(nb == 0xffffffffu) return;
+	const uint64_t off = offsets[f];
+	if(off + nb > out_cap) return;
+	const uint8_t *src = slots + (size_t)f * slot_bytes;
+	uint8_t *dst = out + off;
+	// head bytes up to 4-byte alignment of dst, then aligned words assembled from two source words
+	const uint32_t mis = (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3);
+	const uint32_t head = umin32(mis, nb);
+	if(threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+	const uint32_t words = (nb - head) >> 2;
+	const uint32_t *sw = (const uint32_t *)src;
+	uint32_t *dw = (uint32_t *)(dst + head);
+	const uint32_t sh = head * 8;
+	for(uint32_t w = threadIdx.x; w < words; w += TPB) {
+		uint32_t v;
+		if(sh == 0) v = sw[w];
+		else v = (sw[w] >> sh) | (sw[w + 1] << (32 - sh));
+		dw[w] = v;
+	}
+	const uint32_t done = head + words * 4;
+	if(threadIdx.x < nb - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+}
+
+} // namespace flacgpu
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers (called from flacgpu_api.cpp)
+// ---------------------------------------------------------------------------------------------
+using namespace flacgpu;
+
+template <int MAXORD>
+static hipError_t launch_analyze_t(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
+                                   uint32_t nframes, uint32_t tail_n, SubDecision *dec, size_t lds, hipStream_t s)
+{
+	static bool attr_set = false;
+	if(!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)analyze_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(analyze_kernel<MAXORD>, dim3(nframes * P.ncand), dim3(TPB), lds, s, P, pcm, win, tailwin, nframes, tail_n, dec);
+	return hipGetLastError();
+}
+template <int MAXORD>
+static hipError_t launch_pack_t(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
+                                const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, size_t lds, hipStream_t s)
+{
+	static bool attr_set = false;
+	if(!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)pack_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes), dim3(TPB), lds, s, P, pcm, nframes, tail_n, first, dec, slots, fb, info);
+	return hipGetLastError();
+}
+
+namespace flacgpu {
+size_t analyze_lds_bytes(const DevParams &P) { return (size_t)P.sig_bytes + P.wnd_bytes + sizeof(AnalyzeShared); }
+size_t pack_lds_bytes(const DevParams &P) { return (size_t)P.sig_bytes + P.slot_bytes + sizeof(PackShared); }
+
+hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
+                          uint32_t nframes, uint32_t tail_n, SubDecision *dec, hipStream_t s)
+{
+	const size_t lds = analyze_lds_bytes(P);
+	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
+	if(m <= 8) return launch_analyze_t<8>(P, pcm, win, tailwin, nframes, tail_n, dec, lds, s);
+	if(m <= 12) return launch_analyze_t<12>(P, pcm, win, tailwin, nframes, tail_n, dec, lds, s);
+	return launch_analyze_t<16>(P, pcm, win, tailwin, nframes, tail_n, dec, lds, s);
+}
+hipError_t launch_pack(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
+                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, hipStream_t s)
+{
+	const size_t lds = pack_lds_bytes(P);
+	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
+	if(m <= 8) return launch_pack_t<8>(P, pcm, nframes, tail_n, first, dec, slots, fb, info, lds, s);
+	if(m <= 12) return launch_pack_t<12>(P, pcm, nframes, tail_n, first, dec, slots, fb, info, lds, s);
+	return launch_pack_t<16>(P, pcm, nframes, tail_n, first, dec, slots, fb, info, lds, s);
+}
+hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)
+{
+	hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, fb, nframes, offsets, total);
+	return hipGetLastError();
+}
+hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,
+                          uint8_t *out, uint64_t out_cap, uint32_t nframes, hipStream_t s)
+{
+	hipLaunchKernelGGL(compact_kernel, dim3(nframes), dim3(TPB), 0, s, slots, slot_bytes, fb, offsets, out, out_cap);
+	return hipGetLastError();
+}
+} // namespace flacgpu

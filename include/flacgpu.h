@@ -1,0 +1,136 @@
+/* include/flacgpu.h -- C ABI of the MI355X FLAC frame engine (libflacgpu.so).
+ *
+ * This is the drop-in boundary: it replaces exactly what the reference's
+ * per-frame worker does,
+ *     process_subframes_() + zero-pad + CRC-16        src/libFLAC/stream_encoder.c:3705-3744
+ *     (-> process_subframe_ :4045, apply_apodization_ :4318, evaluate_*_subframe_ :4466-4699,
+ *         find_best_partition_order_ :4701, FLAC__frame_add_header framing.c:245,
+ *         FLAC__subframe_add_* framing.c:393-520, FLAC__bitwriter_write_rice_signed_block
+ *         bitwriter.c:575)
+ * for a BATCH of independent frames instead of one frame per thread-pool task
+ * (stream_encoder.c:3490-3614).  Input is what FLAC__stream_encoder_process_interleaved()
+ * (stream_encoder.c:2570) receives -- int32 inter-channel samples -- and the output is the
+ * byte-aligned frames that write_bitbuffer_()/write_frame_() (stream_encoder.c:2988,3038) hand
+ * to the client's write callback, in stream order.
+ *
+ * Plain C: pointers and sizes only.  Host-side libFLAC API (FLAC__stream_encoder_*) lives in
+ * libFLACgpu.so (flac_amd/csrc/host/), which calls these entry points.
+ */
+#ifndef FLACGPU_H
+#define FLACGPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLACGPU_ABI_VERSION 1
+#define FLACGPU_MAX_CHANNELS 8
+#define FLACGPU_MAX_APODIZATIONS 8
+
+/* error codes (negative returns) */
+enum {
+	FLACGPU_OK = 0,
+	FLACGPU_ERR_UNSUPPORTED = -1,   /* configuration outside the engine's range (see flacgpu_create) */
+	FLACGPU_ERR_NO_DEVICE = -2,     /* no HIP device / kernel image not loadable: there is NO CPU fallback */
+	FLACGPU_ERR_ALLOC = -3,         /* -> FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR */
+	FLACGPU_ERR_OUTPUT_TOO_SMALL = -4,
+	FLACGPU_ERR_LAUNCH = -5,        /* -> FLAC__STREAM_ENCODER_FRAMING_ERROR */
+	FLACGPU_ERR_BAD_ARG = -6
+};
+
+/* apodization kinds as the frame engine sees them (stream_encoder.c:4318-4392): every window
+ * function is a host-computed float table (window.c stays host side); SUBDIVIDE_TUKEY adds the
+ * partial / punch-out state machine of set_next_subdivide_tukey (stream_encoder.c:4293). */
+enum { FLACGPU_APOD_WINDOW = 0, FLACGPU_APOD_SUBDIVIDE_TUKEY = 1 };
+
+typedef struct {
+	uint32_t kind;      /* FLACGPU_APOD_* */
+	uint32_t parts;     /* SUBDIVIDE_TUKEY only */
+} flacgpu_apodization;
+
+/* Immutable encoder settings: the fields of FLAC__StreamEncoderProtected that
+ * process_subframes_ reads (src/libFLAC/include/protected/stream_encoder.h:91-130), already
+ * resolved the way init_stream_internal_ resolves them (stream_encoder.c:723-829). */
+typedef struct {
+	uint32_t abi_version;            /* FLACGPU_ABI_VERSION */
+	uint32_t channels;               /* 1..8 */
+	uint32_t bits_per_sample;        /* 4..24 */
+	uint32_t sample_rate;
+	uint32_t blocksize;              /* 16..16384 */
+	uint32_t do_mid_side_stereo;
+	uint32_t loose_mid_side_stereo;
+	uint32_t max_lpc_order;          /* 0..15 (the FMA autocorrelation routines, stream_encoder.c:1058-1066) */
+	uint32_t qlp_coeff_precision;    /* resolved, 5..15 */
+	uint32_t min_residual_partition_order;
+	uint32_t max_residual_partition_order; /* <= 8 */
+	uint32_t num_apodizations;       /* 1..FLACGPU_MAX_APODIZATIONS */
+	flacgpu_apodization apodizations[FLACGPU_MAX_APODIZATIONS];
+	uint32_t disable_constant_subframes, disable_fixed_subframes, disable_verbatim_subframes;
+	uint32_t limit_min_bitrate;
+	int32_t  device;                 /* HIP device ordinal */
+	uint32_t max_batch_frames;       /* capacity of one encode call */
+} flacgpu_config;
+
+typedef struct flacgpu_ctx flacgpu_ctx;
+
+/* per-frame diagnostics (optional output), mirrors what FLAC__Frame/FLAC__Subframe would hold */
+typedef struct {
+	uint8_t  type;        /* 0 CONSTANT 1 VERBATIM 2 FIXED 3 LPC */
+	uint8_t  order, wasted_bits, partition_order, rice2, precision;
+	int8_t   shift;
+	uint8_t  pad;
+	uint32_t bits;
+} flacgpu_subframe_info;
+
+/* Creates an engine for one stream configuration.
+ * windows: num_apodizations tables of `blocksize` floats each, concatenated -- what
+ * resize_buffers_ computes with FLAC__window_* (stream_encoder.c:2913-2977).
+ * Returns 0 or a negative FLACGPU_ERR_*. */
+int flacgpu_create(const flacgpu_config *cfg, const float *windows, flacgpu_ctx **out);
+void flacgpu_destroy(flacgpu_ctx *ctx);
+
+/* Bytes an output buffer must hold for `nframes` frames in the worst case (all VERBATIM). */
+size_t flacgpu_max_output_bytes(const flacgpu_ctx *ctx, uint32_t nframes);
+
+/* Encode a batch of consecutive frames from HOST memory.
+ *   pcm                interleaved int32 [(nframes-1)*blocksize + last][channels], stream order
+ *   nframes            <= max_batch_frames
+ *   first_frame_number frame number of the first frame in the batch
+ *   last_block_samples 0: every frame has `blocksize` samples; else the LAST frame of the batch
+ *                      has this many (the short final block, stream_encoder.c:1703-1711)
+ *   tail_windows       windows recomputed for last_block_samples (NULL when it is 0)
+ *   out/out_cap        receives the frames back to back
+ *   frame_bytes        [nframes] length of each frame
+ * Returns total bytes written (>= 0) or a negative FLACGPU_ERR_*. */
+int64_t flacgpu_encode_batch(flacgpu_ctx *ctx, const int32_t *pcm, uint32_t nframes,
+                             uint64_t first_frame_number, uint32_t last_block_samples,
+                             const float *tail_windows, uint8_t *out, size_t out_cap,
+                             uint32_t *frame_bytes);
+
+/* Same, with every buffer already resident in DEVICE memory (HBM): d_pcm, d_out and
+ * d_frame_bytes are device pointers; d_total_bytes (device, 8 bytes) receives the byte total.
+ * Asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream); returns 0 or
+ * a negative code.  This is the entry bench.py times. */
+int flacgpu_encode_batch_device(flacgpu_ctx *ctx, const int32_t *d_pcm, uint32_t nframes,
+                                uint64_t first_frame_number, uint32_t last_block_samples,
+                                const float *tail_windows_host, uint8_t *d_out, size_t out_cap,
+                                uint32_t *d_frame_bytes, uint64_t *d_total_bytes, void *stream);
+
+/* Diagnostics of the most recent batch: [nframes][channels] subframe choices and the channel
+ * assignment per frame (0 independent, 1 left/side, 2 right/side, 3 mid/side). Host arrays. */
+int flacgpu_last_batch_info(flacgpu_ctx *ctx, uint32_t nframes, flacgpu_subframe_info *sub,
+                            uint8_t *channel_assignment);
+
+/* Wall-clock-free timing of the last batch, measured with HIP events on the engine's stream:
+ * milliseconds spent in the analysis kernel, the pack kernel and the compaction kernels. */
+int flacgpu_last_batch_kernel_ms(flacgpu_ctx *ctx, float *analyze_ms, float *pack_ms, float *compact_ms);
+
+const char *flacgpu_strerror(int code);
+int flacgpu_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -102,7 +102,7 @@ void fo_window_tukey(float *w, int32_t L, float p)
 		if(p <= 0.0f) { for(n = 0; n < L; n++) w[n] = 1.0f; return; }
 		if(p >= 1.0f) { /* hann, window.c:144 */
 			const int32_t N = L - 1;
-			for(n = 0; n < L; n++) w[n] = (float)(0.5f - 0.5f * cosf(2.0f * (float)M_PI * n / N));
+			for(n = 0; n < L; n++) w[n] = (float)(0.5f - 0.5f * cosf(2.0f * M_PI * n / N));
 			return;
 		}
 		fo_window_tukey(w, L, 0.5f); /* NaN */
