@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- encode throughput of the MI355X FLAC frame engine at -8, 44.1 kHz/16-bit stereo.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (flacgpu_encode_batch_device: analyze -> pack -> scan/compact)
+over one batch of synthetic PCM that is already resident in HBM.  With N > 1 every rank encodes its
+own contiguous frame range (weak scaling, no data-path collective) and the step ends with the ordered
+RCCL gather of the variable-length bitstream to rank 0 (flac_amd/dist.py).
+
+Prints ONE JSON line (rank 0).  `value` = inter-channel samples encoded per second by the whole job,
+in M samples/s; `roofline` prices the dominant kernel (analyze_kernel) against HBM bandwidth with the
+ALGORITHMIC bytes of SURVEY.md 8d (4*C bytes of PCM in + compressed bytes out per inter-channel
+sample); `cpu_baseline` is the unmodified reference libFLAC (oracle/_ref, AVX2+FMA dispatch) timed on
+this box's host cores on a bounded sample of the same signal.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+LEVEL = 8
+RATE, BPS, CH = 44100, 16, 2
+BLOCK = 4096
+FRAMES_PER_GPU = 4096          # 16.8 M inter-channel samples = 380 s of audio per GPU per step
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synth_pcm(nframes, seed):
+    """music-like 16-bit stereo (tests/signals.py: tones + coloured noise, channels correlated)"""
+    import signals
+    base_frames = min(nframes, 512)
+    base = signals.music(base_frames * BLOCK, CH, BPS, seed=seed, rate=RATE)
+    reps = (nframes + base_frames - 1) // base_frames
+    if reps > 1:
+        # repeat the 48 s clip with a per-repeat gain/offset so frames are not byte-identical
+        parts = []
+        for r in range(reps):
+            g = 1.0 - 0.07 * (r % 8)
+            parts.append(np.clip(np.rint(base * g) + (r % 5) - 2, -32768, 32767).astype(np.int32))
+        base = np.concatenate(parts, axis=0)
+    return np.ascontiguousarray(base[: nframes * BLOCK])
+
+
+def cpu_baseline(sample_pcm):
+    """Reference libFLAC on the host cores: single thread, then many independent encoders."""
+    from oracle import pyoracle as po
+    from concurrent.futures import ThreadPoolExecutor
+    n = sample_pcm.shape[0]
+    if po.have_ref():
+        kind = "reference"
+
+        def run():
+            return po.ref_encode(sample_pcm, BPS, RATE, LEVEL, want_bytes=False)["seconds"]
+    else:
+        kind = "port"
+
+        def run():
+            t0 = time.perf_counter()
+            po.oracle_encode(sample_pcm, BPS, RATE, LEVEL)
+            return time.perf_counter() - t0
+    best = min(run() for _ in range(3))
+    single = n / best / 1e6
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:     # ctypes releases the GIL: independent encoders in parallel
+        list(ex.map(lambda _: run(), range(threads * 2)))
+    multi = threads * 2 * n / (time.perf_counter() - t0) / 1e6
+    return {
+        "value": round(single, 3), "unit": "Msamples/s", "cores": 1, "kind": kind,
+        "sample": "%d inter-channel samples (%.0f s) of the bench signal, flac -%d, best of 3, in-memory" % (n, n / RATE, LEVEL),
+        "multi": {"value": round(multi, 3), "cores": threads, "how": "independent single-thread encoders, 2 clips each"},
+        "host_cpus": cores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import flac_amd
+    from flac_amd.dist import ordered_gather
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    nframes = args.frames
+    settings = flac_amd.make_settings(CH, BPS, RATE, LEVEL)
+    eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=nframes)
+
+    # this rank's shard of the corpus: frames [rank*nframes, (rank+1)*nframes)
+    pcm_h = synth_pcm(nframes, seed=1234 + rank)
+    d_pcm = torch.from_numpy(pcm_h).to(dev)
+    cap = eng.max_output_bytes(nframes)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_fb = torch.empty(nframes, dtype=torch.int32, device=dev)
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    first_frame = rank * nframes
+    an_ms, pk_ms, cp_ms = [], [], []
+
+    def step(record):
+        eng.encode_device(d_pcm.data_ptr(), nframes, d_out.data_ptr(), cap, d_fb.data_ptr(), d_total.data_ptr(),
+                          first_frame_number=first_frame)
+        a, p, c = eng.last_kernel_ms()          # HIP events on the engine's stream (waits for this batch)
+        if record:
+            an_ms.append(a); pk_ms.append(p); cp_ms.append(c)
+        if world > 1:
+            nbytes = int(d_total.item())
+            ordered_gather(d_out, nbytes, d_fb, dst=0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_bytes = int(d_total.item())
+    samples_per_step = nframes * BLOCK
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * samples_per_step * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        out_bps = total_bytes / samples_per_step                 # compressed bytes per inter-channel sample
+        alg_bytes = samples_per_step * (4 * CH + out_bps)         # PCM read once + frames written once
+        an = float(np.mean(an_ms))
+        achieved = alg_bytes / (an * 1e-3) / 1e9
+        line = {
+            "metric": "encode Msamples/s at -8, 44.1k/16-bit stereo; bit-exact vs libFLAC",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32+f64", "data": "synthetic",
+            "config": {"workload": "flac -8 (max LPC order 12, subdivide_tukey(3), mid/side, partition order <= 6) on 44.1k/16-bit stereo, "
+                                   "%d frames x %d samples per GPU per step, music-like synthetic PCM resident in HBM" % (nframes, BLOCK),
+                       "frames_per_gpu_per_step": nframes, "blocksize": BLOCK, "channels": CH, "bits_per_sample": BPS,
+                       "samples_are": "inter-channel (x2 for channel-samples)", "parallelism": "frame-shard x%d + ordered RCCL gather" % world,
+                       "compressed_bytes_per_sample": round(out_bps, 4)},
+            "kernel_ms": {"analyze": round(an, 4), "pack": round(float(np.mean(pk_ms)), 4), "scan_compact": round(float(np.mean(cp_ms)), 4)},
+            "roofline": {"bound": "hbm", "kernel": "analyze_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "-8 is VALU/LDS bound (~1e3 integer+fp64 ops per sample); HBM fraction reported as the north star asks"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pcm_h[: 512 * BLOCK])
+            line["speedup_vs_cpu_1thread"] = round(value / line["cpu_baseline"]["value"], 2)
+            line["speedup_vs_cpu_multi"] = round(value / line["cpu_baseline"]["multi"]["value"], 2)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

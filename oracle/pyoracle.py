@@ -170,6 +170,8 @@ def load_oracle():
         lib.fo_quantize_coefficients.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_int)]
         lib.fo_fixed_best_predictor.restype = C.c_uint32
         lib.fo_fixed_best_predictor.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.fo_fixed_best_predictor_ex.restype = C.c_uint32
+        lib.fo_fixed_best_predictor_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
         lib.fo_rice_search.restype = C.c_uint32
         lib.fo_rice_search.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]

@@ -1,0 +1,36 @@
+"""Case list shared by make_golden.py (generator, needs oracle/_ref) and the tests."""
+
+def golden_cases():
+    cases = []
+    n16 = 4096 * 3 + 1000
+    for fam in ["music", "white", "sine", "constant", "silence", "wasted", "square", "quiet", "mixed"]:
+        for level in range(9):
+            cases.append(dict(family=fam, n=n16, channels=2, bps=16, rate=44100, level=level))
+    for level in (0, 3, 5, 8):
+        cases.append(dict(family="music", n=4096 * 2 + 123, channels=2, bps=24, rate=96000, level=level))
+        cases.append(dict(family="music", n=4096 * 2 + 77, channels=1, bps=16, rate=44100, level=level))
+        cases.append(dict(family="white", n=4096 * 2 + 5, channels=2, bps=24, rate=96000, level=level))
+    for tail in (1, 4, 5, 17, 32, 33, 100, 1365, 2049, 4095):
+        for level in (2, 5, 8):
+            cases.append(dict(family="music", n=(1152 if level < 3 else 4096) + tail, channels=2, bps=16, rate=44100, level=level))
+    for ch in (3, 6):
+        cases.append(dict(family="music", n=4096 + 50, channels=ch, bps=16, rate=48000, level=8))
+    for bps in (8, 12, 20):
+        cases.append(dict(family="music", n=4096 * 2 + 9, channels=2, bps=bps, rate=32000, level=6))
+    # pure tones: the ill-conditioned case that pins the autocorrelation association order
+    for freq in (441.0, 1000.0, 997.0, 11025.0):
+        for level in (5, 8):
+            cases.append(dict(family="sine", n=4096 * 4, channels=1, bps=16, rate=44100, level=level, freq=freq))
+    return cases
+
+
+def case_key(c):
+    return "|".join("%s=%s" % (k, c[k]) for k in sorted(c))
+
+
+def case_pcm(c):
+    import signals
+    kw = {}
+    if "freq" in c:
+        kw["freq"] = c["freq"]
+    return signals.FAMILIES[c["family"]](c["n"], c["channels"], c["bps"], **kw)

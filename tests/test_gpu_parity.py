@@ -1,0 +1,217 @@
+"""-m gpu: the HIP path (through the C ABI, libflacgpu.so) against the oracle, the committed golden
+digests of the real reference, and -- at BASELINE.json's full sizes -- size-independent properties.
+Bit-exact is the bar: integer/byte output."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import signals
+from cases import golden_cases, case_key, case_pcm
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(os.path.dirname(__file__), "golden", "frames.json")) as f:
+    GOLDEN = json.load(f)
+
+
+def _engine(channels, bps, rate, level, max_batch=2048, **kw):
+    import flac_amd
+    return flac_amd.FrameEngine(flac_amd.make_settings(channels, bps, rate, level, **kw), device=0, max_batch_frames=max_batch)
+
+
+def _gpu_encode(pcm, bps, rate, level, first_frame=0, max_batch=2048, **kw):
+    eng = _engine(pcm.shape[1], bps, rate, level, max_batch, **kw)
+    try:
+        return eng.encode(pcm, first_frame)
+    finally:
+        eng.close()
+
+
+def test_extension_is_loaded_and_device_present():
+    import flac_amd
+    from flac_amd import engine
+    lib = engine.load_engine()
+    assert lib.flacgpu_device_count() >= 1
+    assert os.path.samefile(engine.ENGINE_SO, os.path.join(os.path.dirname(flac_amd.__file__), "lib", "libflacgpu.so"))
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=case_key)
+def test_gpu_matches_reference_golden(case):
+    want = GOLDEN[case_key(case)]
+    data, fb = _gpu_encode(case_pcm(case), case["bps"], case["rate"], case["level"])
+    assert len(fb) == want["frames"]
+    assert len(data) == want["bytes"]
+    assert hashlib.sha256(data).hexdigest() == want["sha256"]
+
+
+@pytest.mark.parametrize("level", range(9))
+def test_gpu_matches_oracle_per_frame(level):
+    for fam in ("music", "mixed", "white"):
+        pcm = signals.FAMILIES[fam](4096 * 9 + 1234, 2, 16, seed=level + 1)
+        data, fb = _gpu_encode(pcm, 16, 44100, level)
+        o = po.oracle_encode(pcm, 16, 44100, level)
+        assert np.array_equal(fb, o["frame_bytes"])
+        assert data == o["data"]
+
+
+def test_gpu_subframe_decisions_match_oracle():
+    """not only the bytes: the per-subframe model choices reported by the engine equal the oracle's"""
+    pcm = signals.mixed(4096 * 8, 2, 16)
+    eng = _engine(2, 16, 44100, 8)
+    data, fb = eng.encode(pcm)
+    sub, ca = eng.last_batch_info(8)
+    lib = po.load_oracle()
+    cfg = po.OracleConfig(2, 16, 44100, 8)
+    planar = np.ascontiguousarray(pcm.T)
+    out = np.empty(1 << 17, np.uint8)
+    for f in range(8):
+        info = po.FoFrameInfo()
+        ptrs = (C.c_void_p * 2)(planar[0, f * 4096:].ctypes.data, planar[1, f * 4096:].ctypes.data)
+        assert lib.fo_encode_frame(C.byref(cfg.c), ptrs, f, out.ctypes.data, out.size, C.byref(info)) == fb[f]
+        assert info.channel_assignment == ca[f]
+        for ch in range(2):
+            g, o = sub[f * 2 + ch], info.sub[ch]
+            assert (g.type, g.wasted_bits, g.bits) == (o.type, o.wasted_bits, o.bits)
+            if o.type >= 2:
+                assert (g.order, g.partition_order, g.rice2) == (o.order, o.partition_order, o.rice2)
+            if o.type == 3:
+                assert (g.precision, g.shift) == (o.precision, o.shift)
+    eng.close()
+
+
+@pytest.mark.parametrize("tail", [1, 4, 5, 31, 32, 33, 100, 683, 1365, 1932, 2047, 3860, 4095])
+def test_short_last_block(tail):
+    for level, bps, rate in ((2, 16, 44100), (5, 16, 44100), (8, 16, 44100), (8, 24, 96000)):
+        n = (1152 if level < 3 else 4096) * 2 + tail
+        pcm = signals.music(n, 2, bps, seed=tail)
+        data, fb = _gpu_encode(pcm, bps, rate, level)
+        assert data == po.oracle_encode(pcm, bps, rate, level)["data"], (tail, level, bps)
+
+
+def test_batches_and_frame_numbers():
+    """a stream split over several engine calls equals one call; frame numbers cross UTF-8 length classes"""
+    pcm = signals.music(4096 * 37 + 99, 2, 16, seed=21)
+    one, fb1 = _gpu_encode(pcm, 16, 44100, 5, max_batch=64)
+    many, fb2 = _gpu_encode(pcm, 16, 44100, 5, max_batch=5)
+    assert one == many and np.array_equal(fb1, fb2)
+    for first in (0x7E, 0x7FE, 0xFFFE, 0x1FFFFE):
+        data, _ = _gpu_encode(pcm[:4096 * 4], 16, 44100, 5, first_frame=first)
+        assert data == po.oracle_encode(pcm[:4096 * 4], 16, 44100, 5, first_frame=first)["data"]
+
+
+def test_limit_min_bitrate_and_channel_counts():
+    for level in (0, 2, 5, 8):
+        for pcm in (signals.silence(4096 * 3, 2, 16), signals.mixed(4096 * 6, 2, 16), signals.silence(4096 * 2, 1, 16)):
+            data, _ = _gpu_encode(pcm, 16, 44100, level, limit_min_bitrate=1)
+            assert data == po.oracle_encode(pcm, 16, 44100, level, limit_min_bitrate=1)["data"]
+    for ch in (1, 3, 4, 8):
+        pcm = signals.music(4096 * 2 + 50, ch, 16, seed=ch)
+        data, _ = _gpu_encode(pcm, 16, 48000, 8)
+        assert data == po.oracle_encode(pcm, 16, 48000, 8)["data"]
+
+
+def test_config2_1000_noise_frames_level5():
+    """BASELINE.json configs[1]: flac -5 on 1000 x 4096-sample 44.1k/16-bit stereo white-noise frames"""
+    pcm = signals.white(1000 * 4096, 2, 16, seed=1234)
+    data, fb = _gpu_encode(pcm, 16, 44100, 5, max_batch=1000)
+    o = po.oracle_encode(pcm, 16, 44100, 5)
+    assert len(fb) == 1000 and np.array_equal(fb, o["frame_bytes"])
+    assert hashlib.sha256(data).hexdigest() == hashlib.sha256(o["data"]).hexdigest()
+
+
+@pytest.mark.parametrize("bps,rate", [(16, 44100), (24, 96000)])
+def test_config3_4_level8_full_size_and_roundtrip(bps, rate):
+    """configs[2]/[3]: flac -8 at full batch size; compare with the oracle AND decode the GPU's frames with the
+    reference decoder (when oracle/_ref is present) -- encode->decode identity is size independent."""
+    nframes = 1500
+    pcm = signals.music(nframes * 4096, 2, bps, seed=77, rate=rate)
+    data, fb = _gpu_encode(pcm, bps, rate, 8, max_batch=nframes)
+    o = po.oracle_encode(pcm, bps, rate, 8)
+    assert np.array_equal(fb, o["frame_bytes"])
+    assert data == o["data"]
+    # every frame carries a valid CRC-16 footer (checksum of checksums style property)
+    lib = po.load_oracle()
+    off = np.concatenate([[0], np.cumsum(fb.astype(np.int64))])
+    buf = np.frombuffer(data, dtype=np.uint8)
+    for f in range(0, nframes, 97):
+        frame = buf[off[f]:off[f + 1]]
+        assert lib.fo_crc16(frame.ctypes.data, len(frame) - 2) == int(frame[-2]) << 8 | int(frame[-1])
+    if po.have_ref():
+        _decode_and_compare(data, pcm, bps, rate)
+
+
+def _decode_and_compare(frames, pcm, bps, rate):
+    """minimal fLaC + STREAMINFO wrapper, then the reference's stream decoder (test infrastructure)."""
+    ref = po.load_ref()
+    n, ch = pcm.shape
+    si = bytearray(34)
+    si[0:2] = (4096).to_bytes(2, "big"); si[2:4] = (4096).to_bytes(2, "big")
+    v = (rate << 44) | ((ch - 1) << 41) | ((bps - 1) << 36) | n
+    si[10:18] = v.to_bytes(8, "big")
+    blob = b"fLaC" + bytes([0x80, 0, 0, 34]) + bytes(si) + frames
+    state = {"pos": 0, "out": [], "err": 0}
+    RD = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_size_t), C.c_void_p)
+    WR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.c_void_p)
+    ER = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+
+    def rd(dec, buf, nbytes, cd):
+        want = nbytes[0]
+        chunk = blob[state["pos"]:state["pos"] + want]
+        if not chunk:
+            nbytes[0] = 0
+            return 1   # END_OF_STREAM
+        C.memmove(buf, chunk, len(chunk))
+        nbytes[0] = len(chunk)
+        state["pos"] += len(chunk)
+        return 0
+
+    def wr(dec, frame, buffers, cd):
+        bs = C.cast(frame, C.POINTER(C.c_uint32))[0]     # FLAC__Frame.header.blocksize is the first field
+        state["out"].append(np.stack([np.ctypeslib.as_array(buffers[c], (bs,)).copy() for c in range(ch)], axis=1))
+        return 0
+
+    def er(dec, status, cd):
+        state["err"] += 1
+
+    cbs = (RD(rd), WR(wr), ER(er))
+    ref.FLAC__stream_decoder_new.restype = C.c_void_p
+    dec = C.c_void_p(ref.FLAC__stream_decoder_new())
+    ref.FLAC__stream_decoder_init_stream.argtypes = [C.c_void_p, RD, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, WR, C.c_void_p, ER, C.c_void_p]
+    assert ref.FLAC__stream_decoder_init_stream(dec, cbs[0], None, None, None, None, cbs[1], None, cbs[2], None) == 0
+    ref.FLAC__stream_decoder_process_until_end_of_stream.argtypes = [C.c_void_p]
+    assert ref.FLAC__stream_decoder_process_until_end_of_stream(dec)
+    ref.FLAC__stream_decoder_finish.argtypes = [C.c_void_p]
+    ref.FLAC__stream_decoder_finish(dec)
+    ref.FLAC__stream_decoder_delete.argtypes = [C.c_void_p]
+    ref.FLAC__stream_decoder_delete(dec)
+    assert state["err"] == 0
+    got = np.concatenate(state["out"], axis=0)
+    assert got.shape == pcm.shape and np.array_equal(got, pcm)
+
+
+def test_device_resident_entry_point():
+    """flacgpu_encode_batch_device: PCM, frames and lengths never leave HBM; same bytes as the host entry"""
+    import torch
+    pcm = signals.music(4096 * 64, 2, 16, seed=5)
+    eng = _engine(2, 16, 44100, 8, max_batch=64)
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    cap = eng.max_output_bytes(64)
+    d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    d_fb = torch.zeros(64, dtype=torch.int32, device=dev)
+    d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
+    eng.encode_device(d_pcm.data_ptr(), 64, d_out.data_ptr(), cap, d_fb.data_ptr(), d_tot.data_ptr())
+    torch.cuda.synchronize()
+    total = int(d_tot.item())
+    o = po.oracle_encode(pcm, 16, 44100, 8)
+    assert total == len(o["data"])
+    assert d_out[:total].cpu().numpy().tobytes() == o["data"]
+    assert np.array_equal(d_fb.cpu().numpy().astype(np.uint32), o["frame_bytes"])
+    a, p, c = eng.last_kernel_ms()
+    assert a > 0 and p > 0
+    eng.close()

@@ -1,0 +1,178 @@
+"""Pins the oracle (and the host C layer's window tables) to the REAL reference binary, stage by stage
+and end to end.  Needs oracle/_ref/libFLAC_ref.so (built here from /root/reference; it travels to the
+GPU box as a prebuilt file).  Skipped where it is absent -- tests/test_oracle_golden.py then carries
+the pin through committed digests."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import signals
+from oracle import pyoracle as po
+from flac_amd import engine
+
+
+def _frames(r):
+    return r["data"][r["header_bytes"]:]
+
+
+@pytest.mark.parametrize("variant,name", [(8, "FLAC__lpc_compute_autocorrelation_intrin_fma_lag_8"),
+                                          (12, "FLAC__lpc_compute_autocorrelation_intrin_fma_lag_12"),
+                                          (16, "FLAC__lpc_compute_autocorrelation_intrin_fma_lag_16")])
+def test_autocorrelation_association_order(ref, variant, name):
+    """lpc_intrin_fma.c:46-72 as compiled: every lag bit for bit, many lengths."""
+    fn = getattr(ref, name)
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    orc = po.load_oracle()
+    rng = np.random.default_rng(42)
+    for n in (4096, 2048, 1365, 1152, 576, 4100, 3392, 683, 100, 61, 52, 44, 36, 33):
+        for trial in range(20):
+            scale = 10.0 ** rng.integers(0, 5)
+            d = (rng.standard_normal(n) * scale).astype(np.float32)
+            if trial % 4 == 0:      # pure tone: the ill-conditioned case
+                d = (np.sin(np.arange(n) * rng.uniform(0.01, 3.0)) * scale).astype(np.float32)
+            a = np.zeros(33)
+            b = np.zeros(33)
+            fn(d.ctypes.data, n, variant, a.ctypes.data)
+            orc.fo_autocorrelation(variant, d.ctypes.data, n, variant, b.ctypes.data)
+            assert np.array_equal(a[:variant].view(np.uint64), b[:variant].view(np.uint64)), (variant, n, trial)
+
+
+def test_levinson_order_quantise(ref):
+    """lpc.c:176 (with the compiled (r+1)*lpc[j] factoring), :1608, :220"""
+    orc = po.load_oracle()
+    ref.FLAC__lpc_compute_lp_coefficients.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+    ref.FLAC__lpc_compute_best_order.restype = C.c_uint32
+    ref.FLAC__lpc_compute_best_order.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    ref.FLAC__lpc_quantize_coefficients.restype = C.c_int
+    ref.FLAC__lpc_quantize_coefficients.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(7)
+    for trial in range(3000):
+        n = 4096
+        # AR-like signal -> autocorrelation
+        x = rng.standard_normal(n + 40)
+        k = rng.standard_normal(rng.integers(1, 6)) * 0.5
+        x = np.convolve(x, np.concatenate([[1.0], k]))[:n] * 10 ** rng.uniform(0, 4)
+        if trial % 5 == 0:
+            x = np.sin(np.arange(n) * rng.uniform(0.01, 3)) * 1000
+        order = int(rng.integers(1, 16))
+        autoc = np.array([np.dot(x[j:], x[:n - j]) for j in range(order + 1)] + [0.0] * (33 - order - 1))
+        mo_a, mo_b = C.c_uint32(order), C.c_uint32(order)
+        lp_a = np.zeros((32, 32), np.float32); lp_b = np.zeros((32, 32), np.float32)
+        er_a = np.zeros(32); er_b = np.zeros(32)
+        ref.FLAC__lpc_compute_lp_coefficients(autoc.ctypes.data, C.byref(mo_a), lp_a.ctypes.data, er_a.ctypes.data)
+        orc.fo_lp_coefficients(autoc.ctypes.data, C.byref(mo_b), lp_b.ctypes.data, er_b.ctypes.data)
+        assert mo_a.value == mo_b.value
+        m = mo_a.value
+        assert np.array_equal(er_a[:m].view(np.uint64), er_b[:m].view(np.uint64)), trial
+        assert np.array_equal(lp_a[:m].view(np.uint32), lp_b[:m].view(np.uint32)), trial
+        assert ref.FLAC__lpc_compute_best_order(er_a.ctypes.data, m, n, 28) == orc.fo_best_order(er_b.ctypes.data, m, n, 28)
+        for prec in (5, 9, 12, 15):
+            qa = np.zeros(32, np.int32); qb = np.zeros(32, np.int32)
+            sa, sb = C.c_int(0), C.c_int(0)
+            ra = ref.FLAC__lpc_quantize_coefficients(lp_a[m - 1].ctypes.data, m, prec, qa.ctypes.data, C.byref(sa))
+            rb = orc.fo_quantize_coefficients(lp_b[m - 1].ctypes.data, m, prec, qb.ctypes.data, C.byref(sb))
+            assert ra == rb
+            if ra == 0:
+                assert sa.value == sb.value and np.array_equal(qa, qb)
+
+
+def test_fixed_best_predictor_variants(ref):
+    """fixed_intrin_ssse3.c:62 (narrow, exact) and fixed_intrin_avx2.c:57 (wide, lane quirk for n%4 != 0)"""
+    orc = po.load_oracle()
+    for name, wide in (("FLAC__fixed_compute_best_predictor_intrin_ssse3", 0), ("FLAC__fixed_compute_best_predictor_wide_intrin_avx2", 1)):
+        fn = getattr(ref, name)
+        fn.restype = C.c_uint32
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        rng = np.random.default_rng(11 + wide)
+        for n in list(range(1, 40)) + [119, 1148, 1149, 1150, 1151, 4092, 4091, 2045]:
+            for trial in range(8):
+                amp = 1 << int(rng.integers(1, 15 if not wide else 23))
+                x = rng.integers(-amp, amp, n + 4).astype(np.int32)
+                if trial == 0:
+                    x[:] = 5
+                ra = np.zeros(5, np.float32); rb = np.zeros(5, np.float32)
+                oa = fn(x.ctypes.data + 16, n, ra.ctypes.data)
+                ob = orc.fo_fixed_best_predictor_ex(x.ctypes.data + 16, n, rb.ctypes.data, wide)
+                assert oa == ob, (name, n, trial)
+                assert np.array_equal(ra.view(np.uint32), rb.view(np.uint32)), (name, n, trial, ra, rb)
+
+
+WINDOW_SPECS = ["bartlett", "bartlett_hann", "blackman", "blackman_harris_4term_92db", "connes", "flattop", "gauss(0.2)",
+                "hamming", "hann", "kaiser_bessel", "nuttall", "rectangle", "triangle", "tukey(0.5)", "tukey(0.25)",
+                "partial_tukey(2)", "partial_tukey(3/0.3/0.5)", "punchout_tukey(3)", "punchout_tukey(2/0.2/0.4)",
+                "subdivide_tukey(3)", "subdivide_tukey(2/0.7)", "welch"]
+
+
+@pytest.mark.parametrize("spec", WINDOW_SPECS)
+def test_host_window_tables_and_apodization_parser(ref, spec):
+    """flac_amd/csrc/host/{window,settings}.c vs window.c + set_apodization: encode with the spec through the
+    reference and through the oracle fed with the HOST layer's window tables -- frames must match."""
+    pcm = signals.music(4096 * 2 + 333, 2, 16, seed=3)
+    r = po.ref_encode(pcm, 16, 44100, 5, apodization=spec, max_lpc_order=8)
+    s = engine.make_settings(2, 16, 44100, 5, apodization=spec, max_lpc_order=8)
+    frames = b""
+    for blk, off, fn in ((4096, 0, 0), (4096, 4096, 1), (333, 8192, 2)):
+        cfg = po.OracleConfig(2, 16, 44100, 5, blocksize=blk, stream_blocksize=4096, max_lpc_order=8)
+        w = engine.host_windows(s, blk)
+        cfg.c.num_apodizations = s.num_apodizations
+        for a in range(s.num_apodizations):
+            sub = s.apodizations[a].type == 16
+            cfg.c.apodizations[a].kind = 1 if sub else 0
+            cfg.c.apodizations[a].parts = s.apodizations[a].parts if sub else 0
+            cfg.c.apodizations[a].window = w[a].ctypes.data_as(C.POINTER(C.c_float))
+        planar = np.ascontiguousarray(pcm[off:off + blk].T)
+        ptrs = (C.c_void_p * 2)(planar[0].ctypes.data, planar[1].ctypes.data)
+        out = np.empty(65536, np.uint8)
+        n = po.load_oracle().fo_encode_frame(C.byref(cfg.c), ptrs, fn, out.ctypes.data, out.size, None)
+        assert n > 0
+        frames += out[:n].tobytes()
+    assert frames == _frames(r)
+
+
+@pytest.mark.parametrize("level", range(9))
+@pytest.mark.parametrize("family", ["music", "white", "sine", "mixed", "wasted", "square"])
+def test_streams_16bit(ref, family, level):
+    pcm = signals.FAMILIES[family](4096 * 5 + 777, 2, 16)
+    r = po.ref_encode(pcm, 16, 44100, level)
+    o = po.oracle_encode(pcm, 16, 44100, level)
+    assert o["data"] == _frames(r)
+    assert np.array_equal(o["frame_bytes"], r["frame_bytes"])
+
+
+@pytest.mark.parametrize("level", [0, 2, 5, 8])
+def test_streams_24bit_96k(ref, level):
+    for fam in ("music", "white", "sine", "wasted"):
+        pcm = signals.FAMILIES[fam](4096 * 3 + 123, 2, 24)
+        r = po.ref_encode(pcm, 24, 96000, level)
+        assert po.oracle_encode(pcm, 24, 96000, level)["data"] == _frames(r)
+
+
+@pytest.mark.parametrize("tail", [1, 2, 3, 4, 5, 6, 16, 31, 32, 33, 34, 63, 65, 100, 255, 257, 1000, 1931, 1932, 2048, 3859, 3860, 4095])
+def test_short_last_block(ref, tail):
+    for level in (0, 5, 8):
+        n = (1152 if level < 3 else 4096) + tail
+        for bps, rate in ((16, 44100), (24, 96000)):
+            pcm = signals.music(n, 2, bps, seed=tail)
+            r = po.ref_encode(pcm, bps, rate, level)
+            assert po.oracle_encode(pcm, bps, rate, level)["data"] == _frames(r), (tail, level, bps)
+
+
+def test_pure_tones(ref):
+    """10/49 frames of the reference's own sine16-16 stream change if the summation order is wrong."""
+    for f in (55.5, 441.0, 997.0, 1000.0, 4410.0, 11025.0, 20000.0):
+        for level in (3, 5, 8):
+            pcm = signals.sine(4096 * 8 + 777, 1, 16, freq=f)
+            r = po.ref_encode(pcm, 16, 44100, level)
+            assert po.oracle_encode(pcm, 16, 44100, level)["data"] == _frames(r), (f, level)
+
+
+def test_limit_min_bitrate_and_channels(ref):
+    for level in (0, 2, 5, 8):
+        for pcm in (signals.silence(4096 * 3, 2, 16), signals.mixed(4096 * 6, 2, 16), signals.silence(4096 * 2, 1, 16)):
+            r = po.ref_encode(pcm, 16, 44100, level, limit_min_bitrate=1)
+            assert po.oracle_encode(pcm, 16, 44100, level, limit_min_bitrate=1)["data"] == _frames(r)
+    for ch in (1, 3, 4, 6, 8):
+        pcm = signals.music(4096 * 2 + 50, ch, 16, seed=ch)
+        r = po.ref_encode(pcm, 16, 48000, 8)
+        assert po.oracle_encode(pcm, 16, 48000, 8)["data"] == _frames(r)
