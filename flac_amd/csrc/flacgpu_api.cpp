@@ -130,7 +130,19 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	{
 		const uint32_t maxidx = 32 + ((N + 15u) & ~15u) + 16u + 16u;
 		P.sig_bytes = ((maxidx + ((maxidx >> 4) << 1) + 8) * 4 + 15) & ~15u;
-		P.wnd_bytes = ((N + 64) * 4 + 15) & ~15u;
+		// window jobs of one subframe (same enumeration as analyze_kernel): all of them are windowed
+		// into LDS at once so that their autocorrelation chains run concurrently
+		uint32_t nj = 0, na = 0, wfloats = 0;
+		for(uint32_t a = 0; a < P.num_apod; a++) {
+			nj++; na++; wfloats += (N + 3u) & ~1u;
+			if(P.apod_kind[a] == FLACGPU_APOD_SUBDIVIDE_TUKEY)
+				for(uint32_t b = 2; b <= P.apod_parts[a]; b++) {
+					if(N / b <= 32) continue;
+					nj += b; na += b >= 3 ? 2 * b : b; wfloats += b * ((N / b + 3u) & ~1u);
+				}
+		}
+		if(nj > (uint32_t)MAX_JOBS || na > (uint32_t)MAX_ANALYSES) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
+		P.wnd_bytes = ((wfloats + 64) * 4 + 15) & ~15u;
 	}
 	if(analyze_lds_bytes(P) > 160 * 1024 - 1024 || pack_lds_bytes(P) > 160 * 1024 - 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
 

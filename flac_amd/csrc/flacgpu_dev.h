@@ -12,6 +12,8 @@ constexpr int TPB = 256;        // threads per workgroup (4 wavefronts of 64)
 constexpr int CHUNK = 16;       // consecutive samples owned by one thread in FIR passes
 constexpr int MAX_ORDER = 16;   // taps kept per candidate (max_lpc_order <= 15)
 constexpr int MAX_PO = 8;       // max residual partition order (FLAC subset limit)
+constexpr int MAX_JOBS = 24;    // windowed-data jobs per subframe (subdivide_tukey up to 6 parts)
+constexpr int MAX_ANALYSES = 40;// LPC analyses per subframe
 
 // flattened, device-friendly copy of flacgpu_config
 struct DevParams {

@@ -83,9 +83,11 @@ __device__ __forceinline__ uint32_t block_reduce_or_u32(uint32_t v, uint64_t *sc
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp64 model stages, one lane each (lpc.c:176-314,1580-1630 as compiled; see oracle/flac_oracle.c)
+// fp64 model stage: Levinson-Durbin + order guess + quantisation, ONE LANE PER ANALYSIS with the whole
+// recursion in registers (fully unrolled, statically indexed) -- lpc.c:176-314,1580-1630 as the
+// reference binary computes them (see oracle/flac_oracle.c for the compiled-behaviour notes)
 // ---------------------------------------------------------------------------------------------
-__device__ double expected_bits_scaled(double lpc_error, double error_scale)
+__device__ __forceinline__ double expected_bits_scaled(double lpc_error, double error_scale)
 {
 	if(lpc_error > 0.0) {
 		// 0.5*log(x)/M_LN2 folded by -freciprocal-math into log(x) * (0.5/ln 2)
@@ -96,81 +98,83 @@ __device__ double expected_bits_scaled(double lpc_error, double error_scale)
 	return 0.0;
 }
 
-// Levinson-Durbin + order guess + coefficient quantisation for one analysis.
-// Returns 0 when no LPC candidate results (autoc[0]==0, estimate >= bps, quantiser failure, residual
-// would need the >32-bit "limit_residual" flavour).
-__device__ int lpc_model(const double *autoc, uint32_t max_order, uint32_t n, uint32_t sbps,
-                         uint32_t cfg_precision, Candidate *out)
+// One Levinson-Durbin recursion up to `upto` orders (lpc.c:188-217). lpc[] / errs[] live in registers.
+// Returns the number of orders actually produced (stops early when err == 0, lpc.c:213).
+template <int MAXORD>
+__device__ __forceinline__ uint32_t levinson(const double (&a)[MAXORD + 1], uint32_t upto, double (&lpc)[MAXORD], double (&errs)[MAXORD])
 {
-	double lpc[MAX_ORDER], err_of[MAX_ORDER];
-	float coef[MAX_ORDER];          // coefficients of the guessed order, filled on the second pass
-	if(autoc[0] == 0.0) return 0;
-	// pass 1: errors for every order (lp_coeff of all orders is not kept; the chosen order's
-	// coefficients are regenerated below -- Levinson is deterministic)
-	uint32_t used = max_order;
-	{
-		double err = autoc[0];
-		for(uint32_t i = 0; i < max_order; i++) {
-			double r = -autoc[i + 1];
-			uint32_t j;
-			for(j = 0; j < i; j++) r -= lpc[j] * autoc[i - j];
+	double err = a[0];
+	uint32_t used = upto;
+#pragma unroll
+	for(int i = 0; i < MAXORD; i++) {
+		if((uint32_t)i < used) {
+			double r = -a[i + 1];
+#pragma unroll
+			for(int j = 0; j < i; j++) r -= lpc[j] * a[i - j];
 			r /= err;
 			lpc[i] = r;
-			for(j = 0; j < (i >> 1); j++) {
-				double tmp = lpc[j];
+#pragma unroll
+			for(int j = 0; j < (i >> 1); j++) {
+				const double tmp = lpc[j];
 				lpc[j] += r * lpc[i - 1 - j];
 				lpc[i - 1 - j] += r * tmp;
 			}
-			if(i & 1) lpc[j] = (r + 1.0) * lpc[j];
+			if(i & 1) lpc[i >> 1] = (r + 1.0) * lpc[i >> 1];   // compiled form of lpc[j] += lpc[j]*r
 			err *= (1.0 - r * r);
-			err_of[i] = err;
-			if(err == 0.0) { used = i + 1; break; }
+			errs[i] = err;
+			if(err == 0.0) used = (uint32_t)i + 1;
 		}
 	}
+	return used;
+}
+
+// autoc: lag values of this analysis (already punched-out when applicable). Returns 0 when no LPC
+// candidate results (autoc[0]==0, estimate >= bps, quantiser failure, residual would need the
+// >32-bit "limit_residual" flavour).
+template <int MAXORD>
+__device__ int lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint32_t n, uint32_t sbps,
+                         uint32_t cfg_precision, Candidate *out)
+{
+	double lpc[MAXORD], errs[MAXORD];
+	if(a[0] == 0.0) return 0;
+#pragma unroll
+	for(int i = 0; i < MAXORD; i++) { lpc[i] = 0.0; errs[i] = 0.0; }
+	const uint32_t used = levinson<MAXORD>(a, max_order, lpc, errs);
 	// FLAC__lpc_compute_best_order (lpc.c:1608): total_samples is the full blocksize
-	uint32_t order;
+	uint32_t order = 1;
+	double err_order = errs[0];
 	{
 		const double scale = 0.5 / (double)n;
 		const uint32_t overhead = sbps + cfg_precision;
 		double best_bits = 4294967295.0;
-		uint32_t best = 0;
-		for(uint32_t idx = 0, o = 1; idx < used; idx++, o++) {
-			double bits = expected_bits_scaled(err_of[idx], scale) * (double)(n - o) + (double)(o * overhead);
-			if(bits < best_bits) { best = idx; best_bits = bits; }
+#pragma unroll
+		for(int idx = 0; idx < MAXORD; idx++) {
+			if((uint32_t)idx < used) {
+				const uint32_t o = (uint32_t)idx + 1;
+				const double bits = expected_bits_scaled(errs[idx], scale) * (double)(n - o) + (double)(o * overhead);
+				if(bits < best_bits) { order = o; best_bits = bits; err_order = errs[idx]; }
+			}
 		}
-		order = best + 1;
 	}
 	// stream_encoder.c:4227-4229
-	if(expected_bits_scaled(err_of[order - 1], 0.5 / (double)(n - order)) >= (double)sbps) return 0;
-	// pass 2: coefficients of `order`
-	{
-		double err = autoc[0];
-		for(uint32_t i = 0; i < order; i++) {
-			double r = -autoc[i + 1];
-			uint32_t j;
-			for(j = 0; j < i; j++) r -= lpc[j] * autoc[i - j];
-			r /= err;
-			lpc[i] = r;
-			for(j = 0; j < (i >> 1); j++) {
-				double tmp = lpc[j];
-				lpc[j] += r * lpc[i - 1 - j];
-				lpc[i - 1 - j] += r * tmp;
-			}
-			if(i & 1) lpc[j] = (r + 1.0) * lpc[j];
-			err *= (1.0 - r * r);
-		}
-		for(uint32_t j = 0; j < order; j++) coef[j] = (float)(-lpc[j]);
-	}
+	if(expected_bits_scaled(err_order, 0.5 / (double)(n - order)) >= (double)sbps) return 0;
+	// coefficients of `order`: rerun the (deterministic) recursion up to that order
+	(void)levinson<MAXORD>(a, order, lpc, errs);
+	float coef[MAXORD];
+#pragma unroll
+	for(int j = 0; j < MAXORD; j++) coef[j] = (uint32_t)j < order ? (float)(-lpc[j]) : 0.0f;
 	// stream_encoder.c:4591-4595 then FLAC__lpc_quantize_coefficients (lpc.c:220)
 	uint32_t precision = cfg_precision;
 	if(sbps <= 17) precision = umin32(precision, 32 - sbps - ilog2_u32(order));
 	int shift;
+	int32_t q[MAXORD];
 	{
 		const uint32_t p1 = precision - 1;
 		int32_t qmax = (int32_t)1 << p1, qmin = -qmax;
 		qmax--;
 		double cmax = 0.0;
-		for(uint32_t i = 0; i < order; i++) { double a = fabs((double)coef[i]); if(a > cmax) cmax = a; }
+#pragma unroll
+		for(int i = 0; i < MAXORD; i++) { const double v = fabs((double)coef[i]); if(v > cmax) cmax = v; }
 		if(cmax <= 0.0) return 0;
 		int e;
 		(void)frexp(cmax, &e);
@@ -179,39 +183,34 @@ __device__ int lpc_model(const double *autoc, uint32_t max_order, uint32_t n, ui
 		if(shift > 15) shift = 15;
 		else if(shift < -16) return 0;
 		double error = 0.0;
-		for(uint32_t i = 0; i < MAX_ORDER; i++) out->q[i] = 0;
-		if(shift >= 0) {
-			const float scale = (float)(1 << shift);
-			for(uint32_t i = 0; i < order; i++) {
-				error += (double)(coef[i] * scale);
-				int32_t v = (int32_t)lround(error);
+		const bool neg = shift < 0;
+		const float scale = (float)(1 << (neg ? -shift : shift));
+#pragma unroll
+		for(int i = 0; i < MAXORD; i++) {
+			int32_t v = 0;
+			if((uint32_t)i < order) {
+				error += neg ? (double)(coef[i] / scale) : (double)(coef[i] * scale);
+				v = (int32_t)lround(error);
 				if(v > qmax) v = qmax; else if(v < qmin) v = qmin;
 				error -= v;
-				out->q[i] = v;
 			}
+			q[i] = v;
 		}
-		else {
-			const float scale = (float)(1 << (-shift));
-			for(uint32_t i = 0; i < order; i++) {
-				error += (double)(coef[i] / scale);
-				int32_t v = (int32_t)lround(error);
-				if(v > qmax) v = qmax; else if(v < qmin) v = qmin;
-				error -= v;
-				out->q[i] = v;
-			}
-			shift = 0;
-		}
+		if(neg) shift = 0;
 	}
 	// residual kernel selector (stream_encoder.c:4601-4617, lpc.c:942-976)
 	{
 		uint32_t abs_sum = 0;
-		for(uint32_t i = 0; i < order; i++) abs_sum += (uint32_t)abs(out->q[i]);
+#pragma unroll
+		for(int i = 0; i < MAXORD; i++) abs_sum += (uint32_t)abs(q[i]);
 		const uint64_t maxabs = (uint64_t)1 << (sbps - 1);
 		const uint64_t before = maxabs * abs_sum;
 		const uint64_t after = (uint64_t)(-1 * ((-1 * (int64_t)before) >> shift));
 		if(silog2_i64((int64_t)(maxabs + after)) > 32) return 0;
 		out->wide = silog2_i64((int64_t)before) > 32;
 	}
+#pragma unroll
+	for(int i = 0; i < MAX_ORDER; i++) out->q[i] = i < MAXORD ? q[i < MAXORD ? i : 0] : 0;
 	out->order = order;
 	out->precision = precision;
 	out->shift = shift;
@@ -219,110 +218,75 @@ __device__ int lpc_model(const double *autoc, uint32_t max_order, uint32_t n, ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// autocorrelation chains (one lane per (lag j, vector lane l)), SURVEY.md 5.9
-// d = windowed data in LDS, nd = data_len. Result in autoc[0..lag).
+// autocorrelation in the association order of the reference's compiled routines:
+// one lane per chain = (window job, lag j, vector lane l); the 4 lane accumulators of a lag are
+// combined as (acc3+acc1)+(acc2+acc0) afterwards, then the scalar head/tail of lpc_intrin_fma.c.
+// d = windowed data of the job in LDS, nd = its data_len.
 // ---------------------------------------------------------------------------------------------
 #define DD(k) ((double)d[k])
-__device__ __forceinline__ double autoc_tail(const float *d, uint32_t i, uint32_t nd, uint32_t j, double a)
+// body of lpc_intrin_fma.c:46,61 (lag 8 / lag 16): acc_l += fma(d[i],d[i-j], d[i+4]*d[i+4-j]), i = L+8k+l
+__device__ __forceinline__ double autoc_chain_8_16(const float *d, uint32_t nd, uint32_t L, uint32_t j, uint32_t l)
 {
+	const uint32_t nb = (nd - L) / 8;
+	double acc = 0.0;
+	uint32_t i = L + l;
+#pragma unroll 4
+	for(uint32_t k = 0; k < nb; k++, i += 8)
+		acc += fma(DD(i), DD(i - j), DD(i + 4) * DD(i + 4 - j));
+	return acc;
+}
+// body of lpc_intrin_fma.c:54 (lag 12): 2x-unrolled by gcc, lag 8 factored x*y0+x*y2 -> x*(y0+y2)
+__device__ __forceinline__ double autoc_chain_12(const float *d, uint32_t nd, uint32_t j, uint32_t l)
+{
+	const uint32_t L = 12;
+	const uint32_t nb = (nd - L) / 8;
+	const uint32_t npairs = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
+	double acc = 0.0;
+	uint32_t i = L + l, k = 0;
+	if(j == 8) {
+#pragma unroll 2
+		for(uint32_t p = 0; p < npairs; p++, k += 2, i += 16) {
+			const double x0 = DD(i), x1 = DD(i + 4), x2 = DD(i + 8), x3 = DD(i + 12), y0 = DD(i - 8), y1 = DD(i - 4);
+			acc += fma(x0, (y0 + x2), x1 * (y1 + x3));
+		}
+	}
+	else {
+#pragma unroll 2
+		for(uint32_t p = 0; p < npairs; p++, k += 2, i += 16) {
+			const double t0 = fma(DD(i), DD(i - j), DD(i + 4) * DD(i + 4 - j));
+			const double t1 = fma(DD(i + 8), DD(i + 8 - j), DD(i + 12) * DD(i + 12 - j));
+			acc += (t1 + t0);
+		}
+	}
+	for(; k < nb; k++, i += 8)
+		acc += fma(DD(i), DD(i - j), DD(i + 4) * DD(i + 4 - j));
+	return acc;
+}
+// scalar head (samples j..L-1), lane combine and tail for lag j
+__device__ __forceinline__ double autoc_finish(const float *d, uint32_t nd, uint32_t L, uint32_t j, const double *acc4)
+{
+	double a = 0.0;
+	for(uint32_t h = j; h < L; h++) a += DD(h) * DD(h - j);
+	const uint32_t nb = (nd - L) / 8;
+	if(nb) a = ((acc4[3] + acc4[1]) + (acc4[2] + acc4[0])) + a;
+	uint32_t i = L + 8 * nb;
 	if(nd - i >= 4) {
-		double hi = fma(DD(i + 1), DD(i + 1 - j), DD(i + 3) * DD(i + 3 - j));
-		double lo = fma(DD(i), DD(i - j), DD(i + 2) * DD(i + 2 - j));
+		const double hi = fma(DD(i + 1), DD(i + 1 - j), DD(i + 3) * DD(i + 3 - j));
+		const double lo = fma(DD(i), DD(i - j), DD(i + 2) * DD(i + 2 - j));
 		a = (hi + lo) + a;
 		i += 4;
 	}
 	for(; i < nd; i++) a = fma(DD(i), DD(i - j), a);
 	return a;
 }
-
-// FMA lag-8 / lag-16 routines (lpc_intrin_fma.c:46,61)
-__device__ void autoc_fma_8_16(const float *d, uint32_t nd, uint32_t L, uint32_t lag, double *autoc, int tid)
+// lpc.c:133-157 (blocksize <= 32): plain sequential accumulation per lag
+__device__ __forceinline__ double autoc_small(const float *d, uint32_t nd, uint32_t c)
 {
-	const uint32_t j = (uint32_t)tid >> 2, l = (uint32_t)tid & 3;
-	if(j >= ((lag + 15u) & ~15u)) return;            // whole waves of idle lanes leave; lanes sharing a wave stay for the shuffles
-	const bool live = j < lag;
-	const uint32_t jj = live ? j : 0;
-	const uint32_t nb = (nd - L) / 8;
-	double acc = 0.0;
-	uint32_t i = L + l;
-	for(uint32_t k = 0; k < nb; k++, i += 8)
-		acc += fma(DD(i), DD(i - jj), DD(i + 4) * DD(i + 4 - jj));
-	// (acc3+acc1)+(acc2+acc0) within each group of 4 lanes
-	double a_odd, a_even;
-	{
-		// lane l gets partner l^2: l=0:(0,2) l=1:(1,3)
-		uint32_t lo = __shfl_xor((uint32_t)__double2loint(acc), 2), hi = __shfl_xor((uint32_t)__double2hiint(acc), 2);
-		double partner = __hiloint2double((int)hi, (int)lo);
-		// want (acc3+acc1) and (acc2+acc0): on lane 1: partner=acc3 -> acc3+acc1 ; on lane 0: partner=acc2 -> acc2+acc0
-		double s = partner + acc;
-		uint32_t slo = __shfl_xor((uint32_t)__double2loint(s), 1), shi = __shfl_xor((uint32_t)__double2hiint(s), 1);
-		double other = __hiloint2double((int)shi, (int)slo);
-		a_even = (l & 1) ? other : s;   // (acc2+acc0)
-		a_odd = (l & 1) ? s : other;    // (acc3+acc1)
-	}
-	if(live && l == 0) {
-		double a = 0.0;
-		for(uint32_t h = jj; h < L; h++) a += DD(h) * DD(h - jj);
-		if(nb) a = (a_odd + a_even) + a;
-		autoc[jj] = autoc_tail(d, L + 8 * nb, nd, jj, a);
-	}
-}
-
-// FMA lag-12 routine (lpc_intrin_fma.c:54): 2x-unrolled body, lag 8 factored
-__device__ void autoc_fma_12(const float *d, uint32_t nd, uint32_t lag, double *autoc, int tid)
-{
-	const uint32_t L = 12;
-	const uint32_t j = (uint32_t)tid >> 2, l = (uint32_t)tid & 3;
-	if(j >= ((lag + 15u) & ~15u)) return;
-	const bool live = j < lag;
-	const uint32_t jj = live ? j : 0;
-	const uint32_t nb = (nd - L) / 8;
-	const uint32_t npairs = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
-	double acc = 0.0;
-	uint32_t i = L + l, k = 0;
-	if(jj == 8) {
-		for(uint32_t p = 0; p < npairs; p++, k += 2, i += 16) {
-			double x0 = DD(i), x1 = DD(i + 4), x2 = DD(i + 8), x3 = DD(i + 12), y0 = DD(i - 8), y1 = DD(i - 4);
-			acc += fma(x0, (y0 + x2), x1 * (y1 + x3));
-		}
-	}
-	else {
-		for(uint32_t p = 0; p < npairs; p++, k += 2, i += 16) {
-			double t0 = fma(DD(i), DD(i - jj), DD(i + 4) * DD(i + 4 - jj));
-			double t1 = fma(DD(i + 8), DD(i + 8 - jj), DD(i + 12) * DD(i + 12 - jj));
-			acc += (t1 + t0);
-		}
-	}
-	for(; k < nb; k++, i += 8)
-		acc += fma(DD(i), DD(i - jj), DD(i + 4) * DD(i + 4 - jj));
-	double a_odd, a_even;
-	{
-		uint32_t lo = __shfl_xor((uint32_t)__double2loint(acc), 2), hi = __shfl_xor((uint32_t)__double2hiint(acc), 2);
-		double s = __hiloint2double((int)hi, (int)lo) + acc;
-		uint32_t slo = __shfl_xor((uint32_t)__double2loint(s), 1), shi = __shfl_xor((uint32_t)__double2hiint(s), 1);
-		double other = __hiloint2double((int)shi, (int)slo);
-		a_even = (l & 1) ? other : s;
-		a_odd = (l & 1) ? s : other;
-	}
-	if(live && l == 0) {
-		double a = 0.0;
-		for(uint32_t h = jj; h < L; h++) a += DD(h) * DD(h - jj);
-		if(nb) a = (a_odd + a_even) + a;
-		autoc[jj] = autoc_tail(d, L + 8 * nb, nd, jj, a);
-	}
-}
-
-// lpc.c:133-157 (blocksize <= 32): sequential per lag
-__device__ void autoc_small(const float *d, uint32_t nd, uint32_t lag, double *autoc, int tid)
-{
-	if((uint32_t)tid >= lag) return;
-	const uint32_t c = (uint32_t)tid;
 	double a = 0.0;
 	for(uint32_t s = 0; s + c < nd; s++) a += DD(s) * DD(s + c);
-	autoc[c] = a;
+	return a;
 }
 #undef DD
-
 // ---------------------------------------------------------------------------------------------
 // shared between analyze and pack: build the candidate channel's signal in LDS
 // returns the OR of all samples (for wasted bits) reduced over the workgroup
@@ -397,18 +361,29 @@ __device__ __forceinline__ void fir_chunk_dispatch(const int32_t *sig, int base,
 // ---------------------------------------------------------------------------------------------
 // analyze_kernel
 // ---------------------------------------------------------------------------------------------
+struct WindowJob {
+	uint32_t off;       // float offset of this job's windowed data in the LDS window buffer
+	uint32_t nd;        // data_len handed to the autocorrelation
+	uint32_t apod;      // which window table
+	uint32_t full;      // 1: whole block (lpc.c:68), 0: partial window (lpc.c:82)
+	uint32_t part, dshift, i0;
+};
+
 struct AnalyzeShared {
 	uint64_t sums[2u << MAX_PO];        // |residual| per partition at max_po, u64 (masked to 32 bits when the reference accumulates in 32)
 	uint64_t po_bits[MAX_PO + 1];
 	uint64_t scratch[8];
-	double autoc[MAX_ORDER + 1];
-	double root[MAX_ORDER + 1];
-	Candidate cand;
-	int cand_valid;
+	double accs[MAX_JOBS * 4 * MAX_ORDER];       // lane accumulators of every chain
+	double autoc_job[MAX_JOBS][MAX_ORDER];       // finished autocorrelation per window job
+	WindowJob jobs[MAX_JOBS];
+	uint8_t an_job[MAX_ANALYSES], an_punch[MAX_ANALYSES], an_root[MAX_ANALYSES];
+	uint32_t njobs, nanalyses;
+	Candidate cands[MAX_ANALYSES];
+	int cand_valid[MAX_ANALYSES];
+	Candidate fixedc;
 	int32_t bestq[MAX_ORDER];
 	uint8_t kcand[2u << MAX_PO];
 	uint8_t kbest[1u << MAX_PO];
-	uint32_t flag;
 };
 
 // Evaluate one residual candidate (fixed or LPC) with all threads.
@@ -661,11 +636,11 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 						else if(order == 2) c = tid == 0 ? 2 : tid == 1 ? -1 : 0;
 						else if(order == 3) c = tid == 0 ? 3 : tid == 1 ? -3 : tid == 2 ? 1 : 0;
 						else if(order == 4) c = tid == 0 ? 4 : tid == 1 ? -6 : tid == 2 ? 4 : tid == 3 ? -1 : 0;
-						sh->cand.q[tid] = c;
+						sh->fixedc.q[tid] = c;
 					}
 					__syncthreads();
 					uint32_t po, koff;
-					const uint32_t rbits = eval_candidate<MAXORD>(sh, sig, n, order, sh->cand.q, 0, false, sbps, P, frame_max_po, frame_min_po, &po, &koff, tid);
+					const uint32_t rbits = eval_candidate<MAXORD>(sh, sig, n, order, sh->fixedc.q, 0, false, sbps, P, frame_max_po, frame_min_po, &po, &koff, tid);
 					const uint32_t est = sat_add_u32(hdr + order * sbps, rbits);
 					if(est < best_bits) {
 						best_type = 2; best_order = order; best_po = po; best_bits = est;
@@ -674,76 +649,125 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 					__syncthreads();
 				}
 			}
-			// ---- LPC candidates: apply_apodization_ state machine (stream_encoder.c:4199-4275,4318) --
+			// ---- LPC candidates (stream_encoder.c:4199-4275; apply_apodization_ :4318-4392) ----------
+			// The reference walks its apodization state machine sequentially; every step is a pure
+			// function of the block, so here all window jobs are windowed and autocorrelated at once,
+			// all analyses are modelled at once (one lane each), and the candidates are then compared
+			// in the reference's order with its strict '<'.
 			if(P.max_lpc_order > 0) {
 				const uint32_t max_lpc = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
 				const uint32_t variant = n <= 32 ? 0u : P.autoc_variant;
 				if(max_lpc > 0) {
-					uint32_t a = 0, b = 1, c = 0;
-					while(a < P.num_apod) {
-						const float *w = win + (size_t)a * n;
-						const uint32_t kind = P.apod_kind[a], parts = P.apod_parts[a];
-						const uint32_t lag = max_lpc + 1;
-						bool have = true;
-						if(b == 1) {
-							for(uint32_t i = (uint32_t)tid; i < n; i += TPB) wnd[i] = (float)sig[sigidx((int)i)] * w[i];
-							__syncthreads();
-							if(variant == 12) autoc_fma_12(wnd, n, lag, sh->autoc, tid);
-							else if(variant == 0) autoc_small(wnd, n, lag, sh->autoc, tid);
-							else autoc_fma_8_16(wnd, n, variant, lag, sh->autoc, tid);
-							__syncthreads();
-							if(kind == FLACGPU_APOD_SUBDIVIDE_TUKEY) {
-								if((uint32_t)tid < max_lpc) sh->root[tid] = sh->autoc[tid];   // max_order entries, not +1 (:4340)
-								b++;
-							}
-							else a++;
-						}
-						else {
-							if(n / b <= 32) have = false;
-							else if(!(c & 1)) {
-								const uint32_t part = n / b / 2, dshift = (c / 2 * n) / b, nd = n / b;
-								if(part + dshift < n) {
-									const uint32_t i0 = umin32(part, n - part - dshift);
-									for(uint32_t i = (uint32_t)tid; i <= i0 + part; i += TPB) {
-										float o;
-										bool wr = true;
-										if(i >= i0 && i < i0 + part) o = (float)sig[sigidx((int)(dshift + i))] * w[n - part + (i - i0)];
-										else if(i < part) o = (float)sig[sigidx((int)(dshift + i))] * w[i];
-										else if(i == i0 + part && i < n) o = 0.0f;
-										else { wr = false; o = 0.0f; }
-										if(wr) wnd[i] = o;
+					const uint32_t lag = max_lpc + 1;
+					if(tid == 0) {
+						uint32_t nj = 0, na = 0, woff = 0;
+						for(uint32_t a = 0; a < P.num_apod; a++) {
+							const uint32_t root = nj;
+							WindowJob &jr = sh->jobs[nj];
+							jr.off = woff; jr.nd = n; jr.apod = a; jr.full = 1; jr.part = 0; jr.dshift = 0; jr.i0 = 0;
+							woff += (n + 3u) & ~1u;
+							sh->an_job[na] = (uint8_t)nj; sh->an_punch[na] = 0; sh->an_root[na] = (uint8_t)root; na++; nj++;
+							if(P.apod_kind[a] == FLACGPU_APOD_SUBDIVIDE_TUKEY) {
+								for(uint32_t b = 2; b <= P.apod_parts[a]; b++) {
+									if(n / b <= 32) continue;                       // :4349-4357
+									for(uint32_t pi = 0; pi < b; pi++) {
+										WindowJob &jp = sh->jobs[nj];
+										jp.off = woff; jp.nd = n / b; jp.apod = a; jp.full = 0;
+										jp.part = n / b / 2; jp.dshift = (pi * n) / b;   // :4361
+										jp.i0 = umin32(jp.part, n - jp.part - jp.dshift);
+										woff += (jp.nd + 3u) & ~1u;
+										sh->an_job[na] = (uint8_t)nj; sh->an_punch[na] = 0; sh->an_root[na] = (uint8_t)root; na++;
+										if(b >= 3) { sh->an_job[na] = (uint8_t)nj; sh->an_punch[na] = 1; sh->an_root[na] = (uint8_t)root; na++; }   // :4295-4308
+										nj++;
 									}
 								}
-								__syncthreads();
-								if(variant == 12) autoc_fma_12(wnd, nd, lag, sh->autoc, tid);
-								else if(variant == 0) autoc_small(wnd, nd, lag, sh->autoc, tid);
-								else autoc_fma_8_16(wnd, nd, variant, lag, sh->autoc, tid);
 							}
-							else {
-								if((uint32_t)tid < max_lpc) sh->autoc[tid] = sh->root[tid] - sh->autoc[tid];
+						}
+						sh->njobs = nj; sh->nanalyses = na;
+					}
+					__syncthreads();
+					const uint32_t njobs = sh->njobs, nan = sh->nanalyses;
+					// ---- windowing: out[i] = (float)x[i] * w[i] (lpc.c:68-94), all jobs ----------------
+					for(uint32_t jb = 0; jb < njobs; jb++) {
+						const WindowJob jbv = sh->jobs[jb];
+						const float *w = win + (size_t)jbv.apod * n;
+						float *o = wnd + jbv.off;
+						if(jbv.full) {
+							for(uint32_t i = (uint32_t)tid; i < n; i += TPB) o[i] = (float)sig[sigidx((int)i)] * w[i];
+						}
+						else {
+							const uint32_t part = jbv.part, dshift = jbv.dshift, i0 = jbv.i0;
+							for(uint32_t i = (uint32_t)tid; i <= i0 + part; i += TPB) {
+								float v = 0.0f;
+								bool wr = true;
+								if(i >= i0 && i < i0 + part) v = (float)sig[sigidx((int)(dshift + i))] * w[n - part + (i - i0)];
+								else if(i < part) v = (float)sig[sigidx((int)(dshift + i))] * w[i];
+								else if(!(i == i0 + part && i < n)) wr = false;
+								if(wr) o[i] = v;
 							}
-							// set_next_subdivide_tukey (stream_encoder.c:4293)
-							if(b == 2) { if(c == 0) c = 2; else { c = 0; b++; } }
-							else if(c < 2 * b - 1) c++;
-							else { c = 0; b++; }
-							if(b > parts) { a++; b = 1; c = 0; }
+						}
+					}
+					__syncthreads();
+					// ---- autocorrelation chains ---------------------------------------------------------
+					if(variant == 0) {
+						for(uint32_t t = (uint32_t)tid; t < njobs * lag; t += TPB) {
+							const uint32_t jb = t / lag, j = t - jb * lag;
+							sh->autoc_job[jb][j] = autoc_small(wnd + sh->jobs[jb].off, sh->jobs[jb].nd, j);
+						}
+					}
+					else {
+						const uint32_t cpj = 4 * lag, nchains = njobs * cpj;
+						for(uint32_t pass = 0; pass * TPB < nchains; pass++) {
+							// boustrophedon assignment: jobs are ordered long -> short, so reversing every other
+							// pass balances the per-lane chain length
+							const uint32_t c = (pass & 1) ? pass * TPB + (TPB - 1 - (uint32_t)tid) : pass * TPB + (uint32_t)tid;
+							if(c < nchains) {
+								const uint32_t jb = c / cpj, cj = c - jb * cpj, j = cj >> 2, l = cj & 3;
+								const float *d = wnd + sh->jobs[jb].off;
+								const uint32_t nd = sh->jobs[jb].nd;
+								sh->accs[c] = variant == 12 ? autoc_chain_12(d, nd, j, l) : autoc_chain_8_16(d, nd, variant, j, l);
+							}
 						}
 						__syncthreads();
-						if(!have) continue;
-						if(tid == 0) sh->cand_valid = lpc_model(sh->autoc, max_lpc, n, sbps, P.precision, &sh->cand);
-						__syncthreads();
-						if(sh->cand_valid) {
-							const uint32_t order = sh->cand.order, precision = sh->cand.precision;
-							const int shift = sh->cand.shift;
-							uint32_t po, koff;
-							const uint32_t rbits = eval_candidate<MAXORD>(sh, sig, n, order, sh->cand.q, shift, sh->cand.wide != 0, sbps, P, frame_max_po, frame_min_po, &po, &koff, tid);
-							const uint32_t est = sat_add_u32(hdr + 4 + 5 + order * (precision + sbps), rbits);
-							if(est > 0 && est < best_bits) {
-								best_type = 3; best_order = order; best_po = po; best_bits = est;
-								best_precision = precision; best_shift = shift;
-								for(uint32_t p = (uint32_t)tid; p < (1u << po); p += TPB) sh->kbest[p] = sh->kcand[koff + p];
-								if(tid < MAX_ORDER) sh->bestq[tid] = sh->cand.q[tid];
+						for(uint32_t t = (uint32_t)tid; t < njobs * lag; t += TPB) {
+							const uint32_t jb = t / lag, j = t - jb * lag;
+							sh->autoc_job[jb][j] = autoc_finish(wnd + sh->jobs[jb].off, sh->jobs[jb].nd, variant, j, &sh->accs[jb * cpj + j * 4]);
+						}
+					}
+					__syncthreads();
+					// ---- one lane per analysis: Levinson-Durbin, order guess, quantisation -----------------
+					if((uint32_t)tid < nan) {
+						const uint32_t jb = sh->an_job[tid], rt = sh->an_root[tid];
+						const bool punch = sh->an_punch[tid] != 0;
+						double av[MAXORD + 1];
+#pragma unroll
+						for(int j = 0; j <= MAXORD; j++) {
+							double v = 0.0;
+							if((uint32_t)j < lag) {
+								v = sh->autoc_job[jb][j];
+								// punch-out: root - partial for lags < max_order only; lag max_order keeps the
+								// partial's value (stream_encoder.c:4339-4340,4370-4371)
+								if(punch && (uint32_t)j < max_lpc) v = sh->autoc_job[rt][j] - v;
 							}
+							av[j] = v;
+						}
+						sh->cand_valid[tid] = lpc_model<MAXORD>(av, max_lpc, n, sbps, P.precision, &sh->cands[tid]);
+					}
+					__syncthreads();
+					// ---- candidates in the reference's order --------------------------------------------
+					for(uint32_t an = 0; an < nan; an++) {
+						if(!sh->cand_valid[an]) continue;
+						const Candidate *cd = &sh->cands[an];
+						const uint32_t order = cd->order, precision = cd->precision;
+						const int shift = cd->shift;
+						uint32_t po, koff;
+						const uint32_t rbits = eval_candidate<MAXORD>(sh, sig, n, order, cd->q, shift, cd->wide != 0, sbps, P, frame_max_po, frame_min_po, &po, &koff, tid);
+						const uint32_t est = sat_add_u32(hdr + 4 + 5 + order * (precision + sbps), rbits);
+						if(est > 0 && est < best_bits) {
+							best_type = 3; best_order = order; best_po = po; best_bits = est;
+							best_precision = precision; best_shift = shift;
+							for(uint32_t p = (uint32_t)tid; p < (1u << po); p += TPB) sh->kbest[p] = sh->kcand[koff + p];
+							if(tid < MAX_ORDER) sh->bestq[tid] = cd->q[tid];
 						}
 						__syncthreads();
 					}
