@@ -143,6 +143,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		}
 		if(nj > (uint32_t)MAX_JOBS || na > (uint32_t)MAX_ANALYSES) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
 		P.wnd_bytes = ((wfloats + 64) * 4 + 15) & ~15u;
+		P.max_jobs = nj ? nj : 1; P.max_analyses = na;
 	}
 	if(analyze_lds_bytes(P) > 160 * 1024 - 1024 || pack_lds_bytes(P) > 160 * 1024 - 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
 

@@ -27,7 +27,8 @@ struct DevParams {
 	uint32_t disable_constant, disable_fixed, disable_verbatim, limit_min_bitrate;
 	uint32_t slot_bytes;       // bytes reserved per frame in the slot buffer / LDS frame image
 	uint32_t sig_bytes;        // LDS bytes of the padded signal array
-	uint32_t wnd_bytes;        // LDS bytes of the windowed-signal array
+	uint32_t wnd_bytes;        // LDS bytes of the windowed-signal array (all window jobs of a subframe)
+	uint32_t max_jobs, max_analyses; // window jobs / LPC analyses per subframe at the nominal blocksize
 };
 
 // analysis -> pack hand-off, one per (frame, candidate channel); 16-byte multiple

@@ -224,43 +224,59 @@ __device__ int lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint
 // d = windowed data of the job in LDS, nd = its data_len.
 // ---------------------------------------------------------------------------------------------
 #define DD(k) ((double)d[k])
+// One lane runs NT chains at once: lags j0, j0+4, ..., for vector lane l.  They share the x samples and
+// their y samples are the same strided sequence shifted by one element per 4 lags, so a lane reads and
+// converts 4 floats per 8-sample step for NT chain steps (instead of 4 per chain step).
+//   X[m] = d[L + l + 4m],  Y[m] = d[L + l - j0 + 4m];  lag j0+4t at step k uses Y[2k-t], Y[2k+1-t].
 // body of lpc_intrin_fma.c:46,61 (lag 8 / lag 16): acc_l += fma(d[i],d[i-j], d[i+4]*d[i+4-j]), i = L+8k+l
-__device__ __forceinline__ double autoc_chain_8_16(const float *d, uint32_t nd, uint32_t L, uint32_t j, uint32_t l)
+template <int NT>
+__device__ __forceinline__ void autoc_chains_8_16(const float *d, uint32_t nd, uint32_t L, uint32_t j0, uint32_t l, double (&acc)[4])
 {
 	const uint32_t nb = (nd - L) / 8;
-	double acc = 0.0;
-	uint32_t i = L + l;
-#pragma unroll 4
-	for(uint32_t k = 0; k < nb; k++, i += 8)
-		acc += fma(DD(i), DD(i - j), DD(i + 4) * DD(i + 4 - j));
-	return acc;
+	const float *px = d + L + l, *py = px - j0;
+	double ym1 = NT > 1 ? (double)py[-4] : 0.0, ym2 = NT > 2 ? (double)py[-8] : 0.0, ym3 = NT > 3 ? (double)py[-12] : 0.0;
+	acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+#pragma unroll 2
+	for(uint32_t k = 0; k < nb; k++, px += 8, py += 8) {
+		const double x0 = (double)px[0], x1 = (double)px[4], y0 = (double)py[0], y1 = (double)py[4];
+		acc[0] += fma(x0, y0, x1 * y1);
+		if(NT > 1) acc[1] += fma(x0, ym1, x1 * y0);
+		if(NT > 2) acc[2] += fma(x0, ym2, x1 * ym1);
+		if(NT > 3) acc[3] += fma(x0, ym3, x1 * ym2);
+		ym3 = ym1; ym2 = y0; ym1 = y1;
+	}
 }
-// body of lpc_intrin_fma.c:54 (lag 12): 2x-unrolled by gcc, lag 8 factored x*y0+x*y2 -> x*(y0+y2)
-__device__ __forceinline__ double autoc_chain_12(const float *d, uint32_t nd, uint32_t j, uint32_t l)
+// body of lpc_intrin_fma.c:54 (lag 12): gcc unrolled the 8-sample body x2 (acc += t1+t0 per 16 samples) and,
+// for lag 8 only, factored x*y0+x*y2 -> x*(y0+y2) across the two halves.  Lags j0, j0+4, j0+8 per lane.
+__device__ __forceinline__ void autoc_chains_12(const float *d, uint32_t nd, uint32_t j0, uint32_t l, double (&acc)[4])
 {
 	const uint32_t L = 12;
 	const uint32_t nb = (nd - L) / 8;
 	const uint32_t npairs = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
-	double acc = 0.0;
-	uint32_t i = L + l, k = 0;
-	if(j == 8) {
-#pragma unroll 2
-		for(uint32_t p = 0; p < npairs; p++, k += 2, i += 16) {
-			const double x0 = DD(i), x1 = DD(i + 4), x2 = DD(i + 8), x3 = DD(i + 12), y0 = DD(i - 8), y1 = DD(i - 4);
-			acc += fma(x0, (y0 + x2), x1 * (y1 + x3));
-		}
+	const float *px = d + L + l, *py = px - j0;
+	double ym1 = (double)py[-4], ym2 = (double)py[-8];
+	acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+	uint32_t k = 0;
+	const bool lag8 = j0 == 0;       // this lane's third chain is lag 8
+	for(uint32_t p = 0; p < npairs; p++, k += 2, px += 16, py += 16) {
+		const double x0 = (double)px[0], x1 = (double)px[4], x2 = (double)px[8], x3 = (double)px[12];
+		const double y0 = (double)py[0], y1 = (double)py[4], y2 = (double)py[8], y3 = (double)py[12];
+		// lag j0: Y[2k..2k+3]
+		acc[0] += (fma(x2, y2, x3 * y3) + fma(x0, y0, x1 * y1));
+		// lag j0+4: Y[2k-1..2k+2]
+		acc[1] += (fma(x2, y1, x3 * y2) + fma(x0, ym1, x1 * y0));
+		// lag j0+8: Y[2k-2..2k+1]
+		if(lag8) acc[2] += fma(x0, (ym2 + x2), x1 * (ym1 + x3));
+		else acc[2] += (fma(x2, y0, x3 * y1) + fma(x0, ym2, x1 * ym1));
+		ym2 = y2; ym1 = y3;
 	}
-	else {
-#pragma unroll 2
-		for(uint32_t p = 0; p < npairs; p++, k += 2, i += 16) {
-			const double t0 = fma(DD(i), DD(i - j), DD(i + 4) * DD(i + 4 - j));
-			const double t1 = fma(DD(i + 8), DD(i + 8 - j), DD(i + 12) * DD(i + 12 - j));
-			acc += (t1 + t0);
-		}
+	for(; k < nb; k++, px += 8, py += 8) {
+		const double x0 = (double)px[0], x1 = (double)px[4], y0 = (double)py[0], y1 = (double)py[4];
+		acc[0] += fma(x0, y0, x1 * y1);
+		acc[1] += fma(x0, ym1, x1 * y0);
+		acc[2] += fma(x0, ym2, x1 * ym1);
+		ym2 = y0; ym1 = y1;
 	}
-	for(; k < nb; k++, i += 8)
-		acc += fma(DD(i), DD(i - j), DD(i + 4) * DD(i + 4 - j));
-	return acc;
 }
 // scalar head (samples j..L-1), lane combine and tail for lag j
 __device__ __forceinline__ double autoc_finish(const float *d, uint32_t nd, uint32_t L, uint32_t j, const double *acc4)
@@ -369,116 +385,175 @@ struct WindowJob {
 	uint32_t part, dshift, i0;
 };
 
-struct AnalyzeShared {
-	uint64_t sums[2u << MAX_PO];        // |residual| per partition at max_po, u64 (masked to 32 bits when the reference accumulates in 32)
-	uint64_t po_bits[MAX_PO + 1];
+// fixed-size part of the workgroup's LDS state; the large arrays are carved dynamically (analyze_layout)
+struct AnalyzeSmall {
 	uint64_t scratch[8];
-	double accs[MAX_JOBS * 4 * MAX_ORDER];       // lane accumulators of every chain
-	double autoc_job[MAX_JOBS][MAX_ORDER];       // finished autocorrelation per window job
+	uint64_t pob[TPB / 64][MAX_PO + 1];           // slow path: per-wave bit totals per partition order
+	uint32_t divtab[(MAX_PO + 1) * (MAX_ORDER + 1)]; // 0x40000 / ((n >> po) - order)
 	WindowJob jobs[MAX_JOBS];
 	uint8_t an_job[MAX_ANALYSES], an_punch[MAX_ANALYSES], an_root[MAX_ANALYSES];
+	int cand_valid[MAX_ANALYSES + 1];
 	uint32_t njobs, nanalyses;
-	Candidate cands[MAX_ANALYSES];
-	int cand_valid[MAX_ANALYSES];
-	Candidate fixedc;
-	int32_t bestq[MAX_ORDER];
-	uint8_t kcand[2u << MAX_PO];
-	uint8_t kbest[1u << MAX_PO];
+	uint32_t wbest_bits[TPB / 64], wbest_ci[TPB / 64], wbest_po[TPB / 64];
 };
 
-// Evaluate one residual candidate (fixed or LPC) with all threads.
-// Returns the estimated residual bits (find_best_partition_order_, stream_encoder.c:4701) and leaves
-// the Rice parameters of the best partition order in sh->kcand[ koff .. ), *best_po.
-template <int MAXORD>
-__device__ uint32_t eval_candidate(AnalyzeShared *sh, const int32_t *sig, uint32_t n, uint32_t order,
-                                   const int32_t *q, int shift, bool wide, uint32_t sbps,
-                                   const DevParams &P, uint32_t frame_max_po, uint32_t frame_min_po,
-                                   uint32_t *best_po_out, uint32_t *koff_out, int tid)
+struct AnalyzeLayout { uint32_t wsums, accs, autoc, cands, kbestw, kcandw, small, total; };
+__host__ __device__ inline AnalyzeLayout analyze_layout(const DevParams &P)
 {
-	// partition order limits for this predictor order (format.c:550)
-	uint32_t max_po = frame_max_po;
-	while(max_po > 0 && (n >> max_po) <= order) max_po--;
-	const uint32_t min_po = umin32(frame_min_po, max_po);
-	const uint32_t psize = n >> max_po;
-	const uint32_t nparts = 1u << max_po;
-	const bool narrow = (sbps + 4) < (32 - ilog2_u32(psize));   // stream_encoder.c:4814-4817
+	AnalyzeLayout L;
+	uint32_t o = P.sig_bytes + P.wnd_bytes;
+	L.wsums = o;  o += (TPB / 64) * (2u << P.max_po) * 8;                   // per-wave partition sums
+	L.accs = o;   o += P.max_jobs * (P.max_lpc_order + 1) * 4 * 8;          // chain accumulators
+	L.autoc = o;  o += P.max_jobs * MAX_ORDER * 8;                          // finished autocorrelations
+	L.cands = o;  o += (P.max_analyses + 1) * (uint32_t)sizeof(Candidate);  // [0] fixed, [1+a] LPC analysis a
+	L.kbestw = o; o += (TPB / 64) * 2 * (1u << P.max_po);                   // per wave: Rice parameters of its best candidate + scratch
+	L.kcandw = o; o += P.max_po > 6 ? (TPB / 64) * (2u << P.max_po) : 0;    // slow path only
+	o = (o + 15u) & ~15u;
+	L.small = o;  o += (uint32_t)sizeof(AnalyzeSmall);
+	L.total = (o + 15u) & ~15u;
+	return L;
+}
 
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)
+{
+	const uint32_t lo = __shfl_xor((uint32_t)v, mask), hi = __shfl_xor((uint32_t)(v >> 32), mask);
+	return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t sat_add_u32(uint32_t est, uint32_t rbits)
+{
+	return rbits < 0xffffffffu - est ? est + rbits : 0xffffffffu;
+}
+
+// One WAVEFRONT evaluates one residual candidate (fixed or LPC) without any workgroup barrier:
+// integer FIR out of LDS (lane owns S consecutive samples), |residual| per partition, the flat tree of
+// merged sums, Rice parameter and bit estimate per partition, best partition order
+// (find_best_partition_order_ / precompute_partition_info_sums_ / set_partitioned_rice_,
+// stream_encoder.c:4701-5075).  Returns the estimated residual bits; Rice parameters of the best
+// partition order go to kout[0 .. 2^best_po).
+template <int MAXORD>
+__device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_t *pob, uint8_t *kout, const uint32_t *divtab,
+                                        const int32_t *sig, uint32_t n, uint32_t order, const int32_t *q, int shift, bool wide,
+                                        uint32_t sbps, const DevParams &P, uint32_t frame_max_po, uint32_t frame_min_po,
+                                        uint32_t *best_po_out, int lane)
+{
+	uint32_t max_po = frame_max_po;
+	while(max_po > 0 && (n >> max_po) <= order) max_po--;                   // format.c:550
+	const uint32_t min_po = umin32(frame_min_po, max_po);
+	const uint32_t psize = n >> max_po, nparts = 1u << max_po;
+	const bool narrow = (sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
 	int32_t qr[MAXORD];
 #pragma unroll
 	for(int j = 0; j < MAXORD; j++) qr[j] = q[j];
-	for(uint32_t p = (uint32_t)tid; p < nparts; p += TPB) sh->sums[p] = 0;
-	if(tid <= MAX_PO) sh->po_bits[tid] = 0;
-	__syncthreads();
 
-	// residual -> |r| -> partition sums
-	for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * TPB) {
+	const uint32_t S = (((n + 63u) >> 6) + (CHUNK - 1)) & ~(uint32_t)(CHUNK - 1);  // samples per lane
+	const bool direct = psize == S;                                         // lane == leaf partition (4096 @ order 6)
+	if(!direct) {
+		for(uint32_t p = (uint32_t)lane; p < nparts; p += 64) wsums[p] = 0;
+		__builtin_amdgcn_wave_barrier();
+	}
+	uint64_t mine = 0;
+	for(uint32_t c = 0; c < S; c += CHUNK) {
+		const uint32_t base = (uint32_t)lane * S + c;
+		if(base >= n) break;
 		int32_t r[CHUNK];
 		fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, wide, r);
-		uint32_t part = base / psize;
-		uint32_t next = (part + 1) * psize;
-		uint64_t run = 0;
+		if(direct) {
 #pragma unroll
-		for(int s = 0; s < CHUNK; s++) {
-			const uint32_t i = base + s;
-			if(i == next) {
-				if(run) atomicAdd((unsigned long long *)&sh->sums[part], (unsigned long long)run);
-				run = 0; part++; next += psize;
-			}
-			if(i >= order && i < n) {
-				const int32_t v = r[s];
-				run += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v);
+			for(int s = 0; s < CHUNK; s++) {
+				const uint32_t i = base + s;
+				if(i >= order && i < n) { const int32_t v = r[s]; mine += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v); }
 			}
 		}
-		if(run && part < nparts) atomicAdd((unsigned long long *)&sh->sums[part], (unsigned long long)run);
+		else {
+			uint32_t part = base / psize, next = (part + 1) * psize;
+			uint64_t run = 0;
+#pragma unroll
+			for(int s = 0; s < CHUNK; s++) {
+				const uint32_t i = base + s;
+				if(i == next) {
+					if(run) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
+					run = 0; part++; next += psize;
+				}
+				if(i >= order && i < n) { const int32_t v = r[s]; run += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v); }
+			}
+			if(run && part < nparts) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
+		}
 	}
-	__syncthreads();
-
-	// every (partition order, partition) node: merged sum, Rice parameter, bit estimate
-	// node numbering: orders from max_po down to min_po, each with 2^po entries (the flat tree of
-	// precompute_partition_info_sums_, stream_encoder.c:4837-4851)
-	{
+	uint32_t best_bits = 0, best_po = 0;
+	if(max_po <= 6) {
+		// leaves in lanes 0..nparts-1, merged level by level with a butterfly; every lane of a group holds
+		// the group's sum, the group's first lane speaks for the partition
+		uint64_t v;
+		if(direct) v = mine;
+		else { __builtin_amdgcn_wave_barrier(); v = (uint32_t)lane < nparts ? wsums[lane] : 0; }
+		if(narrow) v = (uint32_t)v;
+		uint32_t klev[7];
+#pragma unroll
+		for(int d = 0; d <= 6; d++) {
+			klev[d] = 0;
+			if((uint32_t)d <= max_po - min_po) {
+				const uint32_t po = max_po - (uint32_t)d;
+				if(d > 0) v += shfl_xor_u64(v, 1 << (d - 1));
+				const uint32_t p = (uint32_t)lane >> d;
+				const bool rep = ((uint32_t)lane & ((1u << d) - 1u)) == 0 && (uint32_t)lane < nparts;
+				const uint32_t o = p == 0 ? order : 0;
+				const uint32_t ns = (n >> po) - o;
+				const uint32_t div = divtab[po * (MAX_ORDER + 1) + o];
+				uint32_t k;
+				if(v < 2 || (((v - 1) * div) >> 18) == 0) k = 0;
+				else k = ilog2_u64(((v - 1) * div) >> 18) + 1;
+				if(k >= P.rice_limit) k = P.rice_limit - 1;
+				uint64_t b = 4 + (uint64_t)(1 + k) * ns + (k ? (v >> (k - 1)) : (v << 1)) - (ns >> 1);
+				if(b > 0xffffffffull) b = 0xffffffffull;
+				klev[d] = k;
+				const uint64_t tot = 6 + wave_reduce_add_u64(rep ? b : 0);
+				const uint32_t bits = tot >= 0xffffffffull ? 0xffffffffu : (uint32_t)tot;
+				if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = po; }
+			}
+		}
+		const uint32_t db = max_po - best_po;
+		uint32_t kk = 0;
+#pragma unroll
+		for(int d = 0; d <= 6; d++) if((uint32_t)d == db) kk = klev[d];
+		if((((uint32_t)lane & ((1u << db) - 1u)) == 0) && (uint32_t)lane < nparts) kout[(uint32_t)lane >> db] = (uint8_t)kk;
+	}
+	else {
+		// partition orders 7/8: same computation through LDS (wave-private arrays)
+		__builtin_amdgcn_wave_barrier();
+		if(lane <= MAX_PO) pob[lane] = 0;
+		__builtin_amdgcn_wave_barrier();
 		uint32_t total_nodes = 0;
 		for(int po = (int)max_po; po >= (int)min_po; po--) total_nodes += 1u << po;
-		for(uint32_t node = (uint32_t)tid; node < total_nodes; node += TPB) {
+		for(uint32_t node = (uint32_t)lane; node < total_nodes; node += 64) {
 			uint32_t po = max_po, off = 0;
 			while(node - off >= (1u << po)) { off += 1u << po; po--; }
-			const uint32_t p = node - off;
-			const uint32_t nleaf = 1u << (max_po - po);
+			const uint32_t p = node - off, nleaf = 1u << (max_po - po);
 			uint64_t sum = 0;
-			for(uint32_t k = 0; k < nleaf; k++) {
-				uint64_t v = sh->sums[p * nleaf + k];
-				sum += narrow ? (uint64_t)(uint32_t)v : v;
-			}
-			uint32_t ns = n >> po;
-			if(p == 0) ns -= order;
-			const uint32_t div = 0x40000u / ns;
+			for(uint32_t k = 0; k < nleaf; k++) { const uint64_t t = wsums[p * nleaf + k]; sum += narrow ? (uint64_t)(uint32_t)t : t; }
+			const uint32_t o = p == 0 ? order : 0, ns = (n >> po) - o, div = divtab[po * (MAX_ORDER + 1) + o];
 			uint32_t k;
 			if(sum < 2 || (((sum - 1) * div) >> 18) == 0) k = 0;
 			else k = ilog2_u64(((sum - 1) * div) >> 18) + 1;
 			if(k >= P.rice_limit) k = P.rice_limit - 1;
 			uint64_t b = 4 + (uint64_t)(1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
 			if(b > 0xffffffffull) b = 0xffffffffull;
-			sh->kcand[node] = (uint8_t)k;
-			atomicAdd((unsigned long long *)&sh->po_bits[po], (unsigned long long)b);
+			kcand[node] = (uint8_t)k;
+			atomicAdd((unsigned long long *)&pob[po], (unsigned long long)b);
 		}
+		__builtin_amdgcn_wave_barrier();
+		uint32_t off = 0, best_off = 0;
+		for(int po = (int)max_po; po >= (int)min_po; po--) {
+			const uint64_t b = 6 + pob[po];
+			const uint32_t bits = b >= 0xffffffffull ? 0xffffffffu : (uint32_t)b;
+			if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = (uint32_t)po; best_off = off; }
+			off += 1u << po;
+		}
+		for(uint32_t p = (uint32_t)lane; p < (1u << best_po); p += 64) kout[p] = kcand[best_off + p];
 	}
-	__syncthreads();
-
-	uint32_t best_bits = 0, best_po = 0, best_off = 0, off = 0;
-	for(int po = (int)max_po; po >= (int)min_po; po--) {
-		uint64_t b = 6 + sh->po_bits[po];
-		uint32_t bits = b >= 0xffffffffull ? 0xffffffffu : (uint32_t)b;
-		if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = (uint32_t)po; best_off = off; }
-		off += 1u << po;
-	}
+	__builtin_amdgcn_wave_barrier();
 	*best_po_out = best_po;
-	*koff_out = best_off;
 	return best_bits;
-}
-
-__device__ __forceinline__ uint32_t sat_add_u32(uint32_t est, uint32_t rbits)
-{
-	return rbits < 0xffffffffu - est ? est + rbits : 0xffffffffu;
 }
 
 template <int MAXORD>
@@ -489,7 +564,7 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
                                                       SubDecision *__restrict__ decisions)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int tid = (int)threadIdx.x;
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t C = P.channels, N = P.blocksize;
 
 	// XCD-aware mapping: consecutive workgroup ids round-robin over the 8 XCDs; keep the candidate
@@ -503,22 +578,27 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 		if(b < head) { const uint32_t x = b & 7, k = b >> 3; lin = x * per_xcd_full + k; }
 		else lin = b;
 		f = lin / P.ncand; cand = lin % P.ncand;
-		(void)total;
 	}
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const uint32_t n = is_tail ? tail_n : N;
 	const float *win = is_tail ? tail_windows : windows;
 	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
 
+	const AnalyzeLayout LY = analyze_layout(P);
 	int32_t *sig = (int32_t *)smem;
 	float *wnd = (float *)(smem + P.sig_bytes);
-	AnalyzeShared *sh = (AnalyzeShared *)(smem + P.sig_bytes + P.wnd_bytes);
+	uint64_t *wsums_all = (uint64_t *)(smem + LY.wsums);
+	double *accs = (double *)(smem + LY.accs);
+	double *autoc_job = (double *)(smem + LY.autoc);
+	Candidate *cands = (Candidate *)(smem + LY.cands);
+	uint8_t *kbestw_all = smem + LY.kbestw;
+	uint8_t *kcandw_all = smem + LY.kcandw;
+	AnalyzeSmall *sh = (AnalyzeSmall *)(smem + LY.small);
 
 	SubDecision *dec = decisions + (size_t)f * P.ncand + cand;
 
 	// ---- which signal does this workgroup model? ----------------------------------------------
 	uint32_t which = cand;          // index into {ch0..chC-1, mid, side}
-	bool skip = false;              // loose mid/side: this pair not chosen -> nothing to do (never happens: grid only has the 2 chosen)
 	if(P.ms_mode == 2) {
 		// loose mid/side (stream_encoder.c:3778-3807): both workgroups of the frame compute the decision
 		uint64_t lr = 0, ms = 0;
@@ -533,7 +613,6 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 		ms = block_reduce_add_u64(ms, sh->scratch, tid);
 		if(!(lr < ms)) which = 2 + cand;   // mid, side
 	}
-	(void)skip;
 
 	// limit_min_bitrate (stream_encoder.c:3874-3879): the last independent channel (and then mid/side)
 	// may not be CONSTANT when every earlier channel is
@@ -558,6 +637,12 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 	}
 	const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
 	const uint32_t hdr = 8 + wasted;
+	// reciprocal table of set_partitioned_rice_ (stream_encoder.c:4997,5009)
+	for(uint32_t t = (uint32_t)tid; t < (MAX_PO + 1) * (MAX_ORDER + 1); t += TPB) {
+		const uint32_t po = t / (MAX_ORDER + 1), o = t - po * (MAX_ORDER + 1);
+		const uint32_t ps = n >> po;
+		sh->divtab[t] = ps > o ? 0x40000u / (ps - o) : 0;
+	}
 	__syncthreads();
 
 	// partition order limits of the frame (stream_encoder.c:3759-3761)
@@ -566,11 +651,14 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 	frame_max_po = umin32(frame_max_po, P.max_po);
 	const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
 
-	// ---- running best (uniform across the workgroup) -------------------------------------------
-	uint32_t best_type = 1, best_order = 0, best_po = 0, best_precision = 0;
+	// ---- baseline: VERBATIM (stream_encoder.c:4081-4086) ------------------------------------------
+	uint32_t best_type = 1, best_order = 0, best_po = 0, best_precision = 0, best_ci = 0, best_wave = 0;
 	int32_t best_shift = 0;
 	int32_t best_constant = 0;
 	uint32_t best_bits = (P.disable_verbatim && n >= 4) ? 0xffffffffu : hdr + n * sbps;
+	uint32_t nan = 0;               // LPC analyses
+	bool fixed_valid = false;
+	uint32_t fixed_order = 0;
 
 	if(n > 4) {
 		// ---- fixed predictor estimate (fixed.c:222 / fixed_intrin_avx2.c:57) ----------------------
@@ -626,34 +714,25 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 			if(bits < best_bits) { best_type = 0; best_constant = sig[sigidx(0)]; best_bits = bits; }
 		}
 		else {
-			// ---- FIXED candidate (stream_encoder.c:4153-4196, 4489) --------------------------------
+			// ---- FIXED candidate (stream_encoder.c:4153-4196, 4489): the same FIR with binomial taps ----
 			if(!P.disable_fixed || (P.max_lpc_order == 0 && best_bits == 0xffffffffu)) {
-				const uint32_t order = guess_fixed;   // n > 4 so order <= n-1
-				if(!(rbps_guess >= (float)sbps)) {
-					if(tid < MAX_ORDER) {
-						int32_t c = 0;
-						if(order == 1) c = tid == 0 ? 1 : 0;
-						else if(order == 2) c = tid == 0 ? 2 : tid == 1 ? -1 : 0;
-						else if(order == 3) c = tid == 0 ? 3 : tid == 1 ? -3 : tid == 2 ? 1 : 0;
-						else if(order == 4) c = tid == 0 ? 4 : tid == 1 ? -6 : tid == 2 ? 4 : tid == 3 ? -1 : 0;
-						sh->fixedc.q[tid] = c;
-					}
-					__syncthreads();
-					uint32_t po, koff;
-					const uint32_t rbits = eval_candidate<MAXORD>(sh, sig, n, order, sh->fixedc.q, 0, false, sbps, P, frame_max_po, frame_min_po, &po, &koff, tid);
-					const uint32_t est = sat_add_u32(hdr + order * sbps, rbits);
-					if(est < best_bits) {
-						best_type = 2; best_order = order; best_po = po; best_bits = est;
-						for(uint32_t p = (uint32_t)tid; p < (1u << po); p += TPB) sh->kbest[p] = sh->kcand[koff + p];
-					}
-					__syncthreads();
+				fixed_order = guess_fixed;   // n > 4 so order <= n-1
+				fixed_valid = !(rbps_guess >= (float)sbps);
+				if(fixed_valid && tid < MAX_ORDER) {
+					const uint32_t order = fixed_order;
+					int32_t c = 0;
+					if(order == 1) c = tid == 0 ? 1 : 0;
+					else if(order == 2) c = tid == 0 ? 2 : tid == 1 ? -1 : 0;
+					else if(order == 3) c = tid == 0 ? 3 : tid == 1 ? -3 : tid == 2 ? 1 : 0;
+					else if(order == 4) c = tid == 0 ? 4 : tid == 1 ? -6 : tid == 2 ? 4 : tid == 3 ? -1 : 0;
+					cands[0].q[tid] = c;
 				}
 			}
-			// ---- LPC candidates (stream_encoder.c:4199-4275; apply_apodization_ :4318-4392) ----------
+			// ---- LPC analyses (stream_encoder.c:4199-4275; apply_apodization_ :4318-4392) --------------
 			// The reference walks its apodization state machine sequentially; every step is a pure
-			// function of the block, so here all window jobs are windowed and autocorrelated at once,
-			// all analyses are modelled at once (one lane each), and the candidates are then compared
-			// in the reference's order with its strict '<'.
+			// function of the block, so here all window jobs are windowed and autocorrelated at once, all
+			// analyses are modelled at once (one lane each) and all candidates are evaluated concurrently
+			// (one wavefront each); the winner is the first minimum in the reference's order (its strict '<').
 			if(P.max_lpc_order > 0) {
 				const uint32_t max_lpc = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
 				const uint32_t variant = n <= 32 ? 0u : P.autoc_variant;
@@ -686,7 +765,8 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 						sh->njobs = nj; sh->nanalyses = na;
 					}
 					__syncthreads();
-					const uint32_t njobs = sh->njobs, nan = sh->nanalyses;
+					const uint32_t njobs = sh->njobs;
+					nan = sh->nanalyses;
 					// ---- windowing: out[i] = (float)x[i] * w[i] (lpc.c:68-94), all jobs ----------------
 					for(uint32_t jb = 0; jb < njobs; jb++) {
 						const WindowJob jbv = sh->jobs[jb];
@@ -708,30 +788,32 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 						}
 					}
 					__syncthreads();
-					// ---- autocorrelation chains ---------------------------------------------------------
+					// ---- autocorrelation: 16 lanes per job, each running up to 4 lag chains -------------
 					if(variant == 0) {
 						for(uint32_t t = (uint32_t)tid; t < njobs * lag; t += TPB) {
 							const uint32_t jb = t / lag, j = t - jb * lag;
-							sh->autoc_job[jb][j] = autoc_small(wnd + sh->jobs[jb].off, sh->jobs[jb].nd, j);
+							autoc_job[jb * MAX_ORDER + j] = autoc_small(wnd + sh->jobs[jb].off, sh->jobs[jb].nd, j);
 						}
 					}
 					else {
-						const uint32_t cpj = 4 * lag, nchains = njobs * cpj;
-						for(uint32_t pass = 0; pass * TPB < nchains; pass++) {
-							// boustrophedon assignment: jobs are ordered long -> short, so reversing every other
-							// pass balances the per-lane chain length
-							const uint32_t c = (pass & 1) ? pass * TPB + (TPB - 1 - (uint32_t)tid) : pass * TPB + (uint32_t)tid;
-							if(c < nchains) {
-								const uint32_t jb = c / cpj, cj = c - jb * cpj, j = cj >> 2, l = cj & 3;
-								const float *d = wnd + sh->jobs[jb].off;
-								const uint32_t nd = sh->jobs[jb].nd;
-								sh->accs[c] = variant == 12 ? autoc_chain_12(d, nd, j, l) : autoc_chain_8_16(d, nd, variant, j, l);
+						for(uint32_t t = (uint32_t)tid; t < njobs * 16; t += TPB) {
+							const uint32_t jb = t >> 4, l = t & 3, j0 = (t >> 2) & 3;
+							const float *d = wnd + sh->jobs[jb].off;
+							const uint32_t nd = sh->jobs[jb].nd;
+							double acc[4];
+							if(variant == 12) autoc_chains_12(d, nd, j0, l, acc);
+							else if(variant == 8) autoc_chains_8_16<2>(d, nd, 8, j0, l, acc);
+							else autoc_chains_8_16<4>(d, nd, 16, j0, l, acc);
+#pragma unroll
+							for(int k = 0; k < 4; k++) {
+								const uint32_t j = j0 + 4 * (uint32_t)k;
+								if(j < lag) accs[(jb * lag + j) * 4 + l] = acc[k];
 							}
 						}
 						__syncthreads();
 						for(uint32_t t = (uint32_t)tid; t < njobs * lag; t += TPB) {
 							const uint32_t jb = t / lag, j = t - jb * lag;
-							sh->autoc_job[jb][j] = autoc_finish(wnd + sh->jobs[jb].off, sh->jobs[jb].nd, variant, j, &sh->accs[jb * cpj + j * 4]);
+							autoc_job[jb * MAX_ORDER + j] = autoc_finish(wnd + sh->jobs[jb].off, sh->jobs[jb].nd, variant, j, &accs[(jb * lag + j) * 4]);
 						}
 					}
 					__syncthreads();
@@ -744,52 +826,78 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 						for(int j = 0; j <= MAXORD; j++) {
 							double v = 0.0;
 							if((uint32_t)j < lag) {
-								v = sh->autoc_job[jb][j];
+								v = autoc_job[jb * MAX_ORDER + j];
 								// punch-out: root - partial for lags < max_order only; lag max_order keeps the
 								// partial's value (stream_encoder.c:4339-4340,4370-4371)
-								if(punch && (uint32_t)j < max_lpc) v = sh->autoc_job[rt][j] - v;
+								if(punch && (uint32_t)j < max_lpc) v = autoc_job[rt * MAX_ORDER + j] - v;
 							}
 							av[j] = v;
 						}
-						sh->cand_valid[tid] = lpc_model<MAXORD>(av, max_lpc, n, sbps, P.precision, &sh->cands[tid]);
-					}
-					__syncthreads();
-					// ---- candidates in the reference's order --------------------------------------------
-					for(uint32_t an = 0; an < nan; an++) {
-						if(!sh->cand_valid[an]) continue;
-						const Candidate *cd = &sh->cands[an];
-						const uint32_t order = cd->order, precision = cd->precision;
-						const int shift = cd->shift;
-						uint32_t po, koff;
-						const uint32_t rbits = eval_candidate<MAXORD>(sh, sig, n, order, cd->q, shift, cd->wide != 0, sbps, P, frame_max_po, frame_min_po, &po, &koff, tid);
-						const uint32_t est = sat_add_u32(hdr + 4 + 5 + order * (precision + sbps), rbits);
-						if(est > 0 && est < best_bits) {
-							best_type = 3; best_order = order; best_po = po; best_bits = est;
-							best_precision = precision; best_shift = shift;
-							for(uint32_t p = (uint32_t)tid; p < (1u << po); p += TPB) sh->kbest[p] = sh->kcand[koff + p];
-							if(tid < MAX_ORDER) sh->bestq[tid] = cd->q[tid];
-						}
-						__syncthreads();
+						sh->cand_valid[1 + tid] = lpc_model<MAXORD>(av, max_lpc, n, sbps, P.precision, &cands[1 + tid]);
 					}
 				}
 			}
 		}
 	}
+	if(tid == 0) {
+		sh->cand_valid[0] = fixed_valid ? 1 : 0;
+		if(fixed_valid) { cands[0].order = fixed_order; cands[0].precision = 0; cands[0].shift = 0; cands[0].wide = 0; }
+	}
+	__syncthreads();
+
+	// ---- candidates: one wavefront each, no workgroup barriers -------------------------------------
+	{
+		const uint32_t kstride = 1u << P.max_po;
+		uint64_t *wsums = wsums_all + (size_t)wave * (2u << P.max_po);
+		uint8_t *kbw = kbestw_all + (size_t)wave * 2 * kstride, *ktmp = kbw + kstride;
+		uint8_t *kcw = kcandw_all + (size_t)wave * (2u << P.max_po);
+		uint32_t wb_bits = 0xffffffffu, wb_ci = 0xffffffffu, wb_po = 0;
+		for(uint32_t ci = (uint32_t)wave; ci <= nan; ci += TPB / 64) {
+			if(!sh->cand_valid[ci]) continue;
+			const Candidate *cd = &cands[ci];
+			const uint32_t order = cd->order;
+			uint32_t po;
+			const uint32_t rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, sig, n, order, cd->q, cd->shift,
+			                                                   cd->wide != 0, sbps, P, frame_max_po, frame_min_po, &po, lane);
+			const uint32_t est = ci == 0 ? sat_add_u32(hdr + order * sbps, rbits)
+			                             : sat_add_u32(hdr + 4 + 5 + order * (cd->precision + sbps), rbits);
+			if(est > 0 && est < wb_bits) {      // strict: the earlier candidate keeps a tie (stream_encoder.c:4191,4266)
+				wb_bits = est; wb_ci = ci; wb_po = po;
+				for(uint32_t p = (uint32_t)lane; p < (1u << po); p += 64) kbw[p] = ktmp[p];
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+		if(lane == 0) { sh->wbest_bits[wave] = wb_bits; sh->wbest_ci[wave] = wb_ci; sh->wbest_po[wave] = wb_po; }
+	}
+	__syncthreads();
+	// ---- winner: first minimum in the reference's evaluation order ---------------------------------------
+	{
+		uint32_t cb = 0xffffffffu, cci = 0xffffffffu, cw = 0;
+		for(uint32_t w = 0; w < TPB / 64; w++) {
+			const uint32_t b = sh->wbest_bits[w], ci = sh->wbest_ci[w];
+			if(ci != 0xffffffffu && (b < cb || (b == cb && ci < cci))) { cb = b; cci = ci; cw = w; }
+		}
+		if(cci != 0xffffffffu && cb < best_bits) {
+			best_bits = cb; best_ci = cci; best_wave = cw; best_po = sh->wbest_po[cw];
+			best_type = cci == 0 ? 2 : 3;
+			best_order = cands[cci].order; best_precision = cands[cci].precision; best_shift = cands[cci].shift;
+		}
+	}
 	if(best_bits == 0xffffffffu) { best_type = 1; best_bits = hdr + n * sbps; }   // stream_encoder.c:4281
 
 	// ---- decision record ---------------------------------------------------------------------------
-	__syncthreads();
 	uint32_t rice2 = 0;
 	if(best_type >= 2) {
+		const uint8_t *kb = kbestw_all + (size_t)best_wave * 2 * (1u << P.max_po);
 		uint32_t big = 0;
 		for(uint32_t p = (uint32_t)tid; p < (1u << best_po); p += TPB) {
-			const uint8_t k = sh->kbest[p];
+			const uint8_t k = kb[p];
 			dec->params[p] = k;
 			if(k >= 15) big = 1;
 		}
 		rice2 = block_reduce_or_u32(big, sh->scratch, tid);   // stream_encoder.c:4786-4791
 	}
-	if(tid < MAX_ORDER) dec->q[tid] = best_type == 3 ? sh->bestq[tid] : 0;
+	if(tid < MAX_ORDER) dec->q[tid] = best_type == 3 ? cands[best_ci].q[tid] : 0;
 	if(tid == 0) {
 		dec->bits = best_bits;
 		dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
@@ -1224,7 +1332,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *pcm, uint32_t
 }
 
 namespace flacgpu {
-size_t analyze_lds_bytes(const DevParams &P) { return (size_t)P.sig_bytes + P.wnd_bytes + sizeof(AnalyzeShared); }
+size_t analyze_lds_bytes(const DevParams &P) { return analyze_layout(P).total; }
 size_t pack_lds_bytes(const DevParams &P) { return (size_t)P.sig_bytes + P.slot_bytes + sizeof(PackShared); }
 
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
