@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 #include <new>
 #include "flacgpu.h"
 #include "flacgpu_dev.h"
@@ -32,9 +33,55 @@ struct flacgpu_ctx {
 	size_t d_pcm_bytes, d_out_bytes;
 	uint32_t last_nframes;
 	bool timing_valid;
+	JobTable h_jobtab[2];        // [0] nominal blocksize, [1] the short last block of the current batch
+	JobTable *d_jobtab;          // device copies of both
+	unsigned long long *d_dbg;   // FLACGPU_DEBUG_TIMING=1: per-workgroup phase stamps of analyze_kernel
 };
 
-static int ilog2u(uint32_t v) { int r = -1; while(v) { r++; v >>= 1; } return r; }
+namespace flacgpu {
+// The apply_apodization_ state machine (stream_encoder.c:4293-4392) unrolled into a static schedule.
+void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
+{
+	memset(jt, 0, sizeof *jt);
+	uint32_t nj = 0, na = 0, woff = 0;
+	for(uint32_t a = 0; a < P.num_apod; a++) {
+		const uint32_t root = nj;
+		WindowJob &jr = jt->jobs[nj];
+		jr.off = woff; jr.nd = n; jr.apod = a; jr.full = 1;
+		woff += (n + 3u) & ~1u;
+		jt->an_job[na] = (uint8_t)nj; jt->an_punch[na] = 0; jt->an_root[na] = (uint8_t)root; na++; nj++;
+		if(P.apod_kind[a] == FLACGPU_APOD_SUBDIVIDE_TUKEY) {
+			for(uint32_t b = 2; b <= P.apod_parts[a]; b++) {
+				if(n / b <= 32) continue;                               /* :4349-4357 */
+				for(uint32_t pi = 0; pi < b; pi++) {
+					if(nj >= (uint32_t)MAX_JOBS || na + 2 > (uint32_t)MAX_ANALYSES) continue;   /* create() rejects such configs */
+					WindowJob &jp = jt->jobs[nj];
+					jp.off = woff; jp.nd = n / b; jp.apod = a; jp.full = 0;
+					jp.part = n / b / 2; jp.dshift = (pi * n) / b;      /* :4361 */
+					jp.i0 = jp.part < n - jp.part - jp.dshift ? jp.part : n - jp.part - jp.dshift;
+					woff += (jp.nd + 3u) & ~1u;
+					jt->an_job[na] = (uint8_t)nj; jt->an_punch[na] = 0; jt->an_root[na] = (uint8_t)root; na++;
+					if(b >= 3) { jt->an_job[na] = (uint8_t)nj; jt->an_punch[na] = 1; jt->an_root[na] = (uint8_t)root; na++; }   /* :4295-4308 */
+					nj++;
+				}
+			}
+		}
+	}
+	jt->njobs = nj; jt->nanalyses = na; jt->wnd_floats = woff;
+	// longest job first onto the least loaded wavefront (one job = 64 chains = one wavefront pass)
+	uint32_t load[TPB / 64] = {0};
+	bool done[MAX_JOBS] = {false};
+	for(uint32_t it = 0; it < nj; it++) {
+		uint32_t best = 0, bl = 0; bool have = false;
+		for(uint32_t k = 0; k < nj; k++) if(!done[k] && (!have || jt->jobs[k].nd > bl)) { best = k; bl = jt->jobs[k].nd; have = true; }
+		done[best] = true;
+		uint32_t w = 0;
+		for(uint32_t k = 1; k < TPB / 64; k++) if(load[k] < load[w]) w = k;
+		jt->wave_jobs[w][jt->wave_njobs[w]++] = (uint8_t)best;
+		load[w] += bl;
+	}
+}
+}
 
 extern "C" const char *flacgpu_strerror(int code)
 {
@@ -71,6 +118,8 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->d_info) (void)hipFree(c->d_info);
 	if(c->d_pcm) (void)hipFree(c->d_pcm);
 	if(c->d_out) (void)hipFree(c->d_out);
+	if(c->d_dbg) (void)hipFree(c->d_dbg);
+	if(c->d_jobtab) (void)hipFree(c->d_jobtab);
 	for(int i = 0; i < 5; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -132,17 +181,15 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		P.sig_bytes = ((maxidx + ((maxidx >> 4) << 1) + 8) * 4 + 15) & ~15u;
 		// window jobs of one subframe (same enumeration as analyze_kernel): all of them are windowed
 		// into LDS at once so that their autocorrelation chains run concurrently
-		uint32_t nj = 0, na = 0, wfloats = 0;
+		uint32_t nj = 0, na = 0;
 		for(uint32_t a = 0; a < P.num_apod; a++) {
-			nj++; na++; wfloats += (N + 3u) & ~1u;
+			nj++; na++;
 			if(P.apod_kind[a] == FLACGPU_APOD_SUBDIVIDE_TUKEY)
-				for(uint32_t b = 2; b <= P.apod_parts[a]; b++) {
-					if(N / b <= 32) continue;
-					nj += b; na += b >= 3 ? 2 * b : b; wfloats += b * ((N / b + 3u) & ~1u);
-				}
+				for(uint32_t b = 2; b <= P.apod_parts[a]; b++) { if(N / b <= 32) continue; nj += b; na += b >= 3 ? 2 * b : b; }
 		}
 		if(nj > (uint32_t)MAX_JOBS || na > (uint32_t)MAX_ANALYSES) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
-		P.wnd_bytes = ((wfloats + 64) * 4 + 15) & ~15u;
+		build_job_table(P, N, &c->h_jobtab[0]);
+		P.wnd_bytes = ((c->h_jobtab[0].wnd_floats + 64) * 4 + 15) & ~15u;
 		P.max_jobs = nj ? nj : 1; P.max_analyses = na;
 	}
 	if(analyze_lds_bytes(P) > 160 * 1024 - 1024 || pack_lds_bytes(P) > 160 * 1024 - 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
@@ -160,7 +207,10 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	ok = ok && hipMalloc(&c->d_offsets, (B + 1) * sizeof(uint64_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_total, sizeof(uint64_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_info, B * sizeof(FrameInfo)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_jobtab, 2 * sizeof(JobTable)) == hipSuccess;
+	ok = ok && hipMemcpy(c->d_jobtab, c->h_jobtab, sizeof(JobTable), hipMemcpyHostToDevice) == hipSuccess;
 	if(ok && P.num_apod) ok = hipMemcpy(c->d_windows, windows, wbytes, hipMemcpyHostToDevice) == hipSuccess;
+	if(ok && getenv("FLACGPU_DEBUG_TIMING")) { ok = hipMalloc(&c->d_dbg, B * P.ncand * 16 * sizeof(unsigned long long)) == hipSuccess; if(ok) (void)hipMemset(c->d_dbg, 0, B * P.ncand * 16 * sizeof(unsigned long long)); }
 	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
 	*out = c;
 	return FLACGPU_OK;
@@ -181,12 +231,28 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	if(tail_n >= c->P.blocksize) tail_n = 0;
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	const DevParams &P = c->P;
+	if(tail_n) {
+		build_job_table(P, tail_n, &c->h_jobtab[1]);
+		if(hipMemcpyAsync(c->d_jobtab + 1, &c->h_jobtab[1], sizeof(JobTable), hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	}
 	if(tail_n && P.num_apod) {
 		if(!tail_windows_host) return FLACGPU_ERR_BAD_ARG;
 		if(hipMemcpyAsync(c->d_tail_windows, tail_windows_host, (size_t)P.num_apod * tail_n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
 	(void)hipEventRecord(c->ev[0], s);
-	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_decisions, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->d_decisions, c->d_dbg, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(c->d_dbg) {
+		// development aid: average cycles per phase over all workgroups of this launch
+		const size_t nwg = (size_t)nframes * P.ncand;
+		unsigned long long *h = (unsigned long long *)malloc(nwg * 16 * sizeof(unsigned long long));
+		if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, c->d_dbg, nwg * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+			double acc[8] = {0};
+			for(size_t w = 0; w < nwg; w++) for(int k = 1; k < 8; k++) if(h[w * 16 + k] && h[w * 16 + k - 1]) acc[k] += (double)(h[w * 16 + k] - h[w * 16 + k - 1]);
+			fprintf(stderr, "[flacgpu] analyze phases (avg s_memtime ticks/WG): load+wasted %.0f  fixed %.0f  const+jobs+window %.0f  autoc %.0f  model %.0f  candidates %.0f  decide %.0f\n",
+			        acc[1] / nwg, acc[2] / nwg, acc[3] / nwg, acc[4] / nwg, acc[5] / nwg, acc[6] / nwg, acc[7] / nwg);
+		}
+		free(h);
+	}
 	(void)hipEventRecord(c->ev[1], s);
 	if(launch_pack(P, d_pcm, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	(void)hipEventRecord(c->ev[2], s);

@@ -50,6 +50,27 @@ struct Candidate {
 	int32_t q[MAX_ORDER];
 };
 
+// One windowed-data job of a subframe's LPC analysis (apply_apodization_, stream_encoder.c:4318-4392):
+// the whole block under window table `apod`, or one partial window of a subdivide_tukey depth.
+struct WindowJob {
+	uint32_t off;       // float offset of this job's windowed data in the LDS window buffer
+	uint32_t nd;        // data_len handed to the autocorrelation
+	uint32_t apod;      // which window table
+	uint32_t full;      // 1: whole block (lpc.c:68), 0: partial window (lpc.c:82)
+	uint32_t part, dshift, i0;
+	uint32_t pad;
+};
+// Host-built schedule for one blocksize: jobs, the analyses derived from them in the reference's order
+// (full, then per depth: partial [, punch-out]), and a longest-first assignment of jobs to wavefronts.
+struct JobTable {
+	uint32_t njobs, nanalyses, wnd_floats, pad;
+	WindowJob jobs[MAX_JOBS];
+	uint8_t an_job[MAX_ANALYSES], an_punch[MAX_ANALYSES], an_root[MAX_ANALYSES];
+	uint8_t wave_njobs[TPB / 64];
+	uint8_t wave_jobs[TPB / 64][MAX_JOBS];
+};
+void build_job_table(const DevParams &P, uint32_t n, JobTable *jt);
+
 struct FrameInfo {
 	flacgpu_subframe_info sub[FLACGPU_MAX_CHANNELS];
 	uint8_t channel_assignment;
@@ -59,7 +80,8 @@ struct FrameInfo {
 size_t analyze_lds_bytes(const DevParams &P);
 size_t pack_lds_bytes(const DevParams &P);
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
-                          uint32_t nframes, uint32_t tail_n, SubDecision *dec, hipStream_t s);
+                          uint32_t nframes, uint32_t tail_n, const JobTable *jt_main, const JobTable *jt_tail, SubDecision *dec,
+                          unsigned long long *dbg, hipStream_t s);
 hipError_t launch_pack(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, hipStream_t s);
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);

@@ -100,8 +100,8 @@ __device__ __forceinline__ double expected_bits_scaled(double lpc_error, double 
 
 // One Levinson-Durbin recursion up to `upto` orders (lpc.c:188-217). lpc[] / errs[] live in registers.
 // Returns the number of orders actually produced (stops early when err == 0, lpc.c:213).
-template <int MAXORD>
-__device__ __forceinline__ uint32_t levinson(const double (&a)[MAXORD + 1], uint32_t upto, double (&lpc)[MAXORD], double (&errs)[MAXORD])
+template <int MAXORD, bool ROWS>
+__device__ __forceinline__ uint32_t levinson(const double (&a)[MAXORD + 1], uint32_t upto, double (&lpc)[MAXORD], double (&errs)[MAXORD], float *rows)
 {
 	double err = a[0];
 	uint32_t used = upto;
@@ -122,24 +122,30 @@ __device__ __forceinline__ uint32_t levinson(const double (&a)[MAXORD + 1], uint
 			if(i & 1) lpc[i >> 1] = (r + 1.0) * lpc[i >> 1];   // compiled form of lpc[j] += lpc[j]*r
 			err *= (1.0 - r * r);
 			errs[i] = err;
+			if(ROWS) {
+				// lp_coeff[i][0..i] of lpc.c:208-209, kept so that the guessed order needs no second pass
+#pragma unroll
+				for(int j = 0; j <= i; j++) rows[i * MAXORD + j] = (float)(-lpc[j]);
+			}
 			if(err == 0.0) used = (uint32_t)i + 1;
 		}
 	}
 	return used;
 }
 
-// autoc: lag values of this analysis (already punched-out when applicable). Returns 0 when no LPC
-// candidate results (autoc[0]==0, estimate >= bps, quantiser failure, residual would need the
-// >32-bit "limit_residual" flavour).
+// autoc: lag values of this analysis (already punched-out when applicable). rows: MAXORD*MAXORD floats of
+// LDS scratch private to this lane, or null (then the recursion is simply run twice). Returns 0 when no LPC
+// candidate results (autoc[0]==0, estimate >= bps, quantiser failure, residual would need the >32-bit
+// "limit_residual" flavour).
 template <int MAXORD>
 __device__ int lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint32_t n, uint32_t sbps,
-                         uint32_t cfg_precision, Candidate *out)
+                         uint32_t cfg_precision, float *rows, Candidate *out)
 {
 	double lpc[MAXORD], errs[MAXORD];
 	if(a[0] == 0.0) return 0;
 #pragma unroll
 	for(int i = 0; i < MAXORD; i++) { lpc[i] = 0.0; errs[i] = 0.0; }
-	const uint32_t used = levinson<MAXORD>(a, max_order, lpc, errs);
+	const uint32_t used = rows ? levinson<MAXORD, true>(a, max_order, lpc, errs, rows) : levinson<MAXORD, false>(a, max_order, lpc, errs, rows);
 	// FLAC__lpc_compute_best_order (lpc.c:1608): total_samples is the full blocksize
 	uint32_t order = 1;
 	double err_order = errs[0];
@@ -158,11 +164,17 @@ __device__ int lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint
 	}
 	// stream_encoder.c:4227-4229
 	if(expected_bits_scaled(err_order, 0.5 / (double)(n - order)) >= (double)sbps) return 0;
-	// coefficients of `order`: rerun the (deterministic) recursion up to that order
-	(void)levinson<MAXORD>(a, order, lpc, errs);
 	float coef[MAXORD];
+	if(rows) {
 #pragma unroll
-	for(int j = 0; j < MAXORD; j++) coef[j] = (uint32_t)j < order ? (float)(-lpc[j]) : 0.0f;
+		for(int j = 0; j < MAXORD; j++) coef[j] = (uint32_t)j < order ? rows[(order - 1) * MAXORD + j] : 0.0f;
+	}
+	else {
+		// coefficients of `order`: rerun the (deterministic) recursion up to that order
+		(void)levinson<MAXORD, false>(a, order, lpc, errs, rows);
+#pragma unroll
+		for(int j = 0; j < MAXORD; j++) coef[j] = (uint32_t)j < order ? (float)(-lpc[j]) : 0.0f;
+	}
 	// stream_encoder.c:4591-4595 then FLAC__lpc_quantize_coefficients (lpc.c:220)
 	uint32_t precision = cfg_precision;
 	if(sbps <= 17) precision = umin32(precision, 32 - sbps - ilog2_u32(order));
@@ -224,59 +236,71 @@ __device__ int lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint
 // d = windowed data of the job in LDS, nd = its data_len.
 // ---------------------------------------------------------------------------------------------
 #define DD(k) ((double)d[k])
-// One lane runs NT chains at once: lags j0, j0+4, ..., for vector lane l.  They share the x samples and
-// their y samples are the same strided sequence shifted by one element per 4 lags, so a lane reads and
-// converts 4 floats per 8-sample step for NT chain steps (instead of 4 per chain step).
-//   X[m] = d[L + l + 4m],  Y[m] = d[L + l - j0 + 4m];  lag j0+4t at step k uses Y[2k-t], Y[2k+1-t].
+// One lane per chain (window job, lag j, vector lane l); a wavefront holds all 64 chains of one job, so its
+// LDS reads are broadcasts (x) or a run of <= 19 consecutive words (y): conflict free.  The loads of several
+// steps are issued together so LDS latency overlaps the fp64 work of the previous steps.
 // body of lpc_intrin_fma.c:46,61 (lag 8 / lag 16): acc_l += fma(d[i],d[i-j], d[i+4]*d[i+4-j]), i = L+8k+l
-template <int NT>
-__device__ __forceinline__ void autoc_chains_8_16(const float *d, uint32_t nd, uint32_t L, uint32_t j0, uint32_t l, double (&acc)[4])
+__device__ __forceinline__ double autoc_chain_8_16(const float *d, uint32_t nd, uint32_t L, uint32_t j, uint32_t l)
 {
 	const uint32_t nb = (nd - L) / 8;
-	const float *px = d + L + l, *py = px - j0;
-	double ym1 = NT > 1 ? (double)py[-4] : 0.0, ym2 = NT > 2 ? (double)py[-8] : 0.0, ym3 = NT > 3 ? (double)py[-12] : 0.0;
-	acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
-#pragma unroll 2
-	for(uint32_t k = 0; k < nb; k++, px += 8, py += 8) {
-		const double x0 = (double)px[0], x1 = (double)px[4], y0 = (double)py[0], y1 = (double)py[4];
-		acc[0] += fma(x0, y0, x1 * y1);
-		if(NT > 1) acc[1] += fma(x0, ym1, x1 * y0);
-		if(NT > 2) acc[2] += fma(x0, ym2, x1 * ym1);
-		if(NT > 3) acc[3] += fma(x0, ym3, x1 * ym2);
-		ym3 = ym1; ym2 = y0; ym1 = y1;
+	const float *px = d + L + l, *py = px - j;
+	double acc = 0.0;
+	uint32_t k = 0;
+	for(; k + 4 <= nb; k += 4, px += 32, py += 32) {
+		float x[8], y[8];
+#pragma unroll
+		for(int u = 0; u < 8; u++) { x[u] = px[4 * u]; y[u] = py[4 * u]; }
+#pragma unroll
+		for(int u = 0; u < 4; u++)
+			acc += fma((double)x[2 * u], (double)y[2 * u], (double)x[2 * u + 1] * (double)y[2 * u + 1]);
 	}
+	for(; k < nb; k++, px += 8, py += 8)
+		acc += fma((double)px[0], (double)py[0], (double)px[4] * (double)py[4]);
+	return acc;
 }
 // body of lpc_intrin_fma.c:54 (lag 12): gcc unrolled the 8-sample body x2 (acc += t1+t0 per 16 samples) and,
-// for lag 8 only, factored x*y0+x*y2 -> x*(y0+y2) across the two halves.  Lags j0, j0+4, j0+8 per lane.
-__device__ __forceinline__ void autoc_chains_12(const float *d, uint32_t nd, uint32_t j0, uint32_t l, double (&acc)[4])
+// for lag 8 only, factored x*y0+x*y2 -> x*(y0+y2) across the two halves (y2 == x0 of the next half there)
+__device__ __forceinline__ double autoc_chain_12(const float *d, uint32_t nd, uint32_t j, uint32_t l)
 {
 	const uint32_t L = 12;
 	const uint32_t nb = (nd - L) / 8;
 	const uint32_t npairs = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
-	const float *px = d + L + l, *py = px - j0;
-	double ym1 = (double)py[-4], ym2 = (double)py[-8];
-	acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
-	uint32_t k = 0;
-	const bool lag8 = j0 == 0;       // this lane's third chain is lag 8
-	for(uint32_t p = 0; p < npairs; p++, k += 2, px += 16, py += 16) {
-		const double x0 = (double)px[0], x1 = (double)px[4], x2 = (double)px[8], x3 = (double)px[12];
-		const double y0 = (double)py[0], y1 = (double)py[4], y2 = (double)py[8], y3 = (double)py[12];
-		// lag j0: Y[2k..2k+3]
-		acc[0] += (fma(x2, y2, x3 * y3) + fma(x0, y0, x1 * y1));
-		// lag j0+4: Y[2k-1..2k+2]
-		acc[1] += (fma(x2, y1, x3 * y2) + fma(x0, ym1, x1 * y0));
-		// lag j0+8: Y[2k-2..2k+1]
-		if(lag8) acc[2] += fma(x0, (ym2 + x2), x1 * (ym1 + x3));
-		else acc[2] += (fma(x2, y0, x3 * y1) + fma(x0, ym2, x1 * ym1));
-		ym2 = y2; ym1 = y3;
+	const float *px = d + L + l, *py = px - j;
+	double acc = 0.0;
+	uint32_t k = 0, p = 0;
+	if(j == 8) {
+		for(; p + 2 <= npairs; p += 2, k += 4, px += 32, py += 32) {
+			float x[8], y[4];
+#pragma unroll
+			for(int u = 0; u < 8; u++) x[u] = px[4 * u];
+			y[0] = py[0]; y[1] = py[4]; y[2] = py[16]; y[3] = py[20];
+			acc += fma((double)x[0], ((double)y[0] + (double)x[2]), (double)x[1] * ((double)y[1] + (double)x[3]));
+			acc += fma((double)x[4], ((double)y[2] + (double)x[6]), (double)x[5] * ((double)y[3] + (double)x[7]));
+		}
+		for(; p < npairs; p++, k += 2, px += 16, py += 16)
+			acc += fma((double)px[0], ((double)py[0] + (double)px[8]), (double)px[4] * ((double)py[4] + (double)px[12]));
 	}
-	for(; k < nb; k++, px += 8, py += 8) {
-		const double x0 = (double)px[0], x1 = (double)px[4], y0 = (double)py[0], y1 = (double)py[4];
-		acc[0] += fma(x0, y0, x1 * y1);
-		acc[1] += fma(x0, ym1, x1 * y0);
-		acc[2] += fma(x0, ym2, x1 * ym1);
-		ym2 = y0; ym1 = y1;
+	else {
+		for(; p + 2 <= npairs; p += 2, k += 4, px += 32, py += 32) {
+			float x[8], y[8];
+#pragma unroll
+			for(int u = 0; u < 8; u++) { x[u] = px[4 * u]; y[u] = py[4 * u]; }
+#pragma unroll
+			for(int h = 0; h < 2; h++) {
+				const double t0 = fma((double)x[4 * h], (double)y[4 * h], (double)x[4 * h + 1] * (double)y[4 * h + 1]);
+				const double t1 = fma((double)x[4 * h + 2], (double)y[4 * h + 2], (double)x[4 * h + 3] * (double)y[4 * h + 3]);
+				acc += (t1 + t0);
+			}
+		}
+		for(; p < npairs; p++, k += 2, px += 16, py += 16) {
+			const double t0 = fma((double)px[0], (double)py[0], (double)px[4] * (double)py[4]);
+			const double t1 = fma((double)px[8], (double)py[8], (double)px[12] * (double)py[12]);
+			acc += (t1 + t0);
+		}
 	}
+	for(; k < nb; k++, px += 8, py += 8)
+		acc += fma((double)px[0], (double)py[0], (double)px[4] * (double)py[4]);
+	return acc;
 }
 // scalar head (samples j..L-1), lane combine and tail for lag j
 __device__ __forceinline__ double autoc_finish(const float *d, uint32_t nd, uint32_t L, uint32_t j, const double *acc4)
@@ -344,7 +368,11 @@ __device__ void load_signal(int32_t *sig, const int32_t *frame_pcm, uint32_t C, 
 
 // residual of CHUNK consecutive samples starting at `base` with a zero-padded MAXORD-tap FIR
 // (lpc.c:321 32-bit wrapping / lpc.c:582 64-bit accumulate; fixed.c:470 is the same FIR with binomial taps)
-template <int MAXORD, bool WIDE>
+// MODE 0: 32-bit wrapping accumulate with 24-bit multiplies (lpc.c:321; valid when samples fit 24 bits signed and
+//         |tap| < 2^23: the low 32 bits of the product are the same, at the full VALU rate of v_mad_i32_i24)
+// MODE 1: 32-bit wrapping accumulate, full 32-bit multiplies (lpc.c:321)
+// MODE 2: 64-bit accumulate (lpc.c:582)
+template <int MAXORD, int MODE>
 __device__ __forceinline__ void fir_chunk(const int32_t *sig, int base, const int32_t *q, int shift, int32_t *r)
 {
 	int32_t x[MAXORD + CHUNK];
@@ -352,7 +380,7 @@ __device__ __forceinline__ void fir_chunk(const int32_t *sig, int base, const in
 	for(int k = 0; k < MAXORD + CHUNK; k++) x[k] = sig[sigidx(base - MAXORD + k)];
 #pragma unroll
 	for(int s = 0; s < CHUNK; s++) {
-		if(WIDE) {
+		if(MODE == 2) {
 			int64_t sum = 0;
 #pragma unroll
 			for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)x[MAXORD + s - 1 - j];
@@ -361,39 +389,32 @@ __device__ __forceinline__ void fir_chunk(const int32_t *sig, int base, const in
 		else {
 			uint32_t sum = 0;
 #pragma unroll
-			for(int j = 0; j < MAXORD; j++) sum += (uint32_t)q[j] * (uint32_t)x[MAXORD + s - 1 - j];
+			for(int j = 0; j < MAXORD; j++)
+				sum += MODE == 0 ? (uint32_t)__mul24(q[j], x[MAXORD + s - 1 - j]) : (uint32_t)q[j] * (uint32_t)x[MAXORD + s - 1 - j];
 			r[s] = (int32_t)((uint32_t)x[MAXORD + s] - (uint32_t)((int32_t)sum >> shift));
 		}
 	}
 }
 
+// mode: 0/1/2 as above (wave-uniform)
 template <int MAXORD>
-__device__ __forceinline__ void fir_chunk_dispatch(const int32_t *sig, int base, const int32_t *q, int shift, bool wide, int32_t *r)
+__device__ __forceinline__ void fir_chunk_dispatch(const int32_t *sig, int base, const int32_t *q, int shift, int mode, int32_t *r)
 {
-	if(wide) fir_chunk<MAXORD, true>(sig, base, q, shift, r);
-	else fir_chunk<MAXORD, false>(sig, base, q, shift, r);
+	if(mode == 0) fir_chunk<MAXORD, 0>(sig, base, q, shift, r);
+	else if(mode == 1) fir_chunk<MAXORD, 1>(sig, base, q, shift, r);
+	else fir_chunk<MAXORD, 2>(sig, base, q, shift, r);
 }
+__device__ __forceinline__ int fir_mode(bool wide, uint32_t sbps) { return wide ? 2 : (sbps <= 24 ? 0 : 1); }
 
 // ---------------------------------------------------------------------------------------------
 // analyze_kernel
 // ---------------------------------------------------------------------------------------------
-struct WindowJob {
-	uint32_t off;       // float offset of this job's windowed data in the LDS window buffer
-	uint32_t nd;        // data_len handed to the autocorrelation
-	uint32_t apod;      // which window table
-	uint32_t full;      // 1: whole block (lpc.c:68), 0: partial window (lpc.c:82)
-	uint32_t part, dshift, i0;
-};
-
 // fixed-size part of the workgroup's LDS state; the large arrays are carved dynamically (analyze_layout)
 struct AnalyzeSmall {
 	uint64_t scratch[8];
 	uint64_t pob[TPB / 64][MAX_PO + 1];           // slow path: per-wave bit totals per partition order
 	uint32_t divtab[(MAX_PO + 1) * (MAX_ORDER + 1)]; // 0x40000 / ((n >> po) - order)
-	WindowJob jobs[MAX_JOBS];
-	uint8_t an_job[MAX_ANALYSES], an_punch[MAX_ANALYSES], an_root[MAX_ANALYSES];
 	int cand_valid[MAX_ANALYSES + 1];
-	uint32_t njobs, nanalyses;
 	uint32_t wbest_bits[TPB / 64], wbest_ci[TPB / 64], wbest_po[TPB / 64];
 };
 
@@ -445,71 +466,134 @@ __device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_
 	int32_t qr[MAXORD];
 #pragma unroll
 	for(int j = 0; j < MAXORD; j++) qr[j] = q[j];
+	const int fmode = fir_mode(wide, sbps);
 
-	const uint32_t S = (((n + 63u) >> 6) + (CHUNK - 1)) & ~(uint32_t)(CHUNK - 1);  // samples per lane
-	const bool direct = psize == S;                                         // lane == leaf partition (4096 @ order 6)
+	// Lane `lane` owns chunks lane, lane+64, ... of CHUNK consecutive samples: adjacent lanes read adjacent
+	// 18-word rows of the padded signal, i.e. conflict-free LDS reads.
+	const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
+	const uint32_t g = psize / CHUNK;                                       // chunks per leaf partition
+	// fast path: a leaf partition is g = 2^a adjacent lanes of one pass (e.g. 4096 samples: 64 partitions of 4 chunks)
+	const bool direct = max_po <= 6 && psize % CHUNK == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0;
+	uint64_t vdirect = 0;             // direct path: leaf sum of partition `lane`
 	if(!direct) {
 		for(uint32_t p = (uint32_t)lane; p < nparts; p += 64) wsums[p] = 0;
 		__builtin_amdgcn_wave_barrier();
 	}
-	uint64_t mine = 0;
-	for(uint32_t c = 0; c < S; c += CHUNK) {
-		const uint32_t base = (uint32_t)lane * S + c;
-		if(base >= n) break;
-		int32_t r[CHUNK];
-		fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, wide, r);
-		if(direct) {
+	if(direct) {
+		const uint32_t lp = 64u / g;                      // leaves per pass (power of two)
+		const uint32_t src = ((uint32_t)lane & (lp - 1)) * g, want = (uint32_t)lane / lp;
+#pragma unroll 1
+		for(uint32_t pass = 0; pass * 64 < nchunks; pass++) {
+			const uint32_t base = (pass * 64 + (uint32_t)lane) * CHUNK;
+			uint64_t mine = 0;
+			if(base < n) {
+				int32_t r[CHUNK];
+				fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, fmode, r);
+				uint32_t acc32 = 0;
+				uint64_t acc64 = 0;
 #pragma unroll
-			for(int s = 0; s < CHUNK; s++) {
-				const uint32_t i = base + s;
-				if(i >= order && i < n) { const int32_t v = r[s]; mine += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v); }
+				for(int s2 = 0; s2 < CHUNK; s2++) {
+					const uint32_t i = base + s2;
+					if(i >= order && i < n) {
+						const int32_t v = r[s2];
+						const uint32_t av = (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v);
+						if(narrow) acc32 += av; else acc64 += av;
+					}
+				}
+				mine = narrow ? (uint64_t)acc32 : acc64;
 			}
+			for(uint32_t m = 1; m < g; m <<= 1) mine += shfl_xor_u64(mine, (int)m);
+			// leaf p = pass*lp + lane/g sits in every lane of its group; lane L wants leaf L
+			const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, (int)src), hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), (int)src);
+			if(want == pass) vdirect = ((uint64_t)hi << 32) | lo;
 		}
-		else {
+		if((uint32_t)lane >= nparts) vdirect = 0;
+	}
+	else {
+		for(uint32_t cidx = (uint32_t)lane; cidx < nchunks; cidx += 64) {
+			const uint32_t base = cidx * CHUNK;
+			int32_t r[CHUNK];
+			fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, fmode, r);
 			uint32_t part = base / psize, next = (part + 1) * psize;
 			uint64_t run = 0;
 #pragma unroll
-			for(int s = 0; s < CHUNK; s++) {
-				const uint32_t i = base + s;
+			for(int s2 = 0; s2 < CHUNK; s2++) {
+				const uint32_t i = base + s2;
 				if(i == next) {
 					if(run) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
 					run = 0; part++; next += psize;
 				}
-				if(i >= order && i < n) { const int32_t v = r[s]; run += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v); }
+				if(i >= order && i < n) { const int32_t v = r[s2]; run += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v); }
 			}
 			if(run && part < nparts) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
 		}
 	}
 	uint32_t best_bits = 0, best_po = 0;
 	if(max_po <= 6) {
-		// leaves in lanes 0..nparts-1, merged level by level with a butterfly; every lane of a group holds
+		// leaves into lanes 0..nparts-1, merged level by level with a butterfly; every lane of a group holds
 		// the group's sum, the group's first lane speaks for the partition
 		uint64_t v;
-		if(direct) v = mine;
+		if(direct) v = vdirect;
 		else { __builtin_amdgcn_wave_barrier(); v = (uint32_t)lane < nparts ? wsums[lane] : 0; }
 		if(narrow) v = (uint32_t)v;
+		// (1) merged sums of every level: 6 dependent butterfly stages
+		uint64_t vlev[7];
+		vlev[0] = v;
+#pragma unroll
+		for(int d = 1; d <= 6; d++) {
+			if((uint32_t)d <= max_po - min_po) v += shfl_xor_u64(v, 1 << (d - 1));
+			vlev[d] = v;
+		}
+		// (2) Rice parameter and bit estimate of this lane's partition at every level (independent VALU work)
 		uint32_t klev[7];
+		uint64_t blev[7];
+		bool big = false;
 #pragma unroll
 		for(int d = 0; d <= 6; d++) {
-			klev[d] = 0;
+			klev[d] = 0; blev[d] = 0;
 			if((uint32_t)d <= max_po - min_po) {
 				const uint32_t po = max_po - (uint32_t)d;
-				if(d > 0) v += shfl_xor_u64(v, 1 << (d - 1));
-				const uint32_t p = (uint32_t)lane >> d;
+				const uint32_t pidx = (uint32_t)lane >> d;
 				const bool rep = ((uint32_t)lane & ((1u << d) - 1u)) == 0 && (uint32_t)lane < nparts;
-				const uint32_t o = p == 0 ? order : 0;
+				const uint32_t o = pidx == 0 ? order : 0;
 				const uint32_t ns = (n >> po) - o;
 				const uint32_t div = divtab[po * (MAX_ORDER + 1) + o];
+				const uint64_t sum = vlev[d];
 				uint32_t k;
-				if(v < 2 || (((v - 1) * div) >> 18) == 0) k = 0;
-				else k = ilog2_u64(((v - 1) * div) >> 18) + 1;
+				if(sum < 2 || (((sum - 1) * div) >> 18) == 0) k = 0;
+				else k = ilog2_u64(((sum - 1) * div) >> 18) + 1;
 				if(k >= P.rice_limit) k = P.rice_limit - 1;
-				uint64_t b = 4 + (uint64_t)(1 + k) * ns + (k ? (v >> (k - 1)) : (v << 1)) - (ns >> 1);
-				if(b > 0xffffffffull) b = 0xffffffffull;
+				uint64_t bb = 4 + (uint64_t)(1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
+				if(bb > 0xffffffffull) bb = 0xffffffffull;
 				klev[d] = k;
-				const uint64_t tot = 6 + wave_reduce_add_u64(rep ? b : 0);
+				blev[d] = rep ? bb : 0;
+				big |= bb >= (1ull << 25);
+			}
+		}
+		// (3) totals per level: all levels reduced together so the cross-lane latency overlaps.
+		// 64 terms below 2^25 fit 32 bits -- the usual case; otherwise reduce in 64 bits.
+		if(!__any((int)big)) {
+			uint32_t t[7];
+#pragma unroll
+			for(int d = 0; d <= 6; d++) t[d] = (uint32_t)blev[d];
+#pragma unroll
+			for(int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+				for(int d = 0; d <= 6; d++) t[d] += __shfl_xor(t[d], off);
+			}
+#pragma unroll
+			for(int d = 0; d <= 6; d++) blev[d] = t[d];
+		}
+		else {
+#pragma unroll
+			for(int d = 0; d <= 6; d++) blev[d] = wave_reduce_add_u64(blev[d]);
+		}
+#pragma unroll
+		for(int d = 0; d <= 6; d++) {
+			if((uint32_t)d <= max_po - min_po) {
+				const uint64_t tot = 6 + blev[d];
 				const uint32_t bits = tot >= 0xffffffffull ? 0xffffffffu : (uint32_t)tot;
-				if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = po; }
+				if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = max_po - (uint32_t)d; }
 			}
 		}
 		const uint32_t db = max_po - best_po;
@@ -557,14 +641,19 @@ __device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_
 }
 
 template <int MAXORD>
-__global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const int32_t *__restrict__ pcm,
+__global__ __launch_bounds__(TPB, 2) void analyze_kernel(const DevParams P, const int32_t *__restrict__ pcm,
                                                       const float *__restrict__ windows,
                                                       const float *__restrict__ tail_windows,
                                                       uint32_t nframes, uint32_t tail_n,
-                                                      SubDecision *__restrict__ decisions)
+                                                      const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
+                                                      SubDecision *__restrict__ decisions,
+                                                      unsigned long long *__restrict__ dbg)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	// optional phase stamps (FLACGPU_DEBUG_TIMING=1): s_memtime at phase boundaries of every workgroup
+#define STAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
+	STAMP(0);
 	const uint32_t C = P.channels, N = P.blocksize;
 
 	// XCD-aware mapping: consecutive workgroup ids round-robin over the 8 XCDs; keep the candidate
@@ -582,6 +671,7 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const uint32_t n = is_tail ? tail_n : N;
 	const float *win = is_tail ? tail_windows : windows;
+	const JobTable *jt = is_tail ? jt_tail : jt_main;
 	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
 
 	const AnalyzeLayout LY = analyze_layout(P);
@@ -637,6 +727,7 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 	}
 	const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
 	const uint32_t hdr = 8 + wasted;
+	STAMP(1);
 	// reciprocal table of set_partitioned_rice_ (stream_encoder.c:4997,5009)
 	for(uint32_t t = (uint32_t)tid; t < (MAX_PO + 1) * (MAX_ORDER + 1); t += TPB) {
 		const uint32_t po = t / (MAX_ORDER + 1), o = t - po * (MAX_ORDER + 1);
@@ -665,28 +756,55 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 		const uint32_t n4 = n - 4;
 		const bool fwide = !(sbps + ilog2_u32(n4 * 17) < 32);
 		uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
-		{
-			const uint32_t lanes = fwide ? 4 : 1;
-			const uint32_t q = fwide ? n4 / 4 : n4;
-			for(uint32_t l = 0; l < lanes; l++) {
+		if(!fwide || (n4 & 3) == 0) {
+			// plain sums over samples 4..n-1 (the AVX2 routine's four lanes tile the range exactly when
+			// (n-4) % 4 == 0): per-thread sliding window, 32-bit differences (|d4| < 2^29 for bps <= 25)
+			for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * TPB) {
+				int32_t x[CHUNK + 4];
+#pragma unroll
+				for(int k = 0; k < CHUNK + 4; k++) x[k] = sig[sigidx((int)base - 4 + k)];
+				uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;   // 16 terms < 2^29 each: no overflow
+#pragma unroll
+				for(int t = 0; t < CHUNK; t++) {
+					const uint32_t i = base + t;
+					if(i >= 4 && i < n) {
+						const int32_t a0 = x[t + 4], a1 = x[t + 3], a2 = x[t + 2], a3 = x[t + 1], a4 = x[t];
+						const int32_t d1 = a0 - a1, d2 = a0 - 2 * a1 + a2, d3 = a0 - 3 * a1 + 3 * a2 - a3, d4 = a0 - 4 * a1 + 6 * a2 - 4 * a3 + a4;
+						s0 += (uint32_t)abs(a0); s1 += (uint32_t)abs(d1); s2 += (uint32_t)abs(d2); s3 += (uint32_t)abs(d3); s4 += (uint32_t)abs(d4);
+					}
+				}
+				e0 += s0; e1 += s1; e2 += s2; e3 += s3; e4 += s4;
+			}
+		}
+		else {
+			// fixed_intrin_avx2.c:57 with (n-4) % 4 != 0 (short last blocks): lane l takes its history from l*q but
+			// its data from (l*(n-4))/4 and the remainder is dropped -- restated literally
+			const uint32_t q = n4 / 4;
+			for(uint32_t l = 0; l < 4; l++) {
 				const int hist = (int)(l * q), start = (int)(((uint64_t)l * n4) / 4);
 				for(uint32_t i = (uint32_t)tid; i < q; i += TPB) {
 					int64_t v[5];
 #pragma unroll
 					for(int j = 0; j < 5; j++) { const int m = (int)i - j; v[j] = sig[sigidx(4 + (m >= 0 ? start + m : hist + m))]; }
-					int64_t d0 = v[0], d1 = v[0] - v[1], d2 = v[0] - 2 * v[1] + v[2], d3 = v[0] - 3 * v[1] + 3 * v[2] - v[3],
-					        d4 = v[0] - 4 * v[1] + 6 * v[2] - 4 * v[3] + v[4];
-					if(!fwide) { d0 = (int32_t)d0; d1 = (int32_t)d1; d2 = (int32_t)d2; d3 = (int32_t)d3; d4 = (int32_t)d4; }
+					const int64_t d0 = v[0], d1 = v[0] - v[1], d2 = v[0] - 2 * v[1] + v[2], d3 = v[0] - 3 * v[1] + 3 * v[2] - v[3],
+					              d4 = v[0] - 4 * v[1] + 6 * v[2] - 4 * v[3] + v[4];
 					e0 += (uint64_t)(d0 < 0 ? -d0 : d0); e1 += (uint64_t)(d1 < 0 ? -d1 : d1); e2 += (uint64_t)(d2 < 0 ? -d2 : d2);
 					e3 += (uint64_t)(d3 < 0 ? -d3 : d3); e4 += (uint64_t)(d4 < 0 ? -d4 : d4);
 				}
 			}
 		}
-		e0 = block_reduce_add_u64(e0, sh->scratch, tid);
-		e1 = block_reduce_add_u64(e1, sh->scratch, tid);
-		e2 = block_reduce_add_u64(e2, sh->scratch, tid);
-		e3 = block_reduce_add_u64(e3, sh->scratch, tid);
-		e4 = block_reduce_add_u64(e4, sh->scratch, tid);
+		{
+			// one workgroup reduction for the five totals
+			e0 = wave_reduce_add_u64(e0); e1 = wave_reduce_add_u64(e1); e2 = wave_reduce_add_u64(e2);
+			e3 = wave_reduce_add_u64(e3); e4 = wave_reduce_add_u64(e4);
+			uint64_t *red = wsums_all;      // free at this point
+			__syncthreads();
+			if(lane == 0) { red[wave * 5 + 0] = e0; red[wave * 5 + 1] = e1; red[wave * 5 + 2] = e2; red[wave * 5 + 3] = e3; red[wave * 5 + 4] = e4; }
+			__syncthreads();
+			e0 = e1 = e2 = e3 = e4 = 0;
+			for(int w = 0; w < TPB / 64; w++) { e0 += red[w * 5 + 0]; e1 += red[w * 5 + 1]; e2 += red[w * 5 + 2]; e3 += red[w * 5 + 3]; e4 += red[w * 5 + 4]; }
+			__syncthreads();
+		}
 		uint32_t guess_fixed;
 		{
 			const uint64_t m34 = e3 < e4 ? e3 : e4, m234 = e2 < m34 ? e2 : m34, m1234 = e1 < m234 ? e1 : m234;
@@ -701,6 +819,7 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 		const float rbps_guess = eg ? (float)(log(((double)eg * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
 		const bool rbps1_zero = e1 == 0 || (float)(log(((double)e1 * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) == 0.0f;
 
+		STAMP(2);
 		bool is_constant = false;
 		if(!disable_constant && rbps1_zero) {
 			uint32_t diff = 0;
@@ -738,89 +857,77 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 				const uint32_t variant = n <= 32 ? 0u : P.autoc_variant;
 				if(max_lpc > 0) {
 					const uint32_t lag = max_lpc + 1;
-					if(tid == 0) {
-						uint32_t nj = 0, na = 0, woff = 0;
-						for(uint32_t a = 0; a < P.num_apod; a++) {
-							const uint32_t root = nj;
-							WindowJob &jr = sh->jobs[nj];
-							jr.off = woff; jr.nd = n; jr.apod = a; jr.full = 1; jr.part = 0; jr.dshift = 0; jr.i0 = 0;
-							woff += (n + 3u) & ~1u;
-							sh->an_job[na] = (uint8_t)nj; sh->an_punch[na] = 0; sh->an_root[na] = (uint8_t)root; na++; nj++;
-							if(P.apod_kind[a] == FLACGPU_APOD_SUBDIVIDE_TUKEY) {
-								for(uint32_t b = 2; b <= P.apod_parts[a]; b++) {
-									if(n / b <= 32) continue;                       // :4349-4357
-									for(uint32_t pi = 0; pi < b; pi++) {
-										WindowJob &jp = sh->jobs[nj];
-										jp.off = woff; jp.nd = n / b; jp.apod = a; jp.full = 0;
-										jp.part = n / b / 2; jp.dshift = (pi * n) / b;   // :4361
-										jp.i0 = umin32(jp.part, n - jp.part - jp.dshift);
-										woff += (jp.nd + 3u) & ~1u;
-										sh->an_job[na] = (uint8_t)nj; sh->an_punch[na] = 0; sh->an_root[na] = (uint8_t)root; na++;
-										if(b >= 3) { sh->an_job[na] = (uint8_t)nj; sh->an_punch[na] = 1; sh->an_root[na] = (uint8_t)root; na++; }   // :4295-4308
-										nj++;
-									}
-								}
-							}
-						}
-						sh->njobs = nj; sh->nanalyses = na;
-					}
-					__syncthreads();
-					const uint32_t njobs = sh->njobs;
-					nan = sh->nanalyses;
-					// ---- windowing: out[i] = (float)x[i] * w[i] (lpc.c:68-94), all jobs ----------------
+					const uint32_t njobs = jt->njobs;
+					nan = jt->nanalyses;
+					// ---- windowing: out[i] = (float)x[i] * w[i] (lpc.c:68-94), all jobs, loads batched --------
 					for(uint32_t jb = 0; jb < njobs; jb++) {
-						const WindowJob jbv = sh->jobs[jb];
+						const WindowJob jbv = jt->jobs[jb];
 						const float *w = win + (size_t)jbv.apod * n;
 						float *o = wnd + jbv.off;
 						if(jbv.full) {
-							for(uint32_t i = (uint32_t)tid; i < n; i += TPB) o[i] = (float)sig[sigidx((int)i)] * w[i];
+							uint32_t i = (uint32_t)tid;
+							for(; i + 3 * TPB < n; i += 4 * TPB) {
+								const float w0 = w[i], w1 = w[i + TPB], w2 = w[i + 2 * TPB], w3 = w[i + 3 * TPB];
+								o[i] = (float)sig[sigidx((int)i)] * w0;
+								o[i + TPB] = (float)sig[sigidx((int)(i + TPB))] * w1;
+								o[i + 2 * TPB] = (float)sig[sigidx((int)(i + 2 * TPB))] * w2;
+								o[i + 3 * TPB] = (float)sig[sigidx((int)(i + 3 * TPB))] * w3;
+							}
+							for(; i < n; i += TPB) o[i] = (float)sig[sigidx((int)i)] * w[i];
 						}
 						else {
+							// first `part` taps ramp up with w[0..part), the next `part` ramp down with w[n-part..n), then one 0
 							const uint32_t part = jbv.part, dshift = jbv.dshift, i0 = jbv.i0;
-							for(uint32_t i = (uint32_t)tid; i <= i0 + part; i += TPB) {
-								float v = 0.0f;
-								bool wr = true;
-								if(i >= i0 && i < i0 + part) v = (float)sig[sigidx((int)(dshift + i))] * w[n - part + (i - i0)];
-								else if(i < part) v = (float)sig[sigidx((int)(dshift + i))] * w[i];
-								else if(!(i == i0 + part && i < n)) wr = false;
-								if(wr) o[i] = v;
+							const uint32_t total = i0 + part + 1;
+							uint32_t i = (uint32_t)tid;
+							for(; i + TPB < total; i += 2 * TPB) {
+								const uint32_t i2 = i + TPB;
+								const bool hiA = i >= i0 && i < i0 + part, hiB = i2 >= i0 && i2 < i0 + part;
+								const bool loA = !hiA && i < part, loB = !hiB && i2 < part;
+								const float wa = hiA ? w[n - part + (i - i0)] : loA ? w[i] : 0.0f;
+								const float wb = hiB ? w[n - part + (i2 - i0)] : loB ? w[i2] : 0.0f;
+								if(hiA || loA) o[i] = (float)sig[sigidx((int)(dshift + i))] * wa; else if(i == i0 + part && i < n) o[i] = 0.0f;
+								if(hiB || loB) o[i2] = (float)sig[sigidx((int)(dshift + i2))] * wb; else if(i2 == i0 + part && i2 < n) o[i2] = 0.0f;
+							}
+							for(; i < total; i += TPB) {
+								const bool hi = i >= i0 && i < i0 + part, lo = !hi && i < part;
+								if(hi) o[i] = (float)sig[sigidx((int)(dshift + i))] * w[n - part + (i - i0)];
+								else if(lo) o[i] = (float)sig[sigidx((int)(dshift + i))] * w[i];
+								else if(i == i0 + part && i < n) o[i] = 0.0f;
 							}
 						}
 					}
 					__syncthreads();
-					// ---- autocorrelation: 16 lanes per job, each running up to 4 lag chains -------------
+					STAMP(3);
+					// ---- autocorrelation: one wavefront per job (64 chains = 16 lags x 4 vector lanes) ------------
 					if(variant == 0) {
 						for(uint32_t t = (uint32_t)tid; t < njobs * lag; t += TPB) {
 							const uint32_t jb = t / lag, j = t - jb * lag;
-							autoc_job[jb * MAX_ORDER + j] = autoc_small(wnd + sh->jobs[jb].off, sh->jobs[jb].nd, j);
+							autoc_job[jb * MAX_ORDER + j] = autoc_small(wnd + jt->jobs[jb].off, jt->jobs[jb].nd, j);
 						}
 					}
 					else {
-						for(uint32_t t = (uint32_t)tid; t < njobs * 16; t += TPB) {
-							const uint32_t jb = t >> 4, l = t & 3, j0 = (t >> 2) & 3;
-							const float *d = wnd + sh->jobs[jb].off;
-							const uint32_t nd = sh->jobs[jb].nd;
-							double acc[4];
-							if(variant == 12) autoc_chains_12(d, nd, j0, l, acc);
-							else if(variant == 8) autoc_chains_8_16<2>(d, nd, 8, j0, l, acc);
-							else autoc_chains_8_16<4>(d, nd, 16, j0, l, acc);
-#pragma unroll
-							for(int k = 0; k < 4; k++) {
-								const uint32_t j = j0 + 4 * (uint32_t)k;
-								if(j < lag) accs[(jb * lag + j) * 4 + l] = acc[k];
-							}
+						const uint32_t j = (uint32_t)lane >> 2, l = (uint32_t)lane & 3;
+						const uint32_t mine = jt->wave_njobs[wave];
+						for(uint32_t q = 0; q < mine; q++) {
+							const uint32_t jb = jt->wave_jobs[wave][q];
+							const float *d = wnd + jt->jobs[jb].off;
+							const uint32_t nd = jt->jobs[jb].nd;
+							if(j < lag) accs[(jb * lag + j) * 4 + l] = variant == 12 ? autoc_chain_12(d, nd, j, l) : autoc_chain_8_16(d, nd, variant, j, l);
 						}
 						__syncthreads();
 						for(uint32_t t = (uint32_t)tid; t < njobs * lag; t += TPB) {
-							const uint32_t jb = t / lag, j = t - jb * lag;
-							autoc_job[jb * MAX_ORDER + j] = autoc_finish(wnd + sh->jobs[jb].off, sh->jobs[jb].nd, variant, j, &accs[(jb * lag + j) * 4]);
+							const uint32_t jb = t / lag, jj = t - jb * lag;
+							autoc_job[jb * MAX_ORDER + jj] = autoc_finish(wnd + jt->jobs[jb].off, jt->jobs[jb].nd, variant, jj, &accs[(jb * lag + jj) * 4]);
 						}
 					}
 					__syncthreads();
+					STAMP(4);
 					// ---- one lane per analysis: Levinson-Durbin, order guess, quantisation -----------------
+					// (the window buffer is dead now: it holds each lane's lp_coeff rows)
 					if((uint32_t)tid < nan) {
-						const uint32_t jb = sh->an_job[tid], rt = sh->an_root[tid];
-						const bool punch = sh->an_punch[tid] != 0;
+						const uint32_t jb = jt->an_job[tid], rt = jt->an_root[tid];
+						const bool punch = jt->an_punch[tid] != 0;
 						double av[MAXORD + 1];
 #pragma unroll
 						for(int j = 0; j <= MAXORD; j++) {
@@ -833,7 +940,8 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 							}
 							av[j] = v;
 						}
-						sh->cand_valid[1 + tid] = lpc_model<MAXORD>(av, max_lpc, n, sbps, P.precision, &cands[1 + tid]);
+						float *rows = (nan * MAXORD * MAXORD * 4u <= P.wnd_bytes) ? wnd + (size_t)tid * MAXORD * MAXORD : nullptr;
+						sh->cand_valid[1 + tid] = lpc_model<MAXORD>(av, max_lpc, n, sbps, P.precision, rows, &cands[1 + tid]);
 					}
 				}
 			}
@@ -844,6 +952,7 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 		if(fixed_valid) { cands[0].order = fixed_order; cands[0].precision = 0; cands[0].shift = 0; cands[0].wide = 0; }
 	}
 	__syncthreads();
+	STAMP(5);
 
 	// ---- candidates: one wavefront each, no workgroup barriers -------------------------------------
 	{
@@ -870,6 +979,7 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 		if(lane == 0) { sh->wbest_bits[wave] = wb_bits; sh->wbest_ci[wave] = wb_ci; sh->wbest_po[wave] = wb_po; }
 	}
 	__syncthreads();
+	STAMP(6);
 	// ---- winner: first minimum in the reference's evaluation order ---------------------------------------
 	{
 		uint32_t cb = 0xffffffffu, cci = 0xffffffffu, cw = 0;
@@ -905,6 +1015,8 @@ __global__ __launch_bounds__(TPB) void analyze_kernel(const DevParams P, const i
 		dec->shift = (int8_t)best_shift; dec->which = (uint8_t)which;
 		dec->constant = best_constant;
 	}
+	STAMP(7);
+#undef STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1144,7 +1256,7 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 				int32_t r[CHUNK];
 				uint32_t mybits = 0;
 				if(base < n) {
-					fir_chunk_dispatch<MAXORD>(sig, (int)base, q, shift, wide, r);
+					fir_chunk_dispatch<MAXORD>(sig, (int)base, q, shift, fir_mode(wide, sbps), r);
 					uint32_t part = base / psize, next = (part + 1) * psize;
 					uint32_t k = sh->params[part];
 #pragma unroll
@@ -1306,7 +1418,7 @@ using namespace flacgpu;
 
 template <int MAXORD>
 static hipError_t launch_analyze_t(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
-                                   uint32_t nframes, uint32_t tail_n, SubDecision *dec, size_t lds, hipStream_t s)
+                                   uint32_t nframes, uint32_t tail_n, const JobTable *jtm, const JobTable *jtt, SubDecision *dec, unsigned long long *dbg, size_t lds, hipStream_t s)
 {
 	static bool attr_set = false;
 	if(!attr_set) {
@@ -1314,7 +1426,7 @@ static hipError_t launch_analyze_t(const DevParams &P, const int32_t *pcm, const
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL(analyze_kernel<MAXORD>, dim3(nframes * P.ncand), dim3(TPB), lds, s, P, pcm, win, tailwin, nframes, tail_n, dec);
+	hipLaunchKernelGGL(analyze_kernel<MAXORD>, dim3(nframes * P.ncand), dim3(TPB), lds, s, P, pcm, win, tailwin, nframes, tail_n, jtm, jtt, dec, dbg);
 	return hipGetLastError();
 }
 template <int MAXORD>
@@ -1336,13 +1448,14 @@ size_t analyze_lds_bytes(const DevParams &P) { return analyze_layout(P).total; }
 size_t pack_lds_bytes(const DevParams &P) { return (size_t)P.sig_bytes + P.slot_bytes + sizeof(PackShared); }
 
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
-                          uint32_t nframes, uint32_t tail_n, SubDecision *dec, hipStream_t s)
+                          uint32_t nframes, uint32_t tail_n, const JobTable *jtm, const JobTable *jtt, SubDecision *dec,
+                          unsigned long long *dbg, hipStream_t s)
 {
 	const size_t lds = analyze_lds_bytes(P);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
-	if(m <= 8) return launch_analyze_t<8>(P, pcm, win, tailwin, nframes, tail_n, dec, lds, s);
-	if(m <= 12) return launch_analyze_t<12>(P, pcm, win, tailwin, nframes, tail_n, dec, lds, s);
-	return launch_analyze_t<16>(P, pcm, win, tailwin, nframes, tail_n, dec, lds, s);
+	if(m <= 8) return launch_analyze_t<8>(P, pcm, win, tailwin, nframes, tail_n, jtm, jtt, dec, dbg, lds, s);
+	if(m <= 12) return launch_analyze_t<12>(P, pcm, win, tailwin, nframes, tail_n, jtm, jtt, dec, dbg, lds, s);
+	return launch_analyze_t<16>(P, pcm, win, tailwin, nframes, tail_n, jtm, jtt, dec, dbg, lds, s);
 }
 hipError_t launch_pack(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, hipStream_t s)
