@@ -83,6 +83,14 @@ void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 }
 }
 
+extern "C" void *flacgpu_alloc_pinned(size_t bytes)
+{
+	void *p = nullptr;
+	if(hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+	return p;
+}
+extern "C" void flacgpu_free_pinned(void *p) { if(p) (void)hipHostFree(p); }
+
 extern "C" const char *flacgpu_strerror(int code)
 {
 	switch(code) {

@@ -1,0 +1,852 @@
+/* flac_amd/csrc/host/stream_encoder.c -- the libFLAC stream-encoder API on top of the GPU frame engine.
+ *
+ * Mirrors the reference's public encoder interface (include/FLAC/stream_encoder.h:704-1896; behaviour
+ * of src/libFLAC/stream_encoder.c:570-2626 for the object life cycle, :2988-3300 for stream output and
+ * metadata fix-up, stream_encoder_framing.c:46-243 for metadata block serialisation).
+ *
+ * What is different by design: the reference encodes one block per process_frame_() call
+ * (stream_encoder.c:3627); here whole blocks are STAGED in a pinned host buffer and handed to the HIP
+ * engine `batch_frames` at a time (include/flacgpu.h).  Frames come back byte-aligned and in order;
+ * the per-frame bookkeeping of write_frame_() (seek points, min/max frame size, callbacks) then runs
+ * on the calling thread exactly as it would have.  The one-sample "overread" of the reference
+ * (stream_encoder.c:565-576) is kept: a block is only released once one more sample exists, so the
+ * final block -- full or short -- is always produced by finish().
+ *
+ * No CPU encode path: if the engine cannot be created init fails (ENCODER_ERROR) and says why on stderr.
+ */
+#define _FILE_OFFSET_BITS 64
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include "flacgpu_host.h"
+#include "FLACgpu_stream_encoder.h"
+
+/* format.c:57: the reference writes its vendor string into every VORBIS_COMMENT block.  Files are
+ * required to be byte-identical to the reference's, so the same string is written here. */
+const char *FLAC__VENDOR_STRING = "reference libFLAC 1.5.0 20250211";
+
+const char * const FLAC__StreamEncoderStateString[] = {
+	"FLAC__STREAM_ENCODER_OK", "FLAC__STREAM_ENCODER_UNINITIALIZED", "FLAC__STREAM_ENCODER_OGG_ERROR",
+	"FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR", "FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA",
+	"FLAC__STREAM_ENCODER_CLIENT_ERROR", "FLAC__STREAM_ENCODER_IO_ERROR", "FLAC__STREAM_ENCODER_FRAMING_ERROR",
+	"FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR"
+};
+const char * const FLAC__StreamEncoderInitStatusString[] = {
+	"FLAC__STREAM_ENCODER_INIT_STATUS_OK", "FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_NUMBER_OF_CHANNELS", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BITS_PER_SAMPLE",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_SAMPLE_RATE", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BLOCK_SIZE",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_MAX_LPC_ORDER", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_QLP_COEFF_PRECISION",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_BLOCK_SIZE_TOO_SMALL_FOR_LPC_ORDER", "FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA", "FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED"
+};
+const char * const FLAC__StreamEncoderReadStatusString[] = {
+	"FLAC__STREAM_ENCODER_READ_STATUS_CONTINUE", "FLAC__STREAM_ENCODER_READ_STATUS_END_OF_STREAM",
+	"FLAC__STREAM_ENCODER_READ_STATUS_ABORT", "FLAC__STREAM_ENCODER_READ_STATUS_UNSUPPORTED"
+};
+const char * const FLAC__StreamEncoderWriteStatusString[] = {
+	"FLAC__STREAM_ENCODER_WRITE_STATUS_OK", "FLAC__STREAM_ENCODER_WRITE_STATUS_FATAL_ERROR"
+};
+const char * const FLAC__StreamEncoderSeekStatusString[] = {
+	"FLAC__STREAM_ENCODER_SEEK_STATUS_OK", "FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR", "FLAC__STREAM_ENCODER_SEEK_STATUS_UNSUPPORTED"
+};
+const char * const FLAC__StreamEncoderTellStatusString[] = {
+	"FLAC__STREAM_ENCODER_TELL_STATUS_OK", "FLAC__STREAM_ENCODER_TELL_STATUS_ERROR", "FLAC__STREAM_ENCODER_TELL_STATUS_UNSUPPORTED"
+};
+
+/* what the reference keeps in FLAC__StreamEncoderProtected: the client-visible settings and state */
+struct FLAC__StreamEncoderProtected {
+	FLAC__StreamEncoderState state;
+	flacgpu_host_settings s;
+	uint32_t num_threads;
+	FLAC__StreamMetadata **metadata;
+	uint32_t num_metadata_blocks;
+	FLAC__uint64 streaminfo_offset, seektable_offset, audio_offset;
+};
+
+/* ... and in FLAC__StreamEncoderPrivate: callbacks, stream bookkeeping, and here the batch staging */
+struct FLAC__StreamEncoderPrivate {
+	FLAC__StreamEncoderWriteCallback write_cb;
+	FLAC__StreamEncoderSeekCallback seek_cb;
+	FLAC__StreamEncoderTellCallback tell_cb;
+	FLAC__StreamEncoderMetadataCallback metadata_cb;
+	FLAC__StreamEncoderProgressCallback progress_cb;
+	void *client_data;
+	FILE *file;
+	FLAC__uint64 bytes_written, samples_written;
+	uint32_t frames_written, total_frames_estimate;
+	uint32_t current_frame_number;
+	uint32_t frame_blocksize;                 /* samples of the frame being written (get_blocksize during callbacks) */
+	FLAC__StreamMetadata streaminfo;
+	FLAC__StreamMetadata_SeekTable *seek_table;
+	uint32_t first_seekpoint_to_check;
+	flacgpu_host_md5 md5;
+	int is_being_deleted;
+	/* GPU batch */
+	flacgpu_ctx *gpu;
+	uint32_t batch_frames;
+	int32_t *stage;                           /* pinned, interleaved [batch_frames*blocksize + 1][channels] */
+	size_t staged;                            /* inter-channel samples currently staged */
+	uint8_t *out; size_t out_cap;
+	uint32_t *frame_bytes;
+	float *tail_windows;
+};
+
+#define PROT(e) ((e)->protected_)
+#define PRIV(e) ((e)->private_)
+
+/* ------------------------------------------------------------------------------------------------
+ * object life cycle (stream_encoder.c:570-700)
+ * ---------------------------------------------------------------------------------------------- */
+static void set_defaults(FLAC__StreamEncoder *e)
+{
+	flacgpu_host_settings_defaults(&PROT(e)->s);      /* set_defaults_ :2628-2700, ends with compression level 5 */
+	PROT(e)->num_threads = 1;
+	PROT(e)->metadata = 0;
+	PROT(e)->num_metadata_blocks = 0;
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	p->write_cb = 0; p->seek_cb = 0; p->tell_cb = 0; p->metadata_cb = 0; p->progress_cb = 0; p->client_data = 0;
+	p->seek_table = 0;
+}
+
+FLAC__StreamEncoder *FLAC__stream_encoder_new(void)
+{
+	FLAC__StreamEncoder *e = calloc(1, sizeof *e);
+	if(!e) return 0;
+	e->protected_ = calloc(1, sizeof *e->protected_);
+	e->private_ = calloc(1, sizeof *e->private_);
+	if(!e->protected_ || !e->private_) { free(e->protected_); free(e->private_); free(e); return 0; }
+	set_defaults(e);
+	PROT(e)->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
+	return e;
+}
+
+static void release_engine(FLAC__StreamEncoder *e)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	if(p->gpu) { flacgpu_destroy(p->gpu); p->gpu = 0; }
+	if(p->stage) { flacgpu_free_pinned(p->stage); p->stage = 0; }
+	free(p->out); p->out = 0; p->out_cap = 0;
+	free(p->frame_bytes); p->frame_bytes = 0;
+	free(p->tail_windows); p->tail_windows = 0;
+	p->staged = 0;
+	if(PROT(e)->metadata) { free(PROT(e)->metadata); PROT(e)->metadata = 0; PROT(e)->num_metadata_blocks = 0; }
+}
+
+void FLAC__stream_encoder_delete(FLAC__StreamEncoder *e)
+{
+	if(!e) return;
+	PRIV(e)->is_being_deleted = 1;            /* finish() then only releases, it does not flush (:623-630) */
+	(void)FLAC__stream_encoder_finish(e);
+	release_engine(e);
+	free(e->private_);
+	free(e->protected_);
+	free(e);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * setters: legal only while UNINITIALIZED (stream_encoder.c:1782-2297)
+ * ---------------------------------------------------------------------------------------------- */
+#define SETTER(name, type, stmt) \
+	FLAC__bool FLAC__stream_encoder_##name(FLAC__StreamEncoder *e, type value) { \
+		if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0; \
+		stmt; return 1; }
+
+SETTER(set_verify, FLAC__bool, PROT(e)->s.verify = value)
+SETTER(set_streamable_subset, FLAC__bool, PROT(e)->s.streamable_subset = value)
+SETTER(set_do_md5, FLAC__bool, PROT(e)->s.do_md5 = value)
+SETTER(set_channels, uint32_t, PROT(e)->s.channels = value)
+SETTER(set_bits_per_sample, uint32_t, PROT(e)->s.bits_per_sample = value)
+SETTER(set_sample_rate, uint32_t, PROT(e)->s.sample_rate = value)
+SETTER(set_blocksize, uint32_t, PROT(e)->s.blocksize = value)
+SETTER(set_do_mid_side_stereo, FLAC__bool, PROT(e)->s.do_mid_side_stereo = value)
+SETTER(set_loose_mid_side_stereo, FLAC__bool, PROT(e)->s.loose_mid_side_stereo = value)
+SETTER(set_max_lpc_order, uint32_t, PROT(e)->s.max_lpc_order = value)
+SETTER(set_qlp_coeff_precision, uint32_t, PROT(e)->s.qlp_coeff_precision = value)
+SETTER(set_do_qlp_coeff_prec_search, FLAC__bool, PROT(e)->s.do_qlp_coeff_prec_search = value)
+SETTER(set_do_escape_coding, FLAC__bool, (void)value)                 /* deprecated in the reference too (:2107-2114) */
+SETTER(set_do_exhaustive_model_search, FLAC__bool, PROT(e)->s.do_exhaustive_model_search = value)
+SETTER(set_min_residual_partition_order, uint32_t, PROT(e)->s.min_residual_partition_order = value)
+SETTER(set_max_residual_partition_order, uint32_t, PROT(e)->s.max_residual_partition_order = value)
+SETTER(set_rice_parameter_search_dist, uint32_t, (void)value)         /* deprecated (:2174-2188) */
+SETTER(set_limit_min_bitrate, FLAC__bool, PROT(e)->s.limit_min_bitrate = value)
+SETTER(disable_instruction_set, uint32_t, (void)value)                /* CPU dispatch mask: meaningless here */
+SETTER(disable_constant_subframes, FLAC__bool, PROT(e)->s.disable_constant_subframes = value)
+SETTER(disable_fixed_subframes, FLAC__bool, PROT(e)->s.disable_fixed_subframes = value)
+SETTER(disable_verbatim_subframes, FLAC__bool, PROT(e)->s.disable_verbatim_subframes = value)
+
+FLAC__bool FLAC__stream_encoder_set_ogg_serial_number(FLAC__StreamEncoder *e, long value)
+{
+	(void)e; (void)value;
+	return 0;                                 /* as a reference build without libogg (:1781-1797) */
+}
+
+FLAC__bool FLAC__stream_encoder_set_compression_level(FLAC__StreamEncoder *e, uint32_t value)
+{
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+	flacgpu_host_settings_level(&PROT(e)->s, value);
+	return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_set_apodization(FLAC__StreamEncoder *e, const char *specification)
+{
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED || !specification) return 0;
+	flacgpu_host_settings_apodization(&PROT(e)->s, specification);
+	return 1;
+}
+
+uint32_t FLAC__stream_encoder_set_num_threads(FLAC__StreamEncoder *e, uint32_t value)
+{
+	/* accepted and recorded; parallelism is the GPU batch, not a host thread pool (:2151-2172) */
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_SET_NUM_THREADS_ALREADY_INITIALIZED;
+	if(value > 64) return FLAC__STREAM_ENCODER_SET_NUM_THREADS_TOO_MANY_THREADS;
+	PROT(e)->num_threads = value ? value : 1;
+	return FLAC__STREAM_ENCODER_SET_NUM_THREADS_OK;
+}
+
+FLAC__bool FLAC__stream_encoder_set_total_samples_estimate(FLAC__StreamEncoder *e, FLAC__uint64 value)
+{
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+	const FLAC__uint64 cap = ((FLAC__uint64)1 << 36) - 1;
+	PROT(e)->s.total_samples_estimate = value < cap ? value : cap;
+	return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *e, FLAC__StreamMetadata **metadata, uint32_t num_blocks)
+{
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+	if(!metadata) num_blocks = 0;
+	free(PROT(e)->metadata);                  /* the pointer ARRAY is copied, the blocks stay the client's (:2202-2231) */
+	PROT(e)->metadata = 0; PROT(e)->num_metadata_blocks = 0;
+	if(num_blocks) {
+		FLAC__StreamMetadata **m = malloc(sizeof *m * num_blocks);
+		if(!m) return 0;
+		memcpy(m, metadata, sizeof *m * num_blocks);
+		PROT(e)->metadata = m; PROT(e)->num_metadata_blocks = num_blocks;
+	}
+	return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * getters (stream_encoder.c:2299-2511)
+ * ---------------------------------------------------------------------------------------------- */
+FLAC__StreamEncoderState FLAC__stream_encoder_get_state(const FLAC__StreamEncoder *e) { return PROT(e)->state; }
+/* with verify requested but no decoder object the reference answers MEMORY_ALLOCATION_ERROR (8), :2314-2318 */
+FLAC__StreamDecoderState FLAC__stream_encoder_get_verify_decoder_state(const FLAC__StreamEncoder *e) { return PROT(e)->s.verify ? 8 : FLAC__STREAM_DECODER_UNINITIALIZED; }
+const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *e) { return FLAC__StreamEncoderStateString[PROT(e)->state]; }
+void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *e, FLAC__uint64 *absolute_sample, uint32_t *frame_number, uint32_t *channel, uint32_t *sample, FLAC__int32 *expected, FLAC__int32 *got)
+{
+	(void)e;
+	if(absolute_sample) *absolute_sample = 0;
+	if(frame_number) *frame_number = 0;
+	if(channel) *channel = 0;
+	if(sample) *sample = 0;
+	if(expected) *expected = 0;
+	if(got) *got = 0;
+}
+#define GETTER(name, type, expr) type FLAC__stream_encoder_##name(const FLAC__StreamEncoder *e) { return (type)(expr); }
+GETTER(get_verify, FLAC__bool, PROT(e)->s.verify)
+GETTER(get_streamable_subset, FLAC__bool, PROT(e)->s.streamable_subset)
+GETTER(get_do_md5, FLAC__bool, PROT(e)->s.do_md5)
+GETTER(get_channels, uint32_t, PROT(e)->s.channels)
+GETTER(get_bits_per_sample, uint32_t, PROT(e)->s.bits_per_sample)
+GETTER(get_sample_rate, uint32_t, PROT(e)->s.sample_rate)
+GETTER(get_do_mid_side_stereo, FLAC__bool, PROT(e)->s.do_mid_side_stereo)
+GETTER(get_loose_mid_side_stereo, FLAC__bool, PROT(e)->s.loose_mid_side_stereo)
+GETTER(get_max_lpc_order, uint32_t, PROT(e)->s.max_lpc_order)
+GETTER(get_qlp_coeff_precision, uint32_t, PROT(e)->s.qlp_coeff_precision)
+GETTER(get_do_qlp_coeff_prec_search, FLAC__bool, PROT(e)->s.do_qlp_coeff_prec_search)
+GETTER(get_do_escape_coding, FLAC__bool, PROT(e)->s.do_escape_coding)
+GETTER(get_do_exhaustive_model_search, FLAC__bool, PROT(e)->s.do_exhaustive_model_search)
+GETTER(get_min_residual_partition_order, uint32_t, PROT(e)->s.min_residual_partition_order)
+GETTER(get_max_residual_partition_order, uint32_t, PROT(e)->s.max_residual_partition_order)
+GETTER(get_num_threads, uint32_t, PROT(e)->num_threads)
+GETTER(get_rice_parameter_search_dist, uint32_t, PROT(e)->s.rice_parameter_search_dist)
+GETTER(get_total_samples_estimate, FLAC__uint64, PROT(e)->s.total_samples_estimate)
+GETTER(get_limit_min_bitrate, FLAC__bool, PROT(e)->s.limit_min_bitrate)
+/* during a write callback this is the block size of the frame being delivered (the reference shrinks
+ * protected_->blocksize for the final short block, stream_encoder.c:1704) */
+uint32_t FLAC__stream_encoder_get_blocksize(const FLAC__StreamEncoder *e)
+{
+	return PROT(e)->state == FLAC__STREAM_ENCODER_OK && PRIV(e)->frame_blocksize ? PRIV(e)->frame_blocksize : PROT(e)->s.blocksize;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * metadata serialisation (stream_encoder_framing.c:46-243): big-endian fields, byte aligned throughout
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint8_t *p; size_t n, cap; int bad; } bytebuf;
+
+static void bb_put(bytebuf *b, const void *src, size_t len)
+{
+	if(b->bad) return;
+	if(b->n + len > b->cap) {
+		size_t nc = b->cap ? b->cap * 2 : 256;
+		while(nc < b->n + len) nc *= 2;
+		uint8_t *q = realloc(b->p, nc);
+		if(!q) { b->bad = 1; return; }
+		b->p = q; b->cap = nc;
+	}
+	if(src) memcpy(b->p + b->n, src, len); else memset(b->p + b->n, 0, len);
+	b->n += len;
+}
+static void bb_be(bytebuf *b, uint64_t v, unsigned bytes) { uint8_t t[8]; for(unsigned i = 0; i < bytes; i++) t[i] = (uint8_t)(v >> (8 * (bytes - 1 - i))); bb_put(b, t, bytes); }
+static void bb_le32(bytebuf *b, uint32_t v) { uint8_t t[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)}; bb_put(b, t, 4); }
+
+/* returns 0 when the block cannot be framed (length field disagrees with the content, or >= 2^24) */
+static int serialise_block(const FLAC__StreamMetadata *m, bytebuf *b)
+{
+	const uint32_t vlen = (uint32_t)strlen(FLAC__VENDOR_STRING);
+	uint32_t length = m->length;
+	if(m->type == FLAC__METADATA_TYPE_VORBIS_COMMENT) length = length - m->data.vorbis_comment.vendor_string.length + vlen;
+	if(length >= (1u << 24)) return 0;
+	const size_t start = b->n;
+	bb_be(b, ((uint32_t)(m->is_last ? 1 : 0) << 7) | ((uint32_t)m->type & 0x7f), 1);
+	bb_be(b, length, 3);
+	switch(m->type) {
+		case FLAC__METADATA_TYPE_STREAMINFO: {
+			const FLAC__StreamMetadata_StreamInfo *si = &m->data.stream_info;
+			const uint64_t total = si->total_samples >= ((uint64_t)1 << 36) ? 0 : si->total_samples;
+			bb_be(b, si->min_blocksize, 2); bb_be(b, si->max_blocksize, 2);
+			bb_be(b, si->min_framesize, 3); bb_be(b, si->max_framesize, 3);
+			/* 20 bits rate | 3 bits channels-1 | 5 bits bps-1 | 36 bits total samples */
+			bb_be(b, ((uint64_t)si->sample_rate << 44) | ((uint64_t)(si->channels - 1) << 41) | ((uint64_t)(si->bits_per_sample - 1) << 36) | total, 8);
+			bb_put(b, si->md5sum, 16);
+			break;
+		}
+		case FLAC__METADATA_TYPE_PADDING: bb_put(b, 0, m->length); break;
+		case FLAC__METADATA_TYPE_APPLICATION:
+			if(m->length < 4) return 0;
+			bb_put(b, m->data.application.id, 4);
+			bb_put(b, m->data.application.data, m->length - 4);
+			break;
+		case FLAC__METADATA_TYPE_SEEKTABLE:
+			for(uint32_t i = 0; i < m->data.seek_table.num_points; i++) {
+				const FLAC__StreamMetadata_SeekPoint *sp = &m->data.seek_table.points[i];
+				bb_be(b, sp->sample_number, 8); bb_be(b, sp->stream_offset, 8); bb_be(b, sp->frame_samples, 2);
+			}
+			break;
+		case FLAC__METADATA_TYPE_VORBIS_COMMENT:
+			bb_le32(b, vlen); bb_put(b, FLAC__VENDOR_STRING, vlen);       /* our vendor string replaces the client's */
+			bb_le32(b, m->data.vorbis_comment.num_comments);
+			for(uint32_t i = 0; i < m->data.vorbis_comment.num_comments; i++) {
+				bb_le32(b, m->data.vorbis_comment.comments[i].length);
+				bb_put(b, m->data.vorbis_comment.comments[i].entry, m->data.vorbis_comment.comments[i].length);
+			}
+			break;
+		case FLAC__METADATA_TYPE_CUESHEET: {
+			const FLAC__StreamMetadata_CueSheet *cs = &m->data.cue_sheet;
+			bb_put(b, cs->media_catalog_number, 128);
+			bb_be(b, cs->lead_in, 8);
+			bb_be(b, cs->is_cd ? 0x80 : 0, 1); bb_put(b, 0, 258);             /* 1 bit is_cd + 7+258*8 reserved bits */
+			bb_be(b, cs->num_tracks, 1);
+			for(uint32_t i = 0; i < cs->num_tracks; i++) {
+				const FLAC__StreamMetadata_CueSheet_Track *t = &cs->tracks[i];
+				bb_be(b, t->offset, 8); bb_be(b, t->number, 1); bb_put(b, t->isrc, 12);
+				bb_be(b, ((uint32_t)t->type << 7) | ((uint32_t)t->pre_emphasis << 6), 1); bb_put(b, 0, 13);   /* 2 flags + 6+13*8 reserved bits */
+				bb_be(b, t->num_indices, 1);
+				for(uint32_t j = 0; j < t->num_indices; j++) { bb_be(b, t->indices[j].offset, 8); bb_be(b, t->indices[j].number, 1); bb_put(b, 0, 3); }
+			}
+			break;
+		}
+		case FLAC__METADATA_TYPE_PICTURE: {
+			const FLAC__StreamMetadata_Picture *pic = &m->data.picture;
+			const size_t ml = strlen(pic->mime_type), dl = strlen((const char *)pic->description);
+			bb_be(b, (uint32_t)pic->type, 4);
+			bb_be(b, ml, 4); bb_put(b, pic->mime_type, ml);
+			bb_be(b, dl, 4); bb_put(b, pic->description, dl);
+			bb_be(b, pic->width, 4); bb_be(b, pic->height, 4); bb_be(b, pic->depth, 4); bb_be(b, pic->colors, 4);
+			bb_be(b, pic->data_length, 4); bb_put(b, pic->data, pic->data_length);
+			break;
+		}
+		default: bb_put(b, m->data.unknown.data, m->length); break;
+	}
+	if(b->bad) return 0;
+	return b->n - start == (size_t)length + 4;    /* the declared length must be the written length (framing.c:233-240) */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * legality checks of client metadata (format.c:241-520), as far as init uses them
+ * ---------------------------------------------------------------------------------------------- */
+static unsigned utf8_len(const uint8_t *u)           /* shortest-form UTF-8 only; 0 = invalid (format.c:322) */
+{
+	if(!(u[0] & 0x80)) return 1;
+	unsigned n = (u[0] & 0xE0) == 0xC0 ? 2 : (u[0] & 0xF0) == 0xE0 ? 3 : (u[0] & 0xF8) == 0xF0 ? 4 : (u[0] & 0xFC) == 0xF8 ? 5 : (u[0] & 0xFE) == 0xFC ? 6 : 0;
+	if(!n) return 0;
+	for(unsigned i = 1; i < n; i++) if((u[i] & 0xC0) != 0x80) return 0;
+	if(n == 2 && (u[0] & 0xFE) == 0xC0) return 0;
+	if(n == 3 && ((u[0] == 0xE0 && (u[1] & 0xE0) == 0x80) || (u[0] == 0xED && (u[1] & 0xE0) == 0xA0) || (u[0] == 0xEF && u[1] == 0xBF && (u[2] & 0xFE) == 0xBE))) return 0;
+	if(n > 3 && u[0] == (uint8_t)(0xFF << (8 - n)) && (u[1] & (0xFF << (8 - n) & 0xFF)) == 0x80) return 0;   /* overlong 4/5/6 */
+	return n;
+}
+static int seektable_is_legal(const FLAC__StreamMetadata_SeekTable *st)
+{
+	if((uint64_t)st->num_points * 18 >= (1u << 24)) return 0;
+	for(uint32_t i = 1; i < st->num_points; i++)
+		if(st->points[i].sample_number != FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER && st->points[i].sample_number <= st->points[i - 1].sample_number) return 0;
+	return 1;
+}
+static int seekpoint_cmp(const void *a, const void *b)
+{
+	const FLAC__uint64 l = ((const FLAC__StreamMetadata_SeekPoint *)a)->sample_number, r = ((const FLAC__StreamMetadata_SeekPoint *)b)->sample_number;
+	return l == r ? 0 : l < r ? -1 : 1;
+}
+static void seektable_sort(FLAC__StreamMetadata_SeekTable *st)    /* sort, drop duplicates, pad with placeholders (format.c:283-313) */
+{
+	if(!st->num_points) return;
+	qsort(st->points, st->num_points, sizeof *st->points, seekpoint_cmp);
+	uint32_t j = 0;
+	for(uint32_t i = 0; i < st->num_points; i++) {
+		if(st->points[i].sample_number != FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER && j > 0 && st->points[i].sample_number == st->points[j - 1].sample_number) continue;
+		st->points[j++] = st->points[i];
+	}
+	for(; j < st->num_points; j++) { st->points[j].sample_number = FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER; st->points[j].stream_offset = 0; st->points[j].frame_samples = 0; }
+}
+static int cuesheet_is_legal(const FLAC__StreamMetadata_CueSheet *cs)
+{
+	const int cd = cs->is_cd;
+	if(cd && (cs->lead_in < 2 * 44100 || cs->lead_in % 588)) return 0;
+	if(cs->num_tracks == 0) return 0;
+	if(cd && cs->tracks[cs->num_tracks - 1].number != 170) return 0;
+	for(uint32_t i = 0; i < cs->num_tracks; i++) {
+		const FLAC__StreamMetadata_CueSheet_Track *t = &cs->tracks[i];
+		if(t->number == 0) return 0;
+		if(cd && !((t->number >= 1 && t->number <= 99) || t->number == 170)) return 0;
+		if(cd && t->offset % 588) return 0;
+		if(i + 1 < cs->num_tracks && (t->num_indices == 0 || t->indices[0].number > 1)) return 0;
+		for(uint32_t j = 0; j < t->num_indices; j++) {
+			if(cd && t->indices[j].offset % 588) return 0;
+			if(j && t->indices[j].number != t->indices[j - 1].number + 1) return 0;
+		}
+	}
+	return 1;
+}
+static int picture_is_legal(const FLAC__StreamMetadata_Picture *pic)
+{
+	for(const char *c = pic->mime_type; *c; c++) if(*c < 0x20 || *c > 0x7e) return 0;
+	for(const uint8_t *d = pic->description; *d;) { const unsigned n = utf8_len(d); if(!n) return 0; d += n; }
+	return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * stream output: the bookkeeping of write_frame_ / write_bitbuffer_ (stream_encoder.c:2988-3136)
+ * ---------------------------------------------------------------------------------------------- */
+static int emit(FLAC__StreamEncoder *e, const uint8_t *buf, size_t bytes, uint32_t samples)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	FLAC__uint64 pos = 0;
+	if(samples == 0) {
+		/* watch STREAMINFO and the first SEEKTABLE go by to learn their offsets */
+		const unsigned type = buf[0] & 0x7f;
+		if(p->tell_cb && p->tell_cb(e, &pos, p->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
+		if(type == FLAC__METADATA_TYPE_STREAMINFO) PROT(e)->streaminfo_offset = pos;
+		else if(type == FLAC__METADATA_TYPE_SEEKTABLE && PROT(e)->seektable_offset == 0) PROT(e)->seektable_offset = pos;
+	}
+	if(p->seek_table && PROT(e)->audio_offset > 0 && p->seek_table->num_points > 0) {
+		/* fill every template seek point that falls into this frame (:3070-3103) */
+		const uint32_t bs = FLAC__stream_encoder_get_blocksize(e);
+		const FLAC__uint64 first = p->samples_written, last = first + bs - 1;
+		for(uint32_t i = p->first_seekpoint_to_check; i < p->seek_table->num_points; i++) {
+			const FLAC__uint64 t = p->seek_table->points[i].sample_number;
+			if(t > last) break;
+			if(t >= first) {
+				if(pos == 0 && p->tell_cb && p->tell_cb(e, &pos, p->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
+				p->seek_table->points[i].sample_number = first;
+				p->seek_table->points[i].stream_offset = pos - PROT(e)->audio_offset;
+				p->seek_table->points[i].frame_samples = bs;
+			}
+			p->first_seekpoint_to_check++;
+		}
+	}
+	if(p->write_cb(e, buf, bytes, samples, p->current_frame_number, p->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) {
+		PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+		return 0;
+	}
+	p->bytes_written += bytes;
+	p->samples_written += samples;
+	if(p->current_frame_number + 1 > p->frames_written) p->frames_written = p->current_frame_number + 1;
+	if(samples > 0) {
+		FLAC__StreamMetadata_StreamInfo *si = &p->streaminfo.data.stream_info;
+		if(bytes < si->min_framesize) si->min_framesize = (uint32_t)bytes;
+		if(bytes > si->max_framesize) si->max_framesize = (uint32_t)bytes;
+	}
+	return 1;
+}
+
+static int emit_block(FLAC__StreamEncoder *e, const FLAC__StreamMetadata *m)
+{
+	bytebuf b = {0, 0, 0, 0};
+	int ok = serialise_block(m, &b);
+	if(!ok) PROT(e)->state = b.bad ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+	else ok = emit(e, b.p, b.n, 0);
+	free(b.p);
+	return ok;
+}
+
+/* Encode `nframes` staged blocks on the GPU and deliver them in order; `tail` = samples of a short last block
+ * (0: all full).  MD5 runs over exactly the samples being encoded, in stream order (:3448). */
+static int flush_frames(FLAC__StreamEncoder *e, uint32_t nframes, uint32_t tail)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	const flacgpu_host_settings *s = &PROT(e)->s;
+	const uint32_t N = s->blocksize, C = s->channels;
+	const size_t nsamp = (size_t)(nframes - 1) * N + (tail ? tail : N);
+	if(s->do_md5) flacgpu_host_md5_pcm(&p->md5, p->stage, C, nsamp, (s->bits_per_sample + 7) / 8);
+	const float *tw = 0;
+	if(tail && s->max_lpc_order > 0) {
+		/* windows are recomputed for the short block, as resize_buffers_ does at finish (:1703-1711) */
+		float *w = realloc(p->tail_windows, sizeof(float) * s->num_apodizations * tail);
+		if(!w) { PROT(e)->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		p->tail_windows = w;
+		flacgpu_host_windows(s, tail, w);
+		tw = w;
+	}
+	const int64_t total = flacgpu_encode_batch(p->gpu, p->stage, nframes, p->current_frame_number, tail, tw, p->out, p->out_cap, p->frame_bytes);
+	if(total < 0) {
+		fprintf(stderr, "libFLACgpu: flacgpu_encode_batch failed: %s\n", flacgpu_strerror((int)total));
+		PROT(e)->state = total == FLACGPU_ERR_ALLOC ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+		return 0;
+	}
+	const uint8_t *q = p->out;
+	for(uint32_t f = 0; f < nframes; f++) {
+		const uint32_t samples = (f + 1 == nframes && tail) ? tail : N;
+		p->frame_blocksize = samples;
+		if(!emit(e, q, p->frame_bytes[f], samples)) return 0;
+		q += p->frame_bytes[f];
+		p->current_frame_number++;
+		p->streaminfo.data.stream_info.total_samples += samples;
+	}
+	p->frame_blocksize = 0;
+	return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * init (stream_encoder.c:707-1440)
+ * ---------------------------------------------------------------------------------------------- */
+static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__StreamEncoderWriteCallback wcb, FLAC__StreamEncoderSeekCallback scb,
+                                                 FLAC__StreamEncoderTellCallback tcb, FLAC__StreamEncoderMetadataCallback mcb, void *client_data, int is_ogg)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	flacgpu_host_settings *s = &PROT(e)->s;
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(is_ogg) return FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER;     /* FLAC__HAS_OGG == 0 (:725) */
+	if(!wcb || (scb && !tcb)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS;
+	const int st = flacgpu_host_settings_resolve(s);          /* the checks and defaults of :729-829; codes are the enum's */
+	if(st != FGH_INIT_OK) return (FLAC__StreamEncoderInitStatus)st;
+
+	/* client metadata (:866-925) */
+	p->seek_table = 0;
+	if(!PROT(e)->metadata && PROT(e)->num_metadata_blocks) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+	int has_seektable = 0, has_vc = 0, icon1 = 0, icon2 = 0;
+	for(uint32_t i = 0; i < PROT(e)->num_metadata_blocks; i++) {
+		FLAC__StreamMetadata *m = PROT(e)->metadata[i];
+		if(!m) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+		switch(m->type) {
+			case FLAC__METADATA_TYPE_STREAMINFO: return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+			case FLAC__METADATA_TYPE_SEEKTABLE:
+				if(has_seektable++ || !seektable_is_legal(&m->data.seek_table)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				p->seek_table = &m->data.seek_table;
+				break;
+			case FLAC__METADATA_TYPE_VORBIS_COMMENT:
+				if(has_vc++) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				break;
+			case FLAC__METADATA_TYPE_CUESHEET:
+				if(!cuesheet_is_legal(&m->data.cue_sheet)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				break;
+			case FLAC__METADATA_TYPE_PICTURE:
+				if(!picture_is_legal(&m->data.picture)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				if(m->data.picture.type == 1) {     /* the one 32x32 PNG file icon */
+					if(icon1++) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+					if((strcmp(m->data.picture.mime_type, "image/png") && strcmp(m->data.picture.mime_type, "-->")) || m->data.picture.width != 32 || m->data.picture.height != 32)
+						return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				}
+				else if(m->data.picture.type == 2 && icon2++) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				break;
+			default: break;
+		}
+	}
+
+	/* the GPU engine; features it does not implement are refused, never approximated */
+	if(s->verify) {
+		fprintf(stderr, "libFLACgpu: set_verify(true) needs the stream decoder, which this library does not contain\n");
+		PROT(e)->state = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR;
+		return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	}
+	{
+		const char *env = getenv("FLACGPU_BATCH_FRAMES");
+		long bf = env ? strtol(env, 0, 10) : 512;
+		if(bf < 1) bf = 1; else if(bf > 65536) bf = 65536;
+		p->batch_frames = (uint32_t)bf;
+		env = getenv("FLACGPU_DEVICE");
+		const int device = env ? atoi(env) : 0;
+		flacgpu_config cfg;
+		int r = flacgpu_host_engine_config(s, device, p->batch_frames, &cfg);
+		float *windows = 0;
+		if(r == FLACGPU_OK && s->max_lpc_order > 0) {
+			windows = malloc(sizeof(float) * s->num_apodizations * s->blocksize);
+			if(!windows) r = FLACGPU_ERR_ALLOC; else flacgpu_host_windows(s, s->blocksize, windows);
+		}
+		if(r == FLACGPU_OK) r = flacgpu_create(&cfg, windows, &p->gpu);
+		free(windows);
+		if(r == FLACGPU_OK) {
+			p->out_cap = flacgpu_max_output_bytes(p->gpu, p->batch_frames);
+			p->out = malloc(p->out_cap);
+			p->frame_bytes = malloc(sizeof(uint32_t) * p->batch_frames);
+			p->stage = flacgpu_alloc_pinned(sizeof(int32_t) * s->channels * ((size_t)p->batch_frames * s->blocksize + 1));
+			if(!p->out || !p->frame_bytes || !p->stage) r = FLACGPU_ERR_ALLOC;
+		}
+		if(r != FLACGPU_OK) {
+			fprintf(stderr, "libFLACgpu: cannot create the GPU frame engine: %s\n", flacgpu_strerror(r));
+			release_engine(e);
+			PROT(e)->state = r == FLACGPU_ERR_ALLOC ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+			/* state must read UNINITIALIZED-or-error; the reference leaves the error state set here too */
+			return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+		}
+	}
+
+	p->write_cb = wcb; p->seek_cb = scb; p->tell_cb = tcb; p->metadata_cb = mcb; p->client_data = client_data;
+	p->staged = 0; p->current_frame_number = 0; p->frame_blocksize = 0;
+	p->first_seekpoint_to_check = 0; p->samples_written = 0;
+	PROT(e)->streaminfo_offset = PROT(e)->seektable_offset = PROT(e)->audio_offset = 0;
+	PROT(e)->state = FLAC__STREAM_ENCODER_OK;
+
+	/* "fLaC", STREAMINFO with the unknowns zeroed, a VORBIS_COMMENT if the client gave none, client blocks (:1335-1425) */
+	if(!emit(e, (const uint8_t *)"fLaC", 4, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	memset(&p->streaminfo, 0, sizeof p->streaminfo);
+	p->streaminfo.type = FLAC__METADATA_TYPE_STREAMINFO;
+	p->streaminfo.is_last = 0;
+	p->streaminfo.length = 34;
+	FLAC__StreamMetadata_StreamInfo *si = &p->streaminfo.data.stream_info;
+	si->min_blocksize = si->max_blocksize = s->blocksize;
+	si->sample_rate = s->sample_rate; si->channels = s->channels; si->bits_per_sample = s->bits_per_sample;
+	si->total_samples = s->total_samples_estimate;
+	if(s->do_md5) flacgpu_host_md5_init(&p->md5);
+	if(!emit_block(e, &p->streaminfo)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	si->min_framesize = (1u << 24) - 1;
+	si->total_samples = 0;
+	if(!has_vc) {
+		FLAC__StreamMetadata vc;
+		memset(&vc, 0, sizeof vc);
+		vc.type = FLAC__METADATA_TYPE_VORBIS_COMMENT;
+		vc.is_last = PROT(e)->num_metadata_blocks == 0;
+		vc.length = 8;
+		if(!emit_block(e, &vc)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	}
+	for(uint32_t i = 0; i < PROT(e)->num_metadata_blocks; i++) {
+		PROT(e)->metadata[i]->is_last = i + 1 == PROT(e)->num_metadata_blocks;
+		if(!emit_block(e, PROT(e)->metadata[i])) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	}
+	if(p->tell_cb && p->tell_cb(e, &PROT(e)->audio_offset, p->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) {
+		PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+		return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	}
+	return FLAC__STREAM_ENCODER_INIT_STATUS_OK;
+}
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_stream(FLAC__StreamEncoder *e, FLAC__StreamEncoderWriteCallback wcb, FLAC__StreamEncoderSeekCallback scb,
+                                                               FLAC__StreamEncoderTellCallback tcb, FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
+{
+	return init_common(e, wcb, scb, tcb, mcb, client_data, 0);
+}
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_stream(FLAC__StreamEncoder *e, FLAC__StreamEncoderReadCallback rcb, FLAC__StreamEncoderWriteCallback wcb,
+                                                                   FLAC__StreamEncoderSeekCallback scb, FLAC__StreamEncoderTellCallback tcb,
+                                                                   FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
+{
+	(void)rcb;
+	return init_common(e, wcb, scb, tcb, mcb, client_data, 1);
+}
+
+/* FILE* flavour: our own write/seek/tell callbacks plus the progress callback per frame (:5258-5327) */
+static FLAC__StreamEncoderWriteStatus file_write(const FLAC__StreamEncoder *e, const FLAC__byte buf[], size_t bytes, uint32_t samples, uint32_t frame, void *cd)
+{
+	(void)cd; (void)frame;
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	if(fwrite(buf, 1, bytes, p->file) != bytes) return FLAC__STREAM_ENCODER_WRITE_STATUS_FATAL_ERROR;
+	if(p->progress_cb && samples > 0)     /* the counters are only advanced after we return, hence the +bytes/+samples/+1 */
+		p->progress_cb(e, p->bytes_written + bytes, p->samples_written + samples, p->frames_written + 1, p->total_frames_estimate, p->client_data);
+	return FLAC__STREAM_ENCODER_WRITE_STATUS_OK;
+}
+static FLAC__StreamEncoderSeekStatus file_seek(const FLAC__StreamEncoder *e, FLAC__uint64 off, void *cd)
+{
+	(void)cd;
+	return fseeko(PRIV(e)->file, (off_t)off, SEEK_SET) < 0 ? FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR : FLAC__STREAM_ENCODER_SEEK_STATUS_OK;
+}
+static FLAC__StreamEncoderTellStatus file_tell(const FLAC__StreamEncoder *e, FLAC__uint64 *off, void *cd)
+{
+	(void)cd;
+	const off_t o = ftello(PRIV(e)->file);
+	if(o < 0) return FLAC__STREAM_ENCODER_TELL_STATUS_ERROR;
+	*off = (FLAC__uint64)o;
+	return FLAC__STREAM_ENCODER_TELL_STATUS_OK;
+}
+
+static FLAC__StreamEncoderInitStatus init_FILE_common(FLAC__StreamEncoder *e, FILE *file, FLAC__StreamEncoderProgressCallback pcb, void *client_data, int is_ogg)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(!file) { PROT(e)->state = FLAC__STREAM_ENCODER_IO_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	p->file = file;                            /* owned from here on: closed by finish() even when init fails (:1497-1502) */
+	p->progress_cb = pcb;
+	p->bytes_written = 0; p->samples_written = 0; p->frames_written = 0;
+	const int to_stdout = file == stdout;
+	const FLAC__StreamEncoderInitStatus st = init_common(e, file_write, to_stdout ? 0 : file_seek, to_stdout ? 0 : file_tell, 0, client_data, is_ogg);
+	if(st != FLAC__STREAM_ENCODER_INIT_STATUS_OK) return st;
+	p->progress_cb = pcb;
+	const uint32_t bs = PROT(e)->s.blocksize;
+	p->total_frames_estimate = (uint32_t)((PROT(e)->s.total_samples_estimate + bs - 1) / bs);
+	return st;
+}
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_FILE(FLAC__StreamEncoder *e, FILE *file, FLAC__StreamEncoderProgressCallback pcb, void *cd) { return init_FILE_common(e, file, pcb, cd, 0); }
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_FILE(FLAC__StreamEncoder *e, FILE *file, FLAC__StreamEncoderProgressCallback pcb, void *cd) { return init_FILE_common(e, file, pcb, cd, 1); }
+
+static FLAC__StreamEncoderInitStatus init_file_common(FLAC__StreamEncoder *e, const char *filename, FLAC__StreamEncoderProgressCallback pcb, void *cd, int is_ogg)
+{
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+	FILE *f = filename ? fopen(filename, "w+b") : stdout;      /* NULL filename = stdout (:1578) */
+	if(!f) { PROT(e)->state = FLAC__STREAM_ENCODER_IO_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	return init_FILE_common(e, f, pcb, cd, is_ogg);
+}
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_file(FLAC__StreamEncoder *e, const char *fn, FLAC__StreamEncoderProgressCallback pcb, void *cd) { return init_file_common(e, fn, pcb, cd, 0); }
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_file(FLAC__StreamEncoder *e, const char *fn, FLAC__StreamEncoderProgressCallback pcb, void *cd) { return init_file_common(e, fn, pcb, cd, 1); }
+
+/* ------------------------------------------------------------------------------------------------
+ * process (stream_encoder.c:2513-2626): range check, stage, release full batches
+ * ---------------------------------------------------------------------------------------------- */
+static int release_if_full(FLAC__StreamEncoder *e)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	const uint32_t N = PROT(e)->s.blocksize, C = PROT(e)->s.channels;
+	const size_t full = (size_t)p->batch_frames * N;
+	if(p->staged <= full) return 1;            /* one sample beyond the batch must exist (the overread) */
+	if(!flush_frames(e, p->batch_frames, 0)) return 0;
+	memcpy(p->stage, p->stage + full * C, sizeof(int32_t) * C);
+	p->staged = 1;
+	return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, const FLAC__int32 buffer[], uint32_t samples)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_OK) return 0;
+	const uint32_t N = PROT(e)->s.blocksize, C = PROT(e)->s.channels, bps = PROT(e)->s.bits_per_sample;
+	const int32_t smax = INT32_MAX >> (32 - bps), smin = INT32_MIN >> (32 - bps);
+	const size_t cap = (size_t)p->batch_frames * N + 1;
+	uint32_t j = 0;
+	while(j < samples) {
+		size_t n = cap - p->staged;
+		if(n > samples - j) n = samples - j;
+		const int32_t *src = buffer + (size_t)j * C;
+		int32_t *dst = p->stage + p->staged * C;
+		int32_t lo = 0, hi = 0;
+		for(size_t k = 0; k < n * C; k++) { const int32_t v = src[k]; dst[k] = v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+		if(lo < smin || hi > smax) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
+		p->staged += n; j += (uint32_t)n;
+		if(!release_if_full(e)) return 0;
+	}
+	return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *e, const FLAC__int32 * const buffer[], uint32_t samples)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_OK) return 0;
+	const uint32_t N = PROT(e)->s.blocksize, C = PROT(e)->s.channels, bps = PROT(e)->s.bits_per_sample;
+	const int32_t smax = INT32_MAX >> (32 - bps), smin = INT32_MIN >> (32 - bps);
+	const size_t cap = (size_t)p->batch_frames * N + 1;
+	for(uint32_t c = 0; c < C; c++) if(!buffer[c]) return 0;
+	uint32_t j = 0;
+	while(j < samples) {
+		size_t n = cap - p->staged;
+		if(n > samples - j) n = samples - j;
+		for(uint32_t c = 0; c < C; c++) {
+			const int32_t *src = buffer[c] + j;
+			int32_t *dst = p->stage + p->staged * C + c;
+			int32_t lo = 0, hi = 0;
+			for(size_t k = 0; k < n; k++) { const int32_t v = src[k]; dst[k * C] = v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+			if(lo < smin || hi > smax) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
+		}
+		p->staged += n; j += (uint32_t)n;
+		if(!release_if_full(e)) return 0;
+	}
+	return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * finish (stream_encoder.c:1625-1778) and the STREAMINFO / SEEKTABLE fix-up (update_metadata_, :3139-3298)
+ * ---------------------------------------------------------------------------------------------- */
+static int rewrite(FLAC__StreamEncoder *e, FLAC__uint64 offset, const uint8_t *b, size_t n)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	const FLAC__StreamEncoderSeekStatus ss = p->seek_cb(e, offset, p->client_data);
+	if(ss != FLAC__STREAM_ENCODER_SEEK_STATUS_OK) { if(ss == FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR) PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
+	if(p->write_cb(e, b, n, 0, 0, p->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
+	return 1;
+}
+
+static void update_metadata(FLAC__StreamEncoder *e)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	const FLAC__StreamMetadata_StreamInfo *si = &p->streaminfo.data.stream_info;
+	const FLAC__uint64 base = PROT(e)->streaminfo_offset;
+	uint8_t b[18];
+	/* MD5 at byte 4+18, then the 5 bytes holding (bps-1)<<4 | total_samples[35:32] .. total_samples[7:0] at 4+13,
+	 * then min/max frame size at 4+4 -- the order the reference seeks in */
+	if(!rewrite(e, base + 4 + 18, si->md5sum, 16)) return;
+	{
+		FLAC__uint64 t = si->total_samples;
+		if(t > ((FLAC__uint64)1 << 36)) t = 0;
+		b[0] = (uint8_t)(((si->bits_per_sample - 1) << 4) | ((t >> 32) & 0x0F));
+		b[1] = (uint8_t)(t >> 24); b[2] = (uint8_t)(t >> 16); b[3] = (uint8_t)(t >> 8); b[4] = (uint8_t)t;
+		if(!rewrite(e, base + 4 + 13, b, 5)) return;
+	}
+	b[0] = (uint8_t)(si->min_framesize >> 16); b[1] = (uint8_t)(si->min_framesize >> 8); b[2] = (uint8_t)si->min_framesize;
+	b[3] = (uint8_t)(si->max_framesize >> 16); b[4] = (uint8_t)(si->max_framesize >> 8); b[5] = (uint8_t)si->max_framesize;
+	if(!rewrite(e, base + 4 + 4, b, 6)) return;
+	if(p->seek_table && p->seek_table->num_points > 0 && PROT(e)->seektable_offset > 0) {
+		for(uint32_t i = 0; i < p->seek_table->num_points; i++)      /* template points beyond the end become placeholders */
+			if(p->seek_table->points[i].sample_number > si->total_samples) p->seek_table->points[i].sample_number = FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER;
+		seektable_sort(p->seek_table);
+		if(p->seek_cb(e, PROT(e)->seektable_offset + 4, p->client_data) != FLAC__STREAM_ENCODER_SEEK_STATUS_OK) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return; }
+		for(uint32_t i = 0; i < p->seek_table->num_points; i++) {
+			const FLAC__StreamMetadata_SeekPoint *sp = &p->seek_table->points[i];
+			for(int k = 0; k < 8; k++) { b[k] = (uint8_t)(sp->sample_number >> (56 - 8 * k)); b[8 + k] = (uint8_t)(sp->stream_offset >> (56 - 8 * k)); }
+			b[16] = (uint8_t)(sp->frame_samples >> 8); b[17] = (uint8_t)sp->frame_samples;
+			if(p->write_cb(e, b, 18, 0, 0, p->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return; }
+		}
+	}
+}
+
+FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
+{
+	if(!e) return 0;
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	int error = 0;
+	if(PROT(e)->state == FLAC__STREAM_ENCODER_UNINITIALIZED) {
+		if(PROT(e)->metadata) { free(PROT(e)->metadata); PROT(e)->metadata = 0; PROT(e)->num_metadata_blocks = 0; }
+		if(p->file) { if(p->file != stdout) fclose(p->file); p->file = 0; }
+		return 1;
+	}
+	if(PROT(e)->state == FLAC__STREAM_ENCODER_OK && !p->is_being_deleted && p->staged) {
+		/* everything still staged: full blocks, then the final one (short, or exactly full) */
+		const uint32_t N = PROT(e)->s.blocksize;
+		const uint32_t nframes = (uint32_t)((p->staged + N - 1) / N);
+		uint32_t tail = (uint32_t)(p->staged - (size_t)(nframes - 1) * N);
+		if(tail == N) tail = 0;
+		if(!flush_frames(e, nframes, tail)) error = 1;
+		p->staged = 0;
+	}
+	if(PROT(e)->s.do_md5 && p->gpu) flacgpu_host_md5_final(&p->md5, p->streaminfo.data.stream_info.md5sum);
+	if(!p->is_being_deleted && PROT(e)->state == FLAC__STREAM_ENCODER_OK) {
+		p->current_frame_number = 0;
+		if(p->seek_cb) {
+			update_metadata(e);
+			if(PROT(e)->state != FLAC__STREAM_ENCODER_OK) error = 1;
+		}
+		if(p->metadata_cb) p->metadata_cb(e, &p->streaminfo, p->client_data);
+	}
+	if(p->file) { if(p->file != stdout) fclose(p->file); p->file = 0; }
+	release_engine(e);
+	set_defaults(e);
+	if(!error) PROT(e)->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
+	return !error;
+}

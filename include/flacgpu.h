@@ -127,6 +127,11 @@ int flacgpu_last_batch_info(flacgpu_ctx *ctx, uint32_t nframes, flacgpu_subframe
  * milliseconds spent in the analysis kernel, the pack kernel and the compaction kernels. */
 int flacgpu_last_batch_kernel_ms(flacgpu_ctx *ctx, float *analyze_ms, float *pack_ms, float *compact_ms);
 
+/* Page-locked host memory for PCM staging buffers handed to flacgpu_encode_batch (the H2D copy then runs
+ * at full PCIe rate and asynchronously).  NULL when no device/runtime is available. */
+void *flacgpu_alloc_pinned(size_t bytes);
+void flacgpu_free_pinned(void *p);
+
 const char *flacgpu_strerror(int code);
 int flacgpu_device_count(void);
 
