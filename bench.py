@@ -10,7 +10,7 @@ own contiguous frame range (weak scaling, no data-path collective) and the step 
 RCCL gather of the variable-length bitstream to rank 0 (flac_amd/dist.py).
 
 Prints ONE JSON line (rank 0).  `value` = inter-channel samples encoded per second by the whole job,
-in M samples/s; `roofline` prices the dominant kernel (analyze_kernel) against HBM bandwidth with the
+in M samples/s; `roofline` prices the dominant kernel of the step (by HIP-event time) against HBM bandwidth with the
 ALGORITHMIC bytes of SURVEY.md 8d (4*C bytes of PCM in + compressed bytes out per inter-channel
 sample); `cpu_baseline` is the unmodified reference libFLAC (oracle/_ref, AVX2+FMA dispatch) timed on
 this box's host cores on a bounded sample of the same signal.
@@ -32,6 +32,8 @@ RATE, BPS, CH = 44100, 16, 2
 BLOCK = 4096
 FRAMES_PER_GPU = 4096          # 16.8 M inter-channel samples = 380 s of audio per GPU per step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+KERNEL_NAMES = {"prep": "prep_kernel", "autoc": "autoc_kernel", "model": "model_kernel", "eval": "eval_kernel",
+                "pack": "pack_kernel", "scan_compact": "scan_kernel+compact_kernel"}
 
 
 def synth_pcm(nframes, seed):
@@ -120,14 +122,14 @@ def main():
     d_fb = torch.empty(nframes, dtype=torch.int32, device=dev)
     d_total = torch.zeros(1, dtype=torch.int64, device=dev)
     first_frame = rank * nframes
-    an_ms, pk_ms, cp_ms = [], [], []
+    phase_ms = []
 
     def step(record):
         eng.encode_device(d_pcm.data_ptr(), nframes, d_out.data_ptr(), cap, d_fb.data_ptr(), d_total.data_ptr(),
                           first_frame_number=first_frame)
-        a, p, c = eng.last_kernel_ms()          # HIP events on the engine's stream (waits for this batch)
+        ph = eng.last_phase_ms()                # HIP events on the engine's stream (waits for this batch)
         if record:
-            an_ms.append(a); pk_ms.append(p); cp_ms.append(c)
+            phase_ms.append(ph)
         if world > 1:
             nbytes = int(d_total.item())
             ordered_gather(d_out, nbytes, d_fb, dst=0)
@@ -159,8 +161,9 @@ def main():
     if rank == 0:
         out_bps = total_bytes / samples_per_step                 # compressed bytes per inter-channel sample
         alg_bytes = samples_per_step * (4 * CH + out_bps)         # PCM read once + frames written once
-        an = float(np.mean(an_ms))
-        achieved = alg_bytes / (an * 1e-3) / 1e9
+        kms = {k: float(np.mean([ph[k] for ph in phase_ms])) for k in phase_ms[0]}
+        dom = max(kms, key=kms.get)                               # the dominant kernel of the step
+        achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
         line = {
             "metric": "encode Msamples/s at -8, 44.1k/16-bit stereo; bit-exact vs libFLAC",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,8 +174,8 @@ def main():
                        "frames_per_gpu_per_step": nframes, "blocksize": BLOCK, "channels": CH, "bits_per_sample": BPS,
                        "samples_are": "inter-channel (x2 for channel-samples)", "parallelism": "frame-shard x%d + ordered RCCL gather" % world,
                        "compressed_bytes_per_sample": round(out_bps, 4)},
-            "kernel_ms": {"analyze": round(an, 4), "pack": round(float(np.mean(pk_ms)), 4), "scan_compact": round(float(np.mean(cp_ms)), 4)},
-            "roofline": {"bound": "hbm", "kernel": "analyze_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "-8 is VALU/LDS bound (~1e3 integer+fp64 ops per sample); HBM fraction reported as the north star asks"},

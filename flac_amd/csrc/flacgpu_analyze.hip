@@ -1,0 +1,875 @@
+// flac_amd/csrc/flacgpu_analyze.hip -- the model search of process_subframe_ (stream_encoder.c:4045-4290)
+// as FOUR phase-specialised kernels, each with the parallel shape and occupancy its phase wants:
+//
+//   prep_kernel   workgroup per (frame, candidate channel): wasted bits (stream_encoder.c:5077), loose mid/side
+//                 (:3778), fixed-predictor sums + order guess (fixed.c:222 / fixed_intrin_avx2.c:57), CONSTANT
+//                 detection (:4111-4140).                                      -> ChanPrep, Candidate[0]
+//   autoc_kernel  WAVEFRONT per (frame, channel, window job): streams the block through a small LDS tile:
+//                 coalesced int32 loads -> window multiply (lpc.c:68-94) -> floats de-interleaved by (i mod 4) so
+//                 that each lane's two operand streams are consecutive 8-byte LDS reads -> the reference's fp64
+//                 chains (lpc_intrin_fma.c:46-72).                              -> autoc[job][lag]
+//   model_kernel  LANE per (frame, channel, analysis): punch-out subtraction (stream_encoder.c:4370), Levinson-
+//                 Durbin, order guess, quantisation (lpc.c:176,1608,220).       -> Candidate[1+analysis]
+//   eval_kernel   workgroup per (frame, channel), one wavefront per residual candidate: each lane OWNS n/64
+//                 consecutive samples (so a lane's |residual| sum is a whole leaf partition, no cross-lane
+//                 reduction), 16-bit channels run the FIR as v_dot2_i32_i16 on packed sample pairs, Rice search
+//                 as a butterfly over partition orders (stream_encoder.c:4701-5075), first-minimum winner.
+//                                                                               -> SubDecision
+//
+// The hand-off records between the kernels are a few hundred bytes per channel; residuals and windowed data never
+// reach HBM.  Integer + fp64 VALU work: no MFMA by design.  Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "flacgpu_dev.h"
+#include "flacgpu_devfn.h"
+
+namespace flacgpu {
+
+// XCD-aware mapping (blocks round-robin over the 8 XCDs): keep the candidate channels of one frame on one XCD so
+// that their shared PCM lines hit that XCD's L2.
+__device__ __forceinline__ void map_block(uint32_t b, uint32_t nframes, uint32_t ncand, uint32_t &f, uint32_t &cand)
+{
+	const uint32_t total = nframes * ncand;
+	const uint32_t per_xcd_full = (total / (8 * ncand)) * ncand;
+	const uint32_t head = per_xcd_full * 8;
+	const uint32_t lin = b < head ? (b & 7) * per_xcd_full + (b >> 3) : b;
+	f = lin / ncand; cand = lin % ncand;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// prep_kernel
+// ---------------------------------------------------------------------------------------------------------
+template <int DUMMY>
+__global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nframes, uint32_t tail_n,
+                                                   ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	__shared__ uint64_t scratch[8];
+	__shared__ uint64_t red[(TPB / 64) * 5];
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t C = P.channels, N = P.blocksize;
+	uint32_t f, cand;
+	map_block(blockIdx.x, nframes, P.ncand, f, cand);
+	const bool is_tail = tail_n != 0 && f == nframes - 1;
+	const uint32_t n = is_tail ? tail_n : N;
+	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
+	int32_t *sig = (int32_t *)smem;
+	const size_t fc = (size_t)f * P.ncand + cand;
+	const uint32_t cstride = P.max_analyses + 1;
+
+	uint32_t which = cand;
+	if(P.ms_mode == 2) {
+		// loose mid/side (stream_encoder.c:3778-3807): both workgroups of the frame compute the decision
+		uint64_t lr = 0, ms = 0;
+		const int2 *p = (const int2 *)frame_pcm;
+		for(uint32_t i = 1 + (uint32_t)tid; i < n; i += TPB) {
+			const int2 a = p[i], b = p[i - 1];
+			const int32_t pl = a.x - b.x, pr = a.y - b.y;
+			lr += (uint64_t)(uint32_t)(abs(pl) + abs(pr));
+			ms += (uint64_t)(uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
+		}
+		lr = block_reduce_add_u64(lr, scratch, tid);
+		ms = block_reduce_add_u64(ms, scratch, tid);
+		if(!(lr < ms)) which = 2 + cand;
+	}
+	// limit_min_bitrate (stream_encoder.c:3874-3879)
+	bool disable_constant = P.disable_constant != 0;
+	if(P.limit_min_bitrate && !disable_constant && (P.ms_mode == 2 ? which == 1 : which >= C - 1)) {
+		uint32_t diff = 0;
+		for(uint32_t i = (uint32_t)tid; i < n; i += TPB)
+			for(uint32_t c = 0; c + 1 < C; c++) diff |= (uint32_t)(frame_pcm[(size_t)i * C + c] ^ frame_pcm[c]);
+		diff = block_reduce_or_u32(diff, scratch, tid);
+		if(diff == 0) disable_constant = true;
+	}
+	uint32_t orv;
+	load_signal(sig, frame_pcm, C, n, which, &orv, tid);
+	orv = block_reduce_or_u32(orv, scratch, tid);
+	uint32_t wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
+	if(wasted > P.bps) wasted = P.bps;
+	if(wasted) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) sig[sigidx((int)i)] >>= wasted;
+	const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
+	__syncthreads();
+
+	uint32_t flags = 0, fixed_order = 0;
+	int32_t constant = 0;
+	const uint32_t verbatim_bits = (P.disable_verbatim && n >= 4) ? 0xffffffffu : 8 + wasted + n * sbps;
+	if(n > 4) {
+		// fixed predictor estimate (fixed.c:222 / fixed_intrin_avx2.c:57)
+		const uint32_t n4 = n - 4;
+		const bool fwide = !(sbps + ilog2_u32(n4 * 17) < 32);
+		uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+		if(!fwide || (n4 & 3) == 0) {
+			for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * TPB) {
+				int32_t x[CHUNK + 4];
+#pragma unroll
+				for(int k = 0; k < CHUNK + 4; k++) x[k] = sig[sigidx((int)base - 4 + k)];
+				uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+				for(int t = 0; t < CHUNK; t++) {
+					const uint32_t i = base + t;
+					if(i >= 4 && i < n) {
+						const int32_t a0 = x[t + 4], a1 = x[t + 3], a2 = x[t + 2], a3 = x[t + 1], a4 = x[t];
+						const int32_t d1 = a0 - a1, d2 = a0 - 2 * a1 + a2, d3 = a0 - 3 * a1 + 3 * a2 - a3, d4 = a0 - 4 * a1 + 6 * a2 - 4 * a3 + a4;
+						s0 += (uint32_t)abs(a0); s1 += (uint32_t)abs(d1); s2 += (uint32_t)abs(d2); s3 += (uint32_t)abs(d3); s4 += (uint32_t)abs(d4);
+					}
+				}
+				e0 += s0; e1 += s1; e2 += s2; e3 += s3; e4 += s4;
+			}
+		}
+		else {
+			// fixed_intrin_avx2.c:57 with (n-4) % 4 != 0 (short last blocks): restated literally
+			const uint32_t q = n4 / 4;
+			for(uint32_t l = 0; l < 4; l++) {
+				const int hist = (int)(l * q), start = (int)(((uint64_t)l * n4) / 4);
+				for(uint32_t i = (uint32_t)tid; i < q; i += TPB) {
+					int64_t v[5];
+#pragma unroll
+					for(int j = 0; j < 5; j++) { const int m = (int)i - j; v[j] = sig[sigidx(4 + (m >= 0 ? start + m : hist + m))]; }
+					const int64_t d0 = v[0], d1 = v[0] - v[1], d2 = v[0] - 2 * v[1] + v[2], d3 = v[0] - 3 * v[1] + 3 * v[2] - v[3],
+					              d4 = v[0] - 4 * v[1] + 6 * v[2] - 4 * v[3] + v[4];
+					e0 += (uint64_t)(d0 < 0 ? -d0 : d0); e1 += (uint64_t)(d1 < 0 ? -d1 : d1); e2 += (uint64_t)(d2 < 0 ? -d2 : d2);
+					e3 += (uint64_t)(d3 < 0 ? -d3 : d3); e4 += (uint64_t)(d4 < 0 ? -d4 : d4);
+				}
+			}
+		}
+		e0 = wave_reduce_add_u64(e0); e1 = wave_reduce_add_u64(e1); e2 = wave_reduce_add_u64(e2);
+		e3 = wave_reduce_add_u64(e3); e4 = wave_reduce_add_u64(e4);
+		if(lane == 0) { red[wave * 5 + 0] = e0; red[wave * 5 + 1] = e1; red[wave * 5 + 2] = e2; red[wave * 5 + 3] = e3; red[wave * 5 + 4] = e4; }
+		__syncthreads();
+		e0 = e1 = e2 = e3 = e4 = 0;
+		for(int w = 0; w < TPB / 64; w++) { e0 += red[w * 5 + 0]; e1 += red[w * 5 + 1]; e2 += red[w * 5 + 2]; e3 += red[w * 5 + 3]; e4 += red[w * 5 + 4]; }
+		uint32_t guess_fixed;
+		{
+			const uint64_t m34 = e3 < e4 ? e3 : e4, m234 = e2 < m34 ? e2 : m34, m1234 = e1 < m234 ? e1 : m234;
+			if(e0 <= m1234) guess_fixed = 0;
+			else if(e1 <= m234) guess_fixed = 1;
+			else if(e2 <= m34) guess_fixed = 2;
+			else if(e3 <= e4) guess_fixed = 3;
+			else guess_fixed = 4;
+		}
+		const uint64_t eg = guess_fixed == 0 ? e0 : guess_fixed == 1 ? e1 : guess_fixed == 2 ? e2 : guess_fixed == 3 ? e3 : e4;
+		// rbps = (float)(log(M_LN2*err/n)/M_LN2) as compiled (fixed.c:284-288)
+		const float rbps_guess = eg ? (float)(log(((double)eg * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
+		const bool rbps1_zero = e1 == 0 || (float)(log(((double)e1 * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) == 0.0f;
+		bool is_constant = false;
+		if(!disable_constant && rbps1_zero) {
+			uint32_t diff = 0;
+			const int32_t first = sig[sigidx(0)];
+			for(uint32_t i = (uint32_t)tid; i < n; i += TPB) diff |= (uint32_t)(sig[sigidx((int)i)] ^ first);
+			diff = block_reduce_or_u32(diff, scratch, tid);
+			is_constant = diff == 0;
+		}
+		if(is_constant) { flags |= PREP_CONSTANT; constant = sig[sigidx(0)]; }
+		else {
+			if(!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu)) {
+				fixed_order = guess_fixed;
+				if(!(rbps_guess >= (float)sbps)) flags |= PREP_FIXED_VALID;
+			}
+			if(P.max_lpc_order > 0) flags |= PREP_LPC;          // n > 4, so at least order 4 is possible
+		}
+	}
+	// hand-off
+	if(tid < MAX_ORDER) {
+		const uint32_t order = fixed_order;
+		int32_t c = 0;
+		if(order == 1) c = tid == 0 ? 1 : 0;
+		else if(order == 2) c = tid == 0 ? 2 : tid == 1 ? -1 : 0;
+		else if(order == 3) c = tid == 0 ? 3 : tid == 1 ? -3 : tid == 2 ? 1 : 0;
+		else if(order == 4) c = tid == 0 ? 4 : tid == 1 ? -6 : tid == 2 ? 4 : tid == 3 ? -1 : 0;
+		cands[fc * cstride].q[tid] = c;
+	}
+	if(tid == 0) {
+		Candidate *c0 = &cands[fc * cstride];
+		c0->order = fixed_order; c0->precision = 0; c0->shift = 0; c0->wide = 0;
+		valid[fc * cstride] = (flags & PREP_FIXED_VALID) ? 1 : 0;
+		ChanPrep pr;
+		pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
+		pr.constant = constant; pr.verbatim_bits = verbatim_bits;
+		preps[fc] = pr;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// autoc_kernel
+// ---------------------------------------------------------------------------------------------------------
+// LDS tile of one wavefront: windowed floats of AT block samples + 16 samples of history, de-interleaved into four
+// planes by (i mod 4).  With i = origin + 4*(e - AHE) + r, plane r element e.  Two copies: A at r*APS + e, and B
+// shifted by one float, so that a pair (e, e+1) is an aligned 8-byte read in one of them whatever the parity of e.
+constexpr int AT = 256;                 // new samples per tile = 32 chain steps
+constexpr int AHE = 4;                  // history elements per plane (16 samples >= any lag)
+constexpr int APS = 72;                 // plane stride in floats (AHE + AT/4 = 68, padded: planes 8 banks apart)
+constexpr int ATILE = 8 * APS + 2;      // floats: copy A (4 planes), copy B (4 planes, +1)
+constexpr int AHEAD = 32, ATAIL = 40;   // plain copies of d[0,32) and d[nd-40,nd) for the scalar head/tail code
+__device__ __forceinline__ int aoffA(int r, int e) { return r * APS + e; }
+__device__ __forceinline__ int aoffB(int r, int e) { return 4 * APS + r * APS + e + 1; }
+
+struct AutocWave {
+	float tile[ATILE + 6];
+	float head[AHEAD];
+	float tail[ATAIL];
+	double acc4[MAX_ORDER][4];
+};
+
+// windowed sample i of a job (lpc.c:68 full block, lpc.c:82-94 partial window), 0 beyond the job's data
+struct JobView {
+	const int32_t *frame_pcm; const float *w; uint32_t C, which, wasted, n, nd;
+	uint32_t full, part, dshift, i0;
+};
+__device__ __forceinline__ void job_fetch(const JobView &J, uint32_t i, int32_t &v, float &wt)
+{
+	v = 0; wt = 0.0f;
+	if(i < J.nd) {
+		uint32_t src, widx; bool on = true;
+		if(J.full) { src = i; widx = i; }
+		else {
+			src = J.dshift + i;
+			const bool hi = i >= J.i0 && i < J.i0 + J.part;
+			if(hi) widx = J.n - J.part + (i - J.i0);
+			else if(i < J.part) widx = i;
+			else { widx = 0; on = false; }
+		}
+		if(on) {
+			wt = J.w[widx];
+			if(J.C == 2) {
+				const int2 lr = ((const int2 *)J.frame_pcm)[src];
+				v = J.which == 0 ? lr.x : J.which == 1 ? lr.y : J.which == 2 ? ((lr.x + lr.y) >> 1) : (lr.x - lr.y);
+			}
+			else v = pick_channel(J.frame_pcm, J.C, src, J.which);
+		}
+	}
+}
+__device__ __forceinline__ float job_value(const JobView &J, int32_t v, float wt) { return (float)(v >> J.wasted) * wt; }
+
+// one chain step of lpc_intrin_fma.c:46,61 on stream elements: x = d[i], d[i+4]; y = d[i-j], d[i+4-j]
+#define STEP816(acc, xs, ys, u) acc += fma((double)(xs)[2 * (u)], (double)(ys)[2 * (u)], (double)(xs)[2 * (u) + 1] * (double)(ys)[2 * (u) + 1])
+
+template <int DUMMY>
+__global__ __launch_bounds__(TPB) void autoc_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
+                                                    const float *__restrict__ tail_windows, uint32_t nframes, uint32_t tail_n,
+                                                    const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
+                                                    const ChanPrep *__restrict__ preps, double *__restrict__ autoc_out)
+{
+	__shared__ AutocWave sh[TPB / 64];
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	AutocWave &W = sh[wave];
+	const uint32_t njobs_main = P.max_jobs;
+	const uint32_t item = blockIdx.x * (TPB / 64) + (uint32_t)wave;
+	const uint32_t total = nframes * P.ncand * njobs_main;
+	if(item >= total) return;
+	// longest jobs first within a frame-channel: jobs are enumerated full, halves, thirds ... already
+	const uint32_t fc = item / njobs_main, jb = item - fc * njobs_main;
+	const uint32_t f = fc / P.ncand;
+	const bool is_tail = tail_n != 0 && f == nframes - 1;
+	const JobTable *jt = is_tail ? jt_tail : jt_main;
+	const ChanPrep pr = preps[fc];
+	if(!(pr.flags & PREP_LPC) || jb >= jt->njobs) return;
+	const uint32_t n = pr.n;
+	const uint32_t max_lpc = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
+	const uint32_t lag = max_lpc + 1;
+	const uint32_t variant = n <= 32 ? 0u : P.autoc_variant;
+	const WindowJob jv = jt->jobs[jb];
+	JobView J;
+	J.frame_pcm = pcm + (size_t)f * P.blocksize * P.channels;
+	J.w = (is_tail ? tail_windows : windows) + (size_t)jv.apod * n;
+	J.C = P.channels; J.which = pr.which; J.wasted = pr.wasted; J.n = n; J.nd = jv.nd;
+	J.full = jv.full; J.part = jv.part; J.dshift = jv.dshift; J.i0 = jv.i0;
+	const uint32_t nd = jv.nd;
+	const uint32_t tail_lo = nd > (uint32_t)ATAIL ? nd - ATAIL : 0;
+	double *out = autoc_out + ((size_t)fc * P.max_jobs + jb) * MAX_ORDER;
+
+	// plain head / tail copies
+	if(lane < AHEAD) { int32_t v; float wt; job_fetch(J, (uint32_t)lane, v, wt); W.head[lane] = job_value(J, v, wt); }
+	if(lane < ATAIL) { int32_t v; float wt; job_fetch(J, tail_lo + (uint32_t)lane, v, wt); W.tail[lane] = job_value(J, v, wt); }
+
+	if(variant == 0) {
+		// lpc.c:133-157 (blocksize <= 32): the whole job sits in W.tail (tail_lo == 0)
+		__builtin_amdgcn_wave_barrier();
+		if((uint32_t)lane < lag) out[lane] = autoc_small(W.tail, nd, (uint32_t)lane);
+		return;
+	}
+	const uint32_t L = variant;
+	const uint32_t nb = (nd - L) / 8;
+	const uint32_t j = (uint32_t)lane >> 2, l = (uint32_t)lane & 3;
+	// this lane's operand streams inside a tile
+	const int fl = (int)l - (int)j >= 0 ? 0 : -(((int)j - (int)l + 3) / 4);     // floor((l-j)/4)
+	const int ry = (((int)l - (int)j) % 4 + 4) % 4;
+	const int ey = AHE + fl;
+	const float *xs = W.tile + aoffA((int)l, AHE);
+	const float *ys = W.tile + ((ey & 1) ? aoffB(ry, ey) : aoffA(ry, ey));
+	double acc = 0.0;
+	const uint32_t npairs12 = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;            // lag-12 routine: steps taken two at a time
+	const uint32_t ntiles = (nb + 31) / 32;
+
+	// tile 0 history: d[L-16, L)
+	if(lane < 16) {
+		const int i = (int)L - 16 + lane;
+		int32_t v = 0; float wt = 0.0f;
+		if(i >= 0) job_fetch(J, (uint32_t)i, v, wt);
+		const float d = job_value(J, v, wt);
+		const int r = i & 3, e = (i - ((int)L - 16)) >> 2;       // L multiple of 4
+		W.tile[aoffA(r, e)] = d; W.tile[aoffB(r, e)] = d;
+	}
+	// prefetch tile 0
+	int32_t pv[4]; float pw[4];
+#pragma unroll
+	for(int u = 0; u < 4; u++) job_fetch(J, L + (uint32_t)lane + 64u * (uint32_t)u, pv[u], pw[u]);
+
+	for(uint32_t t = 0; t < ntiles; t++) {
+		const uint32_t tb = L + AT * t;
+		if(t) {
+			// carry the last 16 samples over as history (single wavefront: LDS operations execute in order)
+			float hv = 0.0f;
+			const int c = lane >> 4, r = (lane >> 2) & 3, h = lane & 3;
+			if(lane < 32) hv = W.tile[c ? aoffB(r, AT / 4 + h) : aoffA(r, AT / 4 + h)];
+			__builtin_amdgcn_wave_barrier();
+			if(lane < 32) W.tile[c ? aoffB(r, h) : aoffA(r, h)] = hv;
+		}
+#pragma unroll
+		for(int u = 0; u < 4; u++) {
+			const float d = job_value(J, pv[u], pw[u]);
+			const int r = lane & 3, e = AHE + (lane >> 2) + 16 * u;
+			W.tile[aoffA(r, e)] = d; W.tile[aoffB(r, e)] = d;
+		}
+		if(t + 1 < ntiles) {
+#pragma unroll
+			for(int u = 0; u < 4; u++) job_fetch(J, tb + AT + (uint32_t)lane + 64u * (uint32_t)u, pv[u], pw[u]);
+		}
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t k0 = 32 * t;
+		const uint32_t ksteps = nb - k0 < 32 ? nb - k0 : 32;
+		if(j < lag) {
+			if(variant != 12) {
+				if(ksteps == 32) {
+#pragma unroll
+					for(int g = 0; g < 8; g++) {
+						float x[8], y[8];
+#pragma unroll
+						for(int u = 0; u < 8; u++) { x[u] = xs[8 * g + u]; y[u] = ys[8 * g + u]; }
+#pragma unroll
+						for(int u = 0; u < 4; u++) STEP816(acc, x, y, u);
+					}
+				}
+				else for(uint32_t kk = 0; kk < ksteps; kk++) STEP816(acc, xs + 2 * kk, ys + 2 * kk, 0);
+			}
+			else {
+				// lpc_intrin_fma.c:54 (lag 12) as compiled: the 8-sample body unrolled x2 (acc += t1+t0 per 16 samples); for
+				// lag 8 only, x*y0 + x*y2 factored into x*(y0+y2) across the two halves (y2 == x0 of the next half)
+				uint32_t kk = 0;
+				if(k0 + 32 <= 2 * npairs12) {
+					if(j == 8) {
+#pragma unroll
+						for(int g = 0; g < 16; g++) {
+							const float *px = xs + 4 * g, *py = ys + 4 * g;
+							acc += fma((double)px[0], ((double)py[0] + (double)px[2]), (double)px[1] * ((double)py[1] + (double)px[3]));
+						}
+					}
+					else {
+#pragma unroll
+						for(int g = 0; g < 16; g++) {
+							const float *px = xs + 4 * g, *py = ys + 4 * g;
+							const double t0 = fma((double)px[0], (double)py[0], (double)px[1] * (double)py[1]);
+							const double t1 = fma((double)px[2], (double)py[2], (double)px[3] * (double)py[3]);
+							acc += (t1 + t0);
+						}
+					}
+					kk = 32;
+				}
+				else {
+					for(; kk + 2 <= ksteps && k0 + kk + 2 <= 2 * npairs12; kk += 2) {
+						const float *px = xs + 2 * kk, *py = ys + 2 * kk;
+						if(j == 8) acc += fma((double)px[0], ((double)py[0] + (double)px[2]), (double)px[1] * ((double)py[1] + (double)px[3]));
+						else {
+							const double t0 = fma((double)px[0], (double)py[0], (double)px[1] * (double)py[1]);
+							const double t1 = fma((double)px[2], (double)py[2], (double)px[3] * (double)py[3]);
+							acc += (t1 + t0);
+						}
+					}
+					for(; kk < ksteps; kk++) STEP816(acc, xs + 2 * kk, ys + 2 * kk, 0);
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	if(j < lag) W.acc4[j][l] = acc;
+	__builtin_amdgcn_wave_barrier();
+	if((uint32_t)lane < lag) out[lane] = autoc_finish2(W.head, W.tail, tail_lo, nd, L, (uint32_t)lane, W.acc4[lane]);
+}
+#undef STEP816
+
+// ---------------------------------------------------------------------------------------------------------
+// model_kernel
+// ---------------------------------------------------------------------------------------------------------
+template <int MAXORD>
+__global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t nframes, uint32_t tail_n,
+                                                    const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
+                                                    const ChanPrep *__restrict__ preps, const double *__restrict__ autoc_in,
+                                                    Candidate *__restrict__ cands, int *__restrict__ valid)
+{
+	const uint32_t na_main = P.max_analyses;
+	const uint32_t id = blockIdx.x * TPB + threadIdx.x;
+	if(na_main == 0 || id >= nframes * P.ncand * na_main) return;
+	const uint32_t fc = id / na_main, a = id - fc * na_main;
+	const uint32_t f = fc / P.ncand;
+	const bool is_tail = tail_n != 0 && f == nframes - 1;
+	const JobTable *jt = is_tail ? jt_tail : jt_main;
+	const ChanPrep pr = preps[fc];
+	const uint32_t cstride = P.max_analyses + 1;
+	int ok = 0;
+	if((pr.flags & PREP_LPC) && a < jt->nanalyses) {
+		const uint32_t n = pr.n;
+		const uint32_t max_lpc = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
+		const uint32_t lag = max_lpc + 1;
+		const uint32_t jb = jt->an_job[a], rt = jt->an_root[a];
+		const bool punch = jt->an_punch[a] != 0;
+		const double *aj = autoc_in + ((size_t)fc * P.max_jobs + jb) * MAX_ORDER;
+		const double *ar = autoc_in + ((size_t)fc * P.max_jobs + rt) * MAX_ORDER;
+		double av[MAXORD + 1];
+#pragma unroll
+		for(int j = 0; j <= MAXORD; j++) {
+			double v = 0.0;
+			if((uint32_t)j < lag) {
+				v = aj[j];
+				// punch-out: root - partial for lags < max_order only; lag max_order keeps the partial's value
+				// (stream_encoder.c:4339-4340,4370-4371)
+				if(punch && (uint32_t)j < max_lpc) v = ar[j] - v;
+			}
+			av[j] = v;
+		}
+		ok = lpc_model<MAXORD>(av, max_lpc, n, pr.sbps, P.precision, nullptr, &cands[(size_t)fc * cstride + 1 + a]);
+	}
+	valid[(size_t)fc * cstride + 1 + a] = ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// eval_kernel
+// ---------------------------------------------------------------------------------------------------------
+// "owner" layout of the block in LDS: lane L owns samples [L*S, (L+1)*S), S = n/64, stored with 16 samples of
+// history in front at a stride that is odd in words, so that all lanes reading "their sample s" hit 64 different
+// banks.  PACKED: two 16-bit samples per word (channels with <= 16 bits after the wasted-bits shift).
+constexpr int OH = 16;                  // history samples per lane region (>= MAXORD)
+__device__ __forceinline__ uint32_t owner_stride_words(uint32_t S, bool packed)
+{
+	const uint32_t w = packed ? (S + OH) / 2 : S + OH;
+	return w | 1u;
+}
+
+// Rice search over the partition orders for leaf sums held one per lane group (stream_encoder.c:4701-5075).
+// v: this lane's |residual| sum over its S samples; e = 6 - max_po: 2^e adjacent lanes form a leaf partition.
+__device__ __forceinline__ uint32_t rice_search_owner(uint64_t v, bool narrow, uint32_t e, uint32_t n, uint32_t order, uint32_t max_po, uint32_t min_po,
+                                                      uint32_t rice_limit, const uint32_t *divtab, uint8_t *kout, uint32_t *best_po_out, int lane)
+{
+	for(uint32_t m = 0; m < e; m++) v += shfl_xor_u64(v, 1 << m);
+	if(narrow) v = (uint32_t)v;
+	uint64_t vlev[7];
+	vlev[0] = v;
+#pragma unroll
+	for(int d = 1; d <= 6; d++) {
+		if((uint32_t)d <= max_po - min_po) v += shfl_xor_u64(v, 1 << (e + d - 1));
+		vlev[d] = v;
+	}
+	uint32_t klev[7];
+	uint64_t blev[7];
+	bool big = false;
+#pragma unroll
+	for(int d = 0; d <= 6; d++) {
+		klev[d] = 0; blev[d] = 0;
+		if((uint32_t)d <= max_po - min_po) {
+			const uint32_t po = max_po - (uint32_t)d;
+			const uint32_t g = e + (uint32_t)d;                        // log2 lanes per partition at this order
+			const uint32_t pidx = (uint32_t)lane >> g;
+			const bool rep = ((uint32_t)lane & ((1u << g) - 1u)) == 0;
+			const uint32_t o = pidx == 0 ? order : 0;
+			const uint32_t ns = (n >> po) - o;
+			const uint32_t div = divtab[po * (MAX_ORDER + 1) + o];
+			const uint64_t sum = vlev[d];
+			uint32_t k;
+			if(sum < 2 || (((sum - 1) * div) >> 18) == 0) k = 0;
+			else k = ilog2_u64(((sum - 1) * div) >> 18) + 1;
+			if(k >= rice_limit) k = rice_limit - 1;
+			uint64_t bb = 4 + (uint64_t)(1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
+			if(bb > 0xffffffffull) bb = 0xffffffffull;
+			klev[d] = k;
+			blev[d] = rep ? bb : 0;
+			big |= rep && bb >= (1ull << 25);
+		}
+	}
+	if(!__any((int)big)) {
+		uint32_t t[7];
+#pragma unroll
+		for(int d = 0; d <= 6; d++) t[d] = (uint32_t)blev[d];
+#pragma unroll
+		for(int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+			for(int d = 0; d <= 6; d++) t[d] += __shfl_xor(t[d], off);
+		}
+#pragma unroll
+		for(int d = 0; d <= 6; d++) blev[d] = t[d];
+	}
+	else {
+#pragma unroll
+		for(int d = 0; d <= 6; d++) blev[d] = wave_reduce_add_u64(blev[d]);
+	}
+	uint32_t best_bits = 0, best_po = 0;
+#pragma unroll
+	for(int d = 0; d <= 6; d++) {
+		if((uint32_t)d <= max_po - min_po) {
+			const uint64_t tot = 6 + blev[d];
+			const uint32_t bits = tot >= 0xffffffffull ? 0xffffffffu : (uint32_t)tot;
+			if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = max_po - (uint32_t)d; }
+		}
+	}
+	const uint32_t db = max_po - best_po;
+	uint32_t kk = 0;
+#pragma unroll
+	for(int d = 0; d <= 6; d++) if((uint32_t)d == db) kk = klev[d];
+	const uint32_t g = e + db;
+	if(((uint32_t)lane & ((1u << g) - 1u)) == 0) kout[(uint32_t)lane >> g] = (uint8_t)kk;
+	__builtin_amdgcn_wave_barrier();
+	*best_po_out = best_po;
+	return best_bits;
+}
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, false);
+}
+
+// One wavefront evaluates one residual candidate on the owner layout; requires n == 64*S, S >= 16, max_po <= 6.
+// PACKED: 16-bit sample pairs + v_dot2_i32_i16 (same low 32 bits as the wrapping sum of lpc.c:321); else the int32 FIR.
+template <int MAXORD, bool PACKED>
+__device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's region */, uint32_t S, uint32_t n, uint32_t order, const int32_t *q, int shift,
+                                         bool wide, uint32_t sbps, uint32_t rice_limit, uint32_t max_po, uint32_t min_po, const uint32_t *divtab,
+                                         uint8_t *kout, uint32_t *best_po_out, int lane)
+{
+	const uint32_t psize = n >> max_po;
+	const bool narrow = (sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
+	uint32_t acc32 = 0;
+	uint64_t acc64 = 0;
+	const uint32_t npieces = (S + CHUNK - 1) / CHUNK;
+	if(PACKED) {
+		uint32_t Q[MAXORD / 2];
+#pragma unroll
+		for(int p = 0; p < MAXORD / 2; p++) Q[p] = ((uint32_t)q[2 * p] << 16) | ((uint32_t)q[2 * p + 1] & 0xffffu);
+#pragma unroll 1
+		for(uint32_t c = 0; c < npieces; c++) {
+			const uint32_t *w = reg + (OH + CHUNK * c - MAXORD) / 2;
+			uint32_t A[(MAXORD + CHUNK) / 2 + 1], B[(MAXORD + CHUNK) / 2];
+#pragma unroll
+			for(int m = 0; m < (MAXORD + CHUNK) / 2; m++) A[m] = w[m];
+			A[(MAXORD + CHUNK) / 2] = 0;
+#pragma unroll
+			for(int m = 0; m < (MAXORD + CHUNK) / 2; m++) B[m] = __builtin_amdgcn_alignbit(A[m + 1], A[m], 16);
+			const uint32_t rem = S - CHUNK * c;
+#pragma unroll
+			for(int s = 0; s < CHUNK; s++) {
+				const int t = MAXORD + s;
+				int32_t sum = 0;
+#pragma unroll
+				for(int p = 0; p < MAXORD / 2; p++) sum = dot2((t & 1) ? B[(t - 3) / 2 - p] : A[(t - 2) / 2 - p], Q[p], sum);
+				const int32_t x = (t & 1) ? ((int32_t)A[(t - 1) / 2] >> 16) : (int32_t)(int16_t)(A[t / 2] & 0xffffu);
+				const int32_t r = x - (sum >> shift);
+				uint32_t av = (uint32_t)(r < 0 ? -r : r);
+				if(s < MAXORD) { if(c == 0 && lane == 0 && (uint32_t)s < order) av = 0; }
+				if((uint32_t)s >= rem) av = 0;
+				if(narrow) acc32 += av; else acc64 += av;
+			}
+		}
+	}
+	else {
+		int32_t qr[MAXORD];
+#pragma unroll
+		for(int jj = 0; jj < MAXORD; jj++) qr[jj] = q[jj];
+		const int fmode = fir_mode(wide, sbps);
+#pragma unroll 1
+		for(uint32_t c = 0; c < npieces; c++) {
+			const int32_t *w = (const int32_t *)reg + (OH + CHUNK * c - MAXORD);
+			int32_t x[MAXORD + CHUNK];
+#pragma unroll
+			for(int k = 0; k < MAXORD + CHUNK; k++) x[k] = w[k];
+			const uint32_t rem = S - CHUNK * c;
+#pragma unroll
+			for(int s = 0; s < CHUNK; s++) {
+				int32_t r;
+				if(fmode == 2) {
+					int64_t sum = 0;
+#pragma unroll
+					for(int jj = 0; jj < MAXORD; jj++) sum += (int64_t)qr[jj] * (int64_t)x[MAXORD + s - 1 - jj];
+					r = (int32_t)((int64_t)x[MAXORD + s] - (sum >> shift));
+				}
+				else {
+					uint32_t sum = 0;
+#pragma unroll
+					for(int jj = 0; jj < MAXORD; jj++)
+						sum += fmode == 0 ? (uint32_t)__mul24(qr[jj], x[MAXORD + s - 1 - jj]) : (uint32_t)qr[jj] * (uint32_t)x[MAXORD + s - 1 - jj];
+					r = (int32_t)((uint32_t)x[MAXORD + s] - (uint32_t)((int32_t)sum >> shift));
+				}
+				uint32_t av = (uint32_t)(r < 0 ? -(uint32_t)r : (uint32_t)r);
+				if(s < MAXORD) { if(c == 0 && lane == 0 && (uint32_t)s < order) av = 0; }
+				if((uint32_t)s >= rem) av = 0;
+				if(narrow) acc32 += av; else acc64 += av;
+			}
+		}
+	}
+	const uint64_t v = narrow ? (uint64_t)acc32 : acc64;
+	return rice_search_owner(v, narrow, 6 - max_po, n, order, max_po, min_po, rice_limit, divtab, kout, best_po_out, lane);
+}
+
+struct EvalSmall {
+	uint32_t divtab[(MAX_PO + 1) * (MAX_ORDER + 1)];
+	uint64_t pob[EVAL_MAX_WAVES][MAX_PO + 1];
+	uint32_t wbest_bits[EVAL_MAX_WAVES], wbest_ci[EVAL_MAX_WAVES], wbest_po[EVAL_MAX_WAVES];
+	uint32_t rice2;
+};
+struct EvalLayout { uint32_t wsums, kbestw, kcandw, small, total; };
+__host__ __device__ inline uint32_t eval_sig_bytes(const DevParams &P)
+{
+	const uint32_t N = P.blocksize;
+	uint32_t owner = 0;
+	if(N % 64 == 0 && N / 64 >= (uint32_t)OH) owner = 64 * ((N / 64 + OH) | 1u) * 4 + (CHUNK + MAX_ORDER) * 4;
+	const uint32_t b = owner > P.sig_bytes ? owner : P.sig_bytes;
+	return (b + 15u) & ~15u;
+}
+__host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t waves)
+{
+	EvalLayout L;
+	uint32_t o = eval_sig_bytes(P);
+	L.wsums = o;  o += waves * (2u << P.max_po) * 8;
+	L.kbestw = o; o += waves * 2 * (1u << P.max_po);
+	L.kcandw = o; o += P.max_po > 6 ? waves * (2u << P.max_po) : 0;
+	o = (o + 15u) & ~15u;
+	L.small = o;  o += (uint32_t)sizeof(EvalSmall);
+	L.total = (o + 15u) & ~15u;
+	return L;
+}
+
+template <int MAXORD>
+__global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nframes, uint32_t tail_n,
+                                                                   const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
+                                                                   const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
+                                                                   const int *__restrict__ valid, SubDecision *__restrict__ decisions)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;
+	const uint32_t C = P.channels, N = P.blocksize;
+	uint32_t f, cand;
+	map_block(blockIdx.x, nframes, P.ncand, f, cand);
+	const size_t fc = (size_t)f * P.ncand + cand;
+	const ChanPrep pr = preps[fc];
+	const bool is_tail = tail_n != 0 && f == nframes - 1;
+	const JobTable *jt = is_tail ? jt_tail : jt_main;
+	const uint32_t n = pr.n, sbps = pr.sbps, wasted = pr.wasted, which = pr.which;
+	const uint32_t hdr = 8 + wasted;
+	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
+	const uint32_t cstride = P.max_analyses + 1;
+	const Candidate *mycands = cands + fc * cstride;
+	const int *myvalid = valid + fc * cstride;
+	SubDecision *dec = decisions + fc;
+
+	const EvalLayout LY = eval_layout(P, nwaves);
+	uint32_t *sigw = (uint32_t *)smem;
+	uint64_t *wsums_all = (uint64_t *)(smem + LY.wsums);
+	uint8_t *kbestw_all = smem + LY.kbestw;
+	uint8_t *kcandw_all = smem + LY.kcandw;
+	EvalSmall *sh = (EvalSmall *)(smem + LY.small);
+
+	uint32_t best_type = 1, best_order = 0, best_po = 0, best_precision = 0, best_ci = 0, best_wave = 0;
+	int32_t best_shift = 0, best_constant = 0;
+	uint32_t best_bits = pr.verbatim_bits;
+
+	const uint32_t nan = (pr.flags & PREP_LPC) ? jt->nanalyses : 0;
+	const bool any_candidates = !(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || nan);
+	if(pr.flags & PREP_CONSTANT) {
+		const uint32_t bits = hdr + sbps;
+		if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_bits = bits; }
+	}
+	if(any_candidates) {
+		// partition order limits of the frame (stream_encoder.c:3759-3761)
+		uint32_t frame_max_po = 0;
+		{ uint32_t b = n; while(!(b & 1)) { frame_max_po++; b >>= 1; } if(frame_max_po > 15) frame_max_po = 15; }
+		frame_max_po = umin32(frame_max_po, P.max_po);
+		const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
+		const uint32_t S = n / 64;
+		const bool owner = (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6 && S >= MAX_ORDER;
+		const bool packed = owner && sbps <= 16 && (S % 2 == 0);
+		const uint32_t stride = owner_stride_words(S, packed);
+
+		for(uint32_t t = (uint32_t)tid; t < (MAX_PO + 1) * (MAX_ORDER + 1); t += nthreads) {
+			const uint32_t po = t / (MAX_ORDER + 1), o = t - po * (MAX_ORDER + 1);
+			const uint32_t ps = n >> po;
+			sh->divtab[t] = ps > o ? 0x40000u / (ps - o) : 0;
+		}
+		// ---- block into LDS -------------------------------------------------------------------------------
+		if(owner) {
+			// zero lane 0's history
+			if(tid < OH) { if(packed) { if(tid < OH / 2) sigw[tid] = 0; } else sigw[tid] = 0; }
+			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) {
+				int32_t v;
+				if(C == 2) {
+					const int2 lr = ((const int2 *)frame_pcm)[i];
+					v = which == 0 ? lr.x : which == 1 ? lr.y : which == 2 ? ((lr.x + lr.y) >> 1) : (lr.x - lr.y);
+				}
+				else v = pick_channel(frame_pcm, C, i, which);
+				v >>= wasted;
+				const uint32_t Lo = i / S, s = i - Lo * S;
+				if(packed) {
+					uint16_t *h = (uint16_t *)sigw;
+					h[2 * (Lo * stride) + OH + s] = (uint16_t)v;
+					if(s + OH >= S && Lo + 1 < 64) h[2 * ((Lo + 1) * stride) + (s + OH - S)] = (uint16_t)v;
+				}
+				else {
+					sigw[Lo * stride + OH + s] = (uint32_t)v;
+					if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S)] = (uint32_t)v;
+				}
+			}
+		}
+		else {
+			int32_t *sig = (int32_t *)smem;
+			if(tid < 32) sig[sigidx(tid - 32)] = 0;
+			const uint32_t nround = ((n + 15u) & ~15u) + 16u;
+			for(uint32_t i = n + (uint32_t)tid; i < nround; i += nthreads) sig[sigidx((int)i)] = 0;
+			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = pick_channel(frame_pcm, C, i, which) >> wasted;
+		}
+		__syncthreads();
+
+		// ---- candidates: one wavefront each -------------------------------------------------------------------
+		{
+			const uint32_t kstride = 1u << P.max_po;
+			uint64_t *wsums = wsums_all + (size_t)wave * (2u << P.max_po);
+			uint8_t *kbw = kbestw_all + (size_t)wave * 2 * kstride, *ktmp = kbw + kstride;
+			uint8_t *kcw = kcandw_all + (size_t)wave * (2u << P.max_po);
+			uint32_t wb_bits = 0xffffffffu, wb_ci = 0xffffffffu, wb_po = 0;
+			for(uint32_t ci = (uint32_t)wave; ci <= nan; ci += nwaves) {
+				if(!myvalid[ci]) continue;
+				const Candidate *cd = &mycands[ci];
+				const uint32_t order = cd->order;
+				int32_t q[MAXORD];
+#pragma unroll
+				for(int jj = 0; jj < MAXORD; jj++) q[jj] = cd->q[jj];
+				uint32_t po, rbits;
+				if(owner) {
+					const uint32_t *reg = sigw + (uint32_t)lane * stride;
+					if(packed && !cd->wide)
+						rbits = eval_candidate_owner<MAXORD, true>(reg, S, n, order, q, cd->shift, false, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
+					else
+						rbits = eval_candidate_owner<MAXORD, false>(reg, S, n, order, q, cd->shift, cd->wide != 0, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
+				}
+				else
+					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, (const int32_t *)smem, n, order, q, cd->shift,
+					                                    cd->wide != 0, sbps, P, frame_max_po, frame_min_po, &po, lane);
+				const uint32_t est = ci == 0 ? sat_add_u32(hdr + order * sbps, rbits)
+				                             : sat_add_u32(hdr + 4 + 5 + order * (cd->precision + sbps), rbits);
+				if(est > 0 && est < wb_bits) {      // strict: the earlier candidate keeps a tie (stream_encoder.c:4191,4266)
+					wb_bits = est; wb_ci = ci; wb_po = po;
+					for(uint32_t p = (uint32_t)lane; p < (1u << po); p += 64) kbw[p] = ktmp[p];
+					__builtin_amdgcn_wave_barrier();
+				}
+			}
+			if(lane == 0) { sh->wbest_bits[wave] = wb_bits; sh->wbest_ci[wave] = wb_ci; sh->wbest_po[wave] = wb_po; }
+		}
+		__syncthreads();
+		// ---- winner: first minimum in the reference's evaluation order -----------------------------------------
+		uint32_t cb = 0xffffffffu, cci = 0xffffffffu, cw = 0;
+		for(uint32_t w = 0; w < nwaves; w++) {
+			const uint32_t b = sh->wbest_bits[w], ci = sh->wbest_ci[w];
+			if(ci != 0xffffffffu && (b < cb || (b == cb && ci < cci))) { cb = b; cci = ci; cw = w; }
+		}
+		if(cci != 0xffffffffu && cb < best_bits) {
+			best_bits = cb; best_ci = cci; best_wave = cw; best_po = sh->wbest_po[cw];
+			best_type = cci == 0 ? 2 : 3;
+			best_order = mycands[cci].order; best_precision = mycands[cci].precision; best_shift = mycands[cci].shift;
+		}
+	}
+	if(best_bits == 0xffffffffu) { best_type = 1; best_bits = hdr + n * sbps; }   // stream_encoder.c:4281
+
+	// ---- decision record -----------------------------------------------------------------------------------
+	if(wave == 0) {
+		uint32_t rice2 = 0;
+		if(best_type >= 2) {
+			const uint8_t *kb = kbestw_all + (size_t)best_wave * 2 * (1u << P.max_po);
+			uint32_t big = 0;
+			for(uint32_t p = (uint32_t)lane; p < (1u << best_po); p += 64) {
+				const uint8_t k = kb[p];
+				dec->params[p] = k;
+				if(k >= 15) big = 1;
+			}
+			rice2 = __any((int)big) ? 1u : 0u;                         // stream_encoder.c:4786-4791
+		}
+		if(lane < MAX_ORDER) dec->q[lane] = best_type == 3 ? mycands[best_ci].q[lane] : 0;
+		if(lane == 0) {
+			dec->bits = best_bits;
+			dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
+			dec->po = (uint8_t)best_po; dec->rice2 = (uint8_t)rice2; dec->precision = (uint8_t)best_precision;
+			dec->shift = (int8_t)best_shift; dec->which = (uint8_t)which;
+			dec->constant = best_constant;
+		}
+	}
+}
+
+} // namespace flacgpu
+
+// ---------------------------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------------------------
+using namespace flacgpu;
+
+namespace flacgpu {
+uint32_t eval_waves(const DevParams &P)
+{
+	// wavefronts per (frame, channel) workgroup: enough that the candidates go round in full rounds
+	const uint32_t nc = P.max_analyses + 1;
+	const uint32_t rounds = (nc + EVAL_MAX_WAVES - 1) / EVAL_MAX_WAVES;
+	uint32_t w = (nc + rounds - 1) / rounds;
+	if(w < 1) w = 1;
+	return w;
+}
+size_t analyze_lds_bytes(const DevParams &P)
+{
+	const size_t a = P.sig_bytes, d = eval_layout(P, eval_waves(P)).total;
+	return a > d ? a : d;
+}
+
+template <int MAXORD>
+static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, const JobTable *jtm, const JobTable *jtt,
+                                    const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
+{
+	static bool attr_set = false;
+	if(!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e != hipSuccess) return e;
+		attr_set = true;
+	}
+	if(P.max_analyses) {
+		const uint32_t lanes = nframes * P.ncand * P.max_analyses;
+		hipLaunchKernelGGL(model_kernel<MAXORD>, dim3((lanes + TPB - 1) / TPB), dim3(TPB), 0, s, P, nframes, tail_n, jtm, jtt, B.prep, B.autoc, B.cands, B.valid);
+	}
+	if(pev) (void)hipEventRecord(pev[2], s);
+	const uint32_t waves = eval_waves(P);
+	hipLaunchKernelGGL(eval_kernel<MAXORD>, dim3(nframes * P.ncand), dim3(waves * 64), eval_layout(P, waves).total, s, P, pcm, nframes, tail_n, jtm, jtt,
+	                   B.prep, B.cands, B.valid, dec);
+	return hipGetLastError();
+}
+
+hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin, uint32_t nframes, uint32_t tail_n,
+                          const JobTable *jtm, const JobTable *jtt, const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
+{
+	static bool attr_set = false;
+	if(!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)prep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(prep_kernel<0>, dim3(nframes * P.ncand), dim3(TPB), P.sig_bytes, s, P, pcm, nframes, tail_n, B.prep, B.cands, B.valid);
+	if(pev) (void)hipEventRecord(pev[0], s);
+	if(P.max_analyses) {
+		const uint32_t items = nframes * P.ncand * P.max_jobs;
+		hipLaunchKernelGGL(autoc_kernel<0>, dim3((items + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, P, pcm, win, tailwin, nframes, tail_n, jtm, jtt, B.prep, B.autoc);
+	}
+	if(pev) (void)hipEventRecord(pev[1], s);
+	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
+	if(m <= 8) return launch_model_eval<8>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);
+	if(m <= 12) return launch_model_eval<12>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);
+	return launch_model_eval<16>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);
+}
+} // namespace flacgpu

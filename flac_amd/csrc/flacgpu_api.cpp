@@ -20,6 +20,8 @@ struct flacgpu_ctx {
 	int device;
 	hipStream_t stream;          // engine-owned stream (host-buffer entry point)
 	hipEvent_t ev[5];            // start, after analyze, after pack, after compact, spare
+	hipEvent_t pev[3];           // inside the analysis: after prep, after autoc, after model
+	AnalyzeBuffers ab;           // hand-off records between the analysis kernels
 	float *d_windows;            // [num_apod][blocksize]
 	float *d_tail_windows;       // [num_apod][blocksize] scratch for the short last block
 	SubDecision *d_decisions;    // [max_batch][ncand]
@@ -35,7 +37,6 @@ struct flacgpu_ctx {
 	bool timing_valid;
 	JobTable h_jobtab[2];        // [0] nominal blocksize, [1] the short last block of the current batch
 	JobTable *d_jobtab;          // device copies of both
-	unsigned long long *d_dbg;   // FLACGPU_DEBUG_TIMING=1: per-workgroup phase stamps of analyze_kernel
 };
 
 namespace flacgpu {
@@ -83,6 +84,16 @@ void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 }
 }
 
+extern "C" int flacgpu_last_batch_phase_ms(flacgpu_ctx *c, float ms[6])
+{
+	if(!c || !ms || !c->timing_valid) return FLACGPU_ERR_BAD_ARG;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	if(hipEventSynchronize(c->ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	hipEvent_t seq[7] = {c->ev[0], c->pev[0], c->pev[1], c->pev[2], c->ev[1], c->ev[2], c->ev[3]};
+	for(int i = 0; i < 6; i++) if(hipEventElapsedTime(&ms[i], seq[i], seq[i + 1]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	return FLACGPU_OK;
+}
+
 extern "C" void *flacgpu_alloc_pinned(size_t bytes)
 {
 	void *p = nullptr;
@@ -126,7 +137,11 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->d_info) (void)hipFree(c->d_info);
 	if(c->d_pcm) (void)hipFree(c->d_pcm);
 	if(c->d_out) (void)hipFree(c->d_out);
-	if(c->d_dbg) (void)hipFree(c->d_dbg);
+	if(c->ab.prep) (void)hipFree(c->ab.prep);
+	if(c->ab.autoc) (void)hipFree(c->ab.autoc);
+	if(c->ab.cands) (void)hipFree(c->ab.cands);
+	if(c->ab.valid) (void)hipFree(c->ab.valid);
+	for(int i = 0; i < 3; i++) if(c->pev[i]) (void)hipEventDestroy(c->pev[i]);
 	if(c->d_jobtab) (void)hipFree(c->d_jobtab);
 	for(int i = 0; i < 5; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
@@ -205,6 +220,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	bool ok = true;
 	ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
 	for(int i = 0; i < 5 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+	for(int i = 0; i < 3 && ok; i++) ok = hipEventCreate(&c->pev[i]) == hipSuccess;
 	const size_t B = cfg->max_batch_frames;
 	const size_t wbytes = (size_t)(P.num_apod ? P.num_apod : 1) * N * sizeof(float);
 	ok = ok && hipMalloc(&c->d_windows, wbytes) == hipSuccess;
@@ -218,7 +234,13 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	ok = ok && hipMalloc(&c->d_jobtab, 2 * sizeof(JobTable)) == hipSuccess;
 	ok = ok && hipMemcpy(c->d_jobtab, c->h_jobtab, sizeof(JobTable), hipMemcpyHostToDevice) == hipSuccess;
 	if(ok && P.num_apod) ok = hipMemcpy(c->d_windows, windows, wbytes, hipMemcpyHostToDevice) == hipSuccess;
-	if(ok && getenv("FLACGPU_DEBUG_TIMING")) { ok = hipMalloc(&c->d_dbg, B * P.ncand * 16 * sizeof(unsigned long long)) == hipSuccess; if(ok) (void)hipMemset(c->d_dbg, 0, B * P.ncand * 16 * sizeof(unsigned long long)); }
+	{
+		const size_t nfc = B * P.ncand, ncs = P.max_analyses + 1;
+		ok = ok && hipMalloc(&c->ab.prep, nfc * sizeof(ChanPrep)) == hipSuccess;
+		ok = ok && hipMalloc(&c->ab.autoc, nfc * P.max_jobs * MAX_ORDER * sizeof(double)) == hipSuccess;
+		ok = ok && hipMalloc(&c->ab.cands, nfc * ncs * sizeof(Candidate)) == hipSuccess;
+		ok = ok && hipMalloc(&c->ab.valid, nfc * ncs * sizeof(int)) == hipSuccess;
+	}
 	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
 	*out = c;
 	return FLACGPU_OK;
@@ -248,19 +270,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		if(hipMemcpyAsync(c->d_tail_windows, tail_windows_host, (size_t)P.num_apod * tail_n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
 	(void)hipEventRecord(c->ev[0], s);
-	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->d_decisions, c->d_dbg, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(c->d_dbg) {
-		// development aid: average cycles per phase over all workgroups of this launch
-		const size_t nwg = (size_t)nframes * P.ncand;
-		unsigned long long *h = (unsigned long long *)malloc(nwg * 16 * sizeof(unsigned long long));
-		if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, c->d_dbg, nwg * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-			double acc[8] = {0};
-			for(size_t w = 0; w < nwg; w++) for(int k = 1; k < 8; k++) if(h[w * 16 + k] && h[w * 16 + k - 1]) acc[k] += (double)(h[w * 16 + k] - h[w * 16 + k - 1]);
-			fprintf(stderr, "[flacgpu] analyze phases (avg s_memtime ticks/WG): load+wasted %.0f  fixed %.0f  const+jobs+window %.0f  autoc %.0f  model %.0f  candidates %.0f  decide %.0f\n",
-			        acc[1] / nwg, acc[2] / nwg, acc[3] / nwg, acc[4] / nwg, acc[5] / nwg, acc[6] / nwg, acc[7] / nwg);
-		}
-		free(h);
-	}
+	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->ab, c->d_decisions, c->pev, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	(void)hipEventRecord(c->ev[1], s);
 	if(launch_pack(P, d_pcm, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	(void)hipEventRecord(c->ev[2], s);

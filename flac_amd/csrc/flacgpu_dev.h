@@ -71,6 +71,24 @@ struct JobTable {
 };
 void build_job_table(const DevParams &P, uint32_t n, JobTable *jt);
 
+// ---- hand-off records between the analysis kernels (flacgpu_analyze.hip) ------------------------------------
+enum { PREP_LPC = 1, PREP_FIXED_VALID = 2, PREP_CONSTANT = 4 };
+struct ChanPrep {
+	uint32_t which;            // signal modelled: 0..C-1 channel, C mid, C+1 side
+	uint32_t wasted, sbps, n;  // wasted bits, subframe bps after the shift, samples in this block
+	uint32_t flags;            // PREP_*
+	uint32_t fixed_order;      // guessed fixed-predictor order
+	int32_t constant;          // sample value when PREP_CONSTANT
+	uint32_t verbatim_bits;    // size of the VERBATIM baseline (0xffffffff: disabled)
+};
+struct AnalyzeBuffers {
+	ChanPrep *prep;            // [frames*ncand]
+	double *autoc;             // [frames*ncand][max_jobs][MAX_ORDER]
+	Candidate *cands;          // [frames*ncand][max_analyses+1]: [0] fixed, [1+a] LPC analysis a
+	int *valid;                // same shape
+};
+constexpr int EVAL_MAX_WAVES = 8;   // wavefronts per eval workgroup (one residual candidate each per round)
+
 struct FrameInfo {
 	flacgpu_subframe_info sub[FLACGPU_MAX_CHANNELS];
 	uint8_t channel_assignment;
@@ -80,8 +98,8 @@ struct FrameInfo {
 size_t analyze_lds_bytes(const DevParams &P);
 size_t pack_lds_bytes(const DevParams &P);
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
-                          uint32_t nframes, uint32_t tail_n, const JobTable *jt_main, const JobTable *jt_tail, SubDecision *dec,
-                          unsigned long long *dbg, hipStream_t s);
+                          uint32_t nframes, uint32_t tail_n, const JobTable *jt_main, const JobTable *jt_tail, const AnalyzeBuffers &B,
+                          SubDecision *dec, hipEvent_t *phase_ev /* [3]: after prep, autoc, model; may be null */, hipStream_t s);
 hipError_t launch_pack(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, hipStream_t s);
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);

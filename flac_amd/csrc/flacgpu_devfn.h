@@ -1,0 +1,648 @@
+// flac_amd/csrc/flacgpu_devfn.h -- device helper functions shared by the analysis and pack kernels:
+// integer helpers, wavefront/workgroup reductions, the fp64 model stage (Levinson-Durbin, order guess,
+// quantisation), the autocorrelation chains in the reference's compiled association order, signal staging
+// into LDS, the integer FIR and the generic one-wavefront residual candidate evaluation.
+// Every function cites the reference code (file:line under src/libFLAC/) whose behaviour it restates.
+#ifndef FLACGPU_DEVFN_H
+#define FLACGPU_DEVFN_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "flacgpu_dev.h"
+
+namespace flacgpu {
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ilog2_u32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
+__device__ __forceinline__ uint32_t ilog2_u64(uint64_t v) { return 63u - (uint32_t)__clzll((long long)v); }
+__device__ __forceinline__ uint32_t silog2_i64(int64_t v)
+{
+	if(v == 0) return 0;
+	if(v == -1) return 2;
+	if(v < 0) v = -(v + 1);
+	return ilog2_u64((uint64_t)v) + 2;
+}
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// LDS signal layout: rows of 16 samples padded to 18 words so that the per-thread sliding window
+// (thread t owns samples [16t,16t+16)) reads conflict-free; 32 zero samples in front so that a
+// zero-padded FIR of up to 32 taps never needs a bounds check.
+__device__ __forceinline__ int sigidx(int i) { const int m = i + 32; return m + ((m >> 4) << 1); }
+
+__device__ __forceinline__ uint64_t wave_reduce_add_u64(uint64_t v)
+{
+#pragma unroll
+	for(int off = 32; off >= 1; off >>= 1) {
+		uint32_t lo = __shfl_xor((uint32_t)v, off), hi = __shfl_xor((uint32_t)(v >> 32), off);
+		v += ((uint64_t)hi << 32) | lo;
+	}
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_or_u32(uint32_t v)
+{
+#pragma unroll
+	for(int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off);
+	return v;
+}
+// workgroup reductions through a small LDS scratch (8 x u64)
+__device__ __forceinline__ uint64_t block_reduce_add_u64(uint64_t v, uint64_t *scratch, int tid)
+{
+	v = wave_reduce_add_u64(v);
+	__syncthreads();
+	if((tid & 63) == 0) scratch[tid >> 6] = v;
+	__syncthreads();
+	uint64_t r = 0;
+	for(int w = 0; w < TPB / 64; w++) r += scratch[w];
+	return r;
+}
+__device__ __forceinline__ uint32_t block_reduce_or_u32(uint32_t v, uint64_t *scratch, int tid)
+{
+	v = wave_reduce_or_u32(v);
+	__syncthreads();
+	if((tid & 63) == 0) scratch[tid >> 6] = v;
+	__syncthreads();
+	uint32_t r = 0;
+	for(int w = 0; w < TPB / 64; w++) r |= (uint32_t)scratch[w];
+	return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp64 model stage: Levinson-Durbin + order guess + quantisation, ONE LANE PER ANALYSIS with the whole
+// recursion in registers (fully unrolled, statically indexed) -- lpc.c:176-314,1580-1630 as the
+// reference binary computes them (see oracle/flac_oracle.c for the compiled-behaviour notes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double expected_bits_scaled(double lpc_error, double error_scale)
+{
+	if(lpc_error > 0.0) {
+		// 0.5*log(x)/M_LN2 folded by -freciprocal-math into log(x) * (0.5/ln 2)
+		double bps = log(error_scale * lpc_error) * 0.7213475204444817;
+		return bps >= 0.0 ? bps : 0.0;
+	}
+	if(lpc_error < 0.0) return 1e32;
+	return 0.0;
+}
+
+// One Levinson-Durbin recursion up to `upto` orders (lpc.c:188-217). lpc[] / errs[] live in registers.
+// Returns the number of orders actually produced (stops early when err == 0, lpc.c:213).
+template <int MAXORD, bool ROWS>
+__device__ __forceinline__ uint32_t levinson(const double (&a)[MAXORD + 1], uint32_t upto, double (&lpc)[MAXORD], double (&errs)[MAXORD], float *rows)
+{
+	double err = a[0];
+	uint32_t used = upto;
+#pragma unroll
+	for(int i = 0; i < MAXORD; i++) {
+		if((uint32_t)i < used) {
+			double r = -a[i + 1];
+#pragma unroll
+			for(int j = 0; j < i; j++) r -= lpc[j] * a[i - j];
+			r /= err;
+			lpc[i] = r;
+#pragma unroll
+			for(int j = 0; j < (i >> 1); j++) {
+				const double tmp = lpc[j];
+				lpc[j] += r * lpc[i - 1 - j];
+				lpc[i - 1 - j] += r * tmp;
+			}
+			if(i & 1) lpc[i >> 1] = (r + 1.0) * lpc[i >> 1];   // compiled form of lpc[j] += lpc[j]*r
+			err *= (1.0 - r * r);
+			errs[i] = err;
+			if(ROWS) {
+				// lp_coeff[i][0..i] of lpc.c:208-209, kept so that the guessed order needs no second pass
+#pragma unroll
+				for(int j = 0; j <= i; j++) rows[i * MAXORD + j] = (float)(-lpc[j]);
+			}
+			if(err == 0.0) used = (uint32_t)i + 1;
+		}
+	}
+	return used;
+}
+
+// autoc: lag values of this analysis (already punched-out when applicable). rows: MAXORD*MAXORD floats of
+// LDS scratch private to this lane, or null (then the recursion is simply run twice). Returns 0 when no LPC
+// candidate results (autoc[0]==0, estimate >= bps, quantiser failure, residual would need the >32-bit
+// "limit_residual" flavour).
+template <int MAXORD>
+__device__ int lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint32_t n, uint32_t sbps,
+                         uint32_t cfg_precision, float *rows, Candidate *out)
+{
+	double lpc[MAXORD], errs[MAXORD];
+	if(a[0] == 0.0) return 0;
+#pragma unroll
+	for(int i = 0; i < MAXORD; i++) { lpc[i] = 0.0; errs[i] = 0.0; }
+	const uint32_t used = rows ? levinson<MAXORD, true>(a, max_order, lpc, errs, rows) : levinson<MAXORD, false>(a, max_order, lpc, errs, rows);
+	// FLAC__lpc_compute_best_order (lpc.c:1608): total_samples is the full blocksize
+	uint32_t order = 1;
+	double err_order = errs[0];
+	{
+		const double scale = 0.5 / (double)n;
+		const uint32_t overhead = sbps + cfg_precision;
+		double best_bits = 4294967295.0;
+#pragma unroll
+		for(int idx = 0; idx < MAXORD; idx++) {
+			if((uint32_t)idx < used) {
+				const uint32_t o = (uint32_t)idx + 1;
+				const double bits = expected_bits_scaled(errs[idx], scale) * (double)(n - o) + (double)(o * overhead);
+				if(bits < best_bits) { order = o; best_bits = bits; err_order = errs[idx]; }
+			}
+		}
+	}
+	// stream_encoder.c:4227-4229
+	if(expected_bits_scaled(err_order, 0.5 / (double)(n - order)) >= (double)sbps) return 0;
+	float coef[MAXORD];
+	if(rows) {
+#pragma unroll
+		for(int j = 0; j < MAXORD; j++) coef[j] = (uint32_t)j < order ? rows[(order - 1) * MAXORD + j] : 0.0f;
+	}
+	else {
+		// coefficients of `order`: rerun the (deterministic) recursion up to that order
+		(void)levinson<MAXORD, false>(a, order, lpc, errs, rows);
+#pragma unroll
+		for(int j = 0; j < MAXORD; j++) coef[j] = (uint32_t)j < order ? (float)(-lpc[j]) : 0.0f;
+	}
+	// stream_encoder.c:4591-4595 then FLAC__lpc_quantize_coefficients (lpc.c:220)
+	uint32_t precision = cfg_precision;
+	if(sbps <= 17) precision = umin32(precision, 32 - sbps - ilog2_u32(order));
+	int shift;
+	int32_t q[MAXORD];
+	{
+		const uint32_t p1 = precision - 1;
+		int32_t qmax = (int32_t)1 << p1, qmin = -qmax;
+		qmax--;
+		double cmax = 0.0;
+#pragma unroll
+		for(int i = 0; i < MAXORD; i++) { const double v = fabs((double)coef[i]); if(v > cmax) cmax = v; }
+		if(cmax <= 0.0) return 0;
+		int e;
+		(void)frexp(cmax, &e);
+		e--;
+		shift = (int)p1 - e - 1;
+		if(shift > 15) shift = 15;
+		else if(shift < -16) return 0;
+		double error = 0.0;
+		const bool neg = shift < 0;
+		const float scale = (float)(1 << (neg ? -shift : shift));
+#pragma unroll
+		for(int i = 0; i < MAXORD; i++) {
+			int32_t v = 0;
+			if((uint32_t)i < order) {
+				error += neg ? (double)(coef[i] / scale) : (double)(coef[i] * scale);
+				v = (int32_t)lround(error);
+				if(v > qmax) v = qmax; else if(v < qmin) v = qmin;
+				error -= v;
+			}
+			q[i] = v;
+		}
+		if(neg) shift = 0;
+	}
+	// residual kernel selector (stream_encoder.c:4601-4617, lpc.c:942-976)
+	{
+		uint32_t abs_sum = 0;
+#pragma unroll
+		for(int i = 0; i < MAXORD; i++) abs_sum += (uint32_t)abs(q[i]);
+		const uint64_t maxabs = (uint64_t)1 << (sbps - 1);
+		const uint64_t before = maxabs * abs_sum;
+		const uint64_t after = (uint64_t)(-1 * ((-1 * (int64_t)before) >> shift));
+		if(silog2_i64((int64_t)(maxabs + after)) > 32) return 0;
+		out->wide = silog2_i64((int64_t)before) > 32;
+	}
+#pragma unroll
+	for(int i = 0; i < MAX_ORDER; i++) out->q[i] = i < MAXORD ? q[i < MAXORD ? i : 0] : 0;
+	out->order = order;
+	out->precision = precision;
+	out->shift = shift;
+	return 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// autocorrelation in the association order of the reference's compiled routines:
+// one lane per chain = (window job, lag j, vector lane l); the 4 lane accumulators of a lag are
+// combined as (acc3+acc1)+(acc2+acc0) afterwards, then the scalar head/tail of lpc_intrin_fma.c.
+// d = windowed data of the job in LDS, nd = its data_len.
+// ---------------------------------------------------------------------------------------------
+#define DD(k) ((double)d[k])
+// One lane per chain (window job, lag j, vector lane l); a wavefront holds all 64 chains of one job, so its
+// LDS reads are broadcasts (x) or a run of <= 19 consecutive words (y): conflict free.  The loads of several
+// steps are issued together so LDS latency overlaps the fp64 work of the previous steps.
+// body of lpc_intrin_fma.c:46,61 (lag 8 / lag 16): acc_l += fma(d[i],d[i-j], d[i+4]*d[i+4-j]), i = L+8k+l
+__device__ __forceinline__ double autoc_chain_8_16(const float *d, uint32_t nd, uint32_t L, uint32_t j, uint32_t l)
+{
+	const uint32_t nb = (nd - L) / 8;
+	const float *px = d + L + l, *py = px - j;
+	double acc = 0.0;
+	uint32_t k = 0;
+	for(; k + 4 <= nb; k += 4, px += 32, py += 32) {
+		float x[8], y[8];
+#pragma unroll
+		for(int u = 0; u < 8; u++) { x[u] = px[4 * u]; y[u] = py[4 * u]; }
+#pragma unroll
+		for(int u = 0; u < 4; u++)
+			acc += fma((double)x[2 * u], (double)y[2 * u], (double)x[2 * u + 1] * (double)y[2 * u + 1]);
+	}
+	for(; k < nb; k++, px += 8, py += 8)
+		acc += fma((double)px[0], (double)py[0], (double)px[4] * (double)py[4]);
+	return acc;
+}
+// body of lpc_intrin_fma.c:54 (lag 12): gcc unrolled the 8-sample body x2 (acc += t1+t0 per 16 samples) and,
+// for lag 8 only, factored x*y0+x*y2 -> x*(y0+y2) across the two halves (y2 == x0 of the next half there)
+__device__ __forceinline__ double autoc_chain_12(const float *d, uint32_t nd, uint32_t j, uint32_t l)
+{
+	const uint32_t L = 12;
+	const uint32_t nb = (nd - L) / 8;
+	const uint32_t npairs = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
+	const float *px = d + L + l, *py = px - j;
+	double acc = 0.0;
+	uint32_t k = 0, p = 0;
+	if(j == 8) {
+		for(; p + 2 <= npairs; p += 2, k += 4, px += 32, py += 32) {
+			float x[8], y[4];
+#pragma unroll
+			for(int u = 0; u < 8; u++) x[u] = px[4 * u];
+			y[0] = py[0]; y[1] = py[4]; y[2] = py[16]; y[3] = py[20];
+			acc += fma((double)x[0], ((double)y[0] + (double)x[2]), (double)x[1] * ((double)y[1] + (double)x[3]));
+			acc += fma((double)x[4], ((double)y[2] + (double)x[6]), (double)x[5] * ((double)y[3] + (double)x[7]));
+		}
+		for(; p < npairs; p++, k += 2, px += 16, py += 16)
+			acc += fma((double)px[0], ((double)py[0] + (double)px[8]), (double)px[4] * ((double)py[4] + (double)px[12]));
+	}
+	else {
+		for(; p + 2 <= npairs; p += 2, k += 4, px += 32, py += 32) {
+			float x[8], y[8];
+#pragma unroll
+			for(int u = 0; u < 8; u++) { x[u] = px[4 * u]; y[u] = py[4 * u]; }
+#pragma unroll
+			for(int h = 0; h < 2; h++) {
+				const double t0 = fma((double)x[4 * h], (double)y[4 * h], (double)x[4 * h + 1] * (double)y[4 * h + 1]);
+				const double t1 = fma((double)x[4 * h + 2], (double)y[4 * h + 2], (double)x[4 * h + 3] * (double)y[4 * h + 3]);
+				acc += (t1 + t0);
+			}
+		}
+		for(; p < npairs; p++, k += 2, px += 16, py += 16) {
+			const double t0 = fma((double)px[0], (double)py[0], (double)px[4] * (double)py[4]);
+			const double t1 = fma((double)px[8], (double)py[8], (double)px[12] * (double)py[12]);
+			acc += (t1 + t0);
+		}
+	}
+	for(; k < nb; k++, px += 8, py += 8)
+		acc += fma((double)px[0], (double)py[0], (double)px[4] * (double)py[4]);
+	return acc;
+}
+// scalar head (samples j..L-1), lane combine and tail for lag j
+__device__ __forceinline__ double autoc_finish(const float *d, uint32_t nd, uint32_t L, uint32_t j, const double *acc4)
+{
+	double a = 0.0;
+	for(uint32_t h = j; h < L; h++) a += DD(h) * DD(h - j);
+	const uint32_t nb = (nd - L) / 8;
+	if(nb) a = ((acc4[3] + acc4[1]) + (acc4[2] + acc4[0])) + a;
+	uint32_t i = L + 8 * nb;
+	if(nd - i >= 4) {
+		const double hi = fma(DD(i + 1), DD(i + 1 - j), DD(i + 3) * DD(i + 3 - j));
+		const double lo = fma(DD(i), DD(i - j), DD(i + 2) * DD(i + 2 - j));
+		a = (hi + lo) + a;
+		i += 4;
+	}
+	for(; i < nd; i++) a = fma(DD(i), DD(i - j), a);
+	return a;
+}
+// the same with the data given as two plain windows: head = d[0,32), tail = d[tail_lo, nd)
+__device__ __forceinline__ double autoc_finish2(const float *head, const float *tail, uint32_t tail_lo, uint32_t nd, uint32_t L, uint32_t j, const double *acc4)
+{
+#define D2(k) ((double)((uint32_t)(k) >= tail_lo ? tail[(uint32_t)(k) - tail_lo] : head[(k)]))
+	double a = 0.0;
+	for(uint32_t h = j; h < L; h++) a += D2(h) * D2(h - j);
+	const uint32_t nb = (nd - L) / 8;
+	if(nb) a = ((acc4[3] + acc4[1]) + (acc4[2] + acc4[0])) + a;
+	uint32_t i = L + 8 * nb;
+	if(nd - i >= 4) {
+		const double hi = fma(D2(i + 1), D2(i + 1 - j), D2(i + 3) * D2(i + 3 - j));
+		const double lo = fma(D2(i), D2(i - j), D2(i + 2) * D2(i + 2 - j));
+		a = (hi + lo) + a;
+		i += 4;
+	}
+	for(; i < nd; i++) a = fma(D2(i), D2(i - j), a);
+	return a;
+#undef D2
+}
+// lpc.c:133-157 (blocksize <= 32): plain sequential accumulation per lag
+__device__ __forceinline__ double autoc_small(const float *d, uint32_t nd, uint32_t c)
+{
+	double a = 0.0;
+	for(uint32_t s = 0; s + c < nd; s++) a += DD(s) * DD(s + c);
+	return a;
+}
+#undef DD
+// ---------------------------------------------------------------------------------------------
+// shared between analyze and pack: build the candidate channel's signal in LDS
+// returns the OR of all samples (for wasted bits) reduced over the workgroup
+// ---------------------------------------------------------------------------------------------
+// which: 0..C-1 independent channel, C = mid, C+1 = side
+__device__ __forceinline__ int32_t pick_channel(const int32_t *frame_pcm, uint32_t C, uint32_t i, uint32_t which)
+{
+	if(which < C) return frame_pcm[(size_t)i * C + which];
+	const int32_t l = frame_pcm[(size_t)i * 2], r = frame_pcm[(size_t)i * 2 + 1];
+	return which == C ? ((l + r) >> 1) : (l - r);
+}
+
+__device__ void load_signal(int32_t *sig, const int32_t *frame_pcm, uint32_t C, uint32_t n, uint32_t which,
+                            uint32_t *or_out, int tid)
+{
+	uint32_t orv = 0;
+	// zero the 32-sample front pad and the tail up to the next chunk boundary + one chunk
+	if(tid < 32) sig[sigidx(tid - 32)] = 0;
+	const uint32_t nround = ((n + 15u) & ~15u) + 16u;
+	for(uint32_t i = n + (uint32_t)tid; i < nround; i += TPB) sig[sigidx((int)i)] = 0;
+	if(C == 2) {
+		const int2 *p = (const int2 *)frame_pcm;
+		for(uint32_t i = (uint32_t)tid; i < n; i += TPB) {
+			const int2 lr = p[i];
+			int32_t v = which == 0 ? lr.x : which == 1 ? lr.y : which == 2 ? ((lr.x + lr.y) >> 1) : (lr.x - lr.y);
+			sig[sigidx((int)i)] = v;
+			orv |= (uint32_t)v;
+		}
+	}
+	else {
+		for(uint32_t i = (uint32_t)tid; i < n; i += TPB) {
+			int32_t v = pick_channel(frame_pcm, C, i, which);
+			sig[sigidx((int)i)] = v;
+			orv |= (uint32_t)v;
+		}
+	}
+	*or_out = orv;
+}
+
+// residual of CHUNK consecutive samples starting at `base` with a zero-padded MAXORD-tap FIR
+// (lpc.c:321 32-bit wrapping / lpc.c:582 64-bit accumulate; fixed.c:470 is the same FIR with binomial taps)
+// MODE 0: 32-bit wrapping accumulate with 24-bit multiplies (lpc.c:321; valid when samples fit 24 bits signed and
+//         |tap| < 2^23: the low 32 bits of the product are the same, at the full VALU rate of v_mad_i32_i24)
+// MODE 1: 32-bit wrapping accumulate, full 32-bit multiplies (lpc.c:321)
+// MODE 2: 64-bit accumulate (lpc.c:582)
+template <int MAXORD, int MODE>
+__device__ __forceinline__ void fir_chunk(const int32_t *sig, int base, const int32_t *q, int shift, int32_t *r)
+{
+	int32_t x[MAXORD + CHUNK];
+#pragma unroll
+	for(int k = 0; k < MAXORD + CHUNK; k++) x[k] = sig[sigidx(base - MAXORD + k)];
+#pragma unroll
+	for(int s = 0; s < CHUNK; s++) {
+		if(MODE == 2) {
+			int64_t sum = 0;
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)x[MAXORD + s - 1 - j];
+			r[s] = (int32_t)((int64_t)x[MAXORD + s] - (sum >> shift));
+		}
+		else {
+			uint32_t sum = 0;
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++)
+				sum += MODE == 0 ? (uint32_t)__mul24(q[j], x[MAXORD + s - 1 - j]) : (uint32_t)q[j] * (uint32_t)x[MAXORD + s - 1 - j];
+			r[s] = (int32_t)((uint32_t)x[MAXORD + s] - (uint32_t)((int32_t)sum >> shift));
+		}
+	}
+}
+
+// mode: 0/1/2 as above (wave-uniform)
+template <int MAXORD>
+__device__ __forceinline__ void fir_chunk_dispatch(const int32_t *sig, int base, const int32_t *q, int shift, int mode, int32_t *r)
+{
+	if(mode == 0) fir_chunk<MAXORD, 0>(sig, base, q, shift, r);
+	else if(mode == 1) fir_chunk<MAXORD, 1>(sig, base, q, shift, r);
+	else fir_chunk<MAXORD, 2>(sig, base, q, shift, r);
+}
+__device__ __forceinline__ int fir_mode(bool wide, uint32_t sbps) { return wide ? 2 : (sbps <= 24 ? 0 : 1); }
+
+// ---------------------------------------------------------------------------------------------
+// analyze_kernel
+// ---------------------------------------------------------------------------------------------
+// fixed-size part of the workgroup's LDS state; the large arrays are carved dynamically (analyze_layout)
+struct AnalyzeSmall {
+	uint64_t scratch[8];
+	uint64_t pob[TPB / 64][MAX_PO + 1];           // slow path: per-wave bit totals per partition order
+	uint32_t divtab[(MAX_PO + 1) * (MAX_ORDER + 1)]; // 0x40000 / ((n >> po) - order)
+	int cand_valid[MAX_ANALYSES + 1];
+	uint32_t wbest_bits[TPB / 64], wbest_ci[TPB / 64], wbest_po[TPB / 64];
+};
+
+struct AnalyzeLayout { uint32_t wsums, accs, autoc, cands, kbestw, kcandw, small, total; };
+__host__ __device__ inline AnalyzeLayout analyze_layout(const DevParams &P)
+{
+	AnalyzeLayout L;
+	uint32_t o = P.sig_bytes + P.wnd_bytes;
+	L.wsums = o;  o += (TPB / 64) * (2u << P.max_po) * 8;                   // per-wave partition sums
+	L.accs = o;   o += P.max_jobs * (P.max_lpc_order + 1) * 4 * 8;          // chain accumulators
+	L.autoc = o;  o += P.max_jobs * MAX_ORDER * 8;                          // finished autocorrelations
+	L.cands = o;  o += (P.max_analyses + 1) * (uint32_t)sizeof(Candidate);  // [0] fixed, [1+a] LPC analysis a
+	L.kbestw = o; o += (TPB / 64) * 2 * (1u << P.max_po);                   // per wave: Rice parameters of its best candidate + scratch
+	L.kcandw = o; o += P.max_po > 6 ? (TPB / 64) * (2u << P.max_po) : 0;    // slow path only
+	o = (o + 15u) & ~15u;
+	L.small = o;  o += (uint32_t)sizeof(AnalyzeSmall);
+	L.total = (o + 15u) & ~15u;
+	return L;
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)
+{
+	const uint32_t lo = __shfl_xor((uint32_t)v, mask), hi = __shfl_xor((uint32_t)(v >> 32), mask);
+	return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t sat_add_u32(uint32_t est, uint32_t rbits)
+{
+	return rbits < 0xffffffffu - est ? est + rbits : 0xffffffffu;
+}
+
+// One WAVEFRONT evaluates one residual candidate (fixed or LPC) without any workgroup barrier:
+// integer FIR out of LDS (lane owns S consecutive samples), |residual| per partition, the flat tree of
+// merged sums, Rice parameter and bit estimate per partition, best partition order
+// (find_best_partition_order_ / precompute_partition_info_sums_ / set_partitioned_rice_,
+// stream_encoder.c:4701-5075).  Returns the estimated residual bits; Rice parameters of the best
+// partition order go to kout[0 .. 2^best_po).
+template <int MAXORD>
+__device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_t *pob, uint8_t *kout, const uint32_t *divtab,
+                                        const int32_t *sig, uint32_t n, uint32_t order, const int32_t *q, int shift, bool wide,
+                                        uint32_t sbps, const DevParams &P, uint32_t frame_max_po, uint32_t frame_min_po,
+                                        uint32_t *best_po_out, int lane)
+{
+	uint32_t max_po = frame_max_po;
+	while(max_po > 0 && (n >> max_po) <= order) max_po--;                   // format.c:550
+	const uint32_t min_po = umin32(frame_min_po, max_po);
+	const uint32_t psize = n >> max_po, nparts = 1u << max_po;
+	const bool narrow = (sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
+	int32_t qr[MAXORD];
+#pragma unroll
+	for(int j = 0; j < MAXORD; j++) qr[j] = q[j];
+	const int fmode = fir_mode(wide, sbps);
+
+	// Lane `lane` owns chunks lane, lane+64, ... of CHUNK consecutive samples: adjacent lanes read adjacent
+	// 18-word rows of the padded signal, i.e. conflict-free LDS reads.
+	const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
+	const uint32_t g = psize / CHUNK;                                       // chunks per leaf partition
+	// fast path: a leaf partition is g = 2^a adjacent lanes of one pass (e.g. 4096 samples: 64 partitions of 4 chunks)
+	const bool direct = max_po <= 6 && psize % CHUNK == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0;
+	uint64_t vdirect = 0;             // direct path: leaf sum of partition `lane`
+	if(!direct) {
+		for(uint32_t p = (uint32_t)lane; p < nparts; p += 64) wsums[p] = 0;
+		__builtin_amdgcn_wave_barrier();
+	}
+	if(direct) {
+		const uint32_t lp = 64u / g;                      // leaves per pass (power of two)
+		const uint32_t src = ((uint32_t)lane & (lp - 1)) * g, want = (uint32_t)lane / lp;
+#pragma unroll 1
+		for(uint32_t pass = 0; pass * 64 < nchunks; pass++) {
+			const uint32_t base = (pass * 64 + (uint32_t)lane) * CHUNK;
+			uint64_t mine = 0;
+			if(base < n) {
+				int32_t r[CHUNK];
+				fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, fmode, r);
+				uint32_t acc32 = 0;
+				uint64_t acc64 = 0;
+#pragma unroll
+				for(int s2 = 0; s2 < CHUNK; s2++) {
+					const uint32_t i = base + s2;
+					if(i >= order && i < n) {
+						const int32_t v = r[s2];
+						const uint32_t av = (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v);
+						if(narrow) acc32 += av; else acc64 += av;
+					}
+				}
+				mine = narrow ? (uint64_t)acc32 : acc64;
+			}
+			for(uint32_t m = 1; m < g; m <<= 1) mine += shfl_xor_u64(mine, (int)m);
+			// leaf p = pass*lp + lane/g sits in every lane of its group; lane L wants leaf L
+			const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, (int)src), hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), (int)src);
+			if(want == pass) vdirect = ((uint64_t)hi << 32) | lo;
+		}
+		if((uint32_t)lane >= nparts) vdirect = 0;
+	}
+	else {
+		for(uint32_t cidx = (uint32_t)lane; cidx < nchunks; cidx += 64) {
+			const uint32_t base = cidx * CHUNK;
+			int32_t r[CHUNK];
+			fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, fmode, r);
+			uint32_t part = base / psize, next = (part + 1) * psize;
+			uint64_t run = 0;
+#pragma unroll
+			for(int s2 = 0; s2 < CHUNK; s2++) {
+				const uint32_t i = base + s2;
+				if(i == next) {
+					if(run) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
+					run = 0; part++; next += psize;
+				}
+				if(i >= order && i < n) { const int32_t v = r[s2]; run += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v); }
+			}
+			if(run && part < nparts) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
+		}
+	}
+	uint32_t best_bits = 0, best_po = 0;
+	if(max_po <= 6) {
+		// leaves into lanes 0..nparts-1, merged level by level with a butterfly; every lane of a group holds
+		// the group's sum, the group's first lane speaks for the partition
+		uint64_t v;
+		if(direct) v = vdirect;
+		else { __builtin_amdgcn_wave_barrier(); v = (uint32_t)lane < nparts ? wsums[lane] : 0; }
+		if(narrow) v = (uint32_t)v;
+		// (1) merged sums of every level: 6 dependent butterfly stages
+		uint64_t vlev[7];
+		vlev[0] = v;
+#pragma unroll
+		for(int d = 1; d <= 6; d++) {
+			if((uint32_t)d <= max_po - min_po) v += shfl_xor_u64(v, 1 << (d - 1));
+			vlev[d] = v;
+		}
+		// (2) Rice parameter and bit estimate of this lane's partition at every level (independent VALU work)
+		uint32_t klev[7];
+		uint64_t blev[7];
+		bool big = false;
+#pragma unroll
+		for(int d = 0; d <= 6; d++) {
+			klev[d] = 0; blev[d] = 0;
+			if((uint32_t)d <= max_po - min_po) {
+				const uint32_t po = max_po - (uint32_t)d;
+				const uint32_t pidx = (uint32_t)lane >> d;
+				const bool rep = ((uint32_t)lane & ((1u << d) - 1u)) == 0 && (uint32_t)lane < nparts;
+				const uint32_t o = pidx == 0 ? order : 0;
+				const uint32_t ns = (n >> po) - o;
+				const uint32_t div = divtab[po * (MAX_ORDER + 1) + o];
+				const uint64_t sum = vlev[d];
+				uint32_t k;
+				if(sum < 2 || (((sum - 1) * div) >> 18) == 0) k = 0;
+				else k = ilog2_u64(((sum - 1) * div) >> 18) + 1;
+				if(k >= P.rice_limit) k = P.rice_limit - 1;
+				uint64_t bb = 4 + (uint64_t)(1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
+				if(bb > 0xffffffffull) bb = 0xffffffffull;
+				klev[d] = k;
+				blev[d] = rep ? bb : 0;
+				big |= bb >= (1ull << 25);
+			}
+		}
+		// (3) totals per level: all levels reduced together so the cross-lane latency overlaps.
+		// 64 terms below 2^25 fit 32 bits -- the usual case; otherwise reduce in 64 bits.
+		if(!__any((int)big)) {
+			uint32_t t[7];
+#pragma unroll
+			for(int d = 0; d <= 6; d++) t[d] = (uint32_t)blev[d];
+#pragma unroll
+			for(int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+				for(int d = 0; d <= 6; d++) t[d] += __shfl_xor(t[d], off);
+			}
+#pragma unroll
+			for(int d = 0; d <= 6; d++) blev[d] = t[d];
+		}
+		else {
+#pragma unroll
+			for(int d = 0; d <= 6; d++) blev[d] = wave_reduce_add_u64(blev[d]);
+		}
+#pragma unroll
+		for(int d = 0; d <= 6; d++) {
+			if((uint32_t)d <= max_po - min_po) {
+				const uint64_t tot = 6 + blev[d];
+				const uint32_t bits = tot >= 0xffffffffull ? 0xffffffffu : (uint32_t)tot;
+				if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = max_po - (uint32_t)d; }
+			}
+		}
+		const uint32_t db = max_po - best_po;
+		uint32_t kk = 0;
+#pragma unroll
+		for(int d = 0; d <= 6; d++) if((uint32_t)d == db) kk = klev[d];
+		if((((uint32_t)lane & ((1u << db) - 1u)) == 0) && (uint32_t)lane < nparts) kout[(uint32_t)lane >> db] = (uint8_t)kk;
+	}
+	else {
+		// partition orders 7/8: same computation through LDS (wave-private arrays)
+		__builtin_amdgcn_wave_barrier();
+		if(lane <= MAX_PO) pob[lane] = 0;
+		__builtin_amdgcn_wave_barrier();
+		uint32_t total_nodes = 0;
+		for(int po = (int)max_po; po >= (int)min_po; po--) total_nodes += 1u << po;
+		for(uint32_t node = (uint32_t)lane; node < total_nodes; node += 64) {
+			uint32_t po = max_po, off = 0;
+			while(node - off >= (1u << po)) { off += 1u << po; po--; }
+			const uint32_t p = node - off, nleaf = 1u << (max_po - po);
+			uint64_t sum = 0;
+			for(uint32_t k = 0; k < nleaf; k++) { const uint64_t t = wsums[p * nleaf + k]; sum += narrow ? (uint64_t)(uint32_t)t : t; }
+			const uint32_t o = p == 0 ? order : 0, ns = (n >> po) - o, div = divtab[po * (MAX_ORDER + 1) + o];
+			uint32_t k;
+			if(sum < 2 || (((sum - 1) * div) >> 18) == 0) k = 0;
+			else k = ilog2_u64(((sum - 1) * div) >> 18) + 1;
+			if(k >= P.rice_limit) k = P.rice_limit - 1;
+			uint64_t b = 4 + (uint64_t)(1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
+			if(b > 0xffffffffull) b = 0xffffffffull;
+			kcand[node] = (uint8_t)k;
+			atomicAdd((unsigned long long *)&pob[po], (unsigned long long)b);
+		}
+		__builtin_amdgcn_wave_barrier();
+		uint32_t off = 0, best_off = 0;
+		for(int po = (int)max_po; po >= (int)min_po; po--) {
+			const uint64_t b = 6 + pob[po];
+			const uint32_t bits = b >= 0xffffffffull ? 0xffffffffu : (uint32_t)b;
+			if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = (uint32_t)po; best_off = off; }
+			off += 1u << po;
+		}
+		for(uint32_t p = (uint32_t)lane; p < (1u << best_po); p += 64) kout[p] = kcand[best_off + p];
+	}
+	__builtin_amdgcn_wave_barrier();
+	*best_po_out = best_po;
+	return best_bits;
+}
+
+} // namespace flacgpu
+#endif

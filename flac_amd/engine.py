@@ -74,7 +74,7 @@ def load_host():
     if _host is None:
         if not os.path.exists(HOST_SO):
             raise FlacGpuError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % HOST_SO)
-        lib = C.CDLL(HOST_SO, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(HOST_SO)      # RTLD_LOCAL: it exports the libFLAC encoder names, which must not interpose on a real libFLAC
         lib.flacgpu_host_settings_defaults.argtypes = [C.POINTER(HostSettings)]
         lib.flacgpu_host_settings_level.argtypes = [C.POINTER(HostSettings), C.c_uint32]
         lib.flacgpu_host_settings_apodization.argtypes = [C.POINTER(HostSettings), C.c_char_p]
@@ -92,7 +92,7 @@ def load_engine():
     if _engine is None:
         if not os.path.exists(ENGINE_SO):
             raise FlacGpuError("%s not built: the HIP extension is required (no CPU fallback)" % ENGINE_SO)
-        lib = C.CDLL(ENGINE_SO, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(ENGINE_SO)
         lib.flacgpu_create.restype = C.c_int
         lib.flacgpu_create.argtypes = [C.POINTER(EngineConfig), C.c_void_p, C.POINTER(C.c_void_p)]
         lib.flacgpu_destroy.argtypes = [C.c_void_p]
@@ -110,6 +110,8 @@ def load_engine():
         lib.flacgpu_last_batch_kernel_ms.restype = C.c_int
         lib.flacgpu_last_batch_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                                      C.POINTER(C.c_float)]
+        lib.flacgpu_last_batch_phase_ms.restype = C.c_int
+        lib.flacgpu_last_batch_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float * 6)]
         lib.flacgpu_strerror.restype = C.c_char_p
         lib.flacgpu_strerror.argtypes = [C.c_int]
         lib.flacgpu_device_count.restype = C.c_int
@@ -245,6 +247,14 @@ class FrameEngine:
         if r != 0:
             raise FlacGpuError("flacgpu_last_batch_info: %s" % self.lib.flacgpu_strerror(r).decode())
         return sub, ca
+
+    def last_phase_ms(self):
+        """per-kernel ms of the last batch: prep, autoc, model, eval, pack, scan+compact"""
+        ms = (C.c_float * 6)()
+        r = self.lib.flacgpu_last_batch_phase_ms(self.ctx, C.byref(ms))
+        if r != 0:
+            raise FlacGpuError("flacgpu_last_batch_phase_ms: %s" % self.lib.flacgpu_strerror(r).decode())
+        return dict(zip(("prep", "autoc", "model", "eval", "pack", "scan_compact"), [float(v) for v in ms]))
 
     def last_kernel_ms(self):
         a, p, k = C.c_float(), C.c_float(), C.c_float()

@@ -126,6 +126,10 @@ int flacgpu_last_batch_info(flacgpu_ctx *ctx, uint32_t nframes, flacgpu_subframe
 /* Wall-clock-free timing of the last batch, measured with HIP events on the engine's stream:
  * milliseconds spent in the analysis kernel, the pack kernel and the compaction kernels. */
 int flacgpu_last_batch_kernel_ms(flacgpu_ctx *ctx, float *analyze_ms, float *pack_ms, float *compact_ms);
+/* The same per kernel, in launch order: ms[0] prep (wasted bits, fixed-predictor guess), ms[1] autocorrelation,
+ * ms[2] LPC model (Levinson-Durbin, quantisation), ms[3] residual candidate evaluation + Rice search,
+ * ms[4] pack, ms[5] scan + compaction. */
+int flacgpu_last_batch_phase_ms(flacgpu_ctx *ctx, float ms[6]);
 
 /* Page-locked host memory for PCM staging buffers handed to flacgpu_encode_batch (the H2D copy then runs
  * at full PCIe rate and asynchronously).  NULL when no device/runtime is available. */
