@@ -529,6 +529,86 @@ __device__ __forceinline__ uint32_t rice_search_owner(uint64_t v, bool narrow, u
 	return best_bits;
 }
 
+// The same search when every lane sum is small (< 2^23, so that nothing can wrap or saturate and 32-bit arithmetic
+// is exact): the 2^(max_po+1)-1 nodes of the partition tree are spread over the lanes -- leaf p on lane p, the
+// merged partitions of the lower orders on the lanes after each other -- their sums come from ONE prefix sum over
+// the lanes, and each lane evaluates at most two nodes instead of one node per partition order.
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v, int lane)
+{
+#pragma unroll
+	for(int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off); if(lane >= off) v += t; }
+	return v;
+}
+__device__ __forceinline__ void rice_node(uint32_t sum, uint32_t ns, uint32_t div, uint32_t rice_limit, uint32_t &k, uint32_t &bits)
+{
+	// set_partitioned_rice_ (stream_encoder.c:4997-5046): mean-based parameter, then the closed-form bit count
+	k = 0;
+	if(sum >= 2) {
+		const uint64_t x = ((uint64_t)(sum - 1) * div) >> 18;
+		if(x) k = ilog2_u64(x) + 1;
+	}
+	if(k >= rice_limit) k = rice_limit - 1;
+	bits = 4 + (1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
+}
+__device__ __forceinline__ uint32_t rice_search_nodes(uint32_t v, uint32_t e, uint32_t n, uint32_t order, uint32_t max_po, uint32_t min_po,
+                                                      uint32_t rice_limit, const uint32_t *divtab, uint8_t *kout, uint32_t *best_po_out, int lane)
+{
+	const uint32_t D = max_po - min_po;                     // number of lower orders searched
+	const uint32_t nleaves = 1u << max_po;
+	const uint32_t P = wave_scan_incl_u32(v, lane);
+	// node A: leaf `lane`
+	uint32_t kA = 0, bA = 0;
+	{
+		uint32_t sum = v;
+		if(e) {
+			const uint32_t hi = (((uint32_t)lane + 1) << e) - 1, lo = (uint32_t)lane << e;
+			const uint32_t ph = __shfl(P, (int)(hi & 63)), pl = __shfl(P, (int)((lo - 1) & 63));
+			sum = ph - (lo ? pl : 0);
+		}
+		if((uint32_t)lane < nleaves) {
+			const uint32_t o = lane == 0 ? order : 0;
+			rice_node(sum, (n >> max_po) - o, divtab[max_po * (MAX_ORDER + 1) + o], rice_limit, kA, bA);
+		}
+	}
+	// node B: the lane-th merged partition, orders max_po-1 .. min_po one after the other
+	uint32_t kB = 0, bB = 0, dB = 0, pB = 0;
+	const uint32_t nupper = nleaves - (nleaves >> D);
+	if(D) {
+		uint32_t u = (uint32_t)lane, d = 1, cnt = nleaves >> 1;
+		while(d < D && u >= cnt) { u -= cnt; cnt >>= 1; d++; }
+		const bool have = (uint32_t)lane < nupper;
+		const uint32_t g = e + d;
+		const uint32_t lo = have ? u << g : 0, hi = have ? ((u + 1) << g) - 1 : 0;
+		const uint32_t ph = __shfl(P, (int)(hi & 63)), pl = __shfl(P, (int)((lo - 1) & 63));
+		if(have) {
+			const uint32_t sum = ph - (lo ? pl : 0);
+			const uint32_t po = max_po - d, o = u == 0 ? order : 0;
+			rice_node(sum, (n >> po) - o, divtab[po * (MAX_ORDER + 1) + o], rice_limit, kB, bB);
+			dB = d; pB = u;
+		}
+	}
+	// totals per order: order max_po from the A nodes, the others are consecutive lane ranges of the B nodes
+	uint32_t totA = bA;
+#pragma unroll
+	for(int off = 32; off >= 1; off >>= 1) totA += __shfl_xor(totA, off);
+	const uint32_t Q = D ? wave_scan_incl_u32(bB, lane) : 0;
+	uint32_t best_bits = 6 + totA, best_d = 0;
+	{
+		uint32_t start = 0, cnt = nleaves >> 1;
+		for(uint32_t d = 1; d <= D; d++) {
+			const uint32_t endv = __shfl(Q, (int)(start + cnt - 1)), begv = start ? __shfl(Q, (int)(start - 1)) : 0;
+			const uint32_t bits = 6 + (endv - begv);
+			if(bits < best_bits) { best_bits = bits; best_d = d; }      // strict: ties keep the higher order (stream_encoder.c:4735-4763)
+			start += cnt; cnt >>= 1;
+		}
+	}
+	if(best_d == 0) { if((uint32_t)lane < nleaves) kout[lane] = (uint8_t)kA; }
+	else if(dB == best_d) kout[pB] = (uint8_t)kB;
+	__builtin_amdgcn_wave_barrier();
+	*best_po_out = max_po - best_d;
+	return best_bits;
+}
+
 typedef short short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c)
 {
@@ -537,9 +617,10 @@ __device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c)
 
 // One wavefront evaluates one residual candidate on the owner layout; requires n == 64*S, S >= 16, max_po <= 6.
 // PACKED: 16-bit sample pairs + v_dot2_i32_i16 (same low 32 bits as the wrapping sum of lpc.c:321); else the int32 FIR.
-template <int MAXORD, bool PACKED>
-__device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's region */, uint32_t S, uint32_t n, uint32_t order, const int32_t *q, int shift,
-                                         bool wide, uint32_t sbps, uint32_t rice_limit, uint32_t max_po, uint32_t min_po, const uint32_t *divtab,
+// FMODE (unpacked only): 0 v_mad_i32_i24, 1 32-bit multiplies (both lpc.c:321), 2 64-bit accumulate (lpc.c:582).
+template <int MAXORD, bool PACKED, int FMODE>
+__device__ __forceinline__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's region */, uint32_t S, uint32_t n, uint32_t order, const int32_t *q, int shift,
+                                         uint32_t sbps, uint32_t rice_limit, uint32_t max_po, uint32_t min_po, const uint32_t *divtab,
                                          uint8_t *kout, uint32_t *best_po_out, int lane)
 {
 	const uint32_t psize = n >> max_po;
@@ -580,7 +661,7 @@ __device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's regi
 		int32_t qr[MAXORD];
 #pragma unroll
 		for(int jj = 0; jj < MAXORD; jj++) qr[jj] = q[jj];
-		const int fmode = fir_mode(wide, sbps);
+		constexpr int fmode = FMODE;
 #pragma unroll 1
 		for(uint32_t c = 0; c < npieces; c++) {
 			const int32_t *w = (const int32_t *)reg + (OH + CHUNK * c - MAXORD);
@@ -612,6 +693,8 @@ __device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's regi
 		}
 	}
 	const uint64_t v = narrow ? (uint64_t)acc32 : acc64;
+	if(!__any((int)(v >= (1u << 23))))
+		return rice_search_nodes((uint32_t)v, 6 - max_po, n, order, max_po, min_po, rice_limit, divtab, kout, best_po_out, lane);
 	return rice_search_owner(v, narrow, 6 - max_po, n, order, max_po, min_po, rice_limit, divtab, kout, best_po_out, lane);
 }
 
@@ -643,7 +726,12 @@ __host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t w
 	return L;
 }
 
-template <int MAXORD>
+// VARIANT selects which workgroups a launch serves (the others leave at once), so that each flavour of the
+// residual evaluation gets its own register allocation:
+//   0  owner layout, packed 16-bit samples, dot2 FIR (and every workgroup that has no residual candidate at all)
+//   1  owner layout, 32-bit samples (17..25-bit channels, or a candidate that needs the 64-bit FIR)
+//   2  any other block length / partition order: generic chunked evaluation with LDS partition sums
+template <int MAXORD, int VARIANT>
 __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nframes, uint32_t tail_n,
                                                                    const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                                    const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
@@ -680,19 +768,29 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 
 	const uint32_t nan = (pr.flags & PREP_LPC) ? jt->nanalyses : 0;
 	const bool any_candidates = !(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || nan);
+	// partition order limits of the frame (stream_encoder.c:3759-3761)
+	uint32_t frame_max_po = 0;
+	{ uint32_t b = n; while(!(b & 1)) { frame_max_po++; b >>= 1; } if(frame_max_po > 15) frame_max_po = 15; }
+	frame_max_po = umin32(frame_max_po, P.max_po);
+	const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
+	const uint32_t S = n / 64;
+	const bool owner = (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6;
+	bool packed = owner && sbps <= 16 && (S % 2 == 0);
+	if(packed && any_candidates) {
+		// a candidate whose prediction needs the 64-bit FIR (lpc.c:582) keeps the whole workgroup on 32-bit samples
+		int w = 0;
+		for(uint32_t ci = (uint32_t)lane; ci <= nan; ci += 64) w |= myvalid[ci] && mycands[ci].wide;
+		if(__any(w)) packed = false;
+	}
+	{
+		const int kind = !any_candidates ? 0 : packed ? 0 : owner ? 1 : 2;
+		if(kind != VARIANT) return;
+	}
 	if(pr.flags & PREP_CONSTANT) {
 		const uint32_t bits = hdr + sbps;
 		if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_bits = bits; }
 	}
 	if(any_candidates) {
-		// partition order limits of the frame (stream_encoder.c:3759-3761)
-		uint32_t frame_max_po = 0;
-		{ uint32_t b = n; while(!(b & 1)) { frame_max_po++; b >>= 1; } if(frame_max_po > 15) frame_max_po = 15; }
-		frame_max_po = umin32(frame_max_po, P.max_po);
-		const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
-		const uint32_t S = n / 64;
-		const bool owner = (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6 && S >= MAX_ORDER;
-		const bool packed = owner && sbps <= 16 && (S % 2 == 0);
 		const uint32_t stride = owner_stride_words(S, packed);
 
 		for(uint32_t t = (uint32_t)tid; t < (MAX_PO + 1) * (MAX_ORDER + 1); t += nthreads) {
@@ -701,7 +799,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 			sh->divtab[t] = ps > o ? 0x40000u / (ps - o) : 0;
 		}
 		// ---- block into LDS -------------------------------------------------------------------------------
-		if(owner) {
+		if(VARIANT != 2) {
 			// zero lane 0's history
 			if(tid < OH) { if(packed) { if(tid < OH / 2) sigw[tid] = 0; } else sigw[tid] = 0; }
 			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) {
@@ -748,12 +846,14 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 #pragma unroll
 				for(int jj = 0; jj < MAXORD; jj++) q[jj] = cd->q[jj];
 				uint32_t po, rbits;
-				if(owner) {
+				if(VARIANT == 0)
+					rbits = eval_candidate_owner<MAXORD, true, 0>(sigw + (uint32_t)lane * stride, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
+				else if(VARIANT == 1) {
 					const uint32_t *reg = sigw + (uint32_t)lane * stride;
-					if(packed && !cd->wide)
-						rbits = eval_candidate_owner<MAXORD, true>(reg, S, n, order, q, cd->shift, false, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
-					else
-						rbits = eval_candidate_owner<MAXORD, false>(reg, S, n, order, q, cd->shift, cd->wide != 0, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
+					const int fmode = fir_mode(cd->wide != 0, sbps);
+					if(fmode == 0) rbits = eval_candidate_owner<MAXORD, false, 0>(reg, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
+					else if(fmode == 1) rbits = eval_candidate_owner<MAXORD, false, 1>(reg, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
+					else rbits = eval_candidate_owner<MAXORD, false, 2>(reg, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
 				}
 				else
 					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, (const int32_t *)smem, n, order, q, cd->shift,
@@ -836,7 +936,9 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 {
 	static bool attr_set = false;
 	if(!attr_set) {
-		hipError_t e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		hipError_t e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
@@ -846,8 +948,13 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	}
 	if(pev) (void)hipEventRecord(pev[2], s);
 	const uint32_t waves = eval_waves(P);
-	hipLaunchKernelGGL(eval_kernel<MAXORD>, dim3(nframes * P.ncand), dim3(waves * 64), eval_layout(P, waves).total, s, P, pcm, nframes, tail_n, jtm, jtt,
-	                   B.prep, B.cands, B.valid, dec);
+	const size_t lds = eval_layout(P, waves).total;
+	const bool owner_possible = P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH;
+	// which flavours can occur in this batch at all (each launch serves only its own workgroups)
+	if(owner_possible) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec);
+	if(owner_possible) hipLaunchKernelGGL((eval_kernel<MAXORD, 1>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec);
+	if(!owner_possible || tail_n || P.max_po > 6)
+		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec);
 	return hipGetLastError();
 }
 
