@@ -20,6 +20,7 @@
 // reach HBM.  Integer + fp64 VALU work: no MFMA by design.  Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "flacgpu_dev.h"
 #include "flacgpu_devfn.h"
 
@@ -728,17 +729,19 @@ __host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t w
 
 // VARIANT selects which workgroups a launch serves (the others leave at once), so that each flavour of the
 // residual evaluation gets its own register allocation:
-//   0  owner layout, packed 16-bit samples, dot2 FIR (and every workgroup that has no residual candidate at all)
-//   1  owner layout, 32-bit samples (17..25-bit channels, or a candidate that needs the 64-bit FIR)
+//   0  owner layout: packed 16-bit samples + dot2 FIR, or 32-bit samples (17..25-bit channels, or a candidate that
+//      needs the 64-bit FIR), chosen per workgroup; also every workgroup that has no residual candidate at all
 //   2  any other block length / partition order: generic chunked evaluation with LDS partition sums
 template <int MAXORD, int VARIANT>
 __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nframes, uint32_t tail_n,
                                                                    const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                                    const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
-                                                                   const int *__restrict__ valid, SubDecision *__restrict__ decisions)
+                                                                   const int *__restrict__ valid, SubDecision *__restrict__ decisions, unsigned long long *__restrict__ dbg)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define STAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
+	const unsigned long long t_start = dbg ? (unsigned long long)clock64() : 0ull;
 	const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;
 	const uint32_t C = P.channels, N = P.blocksize;
 	uint32_t f, cand;
@@ -783,9 +786,12 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 		if(__any(w)) packed = false;
 	}
 	{
-		const int kind = !any_candidates ? 0 : packed ? 0 : owner ? 1 : 2;
+		// VARIANT 0 serves every workgroup on the owner layout (packed or 32-bit samples, chosen here per workgroup)
+		// and the ones without residual candidates; VARIANT 2 the remaining block shapes
+		const int kind = !any_candidates ? 0 : owner ? 0 : 2;
 		if(kind != VARIANT) return;
 	}
+	if(dbg && tid == 0) { dbg[(size_t)blockIdx.x * 16] = t_start; dbg[(size_t)blockIdx.x * 16 + 8] = (unsigned long long)clock64(); dbg[(size_t)blockIdx.x * 16 + 9] = (unsigned long long)VARIANT + 1; }
 	if(pr.flags & PREP_CONSTANT) {
 		const uint32_t bits = hdr + sbps;
 		if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_bits = bits; }
@@ -830,6 +836,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = pick_channel(frame_pcm, C, i, which) >> wasted;
 		}
 		__syncthreads();
+		STAMP(1);
 
 		// ---- candidates: one wavefront each -------------------------------------------------------------------
 		{
@@ -846,9 +853,9 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 #pragma unroll
 				for(int jj = 0; jj < MAXORD; jj++) q[jj] = cd->q[jj];
 				uint32_t po, rbits;
-				if(VARIANT == 0)
+				if(VARIANT == 0 && packed)
 					rbits = eval_candidate_owner<MAXORD, true, 0>(sigw + (uint32_t)lane * stride, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
-				else if(VARIANT == 1) {
+				else if(VARIANT == 0) {
 					const uint32_t *reg = sigw + (uint32_t)lane * stride;
 					const int fmode = fir_mode(cd->wide != 0, sbps);
 					if(fmode == 0) rbits = eval_candidate_owner<MAXORD, false, 0>(reg, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
@@ -865,10 +872,13 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 					for(uint32_t p = (uint32_t)lane; p < (1u << po); p += 64) kbw[p] = ktmp[p];
 					__builtin_amdgcn_wave_barrier();
 				}
+				if(ci == 0) STAMP(2);
+				if(ci == nwaves) STAMP(3);
 			}
 			if(lane == 0) { sh->wbest_bits[wave] = wb_bits; sh->wbest_ci[wave] = wb_ci; sh->wbest_po[wave] = wb_po; }
 		}
 		__syncthreads();
+		STAMP(4);
 		// ---- winner: first minimum in the reference's evaluation order -----------------------------------------
 		uint32_t cb = 0xffffffffu, cci = 0xffffffffu, cw = 0;
 		for(uint32_t w = 0; w < nwaves; w++) {
@@ -905,6 +915,8 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 			dec->constant = best_constant;
 		}
 	}
+	STAMP(5);
+#undef STAMP
 }
 
 } // namespace flacgpu
@@ -937,7 +949,6 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	static bool attr_set = false;
 	if(!attr_set) {
 		hipError_t e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e != hipSuccess) return e;
 		attr_set = true;
@@ -949,12 +960,21 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	if(pev) (void)hipEventRecord(pev[2], s);
 	const uint32_t waves = eval_waves(P);
 	const size_t lds = eval_layout(P, waves).total;
+	if(B.dbg) {
+		static bool said = false;
+		if(!said) {
+			said = true;
+			int nb0 = -1, nb1 = -1;
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, (const void *)eval_kernel<MAXORD, 0>, (int)(waves * 64), lds);
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void *)eval_kernel<MAXORD, 2>, (int)(waves * 64), lds);
+			fprintf(stderr, "[flacgpu] eval: %u waves/WG, %zu B LDS/WG, occupancy API: %d / %d WGs per CU\n", waves, lds, nb0, nb1);
+		}
+	}
 	const bool owner_possible = P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH;
 	// which flavours can occur in this batch at all (each launch serves only its own workgroups)
-	if(owner_possible) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec);
-	if(owner_possible) hipLaunchKernelGGL((eval_kernel<MAXORD, 1>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec);
+	if(owner_possible) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	if(!owner_possible || tail_n || P.max_po > 6)
-		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec);
+		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	return hipGetLastError();
 }
 

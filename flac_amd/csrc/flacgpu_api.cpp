@@ -141,6 +141,7 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->ab.autoc) (void)hipFree(c->ab.autoc);
 	if(c->ab.cands) (void)hipFree(c->ab.cands);
 	if(c->ab.valid) (void)hipFree(c->ab.valid);
+	if(c->ab.dbg) (void)hipFree(c->ab.dbg);
 	for(int i = 0; i < 3; i++) if(c->pev[i]) (void)hipEventDestroy(c->pev[i]);
 	if(c->d_jobtab) (void)hipFree(c->d_jobtab);
 	for(int i = 0; i < 5; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -240,6 +241,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		ok = ok && hipMalloc(&c->ab.autoc, nfc * P.max_jobs * MAX_ORDER * sizeof(double)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.cands, nfc * ncs * sizeof(Candidate)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.valid, nfc * ncs * sizeof(int)) == hipSuccess;
+		if(ok && getenv("FLACGPU_DEBUG_TIMING")) { ok = hipMalloc(&c->ab.dbg, nfc * 16 * sizeof(unsigned long long)) == hipSuccess; if(ok) (void)hipMemset(c->ab.dbg, 0, nfc * 16 * sizeof(unsigned long long)); }
 	}
 	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
 	*out = c;
@@ -271,6 +273,32 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	}
 	(void)hipEventRecord(c->ev[0], s);
 	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->ab, c->d_decisions, c->pev, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(c->ab.dbg) {
+		// development aid: average shader cycles per phase of the eval workgroups of this launch
+		const size_t nwg = (size_t)nframes * P.ncand;
+		unsigned long long *h = (unsigned long long *)malloc(nwg * 16 * sizeof(unsigned long long));
+		if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, c->ab.dbg, nwg * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+			double acc[6] = {0}; size_t cnt[6] = {0};
+			for(size_t w = 0; w < nwg; w++) for(int k = 1; k < 6; k++) if(h[w * 16 + k] && h[w * 16 + k - 1]) { acc[k] += (double)(h[w * 16 + k] - h[w * 16 + k - 1]); cnt[k]++; }
+			double pro = 0; size_t npro = 0;
+			for(size_t w = 0; w < nwg; w++) if(h[w * 16 + 8] && h[w * 16]) { pro += (double)(h[w * 16 + 8] - h[w * 16]); npro++; }
+			fprintf(stderr, "[flacgpu] eval prologue %.0f ticks (%zu WGs)\n", npro ? pro / npro : 0, npro);
+			for(int v = 1; v <= 3; v++) {
+				unsigned long long t0 = ~0ull, t1 = 0; double dur = 0; size_t nv = 0;
+				for(size_t w = 0; w < nwg; w++) if(h[w * 16 + 9] == (unsigned long long)v && h[w * 16 + 5]) {
+					nv++; dur += (double)(h[w * 16 + 5] - h[w * 16]);
+					if(h[w * 16] < t0) t0 = h[w * 16];
+					if(h[w * 16 + 5] > t1) t1 = h[w * 16 + 5];
+				}
+				if(nv) fprintf(stderr, "[flacgpu] eval variant %d: %zu WGs, avg %.0f ticks each, first start -> last end %.0f ticks, mean concurrency %.1f WGs\n",
+				               v - 1, nv, dur / nv, (double)(t1 - t0), dur / (double)(t1 - t0));
+			}
+			fprintf(stderr, "[flacgpu] eval phases (avg s_memtime ticks per WG): load %.0f  cand0 %.0f  round1->round2 %.0f  rest %.0f  decide %.0f\n",
+			        cnt[1] ? acc[1] / cnt[1] : 0, cnt[2] ? acc[2] / cnt[2] : 0, cnt[3] ? acc[3] / cnt[3] : 0, cnt[4] ? acc[4] / cnt[4] : 0, cnt[5] ? acc[5] / cnt[5] : 0);
+		}
+		free(h);
+		(void)hipMemsetAsync(c->ab.dbg, 0, nwg * 16 * sizeof(unsigned long long), s);
+	}
 	(void)hipEventRecord(c->ev[1], s);
 	if(launch_pack(P, d_pcm, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	(void)hipEventRecord(c->ev[2], s);

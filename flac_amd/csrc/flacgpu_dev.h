@@ -86,6 +86,7 @@ struct AnalyzeBuffers {
 	double *autoc;             // [frames*ncand][max_jobs][MAX_ORDER]
 	Candidate *cands;          // [frames*ncand][max_analyses+1]: [0] fixed, [1+a] LPC analysis a
 	int *valid;                // same shape
+	unsigned long long *dbg;   // FLACGPU_DEBUG_TIMING=1: [frames*ncand][16] s_memtime stamps of the eval kernel (else null)
 };
 constexpr int EVAL_MAX_WAVES = 8;   // wavefronts per eval workgroup (one residual candidate each per round)
 
