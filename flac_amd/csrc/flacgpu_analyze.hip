@@ -26,6 +26,13 @@
 
 namespace flacgpu {
 
+#ifndef AUTOC_WAVES_PER_SIMD
+#define AUTOC_WAVES_PER_SIMD 8
+#endif
+#ifndef EVAL_WAVES_PER_SIMD
+#define EVAL_WAVES_PER_SIMD 4
+#endif
+
 // XCD-aware mapping (blocks round-robin over the 8 XCDs): keep the candidate channels of one frame on one XCD so
 // that their shared PCM lines hit that XCD's L2.
 __device__ __forceinline__ void map_block(uint32_t b, uint32_t nframes, uint32_t ncand, uint32_t &f, uint32_t &cand)
@@ -34,7 +41,10 @@ __device__ __forceinline__ void map_block(uint32_t b, uint32_t nframes, uint32_t
 	const uint32_t per_xcd_full = (total / (8 * ncand)) * ncand;
 	const uint32_t head = per_xcd_full * 8;
 	const uint32_t lin = b < head ? (b & 7) * per_xcd_full + (b >> 3) : b;
-	f = lin / ncand; cand = lin % ncand;
+	f = lin / ncand;
+	// rotate the channel order from frame to frame: workgroups reach the CUs of an XCD round-robin, and with a fixed
+	// order the slowest channel (side: 17-bit samples, no dot2) of every frame would land on the same quarter of the CUs
+	cand = (lin + f + (f >> 3) + (f >> 6)) % ncand;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -245,7 +255,7 @@ __device__ __forceinline__ float job_value(const JobView &J, int32_t v, float wt
 #define STEP816(acc, xs, ys, u) acc += fma((double)(xs)[2 * (u)], (double)(ys)[2 * (u)], (double)(xs)[2 * (u) + 1] * (double)(ys)[2 * (u) + 1])
 
 template <int DUMMY>
-__global__ __launch_bounds__(TPB) void autoc_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
+__global__ __launch_bounds__(TPB, AUTOC_WAVES_PER_SIMD) void autoc_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
                                                     const float *__restrict__ tail_windows, uint32_t nframes, uint32_t tail_n,
                                                     const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                     const ChanPrep *__restrict__ preps, double *__restrict__ autoc_out)
@@ -616,84 +626,138 @@ __device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c)
 	return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, false);
 }
 
+// ---- residual magnitude of one lane's S samples, packed 16-bit samples -------------------------------------------
+// NP coefficient pairs (order <= 2*NP): sample t of the piece window is predicted from the NP pairs in front of it;
+// even t take their pairs straight from the LDS words (A), odd t from the words shifted by one sample (B).
+// Same low 32 bits as the wrapping sum of lpc.c:321.  FIRST: piece 0, where lane 0 skips its `order` warm-up samples.
+template <int NP, bool NARROW, bool FIRST, bool MASKED>
+__device__ __forceinline__ void fir_piece_packed(const uint32_t *w /* word of sample (piece start - 2*NP) */, const uint32_t (&Q)[NP], int shift, uint32_t order,
+                                                 uint32_t rem, bool lane0, uint32_t &acc32, uint64_t &acc64)
+{
+	constexpr int NW = NP + CHUNK / 2;
+	uint32_t A[NW + 1], B[NW];
+#pragma unroll
+	for(int m = 0; m < NW; m++) A[m] = w[m];
+	A[NW] = 0;
+#pragma unroll
+	for(int m = 0; m < NW; m++) B[m] = __builtin_amdgcn_alignbit(A[m + 1], A[m], 16);
+#pragma unroll
+	for(int s = 0; s < CHUNK; s++) {
+		const int t = 2 * NP + s;
+		int32_t sum = 0;
+#pragma unroll
+		for(int p = 0; p < NP; p++) sum = dot2((t & 1) ? B[(t - 3) / 2 - p] : A[(t - 2) / 2 - p], Q[p], sum);
+		const int32_t x = (t & 1) ? ((int32_t)A[(t - 1) / 2] >> 16) : (int32_t)(int16_t)(A[t / 2] & 0xffffu);
+		const int32_t r = x - (sum >> shift);
+		uint32_t av = (uint32_t)(r < 0 ? -r : r);
+		if(FIRST && s < 2 * NP) { if(lane0 && (uint32_t)s < order) av = 0; }
+		if(MASKED) { if((uint32_t)s >= rem) av = 0; }
+		if(NARROW) acc32 += av; else acc64 += av;
+	}
+}
+template <int NP, bool NARROW>
+__device__ __forceinline__ uint64_t fir_abs_packed(const uint32_t *reg, uint32_t S, uint32_t order, const uint32_t (&Q)[NP], int shift, int lane)
+{
+	uint32_t acc32 = 0;
+	uint64_t acc64 = 0;
+	const uint32_t nfull = S / CHUNK;
+	const uint32_t *w = reg + (OH - 2 * NP) / 2;
+	fir_piece_packed<NP, NARROW, true, false>(w, Q, shift, order, CHUNK, lane == 0, acc32, acc64);      // S >= 16
+#pragma unroll 1
+	for(uint32_t c = 1; c < nfull; c++) fir_piece_packed<NP, NARROW, false, false>(w + (CHUNK / 2) * c, Q, shift, order, CHUNK, false, acc32, acc64);
+	if(S % CHUNK) fir_piece_packed<NP, NARROW, false, true>(w + (CHUNK / 2) * nfull, Q, shift, order, S % CHUNK, false, acc32, acc64);
+	return NARROW ? (uint64_t)acc32 : acc64;
+}
+template <int MAXORD, bool NARROW>
+__device__ __forceinline__ uint64_t fir_abs_packed_dispatch(const uint32_t *reg, uint32_t S, uint32_t order, const int32_t *q, int shift, int lane)
+{
+	// pair p = (q[2p] for the nearer sample, q[2p+1] for the farther one); taps beyond `order` are zero
+	uint32_t Q[MAXORD / 2];
+#pragma unroll
+	for(int p = 0; p < MAXORD / 2; p++) Q[p] = ((uint32_t)q[2 * p] << 16) | ((uint32_t)q[2 * p + 1] & 0xffffu);
+	const uint32_t np = (order + 1) / 2;
+#define FAP(N_) { uint32_t Qn[N_]; _Pragma("unroll") for(int p = 0; p < N_; p++) Qn[p] = Q[p]; return fir_abs_packed<N_, NARROW>(reg, S, order, Qn, shift, lane); }
+	if(MAXORD >= 16 && np > 6) { if(np == 7) FAP(7) else FAP(8) }
+	if(MAXORD >= 12 && np > 4) { if(np == 5) FAP(5) else FAP(6) }
+	if(np > 2) { if(np == 3) FAP(3) else FAP(4) }
+	if(np == 2) FAP(2)
+	FAP(1)
+#undef FAP
+}
+
+// ---- the same on 32-bit samples: NT taps (order <= NT); FMODE 0 v_mad_i32_i24, 1 32-bit multiplies (both lpc.c:321),
+// 2 64-bit accumulate (lpc.c:582)
+template <int NT, int FMODE, bool NARROW, bool FIRST, bool MASKED>
+__device__ __forceinline__ void fir_piece_i32(const int32_t *w /* sample (piece start - NT) */, const int32_t (&q)[NT], int shift, uint32_t order,
+                                              uint32_t rem, bool lane0, uint32_t &acc32, uint64_t &acc64)
+{
+	int32_t x[NT + CHUNK];
+#pragma unroll
+	for(int k = 0; k < NT + CHUNK; k++) x[k] = w[k];
+#pragma unroll
+	for(int s = 0; s < CHUNK; s++) {
+		int32_t r;
+		if(FMODE == 2) {
+			int64_t sum = 0;
+#pragma unroll
+			for(int jj = 0; jj < NT; jj++) sum += (int64_t)q[jj] * (int64_t)x[NT + s - 1 - jj];
+			r = (int32_t)((int64_t)x[NT + s] - (sum >> shift));
+		}
+		else {
+			uint32_t sum = 0;
+#pragma unroll
+			for(int jj = 0; jj < NT; jj++)
+				sum += FMODE == 0 ? (uint32_t)__mul24(q[jj], x[NT + s - 1 - jj]) : (uint32_t)q[jj] * (uint32_t)x[NT + s - 1 - jj];
+			r = (int32_t)((uint32_t)x[NT + s] - (uint32_t)((int32_t)sum >> shift));
+		}
+		uint32_t av = (uint32_t)(r < 0 ? -(uint32_t)r : (uint32_t)r);
+		if(FIRST && s < NT) { if(lane0 && (uint32_t)s < order) av = 0; }
+		if(MASKED) { if((uint32_t)s >= rem) av = 0; }
+		if(NARROW) acc32 += av; else acc64 += av;
+	}
+}
+template <int NT, int FMODE, bool NARROW>
+__device__ __forceinline__ uint64_t fir_abs_i32(const uint32_t *reg, uint32_t S, uint32_t order, const int32_t *qall, int shift, int lane)
+{
+	int32_t q[NT];
+#pragma unroll
+	for(int jj = 0; jj < NT; jj++) q[jj] = qall[jj];
+	uint32_t acc32 = 0;
+	uint64_t acc64 = 0;
+	const uint32_t nfull = S / CHUNK;
+	const int32_t *w = (const int32_t *)reg + (OH - NT);
+	fir_piece_i32<NT, FMODE, NARROW, true, false>(w, q, shift, order, CHUNK, lane == 0, acc32, acc64);
+#pragma unroll 1
+	for(uint32_t c = 1; c < nfull; c++) fir_piece_i32<NT, FMODE, NARROW, false, false>(w + CHUNK * c, q, shift, order, CHUNK, false, acc32, acc64);
+	if(S % CHUNK) fir_piece_i32<NT, FMODE, NARROW, false, true>(w + CHUNK * nfull, q, shift, order, S % CHUNK, false, acc32, acc64);
+	return NARROW ? (uint64_t)acc32 : acc64;
+}
+template <int MAXORD, int FMODE, bool NARROW>
+__device__ __forceinline__ uint64_t fir_abs_i32_dispatch(const uint32_t *reg, uint32_t S, uint32_t order, const int32_t *q, int shift, int lane)
+{
+	if(MAXORD >= 16 && order > 12) return fir_abs_i32<MAXORD >= 16 ? 16 : MAXORD, FMODE, NARROW>(reg, S, order, q, shift, lane);
+	if(MAXORD >= 12 && order > 8) return fir_abs_i32<MAXORD >= 12 ? 12 : MAXORD, FMODE, NARROW>(reg, S, order, q, shift, lane);
+	if(order > 4) return fir_abs_i32<8, FMODE, NARROW>(reg, S, order, q, shift, lane);
+	return fir_abs_i32<4, FMODE, NARROW>(reg, S, order, q, shift, lane);
+}
+
 // One wavefront evaluates one residual candidate on the owner layout; requires n == 64*S, S >= 16, max_po <= 6.
-// PACKED: 16-bit sample pairs + v_dot2_i32_i16 (same low 32 bits as the wrapping sum of lpc.c:321); else the int32 FIR.
-// FMODE (unpacked only): 0 v_mad_i32_i24, 1 32-bit multiplies (both lpc.c:321), 2 64-bit accumulate (lpc.c:582).
-template <int MAXORD, bool PACKED, int FMODE>
-__device__ __forceinline__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's region */, uint32_t S, uint32_t n, uint32_t order, const int32_t *q, int shift,
-                                         uint32_t sbps, uint32_t rice_limit, uint32_t max_po, uint32_t min_po, const uint32_t *divtab,
+template <int MAXORD>
+__device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's region */, bool packed, uint32_t S, uint32_t n, uint32_t order, const int32_t *q, int shift,
+                                         bool wide, uint32_t sbps, uint32_t rice_limit, uint32_t max_po, uint32_t min_po, const uint32_t *divtab,
                                          uint8_t *kout, uint32_t *best_po_out, int lane)
 {
 	const uint32_t psize = n >> max_po;
 	const bool narrow = (sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
-	uint32_t acc32 = 0;
-	uint64_t acc64 = 0;
-	const uint32_t npieces = (S + CHUNK - 1) / CHUNK;
-	if(PACKED) {
-		uint32_t Q[MAXORD / 2];
-#pragma unroll
-		for(int p = 0; p < MAXORD / 2; p++) Q[p] = ((uint32_t)q[2 * p] << 16) | ((uint32_t)q[2 * p + 1] & 0xffffu);
-#pragma unroll 1
-		for(uint32_t c = 0; c < npieces; c++) {
-			const uint32_t *w = reg + (OH + CHUNK * c - MAXORD) / 2;
-			uint32_t A[(MAXORD + CHUNK) / 2 + 1], B[(MAXORD + CHUNK) / 2];
-#pragma unroll
-			for(int m = 0; m < (MAXORD + CHUNK) / 2; m++) A[m] = w[m];
-			A[(MAXORD + CHUNK) / 2] = 0;
-#pragma unroll
-			for(int m = 0; m < (MAXORD + CHUNK) / 2; m++) B[m] = __builtin_amdgcn_alignbit(A[m + 1], A[m], 16);
-			const uint32_t rem = S - CHUNK * c;
-#pragma unroll
-			for(int s = 0; s < CHUNK; s++) {
-				const int t = MAXORD + s;
-				int32_t sum = 0;
-#pragma unroll
-				for(int p = 0; p < MAXORD / 2; p++) sum = dot2((t & 1) ? B[(t - 3) / 2 - p] : A[(t - 2) / 2 - p], Q[p], sum);
-				const int32_t x = (t & 1) ? ((int32_t)A[(t - 1) / 2] >> 16) : (int32_t)(int16_t)(A[t / 2] & 0xffffu);
-				const int32_t r = x - (sum >> shift);
-				uint32_t av = (uint32_t)(r < 0 ? -r : r);
-				if(s < MAXORD) { if(c == 0 && lane == 0 && (uint32_t)s < order) av = 0; }
-				if((uint32_t)s >= rem) av = 0;
-				if(narrow) acc32 += av; else acc64 += av;
-			}
-		}
-	}
+	uint64_t v;
+	if(packed) v = narrow ? fir_abs_packed_dispatch<MAXORD, true>(reg, S, order, q, shift, lane) : fir_abs_packed_dispatch<MAXORD, false>(reg, S, order, q, shift, lane);
 	else {
-		int32_t qr[MAXORD];
-#pragma unroll
-		for(int jj = 0; jj < MAXORD; jj++) qr[jj] = q[jj];
-		constexpr int fmode = FMODE;
-#pragma unroll 1
-		for(uint32_t c = 0; c < npieces; c++) {
-			const int32_t *w = (const int32_t *)reg + (OH + CHUNK * c - MAXORD);
-			int32_t x[MAXORD + CHUNK];
-#pragma unroll
-			for(int k = 0; k < MAXORD + CHUNK; k++) x[k] = w[k];
-			const uint32_t rem = S - CHUNK * c;
-#pragma unroll
-			for(int s = 0; s < CHUNK; s++) {
-				int32_t r;
-				if(fmode == 2) {
-					int64_t sum = 0;
-#pragma unroll
-					for(int jj = 0; jj < MAXORD; jj++) sum += (int64_t)qr[jj] * (int64_t)x[MAXORD + s - 1 - jj];
-					r = (int32_t)((int64_t)x[MAXORD + s] - (sum >> shift));
-				}
-				else {
-					uint32_t sum = 0;
-#pragma unroll
-					for(int jj = 0; jj < MAXORD; jj++)
-						sum += fmode == 0 ? (uint32_t)__mul24(qr[jj], x[MAXORD + s - 1 - jj]) : (uint32_t)qr[jj] * (uint32_t)x[MAXORD + s - 1 - jj];
-					r = (int32_t)((uint32_t)x[MAXORD + s] - (uint32_t)((int32_t)sum >> shift));
-				}
-				uint32_t av = (uint32_t)(r < 0 ? -(uint32_t)r : (uint32_t)r);
-				if(s < MAXORD) { if(c == 0 && lane == 0 && (uint32_t)s < order) av = 0; }
-				if((uint32_t)s >= rem) av = 0;
-				if(narrow) acc32 += av; else acc64 += av;
-			}
-		}
+		const int fmode = fir_mode(wide, sbps);
+		if(fmode == 0) v = narrow ? fir_abs_i32_dispatch<MAXORD, 0, true>(reg, S, order, q, shift, lane) : fir_abs_i32_dispatch<MAXORD, 0, false>(reg, S, order, q, shift, lane);
+		else if(fmode == 1) v = fir_abs_i32_dispatch<MAXORD, 1, false>(reg, S, order, q, shift, lane);     // > 24-bit samples are never "narrow"
+		else v = fir_abs_i32_dispatch<MAXORD, 2, false>(reg, S, order, q, shift, lane);
+		if(fmode != 0 && narrow) v = (uint32_t)v;
 	}
-	const uint64_t v = narrow ? (uint64_t)acc32 : acc64;
 	if(!__any((int)(v >= (1u << 23))))
 		return rice_search_nodes((uint32_t)v, 6 - max_po, n, order, max_po, min_po, rice_limit, divtab, kout, best_po_out, lane);
 	return rice_search_owner(v, narrow, 6 - max_po, n, order, max_po, min_po, rice_limit, divtab, kout, best_po_out, lane);
@@ -705,23 +769,24 @@ struct EvalSmall {
 	uint32_t wbest_bits[EVAL_MAX_WAVES], wbest_ci[EVAL_MAX_WAVES], wbest_po[EVAL_MAX_WAVES];
 	uint32_t rice2;
 };
-struct EvalLayout { uint32_t wsums, kbestw, kcandw, small, total; };
-__host__ __device__ inline uint32_t eval_sig_bytes(const DevParams &P)
+// generic: (sig | per-wave sums, params) ; owner: (sig regions | candidate records | per-wave params)
+struct EvalLayout { uint32_t wsums, kbestw, kcandw, cands, valid, small, total; };
+__host__ __device__ inline uint32_t owner_sig_bytes(const DevParams &P)
 {
 	const uint32_t N = P.blocksize;
-	uint32_t owner = 0;
-	if(N % 64 == 0 && N / 64 >= (uint32_t)OH) owner = 64 * ((N / 64 + OH) | 1u) * 4 + (CHUNK + MAX_ORDER) * 4;
-	const uint32_t b = owner > P.sig_bytes ? owner : P.sig_bytes;
-	return (b + 15u) & ~15u;
+	if(N % 64 == 0 && N / 64 >= (uint32_t)OH) return (64 * ((N / 64 + OH) | 1u) * 4 + (CHUNK + MAX_ORDER) * 4 + 15u) & ~15u;
+	return 0;
 }
-__host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t waves)
+__host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t waves, bool generic)
 {
 	EvalLayout L;
-	uint32_t o = eval_sig_bytes(P);
-	L.wsums = o;  o += waves * (2u << P.max_po) * 8;
+	uint32_t o = generic ? P.sig_bytes : owner_sig_bytes(P);
+	L.wsums = o;  o += generic ? waves * (2u << P.max_po) * 8 : 0;
 	L.kbestw = o; o += waves * 2 * (1u << P.max_po);
-	L.kcandw = o; o += P.max_po > 6 ? waves * (2u << P.max_po) : 0;
+	L.kcandw = o; o += generic && P.max_po > 6 ? waves * (2u << P.max_po) : 0;
 	o = (o + 15u) & ~15u;
+	L.cands = o;  o += (P.max_analyses + 1) * (uint32_t)sizeof(Candidate);
+	L.valid = o;  o += ((P.max_analyses + 1) * 4 + 15u) & ~15u;
 	L.small = o;  o += (uint32_t)sizeof(EvalSmall);
 	L.total = (o + 15u) & ~15u;
 	return L;
@@ -733,7 +798,7 @@ __host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t w
 //      needs the 64-bit FIR), chosen per workgroup; also every workgroup that has no residual candidate at all
 //   2  any other block length / partition order: generic chunked evaluation with LDS partition sums
 template <int MAXORD, int VARIANT>
-__global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nframes, uint32_t tail_n,
+__global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_SIMD : 2) void eval_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nframes, uint32_t tail_n,
                                                                    const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                                    const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
                                                                    const int *__restrict__ valid, SubDecision *__restrict__ decisions, unsigned long long *__restrict__ dbg)
@@ -754,15 +819,15 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 	const uint32_t hdr = 8 + wasted;
 	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
 	const uint32_t cstride = P.max_analyses + 1;
-	const Candidate *mycands = cands + fc * cstride;
-	const int *myvalid = valid + fc * cstride;
 	SubDecision *dec = decisions + fc;
 
-	const EvalLayout LY = eval_layout(P, nwaves);
+	const EvalLayout LY = eval_layout(P, nwaves, VARIANT == 2);
 	uint32_t *sigw = (uint32_t *)smem;
 	uint64_t *wsums_all = (uint64_t *)(smem + LY.wsums);
 	uint8_t *kbestw_all = smem + LY.kbestw;
 	uint8_t *kcandw_all = smem + LY.kcandw;
+	const Candidate *mycands = (const Candidate *)(smem + LY.cands);     // LDS copies of this channel's candidate records
+	const int *myvalid = (const int *)(smem + LY.valid);
 	EvalSmall *sh = (EvalSmall *)(smem + LY.small);
 
 	uint32_t best_type = 1, best_order = 0, best_po = 0, best_precision = 0, best_ci = 0, best_wave = 0;
@@ -778,53 +843,101 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 	const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
 	const uint32_t S = n / 64;
 	const bool owner = (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6;
-	bool packed = owner && sbps <= 16 && (S % 2 == 0);
-	if(packed && any_candidates) {
-		// a candidate whose prediction needs the 64-bit FIR (lpc.c:582) keeps the whole workgroup on 32-bit samples
-		int w = 0;
-		for(uint32_t ci = (uint32_t)lane; ci <= nan; ci += 64) w |= myvalid[ci] && mycands[ci].wide;
-		if(__any(w)) packed = false;
-	}
 	{
-		// VARIANT 0 serves every workgroup on the owner layout (packed or 32-bit samples, chosen here per workgroup)
-		// and the ones without residual candidates; VARIANT 2 the remaining block shapes
 		const int kind = !any_candidates ? 0 : owner ? 0 : 2;
 		if(kind != VARIANT) return;
 	}
 	if(dbg && tid == 0) { dbg[(size_t)blockIdx.x * 16] = t_start; dbg[(size_t)blockIdx.x * 16 + 8] = (unsigned long long)clock64(); dbg[(size_t)blockIdx.x * 16 + 9] = (unsigned long long)VARIANT + 1; }
+
 	if(pr.flags & PREP_CONSTANT) {
 		const uint32_t bits = hdr + sbps;
 		if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_bits = bits; }
 	}
 	if(any_candidates) {
-		const uint32_t stride = owner_stride_words(S, packed);
-
+		// ---- first batch of PCM on its way while the small tables are set up ---------------------------------
+		constexpr int LB = 4;
+		const bool pairs = VARIANT == 0 && C == 2;              // two samples per thread and load (S is even or the layout is 32-bit)
+		const uint32_t npair = n / 2;
+		int4 pv[LB];
+		if(pairs) {
+#pragma unroll
+			for(int u = 0; u < LB; u++) { const uint32_t m = (uint32_t)tid + (uint32_t)u * nthreads; if(m < npair) pv[u] = ((const int4 *)frame_pcm)[m]; }
+		}
 		for(uint32_t t = (uint32_t)tid; t < (MAX_PO + 1) * (MAX_ORDER + 1); t += nthreads) {
 			const uint32_t po = t / (MAX_ORDER + 1), o = t - po * (MAX_ORDER + 1);
 			const uint32_t ps = n >> po;
 			sh->divtab[t] = ps > o ? 0x40000u / (ps - o) : 0;
 		}
+		{
+			const uint32_t *src = (const uint32_t *)(cands + fc * cstride);
+			uint32_t *dst = (uint32_t *)(smem + LY.cands);
+			for(uint32_t t = (uint32_t)tid; t < (nan + 1) * (uint32_t)(sizeof(Candidate) / 4); t += nthreads) dst[t] = src[t];
+			int *vd = (int *)(smem + LY.valid);
+			for(uint32_t t = (uint32_t)tid; t <= nan; t += nthreads) vd[t] = valid[fc * cstride + t];
+		}
+		__syncthreads();
+		bool packed = VARIANT == 0 && sbps <= 16 && (S % 2 == 0);
+		if(packed) {
+			// a candidate whose prediction needs the 64-bit FIR (lpc.c:582) keeps the whole workgroup on 32-bit samples
+			for(uint32_t ci = 0; ci <= nan; ci++) if(myvalid[ci] && mycands[ci].wide) packed = false;
+		}
+		const uint32_t stride = owner_stride_words(S, packed);
+
 		// ---- block into LDS -------------------------------------------------------------------------------
 		if(VARIANT != 2) {
 			// zero lane 0's history
 			if(tid < OH) { if(packed) { if(tid < OH / 2) sigw[tid] = 0; } else sigw[tid] = 0; }
-			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) {
-				int32_t v;
-				if(C == 2) {
-					const int2 lr = ((const int2 *)frame_pcm)[i];
-					v = which == 0 ? lr.x : which == 1 ? lr.y : which == 2 ? ((lr.x + lr.y) >> 1) : (lr.x - lr.y);
+			const bool spow2 = (S & (S - 1)) == 0;
+			const uint32_t slog = ilog2_u32(S);
+			if(pairs) {
+				for(uint32_t m0 = (uint32_t)tid; m0 < npair; m0 += LB * nthreads) {
+					if(m0 != (uint32_t)tid) {
+#pragma unroll
+						for(int u = 0; u < LB; u++) { const uint32_t m = m0 + (uint32_t)u * nthreads; if(m < npair) pv[u] = ((const int4 *)frame_pcm)[m]; }
+					}
+#pragma unroll
+					for(int u = 0; u < LB; u++) {
+						const uint32_t m = m0 + (uint32_t)u * nthreads;
+						if(m < npair) {
+							const int4 d = pv[u];
+							int32_t v0 = which == 0 ? d.x : which == 1 ? d.y : which == 2 ? ((d.x + d.y) >> 1) : (d.x - d.y);
+							int32_t v1 = which == 0 ? d.z : which == 1 ? d.w : which == 2 ? ((d.z + d.w) >> 1) : (d.z - d.w);
+							v0 >>= wasted; v1 >>= wasted;
+							const uint32_t i = 2 * m;
+							const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
+							if(packed) {
+								const uint32_t wv = ((uint32_t)v0 & 0xffffu) | ((uint32_t)v1 << 16);
+								sigw[Lo * stride + (OH + s) / 2] = wv;
+								if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S) / 2] = wv;
+							}
+							else {
+								uint32_t *d0 = sigw + Lo * stride + OH + s;
+								d0[0] = (uint32_t)v0;
+								if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S)] = (uint32_t)v0;
+								// S may be odd here: the second sample can belong to the next lane
+								const uint32_t i1 = i + 1, L1 = spow2 ? i1 >> slog : i1 / S, s1 = i1 - L1 * S;
+								sigw[L1 * stride + OH + s1] = (uint32_t)v1;
+								if(s1 + OH >= S && L1 + 1 < 64) sigw[(L1 + 1) * stride + (s1 + OH - S)] = (uint32_t)v1;
+							}
+						}
+					}
 				}
-				else v = pick_channel(frame_pcm, C, i, which);
-				v >>= wasted;
-				const uint32_t Lo = i / S, s = i - Lo * S;
-				if(packed) {
-					uint16_t *h = (uint16_t *)sigw;
-					h[2 * (Lo * stride) + OH + s] = (uint16_t)v;
-					if(s + OH >= S && Lo + 1 < 64) h[2 * ((Lo + 1) * stride) + (s + OH - S)] = (uint16_t)v;
+				if((n & 1) && tid == 0) {      // cannot happen on the owner layout (n % 64 == 0); kept for completeness
 				}
-				else {
-					sigw[Lo * stride + OH + s] = (uint32_t)v;
-					if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S)] = (uint32_t)v;
+			}
+			else {
+				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) {
+					const int32_t v = pick_channel(frame_pcm, C, i, which) >> wasted;
+					const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
+					if(packed) {
+						uint16_t *h = (uint16_t *)sigw;
+						h[2 * (Lo * stride) + OH + s] = (uint16_t)v;
+						if(s + OH >= S && Lo + 1 < 64) h[2 * ((Lo + 1) * stride) + (s + OH - S)] = (uint16_t)v;
+					}
+					else {
+						sigw[Lo * stride + OH + s] = (uint32_t)v;
+						if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S)] = (uint32_t)v;
+					}
 				}
 			}
 		}
@@ -849,22 +962,17 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64) void eval_kernel(const DevPara
 				if(!myvalid[ci]) continue;
 				const Candidate *cd = &mycands[ci];
 				const uint32_t order = cd->order;
-				int32_t q[MAXORD];
-#pragma unroll
-				for(int jj = 0; jj < MAXORD; jj++) q[jj] = cd->q[jj];
 				uint32_t po, rbits;
-				if(VARIANT == 0 && packed)
-					rbits = eval_candidate_owner<MAXORD, true, 0>(sigw + (uint32_t)lane * stride, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
-				else if(VARIANT == 0) {
-					const uint32_t *reg = sigw + (uint32_t)lane * stride;
-					const int fmode = fir_mode(cd->wide != 0, sbps);
-					if(fmode == 0) rbits = eval_candidate_owner<MAXORD, false, 0>(reg, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
-					else if(fmode == 1) rbits = eval_candidate_owner<MAXORD, false, 1>(reg, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
-					else rbits = eval_candidate_owner<MAXORD, false, 2>(reg, S, n, order, q, cd->shift, sbps, P.rice_limit, frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
-				}
-				else
+				if(VARIANT == 0)
+					rbits = eval_candidate_owner<MAXORD>(sigw + (uint32_t)lane * stride, packed, S, n, order, cd->q, cd->shift, cd->wide != 0, sbps, P.rice_limit,
+					                                     frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
+				else {
+					int32_t q[MAXORD];
+#pragma unroll
+					for(int jj = 0; jj < MAXORD; jj++) q[jj] = cd->q[jj];
 					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, (const int32_t *)smem, n, order, q, cd->shift,
 					                                    cd->wide != 0, sbps, P, frame_max_po, frame_min_po, &po, lane);
+				}
 				const uint32_t est = ci == 0 ? sat_add_u32(hdr + order * sbps, rbits)
 				                             : sat_add_u32(hdr + 4 + 5 + order * (cd->precision + sbps), rbits);
 				if(est > 0 && est < wb_bits) {      // strict: the earlier candidate keeps a tie (stream_encoder.c:4191,4266)
@@ -938,8 +1046,8 @@ uint32_t eval_waves(const DevParams &P)
 }
 size_t analyze_lds_bytes(const DevParams &P)
 {
-	const size_t a = P.sig_bytes, d = eval_layout(P, eval_waves(P)).total;
-	return a > d ? a : d;
+	const size_t a = P.sig_bytes, d = eval_layout(P, eval_waves(P), false).total, g = eval_layout(P, eval_waves(P), true).total;
+	return a > d ? (a > g ? a : g) : (d > g ? d : g);
 }
 
 template <int MAXORD>
@@ -959,14 +1067,14 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	}
 	if(pev) (void)hipEventRecord(pev[2], s);
 	const uint32_t waves = eval_waves(P);
-	const size_t lds = eval_layout(P, waves).total;
+	const size_t lds = eval_layout(P, waves, false).total, lds_generic = eval_layout(P, waves, true).total;
 	if(B.dbg) {
 		static bool said = false;
 		if(!said) {
 			said = true;
 			int nb0 = -1, nb1 = -1;
 			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, (const void *)eval_kernel<MAXORD, 0>, (int)(waves * 64), lds);
-			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void *)eval_kernel<MAXORD, 2>, (int)(waves * 64), lds);
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void *)eval_kernel<MAXORD, 2>, (int)(waves * 64), lds_generic);
 			fprintf(stderr, "[flacgpu] eval: %u waves/WG, %zu B LDS/WG, occupancy API: %d / %d WGs per CU\n", waves, lds, nb0, nb1);
 		}
 	}
@@ -974,7 +1082,7 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	// which flavours can occur in this batch at all (each launch serves only its own workgroups)
 	if(owner_possible) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	if(!owner_possible || tail_n || P.max_po > 6)
-		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(waves * 64), lds_generic, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	return hipGetLastError();
 }
 
