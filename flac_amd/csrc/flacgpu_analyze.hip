@@ -30,7 +30,7 @@ namespace flacgpu {
 #define AUTOC_WAVES_PER_SIMD 8
 #endif
 #ifndef EVAL_WAVES_PER_SIMD
-#define EVAL_WAVES_PER_SIMD 4
+#define EVAL_WAVES_PER_SIMD 5
 #endif
 
 // XCD-aware mapping (blocks round-robin over the 8 XCDs): keep the candidate channels of one frame on one XCD so
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	}
 	if(any_candidates) {
 		// ---- first batch of PCM on its way while the small tables are set up ---------------------------------
-		constexpr int LB = 4;
+		constexpr int LB = 7;
 		const bool pairs = VARIANT == 0 && C == 2;              // two samples per thread and load (S is even or the layout is 32-bit)
 		const uint32_t npair = n / 2;
 		int4 pv[LB];
