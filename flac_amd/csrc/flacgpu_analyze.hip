@@ -256,7 +256,7 @@ __device__ __forceinline__ float job_value(const JobView &J, int32_t v, float wt
 
 template <int DUMMY>
 __global__ __launch_bounds__(TPB, AUTOC_WAVES_PER_SIMD) void autoc_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
-                                                    const float *__restrict__ tail_windows, uint32_t nframes, uint32_t tail_n,
+                                                    const float *__restrict__ tail_windows, uint32_t nframes, uint32_t tail_n, uint32_t f_lo,
                                                     const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                     const ChanPrep *__restrict__ preps, double *__restrict__ autoc_out)
 {
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(TPB, AUTOC_WAVES_PER_SIMD) void autoc_kernel(const 
 	AutocWave &W = sh[wave];
 	const uint32_t njobs_main = P.max_jobs;
 	const uint32_t item = blockIdx.x * (TPB / 64) + (uint32_t)wave;
-	const uint32_t total = nframes * P.ncand * njobs_main;
+	const uint32_t total = (nframes - f_lo) * P.ncand * njobs_main;       // frames [f_lo, nframes)
 	if(item >= total) return;
 	// longest jobs first within a frame-channel: jobs are enumerated full, halves, thirds ... already
-	const uint32_t fc = item / njobs_main, jb = item - fc * njobs_main;
+	const uint32_t fc = f_lo * P.ncand + item / njobs_main, jb = item % njobs_main;
 	const uint32_t f = fc / P.ncand;
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const JobTable *jt = is_tail ? jt_tail : jt_main;
@@ -1098,8 +1098,18 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 	hipLaunchKernelGGL(prep_kernel<0>, dim3(nframes * P.ncand), dim3(TPB), P.sig_bytes, s, P, pcm, nframes, tail_n, B.prep, B.cands, B.valid);
 	if(pev) (void)hipEventRecord(pev[0], s);
 	if(P.max_analyses) {
-		const uint32_t items = nframes * P.ncand * P.max_jobs;
-		hipLaunchKernelGGL(autoc_kernel<0>, dim3((items + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, P, pcm, win, tailwin, nframes, tail_n, jtm, jtt, B.prep, B.autoc);
+		// frames of nominal length: the streaming kernel (flacgpu_autoc.hip); the short last block, and tiny blocks
+		// (lpc.c:133-157), go through the wavefront-per-job kernel above
+		uint32_t f_lo = 0;
+		if(autoc2_applicable(P)) {
+			f_lo = tail_n ? nframes - 1 : nframes;
+			const hipError_t e = launch_autoc2(P, pcm, win, f_lo, P.max_jobs, jtm, B.prep, B.autoc, s);
+			if(e != hipSuccess) return e;
+		}
+		if(f_lo < nframes) {
+			const uint32_t items = (nframes - f_lo) * P.ncand * P.max_jobs;
+			hipLaunchKernelGGL(autoc_kernel<0>, dim3((items + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, P, pcm, win, tailwin, nframes, tail_n, f_lo, jtm, jtt, B.prep, B.autoc);
+		}
 	}
 	if(pev) (void)hipEventRecord(pev[1], s);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;

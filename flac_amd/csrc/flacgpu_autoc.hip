@@ -1,0 +1,279 @@
+// flac_amd/csrc/flacgpu_autoc.hip -- autocorrelation of the windowed block (apply_apodization_ ->
+// FLAC__lpc_window_data{,_partial} -> FLAC__lpc_compute_autocorrelation, stream_encoder.c:4318-4392, lpc.c:68-94,
+// lpc_intrin_fma.c:46-72) for all frames of nominal length.
+//
+// Parallel shape: a WAVEFRONT takes one window job (whole block, a half, a third ...) of 16 consecutive
+// (frame, candidate channel) subframes.  Lane = (subframe s = lane/4, vector lane l = lane%4) and carries the
+// accumulators of ALL lags of "its" AVX lane l of the reference routine: the reference keeps, per lag j, a 4-wide
+// fp64 vector acc_j and steps it 8 samples at a time,
+//     acc_j[l] += fma(d[i], d[i-j], d[i+4] * d[i+4-j]),   i = L + 8k + l,
+// so a lane needs a sliding window of its own block d[i-15 .. i+4] and nothing from other lanes.  Per step a lane
+// converts 8 new floats to fp64 once and runs 3 fp64 operations per lag on them (the rounding sequence of the
+// compiled reference: mul, fma, add); with one lane per (lag, l) instead, every chain step would convert its four
+// operands again and read them from LDS again (4.5x the LDS traffic, 1.8x the VALU work).
+//
+// The block streams through a small per-wavefront LDS tile: coalesced loads of the interleaved PCM (each line of
+// a stereo frame is loaded ONCE and feeds the left/right/mid/side subframes of that frame), wasted-bits shift,
+// int->float, window multiply, one float per (subframe, sample).  Subframe regions are 100 floats apart, so the
+// 32 lanes of an LDS access group (8 subframes x 4 l) hit 32 different banks.  No workgroup barriers anywhere.
+//
+// fp64 VALU bound (39 fp64 operations + 11 conversions per 8 samples and lane at -8).  -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "flacgpu_dev.h"
+#include "flacgpu_devfn.h"
+
+namespace flacgpu {
+
+#ifndef AUTOC2_WAVES_PER_SIMD
+#define AUTOC2_WAVES_PER_SIMD 3
+#endif
+
+constexpr int A2_T = 64;            // new samples per tile = 8 chain steps
+constexpr int A2_H = 16;            // history samples in front of a tile (>= any lag)
+constexpr int A2_IST = 100;         // floats per subframe region (80 + 3 + slack; = 4 mod 32)
+constexpr int A2_ITEMS = 16;        // subframes per wavefront
+
+struct A2Job {
+	const float *w;
+	uint32_t n, nd, full, part, dshift, i0;
+};
+// source sample and window weight of job element i (lpc.c:68 whole block; lpc.c:82-94 partial window);
+// weight 0 (and a harmless source index) outside the job's data
+__device__ __forceinline__ void a2_index(const A2Job &J, int32_t i, uint32_t &src, float &wt)
+{
+	src = 0; wt = 0.0f;
+	if(i >= 0 && (uint32_t)i < J.nd) {
+		uint32_t widx = 0;
+		bool on = true;
+		if(J.full) { src = (uint32_t)i; widx = (uint32_t)i; }
+		else {
+			const uint32_t ui = (uint32_t)i;
+			if(ui >= J.i0 && ui < J.i0 + J.part) widx = J.n - J.part + (ui - J.i0);
+			else if(ui < J.part) widx = ui;
+			else on = false;
+			if(on) src = J.dshift + ui;
+		}
+		if(on) wt = J.w[widx];
+	}
+}
+// (float)sample * window, with a +0 where the weight is 0 (the reference writes 0.0f there)
+__device__ __forceinline__ float a2_value(int32_t v, uint32_t wasted, float wt) { return __builtin_fmaf((float)(v >> wasted), wt, 0.0f); }
+
+struct A2Items {
+	const int32_t *ptr[A2_ITEMS];     // MS4: ptr[0..3] = the four frames; else one per subframe
+	uint32_t which[A2_ITEMS];
+	uint32_t wasted[A2_ITEMS];
+};
+
+template <bool MS4>
+struct A2Fetch {
+	int32_t v[MS4 ? 8 : A2_ITEMS];
+	float wt;
+};
+template <bool MS4>
+__device__ __forceinline__ void a2_fetch(const A2Job &J, const A2Items &I, uint32_t C, int32_t i, A2Fetch<MS4> &F)
+{
+	uint32_t src;
+	a2_index(J, i, src, F.wt);
+	if(MS4) {
+#pragma unroll
+		for(int fr = 0; fr < 4; fr++) { const int2 lr = ((const int2 *)I.ptr[fr])[src]; F.v[2 * fr] = lr.x; F.v[2 * fr + 1] = lr.y; }
+	}
+	else {
+#pragma unroll
+		for(int t = 0; t < A2_ITEMS; t++) F.v[t] = pick_channel(I.ptr[t], C, src, I.which[t]);
+	}
+}
+template <bool MS4>
+__device__ __forceinline__ void a2_store(float *tile, const A2Items &I, const A2Fetch<MS4> &F, int slot)
+{
+	if(MS4) {
+#pragma unroll
+		for(int fr = 0; fr < 4; fr++) {
+			const int32_t l = F.v[2 * fr], r = F.v[2 * fr + 1];
+			tile[(4 * fr + 0) * A2_IST + slot] = a2_value(l, I.wasted[4 * fr + 0], F.wt);
+			tile[(4 * fr + 1) * A2_IST + slot] = a2_value(r, I.wasted[4 * fr + 1], F.wt);
+			tile[(4 * fr + 2) * A2_IST + slot] = a2_value((l + r) >> 1, I.wasted[4 * fr + 2], F.wt);
+			tile[(4 * fr + 3) * A2_IST + slot] = a2_value(l - r, I.wasted[4 * fr + 3], F.wt);
+		}
+	}
+	else {
+#pragma unroll
+		for(int t = 0; t < A2_ITEMS; t++) tile[t * A2_IST + slot] = a2_value(F.v[t], I.wasted[t], F.wt);
+	}
+}
+
+// one chain step of lpc_intrin_fma.c:46,61 for every lag; w[HB + c] = d[i + c] of this lane, HB = LAG-1 samples of history
+#define A2_STEP(c) _Pragma("unroll") for(int j = 0; j < LAG; j++) acc[j] += fma(w[HB + (c)], w[HB + (c) - j], w[HB + (c) + 4] * w[HB + (c) + 4 - j])
+// two steps of the lag-12 routine as compiled (lpc_intrin_fma.c:54): acc += t1 + t0 per 16 samples and, for lag 8
+// only, x*y0 + x*y2 factored into x*(y0+y2) across the two halves
+#define A2_PAIR(c) _Pragma("unroll") for(int j = 0; j < LAG; j++) { \
+		if(j == 8) acc[j] += fma(w[HB + (c)], (w[HB + (c) - 8] + w[HB + (c) + 8]), w[HB + (c) + 4] * (w[HB + (c) - 4] + w[HB + (c) + 12])); \
+		else { const double t0 = fma(w[HB + (c)], w[HB + (c) - j], w[HB + (c) + 4] * w[HB + (c) + 4 - j]); \
+		       const double t1 = fma(w[HB + (c) + 8], w[HB + (c) + 8 - j], w[HB + (c) + 12] * w[HB + (c) + 12 - j]); acc[j] += (t1 + t0); } }
+
+template <int VARIANT, int LAG, bool MS4>
+__global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
+                                                                            uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
+                                                                            double *__restrict__ autoc_out)
+{
+	__shared__ float sh[TPB / 64][A2_ITEMS * A2_IST];
+	const int lane = (int)threadIdx.x & 63;
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	float *tile = sh[wave];
+	const uint32_t nfc = nmain * P.ncand;
+	const uint32_t ngroups = (nfc + A2_ITEMS - 1) / A2_ITEMS;
+	const uint32_t wi = blockIdx.x * (TPB / 64) + wave;
+	if(wi >= jt->njobs * ngroups) return;
+	// jobs are enumerated longest first (whole block, halves, thirds ...): the long wavefronts start first
+	const uint32_t jb = wi / ngroups, fc0 = (wi - jb * ngroups) * A2_ITEMS;
+	const WindowJob jv = jt->jobs[jb];
+	const uint32_t N = P.blocksize, C = P.channels;
+	A2Job J;
+	J.w = windows + (size_t)jv.apod * N;
+	J.n = N; J.nd = jv.nd; J.full = jv.full; J.part = jv.part; J.dshift = jv.dshift; J.i0 = jv.i0;
+	const uint32_t nd = jv.nd;
+	constexpr uint32_t L = VARIANT;
+	constexpr int HB = LAG - 1;
+
+	A2Items I;
+	uint32_t any_lpc = 0;
+#pragma unroll
+	for(int t = 0; t < A2_ITEMS; t++) {
+		const uint32_t fc = fc0 + (uint32_t)t < nfc ? fc0 + (uint32_t)t : nfc - 1;
+		const ChanPrep pr = preps[fc];
+		I.wasted[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.wasted);
+		I.which[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.which);
+		any_lpc |= pr.flags & PREP_LPC;
+		if(!MS4) I.ptr[t] = pcm + (size_t)(fc / P.ncand) * N * C;
+	}
+	if(MS4) {
+#pragma unroll
+		for(int fr = 0; fr < 4; fr++) {
+			const uint32_t f = fc0 / 4 + (uint32_t)fr < nmain ? fc0 / 4 + (uint32_t)fr : nmain - 1;
+			I.ptr[fr] = pcm + (size_t)f * N * C;
+		}
+	}
+	if(!__builtin_amdgcn_readfirstlane((int)any_lpc)) return;      // 16 constant subframes: nothing to analyse
+
+	const uint32_t nb = (nd - L) / 8;
+	const uint32_t npairs12 = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
+	const uint32_t ntiles = (nb + 7) / 8;
+	const int item = lane >> 2, l = lane & 3;
+	const float *rd = tile + item * A2_IST + A2_H + l;                // rd[t] = d[tile base + t + l]
+
+	double acc[LAG];
+#pragma unroll
+	for(int j = 0; j < LAG; j++) acc[j] = 0.0;
+
+	// history of tile 0: d[L-16, L)
+	{
+		A2Fetch<MS4> H;
+		a2_fetch<MS4>(J, I, C, (int32_t)L - A2_H + (lane & 15), H);
+		if(lane < A2_H) a2_store<MS4>(tile, I, H, lane);
+	}
+	A2Fetch<MS4> F;
+	a2_fetch<MS4>(J, I, C, (int32_t)L + lane, F);
+	for(uint32_t t = 0; t < ntiles; t++) {
+		if(t) {
+			// the last 16 samples become the history of the next tile (one wavefront: LDS operations execute in order)
+			float hv[4];
+#pragma unroll
+			for(int u = 0; u < 4; u++) hv[u] = tile[item * A2_IST + A2_T + 4 * l + u];
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for(int u = 0; u < 4; u++) tile[item * A2_IST + 4 * l + u] = hv[u];
+		}
+		a2_store<MS4>(tile, I, F, A2_H + lane);
+		if(t + 1 < ntiles) a2_fetch<MS4>(J, I, C, (int32_t)(L + A2_T * (t + 1)) + lane, F);
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t k0 = 8 * t;
+		const uint32_t ksteps = nb - k0 < 8 ? nb - k0 : 8;
+		if(ksteps == 8 && (VARIANT != 12 || k0 + 8 <= 2 * npairs12)) {
+#pragma unroll
+			for(int h = 0; h < 2; h++) {
+				double w[HB + 32];
+#pragma unroll
+				for(int u = 0; u < HB + 32; u++) w[u] = (double)rd[32 * h - HB + u];
+				if(VARIANT != 12) { A2_STEP(0); A2_STEP(8); A2_STEP(16); A2_STEP(24); }
+				else { A2_PAIR(0); A2_PAIR(16); }
+			}
+		}
+		else {
+			uint32_t kk = 0;
+			while(kk < ksteps) {
+				double w[HB + 16];
+				const float *p = rd + 8 * kk;
+#pragma unroll
+				for(int u = 0; u < HB + 16; u++) w[u] = (double)p[u - HB];
+				if(VARIANT == 12 && kk + 2 <= ksteps && k0 + kk + 2 <= 2 * npairs12) { A2_PAIR(0); kk += 2; }
+				else { A2_STEP(0); kk += 1; }
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+
+	// ---- head d[0,16) and tail d[nd-24, nd) of every subframe as plain copies (the tile is dead now) --------------
+	const uint32_t tail_lo = nd - 24;               // nd > 32
+	{
+		A2Fetch<MS4> H;
+		const int u = lane < 40 ? lane : 39;
+		a2_fetch<MS4>(J, I, C, u < 16 ? u : (int32_t)tail_lo + (u - 16), H);
+		if(lane < 40) a2_store<MS4>(tile, I, H, lane);
+	}
+	__builtin_amdgcn_wave_barrier();
+	// lane (subframe, l) finishes lags l, l+4, l+8, l+12: the four lane accumulators of a lag sit in one quad
+	const uint32_t max_lpc = P.max_lpc_order >= N ? N - 1 : P.max_lpc_order;
+	const uint32_t lag = max_lpc + 1;
+	const uint32_t fc = fc0 + (uint32_t)item;
+	double *out = autoc_out + ((size_t)fc * P.max_jobs + jb) * MAX_ORDER;
+	const float *head = tile + item * A2_IST, *tail = head + 16;
+#pragma unroll
+	for(int m = 0; m < (LAG + 3) / 4; m++) {
+		double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+		for(int jj = 0; jj < 4; jj++) {
+			const int j = 4 * m + jj;                  // lag whose owner is quad lane jj
+			if(j < LAG) {
+#pragma unroll
+				for(int q = 0; q < 4; q++) {
+					const double v = __shfl(acc[j], (lane & ~3) | q);
+					if(l == jj) a4[q] = v;
+				}
+			}
+		}
+		const uint32_t j = 4 * (uint32_t)m + (uint32_t)l;
+		if(j < lag && fc < nfc) out[j] = autoc_finish2(head, tail, tail_lo, nd, L, j, a4);
+	}
+}
+#undef A2_STEP
+#undef A2_PAIR
+
+template <int VARIANT, int LAG>
+static void launch_autoc2_t(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt,
+                            const ChanPrep *preps, double *autoc, hipStream_t s)
+{
+	const uint32_t nfc = nmain * P.ncand, ngroups = (nfc + A2_ITEMS - 1) / A2_ITEMS;
+	const uint32_t waves = njobs * ngroups;
+	const dim3 grid((waves + TPB / 64 - 1) / (TPB / 64)), block(TPB);
+	if(P.channels == 2 && P.ms_mode == 1) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+	else hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, false>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+}
+
+// true when the streaming kernel serves the nominal-length frames of this configuration
+bool autoc2_applicable(const DevParams &P) { return P.blocksize > 32 && P.max_lpc_order > 0 && P.autoc_variant != 0; }
+
+hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt,
+                         const ChanPrep *preps, double *autoc, hipStream_t s)
+{
+	if(nmain == 0 || njobs == 0) return hipSuccess;
+	const uint32_t max_lpc = P.max_lpc_order >= P.blocksize ? P.blocksize - 1 : P.max_lpc_order;
+	const uint32_t lag = max_lpc + 1;
+	if(P.autoc_variant == 8) launch_autoc2_t<8, 8>(P, pcm, win, nmain, njobs, jt, preps, autoc, s);
+	else if(P.autoc_variant == 12) { if(lag <= 9) launch_autoc2_t<12, 9>(P, pcm, win, nmain, njobs, jt, preps, autoc, s); else launch_autoc2_t<12, 12>(P, pcm, win, nmain, njobs, jt, preps, autoc, s); }
+	else { if(lag <= 13) launch_autoc2_t<16, 13>(P, pcm, win, nmain, njobs, jt, preps, autoc, s); else launch_autoc2_t<16, 16>(P, pcm, win, nmain, njobs, jt, preps, autoc, s); }
+	return hipGetLastError();
+}
+
+} // namespace flacgpu

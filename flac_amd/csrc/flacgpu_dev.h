@@ -101,6 +101,9 @@ size_t pack_lds_bytes(const DevParams &P);
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
                           uint32_t nframes, uint32_t tail_n, const JobTable *jt_main, const JobTable *jt_tail, const AnalyzeBuffers &B,
                           SubDecision *dec, hipEvent_t *phase_ev /* [3]: after prep, autoc, model; may be null */, hipStream_t s);
+bool autoc2_applicable(const DevParams &P);
+hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt,
+                         const ChanPrep *preps, double *autoc, hipStream_t s);
 hipError_t launch_pack(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, hipStream_t s);
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);
