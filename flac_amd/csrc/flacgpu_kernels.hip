@@ -35,35 +35,50 @@ __device__ __forceinline__ void put_bits(uint32_t *buf, uint32_t cap_words, uint
 	if(lo && w + 1 < cap_words) atomicOr(&buf[w + 1], lo);
 }
 
-__device__ __forceinline__ uint32_t crc16_step_byte(uint32_t c, uint32_t byte)
+// ---- CRC-16 (poly 0x8005, init 0, crc.c:376) -----------------------------------------------------------------
+// The frame image is cut into 64-byte spans from byte 0; a thread runs one span a 32-bit word at a time with four
+// 256-entry tables (TAB[k][v] = v * x^(16+8k) mod P: one independent lookup per byte of the word, no serial
+// byte chain), shifts its remainder past the whole spans behind it with a precomputed x^(512 m) mod P, and the
+// spans are xor-reduced: crc(A||B) = crc(A) * x^(8|B|) + crc(B) in GF(2)[x]/(x^16+x^15+x^2+1).
+constexpr uint32_t CRC_SPAN = 64;                       // bytes per span
+constexpr uint32_t CRC_MAX_SPANS = 160 * 1024 / 64;     // the frame image lives in LDS (< 160 KiB)
+struct CrcTables { uint16_t tab[4][256]; uint16_t xspan[CRC_MAX_SPANS]; uint16_t xbyte[CRC_SPAN + 1]; };
+constexpr uint32_t crc_mulx(uint32_t c) { return (c & 0x8000u) ? ((c << 1) ^ 0x8005u) & 0xffffu : (c << 1) & 0xffffu; }
+constexpr uint32_t crc_mulx8(uint32_t c) { for(int b = 0; b < 8; b++) c = crc_mulx(c); return c; }
+constexpr CrcTables make_crc_tables()
 {
-	c ^= byte << 8;
-#pragma unroll
-	for(int b = 0; b < 8; b++) c = (c & 0x8000u) ? ((c << 1) ^ 0x8005u) & 0xffffu : (c << 1) & 0xffffu;
-	return c;
+	CrcTables t{};
+	for(uint32_t v = 0; v < 256; v++) {
+		uint32_t c = v << 8;                  // v * x^8
+		c = crc_mulx8(c);                     // v * x^16 mod P
+		for(int k = 0; k < 4; k++) { t.tab[k][v] = (uint16_t)c; c = crc_mulx8(c); }
+	}
+	uint32_t c = 1;
+	for(uint32_t r = 0; r <= CRC_SPAN; r++) { t.xbyte[r] = (uint16_t)c; c = crc_mulx8(c); }      // x^(8r)
+	const uint32_t xs = t.xbyte[CRC_SPAN];                                                     // x^512
+	c = 1;
+	for(uint32_t m = 0; m < CRC_MAX_SPANS; m++) {
+		t.xspan[m] = (uint16_t)c;
+		// c *= xs  (schoolbook product mod P)
+		uint32_t r = 0, b = xs;
+		for(int i = 0; i < 16; i++) { r = crc_mulx(r); if(b & 0x8000u) r ^= c; b = (b << 1) & 0xffffu; }
+		c = r;
+	}
+	return t;
 }
+__device__ const CrcTables g_crc_tables = make_crc_tables();
+
 // multiply two GF(2) polynomials of degree < 16 modulo x^16+x^15+x^2+1
 __device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
 {
 	uint32_t r = 0;
 #pragma unroll
 	for(int i = 0; i < 16; i++) {
-		if(b & 0x8000u) r ^= a;       // process b from its top bit: r = r*x + (bit? a : 0) done below
+		r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu;
+		if(b & 0x8000u) r ^= a;
 		b <<= 1;
-		if(i != 15) r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu;
 	}
 	return r;
-}
-// x^(8*nbytes) mod P
-__device__ uint32_t gf16_xpow8(uint32_t nbytes)
-{
-	uint32_t result = 1, base = 0x0100u;    // x^8
-	while(nbytes) {
-		if(nbytes & 1) result = gf16_mul(result, base);
-		base = gf16_mul(base, base);
-		nbytes >>= 1;
-	}
-	return result;
 }
 
 struct PackShared {
@@ -71,7 +86,8 @@ struct PackShared {
 	uint8_t params[1u << MAX_PO];
 	uint32_t scan[TPB / 64 + 1];
 	uint32_t ca, left, right;
-	uint32_t crc_parts[TPB];
+	uint32_t crc_parts[TPB / 64];
+	uint16_t crc_tab[4][256];
 	uint32_t bitpos;
 	uint32_t overflow;
 };
@@ -98,6 +114,7 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	const uint32_t cap_words = P.slot_bytes / 4;
 
 	for(uint32_t w = (uint32_t)tid; w < cap_words; w += TPB) img[w] = 0;
+	for(uint32_t w = (uint32_t)tid; w < 4 * 256 / 2; w += TPB) ((uint32_t *)sh->crc_tab)[w] = ((const uint32_t *)g_crc_tables.tab)[w];
 	if(tid == 0) {
 		// channel assignment (stream_encoder.c:3944-3972)
 		uint32_t ca = 0, left = 0, right = 1;
@@ -320,12 +337,30 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	if(total_bytes > P.slot_bytes) { if(tid == 0) { sh->overflow = 1; } }
 	__syncthreads();
 	{
-		// each thread CRCs a contiguous span, then spans are combined: crc(A||B) = crc(A)*x^(8|B|) + crc(B)
-		const uint32_t span = (body_bytes + TPB - 1) / TPB;
-		const uint32_t lo = umin32((uint32_t)tid * span, body_bytes), hi = umin32(lo + span, body_bytes);
+		// spans of 64 bytes; the last (possibly short) span is followed by nothing, span s by nsp-1-s whole or short spans
+		const uint32_t nsp = (body_bytes + CRC_SPAN - 1) / CRC_SPAN;
+		const uint32_t last_len = body_bytes - (nsp - 1) * CRC_SPAN;                 // 1..64 bytes
 		uint32_t c = 0;
-		for(uint32_t k = lo; k < hi; k++) c = crc16_step_byte(c, (img[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu);
-		c = gf16_mul(c, gf16_xpow8(body_bytes - hi));
+		for(uint32_t sp = (uint32_t)tid; sp < nsp; sp += TPB) {
+			const uint32_t *wp = img + sp * (CRC_SPAN / 4);
+			uint32_t cs = 0;
+			if(sp + 1 < nsp) {
+#pragma unroll
+				for(int k = 0; k < (int)(CRC_SPAN / 4); k++) {
+					const uint32_t v = (cs << 16) ^ wp[k];
+					cs = (uint32_t)sh->crc_tab[3][v >> 24] ^ sh->crc_tab[2][(v >> 16) & 0xffu] ^ sh->crc_tab[1][(v >> 8) & 0xffu] ^ sh->crc_tab[0][v & 0xffu];
+				}
+				// behind this span: nsp-2-sp whole spans and the last one
+				cs = gf16_mul(gf16_mul(cs, g_crc_tables.xspan[nsp - 2 - sp]), g_crc_tables.xbyte[last_len]);
+			}
+			else {
+				for(uint32_t k = 0; k < last_len; k++) {
+					const uint32_t b = (wp[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu;
+					cs = ((cs << 8) & 0xffffu) ^ sh->crc_tab[0][(cs >> 8) ^ b];
+				}
+			}
+			c ^= cs;
+		}
 		// xor-reduce
 #pragma unroll
 		for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
