@@ -51,8 +51,8 @@ __device__ __forceinline__ void map_block(uint32_t b, uint32_t nframes, uint32_t
 // prep_kernel
 // ---------------------------------------------------------------------------------------------------------
 template <int DUMMY>
-__global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nframes, uint32_t tail_n,
-                                                   ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid)
+__global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nframes, uint32_t tail_n, uint32_t f_lo,
+                                                   ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid, int32_t *__restrict__ chan)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	__shared__ uint64_t scratch[8];
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t C = P.channels, N = P.blocksize;
 	uint32_t f, cand;
-	map_block(blockIdx.x, nframes, P.ncand, f, cand);
+	if(f_lo) { f = f_lo + blockIdx.x / P.ncand; cand = blockIdx.x % P.ncand; }      // frames [f_lo, nframes) only
+	else map_block(blockIdx.x, nframes, P.ncand, f, cand);
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const uint32_t n = is_tail ? tail_n : N;
 	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
@@ -100,6 +101,13 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 	if(wasted) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) sig[sigidx((int)i)] >>= wasted;
 	const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
 	__syncthreads();
+	// planar copy of the shifted channel for the evaluation and pack kernels
+	const uint32_t fmt = sbps <= 16 ? 1u : 0u;
+	{
+		int32_t *dst = chan + fc * (size_t)N;
+		if(fmt) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) ((uint16_t *)dst)[i] = (uint16_t)sig[sigidx((int)i)];
+		else for(uint32_t i = (uint32_t)tid; i < n; i += TPB) dst[i] = sig[sigidx((int)i)];
+	}
 
 	uint32_t flags = 0, fixed_order = 0;
 	int32_t constant = 0;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 		valid[fc * cstride] = (flags & PREP_FIXED_VALID) ? 1 : 0;
 		ChanPrep pr;
 		pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
-		pr.constant = constant; pr.verbatim_bits = verbatim_bits;
+		pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;
 		preps[fc] = pr;
 	}
 }
@@ -798,7 +806,7 @@ __host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t w
 //      needs the 64-bit FIR), chosen per workgroup; also every workgroup that has no residual candidate at all
 //   2  any other block length / partition order: generic chunked evaluation with LDS partition sums
 template <int MAXORD, int VARIANT>
-__global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_SIMD : 2) void eval_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nframes, uint32_t tail_n,
+__global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_SIMD : 2) void eval_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
                                                                    const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                                    const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
                                                                    const int *__restrict__ valid, SubDecision *__restrict__ decisions, unsigned long long *__restrict__ dbg)
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 #define STAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
 	const unsigned long long t_start = dbg ? (unsigned long long)clock64() : 0ull;
 	const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;
-	const uint32_t C = P.channels, N = P.blocksize;
+	const uint32_t N = P.blocksize;
 	uint32_t f, cand;
 	map_block(blockIdx.x, nframes, P.ncand, f, cand);
 	const size_t fc = (size_t)f * P.ncand + cand;
@@ -817,7 +825,8 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	const JobTable *jt = is_tail ? jt_tail : jt_main;
 	const uint32_t n = pr.n, sbps = pr.sbps, wasted = pr.wasted, which = pr.which;
 	const uint32_t hdr = 8 + wasted;
-	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
+	const uint32_t *src = (const uint32_t *)(chan + fc * (size_t)N);       // planar channel, already shifted (ChanPrep::fmt)
+	const uint32_t srcfmt = pr.fmt;
 	const uint32_t cstride = P.max_analyses + 1;
 	SubDecision *dec = decisions + fc;
 
@@ -854,14 +863,13 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 		if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_bits = bits; }
 	}
 	if(any_candidates) {
-		// ---- first batch of PCM on its way while the small tables are set up ---------------------------------
-		constexpr int LB = 7;
-		const bool pairs = VARIANT == 0 && C == 2;              // two samples per thread and load (S is even or the layout is 32-bit)
-		const uint32_t npair = n / 2;
-		int4 pv[LB];
-		if(pairs) {
+		// ---- first batch of the channel on its way while the small tables are set up ------------------------------
+		constexpr int LB = 4;
+		const uint32_t nvec = srcfmt ? (n + 7) / 8 : (n + 3) / 4;       // 16-byte pieces: 8 packed / 4 plain samples each
+		uint4 pv[LB];
+		if(VARIANT == 0) {
 #pragma unroll
-			for(int u = 0; u < LB; u++) { const uint32_t m = (uint32_t)tid + (uint32_t)u * nthreads; if(m < npair) pv[u] = ((const int4 *)frame_pcm)[m]; }
+			for(int u = 0; u < LB; u++) { const uint32_t m = (uint32_t)tid + (uint32_t)u * nthreads; if(m < nvec) pv[u] = ((const uint4 *)src)[m]; }
 		}
 		for(uint32_t t = (uint32_t)tid; t < (MAX_PO + 1) * (MAX_ORDER + 1); t += nthreads) {
 			const uint32_t po = t / (MAX_ORDER + 1), o = t - po * (MAX_ORDER + 1);
@@ -889,54 +897,38 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			if(tid < OH) { if(packed) { if(tid < OH / 2) sigw[tid] = 0; } else sigw[tid] = 0; }
 			const bool spow2 = (S & (S - 1)) == 0;
 			const uint32_t slog = ilog2_u32(S);
-			if(pairs) {
-				for(uint32_t m0 = (uint32_t)tid; m0 < npair; m0 += LB * nthreads) {
-					if(m0 != (uint32_t)tid) {
+			for(uint32_t m0 = (uint32_t)tid; m0 < nvec; m0 += LB * nthreads) {
+				if(m0 != (uint32_t)tid) {
 #pragma unroll
-						for(int u = 0; u < LB; u++) { const uint32_t m = m0 + (uint32_t)u * nthreads; if(m < npair) pv[u] = ((const int4 *)frame_pcm)[m]; }
-					}
+					for(int u = 0; u < LB; u++) { const uint32_t m = m0 + (uint32_t)u * nthreads; if(m < nvec) pv[u] = ((const uint4 *)src)[m]; }
+				}
 #pragma unroll
-					for(int u = 0; u < LB; u++) {
-						const uint32_t m = m0 + (uint32_t)u * nthreads;
-						if(m < npair) {
-							const int4 d = pv[u];
-							int32_t v0 = which == 0 ? d.x : which == 1 ? d.y : which == 2 ? ((d.x + d.y) >> 1) : (d.x - d.y);
-							int32_t v1 = which == 0 ? d.z : which == 1 ? d.w : which == 2 ? ((d.z + d.w) >> 1) : (d.z - d.w);
-							v0 >>= wasted; v1 >>= wasted;
-							const uint32_t i = 2 * m;
-							const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
-							if(packed) {
-								const uint32_t wv = ((uint32_t)v0 & 0xffffu) | ((uint32_t)v1 << 16);
-								sigw[Lo * stride + (OH + s) / 2] = wv;
-								if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S) / 2] = wv;
-							}
-							else {
-								uint32_t *d0 = sigw + Lo * stride + OH + s;
-								d0[0] = (uint32_t)v0;
-								if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S)] = (uint32_t)v0;
-								// S may be odd here: the second sample can belong to the next lane
-								const uint32_t i1 = i + 1, L1 = spow2 ? i1 >> slog : i1 / S, s1 = i1 - L1 * S;
-								sigw[L1 * stride + OH + s1] = (uint32_t)v1;
-								if(s1 + OH >= S && L1 + 1 < 64) sigw[(L1 + 1) * stride + (s1 + OH - S)] = (uint32_t)v1;
+				for(int u = 0; u < LB; u++) {
+					const uint32_t m = m0 + (uint32_t)u * nthreads;
+					if(m < nvec) {
+						const uint32_t wv[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+						if(srcfmt && packed) {
+							// word = two samples; S is even, so a pair never straddles two lanes
+#pragma unroll
+							for(int k = 0; k < 4; k++) {
+								const uint32_t i = 8 * m + 2 * (uint32_t)k;
+								const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
+								sigw[Lo * stride + (OH + s) / 2] = wv[k];
+								if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S) / 2] = wv[k];
 							}
 						}
-					}
-				}
-				if((n & 1) && tid == 0) {      // cannot happen on the owner layout (n % 64 == 0); kept for completeness
-				}
-			}
-			else {
-				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) {
-					const int32_t v = pick_channel(frame_pcm, C, i, which) >> wasted;
-					const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
-					if(packed) {
-						uint16_t *h = (uint16_t *)sigw;
-						h[2 * (Lo * stride) + OH + s] = (uint16_t)v;
-						if(s + OH >= S && Lo + 1 < 64) h[2 * ((Lo + 1) * stride) + (s + OH - S)] = (uint16_t)v;
-					}
-					else {
-						sigw[Lo * stride + OH + s] = (uint32_t)v;
-						if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S)] = (uint32_t)v;
+						else {
+							// 32-bit lane regions (from either source format)
+#pragma unroll
+							for(int k = 0; k < 8; k++) {
+								if(!srcfmt && k >= 4) break;
+								const uint32_t i = (srcfmt ? 8 : 4) * m + (uint32_t)k;
+								const int32_t v = srcfmt ? ((k & 1) ? ((int32_t)wv[k >> 1] >> 16) : (int32_t)(int16_t)(wv[k >> 1] & 0xffffu)) : (int32_t)wv[k & 3];
+								const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
+								sigw[Lo * stride + OH + s] = (uint32_t)v;
+								if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S)] = (uint32_t)v;
+							}
+						}
 					}
 				}
 			}
@@ -946,7 +938,8 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			if(tid < 32) sig[sigidx(tid - 32)] = 0;
 			const uint32_t nround = ((n + 15u) & ~15u) + 16u;
 			for(uint32_t i = n + (uint32_t)tid; i < nround; i += nthreads) sig[sigidx((int)i)] = 0;
-			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = pick_channel(frame_pcm, C, i, which) >> wasted;
+			if(srcfmt) for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = (int32_t)((const int16_t *)src)[i];
+			else for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = (int32_t)src[i];
 		}
 		__syncthreads();
 		STAMP(1);
@@ -1080,9 +1073,9 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	}
 	const bool owner_possible = P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH;
 	// which flavours can occur in this batch at all (each launch serves only its own workgroups)
-	if(owner_possible) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+	if(owner_possible) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	if(!owner_possible || tail_n || P.max_po > 6)
-		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(waves * 64), lds_generic, s, P, pcm, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(waves * 64), lds_generic, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	return hipGetLastError();
 }
 
@@ -1095,7 +1088,18 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL(prep_kernel<0>, dim3(nframes * P.ncand), dim3(TPB), P.sig_bytes, s, P, pcm, nframes, tail_n, B.prep, B.cands, B.valid);
+	{
+		// frames of nominal length: one workgroup per frame (flacgpu_prep.hip); the short last block, and block sizes that
+		// kernel does not take, go through the workgroup-per-subframe kernel above
+		uint32_t f_lo = 0;
+		if(prep2_applicable(P)) {
+			f_lo = tail_n ? nframes - 1 : nframes;
+			const hipError_t e = launch_prep2(P, pcm, f_lo, B, s);
+			if(e != hipSuccess) return e;
+		}
+		if(f_lo < nframes)
+			hipLaunchKernelGGL(prep_kernel<0>, dim3((nframes - f_lo) * P.ncand), dim3(TPB), P.sig_bytes, s, P, pcm, nframes, tail_n, f_lo, B.prep, B.cands, B.valid, B.chan);
+	}
 	if(pev) (void)hipEventRecord(pev[0], s);
 	if(P.max_analyses) {
 		// frames of nominal length: the streaming kernel (flacgpu_autoc.hip); the short last block, and tiny blocks

@@ -141,6 +141,7 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->ab.autoc) (void)hipFree(c->ab.autoc);
 	if(c->ab.cands) (void)hipFree(c->ab.cands);
 	if(c->ab.valid) (void)hipFree(c->ab.valid);
+	if(c->ab.chan) (void)hipFree(c->ab.chan);
 	if(c->ab.dbg) (void)hipFree(c->ab.dbg);
 	for(int i = 0; i < 3; i++) if(c->pev[i]) (void)hipEventDestroy(c->pev[i]);
 	if(c->d_jobtab) (void)hipFree(c->d_jobtab);
@@ -241,6 +242,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		ok = ok && hipMalloc(&c->ab.autoc, nfc * P.max_jobs * MAX_ORDER * sizeof(double)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.cands, nfc * ncs * sizeof(Candidate)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.valid, nfc * ncs * sizeof(int)) == hipSuccess;
+		ok = ok && hipMalloc(&c->ab.chan, nfc * N * sizeof(int32_t)) == hipSuccess;
 		if(ok && getenv("FLACGPU_DEBUG_TIMING")) { ok = hipMalloc(&c->ab.dbg, nfc * 16 * sizeof(unsigned long long)) == hipSuccess; if(ok) (void)hipMemset(c->ab.dbg, 0, nfc * 16 * sizeof(unsigned long long)); }
 	}
 	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
@@ -300,7 +302,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		(void)hipMemsetAsync(c->ab.dbg, 0, nwg * 16 * sizeof(unsigned long long), s);
 	}
 	(void)hipEventRecord(c->ev[1], s);
-	if(launch_pack(P, d_pcm, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	(void)hipEventRecord(c->ev[2], s);
 	if(launch_scan(c->d_frame_bytes, nframes, c->d_offsets, c->d_total, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	if(launch_compact(c->d_slots, P.slot_bytes, c->d_frame_bytes, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;

@@ -80,12 +80,15 @@ struct ChanPrep {
 	uint32_t fixed_order;      // guessed fixed-predictor order
 	int32_t constant;          // sample value when PREP_CONSTANT
 	uint32_t verbatim_bits;    // size of the VERBATIM baseline (0xffffffff: disabled)
+	uint32_t fmt;              // planar channel copy: 1 = 16-bit pairs (sbps <= 16), 0 = 32-bit samples
+	uint32_t pad[3];
 };
 struct AnalyzeBuffers {
 	ChanPrep *prep;            // [frames*ncand]
 	double *autoc;             // [frames*ncand][max_jobs][MAX_ORDER]
 	Candidate *cands;          // [frames*ncand][max_analyses+1]: [0] fixed, [1+a] LPC analysis a
 	int *valid;                // same shape
+	int32_t *chan;             // [frames*ncand][blocksize] planar channel signals, wasted bits shifted out (ChanPrep::fmt)
 	unsigned long long *dbg;   // FLACGPU_DEBUG_TIMING=1: [frames*ncand][16] s_memtime stamps of the eval kernel (else null)
 };
 constexpr int EVAL_MAX_WAVES = 8;   // wavefronts per eval workgroup (one residual candidate each per round)
@@ -104,7 +107,9 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 bool autoc2_applicable(const DevParams &P);
 hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt,
                          const ChanPrep *preps, double *autoc, hipStream_t s);
-hipError_t launch_pack(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
+bool prep2_applicable(const DevParams &P);
+hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s);
+hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, hipStream_t s);
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);
 hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,

@@ -93,7 +93,7 @@ struct PackShared {
 };
 
 template <int MAXORD>
-__global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int32_t *__restrict__ pcm,
+__global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int32_t *__restrict__ chan,
                                                    uint32_t nframes, uint32_t tail_n, uint64_t first_frame_number,
                                                    const SubDecision *__restrict__ decisions,
                                                    uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
@@ -105,7 +105,6 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	const uint32_t f = blockIdx.x;
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const uint32_t n = is_tail ? tail_n : N;
-	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
 	const SubDecision *dec = decisions + (size_t)f * P.ncand;
 
 	int32_t *sig = (int32_t *)smem;
@@ -208,10 +207,32 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 		uint32_t pos = sh->bitpos;
 		__syncthreads();
 
-		uint32_t orv;
-		load_signal(sig, frame_pcm, C, n, which, &orv, tid);
-		__syncthreads();
-		if(wasted) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) sig[sigidx((int)i)] >>= wasted;
+		// the planar channel written by the prep kernels: wasted bits already shifted out, 16-bit pairs when sbps <= 16
+		{
+			const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + di) * N);
+			if(tid < 32) sig[sigidx(tid - 32)] = 0;
+			const uint32_t nround = ((n + 15u) & ~15u) + 16u;
+			for(uint32_t i = n + (uint32_t)tid; i < nround; i += TPB) sig[sigidx((int)i)] = 0;
+			if(sbps <= 16) {
+				for(uint32_t m = (uint32_t)tid; m < (n + 7) / 8; m += TPB) {
+					const uint4 w = ((const uint4 *)src)[m];
+					const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+					for(int k = 0; k < 8; k++) {
+						const uint32_t i = 8 * m + (uint32_t)k;
+						if(i < n) sig[sigidx((int)i)] = (k & 1) ? ((int32_t)wv[k >> 1] >> 16) : (int32_t)(int16_t)(wv[k >> 1] & 0xffffu);
+					}
+				}
+			}
+			else {
+				for(uint32_t m = (uint32_t)tid; m < (n + 3) / 4; m += TPB) {
+					const uint4 w = ((const uint4 *)src)[m];
+					const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+					for(int k = 0; k < 4; k++) { const uint32_t i = 4 * m + (uint32_t)k; if(i < n) sig[sigidx((int)i)] = (int32_t)wv[k]; }
+				}
+			}
+		}
 		__syncthreads();
 
 		// subframe header byte (+ unary wasted bits)
@@ -454,7 +475,7 @@ __global__ __launch_bounds__(TPB) void compact_kernel(const uint8_t *__restrict_
 using namespace flacgpu;
 
 template <int MAXORD>
-static hipError_t launch_pack_t(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
+static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                                 const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, size_t lds, hipStream_t s)
 {
 	static bool attr_set = false;
@@ -463,21 +484,21 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *pcm, uint32_t
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes), dim3(TPB), lds, s, P, pcm, nframes, tail_n, first, dec, slots, fb, info);
+	hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes), dim3(TPB), lds, s, P, chan, nframes, tail_n, first, dec, slots, fb, info);
 	return hipGetLastError();
 }
 
 namespace flacgpu {
 size_t pack_lds_bytes(const DevParams &P) { return (size_t)P.sig_bytes + P.slot_bytes + sizeof(PackShared); }
 
-hipError_t launch_pack(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, uint64_t first,
+hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, hipStream_t s)
 {
 	const size_t lds = pack_lds_bytes(P);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
-	if(m <= 8) return launch_pack_t<8>(P, pcm, nframes, tail_n, first, dec, slots, fb, info, lds, s);
-	if(m <= 12) return launch_pack_t<12>(P, pcm, nframes, tail_n, first, dec, slots, fb, info, lds, s);
-	return launch_pack_t<16>(P, pcm, nframes, tail_n, first, dec, slots, fb, info, lds, s);
+	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, lds, s);
+	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, lds, s);
+	return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, lds, s);
 }
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)
 {

@@ -1,0 +1,270 @@
+// flac_amd/csrc/flacgpu_prep.hip -- per-subframe preparation for all frames of nominal length:
+// mid/side build (stream_encoder.c:3823-3836), loose mid/side decision (:3778-3807), wasted bits (:5077, :3842-3867),
+// fixed-predictor error sums and order guess (fixed.c:222-299 / fixed_intrin_avx2.c:57), CONSTANT detection
+// (:4111-4140), limit_min_bitrate (:3874-3879).  Writes the hand-off record (ChanPrep, Candidate[0]) and the
+// PLANAR, already wasted-bits-shifted channel signal that the evaluation and pack kernels read (16-bit pairs when
+// the subframe fits 16 bits, else 32-bit), so that those kernels stream 2-4 bytes per sample instead of re-reading
+// and re-deriving the interleaved frame.
+//
+// One workgroup per frame, one WAVEFRONT per candidate channel: the frame is staged once in LDS (coalesced loads),
+// then every wavefront derives its own channel (L, R, (L+R)>>1, L-R) from the staged data, each lane owning
+// runs of 16 consecutive samples (conflict-free 18-word rows), reduces its statistics with wavefront shuffles only,
+// decides, and stores its channel.  HBM/L2 bound: reads 4*C bytes, writes ~10 bytes per inter-channel sample.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "flacgpu_dev.h"
+#include "flacgpu_devfn.h"
+
+namespace flacgpu {
+
+struct Prep2Acc {
+	uint32_t orv, diff;
+	uint64_t e[5];
+};
+
+// statistics of 16 consecutive samples x[4..19] (x[0..3] = the four samples in front of them) at block offset base.
+// Sums are taken on the UNSHIFTED signal: every |difference| is a multiple of 2^wasted, so the sums of the shifted
+// signal the reference computes (it shifts in place first) are these sums >> wasted, exactly.
+template <bool WIDE>
+__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], uint32_t base, uint32_t n, int32_t first, Prep2Acc &A)
+{
+	uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+	for(int t = 0; t < CHUNK; t++) {
+		const uint32_t i = base + (uint32_t)t;
+		const int32_t a0 = x[t + 4], a1 = x[t + 3], a2 = x[t + 2], a3 = x[t + 1], a4 = x[t];
+		if(i < n) { A.orv |= (uint32_t)a0; A.diff |= (uint32_t)(a0 ^ first); }
+		if(i >= 4 && i < n) {
+			const int32_t d1 = a0 - a1, d2 = a0 - 2 * a1 + a2, d3 = a0 - 3 * a1 + 3 * a2 - a3, d4 = a0 - 4 * a1 + 6 * a2 - 4 * a3 + a4;
+			if(WIDE) {
+				A.e[0] += (uint32_t)abs(a0); A.e[1] += (uint32_t)abs(d1); A.e[2] += (uint32_t)abs(d2); A.e[3] += (uint32_t)abs(d3); A.e[4] += (uint32_t)abs(d4);
+			}
+			else { s0 += (uint32_t)abs(a0); s1 += (uint32_t)abs(d1); s2 += (uint32_t)abs(d2); s3 += (uint32_t)abs(d3); s4 += (uint32_t)abs(d4); }
+		}
+	}
+	if(!WIDE) { A.e[0] += s0; A.e[1] += s1; A.e[2] += s2; A.e[3] += s3; A.e[4] += s4; }
+}
+
+// WIDE: per-run partial sums may exceed 32 bits (more than 20 bits per sample)
+template <bool WIDE>
+__global__ __launch_bounds__(TPB) void prep2_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
+                                                    ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
+                                                    int32_t *__restrict__ chan)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	__shared__ uint32_t sh_alleq[FLACGPU_MAX_CHANNELS];
+	__shared__ uint32_t sh_loose_ms;
+	const int tid = (int)threadIdx.x, lane = tid & 63;
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6), nthreads = blockDim.x;
+	const uint32_t C = P.channels, N = P.blocksize, n = N;
+	const uint32_t f = blockIdx.x;
+	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
+	const bool stereo_ms = C == 2 && P.ms_mode != 0;
+	const uint32_t G = stereo_ms ? 2u : (C < 4 ? C : 4u);            // raw channels staged per round
+	const uint32_t cstride = P.max_analyses + 1;
+	const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
+	const bool need_flags = P.limit_min_bitrate || P.ms_mode == 2;
+
+	for(uint32_t c0 = 0; c0 < C; c0 += G) {
+		const uint32_t nraw = C - c0 < G ? C - c0 : G;
+		__syncthreads();
+		// ---- stage the raw channels: sigidx rows, 32 zero samples in front, zero tail ------------------------------
+		for(uint32_t r = 0; r < nraw; r++) {
+			int32_t *sig = (int32_t *)(smem + (size_t)r * P.sig_bytes);
+			if(tid < 32) sig[sigidx(tid - 32)] = 0;
+			const uint32_t nround = ((n + 15u) & ~15u) + 16u;
+			for(uint32_t i = n + (uint32_t)tid; i < nround; i += nthreads) sig[sigidx((int)i)] = 0;
+		}
+		if(C == 2) {
+			int32_t *sl = (int32_t *)smem, *sr = (int32_t *)(smem + P.sig_bytes);
+			const int2 *p = (const int2 *)frame_pcm;
+			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) { const int2 lr = p[i]; sl[sigidx((int)i)] = lr.x; sr[sigidx((int)i)] = lr.y; }
+		}
+		else {
+			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads)
+				for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * P.sig_bytes))[sigidx((int)i)] = frame_pcm[(size_t)i * C + c0 + r];
+		}
+		__syncthreads();
+
+		// ---- this wavefront's channel ---------------------------------------------------------------------
+		const bool active = stereo_ms ? true : wave < nraw;
+		const uint32_t which = stereo_ms ? wave : c0 + wave;            // 0..C-1 channel, C mid, C+1 side
+		const int32_t *sa = (const int32_t *)(smem + (size_t)((stereo_ms || !active) ? 0 : wave) * P.sig_bytes);
+		const int32_t *sb = (const int32_t *)(smem + (size_t)(stereo_ms ? 1 : 0) * P.sig_bytes);
+		const int mode = !stereo_ms ? 0 : (int)which;                   // 0 take a, 1 take b, 2 mid, 3 side
+		Prep2Acc A;
+		A.orv = 0; A.diff = 0;
+#pragma unroll
+		for(int k = 0; k < 5; k++) A.e[k] = 0;
+		uint64_t lr_sum = 0, ms_sum = 0;
+		int32_t first = 0;
+		if(active) {
+			{
+				const int32_t a = sa[sigidx(0)], b = sb[sigidx(0)];
+				first = mode == 0 ? a : mode == 1 ? b : mode == 2 ? ((a + b) >> 1) : (a - b);
+			}
+			for(uint32_t ch = (uint32_t)lane; ch < nchunks; ch += 64) {
+				const uint32_t base = ch * CHUNK;
+				int32_t x[20];
+				if(mode == 0 && !(P.ms_mode == 2 && wave == 0)) {
+#pragma unroll
+					for(int k = 0; k < 20; k++) x[k] = sa[sigidx((int)base - 4 + k)];
+				}
+				else {
+					int32_t a[20], b[20];
+#pragma unroll
+					for(int k = 0; k < 20; k++) { a[k] = sa[sigidx((int)base - 4 + k)]; b[k] = sb[sigidx((int)base - 4 + k)]; }
+					if(P.ms_mode == 2 && wave == 0) {
+						// loose mid/side (stream_encoder.c:3778-3807), bps < 25
+#pragma unroll
+						for(int t = 0; t < CHUNK; t++) {
+							const uint32_t i = base + (uint32_t)t;
+							if(i >= 1 && i < n) {
+								const int32_t pl = a[t + 4] - a[t + 3], pr = b[t + 4] - b[t + 3];
+								lr_sum += (uint64_t)(uint32_t)(abs(pl) + abs(pr));
+								ms_sum += (uint64_t)(uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
+							}
+						}
+					}
+#pragma unroll
+					for(int k = 0; k < 20; k++) x[k] = mode == 0 ? a[k] : mode == 1 ? b[k] : mode == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
+				}
+				prep2_chunk<WIDE>(x, base, n, first, A);
+			}
+			A.orv = wave_reduce_or_u32(A.orv);
+			A.diff = wave_reduce_or_u32(A.diff);
+#pragma unroll
+			for(int k = 0; k < 5; k++) A.e[k] = wave_reduce_add_u64(A.e[k]);
+		}
+		uint32_t cand = stereo_ms ? wave : which;
+		bool emit = active;
+		if(need_flags) {
+			if(P.ms_mode == 2 && wave == 0) { lr_sum = wave_reduce_add_u64(lr_sum); ms_sum = wave_reduce_add_u64(ms_sum); if(lane == 0) sh_loose_ms = lr_sum < ms_sum ? 0u : 1u; }
+			if(active && lane == 0 && which < C) sh_alleq[which] = A.diff == 0 ? 1u : 0u;
+			__syncthreads();
+			if(P.ms_mode == 2) {
+				const uint32_t ms = sh_loose_ms;
+				emit = ms ? wave >= 2 : wave < 2;
+				cand = ms ? wave - 2 : wave;
+			}
+		}
+		else if(P.ms_mode == 2) emit = false;     // unreachable (need_flags covers loose mode)
+		if(!emit) continue;
+
+		// ---- decisions (every lane holds the reduced values) --------------------------------------------------------
+		bool disable_constant = P.disable_constant != 0;
+		if(P.limit_min_bitrate && !disable_constant && (P.ms_mode == 2 ? which == 1 : which >= C - 1)) {
+			bool all = true;
+			for(uint32_t c = 0; c + 1 < C; c++) all = all && sh_alleq[c] != 0;
+			if(all) disable_constant = true;
+		}
+		uint32_t wasted = A.orv ? (uint32_t)(__ffs((int)A.orv) - 1) : 0;
+		if(wasted > P.bps) wasted = P.bps;
+		const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
+		uint32_t flags = 0, fixed_order = 0;
+		int32_t constant = 0;
+		const uint32_t verbatim_bits = (P.disable_verbatim && n >= 4) ? 0xffffffffu : 8 + wasted + n * sbps;
+		if(n > 4) {
+			const uint32_t n4 = n - 4;
+			const uint64_t e0 = A.e[0] >> wasted, e1 = A.e[1] >> wasted, e2 = A.e[2] >> wasted, e3 = A.e[3] >> wasted, e4 = A.e[4] >> wasted;
+			uint32_t guess_fixed;
+			{
+				const uint64_t m34 = e3 < e4 ? e3 : e4, m234 = e2 < m34 ? e2 : m34, m1234 = e1 < m234 ? e1 : m234;
+				if(e0 <= m1234) guess_fixed = 0;
+				else if(e1 <= m234) guess_fixed = 1;
+				else if(e2 <= m34) guess_fixed = 2;
+				else if(e3 <= e4) guess_fixed = 3;
+				else guess_fixed = 4;
+			}
+			const uint64_t eg = guess_fixed == 0 ? e0 : guess_fixed == 1 ? e1 : guess_fixed == 2 ? e2 : guess_fixed == 3 ? e3 : e4;
+			// rbps = (float)(log(M_LN2*err/n)/M_LN2) as compiled (fixed.c:284-288)
+			const float rbps_guess = eg ? (float)(log(((double)eg * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
+			// CONSTANT needs rbps[1] == 0 and all samples equal (stream_encoder.c:4111-4140); all equal implies e1 == 0
+			const bool is_constant = !disable_constant && A.diff == 0;
+			if(is_constant) { flags |= PREP_CONSTANT; constant = first >> wasted; }
+			else {
+				if(!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu)) {
+					fixed_order = guess_fixed;
+					if(!(rbps_guess >= (float)sbps)) flags |= PREP_FIXED_VALID;
+				}
+				if(P.max_lpc_order > 0) flags |= PREP_LPC;
+			}
+		}
+		const uint32_t fmt = sbps <= 16 ? 1u : 0u;
+		const size_t fc = (size_t)f * P.ncand + cand;
+		if(lane < MAX_ORDER) {
+			const uint32_t order = fixed_order;
+			int32_t c = 0;
+			if(order == 1) c = lane == 0 ? 1 : 0;
+			else if(order == 2) c = lane == 0 ? 2 : lane == 1 ? -1 : 0;
+			else if(order == 3) c = lane == 0 ? 3 : lane == 1 ? -3 : lane == 2 ? 1 : 0;
+			else if(order == 4) c = lane == 0 ? 4 : lane == 1 ? -6 : lane == 2 ? 4 : lane == 3 ? -1 : 0;
+			cands[fc * cstride].q[lane] = c;
+		}
+		if(lane == 0) {
+			Candidate *cd0 = &cands[fc * cstride];
+			cd0->order = fixed_order; cd0->precision = 0; cd0->shift = 0; cd0->wide = 0;
+			valid[fc * cstride] = (flags & PREP_FIXED_VALID) ? 1 : 0;
+			ChanPrep pr;
+			pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
+			pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;
+			preps[fc] = pr;
+		}
+		// ---- planar channel, shifted ---------------------------------------------------------------------------
+		uint32_t *dst = (uint32_t *)(chan + fc * (size_t)N);
+		for(uint32_t ch = (uint32_t)lane; ch < nchunks; ch += 64) {
+			const uint32_t base = ch * CHUNK;
+			int32_t x[CHUNK];
+#pragma unroll
+			for(int k = 0; k < CHUNK; k++) {
+				const int32_t a = sa[sigidx((int)base + k)];
+				int32_t v = a;
+				if(mode != 0) { const int32_t b = sb[sigidx((int)base + k)]; v = mode == 1 ? b : mode == 2 ? ((a + b) >> 1) : (a - b); }
+				x[k] = v >> wasted;
+			}
+			if(fmt) {
+				uint4 w0, w1;
+				w0.x = ((uint32_t)x[0] & 0xffffu) | ((uint32_t)x[1] << 16); w0.y = ((uint32_t)x[2] & 0xffffu) | ((uint32_t)x[3] << 16);
+				w0.z = ((uint32_t)x[4] & 0xffffu) | ((uint32_t)x[5] << 16); w0.w = ((uint32_t)x[6] & 0xffffu) | ((uint32_t)x[7] << 16);
+				w1.x = ((uint32_t)x[8] & 0xffffu) | ((uint32_t)x[9] << 16); w1.y = ((uint32_t)x[10] & 0xffffu) | ((uint32_t)x[11] << 16);
+				w1.z = ((uint32_t)x[12] & 0xffffu) | ((uint32_t)x[13] << 16); w1.w = ((uint32_t)x[14] & 0xffffu) | ((uint32_t)x[15] << 16);
+				uint4 *d4 = (uint4 *)(dst + base / 2);
+				d4[0] = w0; d4[1] = w1;
+			}
+			else {
+				uint4 *d4 = (uint4 *)(dst + base);
+#pragma unroll
+				for(int k = 0; k < 4; k++) { uint4 w; w.x = (uint32_t)x[4 * k]; w.y = (uint32_t)x[4 * k + 1]; w.z = (uint32_t)x[4 * k + 2]; w.w = (uint32_t)x[4 * k + 3]; d4[k] = w; }
+			}
+		}
+	}
+}
+
+// the kernel above serves frames of nominal length when every lane run is whole and the AVX2 short-tail quirk of
+// the reference's wide fixed-predictor routine cannot occur (fixed_intrin_avx2.c:57 with (n-4) % 4 != 0)
+bool prep2_applicable(const DevParams &P)
+{
+	const uint32_t nraw = (P.channels == 2 && P.ms_mode != 0) ? 2u : (P.channels < 4 ? P.channels : 4u);
+	return P.blocksize % 16 == 0 && P.blocksize > 4 && (size_t)nraw * P.sig_bytes <= 150 * 1024;
+}
+
+hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s)
+{
+	if(nmain == 0) return hipSuccess;
+	static bool attr_set = false;
+	if(!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)prep2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e != hipSuccess) return e;
+		attr_set = true;
+	}
+	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;
+	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
+	const uint32_t waves = stereo_ms ? 4u : nraw;
+	const size_t lds = (size_t)nraw * P.sig_bytes;
+	if(P.bps > 20) hipLaunchKernelGGL(prep2_kernel<true>, dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
+	else hipLaunchKernelGGL(prep2_kernel<false>, dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
+	return hipGetLastError();
+}
+
+} // namespace flacgpu
