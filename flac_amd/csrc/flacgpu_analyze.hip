@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "flacgpu_dev.h"
 #include "flacgpu_devfn.h"
 
@@ -30,7 +31,7 @@ namespace flacgpu {
 #define AUTOC_WAVES_PER_SIMD 8
 #endif
 #ifndef EVAL_WAVES_PER_SIMD
-#define EVAL_WAVES_PER_SIMD 5
+#define EVAL_WAVES_PER_SIMD 4
 #endif
 
 // XCD-aware mapping (blocks round-robin over the 8 XCDs): keep the candidate channels of one frame on one XCD so
@@ -628,19 +629,53 @@ __device__ __forceinline__ uint32_t rice_search_nodes(uint32_t v, uint32_t e, ui
 	return best_bits;
 }
 
+// VOP3P form with a separate destination (the compiler's v_dot2c accumulates in place and needs a v_mov per sample)
 typedef short short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c)
 {
 	return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, false);
 }
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c)       // |a - b| + c, a and b unsigned
+{
+	uint32_t d;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+__device__ __forceinline__ uint32_t mad24(int32_t a, int32_t b, uint32_t c)
+{
+	uint32_t d;
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
 
+// NP dependent v_dot2_i32_i16 and the logical shift as ONE asm statement: between separate asm statements the
+// compiler pads every dependent pair with an s_nop, and its own v_dot2c form costs a v_mov per sample.
+template <int NP>
+__device__ __forceinline__ uint32_t dot2_chain_lshr(const uint32_t (&W)[NP], const uint32_t (&Q)[NP], int32_t sum0, uint32_t shift)
+{
+	uint32_t d;
+	if constexpr(NP == 1) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_lshrrev_b32 %0, %4, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(shift));
+	if constexpr(NP == 2) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_lshrrev_b32 %0, %6, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(shift));
+	if constexpr(NP == 3) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_lshrrev_b32 %0, %8, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(shift));
+	if constexpr(NP == 4) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_lshrrev_b32 %0, %10, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(shift));
+	if constexpr(NP == 5) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_lshrrev_b32 %0, %12, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(W[4]), "v"(Q[4]), "v"(shift));
+	if constexpr(NP == 6) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_lshrrev_b32 %0, %14, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(W[4]), "v"(Q[4]), "v"(W[5]), "v"(Q[5]), "v"(shift));
+	if constexpr(NP == 7) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_dot2_i32_i16 %0, %14, %15, %0\n\tv_lshrrev_b32 %0, %16, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(W[4]), "v"(Q[4]), "v"(W[5]), "v"(Q[5]), "v"(W[6]), "v"(Q[6]), "v"(shift));
+	if constexpr(NP == 8) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_dot2_i32_i16 %0, %14, %15, %0\n\tv_dot2_i32_i16 %0, %16, %17, %0\n\tv_lshrrev_b32 %0, %18, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(W[4]), "v"(Q[4]), "v"(W[5]), "v"(Q[5]), "v"(W[6]), "v"(Q[6]), "v"(W[7]), "v"(Q[7]), "v"(shift));
+	return d;
+}
+
+// |residual| without forming the residual.  With p = sum >> shift (arithmetic) the reference's residual is x - p.
+// Start the wrapping tap sum at 2^31: (sum + 2^31) >> shift LOGICAL = p + 2^(31-shift) =: p + bias, exactly, and
+// never negative; x + bias is not negative either as long as |x| <= bias (16-bit samples, shift <= 15).  Then
+// |x - p| = |(x + bias) - (p + bias)| as UNSIGNED numbers: one v_sad_u32, which also accumulates.
 // ---- residual magnitude of one lane's S samples, packed 16-bit samples -------------------------------------------
 // NP coefficient pairs (order <= 2*NP): sample t of the piece window is predicted from the NP pairs in front of it;
 // even t take their pairs straight from the LDS words (A), odd t from the words shifted by one sample (B).
 // Same low 32 bits as the wrapping sum of lpc.c:321.  FIRST: piece 0, where lane 0 skips its `order` warm-up samples.
 template <int NP, bool NARROW, bool FIRST, bool MASKED>
-__device__ __forceinline__ void fir_piece_packed(const uint32_t *w /* word of sample (piece start - 2*NP) */, const uint32_t (&Q)[NP], int shift, uint32_t order,
-                                                 uint32_t rem, bool lane0, uint32_t &acc32, uint64_t &acc64)
+__device__ __forceinline__ void fir_piece_packed(const uint32_t *w /* word of sample (piece start - 2*NP) */, const uint32_t (&Q)[NP], uint32_t shift, uint32_t bias, uint32_t order,
+                                                 uint32_t rem, bool lane0, int32_t sum0, uint32_t &acc32, uint64_t &acc64)
 {
 	constexpr int NW = NP + CHUNK / 2;
 	uint32_t A[NW + 1], B[NW];
@@ -652,28 +687,30 @@ __device__ __forceinline__ void fir_piece_packed(const uint32_t *w /* word of sa
 #pragma unroll
 	for(int s = 0; s < CHUNK; s++) {
 		const int t = 2 * NP + s;
-		int32_t sum = 0;
+		uint32_t W[NP];
 #pragma unroll
-		for(int p = 0; p < NP; p++) sum = dot2((t & 1) ? B[(t - 3) / 2 - p] : A[(t - 2) / 2 - p], Q[p], sum);
-		const int32_t x = (t & 1) ? ((int32_t)A[(t - 1) / 2] >> 16) : (int32_t)(int16_t)(A[t / 2] & 0xffffu);
-		const int32_t r = x - (sum >> shift);
-		uint32_t av = (uint32_t)(r < 0 ? -r : r);
-		if(FIRST && s < 2 * NP) { if(lane0 && (uint32_t)s < order) av = 0; }
-		if(MASKED) { if((uint32_t)s >= rem) av = 0; }
-		if(NARROW) acc32 += av; else acc64 += av;
+		for(int p = 0; p < NP; p++) W[p] = (t & 1) ? B[(t - 3) / 2 - p] : A[(t - 2) / 2 - p];
+		const uint32_t pb = dot2_chain_lshr<NP>(W, Q, sum0, shift);
+		const uint32_t xb = bias + (uint32_t)((t & 1) ? ((int32_t)A[(t - 1) / 2] >> 16) : (int32_t)(int16_t)(A[t / 2] & 0xffffu));
+		uint32_t pbm = pb;
+		if(FIRST && s < 2 * NP) { if(lane0 && (uint32_t)s < order) pbm = xb; }
+		if(MASKED) { if((uint32_t)s >= rem) pbm = xb; }
+		if(NARROW) acc32 = sad_u32(xb, pbm, acc32); else acc64 += sad_u32(xb, pbm, 0);
 	}
 }
 template <int NP, bool NARROW>
-__device__ __forceinline__ uint64_t fir_abs_packed(const uint32_t *reg, uint32_t S, uint32_t order, const uint32_t (&Q)[NP], int shift, int lane)
+__device__ __forceinline__ uint64_t fir_abs_packed(const uint32_t *reg, uint32_t S, uint32_t order, const uint32_t (&Q)[NP], int shift_, int lane)
 {
 	uint32_t acc32 = 0;
 	uint64_t acc64 = 0;
 	const uint32_t nfull = S / CHUNK;
 	const uint32_t *w = reg + (OH - 2 * NP) / 2;
-	fir_piece_packed<NP, NARROW, true, false>(w, Q, shift, order, CHUNK, lane == 0, acc32, acc64);      // S >= 16
+	const uint32_t shift = (uint32_t)shift_, bias = 0x80000000u >> shift;                               // 0 <= shift <= 15 (lpc.c:220-314)
+	const int32_t sum0 = (int32_t)0x80000000;
+	fir_piece_packed<NP, NARROW, true, false>(w, Q, shift, bias, order, CHUNK, lane == 0, sum0, acc32, acc64);      // S >= 16
 #pragma unroll 1
-	for(uint32_t c = 1; c < nfull; c++) fir_piece_packed<NP, NARROW, false, false>(w + (CHUNK / 2) * c, Q, shift, order, CHUNK, false, acc32, acc64);
-	if(S % CHUNK) fir_piece_packed<NP, NARROW, false, true>(w + (CHUNK / 2) * nfull, Q, shift, order, S % CHUNK, false, acc32, acc64);
+	for(uint32_t c = 1; c < nfull; c++) fir_piece_packed<NP, NARROW, false, false>(w + (CHUNK / 2) * c, Q, shift, bias, order, CHUNK, false, sum0, acc32, acc64);
+	if(S % CHUNK) fir_piece_packed<NP, NARROW, false, true>(w + (CHUNK / 2) * nfull, Q, shift, bias, order, S % CHUNK, false, sum0, acc32, acc64);
 	return NARROW ? (uint64_t)acc32 : acc64;
 }
 template <int MAXORD, bool NARROW>
@@ -693,6 +730,21 @@ __device__ __forceinline__ uint64_t fir_abs_packed_dispatch(const uint32_t *reg,
 #undef FAP
 }
 
+// the same for the 24-bit multiply-add chain on 32-bit samples: K taps per asm statement (30-operand limit), the
+// last one followed by the arithmetic shift and the sign flip that make the prediction an order-preserving unsigned
+template <int K, bool LAST>
+__device__ __forceinline__ uint32_t mad24_chain(const int32_t *xr /* xr[-j] is the sample tap j reads */, const int32_t *q, uint32_t sum, uint32_t shift)
+{
+	uint32_t d;
+	if constexpr(K == 4 && !LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]));
+	if constexpr(K == 4 && LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_ashrrev_i32 %0, %10, %0\n\tv_xor_b32 %0, 0x80000000, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(shift));
+	if constexpr(K == 8 && !LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_mad_i32_i24 %0, %10, %11, %0\n\tv_mad_i32_i24 %0, %12, %13, %0\n\tv_mad_i32_i24 %0, %14, %15, %0\n\tv_mad_i32_i24 %0, %16, %17, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(q[4]), "v"(xr[-4]), "v"(q[5]), "v"(xr[-5]), "v"(q[6]), "v"(xr[-6]), "v"(q[7]), "v"(xr[-7]));
+	if constexpr(K == 8 && LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_mad_i32_i24 %0, %10, %11, %0\n\tv_mad_i32_i24 %0, %12, %13, %0\n\tv_mad_i32_i24 %0, %14, %15, %0\n\tv_mad_i32_i24 %0, %16, %17, %0\n\tv_ashrrev_i32 %0, %18, %0\n\tv_xor_b32 %0, 0x80000000, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(q[4]), "v"(xr[-4]), "v"(q[5]), "v"(xr[-5]), "v"(q[6]), "v"(xr[-6]), "v"(q[7]), "v"(xr[-7]), "v"(shift));
+	if constexpr(K == 12 && !LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_mad_i32_i24 %0, %10, %11, %0\n\tv_mad_i32_i24 %0, %12, %13, %0\n\tv_mad_i32_i24 %0, %14, %15, %0\n\tv_mad_i32_i24 %0, %16, %17, %0\n\tv_mad_i32_i24 %0, %18, %19, %0\n\tv_mad_i32_i24 %0, %20, %21, %0\n\tv_mad_i32_i24 %0, %22, %23, %0\n\tv_mad_i32_i24 %0, %24, %25, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(q[4]), "v"(xr[-4]), "v"(q[5]), "v"(xr[-5]), "v"(q[6]), "v"(xr[-6]), "v"(q[7]), "v"(xr[-7]), "v"(q[8]), "v"(xr[-8]), "v"(q[9]), "v"(xr[-9]), "v"(q[10]), "v"(xr[-10]), "v"(q[11]), "v"(xr[-11]));
+	if constexpr(K == 12 && LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_mad_i32_i24 %0, %10, %11, %0\n\tv_mad_i32_i24 %0, %12, %13, %0\n\tv_mad_i32_i24 %0, %14, %15, %0\n\tv_mad_i32_i24 %0, %16, %17, %0\n\tv_mad_i32_i24 %0, %18, %19, %0\n\tv_mad_i32_i24 %0, %20, %21, %0\n\tv_mad_i32_i24 %0, %22, %23, %0\n\tv_mad_i32_i24 %0, %24, %25, %0\n\tv_ashrrev_i32 %0, %26, %0\n\tv_xor_b32 %0, 0x80000000, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(q[4]), "v"(xr[-4]), "v"(q[5]), "v"(xr[-5]), "v"(q[6]), "v"(xr[-6]), "v"(q[7]), "v"(xr[-7]), "v"(q[8]), "v"(xr[-8]), "v"(q[9]), "v"(xr[-9]), "v"(q[10]), "v"(xr[-10]), "v"(q[11]), "v"(xr[-11]), "v"(shift));
+	return d;
+}
+
 // ---- the same on 32-bit samples: NT taps (order <= NT); FMODE 0 v_mad_i32_i24, 1 32-bit multiplies (both lpc.c:321),
 // 2 64-bit accumulate (lpc.c:582)
 template <int NT, int FMODE, bool NARROW, bool FIRST, bool MASKED>
@@ -704,21 +756,29 @@ __device__ __forceinline__ void fir_piece_i32(const int32_t *w /* sample (piece 
 	for(int k = 0; k < NT + CHUNK; k++) x[k] = w[k];
 #pragma unroll
 	for(int s = 0; s < CHUNK; s++) {
-		int32_t r;
+		uint32_t av;
 		if(FMODE == 2) {
 			int64_t sum = 0;
 #pragma unroll
 			for(int jj = 0; jj < NT; jj++) sum += (int64_t)q[jj] * (int64_t)x[NT + s - 1 - jj];
-			r = (int32_t)((int64_t)x[NT + s] - (sum >> shift));
+			const int32_t r = (int32_t)((int64_t)x[NT + s] - (sum >> shift));
+			av = (uint32_t)(r < 0 ? -(uint32_t)r : (uint32_t)r);
 		}
 		else {
-			uint32_t sum = 0;
+			// |x - p| as an unsigned difference of the sign-flipped operands (order preserving): one v_sad_u32
+			uint32_t pb;
+			if(FMODE == 0) {
+				if(NT == 16) pb = mad24_chain<8, true>(&x[NT + s - 9], &q[8], mad24_chain<8, false>(&x[NT + s - 1], &q[0], 0, 0), (uint32_t)shift);
+				else pb = mad24_chain<NT == 16 ? 8 : NT, true>(&x[NT + s - 1], &q[0], 0, (uint32_t)shift);
+			}
+			else {
+				uint32_t sum = 0;
 #pragma unroll
-			for(int jj = 0; jj < NT; jj++)
-				sum += FMODE == 0 ? (uint32_t)__mul24(q[jj], x[NT + s - 1 - jj]) : (uint32_t)q[jj] * (uint32_t)x[NT + s - 1 - jj];
-			r = (int32_t)((uint32_t)x[NT + s] - (uint32_t)((int32_t)sum >> shift));
+				for(int jj = 0; jj < NT; jj++) sum += (uint32_t)q[jj] * (uint32_t)x[NT + s - 1 - jj];
+				pb = (uint32_t)((int32_t)sum >> shift) ^ 0x80000000u;
+			}
+			av = sad_u32((uint32_t)x[NT + s] ^ 0x80000000u, pb, 0);
 		}
-		uint32_t av = (uint32_t)(r < 0 ? -(uint32_t)r : (uint32_t)r);
 		if(FIRST && s < NT) { if(lane0 && (uint32_t)s < order) av = 0; }
 		if(MASKED) { if((uint32_t)s >= rem) av = 0; }
 		if(NARROW) acc32 += av; else acc64 += av;
@@ -749,6 +809,22 @@ __device__ __forceinline__ uint64_t fir_abs_i32_dispatch(const uint32_t *reg, ui
 	return fir_abs_i32<4, FMODE, NARROW>(reg, S, order, q, shift, lane);
 }
 
+// a candidate that needs the 64-bit accumulate (lpc.c:582) on a packed 16-bit channel: rare, plain code
+template <int MAXORD>
+__device__ uint64_t fir_abs_packed_wide(const uint32_t *reg, uint32_t S, uint32_t order, const int32_t *q, int shift, int lane)
+{
+	const int16_t *x = (const int16_t *)reg + OH;          // x[s] = this lane's sample s, x[-1..-OH] its history
+	uint64_t acc = 0;
+	for(uint32_t s = (lane == 0 ? order : 0); s < S; s++) {
+		int64_t sum = 0;
+#pragma unroll
+		for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)x[(int)s - 1 - j];
+		const int32_t r = (int32_t)((int64_t)x[s] - (sum >> shift));
+		acc += (uint32_t)(r < 0 ? -(uint32_t)r : (uint32_t)r);
+	}
+	return acc;
+}
+
 // One wavefront evaluates one residual candidate on the owner layout; requires n == 64*S, S >= 16, max_po <= 6.
 template <int MAXORD>
 __device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's region */, bool packed, uint32_t S, uint32_t n, uint32_t order, const int32_t *q, int shift,
@@ -758,7 +834,10 @@ __device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's regi
 	const uint32_t psize = n >> max_po;
 	const bool narrow = (sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
 	uint64_t v;
-	if(packed) v = narrow ? fir_abs_packed_dispatch<MAXORD, true>(reg, S, order, q, shift, lane) : fir_abs_packed_dispatch<MAXORD, false>(reg, S, order, q, shift, lane);
+	if(packed) {
+		if(!wide) v = narrow ? fir_abs_packed_dispatch<MAXORD, true>(reg, S, order, q, shift, lane) : fir_abs_packed_dispatch<MAXORD, false>(reg, S, order, q, shift, lane);
+		else { v = fir_abs_packed_wide<MAXORD>(reg, S, order, q, shift, lane); if(narrow) v = (uint32_t)v; }
+	}
 	else {
 		const int fmode = fir_mode(wide, sbps);
 		if(fmode == 0) v = narrow ? fir_abs_i32_dispatch<MAXORD, 0, true>(reg, S, order, q, shift, lane) : fir_abs_i32_dispatch<MAXORD, 0, false>(reg, S, order, q, shift, lane);
@@ -771,239 +850,289 @@ __device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's regi
 	return rice_search_owner(v, narrow, 6 - max_po, n, order, max_po, min_po, rice_limit, divtab, kout, best_po_out, lane);
 }
 
+// ---- workgroup state of the evaluation kernel ---------------------------------------------------------------------
+constexpr int EVAL_CPW_MAX = 4;          // candidate channels of one frame served by one workgroup
+struct EvalChan {                         // per channel, written once by one lane, then read by everybody
+	ChanPrep pr;
+	uint32_t nan, any, mine, packed, stride, ctx, pad[2];
+};
 struct EvalSmall {
 	uint32_t divtab[(MAX_PO + 1) * (MAX_ORDER + 1)];
 	uint64_t pob[EVAL_MAX_WAVES][MAX_PO + 1];
-	uint32_t wbest_bits[EVAL_MAX_WAVES], wbest_ci[EVAL_MAX_WAVES], wbest_po[EVAL_MAX_WAVES];
-	uint32_t rice2;
+	uint32_t wbest_bits[EVAL_CPW_MAX][EVAL_MAX_WAVES], wbest_ci[EVAL_CPW_MAX][EVAL_MAX_WAVES], wbest_po[EVAL_CPW_MAX][EVAL_MAX_WAVES];
+	EvalChan ch[EVAL_CPW_MAX];
 };
-// generic: (sig | per-wave sums, params) ; owner: (sig regions | candidate records | per-wave params)
-struct EvalLayout { uint32_t wsums, kbestw, kcandw, cands, valid, small, total; };
-__host__ __device__ inline uint32_t owner_sig_bytes(const DevParams &P)
+// LDS bytes of one lane-owner channel image: 64 lane regions of S samples + OH history at an odd word stride
+__host__ __device__ inline uint32_t owner_chan_bytes(uint32_t N, bool packed)
 {
-	const uint32_t N = P.blocksize;
-	if(N % 64 == 0 && N / 64 >= (uint32_t)OH) return (64 * ((N / 64 + OH) | 1u) * 4 + (CHUNK + MAX_ORDER) * 4 + 15u) & ~15u;
-	return 0;
+	const uint32_t S = N / 64, w = (packed ? (S + OH) / 2 : S + OH) | 1u;
+	return (64 * w * 4 + (CHUNK + MAX_ORDER) * 4 + 15u) & ~15u;
 }
-__host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t waves, bool generic)
+__host__ __device__ inline bool owner_possible(const DevParams &P) { return P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH; }
+__host__ __device__ inline uint32_t eval_cand_bytes(const DevParams &P) { return (P.max_analyses + 1) * (uint32_t)sizeof(Candidate) + (((P.max_analyses + 1) * 4 + 15u) & ~15u); }
+// worst-case subframe width of candidate channel `cand` (the side channel carries one bit more)
+__host__ __device__ inline uint32_t cand_max_sbps(const DevParams &P, uint32_t cand)
+{
+	const bool side = (P.ms_mode == 1 && cand == 3) || (P.ms_mode == 2 && cand == 1);
+	return P.bps + (side ? 1 : 0);
+}
+// [channel contexts: image | candidate records | valid flags] [wsums] [kbestw] [kcandw] [EvalSmall]
+struct EvalLayout { uint32_t ctx_bytes, wsums, kbestw, kcandw, small, total; };
+__host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t waves, uint32_t cpw, bool generic)
 {
 	EvalLayout L;
-	uint32_t o = generic ? P.sig_bytes : owner_sig_bytes(P);
+	uint32_t o = 0;
+	if(generic) o = cpw * (P.sig_bytes + eval_cand_bytes(P));
+	else {
+		// the most demanding group of cpw consecutive candidate channels
+		const bool s_even = (P.blocksize / 64) % 2 == 0;
+		for(uint32_t g = 0; g * cpw < P.ncand; g++) {
+			uint32_t t = 0;
+			for(uint32_t c = g * cpw; c < (g + 1) * cpw && c < P.ncand; c++) t += owner_chan_bytes(P.blocksize, s_even && cand_max_sbps(P, c) <= 16) + eval_cand_bytes(P);
+			if(t > o) o = t;
+		}
+	}
+	L.ctx_bytes = o;
 	L.wsums = o;  o += generic ? waves * (2u << P.max_po) * 8 : 0;
-	L.kbestw = o; o += waves * 2 * (1u << P.max_po);
+	L.kbestw = o; o += cpw * waves * 2 * (1u << P.max_po);
 	L.kcandw = o; o += generic && P.max_po > 6 ? waves * (2u << P.max_po) : 0;
 	o = (o + 15u) & ~15u;
-	L.cands = o;  o += (P.max_analyses + 1) * (uint32_t)sizeof(Candidate);
-	L.valid = o;  o += ((P.max_analyses + 1) * 4 + 15u) & ~15u;
 	L.small = o;  o += (uint32_t)sizeof(EvalSmall);
 	L.total = (o + 15u) & ~15u;
 	return L;
 }
 
-// VARIANT selects which workgroups a launch serves (the others leave at once), so that each flavour of the
+// VARIANT selects which (frame, channel)s a launch serves (the others are left alone), so that each flavour of the
 // residual evaluation gets its own register allocation:
-//   0  owner layout: packed 16-bit samples + dot2 FIR, or 32-bit samples (17..25-bit channels, or a candidate that
-//      needs the 64-bit FIR), chosen per workgroup; also every workgroup that has no residual candidate at all
+//   0  owner layout: packed 16-bit samples + dot2 FIR, or 32-bit samples (17..25-bit channels), chosen per channel;
+//      also every channel that has no residual candidate at all
 //   2  any other block length / partition order: generic chunked evaluation with LDS partition sums
+// A workgroup serves cpw consecutive candidate channels of one frame with nwaves wavefronts: the work items
+// (channel, candidate) are dealt to the wavefronts round-robin, rotating the channel from round to round so that the
+// expensive channel (side: 17-bit samples, no dot2) is spread evenly.  nwaves is a multiple of 4 wherever possible:
+// a 5-wavefront workgroup puts two wavefronts on one SIMD and the dispatcher then fits only 2 such workgroups per CU.
 template <int MAXORD, int VARIANT>
-__global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_SIMD : 2) void eval_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
+__global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_SIMD : 2) void eval_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n, uint32_t cpw,
                                                                    const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                                    const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
                                                                    const int *__restrict__ valid, SubDecision *__restrict__ decisions, unsigned long long *__restrict__ dbg)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = (int)threadIdx.x, lane = tid & 63;
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
 #define STAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
 	const unsigned long long t_start = dbg ? (unsigned long long)clock64() : 0ull;
 	const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;
 	const uint32_t N = P.blocksize;
-	uint32_t f, cand;
-	map_block(blockIdx.x, nframes, P.ncand, f, cand);
-	const size_t fc = (size_t)f * P.ncand + cand;
-	const ChanPrep pr = preps[fc];
+	const uint32_t ngrp = P.ncand / cpw;
+	uint32_t f, grp;
+	map_block(blockIdx.x, nframes, ngrp, f, grp);
+	const size_t fc0 = (size_t)f * P.ncand + (size_t)grp * cpw;
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const JobTable *jt = is_tail ? jt_tail : jt_main;
-	const uint32_t n = pr.n, sbps = pr.sbps, wasted = pr.wasted, which = pr.which;
-	const uint32_t hdr = 8 + wasted;
-	const uint32_t *src = (const uint32_t *)(chan + fc * (size_t)N);       // planar channel, already shifted (ChanPrep::fmt)
-	const uint32_t srcfmt = pr.fmt;
+	const uint32_t n = is_tail ? tail_n : N;
 	const uint32_t cstride = P.max_analyses + 1;
-	SubDecision *dec = decisions + fc;
 
-	const EvalLayout LY = eval_layout(P, nwaves, VARIANT == 2);
-	uint32_t *sigw = (uint32_t *)smem;
+	const EvalLayout LY = eval_layout(P, nwaves, cpw, VARIANT == 2);
 	uint64_t *wsums_all = (uint64_t *)(smem + LY.wsums);
 	uint8_t *kbestw_all = smem + LY.kbestw;
 	uint8_t *kcandw_all = smem + LY.kcandw;
-	const Candidate *mycands = (const Candidate *)(smem + LY.cands);     // LDS copies of this channel's candidate records
-	const int *myvalid = (const int *)(smem + LY.valid);
 	EvalSmall *sh = (EvalSmall *)(smem + LY.small);
+	const uint32_t kstride = 1u << P.max_po;
 
-	uint32_t best_type = 1, best_order = 0, best_po = 0, best_precision = 0, best_ci = 0, best_wave = 0;
-	int32_t best_shift = 0, best_constant = 0;
-	uint32_t best_bits = pr.verbatim_bits;
-
-	const uint32_t nan = (pr.flags & PREP_LPC) ? jt->nanalyses : 0;
-	const bool any_candidates = !(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || nan);
 	// partition order limits of the frame (stream_encoder.c:3759-3761)
 	uint32_t frame_max_po = 0;
 	{ uint32_t b = n; while(!(b & 1)) { frame_max_po++; b >>= 1; } if(frame_max_po > 15) frame_max_po = 15; }
 	frame_max_po = umin32(frame_max_po, P.max_po);
 	const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
 	const uint32_t S = n / 64;
-	const bool owner = (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6;
-	{
-		const int kind = !any_candidates ? 0 : owner ? 0 : 2;
-		if(kind != VARIANT) return;
+	// (a short last block whose lane runs are odd while the nominal ones are even would need a wider image than the
+	// launch reserved: it takes the generic path)
+	const bool owner = (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6 && (S % 2 == 0 || (N / 64) % 2 == 1);
+	const uint32_t cand_bytes = eval_cand_bytes(P), cand_valid_off = (P.max_analyses + 1) * (uint32_t)sizeof(Candidate);
+
+	// ---- channel facts ---------------------------------------------------------------------------------------
+	if(tid < (int)cpw) {
+		EvalChan &E = sh->ch[tid];
+		const ChanPrep pr = preps[fc0 + (size_t)tid];
+		E.pr = pr;
+		E.nan = (pr.flags & PREP_LPC) ? jt->nanalyses : 0;
+		E.any = (!(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || E.nan)) ? 1u : 0u;
+		const int kind = !E.any ? 0 : owner ? 0 : 2;
+		E.mine = kind == VARIANT ? 1u : 0u;
+		E.packed = (VARIANT == 0 && pr.fmt && (S % 2 == 0)) ? 1u : 0u;
+		E.stride = owner_stride_words(S, E.packed != 0);
 	}
+	if(tid < EVAL_CPW_MAX * EVAL_MAX_WAVES) { (&sh->wbest_bits[0][0])[tid] = 0xffffffffu; (&sh->wbest_ci[0][0])[tid] = 0xffffffffu; (&sh->wbest_po[0][0])[tid] = 0; }
+	__syncthreads();
+	uint32_t nmine = 0, nwork = 0;
+	{
+		uint32_t o = 0;
+		for(uint32_t c = 0; c < cpw; c++) {
+			if(tid == 0) sh->ch[c].ctx = o;
+			if(sh->ch[c].mine) {
+				nmine++;
+				if(sh->ch[c].any) { nwork++; o += (VARIANT == 2 ? P.sig_bytes : owner_chan_bytes(n, sh->ch[c].packed != 0)) + cand_bytes; }
+			}
+		}
+	}
+	if(nmine == 0) return;
 	if(dbg && tid == 0) { dbg[(size_t)blockIdx.x * 16] = t_start; dbg[(size_t)blockIdx.x * 16 + 8] = (unsigned long long)clock64(); dbg[(size_t)blockIdx.x * 16 + 9] = (unsigned long long)VARIANT + 1; }
 
-	if(pr.flags & PREP_CONSTANT) {
-		const uint32_t bits = hdr + sbps;
-		if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_bits = bits; }
-	}
-	if(any_candidates) {
-		// ---- first batch of the channel on its way while the small tables are set up ------------------------------
-		constexpr int LB = 4;
-		const uint32_t nvec = srcfmt ? (n + 7) / 8 : (n + 3) / 4;       // 16-byte pieces: 8 packed / 4 plain samples each
-		uint4 pv[LB];
-		if(VARIANT == 0) {
-#pragma unroll
-			for(int u = 0; u < LB; u++) { const uint32_t m = (uint32_t)tid + (uint32_t)u * nthreads; if(m < nvec) pv[u] = ((const uint4 *)src)[m]; }
-		}
+	if(nwork) {
 		for(uint32_t t = (uint32_t)tid; t < (MAX_PO + 1) * (MAX_ORDER + 1); t += nthreads) {
 			const uint32_t po = t / (MAX_ORDER + 1), o = t - po * (MAX_ORDER + 1);
 			const uint32_t ps = n >> po;
 			sh->divtab[t] = ps > o ? 0x40000u / (ps - o) : 0;
 		}
-		{
-			const uint32_t *src = (const uint32_t *)(cands + fc * cstride);
-			uint32_t *dst = (uint32_t *)(smem + LY.cands);
-			for(uint32_t t = (uint32_t)tid; t < (nan + 1) * (uint32_t)(sizeof(Candidate) / 4); t += nthreads) dst[t] = src[t];
-			int *vd = (int *)(smem + LY.valid);
-			for(uint32_t t = (uint32_t)tid; t <= nan; t += nthreads) vd[t] = valid[fc * cstride + t];
-		}
-		__syncthreads();
-		bool packed = VARIANT == 0 && sbps <= 16 && (S % 2 == 0);
-		if(packed) {
-			// a candidate whose prediction needs the 64-bit FIR (lpc.c:582) keeps the whole workgroup on 32-bit samples
-			for(uint32_t ci = 0; ci <= nan; ci++) if(myvalid[ci] && mycands[ci].wide) packed = false;
-		}
-		const uint32_t stride = owner_stride_words(S, packed);
-
-		// ---- block into LDS -------------------------------------------------------------------------------
-		if(VARIANT != 2) {
-			// zero lane 0's history
-			if(tid < OH) { if(packed) { if(tid < OH / 2) sigw[tid] = 0; } else sigw[tid] = 0; }
-			const bool spow2 = (S & (S - 1)) == 0;
-			const uint32_t slog = ilog2_u32(S);
-			for(uint32_t m0 = (uint32_t)tid; m0 < nvec; m0 += LB * nthreads) {
-				if(m0 != (uint32_t)tid) {
+		__syncthreads();         // ctx offsets visible
+		// ---- candidate records and the channel signals into LDS -------------------------------------------------------
+		for(uint32_t c = 0; c < cpw; c++) {
+			const EvalChan &E = sh->ch[c];
+			if(!E.mine || !E.any) continue;
+			const size_t fc = fc0 + c;
+			unsigned char *ctx = smem + E.ctx;
+			const uint32_t img_bytes = VARIANT == 2 ? P.sig_bytes : owner_chan_bytes(n, E.packed != 0);
+			{
+				const uint32_t *src = (const uint32_t *)(cands + fc * cstride);
+				uint32_t *dst = (uint32_t *)(ctx + img_bytes);
+				for(uint32_t t = (uint32_t)tid; t < (E.nan + 1) * (uint32_t)(sizeof(Candidate) / 4); t += nthreads) dst[t] = src[t];
+				int *vd = (int *)(ctx + img_bytes + cand_valid_off);
+				for(uint32_t t = (uint32_t)tid; t <= E.nan; t += nthreads) vd[t] = valid[fc * cstride + t];
+			}
+			const uint32_t *src = (const uint32_t *)(chan + fc * (size_t)N);       // planar channel, already shifted (ChanPrep::fmt)
+			const uint32_t srcfmt = E.pr.fmt;
+			if(VARIANT != 2) {
+				uint32_t *sigw = (uint32_t *)ctx;
+				const bool packed = E.packed != 0;
+				const uint32_t stride = E.stride;
+				// zero lane 0's history
+				if(tid < OH) { if(packed) { if(tid < OH / 2) sigw[tid] = 0; } else sigw[tid] = 0; }
+				const bool spow2 = (S & (S - 1)) == 0;
+				const uint32_t slog = ilog2_u32(S);
+				const uint32_t nvec = srcfmt ? (n + 7) / 8 : (n + 3) / 4;       // 16-byte pieces: 8 packed / 4 plain samples each
+				for(uint32_t m = (uint32_t)tid; m < nvec; m += nthreads) {
+					const uint4 pv = ((const uint4 *)src)[m];
+					const uint32_t wv[4] = {pv.x, pv.y, pv.z, pv.w};
+					if(srcfmt && packed) {
+						// word = two samples; S is even, so a pair never straddles two lanes
 #pragma unroll
-					for(int u = 0; u < LB; u++) { const uint32_t m = m0 + (uint32_t)u * nthreads; if(m < nvec) pv[u] = ((const uint4 *)src)[m]; }
-				}
-#pragma unroll
-				for(int u = 0; u < LB; u++) {
-					const uint32_t m = m0 + (uint32_t)u * nthreads;
-					if(m < nvec) {
-						const uint32_t wv[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
-						if(srcfmt && packed) {
-							// word = two samples; S is even, so a pair never straddles two lanes
-#pragma unroll
-							for(int k = 0; k < 4; k++) {
-								const uint32_t i = 8 * m + 2 * (uint32_t)k;
-								const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
-								sigw[Lo * stride + (OH + s) / 2] = wv[k];
-								if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S) / 2] = wv[k];
-							}
+						for(int k = 0; k < 4; k++) {
+							const uint32_t i = 8 * m + 2 * (uint32_t)k;
+							const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
+							sigw[Lo * stride + (OH + s) / 2] = wv[k];
+							if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S) / 2] = wv[k];
 						}
-						else {
-							// 32-bit lane regions (from either source format)
+					}
+					else {
+						// 32-bit lane regions (from either source format)
 #pragma unroll
-							for(int k = 0; k < 8; k++) {
-								if(!srcfmt && k >= 4) break;
-								const uint32_t i = (srcfmt ? 8 : 4) * m + (uint32_t)k;
-								const int32_t v = srcfmt ? ((k & 1) ? ((int32_t)wv[k >> 1] >> 16) : (int32_t)(int16_t)(wv[k >> 1] & 0xffffu)) : (int32_t)wv[k & 3];
-								const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
-								sigw[Lo * stride + OH + s] = (uint32_t)v;
-								if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S)] = (uint32_t)v;
-							}
+						for(int k = 0; k < 8; k++) {
+							if(!srcfmt && k >= 4) break;
+							const uint32_t i = (srcfmt ? 8 : 4) * m + (uint32_t)k;
+							const int32_t v = srcfmt ? ((k & 1) ? ((int32_t)wv[k >> 1] >> 16) : (int32_t)(int16_t)(wv[k >> 1] & 0xffffu)) : (int32_t)wv[k & 3];
+							const uint32_t Lo = spow2 ? i >> slog : i / S, s = i - Lo * S;
+							sigw[Lo * stride + OH + s] = (uint32_t)v;
+							if(s + OH >= S && Lo + 1 < 64) sigw[(Lo + 1) * stride + (s + OH - S)] = (uint32_t)v;
 						}
 					}
 				}
 			}
-		}
-		else {
-			int32_t *sig = (int32_t *)smem;
-			if(tid < 32) sig[sigidx(tid - 32)] = 0;
-			const uint32_t nround = ((n + 15u) & ~15u) + 16u;
-			for(uint32_t i = n + (uint32_t)tid; i < nround; i += nthreads) sig[sigidx((int)i)] = 0;
-			if(srcfmt) for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = (int32_t)((const int16_t *)src)[i];
-			else for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = (int32_t)src[i];
+			else {
+				int32_t *sig = (int32_t *)ctx;
+				if(tid < 32) sig[sigidx(tid - 32)] = 0;
+				const uint32_t nround = ((n + 15u) & ~15u) + 16u;
+				for(uint32_t i = n + (uint32_t)tid; i < nround; i += nthreads) sig[sigidx((int)i)] = 0;
+				if(srcfmt) for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = (int32_t)((const int16_t *)src)[i];
+				else for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = (int32_t)src[i];
+			}
 		}
 		__syncthreads();
 		STAMP(1);
 
-		// ---- candidates: one wavefront each -------------------------------------------------------------------
+		// ---- work items (candidate, channel): one wavefront each ---------------------------------------------------------
 		{
-			const uint32_t kstride = 1u << P.max_po;
 			uint64_t *wsums = wsums_all + (size_t)wave * (2u << P.max_po);
-			uint8_t *kbw = kbestw_all + (size_t)wave * 2 * kstride, *ktmp = kbw + kstride;
 			uint8_t *kcw = kcandw_all + (size_t)wave * (2u << P.max_po);
-			uint32_t wb_bits = 0xffffffffu, wb_ci = 0xffffffffu, wb_po = 0;
-			for(uint32_t ci = (uint32_t)wave; ci <= nan; ci += nwaves) {
-				if(!myvalid[ci]) continue;
-				const Candidate *cd = &mycands[ci];
-				const uint32_t order = cd->order;
+			uint8_t *ktmp = kbestw_all + ((size_t)wave * 2 + 1) * kstride;           // scratch of this wavefront (slot of channel 0)
+			const uint32_t ncmax = jt->nanalyses + 1;
+			const bool rotate = nwaves % cpw == 0;
+			for(uint32_t item = wave, k = 0; item < cpw * ncmax; item += nwaves, k++) {
+				const uint32_t ci = item / cpw;
+				const uint32_t c = (item - ci * cpw + (rotate ? k : 0)) % cpw;
+				const EvalChan &E = sh->ch[c];
+				if(!E.mine || !E.any || ci > E.nan) continue;
+				unsigned char *ctx = smem + E.ctx;
+				const uint32_t img_bytes = VARIANT == 2 ? P.sig_bytes : owner_chan_bytes(n, E.packed != 0);
+				const Candidate *cd = (const Candidate *)(ctx + img_bytes) + ci;
+				if(!((const int *)(ctx + img_bytes + cand_valid_off))[ci]) continue;
+				const uint32_t order = cd->order, sbps = E.pr.sbps, hdr = 8 + E.pr.wasted;
 				uint32_t po, rbits;
 				if(VARIANT == 0)
-					rbits = eval_candidate_owner<MAXORD>(sigw + (uint32_t)lane * stride, packed, S, n, order, cd->q, cd->shift, cd->wide != 0, sbps, P.rice_limit,
+					rbits = eval_candidate_owner<MAXORD>((const uint32_t *)ctx + (uint32_t)lane * E.stride, E.packed != 0, S, n, order, cd->q, cd->shift, cd->wide != 0, sbps, P.rice_limit,
 					                                     frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
 				else {
 					int32_t q[MAXORD];
 #pragma unroll
 					for(int jj = 0; jj < MAXORD; jj++) q[jj] = cd->q[jj];
-					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, (const int32_t *)smem, n, order, q, cd->shift,
+					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, (const int32_t *)ctx, n, order, q, cd->shift,
 					                                    cd->wide != 0, sbps, P, frame_max_po, frame_min_po, &po, lane);
 				}
 				const uint32_t est = ci == 0 ? sat_add_u32(hdr + order * sbps, rbits)
 				                             : sat_add_u32(hdr + 4 + 5 + order * (cd->precision + sbps), rbits);
-				if(est > 0 && est < wb_bits) {      // strict: the earlier candidate keeps a tie (stream_encoder.c:4191,4266)
-					wb_bits = est; wb_ci = ci; wb_po = po;
+				// a wavefront meets the candidates of a channel in increasing order; strict <: the earlier candidate keeps a
+				// tie (stream_encoder.c:4191,4266)
+				if(est > 0 && est < sh->wbest_bits[c][wave]) {
+					__builtin_amdgcn_wave_barrier();
+					if(lane == 0) { sh->wbest_bits[c][wave] = est; sh->wbest_ci[c][wave] = ci; sh->wbest_po[c][wave] = po; }
+					uint8_t *kbw = kbestw_all + (((size_t)c * nwaves + wave) * 2) * kstride;
 					for(uint32_t p = (uint32_t)lane; p < (1u << po); p += 64) kbw[p] = ktmp[p];
 					__builtin_amdgcn_wave_barrier();
 				}
-				if(ci == 0) STAMP(2);
-				if(ci == nwaves) STAMP(3);
+				if(item == wave) STAMP(2);
 			}
-			if(lane == 0) { sh->wbest_bits[wave] = wb_bits; sh->wbest_ci[wave] = wb_ci; sh->wbest_po[wave] = wb_po; }
 		}
 		__syncthreads();
 		STAMP(4);
-		// ---- winner: first minimum in the reference's evaluation order -----------------------------------------
-		uint32_t cb = 0xffffffffu, cci = 0xffffffffu, cw = 0;
-		for(uint32_t w = 0; w < nwaves; w++) {
-			const uint32_t b = sh->wbest_bits[w], ci = sh->wbest_ci[w];
-			if(ci != 0xffffffffu && (b < cb || (b == cb && ci < cci))) { cb = b; cci = ci; cw = w; }
-		}
-		if(cci != 0xffffffffu && cb < best_bits) {
-			best_bits = cb; best_ci = cci; best_wave = cw; best_po = sh->wbest_po[cw];
-			best_type = cci == 0 ? 2 : 3;
-			best_order = mycands[cci].order; best_precision = mycands[cci].precision; best_shift = mycands[cci].shift;
-		}
 	}
-	if(best_bits == 0xffffffffu) { best_type = 1; best_bits = hdr + n * sbps; }   // stream_encoder.c:4281
 
-	// ---- decision record -----------------------------------------------------------------------------------
-	if(wave == 0) {
+	// ---- decisions: first minimum in the reference's evaluation order; one wavefront per channel ---------------------------
+	for(uint32_t c = wave; c < cpw; c += nwaves) {
+		const EvalChan &E = sh->ch[c];
+		if(!E.mine) continue;
+		const ChanPrep &pr = E.pr;
+		const uint32_t sbps = pr.sbps, wasted = pr.wasted, hdr = 8 + wasted;
+		SubDecision *dec = decisions + fc0 + c;
+		uint32_t best_type = 1, best_order = 0, best_po = 0, best_precision = 0, best_ci = 0, best_wave = 0;
+		int32_t best_shift = 0, best_constant = 0;
+		uint32_t best_bits = pr.verbatim_bits;
+		if(pr.flags & PREP_CONSTANT) {
+			const uint32_t bits = hdr + sbps;
+			if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_bits = bits; }
+		}
+		const Candidate *mycands = nullptr;
+		if(E.any) {
+			mycands = (const Candidate *)(smem + E.ctx + (VARIANT == 2 ? P.sig_bytes : owner_chan_bytes(n, E.packed != 0)));
+			uint32_t cb = 0xffffffffu, cci = 0xffffffffu, cw = 0;
+			for(uint32_t w = 0; w < nwaves; w++) {
+				const uint32_t b = sh->wbest_bits[c][w], ci = sh->wbest_ci[c][w];
+				if(ci != 0xffffffffu && (b < cb || (b == cb && ci < cci))) { cb = b; cci = ci; cw = w; }
+			}
+			if(cci != 0xffffffffu && cb < best_bits) {
+				best_bits = cb; best_ci = cci; best_wave = cw; best_po = sh->wbest_po[c][cw];
+				best_type = cci == 0 ? 2 : 3;
+				best_order = mycands[cci].order; best_precision = mycands[cci].precision; best_shift = mycands[cci].shift;
+			}
+		}
+		if(best_bits == 0xffffffffu) { best_type = 1; best_bits = hdr + n * sbps; }   // stream_encoder.c:4281
 		uint32_t rice2 = 0;
 		if(best_type >= 2) {
-			const uint8_t *kb = kbestw_all + (size_t)best_wave * 2 * (1u << P.max_po);
+			const uint8_t *kb = kbestw_all + (((size_t)c * nwaves + best_wave) * 2) * kstride;
 			uint32_t big = 0;
 			for(uint32_t p = (uint32_t)lane; p < (1u << best_po); p += 64) {
-				const uint8_t k = kb[p];
-				dec->params[p] = k;
-				if(k >= 15) big = 1;
+				const uint8_t kk = kb[p];
+				dec->params[p] = kk;
+				if(kk >= 15) big = 1;
 			}
 			rice2 = __any((int)big) ? 1u : 0u;                         // stream_encoder.c:4786-4791
 		}
@@ -1012,7 +1141,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			dec->bits = best_bits;
 			dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
 			dec->po = (uint8_t)best_po; dec->rice2 = (uint8_t)rice2; dec->precision = (uint8_t)best_precision;
-			dec->shift = (int8_t)best_shift; dec->which = (uint8_t)which;
+			dec->shift = (int8_t)best_shift; dec->which = (uint8_t)pr.which;
 			dec->constant = best_constant;
 		}
 	}
@@ -1028,18 +1157,44 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 using namespace flacgpu;
 
 namespace flacgpu {
-uint32_t eval_waves(const DevParams &P)
+// (channels per workgroup, wavefronts per workgroup) of the owner-layout evaluation
+static void eval_shape(const DevParams &P, uint32_t &cpw, uint32_t &waves)
 {
-	// wavefronts per (frame, channel) workgroup: enough that the candidates go round in full rounds
+	const uint32_t nc = P.max_analyses + 1;
+	// prefer a multiple of 4 wavefronts with every wavefront busy in every round, and the smallest workgroup that does it
+	cpw = 1; waves = 0;
+	for(uint32_t c = 1; c <= P.ncand && c <= (uint32_t)EVAL_CPW_MAX; c *= 2) {
+		if(P.ncand % c) continue;
+		const uint32_t items = c * nc;
+		for(uint32_t w = 4; w <= (uint32_t)EVAL_MAX_WAVES; w += 4)
+			if(items % w == 0 && w % c == 0 && waves == 0) { cpw = c; waves = w; }
+		if(waves) break;
+	}
+	if(!waves) {
+		// no exact fit: as many wavefronts as items, rounded to full rounds
+		cpw = 1;
+		const uint32_t rounds = (nc + EVAL_MAX_WAVES - 1) / EVAL_MAX_WAVES;
+		waves = (nc + rounds - 1) / rounds;
+		if(nc >= 4) waves = waves >= 8 ? 8 : 4;
+	}
+	static int fw = -1, fc = -1;
+	if(fw < 0) { const char *e = getenv("FLACGPU_EVAL_WAVES"); fw = e ? atoi(e) : 0; e = getenv("FLACGPU_EVAL_CPW"); fc = e ? atoi(e) : 0; }
+	if(fc > 0 && fc <= EVAL_CPW_MAX && P.ncand % (uint32_t)fc == 0) cpw = (uint32_t)fc;
+	if(fw > 0 && fw <= EVAL_MAX_WAVES) waves = (uint32_t)fw;
+	while(owner_possible(P) && cpw > 1 && eval_layout(P, waves, cpw, false).total > 64 * 1024) cpw /= 2;     // keep at least 2 workgroups per CU
+}
+static uint32_t eval_waves_generic(const DevParams &P)
+{
 	const uint32_t nc = P.max_analyses + 1;
 	const uint32_t rounds = (nc + EVAL_MAX_WAVES - 1) / EVAL_MAX_WAVES;
 	uint32_t w = (nc + rounds - 1) / rounds;
-	if(w < 1) w = 1;
-	return w;
+	return w < 1 ? 1 : w;
 }
 size_t analyze_lds_bytes(const DevParams &P)
 {
-	const size_t a = P.sig_bytes, d = eval_layout(P, eval_waves(P), false).total, g = eval_layout(P, eval_waves(P), true).total;
+	uint32_t cpw, waves;
+	eval_shape(P, cpw, waves);
+	const size_t a = P.sig_bytes, d = owner_possible(P) ? eval_layout(P, waves, cpw, false).total : 0, g = eval_layout(P, eval_waves_generic(P), 1, true).total;
 	return a > d ? (a > g ? a : g) : (d > g ? d : g);
 }
 
@@ -1059,23 +1214,26 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		hipLaunchKernelGGL(model_kernel<MAXORD>, dim3((lanes + TPB - 1) / TPB), dim3(TPB), 0, s, P, nframes, tail_n, jtm, jtt, B.prep, B.autoc, B.cands, B.valid);
 	}
 	if(pev) (void)hipEventRecord(pev[2], s);
-	const uint32_t waves = eval_waves(P);
-	const size_t lds = eval_layout(P, waves, false).total, lds_generic = eval_layout(P, waves, true).total;
+	uint32_t cpw, waves;
+	eval_shape(P, cpw, waves);
+	const uint32_t gwaves = eval_waves_generic(P);
+	const bool op = owner_possible(P);
+	const size_t lds = op ? eval_layout(P, waves, cpw, false).total : 0, lds_generic = eval_layout(P, gwaves, 1, true).total;
 	if(B.dbg) {
 		static bool said = false;
 		if(!said) {
 			said = true;
 			int nb0 = -1, nb1 = -1;
 			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, (const void *)eval_kernel<MAXORD, 0>, (int)(waves * 64), lds);
-			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void *)eval_kernel<MAXORD, 2>, (int)(waves * 64), lds_generic);
-			fprintf(stderr, "[flacgpu] eval: %u waves/WG, %zu B LDS/WG, occupancy API: %d / %d WGs per CU\n", waves, lds, nb0, nb1);
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void *)eval_kernel<MAXORD, 2>, (int)(gwaves * 64), lds_generic);
+			fprintf(stderr, "[flacgpu] eval: %u channels x %u waves per WG, %zu B LDS/WG, occupancy API: %d / %d WGs per CU\n", cpw, waves, lds, nb0, nb1);
 		}
 	}
-	const bool owner_possible = P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH;
-	// which flavours can occur in this batch at all (each launch serves only its own workgroups)
-	if(owner_possible) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
-	if(!owner_possible || tail_n || P.max_po > 6)
-		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(waves * 64), lds_generic, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+	// which flavours can occur in this batch at all (each launch serves only its own channels)
+	if(op) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, true).total, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+	if(!op || tail_n || P.max_po > 6)
+		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(gwaves * 64), lds_generic, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	return hipGetLastError();
 }
 
