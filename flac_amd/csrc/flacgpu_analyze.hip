@@ -570,62 +570,87 @@ __device__ __forceinline__ void rice_node(uint32_t sum, uint32_t ns, uint32_t di
 	if(k >= rice_limit) k = rice_limit - 1;
 	bits = 4 + (1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
 }
+// v + (value of the lane's partner group) at exchange stage M; groups of 2^M lanes hold equal values
+template <int M>
+__device__ __forceinline__ uint32_t bfly_add(uint32_t v)
+{
+	uint32_t d;
+	if(M == 0) { asm("v_add_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
+	if(M == 1) { asm("v_add_u32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
+	if(M == 2) { asm("v_add_u32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }     // the other quad of the 8
+	if(M == 3) { asm("v_add_u32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }          // the other half of the row
+	if(M == 4) return v + (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                                                // lane ^ 16
+	// both halves of the wavefront are uniform by now: two scalar reads
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+}
+// set_partitioned_rice_ (stream_encoder.c:4997-5046) without branches, for sum < 2^23: mean-based parameter
+// k = ilog2(((sum-1)*div) >> 18) + 1 (0 when that quotient is 0 or sum < 2), then the closed-form bit count
+__device__ __forceinline__ void rice_node_small(uint32_t sum, uint32_t ns, uint32_t div, uint32_t rice_limit_m1, uint32_t &k, uint32_t &bits)
+{
+	const uint32_t sm1 = (sum > 1u ? sum : 1u) - 1u;
+	const uint32_t x = (uint32_t)(((uint64_t)sm1 * div) >> 18);                  // < 2^23
+	uint32_t kk = 32u - umin32((uint32_t)__clz((int)x), 32u);   // __clz(0) = 32
+	kk = umin32(kk, rice_limit_m1);
+	k = kk;
+	bits = 4 + (1 + kk) * ns + ((sum << 1) >> kk) - (ns >> 1);
+}
+// Rice search over the partition orders as ONE butterfly: after exchange stage m every lane holds the |residual|
+// sum of its aligned group of 2^m lanes, i.e. of "its" partition at order max_po - (m - e); it evaluates that node
+// right there (all lanes of a group redundantly -- redundancy is free in SIMD) and the per-order bit totals ride along
+// through the remaining stages, so that at the end every lane holds every order's total.  No prefix sums, no
+// gathers; DPP adds for the first four stages.  Requires every lane sum < 2^23 (32-bit arithmetic exact).
 __device__ __forceinline__ uint32_t rice_search_nodes(uint32_t v, uint32_t e, uint32_t n, uint32_t order, uint32_t max_po, uint32_t min_po,
                                                       uint32_t rice_limit, const uint32_t *divtab, uint8_t *kout, uint32_t *best_po_out, int lane)
 {
 	const uint32_t D = max_po - min_po;                     // number of lower orders searched
-	const uint32_t nleaves = 1u << max_po;
-	const uint32_t P = wave_scan_incl_u32(v, lane);
-	// node A: leaf `lane`
-	uint32_t kA = 0, bA = 0;
-	{
-		uint32_t sum = v;
-		if(e) {
-			const uint32_t hi = (((uint32_t)lane + 1) << e) - 1, lo = (uint32_t)lane << e;
-			const uint32_t ph = __shfl(P, (int)(hi & 63)), pl = __shfl(P, (int)((lo - 1) & 63));
-			sum = ph - (lo ? pl : 0);
-		}
-		if((uint32_t)lane < nleaves) {
-			const uint32_t o = lane == 0 ? order : 0;
-			rice_node(sum, (n >> max_po) - o, divtab[max_po * (MAX_ORDER + 1) + o], rice_limit, kA, bA);
-		}
-	}
-	// node B: the lane-th merged partition, orders max_po-1 .. min_po one after the other
-	uint32_t kB = 0, bB = 0, dB = 0, pB = 0;
-	const uint32_t nupper = nleaves - (nleaves >> D);
-	if(D) {
-		uint32_t u = (uint32_t)lane, d = 1, cnt = nleaves >> 1;
-		while(d < D && u >= cnt) { u -= cnt; cnt >>= 1; d++; }
-		const bool have = (uint32_t)lane < nupper;
-		const uint32_t g = e + d;
-		const uint32_t lo = have ? u << g : 0, hi = have ? ((u + 1) << g) - 1 : 0;
-		const uint32_t ph = __shfl(P, (int)(hi & 63)), pl = __shfl(P, (int)((lo - 1) & 63));
-		if(have) {
-			const uint32_t sum = ph - (lo ? pl : 0);
-			const uint32_t po = max_po - d, o = u == 0 ? order : 0;
-			rice_node(sum, (n >> po) - o, divtab[po * (MAX_ORDER + 1) + o], rice_limit, kB, bB);
-			dB = d; pB = u;
-		}
-	}
-	// totals per order: order max_po from the A nodes, the others are consecutive lane ranges of the B nodes
-	uint32_t totA = bA;
+	const uint32_t rl1 = rice_limit - 1;
+	uint32_t tm[7], km[7];
 #pragma unroll
-	for(int off = 32; off >= 1; off >>= 1) totA += __shfl_xor(totA, off);
-	const uint32_t Q = D ? wave_scan_incl_u32(bB, lane) : 0;
-	uint32_t best_bits = 6 + totA, best_d = 0;
-	{
-		uint32_t start = 0, cnt = nleaves >> 1;
-		for(uint32_t d = 1; d <= D; d++) {
-			const uint32_t endv = __shfl(Q, (int)(start + cnt - 1)), begv = start ? __shfl(Q, (int)(start - 1)) : 0;
-			const uint32_t bits = 6 + (endv - begv);
-			if(bits < best_bits) { best_bits = bits; best_d = d; }      // strict: ties keep the higher order (stream_encoder.c:4735-4763)
-			start += cnt; cnt >>= 1;
+	for(int m = 0; m < 7; m++) { tm[m] = 0; km[m] = 0; }
+#pragma unroll
+	for(int m = 0; m < 7; m++) {
+		if((uint32_t)m >= e && (uint32_t)m - e <= D) {
+			// node of this lane at partition order po: partition index lane >> m; partition 0 is `order` samples short
+			const uint32_t po = max_po - ((uint32_t)m - e);
+			const uint32_t nsf = n >> po;
+			const uint32_t d0 = divtab[po * (MAX_ORDER + 1)], d1 = divtab[po * (MAX_ORDER + 1) + order];
+			const bool p0 = (uint32_t)lane < (1u << m);
+			rice_node_small(v, p0 ? nsf - order : nsf, p0 ? d1 : d0, rl1, km[m], tm[m]);
+		}
+		if(m < 6) {
+			if(m == 0) { v = bfly_add<0>(v); }
+			if(m == 1) { v = bfly_add<1>(v); }
+			if(m == 2) { v = bfly_add<2>(v); }
+			if(m == 3) { v = bfly_add<3>(v); }
+			if(m == 4) { v = bfly_add<4>(v); }
+			if(m == 5) { v = bfly_add<5>(v); }
+#pragma unroll
+			for(int j = 0; j <= m; j++) {
+				if(m == 0) tm[j] = bfly_add<0>(tm[j]);
+				if(m == 1) tm[j] = bfly_add<1>(tm[j]);
+				if(m == 2) tm[j] = bfly_add<2>(tm[j]);
+				if(m == 3) tm[j] = bfly_add<3>(tm[j]);
+				if(m == 4) tm[j] = bfly_add<4>(tm[j]);
+				if(m == 5) tm[j] = bfly_add<5>(tm[j]);
+			}
 		}
 	}
-	if(best_d == 0) { if((uint32_t)lane < nleaves) kout[lane] = (uint8_t)kA; }
-	else if(dB == best_d) kout[pB] = (uint8_t)kB;
+	// strict <, highest order first: ties keep the higher order (stream_encoder.c:4735-4763); all uniform by now
+	uint32_t best_bits = 0, best_m = 0;
+	bool have = false;
+#pragma unroll
+	for(int m = 0; m < 7; m++) {
+		if((uint32_t)m >= e && (uint32_t)m - e <= D) {
+			const uint32_t bits = 6 + (uint32_t)__builtin_amdgcn_readfirstlane((int)tm[m]);
+			if(!have || bits < best_bits) { best_bits = bits; best_m = (uint32_t)m; have = true; }
+		}
+	}
+	uint32_t kk = km[0];
+#pragma unroll
+	for(int m = 1; m < 7; m++) if((uint32_t)m == best_m) kk = km[m];
+	if(((uint32_t)lane & ((1u << best_m) - 1u)) == 0) kout[(uint32_t)lane >> best_m] = (uint8_t)kk;
 	__builtin_amdgcn_wave_barrier();
-	*best_po_out = max_po - best_d;
+	*best_po_out = max_po - (best_m - e);
 	return best_bits;
 }
 
