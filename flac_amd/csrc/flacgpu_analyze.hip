@@ -570,19 +570,6 @@ __device__ __forceinline__ void rice_node(uint32_t sum, uint32_t ns, uint32_t di
 	if(k >= rice_limit) k = rice_limit - 1;
 	bits = 4 + (1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
 }
-// v + (value of the lane's partner group) at exchange stage M; groups of 2^M lanes hold equal values
-template <int M>
-__device__ __forceinline__ uint32_t bfly_add(uint32_t v)
-{
-	uint32_t d;
-	if(M == 0) { asm("v_add_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
-	if(M == 1) { asm("v_add_u32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
-	if(M == 2) { asm("v_add_u32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }     // the other quad of the 8
-	if(M == 3) { asm("v_add_u32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }          // the other half of the row
-	if(M == 4) return v + (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                                                // lane ^ 16
-	// both halves of the wavefront are uniform by now: two scalar reads
-	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
-}
 // set_partitioned_rice_ (stream_encoder.c:4997-5046) without branches, for sum < 2^23: mean-based parameter
 // k = ilog2(((sum-1)*div) >> 18) + 1 (0 when that quotient is 0 or sum < 2), then the closed-form bit count
 __device__ __forceinline__ void rice_node_small(uint32_t sum, uint32_t ns, uint32_t div, uint32_t rice_limit_m1, uint32_t &k, uint32_t &bits)

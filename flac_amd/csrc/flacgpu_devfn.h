@@ -45,6 +45,48 @@ __device__ __forceinline__ uint32_t wave_reduce_or_u32(uint32_t v)
 	for(int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off);
 	return v;
 }
+// v + (value of the lane's partner group) at exchange stage M; groups of 2^M lanes hold equal values.
+// (s_nop 1: a DPP read needs two wait states after the VALU write of its source, and the compiler does not see
+// into an asm statement)
+template <int M>
+__device__ __forceinline__ uint32_t bfly_add(uint32_t v)
+{
+	uint32_t d;
+	if(M == 0) { asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
+	if(M == 1) { asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
+	if(M == 2) { asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }     // the other quad of the 8
+	if(M == 3) { asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }          // the other half of the row
+	if(M == 4) return v + (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                                                // lane ^ 16
+	// both halves of the wavefront are uniform by now: two scalar reads
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+}
+template <int M>
+__device__ __forceinline__ uint32_t bfly_or(uint32_t v)
+{
+	uint32_t d;
+	if(M == 0) { asm("s_nop 1\n\tv_or_b32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
+	if(M == 1) { asm("s_nop 1\n\tv_or_b32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
+	if(M == 2) { asm("s_nop 1\n\tv_or_b32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
+	if(M == 3) { asm("s_nop 1\n\tv_or_b32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v)); return d; }
+	if(M == 4) return v | (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+}
+// wavefront-wide sum / or, result in every lane: DPP butterflies, no LDS round trips
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+	v = bfly_add<0>(v); v = bfly_add<1>(v); v = bfly_add<2>(v); v = bfly_add<3>(v); v = bfly_add<4>(v); return bfly_add<5>(v);
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+	v = bfly_or<0>(v); v = bfly_or<1>(v); v = bfly_or<2>(v); v = bfly_or<3>(v); v = bfly_or<4>(v); return bfly_or<5>(v);
+}
+// 64-bit sum of lane values below 2^50 as two 32-bit butterflies (24-bit low limb: 64 of them cannot overflow)
+__device__ __forceinline__ uint64_t wave_sum_u50(uint64_t v)
+{
+	const uint32_t lo = wave_sum_u32((uint32_t)v & 0xffffffu), hi = wave_sum_u32((uint32_t)(v >> 24));
+	return (uint64_t)lo + ((uint64_t)hi << 24);
+}
+
 // workgroup reductions through a small LDS scratch (8 x u64)
 __device__ __forceinline__ uint64_t block_reduce_add_u64(uint64_t v, uint64_t *scratch, int tid)
 {

@@ -22,32 +22,53 @@ struct Prep2Acc {
 	uint64_t e[5];
 };
 
-// statistics of 16 consecutive samples x[4..19] (x[0..3] = the four samples in front of them) at block offset base.
+// LDS image of one raw channel, transposed: sample i sits in row i%16, column i/16 + 1 (column 0 holds zeros: the
+// samples in front of the block), rows P2_TS(n) words apart.  A lane that owns the 16 samples of chunk t reads
+// row r at column t+1 -- consecutive lanes, consecutive words, no address arithmetic (ds_read offsets); the staging
+// store of 32 consecutive samples hits 32 banks because the row stride is 2 mod 32.
+__host__ __device__ inline uint32_t p2_ts(uint32_t n) { const uint32_t nch = (n + CHUNK - 1) / CHUNK; return ((nch - 1 + 31) / 32) * 32 + 2; }
+__host__ __device__ inline uint32_t p2_chan_bytes(uint32_t n) { return CHUNK * p2_ts(n) * 4; }
+
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c)       // |a - b| + c, a and b unsigned
+{
+	uint32_t d;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+// statistics of the 16 samples x[4..19] of a chunk (x[0..3] = the four samples in front of them).
 // Sums are taken on the UNSHIFTED signal: every |difference| is a multiple of 2^wasted, so the sums of the shifted
 // signal the reference computes (it shifts in place first) are these sums >> wasted, exactly.
+// |d_k[i]| = |d_(k-1)[i] - d_(k-1)[i-1]| is one v_sad_u32 on the sign-flipped (order preserving) operands.
 template <bool WIDE>
-__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], uint32_t base, uint32_t n, int32_t first, Prep2Acc &A)
+__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_chunk, int32_t first, Prep2Acc &A)
 {
-	uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+	constexpr uint32_t M = 0x80000000u;
+	uint32_t s[5] = {0, 0, 0, 0, 0};
+	// differences at the three samples in front of the chunk
+	int32_t d1p = x[3] - x[2], d2p = (x[3] - x[2]) - (x[2] - x[1]), d3p = ((x[3] - x[2]) - (x[2] - x[1])) - ((x[2] - x[1]) - (x[1] - x[0]));
+	uint32_t xbp = (uint32_t)x[3] ^ M;
 #pragma unroll
 	for(int t = 0; t < CHUNK; t++) {
-		const uint32_t i = base + (uint32_t)t;
-		const int32_t a0 = x[t + 4], a1 = x[t + 3], a2 = x[t + 2], a3 = x[t + 1], a4 = x[t];
-		if(i < n) { A.orv |= (uint32_t)a0; A.diff |= (uint32_t)(a0 ^ first); }
-		if(i >= 4 && i < n) {
-			const int32_t d1 = a0 - a1, d2 = a0 - 2 * a1 + a2, d3 = a0 - 3 * a1 + 3 * a2 - a3, d4 = a0 - 4 * a1 + 6 * a2 - 4 * a3 + a4;
-			if(WIDE) {
-				A.e[0] += (uint32_t)abs(a0); A.e[1] += (uint32_t)abs(d1); A.e[2] += (uint32_t)abs(d2); A.e[3] += (uint32_t)abs(d3); A.e[4] += (uint32_t)abs(d4);
-			}
-			else { s0 += (uint32_t)abs(a0); s1 += (uint32_t)abs(d1); s2 += (uint32_t)abs(d2); s3 += (uint32_t)abs(d3); s4 += (uint32_t)abs(d4); }
-		}
+		const int32_t a0 = x[t + 4];
+		A.orv |= (uint32_t)a0; A.diff |= (uint32_t)(a0 ^ first);
+		const uint32_t xb = (uint32_t)a0 ^ M;
+		const int32_t d1 = a0 - x[t + 3], d2 = d1 - d1p, d3 = d2 - d2p;
+		uint32_t t0 = sad_u32(xb, M, 0), t1 = sad_u32(xb, xbp, 0), t2 = sad_u32((uint32_t)d1 ^ M, (uint32_t)d1p ^ M, 0),
+		         t3 = sad_u32((uint32_t)d2 ^ M, (uint32_t)d2p ^ M, 0), t4 = sad_u32((uint32_t)d3 ^ M, (uint32_t)d3p ^ M, 0);
+		if(t < 4) { if(first_chunk) { t0 = t1 = t2 = t3 = t4 = 0; } }          // the sums start at sample 4 (stream_encoder.c:4100)
+		if(WIDE) { A.e[0] += t0; A.e[1] += t1; A.e[2] += t2; A.e[3] += t3; A.e[4] += t4; }
+		else { s[0] += t0; s[1] += t1; s[2] += t2; s[3] += t3; s[4] += t4; }
+		d1p = d1; d2p = d2; d3p = d3; xbp = xb;
 	}
-	if(!WIDE) { A.e[0] += s0; A.e[1] += s1; A.e[2] += s2; A.e[3] += s3; A.e[4] += s4; }
+	if(!WIDE) {
+#pragma unroll
+		for(int k = 0; k < 5; k++) A.e[k] += s[k];
+	}
 }
 
 // WIDE: per-run partial sums may exceed 32 bits (more than 20 bits per sample)
 template <bool WIDE>
-__global__ __launch_bounds__(TPB) void prep2_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
+__global__ __launch_bounds__(TPB, 4) void prep2_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
                                                     ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
                                                     int32_t *__restrict__ chan)
 {
@@ -56,42 +77,44 @@ __global__ __launch_bounds__(TPB) void prep2_kernel(const DevParams P, const int
 	__shared__ uint32_t sh_loose_ms;
 	const int tid = (int)threadIdx.x, lane = tid & 63;
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6), nthreads = blockDim.x;
-	const uint32_t C = P.channels, N = P.blocksize, n = N;
+	const uint32_t C = P.channels, N = P.blocksize, n = N;          // n % 16 == 0 (prep2_applicable)
 	const uint32_t f = blockIdx.x;
 	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
 	const bool stereo_ms = C == 2 && P.ms_mode != 0;
 	const uint32_t G = stereo_ms ? 2u : (C < 4 ? C : 4u);            // raw channels staged per round
 	const uint32_t cstride = P.max_analyses + 1;
-	const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
+	const uint32_t nchunks = n / CHUNK;
+	const uint32_t TS = p2_ts(n), cbytes = p2_chan_bytes(n);
 	const bool need_flags = P.limit_min_bitrate || P.ms_mode == 2;
 
 	for(uint32_t c0 = 0; c0 < C; c0 += G) {
 		const uint32_t nraw = C - c0 < G ? C - c0 : G;
 		__syncthreads();
-		// ---- stage the raw channels: sigidx rows, 32 zero samples in front, zero tail ------------------------------
-		for(uint32_t r = 0; r < nraw; r++) {
-			int32_t *sig = (int32_t *)(smem + (size_t)r * P.sig_bytes);
-			if(tid < 32) sig[sigidx(tid - 32)] = 0;
-			const uint32_t nround = ((n + 15u) & ~15u) + 16u;
-			for(uint32_t i = n + (uint32_t)tid; i < nround; i += nthreads) sig[sigidx((int)i)] = 0;
-		}
-		if(C == 2) {
-			int32_t *sl = (int32_t *)smem, *sr = (int32_t *)(smem + P.sig_bytes);
-			const int2 *p = (const int2 *)frame_pcm;
-			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) { const int2 lr = p[i]; sl[sigidx((int)i)] = lr.x; sr[sigidx((int)i)] = lr.y; }
-		}
-		else {
-			for(uint32_t i = (uint32_t)tid; i < n; i += nthreads)
-				for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * P.sig_bytes))[sigidx((int)i)] = frame_pcm[(size_t)i * C + c0 + r];
+		// ---- stage the raw channels -------------------------------------------------------------------------
+		if(tid < CHUNK) for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * cbytes))[(uint32_t)tid * TS] = 0;
+		{
+			const uint32_t a0 = ((uint32_t)tid & 15u) * TS + ((uint32_t)tid >> 4) + 1;     // sample i = tid; i += nthreads moves nthreads/16 columns
+			if(C == 2) {
+				int32_t *sl = (int32_t *)smem, *sr = (int32_t *)(smem + cbytes);
+				const int2 *p = (const int2 *)frame_pcm;
+				uint32_t a = a0;
+				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads, a += nthreads / 16) { const int2 lr = p[i]; sl[a] = lr.x; sr[a] = lr.y; }
+			}
+			else {
+				uint32_t a = a0;
+				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads, a += nthreads / 16)
+					for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * cbytes))[a] = frame_pcm[(size_t)i * C + c0 + r];
+			}
 		}
 		__syncthreads();
 
 		// ---- this wavefront's channel ---------------------------------------------------------------------
 		const bool active = stereo_ms ? true : wave < nraw;
 		const uint32_t which = stereo_ms ? wave : c0 + wave;            // 0..C-1 channel, C mid, C+1 side
-		const int32_t *sa = (const int32_t *)(smem + (size_t)((stereo_ms || !active) ? 0 : wave) * P.sig_bytes);
-		const int32_t *sb = (const int32_t *)(smem + (size_t)(stereo_ms ? 1 : 0) * P.sig_bytes);
+		const int32_t *sa = (const int32_t *)(smem + (size_t)((stereo_ms || !active) ? 0 : wave) * cbytes);
+		const int32_t *sb = (const int32_t *)(smem + (size_t)(stereo_ms ? 1 : 0) * cbytes);
 		const int mode = !stereo_ms ? 0 : (int)which;                   // 0 take a, 1 take b, 2 mid, 3 side
+		const bool loose_here = P.ms_mode == 2 && wave == 0;
 		Prep2Acc A;
 		A.orv = 0; A.diff = 0;
 #pragma unroll
@@ -100,26 +123,26 @@ __global__ __launch_bounds__(TPB) void prep2_kernel(const DevParams P, const int
 		int32_t first = 0;
 		if(active) {
 			{
-				const int32_t a = sa[sigidx(0)], b = sb[sigidx(0)];
+				const int32_t a = sa[1], b = sb[1];          // sample 0: row 0, column 1
 				first = mode == 0 ? a : mode == 1 ? b : mode == 2 ? ((a + b) >> 1) : (a - b);
 			}
 			for(uint32_t ch = (uint32_t)lane; ch < nchunks; ch += 64) {
-				const uint32_t base = ch * CHUNK;
+				// x[k] = sample 16*ch - 4 + k: rows 12..15 of column ch, then rows 0..15 of column ch+1
+				const int32_t *pa = sa + ch, *pb = sb + ch;
 				int32_t x[20];
-				if(mode == 0 && !(P.ms_mode == 2 && wave == 0)) {
+				if(mode == 0 && !loose_here) {
 #pragma unroll
-					for(int k = 0; k < 20; k++) x[k] = sa[sigidx((int)base - 4 + k)];
+					for(int k = 0; k < 20; k++) x[k] = k < 4 ? pa[(12 + k) * TS] : pa[(k - 4) * TS + 1];
 				}
 				else {
 					int32_t a[20], b[20];
 #pragma unroll
-					for(int k = 0; k < 20; k++) { a[k] = sa[sigidx((int)base - 4 + k)]; b[k] = sb[sigidx((int)base - 4 + k)]; }
-					if(P.ms_mode == 2 && wave == 0) {
+					for(int k = 0; k < 20; k++) { a[k] = k < 4 ? pa[(12 + k) * TS] : pa[(k - 4) * TS + 1]; b[k] = k < 4 ? pb[(12 + k) * TS] : pb[(k - 4) * TS + 1]; }
+					if(loose_here) {
 						// loose mid/side (stream_encoder.c:3778-3807), bps < 25
 #pragma unroll
 						for(int t = 0; t < CHUNK; t++) {
-							const uint32_t i = base + (uint32_t)t;
-							if(i >= 1 && i < n) {
+							if(t > 0 || ch > 0) {
 								const int32_t pl = a[t + 4] - a[t + 3], pr = b[t + 4] - b[t + 3];
 								lr_sum += (uint64_t)(uint32_t)(abs(pl) + abs(pr));
 								ms_sum += (uint64_t)(uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
@@ -129,17 +152,17 @@ __global__ __launch_bounds__(TPB) void prep2_kernel(const DevParams P, const int
 #pragma unroll
 					for(int k = 0; k < 20; k++) x[k] = mode == 0 ? a[k] : mode == 1 ? b[k] : mode == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
 				}
-				prep2_chunk<WIDE>(x, base, n, first, A);
+				prep2_chunk<WIDE>(x, ch == 0, first, A);
 			}
-			A.orv = wave_reduce_or_u32(A.orv);
-			A.diff = wave_reduce_or_u32(A.diff);
+			A.orv = wave_or_u32(A.orv);
+			A.diff = wave_or_u32(A.diff);
 #pragma unroll
-			for(int k = 0; k < 5; k++) A.e[k] = wave_reduce_add_u64(A.e[k]);
+			for(int k = 0; k < 5; k++) A.e[k] = wave_sum_u50(A.e[k]);
 		}
 		uint32_t cand = stereo_ms ? wave : which;
 		bool emit = active;
 		if(need_flags) {
-			if(P.ms_mode == 2 && wave == 0) { lr_sum = wave_reduce_add_u64(lr_sum); ms_sum = wave_reduce_add_u64(ms_sum); if(lane == 0) sh_loose_ms = lr_sum < ms_sum ? 0u : 1u; }
+			if(P.ms_mode == 2 && wave == 0) { lr_sum = wave_sum_u50(lr_sum); ms_sum = wave_sum_u50(ms_sum); if(lane == 0) sh_loose_ms = lr_sum < ms_sum ? 0u : 1u; }
 			if(active && lane == 0 && which < C) sh_alleq[which] = A.diff == 0 ? 1u : 0u;
 			__syncthreads();
 			if(P.ms_mode == 2) {
@@ -214,12 +237,13 @@ __global__ __launch_bounds__(TPB) void prep2_kernel(const DevParams P, const int
 		uint32_t *dst = (uint32_t *)(chan + fc * (size_t)N);
 		for(uint32_t ch = (uint32_t)lane; ch < nchunks; ch += 64) {
 			const uint32_t base = ch * CHUNK;
+			const int32_t *pa = sa + ch + 1, *pb = sb + ch + 1;
 			int32_t x[CHUNK];
 #pragma unroll
 			for(int k = 0; k < CHUNK; k++) {
-				const int32_t a = sa[sigidx((int)base + k)];
+				const int32_t a = pa[k * TS];
 				int32_t v = a;
-				if(mode != 0) { const int32_t b = sb[sigidx((int)base + k)]; v = mode == 1 ? b : mode == 2 ? ((a + b) >> 1) : (a - b); }
+				if(mode != 0) { const int32_t b = pb[k * TS]; v = mode == 1 ? b : mode == 2 ? ((a + b) >> 1) : (a - b); }
 				x[k] = v >> wasted;
 			}
 			if(fmt) {
@@ -245,7 +269,7 @@ __global__ __launch_bounds__(TPB) void prep2_kernel(const DevParams P, const int
 bool prep2_applicable(const DevParams &P)
 {
 	const uint32_t nraw = (P.channels == 2 && P.ms_mode != 0) ? 2u : (P.channels < 4 ? P.channels : 4u);
-	return P.blocksize % 16 == 0 && P.blocksize > 4 && (size_t)nraw * P.sig_bytes <= 150 * 1024;
+	return P.blocksize % 16 == 0 && P.blocksize > 4 && (size_t)nraw * p2_chan_bytes(P.blocksize) <= 150 * 1024;
 }
 
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s)
@@ -261,7 +285,7 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
 	const uint32_t waves = stereo_ms ? 4u : nraw;
-	const size_t lds = (size_t)nraw * P.sig_bytes;
+	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize);
 	if(P.bps > 20) hipLaunchKernelGGL(prep2_kernel<true>, dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
 	else hipLaunchKernelGGL(prep2_kernel<false>, dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
 	return hipGetLastError();
