@@ -453,6 +453,61 @@ __device__ __forceinline__ void fir_chunk_dispatch(const int32_t *sig, int base,
 __device__ __forceinline__ int fir_mode(bool wide, uint32_t sbps) { return wide ? 2 : (sbps <= 24 ? 0 : 1); }
 
 // ---------------------------------------------------------------------------------------------
+// integer FIR building blocks shared by the evaluation and pack kernels
+// ---------------------------------------------------------------------------------------------
+// VOP3P form with a separate destination (the compiler's v_dot2c accumulates in place and needs a v_mov per sample)
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, false);
+}
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c)       // |a - b| + c, a and b unsigned
+{
+	uint32_t d;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+__device__ __forceinline__ uint32_t mad24(int32_t a, int32_t b, uint32_t c)
+{
+	uint32_t d;
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+
+// NP dependent v_dot2_i32_i16 and the logical shift as ONE asm statement: between separate asm statements the
+// compiler pads every dependent pair with an s_nop, and its own v_dot2c form costs a v_mov per sample.
+template <int NP>
+__device__ __forceinline__ uint32_t dot2_chain_lshr(const uint32_t (&W)[NP], const uint32_t (&Q)[NP], int32_t sum0, uint32_t shift)
+{
+	uint32_t d;
+	if constexpr(NP == 1) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_lshrrev_b32 %0, %4, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(shift));
+	if constexpr(NP == 2) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_lshrrev_b32 %0, %6, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(shift));
+	if constexpr(NP == 3) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_lshrrev_b32 %0, %8, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(shift));
+	if constexpr(NP == 4) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_lshrrev_b32 %0, %10, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(shift));
+	if constexpr(NP == 5) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_lshrrev_b32 %0, %12, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(W[4]), "v"(Q[4]), "v"(shift));
+	if constexpr(NP == 6) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_lshrrev_b32 %0, %14, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(W[4]), "v"(Q[4]), "v"(W[5]), "v"(Q[5]), "v"(shift));
+	if constexpr(NP == 7) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_dot2_i32_i16 %0, %14, %15, %0\n\tv_lshrrev_b32 %0, %16, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(W[4]), "v"(Q[4]), "v"(W[5]), "v"(Q[5]), "v"(W[6]), "v"(Q[6]), "v"(shift));
+	if constexpr(NP == 8) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_dot2_i32_i16 %0, %14, %15, %0\n\tv_dot2_i32_i16 %0, %16, %17, %0\n\tv_lshrrev_b32 %0, %18, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "v"(Q[0]), "v"(W[1]), "v"(Q[1]), "v"(W[2]), "v"(Q[2]), "v"(W[3]), "v"(Q[3]), "v"(W[4]), "v"(Q[4]), "v"(W[5]), "v"(Q[5]), "v"(W[6]), "v"(Q[6]), "v"(W[7]), "v"(Q[7]), "v"(shift));
+	return d;
+}
+
+// the same for the 24-bit multiply-add chain on 32-bit samples: K taps per asm statement (30-operand limit), the
+// last one followed by the arithmetic shift and the sign flip that make the prediction an order-preserving unsigned
+template <int K, bool LAST>
+__device__ __forceinline__ uint32_t mad24_chain(const int32_t *xr /* xr[-j] is the sample tap j reads */, const int32_t *q, uint32_t sum, uint32_t shift)
+{
+	uint32_t d;
+	if constexpr(K == 4 && !LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]));
+	if constexpr(K == 4 && LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_ashrrev_i32 %0, %10, %0\n\tv_xor_b32 %0, 0x80000000, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(shift));
+	if constexpr(K == 8 && !LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_mad_i32_i24 %0, %10, %11, %0\n\tv_mad_i32_i24 %0, %12, %13, %0\n\tv_mad_i32_i24 %0, %14, %15, %0\n\tv_mad_i32_i24 %0, %16, %17, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(q[4]), "v"(xr[-4]), "v"(q[5]), "v"(xr[-5]), "v"(q[6]), "v"(xr[-6]), "v"(q[7]), "v"(xr[-7]));
+	if constexpr(K == 8 && LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_mad_i32_i24 %0, %10, %11, %0\n\tv_mad_i32_i24 %0, %12, %13, %0\n\tv_mad_i32_i24 %0, %14, %15, %0\n\tv_mad_i32_i24 %0, %16, %17, %0\n\tv_ashrrev_i32 %0, %18, %0\n\tv_xor_b32 %0, 0x80000000, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(q[4]), "v"(xr[-4]), "v"(q[5]), "v"(xr[-5]), "v"(q[6]), "v"(xr[-6]), "v"(q[7]), "v"(xr[-7]), "v"(shift));
+	if constexpr(K == 12 && !LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_mad_i32_i24 %0, %10, %11, %0\n\tv_mad_i32_i24 %0, %12, %13, %0\n\tv_mad_i32_i24 %0, %14, %15, %0\n\tv_mad_i32_i24 %0, %16, %17, %0\n\tv_mad_i32_i24 %0, %18, %19, %0\n\tv_mad_i32_i24 %0, %20, %21, %0\n\tv_mad_i32_i24 %0, %22, %23, %0\n\tv_mad_i32_i24 %0, %24, %25, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(q[4]), "v"(xr[-4]), "v"(q[5]), "v"(xr[-5]), "v"(q[6]), "v"(xr[-6]), "v"(q[7]), "v"(xr[-7]), "v"(q[8]), "v"(xr[-8]), "v"(q[9]), "v"(xr[-9]), "v"(q[10]), "v"(xr[-10]), "v"(q[11]), "v"(xr[-11]));
+	if constexpr(K == 12 && LAST) asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\tv_mad_i32_i24 %0, %10, %11, %0\n\tv_mad_i32_i24 %0, %12, %13, %0\n\tv_mad_i32_i24 %0, %14, %15, %0\n\tv_mad_i32_i24 %0, %16, %17, %0\n\tv_mad_i32_i24 %0, %18, %19, %0\n\tv_mad_i32_i24 %0, %20, %21, %0\n\tv_mad_i32_i24 %0, %22, %23, %0\n\tv_mad_i32_i24 %0, %24, %25, %0\n\tv_ashrrev_i32 %0, %26, %0\n\tv_xor_b32 %0, 0x80000000, %0" : "=&v"(d) : "v"(sum), "v"(q[0]), "v"(xr[-0]), "v"(q[1]), "v"(xr[-1]), "v"(q[2]), "v"(xr[-2]), "v"(q[3]), "v"(xr[-3]), "v"(q[4]), "v"(xr[-4]), "v"(q[5]), "v"(xr[-5]), "v"(q[6]), "v"(xr[-6]), "v"(q[7]), "v"(xr[-7]), "v"(q[8]), "v"(xr[-8]), "v"(q[9]), "v"(xr[-9]), "v"(q[10]), "v"(xr[-10]), "v"(q[11]), "v"(xr[-11]), "v"(shift));
+	return d;
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // analyze_kernel
 // ---------------------------------------------------------------------------------------------
 // fixed-size part of the workgroup's LDS state; the large arrays are carved dynamically (analyze_layout)

@@ -81,6 +81,101 @@ __device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
 	return r;
 }
 
+// frame header bytes including the CRC-8 (stream_encoder_framing.c:245-391, bitwriter.c:832); returns their number
+__device__ uint32_t frame_header_bytes(const DevParams &P, uint32_t n, uint32_t ca, uint32_t frame_number, uint8_t (&hb)[16])
+{
+	const uint32_t C = P.channels;
+	uint32_t nb = 0;
+	uint32_t bs_code, bs_hint = 0, sr_code, sr_hint = 0;
+	switch(n) {
+		case 192: bs_code = 1; break; case 576: bs_code = 2; break; case 1152: bs_code = 3; break;
+		case 2304: bs_code = 4; break; case 4608: bs_code = 5; break; case 256: bs_code = 8; break;
+		case 512: bs_code = 9; break; case 1024: bs_code = 10; break; case 2048: bs_code = 11; break;
+		case 4096: bs_code = 12; break; case 8192: bs_code = 13; break; case 16384: bs_code = 14; break;
+		case 32768: bs_code = 15; break;
+		default: bs_hint = bs_code = (n <= 0x100) ? 6 : 7; break;
+	}
+	const uint32_t sr = P.sample_rate;
+	switch(sr) {
+		case 88200: sr_code = 1; break; case 176400: sr_code = 2; break; case 192000: sr_code = 3; break;
+		case 8000: sr_code = 4; break; case 16000: sr_code = 5; break; case 22050: sr_code = 6; break;
+		case 24000: sr_code = 7; break; case 32000: sr_code = 8; break; case 44100: sr_code = 9; break;
+		case 48000: sr_code = 10; break; case 96000: sr_code = 11; break;
+		default:
+			if(sr <= 255000 && sr % 1000 == 0) sr_hint = sr_code = 12;
+			else if(sr <= 655350 && sr % 10 == 0) sr_hint = sr_code = 14;
+			else if(sr <= 0xffff) sr_hint = sr_code = 13;
+			else sr_code = 0;
+			break;
+	}
+	uint32_t bps_code;
+	switch(P.bps) {
+		case 8: bps_code = 1; break; case 12: bps_code = 2; break; case 16: bps_code = 4; break;
+		case 20: bps_code = 5; break; case 24: bps_code = 6; break; case 32: bps_code = 7; break;
+		default: bps_code = 0; break;
+	}
+	hb[nb++] = 0xff; hb[nb++] = 0xf8;
+	hb[nb++] = (uint8_t)((bs_code << 4) | sr_code);
+	hb[nb++] = (uint8_t)(((ca == 0 ? C - 1 : 7 + ca) << 4) | (bps_code << 1));
+	{
+		const uint32_t v = frame_number;   // bitwriter.c:832
+		if(v < 0x80) hb[nb++] = (uint8_t)v;
+		else if(v < 0x800) { hb[nb++] = (uint8_t)(0xC0 | (v >> 6)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+		else if(v < 0x10000) { hb[nb++] = (uint8_t)(0xE0 | (v >> 12)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+		else if(v < 0x200000) { hb[nb++] = (uint8_t)(0xF0 | (v >> 18)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+		else if(v < 0x4000000) { hb[nb++] = (uint8_t)(0xF8 | (v >> 24)); hb[nb++] = (uint8_t)(0x80 | ((v >> 18) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+		else { hb[nb++] = (uint8_t)(0xFC | (v >> 30)); hb[nb++] = (uint8_t)(0x80 | ((v >> 24) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 18) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+	}
+	if(bs_hint == 6) hb[nb++] = (uint8_t)(n - 1);
+	else if(bs_hint == 7) { hb[nb++] = (uint8_t)((n - 1) >> 8); hb[nb++] = (uint8_t)(n - 1); }
+	if(sr_hint == 12) hb[nb++] = (uint8_t)(sr / 1000);
+	else if(sr_hint == 13) { hb[nb++] = (uint8_t)(sr >> 8); hb[nb++] = (uint8_t)sr; }
+	else if(sr_hint == 14) { hb[nb++] = (uint8_t)((sr / 10) >> 8); hb[nb++] = (uint8_t)(sr / 10); }
+	uint32_t crc = 0;
+	for(uint32_t k = 0; k < nb; k++) {
+		crc ^= hb[k];
+		for(int b = 0; b < 8; b++) crc = (crc & 0x80u) ? ((crc << 1) ^ 0x07u) & 0xffu : (crc << 1) & 0xffu;
+	}
+	hb[nb++] = (uint8_t)crc;
+	return nb;
+}
+
+// CRC-16 of the first body_bytes of the frame image (see above); result valid in thread 0.  Ends with a barrier.
+__device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const uint16_t (*crc_tab)[256], uint32_t *crc_parts, int tid)
+{
+	// spans of 64 bytes; the last (possibly short) span is followed by nothing, span s by nsp-1-s whole or short spans
+	const uint32_t nsp = (body_bytes + CRC_SPAN - 1) / CRC_SPAN;
+	const uint32_t last_len = body_bytes - (nsp ? nsp - 1 : 0) * CRC_SPAN;                 // 1..64 bytes
+	uint32_t c = 0;
+	for(uint32_t sp = (uint32_t)tid; sp < nsp; sp += TPB) {
+		const uint32_t *wp = img + sp * (CRC_SPAN / 4);
+		uint32_t cs = 0;
+		if(sp + 1 < nsp) {
+#pragma unroll
+			for(int k = 0; k < (int)(CRC_SPAN / 4); k++) {
+				const uint32_t v = (cs << 16) ^ wp[k];
+				cs = (uint32_t)crc_tab[3][v >> 24] ^ crc_tab[2][(v >> 16) & 0xffu] ^ crc_tab[1][(v >> 8) & 0xffu] ^ crc_tab[0][v & 0xffu];
+			}
+			// behind this span: nsp-2-sp whole spans and the last one
+			cs = gf16_mul(gf16_mul(cs, g_crc_tables.xspan[nsp - 2 - sp]), g_crc_tables.xbyte[last_len]);
+		}
+		else {
+			for(uint32_t k = 0; k < last_len; k++) {
+				const uint32_t b = (wp[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu;
+				cs = ((cs << 8) & 0xffffu) ^ crc_tab[0][(cs >> 8) ^ b];
+			}
+		}
+		c ^= cs;
+	}
+#pragma unroll
+	for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
+	if((tid & 63) == 0) crc_parts[tid >> 6] = c;
+	__syncthreads();
+	uint32_t crc = 0;
+	for(int w = 0; w < TPB / 64; w++) crc ^= crc_parts[w];
+	return crc;
+}
+
 struct PackShared {
 	uint64_t scratch[8];
 	uint8_t params[1u << MAX_PO];
@@ -94,7 +189,7 @@ struct PackShared {
 
 template <int MAXORD>
 __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int32_t *__restrict__ chan,
-                                                   uint32_t nframes, uint32_t tail_n, uint64_t first_frame_number,
+                                                   uint32_t nframes, uint32_t tail_n, uint32_t f_lo, uint64_t first_frame_number,
                                                    const SubDecision *__restrict__ decisions,
                                                    uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
                                                    FrameInfo *__restrict__ info)
@@ -102,7 +197,7 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = (int)threadIdx.x;
 	const uint32_t C = P.channels, N = P.blocksize;
-	const uint32_t f = blockIdx.x;
+	const uint32_t f = f_lo + blockIdx.x;                  // frames [f_lo, nframes)
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const uint32_t n = is_tail ? tail_n : N;
 	const SubDecision *dec = decisions + (size_t)f * P.ncand;
@@ -138,58 +233,7 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	// ---- frame header (stream_encoder_framing.c:245-391), one lane -------------------------------
 	if(tid == 0) {
 		uint8_t hb[16];
-		uint32_t nb = 0;
-		uint32_t bs_code, bs_hint = 0, sr_code, sr_hint = 0;
-		switch(n) {
-			case 192: bs_code = 1; break; case 576: bs_code = 2; break; case 1152: bs_code = 3; break;
-			case 2304: bs_code = 4; break; case 4608: bs_code = 5; break; case 256: bs_code = 8; break;
-			case 512: bs_code = 9; break; case 1024: bs_code = 10; break; case 2048: bs_code = 11; break;
-			case 4096: bs_code = 12; break; case 8192: bs_code = 13; break; case 16384: bs_code = 14; break;
-			case 32768: bs_code = 15; break;
-			default: bs_hint = bs_code = (n <= 0x100) ? 6 : 7; break;
-		}
-		const uint32_t sr = P.sample_rate;
-		switch(sr) {
-			case 88200: sr_code = 1; break; case 176400: sr_code = 2; break; case 192000: sr_code = 3; break;
-			case 8000: sr_code = 4; break; case 16000: sr_code = 5; break; case 22050: sr_code = 6; break;
-			case 24000: sr_code = 7; break; case 32000: sr_code = 8; break; case 44100: sr_code = 9; break;
-			case 48000: sr_code = 10; break; case 96000: sr_code = 11; break;
-			default:
-				if(sr <= 255000 && sr % 1000 == 0) sr_hint = sr_code = 12;
-				else if(sr <= 655350 && sr % 10 == 0) sr_hint = sr_code = 14;
-				else if(sr <= 0xffff) sr_hint = sr_code = 13;
-				else sr_code = 0;
-				break;
-		}
-		uint32_t bps_code;
-		switch(P.bps) {
-			case 8: bps_code = 1; break; case 12: bps_code = 2; break; case 16: bps_code = 4; break;
-			case 20: bps_code = 5; break; case 24: bps_code = 6; break; case 32: bps_code = 7; break;
-			default: bps_code = 0; break;
-		}
-		hb[nb++] = 0xff; hb[nb++] = 0xf8;
-		hb[nb++] = (uint8_t)((bs_code << 4) | sr_code);
-		hb[nb++] = (uint8_t)(((ca == 0 ? C - 1 : 7 + ca) << 4) | (bps_code << 1));
-		{
-			const uint32_t v = (uint32_t)(first_frame_number + f);   // bitwriter.c:832
-			if(v < 0x80) hb[nb++] = (uint8_t)v;
-			else if(v < 0x800) { hb[nb++] = (uint8_t)(0xC0 | (v >> 6)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
-			else if(v < 0x10000) { hb[nb++] = (uint8_t)(0xE0 | (v >> 12)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
-			else if(v < 0x200000) { hb[nb++] = (uint8_t)(0xF0 | (v >> 18)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
-			else if(v < 0x4000000) { hb[nb++] = (uint8_t)(0xF8 | (v >> 24)); hb[nb++] = (uint8_t)(0x80 | ((v >> 18) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
-			else { hb[nb++] = (uint8_t)(0xFC | (v >> 30)); hb[nb++] = (uint8_t)(0x80 | ((v >> 24) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 18) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
-		}
-		if(bs_hint == 6) hb[nb++] = (uint8_t)(n - 1);
-		else if(bs_hint == 7) { hb[nb++] = (uint8_t)((n - 1) >> 8); hb[nb++] = (uint8_t)(n - 1); }
-		if(sr_hint == 12) hb[nb++] = (uint8_t)(sr / 1000);
-		else if(sr_hint == 13) { hb[nb++] = (uint8_t)(sr >> 8); hb[nb++] = (uint8_t)sr; }
-		else if(sr_hint == 14) { hb[nb++] = (uint8_t)((sr / 10) >> 8); hb[nb++] = (uint8_t)(sr / 10); }
-		uint32_t crc = 0;
-		for(uint32_t k = 0; k < nb; k++) {
-			crc ^= hb[k];
-			for(int b = 0; b < 8; b++) crc = (crc & 0x80u) ? ((crc << 1) ^ 0x07u) & 0xffu : (crc << 1) & 0xffu;
-		}
-		hb[nb++] = (uint8_t)crc;
+		const uint32_t nb = frame_header_bytes(P, n, ca, (uint32_t)(first_frame_number + f), hb);
 		for(uint32_t k = 0; k < nb; k++) put_bits(img, cap_words, 8 * k, hb[k], 8);
 		sh->bitpos = 8 * nb;
 	}
@@ -358,40 +402,8 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	if(total_bytes > P.slot_bytes) { if(tid == 0) { sh->overflow = 1; } }
 	__syncthreads();
 	{
-		// spans of 64 bytes; the last (possibly short) span is followed by nothing, span s by nsp-1-s whole or short spans
-		const uint32_t nsp = (body_bytes + CRC_SPAN - 1) / CRC_SPAN;
-		const uint32_t last_len = body_bytes - (nsp - 1) * CRC_SPAN;                 // 1..64 bytes
-		uint32_t c = 0;
-		for(uint32_t sp = (uint32_t)tid; sp < nsp; sp += TPB) {
-			const uint32_t *wp = img + sp * (CRC_SPAN / 4);
-			uint32_t cs = 0;
-			if(sp + 1 < nsp) {
-#pragma unroll
-				for(int k = 0; k < (int)(CRC_SPAN / 4); k++) {
-					const uint32_t v = (cs << 16) ^ wp[k];
-					cs = (uint32_t)sh->crc_tab[3][v >> 24] ^ sh->crc_tab[2][(v >> 16) & 0xffu] ^ sh->crc_tab[1][(v >> 8) & 0xffu] ^ sh->crc_tab[0][v & 0xffu];
-				}
-				// behind this span: nsp-2-sp whole spans and the last one
-				cs = gf16_mul(gf16_mul(cs, g_crc_tables.xspan[nsp - 2 - sp]), g_crc_tables.xbyte[last_len]);
-			}
-			else {
-				for(uint32_t k = 0; k < last_len; k++) {
-					const uint32_t b = (wp[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu;
-					cs = ((cs << 8) & 0xffffu) ^ sh->crc_tab[0][(cs >> 8) ^ b];
-				}
-			}
-			c ^= cs;
-		}
-		// xor-reduce
-#pragma unroll
-		for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
-		if((tid & 63) == 0) sh->crc_parts[tid >> 6] = c;
-		__syncthreads();
-		if(tid == 0) {
-			uint32_t crc = 0;
-			for(int w = 0; w < TPB / 64; w++) crc ^= sh->crc_parts[w];
-			put_bits(img, cap_words, body_bytes * 8, crc, 16);
-		}
+		const uint32_t crc = frame_crc16(img, body_bytes, sh->crc_tab, sh->crc_parts, tid);
+		if(tid == 0) put_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
 	}
 	// ---- store: image words are big-endian views, slots are byte arrays ---------------------------
@@ -401,6 +413,357 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 		for(uint32_t w = (uint32_t)tid; w < words; w += TPB) dst[w] = __builtin_bswap32(img[w]);
 		if(tid == 0) {
 			frame_bytes[f] = sh->overflow ? 0xffffffffu : total_bytes;
+			if(info) info[f].channel_assignment = (uint8_t)ca;
+		}
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// pack2_kernel: frames of nominal length whose partitions are whole 16-sample runs
+// ---------------------------------------------------------------------------------------------
+// One workgroup per frame; thread t owns samples [16t, 16t+16) of every subframe (per 4096-sample pass).  It loads its
+// window of the planar channel straight from global memory (32 bytes of packed history + 32 bytes of its own samples:
+// no LDS staging, no barrier), recomputes the winning residual with the same dot2 / mad24 chains as the evaluation
+// kernel, sizes its 16 Rice codes, takes its bit offset from a DPP wavefront scan plus one LDS hop, and ORs the codes
+// into the zeroed LDS frame image.  Only the non-zero part of a code is written (stop bit + low bits): the unary zeros
+// are already there.
+__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v)
+{
+	uint32_t d;
+	asm("s_nop 1\n\t"
+	    "v_add_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+	    "v_add_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+	    "v_add_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+	    "s_nop 1\n\t"
+	    "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+	    "s_nop 1\n\t"
+	    "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+	    "s_nop 1\n\t"
+	    "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+	    : "=&v"(d) : "v"(v));
+	return d;
+}
+// OR `len` bits (1..32) of v into the image at bit `pos`; positions past the image go to two dump words behind it
+__device__ __forceinline__ void or_bits(uint32_t *buf, uint32_t cap_words, uint32_t pos, uint32_t v, uint32_t len)
+{
+	const uint32_t w = umin32(pos >> 5, cap_words), o = pos & 31;
+	const uint64_t t = ((uint64_t)(v << (32 - len)) << 32) >> o;
+	atomicOr(&buf[w], (uint32_t)(t >> 32));
+	atomicOr(&buf[w + 1], (uint32_t)t);
+}
+
+struct Pack2Shared {
+	uint32_t wtot[2][TPB / 64];
+	uint8_t params[1u << MAX_PO];
+	uint32_t ca, left, right, hdr_bits;
+	uint32_t crc_parts[TPB / 64];
+	uint16_t crc_tab[4][256];
+};
+
+// residuals of this thread's 16 samples from the packed window A[0..15] (A[0..7] = the 16 samples in front)
+template <int NP>
+__device__ __forceinline__ void pack_fir_packed(const uint32_t (&A)[16], const int32_t *q, uint32_t shift, int32_t (&r)[CHUNK])
+{
+	uint32_t Q[NP], B[15];
+#pragma unroll
+	for(int p = 0; p < NP; p++) Q[p] = ((uint32_t)q[2 * p] << 16) | ((uint32_t)q[2 * p + 1] & 0xffffu);
+#pragma unroll
+	for(int m = 0; m < 15; m++) B[m] = __builtin_amdgcn_alignbit(A[m + 1], A[m], 16);
+	const uint32_t bias = 0x80000000u >> shift;
+	const int32_t sum0 = (int32_t)0x80000000;
+#pragma unroll
+	for(int s = 0; s < CHUNK; s++) {
+		const int u = 16 + s;
+		uint32_t W[NP];
+#pragma unroll
+		for(int p = 0; p < NP; p++) W[p] = (u & 1) ? B[(u - 3) / 2 - p] : A[(u - 2) / 2 - p];
+		const uint32_t pb = dot2_chain_lshr<NP>(W, Q, sum0, shift);                     // prediction + bias (see flacgpu_devfn.h)
+		const uint32_t xb = bias + (uint32_t)((u & 1) ? ((int32_t)A[u / 2] >> 16) : (int32_t)(int16_t)(A[u / 2] & 0xffffu));
+		r[s] = (int32_t)(xb - pb);
+	}
+}
+// the same from 32-bit samples x[0..31] (x[16+s] = own sample s): FMODE 0 v_mad_i32_i24, 1 32-bit multiplies (lpc.c:321),
+// 2 64-bit accumulate (lpc.c:582)
+template <int NT, int FMODE>
+__device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[32], const int32_t *qg, int shift, int32_t (&r)[CHUNK])
+{
+	int32_t q[NT];
+#pragma unroll
+	for(int j = 0; j < NT; j++) q[j] = qg[j];
+#pragma unroll
+	for(int s = 0; s < CHUNK; s++) {
+		if(FMODE == 0) {
+			uint32_t pb;
+			if(NT == 16) pb = mad24_chain<8, true>(&x[16 + s - 9], &q[8], mad24_chain<8, false>(&x[16 + s - 1], &q[0], 0, 0), (uint32_t)shift);
+			else pb = mad24_chain<NT == 16 ? 8 : NT, true>(&x[16 + s - 1], &q[0], 0, (uint32_t)shift);
+			r[s] = x[16 + s] - (int32_t)(pb ^ 0x80000000u);
+		}
+		else if(FMODE == 1) {
+			uint32_t sum = 0;
+#pragma unroll
+			for(int j = 0; j < NT; j++) sum += (uint32_t)q[j] * (uint32_t)x[16 + s - 1 - j];
+			r[s] = (int32_t)((uint32_t)x[16 + s] - (uint32_t)((int32_t)sum >> shift));
+		}
+		else {
+			int64_t sum = 0;
+#pragma unroll
+			for(int j = 0; j < NT; j++) sum += (int64_t)q[j] * (int64_t)x[16 + s - 1 - j];
+			r[s] = (int32_t)((int64_t)x[16 + s] - (sum >> shift));
+		}
+	}
+}
+
+template <int MAXORD>
+__global__ __launch_bounds__(TPB) void pack2_kernel(const DevParams P, const int32_t *__restrict__ chan,
+                                                    uint32_t nmain, uint64_t first_frame_number,
+                                                    const SubDecision *__restrict__ decisions,
+                                                    uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
+                                                    FrameInfo *__restrict__ info)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t C = P.channels, N = P.blocksize, n = N;
+	const uint32_t f = blockIdx.x;
+	const SubDecision *dec = decisions + (size_t)f * P.ncand;
+	uint32_t *img = (uint32_t *)smem;
+	const uint32_t cap_words = P.slot_bytes / 4;
+	Pack2Shared *sh = (Pack2Shared *)(smem + P.slot_bytes + 16);
+
+	for(uint32_t w = (uint32_t)tid; w < cap_words + 2; w += TPB) img[w] = 0;
+	for(uint32_t w = (uint32_t)tid; w < 4 * 256 / 2; w += TPB) ((uint32_t *)sh->crc_tab)[w] = ((const uint32_t *)g_crc_tables.tab)[w];
+	uint8_t hb[16];
+	uint32_t nb = 0;
+	if(tid == 0) {
+		// channel assignment (stream_encoder.c:3944-3972)
+		uint32_t ca = 0, left = 0, right = 1;
+		if(P.ms_mode == 1) {
+			const uint32_t b0 = dec[0].bits + dec[1].bits, b1 = dec[0].bits + dec[3].bits,
+			               b2 = dec[1].bits + dec[3].bits, b3 = dec[2].bits + dec[3].bits;
+			uint32_t mn = b0;
+			if(b1 < mn) { mn = b1; ca = 1; }
+			if(b2 < mn) { mn = b2; ca = 2; }
+			if(b3 < mn) { mn = b3; ca = 3; }
+			left = ca == 2 ? 3 : ca == 3 ? 2 : 0;
+			right = ca == 0 ? 1 : ca == 2 ? 1 : 3;
+		}
+		else if(P.ms_mode == 2) ca = dec[0].which >= 2 ? 3 : 0;
+		sh->ca = ca; sh->left = left; sh->right = right;
+		nb = frame_header_bytes(P, n, ca, (uint32_t)(first_frame_number + f), hb);
+		sh->hdr_bits = 8 * nb;
+	}
+	__syncthreads();
+	const uint32_t ca = sh->ca;
+	if(tid == 0) for(uint32_t k = 0; k < nb; k++) or_bits(img, cap_words, 8 * k, hb[k], 8);
+	uint32_t pos = sh->hdr_bits;
+	uint32_t scan_buf = 0;
+
+	// ---- subframes (stream_encoder_framing.c:393-594) -------------------------------------------
+	for(uint32_t s = 0; s < C; s++) {
+		const uint32_t di = P.ms_mode == 1 ? (s == 0 ? sh->left : sh->right) : s;
+		const SubDecision *d = dec + di;
+		const uint32_t which = d->which, type = d->type, order = d->order, wasted = d->wasted;
+		const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
+		const bool fmt16 = sbps <= 16;
+		const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + di) * N);
+		const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : type == 2 ? (0x10u | (order << 1)) : (0x40u | ((order - 1) << 1));
+		if(tid == 0) {
+			or_bits(img, cap_words, pos, type_bits | (wasted ? 1u : 0u), 8);
+			if(wasted) or_bits(img, cap_words, pos + 8 + (wasted - 1), 1, 1);
+		}
+		pos += 8 + wasted;
+		const uint32_t smask = sbps >= 32 ? 0xffffffffu : (1u << sbps) - 1u;
+		if(type == 0) {
+			if(tid == 0) or_bits(img, cap_words, pos, (uint32_t)d->constant & smask, sbps);
+			pos += sbps;
+		}
+		else if(type == 1) {
+			for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * TPB) {
+				int32_t x[CHUNK];
+				if(fmt16) {
+					const uint4 a = ((const uint4 *)src)[base / 8], b = ((const uint4 *)src)[base / 8 + 1];
+					const uint32_t wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+					for(int k = 0; k < CHUNK; k++) x[k] = (k & 1) ? ((int32_t)wv[k >> 1] >> 16) : (int32_t)(int16_t)(wv[k >> 1] & 0xffffu);
+				}
+				else {
+#pragma unroll
+					for(int k = 0; k < 4; k++) { const uint4 a = ((const uint4 *)src)[base / 4 + k]; x[4 * k] = (int32_t)a.x; x[4 * k + 1] = (int32_t)a.y; x[4 * k + 2] = (int32_t)a.z; x[4 * k + 3] = (int32_t)a.w; }
+				}
+#pragma unroll
+				for(int k = 0; k < CHUNK; k++) or_bits(img, cap_words, pos + (base + (uint32_t)k) * sbps, (uint32_t)x[k] & smask, sbps);
+			}
+			pos += n * sbps;
+		}
+		else {
+			const uint32_t warm_pos = pos;
+			pos += order * sbps;
+			const int shift = type == 3 ? d->shift : 0;
+			bool wide = false;
+			if(type == 3) {
+				const uint32_t precision = d->precision;
+				if(tid == 0) {
+					or_bits(img, cap_words, pos, precision - 1, 4);
+					or_bits(img, cap_words, pos + 4, (uint32_t)shift & 31u, 5);
+				}
+				if((uint32_t)tid < order) or_bits(img, cap_words, pos + 9 + (uint32_t)tid * precision, (uint32_t)d->q[tid] & ((1u << precision) - 1u), precision);
+				pos += 9 + order * precision;
+				uint32_t abs_sum = 0;
+				for(uint32_t i = 0; i < order; i++) abs_sum += (uint32_t)abs(d->q[i]);
+				wide = silog2_i64((int64_t)(((uint64_t)1 << (sbps - 1)) * abs_sum)) > 32;
+			}
+			const uint32_t po = d->po, plen = d->rice2 ? 5u : 4u;
+			if(tid == 0) {
+				or_bits(img, cap_words, pos, d->rice2 ? 1u : 0u, 2);
+				or_bits(img, cap_words, pos + 2, po, 4);
+			}
+			pos += 6;
+			// taps (fixed.c:470: the fixed predictors are FIRs with binomial taps and shift 0)
+			int32_t q[MAXORD];
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++) {
+				int32_t c = 0;
+				if(type == 3) c = j < MAX_ORDER ? d->q[j] : 0;
+				else if(order == 1) c = j == 0 ? 1 : 0;
+				else if(order == 2) c = j == 0 ? 2 : j == 1 ? -1 : 0;
+				else if(order == 3) c = j == 0 ? 3 : j == 1 ? -3 : j == 2 ? 1 : 0;
+				else if(order == 4) c = j == 0 ? 4 : j == 1 ? -6 : j == 2 ? 4 : j == 3 ? -1 : 0;
+				q[j] = c;
+			}
+			const uint32_t psize = n >> po;
+			__syncthreads();                       // the previous subframe's readers of params are done
+			for(uint32_t p = (uint32_t)tid; p < (1u << po); p += TPB) sh->params[p] = d->params[p];
+			__syncthreads();
+			const int fmode = fir_mode(wide, sbps);
+			for(uint32_t base0 = 0; base0 < n; base0 += CHUNK * TPB) {
+				const uint32_t base = base0 + CHUNK * (uint32_t)tid;
+				const bool active = base < n;
+				int32_t r[CHUNK];
+				uint32_t mybits = 0, k = 0;
+				bool starts = false;
+				if(active) {
+					if(fmt16) {
+						// window words: A[0..7] = samples base-16..base-1, A[8..15] = own
+						uint32_t A[16];
+						{
+							const uint4 c0 = ((const uint4 *)src)[base / 8], c1 = ((const uint4 *)src)[base / 8 + 1];
+							A[8] = c0.x; A[9] = c0.y; A[10] = c0.z; A[11] = c0.w; A[12] = c1.x; A[13] = c1.y; A[14] = c1.z; A[15] = c1.w;
+							uint4 h0 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);
+							if(base) { h0 = ((const uint4 *)src)[base / 8 - 2]; h1 = ((const uint4 *)src)[base / 8 - 1]; }
+							A[0] = h0.x; A[1] = h0.y; A[2] = h0.z; A[3] = h0.w; A[4] = h1.x; A[5] = h1.y; A[6] = h1.z; A[7] = h1.w;
+						}
+						if(base == 0 && order) {
+							// warm-up samples, verbatim (thread 0 of pass 0 holds them)
+							for(uint32_t i = 0; i < order; i++) {
+								const uint32_t wv = A[8 + i / 2];
+								or_bits(img, cap_words, warm_pos + i * sbps, ((i & 1) ? (wv >> 16) : wv) & smask, sbps);
+							}
+						}
+						if(!wide) {
+							const uint32_t np = (order + 1) / 2;
+							if(MAXORD >= 16 && np > 6) pack_fir_packed<MAXORD >= 16 ? 8 : 2>(A, q, (uint32_t)shift, r);
+							else if(MAXORD >= 12 && np > 4) pack_fir_packed<MAXORD >= 12 ? 6 : 2>(A, q, (uint32_t)shift, r);
+							else if(np > 2) pack_fir_packed<4>(A, q, (uint32_t)shift, r);
+							else pack_fir_packed<2>(A, q, (uint32_t)shift, r);
+						}
+						else {
+							int32_t x[32];
+#pragma unroll
+							for(int kk = 0; kk < 32; kk++) x[kk] = (kk & 1) ? ((int32_t)A[kk >> 1] >> 16) : (int32_t)(int16_t)(A[kk >> 1] & 0xffffu);
+							pack_fir_i32<MAXORD, 2>(x, q, shift, r);
+						}
+					}
+					else {
+						int32_t x[32];
+#pragma unroll
+						for(int kk = 0; kk < 4; kk++) {
+							uint4 a = make_uint4(0, 0, 0, 0);
+							if(base) a = ((const uint4 *)src)[base / 4 - 4 + kk];
+							x[4 * kk] = (int32_t)a.x; x[4 * kk + 1] = (int32_t)a.y; x[4 * kk + 2] = (int32_t)a.z; x[4 * kk + 3] = (int32_t)a.w;
+						}
+#pragma unroll
+						for(int kk = 0; kk < 4; kk++) {
+							const uint4 a = ((const uint4 *)src)[base / 4 + kk];
+							x[16 + 4 * kk] = (int32_t)a.x; x[16 + 4 * kk + 1] = (int32_t)a.y; x[16 + 4 * kk + 2] = (int32_t)a.z; x[16 + 4 * kk + 3] = (int32_t)a.w;
+						}
+						if(base == 0 && order) for(uint32_t i = 0; i < order; i++) {
+							uint32_t v = 0;
+#pragma unroll
+							for(int kk = 0; kk < CHUNK; kk++) if((uint32_t)kk == i) v = (uint32_t)x[16 + kk];
+							or_bits(img, cap_words, warm_pos + i * sbps, v & smask, sbps);
+						}
+						if(fmode == 0) {
+							if(MAXORD >= 16 && order > 12) pack_fir_i32<MAXORD >= 16 ? 16 : 4, 0>(x, q, shift, r);
+							else if(MAXORD >= 12 && order > 8) pack_fir_i32<MAXORD >= 12 ? 12 : 4, 0>(x, q, shift, r);
+							else if(order > 4) pack_fir_i32<8, 0>(x, q, shift, r);
+							else pack_fir_i32<4, 0>(x, q, shift, r);
+						}
+						else if(fmode == 1) pack_fir_i32<MAXORD, 1>(x, q, shift, r);
+						else pack_fir_i32<MAXORD, 2>(x, q, shift, r);
+					}
+					// Rice code sizes: the whole run lies in one partition (partition sizes are multiples of 16)
+					const uint32_t part = base / psize;
+					k = sh->params[part];
+					starts = base == part * psize;
+					if(starts) mybits = plen;
+#pragma unroll
+					for(int t = 0; t < CHUNK; t++) {
+						const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
+						const uint32_t cb = (u >> k) + 1 + k;
+						mybits += (base == 0 && (uint32_t)t < order) ? 0u : cb;
+					}
+				}
+				// bit offset of this thread: wavefront scan + wavefront totals through LDS
+				const uint32_t incl = wave_scan_incl_dpp(mybits);
+				if(lane == 63) sh->wtot[scan_buf][wave] = incl;
+				__syncthreads();
+				uint32_t woff = 0, total = 0;
+#pragma unroll
+				for(int w = 0; w < TPB / 64; w++) { const uint32_t tw = sh->wtot[scan_buf][w]; if(w < wave) woff += tw; total += tw; }
+				scan_buf ^= 1;
+				if(active) {
+					uint32_t p = pos + woff + incl - mybits;
+					if(starts) { or_bits(img, cap_words, p, k, plen); p += plen; }
+#pragma unroll
+					for(int t = 0; t < CHUNK; t++) {
+						if(!(base == 0 && (uint32_t)t < order)) {
+							const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
+							const uint32_t msbs = u >> k;
+							or_bits(img, cap_words, p + msbs, (1u << k) | (u & ((1u << k) - 1u)), k + 1);
+							p += msbs + 1 + k;
+						}
+					}
+				}
+				pos += total;
+			}
+		}
+		if(tid == 0 && info) {
+			flacgpu_subframe_info *si = &info[f].sub[s];
+			si->type = (uint8_t)type; si->order = (uint8_t)order; si->wasted_bits = (uint8_t)wasted;
+			si->partition_order = d->po; si->rice2 = d->rice2; si->precision = d->precision; si->shift = d->shift;
+			si->pad = 0; si->bits = d->bits;
+		}
+	}
+	__syncthreads();
+
+	// ---- zero-pad to a byte, CRC-16 over the whole frame, footer (stream_encoder.c:3720-3734) --------
+	const uint32_t body_bytes = (pos + 7) >> 3;
+	const uint32_t total_bytes = body_bytes + 2;
+	const bool overflow = total_bytes > P.slot_bytes;
+	{
+		const uint32_t crc = frame_crc16(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, tid);
+		if(tid == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
+		__syncthreads();
+	}
+	// ---- store: image words are big-endian views, slots are byte arrays ---------------------------
+	{
+		uint32_t *dst = (uint32_t *)(slots + (size_t)f * P.slot_bytes);
+		const uint32_t words = (umin32(total_bytes, P.slot_bytes) + 3) >> 2;
+		for(uint32_t w = (uint32_t)tid; w < words; w += TPB) dst[w] = __builtin_bswap32(img[w]);
+		if(tid == 0) {
+			frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
 			if(info) info[f].channel_assignment = (uint8_t)ca;
 		}
 	}
@@ -474,6 +837,12 @@ __global__ __launch_bounds__(TPB) void compact_kernel(const uint8_t *__restrict_
 // ---------------------------------------------------------------------------------------------
 using namespace flacgpu;
 
+// pack2_kernel takes the frames of nominal length when every Rice partition is a whole number of 16-sample runs
+static bool pack2_applicable(const DevParams &P)
+{
+	const uint32_t ps = P.blocksize >> P.max_po;
+	return P.blocksize % CHUNK == 0 && ps >= (uint32_t)CHUNK && ps % CHUNK == 0 && ((size_t)ps << P.max_po) == P.blocksize;
+}
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                                 const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, size_t lds, hipStream_t s)
@@ -481,10 +850,17 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 	static bool attr_set = false;
 	if(!attr_set) {
 		hipError_t e = hipFuncSetAttribute((const void *)pack_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes), dim3(TPB), lds, s, P, chan, nframes, tail_n, first, dec, slots, fb, info);
+	uint32_t f_lo = 0;
+	if(pack2_applicable(P)) {
+		f_lo = tail_n ? nframes - 1 : nframes;
+		const size_t lds2 = (size_t)P.slot_bytes + 16 + sizeof(Pack2Shared);
+		if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info);
+	}
+	if(f_lo < nframes) hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes - f_lo), dim3(TPB), lds, s, P, chan, nframes, tail_n, f_lo, first, dec, slots, fb, info);
 	return hipGetLastError();
 }
 

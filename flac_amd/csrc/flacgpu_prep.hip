@@ -29,12 +29,6 @@ struct Prep2Acc {
 __host__ __device__ inline uint32_t p2_ts(uint32_t n) { const uint32_t nch = (n + CHUNK - 1) / CHUNK; return ((nch - 1 + 31) / 32) * 32 + 2; }
 __host__ __device__ inline uint32_t p2_chan_bytes(uint32_t n) { return CHUNK * p2_ts(n) * 4; }
 
-__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c)       // |a - b| + c, a and b unsigned
-{
-	uint32_t d;
-	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-	return d;
-}
 // statistics of the 16 samples x[4..19] of a chunk (x[0..3] = the four samples in front of them).
 // Sums are taken on the UNSHIFTED signal: every |difference| is a multiple of 2^wasted, so the sums of the shifted
 // signal the reference computes (it shifts in place first) are these sums >> wasted, exactly.
