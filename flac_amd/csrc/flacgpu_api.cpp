@@ -302,7 +302,20 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		(void)hipMemsetAsync(c->ab.dbg, 0, nwg * 16 * sizeof(unsigned long long), s);
 	}
 	(void)hipEventRecord(c->ev[1], s);
-	if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(c->ab.dbg) {
+		// development aid: wall cycles of the pack2 workgroups between their stamps
+		unsigned long long *h = (unsigned long long *)malloc((size_t)nframes * 16 * sizeof(unsigned long long));
+		if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, c->ab.dbg, (size_t)nframes * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+			double acc[13] = {0}; size_t cnt[13] = {0};
+			for(size_t w = 0; w < nframes; w++) { int prev = 0; for(int k = 1; k < 13; k++) if(h[w * 16 + k] && h[w * 16 + prev]) { acc[k] += (double)(h[w * 16 + k] - h[w * 16 + prev]); cnt[k]++; prev = k; } }
+			fprintf(stderr, "[flacgpu] pack2 stamps (avg ticks since previous stamp):");
+			for(int k = 1; k < 13; k++) fprintf(stderr, " %d:%.0f", k, cnt[k] ? acc[k] / cnt[k] : 0.0);
+			fprintf(stderr, "\n");
+		}
+		free(h);
+		(void)hipMemsetAsync(c->ab.dbg, 0, (size_t)nframes * P.ncand * 16 * sizeof(unsigned long long), s);
+	}
 	(void)hipEventRecord(c->ev[2], s);
 	if(launch_scan(c->d_frame_bytes, nframes, c->d_offsets, c->d_total, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	if(launch_compact(c->d_slots, P.slot_bytes, c->d_frame_bytes, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;

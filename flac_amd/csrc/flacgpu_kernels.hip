@@ -81,11 +81,22 @@ __device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
 	return r;
 }
 
-// frame header bytes including the CRC-8 (stream_encoder_framing.c:245-391, bitwriter.c:832); returns their number
-__device__ uint32_t frame_header_bytes(const DevParams &P, uint32_t n, uint32_t ca, uint32_t frame_number, uint8_t (&hb)[16])
+// frame header (stream_encoder_framing.c:245-391, bitwriter.c:832): every byte goes to sink(byte) as it is produced,
+// the CRC-8 (poly 0x07) runs along; returns the number of bytes including the CRC.  No byte array: a dynamically
+// indexed local array lives in scratch memory, and its round trips were the slowest part of the pack kernel.
+template <class SINK>
+__device__ __forceinline__ uint32_t frame_header_gen(const DevParams &P, uint32_t n, uint32_t ca, uint32_t frame_number, SINK sink)
 {
+	uint32_t nb = 0, crc = 0;
+	auto put = [&](uint32_t byte) {
+		byte &= 0xffu;
+		// crc = (crc ^ byte) * x^8 mod x^8+x^2+x+1: x^8 = x^2+x+1, applied twice (the first product has 10 bits)
+		const uint32_t v = crc ^ byte, w = v ^ (v << 1) ^ (v << 2), hi = w >> 8;
+		crc = (w ^ hi ^ (hi << 1) ^ (hi << 2)) & 0xffu;
+		sink(nb, byte);
+		nb++;
+	};
 	const uint32_t C = P.channels;
-	uint32_t nb = 0;
 	uint32_t bs_code, bs_hint = 0, sr_code, sr_hint = 0;
 	switch(n) {
 		case 192: bs_code = 1; break; case 576: bs_code = 2; break; case 1152: bs_code = 3; break;
@@ -114,34 +125,34 @@ __device__ uint32_t frame_header_bytes(const DevParams &P, uint32_t n, uint32_t 
 		case 20: bps_code = 5; break; case 24: bps_code = 6; break; case 32: bps_code = 7; break;
 		default: bps_code = 0; break;
 	}
-	hb[nb++] = 0xff; hb[nb++] = 0xf8;
-	hb[nb++] = (uint8_t)((bs_code << 4) | sr_code);
-	hb[nb++] = (uint8_t)(((ca == 0 ? C - 1 : 7 + ca) << 4) | (bps_code << 1));
+	put(0xff); put(0xf8);
+	put(((bs_code << 4) | sr_code));
+	put((((ca == 0 ? C - 1 : 7 + ca) << 4) | (bps_code << 1)));
 	{
 		const uint32_t v = frame_number;   // bitwriter.c:832
-		if(v < 0x80) hb[nb++] = (uint8_t)v;
-		else if(v < 0x800) { hb[nb++] = (uint8_t)(0xC0 | (v >> 6)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
-		else if(v < 0x10000) { hb[nb++] = (uint8_t)(0xE0 | (v >> 12)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
-		else if(v < 0x200000) { hb[nb++] = (uint8_t)(0xF0 | (v >> 18)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
-		else if(v < 0x4000000) { hb[nb++] = (uint8_t)(0xF8 | (v >> 24)); hb[nb++] = (uint8_t)(0x80 | ((v >> 18) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
-		else { hb[nb++] = (uint8_t)(0xFC | (v >> 30)); hb[nb++] = (uint8_t)(0x80 | ((v >> 24) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 18) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 12) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | ((v >> 6) & 0x3F)); hb[nb++] = (uint8_t)(0x80 | (v & 0x3F)); }
+		if(v < 0x80) put(v);
+		else if(v < 0x800) { put((0xC0 | (v >> 6))); put((0x80 | (v & 0x3F))); }
+		else if(v < 0x10000) { put((0xE0 | (v >> 12))); put((0x80 | ((v >> 6) & 0x3F))); put((0x80 | (v & 0x3F))); }
+		else if(v < 0x200000) { put((0xF0 | (v >> 18))); put((0x80 | ((v >> 12) & 0x3F))); put((0x80 | ((v >> 6) & 0x3F))); put((0x80 | (v & 0x3F))); }
+		else if(v < 0x4000000) { put((0xF8 | (v >> 24))); put((0x80 | ((v >> 18) & 0x3F))); put((0x80 | ((v >> 12) & 0x3F))); put((0x80 | ((v >> 6) & 0x3F))); put((0x80 | (v & 0x3F))); }
+		else { put((0xFC | (v >> 30))); put((0x80 | ((v >> 24) & 0x3F))); put((0x80 | ((v >> 18) & 0x3F))); put((0x80 | ((v >> 12) & 0x3F))); put((0x80 | ((v >> 6) & 0x3F))); put((0x80 | (v & 0x3F))); }
 	}
-	if(bs_hint == 6) hb[nb++] = (uint8_t)(n - 1);
-	else if(bs_hint == 7) { hb[nb++] = (uint8_t)((n - 1) >> 8); hb[nb++] = (uint8_t)(n - 1); }
-	if(sr_hint == 12) hb[nb++] = (uint8_t)(sr / 1000);
-	else if(sr_hint == 13) { hb[nb++] = (uint8_t)(sr >> 8); hb[nb++] = (uint8_t)sr; }
-	else if(sr_hint == 14) { hb[nb++] = (uint8_t)((sr / 10) >> 8); hb[nb++] = (uint8_t)(sr / 10); }
-	uint32_t crc = 0;
-	for(uint32_t k = 0; k < nb; k++) {
-		crc ^= hb[k];
-		for(int b = 0; b < 8; b++) crc = (crc & 0x80u) ? ((crc << 1) ^ 0x07u) & 0xffu : (crc << 1) & 0xffu;
-	}
-	hb[nb++] = (uint8_t)crc;
-	return nb;
+	if(bs_hint == 6) put((n - 1));
+	else if(bs_hint == 7) { put(((n - 1) >> 8)); put((n - 1)); }
+	if(sr_hint == 12) put((sr / 1000));
+	else if(sr_hint == 13) { put((sr >> 8)); put(sr); }
+	else if(sr_hint == 14) { put(((sr / 10) >> 8)); put((sr / 10)); }
+	sink(nb, crc);
+	return nb + 1;
+}
+__device__ uint32_t frame_header_bytes(const DevParams &P, uint32_t n, uint32_t ca, uint32_t frame_number, uint8_t (&hb)[16])
+{
+	return frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { hb[k] = (uint8_t)byte; });
 }
 
 // CRC-16 of the first body_bytes of the frame image (see above); result valid in thread 0.  Ends with a barrier.
-__device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const uint16_t (*crc_tab)[256], uint32_t *crc_parts, int tid)
+__device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const uint16_t (*crc_tab)[256], uint32_t *crc_parts, int tid,
+                                const uint16_t *xspan_lds = nullptr, uint32_t nxspan_lds = 0, const uint16_t *xbyte_lds = nullptr)
 {
 	// spans of 64 bytes; the last (possibly short) span is followed by nothing, span s by nsp-1-s whole or short spans
 	const uint32_t nsp = (body_bytes + CRC_SPAN - 1) / CRC_SPAN;
@@ -157,7 +168,9 @@ __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const 
 				cs = (uint32_t)crc_tab[3][v >> 24] ^ crc_tab[2][(v >> 16) & 0xffu] ^ crc_tab[1][(v >> 8) & 0xffu] ^ crc_tab[0][v & 0xffu];
 			}
 			// behind this span: nsp-2-sp whole spans and the last one
-			cs = gf16_mul(gf16_mul(cs, g_crc_tables.xspan[nsp - 2 - sp]), g_crc_tables.xbyte[last_len]);
+			const uint32_t m = nsp - 2 - sp;
+			const uint32_t xs = m < nxspan_lds ? xspan_lds[m] : g_crc_tables.xspan[m], xb = xbyte_lds ? xbyte_lds[last_len] : g_crc_tables.xbyte[last_len];
+			cs = gf16_mul(gf16_mul(cs, xs), xb);
 		}
 		else {
 			for(uint32_t k = 0; k < last_len; k++) {
@@ -174,6 +187,24 @@ __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const 
 	uint32_t crc = 0;
 	for(int w = 0; w < TPB / 64; w++) crc ^= crc_parts[w];
 	return crc;
+}
+
+// number of frame header bytes including the CRC-8, without building them (same cases as frame_header_bytes)
+__device__ __forceinline__ uint32_t frame_header_len(const DevParams &P, uint32_t n, uint32_t v)
+{
+	uint32_t nb = 4 + 1;
+	nb += v < 0x80 ? 1 : v < 0x800 ? 2 : v < 0x10000 ? 3 : v < 0x200000 ? 4 : v < 0x4000000 ? 5 : 6;
+	const bool bs_std = n == 192 || n == 576 || n == 1152 || n == 2304 || n == 4608 || (n >= 256 && n <= 32768 && (n & (n - 1)) == 0);
+	if(!bs_std) nb += n <= 0x100 ? 1 : 2;
+	const uint32_t sr = P.sample_rate;
+	const bool sr_std = sr == 88200 || sr == 176400 || sr == 192000 || sr == 8000 || sr == 16000 || sr == 22050 || sr == 24000 || sr == 32000 ||
+	                    sr == 44100 || sr == 48000 || sr == 96000;
+	if(!sr_std) {
+		if(sr <= 255000 && sr % 1000 == 0) nb += 1;
+		else if(sr <= 655350 && sr % 10 == 0) nb += 2;
+		else if(sr <= 0xffff) nb += 2;
+	}
+	return nb;
 }
 
 struct PackShared {
@@ -455,12 +486,14 @@ __device__ __forceinline__ void or_bits(uint32_t *buf, uint32_t cap_words, uint3
 	atomicOr(&buf[w + 1], (uint32_t)t);
 }
 
+constexpr uint32_t P2_XSPAN = 512;           // span shifts kept in LDS (frames up to 32 KiB; longer ones read the global table)
 struct Pack2Shared {
 	uint32_t wtot[2][TPB / 64];
-	uint8_t params[1u << MAX_PO];
-	uint32_t ca, left, right, hdr_bits;
 	uint32_t crc_parts[TPB / 64];
 	uint16_t crc_tab[4][256];
+	uint16_t xspan[P2_XSPAN];
+	uint16_t xbyte[CRC_SPAN + 2];
+	uint32_t dec[FLACGPU_MAX_CHANNELS * sizeof(SubDecision) / 4];      // this frame's decision records
 };
 
 // residuals of this thread's 16 samples from the packed window A[0..15] (A[0..7] = the 16 samples in front)
@@ -517,53 +550,63 @@ __device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[32], const int32
 }
 
 template <int MAXORD>
-__global__ __launch_bounds__(TPB) void pack2_kernel(const DevParams P, const int32_t *__restrict__ chan,
+#ifndef PACK2_WAVES
+#define PACK2_WAVES 4
+#endif
+__global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams P, const int32_t *__restrict__ chan,
                                                     uint32_t nmain, uint64_t first_frame_number,
                                                     const SubDecision *__restrict__ decisions,
                                                     uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
-                                                    FrameInfo *__restrict__ info)
+                                                    FrameInfo *__restrict__ info, unsigned long long *__restrict__ dbg)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t C = P.channels, N = P.blocksize, n = N;
 	const uint32_t f = blockIdx.x;
+#define PSTAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
+	PSTAMP(0);
 	const SubDecision *dec = decisions + (size_t)f * P.ncand;
 	uint32_t *img = (uint32_t *)smem;
 	const uint32_t cap_words = P.slot_bytes / 4;
 	Pack2Shared *sh = (Pack2Shared *)(smem + P.slot_bytes + 16);
 
-	for(uint32_t w = (uint32_t)tid; w < cap_words + 2; w += TPB) img[w] = 0;
-	for(uint32_t w = (uint32_t)tid; w < 4 * 256 / 2; w += TPB) ((uint32_t *)sh->crc_tab)[w] = ((const uint32_t *)g_crc_tables.tab)[w];
-	uint8_t hb[16];
-	uint32_t nb = 0;
-	if(tid == 0) {
-		// channel assignment (stream_encoder.c:3944-3972)
-		uint32_t ca = 0, left = 0, right = 1;
-		if(P.ms_mode == 1) {
-			const uint32_t b0 = dec[0].bits + dec[1].bits, b1 = dec[0].bits + dec[3].bits,
-			               b2 = dec[1].bits + dec[3].bits, b3 = dec[2].bits + dec[3].bits;
-			uint32_t mn = b0;
-			if(b1 < mn) { mn = b1; ca = 1; }
-			if(b2 < mn) { mn = b2; ca = 2; }
-			if(b3 < mn) { mn = b3; ca = 3; }
-			left = ca == 2 ? 3 : ca == 3 ? 2 : 0;
-			right = ca == 0 ? 1 : ca == 2 ? 1 : 3;
-		}
-		else if(P.ms_mode == 2) ca = dec[0].which >= 2 ? 3 : 0;
-		sh->ca = ca; sh->left = left; sh->right = right;
-		nb = frame_header_bytes(P, n, ca, (uint32_t)(first_frame_number + f), hb);
-		sh->hdr_bits = 8 * nb;
+	// decision records, CRC tables: one round of loads for everything the frame needs; image zeroed meanwhile
+	{
+		const uint32_t ndw = P.ncand * (uint32_t)(sizeof(SubDecision) / 4);
+		for(uint32_t w = (uint32_t)tid; w < ndw; w += TPB) sh->dec[w] = ((const uint32_t *)dec)[w];
+		for(uint32_t w = (uint32_t)tid; w < 4 * 256 / 2; w += TPB) ((uint32_t *)sh->crc_tab)[w] = ((const uint32_t *)g_crc_tables.tab)[w];
+		for(uint32_t w = (uint32_t)tid; w < P2_XSPAN / 2; w += TPB) ((uint32_t *)sh->xspan)[w] = ((const uint32_t *)g_crc_tables.xspan)[w];
+		if(tid < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[tid] = ((const uint32_t *)g_crc_tables.xbyte)[tid];
+		for(uint32_t w = (uint32_t)tid; w < cap_words + 2; w += TPB) img[w] = 0;
 	}
 	__syncthreads();
-	const uint32_t ca = sh->ca;
-	if(tid == 0) for(uint32_t k = 0; k < nb; k++) or_bits(img, cap_words, 8 * k, hb[k], 8);
-	uint32_t pos = sh->hdr_bits;
+	PSTAMP(1);
+	const SubDecision *ldec = (const SubDecision *)sh->dec;
+	// channel assignment (stream_encoder.c:3944-3972), by every thread from the LDS copies
+	uint32_t ca = 0, left = 0, right = 1;
+	if(P.ms_mode == 1) {
+		const uint32_t b0 = ldec[0].bits + ldec[1].bits, b1 = ldec[0].bits + ldec[3].bits,
+		               b2 = ldec[1].bits + ldec[3].bits, b3 = ldec[2].bits + ldec[3].bits;
+		uint32_t mn = b0;
+		if(b1 < mn) { mn = b1; ca = 1; }
+		if(b2 < mn) { mn = b2; ca = 2; }
+		if(b3 < mn) { mn = b3; ca = 3; }
+		left = ca == 2 ? 3 : ca == 3 ? 2 : 0;
+		right = ca == 0 ? 1 : ca == 2 ? 1 : 3;
+	}
+	else if(P.ms_mode == 2) ca = ldec[0].which >= 2 ? 3 : 0;
+	const uint32_t frame_number = (uint32_t)(first_frame_number + f);
+	if(tid == 64) {
+		// one lane (of a wavefront that has no other single-lane duties) builds and writes the header while the others go on
+		(void)frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { or_bits(img, cap_words, 8 * k, byte, 8); });
+	}
+	uint32_t pos = 8 * frame_header_len(P, n, frame_number);
 	uint32_t scan_buf = 0;
 
 	// ---- subframes (stream_encoder_framing.c:393-594) -------------------------------------------
 	for(uint32_t s = 0; s < C; s++) {
-		const uint32_t di = P.ms_mode == 1 ? (s == 0 ? sh->left : sh->right) : s;
-		const SubDecision *d = dec + di;
+		const uint32_t di = P.ms_mode == 1 ? (s == 0 ? left : right) : s;
+		const SubDecision *d = ldec + di;
 		const uint32_t which = d->which, type = d->type, order = d->order, wasted = d->wasted;
 		const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
 		const bool fmt16 = sbps <= 16;
@@ -633,9 +676,7 @@ __global__ __launch_bounds__(TPB) void pack2_kernel(const DevParams P, const int
 				q[j] = c;
 			}
 			const uint32_t psize = n >> po;
-			__syncthreads();                       // the previous subframe's readers of params are done
-			for(uint32_t p = (uint32_t)tid; p < (1u << po); p += TPB) sh->params[p] = d->params[p];
-			__syncthreads();
+			PSTAMP(2 + 4 * s);
 			const int fmode = fir_mode(wide, sbps);
 			for(uint32_t base0 = 0; base0 < n; base0 += CHUNK * TPB) {
 				const uint32_t base = base0 + CHUNK * (uint32_t)tid;
@@ -705,7 +746,7 @@ __global__ __launch_bounds__(TPB) void pack2_kernel(const DevParams P, const int
 					}
 					// Rice code sizes: the whole run lies in one partition (partition sizes are multiples of 16)
 					const uint32_t part = base / psize;
-					k = sh->params[part];
+					k = d->params[part];
 					starts = base == part * psize;
 					if(starts) mybits = plen;
 #pragma unroll
@@ -715,6 +756,7 @@ __global__ __launch_bounds__(TPB) void pack2_kernel(const DevParams P, const int
 						mybits += (base == 0 && (uint32_t)t < order) ? 0u : cb;
 					}
 				}
+				PSTAMP(3 + 4 * s);
 				// bit offset of this thread: wavefront scan + wavefront totals through LDS
 				const uint32_t incl = wave_scan_incl_dpp(mybits);
 				if(lane == 63) sh->wtot[scan_buf][wave] = incl;
@@ -723,6 +765,7 @@ __global__ __launch_bounds__(TPB) void pack2_kernel(const DevParams P, const int
 #pragma unroll
 				for(int w = 0; w < TPB / 64; w++) { const uint32_t tw = sh->wtot[scan_buf][w]; if(w < wave) woff += tw; total += tw; }
 				scan_buf ^= 1;
+				PSTAMP(4 + 4 * s);
 				if(active) {
 					uint32_t p = pos + woff + incl - mybits;
 					if(starts) { or_bits(img, cap_words, p, k, plen); p += plen; }
@@ -737,6 +780,7 @@ __global__ __launch_bounds__(TPB) void pack2_kernel(const DevParams P, const int
 					}
 				}
 				pos += total;
+				PSTAMP(5 + 4 * s);
 			}
 		}
 		if(tid == 0 && info) {
@@ -747,13 +791,15 @@ __global__ __launch_bounds__(TPB) void pack2_kernel(const DevParams P, const int
 		}
 	}
 	__syncthreads();
+	PSTAMP(10);
 
 	// ---- zero-pad to a byte, CRC-16 over the whole frame, footer (stream_encoder.c:3720-3734) --------
 	const uint32_t body_bytes = (pos + 7) >> 3;
 	const uint32_t total_bytes = body_bytes + 2;
 	const bool overflow = total_bytes > P.slot_bytes;
 	{
-		const uint32_t crc = frame_crc16(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, tid);
+		const uint32_t crc = frame_crc16(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, tid, sh->xspan, P2_XSPAN, sh->xbyte);
+		PSTAMP(11);
 		if(tid == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
 	}
@@ -767,6 +813,8 @@ __global__ __launch_bounds__(TPB) void pack2_kernel(const DevParams P, const int
 			if(info) info[f].channel_assignment = (uint8_t)ca;
 		}
 	}
+	PSTAMP(12);
+#undef PSTAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -845,7 +893,7 @@ static bool pack2_applicable(const DevParams &P)
 }
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                                const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, size_t lds, hipStream_t s)
+                                const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, hipStream_t s)
 {
 	static bool attr_set = false;
 	if(!attr_set) {
@@ -858,7 +906,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 	if(pack2_applicable(P)) {
 		f_lo = tail_n ? nframes - 1 : nframes;
 		const size_t lds2 = (size_t)P.slot_bytes + 16 + sizeof(Pack2Shared);
-		if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info);
+		if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg);
 	}
 	if(f_lo < nframes) hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes - f_lo), dim3(TPB), lds, s, P, chan, nframes, tail_n, f_lo, first, dec, slots, fb, info);
 	return hipGetLastError();
@@ -868,13 +916,13 @@ namespace flacgpu {
 size_t pack_lds_bytes(const DevParams &P) { return (size_t)P.sig_bytes + P.slot_bytes + sizeof(PackShared); }
 
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, hipStream_t s)
+                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, hipStream_t s)
 {
 	const size_t lds = pack_lds_bytes(P);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
-	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, lds, s);
-	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, lds, s);
-	return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, lds, s);
+	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
+	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
+	return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
 }
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)
 {
