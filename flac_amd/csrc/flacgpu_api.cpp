@@ -14,13 +14,21 @@
 
 using namespace flacgpu;
 
+constexpr int TIMING_RING = 64;
 struct flacgpu_ctx {
 	flacgpu_config cfg;
 	DevParams P;
 	int device;
 	hipStream_t stream;          // engine-owned stream (host-buffer entry point)
-	hipEvent_t ev[5];            // start, after analyze, after pack, after compact, spare
-	hipEvent_t pev[3];           // inside the analysis: after prep, after autoc, after model
+	// HIP events of the last TIMING_RING batches (so that a caller can read per-kernel times of a run of batches
+	// afterwards, without a host sync in between); ev/pev point at the set of the current batch
+	hipEvent_t ev_ring[TIMING_RING][5], pev_ring[TIMING_RING][3];
+	hipEvent_t *ev;              // start, after analyze, after pack, after compact, spare
+	hipEvent_t *pev;             // inside the analysis: after prep, after autoc, after model
+	uint64_t batch_seq;          // batches launched so far
+	uint32_t nsub;               // sub-batches of a batch, each on its own stream (1: everything on one stream)
+	hipStream_t sub_stream[FLACGPU_MAX_SUBBATCHES];
+	hipEvent_t sub_done[FLACGPU_MAX_SUBBATCHES], ev_fork;
 	AnalyzeBuffers ab;           // hand-off records between the analysis kernels
 	float *d_windows;            // [num_apod][blocksize]
 	float *d_tail_windows;       // [num_apod][blocksize] scratch for the short last block
@@ -84,13 +92,22 @@ void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 }
 }
 
-extern "C" int flacgpu_last_batch_phase_ms(flacgpu_ctx *c, float ms[6])
+extern "C" int flacgpu_batch_phase_ms(flacgpu_ctx *c, uint32_t batches_ago, float ms[6])
 {
-	if(!c || !ms || !c->timing_valid) return FLACGPU_ERR_BAD_ARG;
+	if(!c || !ms || !c->timing_valid || batches_ago >= (uint32_t)TIMING_RING || batches_ago >= c->batch_seq) return FLACGPU_ERR_BAD_ARG;
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
-	if(hipEventSynchronize(c->ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	hipEvent_t seq[7] = {c->ev[0], c->pev[0], c->pev[1], c->pev[2], c->ev[1], c->ev[2], c->ev[3]};
+	const size_t slot = (size_t)((c->batch_seq - 1 - batches_ago) % TIMING_RING);
+	hipEvent_t *ev = c->ev_ring[slot], *pev = c->pev_ring[slot];
+	if(hipEventSynchronize(ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	hipEvent_t seq[7] = {ev[0], pev[0], pev[1], pev[2], ev[1], ev[2], ev[3]};
 	for(int i = 0; i < 6; i++) if(hipEventElapsedTime(&ms[i], seq[i], seq[i + 1]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	return FLACGPU_OK;
+}
+extern "C" int flacgpu_last_batch_phase_ms(flacgpu_ctx *c, float ms[6]) { return flacgpu_batch_phase_ms(c, 0, ms); }
+extern "C" int flacgpu_set_subbatches(flacgpu_ctx *c, uint32_t n)
+{
+	if(!c || n < 1 || n > (uint32_t)FLACGPU_MAX_SUBBATCHES) return FLACGPU_ERR_BAD_ARG;
+	c->nsub = n;
 	return FLACGPU_OK;
 }
 
@@ -143,9 +160,11 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->ab.valid) (void)hipFree(c->ab.valid);
 	if(c->ab.chan) (void)hipFree(c->ab.chan);
 	if(c->ab.dbg) (void)hipFree(c->ab.dbg);
-	for(int i = 0; i < 3; i++) if(c->pev[i]) (void)hipEventDestroy(c->pev[i]);
+	for(int r = 0; r < TIMING_RING; r++) for(int i = 0; i < 3; i++) if(c->pev_ring[r][i]) (void)hipEventDestroy(c->pev_ring[r][i]);
+	for(int i = 0; i < FLACGPU_MAX_SUBBATCHES; i++) { if(c->sub_stream[i]) (void)hipStreamDestroy(c->sub_stream[i]); if(c->sub_done[i]) (void)hipEventDestroy(c->sub_done[i]); }
+	if(c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if(c->d_jobtab) (void)hipFree(c->d_jobtab);
-	for(int i = 0; i < 5; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	for(int r = 0; r < TIMING_RING; r++) for(int i = 0; i < 5; i++) if(c->ev_ring[r][i]) (void)hipEventDestroy(c->ev_ring[r][i]);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -221,8 +240,18 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 
 	bool ok = true;
 	ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-	for(int i = 0; i < 5 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
-	for(int i = 0; i < 3 && ok; i++) ok = hipEventCreate(&c->pev[i]) == hipSuccess;
+	for(int r = 0; r < TIMING_RING && ok; r++) {
+		for(int i = 0; i < 5 && ok; i++) ok = hipEventCreate(&c->ev_ring[r][i]) == hipSuccess;
+		for(int i = 0; i < 3 && ok; i++) ok = hipEventCreate(&c->pev_ring[r][i]) == hipSuccess;
+	}
+	c->ev = c->ev_ring[0]; c->pev = c->pev_ring[0];
+	for(int i = 0; i < FLACGPU_MAX_SUBBATCHES && ok; i++) {
+		ok = hipStreamCreateWithFlags(&c->sub_stream[i], hipStreamNonBlocking) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&c->sub_done[i], hipEventDisableTiming) == hipSuccess;
+	}
+	ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+	c->nsub = 1;
+	if(const char *e = getenv("FLACGPU_SUBBATCHES")) { const int v = atoi(e); if(v >= 1 && v <= FLACGPU_MAX_SUBBATCHES) c->nsub = (uint32_t)v; }
 	const size_t B = cfg->max_batch_frames;
 	const size_t wbytes = (size_t)(P.num_apod ? P.num_apod : 1) * N * sizeof(float);
 	ok = ok && hipMalloc(&c->d_windows, wbytes) == hipSuccess;
@@ -273,48 +302,78 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		if(!tail_windows_host) return FLACGPU_ERR_BAD_ARG;
 		if(hipMemcpyAsync(c->d_tail_windows, tail_windows_host, (size_t)P.num_apod * tail_n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
+	c->ev = c->ev_ring[c->batch_seq % TIMING_RING]; c->pev = c->pev_ring[c->batch_seq % TIMING_RING];
+	c->batch_seq++;
 	(void)hipEventRecord(c->ev[0], s);
-	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->ab, c->d_decisions, c->pev, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(c->ab.dbg) {
-		// development aid: average shader cycles per phase of the eval workgroups of this launch
-		const size_t nwg = (size_t)nframes * P.ncand;
-		unsigned long long *h = (unsigned long long *)malloc(nwg * 16 * sizeof(unsigned long long));
-		if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, c->ab.dbg, nwg * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-			double acc[6] = {0}; size_t cnt[6] = {0};
-			for(size_t w = 0; w < nwg; w++) for(int k = 1; k < 6; k++) if(h[w * 16 + k] && h[w * 16 + k - 1]) { acc[k] += (double)(h[w * 16 + k] - h[w * 16 + k - 1]); cnt[k]++; }
-			double pro = 0; size_t npro = 0;
-			for(size_t w = 0; w < nwg; w++) if(h[w * 16 + 8] && h[w * 16]) { pro += (double)(h[w * 16 + 8] - h[w * 16]); npro++; }
-			fprintf(stderr, "[flacgpu] eval prologue %.0f ticks (%zu WGs)\n", npro ? pro / npro : 0, npro);
-			for(int v = 1; v <= 3; v++) {
-				unsigned long long t0 = ~0ull, t1 = 0; double dur = 0; size_t nv = 0;
-				for(size_t w = 0; w < nwg; w++) if(h[w * 16 + 9] == (unsigned long long)v && h[w * 16 + 5]) {
-					nv++; dur += (double)(h[w * 16 + 5] - h[w * 16]);
-					if(h[w * 16] < t0) t0 = h[w * 16];
-					if(h[w * 16 + 5] > t1) t1 = h[w * 16 + 5];
-				}
-				if(nv) fprintf(stderr, "[flacgpu] eval variant %d: %zu WGs, avg %.0f ticks each, first start -> last end %.0f ticks, mean concurrency %.1f WGs\n",
-				               v - 1, nv, dur / nv, (double)(t1 - t0), dur / (double)(t1 - t0));
-			}
-			fprintf(stderr, "[flacgpu] eval phases (avg s_memtime ticks per WG): load %.0f  cand0 %.0f  round1->round2 %.0f  rest %.0f  decide %.0f\n",
-			        cnt[1] ? acc[1] / cnt[1] : 0, cnt[2] ? acc[2] / cnt[2] : 0, cnt[3] ? acc[3] / cnt[3] : 0, cnt[4] ? acc[4] / cnt[4] : 0, cnt[5] ? acc[5] / cnt[5] : 0);
+	uint32_t nsub = c->nsub;
+	if(c->ab.dbg || nframes < 256 * nsub) nsub = 1;
+	if(nsub > 1) {
+		// Independent sub-batches on their own streams: the latency-bound kernels of one (prep, model, pack) fill the
+		// gaps of the VALU-bound kernels of another (autoc, eval).  Every buffer is indexed by frame, so a sub-batch
+		// is the same launches on offset pointers; they join before the scan over all frame lengths.
+		(void)hipEventRecord(c->ev_fork, s);
+		for(uint32_t i = 0; i < nsub; i++) {
+			const uint32_t f0 = (uint32_t)((uint64_t)nframes * i / nsub), f1 = (uint32_t)((uint64_t)nframes * (i + 1) / nsub), nf = f1 - f0;
+			hipStream_t ss = c->sub_stream[i];
+			(void)hipStreamWaitEvent(ss, c->ev_fork, 0);
+			const size_t fc0 = (size_t)f0 * P.ncand, ncs = P.max_analyses + 1;
+			AnalyzeBuffers B = c->ab;
+			B.prep += fc0; B.autoc += fc0 * P.max_jobs * MAX_ORDER; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.blocksize; B.dbg = nullptr;
+			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
+			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, B,
+			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, ss) != hipSuccess)
+				return FLACGPU_ERR_LAUNCH;
+			(void)hipEventRecord(c->sub_done[i], ss);
+			(void)hipStreamWaitEvent(s, c->sub_done[i], 0);
 		}
-		free(h);
-		(void)hipMemsetAsync(c->ab.dbg, 0, nwg * 16 * sizeof(unsigned long long), s);
+		// the per-kernel events of the single-stream path are not meaningful here
+		for(int i = 0; i < 3; i++) (void)hipEventRecord(c->pev[i], s);
+		(void)hipEventRecord(c->ev[1], s);
 	}
-	(void)hipEventRecord(c->ev[1], s);
-	if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(c->ab.dbg) {
-		// development aid: wall cycles of the pack2 workgroups between their stamps
-		unsigned long long *h = (unsigned long long *)malloc((size_t)nframes * 16 * sizeof(unsigned long long));
-		if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, c->ab.dbg, (size_t)nframes * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-			double acc[13] = {0}; size_t cnt[13] = {0};
-			for(size_t w = 0; w < nframes; w++) { int prev = 0; for(int k = 1; k < 13; k++) if(h[w * 16 + k] && h[w * 16 + prev]) { acc[k] += (double)(h[w * 16 + k] - h[w * 16 + prev]); cnt[k]++; prev = k; } }
-			fprintf(stderr, "[flacgpu] pack2 stamps (avg ticks since previous stamp):");
-			for(int k = 1; k < 13; k++) fprintf(stderr, " %d:%.0f", k, cnt[k] ? acc[k] / cnt[k] : 0.0);
-			fprintf(stderr, "\n");
+	else {
+	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->ab, c->d_decisions, c->pev, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(c->ab.dbg) {
+			// development aid: average shader cycles per phase of the eval workgroups of this launch
+			const size_t nwg = (size_t)nframes * P.ncand;
+			unsigned long long *h = (unsigned long long *)malloc(nwg * 16 * sizeof(unsigned long long));
+			if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, c->ab.dbg, nwg * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+				double acc[6] = {0}; size_t cnt[6] = {0};
+				for(size_t w = 0; w < nwg; w++) for(int k = 1; k < 6; k++) if(h[w * 16 + k] && h[w * 16 + k - 1]) { acc[k] += (double)(h[w * 16 + k] - h[w * 16 + k - 1]); cnt[k]++; }
+				double pro = 0; size_t npro = 0;
+				for(size_t w = 0; w < nwg; w++) if(h[w * 16 + 8] && h[w * 16]) { pro += (double)(h[w * 16 + 8] - h[w * 16]); npro++; }
+				fprintf(stderr, "[flacgpu] eval prologue %.0f ticks (%zu WGs)\n", npro ? pro / npro : 0, npro);
+				for(int v = 1; v <= 3; v++) {
+					unsigned long long t0 = ~0ull, t1 = 0; double dur = 0; size_t nv = 0;
+					for(size_t w = 0; w < nwg; w++) if(h[w * 16 + 9] == (unsigned long long)v && h[w * 16 + 5]) {
+						nv++; dur += (double)(h[w * 16 + 5] - h[w * 16]);
+						if(h[w * 16] < t0) t0 = h[w * 16];
+						if(h[w * 16 + 5] > t1) t1 = h[w * 16 + 5];
+					}
+					if(nv) fprintf(stderr, "[flacgpu] eval variant %d: %zu WGs, avg %.0f ticks each, first start -> last end %.0f ticks, mean concurrency %.1f WGs\n",
+					               v - 1, nv, dur / nv, (double)(t1 - t0), dur / (double)(t1 - t0));
+				}
+				fprintf(stderr, "[flacgpu] eval phases (avg s_memtime ticks per WG): load %.0f  cand0 %.0f  round1->round2 %.0f  rest %.0f  decide %.0f\n",
+				        cnt[1] ? acc[1] / cnt[1] : 0, cnt[2] ? acc[2] / cnt[2] : 0, cnt[3] ? acc[3] / cnt[3] : 0, cnt[4] ? acc[4] / cnt[4] : 0, cnt[5] ? acc[5] / cnt[5] : 0);
+			}
+			free(h);
+			(void)hipMemsetAsync(c->ab.dbg, 0, nwg * 16 * sizeof(unsigned long long), s);
 		}
-		free(h);
-		(void)hipMemsetAsync(c->ab.dbg, 0, (size_t)nframes * P.ncand * 16 * sizeof(unsigned long long), s);
+		(void)hipEventRecord(c->ev[1], s);
+		if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(c->ab.dbg) {
+			// development aid: wall cycles of the pack2 workgroups between their stamps
+			unsigned long long *h = (unsigned long long *)malloc((size_t)nframes * 16 * sizeof(unsigned long long));
+			if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, c->ab.dbg, (size_t)nframes * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+				double acc[13] = {0}; size_t cnt[13] = {0};
+				for(size_t w = 0; w < nframes; w++) { int prev = 0; for(int k = 1; k < 13; k++) if(h[w * 16 + k] && h[w * 16 + prev]) { acc[k] += (double)(h[w * 16 + k] - h[w * 16 + prev]); cnt[k]++; prev = k; } }
+				fprintf(stderr, "[flacgpu] pack2 stamps (avg ticks since previous stamp):");
+				for(int k = 1; k < 13; k++) fprintf(stderr, " %d:%.0f", k, cnt[k] ? acc[k] / cnt[k] : 0.0);
+				fprintf(stderr, "\n");
+			}
+			free(h);
+			(void)hipMemsetAsync(c->ab.dbg, 0, (size_t)nframes * P.ncand * 16 * sizeof(unsigned long long), s);
+		}
 	}
 	(void)hipEventRecord(c->ev[2], s);
 	if(launch_scan(c->d_frame_bytes, nframes, c->d_offsets, c->d_total, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;

@@ -91,6 +91,7 @@ struct AnalyzeBuffers {
 	int32_t *chan;             // [frames*ncand][blocksize] planar channel signals, wasted bits shifted out (ChanPrep::fmt)
 	unsigned long long *dbg;   // FLACGPU_DEBUG_TIMING=1: [frames*ncand][16] s_memtime stamps of the eval kernel (else null)
 };
+constexpr int FLACGPU_MAX_SUBBATCHES = 8;   // streams a batch may be split over (FLACGPU_SUBBATCHES / flacgpu_set_subbatches)
 constexpr int EVAL_MAX_WAVES = 8;   // wavefronts per eval workgroup (one residual candidate each per round)
 
 struct FrameInfo {

@@ -112,6 +112,10 @@ def load_engine():
                                                      C.POINTER(C.c_float)]
         lib.flacgpu_last_batch_phase_ms.restype = C.c_int
         lib.flacgpu_last_batch_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float * 6)]
+        lib.flacgpu_batch_phase_ms.restype = C.c_int
+        lib.flacgpu_batch_phase_ms.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float * 6)]
+        lib.flacgpu_set_subbatches.restype = C.c_int
+        lib.flacgpu_set_subbatches.argtypes = [C.c_void_p, C.c_uint32]
         lib.flacgpu_strerror.restype = C.c_char_p
         lib.flacgpu_strerror.argtypes = [C.c_int]
         lib.flacgpu_device_count.restype = C.c_int
@@ -248,12 +252,17 @@ class FrameEngine:
             raise FlacGpuError("flacgpu_last_batch_info: %s" % self.lib.flacgpu_strerror(r).decode())
         return sub, ca
 
-    def last_phase_ms(self):
-        """per-kernel ms of the last batch: prep, autoc, model, eval, pack, scan+compact"""
-        ms = (C.c_float * 6)()
-        r = self.lib.flacgpu_last_batch_phase_ms(self.ctx, C.byref(ms))
+    def set_subbatches(self, n):
+        r = self.lib.flacgpu_set_subbatches(self.ctx, n)
         if r != 0:
-            raise FlacGpuError("flacgpu_last_batch_phase_ms: %s" % self.lib.flacgpu_strerror(r).decode())
+            raise FlacGpuError("flacgpu_set_subbatches: %s" % self.lib.flacgpu_strerror(r).decode())
+
+    def last_phase_ms(self, batches_ago=0):
+        """per-kernel ms of a recent batch (0 = the last): prep, autoc, model, eval, pack, scan+compact"""
+        ms = (C.c_float * 6)()
+        r = self.lib.flacgpu_batch_phase_ms(self.ctx, batches_ago, C.byref(ms))
+        if r != 0:
+            raise FlacGpuError("flacgpu_batch_phase_ms: %s" % self.lib.flacgpu_strerror(r).decode())
         return dict(zip(("prep", "autoc", "model", "eval", "pack", "scan_compact"), [float(v) for v in ms]))
 
     def last_kernel_ms(self):

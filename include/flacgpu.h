@@ -130,6 +130,12 @@ int flacgpu_last_batch_kernel_ms(flacgpu_ctx *ctx, float *analyze_ms, float *pac
  * ms[2] LPC model (Levinson-Durbin, quantisation), ms[3] residual candidate evaluation + Rice search,
  * ms[4] pack, ms[5] scan + compaction. */
 int flacgpu_last_batch_phase_ms(flacgpu_ctx *ctx, float ms[6]);
+/* The same for the batch launched `batches_ago` batches before the last one (0 = the last; the engine keeps the
+ * events of its 64 most recent batches), so that a run of batches can be timed without a host sync in between. */
+int flacgpu_batch_phase_ms(flacgpu_ctx *ctx, uint32_t batches_ago, float ms[6]);
+/* Split every batch into n (1..8) sub-batches that run on separate HIP streams inside the engine and join before the
+ * frame compaction (default 1, or the FLACGPU_SUBBATCHES environment variable).  Output is identical. */
+int flacgpu_set_subbatches(flacgpu_ctx *ctx, uint32_t n);
 
 /* Page-locked host memory for PCM staging buffers handed to flacgpu_encode_batch (the H2D copy then runs
  * at full PCIe rate and asynchronously).  NULL when no device/runtime is available. */

@@ -27,7 +27,7 @@ for w in $WHAT; do
                  "SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE GRBM_COUNT" \
                  "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
         i=$((i+1))
-        timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$i -o p$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc$i.json 2> $OUT/pmc$i.err
+        timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$i -o p$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --frames 4096 > $OUT/pmc$i.json 2> $OUT/pmc$i.err
         echo "pmc pass $i rc=$? : $SET"
         DB=$(ls $OUT/pmc$i/*.db 2>/dev/null | head -1)
         [ -n "$DB" ] && python scripts/rocpd_pmc.py $DB >> $OUT/pmc_counters.txt
