@@ -17,6 +17,10 @@
 
 namespace flacgpu {
 
+#ifndef P2_WAVES
+#define P2_WAVES 4
+#endif
+
 struct Prep2Acc {
 	uint32_t orv, diff;
 	uint64_t e[5];
@@ -62,7 +66,7 @@ __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_c
 
 // WIDE: per-run partial sums may exceed 32 bits (more than 20 bits per sample)
 template <bool WIDE>
-__global__ __launch_bounds__(TPB, 4) void prep2_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
+__global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
                                                     ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
                                                     int32_t *__restrict__ chan)
 {
