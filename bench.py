@@ -97,6 +97,11 @@ def main():
                     "overlapped ordered gather) even with one rank")
     args = ap.parse_args()
 
+    # stdout must carry exactly one JSON line: libraries underneath (RCCL prints a version banner from C) get stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import flac_amd
@@ -232,7 +237,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pcm_h[: 512 * BLOCK])
             line["speedup_vs_cpu_1thread"] = round(value / line["cpu_baseline"]["value"], 2)
             line["speedup_vs_cpu_multi"] = round(value / line["cpu_baseline"]["multi"]["value"], 2)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     eng.close()
     if multi:
         dist.barrier()
