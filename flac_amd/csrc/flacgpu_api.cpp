@@ -39,6 +39,9 @@ struct flacgpu_ctx {
 	uint64_t *d_total;
 	FrameInfo *d_info;           // [max_batch]
 	int32_t *d_pcm;              // staging for the host entry point
+	uint8_t *d_raw;              // raw sample bytes of flacgpu_encode_batch_raw
+	size_t d_raw_bytes;
+	uint32_t *d_stage_err;
 	uint8_t *d_out;
 	size_t d_pcm_bytes, d_out_bytes;
 	uint32_t last_nframes;
@@ -129,6 +132,7 @@ extern "C" const char *flacgpu_strerror(int code)
 		case FLACGPU_ERR_OUTPUT_TOO_SMALL: return "output buffer too small";
 		case FLACGPU_ERR_LAUNCH: return "kernel launch or execution failed";
 		case FLACGPU_ERR_BAD_ARG: return "bad argument";
+		case FLACGPU_ERR_INPUT: return "raw sample data has non-zero bits below its declared shift";
 		default: return "unknown error";
 	}
 }
@@ -153,6 +157,8 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->d_total) (void)hipFree(c->d_total);
 	if(c->d_info) (void)hipFree(c->d_info);
 	if(c->d_pcm) (void)hipFree(c->d_pcm);
+	if(c->d_raw) (void)hipFree(c->d_raw);
+	if(c->d_stage_err) (void)hipFree(c->d_stage_err);
 	if(c->d_out) (void)hipFree(c->d_out);
 	if(c->ab.prep) (void)hipFree(c->ab.prep);
 	if(c->ab.autoc) (void)hipFree(c->ab.autoc);
@@ -395,16 +401,38 @@ extern "C" int flacgpu_encode_batch_device(flacgpu_ctx *ctx, const int32_t *d_pc
 	                 d_frame_bytes, d_total_bytes, stream ? (hipStream_t)stream : (ctx ? ctx->stream : nullptr));
 }
 
-extern "C" int64_t flacgpu_encode_batch(flacgpu_ctx *c, const int32_t *pcm, uint32_t nframes,
-                                        uint64_t first_frame_number, uint32_t last_block_samples,
-                                        const float *tail_windows, uint8_t *out, size_t out_cap,
-                                        uint32_t *frame_bytes)
+static int make_stage_params(const flacgpu_ctx *c, const flacgpu_raw_format *fmt, StageParams *S)
 {
-	if(!c || !pcm || !out || !frame_bytes || nframes == 0 || nframes > c->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
+	if(!fmt || (fmt->container_bits != 8 && fmt->container_bits != 16 && fmt->container_bits != 24 && fmt->container_bits != 32)) return FLACGPU_ERR_BAD_ARG;
+	if(fmt->shift >= fmt->container_bits) return FLACGPU_ERR_BAD_ARG;
+	memset(S, 0, sizeof *S);
+	S->bytes = fmt->container_bits / 8; S->big_endian = fmt->big_endian ? 1 : 0; S->is_unsigned = fmt->is_unsigned ? 1 : 0;
+	S->shift = fmt->shift; S->channels = c->P.channels; S->use_map = fmt->use_channel_map ? 1 : 0;
+	uint32_t seen = 0;
+	for(uint32_t ch = 0; ch < c->P.channels; ch++) {
+		S->map[ch] = S->use_map ? fmt->channel_map[ch] : (uint8_t)ch;
+		if(S->map[ch] >= c->P.channels || (seen & (1u << S->map[ch]))) return FLACGPU_ERR_BAD_ARG;      // must be a permutation
+		seen |= 1u << S->map[ch];
+	}
+	return FLACGPU_OK;
+}
+
+extern "C" int flacgpu_stage_raw_device(flacgpu_ctx *c, const void *d_raw, const flacgpu_raw_format *fmt, uint64_t wide_samples,
+                                        int32_t *d_pcm, uint32_t *d_error, void *stream)
+{
+	if(!c || !d_raw || !d_pcm) return FLACGPU_ERR_BAD_ARG;
+	StageParams S;
+	const int r = make_stage_params(c, fmt, &S);
+	if(r != FLACGPU_OK) return r;
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	if(launch_stage_raw(S, d_raw, wide_samples * c->P.channels, d_pcm, d_error, stream ? (hipStream_t)stream : c->stream) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	return FLACGPU_OK;
+}
+
+// the device buffers of the host entry points
+static int ensure_host_staging(flacgpu_ctx *c, uint32_t nframes)
+{
 	const DevParams &P = c->P;
-	uint32_t tail_n = last_block_samples < P.blocksize ? last_block_samples : 0;
-	const size_t nsamp = (size_t)(nframes - 1) * P.blocksize + (tail_n ? tail_n : P.blocksize);
 	// the kernels index frames at a fixed stride of blocksize*channels; staging is sized for full frames
 	const size_t pcm_bytes = (size_t)nframes * P.blocksize * P.channels * sizeof(int32_t);
 	const size_t out_bytes = (size_t)nframes * P.slot_bytes;
@@ -420,9 +448,14 @@ extern "C" int64_t flacgpu_encode_batch(flacgpu_ctx *c, const int32_t *pcm, uint
 		if(hipMalloc(&c->d_out, out_bytes) != hipSuccess) return FLACGPU_ERR_ALLOC;
 		c->d_out_bytes = out_bytes;
 	}
+	return FLACGPU_OK;
+}
+// encode c->d_pcm (already filled on the engine's stream) and bring the frames back
+static int64_t encode_staged(flacgpu_ctx *c, uint32_t nframes, uint64_t first_frame_number, uint32_t tail_n, const float *tail_windows,
+                             uint8_t *out, size_t out_cap, uint32_t *frame_bytes)
+{
 	hipStream_t s = c->stream;
-	if(hipMemcpyAsync(c->d_pcm, pcm, nsamp * P.channels * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	int r = run_batch(c, c->d_pcm, nframes, first_frame_number, tail_n, tail_windows, c->d_out, out_bytes, nullptr, nullptr, s);
+	int r = run_batch(c, c->d_pcm, nframes, first_frame_number, tail_n, tail_windows, c->d_out, c->d_out_bytes, nullptr, nullptr, s);
 	if(r != FLACGPU_OK) return r;
 	uint64_t total = 0;
 	if(hipMemcpyAsync(frame_bytes, c->d_frame_bytes, nframes * sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
@@ -432,6 +465,57 @@ extern "C" int64_t flacgpu_encode_batch(flacgpu_ctx *c, const int32_t *pcm, uint
 	if(total > out_cap) return FLACGPU_ERR_OUTPUT_TOO_SMALL;
 	if(hipMemcpy(out, c->d_out, total, hipMemcpyDeviceToHost) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	return (int64_t)total;
+}
+
+extern "C" int64_t flacgpu_encode_batch(flacgpu_ctx *c, const int32_t *pcm, uint32_t nframes,
+                                        uint64_t first_frame_number, uint32_t last_block_samples,
+                                        const float *tail_windows, uint8_t *out, size_t out_cap,
+                                        uint32_t *frame_bytes)
+{
+	if(!c || !pcm || !out || !frame_bytes || nframes == 0 || nframes > c->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	const DevParams &P = c->P;
+	const uint32_t tail_n = last_block_samples < P.blocksize ? last_block_samples : 0;
+	const size_t nsamp = (size_t)(nframes - 1) * P.blocksize + (tail_n ? tail_n : P.blocksize);
+	const int r = ensure_host_staging(c, nframes);
+	if(r != FLACGPU_OK) return r;
+	if(hipMemcpyAsync(c->d_pcm, pcm, nsamp * P.channels * sizeof(int32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	return encode_staged(c, nframes, first_frame_number, tail_n, tail_windows, out, out_cap, frame_bytes);
+}
+
+extern "C" int64_t flacgpu_encode_batch_raw(flacgpu_ctx *c, const void *raw, const flacgpu_raw_format *fmt, uint32_t nframes,
+                                            uint64_t first_frame_number, uint32_t last_block_samples,
+                                            const float *tail_windows, uint8_t *out, size_t out_cap,
+                                            uint32_t *frame_bytes)
+{
+	if(!c || !raw || !out || !frame_bytes || nframes == 0 || nframes > c->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
+	StageParams S;
+	int r = make_stage_params(c, fmt, &S);
+	if(r != FLACGPU_OK) return r;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	const DevParams &P = c->P;
+	const uint32_t tail_n = last_block_samples < P.blocksize ? last_block_samples : 0;
+	const size_t nsamp = (size_t)(nframes - 1) * P.blocksize + (tail_n ? tail_n : P.blocksize);
+	r = ensure_host_staging(c, nframes);
+	if(r != FLACGPU_OK) return r;
+	const size_t raw_bytes = nsamp * P.channels * S.bytes;
+	if(c->d_raw_bytes < raw_bytes) {
+		if(c->d_raw) (void)hipFree(c->d_raw);
+		c->d_raw = nullptr; c->d_raw_bytes = 0;
+		if(hipMalloc(&c->d_raw, raw_bytes) != hipSuccess) return FLACGPU_ERR_ALLOC;
+		c->d_raw_bytes = raw_bytes;
+	}
+	if(!c->d_stage_err && hipMalloc(&c->d_stage_err, sizeof(uint32_t)) != hipSuccess) return FLACGPU_ERR_ALLOC;
+	hipStream_t s = c->stream;
+	uint32_t herr = 0;
+	if(hipMemsetAsync(c->d_stage_err, 0, sizeof(uint32_t), s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipMemcpyAsync(c->d_raw, raw, raw_bytes, hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(launch_stage_raw(S, c->d_raw, (uint64_t)nsamp * P.channels, c->d_pcm, c->d_stage_err, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(S.shift) {
+		if(hipMemcpyAsync(&herr, c->d_stage_err, sizeof herr, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(herr) return FLACGPU_ERR_INPUT;
+	}
+	return encode_staged(c, nframes, first_frame_number, tail_n, tail_windows, out, out_cap, frame_bytes);
 }
 
 extern "C" int flacgpu_last_batch_info(flacgpu_ctx *c, uint32_t nframes, flacgpu_subframe_info *sub, uint8_t *channel_assignment)

@@ -112,6 +112,13 @@ bool prep2_applicable(const DevParams &P);
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s);
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, hipStream_t s);
+// raw sample bytes -> interleaved int32 (flacgpu_stage.hip)
+struct StageParams {
+	uint32_t bytes;          // container bytes per sample: 1, 2, 3, 4
+	uint32_t big_endian, is_unsigned, shift, channels, use_map;
+	uint8_t map[FLACGPU_MAX_CHANNELS];   // input channel c goes to output channel map[c]
+};
+hipError_t launch_stage_raw(const StageParams &S, const void *d_raw, uint64_t nvalues, int32_t *d_pcm, uint32_t *d_err, hipStream_t s);
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);
 hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,
                           uint8_t *out, uint64_t out_cap, uint32_t nframes, hipStream_t s);

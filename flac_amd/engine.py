@@ -17,6 +17,21 @@ FLACGPU_MAX_APODIZATIONS = 8
 FGH_MAX_APODIZATIONS = 32
 
 
+class RawFormat(C.Structure):
+    """flacgpu_raw_format (include/flacgpu.h)"""
+    _fields_ = [("container_bits", C.c_uint32), ("big_endian", C.c_uint32), ("is_unsigned", C.c_uint32), ("shift", C.c_uint32),
+                ("use_channel_map", C.c_uint32), ("channel_map", C.c_uint8 * 8)]
+
+
+def raw_format(container_bits, big_endian=False, is_unsigned=False, shift=0, channel_map=None):
+    f = RawFormat(container_bits, int(big_endian), int(is_unsigned), shift, 0)
+    if channel_map is not None:
+        f.use_channel_map = 1
+        for i, c in enumerate(channel_map):
+            f.channel_map[i] = c
+    return f
+
+
 class FlacGpuError(RuntimeError):
     pass
 
@@ -114,6 +129,11 @@ def load_engine():
         lib.flacgpu_last_batch_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float * 6)]
         lib.flacgpu_batch_phase_ms.restype = C.c_int
         lib.flacgpu_batch_phase_ms.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float * 6)]
+        lib.flacgpu_stage_raw_device.restype = C.c_int
+        lib.flacgpu_stage_raw_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RawFormat), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.flacgpu_encode_batch_raw.restype = C.c_int64
+        lib.flacgpu_encode_batch_raw.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RawFormat), C.c_uint32, C.c_uint64, C.c_uint32,
+                                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.flacgpu_set_subbatches.restype = C.c_int
         lib.flacgpu_set_subbatches.argtypes = [C.c_void_p, C.c_uint32]
         lib.flacgpu_strerror.restype = C.c_char_p
@@ -233,6 +253,32 @@ class FrameEngine:
             fbs.append(fb)
             f0 += nf
         return b"".join(out_parts), np.concatenate(fbs) if fbs else np.zeros(0, np.uint32)
+
+    def encode_raw(self, raw, fmt, first_frame_number=0):
+        """raw: the sample bytes of ONE batch (<= max_batch_frames blocks) as they sit in a WAVE/AIFF/raw file;
+        fmt: RawFormat.  Staged to int32 on the device (format_input of the reference's CLI), then encoded."""
+        raw = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else np.ascontiguousarray(raw).view(np.uint8)
+        bytes_per_wide = (fmt.container_bits // 8) * self.channels
+        n = raw.size // bytes_per_wide
+        N = self.blocksize
+        nf = (n + N - 1) // N
+        assert 0 < nf <= self.max_batch_frames
+        tail = n - (nf - 1) * N
+        tail = 0 if tail == N else tail
+        tw = self._tail_windows(tail)
+        cap = self.max_output_bytes(nf)
+        out = np.empty(cap, dtype=np.uint8)
+        fb = np.empty(nf, dtype=np.uint32)
+        r = self.lib.flacgpu_encode_batch_raw(self.ctx, raw.ctypes.data, C.byref(fmt), nf, first_frame_number, tail,
+                                              tw.ctypes.data if tw is not None else None, out.ctypes.data, cap, fb.ctypes.data)
+        if r < 0:
+            raise FlacGpuError("flacgpu_encode_batch_raw: %s" % self.lib.flacgpu_strerror(int(r)).decode())
+        return out[:r].tobytes(), fb
+
+    def stage_raw_device(self, d_raw_ptr, fmt, wide_samples, d_pcm_ptr, d_err_ptr=None, stream=None):
+        r = self.lib.flacgpu_stage_raw_device(self.ctx, d_raw_ptr, C.byref(fmt), wide_samples, d_pcm_ptr, d_err_ptr, stream)
+        if r != 0:
+            raise FlacGpuError("flacgpu_stage_raw_device: %s" % self.lib.flacgpu_strerror(r).decode())
 
     def encode_device(self, d_pcm_ptr, nframes, d_out_ptr, out_cap, d_frame_bytes_ptr, d_total_ptr,
                       first_frame_number=0, tail=0, stream=None):

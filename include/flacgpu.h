@@ -37,7 +37,8 @@ enum {
 	FLACGPU_ERR_ALLOC = -3,         /* -> FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR */
 	FLACGPU_ERR_OUTPUT_TOO_SMALL = -4,
 	FLACGPU_ERR_LAUNCH = -5,        /* -> FLAC__STREAM_ENCODER_FRAMING_ERROR */
-	FLACGPU_ERR_BAD_ARG = -6
+	FLACGPU_ERR_BAD_ARG = -6,
+	FLACGPU_ERR_INPUT = -7          /* raw input violates its declared format (non-zero bits below `shift`) */
 };
 
 /* apodization kinds as the frame engine sees them (stream_encoder.c:4318-4392): every window
@@ -117,6 +118,30 @@ int flacgpu_encode_batch_device(flacgpu_ctx *ctx, const int32_t *d_pcm, uint32_t
                                 uint64_t first_frame_number, uint32_t last_block_samples,
                                 const float *tail_windows_host, uint8_t *d_out, size_t out_cap,
                                 uint32_t *d_frame_bytes, uint64_t *d_total_bytes, void *stream);
+
+/* ---- input staging on the device (what format_input() of the reference's `flac` tool does on the host,
+ * src/flac/encode.c:2352-2492): raw interleaved sample bytes as they sit in a WAVE/AIFF/raw file -> int32 ---- */
+typedef struct {
+	uint32_t container_bits;         /* 8, 16, 24 or 32: bits each sample occupies in the raw data */
+	uint32_t big_endian;             /* byte order of the raw data */
+	uint32_t is_unsigned;            /* unsigned samples: the mid-point is subtracted */
+	uint32_t shift;                  /* samples are left-justified: low `shift` bits must be zero and are dropped */
+	uint32_t use_channel_map;        /* 0: identity */
+	uint8_t  channel_map[FLACGPU_MAX_CHANNELS]; /* input channel c goes to output channel channel_map[c] */
+} flacgpu_raw_format;
+
+/* d_raw (device) holds wide_samples * channels samples in `fmt`; writes the interleaved int32 block to d_pcm (device).
+ * d_error (device uint32, may be NULL, caller zeroes it) gets bit 0 set when a sample has non-zero bits below
+ * `shift` (encode.c:2479-2488).  Asynchronous on `stream`. */
+int flacgpu_stage_raw_device(flacgpu_ctx *ctx, const void *d_raw, const flacgpu_raw_format *fmt, uint64_t wide_samples,
+                             int32_t *d_pcm, uint32_t *d_error, void *stream);
+
+/* flacgpu_encode_batch() from raw HOST sample bytes: copies the raw bytes (2 bytes per 16-bit sample instead of 4),
+ * stages them on the device and encodes.  Returns FLACGPU_ERR_INPUT for a shift violation. */
+int64_t flacgpu_encode_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgpu_raw_format *fmt, uint32_t nframes,
+                                 uint64_t first_frame_number, uint32_t last_block_samples,
+                                 const float *tail_windows, uint8_t *out, size_t out_cap,
+                                 uint32_t *frame_bytes);
 
 /* Diagnostics of the most recent batch: [nframes][channels] subframe choices and the channel
  * assignment per frame (0 independent, 1 left/side, 2 right/side, 3 mid/side). Host arrays. */

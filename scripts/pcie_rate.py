@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive encode rate: host buffers through flacgpu_encode_batch (int32 block) and flacgpu_encode_batch_raw
+(16-bit little-endian file bytes, staged on the device), pinned staging memory.  Never bench.py's `value`."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import flac_amd  # noqa: E402
+import signals  # noqa: E402
+from rawfmt import to_raw  # noqa: E402
+
+NF, N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 4096
+eng = flac_amd.FrameEngine(flac_amd.make_settings(2, 16, 44100, 8), device=0, max_batch_frames=NF)
+lib = eng.lib
+lib.flacgpu_alloc_pinned.restype = C.c_void_p
+lib.flacgpu_alloc_pinned.argtypes = [C.c_size_t]
+base = signals.music(512 * N, 2, 16, seed=3)
+pcm = np.tile(base, ((NF + 511) // 512, 1))[: NF * N]
+raw = to_raw(pcm, 16)
+
+
+def pinned(arr):
+    p = lib.flacgpu_alloc_pinned(arr.nbytes)
+    buf = (C.c_uint8 * arr.nbytes).from_address(p)
+    np.frombuffer(buf, dtype=np.uint8)[:] = arr.view(np.uint8).reshape(-1)
+    return p
+
+
+cap = eng.max_output_bytes(NF)
+out_p = lib.flacgpu_alloc_pinned(cap)
+fb = np.empty(NF, dtype=np.uint32)
+p32, p16 = pinned(pcm), pinned(raw)
+fmt = flac_amd.raw_format(16)
+for name, call in (("int32 host block (flacgpu_encode_batch)", lambda: lib.flacgpu_encode_batch(eng.ctx, p32, NF, 0, 0, None, out_p, cap, fb.ctypes.data)),
+                   ("16-bit file bytes (flacgpu_encode_batch_raw)", lambda: lib.flacgpu_encode_batch_raw(eng.ctx, p16, C.byref(fmt), NF, 0, 0, None, out_p, cap, fb.ctypes.data))):
+    call()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        r = call()
+        assert r > 0
+    dt = (time.perf_counter() - t0) / reps
+    print("%-48s %7.2f ms per %d frames  %8.1f M samples/s (PCIe inclusive, D2H of the frames included)" % (name, dt * 1e3, NF, NF * N / dt / 1e6))
+eng.close()

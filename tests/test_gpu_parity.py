@@ -215,3 +215,56 @@ def test_device_resident_entry_point():
     a, p, c = eng.last_kernel_ms()
     assert a > 0 and p > 0
     eng.close()
+
+
+# ---- input staging on the device (format_input of the reference's CLI, src/flac/encode.c:2352-2492) ---------------------
+RAW_FORMATS = [(8, False, True, 0), (8, False, False, 0), (16, False, False, 0), (16, True, False, 0), (16, False, True, 0),
+               (24, False, False, 0), (24, True, False, 0), (24, True, True, 0), (32, False, False, 8), (32, True, True, 8),
+               (16, False, False, 4), (24, True, False, 4)]
+
+
+@pytest.mark.parametrize("fmt", RAW_FORMATS, ids=lambda f: "c%d_%s_%s_sh%d" % (f[0], "be" if f[1] else "le", "u" if f[2] else "s", f[3]))
+def test_raw_staging_matches_format_input_and_encodes_identically(fmt):
+    import torch
+    import flac_amd
+    from rawfmt import format_input, to_raw
+    bits, be, uns, shift = fmt
+    bps = bits - shift
+    channels = 2
+    pcm = signals.music(4096 * 3 + 777, channels, bps, seed=bits + shift)
+    lo, hi = -(1 << (bps - 1)), (1 << (bps - 1)) - 1
+    pcm = np.clip(pcm, lo, hi).astype(np.int32)
+    cmap = [1, 0] if bits == 24 else None
+    raw = to_raw(pcm, bits, be, uns, shift, cmap)
+    assert np.array_equal(format_input(raw, channels, bits, be, uns, shift, cmap), pcm)
+    eng = _engine(channels, bps, 44100, 5, max_batch=16)
+    try:
+        f = flac_amd.raw_format(bits, be, uns, shift, cmap)
+        # the staging kernel alone, device to device
+        d_raw = torch.from_numpy(raw.copy()).cuda()
+        d_pcm = torch.empty(pcm.size, dtype=torch.int32, device="cuda")
+        d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        eng.stage_raw_device(d_raw.data_ptr(), f, pcm.shape[0], d_pcm.data_ptr(), d_err.data_ptr())
+        torch.cuda.synchronize()
+        assert int(d_err.item()) == 0
+        assert np.array_equal(d_pcm.cpu().numpy().reshape(pcm.shape), pcm)
+        # raw host bytes -> frames == int32 host block -> frames
+        want, wfb = eng.encode(pcm)
+        got, gfb = eng.encode_raw(raw, f)
+        assert np.array_equal(gfb, wfb) and got == want
+    finally:
+        eng.close()
+
+
+def test_raw_staging_reports_shift_violation():
+    import flac_amd
+    from rawfmt import to_raw
+    pcm = signals.music(4096, 2, 12, seed=5).astype(np.int32)
+    raw = to_raw(np.clip(pcm, -2048, 2047), 16, False, False, 4).copy()
+    raw[10] |= 1                                       # a bit below the declared shift
+    eng = _engine(2, 12, 44100, 5, max_batch=4)
+    try:
+        with pytest.raises(flac_amd.FlacGpuError, match="non-zero bits"):
+            eng.encode_raw(raw, flac_amd.raw_format(16, False, False, 4))
+    finally:
+        eng.close()
