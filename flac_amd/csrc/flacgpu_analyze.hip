@@ -68,7 +68,7 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
 	int32_t *sig = (int32_t *)smem;
 	const size_t fc = (size_t)f * P.ncand + cand;
-	const uint32_t cstride = P.max_analyses + 1;
+	const uint32_t cstride = P.ncslots;
 
 	uint32_t which = cand;
 	if(P.ms_mode == 2) {
@@ -167,10 +167,7 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 			else if(e3 <= e4) guess_fixed = 3;
 			else guess_fixed = 4;
 		}
-		const uint64_t eg = guess_fixed == 0 ? e0 : guess_fixed == 1 ? e1 : guess_fixed == 2 ? e2 : guess_fixed == 3 ? e3 : e4;
-		// rbps = (float)(log(M_LN2*err/n)/M_LN2) as compiled (fixed.c:284-288)
-		const float rbps_guess = eg ? (float)(log(((double)eg * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
-		const bool rbps1_zero = e1 == 0 || (float)(log(((double)e1 * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) == 0.0f;
+		const bool rbps1_zero = e1 == 0 || fixed_rbps(e1, n4) == 0.0f;
 		bool is_constant = false;
 		if(!disable_constant && rbps1_zero) {
 			uint32_t diff = 0;
@@ -180,28 +177,18 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 			is_constant = diff == 0;
 		}
 		if(is_constant) { flags |= PREP_CONSTANT; constant = sig[sigidx(0)]; }
-		else {
-			if(!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu)) {
-				fixed_order = guess_fixed;
-				if(!(rbps_guess >= (float)sbps)) flags |= PREP_FIXED_VALID;
-			}
-			if(P.max_lpc_order > 0) flags |= PREP_LPC;          // n > 4, so at least order 4 is possible
-		}
+		else if(P.max_lpc_order > 0) flags |= PREP_LPC;          // n > 4, so at least order 4 is possible
+		const bool fixed_allowed = !is_constant && (!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu));
+		fixed_order = fixed_allowed ? guess_fixed : 0;
+		const uint64_t es[5] = {e0, e1, e2, e3, e4};
+		if(tid < 64 && emit_fixed_candidates(P, &cands[fc * cstride], &valid[fc * cstride], es, n4, guess_fixed, fixed_allowed, sbps, tid)) flags |= PREP_FIXED_VALID;
+	}
+	else if(tid < 64) {
+		// n <= 4: no fixed or LPC candidate at all
+		for(uint32_t k = (uint32_t)tid; k < P.nfixed; k += 64) valid[fc * cstride + k] = 0;
 	}
 	// hand-off
-	if(tid < MAX_ORDER) {
-		const uint32_t order = fixed_order;
-		int32_t c = 0;
-		if(order == 1) c = tid == 0 ? 1 : 0;
-		else if(order == 2) c = tid == 0 ? 2 : tid == 1 ? -1 : 0;
-		else if(order == 3) c = tid == 0 ? 3 : tid == 1 ? -3 : tid == 2 ? 1 : 0;
-		else if(order == 4) c = tid == 0 ? 4 : tid == 1 ? -6 : tid == 2 ? 4 : tid == 3 ? -1 : 0;
-		cands[fc * cstride].q[tid] = c;
-	}
 	if(tid == 0) {
-		Candidate *c0 = &cands[fc * cstride];
-		c0->order = fixed_order; c0->precision = 0; c0->shift = 0; c0->wide = 0;
-		valid[fc * cstride] = (flags & PREP_FIXED_VALID) ? 1 : 0;
 		ChanPrep pr;
 		pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
 		pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;
@@ -433,8 +420,9 @@ __global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t 
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const JobTable *jt = is_tail ? jt_tail : jt_main;
 	const ChanPrep pr = preps[fc];
-	const uint32_t cstride = P.max_analyses + 1;
-	int ok = 0;
+	const uint32_t cstride = P.ncslots, aslots = P.norders * P.nprec;
+	Candidate *slots = &cands[(size_t)fc * cstride + P.nfixed + (size_t)a * aslots];
+	int *vslots = &valid[(size_t)fc * cstride + P.nfixed + (size_t)a * aslots];
 	if((pr.flags & PREP_LPC) && a < jt->nanalyses) {
 		const uint32_t n = pr.n;
 		const uint32_t max_lpc = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
@@ -455,9 +443,9 @@ __global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t 
 			}
 			av[j] = v;
 		}
-		ok = lpc_model<MAXORD>(av, max_lpc, n, pr.sbps, P.precision, nullptr, &cands[(size_t)fc * cstride + 1 + a]);
+		lpc_model<MAXORD>(av, max_lpc, n, pr.sbps, P, slots, vslots);
 	}
-	valid[(size_t)fc * cstride + 1 + a] = ok;
+	else for(uint32_t s = 0; s < aslots; s++) vslots[s] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -830,7 +818,13 @@ __host__ __device__ inline uint32_t owner_chan_bytes(uint32_t N, bool packed)
 	return (64 * w * 4 + (CHUNK + MAX_ORDER) * 4 + 15u) & ~15u;
 }
 __host__ __device__ inline bool owner_possible(const DevParams &P) { return P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH; }
-__host__ __device__ inline uint32_t eval_cand_bytes(const DevParams &P) { return (P.max_analyses + 1) * (uint32_t)sizeof(Candidate) + (((P.max_analyses + 1) * 4 + 15u) & ~15u); }
+// candidate records are staged in LDS next to the channel image when there are few of them (every preset); the wide
+// searches (-e, -p: hundreds of slots per channel) read them from global memory and keep only the valid flags in LDS
+__host__ __device__ inline bool eval_cands_in_lds(const DevParams &P) { return P.ncslots <= 48; }
+__host__ __device__ inline uint32_t eval_cand_bytes(const DevParams &P)
+{
+	return (eval_cands_in_lds(P) ? P.ncslots * (uint32_t)sizeof(Candidate) : 0u) + ((P.ncslots * 4 + 15u) & ~15u);
+}
 // worst-case subframe width of candidate channel `cand` (the side channel carries one bit more)
 __host__ __device__ inline uint32_t cand_max_sbps(const DevParams &P, uint32_t cand)
 {
@@ -892,7 +886,8 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const JobTable *jt = is_tail ? jt_tail : jt_main;
 	const uint32_t n = is_tail ? tail_n : N;
-	const uint32_t cstride = P.max_analyses + 1;
+	const uint32_t cstride = P.ncslots, aslots = P.norders * P.nprec;
+	const bool cands_lds = eval_cands_in_lds(P);
 
 	const EvalLayout LY = eval_layout(P, nwaves, cpw, VARIANT == 2);
 	uint64_t *wsums_all = (uint64_t *)(smem + LY.wsums);
@@ -910,15 +905,15 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	// (a short last block whose lane runs are odd while the nominal ones are even would need a wider image than the
 	// launch reserved: it takes the generic path)
 	const bool owner = (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6 && (S % 2 == 0 || (N / 64) % 2 == 1);
-	const uint32_t cand_bytes = eval_cand_bytes(P), cand_valid_off = (P.max_analyses + 1) * (uint32_t)sizeof(Candidate);
+	const uint32_t cand_bytes = eval_cand_bytes(P), cand_valid_off = cands_lds ? P.ncslots * (uint32_t)sizeof(Candidate) : 0u;
 
 	// ---- channel facts ---------------------------------------------------------------------------------------
 	if(tid < (int)cpw) {
 		EvalChan &E = sh->ch[tid];
 		const ChanPrep pr = preps[fc0 + (size_t)tid];
 		E.pr = pr;
-		E.nan = (pr.flags & PREP_LPC) ? jt->nanalyses : 0;
-		E.any = (!(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || E.nan)) ? 1u : 0u;
+		E.nan = P.nfixed + ((pr.flags & PREP_LPC) ? jt->nanalyses * aslots : 0);       // candidate slots of this channel
+		E.any = (!(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || E.nan > P.nfixed)) ? 1u : 0u;
 		const int kind = !E.any ? 0 : owner ? 0 : 2;
 		E.mine = kind == VARIANT ? 1u : 0u;
 		E.packed = (VARIANT == 0 && pr.fmt && (S % 2 == 0)) ? 1u : 0u;
@@ -957,9 +952,9 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			{
 				const uint32_t *src = (const uint32_t *)(cands + fc * cstride);
 				uint32_t *dst = (uint32_t *)(ctx + img_bytes);
-				for(uint32_t t = (uint32_t)tid; t < (E.nan + 1) * (uint32_t)(sizeof(Candidate) / 4); t += nthreads) dst[t] = src[t];
+				if(cands_lds) for(uint32_t t = (uint32_t)tid; t < E.nan * (uint32_t)(sizeof(Candidate) / 4); t += nthreads) dst[t] = src[t];
 				int *vd = (int *)(ctx + img_bytes + cand_valid_off);
-				for(uint32_t t = (uint32_t)tid; t <= E.nan; t += nthreads) vd[t] = valid[fc * cstride + t];
+				for(uint32_t t = (uint32_t)tid; t < E.nan; t += nthreads) vd[t] = valid[fc * cstride + t];
 			}
 			const uint32_t *src = (const uint32_t *)(chan + fc * (size_t)N);       // planar channel, already shifted (ChanPrep::fmt)
 			const uint32_t srcfmt = E.pr.fmt;
@@ -1016,16 +1011,16 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			uint64_t *wsums = wsums_all + (size_t)wave * (2u << P.max_po);
 			uint8_t *kcw = kcandw_all + (size_t)wave * (2u << P.max_po);
 			uint8_t *ktmp = kbestw_all + ((size_t)wave * 2 + 1) * kstride;           // scratch of this wavefront (slot of channel 0)
-			const uint32_t ncmax = jt->nanalyses + 1;
+			const uint32_t ncmax = P.nfixed + jt->nanalyses * aslots;
 			const bool rotate = nwaves % cpw == 0;
 			for(uint32_t item = wave, k = 0; item < cpw * ncmax; item += nwaves, k++) {
 				const uint32_t ci = item / cpw;
 				const uint32_t c = (item - ci * cpw + (rotate ? k : 0)) % cpw;
 				const EvalChan &E = sh->ch[c];
-				if(!E.mine || !E.any || ci > E.nan) continue;
+				if(!E.mine || !E.any || ci >= E.nan) continue;
 				unsigned char *ctx = smem + E.ctx;
 				const uint32_t img_bytes = VARIANT == 2 ? P.sig_bytes : owner_chan_bytes(n, E.packed != 0);
-				const Candidate *cd = (const Candidate *)(ctx + img_bytes) + ci;
+				const Candidate *cd = (cands_lds ? (const Candidate *)(ctx + img_bytes) : cands + (fc0 + c) * cstride) + ci;
 				if(!((const int *)(ctx + img_bytes + cand_valid_off))[ci]) continue;
 				const uint32_t order = cd->order, sbps = E.pr.sbps, hdr = 8 + E.pr.wasted;
 				uint32_t po, rbits;
@@ -1039,7 +1034,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, (const int32_t *)ctx, n, order, q, cd->shift,
 					                                    cd->wide != 0, sbps, P, frame_max_po, frame_min_po, &po, lane);
 				}
-				const uint32_t est = ci == 0 ? sat_add_u32(hdr + order * sbps, rbits)
+				const uint32_t est = ci < P.nfixed ? sat_add_u32(hdr + order * sbps, rbits)
 				                             : sat_add_u32(hdr + 4 + 5 + order * (cd->precision + sbps), rbits);
 				// a wavefront meets the candidates of a channel in increasing order; strict <: the earlier candidate keeps a
 				// tie (stream_encoder.c:4191,4266)
@@ -1073,7 +1068,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 		}
 		const Candidate *mycands = nullptr;
 		if(E.any) {
-			mycands = (const Candidate *)(smem + E.ctx + (VARIANT == 2 ? P.sig_bytes : owner_chan_bytes(n, E.packed != 0)));
+			mycands = cands_lds ? (const Candidate *)(smem + E.ctx + (VARIANT == 2 ? P.sig_bytes : owner_chan_bytes(n, E.packed != 0))) : cands + (fc0 + c) * cstride;
 			uint32_t cb = 0xffffffffu, cci = 0xffffffffu, cw = 0;
 			for(uint32_t w = 0; w < nwaves; w++) {
 				const uint32_t b = sh->wbest_bits[c][w], ci = sh->wbest_ci[c][w];
@@ -1081,7 +1076,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			}
 			if(cci != 0xffffffffu && cb < best_bits) {
 				best_bits = cb; best_ci = cci; best_wave = cw; best_po = sh->wbest_po[c][cw];
-				best_type = cci == 0 ? 2 : 3;
+				best_type = cci < P.nfixed ? 2 : 3;
 				best_order = mycands[cci].order; best_precision = mycands[cci].precision; best_shift = mycands[cci].shift;
 			}
 		}
@@ -1121,7 +1116,7 @@ namespace flacgpu {
 // (channels per workgroup, wavefronts per workgroup) of the owner-layout evaluation
 static void eval_shape(const DevParams &P, uint32_t &cpw, uint32_t &waves)
 {
-	const uint32_t nc = P.max_analyses + 1;
+	const uint32_t nc = P.ncslots;
 	// prefer a multiple of 4 wavefronts with every wavefront busy in every round, and the smallest workgroup that does it
 	cpw = 1; waves = 0;
 	for(uint32_t c = 1; c <= P.ncand && c <= (uint32_t)EVAL_CPW_MAX; c *= 2) {
@@ -1146,7 +1141,7 @@ static void eval_shape(const DevParams &P, uint32_t &cpw, uint32_t &waves)
 }
 static uint32_t eval_waves_generic(const DevParams &P)
 {
-	const uint32_t nc = P.max_analyses + 1;
+	const uint32_t nc = P.ncslots;
 	const uint32_t rounds = (nc + EVAL_MAX_WAVES - 1) / EVAL_MAX_WAVES;
 	uint32_t w = (nc + rounds - 1) / rounds;
 	return w < 1 ? 1 : w;

@@ -241,6 +241,12 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		build_job_table(P, N, &c->h_jobtab[0]);
 		P.wnd_bytes = ((c->h_jobtab[0].wnd_floats + 64) * 4 + 15) & ~15u;
 		P.max_jobs = nj ? nj : 1; P.max_analyses = na;
+		P.exhaustive = cfg->do_exhaustive_model_search ? 1 : 0;
+		P.prec_search = cfg->do_qlp_coeff_prec_search && cfg->max_lpc_order > 0 ? 1 : 0;
+		P.nfixed = P.exhaustive ? 5 : 1;
+		P.norders = P.exhaustive && cfg->max_lpc_order ? cfg->max_lpc_order : 1;
+		P.nprec = P.prec_search ? 11 : 1;
+		P.ncslots = P.nfixed + na * P.norders * P.nprec;
 	}
 	if(analyze_lds_bytes(P) > 160 * 1024 - 1024 || pack_lds_bytes(P) > 160 * 1024 - 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
 
@@ -272,7 +278,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	ok = ok && hipMemcpy(c->d_jobtab, c->h_jobtab, sizeof(JobTable), hipMemcpyHostToDevice) == hipSuccess;
 	if(ok && P.num_apod) ok = hipMemcpy(c->d_windows, windows, wbytes, hipMemcpyHostToDevice) == hipSuccess;
 	{
-		const size_t nfc = B * P.ncand, ncs = P.max_analyses + 1;
+		const size_t nfc = B * P.ncand, ncs = P.ncslots;
 		ok = ok && hipMalloc(&c->ab.prep, nfc * sizeof(ChanPrep)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.autoc, nfc * P.max_jobs * MAX_ORDER * sizeof(double)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.cands, nfc * ncs * sizeof(Candidate)) == hipSuccess;
@@ -322,7 +328,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			const uint32_t f0 = (uint32_t)((uint64_t)nframes * i / nsub), f1 = (uint32_t)((uint64_t)nframes * (i + 1) / nsub), nf = f1 - f0;
 			hipStream_t ss = c->sub_stream[i];
 			(void)hipStreamWaitEvent(ss, c->ev_fork, 0);
-			const size_t fc0 = (size_t)f0 * P.ncand, ncs = P.max_analyses + 1;
+			const size_t fc0 = (size_t)f0 * P.ncand, ncs = P.ncslots;
 			AnalyzeBuffers B = c->ab;
 			B.prep += fc0; B.autoc += fc0 * P.max_jobs * MAX_ORDER; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.blocksize; B.dbg = nullptr;
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;

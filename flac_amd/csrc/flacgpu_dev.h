@@ -29,6 +29,13 @@ struct DevParams {
 	uint32_t sig_bytes;        // LDS bytes of the padded signal array
 	uint32_t wnd_bytes;        // LDS bytes of the windowed-signal array (all window jobs of a subframe)
 	uint32_t max_jobs, max_analyses; // window jobs / LPC analyses per subframe at the nominal blocksize
+	// candidate slots of a subframe, in the reference's evaluation order (stream_encoder.c:4155-4266): nfixed fixed
+	// orders, then per analysis norders LPC orders x nprec coefficient precisions
+	uint32_t exhaustive, prec_search;
+	uint32_t nfixed;           // 1 (the guessed order) or 5 (-e: orders 0..4)
+	uint32_t norders;          // 1 (the guessed order) or max_lpc_order (-e: orders 1..max)
+	uint32_t nprec;            // 1 or 11 (-p: precisions 5..15)
+	uint32_t ncslots;          // nfixed + max_analyses * norders * nprec
 };
 
 // analysis -> pack hand-off, one per (frame, candidate channel); 16-byte multiple
@@ -86,7 +93,7 @@ struct ChanPrep {
 struct AnalyzeBuffers {
 	ChanPrep *prep;            // [frames*ncand]
 	double *autoc;             // [frames*ncand][max_jobs][MAX_ORDER]
-	Candidate *cands;          // [frames*ncand][max_analyses+1]: [0] fixed, [1+a] LPC analysis a
+	Candidate *cands;          // [frames*ncand][ncslots]: fixed orders, then analysis a / order / precision (DevParams::ncslots)
 	int *valid;                // same shape
 	int32_t *chan;             // [frames*ncand][blocksize] planar channel signals, wasted bits shifted out (ChanPrep::fmt)
 	unsigned long long *dbg;   // FLACGPU_DEBUG_TIMING=1: [frames*ncand][16] s_memtime stamps of the eval kernel (else null)

@@ -160,50 +160,12 @@ __device__ __forceinline__ uint32_t levinson(const double (&a)[MAXORD + 1], uint
 	return used;
 }
 
-// autoc: lag values of this analysis (already punched-out when applicable). rows: MAXORD*MAXORD floats of
-// LDS scratch private to this lane, or null (then the recursion is simply run twice). Returns 0 when no LPC
-// candidate results (autoc[0]==0, estimate >= bps, quantiser failure, residual would need the >32-bit
-// "limit_residual" flavour).
+// evaluate_lpc_subframe_'s front end for one (order, precision): precision clamp (stream_encoder.c:4591-4595),
+// FLAC__lpc_quantize_coefficients (lpc.c:220-314), residual-width selector (stream_encoder.c:4601-4617, lpc.c:942-976).
+// Returns 0 when no candidate results (quantiser failure; residual would need the >32-bit "limit_residual" flavour).
 template <int MAXORD>
-__device__ int lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint32_t n, uint32_t sbps,
-                         uint32_t cfg_precision, float *rows, Candidate *out)
+__device__ __forceinline__ int quantize_candidate(const float (&coef)[MAXORD], uint32_t order, uint32_t precision, uint32_t sbps, Candidate *out)
 {
-	double lpc[MAXORD], errs[MAXORD];
-	if(a[0] == 0.0) return 0;
-#pragma unroll
-	for(int i = 0; i < MAXORD; i++) { lpc[i] = 0.0; errs[i] = 0.0; }
-	const uint32_t used = rows ? levinson<MAXORD, true>(a, max_order, lpc, errs, rows) : levinson<MAXORD, false>(a, max_order, lpc, errs, rows);
-	// FLAC__lpc_compute_best_order (lpc.c:1608): total_samples is the full blocksize
-	uint32_t order = 1;
-	double err_order = errs[0];
-	{
-		const double scale = 0.5 / (double)n;
-		const uint32_t overhead = sbps + cfg_precision;
-		double best_bits = 4294967295.0;
-#pragma unroll
-		for(int idx = 0; idx < MAXORD; idx++) {
-			if((uint32_t)idx < used) {
-				const uint32_t o = (uint32_t)idx + 1;
-				const double bits = expected_bits_scaled(errs[idx], scale) * (double)(n - o) + (double)(o * overhead);
-				if(bits < best_bits) { order = o; best_bits = bits; err_order = errs[idx]; }
-			}
-		}
-	}
-	// stream_encoder.c:4227-4229
-	if(expected_bits_scaled(err_order, 0.5 / (double)(n - order)) >= (double)sbps) return 0;
-	float coef[MAXORD];
-	if(rows) {
-#pragma unroll
-		for(int j = 0; j < MAXORD; j++) coef[j] = (uint32_t)j < order ? rows[(order - 1) * MAXORD + j] : 0.0f;
-	}
-	else {
-		// coefficients of `order`: rerun the (deterministic) recursion up to that order
-		(void)levinson<MAXORD, false>(a, order, lpc, errs, rows);
-#pragma unroll
-		for(int j = 0; j < MAXORD; j++) coef[j] = (uint32_t)j < order ? (float)(-lpc[j]) : 0.0f;
-	}
-	// stream_encoder.c:4591-4595 then FLAC__lpc_quantize_coefficients (lpc.c:220)
-	uint32_t precision = cfg_precision;
 	if(sbps <= 17) precision = umin32(precision, 32 - sbps - ilog2_u32(order));
 	int shift;
 	int32_t q[MAXORD];
@@ -237,7 +199,6 @@ __device__ int lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint
 		}
 		if(neg) shift = 0;
 	}
-	// residual kernel selector (stream_encoder.c:4601-4617, lpc.c:942-976)
 	{
 		uint32_t abs_sum = 0;
 #pragma unroll
@@ -254,6 +215,89 @@ __device__ int lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint
 	out->precision = precision;
 	out->shift = shift;
 	return 1;
+}
+// the candidates of one LPC order: the configured precision, or with -p every precision 5..max (stream_encoder.c:4230-4243)
+template <int MAXORD>
+__device__ __forceinline__ void emit_order_candidates(const float (&coef)[MAXORD], uint32_t order, uint32_t sbps, const DevParams &P, Candidate *slots, int *vslots)
+{
+	if(!P.prec_search) { vslots[0] = quantize_candidate<MAXORD>(coef, order, P.precision, sbps, &slots[0]); return; }
+	uint32_t maxp = 15;
+	if(sbps <= 17) { maxp = umin32(32 - sbps - ilog2_u32(order), 15); if(maxp < 5) maxp = 5; }
+	for(uint32_t prec = 5; prec <= maxp; prec++) vslots[prec - 5] = quantize_candidate<MAXORD>(coef, order, prec, sbps, &slots[prec - 5]);
+}
+
+// One LPC analysis (autocorrelation a[], already punched-out when applicable) -> its candidate slots
+// [norders][nprec] and their valid flags.  Normally one slot: the guessed order (lpc.c:1608) at the configured
+// precision; -e emits every order 1..max as the recursion produces it; -p every precision.
+template <int MAXORD>
+__device__ void lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint32_t n, uint32_t sbps, const DevParams &P,
+                          Candidate *slots, int *vslots)
+{
+	const uint32_t nslots = P.norders * P.nprec;
+	for(uint32_t s = 0; s < nslots; s++) vslots[s] = 0;
+	if(a[0] == 0.0) return;
+	double lpc[MAXORD], errs[MAXORD];
+#pragma unroll
+	for(int i = 0; i < MAXORD; i++) { lpc[i] = 0.0; errs[i] = 0.0; }
+	if(P.exhaustive) {
+		// the recursion of levinson<> with the candidates of order i+1 emitted as soon as its coefficients exist
+		double err = a[0];
+		uint32_t used = max_order;
+#pragma unroll
+		for(int i = 0; i < MAXORD; i++) {
+			if((uint32_t)i < used) {
+				double r = -a[i + 1];
+#pragma unroll
+				for(int j = 0; j < i; j++) r -= lpc[j] * a[i - j];
+				r /= err;
+				lpc[i] = r;
+#pragma unroll
+				for(int j = 0; j < (i >> 1); j++) {
+					const double tmp = lpc[j];
+					lpc[j] += r * lpc[i - 1 - j];
+					lpc[i - 1 - j] += r * tmp;
+				}
+				if(i & 1) lpc[i >> 1] = (r + 1.0) * lpc[i >> 1];
+				err *= (1.0 - r * r);
+				if(err == 0.0) used = (uint32_t)i + 1;
+				const uint32_t order = (uint32_t)i + 1;
+				// stream_encoder.c:4227-4229
+				if(!(expected_bits_scaled(err, 0.5 / (double)(n - order)) >= (double)sbps)) {
+					float coef[MAXORD];
+#pragma unroll
+					for(int j = 0; j < MAXORD; j++) coef[j] = j <= i ? (float)(-lpc[j]) : 0.0f;
+					emit_order_candidates<MAXORD>(coef, order, sbps, P, slots + (size_t)i * P.nprec, vslots + (size_t)i * P.nprec);
+				}
+			}
+		}
+		return;
+	}
+	const uint32_t used = levinson<MAXORD, false>(a, max_order, lpc, errs, nullptr);
+	// FLAC__lpc_compute_best_order (lpc.c:1608): total_samples is the full blocksize; with -p the overhead is priced
+	// at the smallest precision (stream_encoder.c:4384-4388)
+	uint32_t order = 1;
+	double err_order = errs[0];
+	{
+		const double scale = 0.5 / (double)n;
+		const uint32_t overhead = sbps + (P.prec_search ? 5u : P.precision);
+		double best_bits = 4294967295.0;
+#pragma unroll
+		for(int idx = 0; idx < MAXORD; idx++) {
+			if((uint32_t)idx < used) {
+				const uint32_t o = (uint32_t)idx + 1;
+				const double bits = expected_bits_scaled(errs[idx], scale) * (double)(n - o) + (double)(o * overhead);
+				if(bits < best_bits) { order = o; best_bits = bits; err_order = errs[idx]; }
+			}
+		}
+	}
+	// stream_encoder.c:4227-4229
+	if(expected_bits_scaled(err_order, 0.5 / (double)(n - order)) >= (double)sbps) return;
+	// coefficients of `order`: rerun the (deterministic) recursion up to that order
+	(void)levinson<MAXORD, false>(a, order, lpc, errs, nullptr);
+	float coef[MAXORD];
+#pragma unroll
+	for(int j = 0; j < MAXORD; j++) coef[j] = (uint32_t)j < order ? (float)(-lpc[j]) : 0.0f;
+	emit_order_candidates<MAXORD>(coef, order, sbps, P, slots, vslots);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -451,6 +495,38 @@ __device__ __forceinline__ void fir_chunk_dispatch(const int32_t *sig, int base,
 	else fir_chunk<MAXORD, 2>(sig, base, q, shift, r);
 }
 __device__ __forceinline__ int fir_mode(bool wide, uint32_t sbps) { return wide ? 2 : (sbps <= 24 ? 0 : 1); }
+
+// ---------------------------------------------------------------------------------------------
+// fixed-predictor candidates of a subframe (stream_encoder.c:4153-4190): the guessed order, or with -e every
+// order 0..4, each skipped when its estimate rbps[order] = (float)(log(M_LN2*err/n)/M_LN2) (as compiled,
+// fixed.c:284-288) is not below the sample width.  Called by all lanes of one wavefront / the first 64 threads.
+// e[k]: error sums of the SHIFTED signal.  Returns true when at least one candidate is valid.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fixed_rbps(uint64_t e, uint32_t n4)
+{
+	return e ? (float)(log(((double)e * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
+}
+__device__ __forceinline__ bool emit_fixed_candidates(const DevParams &P, Candidate *c0, int *v0, const uint64_t (&e)[5], uint32_t n4, uint32_t guess,
+                                                      bool allowed, uint32_t sbps, int lane)
+{
+	bool any = false;
+	for(uint32_t k = 0; k < P.nfixed; k++) {
+		const uint32_t order = P.exhaustive ? k : guess;
+		const uint64_t eo = order == 0 ? e[0] : order == 1 ? e[1] : order == 2 ? e[2] : order == 3 ? e[3] : e[4];
+		const bool ok = allowed && !(fixed_rbps(eo, n4) >= (float)sbps);
+		any = any || ok;
+		if(lane < MAX_ORDER) {
+			int32_t c = 0;
+			if(order == 1) c = lane == 0 ? 1 : 0;
+			else if(order == 2) c = lane == 0 ? 2 : lane == 1 ? -1 : 0;
+			else if(order == 3) c = lane == 0 ? 3 : lane == 1 ? -3 : lane == 2 ? 1 : 0;
+			else if(order == 4) c = lane == 0 ? 4 : lane == 1 ? -6 : lane == 2 ? 4 : lane == 3 ? -1 : 0;
+			c0[k].q[lane] = c;
+		}
+		if(lane == 0) { c0[k].order = order; c0[k].precision = 0; c0[k].shift = 0; c0[k].wide = 0; v0[k] = ok ? 1 : 0; }
+	}
+	return any;
+}
 
 // ---------------------------------------------------------------------------------------------
 // integer FIR building blocks shared by the evaluation and pack kernels

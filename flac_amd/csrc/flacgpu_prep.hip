@@ -80,7 +80,7 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
 	const bool stereo_ms = C == 2 && P.ms_mode != 0;
 	const uint32_t G = stereo_ms ? 2u : (C < 4 ? C : 4u);            // raw channels staged per round
-	const uint32_t cstride = P.max_analyses + 1;
+	const uint32_t cstride = P.ncslots;
 	const uint32_t nchunks = n / CHUNK;
 	const uint32_t TS = p2_ts(n), cbytes = p2_chan_bytes(n);
 	const bool need_flags = P.limit_min_bitrate || P.ms_mode == 2;
@@ -197,35 +197,19 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 				else if(e3 <= e4) guess_fixed = 3;
 				else guess_fixed = 4;
 			}
-			const uint64_t eg = guess_fixed == 0 ? e0 : guess_fixed == 1 ? e1 : guess_fixed == 2 ? e2 : guess_fixed == 3 ? e3 : e4;
-			// rbps = (float)(log(M_LN2*err/n)/M_LN2) as compiled (fixed.c:284-288)
-			const float rbps_guess = eg ? (float)(log(((double)eg * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
 			// CONSTANT needs rbps[1] == 0 and all samples equal (stream_encoder.c:4111-4140); all equal implies e1 == 0
 			const bool is_constant = !disable_constant && A.diff == 0;
+			const size_t fcx = (size_t)f * P.ncand + cand;
 			if(is_constant) { flags |= PREP_CONSTANT; constant = first >> wasted; }
-			else {
-				if(!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu)) {
-					fixed_order = guess_fixed;
-					if(!(rbps_guess >= (float)sbps)) flags |= PREP_FIXED_VALID;
-				}
-				if(P.max_lpc_order > 0) flags |= PREP_LPC;
-			}
+			else if(P.max_lpc_order > 0) flags |= PREP_LPC;
+			const bool fixed_allowed = !is_constant && (!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu));
+			fixed_order = fixed_allowed ? guess_fixed : 0;
+			const uint64_t es[5] = {e0, e1, e2, e3, e4};
+			if(emit_fixed_candidates(P, &cands[fcx * cstride], &valid[fcx * cstride], es, n4, guess_fixed, fixed_allowed, sbps, lane)) flags |= PREP_FIXED_VALID;
 		}
 		const uint32_t fmt = sbps <= 16 ? 1u : 0u;
 		const size_t fc = (size_t)f * P.ncand + cand;
-		if(lane < MAX_ORDER) {
-			const uint32_t order = fixed_order;
-			int32_t c = 0;
-			if(order == 1) c = lane == 0 ? 1 : 0;
-			else if(order == 2) c = lane == 0 ? 2 : lane == 1 ? -1 : 0;
-			else if(order == 3) c = lane == 0 ? 3 : lane == 1 ? -3 : lane == 2 ? 1 : 0;
-			else if(order == 4) c = lane == 0 ? 4 : lane == 1 ? -6 : lane == 2 ? 4 : lane == 3 ? -1 : 0;
-			cands[fc * cstride].q[lane] = c;
-		}
 		if(lane == 0) {
-			Candidate *cd0 = &cands[fc * cstride];
-			cd0->order = fixed_order; cd0->precision = 0; cd0->shift = 0; cd0->wide = 0;
-			valid[fc * cstride] = (flags & PREP_FIXED_VALID) ? 1 : 0;
 			ChanPrep pr;
 			pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
 			pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;

@@ -155,8 +155,7 @@ int flacgpu_host_settings_resolve(flacgpu_host_settings *s)
 int flacgpu_host_engine_config(const flacgpu_host_settings *s, int device, uint32_t max_batch_frames, flacgpu_config *c)
 {
 	memset(c, 0, sizeof *c);
-	/* searches the GPU engine does not implement (-e, -p): refuse loudly, never fall back */
-	if(s->do_exhaustive_model_search || s->do_qlp_coeff_prec_search) return FLACGPU_ERR_UNSUPPORTED;
+	/* escape coding is a no-op in production builds of the reference (stream_encoder.c:2107-2114) */
 	if(s->max_lpc_order > 0 && s->num_apodizations > FLACGPU_MAX_APODIZATIONS) return FLACGPU_ERR_UNSUPPORTED;
 	c->abi_version = FLACGPU_ABI_VERSION;
 	c->channels = s->channels; c->bits_per_sample = s->bits_per_sample; c->sample_rate = s->sample_rate;
@@ -175,6 +174,8 @@ int flacgpu_host_engine_config(const flacgpu_host_settings *s, int device, uint3
 	c->disable_fixed_subframes = (uint32_t)s->disable_fixed_subframes;
 	c->disable_verbatim_subframes = (uint32_t)s->disable_verbatim_subframes;
 	c->limit_min_bitrate = (uint32_t)s->limit_min_bitrate;
+	c->do_exhaustive_model_search = s->do_exhaustive_model_search ? 1 : 0;
+	c->do_qlp_coeff_prec_search = s->do_qlp_coeff_prec_search ? 1 : 0;
 	c->device = device;
 	c->max_batch_frames = max_batch_frames;
 	return FLACGPU_OK;

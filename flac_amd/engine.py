@@ -50,6 +50,7 @@ class EngineConfig(C.Structure):
         ("disable_constant_subframes", C.c_uint32), ("disable_fixed_subframes", C.c_uint32),
         ("disable_verbatim_subframes", C.c_uint32), ("limit_min_bitrate", C.c_uint32),
         ("device", C.c_int32), ("max_batch_frames", C.c_uint32),
+        ("do_exhaustive_model_search", C.c_uint32), ("do_qlp_coeff_prec_search", C.c_uint32),
     ]
 
 
@@ -145,7 +146,7 @@ def load_engine():
 
 def make_settings(channels=2, bps=16, rate=44100, level=5, blocksize=0, apodization=None, limit_min_bitrate=0,
                   max_lpc_order=None, max_partition_order=None, min_partition_order=None, mid_side=None,
-                  loose_mid_side=None, qlp_coeff_precision=None, streamable_subset=1):
+                  loose_mid_side=None, qlp_coeff_precision=None, streamable_subset=1, exhaustive=0, prec_search=0):
     """Mirrors the order of the FLAC__stream_encoder_set_* calls a client makes before init."""
     h = load_host()
     s = HostSettings()
@@ -170,6 +171,8 @@ def make_settings(channels=2, bps=16, rate=44100, level=5, blocksize=0, apodizat
     if apodization:
         h.flacgpu_host_settings_apodization(C.byref(s), apodization.encode())
     s.limit_min_bitrate = limit_min_bitrate
+    s.do_exhaustive_model_search = 1 if exhaustive else 0
+    s.do_qlp_coeff_prec_search = 1 if prec_search else 0
     st = h.flacgpu_host_settings_resolve(C.byref(s))
     if st != 0:
         raise FlacGpuError("invalid encoder settings: FLAC__StreamEncoderInitStatus %d" % st)

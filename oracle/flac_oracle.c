@@ -575,7 +575,7 @@ static int apply_apodization(const fo_config *cfg, apod_state *st, const int32_t
 	}
 	if(st->autoc[0] == 0.0) return 0;
 	fo_lp_coefficients(st->autoc, max_order, lp, lpc_error);
-	*guess = fo_best_order(lpc_error, *max_order, N, subframe_bps + cfg->qlp_coeff_precision);
+	*guess = fo_best_order(lpc_error, *max_order, N, subframe_bps + (cfg->prec_search ? 5 : cfg->qlp_coeff_precision) /* :4384-4388 */);
 	return 1;
 }
 
@@ -608,10 +608,12 @@ static void process_subframe(const fo_config *cfg, const int32_t *sig /* already
 		}
 		else {
 			if(!cfg->disable_fixed || (cfg->max_lpc_order == 0 && best_bits == 0xffffffffu)) {
-				uint32_t order = guess_fixed;
-				if(order >= N) order = N - 1;
-				if(!(rbps[order] >= (float)subframe_bps)) {
+				/* -e tries every fixed order, else the guessed one (stream_encoder.c:4155-4166) */
+				uint32_t min_fixed = cfg->exhaustive ? 0 : guess_fixed, max_fixed = cfg->exhaustive ? 4 : guess_fixed;
+				if(max_fixed >= N) max_fixed = N - 1;
+				for(uint32_t order = min_fixed; order <= max_fixed; order++) {
 					uint32_t po, rbits, est;
+					if(rbps[order] >= (float)subframe_bps) continue;
 					fixed_residual(sig + order, N - order, order, residual);
 					rbits = fo_rice_search(residual, N - order, order, rice_limit, min_po, max_po, subframe_bps, &po, cand->params);
 					est = hdr + order * subframe_bps;
@@ -634,30 +636,42 @@ static void process_subframe(const fo_config *cfg, const int32_t *sig /* already
 						uint32_t max_this = max_lpc, guess = 0;
 						if(!apply_apodization(cfg, &st, sig, windowed, &max_this, subframe_bps, lp, lpc_error, &guess))
 							continue;
-						{
-							const uint32_t order = guess;
-							uint32_t precision = cfg->qlp_coeff_precision, po, rbits, est;
-							int32_t q[FO_MAX_LPC_ORDER];
-							int shift;
+						/* -e: every order 1..max_this (which the recursion may have shortened), else the guessed one (:4220-4226) */
+						for(uint32_t order = cfg->exhaustive ? 1 : guess; order <= (cfg->exhaustive ? max_this : guess); order++) {
+							uint32_t min_prec, max_prec;
 							if(fo_expected_bits_per_residual_sample(lpc_error[order - 1], N - order) >= (double)subframe_bps)
 								continue;
-							if(subframe_bps <= 17) precision = umin(precision, 32 - subframe_bps - ilog2_u32(order)); /* :4591 */
-							memset(q, 0, sizeof q);
-							if(fo_quantize_coefficients(lp[order - 1], order, precision, q, &shift) != 0)
-								continue;
-							if(max_residual_bps(subframe_bps, q, order, shift) > 32)
-								continue; /* limit_residual flavours: outside this restatement's bps range */
-							lpc_residual(sig + order, N - order, q, order, shift,
-							             max_prediction_before_shift_bps(subframe_bps, q, order) > 32, residual);
-							rbits = fo_rice_search(residual, N - order, order, rice_limit, min_po, max_po, subframe_bps, &po, cand->params);
-							est = hdr + 4 + 5 + order * (precision + subframe_bps);
-							est = rbits < 0xffffffffu - est ? est + rbits : 0xffffffffu;
-							if(est > 0 && est < best_bits) {
-								uint32_t *t = best->params; best->params = cand->params; cand->params = t;
-								best->s.type = 3; best->s.order = order; best->s.partition_order = po;
-								best->s.precision = precision; best->s.shift = shift;
-								memcpy(best->s.qlp, q, sizeof q);
-								best_bits = est;
+							if(cfg->prec_search) {           /* :4230-4240 */
+								min_prec = 5;
+								if(subframe_bps <= 17) {
+									max_prec = umin(32 - subframe_bps - ilog2_u32(order), 15);
+									if(max_prec < min_prec) max_prec = min_prec;
+								}
+								else max_prec = 15;
+							}
+							else min_prec = max_prec = cfg->qlp_coeff_precision;
+							for(uint32_t prec = min_prec; prec <= max_prec; prec++) {
+								uint32_t precision = prec, po, rbits, est;
+								int32_t q[FO_MAX_LPC_ORDER];
+								int shift;
+								if(subframe_bps <= 17) precision = umin(precision, 32 - subframe_bps - ilog2_u32(order)); /* :4591 */
+								memset(q, 0, sizeof q);
+								if(fo_quantize_coefficients(lp[order - 1], order, precision, q, &shift) != 0)
+									continue;
+								if(max_residual_bps(subframe_bps, q, order, shift) > 32)
+									continue; /* limit_residual flavours: outside this restatement's bps range */
+								lpc_residual(sig + order, N - order, q, order, shift,
+								             max_prediction_before_shift_bps(subframe_bps, q, order) > 32, residual);
+								rbits = fo_rice_search(residual, N - order, order, rice_limit, min_po, max_po, subframe_bps, &po, cand->params);
+								est = hdr + 4 + 5 + order * (precision + subframe_bps);
+								est = rbits < 0xffffffffu - est ? est + rbits : 0xffffffffu;
+								if(est > 0 && est < best_bits) {
+									uint32_t *t = best->params; best->params = cand->params; cand->params = t;
+									best->s.type = 3; best->s.order = order; best->s.partition_order = po;
+									best->s.precision = precision; best->s.shift = shift;
+									memcpy(best->s.qlp, q, sizeof q);
+									best_bits = est;
+								}
 							}
 						}
 					}

@@ -54,6 +54,8 @@ typedef struct {
 	uint32_t autoc_variant;         /* FO_AUTOC_*; blocksize<=32 forces GENERIC (stream_encoder.c:2978) */
 	uint32_t disable_constant, disable_fixed, disable_verbatim;
 	uint32_t limit_min_bitrate;
+	uint32_t exhaustive;            /* -e: every fixed order 0..4 and every LPC order 1..max (stream_encoder.c:4155-4163,4220-4226) */
+	uint32_t prec_search;           /* -p: every coefficient precision 5..max (stream_encoder.c:4230-4243) */
 } fo_config;
 
 typedef struct {

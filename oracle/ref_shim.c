@@ -65,6 +65,7 @@ typedef struct {
 	int32_t min_partition_order, max_partition_order; /* -1 = keep preset */
 	int32_t mid_side, loose_mid_side; /* -1 = keep preset */
 	const char *apodization;  /* NULL = keep preset */
+	int32_t exhaustive, prec_search; /* -e / -p: FLAC__stream_encoder_set_do_exhaustive_model_search / _qlp_coeff_prec_search */
 } ref_cfg_t;
 
 static FLAC__StreamEncoder *make_encoder(const ref_cfg_t *cfg, uint64_t total_samples)
@@ -84,6 +85,8 @@ static FLAC__StreamEncoder *make_encoder(const ref_cfg_t *cfg, uint64_t total_sa
 	if(cfg->mid_side >= 0) FLAC__stream_encoder_set_do_mid_side_stereo(e, cfg->mid_side ? true : false);
 	if(cfg->loose_mid_side >= 0) FLAC__stream_encoder_set_loose_mid_side_stereo(e, cfg->loose_mid_side ? true : false);
 	if(cfg->apodization) FLAC__stream_encoder_set_apodization(e, cfg->apodization);
+	if(cfg->exhaustive > 0) FLAC__stream_encoder_set_do_exhaustive_model_search(e, true);
+	if(cfg->prec_search > 0) FLAC__stream_encoder_set_do_qlp_coeff_prec_search(e, true);
 	FLAC__stream_encoder_set_limit_min_bitrate(e, cfg->limit_min_bitrate ? true : false);
 	FLAC__stream_encoder_set_do_md5(e, cfg->do_md5 ? true : false);
 	FLAC__stream_encoder_set_total_samples_estimate(e, total_samples);

@@ -21,7 +21,20 @@ def golden_cases():
     for freq in (441.0, 1000.0, 997.0, 11025.0):
         for level in (5, 8):
             cases.append(dict(family="sine", n=4096 * 4, channels=1, bps=16, rate=44100, level=level, freq=freq))
+    # the wider model searches: -e (every fixed / LPC order) and -p (every coefficient precision)
+    for level in (3, 5, 8):
+        for ex, ps in ((1, 0), (0, 1), (1, 1)):
+            cases.append(dict(family="music", n=4096 * 2 + 411, channels=2, bps=16, rate=44100, level=level, exhaustive=ex, prec_search=ps))
+    for ex, ps in ((1, 0), (1, 1)):
+        cases.append(dict(family="mixed", n=4096 * 2 + 33, channels=2, bps=16, rate=44100, level=8, exhaustive=ex, prec_search=ps))
+        cases.append(dict(family="music", n=4096 + 200, channels=2, bps=24, rate=96000, level=8, exhaustive=ex, prec_search=ps))
+        cases.append(dict(family="sine", n=4096 * 2, channels=1, bps=16, rate=44100, level=5, exhaustive=ex, prec_search=ps))
     return cases
+
+
+def case_search(c):
+    """keyword arguments selecting the wider searches, for pyoracle / make_settings alike"""
+    return dict(exhaustive=c.get("exhaustive", 0), prec_search=c.get("prec_search", 0))
 
 
 def case_key(c):

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, HERE)
 from oracle import pyoracle as po
-from cases import golden_cases, case_key, case_pcm
+from cases import golden_cases, case_key, case_pcm, case_search
 
 def main():
     po.build(ref=True)
@@ -16,7 +16,7 @@ def main():
                      "compiler": subprocess.check_output(["gcc", "--version"]).decode().splitlines()[0],
                      "flags": "-O3 -DNDEBUG -fassociative-math -fno-signed-zeros -fno-trapping-math -freciprocal-math; FMA+AVX2 dispatch"}}
     for c in golden_cases():
-        r = po.ref_encode(case_pcm(c), c["bps"], c["rate"], c["level"])
+        r = po.ref_encode(case_pcm(c), c["bps"], c["rate"], c["level"], **case_search(c))
         frames = r["data"][r["header_bytes"]:]
         out[case_key(c)] = {"sha256": hashlib.sha256(frames).hexdigest(), "frames": int(len(r["frame_bytes"])), "bytes": len(frames)}
     with open(os.path.join(HERE, "frames.json"), "w") as f:

@@ -49,10 +49,16 @@ def test_settings_resolution_matches_reference_defaults():
 
 
 def test_unsupported_configuration_is_refused_not_emulated():
-    s = engine.make_settings(2, 16, 44100, 8)
-    s.do_exhaustive_model_search = 1
+    s = engine.make_settings(2, 16, 44100, 8, apodization=";".join(["hann"] * 9))      # more window functions than the engine takes
     cfg = engine.EngineConfig()
     assert engine.load_host().flacgpu_host_engine_config(C.byref(s), 0, 16, C.byref(cfg)) == -1
+
+
+def test_wider_searches_reach_the_engine_config():
+    s = engine.make_settings(2, 16, 44100, 8, exhaustive=1, prec_search=1)
+    cfg = engine.EngineConfig()
+    assert engine.load_host().flacgpu_host_engine_config(C.byref(s), 0, 16, C.byref(cfg)) == 0
+    assert (cfg.abi_version, cfg.do_exhaustive_model_search, cfg.do_qlp_coeff_prec_search) == (2, 1, 1)
 
 
 def test_no_device_fails_loudly():

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import signals
-from cases import golden_cases, case_key, case_pcm
+from cases import golden_cases, case_key, case_pcm, case_search
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -43,7 +43,7 @@ def test_extension_is_loaded_and_device_present():
 @pytest.mark.parametrize("case", golden_cases(), ids=case_key)
 def test_gpu_matches_reference_golden(case):
     want = GOLDEN[case_key(case)]
-    data, fb = _gpu_encode(case_pcm(case), case["bps"], case["rate"], case["level"])
+    data, fb = _gpu_encode(case_pcm(case), case["bps"], case["rate"], case["level"], **case_search(case))
     assert len(fb) == want["frames"]
     assert len(data) == want["bytes"]
     assert hashlib.sha256(data).hexdigest() == want["sha256"]
@@ -268,3 +268,18 @@ def test_raw_staging_reports_shift_violation():
             eng.encode_raw(raw, flac_amd.raw_format(16, False, False, 4))
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("mode", [(1, 0), (0, 1), (1, 1)], ids=["e", "p", "ep"])
+@pytest.mark.parametrize("level", [0, 2, 3, 4, 6, 7, 8])
+def test_wider_model_searches_match_oracle(level, mode):
+    """-e / -p (stream_encoder.c:4155-4163, 4220-4243): every frame equal to the oracle's, incl. a short last block"""
+    ex, ps = mode
+    for fam, bps, rate in (("music", 16, 44100), ("mixed", 16, 44100), ("wasted", 16, 44100), ("music", 24, 96000)):
+        if bps == 24 and level not in (3, 8):
+            continue
+        pcm = signals.FAMILIES[fam](4096 * 2 + 700, 2, bps, seed=level + 3) if fam != "wasted" else signals.FAMILIES[fam](4096 * 2 + 700, 2, bps)
+        data, fb = _gpu_encode(pcm, bps, rate, level, exhaustive=ex, prec_search=ps, max_batch=64)
+        o = po.oracle_encode(pcm, bps, rate, level, exhaustive=ex, prec_search=ps)
+        assert np.array_equal(fb, o["frame_bytes"]), (fam, bps, level, mode)
+        assert data == o["data"], (fam, bps, level, mode)

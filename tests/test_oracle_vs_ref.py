@@ -176,3 +176,19 @@ def test_limit_min_bitrate_and_channels(ref):
         pcm = signals.music(4096 * 2 + 50, ch, 16, seed=ch)
         r = po.ref_encode(pcm, 16, 48000, 8)
         assert po.oracle_encode(pcm, 16, 48000, 8)["data"] == _frames(r)
+
+
+@pytest.mark.parametrize("mode", [(1, 0), (0, 1), (1, 1)], ids=["e", "p", "ep"])
+@pytest.mark.parametrize("level", [3, 5, 8])
+def test_exhaustive_and_precision_search(ref, level, mode):
+    """-e (every fixed order, every LPC order) and -p (every coefficient precision), stream_encoder.c:4155-4243."""
+    ex, ps = mode
+    cases = [("music", 16, 44100), ("mixed", 16, 44100), ("sine", 16, 44100)]
+    if level == 8:
+        cases.append(("music", 24, 96000))
+    for fam, bps, rate in cases:
+        n = 4096 * 2 + 411 if not (ex and ps) else 4096 + 411
+        pcm = signals.FAMILIES[fam](n, 2, bps)
+        r = po.ref_encode(pcm, bps, rate, level, exhaustive=ex, prec_search=ps)
+        o = po.oracle_encode(pcm, bps, rate, level, exhaustive=ex, prec_search=ps)
+        assert o["data"] == _frames(r), (fam, bps, level, mode)

@@ -294,7 +294,16 @@ def test_out_of_range_sample_is_a_client_error_and_unsupported_features_are_refu
     pcm[4000, 1] = 40000
     with pytest.raises(RuntimeError, match="CLIENT_ERROR"):
         fa.encode("gpu", pcm, 16, 44100, 5)
-    for settings in ((("set_verify", 1),), (("set_do_exhaustive_model_search", 1),), (("set_do_qlp_coeff_prec_search", 1),)):
+    for settings in ((("set_verify", 1),),):
         with pytest.raises(RuntimeError, match="init status 1"):
             fa.encode("gpu", pcm[:100], 16, 44100, 5, settings=settings)
     assert lib is not None
+
+
+@gpu
+def test_wider_model_searches_through_the_api():
+    """flac -5e / -5p / -8ep: whole files identical to the reference's"""
+    pcm = signals.music(4096 * 3 + 99, 2, 16, seed=8)
+    for level, settings in ((5, (("set_do_exhaustive_model_search", 1),)), (5, (("set_do_qlp_coeff_prec_search", 1),)),
+                            (8, (("set_do_exhaustive_model_search", 1), ("set_do_qlp_coeff_prec_search", 1)))):
+        _same_file(pcm, 16, 44100, level, settings=settings, chunk=3000)
