@@ -53,7 +53,7 @@ def synth_pcm(nframes, seed):
     return np.ascontiguousarray(base[: nframes * BLOCK])
 
 
-def cpu_baseline(sample_pcm):
+def cpu_baseline(sample_pcm, search=None):
     """Reference libFLAC on the host cores: single thread, then many independent encoders."""
     from oracle import pyoracle as po
     from concurrent.futures import ThreadPoolExecutor
@@ -62,13 +62,13 @@ def cpu_baseline(sample_pcm):
         kind = "reference"
 
         def run():
-            return po.ref_encode(sample_pcm, BPS, RATE, LEVEL, want_bytes=False)["seconds"]
+            return po.ref_encode(sample_pcm, BPS, RATE, LEVEL, want_bytes=False, **(search or {}))["seconds"]
     else:
         kind = "port"
 
         def run():
             t0 = time.perf_counter()
-            po.oracle_encode(sample_pcm, BPS, RATE, LEVEL)
+            po.oracle_encode(sample_pcm, BPS, RATE, LEVEL, **(search or {}))
             return time.perf_counter() - t0
     best = min(run() for _ in range(3))
     single = n / best / 1e6
@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exhaustive", action="store_true", help="flac -8e: not the headline workload, a side measurement")
+    ap.add_argument("--prec-search", action="store_true", help="flac -8p")
     ap.add_argument("--force-dist", action="store_true", help="development aid: run the multi-rank pipeline (process group, "
                     "overlapped ordered gather) even with one rank")
     args = ap.parse_args()
@@ -121,7 +123,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     nframes = args.frames
-    settings = flac_amd.make_settings(CH, BPS, RATE, LEVEL)
+    search = dict(exhaustive=int(args.exhaustive), prec_search=int(args.prec_search))
+    settings = flac_amd.make_settings(CH, BPS, RATE, LEVEL, **search)
     eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=nframes)
 
     # this rank's shard of the corpus: frames [rank*nframes, (rank+1)*nframes)
@@ -220,8 +223,8 @@ def main():
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": "flac -8 (max LPC order 12, subdivide_tukey(3), mid/side, partition order <= 6) on 44.1k/16-bit stereo, "
-                                   "%d frames x %d samples per GPU per step, music-like synthetic PCM resident in HBM" % (nframes, BLOCK),
+            "config": {"workload": "flac -8%s%s (max LPC order 12, subdivide_tukey(3), mid/side, partition order <= 6) on 44.1k/16-bit stereo, "
+                                   "%d frames x %d samples per GPU per step, music-like synthetic PCM resident in HBM" % ("e" if args.exhaustive else "", "p" if args.prec_search else "", nframes, BLOCK),
                        "frames_per_gpu_per_step": nframes, "blocksize": BLOCK, "channels": CH, "bits_per_sample": BPS,
                        "samples_are": "inter-channel (x2 for channel-samples)", "parallelism": "frame-shard x%d + ordered RCCL gather of every step's frames to rank 0, overlapped with the next step's encode" % world,
                        "compressed_bytes_per_sample": round(out_bps, 4)},
@@ -234,7 +237,7 @@ def main():
                                  "of the committed PMC pass scaled to this batch"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pcm_h[: 512 * BLOCK])
+            line["cpu_baseline"] = cpu_baseline(pcm_h[: (512 if not (args.exhaustive or args.prec_search) else 64) * BLOCK], search)
             line["speedup_vs_cpu_1thread"] = round(value / line["cpu_baseline"]["value"], 2)
             line["speedup_vs_cpu_multi"] = round(value / line["cpu_baseline"]["multi"]["value"], 2)
         sys.stdout.flush()
