@@ -48,7 +48,7 @@ def synth_pcm(nframes, seed):
         parts = []
         for r in range(reps):
             g = 1.0 - 0.07 * (r % 8)
-            parts.append(np.clip(np.rint(base * g) + (r % 5) - 2, -32768, 32767).astype(np.int32))
+            parts.append(np.clip(np.rint(base * g) + (r % 5) - 2, -(1 << (BPS - 1)), (1 << (BPS - 1)) - 1).astype(np.int32))
         base = np.concatenate(parts, axis=0)
     return np.ascontiguousarray(base[: nframes * BLOCK])
 
@@ -78,10 +78,21 @@ def cpu_baseline(sample_pcm, search=None):
     with ThreadPoolExecutor(threads) as ex:     # ctypes releases the GIL: independent encoders in parallel
         list(ex.map(lambda _: run(), range(threads * 2)))
     multi = threads * 2 * n / (time.perf_counter() - t0) / 1e6
+    # the library's own frame-parallel thread pool (flac -j N, stream_encoder.c:2151) on one longer stream
+    pool = None
+    if kind == "reference":
+        try:
+            long_pcm = np.concatenate([sample_pcm] * 8, axis=0)
+            nthr = min(threads, 32)
+            sec = min(po.ref_encode(long_pcm, BPS, RATE, LEVEL, want_bytes=False, num_threads=nthr, **(search or {}))["seconds"] for _ in range(2))
+            pool = {"value": round(long_pcm.shape[0] / sec / 1e6, 3), "threads": nthr, "how": "one stream, FLAC__stream_encoder_set_num_threads"}
+        except Exception as e:           # a reference build without threads
+            pool = {"error": str(e)}
     return {
         "value": round(single, 3), "unit": "Msamples/s", "cores": 1, "kind": kind,
         "sample": "%d inter-channel samples (%.0f s) of the bench signal, flac -%d, best of 3, in-memory" % (n, n / RATE, LEVEL),
         "multi": {"value": round(multi, 3), "cores": threads, "how": "independent single-thread encoders, 2 clips each"},
+        "library_thread_pool": pool,
         "host_cpus": cores,
     }
 
@@ -93,11 +104,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hires", action="store_true", help="96 kHz / 24-bit stereo (BASELINE.json config 4): a side measurement")
     ap.add_argument("--exhaustive", action="store_true", help="flac -8e: not the headline workload, a side measurement")
     ap.add_argument("--prec-search", action="store_true", help="flac -8p")
     ap.add_argument("--force-dist", action="store_true", help="development aid: run the multi-rank pipeline (process group, "
                     "overlapped ordered gather) even with one rank")
     args = ap.parse_args()
+    global RATE, BPS
+    if args.hires:
+        RATE, BPS = 96000, 24
 
     # stdout must carry exactly one JSON line: libraries underneath (RCCL prints a version banner from C) get stderr
     sys.stdout.flush()
@@ -219,12 +234,12 @@ def main():
         except Exception:
             pass
         line = {
-            "metric": "encode Msamples/s at -8, 44.1k/16-bit stereo; bit-exact vs libFLAC",
+            "metric": "encode Msamples/s at -8, 44.1k/16-bit stereo; bit-exact vs libFLAC" if not args.hires else "encode Msamples/s at -8, 96k/24-bit stereo (side measurement)",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": "flac -8%s%s (max LPC order 12, subdivide_tukey(3), mid/side, partition order <= 6) on 44.1k/16-bit stereo, "
-                                   "%d frames x %d samples per GPU per step, music-like synthetic PCM resident in HBM" % ("e" if args.exhaustive else "", "p" if args.prec_search else "", nframes, BLOCK),
+            "config": {"workload": "flac -8%s%s (max LPC order 12, subdivide_tukey(3), mid/side, partition order <= 6) on %s stereo, "
+                                   "%d frames x %d samples per GPU per step, music-like synthetic PCM resident in HBM" % ("e" if args.exhaustive else "", "p" if args.prec_search else "", "96k/24-bit" if args.hires else "44.1k/16-bit", nframes, BLOCK),
                        "frames_per_gpu_per_step": nframes, "blocksize": BLOCK, "channels": CH, "bits_per_sample": BPS,
                        "samples_are": "inter-channel (x2 for channel-samples)", "parallelism": "frame-shard x%d + ordered RCCL gather of every step's frames to rank 0, overlapped with the next step's encode" % world,
                        "compressed_bytes_per_sample": round(out_bps, 4)},

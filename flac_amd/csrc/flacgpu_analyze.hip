@@ -541,23 +541,6 @@ __device__ __forceinline__ uint32_t rice_search_owner(uint64_t v, bool narrow, u
 // is exact): the 2^(max_po+1)-1 nodes of the partition tree are spread over the lanes -- leaf p on lane p, the
 // merged partitions of the lower orders on the lanes after each other -- their sums come from ONE prefix sum over
 // the lanes, and each lane evaluates at most two nodes instead of one node per partition order.
-__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v, int lane)
-{
-#pragma unroll
-	for(int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off); if(lane >= off) v += t; }
-	return v;
-}
-__device__ __forceinline__ void rice_node(uint32_t sum, uint32_t ns, uint32_t div, uint32_t rice_limit, uint32_t &k, uint32_t &bits)
-{
-	// set_partitioned_rice_ (stream_encoder.c:4997-5046): mean-based parameter, then the closed-form bit count
-	k = 0;
-	if(sum >= 2) {
-		const uint64_t x = ((uint64_t)(sum - 1) * div) >> 18;
-		if(x) k = ilog2_u64(x) + 1;
-	}
-	if(k >= rice_limit) k = rice_limit - 1;
-	bits = 4 + (1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
-}
 // set_partitioned_rice_ (stream_encoder.c:4997-5046) without branches, for sum < 2^23: mean-based parameter
 // k = ilog2(((sum-1)*div) >> 18) + 1 (0 when that quotient is 0 or sum < 2), then the closed-form bit count
 __device__ __forceinline__ void rice_node_small(uint32_t sum, uint32_t ns, uint32_t div, uint32_t rice_limit_m1, uint32_t &k, uint32_t &bits)

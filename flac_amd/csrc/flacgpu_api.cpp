@@ -80,18 +80,6 @@ void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 		}
 	}
 	jt->njobs = nj; jt->nanalyses = na; jt->wnd_floats = woff;
-	// longest job first onto the least loaded wavefront (one job = 64 chains = one wavefront pass)
-	uint32_t load[TPB / 64] = {0};
-	bool done[MAX_JOBS] = {false};
-	for(uint32_t it = 0; it < nj; it++) {
-		uint32_t best = 0, bl = 0; bool have = false;
-		for(uint32_t k = 0; k < nj; k++) if(!done[k] && (!have || jt->jobs[k].nd > bl)) { best = k; bl = jt->jobs[k].nd; have = true; }
-		done[best] = true;
-		uint32_t w = 0;
-		for(uint32_t k = 1; k < TPB / 64; k++) if(load[k] < load[w]) w = k;
-		jt->wave_jobs[w][jt->wave_njobs[w]++] = (uint8_t)best;
-		load[w] += bl;
-	}
 }
 }
 
@@ -239,7 +227,6 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		}
 		if(nj > (uint32_t)MAX_JOBS || na > (uint32_t)MAX_ANALYSES) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
 		build_job_table(P, N, &c->h_jobtab[0]);
-		P.wnd_bytes = ((c->h_jobtab[0].wnd_floats + 64) * 4 + 15) & ~15u;
 		P.max_jobs = nj ? nj : 1; P.max_analyses = na;
 		P.exhaustive = cfg->do_exhaustive_model_search ? 1 : 0;
 		P.prec_search = cfg->do_qlp_coeff_prec_search && cfg->max_lpc_order > 0 ? 1 : 0;

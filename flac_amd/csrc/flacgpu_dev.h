@@ -27,7 +27,6 @@ struct DevParams {
 	uint32_t disable_constant, disable_fixed, disable_verbatim, limit_min_bitrate;
 	uint32_t slot_bytes;       // bytes reserved per frame in the slot buffer / LDS frame image
 	uint32_t sig_bytes;        // LDS bytes of the padded signal array
-	uint32_t wnd_bytes;        // LDS bytes of the windowed-signal array (all window jobs of a subframe)
 	uint32_t max_jobs, max_analyses; // window jobs / LPC analyses per subframe at the nominal blocksize
 	// candidate slots of a subframe, in the reference's evaluation order (stream_encoder.c:4155-4266): nfixed fixed
 	// orders, then per analysis norders LPC orders x nprec coefficient precisions
@@ -67,14 +66,12 @@ struct WindowJob {
 	uint32_t part, dshift, i0;
 	uint32_t pad;
 };
-// Host-built schedule for one blocksize: jobs, the analyses derived from them in the reference's order
-// (full, then per depth: partial [, punch-out]), and a longest-first assignment of jobs to wavefronts.
+// Host-built schedule for one blocksize: jobs (longest first) and the analyses derived from them in the reference's
+// order (full, then per depth: partial [, punch-out]).
 struct JobTable {
 	uint32_t njobs, nanalyses, wnd_floats, pad;
 	WindowJob jobs[MAX_JOBS];
 	uint8_t an_job[MAX_ANALYSES], an_punch[MAX_ANALYSES], an_root[MAX_ANALYSES];
-	uint8_t wave_njobs[TPB / 64];
-	uint8_t wave_jobs[TPB / 64][MAX_JOBS];
 };
 void build_job_table(const DevParams &P, uint32_t n, JobTable *jt);
 

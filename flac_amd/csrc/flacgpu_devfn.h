@@ -307,89 +307,6 @@ __device__ void lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uin
 // d = windowed data of the job in LDS, nd = its data_len.
 // ---------------------------------------------------------------------------------------------
 #define DD(k) ((double)d[k])
-// One lane per chain (window job, lag j, vector lane l); a wavefront holds all 64 chains of one job, so its
-// LDS reads are broadcasts (x) or a run of <= 19 consecutive words (y): conflict free.  The loads of several
-// steps are issued together so LDS latency overlaps the fp64 work of the previous steps.
-// body of lpc_intrin_fma.c:46,61 (lag 8 / lag 16): acc_l += fma(d[i],d[i-j], d[i+4]*d[i+4-j]), i = L+8k+l
-__device__ __forceinline__ double autoc_chain_8_16(const float *d, uint32_t nd, uint32_t L, uint32_t j, uint32_t l)
-{
-	const uint32_t nb = (nd - L) / 8;
-	const float *px = d + L + l, *py = px - j;
-	double acc = 0.0;
-	uint32_t k = 0;
-	for(; k + 4 <= nb; k += 4, px += 32, py += 32) {
-		float x[8], y[8];
-#pragma unroll
-		for(int u = 0; u < 8; u++) { x[u] = px[4 * u]; y[u] = py[4 * u]; }
-#pragma unroll
-		for(int u = 0; u < 4; u++)
-			acc += fma((double)x[2 * u], (double)y[2 * u], (double)x[2 * u + 1] * (double)y[2 * u + 1]);
-	}
-	for(; k < nb; k++, px += 8, py += 8)
-		acc += fma((double)px[0], (double)py[0], (double)px[4] * (double)py[4]);
-	return acc;
-}
-// body of lpc_intrin_fma.c:54 (lag 12): gcc unrolled the 8-sample body x2 (acc += t1+t0 per 16 samples) and,
-// for lag 8 only, factored x*y0+x*y2 -> x*(y0+y2) across the two halves (y2 == x0 of the next half there)
-__device__ __forceinline__ double autoc_chain_12(const float *d, uint32_t nd, uint32_t j, uint32_t l)
-{
-	const uint32_t L = 12;
-	const uint32_t nb = (nd - L) / 8;
-	const uint32_t npairs = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
-	const float *px = d + L + l, *py = px - j;
-	double acc = 0.0;
-	uint32_t k = 0, p = 0;
-	if(j == 8) {
-		for(; p + 2 <= npairs; p += 2, k += 4, px += 32, py += 32) {
-			float x[8], y[4];
-#pragma unroll
-			for(int u = 0; u < 8; u++) x[u] = px[4 * u];
-			y[0] = py[0]; y[1] = py[4]; y[2] = py[16]; y[3] = py[20];
-			acc += fma((double)x[0], ((double)y[0] + (double)x[2]), (double)x[1] * ((double)y[1] + (double)x[3]));
-			acc += fma((double)x[4], ((double)y[2] + (double)x[6]), (double)x[5] * ((double)y[3] + (double)x[7]));
-		}
-		for(; p < npairs; p++, k += 2, px += 16, py += 16)
-			acc += fma((double)px[0], ((double)py[0] + (double)px[8]), (double)px[4] * ((double)py[4] + (double)px[12]));
-	}
-	else {
-		for(; p + 2 <= npairs; p += 2, k += 4, px += 32, py += 32) {
-			float x[8], y[8];
-#pragma unroll
-			for(int u = 0; u < 8; u++) { x[u] = px[4 * u]; y[u] = py[4 * u]; }
-#pragma unroll
-			for(int h = 0; h < 2; h++) {
-				const double t0 = fma((double)x[4 * h], (double)y[4 * h], (double)x[4 * h + 1] * (double)y[4 * h + 1]);
-				const double t1 = fma((double)x[4 * h + 2], (double)y[4 * h + 2], (double)x[4 * h + 3] * (double)y[4 * h + 3]);
-				acc += (t1 + t0);
-			}
-		}
-		for(; p < npairs; p++, k += 2, px += 16, py += 16) {
-			const double t0 = fma((double)px[0], (double)py[0], (double)px[4] * (double)py[4]);
-			const double t1 = fma((double)px[8], (double)py[8], (double)px[12] * (double)py[12]);
-			acc += (t1 + t0);
-		}
-	}
-	for(; k < nb; k++, px += 8, py += 8)
-		acc += fma((double)px[0], (double)py[0], (double)px[4] * (double)py[4]);
-	return acc;
-}
-// scalar head (samples j..L-1), lane combine and tail for lag j
-__device__ __forceinline__ double autoc_finish(const float *d, uint32_t nd, uint32_t L, uint32_t j, const double *acc4)
-{
-	double a = 0.0;
-	for(uint32_t h = j; h < L; h++) a += DD(h) * DD(h - j);
-	const uint32_t nb = (nd - L) / 8;
-	if(nb) a = ((acc4[3] + acc4[1]) + (acc4[2] + acc4[0])) + a;
-	uint32_t i = L + 8 * nb;
-	if(nd - i >= 4) {
-		const double hi = fma(DD(i + 1), DD(i + 1 - j), DD(i + 3) * DD(i + 3 - j));
-		const double lo = fma(DD(i), DD(i - j), DD(i + 2) * DD(i + 2 - j));
-		a = (hi + lo) + a;
-		i += 4;
-	}
-	for(; i < nd; i++) a = fma(DD(i), DD(i - j), a);
-	return a;
-}
 // the same with the data given as two plain windows: head = d[0,32), tail = d[tail_lo, nd)
 __device__ __forceinline__ double autoc_finish2(const float *head, const float *tail, uint32_t tail_lo, uint32_t nd, uint32_t L, uint32_t j, const double *acc4)
 {
@@ -531,22 +448,10 @@ __device__ __forceinline__ bool emit_fixed_candidates(const DevParams &P, Candid
 // ---------------------------------------------------------------------------------------------
 // integer FIR building blocks shared by the evaluation and pack kernels
 // ---------------------------------------------------------------------------------------------
-// VOP3P form with a separate destination (the compiler's v_dot2c accumulates in place and needs a v_mov per sample)
-typedef short short2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c)
-{
-	return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, false);
-}
 __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c)       // |a - b| + c, a and b unsigned
 {
 	uint32_t d;
 	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-	return d;
-}
-__device__ __forceinline__ uint32_t mad24(int32_t a, int32_t b, uint32_t c)
-{
-	uint32_t d;
-	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
 	return d;
 }
 
@@ -584,34 +489,8 @@ __device__ __forceinline__ uint32_t mad24_chain(const int32_t *xr /* xr[-j] is t
 
 
 // ---------------------------------------------------------------------------------------------
-// analyze_kernel
+// generic one-wavefront residual candidate evaluation (any block length / partition order)
 // ---------------------------------------------------------------------------------------------
-// fixed-size part of the workgroup's LDS state; the large arrays are carved dynamically (analyze_layout)
-struct AnalyzeSmall {
-	uint64_t scratch[8];
-	uint64_t pob[TPB / 64][MAX_PO + 1];           // slow path: per-wave bit totals per partition order
-	uint32_t divtab[(MAX_PO + 1) * (MAX_ORDER + 1)]; // 0x40000 / ((n >> po) - order)
-	int cand_valid[MAX_ANALYSES + 1];
-	uint32_t wbest_bits[TPB / 64], wbest_ci[TPB / 64], wbest_po[TPB / 64];
-};
-
-struct AnalyzeLayout { uint32_t wsums, accs, autoc, cands, kbestw, kcandw, small, total; };
-__host__ __device__ inline AnalyzeLayout analyze_layout(const DevParams &P)
-{
-	AnalyzeLayout L;
-	uint32_t o = P.sig_bytes + P.wnd_bytes;
-	L.wsums = o;  o += (TPB / 64) * (2u << P.max_po) * 8;                   // per-wave partition sums
-	L.accs = o;   o += P.max_jobs * (P.max_lpc_order + 1) * 4 * 8;          // chain accumulators
-	L.autoc = o;  o += P.max_jobs * MAX_ORDER * 8;                          // finished autocorrelations
-	L.cands = o;  o += (P.max_analyses + 1) * (uint32_t)sizeof(Candidate);  // [0] fixed, [1+a] LPC analysis a
-	L.kbestw = o; o += (TPB / 64) * 2 * (1u << P.max_po);                   // per wave: Rice parameters of its best candidate + scratch
-	L.kcandw = o; o += P.max_po > 6 ? (TPB / 64) * (2u << P.max_po) : 0;    // slow path only
-	o = (o + 15u) & ~15u;
-	L.small = o;  o += (uint32_t)sizeof(AnalyzeSmall);
-	L.total = (o + 15u) & ~15u;
-	return L;
-}
-
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)
 {
 	const uint32_t lo = __shfl_xor((uint32_t)v, mask), hi = __shfl_xor((uint32_t)(v >> 32), mask);

@@ -5,36 +5,35 @@
 #include <string.h>
 #include "flacgpu_host.h"
 
-static const uint32_t K[64] = {
-	0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
-	0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
-	0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
-	0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
-	0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
-	0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
-	0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
-	0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391
-};
-static const uint8_t S[64] = {
-	7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
-	4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21
-};
+/* the 64 steps unrolled, rounds as RFC 1321 section 3.4 writes them: the chain is serial, so the only speed there is
+ * to be had is in not computing table indices and branches per step */
+#define F1(x, y, z) ((z) ^ ((x) & ((y) ^ (z))))
+#define F2(x, y, z) F1(z, x, y)
+#define F3(x, y, z) ((x) ^ (y) ^ (z))
+#define F4(x, y, z) ((y) ^ ((x) | ~(z)))
+#define STEP(f, a, b, c, d, w, k, s) do { (a) += f((b), (c), (d)) + (w) + (k); (a) = ((a) << (s)) | ((a) >> (32 - (s))); (a) += (b); } while(0)
 
 static void md5_block(uint32_t st[4], const uint8_t *p)
 {
 	uint32_t w[16], a = st[0], b = st[1], c = st[2], d = st[3];
 	for(int i = 0; i < 16; i++)
 		w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
-	for(int i = 0; i < 64; i++) {
-		uint32_t f, g;
-		if(i < 16) { f = (b & c) | (~b & d); g = (uint32_t)i; }
-		else if(i < 32) { f = (d & b) | (~d & c); g = (5u * i + 1) & 15; }
-		else if(i < 48) { f = b ^ c ^ d; g = (3u * i + 5) & 15; }
-		else { f = c ^ (b | ~d); g = (7u * i) & 15; }
-		const uint32_t t = a + f + K[i] + w[g];
-		a = d; d = c; c = b;
-		b = b + ((t << S[i]) | (t >> (32 - S[i])));
-	}
+	STEP(F1, a, b, c, d, w[0], 0xd76aa478, 7);   STEP(F1, d, a, b, c, w[1], 0xe8c7b756, 12);  STEP(F1, c, d, a, b, w[2], 0x242070db, 17);  STEP(F1, b, c, d, a, w[3], 0xc1bdceee, 22);
+	STEP(F1, a, b, c, d, w[4], 0xf57c0faf, 7);   STEP(F1, d, a, b, c, w[5], 0x4787c62a, 12);  STEP(F1, c, d, a, b, w[6], 0xa8304613, 17);  STEP(F1, b, c, d, a, w[7], 0xfd469501, 22);
+	STEP(F1, a, b, c, d, w[8], 0x698098d8, 7);   STEP(F1, d, a, b, c, w[9], 0x8b44f7af, 12);  STEP(F1, c, d, a, b, w[10], 0xffff5bb1, 17); STEP(F1, b, c, d, a, w[11], 0x895cd7be, 22);
+	STEP(F1, a, b, c, d, w[12], 0x6b901122, 7);  STEP(F1, d, a, b, c, w[13], 0xfd987193, 12); STEP(F1, c, d, a, b, w[14], 0xa679438e, 17); STEP(F1, b, c, d, a, w[15], 0x49b40821, 22);
+	STEP(F2, a, b, c, d, w[1], 0xf61e2562, 5);   STEP(F2, d, a, b, c, w[6], 0xc040b340, 9);   STEP(F2, c, d, a, b, w[11], 0x265e5a51, 14); STEP(F2, b, c, d, a, w[0], 0xe9b6c7aa, 20);
+	STEP(F2, a, b, c, d, w[5], 0xd62f105d, 5);   STEP(F2, d, a, b, c, w[10], 0x02441453, 9);  STEP(F2, c, d, a, b, w[15], 0xd8a1e681, 14); STEP(F2, b, c, d, a, w[4], 0xe7d3fbc8, 20);
+	STEP(F2, a, b, c, d, w[9], 0x21e1cde6, 5);   STEP(F2, d, a, b, c, w[14], 0xc33707d6, 9);  STEP(F2, c, d, a, b, w[3], 0xf4d50d87, 14);  STEP(F2, b, c, d, a, w[8], 0x455a14ed, 20);
+	STEP(F2, a, b, c, d, w[13], 0xa9e3e905, 5);  STEP(F2, d, a, b, c, w[2], 0xfcefa3f8, 9);   STEP(F2, c, d, a, b, w[7], 0x676f02d9, 14);  STEP(F2, b, c, d, a, w[12], 0x8d2a4c8a, 20);
+	STEP(F3, a, b, c, d, w[5], 0xfffa3942, 4);   STEP(F3, d, a, b, c, w[8], 0x8771f681, 11);  STEP(F3, c, d, a, b, w[11], 0x6d9d6122, 16); STEP(F3, b, c, d, a, w[14], 0xfde5380c, 23);
+	STEP(F3, a, b, c, d, w[1], 0xa4beea44, 4);   STEP(F3, d, a, b, c, w[4], 0x4bdecfa9, 11);  STEP(F3, c, d, a, b, w[7], 0xf6bb4b60, 16);  STEP(F3, b, c, d, a, w[10], 0xbebfbc70, 23);
+	STEP(F3, a, b, c, d, w[13], 0x289b7ec6, 4);  STEP(F3, d, a, b, c, w[0], 0xeaa127fa, 11);  STEP(F3, c, d, a, b, w[3], 0xd4ef3085, 16);  STEP(F3, b, c, d, a, w[6], 0x04881d05, 23);
+	STEP(F3, a, b, c, d, w[9], 0xd9d4d039, 4);   STEP(F3, d, a, b, c, w[12], 0xe6db99e5, 11); STEP(F3, c, d, a, b, w[15], 0x1fa27cf8, 16); STEP(F3, b, c, d, a, w[2], 0xc4ac5665, 23);
+	STEP(F4, a, b, c, d, w[0], 0xf4292244, 6);   STEP(F4, d, a, b, c, w[7], 0x432aff97, 10);  STEP(F4, c, d, a, b, w[14], 0xab9423a7, 15); STEP(F4, b, c, d, a, w[5], 0xfc93a039, 21);
+	STEP(F4, a, b, c, d, w[12], 0x655b59c3, 6);  STEP(F4, d, a, b, c, w[3], 0x8f0ccc92, 10);  STEP(F4, c, d, a, b, w[10], 0xffeff47d, 15); STEP(F4, b, c, d, a, w[1], 0x85845dd1, 21);
+	STEP(F4, a, b, c, d, w[8], 0x6fa87e4f, 6);   STEP(F4, d, a, b, c, w[15], 0xfe2ce6e0, 10); STEP(F4, c, d, a, b, w[6], 0xa3014314, 15);  STEP(F4, b, c, d, a, w[13], 0x4e0811a1, 21);
+	STEP(F4, a, b, c, d, w[4], 0xf7537e82, 6);   STEP(F4, d, a, b, c, w[11], 0xbd3af235, 10); STEP(F4, c, d, a, b, w[2], 0x2ad7d2bb, 15);  STEP(F4, b, c, d, a, w[9], 0xeb86d391, 21);
 	st[0] += a; st[1] += b; st[2] += c; st[3] += d;
 }
 

@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include <limits.h>
 #include "flacgpu_host.h"
 #include "FLACgpu_stream_encoder.h"
@@ -83,14 +84,30 @@ struct FLAC__StreamEncoderPrivate {
 	uint32_t first_seekpoint_to_check;
 	flacgpu_host_md5 md5;
 	int is_being_deleted;
-	/* GPU batch */
+	/* GPU batches.  Two slots: the caller's thread fills one with sample BYTES (little endian, ceil(bps/8) wide: at
+	 * once the input format of the MD5 (:3448) and a raw format the engine stages on the device), while the worker
+	 * thread runs MD5 + the GPU encode of the other; frames are delivered on the caller's thread, in stream order. */
 	flacgpu_ctx *gpu;
 	uint32_t batch_frames;
-	int32_t *stage;                           /* pinned, interleaved [batch_frames*blocksize + 1][channels] */
-	size_t staged;                            /* inter-channel samples currently staged */
-	uint8_t *out; size_t out_cap;
-	uint32_t *frame_bytes;
+	uint32_t width;                           /* bytes per staged sample */
+	flacgpu_raw_format rawfmt;
+	struct batch_slot {
+		uint8_t *raw;                         /* pinned [batch_frames*blocksize + 1][channels][width] */
+		uint8_t *out;                         /* pinned, frames back to back */
+		uint32_t *frame_bytes;
+		uint32_t nframes, tail, first_frame;  /* the submitted batch */
+		int64_t total;                        /* result: bytes, or a negative FLACGPU_ERR_* */
+		int state;                            /* 0 being filled / free, 1 submitted, 2 done */
+	} slot[2];
+	int cur;                                  /* slot the caller is filling */
+	size_t staged;                            /* inter-channel samples in slot[cur] */
+	size_t out_cap;
+	uint32_t next_frame_number;               /* of the next batch to submit */
 	float *tail_windows;
+	pthread_t worker;
+	int worker_started, worker_quit;
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
 };
 
 #define PROT(e) ((e)->protected_)
@@ -125,12 +142,26 @@ FLAC__StreamEncoder *FLAC__stream_encoder_new(void)
 static void release_engine(FLAC__StreamEncoder *e)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	if(p->worker_started) {
+		pthread_mutex_lock(&p->mu);
+		p->worker_quit = 1;
+		pthread_cond_broadcast(&p->cv);
+		pthread_mutex_unlock(&p->mu);
+		pthread_join(p->worker, 0);
+		pthread_mutex_destroy(&p->mu);
+		pthread_cond_destroy(&p->cv);
+		p->worker_started = 0; p->worker_quit = 0;
+	}
 	if(p->gpu) { flacgpu_destroy(p->gpu); p->gpu = 0; }
-	if(p->stage) { flacgpu_free_pinned(p->stage); p->stage = 0; }
-	free(p->out); p->out = 0; p->out_cap = 0;
-	free(p->frame_bytes); p->frame_bytes = 0;
+	for(int i = 0; i < 2; i++) {
+		if(p->slot[i].raw) { flacgpu_free_pinned(p->slot[i].raw); p->slot[i].raw = 0; }
+		if(p->slot[i].out) { flacgpu_free_pinned(p->slot[i].out); p->slot[i].out = 0; }
+		free(p->slot[i].frame_bytes); p->slot[i].frame_bytes = 0;
+		p->slot[i].state = 0;
+	}
+	p->out_cap = 0;
 	free(p->tail_windows); p->tail_windows = 0;
-	p->staged = 0;
+	p->staged = 0; p->cur = 0;
 	if(PROT(e)->metadata) { free(PROT(e)->metadata); PROT(e)->metadata = 0; PROT(e)->num_metadata_blocks = 0; }
 }
 
@@ -483,36 +514,80 @@ static int emit_block(FLAC__StreamEncoder *e, const FLAC__StreamMetadata *m)
 	return ok;
 }
 
-/* Encode `nframes` staged blocks on the GPU and deliver them in order; `tail` = samples of a short last block
- * (0: all full).  MD5 runs over exactly the samples being encoded, in stream order (:3448). */
-static int flush_frames(FLAC__StreamEncoder *e, uint32_t nframes, uint32_t tail)
+/* The worker: MD5 over exactly the sample bytes being encoded, in stream order (:3448), then the GPU encode. */
+static void run_batch_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	const flacgpu_host_settings *s = &PROT(e)->s;
 	const uint32_t N = s->blocksize, C = s->channels;
-	const size_t nsamp = (size_t)(nframes - 1) * N + (tail ? tail : N);
-	if(s->do_md5) flacgpu_host_md5_pcm(&p->md5, p->stage, C, nsamp, (s->bits_per_sample + 7) / 8);
+	const size_t nsamp = (size_t)(b->nframes - 1) * N + (b->tail ? b->tail : N);
+	if(s->do_md5) flacgpu_host_md5_update(&p->md5, b->raw, nsamp * C * p->width);
 	const float *tw = 0;
-	if(tail && s->max_lpc_order > 0) {
+	if(b->tail && s->max_lpc_order > 0) {
 		/* windows are recomputed for the short block, as resize_buffers_ does at finish (:1703-1711) */
-		float *w = realloc(p->tail_windows, sizeof(float) * s->num_apodizations * tail);
-		if(!w) { PROT(e)->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		float *w = realloc(p->tail_windows, sizeof(float) * s->num_apodizations * b->tail);
+		if(!w) { b->total = FLACGPU_ERR_ALLOC; return; }
 		p->tail_windows = w;
-		flacgpu_host_windows(s, tail, w);
+		flacgpu_host_windows(s, b->tail, w);
 		tw = w;
 	}
-	const int64_t total = flacgpu_encode_batch(p->gpu, p->stage, nframes, p->current_frame_number, tail, tw, p->out, p->out_cap, p->frame_bytes);
-	if(total < 0) {
-		fprintf(stderr, "libFLACgpu: flacgpu_encode_batch failed: %s\n", flacgpu_strerror((int)total));
-		PROT(e)->state = total == FLACGPU_ERR_ALLOC ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+	b->total = flacgpu_encode_batch_raw(p->gpu, b->raw, &p->rawfmt, b->nframes, b->first_frame, b->tail, tw, b->out, p->out_cap, b->frame_bytes);
+}
+static void *worker_main(void *arg)
+{
+	FLAC__StreamEncoder *e = arg;
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	pthread_mutex_lock(&p->mu);
+	for(;;) {
+		int k = p->slot[0].state == 1 ? 0 : p->slot[1].state == 1 ? 1 : -1;
+		if(k < 0) {
+			if(p->worker_quit) break;
+			pthread_cond_wait(&p->cv, &p->mu);
+			continue;
+		}
+		pthread_mutex_unlock(&p->mu);
+		run_batch_slot(e, &p->slot[k]);
+		pthread_mutex_lock(&p->mu);
+		p->slot[k].state = 2;
+		pthread_cond_broadcast(&p->cv);
+	}
+	pthread_mutex_unlock(&p->mu);
+	return 0;
+}
+/* hand slot k (nframes staged blocks; `tail` = samples of a short last block, 0: all full) to the worker */
+static void submit_slot(FLAC__StreamEncoder *e, int k, uint32_t nframes, uint32_t tail)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	struct batch_slot *b = &p->slot[k];
+	b->nframes = nframes; b->tail = tail; b->first_frame = p->next_frame_number;
+	p->next_frame_number += nframes;
+	pthread_mutex_lock(&p->mu);
+	b->state = 1;
+	pthread_cond_broadcast(&p->cv);
+	pthread_mutex_unlock(&p->mu);
+}
+/* wait for slot k (if it is in flight) and deliver its frames in order on this thread */
+static int collect_slot(FLAC__StreamEncoder *e, int k)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	struct batch_slot *b = &p->slot[k];
+	pthread_mutex_lock(&p->mu);
+	if(b->state == 0) { pthread_mutex_unlock(&p->mu); return 1; }
+	while(b->state != 2) pthread_cond_wait(&p->cv, &p->mu);
+	b->state = 0;
+	pthread_mutex_unlock(&p->mu);
+	if(b->total < 0) {
+		fprintf(stderr, "libFLACgpu: the GPU frame engine failed: %s\n", flacgpu_strerror((int)b->total));
+		PROT(e)->state = b->total == FLACGPU_ERR_ALLOC ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
 		return 0;
 	}
-	const uint8_t *q = p->out;
-	for(uint32_t f = 0; f < nframes; f++) {
-		const uint32_t samples = (f + 1 == nframes && tail) ? tail : N;
+	const uint32_t N = PROT(e)->s.blocksize;
+	const uint8_t *q = b->out;
+	for(uint32_t f = 0; f < b->nframes; f++) {
+		const uint32_t samples = (f + 1 == b->nframes && b->tail) ? b->tail : N;
 		p->frame_blocksize = samples;
-		if(!emit(e, q, p->frame_bytes[f], samples)) return 0;
-		q += p->frame_bytes[f];
+		if(!emit(e, q, b->frame_bytes[f], samples)) return 0;
+		q += b->frame_bytes[f];
 		p->current_frame_number++;
 		p->streaminfo.data.stream_info.total_samples += samples;
 	}
@@ -589,11 +664,24 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 		if(r == FLACGPU_OK) r = flacgpu_create(&cfg, windows, &p->gpu);
 		free(windows);
 		if(r == FLACGPU_OK) {
+			p->width = (s->bits_per_sample + 7) / 8;
+			memset(&p->rawfmt, 0, sizeof p->rawfmt);
+			p->rawfmt.container_bits = 8 * p->width;            /* little endian, signed, right-justified */
 			p->out_cap = flacgpu_max_output_bytes(p->gpu, p->batch_frames);
-			p->out = malloc(p->out_cap);
-			p->frame_bytes = malloc(sizeof(uint32_t) * p->batch_frames);
-			p->stage = flacgpu_alloc_pinned(sizeof(int32_t) * s->channels * ((size_t)p->batch_frames * s->blocksize + 1));
-			if(!p->out || !p->frame_bytes || !p->stage) r = FLACGPU_ERR_ALLOC;
+			for(int i = 0; i < 2; i++) {
+				p->slot[i].raw = flacgpu_alloc_pinned((size_t)p->width * s->channels * ((size_t)p->batch_frames * s->blocksize + 1));
+				p->slot[i].out = flacgpu_alloc_pinned(p->out_cap);
+				p->slot[i].frame_bytes = malloc(sizeof(uint32_t) * p->batch_frames);
+				p->slot[i].state = 0;
+				if(!p->slot[i].raw || !p->slot[i].out || !p->slot[i].frame_bytes) r = FLACGPU_ERR_ALLOC;
+			}
+			if(r == FLACGPU_OK) {
+				pthread_mutex_init(&p->mu, 0);
+				pthread_cond_init(&p->cv, 0);
+				p->worker_quit = 0;
+				if(pthread_create(&p->worker, 0, worker_main, e) == 0) p->worker_started = 1;
+				else { pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv); r = FLACGPU_ERR_ALLOC; }
+			}
 		}
 		if(r != FLACGPU_OK) {
 			fprintf(stderr, "libFLACgpu: cannot create the GPU frame engine: %s\n", flacgpu_strerror(r));
@@ -605,7 +693,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 	}
 
 	p->write_cb = wcb; p->seek_cb = scb; p->tell_cb = tcb; p->metadata_cb = mcb; p->client_data = client_data;
-	p->staged = 0; p->current_frame_number = 0; p->frame_blocksize = 0;
+	p->staged = 0; p->cur = 0; p->current_frame_number = 0; p->next_frame_number = 0; p->frame_blocksize = 0;
 	p->first_seekpoint_to_check = 0; p->samples_written = 0;
 	PROT(e)->streaminfo_offset = PROT(e)->seektable_offset = PROT(e)->audio_offset = 0;
 	PROT(e)->state = FLAC__STREAM_ENCODER_OK;
@@ -718,10 +806,43 @@ static int release_if_full(FLAC__StreamEncoder *e)
 	const uint32_t N = PROT(e)->s.blocksize, C = PROT(e)->s.channels;
 	const size_t full = (size_t)p->batch_frames * N;
 	if(p->staged <= full) return 1;            /* one sample beyond the batch must exist (the overread) */
-	if(!flush_frames(e, p->batch_frames, 0)) return 0;
-	memcpy(p->stage, p->stage + full * C, sizeof(int32_t) * C);
+	const int k = p->cur, o = k ^ 1;
+	/* the other slot's batch comes first in the stream: deliver it, then this one goes to the worker and the caller
+	 * carries on filling the other slot, starting with the overread sample */
+	if(!collect_slot(e, o)) return 0;
+	memcpy(p->slot[o].raw, p->slot[k].raw + full * C * p->width, (size_t)C * p->width);
+	submit_slot(e, k, p->batch_frames, 0);
+	p->cur = o;
 	p->staged = 1;
 	return 1;
+}
+
+/* range check (stream_encoder.c:2544-2547) and narrowing copy of `count` values spaced `sstride` apart in src to
+ * sample slots spaced `dstride` samples apart in dst */
+static int stage_values(uint8_t *dst, size_t dstride, const int32_t *src, size_t sstride, size_t count, uint32_t width, int32_t smin, int32_t smax)
+{
+	int32_t lo = 0, hi = 0;
+	if(width == 2) {
+		int16_t *d = (int16_t *)dst;
+		if(dstride == 1 && sstride == 1) for(size_t k = 0; k < count; k++) { const int32_t v = src[k]; d[k] = (int16_t)v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+		else for(size_t k = 0; k < count; k++) { const int32_t v = src[k * sstride]; d[k * dstride] = (int16_t)v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+	}
+	else if(width == 1) {
+		for(size_t k = 0; k < count; k++) { const int32_t v = src[k * sstride]; dst[k * dstride] = (uint8_t)v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+	}
+	else if(width == 3) {
+		for(size_t k = 0; k < count; k++) {
+			const int32_t v = src[k * sstride];
+			uint8_t *q = dst + 3 * k * dstride;
+			q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); q[2] = (uint8_t)(v >> 16);
+			lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+		}
+	}
+	else {
+		int32_t *d = (int32_t *)dst;
+		for(size_t k = 0; k < count; k++) { const int32_t v = src[k * sstride]; d[k * dstride] = v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+	}
+	return !(lo < smin || hi > smax);
 }
 
 FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, const FLAC__int32 buffer[], uint32_t samples)
@@ -735,11 +856,10 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, cons
 	while(j < samples) {
 		size_t n = cap - p->staged;
 		if(n > samples - j) n = samples - j;
-		const int32_t *src = buffer + (size_t)j * C;
-		int32_t *dst = p->stage + p->staged * C;
-		int32_t lo = 0, hi = 0;
-		for(size_t k = 0; k < n * C; k++) { const int32_t v = src[k]; dst[k] = v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-		if(lo < smin || hi > smax) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
+		if(!stage_values(p->slot[p->cur].raw + p->staged * C * p->width, 1, buffer + (size_t)j * C, 1, n * C, p->width, smin, smax)) {
+			PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+			return 0;
+		}
 		p->staged += n; j += (uint32_t)n;
 		if(!release_if_full(e)) return 0;
 	}
@@ -758,13 +878,11 @@ FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *e, const FLAC__int3
 	while(j < samples) {
 		size_t n = cap - p->staged;
 		if(n > samples - j) n = samples - j;
-		for(uint32_t c = 0; c < C; c++) {
-			const int32_t *src = buffer[c] + j;
-			int32_t *dst = p->stage + p->staged * C + c;
-			int32_t lo = 0, hi = 0;
-			for(size_t k = 0; k < n; k++) { const int32_t v = src[k]; dst[k * C] = v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-			if(lo < smin || hi > smax) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
-		}
+		for(uint32_t c = 0; c < C; c++)
+			if(!stage_values(p->slot[p->cur].raw + (p->staged * C + c) * p->width, C, buffer[c] + j, 1, n, p->width, smin, smax)) {
+				PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+				return 0;
+			}
 		p->staged += n; j += (uint32_t)n;
 		if(!release_if_full(e)) return 0;
 	}
@@ -826,14 +944,24 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 		if(p->file) { if(p->file != stdout) fclose(p->file); p->file = 0; }
 		return 1;
 	}
-	if(PROT(e)->state == FLAC__STREAM_ENCODER_OK && !p->is_being_deleted && p->staged) {
-		/* everything still staged: full blocks, then the final one (short, or exactly full) */
-		const uint32_t N = PROT(e)->s.blocksize;
-		const uint32_t nframes = (uint32_t)((p->staged + N - 1) / N);
-		uint32_t tail = (uint32_t)(p->staged - (size_t)(nframes - 1) * N);
-		if(tail == N) tail = 0;
-		if(!flush_frames(e, nframes, tail)) error = 1;
+	if(PROT(e)->state == FLAC__STREAM_ENCODER_OK && !p->is_being_deleted && p->gpu) {
+		/* the batch in flight, then everything still staged: full blocks and the final one (short, or exactly full) */
+		if(!collect_slot(e, p->cur ^ 1)) error = 1;
+		if(!error && p->staged) {
+			const uint32_t N = PROT(e)->s.blocksize;
+			const uint32_t nframes = (uint32_t)((p->staged + N - 1) / N);
+			uint32_t tail = (uint32_t)(p->staged - (size_t)(nframes - 1) * N);
+			if(tail == N) tail = 0;
+			submit_slot(e, p->cur, nframes, tail);
+			if(!collect_slot(e, p->cur)) error = 1;
+		}
 		p->staged = 0;
+	}
+	else if(p->worker_started) {
+		/* an encoder that is torn down or already failed: let the worker drain, deliver nothing */
+		pthread_mutex_lock(&p->mu);
+		while(p->slot[0].state == 1 || p->slot[1].state == 1) pthread_cond_wait(&p->cv, &p->mu);
+		pthread_mutex_unlock(&p->mu);
 	}
 	if(PROT(e)->s.do_md5 && p->gpu) flacgpu_host_md5_final(&p->md5, p->streaminfo.data.stream_info.md5sum);
 	if(!p->is_being_deleted && PROT(e)->state == FLAC__STREAM_ENCODER_OK) {
