@@ -74,6 +74,13 @@ void flacgpu_host_md5_final(flacgpu_host_md5 *m, uint8_t digest[16]);
 /* feeds `samples` inter-channel samples of interleaved int32 PCM as bytes_per_sample-byte little-endian */
 void flacgpu_host_md5_pcm(flacgpu_host_md5 *m, const int32_t *interleaved, uint32_t channels, size_t samples, uint32_t bytes_per_sample);
 
+/* the encoder's self check (set_verify): decode the frames of a batch again and compare them with the samples that
+ * went in (`raw`: little endian, `width` bytes per sample, interleaved).  status 0 ok, 1 audio mismatch (the fields
+ * locate the first one in stream order), 2 a frame does not decode.  Returns the status. */
+typedef struct { int status; uint32_t frame_number, channel, sample; uint64_t absolute_sample; int32_t expected, got; } flacgpu_host_verify_result;
+int flacgpu_host_verify_batch(const flacgpu_host_settings *s, const uint8_t *frames, const uint32_t *frame_bytes, uint32_t nframes, uint32_t tail,
+                              uint32_t first_frame, const uint8_t *raw, uint32_t width, uint32_t nthreads, flacgpu_host_verify_result *out);
+
 #ifdef __cplusplus
 }
 #endif

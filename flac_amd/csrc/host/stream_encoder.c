@@ -97,6 +97,7 @@ struct FLAC__StreamEncoderPrivate {
 		uint32_t *frame_bytes;
 		uint32_t nframes, tail, first_frame;  /* the submitted batch */
 		int64_t total;                        /* result: bytes, or a negative FLACGPU_ERR_* */
+		flacgpu_host_verify_result vres;      /* set_verify: the first frame of the batch that does not decode back to its input */
 		int state;                            /* 0 being filled / free, 1 submitted, 2 done */
 	} slot[2];
 	int cur;                                  /* slot the caller is filling */
@@ -106,6 +107,8 @@ struct FLAC__StreamEncoderPrivate {
 	float *tail_windows;
 	pthread_t worker;
 	int worker_started, worker_quit;
+	uint32_t verify_threads;
+	flacgpu_host_verify_result verify_stats;  /* get_verify_decoder_error_stats */
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
 };
@@ -263,18 +266,19 @@ FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *e, FLAC__Strea
  * getters (stream_encoder.c:2299-2511)
  * ---------------------------------------------------------------------------------------------- */
 FLAC__StreamEncoderState FLAC__stream_encoder_get_state(const FLAC__StreamEncoder *e) { return PROT(e)->state; }
-/* with verify requested but no decoder object the reference answers MEMORY_ALLOCATION_ERROR (8), :2314-2318 */
-FLAC__StreamDecoderState FLAC__stream_encoder_get_verify_decoder_state(const FLAC__StreamEncoder *e) { return PROT(e)->s.verify ? 8 : FLAC__STREAM_DECODER_UNINITIALIZED; }
+/* the verify decoder here is a frame decoder without a state machine of its own: "searching for the next frame"
+ * while verification is on (FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC), else uninitialized (:2314-2318) */
+FLAC__StreamDecoderState FLAC__stream_encoder_get_verify_decoder_state(const FLAC__StreamEncoder *e) { return PROT(e)->s.verify ? 2 : FLAC__STREAM_DECODER_UNINITIALIZED; }
 const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *e) { return FLAC__StreamEncoderStateString[PROT(e)->state]; }
 void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *e, FLAC__uint64 *absolute_sample, uint32_t *frame_number, uint32_t *channel, uint32_t *sample, FLAC__int32 *expected, FLAC__int32 *got)
 {
-	(void)e;
-	if(absolute_sample) *absolute_sample = 0;
-	if(frame_number) *frame_number = 0;
-	if(channel) *channel = 0;
-	if(sample) *sample = 0;
-	if(expected) *expected = 0;
-	if(got) *got = 0;
+	const flacgpu_host_verify_result *v = &PRIV(e)->verify_stats;           /* :2327-2343 */
+	if(absolute_sample) *absolute_sample = v->absolute_sample;
+	if(frame_number) *frame_number = v->frame_number;
+	if(channel) *channel = v->channel;
+	if(sample) *sample = v->sample;
+	if(expected) *expected = v->expected;
+	if(got) *got = v->got;
 }
 #define GETTER(name, type, expr) type FLAC__stream_encoder_##name(const FLAC__StreamEncoder *e) { return (type)(expr); }
 GETTER(get_verify, FLAC__bool, PROT(e)->s.verify)
@@ -532,6 +536,9 @@ static void run_batch_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
 		tw = w;
 	}
 	b->total = flacgpu_encode_batch_raw(p->gpu, b->raw, &p->rawfmt, b->nframes, b->first_frame, b->tail, tw, b->out, p->out_cap, b->frame_bytes);
+	b->vres.status = 0;
+	if(b->total >= 0 && s->verify)          /* write_bitbuffer_ verifies every frame before it is written (:3000-3018) */
+		(void)flacgpu_host_verify_batch(s, b->out, b->frame_bytes, b->nframes, b->tail, b->first_frame, b->raw, p->width, p->verify_threads, &b->vres);
 }
 static void *worker_main(void *arg)
 {
@@ -584,6 +591,13 @@ static int collect_slot(FLAC__StreamEncoder *e, int k)
 	const uint32_t N = PROT(e)->s.blocksize;
 	const uint8_t *q = b->out;
 	for(uint32_t f = 0; f < b->nframes; f++) {
+		if(b->vres.status && b->first_frame + f == b->vres.frame_number) {
+			/* the frames in front of it were fine and are out; this one is not written (:3005-3016) */
+			p->verify_stats = b->vres;
+			PROT(e)->state = b->vres.status == 1 ? FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA : FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR;
+			p->frame_blocksize = 0;
+			return 0;
+		}
 		const uint32_t samples = (f + 1 == b->nframes && b->tail) ? b->tail : N;
 		p->frame_blocksize = samples;
 		if(!emit(e, q, b->frame_bytes[f], samples)) return 0;
@@ -642,16 +656,14 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 	}
 
 	/* the GPU engine; features it does not implement are refused, never approximated */
-	if(s->verify) {
-		fprintf(stderr, "libFLACgpu: set_verify(true) needs the stream decoder, which this library does not contain\n");
-		PROT(e)->state = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR;
-		return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
-	}
 	{
 		const char *env = getenv("FLACGPU_BATCH_FRAMES");
 		long bf = env ? strtol(env, 0, 10) : 512;
 		if(bf < 1) bf = 1; else if(bf > 65536) bf = 65536;
 		p->batch_frames = (uint32_t)bf;
+		env = getenv("FLACGPU_VERIFY_THREADS");
+		p->verify_threads = env ? (uint32_t)atoi(env) : 8;
+		memset(&p->verify_stats, 0, sizeof p->verify_stats);
 		env = getenv("FLACGPU_DEVICE");
 		const int device = env ? atoi(env) : 0;
 		flacgpu_config cfg;

@@ -51,7 +51,8 @@ typedef enum { FLAC__STREAM_ENCODER_SEEK_STATUS_OK, FLAC__STREAM_ENCODER_SEEK_ST
 typedef enum { FLAC__STREAM_ENCODER_TELL_STATUS_OK, FLAC__STREAM_ENCODER_TELL_STATUS_ERROR,
                FLAC__STREAM_ENCODER_TELL_STATUS_UNSUPPORTED } FLAC__StreamEncoderTellStatus;
 
-/* the verify decoder is not part of this library: its state is always "uninitialized"
+/* the verify decoder of this library is a plain frame decoder on the host (flac_amd/csrc/host/verify.c): its state reads
+ * SEARCH_FOR_FRAME_SYNC (2) while verification is on, else "uninitialized"
  * (FLAC__StreamDecoderState, include/FLAC/stream_decoder.h:205-250: last enumerator) */
 typedef int FLAC__StreamDecoderState;
 #define FLAC__STREAM_DECODER_UNINITIALIZED 9

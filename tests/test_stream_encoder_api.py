@@ -294,10 +294,16 @@ def test_out_of_range_sample_is_a_client_error_and_unsupported_features_are_refu
     pcm[4000, 1] = 40000
     with pytest.raises(RuntimeError, match="CLIENT_ERROR"):
         fa.encode("gpu", pcm, 16, 44100, 5)
-    for settings in ((("set_verify", 1),),):
-        with pytest.raises(RuntimeError, match="init status 1"):
-            fa.encode("gpu", pcm[:100], 16, 44100, 5, settings=settings)
     assert lib is not None
+
+
+@gpu
+def test_verify_through_the_api():
+    """flac --verify: same file as the reference's (which verifies with its own decoder), verify state and stats readable"""
+    pcm = signals.mixed(4096 * 5 + 200, 2, 16)
+    for level in (0, 5, 8):
+        _same_file(pcm, 16, 44100, level, settings=(("set_verify", 1),), chunk=5000)
+    _same_file(signals.music(4096 * 2 + 77, 2, 24, seed=2), 24, 96000, 8, settings=(("set_verify", 1),))
 
 
 @gpu
