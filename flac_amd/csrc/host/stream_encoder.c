@@ -266,9 +266,14 @@ FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *e, FLAC__Strea
  * getters (stream_encoder.c:2299-2511)
  * ---------------------------------------------------------------------------------------------- */
 FLAC__StreamEncoderState FLAC__stream_encoder_get_state(const FLAC__StreamEncoder *e) { return PROT(e)->state; }
-/* the verify decoder here is a frame decoder without a state machine of its own: "searching for the next frame"
- * while verification is on (FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC), else uninitialized (:2314-2318) */
-FLAC__StreamDecoderState FLAC__stream_encoder_get_verify_decoder_state(const FLAC__StreamEncoder *e) { return PROT(e)->s.verify ? 2 : FLAC__STREAM_DECODER_UNINITIALIZED; }
+/* :2308-2319.  Verify requested but the encoder not initialised: the reference has no decoder object yet and answers
+ * MEMORY_ALLOCATION_ERROR (8).  Afterwards the decoder here is a frame decoder without a state machine of its own:
+ * "searching for the next frame" (FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC, 2). */
+FLAC__StreamDecoderState FLAC__stream_encoder_get_verify_decoder_state(const FLAC__StreamEncoder *e)
+{
+	if(!PROT(e)->s.verify) return FLAC__STREAM_DECODER_UNINITIALIZED;
+	return PRIV(e)->gpu ? 2 : 8;
+}
 const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *e) { return FLAC__StreamEncoderStateString[PROT(e)->state]; }
 void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *e, FLAC__uint64 *absolute_sample, uint32_t *frame_number, uint32_t *channel, uint32_t *sample, FLAC__int32 *expected, FLAC__int32 *got)
 {
