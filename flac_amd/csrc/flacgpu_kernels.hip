@@ -207,6 +207,14 @@ __device__ __forceinline__ uint32_t frame_header_len(const DevParams &P, uint32_
 	return nb;
 }
 
+// LDS bytes of the one-pass signal window of pack_kernel: 32 samples in front, CHUNK*TPB samples, 16 + 16 behind, 18-word rows
+__host__ __device__ inline uint32_t pack_pass_sig_bytes(const DevParams &P)
+{
+	const uint32_t span = P.blocksize < (uint32_t)(CHUNK * TPB) ? ((P.blocksize + 15u) & ~15u) : (uint32_t)(CHUNK * TPB);
+	const uint32_t maxidx = 32 + span + 16u + 16u;
+	return ((maxidx + ((maxidx >> 4) << 1) + 8) * 4 + 15) & ~15u;
+}
+
 struct PackShared {
 	uint64_t scratch[8];
 	uint8_t params[1u << MAX_PO];
@@ -233,9 +241,11 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	const uint32_t n = is_tail ? tail_n : N;
 	const SubDecision *dec = decisions + (size_t)f * P.ncand;
 
+	// LDS: the samples of ONE pass (4096 samples + 32 in front, 18-word rows) | frame image | small state
 	int32_t *sig = (int32_t *)smem;
-	uint32_t *img = (uint32_t *)(smem + P.sig_bytes);
-	PackShared *sh = (PackShared *)(smem + P.sig_bytes + P.slot_bytes);
+	const uint32_t sigb = pack_pass_sig_bytes(P);
+	uint32_t *img = (uint32_t *)(smem + sigb);
+	PackShared *sh = (PackShared *)(smem + sigb + P.slot_bytes);
 	const uint32_t cap_words = P.slot_bytes / 4;
 
 	for(uint32_t w = (uint32_t)tid; w < cap_words; w += TPB) img[w] = 0;
@@ -282,33 +292,20 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 		uint32_t pos = sh->bitpos;
 		__syncthreads();
 
-		// the planar channel written by the prep kernels: wasted bits already shifted out, 16-bit pairs when sbps <= 16
-		{
-			const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + di) * N);
-			if(tid < 32) sig[sigidx(tid - 32)] = 0;
-			const uint32_t nround = ((n + 15u) & ~15u) + 16u;
-			for(uint32_t i = n + (uint32_t)tid; i < nround; i += TPB) sig[sigidx((int)i)] = 0;
-			if(sbps <= 16) {
-				for(uint32_t m = (uint32_t)tid; m < (n + 7) / 8; m += TPB) {
-					const uint4 w = ((const uint4 *)src)[m];
-					const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-					for(int k = 0; k < 8; k++) {
-						const uint32_t i = 8 * m + (uint32_t)k;
-						if(i < n) sig[sigidx((int)i)] = (k & 1) ? ((int32_t)wv[k >> 1] >> 16) : (int32_t)(int16_t)(wv[k >> 1] & 0xffffu);
-					}
-				}
+		// the planar channel written by the prep kernels (wasted bits already shifted out, 16-bit pairs when sbps <= 16)
+		// is staged one pass of CHUNK*TPB samples at a time: sample pass + k sits at sigidx(k), k = -32 .. CHUNK*TPB+16
+		const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + di) * N);
+		auto stage_pass = [&](uint32_t pass) {
+			__syncthreads();
+			const int span = (int)(N < (uint32_t)(CHUNK * TPB) ? ((N + 15u) & ~15u) : (uint32_t)(CHUNK * TPB));
+			for(int k = tid - 32; k < span + 16; k += TPB) {
+				const int64_t i = (int64_t)pass + k;
+				int32_t v = 0;
+				if(i >= 0 && i < (int64_t)n) v = sbps <= 16 ? (int32_t)((const int16_t *)src)[i] : (int32_t)src[i];
+				sig[sigidx(k)] = v;
 			}
-			else {
-				for(uint32_t m = (uint32_t)tid; m < (n + 3) / 4; m += TPB) {
-					const uint4 w = ((const uint4 *)src)[m];
-					const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-					for(int k = 0; k < 4; k++) { const uint32_t i = 4 * m + (uint32_t)k; if(i < n) sig[sigidx((int)i)] = (int32_t)wv[k]; }
-				}
-			}
-		}
-		__syncthreads();
+			__syncthreads();
+		};
 
 		// subframe header byte (+ unary wasted bits)
 		uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : type == 2 ? (0x10u | (order << 1)) : (0x40u | ((order - 1) << 1));
@@ -323,12 +320,15 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 			pos += sbps;
 		}
 		else if(type == 1) {
-			for(uint32_t i = (uint32_t)tid; i < n; i += TPB) put_bits(img, cap_words, pos + i * sbps, (uint32_t)sig[sigidx((int)i)], sbps);
+			for(uint32_t pass = 0; pass < n; pass += CHUNK * TPB) {
+				stage_pass(pass);
+				for(uint32_t k = (uint32_t)tid; k < CHUNK * TPB && pass + k < n; k += TPB) put_bits(img, cap_words, pos + (pass + k) * sbps, (uint32_t)sig[sigidx((int)k)], sbps);
+			}
 			pos += n * sbps;
 		}
 		else {
-			// warm-up, (precision, shift, coefficients), entropy coding header
-			if((uint32_t)tid < order) put_bits(img, cap_words, pos + (uint32_t)tid * sbps, (uint32_t)sig[sigidx(tid)], sbps);
+			// warm-up (written when pass 0 is staged), (precision, shift, coefficients), entropy coding header
+			const uint32_t warm_pos = pos;
 			pos += order * sbps;
 			const int shift = type == 3 ? d->shift : 0;
 			bool wide = false;
@@ -370,8 +370,10 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 				const uint32_t base = pass + CHUNK * (uint32_t)tid;
 				int32_t r[CHUNK];
 				uint32_t mybits = 0;
+				stage_pass(pass);
+				if(pass == 0 && (uint32_t)tid < order) put_bits(img, cap_words, warm_pos + (uint32_t)tid * sbps, (uint32_t)sig[sigidx(tid)], sbps);
 				if(base < n) {
-					fir_chunk_dispatch<MAXORD>(sig, (int)base, q, shift, fir_mode(wide, sbps), r);
+					fir_chunk_dispatch<MAXORD>(sig, (int)(CHUNK * (uint32_t)tid), q, shift, fir_mode(wide, sbps), r);
 					uint32_t part = base / psize, next = (part + 1) * psize;
 					uint32_t k = sh->params[part];
 #pragma unroll
@@ -913,7 +915,11 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 }
 
 namespace flacgpu {
-size_t pack_lds_bytes(const DevParams &P) { return (size_t)P.sig_bytes + P.slot_bytes + sizeof(PackShared); }
+size_t pack_lds_bytes(const DevParams &P)
+{
+	const size_t a = (size_t)pack_pass_sig_bytes(P) + P.slot_bytes + sizeof(PackShared), b = (size_t)P.slot_bytes + 16 + sizeof(Pack2Shared);
+	return a > b ? a : b;
+}
 
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, hipStream_t s)

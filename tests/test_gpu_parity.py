@@ -283,3 +283,35 @@ def test_wider_model_searches_match_oracle(level, mode):
         o = po.oracle_encode(pcm, bps, rate, level, exhaustive=ex, prec_search=ps)
         assert np.array_equal(fb, o["frame_bytes"]), (fam, bps, level, mode)
         assert data == o["data"], (fam, bps, level, mode)
+
+
+@pytest.mark.parametrize("order", [1, 2, 4, 5, 7, 9, 10, 11, 13, 14, 15])
+def test_every_lpc_order_class(order):
+    """one max_lpc_order from every autocorrelation-routine / FIR-width class (the MAXORD 8 / 12 / 16 kernel instances)"""
+    for bps in (16, 24):
+        pcm = signals.music(4096 * 2 + 501, 2, bps, seed=order)
+        for level in (5, 8):
+            data, fb = _gpu_encode(pcm, bps, 96000, level, max_lpc_order=order, max_batch=16)
+            o = po.oracle_encode(pcm, bps, 96000, level, max_lpc_order=order)
+            assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (order, bps, level)
+
+
+@pytest.mark.parametrize("blocksize", [192, 256, 576, 1000, 1024, 2304, 4000, 4608, 8192, 16384])
+def test_block_sizes(blocksize):
+    """block sizes on and off the fast paths (multiples of 64 / 16 or not, one or several 4096-sample passes, Rice
+    partitions of every size), incl. a short last block"""
+    for bps, level in ((16, 2), (16, 8), (24, 8)):
+        pcm = signals.music(blocksize * 3 + blocksize // 3 + 7, 2, bps, seed=blocksize % 97)
+        data, fb = _gpu_encode(pcm, bps, 96000, level, blocksize=blocksize, max_batch=8)
+        o = po.oracle_encode(pcm, bps, 96000, level, blocksize=blocksize)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (blocksize, bps, level)
+
+
+@pytest.mark.parametrize("po_range", [(0, 0), (0, 2), (3, 3), (2, 6), (0, 8), (8, 8)])
+def test_partition_order_ranges(po_range):
+    lo, hi = po_range
+    pcm = signals.mixed(4096 * 3 + 99, 2, 16)
+    for level in (2, 8):
+        data, fb = _gpu_encode(pcm, 16, 44100, level, min_partition_order=lo, max_partition_order=hi, max_batch=8)
+        o = po.oracle_encode(pcm, 16, 44100, level, min_po=lo, max_po=hi)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (po_range, level)

@@ -192,3 +192,32 @@ def test_exhaustive_and_precision_search(ref, level, mode):
         r = po.ref_encode(pcm, bps, rate, level, exhaustive=ex, prec_search=ps)
         o = po.oracle_encode(pcm, bps, rate, level, exhaustive=ex, prec_search=ps)
         assert o["data"] == _frames(r), (fam, bps, level, mode)
+
+
+@pytest.mark.parametrize("order", [1, 2, 4, 5, 7, 9, 10, 11, 13, 14, 15])
+def test_every_lpc_order_class(ref, order):
+    """max_lpc_order selects the compiled autocorrelation routine (lag 8 / 12 / 16, stream_encoder.c:1058-1066) and the
+    FIR width: one value from every class, 16-bit at 96 kHz (orders above 12 are not in the subset at <= 48 kHz) and 24-bit"""
+    for bps in (16, 24):
+        pcm = signals.music(4096 * 2 + 501, 2, bps, seed=order)
+        for level in (5, 8):
+            r = po.ref_encode(pcm, bps, 96000, level, max_lpc_order=order)
+            o = po.oracle_encode(pcm, bps, 96000, level, max_lpc_order=order)
+            assert o["data"] == _frames(r), (order, bps, level)
+
+
+@pytest.mark.parametrize("blocksize", [192, 256, 576, 1000, 1024, 2304, 4000, 4608, 8192, 16384])
+def test_block_sizes(ref, blocksize):
+    for bps, level in ((16, 2), (16, 8), (24, 8)):
+        pcm = signals.music(blocksize * 3 + blocksize // 3 + 7, 2, bps, seed=blocksize % 97)
+        r = po.ref_encode(pcm, bps, 96000, level, blocksize=blocksize)
+        assert po.oracle_encode(pcm, bps, 96000, level, blocksize=blocksize)["data"] == _frames(r), (blocksize, bps, level)
+
+
+@pytest.mark.parametrize("po_range", [(0, 0), (0, 2), (3, 3), (2, 6), (0, 8), (8, 8)])
+def test_partition_order_ranges(ref, po_range):
+    lo, hi = po_range
+    pcm = signals.mixed(4096 * 3 + 99, 2, 16)
+    for level in (2, 8):
+        r = po.ref_encode(pcm, 16, 44100, level, min_po=lo, max_po=hi)
+        assert po.oracle_encode(pcm, 16, 44100, level, min_po=lo, max_po=hi)["data"] == _frames(r), (po_range, level)
