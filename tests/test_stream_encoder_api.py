@@ -298,6 +298,7 @@ def test_out_of_range_sample_is_a_client_error_and_unsupported_features_are_refu
 
 
 @gpu
+@needs_ref
 def test_verify_through_the_api():
     """flac --verify: same file as the reference's (which verifies with its own decoder), verify state and stats readable"""
     pcm = signals.mixed(4096 * 5 + 200, 2, 16)
@@ -307,9 +308,30 @@ def test_verify_through_the_api():
 
 
 @gpu
+@needs_ref
 def test_wider_model_searches_through_the_api():
     """flac -5e / -5p / -8ep: whole files identical to the reference's"""
     pcm = signals.music(4096 * 3 + 99, 2, 16, seed=8)
     for level, settings in ((5, (("set_do_exhaustive_model_search", 1),)), (5, (("set_do_qlp_coeff_prec_search", 1),)),
                             (8, (("set_do_exhaustive_model_search", 1), ("set_do_qlp_coeff_prec_search", 1)))):
         _same_file(pcm, 16, 44100, level, settings=settings, chunk=3000)
+
+
+@gpu
+@needs_ref
+@pytest.mark.parametrize("spec", [b"partial_tukey(3/0.3/0.5)", b"punchout_tukey(2/0.2/0.4)", b"gauss(0.2);welch", b"subdivide_tukey(5)",
+                                  b"blackman;hamming;flattop;nuttall", b"tukey(0.1);partial_tukey(2);punchout_tukey(3)", b"rectangle"])
+def test_apodization_specs_through_the_api(spec):
+    """window functions and their expansions (set_apodization, stream_encoder.c:1940-2070) through the whole stack"""
+    pcm = signals.music(4096 * 3 + 517, 2, 16, seed=len(spec))
+    _same_file(pcm, 16, 44100, 8, settings=(("set_apodization", spec),), chunk=4096)
+    _same_file(pcm[:, :1], 16, 44100, 5, settings=(("set_apodization", spec), ("set_qlp_coeff_precision", 9)), chunk=777)
+
+
+@gpu
+@needs_ref
+@pytest.mark.parametrize("precision", [5, 8, 14, 15])
+def test_coefficient_precisions_through_the_api(precision):
+    for bps, rate in ((16, 44100), (24, 96000)):
+        pcm = signals.music(4096 * 2 + 123, 2, bps, seed=precision)
+        _same_file(pcm, bps, rate, 8, settings=(("set_qlp_coeff_precision", precision),))
