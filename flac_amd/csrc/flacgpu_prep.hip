@@ -12,6 +12,7 @@
 // decides, and stores its channel.  HBM/L2 bound: reads 4*C bytes, writes ~10 bytes per inter-channel sample.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "flacgpu_dev.h"
 #include "flacgpu_devfn.h"
 
@@ -246,6 +247,193 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// prep3_kernel: stereo frames of 4096 samples with a mid/side search (what the presets from -4 up encode)
+// ---------------------------------------------------------------------------------------------------------
+// Same results as prep2_kernel, different split of the work: wavefront w owns the QUARTER [w*N/4, (w+1)*N/4) of the
+// frame for ALL candidate channels.  It stages its own quarter (coalesced loads -> its own transposed LDS tile, no
+// workgroup barrier in front of the compute), reads left and right ONCE for the four channels derived from them, and
+// the workgroup meets only twice: to add up the four partial statistics and to learn the wasted bits before the planar
+// channels are written.
+struct Prep3Part {
+	uint32_t orv[4], diff[4];
+	int32_t first[4];
+	uint64_t e[4][5];
+	uint64_t lr, ms;
+};
+struct Prep3Out { uint32_t wasted[4]; int32_t slot[4]; uint32_t fmt[4]; };
+
+template <bool WIDE>
+__global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
+                                                       ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
+                                                       int32_t *__restrict__ chan)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	__shared__ Prep3Part part[TPB / 64];
+	__shared__ Prep3Out outp;
+	const int tid = (int)threadIdx.x, lane = tid & 63;
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t N = P.blocksize, Q = N / 4;                            // 1024: one 16-sample chunk per lane
+	const uint32_t f = blockIdx.x;
+	const uint32_t q0 = wave * Q;
+	const int2 *p = (const int2 *)(pcm + (size_t)f * N * 2) + q0;
+	const uint32_t TS = p2_ts(Q), cbytes = p2_chan_bytes(Q);
+	int32_t *sa = (int32_t *)(smem + (size_t)wave * 2 * cbytes), *sb = (int32_t *)(smem + (size_t)wave * 2 * cbytes + cbytes);
+	const uint32_t cstride = P.ncslots;
+
+	// ---- stage this quarter: sample q0 + i -> row i%16, column i/16 + 1; column 0 = the four samples in front ---------
+	{
+		int2 v[16];
+		for(uint32_t i0 = 0; i0 < Q; i0 += 64 * 16) {
+#pragma unroll
+			for(int r = 0; r < 16; r++) v[r] = p[i0 + (uint32_t)lane + 64u * (uint32_t)r];
+#pragma unroll
+			for(int r = 0; r < 16; r++) {
+				const uint32_t i = i0 + (uint32_t)lane + 64u * (uint32_t)r;
+				const uint32_t a = (i & 15u) * TS + (i >> 4) + 1;
+				sa[a] = v[r].x; sb[a] = v[r].y;
+			}
+		}
+		if(lane < CHUNK) {
+			int2 h = make_int2(0, 0);
+			if(lane >= 12 && wave) h = p[lane - 16];
+			sa[(uint32_t)lane * TS] = h.x; sb[(uint32_t)lane * TS] = h.y;
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+
+	// ---- statistics of the four channels over this quarter: one 16-sample chunk per lane ------------------------------
+	int32_t a[20], b[20];
+	{
+		const int32_t *pa = sa + lane, *pb = sb + lane;
+#pragma unroll
+		for(int k = 0; k < 20; k++) { a[k] = k < 4 ? pa[(12 + k) * TS] : pa[(k - 4) * TS + 1]; b[k] = k < 4 ? pb[(12 + k) * TS] : pb[(k - 4) * TS + 1]; }
+	}
+	const bool first_chunk = wave == 0 && lane == 0;
+	if(P.ms_mode == 2) {
+		// loose mid/side (stream_encoder.c:3778-3807), bps < 25
+		uint64_t lr_sum = 0, ms_sum = 0;
+#pragma unroll
+		for(int t = 0; t < CHUNK; t++) {
+			if(t > 0 || !first_chunk) {
+				const int32_t pl = a[t + 4] - a[t + 3], pr = b[t + 4] - b[t + 3];
+				lr_sum += (uint64_t)(uint32_t)(abs(pl) + abs(pr));
+				ms_sum += (uint64_t)(uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
+			}
+		}
+		lr_sum = wave_sum_u50(lr_sum); ms_sum = wave_sum_u50(ms_sum);
+		if(lane == 0) { part[wave].lr = lr_sum; part[wave].ms = ms_sum; }
+	}
+#pragma unroll
+	for(int c = 0; c < 4; c++) {
+		int32_t x[20];
+#pragma unroll
+		for(int k = 0; k < 20; k++) x[k] = c == 0 ? a[k] : c == 1 ? b[k] : c == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
+		const int32_t first = __builtin_amdgcn_readfirstlane(x[4]);      // this quarter's first sample
+		Prep2Acc A;
+		A.orv = 0; A.diff = 0;
+#pragma unroll
+		for(int k = 0; k < 5; k++) A.e[k] = 0;
+		prep2_chunk<WIDE>(x, first_chunk, first, A);
+		A.orv = wave_or_u32(A.orv);
+		A.diff = wave_or_u32(A.diff);
+#pragma unroll
+		for(int k = 0; k < 5; k++) A.e[k] = WIDE ? wave_sum_u50(A.e[k]) : (uint64_t)wave_sum_u32((uint32_t)A.e[k]);   // !WIDE: 2^30 at most
+		if(lane == 0) {
+			Prep3Part &pt = part[wave];
+			pt.orv[c] = A.orv; pt.diff[c] = A.diff; pt.first[c] = first;
+#pragma unroll
+			for(int k = 0; k < 5; k++) pt.e[c][k] = A.e[k];
+		}
+	}
+	__syncthreads();
+
+	// ---- wavefront c decides channel c (every lane holds the totals) ----------------------------------------------------
+	{
+		const uint32_t c = wave, which = wave;                      // 0 left, 1 right, 2 mid, 3 side
+		uint32_t orv = 0, diff = 0;
+		uint64_t e[5] = {0, 0, 0, 0, 0}, lr = 0, ms = 0;
+		bool alleq0 = true;                                         // the LEFT channel is constant (limit_min_bitrate)
+		const int32_t f0 = part[0].first[c];
+		for(int w = 0; w < TPB / 64; w++) {
+			orv |= part[w].orv[c];
+			diff |= part[w].diff[c] | (uint32_t)(part[w].first[c] ^ f0);
+			for(int k = 0; k < 5; k++) e[k] += part[w].e[c][k];
+			lr += part[w].lr; ms += part[w].ms;
+			alleq0 = alleq0 && part[w].diff[0] == 0 && part[w].first[0] == part[0].first[0];
+		}
+		int32_t slot = (int32_t)c;
+		if(P.ms_mode == 2) { const bool use_ms = !(lr < ms); slot = use_ms ? (c >= 2 ? (int32_t)c - 2 : -1) : (c < 2 ? (int32_t)c : -1); }
+		uint32_t wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
+		if(wasted > P.bps) wasted = P.bps;
+		const uint32_t sbps = P.bps - wasted + (which == 3 ? 1 : 0);
+		const uint32_t fmt = sbps <= 16 ? 1u : 0u;
+		if(lane == 0) { outp.wasted[c] = wasted; outp.slot[c] = slot; outp.fmt[c] = fmt; }
+		if(slot >= 0) {
+			bool disable_constant = P.disable_constant != 0;
+			if(P.limit_min_bitrate && !disable_constant && (P.ms_mode == 2 ? which == 1 : which >= 1) && alleq0) disable_constant = true;
+			uint32_t flags = 0, fixed_order = 0;
+			int32_t constant = 0;
+			const uint32_t verbatim_bits = P.disable_verbatim ? 0xffffffffu : 8 + wasted + N * sbps;
+			const uint32_t n4 = N - 4;
+			const uint64_t es[5] = {e[0] >> wasted, e[1] >> wasted, e[2] >> wasted, e[3] >> wasted, e[4] >> wasted};
+			uint32_t guess_fixed;
+			{
+				const uint64_t m34 = es[3] < es[4] ? es[3] : es[4], m234 = es[2] < m34 ? es[2] : m34, m1234 = es[1] < m234 ? es[1] : m234;
+				if(es[0] <= m1234) guess_fixed = 0;
+				else if(es[1] <= m234) guess_fixed = 1;
+				else if(es[2] <= m34) guess_fixed = 2;
+				else if(es[3] <= es[4]) guess_fixed = 3;
+				else guess_fixed = 4;
+			}
+			const bool is_constant = !disable_constant && diff == 0;
+			const size_t fc = (size_t)f * P.ncand + (uint32_t)slot;
+			if(is_constant) { flags |= PREP_CONSTANT; constant = f0 >> wasted; }
+			else if(P.max_lpc_order > 0) flags |= PREP_LPC;
+			const bool fixed_allowed = !is_constant && (!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu));
+			fixed_order = fixed_allowed ? guess_fixed : 0;
+			if(emit_fixed_candidates(P, &cands[fc * cstride], &valid[fc * cstride], es, n4, guess_fixed, fixed_allowed, sbps, lane)) flags |= PREP_FIXED_VALID;
+			if(lane == 0) {
+				ChanPrep pr;
+				pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = N; pr.flags = flags; pr.fixed_order = fixed_order;
+				pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;
+				preps[fc] = pr;
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- planar channels of this quarter, shifted, straight from the registers ----------------------------------------
+	{
+		const uint32_t base = q0 + (uint32_t)lane * CHUNK;
+#pragma unroll
+		for(int c = 0; c < 4; c++) {
+			const int32_t slot = outp.slot[c];
+			if(slot < 0) continue;
+			const uint32_t wasted = outp.wasted[c];
+			int32_t x[CHUNK];
+#pragma unroll
+			for(int k = 0; k < CHUNK; k++) x[k] = (c == 0 ? a[k + 4] : c == 1 ? b[k + 4] : c == 2 ? ((a[k + 4] + b[k + 4]) >> 1) : (a[k + 4] - b[k + 4])) >> wasted;
+			uint32_t *dst = (uint32_t *)(chan + ((size_t)f * P.ncand + (uint32_t)slot) * (size_t)N);
+			if(outp.fmt[c]) {
+				uint4 w0, w1;
+				w0.x = ((uint32_t)x[0] & 0xffffu) | ((uint32_t)x[1] << 16); w0.y = ((uint32_t)x[2] & 0xffffu) | ((uint32_t)x[3] << 16);
+				w0.z = ((uint32_t)x[4] & 0xffffu) | ((uint32_t)x[5] << 16); w0.w = ((uint32_t)x[6] & 0xffffu) | ((uint32_t)x[7] << 16);
+				w1.x = ((uint32_t)x[8] & 0xffffu) | ((uint32_t)x[9] << 16); w1.y = ((uint32_t)x[10] & 0xffffu) | ((uint32_t)x[11] << 16);
+				w1.z = ((uint32_t)x[12] & 0xffffu) | ((uint32_t)x[13] << 16); w1.w = ((uint32_t)x[14] & 0xffffu) | ((uint32_t)x[15] << 16);
+				uint4 *d4 = (uint4 *)(dst + base / 2);
+				d4[0] = w0; d4[1] = w1;
+			}
+			else {
+				uint4 *d4 = (uint4 *)(dst + base);
+#pragma unroll
+				for(int k = 0; k < 4; k++) { uint4 w; w.x = (uint32_t)x[4 * k]; w.y = (uint32_t)x[4 * k + 1]; w.z = (uint32_t)x[4 * k + 2]; w.w = (uint32_t)x[4 * k + 3]; d4[k] = w; }
+			}
+		}
+	}
+}
+bool prep3_applicable(const DevParams &P) { return P.channels == 2 && P.ms_mode != 0 && P.blocksize == 4096; }
+
 // the kernel above serves frames of nominal length when every lane run is whole and the AVX2 short-tail quirk of
 // the reference's wide fixed-predictor routine cannot occur (fixed_intrin_avx2.c:57 with (n-4) % 4 != 0)
 bool prep2_applicable(const DevParams &P)
@@ -263,6 +451,19 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e != hipSuccess) return e;
 		attr_set = true;
+	}
+	if(prep3_applicable(P) && !getenv("FLACGPU_NO_PREP3")) {
+		static bool attr3 = false;
+		if(!attr3) {
+			hipError_t e = hipFuncSetAttribute((const void *)prep3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e != hipSuccess) return e;
+			attr3 = true;
+		}
+		const size_t lds3 = 8 * (size_t)p2_chan_bytes(P.blocksize / 4);
+		if(P.bps > 20) hipLaunchKernelGGL(prep3_kernel<true>, dim3(nmain), dim3(TPB), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
+		else hipLaunchKernelGGL(prep3_kernel<false>, dim3(nmain), dim3(TPB), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
+		return hipGetLastError();
 	}
 	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
