@@ -273,7 +273,7 @@ __global__ __launch_bounds__(TPB, AUTOC_WAVES_PER_SIMD) void autoc_kernel(const 
 	const uint32_t n = pr.n;
 	const uint32_t max_lpc = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
 	const uint32_t lag = max_lpc + 1;
-	const uint32_t variant = n <= 32 ? 0u : P.autoc_variant;
+	const uint32_t variant = n <= 32 ? 0u : P.autoc_variant;      // 0: the plain loop of lpc.c:133-157
 	const WindowJob jv = jt->jobs[jb];
 	JobView J;
 	J.frame_pcm = pcm + (size_t)f * P.blocksize * P.channels;
@@ -282,16 +282,40 @@ __global__ __launch_bounds__(TPB, AUTOC_WAVES_PER_SIMD) void autoc_kernel(const 
 	J.full = jv.full; J.part = jv.part; J.dshift = jv.dshift; J.i0 = jv.i0;
 	const uint32_t nd = jv.nd;
 	const uint32_t tail_lo = nd > (uint32_t)ATAIL ? nd - ATAIL : 0;
-	double *out = autoc_out + ((size_t)fc * P.max_jobs + jb) * MAX_ORDER;
+	double *out = autoc_out + ((size_t)fc * P.max_jobs + jb) * AUTOC_STRIDE;
 
 	// plain head / tail copies
 	if(lane < AHEAD) { int32_t v; float wt; job_fetch(J, (uint32_t)lane, v, wt); W.head[lane] = job_value(J, v, wt); }
 	if(lane < ATAIL) { int32_t v; float wt; job_fetch(J, tail_lo + (uint32_t)lane, v, wt); W.tail[lane] = job_value(J, v, wt); }
 
-	if(variant == 0) {
+	if(variant == 0 && n <= 32) {
 		// lpc.c:133-157 (blocksize <= 32): the whole job sits in W.tail (tail_lo == 0)
 		__builtin_amdgcn_wave_barrier();
 		if((uint32_t)lane < lag) out[lane] = autoc_small(W.tail, nd, (uint32_t)lane);
+		return;
+	}
+	if(variant == 0) {
+		// lpc.c:133-157 with lag > 16 (max_lpc_order >= 16): autoc[c] = sum over s of d[s]*d[s+c] in increasing s, one lane
+		// per lag.  Every product of two floats is exact in double, so the chain is a plain sequence of additions; the
+		// samples stream through the tile as doubles, 256 at a time plus the 32 the largest lag looks ahead (zeros
+		// beyond the job's data add nothing).
+		double *td = (double *)W.tile;                       // 288 doubles
+		double acc = 0.0;
+		for(uint32_t t0 = 0; t0 < nd; t0 += 256) {
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for(int u = 0; u < 5; u++) {
+				const uint32_t k = (uint32_t)lane + 64u * (uint32_t)u;
+				if(k < 288) { int32_t v; float wt; job_fetch(J, t0 + k, v, wt); td[k] = (double)job_value(J, v, wt); }
+			}
+			__builtin_amdgcn_wave_barrier();
+			if((uint32_t)lane < lag) {
+				const double *py = td + lane;
+#pragma unroll 8
+				for(int sidx = 0; sidx < 256; sidx++) acc = fma(td[sidx], py[sidx], acc);
+			}
+		}
+		if((uint32_t)lane < lag) out[lane] = acc;
 		return;
 	}
 	const uint32_t L = variant;
@@ -429,8 +453,8 @@ __global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t 
 		const uint32_t lag = max_lpc + 1;
 		const uint32_t jb = jt->an_job[a], rt = jt->an_root[a];
 		const bool punch = jt->an_punch[a] != 0;
-		const double *aj = autoc_in + ((size_t)fc * P.max_jobs + jb) * MAX_ORDER;
-		const double *ar = autoc_in + ((size_t)fc * P.max_jobs + rt) * MAX_ORDER;
+		const double *aj = autoc_in + ((size_t)fc * P.max_jobs + jb) * AUTOC_STRIDE;
+		const double *ar = autoc_in + ((size_t)fc * P.max_jobs + rt) * AUTOC_STRIDE;
 		double av[MAXORD + 1];
 #pragma unroll
 		for(int j = 0; j <= MAXORD; j++) {
@@ -800,7 +824,7 @@ __host__ __device__ inline uint32_t owner_chan_bytes(uint32_t N, bool packed)
 	const uint32_t S = N / 64, w = (packed ? (S + OH) / 2 : S + OH) | 1u;
 	return (64 * w * 4 + (CHUNK + MAX_ORDER) * 4 + 15u) & ~15u;
 }
-__host__ __device__ inline bool owner_possible(const DevParams &P) { return P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH; }
+__host__ __device__ inline bool owner_possible(const DevParams &P) { return P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH && P.max_lpc_order <= (uint32_t)OH; }
 // candidate records are staged in LDS next to the channel image when there are few of them (every preset); the wide
 // searches (-e, -p: hundreds of slots per channel) read them from global memory and keep only the valid flags in LDS
 __host__ __device__ inline bool eval_cands_in_lds(const DevParams &P) { return P.ncslots <= 48; }
@@ -887,7 +911,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	const uint32_t S = n / 64;
 	// (a short last block whose lane runs are odd while the nominal ones are even would need a wider image than the
 	// launch reserved: it takes the generic path)
-	const bool owner = (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6 && (S % 2 == 0 || (N / 64) % 2 == 1);
+	const bool owner = MAXORD <= OH && (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6 && (S % 2 == 0 || (N / 64) % 2 == 1);
 	const uint32_t cand_bytes = eval_cand_bytes(P), cand_valid_off = cands_lds ? P.ncslots * (uint32_t)sizeof(Candidate) : 0u;
 
 	// ---- channel facts ---------------------------------------------------------------------------------------
@@ -1006,8 +1030,9 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 				const Candidate *cd = (cands_lds ? (const Candidate *)(ctx + img_bytes) : cands + (fc0 + c) * cstride) + ci;
 				if(!((const int *)(ctx + img_bytes + cand_valid_off))[ci]) continue;
 				const uint32_t order = cd->order, sbps = E.pr.sbps, hdr = 8 + E.pr.wasted;
-				uint32_t po, rbits;
-				if(VARIANT == 0)
+				uint32_t po = 0, rbits;
+				if constexpr(VARIANT == 0 && MAXORD > OH) rbits = 0;      // predictors of more than 16 taps are evaluated by VARIANT 2
+				else if constexpr(VARIANT == 0)
 					rbits = eval_candidate_owner<MAXORD>((const uint32_t *)ctx + (uint32_t)lane * E.stride, E.packed != 0, S, n, order, cd->q, cd->shift, cd->wide != 0, sbps, P.rice_limit,
 					                                     frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
 				else {
@@ -1075,7 +1100,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			}
 			rice2 = __any((int)big) ? 1u : 0u;                         // stream_encoder.c:4786-4791
 		}
-		if(lane < MAX_ORDER) dec->q[lane] = best_type == 3 ? mycands[best_ci].q[lane] : 0;
+		if(lane < MAX_ORDER) dec->q[lane] = best_type == 3 && lane < MAXORD ? mycands[best_ci].q[lane] : 0;
 		if(lane == 0) {
 			dec->bits = best_bits;
 			dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
@@ -1170,7 +1195,7 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	}
 	// which flavours can occur in this batch at all (each launch serves only its own channels)
 	if(op) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
-	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, true).total, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	if(!op || tail_n || P.max_po > 6)
 		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(gwaves * 64), lds_generic, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	return hipGetLastError();
@@ -1216,6 +1241,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
 	if(m <= 8) return launch_model_eval<8>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);
 	if(m <= 12) return launch_model_eval<12>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);
-	return launch_model_eval<16>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);
+	if(m <= 16) return launch_model_eval<16>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);
+	return launch_model_eval<32>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);
 }
 } // namespace flacgpu

@@ -171,7 +171,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	if(cfg->channels < 1 || cfg->channels > FLACGPU_MAX_CHANNELS) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->bits_per_sample < 4 || cfg->bits_per_sample > 24) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->blocksize < 16 || cfg->blocksize > 16384) return FLACGPU_ERR_UNSUPPORTED;
-	if(cfg->max_lpc_order > 15) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->max_lpc_order > (uint32_t)MAX_ORDER) return FLACGPU_ERR_UNSUPPORTED;       // FLAC__MAX_LPC_ORDER
 	if(cfg->max_lpc_order > 0 && (cfg->qlp_coeff_precision < 5 || cfg->qlp_coeff_precision > 15)) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->max_residual_partition_order > MAX_PO) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->max_lpc_order > 0 && (cfg->num_apodizations < 1 || cfg->num_apodizations > FLACGPU_MAX_APODIZATIONS)) return FLACGPU_ERR_UNSUPPORTED;
@@ -205,7 +205,8 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	P.num_apod = cfg->max_lpc_order > 0 ? cfg->num_apodizations : 0;
 	for(uint32_t a = 0; a < P.num_apod; a++) { P.apod_kind[a] = cfg->apodizations[a].kind; P.apod_parts[a] = cfg->apodizations[a].parts; }
 	// stream_encoder.c:1058-1066 on an FMA-capable x86-64 host
-	P.autoc_variant = cfg->max_lpc_order < 8 ? 8u : cfg->max_lpc_order < 12 ? 12u : 16u;
+	// 0: from order 16 up the plain C loop of lpc.c:133-157 does the work (lag > 16)
+	P.autoc_variant = cfg->max_lpc_order < 8 ? 8u : cfg->max_lpc_order < 12 ? 12u : cfg->max_lpc_order < 16 ? 16u : 0u;
 	P.disable_constant = cfg->disable_constant_subframes; P.disable_fixed = cfg->disable_fixed_subframes;
 	P.disable_verbatim = cfg->disable_verbatim_subframes; P.limit_min_bitrate = cfg->limit_min_bitrate;
 	// worst-case frame: header + per channel (verbatim size + Rice estimate slack of N/2 bits + side info)
@@ -267,7 +268,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	{
 		const size_t nfc = B * P.ncand, ncs = P.ncslots;
 		ok = ok && hipMalloc(&c->ab.prep, nfc * sizeof(ChanPrep)) == hipSuccess;
-		ok = ok && hipMalloc(&c->ab.autoc, nfc * P.max_jobs * MAX_ORDER * sizeof(double)) == hipSuccess;
+		ok = ok && hipMalloc(&c->ab.autoc, nfc * P.max_jobs * AUTOC_STRIDE * sizeof(double)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.cands, nfc * ncs * sizeof(Candidate)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.valid, nfc * ncs * sizeof(int)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.chan, nfc * N * sizeof(int32_t)) == hipSuccess;
@@ -317,7 +318,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			(void)hipStreamWaitEvent(ss, c->ev_fork, 0);
 			const size_t fc0 = (size_t)f0 * P.ncand, ncs = P.ncslots;
 			AnalyzeBuffers B = c->ab;
-			B.prep += fc0; B.autoc += fc0 * P.max_jobs * MAX_ORDER; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.blocksize; B.dbg = nullptr;
+			B.prep += fc0; B.autoc += fc0 * P.max_jobs * AUTOC_STRIDE; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.blocksize; B.dbg = nullptr;
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
 			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, B,
 			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;

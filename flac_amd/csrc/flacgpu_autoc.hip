@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(cons
 	const uint32_t max_lpc = P.max_lpc_order >= N ? N - 1 : P.max_lpc_order;
 	const uint32_t lag = max_lpc + 1;
 	const uint32_t fc = fc0 + (uint32_t)item;
-	double *out = autoc_out + ((size_t)fc * P.max_jobs + jb) * MAX_ORDER;
+	double *out = autoc_out + ((size_t)fc * P.max_jobs + jb) * AUTOC_STRIDE;
 	const float *head = tile + item * A2_IST, *tail = head + 16;
 #pragma unroll
 	for(int m = 0; m < (LAG + 3) / 4; m++) {

@@ -10,7 +10,8 @@ namespace flacgpu {
 
 constexpr int TPB = 256;        // threads per workgroup (4 wavefronts of 64)
 constexpr int CHUNK = 16;       // consecutive samples owned by one thread in FIR passes
-constexpr int MAX_ORDER = 16;   // taps kept per candidate (max_lpc_order <= 15)
+constexpr int MAX_ORDER = 32;   // taps kept per candidate (FLAC__MAX_LPC_ORDER, format.h)
+constexpr int AUTOC_STRIDE = 40;// doubles per autocorrelation record (lags 0..32)
 constexpr int MAX_PO = 8;       // max residual partition order (FLAC subset limit)
 constexpr int MAX_JOBS = 24;    // windowed-data jobs per subframe (subdivide_tukey up to 6 parts)
 constexpr int MAX_ANALYSES = 40;// LPC analyses per subframe
@@ -89,7 +90,7 @@ struct ChanPrep {
 };
 struct AnalyzeBuffers {
 	ChanPrep *prep;            // [frames*ncand]
-	double *autoc;             // [frames*ncand][max_jobs][MAX_ORDER]
+	double *autoc;             // [frames*ncand][max_jobs][AUTOC_STRIDE]
 	Candidate *cands;          // [frames*ncand][ncslots]: fixed orders, then analysis a / order / precision (DevParams::ncslots)
 	int *valid;                // same shape
 	int32_t *chan;             // [frames*ncand][blocksize] planar channel signals, wasted bits shifted out (ChanPrep::fmt)

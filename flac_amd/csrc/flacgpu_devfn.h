@@ -210,7 +210,7 @@ __device__ __forceinline__ int quantize_candidate(const float (&coef)[MAXORD], u
 		out->wide = silog2_i64((int64_t)before) > 32;
 	}
 #pragma unroll
-	for(int i = 0; i < MAX_ORDER; i++) out->q[i] = i < MAXORD ? q[i < MAXORD ? i : 0] : 0;
+	for(int i = 0; i < MAXORD; i++) out->q[i] = q[i];                // taps past MAXORD are never read
 	out->order = order;
 	out->precision = precision;
 	out->shift = shift;
@@ -432,7 +432,7 @@ __device__ __forceinline__ bool emit_fixed_candidates(const DevParams &P, Candid
 		const uint64_t eo = order == 0 ? e[0] : order == 1 ? e[1] : order == 2 ? e[2] : order == 3 ? e[3] : e[4];
 		const bool ok = allowed && !(fixed_rbps(eo, n4) >= (float)sbps);
 		any = any || ok;
-		if(lane < MAX_ORDER) {
+		if(lane < 16) {                                               // every kernel flavour keeps at least 8 taps
 			int32_t c = 0;
 			if(order == 1) c = lane == 0 ? 1 : 0;
 			else if(order == 2) c = lane == 0 ? 2 : lane == 1 ? -1 : 0;

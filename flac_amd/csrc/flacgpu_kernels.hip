@@ -900,15 +900,17 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 	static bool attr_set = false;
 	if(!attr_set) {
 		hipError_t e = hipFuncSetAttribute((const void *)pack_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if constexpr(MAXORD <= 16) { if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); }
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
 	uint32_t f_lo = 0;
-	if(pack2_applicable(P)) {
-		f_lo = tail_n ? nframes - 1 : nframes;
-		const size_t lds2 = (size_t)P.slot_bytes + 16 + sizeof(Pack2Shared);
-		if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg);
+	if constexpr(MAXORD <= 16) {                  // predictors of more than 16 taps (-l 17..32) take the general kernel
+		if(pack2_applicable(P)) {
+			f_lo = tail_n ? nframes - 1 : nframes;
+			const size_t lds2 = (size_t)P.slot_bytes + 16 + sizeof(Pack2Shared);
+			if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg);
+		}
 	}
 	if(f_lo < nframes) hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes - f_lo), dim3(TPB), lds, s, P, chan, nframes, tail_n, f_lo, first, dec, slots, fb, info);
 	return hipGetLastError();
@@ -928,7 +930,8 @@ hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
 	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
 	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
-	return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
+	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
+	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
 }
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)
 {

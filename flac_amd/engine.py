@@ -146,7 +146,8 @@ def load_engine():
 
 def make_settings(channels=2, bps=16, rate=44100, level=5, blocksize=0, apodization=None, limit_min_bitrate=0,
                   max_lpc_order=None, max_partition_order=None, min_partition_order=None, mid_side=None,
-                  loose_mid_side=None, qlp_coeff_precision=None, streamable_subset=1, exhaustive=0, prec_search=0):
+                  loose_mid_side=None, qlp_coeff_precision=None, streamable_subset=1, exhaustive=0, prec_search=0,
+                  disable=(0, 0, 0)):
     """Mirrors the order of the FLAC__stream_encoder_set_* calls a client makes before init."""
     h = load_host()
     s = HostSettings()
@@ -173,6 +174,7 @@ def make_settings(channels=2, bps=16, rate=44100, level=5, blocksize=0, apodizat
     s.limit_min_bitrate = limit_min_bitrate
     s.do_exhaustive_model_search = 1 if exhaustive else 0
     s.do_qlp_coeff_prec_search = 1 if prec_search else 0
+    s.disable_constant_subframes, s.disable_fixed_subframes, s.disable_verbatim_subframes = disable
     st = h.flacgpu_host_settings_resolve(C.byref(s))
     if st != 0:
         raise FlacGpuError("invalid encoder settings: FLAC__StreamEncoderInitStatus %d" % st)

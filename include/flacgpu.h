@@ -62,7 +62,7 @@ typedef struct {
 	uint32_t blocksize;              /* 16..16384 */
 	uint32_t do_mid_side_stereo;
 	uint32_t loose_mid_side_stereo;
-	uint32_t max_lpc_order;          /* 0..15 (the FMA autocorrelation routines, stream_encoder.c:1058-1066) */
+	uint32_t max_lpc_order;          /* 0..32; below 16 the FMA autocorrelation routines (stream_encoder.c:1058-1066), from 16 the C loop (lpc.c:133) */
 	uint32_t qlp_coeff_precision;    /* resolved, 5..15 */
 	uint32_t min_residual_partition_order;
 	uint32_t max_residual_partition_order; /* <= 8 */

@@ -779,7 +779,7 @@ int64_t fo_encode_frame(const fo_config *cfg, const int32_t *const pcm[], uint64
 {
 	const uint32_t N = cfg->blocksize, C = cfg->channels, bps = cfg->bits_per_sample;
 	if(C < 1 || C > FO_MAX_CHANNELS || bps < 4 || bps > 24 || N < 1 || N > 65535) return -1;
-	if(cfg->max_lpc_order >= 16 && N > FO_MAX_LPC_ORDER) return -1; /* would dispatch to a routine not restated here */
+	if(cfg->max_lpc_order > FO_MAX_LPC_ORDER) return -1;
 	const int ms = cfg->do_mid_side && C == 2;
 	int do_indep = 1, do_ms = 0, loose_pick_ms = 0;
 	uint32_t max_po = umin(max_po_from_blocksize(N), cfg->max_partition_order);

@@ -49,6 +49,7 @@ class RefCfg(C.Structure):
         ("mid_side", C.c_int32), ("loose_mid_side", C.c_int32),
         ("apodization", C.c_char_p),
         ("exhaustive", C.c_int32), ("prec_search", C.c_int32),
+        ("disable_constant", C.c_int32), ("disable_fixed", C.c_int32), ("disable_verbatim", C.c_int32),
     ]
 
 
@@ -76,10 +77,13 @@ def load_ref():
 
 def ref_cfg(channels, bps, rate, level, blocksize=0, do_md5=0, num_threads=0, limit_min_bitrate=0,
             streamable_subset=1, max_lpc_order=-1, qlp_precision=-1, min_po=-1, max_po=-1,
-            mid_side=-1, loose_mid_side=-1, apodization=None, disable_isa_mask=0, exhaustive=0, prec_search=0):
+            mid_side=-1, loose_mid_side=-1, apodization=None, disable_isa_mask=0, exhaustive=0, prec_search=0,
+            disable=(0, 0, 0)):
+    """disable = (constant, fixed, verbatim) subframes switched off"""
     return RefCfg(channels, bps, rate, level, blocksize, do_md5, num_threads, disable_isa_mask,
                   limit_min_bitrate, streamable_subset, max_lpc_order, qlp_precision, min_po, max_po,
-                  mid_side, loose_mid_side, apodization.encode() if apodization else None, exhaustive, prec_search)
+                  mid_side, loose_mid_side, apodization.encode() if apodization else None, exhaustive, prec_search,
+                  disable[0], disable[1], disable[2])
 
 
 def ref_encode(pcm, bps, rate, level, want_bytes=True, **kw):
@@ -215,7 +219,7 @@ class OracleConfig:
 
     def __init__(self, channels, bps, rate, level, blocksize=None, stream_blocksize=None, limit_min_bitrate=0,
                  max_lpc_order=None, max_po=None, min_po=0, mid_side=None, loose=None, apod=None,
-                 qlp_precision=None, exhaustive=0, prec_search=0):
+                 qlp_precision=None, exhaustive=0, prec_search=0, disable=(0, 0, 0)):
         ms, lo, lpc, mpo, ap = PRESETS[level]
         if max_lpc_order is not None:
             lpc = max_lpc_order
@@ -256,6 +260,7 @@ class OracleConfig:
         c.autoc_variant = 8 if lpc < 8 else 12 if lpc < 12 else 16 if lpc < 16 else 0
         c.limit_min_bitrate = limit_min_bitrate
         c.exhaustive, c.prec_search = exhaustive, prec_search
+        c.disable_constant, c.disable_fixed, c.disable_verbatim = disable
         self.c = c
 
 

@@ -18,6 +18,9 @@
 /* exported-but-unheadered test hooks of the reference (stream_encoder.c:1829,2249) */
 extern FLAC__bool FLAC__stream_encoder_set_do_md5(FLAC__StreamEncoder *encoder, FLAC__bool value);
 extern FLAC__bool FLAC__stream_encoder_disable_instruction_set(FLAC__StreamEncoder *encoder, int value);
+extern FLAC__bool FLAC__stream_encoder_disable_constant_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
+extern FLAC__bool FLAC__stream_encoder_disable_fixed_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
+extern FLAC__bool FLAC__stream_encoder_disable_verbatim_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
 
 typedef struct {
 	uint8_t *out;
@@ -66,6 +69,7 @@ typedef struct {
 	int32_t mid_side, loose_mid_side; /* -1 = keep preset */
 	const char *apodization;  /* NULL = keep preset */
 	int32_t exhaustive, prec_search; /* -e / -p: FLAC__stream_encoder_set_do_exhaustive_model_search / _qlp_coeff_prec_search */
+	int32_t disable_constant, disable_fixed, disable_verbatim; /* --disable-*-subframes (stream_encoder.c:2262-2292) */
 } ref_cfg_t;
 
 static FLAC__StreamEncoder *make_encoder(const ref_cfg_t *cfg, uint64_t total_samples)
@@ -92,6 +96,9 @@ static FLAC__StreamEncoder *make_encoder(const ref_cfg_t *cfg, uint64_t total_sa
 	FLAC__stream_encoder_set_total_samples_estimate(e, total_samples);
 	if(cfg->num_threads > 1) FLAC__stream_encoder_set_num_threads(e, (uint32_t)cfg->num_threads);
 	if(cfg->disable_isa_mask) FLAC__stream_encoder_disable_instruction_set(e, cfg->disable_isa_mask);
+	if(cfg->disable_constant) FLAC__stream_encoder_disable_constant_subframes(e, true);
+	if(cfg->disable_fixed) FLAC__stream_encoder_disable_fixed_subframes(e, true);
+	if(cfg->disable_verbatim) FLAC__stream_encoder_disable_verbatim_subframes(e, true);
 	return e;
 }
 

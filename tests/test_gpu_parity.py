@@ -285,7 +285,7 @@ def test_wider_model_searches_match_oracle(level, mode):
         assert data == o["data"], (fam, bps, level, mode)
 
 
-@pytest.mark.parametrize("order", [1, 2, 4, 5, 7, 9, 10, 11, 13, 14, 15])
+@pytest.mark.parametrize("order", [1, 2, 4, 5, 7, 9, 10, 11, 13, 14, 15, 16, 17, 24, 31, 32])
 def test_every_lpc_order_class(order):
     """one max_lpc_order from every autocorrelation-routine / FIR-width class (the MAXORD 8 / 12 / 16 kernel instances)"""
     for bps in (16, 24):
@@ -315,3 +315,51 @@ def test_partition_order_ranges(po_range):
         data, fb = _gpu_encode(pcm, 16, 44100, level, min_partition_order=lo, max_partition_order=hi, max_batch=8)
         o = po.oracle_encode(pcm, 16, 44100, level, min_po=lo, max_po=hi)
         assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (po_range, level)
+
+
+TINY_ORDERS = (0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32)
+DISABLES = ((0, 0, 0), (1, 0, 1), (1, 1, 1))
+
+
+@pytest.mark.parametrize("blocksize", [16, 17, 19, 24, 31, 32, 33])
+def test_tiny_blocks_all_orders(blocksize):
+    """test/test_streams.sh:221-239: 8-bit mono noise, -8 -p -e -l <order> --lax --blocksize=<16..33>, with the
+    constant / fixed / verbatim subframes switched off in turn, and the same with subdivide_tukey(32)"""
+    pcm = signals.white(blocksize * 5 + 7, 1, 8, seed=blocksize)
+    for order in TINY_ORDERS:
+        if order > blocksize:
+            continue
+        for kw in [dict(disable=d) for d in DISABLES] + [dict(apodization="subdivide_tukey(32)")]:
+            okw = dict(kw)
+            if "apodization" in okw:
+                okw["apod"] = ("subdivide_tukey", 32)
+                del okw["apodization"]
+            data, fb = _gpu_encode(pcm, 8, 44100, 8, blocksize=blocksize, max_lpc_order=order, exhaustive=1, prec_search=1,
+                                   streamable_subset=0, max_batch=8, **kw)
+            o = po.oracle_encode(pcm, 8, 44100, 8, blocksize=blocksize, max_lpc_order=order, exhaustive=1, prec_search=1, **okw)
+            assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (blocksize, order, kw)
+
+
+@pytest.mark.parametrize("order", [16, 32])
+def test_high_orders_with_searches(order):
+    """test/test_streams.sh:181-219: -0 -l 16|32 --lax -m -e -p on sines and full-scale streams, 8 / 16 / 24 bits"""
+    for bps in (8, 16, 24):
+        for fam, ch in (("sine", 1), ("music", 2), ("square", 2)):
+            pcm = signals.FAMILIES[fam](1152 * 2 + 301, ch, bps)
+            data, fb = _gpu_encode(pcm, bps, 44100, 0, max_lpc_order=order, exhaustive=1, prec_search=1, mid_side=1,
+                                   loose_mid_side=0, streamable_subset=0, max_batch=8)
+            o = po.oracle_encode(pcm, bps, 44100, 0, max_lpc_order=order, exhaustive=1, prec_search=1, mid_side=1, loose=0)
+            assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (order, bps, fam)
+
+
+@pytest.mark.parametrize("kw", [dict(blocksize=1000), dict(blocksize=4096, max_lpc_order=20, streamable_subset=0), dict(blocksize=576),
+                                dict(blocksize=33, max_lpc_order=32, streamable_subset=0)],
+                         ids=["b1000", "l20", "b576", "b33l32"])
+def test_constant_and_silent_channels_off_the_fast_paths(kw):
+    """CONSTANT subframes (a channel, or only the mid channel of a full-scale square pair) where the general kernels do the work"""
+    for fam in ("square", "constant", "silence", "mixed"):
+        pcm = signals.FAMILIES[fam](kw["blocksize"] * 3 + 77, 2, 16)
+        data, fb = _gpu_encode(pcm, 16, 44100, 8, max_batch=8, **kw)
+        okw = {k: v for k, v in kw.items() if k != "streamable_subset"}
+        o = po.oracle_encode(pcm, 16, 44100, 8, **okw)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (fam, kw)

@@ -194,7 +194,7 @@ def test_exhaustive_and_precision_search(ref, level, mode):
         assert o["data"] == _frames(r), (fam, bps, level, mode)
 
 
-@pytest.mark.parametrize("order", [1, 2, 4, 5, 7, 9, 10, 11, 13, 14, 15])
+@pytest.mark.parametrize("order", [1, 2, 4, 5, 7, 9, 10, 11, 13, 14, 15, 16, 17, 24, 31, 32])
 def test_every_lpc_order_class(ref, order):
     """max_lpc_order selects the compiled autocorrelation routine (lag 8 / 12 / 16, stream_encoder.c:1058-1066) and the
     FIR width: one value from every class, 16-bit at 96 kHz (orders above 12 are not in the subset at <= 48 kHz) and 24-bit"""
@@ -221,3 +221,49 @@ def test_partition_order_ranges(ref, po_range):
     for level in (2, 8):
         r = po.ref_encode(pcm, 16, 44100, level, min_po=lo, max_po=hi)
         assert po.oracle_encode(pcm, 16, 44100, level, min_po=lo, max_po=hi)["data"] == _frames(r), (po_range, level)
+
+
+TINY_ORDERS = (0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32)
+DISABLES = ((0, 0, 0), (1, 0, 1), (1, 1, 1))
+
+
+@pytest.mark.parametrize("blocksize", range(16, 34))
+def test_tiny_blocks_all_orders(ref, blocksize):
+    """test/test_streams.sh:221-239: 8-bit mono noise, -8 -p -e -l <order> --lax --blocksize=<16..33>, with the
+    constant / fixed / verbatim subframes switched off in turn, and the same with subdivide_tukey(32)"""
+    pcm = signals.white(blocksize * 5 + 7, 1, 8, seed=blocksize)
+    for order in TINY_ORDERS:
+        if order > blocksize:
+            continue
+        for kw in [dict(disable=d) for d in DISABLES] + [dict(apodization="subdivide_tukey(32)")]:
+            okw = dict(kw)
+            if "apodization" in okw:
+                okw["apod"] = ("subdivide_tukey", 32)
+                del okw["apodization"]
+            r = po.ref_encode(pcm, 8, 44100, 8, blocksize=blocksize, max_lpc_order=order, exhaustive=1, prec_search=1,
+                              streamable_subset=0, **kw)
+            o = po.oracle_encode(pcm, 8, 44100, 8, blocksize=blocksize, max_lpc_order=order, exhaustive=1, prec_search=1, **okw)
+            assert o["data"] == _frames(r), (blocksize, order, kw)
+
+
+@pytest.mark.parametrize("order", [16, 32])
+def test_high_orders_with_searches(ref, order):
+    """test/test_streams.sh:181-219: -0 -l 16|32 --lax -m -e -p on sines and full-scale streams, 8 / 16 / 24 bits"""
+    for bps in (8, 16, 24):
+        for fam, ch in (("sine", 1), ("music", 2), ("square", 2)):
+            pcm = signals.FAMILIES[fam](1152 * 2 + 301, ch, bps)
+            kw = dict(max_lpc_order=order, exhaustive=1, prec_search=1, mid_side=1, loose_mid_side=0)
+            r = po.ref_encode(pcm, bps, 44100, 0, streamable_subset=0, **kw)
+            kw["loose"] = kw.pop("loose_mid_side")
+            o = po.oracle_encode(pcm, bps, 44100, 0, **kw)
+            assert o["data"] == _frames(r), (order, bps, fam)
+
+
+@pytest.mark.parametrize("kw", [dict(blocksize=1000), dict(blocksize=4096, max_lpc_order=20), dict(blocksize=576),
+                                dict(blocksize=33, max_lpc_order=32)], ids=["b1000", "l20", "b576", "b33l32"])
+def test_constant_and_silent_channels(ref, kw):
+    for fam in ("square", "constant", "silence", "mixed"):
+        pcm = signals.FAMILIES[fam](kw["blocksize"] * 3 + 77, 2, 16)
+        r = po.ref_encode(pcm, 16, 44100, 8, streamable_subset=0, **kw)
+        o = po.oracle_encode(pcm, 16, 44100, 8, **kw)
+        assert o["data"] == _frames(r), (fam, kw)
