@@ -138,6 +138,23 @@ void fo_window_data_partial(const int32_t *in, const float *w, float *out, uint3
 	}
 }
 
+/* the same on the 64-bit signal arrays this restatement keeps internally: lpc.c:75,96 for the 33-bit side channel;
+ * for every narrower channel (float)(int64)v == (float)(int32)v, one rounding either way */
+static void window_data64(const int64_t *in, const float *w, float *out, uint32_t n)
+{
+	for(uint32_t i = 0; i < n; i++) out[i] = (float)in[i] * w[i];
+}
+static void window_data_partial64(const int64_t *in, const float *w, float *out, uint32_t n, uint32_t part_size, uint32_t data_shift)
+{
+	uint32_t i, j;
+	if(part_size + data_shift < n) {
+		for(i = 0; i < part_size; i++) out[i] = (float)in[data_shift + i] * w[i];
+		i = umin(i, n - part_size - data_shift);
+		for(j = n - part_size; j < n; i++, j++) out[i] = (float)in[data_shift + i] * w[j];
+		if(i < n) out[i] = 0.0f;
+	}
+}
+
 /* ------------------------------------------------------------------------------------
  * autocorrelation, in the association order of the reference's compiled routines
  * ---------------------------------------------------------------------------------- */
@@ -409,10 +426,92 @@ uint32_t fo_fixed_best_predictor(const int32_t *data, uint32_t n, float rbps[5])
 	return fo_fixed_best_predictor_ex(data, n, rbps, 0);
 }
 
-/* fixed.c:470-499 (32-bit wrapping; the _wide flavour at :501 is selected only when
- * bps+order > 32, which this restatement's bps <= 24(+1) range never reaches) */
-static void fixed_residual(const int32_t *x, uint32_t n, uint32_t order, int32_t *r) /* x -> sample `order` */
+static uint64_t abs64(int64_t v) { return (uint64_t)(v < 0 ? -v : v); }
+#define RBPS_OF(err, n) ((float)(((err) > 0) ? log(M_LN2 * (double)(err) / (double)(n)) / M_LN2 : 0.0))
+/* subframe_bps 28..32: FLAC__fixed_compute_best_predictor_limit_residual_intrin_avx2 (fixed_intrin_avx2.c:187, selected at
+ * stream_encoder.c:1027/1088).  Unlike the estimators above the sums start at sample 0 of the block (orders that can be
+ * formed there), four 64-bit lanes take n/4 samples each -- history from offset l*(n/4), data from offset (l*n)/4, the
+ * same quirk as the _wide flavour -- and the n%4 trailing samples are added afterwards.  An order whose residual
+ * leaves the int32 range anywhere is marked with 34 bits per sample and cannot be picked. */
+static uint32_t fixed_best_predictor_limit_avx2(const int32_t *data, uint32_t n, float rbps[5])
 {
+	uint64_t tot[5] = {0, 0, 0, 0, 0}, sh[5] = {0, 0, 0, 0, 0}, smallest = UINT64_MAX;
+	const int32_t q = (int32_t)(n / 4);
+	uint32_t order = 0;
+	for(int32_t i = -4; i < 0; i++) {
+		uint64_t e[4];
+		e[0] = abs64((int64_t)data[i]);
+		e[1] = i > -4 ? abs64((int64_t)data[i] - data[i - 1]) : 0;
+		e[2] = i > -3 ? abs64((int64_t)data[i] - 2 * (int64_t)data[i - 1] + data[i - 2]) : 0;
+		e[3] = i > -2 ? abs64((int64_t)data[i] - 3 * (int64_t)data[i - 1] + 3 * (int64_t)data[i - 2] - data[i - 3]) : 0;
+		for(int k = 0; k < 4; k++) { tot[k] += e[k]; sh[k] |= e[k]; }
+	}
+	for(int32_t l = 0; l < 4; l++) {
+		const int32_t h = l * q, start = (int32_t)(((uint64_t)l * n) / 4);
+		int64_t p0 = data[-1 + h], p1 = (int64_t)data[-1 + h] - data[-2 + h], p2 = p1 - ((int64_t)data[-2 + h] - data[-3 + h]),
+		        p3 = p2 - ((int64_t)data[-2 + h] - 2 * (int64_t)data[-3 + h] + data[-4 + h]);
+		for(int32_t i = 0; i < q; i++) {
+			const int64_t d0 = data[i + start], d1 = d0 - p0, d2 = d1 - p1, d3 = d2 - p2, d4 = d3 - p3;
+			const uint64_t e[5] = { abs64(d0), abs64(d1), abs64(d2), abs64(d3), abs64(d4) };
+			for(int k = 0; k < 5; k++) { tot[k] += e[k]; sh[k] |= e[k]; }
+			p0 = d0; p1 = d1; p2 = d2; p3 = d3;
+		}
+	}
+	for(int32_t i = 4 * q; i < (int32_t)n; i++) {
+		const uint64_t e[5] = {
+			abs64((int64_t)data[i]), abs64((int64_t)data[i] - data[i - 1]), abs64((int64_t)data[i] - 2 * (int64_t)data[i - 1] + data[i - 2]),
+			abs64((int64_t)data[i] - 3 * (int64_t)data[i - 1] + 3 * (int64_t)data[i - 2] - data[i - 3]),
+			abs64((int64_t)data[i] - 4 * (int64_t)data[i - 1] + 6 * (int64_t)data[i - 2] - 4 * (int64_t)data[i - 3] + data[i - 4]) };
+		for(int k = 0; k < 5; k++) { tot[k] += e[k]; sh[k] |= e[k]; }
+	}
+	for(uint32_t k = 0; k < 5; k++) {                      /* CHECK_ORDER_IS_VALID, fixed_intrin_avx2.c:172 */
+		if(sh[k] <= INT32_MAX) {
+			if(tot[k] < smallest) { order = k; smallest = tot[k]; }
+			rbps[k] = RBPS_OF(tot[k], n);
+		}
+		else rbps[k] = 34.0f;
+	}
+	return order;
+}
+/* subframe_bps 33: FLAC__fixed_compute_best_predictor_limit_residual_33bit (fixed.c:424, plain C only).  Its
+ * CHECK_ORDER_IS_VALID (fixed.c:360) gives 34 bits per sample to every order that is not a new minimum as well. */
+static uint32_t fixed_best_predictor_limit_33bit(const int64_t *data, uint32_t n, float rbps[5])
+{
+	uint64_t tot[5] = {0, 0, 0, 0, 0}, smallest = UINT64_MAX;
+	int valid[5] = {1, 1, 1, 1, 1};
+	uint32_t order = 0;
+	for(int32_t i = -4; i < (int32_t)n; i++) {
+		uint64_t e[5];
+		e[0] = abs64(data[i]);
+		e[1] = i > -4 ? abs64(data[i] - data[i - 1]) : 0;
+		e[2] = i > -3 ? abs64(data[i] - 2 * data[i - 1] + data[i - 2]) : 0;
+		e[3] = i > -2 ? abs64(data[i] - 3 * data[i - 1] + 3 * data[i - 2] - data[i - 3]) : 0;
+		e[4] = i > -1 ? abs64(data[i] - 4 * data[i - 1] + 6 * data[i - 2] - 4 * data[i - 3] + data[i - 4]) : 0;
+		for(int k = 0; k < 5; k++) { tot[k] += e[k]; if(e[k] > INT32_MAX) valid[k] = 0; }
+	}
+	for(uint32_t k = 0; k < 5; k++) {
+		if(valid[k] && tot[k] < smallest) { order = k; smallest = tot[k]; rbps[k] = RBPS_OF(tot[k], n); }
+		else rbps[k] = 34.0f;
+	}
+	return order;
+}
+
+/* fixed.c:470-499 (32-bit wrapping, subframe_bps + order <= 32), fixed.c:501 / :532 (64-bit differences truncated to 32
+ * bits: stream_encoder.c:4511-4516).  x -> sample `order` */
+static void fixed_residual(const int64_t *x, uint32_t n, uint32_t order, int wide, int32_t *r)
+{
+	if(wide) {
+		for(int32_t i = 0; i < (int32_t)n; i++) {
+			switch(order) {
+				case 0: r[i] = (int32_t)x[i]; break;
+				case 1: r[i] = (int32_t)(x[i] - x[i - 1]); break;
+				case 2: r[i] = (int32_t)(x[i] - 2 * x[i - 1] + x[i - 2]); break;
+				case 3: r[i] = (int32_t)(x[i] - 3 * x[i - 1] + 3 * x[i - 2] - x[i - 3]); break;
+				default: r[i] = (int32_t)(x[i] - 4 * x[i - 1] + 6 * x[i - 2] - 4 * x[i - 3] + x[i - 4]); break;
+			}
+		}
+		return;
+	}
 	for(int32_t i = 0; i < (int32_t)n; i++) {
 		uint32_t a = (uint32_t)x[i];
 		switch(order) {
@@ -425,11 +524,20 @@ static void fixed_residual(const int32_t *x, uint32_t n, uint32_t order, int32_t
 	}
 }
 
-/* lpc.c:321 (32-bit wrapping accumulate) and lpc.c:582 (64-bit accumulate) */
-static void lpc_residual(const int32_t *x, uint32_t n, const int32_t *q, uint32_t order, int shift, int wide, int32_t *r)
+/* lpc.c:321 (32-bit wrapping accumulate), lpc.c:582 (64-bit accumulate), and -- wide == 2 -- lpc.c:832 / :886, the
+ * overflow-checked flavours taken when the residual may not fit 32 bits (stream_encoder.c:4601-4609): they return 0,
+ * and the candidate is dropped, as soon as one residual leaves (INT32_MIN, INT32_MAX] */
+static int lpc_residual(const int64_t *x, uint32_t n, const int32_t *q, uint32_t order, int shift, int wide, int32_t *r)
 {
 	for(int32_t i = 0; i < (int32_t)n; i++) {
-		if(wide) {
+		if(wide == 2) {
+			int64_t s = 0, v;
+			for(uint32_t j = 0; j < order; j++) s += (int64_t)q[j] * x[i - 1 - (int32_t)j];
+			v = x[i] - (s >> shift);
+			if(v <= INT32_MIN || v > INT32_MAX) return 0;
+			r[i] = (int32_t)v;
+		}
+		else if(wide) {
 			int64_t s = 0;
 			for(uint32_t j = 0; j < order; j++) s += (int64_t)q[j] * (int64_t)x[i - 1 - (int32_t)j];
 			r[i] = (int32_t)((int64_t)x[i] - (s >> shift));
@@ -440,6 +548,12 @@ static void lpc_residual(const int32_t *x, uint32_t n, const int32_t *q, uint32_
 			r[i] = (int32_t)((uint32_t)x[i] - (uint32_t)((int32_t)s >> shift));
 		}
 	}
+	return 1;
+}
+static int lpc_residual_mode(uint32_t bps, const int32_t *q, uint32_t order, int shift)   /* stream_encoder.c:4601-4617 */
+{
+	if(max_residual_bps(bps, q, order, shift) > 32) return 2;
+	return max_prediction_before_shift_bps(bps, q, order) > 32 ? 1 : 0;
 }
 
 /* ------------------------------------------------------------------------------------
@@ -543,7 +657,7 @@ static void next_subdivide(int32_t parts, uint32_t *a, uint32_t *depth, uint32_t
 	if(*depth > (uint32_t)parts) { (*a)++; *depth = 1; *part = 0; }
 }
 
-static int apply_apodization(const fo_config *cfg, apod_state *st, const int32_t *sig, float *windowed,
+static int apply_apodization(const fo_config *cfg, apod_state *st, const int64_t *sig, float *windowed,
                              uint32_t *max_order, uint32_t subframe_bps, float lp[][FO_MAX_LPC_ORDER],
                              double *lpc_error, uint32_t *guess)
 {
@@ -551,7 +665,7 @@ static int apply_apodization(const fo_config *cfg, apod_state *st, const int32_t
 	const fo_apodization *ap = &cfg->apodizations[st->a];
 	const uint32_t variant = N <= FO_MAX_LPC_ORDER ? FO_AUTOC_GENERIC : cfg->autoc_variant;
 	if(st->b == 1) {
-		fo_window_data(sig, ap->window, windowed, N);
+		window_data64(sig, ap->window, windowed, N);
 		fo_autocorrelation(variant, windowed, N, *max_order + 1, st->autoc);
 		if(ap->kind == FO_APOD_SUBDIVIDE_TUKEY) {
 			memcpy(st->root, st->autoc, *max_order * sizeof(double)); /* note: max_order, not +1 (:4340) */
@@ -565,7 +679,7 @@ static int apply_apodization(const fo_config *cfg, apod_state *st, const int32_t
 			return 0;
 		}
 		if(!(st->c % 2)) {
-			fo_window_data_partial(sig, ap->window, windowed, N, N / st->b / 2, (st->c / 2 * N) / st->b);
+			window_data_partial64(sig, ap->window, windowed, N, N / st->b / 2, (st->c / 2 * N) / st->b);
 			fo_autocorrelation(variant, windowed, N / st->b, *max_order + 1, st->autoc);
 		}
 		else {
@@ -579,7 +693,7 @@ static int apply_apodization(const fo_config *cfg, apod_state *st, const int32_t
 	return 1;
 }
 
-static void process_subframe(const fo_config *cfg, const int32_t *sig /* already >> wasted */, uint32_t subframe_bps,
+static void process_subframe(const fo_config *cfg, const int64_t *sig /* already >> wasted */, uint32_t subframe_bps,
                              uint32_t wasted, int disable_constant, uint32_t min_po, uint32_t max_po,
                              subframe_t *best, subframe_t *cand, int32_t *residual, float *windowed)
 {
@@ -594,9 +708,16 @@ static void process_subframe(const fo_config *cfg, const int32_t *sig /* already
 
 	if(N > 4) {
 		float rbps[5];
-		/* selector: stream_encoder.c:4098-4103 (bps >= 28 flavours are outside this restatement) */
-		const int wide = !(subframe_bps + ilog2_u32((N - 4) * 17) < 32);
-		const uint32_t guess_fixed = fo_fixed_best_predictor_ex(sig + 4, N - 4, rbps, wide);
+		uint32_t guess_fixed;
+		/* selector: stream_encoder.c:4098-4108 */
+		if(subframe_bps <= 32) {
+			int32_t *s32 = (int32_t *)malloc(sizeof(int32_t) * N);
+			for(uint32_t i = 0; i < N; i++) s32[i] = (int32_t)sig[i];
+			if(subframe_bps < 28) guess_fixed = fo_fixed_best_predictor_ex(s32 + 4, N - 4, rbps, !(subframe_bps + ilog2_u32((N - 4) * 17) < 32));
+			else guess_fixed = fixed_best_predictor_limit_avx2(s32 + 4, N - 4, rbps);
+			free(s32);
+		}
+		else guess_fixed = fixed_best_predictor_limit_33bit(sig + 4, N - 4, rbps);
 		int constant = 0;
 		if(!disable_constant && rbps[1] == 0.0f) {
 			constant = 1;
@@ -614,7 +735,7 @@ static void process_subframe(const fo_config *cfg, const int32_t *sig /* already
 				for(uint32_t order = min_fixed; order <= max_fixed; order++) {
 					uint32_t po, rbits, est;
 					if(rbps[order] >= (float)subframe_bps) continue;
-					fixed_residual(sig + order, N - order, order, residual);
+					fixed_residual(sig + order, N - order, order, subframe_bps + order > 32, residual);
 					rbits = fo_rice_search(residual, N - order, order, rice_limit, min_po, max_po, subframe_bps, &po, cand->params);
 					est = hdr + order * subframe_bps;
 					est = rbits < 0xffffffffu - est ? est + rbits : 0xffffffffu;
@@ -658,10 +779,8 @@ static void process_subframe(const fo_config *cfg, const int32_t *sig /* already
 								memset(q, 0, sizeof q);
 								if(fo_quantize_coefficients(lp[order - 1], order, precision, q, &shift) != 0)
 									continue;
-								if(max_residual_bps(subframe_bps, q, order, shift) > 32)
-									continue; /* limit_residual flavours: outside this restatement's bps range */
-								lpc_residual(sig + order, N - order, q, order, shift,
-								             max_prediction_before_shift_bps(subframe_bps, q, order) > 32, residual);
+								if(!lpc_residual(sig + order, N - order, q, order, shift, lpc_residual_mode(subframe_bps, q, order, shift), residual))
+									continue; /* a residual does not fit 32 bits (:4603-4608) */
 								rbits = fo_rice_search(residual, N - order, order, rice_limit, min_po, max_po, subframe_bps, &po, cand->params);
 								est = hdr + 4 + 5 + order * (precision + subframe_bps);
 								est = rbits < 0xffffffffu - est ? est + rbits : 0xffffffffu;
@@ -730,7 +849,7 @@ static void write_frame_header(bitw *w, const fo_config *cfg, uint32_t channel_a
 	if(!w->overflow) bw_bits(w, fo_crc8(w->buf + start, (size_t)(w->nbits >> 3) - start), 8);
 }
 
-static void write_subframe(bitw *w, const fo_config *cfg, const subframe_t *sf, const int32_t *sig, uint32_t bps, int32_t *residual)
+static void write_subframe(bitw *w, const fo_config *cfg, const subframe_t *sf, const int64_t *sig, uint32_t bps, int32_t *residual)
 {
 	const uint32_t N = cfg->blocksize, wasted = sf->s.wasted_bits, order = sf->s.order;
 	uint32_t type_bits;
@@ -749,10 +868,9 @@ static void write_subframe(bitw *w, const fo_config *cfg, const subframe_t *sf, 
 		bw_bits(w, sf->s.precision - 1, 4);
 		bw_signed(w, sf->s.shift, 5);
 		for(uint32_t i = 0; i < order; i++) bw_signed(w, sf->s.qlp[i], sf->s.precision);
-		lpc_residual(sig + order, N - order, sf->s.qlp, order, sf->s.shift,
-		             max_prediction_before_shift_bps(bps, sf->s.qlp, order) > 32, residual);
+		(void)lpc_residual(sig + order, N - order, sf->s.qlp, order, sf->s.shift, lpc_residual_mode(bps, sf->s.qlp, order, sf->s.shift), residual);
 	}
-	else fixed_residual(sig + order, N - order, order, residual);
+	else fixed_residual(sig + order, N - order, order, bps + order > 32, residual);
 	{
 		const uint32_t po = sf->s.partition_order, plen = sf->s.rice2 ? 5 : 4;
 		uint32_t k = 0;
@@ -767,18 +885,20 @@ static void write_subframe(bitw *w, const fo_config *cfg, const subframe_t *sf, 
 	}
 }
 
-static uint32_t wasted_bits_of(const int32_t *sig, uint32_t n) /* stream_encoder.c:5077 */
+/* stream_encoder.c:5077 get_wasted_bits_, :5103 get_wasted_bits_wide_ (the side channel of a 32-bit stream; an all-zero
+ * one loses 1 bit there) */
+static uint32_t wasted_bits_of(const int64_t *sig, uint32_t n, int wide)
 {
-	uint32_t x = 0;
-	for(uint32_t i = 0; i < n; i++) x |= (uint32_t)sig[i];
-	return x ? (uint32_t)__builtin_ctz(x) : 0;
+	uint64_t x = 0;
+	for(uint32_t i = 0; i < n; i++) x |= (uint64_t)sig[i];
+	return x ? (uint32_t)__builtin_ctzll(x) : (wide ? 1 : 0);
 }
 
 int64_t fo_encode_frame(const fo_config *cfg, const int32_t *const pcm[], uint64_t frame_number,
                         uint8_t *out, size_t cap, fo_frame_info *info)
 {
 	const uint32_t N = cfg->blocksize, C = cfg->channels, bps = cfg->bits_per_sample;
-	if(C < 1 || C > FO_MAX_CHANNELS || bps < 4 || bps > 24 || N < 1 || N > 65535) return -1;
+	if(C < 1 || C > FO_MAX_CHANNELS || bps < 4 || bps > 32 || N < 1 || N > 65535) return -1;
 	if(cfg->max_lpc_order > FO_MAX_LPC_ORDER) return -1;
 	const int ms = cfg->do_mid_side && C == 2;
 	int do_indep = 1, do_ms = 0, loose_pick_ms = 0;
@@ -788,15 +908,15 @@ int64_t fo_encode_frame(const fo_config *cfg, const int32_t *const pcm[], uint64
 	/* signals: [0..C) independent, [C], [C+1] mid and side; 4 leading zeros like the
 	 * reference's buffers (stream_encoder.c:2846-2850) -- never read by valid orders */
 	const uint32_t nsig = C + (ms ? 2 : 0);
-	int32_t *store = (int32_t *)calloc((size_t)nsig * (N + 4), sizeof(int32_t));
-	int32_t *sig[FO_MAX_CHANNELS + 2];
+	int64_t *store = (int64_t *)calloc((size_t)nsig * (N + 4), sizeof(int64_t));
+	int64_t *sig[FO_MAX_CHANNELS + 2];
 	uint32_t sbps[FO_MAX_CHANNELS + 2], wasted[FO_MAX_CHANNELS + 2];
 	subframe_t best[FO_MAX_CHANNELS + 2], cand;
 	int32_t *residual = (int32_t *)malloc(sizeof(int32_t) * (N + 1));
 	float *windowed = (float *)malloc(sizeof(float) * (N + 1));
 	int64_t ret;
 	for(uint32_t c = 0; c < nsig; c++) sig[c] = store + (size_t)c * (N + 4) + 4;
-	for(uint32_t c = 0; c < C; c++) memcpy(sig[c], pcm[c], sizeof(int32_t) * N);
+	for(uint32_t c = 0; c < C; c++) for(uint32_t i = 0; i < N; i++) sig[c][i] = pcm[c][i];
 	memset(best, 0, sizeof best); memset(&cand, 0, sizeof cand);
 	cand.params = (uint32_t *)malloc(sizeof(uint32_t) << max_po);
 	for(uint32_t c = 0; c < nsig; c++) best[c].params = (uint32_t *)malloc(sizeof(uint32_t) << max_po);
@@ -804,10 +924,10 @@ int64_t fo_encode_frame(const fo_config *cfg, const int32_t *const pcm[], uint64
 	if(ms) {
 		if(cfg->loose_mid_side) { /* :3778-3807 */
 			uint64_t lr = 0, msum = 0;
-			for(uint32_t i = 1; i < N; i++) {
-				int32_t pl = sig[0][i] - sig[0][i - 1], pr = sig[1][i] - sig[1][i - 1];
-				lr += (uint64_t)(abs(pl) + abs(pr));
-				msum += (uint64_t)(abs((pl + pr) >> 1) + abs(pl - pr));
+			for(uint32_t i = 1; i < N; i++) {      /* 64-bit from 25 bits per sample up; the same sums below that */
+				int64_t pl = sig[0][i] - sig[0][i - 1], pr = sig[1][i] - sig[1][i - 1];
+				lr += abs64(pl) + abs64(pr);
+				msum += abs64((pl + pr) >> 1) + abs64(pl - pr);
 			}
 			if(lr < msum) { do_indep = 1; do_ms = 0; }
 			else { do_indep = 0; do_ms = 1; loose_pick_ms = 1; }
@@ -821,13 +941,13 @@ int64_t fo_encode_frame(const fo_config *cfg, const int32_t *const pcm[], uint64
 		}
 	}
 	if(do_indep) for(uint32_t c = 0; c < C; c++) {
-		uint32_t w = wasted_bits_of(sig[c], N);
+		uint32_t w = wasted_bits_of(sig[c], N, 0);
 		if(w > bps) w = bps;
 		if(w) for(uint32_t i = 0; i < N; i++) sig[c][i] >>= w;
 		wasted[c] = w; sbps[c] = bps - w;
 	}
 	if(do_ms) for(uint32_t c = 0; c < 2; c++) {
-		uint32_t w = wasted_bits_of(sig[C + c], N);
+		uint32_t w = wasted_bits_of(sig[C + c], N, bps == 32 && c == 1);
 		if(w > bps) w = bps;
 		if(w) for(uint32_t i = 0; i < N; i++) sig[C + c][i] >>= w;
 		wasted[C + c] = w; sbps[C + c] = bps - w + c;

@@ -85,6 +85,18 @@ def mixed(n, channels=2, bps=16, seed=99):
     return x[:n]
 
 
+FSD_PATTERNS = {1: (1, -1), 2: (1, 1, -1), 3: (1, -1, -1), 4: (1, -1, 1, -1), 5: (1, -1, -1, 1), 6: (1, -1, 1, 1, -1), 7: (1, -1, -1, 1, -1)}
+
+
+def fsd(n, channels=1, bps=16, pattern=1):
+    """full-scale deflection streams of the reference's test suite (src/test_streams/main.c:306-433,1341-1347);
+    the second channel of a stereo pair runs the pattern inverted, which drives the side channel to bps+1 bits"""
+    hi, lo = (1 << (bps - 1)) - 1, -(1 << (bps - 1))
+    pat = np.array([hi if v > 0 else lo for v in FSD_PATTERNS[pattern]], dtype=np.int64)
+    x = np.resize(pat, n)
+    return np.stack([x if c % 2 == 0 else -1 - x for c in range(channels)], axis=1).astype(np.int32)
+
+
 FAMILIES = {
     "white": white, "music": music, "sine": sine, "constant": constant, "silence": silence,
     "wasted": wasted, "square": fullscale_square, "quiet": quiet, "mixed": mixed,

@@ -363,3 +363,12 @@ def test_constant_and_silent_channels_off_the_fast_paths(kw):
         okw = {k: v for k, v in kw.items() if k != "streamable_subset"}
         o = po.oracle_encode(pcm, 16, 44100, 8, **okw)
         assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (fam, kw)
+
+
+@pytest.mark.parametrize("rate", [9, 90, 8000, 22050, 90000, 96000, 192000, 352800, 655350, 1048575])
+def test_sample_rate_codes(rate):
+    """test/test_streams.sh:241-250 frame-header variations: the sample-rate field (framing.c:289-329)"""
+    pcm = signals.music(4096 + 300, 1, 16, seed=rate % 97)
+    data, fb = _gpu_encode(pcm, 16, rate, 5, streamable_subset=0, max_batch=8)
+    o = po.oracle_encode(pcm, 16, rate, 5)
+    assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], rate

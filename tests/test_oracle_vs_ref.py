@@ -267,3 +267,49 @@ def test_constant_and_silent_channels(ref, kw):
         r = po.ref_encode(pcm, 16, 44100, 8, streamable_subset=0, **kw)
         o = po.oracle_encode(pcm, 16, 44100, 8, **kw)
         assert o["data"] == _frames(r), (fam, kw)
+
+
+@pytest.mark.parametrize("rate", [9, 90, 8000, 22050, 90000, 96000, 192000, 352800, 655350, 1048575])
+def test_sample_rate_codes(ref, rate):
+    """test/test_streams.sh:241-250 frame-header variations: the sample-rate field (framing.c:289-329)"""
+    pcm = signals.music(4096 + 300, 1, 16, seed=rate % 97)
+    r = po.ref_encode(pcm, 16, rate, 5, streamable_subset=0)
+    o = po.oracle_encode(pcm, 16, rate, 5)
+    assert o["data"] == _frames(r), rate
+
+
+@pytest.mark.parametrize("bps", [25, 27, 28, 31, 32])
+def test_wide_samples(ref, bps):
+    """more than 24 bits per sample: the overflow-checked estimators and residuals (fixed_intrin_avx2.c:187, fixed.c:424,
+    lpc.c:832,886), 64-bit fixed residuals, and at 32 bits the 33-bit side channel (stream_encoder.c:3831-3835,5103)"""
+    for fam in ("music", "white", "sine", "square", "mixed", "wasted", "quiet", "constant", "silence"):
+        for level in (0, 1, 2, 5, 8):
+            for ch in (1, 2):
+                pcm = signals.FAMILIES[fam](4096 + 1333, ch, bps)
+                r = po.ref_encode(pcm, bps, 96000, level, streamable_subset=0)
+                o = po.oracle_encode(pcm, bps, 96000, level)
+                assert o["data"] == _frames(r), (bps, fam, level, ch)
+
+
+@pytest.mark.parametrize("bps", [8, 16, 24, 32])
+@pytest.mark.parametrize("pattern", range(1, 8))
+def test_full_scale_deflection(ref, bps, pattern):
+    """test/test_streams.sh:188-193: fsd<bps>-0<pattern>, -0 -l 16 --lax -m -e -p; mono like the suite, and as an inverted pair"""
+    for ch in (1, 2):
+        pcm = signals.fsd(1152 * 2 + 100, ch, bps, pattern)
+        kw = dict(max_lpc_order=16, exhaustive=1, prec_search=1, mid_side=1)
+        r = po.ref_encode(pcm, bps, 44100, 0, streamable_subset=0, loose_mid_side=0, **kw)
+        o = po.oracle_encode(pcm, bps, 44100, 0, loose=0, **kw)
+        assert o["data"] == _frames(r), (bps, pattern, ch)
+
+
+@pytest.mark.parametrize("tail", [1, 5, 6, 7, 9, 33, 1001, 4095])
+def test_wide_samples_short_last_block(ref, tail):
+    """(n-4) % 4 != 0 in the four-lane estimators of the overflow-checked flavour"""
+    for bps in (28, 32):
+        for fam in ("music", "white"):
+            pcm = signals.FAMILIES[fam](4096 + tail, 2, bps)
+            for level, kw in ((5, {}), (8, dict(exhaustive=1))):
+                r = po.ref_encode(pcm, bps, 96000, level, streamable_subset=0, **kw)
+                o = po.oracle_encode(pcm, bps, 96000, level, **kw)
+                assert o["data"] == _frames(r), (bps, fam, tail, level)
