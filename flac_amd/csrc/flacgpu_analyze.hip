@@ -75,11 +75,22 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 		// loose mid/side (stream_encoder.c:3778-3807): both workgroups of the frame compute the decision
 		uint64_t lr = 0, ms = 0;
 		const int2 *p = (const int2 *)frame_pcm;
-		for(uint32_t i = 1 + (uint32_t)tid; i < n; i += TPB) {
-			const int2 a = p[i], b = p[i - 1];
-			const int32_t pl = a.x - b.x, pr = a.y - b.y;
-			lr += (uint64_t)(uint32_t)(abs(pl) + abs(pr));
-			ms += (uint64_t)(uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
+		if(!P.wide_samples) {
+			for(uint32_t i = 1 + (uint32_t)tid; i < n; i += TPB) {
+				const int2 a = p[i], b = p[i - 1];
+				const int32_t pl = a.x - b.x, pr = a.y - b.y;
+				lr += (uint64_t)(uint32_t)(abs(pl) + abs(pr));
+				ms += (uint64_t)(uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
+			}
+		}
+		else {
+			// 25 bits per sample and more: 64-bit differences (stream_encoder.c:3789-3796)
+			for(uint32_t i = 1 + (uint32_t)tid; i < n; i += TPB) {
+				const int2 a = p[i], b = p[i - 1];
+				const int64_t pl = (int64_t)a.x - (int64_t)b.x, pr = (int64_t)a.y - (int64_t)b.y;
+				lr += abs_i64(pl) + abs_i64(pr);
+				ms += abs_i64((pl + pr) >> 1) + abs_i64(pl - pr);
+			}
 		}
 		lr = block_reduce_add_u64(lr, scratch, tid);
 		ms = block_reduce_add_u64(ms, scratch, tid);
@@ -94,31 +105,100 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 		diff = block_reduce_or_u32(diff, scratch, tid);
 		if(diff == 0) disable_constant = true;
 	}
-	uint32_t orv;
-	load_signal(sig, frame_pcm, C, n, which, &orv, tid);
-	orv = block_reduce_or_u32(orv, scratch, tid);
-	uint32_t wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
-	if(wasted > P.bps) wasted = P.bps;
-	if(wasted) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) sig[sigidx((int)i)] >>= wasted;
+	uint32_t wasted;
+	bool s64 = false;                                   // this channel keeps 64-bit samples (33 bits after the shift)
+	int64_t *sig64 = (int64_t *)smem;
+	if(P.bps == 32 && C == 2 && which == 3) {
+		// side channel of a 32-bit stream: 33 bits; get_wasted_bits_wide_ (stream_encoder.c:5103), all-zero loses 1 bit
+		const int2 *p = (const int2 *)frame_pcm;
+		uint32_t olo = 0, ohi = 0;
+		for(uint32_t i = (uint32_t)tid; i < n; i += TPB) { const uint64_t v = (uint64_t)side64(p[i]); olo |= (uint32_t)v; ohi |= (uint32_t)(v >> 32); }
+		olo = block_reduce_or_u32(olo, scratch, tid);
+		ohi = block_reduce_or_u32(ohi, scratch, tid);
+		wasted = olo ? (uint32_t)(__ffs((int)olo) - 1) : ohi ? 32u : 1u;
+		if(wasted > P.bps) wasted = P.bps;
+		s64 = wasted == 0;
+		const uint32_t nround = ((n + 15u) & ~15u) + 16u;
+		if(s64) {
+			if(tid < 32) sig64[sigidx(tid - 32)] = 0;
+			for(uint32_t i = n + (uint32_t)tid; i < nround; i += TPB) sig64[sigidx((int)i)] = 0;
+			for(uint32_t i = (uint32_t)tid; i < n; i += TPB) sig64[sigidx((int)i)] = side64(p[i]);
+		}
+		else {
+			if(tid < 32) sig[sigidx(tid - 32)] = 0;
+			for(uint32_t i = n + (uint32_t)tid; i < nround; i += TPB) sig[sigidx((int)i)] = 0;
+			for(uint32_t i = (uint32_t)tid; i < n; i += TPB) sig[sigidx((int)i)] = (int32_t)(side64(p[i]) >> wasted);
+		}
+	}
+	else {
+		uint32_t orv;
+		load_signal(sig, frame_pcm, C, n, which, &orv, tid);
+		orv = block_reduce_or_u32(orv, scratch, tid);
+		wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
+		if(wasted > P.bps) wasted = P.bps;
+		if(wasted) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) sig[sigidx((int)i)] >>= wasted;
+	}
 	const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
 	__syncthreads();
+	// sample i of the shifted channel, whatever its width
+	auto SV = [&](int i) -> int64_t { return s64 ? sig64[sigidx(i)] : (int64_t)sig[sigidx(i)]; };
 	// planar copy of the shifted channel for the evaluation and pack kernels
-	const uint32_t fmt = sbps <= 16 ? 1u : 0u;
+	const uint32_t fmt = s64 ? 2u : sbps <= 16 ? 1u : 0u;
 	{
-		int32_t *dst = chan + fc * (size_t)N;
-		if(fmt) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) ((uint16_t *)dst)[i] = (uint16_t)sig[sigidx((int)i)];
+		int32_t *dst = chan + fc * (size_t)P.chan_stride;
+		if(fmt == 2) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) ((int64_t *)dst)[i] = sig64[sigidx((int)i)];
+		else if(fmt) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) ((uint16_t *)dst)[i] = (uint16_t)sig[sigidx((int)i)];
 		else for(uint32_t i = (uint32_t)tid; i < n; i += TPB) dst[i] = sig[sigidx((int)i)];
 	}
 
 	uint32_t flags = 0, fixed_order = 0;
-	int32_t constant = 0;
+	int64_t constant = 0;
 	const uint32_t verbatim_bits = (P.disable_verbatim && n >= 4) ? 0xffffffffu : 8 + wasted + n * sbps;
 	if(n > 4) {
-		// fixed predictor estimate (fixed.c:222 / fixed_intrin_avx2.c:57)
+		// fixed predictor estimate (fixed.c:222 / fixed_intrin_avx2.c:57; from 28 bits the overflow-checked flavours
+		// fixed_intrin_avx2.c:187 and, for 33-bit samples, fixed.c:424)
 		const uint32_t n4 = n - 4;
 		const bool fwide = !(sbps + ilog2_u32(n4 * 17) < 32);
+		const bool flimit = sbps >= 28;
 		uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
-		if(!fwide || (n4 & 3) == 0) {
+		uint32_t over = 0;            // flimit: bit k = a residual of order k does not fit 31 bits + sign
+		if(flimit) {
+			const bool lanes4 = !s64 && (n4 & 3) != 0;       // the four-lane AVX2 routine on a length that is no multiple of 4
+			const uint32_t q4 = n4 / 4;
+			auto acc = [&](int64_t d0, int64_t d1, int64_t d2, int64_t d3, int64_t d4, uint32_t upto) {
+				const uint64_t a0 = abs_i64(d0), a1 = abs_i64(d1), a2 = abs_i64(d2), a3 = abs_i64(d3), a4 = abs_i64(d4);
+				e0 += a0; if(a0 > 0x7fffffffull) over |= 1u;
+				if(upto >= 1) { e1 += a1; if(a1 > 0x7fffffffull) over |= 2u; }
+				if(upto >= 2) { e2 += a2; if(a2 > 0x7fffffffull) over |= 4u; }
+				if(upto >= 3) { e3 += a3; if(a3 > 0x7fffffffull) over |= 8u; }
+				if(upto >= 4) { e4 += a4; if(a4 > 0x7fffffffull) over |= 16u; }
+			};
+			auto full = [&](int i, uint32_t upto) {
+				const int64_t v0 = SV(i), v1 = SV(i - 1), v2 = SV(i - 2), v3 = SV(i - 3), v4 = SV(i - 4);
+				acc(v0, v0 - v1, v0 - 2 * v1 + v2, v0 - 3 * v1 + 3 * v2 - v3, v0 - 4 * v1 + 6 * v2 - 4 * v3 + v4, upto);
+			};
+			if(!lanes4) {
+				// the sums run over the whole block, each order from the first sample it can be formed at
+				for(uint32_t i = (uint32_t)tid; i < n; i += TPB) full((int)i, i < 4 ? i : 4u);
+			}
+			else {
+				// fixed_intrin_avx2.c:219-340 restated literally: the four samples in front (orders 0..3 as far as they can
+				// be formed), four lanes of q4 samples (history at l*q4, data at (l*n4)/4), then the n4 % 4 samples left
+				if(tid < 4) full(tid, (uint32_t)tid);
+				for(uint32_t l = 0; l < 4; l++) {
+					const int hist = (int)(l * q4), start = (int)(((uint64_t)l * n4) / 4);
+					for(uint32_t i = (uint32_t)tid; i < q4; i += TPB) {
+						int64_t v[5];
+#pragma unroll
+						for(int j = 0; j < 5; j++) { const int m = (int)i - j; v[j] = SV(4 + (m >= 0 ? start + m : hist + m)); }
+						acc(v[0], v[0] - v[1], v[0] - 2 * v[1] + v[2], v[0] - 3 * v[1] + 3 * v[2] - v[3], v[0] - 4 * v[1] + 6 * v[2] - 4 * v[3] + v[4], 4u);
+					}
+				}
+				for(uint32_t i = 4 * q4 + (uint32_t)tid; i < n4; i += TPB) full((int)(4 + i), 4u);
+			}
+			over = block_reduce_or_u32(over, scratch, tid);
+		}
+		else if(!fwide || (n4 & 3) == 0) {
 			for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * TPB) {
 				int32_t x[CHUNK + 4];
 #pragma unroll
@@ -158,8 +238,8 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 		__syncthreads();
 		e0 = e1 = e2 = e3 = e4 = 0;
 		for(int w = 0; w < TPB / 64; w++) { e0 += red[w * 5 + 0]; e1 += red[w * 5 + 1]; e2 += red[w * 5 + 2]; e3 += red[w * 5 + 3]; e4 += red[w * 5 + 4]; }
-		uint32_t guess_fixed;
-		{
+		uint32_t guess_fixed, invalid = 0;
+		if(!flimit) {
 			const uint64_t m34 = e3 < e4 ? e3 : e4, m234 = e2 < m34 ? e2 : m34, m1234 = e1 < m234 ? e1 : m234;
 			if(e0 <= m1234) guess_fixed = 0;
 			else if(e1 <= m234) guess_fixed = 1;
@@ -167,21 +247,34 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 			else if(e3 <= e4) guess_fixed = 3;
 			else guess_fixed = 4;
 		}
-		const bool rbps1_zero = e1 == 0 || fixed_rbps(e1, n4) == 0.0f;
+		else {
+			// CHECK_ORDER_IS_VALID: first minimum among the orders whose residuals all fit; the others count 34 bits per
+			// sample (fixed_intrin_avx2.c:172).  The plain C flavour behind 33-bit samples (fixed.c:360) gives 34 bits to
+			// every order that is not a new minimum, too.
+			const uint64_t ev[5] = {e0, e1, e2, e3, e4};
+			uint64_t smallest = ~0ull;
+			guess_fixed = 0; invalid = over;
+			for(uint32_t k = 0; k < 5; k++) {
+				if((over >> k) & 1u) continue;
+				if(ev[k] < smallest) { guess_fixed = k; smallest = ev[k]; }
+				else if(s64) invalid |= 1u << k;
+			}
+		}
+		const bool rbps1_zero = !(invalid & 2u) && (e1 == 0 || fixed_rbps(e1, n4) == 0.0f);
 		bool is_constant = false;
 		if(!disable_constant && rbps1_zero) {
 			uint32_t diff = 0;
-			const int32_t first = sig[sigidx(0)];
-			for(uint32_t i = (uint32_t)tid; i < n; i += TPB) diff |= (uint32_t)(sig[sigidx((int)i)] ^ first);
+			const int64_t first = SV(0);
+			for(uint32_t i = (uint32_t)tid; i < n; i += TPB) { const uint64_t x = (uint64_t)(SV((int)i) ^ first); diff |= (uint32_t)x | (uint32_t)(x >> 32); }
 			diff = block_reduce_or_u32(diff, scratch, tid);
 			is_constant = diff == 0;
 		}
-		if(is_constant) { flags |= PREP_CONSTANT; constant = sig[sigidx(0)]; }
+		if(is_constant) { flags |= PREP_CONSTANT; constant = SV(0); }
 		else if(P.max_lpc_order > 0) flags |= PREP_LPC;          // n > 4, so at least order 4 is possible
 		const bool fixed_allowed = !is_constant && (!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu));
 		fixed_order = fixed_allowed ? guess_fixed : 0;
 		const uint64_t es[5] = {e0, e1, e2, e3, e4};
-		if(tid < 64 && emit_fixed_candidates(P, &cands[fc * cstride], &valid[fc * cstride], es, n4, guess_fixed, fixed_allowed, sbps, tid)) flags |= PREP_FIXED_VALID;
+		if(tid < 64 && emit_fixed_candidates(P, &cands[fc * cstride], &valid[fc * cstride], es, n4, guess_fixed, fixed_allowed, sbps, tid, invalid)) flags |= PREP_FIXED_VALID;
 	}
 	else if(tid < 64) {
 		// n <= 4: no fixed or LPC candidate at all
@@ -191,7 +284,7 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 	if(tid == 0) {
 		ChanPrep pr;
 		pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
-		pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;
+		pr.constant = (int32_t)constant; pr.constant_hi = (int32_t)(constant >> 32); pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = 0;
 		preps[fc] = pr;
 	}
 }
@@ -221,8 +314,10 @@ struct AutocWave {
 struct JobView {
 	const int32_t *frame_pcm; const float *w; uint32_t C, which, wasted, n, nd;
 	uint32_t full, part, dshift, i0;
+	uint32_t side33;        // the side channel of a 32-bit stream: 33-bit values (lpc.c:75,96)
 };
-__device__ __forceinline__ void job_fetch(const JobView &J, uint32_t i, int32_t &v, float &wt)
+// v: the unshifted sample (64 bits wide only for side33)
+__device__ __forceinline__ void job_fetch(const JobView &J, uint32_t i, int64_t &v, float &wt)
 {
 	v = 0; wt = 0.0f;
 	if(i < J.nd) {
@@ -239,13 +334,19 @@ __device__ __forceinline__ void job_fetch(const JobView &J, uint32_t i, int32_t 
 			wt = J.w[widx];
 			if(J.C == 2) {
 				const int2 lr = ((const int2 *)J.frame_pcm)[src];
-				v = J.which == 0 ? lr.x : J.which == 1 ? lr.y : J.which == 2 ? ((lr.x + lr.y) >> 1) : (lr.x - lr.y);
+				v = J.which == 0 ? (int64_t)lr.x : J.which == 1 ? (int64_t)lr.y : J.which == 2 ? (((int64_t)lr.x + (int64_t)lr.y) >> 1) : J.side33 ? side64(lr) : (int64_t)(lr.x - lr.y);
 			}
 			else v = pick_channel(J.frame_pcm, J.C, src, J.which);
 		}
 	}
 }
-__device__ __forceinline__ float job_value(const JobView &J, int32_t v, float wt) { return (float)(v >> J.wasted) * wt; }
+// (float)sample * window: one integer -> float rounding, one multiply.  A 33-bit sample goes through double, which
+// holds it exactly, so that the conversion rounds once like the reference's cvtsi2ss does.
+__device__ __forceinline__ float job_value(const JobView &J, int64_t v, float wt)
+{
+	if(J.side33) return (float)(double)(v >> J.wasted) * wt;
+	return (float)(int32_t)(v >> J.wasted) * wt;
+}
 
 // one chain step of lpc_intrin_fma.c:46,61 on stream elements: x = d[i], d[i+4]; y = d[i-j], d[i+4-j]
 #define STEP816(acc, xs, ys, u) acc += fma((double)(xs)[2 * (u)], (double)(ys)[2 * (u)], (double)(xs)[2 * (u) + 1] * (double)(ys)[2 * (u) + 1])
@@ -280,13 +381,14 @@ __global__ __launch_bounds__(TPB, AUTOC_WAVES_PER_SIMD) void autoc_kernel(const 
 	J.w = (is_tail ? tail_windows : windows) + (size_t)jv.apod * n;
 	J.C = P.channels; J.which = pr.which; J.wasted = pr.wasted; J.n = n; J.nd = jv.nd;
 	J.full = jv.full; J.part = jv.part; J.dshift = jv.dshift; J.i0 = jv.i0;
+	J.side33 = (P.bps == 32 && P.channels == 2 && pr.which == 3) ? 1u : 0u;
 	const uint32_t nd = jv.nd;
 	const uint32_t tail_lo = nd > (uint32_t)ATAIL ? nd - ATAIL : 0;
 	double *out = autoc_out + ((size_t)fc * P.max_jobs + jb) * AUTOC_STRIDE;
 
 	// plain head / tail copies
-	if(lane < AHEAD) { int32_t v; float wt; job_fetch(J, (uint32_t)lane, v, wt); W.head[lane] = job_value(J, v, wt); }
-	if(lane < ATAIL) { int32_t v; float wt; job_fetch(J, tail_lo + (uint32_t)lane, v, wt); W.tail[lane] = job_value(J, v, wt); }
+	if(lane < AHEAD) { int64_t v; float wt; job_fetch(J, (uint32_t)lane, v, wt); W.head[lane] = job_value(J, v, wt); }
+	if(lane < ATAIL) { int64_t v; float wt; job_fetch(J, tail_lo + (uint32_t)lane, v, wt); W.tail[lane] = job_value(J, v, wt); }
 
 	if(variant == 0 && n <= 32) {
 		// lpc.c:133-157 (blocksize <= 32): the whole job sits in W.tail (tail_lo == 0)
@@ -306,7 +408,7 @@ __global__ __launch_bounds__(TPB, AUTOC_WAVES_PER_SIMD) void autoc_kernel(const 
 #pragma unroll
 			for(int u = 0; u < 5; u++) {
 				const uint32_t k = (uint32_t)lane + 64u * (uint32_t)u;
-				if(k < 288) { int32_t v; float wt; job_fetch(J, t0 + k, v, wt); td[k] = (double)job_value(J, v, wt); }
+				if(k < 288) { int64_t v; float wt; job_fetch(J, t0 + k, v, wt); td[k] = (double)job_value(J, v, wt); }
 			}
 			__builtin_amdgcn_wave_barrier();
 			if((uint32_t)lane < lag) {
@@ -334,14 +436,14 @@ __global__ __launch_bounds__(TPB, AUTOC_WAVES_PER_SIMD) void autoc_kernel(const 
 	// tile 0 history: d[L-16, L)
 	if(lane < 16) {
 		const int i = (int)L - 16 + lane;
-		int32_t v = 0; float wt = 0.0f;
+		int64_t v = 0; float wt = 0.0f;
 		if(i >= 0) job_fetch(J, (uint32_t)i, v, wt);
 		const float d = job_value(J, v, wt);
 		const int r = i & 3, e = (i - ((int)L - 16)) >> 2;       // L multiple of 4
 		W.tile[aoffA(r, e)] = d; W.tile[aoffB(r, e)] = d;
 	}
 	// prefetch tile 0
-	int32_t pv[4]; float pw[4];
+	int64_t pv[4]; float pw[4];
 #pragma unroll
 	for(int u = 0; u < 4; u++) job_fetch(J, L + (uint32_t)lane + 64u * (uint32_t)u, pv[u], pw[u]);
 
@@ -765,17 +867,22 @@ __device__ __forceinline__ uint64_t fir_abs_i32_dispatch(const uint32_t *reg, ui
 	return fir_abs_i32<4, FMODE, NARROW>(reg, S, order, q, shift, lane);
 }
 
-// a candidate that needs the 64-bit accumulate (lpc.c:582) on a packed 16-bit channel: rare, plain code
+// the rare candidates, plain code: the 64-bit accumulate (lpc.c:582) on a packed 16-bit channel, and -- check -- the
+// overflow-checked flavour (lpc.c:832) on either layout: bad comes back true when a residual leaves (INT32_MIN, INT32_MAX]
 template <int MAXORD>
-__device__ uint64_t fir_abs_packed_wide(const uint32_t *reg, uint32_t S, uint32_t order, const int32_t *q, int shift, int lane)
+__device__ uint64_t fir_abs_plain64(const uint32_t *reg, bool packed, uint32_t S, uint32_t order, const int32_t *q, int shift, int lane, bool check, bool &bad)
 {
-	const int16_t *x = (const int16_t *)reg + OH;          // x[s] = this lane's sample s, x[-1..-OH] its history
+	const int16_t *x16 = (const int16_t *)reg + OH;        // x[s] = this lane's sample s, x[-1..-OH] its history
+	const int32_t *x32 = (const int32_t *)reg + OH;
 	uint64_t acc = 0;
+	bad = false;
 	for(uint32_t s = (lane == 0 ? order : 0); s < S; s++) {
 		int64_t sum = 0;
 #pragma unroll
-		for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)x[(int)s - 1 - j];
-		const int32_t r = (int32_t)((int64_t)x[s] - (sum >> shift));
+		for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)(packed ? (int32_t)x16[(int)s - 1 - j] : x32[(int)s - 1 - j]);
+		const int64_t v = (int64_t)(packed ? (int32_t)x16[s] : x32[s]) - (sum >> shift);
+		if(check && (v <= (int64_t)INT32_MIN || v > (int64_t)INT32_MAX)) bad = true;
+		const int32_t r = (int32_t)v;
 		acc += (uint32_t)(r < 0 ? -(uint32_t)r : (uint32_t)r);
 	}
 	return acc;
@@ -784,15 +891,21 @@ __device__ uint64_t fir_abs_packed_wide(const uint32_t *reg, uint32_t S, uint32_
 // One wavefront evaluates one residual candidate on the owner layout; requires n == 64*S, S >= 16, max_po <= 6.
 template <int MAXORD>
 __device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's region */, bool packed, uint32_t S, uint32_t n, uint32_t order, const int32_t *q, int shift,
-                                         bool wide, uint32_t sbps, uint32_t rice_limit, uint32_t max_po, uint32_t min_po, const uint32_t *divtab,
+                                         uint32_t wide /* Candidate::wide */, uint32_t sbps, uint32_t rice_limit, uint32_t max_po, uint32_t min_po, const uint32_t *divtab,
                                          uint8_t *kout, uint32_t *best_po_out, int lane)
 {
 	const uint32_t psize = n >> max_po;
 	const bool narrow = (sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
 	uint64_t v;
-	if(packed) {
+	bool bad = false;
+	if(wide == 2) {
+		v = fir_abs_plain64<MAXORD>(reg, packed, S, order, q, shift, lane, true, bad);
+		if(__any((int)bad)) return 0xffffffffu;                         // no candidate (stream_encoder.c:4603-4604)
+		if(narrow) v = (uint32_t)v;
+	}
+	else if(packed) {
 		if(!wide) v = narrow ? fir_abs_packed_dispatch<MAXORD, true>(reg, S, order, q, shift, lane) : fir_abs_packed_dispatch<MAXORD, false>(reg, S, order, q, shift, lane);
-		else { v = fir_abs_packed_wide<MAXORD>(reg, S, order, q, shift, lane); if(narrow) v = (uint32_t)v; }
+		else { v = fir_abs_plain64<MAXORD>(reg, true, S, order, q, shift, lane, false, bad); if(narrow) v = (uint32_t)v; }
 	}
 	else {
 		const int fmode = fir_mode(wide, sbps);
@@ -824,7 +937,7 @@ __host__ __device__ inline uint32_t owner_chan_bytes(uint32_t N, bool packed)
 	const uint32_t S = N / 64, w = (packed ? (S + OH) / 2 : S + OH) | 1u;
 	return (64 * w * 4 + (CHUNK + MAX_ORDER) * 4 + 15u) & ~15u;
 }
-__host__ __device__ inline bool owner_possible(const DevParams &P) { return P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH && P.max_lpc_order <= (uint32_t)OH; }
+__host__ __device__ inline bool owner_possible(const DevParams &P) { return P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH && P.max_lpc_order <= (uint32_t)OH && !P.wide_samples; }
 // candidate records are staged in LDS next to the channel image when there are few of them (every preset); the wide
 // searches (-e, -p: hundreds of slots per channel) read them from global memory and keep only the valid flags in LDS
 __host__ __device__ inline bool eval_cands_in_lds(const DevParams &P) { return P.ncslots <= 48; }
@@ -911,7 +1024,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	const uint32_t S = n / 64;
 	// (a short last block whose lane runs are odd while the nominal ones are even would need a wider image than the
 	// launch reserved: it takes the generic path)
-	const bool owner = MAXORD <= OH && (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6 && (S % 2 == 0 || (N / 64) % 2 == 1);
+	const bool owner = MAXORD <= OH && owner_possible(P) && (n % 64 == 0) && S >= (uint32_t)OH && frame_max_po <= 6 && (S % 2 == 0 || (N / 64) % 2 == 1);
 	const uint32_t cand_bytes = eval_cand_bytes(P), cand_valid_off = cands_lds ? P.ncslots * (uint32_t)sizeof(Candidate) : 0u;
 
 	// ---- channel facts ---------------------------------------------------------------------------------------
@@ -963,7 +1076,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 				int *vd = (int *)(ctx + img_bytes + cand_valid_off);
 				for(uint32_t t = (uint32_t)tid; t < E.nan; t += nthreads) vd[t] = valid[fc * cstride + t];
 			}
-			const uint32_t *src = (const uint32_t *)(chan + fc * (size_t)N);       // planar channel, already shifted (ChanPrep::fmt)
+			const uint32_t *src = (const uint32_t *)(chan + fc * (size_t)P.chan_stride);       // planar channel, already shifted (ChanPrep::fmt)
 			const uint32_t srcfmt = E.pr.fmt;
 			if(VARIANT != 2) {
 				uint32_t *sigw = (uint32_t *)ctx;
@@ -1001,6 +1114,14 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 					}
 				}
 			}
+			else if(srcfmt == 2) {
+				// 33-bit side channel: 64-bit samples, same row layout
+				int64_t *sig = (int64_t *)ctx;
+				if(tid < 32) sig[sigidx(tid - 32)] = 0;
+				const uint32_t nround = ((n + 15u) & ~15u) + 16u;
+				for(uint32_t i = n + (uint32_t)tid; i < nround; i += nthreads) sig[sigidx((int)i)] = 0;
+				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) sig[sigidx((int)i)] = ((const int64_t *)src)[i];
+			}
 			else {
 				int32_t *sig = (int32_t *)ctx;
 				if(tid < 32) sig[sigidx(tid - 32)] = 0;
@@ -1033,14 +1154,14 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 				uint32_t po = 0, rbits;
 				if constexpr(VARIANT == 0 && MAXORD > OH) rbits = 0;      // predictors of more than 16 taps are evaluated by VARIANT 2
 				else if constexpr(VARIANT == 0)
-					rbits = eval_candidate_owner<MAXORD>((const uint32_t *)ctx + (uint32_t)lane * E.stride, E.packed != 0, S, n, order, cd->q, cd->shift, cd->wide != 0, sbps, P.rice_limit,
+					rbits = eval_candidate_owner<MAXORD>((const uint32_t *)ctx + (uint32_t)lane * E.stride, E.packed != 0, S, n, order, cd->q, cd->shift, cd->wide, sbps, P.rice_limit,
 					                                     frame_max_po, frame_min_po, sh->divtab, ktmp, &po, lane);
 				else {
 					int32_t q[MAXORD];
 #pragma unroll
 					for(int jj = 0; jj < MAXORD; jj++) q[jj] = cd->q[jj];
-					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, (const int32_t *)ctx, n, order, q, cd->shift,
-					                                    cd->wide != 0, sbps, P, frame_max_po, frame_min_po, &po, lane);
+					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, (const void *)ctx, E.pr.fmt == 2, n, order, q, cd->shift,
+					                                    cd->wide, sbps, P, frame_max_po, frame_min_po, &po, lane);
 				}
 				const uint32_t est = ci < P.nfixed ? sat_add_u32(hdr + order * sbps, rbits)
 				                             : sat_add_u32(hdr + 4 + 5 + order * (cd->precision + sbps), rbits);
@@ -1068,11 +1189,11 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 		const uint32_t sbps = pr.sbps, wasted = pr.wasted, hdr = 8 + wasted;
 		SubDecision *dec = decisions + fc0 + c;
 		uint32_t best_type = 1, best_order = 0, best_po = 0, best_precision = 0, best_ci = 0, best_wave = 0;
-		int32_t best_shift = 0, best_constant = 0;
+		int32_t best_shift = 0, best_constant = 0, best_constant_hi = 0;
 		uint32_t best_bits = pr.verbatim_bits;
 		if(pr.flags & PREP_CONSTANT) {
 			const uint32_t bits = hdr + sbps;
-			if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_bits = bits; }
+			if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_constant_hi = pr.constant_hi; best_bits = bits; }
 		}
 		const Candidate *mycands = nullptr;
 		if(E.any) {
@@ -1106,7 +1227,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
 			dec->po = (uint8_t)best_po; dec->rice2 = (uint8_t)rice2; dec->precision = (uint8_t)best_precision;
 			dec->shift = (int8_t)best_shift; dec->which = (uint8_t)pr.which;
-			dec->constant = best_constant;
+			dec->constant = best_constant; dec->constant_hi = best_constant_hi;
 		}
 	}
 	STAMP(5);

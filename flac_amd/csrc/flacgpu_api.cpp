@@ -169,7 +169,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	*out = nullptr;
 	// ---- supported range (everything else is a documented, loud failure; no CPU fallback) ----
 	if(cfg->channels < 1 || cfg->channels > FLACGPU_MAX_CHANNELS) return FLACGPU_ERR_UNSUPPORTED;
-	if(cfg->bits_per_sample < 4 || cfg->bits_per_sample > 24) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->bits_per_sample < 4 || cfg->bits_per_sample > 32) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->blocksize < 16 || cfg->blocksize > 16384) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->max_lpc_order > (uint32_t)MAX_ORDER) return FLACGPU_ERR_UNSUPPORTED;       // FLAC__MAX_LPC_ORDER
 	if(cfg->max_lpc_order > 0 && (cfg->qlp_coeff_precision < 5 || cfg->qlp_coeff_precision > 15)) return FLACGPU_ERR_UNSUPPORTED;
@@ -197,6 +197,8 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	const bool ms = cfg->do_mid_side_stereo && C == 2;
 	P.ms_mode = ms ? (cfg->loose_mid_side_stereo ? 2u : 1u) : 0u;
 	P.ncand = P.ms_mode == 1 ? 4u : C;
+	P.wide_samples = bps > 24 ? 1u : 0u;
+	P.chan_stride = (bps == 32 && P.ms_mode != 0) ? 2 * N : N;
 	P.max_lpc_order = cfg->max_lpc_order;
 	P.precision = cfg->qlp_coeff_precision;
 	P.min_po = cfg->min_residual_partition_order;
@@ -218,6 +220,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	{
 		const uint32_t maxidx = 32 + ((N + 15u) & ~15u) + 16u + 16u;
 		P.sig_bytes = ((maxidx + ((maxidx >> 4) << 1) + 8) * 4 + 15) & ~15u;
+		if(P.chan_stride != N) P.sig_bytes *= 2;               // 64-bit samples
 		// window jobs of one subframe (same enumeration as analyze_kernel): all of them are windowed
 		// into LDS at once so that their autocorrelation chains run concurrently
 		uint32_t nj = 0, na = 0;
@@ -271,7 +274,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		ok = ok && hipMalloc(&c->ab.autoc, nfc * P.max_jobs * AUTOC_STRIDE * sizeof(double)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.cands, nfc * ncs * sizeof(Candidate)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.valid, nfc * ncs * sizeof(int)) == hipSuccess;
-		ok = ok && hipMalloc(&c->ab.chan, nfc * N * sizeof(int32_t)) == hipSuccess;
+		ok = ok && hipMalloc(&c->ab.chan, nfc * P.chan_stride * sizeof(int32_t)) == hipSuccess;
 		if(ok && getenv("FLACGPU_DEBUG_TIMING")) { ok = hipMalloc(&c->ab.dbg, nfc * 16 * sizeof(unsigned long long)) == hipSuccess; if(ok) (void)hipMemset(c->ab.dbg, 0, nfc * 16 * sizeof(unsigned long long)); }
 	}
 	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
@@ -318,7 +321,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			(void)hipStreamWaitEvent(ss, c->ev_fork, 0);
 			const size_t fc0 = (size_t)f0 * P.ncand, ncs = P.ncslots;
 			AnalyzeBuffers B = c->ab;
-			B.prep += fc0; B.autoc += fc0 * P.max_jobs * AUTOC_STRIDE; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.blocksize; B.dbg = nullptr;
+			B.prep += fc0; B.autoc += fc0 * P.max_jobs * AUTOC_STRIDE; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.chan_stride; B.dbg = nullptr;
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
 			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, B,
 			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;

@@ -262,7 +262,7 @@ static void launch_autoc2_t(const DevParams &P, const int32_t *pcm, const float 
 }
 
 // true when the streaming kernel serves the nominal-length frames of this configuration
-bool autoc2_applicable(const DevParams &P) { return P.blocksize > 32 && P.max_lpc_order > 0 && P.autoc_variant != 0; }
+bool autoc2_applicable(const DevParams &P) { return P.blocksize > 32 && P.max_lpc_order > 0 && P.autoc_variant != 0 && !P.wide_samples; }
 
 hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt,
                          const ChanPrep *preps, double *autoc, hipStream_t s)

@@ -36,6 +36,10 @@ struct DevParams {
 	uint32_t norders;          // 1 (the guessed order) or max_lpc_order (-e: orders 1..max)
 	uint32_t nprec;            // 1 or 11 (-p: precisions 5..15)
 	uint32_t ncslots;          // nfixed + max_analyses * norders * nprec
+	// more than 24 bits per sample: only the general kernels run; the side channel of a 32-bit stream has 33 bits
+	// (stream_encoder.c:3831-3835) and is kept as 64-bit samples in HBM and LDS
+	uint32_t wide_samples;     // bps > 24
+	uint32_t chan_stride;      // 32-bit words per planar channel: blocksize, or 2 * blocksize when a 33-bit channel can occur
 };
 
 // analysis -> pack hand-off, one per (frame, candidate channel); 16-byte multiple
@@ -45,15 +49,17 @@ struct SubDecision {
 	uint8_t order, wasted, po, rice2, precision;
 	int8_t shift;
 	uint8_t which;             // signal modelled: 0..C-1 channel, C mid, C+1 side
-	int32_t constant;
+	int32_t constant;          // CONSTANT: the sample value (low 32 bits)
 	int32_t q[MAX_ORDER];
 	uint8_t params[1u << MAX_PO];
+	int32_t constant_hi;       // bits 32.. of a 33-bit constant (sign extension otherwise)
+	uint32_t pad[3];
 };
 
 struct Candidate {
 	uint32_t order, precision;
 	int32_t shift;
-	uint32_t wide;             // 64-bit accumulate FIR (lpc.c:582) instead of 32-bit (lpc.c:321)
+	uint32_t wide;             // 0: 32-bit FIR (lpc.c:321), 1: 64-bit accumulate (lpc.c:582), 2: overflow-checked (lpc.c:832,886)
 	int32_t q[MAX_ORDER];
 };
 
@@ -85,8 +91,9 @@ struct ChanPrep {
 	uint32_t fixed_order;      // guessed fixed-predictor order
 	int32_t constant;          // sample value when PREP_CONSTANT
 	uint32_t verbatim_bits;    // size of the VERBATIM baseline (0xffffffff: disabled)
-	uint32_t fmt;              // planar channel copy: 1 = 16-bit pairs (sbps <= 16), 0 = 32-bit samples
-	uint32_t pad[3];
+	uint32_t fmt;              // planar channel copy: 1 = 16-bit pairs (sbps <= 16), 0 = 32-bit samples, 2 = 64-bit samples (sbps 33)
+	int32_t constant_hi;       // bits 32.. of a 33-bit constant
+	uint32_t pad[2];
 };
 struct AnalyzeBuffers {
 	ChanPrep *prep;            // [frames*ncand]

@@ -98,6 +98,7 @@ __device__ __forceinline__ uint64_t block_reduce_add_u64(uint64_t v, uint64_t *s
 	for(int w = 0; w < TPB / 64; w++) r += scratch[w];
 	return r;
 }
+__device__ __forceinline__ uint64_t abs_i64(int64_t v) { return (uint64_t)(v < 0 ? -v : v); }
 __device__ __forceinline__ uint32_t block_reduce_or_u32(uint32_t v, uint64_t *scratch, int tid)
 {
 	v = wave_reduce_or_u32(v);
@@ -162,7 +163,7 @@ __device__ __forceinline__ uint32_t levinson(const double (&a)[MAXORD + 1], uint
 
 // evaluate_lpc_subframe_'s front end for one (order, precision): precision clamp (stream_encoder.c:4591-4595),
 // FLAC__lpc_quantize_coefficients (lpc.c:220-314), residual-width selector (stream_encoder.c:4601-4617, lpc.c:942-976).
-// Returns 0 when no candidate results (quantiser failure; residual would need the >32-bit "limit_residual" flavour).
+// Returns 0 when no candidate results (quantiser failure).
 template <int MAXORD>
 __device__ __forceinline__ int quantize_candidate(const float (&coef)[MAXORD], uint32_t order, uint32_t precision, uint32_t sbps, Candidate *out)
 {
@@ -206,8 +207,8 @@ __device__ __forceinline__ int quantize_candidate(const float (&coef)[MAXORD], u
 		const uint64_t maxabs = (uint64_t)1 << (sbps - 1);
 		const uint64_t before = maxabs * abs_sum;
 		const uint64_t after = (uint64_t)(-1 * ((-1 * (int64_t)before) >> shift));
-		if(silog2_i64((int64_t)(maxabs + after)) > 32) return 0;
-		out->wide = silog2_i64((int64_t)before) > 32;
+		if(silog2_i64((int64_t)(maxabs + after)) > 32) out->wide = 2;          // the residual may not fit 32 bits: checked while it is computed
+		else out->wide = silog2_i64((int64_t)before) > 32 ? 1u : 0u;
 	}
 #pragma unroll
 	for(int i = 0; i < MAXORD; i++) out->q[i] = q[i];                // taps past MAXORD are never read
@@ -343,8 +344,10 @@ __device__ __forceinline__ int32_t pick_channel(const int32_t *frame_pcm, uint32
 {
 	if(which < C) return frame_pcm[(size_t)i * C + which];
 	const int32_t l = frame_pcm[(size_t)i * 2], r = frame_pcm[(size_t)i * 2 + 1];
-	return which == C ? ((l + r) >> 1) : (l - r);
+	return which == C ? (int32_t)(((int64_t)l + (int64_t)r) >> 1) : (l - r);      // (the 33-bit side of a 32-bit stream: side64())
 }
+// side channel of a 32-bit stream: 33 bits (stream_encoder.c:3833)
+__device__ __forceinline__ int64_t side64(int2 lr) { return (int64_t)lr.x - (int64_t)lr.y; }
 
 __device__ void load_signal(int32_t *sig, const int32_t *frame_pcm, uint32_t C, uint32_t n, uint32_t which,
                             uint32_t *or_out, int tid)
@@ -358,7 +361,7 @@ __device__ void load_signal(int32_t *sig, const int32_t *frame_pcm, uint32_t C, 
 		const int2 *p = (const int2 *)frame_pcm;
 		for(uint32_t i = (uint32_t)tid; i < n; i += TPB) {
 			const int2 lr = p[i];
-			int32_t v = which == 0 ? lr.x : which == 1 ? lr.y : which == 2 ? ((lr.x + lr.y) >> 1) : (lr.x - lr.y);
+			int32_t v = which == 0 ? lr.x : which == 1 ? lr.y : which == 2 ? (int32_t)(((int64_t)lr.x + (int64_t)lr.y) >> 1) : (lr.x - lr.y);
 			sig[sigidx((int)i)] = v;
 			orv |= (uint32_t)v;
 		}
@@ -378,40 +381,54 @@ __device__ void load_signal(int32_t *sig, const int32_t *frame_pcm, uint32_t C, 
 // MODE 0: 32-bit wrapping accumulate with 24-bit multiplies (lpc.c:321; valid when samples fit 24 bits signed and
 //         |tap| < 2^23: the low 32 bits of the product are the same, at the full VALU rate of v_mad_i32_i24)
 // MODE 1: 32-bit wrapping accumulate, full 32-bit multiplies (lpc.c:321)
-// MODE 2: 64-bit accumulate (lpc.c:582)
-template <int MAXORD, int MODE>
-__device__ __forceinline__ void fir_chunk(const int32_t *sig, int base, const int32_t *q, int shift, int32_t *r)
+// MODE 2: 64-bit accumulate (lpc.c:582; with 64-bit samples fixed.c:532)
+// MODE 3: 64-bit accumulate, and the residual must lie in (INT32_MIN, INT32_MAX] (lpc.c:832; 64-bit samples lpc.c:886):
+//         returns true when a residual of a sample in [lo, hi) does not
+// ST: int32_t samples, or int64_t (the 33-bit side channel of a 32-bit stream; modes 2 and 3 only)
+template <int MAXORD, int MODE, typename ST>
+__device__ __forceinline__ bool fir_chunk(const ST *sig, int base, const int32_t *q, int shift, int32_t *r, uint32_t lo, uint32_t hi)
 {
-	int32_t x[MAXORD + CHUNK];
+	ST x[MAXORD + CHUNK];
+	bool bad = false;
 #pragma unroll
 	for(int k = 0; k < MAXORD + CHUNK; k++) x[k] = sig[sigidx(base - MAXORD + k)];
 #pragma unroll
 	for(int s = 0; s < CHUNK; s++) {
-		if(MODE == 2) {
-			int64_t sum = 0;
+		if(MODE >= 2) {
+			uint64_t sum = 0;                                             // wraps like the reference's int64 does
 #pragma unroll
-			for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)x[MAXORD + s - 1 - j];
-			r[s] = (int32_t)((int64_t)x[MAXORD + s] - (sum >> shift));
+			for(int j = 0; j < MAXORD; j++) sum += (uint64_t)((int64_t)q[j] * (int64_t)x[MAXORD + s - 1 - j]);
+			const int64_t v = (int64_t)((uint64_t)(int64_t)x[MAXORD + s] - (uint64_t)((int64_t)sum >> shift));
+			r[s] = (int32_t)v;
+			if(MODE == 3) { const uint32_t i = (uint32_t)(base + s); bad = bad || (i >= lo && i < hi && (v <= (int64_t)INT32_MIN || v > (int64_t)INT32_MAX)); }
 		}
 		else {
 			uint32_t sum = 0;
 #pragma unroll
 			for(int j = 0; j < MAXORD; j++)
-				sum += MODE == 0 ? (uint32_t)__mul24(q[j], x[MAXORD + s - 1 - j]) : (uint32_t)q[j] * (uint32_t)x[MAXORD + s - 1 - j];
+				sum += MODE == 0 ? (uint32_t)__mul24(q[j], (int32_t)x[MAXORD + s - 1 - j]) : (uint32_t)q[j] * (uint32_t)x[MAXORD + s - 1 - j];
 			r[s] = (int32_t)((uint32_t)x[MAXORD + s] - (uint32_t)((int32_t)sum >> shift));
 		}
 	}
+	return bad;
 }
 
-// mode: 0/1/2 as above (wave-uniform)
+// mode: 0..3 as above (wave-uniform); s64: the signal array holds 64-bit samples.  lo/hi: the samples the overflow
+// check of mode 3 looks at (predictor order .. block length).  Returns the mode-3 verdict (false otherwise).
 template <int MAXORD>
-__device__ __forceinline__ void fir_chunk_dispatch(const int32_t *sig, int base, const int32_t *q, int shift, int mode, int32_t *r)
+__device__ __forceinline__ bool fir_chunk_dispatch(const void *sig, bool s64, int base, const int32_t *q, int shift, int mode, int32_t *r, uint32_t lo, uint32_t hi)
 {
-	if(mode == 0) fir_chunk<MAXORD, 0>(sig, base, q, shift, r);
-	else if(mode == 1) fir_chunk<MAXORD, 1>(sig, base, q, shift, r);
-	else fir_chunk<MAXORD, 2>(sig, base, q, shift, r);
+	if(s64) {
+		if(mode == 3) return fir_chunk<MAXORD, 3, int64_t>((const int64_t *)sig, base, q, shift, r, lo, hi);
+		return fir_chunk<MAXORD, 2, int64_t>((const int64_t *)sig, base, q, shift, r, lo, hi);
+	}
+	if(mode == 0) return fir_chunk<MAXORD, 0, int32_t>((const int32_t *)sig, base, q, shift, r, lo, hi);
+	if(mode == 1) return fir_chunk<MAXORD, 1, int32_t>((const int32_t *)sig, base, q, shift, r, lo, hi);
+	if(mode == 2) return fir_chunk<MAXORD, 2, int32_t>((const int32_t *)sig, base, q, shift, r, lo, hi);
+	return fir_chunk<MAXORD, 3, int32_t>((const int32_t *)sig, base, q, shift, r, lo, hi);
 }
-__device__ __forceinline__ int fir_mode(bool wide, uint32_t sbps) { return wide ? 2 : (sbps <= 24 ? 0 : 1); }
+// Candidate::wide (0 / 1 / 2) -> FIR mode
+__device__ __forceinline__ int fir_mode(uint32_t wide, uint32_t sbps) { return wide == 2 ? 3 : wide ? 2 : (sbps <= 24 ? 0 : 1); }
 
 // ---------------------------------------------------------------------------------------------
 // fixed-predictor candidates of a subframe (stream_encoder.c:4153-4190): the guessed order, or with -e every
@@ -423,14 +440,15 @@ __device__ __forceinline__ float fixed_rbps(uint64_t e, uint32_t n4)
 {
 	return e ? (float)(log(((double)e * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
 }
+// invalid: bit k set = order k got 34 bits per sample from an overflow-checked estimator (fixed_intrin_avx2.c:172, fixed.c:360)
 __device__ __forceinline__ bool emit_fixed_candidates(const DevParams &P, Candidate *c0, int *v0, const uint64_t (&e)[5], uint32_t n4, uint32_t guess,
-                                                      bool allowed, uint32_t sbps, int lane)
+                                                      bool allowed, uint32_t sbps, int lane, uint32_t invalid = 0)
 {
 	bool any = false;
 	for(uint32_t k = 0; k < P.nfixed; k++) {
 		const uint32_t order = P.exhaustive ? k : guess;
 		const uint64_t eo = order == 0 ? e[0] : order == 1 ? e[1] : order == 2 ? e[2] : order == 3 ? e[3] : e[4];
-		const bool ok = allowed && !(fixed_rbps(eo, n4) >= (float)sbps);
+		const bool ok = allowed && !((invalid >> order) & 1u) && !(fixed_rbps(eo, n4) >= (float)sbps);
 		any = any || ok;
 		if(lane < 16) {                                               // every kernel flavour keeps at least 8 taps
 			int32_t c = 0;
@@ -440,7 +458,8 @@ __device__ __forceinline__ bool emit_fixed_candidates(const DevParams &P, Candid
 			else if(order == 4) c = lane == 0 ? 4 : lane == 1 ? -6 : lane == 2 ? 4 : lane == 3 ? -1 : 0;
 			c0[k].q[lane] = c;
 		}
-		if(lane == 0) { c0[k].order = order; c0[k].precision = 0; c0[k].shift = 0; c0[k].wide = 0; v0[k] = ok ? 1 : 0; }
+		// 64-bit differences once the 32-bit ones could wrap (stream_encoder.c:4511-4516)
+		if(lane == 0) { c0[k].order = order; c0[k].precision = 0; c0[k].shift = 0; c0[k].wide = sbps + order > 32 ? 1u : 0u; v0[k] = ok ? 1 : 0; }
 	}
 	return any;
 }
@@ -510,7 +529,7 @@ __device__ __forceinline__ uint32_t sat_add_u32(uint32_t est, uint32_t rbits)
 // partition order go to kout[0 .. 2^best_po).
 template <int MAXORD>
 __device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_t *pob, uint8_t *kout, const uint32_t *divtab,
-                                        const int32_t *sig, uint32_t n, uint32_t order, const int32_t *q, int shift, bool wide,
+                                        const void *sig, bool s64, uint32_t n, uint32_t order, const int32_t *q, int shift, uint32_t wide,
                                         uint32_t sbps, const DevParams &P, uint32_t frame_max_po, uint32_t frame_min_po,
                                         uint32_t *best_po_out, int lane)
 {
@@ -523,6 +542,7 @@ __device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_
 #pragma unroll
 	for(int j = 0; j < MAXORD; j++) qr[j] = q[j];
 	const int fmode = fir_mode(wide, sbps);
+	bool bad = false;                 // mode 3: a residual left the 32-bit range -> no candidate (stream_encoder.c:4603-4608)
 
 	// Lane `lane` owns chunks lane, lane+64, ... of CHUNK consecutive samples: adjacent lanes read adjacent
 	// 18-word rows of the padded signal, i.e. conflict-free LDS reads.
@@ -544,7 +564,7 @@ __device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_
 			uint64_t mine = 0;
 			if(base < n) {
 				int32_t r[CHUNK];
-				fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, fmode, r);
+				bad = fir_chunk_dispatch<MAXORD>(sig, s64, (int)base, qr, shift, fmode, r, order, n) || bad;
 				uint32_t acc32 = 0;
 				uint64_t acc64 = 0;
 #pragma unroll
@@ -569,7 +589,7 @@ __device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_
 		for(uint32_t cidx = (uint32_t)lane; cidx < nchunks; cidx += 64) {
 			const uint32_t base = cidx * CHUNK;
 			int32_t r[CHUNK];
-			fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, fmode, r);
+			bad = fir_chunk_dispatch<MAXORD>(sig, s64, (int)base, qr, shift, fmode, r, order, n) || bad;
 			uint32_t part = base / psize, next = (part + 1) * psize;
 			uint64_t run = 0;
 #pragma unroll
@@ -693,7 +713,7 @@ __device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_
 	}
 	__builtin_amdgcn_wave_barrier();
 	*best_po_out = best_po;
-	return best_bits;
+	return __any((int)bad) ? 0xffffffffu : best_bits;
 }
 
 } // namespace flacgpu

@@ -212,7 +212,13 @@ __host__ __device__ inline uint32_t pack_pass_sig_bytes(const DevParams &P)
 {
 	const uint32_t span = P.blocksize < (uint32_t)(CHUNK * TPB) ? ((P.blocksize + 15u) & ~15u) : (uint32_t)(CHUNK * TPB);
 	const uint32_t maxidx = 32 + span + 16u + 16u;
-	return ((maxidx + ((maxidx >> 4) << 1) + 8) * 4 + 15) & ~15u;
+	return (((maxidx + ((maxidx >> 4) << 1) + 8) * 4 + 15) & ~15u) * (P.chan_stride != P.blocksize ? 2u : 1u);     // 64-bit samples
+}
+// a sample of up to 33 bits, two's complement, MSB first
+__device__ __forceinline__ void put_sample(uint32_t *buf, uint32_t cap_words, uint32_t pos, int64_t v, uint32_t len)
+{
+	if(len > 32) { put_bits(buf, cap_words, pos, (uint32_t)((uint64_t)v >> 32), len - 32); put_bits(buf, cap_words, pos + len - 32, (uint32_t)v, 32); }
+	else put_bits(buf, cap_words, pos, (uint32_t)v, len);
 }
 
 struct PackShared {
@@ -294,18 +300,22 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 
 		// the planar channel written by the prep kernels (wasted bits already shifted out, 16-bit pairs when sbps <= 16)
 		// is staged one pass of CHUNK*TPB samples at a time: sample pass + k sits at sigidx(k), k = -32 .. CHUNK*TPB+16
-		const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + di) * N);
+		const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + di) * P.chan_stride);
+		const bool s64 = sbps > 32;                 // the 33-bit side channel of a 32-bit stream: 64-bit samples
+		int64_t *sig64 = (int64_t *)smem;
 		auto stage_pass = [&](uint32_t pass) {
 			__syncthreads();
 			const int span = (int)(N < (uint32_t)(CHUNK * TPB) ? ((N + 15u) & ~15u) : (uint32_t)(CHUNK * TPB));
 			for(int k = tid - 32; k < span + 16; k += TPB) {
 				const int64_t i = (int64_t)pass + k;
+				if(s64) { sig64[sigidx(k)] = (i >= 0 && i < (int64_t)n) ? ((const int64_t *)src)[i] : 0; continue; }
 				int32_t v = 0;
 				if(i >= 0 && i < (int64_t)n) v = sbps <= 16 ? (int32_t)((const int16_t *)src)[i] : (int32_t)src[i];
 				sig[sigidx(k)] = v;
 			}
 			__syncthreads();
 		};
+		auto SV = [&](int k) -> int64_t { return s64 ? sig64[sigidx(k)] : (int64_t)sig[sigidx(k)]; };
 
 		// subframe header byte (+ unary wasted bits)
 		uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : type == 2 ? (0x10u | (order << 1)) : (0x40u | ((order - 1) << 1));
@@ -316,13 +326,13 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 		pos += 8 + wasted;
 
 		if(type == 0) {
-			if(tid == 0) put_bits(img, cap_words, pos, (uint32_t)d->constant, sbps);
+			if(tid == 0) put_sample(img, cap_words, pos, ((int64_t)d->constant_hi << 32) | (int64_t)(uint32_t)d->constant, sbps);
 			pos += sbps;
 		}
 		else if(type == 1) {
 			for(uint32_t pass = 0; pass < n; pass += CHUNK * TPB) {
 				stage_pass(pass);
-				for(uint32_t k = (uint32_t)tid; k < CHUNK * TPB && pass + k < n; k += TPB) put_bits(img, cap_words, pos + (pass + k) * sbps, (uint32_t)sig[sigidx((int)k)], sbps);
+				for(uint32_t k = (uint32_t)tid; k < CHUNK * TPB && pass + k < n; k += TPB) put_sample(img, cap_words, pos + (pass + k) * sbps, SV((int)k), sbps);
 			}
 			pos += n * sbps;
 		}
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 			const uint32_t warm_pos = pos;
 			pos += order * sbps;
 			const int shift = type == 3 ? d->shift : 0;
-			bool wide = false;
+			bool wide = sbps + order > 32;                 // FIXED: 64-bit differences (stream_encoder.c:4511-4516)
 			if(type == 3) {
 				const uint32_t precision = d->precision;
 				if(tid == 0) {
@@ -371,9 +381,9 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 				int32_t r[CHUNK];
 				uint32_t mybits = 0;
 				stage_pass(pass);
-				if(pass == 0 && (uint32_t)tid < order) put_bits(img, cap_words, warm_pos + (uint32_t)tid * sbps, (uint32_t)sig[sigidx(tid)], sbps);
+				if(pass == 0 && (uint32_t)tid < order) put_sample(img, cap_words, warm_pos + (uint32_t)tid * sbps, SV(tid), sbps);
 				if(base < n) {
-					fir_chunk_dispatch<MAXORD>(sig, (int)(CHUNK * (uint32_t)tid), q, shift, fir_mode(wide, sbps), r);
+					(void)fir_chunk_dispatch<MAXORD>((const void *)smem, s64, (int)(CHUNK * (uint32_t)tid), q, shift, fir_mode(wide ? 1u : 0u, sbps), r, 0, 0);
 					uint32_t part = base / psize, next = (part + 1) * psize;
 					uint32_t k = sh->params[part];
 #pragma unroll
@@ -891,7 +901,7 @@ using namespace flacgpu;
 static bool pack2_applicable(const DevParams &P)
 {
 	const uint32_t ps = P.blocksize >> P.max_po;
-	return P.blocksize % CHUNK == 0 && ps >= (uint32_t)CHUNK && ps % CHUNK == 0 && ((size_t)ps << P.max_po) == P.blocksize;
+	return P.blocksize % CHUNK == 0 && ps >= (uint32_t)CHUNK && ps % CHUNK == 0 && ((size_t)ps << P.max_po) == P.blocksize && !P.wide_samples;
 }
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,

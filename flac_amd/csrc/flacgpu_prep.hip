@@ -213,7 +213,7 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 		if(lane == 0) {
 			ChanPrep pr;
 			pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
-			pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;
+			pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.pad[0] = pr.pad[1] = 0;
 			preps[fc] = pr;
 		}
 		// ---- planar channel, shifted ---------------------------------------------------------------------------
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 			if(lane == 0) {
 				ChanPrep pr;
 				pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = N; pr.flags = flags; pr.fixed_order = fixed_order;
-				pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;
+				pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.pad[0] = pr.pad[1] = 0;
 				preps[fc] = pr;
 			}
 		}
@@ -432,14 +432,14 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 		}
 	}
 }
-bool prep3_applicable(const DevParams &P) { return P.channels == 2 && P.ms_mode != 0 && P.blocksize == 4096; }
+bool prep3_applicable(const DevParams &P) { return P.channels == 2 && P.ms_mode != 0 && P.blocksize == 4096 && !P.wide_samples; }
 
 // the kernel above serves frames of nominal length when every lane run is whole and the AVX2 short-tail quirk of
 // the reference's wide fixed-predictor routine cannot occur (fixed_intrin_avx2.c:57 with (n-4) % 4 != 0)
 bool prep2_applicable(const DevParams &P)
 {
 	const uint32_t nraw = (P.channels == 2 && P.ms_mode != 0) ? 2u : (P.channels < 4 ? P.channels : 4u);
-	return P.blocksize % 16 == 0 && P.blocksize > 4 && (size_t)nraw * p2_chan_bytes(P.blocksize) <= 150 * 1024;
+	return P.blocksize % 16 == 0 && P.blocksize > 4 && (size_t)nraw * p2_chan_bytes(P.blocksize) <= 150 * 1024 && !P.wide_samples;
 }
 
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s)

@@ -85,6 +85,23 @@ def mixed(n, channels=2, bps=16, seed=99):
     return x[:n]
 
 
+def slow(n, channels=2, bps=24, kind=0, rate=96000):
+    """very smooth full-scale signals, the two channels in anti-phase: the LPC coefficients grow past 2^7, the predicted
+    residual width past 32 bits, and the reference switches to its overflow-checked FIR (stream_encoder.c:4601-4609)"""
+    t = np.arange(n, dtype=np.float64)
+    if kind == 0:
+        x = np.sin(2 * np.pi * 2.0 * t / rate)
+    elif kind == 1:
+        x = sum(np.sin(2 * np.pi * f * t / rate + f) for f in (3.0, 7.0, 11.0, 19.0, 31.0, 43.0)) / 6
+    elif kind == 2:
+        x = (t / n - 0.5) ** 7
+    else:
+        x = np.sin(2 * np.pi * (1.0 + 30.0 * t / n) * t / rate)
+    x = x / np.abs(x).max() * ((1 << (bps - 1)) - 1) * 0.99
+    cols = [np.round(x) if c % 2 == 0 else np.round(-x * 0.98) for c in range(channels)]
+    return np.stack(cols, axis=1).astype(np.int32)
+
+
 FSD_PATTERNS = {1: (1, -1), 2: (1, 1, -1), 3: (1, -1, -1), 4: (1, -1, 1, -1), 5: (1, -1, -1, 1), 6: (1, -1, 1, 1, -1), 7: (1, -1, -1, 1, -1)}
 
 

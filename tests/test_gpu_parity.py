@@ -372,3 +372,52 @@ def test_sample_rate_codes(rate):
     data, fb = _gpu_encode(pcm, 16, rate, 5, streamable_subset=0, max_batch=8)
     o = po.oracle_encode(pcm, 16, rate, 5)
     assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], rate
+
+
+@pytest.mark.parametrize("bps", [25, 27, 28, 31, 32])
+def test_wide_samples(bps):
+    """more than 24 bits per sample: overflow-checked estimators and residuals, 64-bit fixed residuals, and at 32 bits the
+    33-bit side channel (64-bit samples through prep / autocorrelation / evaluation / pack)"""
+    for fam in ("music", "white", "sine", "square", "mixed", "wasted", "quiet", "constant", "silence"):
+        for level in (0, 1, 2, 5, 8):
+            for ch in (1, 2):
+                pcm = signals.FAMILIES[fam](4096 + 1333, ch, bps)
+                data, fb = _gpu_encode(pcm, bps, 96000, level, streamable_subset=0, max_batch=8)
+                o = po.oracle_encode(pcm, bps, 96000, level)
+                assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (bps, fam, level, ch)
+
+
+@pytest.mark.parametrize("bps", [8, 16, 24, 32])
+@pytest.mark.parametrize("pattern", range(1, 8))
+def test_full_scale_deflection(bps, pattern):
+    """test/test_streams.sh:188-193: fsd<bps>-0<pattern>, -0 -l 16 --lax -m -e -p; mono like the suite, and as an inverted pair"""
+    for ch in (1, 2):
+        pcm = signals.fsd(1152 * 2 + 100, ch, bps, pattern)
+        kw = dict(max_lpc_order=16, exhaustive=1, prec_search=1, mid_side=1)
+        data, fb = _gpu_encode(pcm, bps, 44100, 0, streamable_subset=0, loose_mid_side=0, max_batch=8, **kw)
+        o = po.oracle_encode(pcm, bps, 44100, 0, loose=0, **kw)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (bps, pattern, ch)
+
+
+@pytest.mark.parametrize("tail", [1, 5, 6, 7, 9, 33, 1001, 4095])
+def test_wide_samples_short_last_block(tail):
+    """(n-4) % 4 != 0 in the four-lane estimators of the overflow-checked flavour"""
+    for bps in (28, 32):
+        for fam in ("music", "white"):
+            pcm = signals.FAMILIES[fam](4096 + tail, 2, bps)
+            for level, kw in ((5, {}), (8, dict(exhaustive=1))):
+                data, fb = _gpu_encode(pcm, bps, 96000, level, streamable_subset=0, max_batch=8, **kw)
+                o = po.oracle_encode(pcm, bps, 96000, level, **kw)
+                assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (bps, fam, tail, level)
+
+
+@pytest.mark.parametrize("kind", range(4))
+def test_overflow_checked_residual_at_24_bits(kind):
+    """smooth anti-phase pairs: candidates whose bound on the residual width exceeds 32 bits take the overflow-checked FIR
+    (lpc.c:832) already at 24 bits per sample -- on the owner-layout evaluation and through pack2"""
+    for bps in (24, 20):
+        pcm = signals.slow(4096 * 2 + 77, 2, bps, kind)
+        for level, kw in ((5, {}), (8, {}), (8, dict(exhaustive=1)), (5, dict(prec_search=1))):
+            data, fb = _gpu_encode(pcm, bps, 96000, level, streamable_subset=0, max_batch=8, **kw)
+            o = po.oracle_encode(pcm, bps, 96000, level, **kw)
+            assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (kind, bps, level, kw)

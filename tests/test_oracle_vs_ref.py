@@ -313,3 +313,15 @@ def test_wide_samples_short_last_block(ref, tail):
                 r = po.ref_encode(pcm, bps, 96000, level, streamable_subset=0, **kw)
                 o = po.oracle_encode(pcm, bps, 96000, level, **kw)
                 assert o["data"] == _frames(r), (bps, fam, tail, level)
+
+
+@pytest.mark.parametrize("kind", range(4))
+def test_overflow_checked_residual_at_24_bits(ref, kind):
+    """smooth anti-phase pairs: candidates whose bound on the residual width exceeds 32 bits (lpc.c:962) take
+    FLAC__lpc_compute_residual_from_qlp_coefficients_limit_residual (lpc.c:832) already at 24 bits per sample"""
+    for bps in (24, 20):
+        pcm = signals.slow(4096 * 2 + 77, 2, bps, kind)
+        for level, kw in ((5, {}), (8, {}), (8, dict(exhaustive=1)), (5, dict(prec_search=1))):
+            r = po.ref_encode(pcm, bps, 96000, level, streamable_subset=0, **kw)
+            o = po.oracle_encode(pcm, bps, 96000, level, **kw)
+            assert o["data"] == _frames(r), (kind, bps, level, kw)
