@@ -27,6 +27,14 @@ static inline uint32_t br_bits(bitr *b, unsigned n)           /* n <= 32 */
 	return v;
 }
 static inline int32_t br_sbits(bitr *b, unsigned n) { const uint32_t v = br_bits(b, n); return n >= 32 ? (int32_t)v : (int32_t)(v << (32 - n)) >> (32 - n); }
+/* a sample of up to 33 bits (the side channel of a 32-bit stream) */
+static inline int64_t br_sample(bitr *b, unsigned n)
+{
+	if(n <= 32) return br_sbits(b, n);
+	const uint64_t hi = br_bits(b, n - 32), lo = br_bits(b, 32);
+	const uint64_t v = (hi << 32) | lo;
+	return (int64_t)(v << (64 - n)) >> (64 - n);
+}
 static inline uint32_t br_unary(bitr *b)                       /* zeros before the next 1 */
 {
 	uint32_t z = 0;
@@ -107,7 +115,7 @@ static inline int32_t expected_sample(const uint8_t *raw, uint32_t width, size_t
 }
 
 /* returns 0 ok, 1 audio mismatch, 2 the frame does not decode */
-static int verify_frame(const vjob *J, uint32_t f, int32_t *x /* [C][N] */, int32_t *r, flacgpu_host_verify_result *out)
+static int verify_frame(const vjob *J, uint32_t f, int64_t *x /* [C][N] */, int32_t *r, flacgpu_host_verify_result *out)
 {
 	const flacgpu_host_settings *s = J->s;
 	const uint32_t C = s->channels, N = s->blocksize, bps = s->bits_per_sample;
@@ -150,7 +158,7 @@ static int verify_frame(const vjob *J, uint32_t f, int32_t *x /* [C][N] */, int3
 	if((ca < 8 && ca + 1 != C) || ca > 10 || (ca >= 8 && C != 2)) return 2;
 
 	for(uint32_t ch = 0; ch < C; ch++) {
-		int32_t *xc = x + (size_t)ch * N;
+		int64_t *xc = x + (size_t)ch * N;
 		if(br_bits(&b, 1) != 0) return 2;
 		const uint32_t type = br_bits(&b, 6);
 		uint32_t wasted = 0;
@@ -158,30 +166,30 @@ static int verify_frame(const vjob *J, uint32_t f, int32_t *x /* [C][N] */, int3
 		const int side = (ca == 8 && ch == 1) || (ca == 9 && ch == 0) || (ca == 10 && ch == 1);
 		if(wasted >= bps + (side ? 1u : 0u)) return 2;
 		const uint32_t sb = bps - wasted + (side ? 1 : 0);
-		if(type == 0) { const int32_t v = br_sbits(&b, sb); for(uint32_t i = 0; i < n; i++) xc[i] = v; }
-		else if(type == 1) for(uint32_t i = 0; i < n; i++) xc[i] = br_sbits(&b, sb);
+		if(type == 0) { const int64_t v = br_sample(&b, sb); for(uint32_t i = 0; i < n; i++) xc[i] = v; }
+		else if(type == 1) for(uint32_t i = 0; i < n; i++) xc[i] = br_sample(&b, sb);
 		else if(type >= 8 && type <= 12) {
 			const uint32_t order = type - 8;
 			if(order > n) return 2;
-			for(uint32_t i = 0; i < order; i++) xc[i] = br_sbits(&b, sb);
+			for(uint32_t i = 0; i < order; i++) xc[i] = br_sample(&b, sb);
 			if(!read_residual(&b, r, n, order)) return 2;
 			for(uint32_t i = order; i < n; i++) {           /* fixed.c:571: the predictors are binomial FIRs */
 				int64_t pr;
 				switch(order) {
 					case 0: pr = 0; break;
 					case 1: pr = xc[i - 1]; break;
-					case 2: pr = 2 * (int64_t)xc[i - 1] - xc[i - 2]; break;
-					case 3: pr = 3 * (int64_t)xc[i - 1] - 3 * (int64_t)xc[i - 2] + xc[i - 3]; break;
-					default: pr = 4 * (int64_t)xc[i - 1] - 6 * (int64_t)xc[i - 2] + 4 * (int64_t)xc[i - 3] - xc[i - 4]; break;
+					case 2: pr = 2 * xc[i - 1] - xc[i - 2]; break;
+					case 3: pr = 3 * xc[i - 1] - 3 * xc[i - 2] + xc[i - 3]; break;
+					default: pr = 4 * xc[i - 1] - 6 * xc[i - 2] + 4 * xc[i - 3] - xc[i - 4]; break;
 				}
-				xc[i] = (int32_t)(r[i - order] + pr);
+				xc[i] = (int64_t)r[i - order] + pr;
 			}
 		}
 		else if(type >= 32) {
 			const uint32_t order = type - 31;
 			int32_t q[32];
 			if(order > n) return 2;
-			for(uint32_t i = 0; i < order; i++) xc[i] = br_sbits(&b, sb);
+			for(uint32_t i = 0; i < order; i++) xc[i] = br_sample(&b, sb);
 			const uint32_t prec = br_bits(&b, 4) + 1;
 			if(prec == 16) return 2;
 			const int32_t shift = br_sbits(&b, 5);
@@ -191,12 +199,12 @@ static int verify_frame(const vjob *J, uint32_t f, int32_t *x /* [C][N] */, int3
 			for(uint32_t i = order; i < n; i++) {           /* lpc.c:978 */
 				int64_t sum = 0;
 				for(uint32_t j = 0; j < order; j++) sum += (int64_t)q[j] * xc[i - 1 - j];
-				xc[i] = (int32_t)(r[i - order] + (sum >> shift));
+				xc[i] = (int64_t)r[i - order] + (sum >> shift);
 			}
 		}
 		else return 2;
 		if(b.bad) return 2;
-		if(wasted) for(uint32_t i = 0; i < n; i++) xc[i] = (int32_t)((uint32_t)xc[i] << wasted);
+		if(wasted) for(uint32_t i = 0; i < n; i++) xc[i] = (int64_t)((uint64_t)xc[i] << wasted);
 	}
 	/* zero padding up to the byte boundary, and nothing but the CRC behind it */
 	{
@@ -208,15 +216,15 @@ static int verify_frame(const vjob *J, uint32_t f, int32_t *x /* [C][N] */, int3
 	if(ca == 8) for(uint32_t i = 0; i < n; i++) x[N + i] = x[i] - x[N + i];
 	else if(ca == 9) for(uint32_t i = 0; i < n; i++) x[i] += x[N + i];
 	else if(ca == 10) for(uint32_t i = 0; i < n; i++) {
-		const int32_t sd = x[N + i];
-		const int32_t mid = (int32_t)(((uint32_t)x[i] << 1) | ((uint32_t)sd & 1));
+		const int64_t sd = x[N + i];
+		const int64_t mid = (int64_t)(((uint64_t)x[i] << 1) | ((uint64_t)sd & 1));
 		x[i] = (mid + sd) >> 1; x[N + i] = (mid - sd) >> 1;
 	}
 	for(uint32_t i = 0; i < n; i++)
 		for(uint32_t ch = 0; ch < C; ch++) {
 			const int32_t want = expected_sample(J->raw, J->width, ((size_t)f * N + i) * C + ch);
-			if(x[(size_t)ch * N + i] != want) {
-				out->absolute_sample += i; out->channel = ch; out->sample = i; out->expected = want; out->got = x[(size_t)ch * N + i];
+			if(x[(size_t)ch * N + i] != (int64_t)want) {
+				out->absolute_sample += i; out->channel = ch; out->sample = i; out->expected = want; out->got = (int32_t)x[(size_t)ch * N + i];
 				return 1;
 			}
 		}
@@ -227,12 +235,12 @@ static void *vthread(void *arg)
 {
 	vjob *J = arg;
 	const uint32_t C = J->s->channels, N = J->s->blocksize;
-	int32_t *x = malloc(sizeof(int32_t) * ((size_t)C + 1) * N);
+	int64_t *x = malloc(sizeof(int64_t) * ((size_t)C + 1) * N);
 	J->res.status = 0;
 	if(!x) { J->res.status = 2; J->res.frame_number = J->first_frame; return 0; }
 	for(uint32_t f = J->t; f < J->nframes; f += J->nthreads) {
 		flacgpu_host_verify_result r;
-		const int st = verify_frame(J, f, x, x + (size_t)C * N, &r);
+		const int st = verify_frame(J, f, x, (int32_t *)(x + (size_t)C * N), &r);
 		if(st) { r.status = st; J->res = r; break; }           /* frames are visited in increasing order: the first problem of this thread */
 	}
 	free(x);

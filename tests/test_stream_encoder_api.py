@@ -335,3 +335,15 @@ def test_coefficient_precisions_through_the_api(precision):
     for bps, rate in ((16, 44100), (24, 96000)):
         pcm = signals.music(4096 * 2 + 123, 2, bps, seed=precision)
         _same_file(pcm, bps, rate, 8, settings=(("set_qlp_coeff_precision", precision),))
+
+
+@gpu
+@needs_ref
+def test_wide_samples_and_high_orders_through_the_api():
+    """32-bit input (33-bit side channel, MD5 over 4-byte samples, verify on), 28-bit, and -l 32: whole files identical"""
+    lax = (("set_streamable_subset", 0),)
+    _same_file(signals.music(4096 * 3 + 50, 2, 32, seed=1), 32, 96000, 8, settings=(("set_verify", 1),), chunk=999)
+    _same_file(signals.fsd(4096 * 2 + 50, 2, 32, 3), 32, 48000, 5, settings=(("set_verify", 1),))
+    _same_file(signals.white(4096 * 2 + 50, 2, 28), 28, 48000, 5, settings=lax + (("set_verify", 1),), planar=True)
+    _same_file(signals.music(4096 * 2 + 50, 2, 16, seed=5), 16, 44100, 8, settings=lax + (("set_max_lpc_order", 32),))
+    _same_file(signals.music(4096 * 2 + 50, 1, 24, seed=6), 24, 96000, 5, settings=lax + (("set_max_lpc_order", 17), ("set_do_exhaustive_model_search", 1)))

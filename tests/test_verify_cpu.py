@@ -73,3 +73,19 @@ def test_reference_frames_verify_with_escape_free_rice2():
     frames = r["data"][r["header_bytes"]:]
     st, res = _verify(pcm, 24, 96000, 5, frames, r["frame_bytes"])
     assert st == 0
+
+
+@pytest.mark.parametrize("bps", [25, 28, 32])
+def test_wide_sample_frames_verify(bps):
+    """more than 24 bits per sample; at 32 the side channel is read back as 33-bit samples"""
+    for fam, ch in (("music", 2), ("white", 2), ("square", 2), ("wasted", 2), ("music", 1)):
+        for level in (0, 2, 5, 8):
+            pcm = signals.FAMILIES[fam](4096 * 2 + 321, ch, bps)
+            o = po.oracle_encode(pcm, bps, 96000, level)
+            st, res = _verify(pcm, bps, 96000, level, o["data"], o["frame_bytes"], streamable_subset=0)
+            assert st == 0, (fam, ch, bps, level, res.status, res.frame_number)
+    for pattern in range(1, 8):
+        pcm = signals.fsd(4096 + 100, 2, bps, pattern)
+        o = po.oracle_encode(pcm, bps, 96000, 5)
+        st, res = _verify(pcm, bps, 96000, 5, o["data"], o["frame_bytes"], streamable_subset=0)
+        assert st == 0, (pattern, bps, res.status, res.frame_number)
