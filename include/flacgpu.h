@@ -57,7 +57,7 @@ typedef struct {
 typedef struct {
 	uint32_t abi_version;            /* FLACGPU_ABI_VERSION */
 	uint32_t channels;               /* 1..8 */
-	uint32_t bits_per_sample;        /* 4..24 */
+	uint32_t bits_per_sample;        /* 4..32 (at 32 the side channel has 33 bits, stream_encoder.c:3831-3835) */
 	uint32_t sample_rate;
 	uint32_t blocksize;              /* 16..16384 */
 	uint32_t do_mid_side_stereo;
