@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
 			dec->po = (uint8_t)best_po; dec->rice2 = (uint8_t)rice2; dec->precision = (uint8_t)best_precision;
 			dec->shift = (int8_t)best_shift; dec->which = (uint8_t)pr.which;
-			dec->constant = best_constant; dec->constant_hi = best_constant_hi;
+			dec->constant = best_constant; dec->constant_hi = best_constant_hi; dec->fmt = pr.fmt;
 		}
 	}
 	STAMP(5);

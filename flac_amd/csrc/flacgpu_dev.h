@@ -53,7 +53,8 @@ struct SubDecision {
 	int32_t q[MAX_ORDER];
 	uint8_t params[1u << MAX_PO];
 	int32_t constant_hi;       // bits 32.. of a 33-bit constant (sign extension otherwise)
-	uint32_t pad[3];
+	uint32_t fmt;              // ChanPrep::fmt of the channel: how its planar copy is stored
+	uint32_t pad[2];
 };
 
 struct Candidate {
@@ -91,7 +92,8 @@ struct ChanPrep {
 	uint32_t fixed_order;      // guessed fixed-predictor order
 	int32_t constant;          // sample value when PREP_CONSTANT
 	uint32_t verbatim_bits;    // size of the VERBATIM baseline (0xffffffff: disabled)
-	uint32_t fmt;              // planar channel copy: 1 = 16-bit pairs (sbps <= 16), 0 = 32-bit samples, 2 = 64-bit samples (sbps 33)
+	uint32_t fmt;              // planar channel copy: 1 = 16-bit pairs (every sample fits int16: sbps <= 16, or a quiet side
+	                           // channel), 0 = 32-bit samples, 2 = 64-bit samples (sbps 33)
 	int32_t constant_hi;       // bits 32.. of a 33-bit constant
 	uint32_t pad[2];
 };

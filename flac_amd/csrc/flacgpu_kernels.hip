@@ -310,7 +310,7 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 				const int64_t i = (int64_t)pass + k;
 				if(s64) { sig64[sigidx(k)] = (i >= 0 && i < (int64_t)n) ? ((const int64_t *)src)[i] : 0; continue; }
 				int32_t v = 0;
-				if(i >= 0 && i < (int64_t)n) v = sbps <= 16 ? (int32_t)((const int16_t *)src)[i] : (int32_t)src[i];
+				if(i >= 0 && i < (int64_t)n) v = d->fmt == 1 ? (int32_t)((const int16_t *)src)[i] : (int32_t)src[i];
 				sig[sigidx(k)] = v;
 			}
 			__syncthreads();
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 		const SubDecision *d = ldec + di;
 		const uint32_t which = d->which, type = d->type, order = d->order, wasted = d->wasted;
 		const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
-		const bool fmt16 = sbps <= 16;
+		const bool fmt16 = d->fmt == 1;            // 16-bit pairs: sbps <= 16, or a side channel whose samples all fit int16
 		const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + di) * N);
 		const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : type == 2 ? (0x10u | (order << 1)) : (0x40u | ((order - 1) << 1));
 		if(tid == 0) {
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 							// warm-up samples, verbatim (thread 0 of pass 0 holds them)
 							for(uint32_t i = 0; i < order; i++) {
 								const uint32_t wv = A[8 + i / 2];
-								or_bits(img, cap_words, warm_pos + i * sbps, ((i & 1) ? (wv >> 16) : wv) & smask, sbps);
+								or_bits(img, cap_words, warm_pos + i * sbps, (uint32_t)((i & 1) ? ((int32_t)wv >> 16) : (int32_t)(int16_t)(wv & 0xffffu)) & smask, sbps);
 							}
 						}
 						if(!wide) {

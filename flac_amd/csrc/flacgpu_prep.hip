@@ -24,6 +24,7 @@ namespace flacgpu {
 
 struct Prep2Acc {
 	uint32_t orv, diff;
+	uint32_t mag;              // OR of x ^ (x >> 31): every sample fits int16 iff (mag >> wasted) < 2^15
 	uint64_t e[5];
 };
 
@@ -38,7 +39,8 @@ __host__ __device__ inline uint32_t p2_chan_bytes(uint32_t n) { return CHUNK * p
 // Sums are taken on the UNSHIFTED signal: every |difference| is a multiple of 2^wasted, so the sums of the shifted
 // signal the reference computes (it shifts in place first) are these sums >> wasted, exactly.
 // |d_k[i]| = |d_(k-1)[i] - d_(k-1)[i-1]| is one v_sad_u32 on the sign-flipped (order preserving) operands.
-template <bool WIDE>
+// MAG: also collect Prep2Acc::mag (the side channel: 17 bits wide, but quiet enough for the packed 16-bit kernels most of the time)
+template <bool WIDE, bool MAG = false>
 __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_chunk, int32_t first, Prep2Acc &A)
 {
 	constexpr uint32_t M = 0x80000000u;
@@ -50,6 +52,7 @@ __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_c
 	for(int t = 0; t < CHUNK; t++) {
 		const int32_t a0 = x[t + 4];
 		A.orv |= (uint32_t)a0; A.diff |= (uint32_t)(a0 ^ first);
+		if(MAG) A.mag |= (uint32_t)(a0 ^ (a0 >> 31));
 		const uint32_t xb = (uint32_t)a0 ^ M;
 		const int32_t d1 = a0 - x[t + 3], d2 = d1 - d1p, d3 = d2 - d2p;
 		uint32_t t0 = sad_u32(xb, M, 0), t1 = sad_u32(xb, xbp, 0), t2 = sad_u32((uint32_t)d1 ^ M, (uint32_t)d1p ^ M, 0),
@@ -115,11 +118,12 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 		const int mode = !stereo_ms ? 0 : (int)which;                   // 0 take a, 1 take b, 2 mid, 3 side
 		const bool loose_here = P.ms_mode == 2 && wave == 0;
 		Prep2Acc A;
-		A.orv = 0; A.diff = 0;
+		A.orv = 0; A.diff = 0; A.mag = 0xffffffffu;
 #pragma unroll
 		for(int k = 0; k < 5; k++) A.e[k] = 0;
 		uint64_t lr_sum = 0, ms_sum = 0;
 		int32_t first = 0;
+		if(mode == 3) A.mag = 0;
 		if(active) {
 			{
 				const int32_t a = sa[1], b = sb[1];          // sample 0: row 0, column 1
@@ -151,10 +155,12 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 #pragma unroll
 					for(int k = 0; k < 20; k++) x[k] = mode == 0 ? a[k] : mode == 1 ? b[k] : mode == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
 				}
-				prep2_chunk<WIDE>(x, ch == 0, first, A);
+				if(mode == 3) prep2_chunk<WIDE, true>(x, ch == 0, first, A);
+				else prep2_chunk<WIDE>(x, ch == 0, first, A);
 			}
 			A.orv = wave_or_u32(A.orv);
 			A.diff = wave_or_u32(A.diff);
+			if(mode == 3) A.mag = wave_or_u32(A.mag);
 #pragma unroll
 			for(int k = 0; k < 5; k++) A.e[k] = wave_sum_u50(A.e[k]);
 		}
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 			const uint64_t es[5] = {e0, e1, e2, e3, e4};
 			if(emit_fixed_candidates(P, &cands[fcx * cstride], &valid[fcx * cstride], es, n4, guess_fixed, fixed_allowed, sbps, lane)) flags |= PREP_FIXED_VALID;
 		}
-		const uint32_t fmt = sbps <= 16 ? 1u : 0u;
+		const uint32_t fmt = (sbps <= 16 || (A.mag >> wasted) < 32768u) ? 1u : 0u;
 		const size_t fc = (size_t)f * P.ncand + cand;
 		if(lane == 0) {
 			ChanPrep pr;
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 // the workgroup meets only twice: to add up the four partial statistics and to learn the wasted bits before the planar
 // channels are written.
 struct Prep3Part {
-	uint32_t orv[4], diff[4];
+	uint32_t orv[4], diff[4], mag;
 	int32_t first[4];
 	uint64_t e[4][5];
 	uint64_t lr, ms;
@@ -331,17 +337,20 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 		for(int k = 0; k < 20; k++) x[k] = c == 0 ? a[k] : c == 1 ? b[k] : c == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
 		const int32_t first = __builtin_amdgcn_readfirstlane(x[4]);      // this quarter's first sample
 		Prep2Acc A;
-		A.orv = 0; A.diff = 0;
+		A.orv = 0; A.diff = 0; A.mag = 0;
 #pragma unroll
 		for(int k = 0; k < 5; k++) A.e[k] = 0;
-		prep2_chunk<WIDE>(x, first_chunk, first, A);
+		if(c == 3) prep2_chunk<WIDE, true>(x, first_chunk, first, A);
+		else prep2_chunk<WIDE>(x, first_chunk, first, A);
 		A.orv = wave_or_u32(A.orv);
 		A.diff = wave_or_u32(A.diff);
+		if(c == 3) A.mag = wave_or_u32(A.mag);
 #pragma unroll
 		for(int k = 0; k < 5; k++) A.e[k] = WIDE ? wave_sum_u50(A.e[k]) : (uint64_t)wave_sum_u32((uint32_t)A.e[k]);   // !WIDE: 2^30 at most
 		if(lane == 0) {
 			Prep3Part &pt = part[wave];
 			pt.orv[c] = A.orv; pt.diff[c] = A.diff; pt.first[c] = first;
+			if(c == 3) pt.mag = A.mag;
 #pragma unroll
 			for(int k = 0; k < 5; k++) pt.e[c][k] = A.e[k];
 		}
@@ -351,12 +360,12 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 	// ---- wavefront c decides channel c (every lane holds the totals) ----------------------------------------------------
 	{
 		const uint32_t c = wave, which = wave;                      // 0 left, 1 right, 2 mid, 3 side
-		uint32_t orv = 0, diff = 0;
+		uint32_t orv = 0, diff = 0, mag = 0;
 		uint64_t e[5] = {0, 0, 0, 0, 0}, lr = 0, ms = 0;
 		bool alleq0 = true;                                         // the LEFT channel is constant (limit_min_bitrate)
 		const int32_t f0 = part[0].first[c];
 		for(int w = 0; w < TPB / 64; w++) {
-			orv |= part[w].orv[c];
+			orv |= part[w].orv[c]; mag |= part[w].mag;
 			diff |= part[w].diff[c] | (uint32_t)(part[w].first[c] ^ f0);
 			for(int k = 0; k < 5; k++) e[k] += part[w].e[c][k];
 			lr += part[w].lr; ms += part[w].ms;
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 		uint32_t wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
 		if(wasted > P.bps) wasted = P.bps;
 		const uint32_t sbps = P.bps - wasted + (which == 3 ? 1 : 0);
-		const uint32_t fmt = sbps <= 16 ? 1u : 0u;
+		const uint32_t fmt = (sbps <= 16 || (which == 3 && (mag >> wasted) < 32768u)) ? 1u : 0u;
 		if(lane == 0) { outp.wasted[c] = wasted; outp.slot[c] = slot; outp.fmt[c] = fmt; }
 		if(slot >= 0) {
 			bool disable_constant = P.disable_constant != 0;
