@@ -239,6 +239,8 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		P.nprec = P.prec_search ? 11 : 1;
 		P.ncslots = P.nfixed + na * P.norders * P.nprec;
 	}
+	P.img_global = 0;
+	if(pack_lds_bytes(P) > 160 * 1024 - 1024) P.img_global = 1;            // many channels x long blocks: the frame is assembled in HBM
 	if(analyze_lds_bytes(P) > 160 * 1024 - 1024 || pack_lds_bytes(P) > 160 * 1024 - 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
 
 	bool ok = true;

@@ -40,6 +40,7 @@ struct DevParams {
 	// (stream_encoder.c:3831-3835) and is kept as 64-bit samples in HBM and LDS
 	uint32_t wide_samples;     // bps > 24
 	uint32_t chan_stride;      // 32-bit words per planar channel: blocksize, or 2 * blocksize when a 33-bit channel can occur
+	uint32_t img_global;       // the worst-case frame does not fit the LDS next to the pack kernel's state: it is assembled in its HBM slot
 };
 
 // analysis -> pack hand-off, one per (frame, candidate channel); 16-byte multiple

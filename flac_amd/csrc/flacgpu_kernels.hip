@@ -41,7 +41,7 @@ __device__ __forceinline__ void put_bits(uint32_t *buf, uint32_t cap_words, uint
 // byte chain), shifts its remainder past the whole spans behind it with a precomputed x^(512 m) mod P, and the
 // spans are xor-reduced: crc(A||B) = crc(A) * x^(8|B|) + crc(B) in GF(2)[x]/(x^16+x^15+x^2+1).
 constexpr uint32_t CRC_SPAN = 64;                       // bytes per span
-constexpr uint32_t CRC_MAX_SPANS = 160 * 1024 / 64;     // the frame image lives in LDS (< 160 KiB)
+constexpr uint32_t CRC_MAX_SPANS = 1024 * 1024 / 64;    // frames up to 1 MiB (8 channels x 16384 samples x 33 bits = 540 KiB)
 struct CrcTables { uint16_t tab[4][256]; uint16_t xspan[CRC_MAX_SPANS]; uint16_t xbyte[CRC_SPAN + 1]; };
 constexpr uint32_t crc_mulx(uint32_t c) { return (c & 0x8000u) ? ((c << 1) ^ 0x8005u) & 0xffffu : (c << 1) & 0xffffu; }
 constexpr uint32_t crc_mulx8(uint32_t c) { for(int b = 0; b < 8; b++) c = crc_mulx(c); return c; }
@@ -151,8 +151,13 @@ __device__ uint32_t frame_header_bytes(const DevParams &P, uint32_t n, uint32_t 
 }
 
 // CRC-16 of the first body_bytes of the frame image (see above); result valid in thread 0.  Ends with a barrier.
+// a word of the frame image; an image in HBM was built with atomics at the L2, so the read must not be served by this CU's L1
+__device__ __forceinline__ uint32_t img_word(const uint32_t *img, uint32_t w, bool global_img)
+{
+	return global_img ? __hip_atomic_load(img + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : img[w];
+}
 __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const uint16_t (*crc_tab)[256], uint32_t *crc_parts, int tid,
-                                const uint16_t *xspan_lds = nullptr, uint32_t nxspan_lds = 0, const uint16_t *xbyte_lds = nullptr)
+                                const uint16_t *xspan_lds = nullptr, uint32_t nxspan_lds = 0, const uint16_t *xbyte_lds = nullptr, bool global_img = false)
 {
 	// spans of 64 bytes; the last (possibly short) span is followed by nothing, span s by nsp-1-s whole or short spans
 	const uint32_t nsp = (body_bytes + CRC_SPAN - 1) / CRC_SPAN;
@@ -164,7 +169,7 @@ __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const 
 		if(sp + 1 < nsp) {
 #pragma unroll
 			for(int k = 0; k < (int)(CRC_SPAN / 4); k++) {
-				const uint32_t v = (cs << 16) ^ wp[k];
+				const uint32_t v = (cs << 16) ^ img_word(wp, (uint32_t)k, global_img);
 				cs = (uint32_t)crc_tab[3][v >> 24] ^ crc_tab[2][(v >> 16) & 0xffu] ^ crc_tab[1][(v >> 8) & 0xffu] ^ crc_tab[0][v & 0xffu];
 			}
 			// behind this span: nsp-2-sp whole spans and the last one
@@ -174,7 +179,7 @@ __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const 
 		}
 		else {
 			for(uint32_t k = 0; k < last_len; k++) {
-				const uint32_t b = (wp[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu;
+				const uint32_t b = (img_word(wp, k >> 2, global_img) >> (24 - 8 * (k & 3))) & 0xffu;
 				cs = ((cs << 8) & 0xffffu) ^ crc_tab[0][(cs >> 8) ^ b];
 			}
 		}
@@ -250,8 +255,10 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	// LDS: the samples of ONE pass (4096 samples + 32 in front, 18-word rows) | frame image | small state
 	int32_t *sig = (int32_t *)smem;
 	const uint32_t sigb = pack_pass_sig_bytes(P);
-	uint32_t *img = (uint32_t *)(smem + sigb);
-	PackShared *sh = (PackShared *)(smem + sigb + P.slot_bytes);
+	// (frames too large for the LDS are assembled in place in their HBM slot: same code, atomics at the L2)
+	const bool gimg = P.img_global != 0;
+	uint32_t *img = gimg ? (uint32_t *)(slots + (size_t)f * P.slot_bytes) : (uint32_t *)(smem + sigb);
+	PackShared *sh = (PackShared *)(smem + sigb + (gimg ? 0 : P.slot_bytes));
 	const uint32_t cap_words = P.slot_bytes / 4;
 
 	for(uint32_t w = (uint32_t)tid; w < cap_words; w += TPB) img[w] = 0;
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	if(total_bytes > P.slot_bytes) { if(tid == 0) { sh->overflow = 1; } }
 	__syncthreads();
 	{
-		const uint32_t crc = frame_crc16(img, body_bytes, sh->crc_tab, sh->crc_parts, tid);
+		const uint32_t crc = frame_crc16(img, body_bytes, sh->crc_tab, sh->crc_parts, tid, nullptr, 0, nullptr, gimg);
 		if(tid == 0) put_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
 	}
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 	{
 		uint32_t *dst = (uint32_t *)(slots + (size_t)f * P.slot_bytes);
 		const uint32_t words = (umin32(total_bytes, P.slot_bytes) + 3) >> 2;
-		for(uint32_t w = (uint32_t)tid; w < words; w += TPB) dst[w] = __builtin_bswap32(img[w]);
+		for(uint32_t w = (uint32_t)tid; w < words; w += TPB) dst[w] = __builtin_bswap32(img_word(img, w, gimg));      // (in place when the image is the slot)
 		if(tid == 0) {
 			frame_bytes[f] = sh->overflow ? 0xffffffffu : total_bytes;
 			if(info) info[f].channel_assignment = (uint8_t)ca;
@@ -901,7 +908,7 @@ using namespace flacgpu;
 static bool pack2_applicable(const DevParams &P)
 {
 	const uint32_t ps = P.blocksize >> P.max_po;
-	return P.blocksize % CHUNK == 0 && ps >= (uint32_t)CHUNK && ps % CHUNK == 0 && ((size_t)ps << P.max_po) == P.blocksize && !P.wide_samples;
+	return P.blocksize % CHUNK == 0 && ps >= (uint32_t)CHUNK && ps % CHUNK == 0 && ((size_t)ps << P.max_po) == P.blocksize && !P.wide_samples && !P.img_global;
 }
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
@@ -929,6 +936,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 namespace flacgpu {
 size_t pack_lds_bytes(const DevParams &P)
 {
+	if(P.img_global) return (size_t)pack_pass_sig_bytes(P) + sizeof(PackShared);
 	const size_t a = (size_t)pack_pass_sig_bytes(P) + P.slot_bytes + sizeof(PackShared), b = (size_t)P.slot_bytes + 16 + sizeof(Pack2Shared);
 	return a > b ? a : b;
 }

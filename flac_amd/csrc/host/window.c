@@ -26,19 +26,23 @@ static void w_bartlett_hann(float *w, int32_t L) /* window.c:70 */
 {
 	const int32_t N = L - 1;
 	for(int32_t n = 0; n < L; n++)
-		w[n] = (float)(0.62f - 0.48f * fabsf((float)n / (float)N - 0.5f) - 0.38f * cosf(2.0f * M_PI * ((float)n / (float)N)));
+		w[n] = (float)((0.62f - 0.38f * cosf(2.0f * M_PI * ((float)n / (float)N))) - 0.48f * fabsf((float)n / (float)N - 0.5f));   /* as regrouped by the reference's build, see below */
 }
-/* generalised cosine-sum windows: a0 - a1 cos(2 pi n/N) + a2 cos(4 pi n/N) - a3 cos(6 pi n/N) + a4 cos(8 pi n/N) */
+/* generalised cosine-sum windows: a0 - a1 cos(2 pi n/N) + a2 cos(4 pi n/N) - a3 cos(6 pi n/N) + a4 cos(8 pi n/N).
+ * The reference is built with -fassociative-math (configure.ac / CMakeLists.txt), and its compiler regroups the terms:
+ * positive and negative ones are summed separately -- (a0 + a2 c2) - (a1 c1 + a3 c3), and for the five terms of flattop
+ * a0 + ((a2 c2 + a4 c4) - (a1 c1 + a3 c3)).  This file is compiled strictly, so the grouping is written out; the tables
+ * are compared bit for bit with the reference's in tests/test_oracle_vs_ref.py::test_host_window_tables_bit_exact. */
 static void w_blackman(float *w, int32_t L) /* window.c:79 */
 {
 	const int32_t N = L - 1;
-	for(int32_t n = 0; n < L; n++) w[n] = (float)(0.42f - 0.5f * cosf(2.0f * M_PI * n / N) + 0.08f * cosf(4.0f * M_PI * n / N));
+	for(int32_t n = 0; n < L; n++) w[n] = (float)((0.42f + 0.08f * cosf(4.0f * M_PI * n / N)) - 0.5f * cosf(2.0f * M_PI * n / N));
 }
 static void w_blackman_harris(float *w, int32_t L) /* window.c:89 */
 {
 	const int32_t N = L - 1;
 	for(int32_t n = 0; n <= N; n++)
-		w[n] = (float)(0.35875f - 0.48829f * cosf(2.0f * M_PI * n / N) + 0.14128f * cosf(4.0f * M_PI * n / N) - 0.01168f * cosf(6.0f * M_PI * n / N));
+		w[n] = (float)((0.35875f + 0.14128f * cosf(4.0f * M_PI * n / N)) - (0.48829f * cosf(2.0f * M_PI * n / N) + 0.01168f * cosf(6.0f * M_PI * n / N)));
 }
 static void w_connes(float *w, int32_t L) /* window.c:98 */
 {
@@ -54,7 +58,7 @@ static void w_flattop(float *w, int32_t L) /* window.c:111 */
 {
 	const int32_t N = L - 1;
 	for(int32_t n = 0; n < L; n++)
-		w[n] = (float)(0.21557895f - 0.41663158f * cosf(2.0f * M_PI * n / N) + 0.277263158f * cosf(4.0f * M_PI * n / N) - 0.083578947f * cosf(6.0f * M_PI * n / N) + 0.006947368f * cosf(8.0f * M_PI * n / N));
+		w[n] = (float)(0.21557895f + ((0.277263158f * cosf(4.0f * M_PI * n / N) + 0.006947368f * cosf(8.0f * M_PI * n / N)) - (0.41663158f * cosf(2.0f * M_PI * n / N) + 0.083578947f * cosf(6.0f * M_PI * n / N))));
 }
 static void w_gauss(float *w, int32_t L, float stddev) /* window.c:120 */
 {
@@ -80,13 +84,13 @@ static void w_kaiser_bessel(float *w, int32_t L) /* window.c:156 */
 {
 	const int32_t N = L - 1;
 	for(int32_t n = 0; n < L; n++)
-		w[n] = (float)(0.402f - 0.498f * cosf(2.0f * M_PI * n / N) + 0.098f * cosf(4.0f * M_PI * n / N) - 0.001f * cosf(6.0f * M_PI * n / N));
+		w[n] = (float)((0.402f + 0.098f * cosf(4.0f * M_PI * n / N)) - (0.498f * cosf(2.0f * M_PI * n / N) + 0.001f * cosf(6.0f * M_PI * n / N)));
 }
 static void w_nuttall(float *w, int32_t L) /* window.c:165 */
 {
 	const int32_t N = L - 1;
 	for(int32_t n = 0; n < L; n++)
-		w[n] = (float)(0.3635819f - 0.4891775f * cosf(2.0f * M_PI * n / N) + 0.1365995f * cosf(4.0f * M_PI * n / N) - 0.0106411f * cosf(6.0f * M_PI * n / N));
+		w[n] = (float)((0.3635819f + 0.1365995f * cosf(4.0f * M_PI * n / N)) - (0.4891775f * cosf(2.0f * M_PI * n / N) + 0.0106411f * cosf(6.0f * M_PI * n / N)));
 }
 static void w_triangle(float *w, int32_t L) /* window.c:182 */
 {

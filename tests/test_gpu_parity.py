@@ -421,3 +421,86 @@ def test_overflow_checked_residual_at_24_bits(kind):
             data, fb = _gpu_encode(pcm, bps, 96000, level, streamable_subset=0, max_batch=8, **kw)
             o = po.oracle_encode(pcm, bps, 96000, level, **kw)
             assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (kind, bps, level, kw)
+
+
+def _random_config(rng):
+    """one legal encoder configuration + signal, drawn over the whole range the engine accepts"""
+    bps = int(rng.choice([8, 12, 16, 16, 16, 20, 24, 24, 32, int(rng.integers(4, 33))]))
+    ch = int(rng.choice([1, 2, 2, 2, 3, 6, 8]))
+    blocksize = int(rng.choice([16, 17, 64, 192, 576, 1000, 1152, 2304, 4096, 4096, 4096, 4608, 8192, 16384, int(rng.integers(16, 5000))]))
+    lpc = int(rng.choice([0, 1, 4, 6, 8, 12, 12, 15, 16, 20, 32, int(rng.integers(0, 33))]))
+    lpc = min(lpc, blocksize)
+    kw = dict(blocksize=blocksize, max_lpc_order=lpc, streamable_subset=0)
+    kw["max_partition_order"] = int(rng.integers(0, 9))
+    kw["min_partition_order"] = int(rng.integers(0, kw["max_partition_order"] + 1))
+    if ch == 2:
+        kw["mid_side"] = int(rng.integers(0, 2))
+        kw["loose_mid_side"] = int(rng.integers(0, 2)) if kw["mid_side"] else 0
+    if lpc:
+        kw["qlp_coeff_precision"] = int(rng.choice([0, 0, 5, 9, 12, 15]))
+        if kw["qlp_coeff_precision"] == 0:
+            del kw["qlp_coeff_precision"]
+        kw["apodization"] = str(rng.choice(["tukey(0.5)", "subdivide_tukey(2)", "subdivide_tukey(3)", "hann;partial_tukey(2)", "welch;punchout_tukey(3/0.2)",
+                                            "gauss(0.3)", "blackman;flattop", "subdivide_tukey(4/0.3)"]))
+        kw["exhaustive"] = int(rng.random() < 0.25)
+        kw["prec_search"] = int(rng.random() < 0.15)
+    kw["limit_min_bitrate"] = int(rng.random() < 0.2)
+    kw["disable"] = tuple(int(rng.random() < 0.15) for _ in range(3))
+    fam = str(rng.choice(["music", "white", "sine", "mixed", "wasted", "square", "quiet", "constant", "silence"]))
+    nframes = 1 + int(rng.integers(0, 3))
+    n = blocksize * nframes + int(rng.integers(0, blocksize))
+    n = max(n, 1)
+    if blocksize >= 8192 and (kw.get("exhaustive") or kw.get("prec_search")):
+        n = min(n, blocksize + 100)
+    rate = int(rng.choice([8000, 22050, 44100, 48000, 96000, 192000, 12345]))
+    return fam, n, ch, bps, rate, kw
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configurations(seed):
+    """seeded sweep over the configuration space (block size, width, channels, orders, partition orders, apodizations,
+    searches, disable switches, short last blocks): GPU == oracle driven by the same resolved settings"""
+    import flac_amd
+    from oracle_from_settings import oracle_encode_settings
+    rng = np.random.default_rng(1000 + seed)
+    done = 0
+    for _ in range(14):
+        fam, n, ch, bps, rate, kw = _random_config(rng)
+        pcm = signals.FAMILIES[fam](n, ch, bps)
+        try:
+            s = flac_amd.make_settings(ch, bps, rate, 5, **kw)
+        except flac_amd.FlacGpuError:
+            continue                                   # the reference's init would refuse this combination, too
+        try:
+            eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=8)
+        except flac_amd.FlacGpuError as e:
+            assert "UNSUPPORTED" in str(e).upper() or "unsupported" in str(e), (str(e), kw)
+            continue
+        try:
+            data, fb = eng.encode(pcm)
+        finally:
+            eng.close()
+        o = oracle_encode_settings(pcm, s)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (fam, n, ch, bps, rate, kw)
+        done += 1
+    assert done >= 6
+
+
+@pytest.mark.parametrize("ch,bps,blocksize", [(6, 16, 16384), (8, 24, 16384), (8, 32, 8192), (3, 20, 16384)])
+def test_frames_larger_than_the_lds(ch, bps, blocksize):
+    """many channels x long blocks: the frame image is assembled in its HBM slot instead of the LDS"""
+    for fam, level in (("music", 5), ("white", 8), ("mixed", 2)):
+        pcm = signals.FAMILIES[fam](blocksize * 2 + 1234, ch, bps)
+        data, fb = _gpu_encode(pcm, bps, 96000, level, blocksize=blocksize, streamable_subset=0, max_batch=4)
+        o = po.oracle_encode(pcm, bps, 96000, level, blocksize=blocksize)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (ch, bps, blocksize, fam, level)
+
+
+def test_longest_block_widest_search():
+    """test/test_streams.sh:268: -b 16384 -m -r 8 -l 32 --lax -e -p"""
+    for fam, ch in (("sine", 1), ("music", 2)):
+        pcm = signals.FAMILIES[fam](16384 + 500, ch, 16)
+        kw = dict(blocksize=16384, max_lpc_order=32, exhaustive=1, prec_search=1)
+        data, fb = _gpu_encode(pcm, 16, 44100, 5, mid_side=1, loose_mid_side=0, max_partition_order=8, streamable_subset=0, max_batch=2, **kw)
+        o = po.oracle_encode(pcm, 16, 44100, 5, mid_side=1, loose=0, max_po=8, **kw)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (fam, ch)

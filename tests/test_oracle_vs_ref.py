@@ -325,3 +325,49 @@ def test_overflow_checked_residual_at_24_bits(ref, kind):
             r = po.ref_encode(pcm, bps, 96000, level, streamable_subset=0, **kw)
             o = po.oracle_encode(pcm, bps, 96000, level, **kw)
             assert o["data"] == _frames(r), (kind, bps, level, kw)
+
+
+ALL_WINDOW_SPECS = [("bartlett", "bartlett", ()), ("bartlett_hann", "bartlett_hann", ()), ("blackman", "blackman", ()),
+                    ("blackman_harris_4term_92db", "blackman_harris_4term_92db_sidelobe", ()), ("connes", "connes", ()),
+                    ("flattop", "flattop", ()), ("gauss(0.3)", "gauss", (0.3,)), ("gauss(0.05)", "gauss", (0.05,)), ("hamming", "hamming", ()),
+                    ("hann", "hann", ()), ("kaiser_bessel", "kaiser_bessel", ()), ("nuttall", "nuttall", ()), ("rectangle", "rectangle", ()),
+                    ("triangle", "triangle", ()), ("tukey(0.5)", "tukey", (0.5,)), ("tukey(0.03)", "tukey", (0.03,)), ("welch", "welch", ()),
+                    ("partial_tukey(3/0.3/0.5)", None, ()), ("punchout_tukey(2/0.2/0.4)", None, ())]
+
+
+@pytest.mark.parametrize("spec,fn,args", ALL_WINDOW_SPECS, ids=[s[0] for s in ALL_WINDOW_SPECS])
+def test_host_window_tables_bit_exact(ref, spec, fn, args):
+    """flac_amd/csrc/host/window.c against the reference's compiled window.c, table by table and bit for bit (the
+    reference's build regroups the cosine sums: -fassociative-math)"""
+    lib = po.load_ref()
+    for L in (4096, 2206, 1152, 333, 33, 17, 16):
+        s = engine.make_settings(2, 16, 44100, 5, apodization=spec, blocksize=4096)
+        w = engine.host_windows(s, L)
+        if fn is not None:
+            want = np.zeros(L, dtype=np.float32)
+            f = getattr(lib, "FLAC__window_" + fn)
+            f.restype = None
+            f.argtypes = [C.c_void_p, C.c_int32] + [C.c_float] * len(args)
+            f(want.ctypes.data, L, *[C.c_float(a) for a in args])
+            assert np.array_equal(w[0].view(np.uint32), want.view(np.uint32)), (spec, L)
+        else:
+            # the multi-window specs expand into several partial / punch-out tukey windows (stream_encoder.c:1973-2030)
+            kind, rest = spec.split("(")
+            n, p_, _ = rest[:-1].split("/")[0], *rest[:-1].split("/")[1:]
+            n = int(n)
+            tukey_p = float(rest[:-1].split("/")[2]) if len(rest[:-1].split("/")) > 2 else 0.5
+            overlap = float(rest[:-1].split("/")[1])
+            overlap_units = 1.0 / (1.0 - overlap) - 1.0
+            f = getattr(lib, "FLAC__window_" + kind)
+            f.restype = None
+            f.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float]
+            k = 0
+            for m in range(n):
+                start = np.float32(m / (n + overlap_units))
+                end = np.float32((m + 1 + overlap_units) / (n + overlap_units))
+                if kind == "punchout_tukey":
+                    pass
+                want = np.zeros(L, dtype=np.float32)
+                f(want.ctypes.data, L, C.c_float(tukey_p), C.c_float(float(start)), C.c_float(float(end)))
+                assert np.array_equal(w[k].view(np.uint32), want.view(np.uint32)), (spec, L, m)
+                k += 1
