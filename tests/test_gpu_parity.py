@@ -456,7 +456,7 @@ def _random_config(rng):
     return fam, n, ch, bps, rate, kw
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FLACGPU_TEST_SEEDS", "40"))))
 def test_random_configurations(seed):
     """seeded sweep over the configuration space (block size, width, channels, orders, partition orders, apodizations,
     searches, disable switches, short last blocks): GPU == oracle driven by the same resolved settings"""

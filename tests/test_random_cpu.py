@@ -1,5 +1,7 @@
 """CPU: the seeded configuration sweep of test_gpu_parity.py::test_random_configurations, oracle (driven by the host layer's
 resolved settings and window tables) against the real reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,7 +11,7 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref not built")
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FLACGPU_TEST_SEEDS", "40"))))
 def test_random_configurations_oracle_vs_reference(seed):
     import flac_amd
     from oracle_from_settings import oracle_encode_settings
