@@ -47,4 +47,31 @@ for name, call in (("int32 host block (flacgpu_encode_batch)", lambda: lib.flacg
         assert r > 0
     dt = (time.perf_counter() - t0) / reps
     print("%-48s %7.2f ms per %d frames  %8.1f M samples/s (PCIe inclusive, D2H of the frames included)" % (name, dt * 1e3, NF, NF * N / dt / 1e6))
+
+# Two engines, two host threads: each call is synchronous on its own HIP stream (H2D copy -> kernels -> D2H copy), so two
+# callers overlap one another's copies and kernels -- the pipelined use of the ABI (a corpus encoder keeps two batches in flight).
+import threading  # noqa: E402
+eng2 = flac_amd.FrameEngine(flac_amd.make_settings(2, 16, 44100, 8), device=0, max_batch_frames=NF)
+out2_p = lib.flacgpu_alloc_pinned(cap)
+fb2 = np.empty(NF, dtype=np.uint32)
+p16b = pinned(raw)
+reps = 6
+
+
+def worker(e, src, outp, fbb):
+    for _ in range(reps):
+        r = lib.flacgpu_encode_batch_raw(e.ctx, src, C.byref(fmt), NF, 0, 0, None, outp, cap, fbb.ctypes.data)
+        assert r > 0
+
+
+worker(eng2, p16b, out2_p, fb2)
+t0 = time.perf_counter()
+ths = [threading.Thread(target=worker, args=a) for a in ((eng, p16, out_p, fb), (eng2, p16b, out2_p, fb2))]
+for t in ths:
+    t.start()
+for t in ths:
+    t.join()
+dt = (time.perf_counter() - t0) / (2 * reps)
+print("%-48s %7.2f ms per %d frames  %8.1f M samples/s (two engines, two host threads)" % ("16-bit file bytes, 2 batches in flight", dt * 1e3, NF, NF * N / dt / 1e6))
+eng2.close()
 eng.close()
