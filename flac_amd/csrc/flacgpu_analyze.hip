@@ -108,7 +108,23 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 	uint32_t wasted;
 	bool s64 = false;                                   // this channel keeps 64-bit samples (33 bits after the shift)
 	int64_t *sig64 = (int64_t *)smem;
-	if(P.bps == 32 && C == 2 && which == 3) {
+	const bool stream = P.stream_sig != 0;              // the block does not fit the LDS: every pass reads the PCM again
+	const bool side33 = P.bps == 32 && C == 2 && which == 3;
+	// unshifted sample i of this channel (stream mode)
+	auto RAW = [&](uint32_t i) -> int64_t {
+		if(C == 2) { const int2 lr = ((const int2 *)frame_pcm)[i]; return which == 0 ? (int64_t)lr.x : which == 1 ? (int64_t)lr.y : which == 2 ? (((int64_t)lr.x + (int64_t)lr.y) >> 1) : side64(lr); }
+		return (int64_t)pick_channel(frame_pcm, C, i, which);
+	};
+	if(stream) {
+		uint32_t olo = 0, ohi = 0;
+		for(uint32_t i = (uint32_t)tid; i < n; i += TPB) { const uint64_t v = (uint64_t)RAW(i); olo |= (uint32_t)v; ohi |= (uint32_t)(v >> 32); }
+		olo = block_reduce_or_u32(olo, scratch, tid);
+		ohi = block_reduce_or_u32(ohi, scratch, tid);
+		wasted = olo ? (uint32_t)(__ffs((int)olo) - 1) : (side33 ? (ohi ? 32u : 1u) : 0u);
+		if(wasted > P.bps) wasted = P.bps;
+		s64 = side33 && wasted == 0;
+	}
+	else if(side33) {
 		// side channel of a 32-bit stream: 33 bits; get_wasted_bits_wide_ (stream_encoder.c:5103), all-zero loses 1 bit
 		const int2 *p = (const int2 *)frame_pcm;
 		uint32_t olo = 0, ohi = 0;
@@ -141,14 +157,17 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 	const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
 	__syncthreads();
 	// sample i of the shifted channel, whatever its width
-	auto SV = [&](int i) -> int64_t { return s64 ? sig64[sigidx(i)] : (int64_t)sig[sigidx(i)]; };
+	auto SV = [&](int i) -> int64_t {
+		if(stream) return (i < 0 || (uint32_t)i >= n) ? 0 : (RAW((uint32_t)i) >> wasted);
+		return s64 ? sig64[sigidx(i)] : (int64_t)sig[sigidx(i)];
+	};
 	// planar copy of the shifted channel for the evaluation and pack kernels
 	const uint32_t fmt = s64 ? 2u : sbps <= 16 ? 1u : 0u;
 	{
 		int32_t *dst = chan + fc * (size_t)P.chan_stride;
-		if(fmt == 2) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) ((int64_t *)dst)[i] = sig64[sigidx((int)i)];
-		else if(fmt) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) ((uint16_t *)dst)[i] = (uint16_t)sig[sigidx((int)i)];
-		else for(uint32_t i = (uint32_t)tid; i < n; i += TPB) dst[i] = sig[sigidx((int)i)];
+		if(fmt == 2) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) ((int64_t *)dst)[i] = SV((int)i);
+		else if(fmt) for(uint32_t i = (uint32_t)tid; i < n; i += TPB) ((uint16_t *)dst)[i] = (uint16_t)SV((int)i);
+		else for(uint32_t i = (uint32_t)tid; i < n; i += TPB) dst[i] = (int32_t)SV((int)i);
 	}
 
 	uint32_t flags = 0, fixed_order = 0;
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 			for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * TPB) {
 				int32_t x[CHUNK + 4];
 #pragma unroll
-				for(int k = 0; k < CHUNK + 4; k++) x[k] = sig[sigidx((int)base - 4 + k)];
+				for(int k = 0; k < CHUNK + 4; k++) x[k] = stream ? (int32_t)SV((int)base - 4 + k) : sig[sigidx((int)base - 4 + k)];
 				uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
 #pragma unroll
 				for(int t = 0; t < CHUNK; t++) {
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 				for(uint32_t i = (uint32_t)tid; i < q; i += TPB) {
 					int64_t v[5];
 #pragma unroll
-					for(int j = 0; j < 5; j++) { const int m = (int)i - j; v[j] = sig[sigidx(4 + (m >= 0 ? start + m : hist + m))]; }
+					for(int j = 0; j < 5; j++) { const int m = (int)i - j; v[j] = SV(4 + (m >= 0 ? start + m : hist + m)); }
 					const int64_t d0 = v[0], d1 = v[0] - v[1], d2 = v[0] - 2 * v[1] + v[2], d3 = v[0] - 3 * v[1] + 3 * v[2] - v[3],
 					              d4 = v[0] - 4 * v[1] + 6 * v[2] - 4 * v[3] + v[4];
 					e0 += (uint64_t)(d0 < 0 ? -d0 : d0); e1 += (uint64_t)(d1 < 0 ? -d1 : d1); e2 += (uint64_t)(d2 < 0 ? -d2 : d2);
@@ -937,7 +956,7 @@ __host__ __device__ inline uint32_t owner_chan_bytes(uint32_t N, bool packed)
 	const uint32_t S = N / 64, w = (packed ? (S + OH) / 2 : S + OH) | 1u;
 	return (64 * w * 4 + (CHUNK + MAX_ORDER) * 4 + 15u) & ~15u;
 }
-__host__ __device__ inline bool owner_possible(const DevParams &P) { return P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH && P.max_lpc_order <= (uint32_t)OH && !P.wide_samples; }
+__host__ __device__ inline bool owner_possible(const DevParams &P) { return P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH && P.max_lpc_order <= (uint32_t)OH && !P.wide_samples && !P.stream_sig; }
 // candidate records are staged in LDS next to the channel image when there are few of them (every preset); the wide
 // searches (-e, -p: hundreds of slots per channel) read them from global memory and keep only the valid flags in LDS
 __host__ __device__ inline bool eval_cands_in_lds(const DevParams &P) { return P.ncslots <= 48; }
@@ -958,6 +977,7 @@ __host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t w
 	EvalLayout L;
 	uint32_t o = 0;
 	if(generic) o = cpw * (P.sig_bytes + eval_cand_bytes(P));
+	else if(!owner_possible(P)) o = 0;      // VARIANT 0 then only decides the channels that have no residual candidate: no image
 	else {
 		// the most demanding group of cpw consecutive candidate channels
 		const bool s_even = (P.blocksize / 64) % 2 == 0;
@@ -1114,6 +1134,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 					}
 				}
 			}
+			else if(P.stream_sig) { /* the candidates read the plane itself */ }
 			else if(srcfmt == 2) {
 				// 33-bit side channel: 64-bit samples, same row layout
 				int64_t *sig = (int64_t *)ctx;
@@ -1160,7 +1181,11 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 					int32_t q[MAXORD];
 #pragma unroll
 					for(int jj = 0; jj < MAXORD; jj++) q[jj] = cd->q[jj];
-					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, (const void *)ctx, E.pr.fmt == 2, n, order, q, cd->shift,
+					SigRef sref;
+					if(P.stream_sig) { sref.p = (const void *)(chan + (fc0 + c) * (size_t)P.chan_stride); sref.kind = 2; }
+					else { sref.p = (const void *)ctx; sref.kind = E.pr.fmt == 2 ? 1u : 0u; }
+					sref.fmt = E.pr.fmt; sref.n = n;
+					rbits = eval_candidate_wave<MAXORD>(wsums, kcw, sh->pob[wave], ktmp, sh->divtab, sref, n, order, q, cd->shift,
 					                                    cd->wide, sbps, P, frame_max_po, frame_min_po, &po, lane);
 				}
 				const uint32_t est = ci < P.nfixed ? sat_add_u32(hdr + order * sbps, rbits)
@@ -1298,6 +1323,7 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		const uint32_t lanes = nframes * P.ncand * P.max_analyses;
 		hipLaunchKernelGGL(model_kernel<MAXORD>, dim3((lanes + TPB - 1) / TPB), dim3(TPB), 0, s, P, nframes, tail_n, jtm, jtt, B.prep, B.autoc, B.cands, B.valid);
 	}
+	sync_debug("model", s);
 	if(pev) (void)hipEventRecord(pev[2], s);
 	uint32_t cpw, waves;
 	eval_shape(P, cpw, waves);
@@ -1319,9 +1345,20 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
 	if(!op || tail_n || P.max_po > 6)
 		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(gwaves * 64), lds_generic, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+	sync_debug("eval", s);
 	return hipGetLastError();
 }
 
+// FLACGPU_SYNC_DEBUG=1: wait for every kernel and name the one that faults (development aid)
+void sync_debug(const char *what, hipStream_t s)
+{
+	static int on = -1;
+	if(on < 0) on = getenv("FLACGPU_SYNC_DEBUG") ? 1 : 0;
+	if(!on) return;
+	fprintf(stderr, "[flacgpu] %s ...", what); fflush(stderr);
+	const hipError_t e = hipStreamSynchronize(s);
+	fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr);
+}
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin, uint32_t nframes, uint32_t tail_n,
                           const JobTable *jtm, const JobTable *jtt, const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
 {
@@ -1343,6 +1380,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 		if(f_lo < nframes)
 			hipLaunchKernelGGL(prep_kernel<0>, dim3((nframes - f_lo) * P.ncand), dim3(TPB), P.sig_bytes, s, P, pcm, nframes, tail_n, f_lo, B.prep, B.cands, B.valid, B.chan);
 	}
+	sync_debug("prep", s);
 	if(pev) (void)hipEventRecord(pev[0], s);
 	if(P.max_analyses) {
 		// frames of nominal length: the streaming kernel (flacgpu_autoc.hip); the short last block, and tiny blocks
@@ -1358,6 +1396,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 			hipLaunchKernelGGL(autoc_kernel<0>, dim3((items + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, P, pcm, win, tailwin, nframes, tail_n, f_lo, jtm, jtt, B.prep, B.autoc);
 		}
 	}
+	sync_debug("autoc", s);
 	if(pev) (void)hipEventRecord(pev[1], s);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
 	if(m <= 8) return launch_model_eval<8>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);

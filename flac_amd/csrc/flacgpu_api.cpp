@@ -170,7 +170,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	// ---- supported range (everything else is a documented, loud failure; no CPU fallback) ----
 	if(cfg->channels < 1 || cfg->channels > FLACGPU_MAX_CHANNELS) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->bits_per_sample < 4 || cfg->bits_per_sample > 32) return FLACGPU_ERR_UNSUPPORTED;
-	if(cfg->blocksize < 16 || cfg->blocksize > 16384) return FLACGPU_ERR_UNSUPPORTED;
+	if(cfg->blocksize < 16 || cfg->blocksize > 65535) return FLACGPU_ERR_UNSUPPORTED;          // FLAC__MAX_BLOCK_SIZE
 	if(cfg->max_lpc_order > (uint32_t)MAX_ORDER) return FLACGPU_ERR_UNSUPPORTED;       // FLAC__MAX_LPC_ORDER
 	if(cfg->max_lpc_order > 0 && (cfg->qlp_coeff_precision < 5 || cfg->qlp_coeff_precision > 15)) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->max_residual_partition_order > MAX_PO) return FLACGPU_ERR_UNSUPPORTED;
@@ -239,8 +239,10 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		P.nprec = P.prec_search ? 11 : 1;
 		P.ncslots = P.nfixed + na * P.norders * P.nprec;
 	}
-	P.img_global = 0;
+	P.img_global = 0; P.stream_sig = 0;
+	if(N > 16384 || analyze_lds_bytes(P) > 160 * 1024 - 1024) { P.stream_sig = 1; P.sig_bytes = 0; }     // the block does not fit the LDS: the general kernels read HBM
 	if(pack_lds_bytes(P) > 160 * 1024 - 1024) P.img_global = 1;            // many channels x long blocks: the frame is assembled in HBM
+	if((uint64_t)P.slot_bytes > (uint64_t)4 * 1024 * 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }      // CRC span table (flacgpu_kernels.hip)
 	if(analyze_lds_bytes(P) > 160 * 1024 - 1024 || pack_lds_bytes(P) > 160 * 1024 - 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
 
 	bool ok = true;

@@ -41,6 +41,8 @@ struct DevParams {
 	uint32_t wide_samples;     // bps > 24
 	uint32_t chan_stride;      // 32-bit words per planar channel: blocksize, or 2 * blocksize when a 33-bit channel can occur
 	uint32_t img_global;       // the worst-case frame does not fit the LDS next to the pack kernel's state: it is assembled in its HBM slot
+	uint32_t stream_sig;       // a block does not fit the LDS (more than 16384 samples, or 16384 64-bit ones): the general prep and
+	                           // evaluation kernels read the samples from HBM instead of an LDS copy (sig_bytes = 0)
 };
 
 // analysis -> pack hand-off, one per (frame, candidate channel); 16-byte multiple
@@ -115,6 +117,7 @@ struct FrameInfo {
 	uint8_t pad[3];
 };
 
+void sync_debug(const char *what, hipStream_t s);
 size_t analyze_lds_bytes(const DevParams &P);
 size_t pack_lds_bytes(const DevParams &P);
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,

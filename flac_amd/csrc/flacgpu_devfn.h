@@ -385,13 +385,14 @@ __device__ void load_signal(int32_t *sig, const int32_t *frame_pcm, uint32_t C, 
 // MODE 3: 64-bit accumulate, and the residual must lie in (INT32_MIN, INT32_MAX] (lpc.c:832; 64-bit samples lpc.c:886):
 //         returns true when a residual of a sample in [lo, hi) does not
 // ST: int32_t samples, or int64_t (the 33-bit side channel of a 32-bit stream; modes 2 and 3 only)
-template <int MAXORD, int MODE, typename ST>
-__device__ __forceinline__ bool fir_chunk(const ST *sig, int base, const int32_t *q, int shift, int32_t *r, uint32_t lo, uint32_t hi)
+// LOAD: sample i of the channel (0 in front of the block and behind it)
+template <int MAXORD, int MODE, typename ST, typename LOAD>
+__device__ __forceinline__ bool fir_chunk_core(LOAD load, int base, const int32_t *q, int shift, int32_t *r, uint32_t lo, uint32_t hi)
 {
 	ST x[MAXORD + CHUNK];
 	bool bad = false;
 #pragma unroll
-	for(int k = 0; k < MAXORD + CHUNK; k++) x[k] = sig[sigidx(base - MAXORD + k)];
+	for(int k = 0; k < MAXORD + CHUNK; k++) x[k] = (ST)load(base - MAXORD + k);
 #pragma unroll
 	for(int s = 0; s < CHUNK; s++) {
 		if(MODE >= 2) {
@@ -412,12 +413,38 @@ __device__ __forceinline__ bool fir_chunk(const ST *sig, int base, const int32_t
 	}
 	return bad;
 }
-
-// mode: 0..3 as above (wave-uniform); s64: the signal array holds 64-bit samples.  lo/hi: the samples the overflow
-// check of mode 3 looks at (predictor order .. block length).  Returns the mode-3 verdict (false otherwise).
-template <int MAXORD>
-__device__ __forceinline__ bool fir_chunk_dispatch(const void *sig, bool s64, int base, const int32_t *q, int shift, int mode, int32_t *r, uint32_t lo, uint32_t hi)
+template <int MAXORD, int MODE, typename ST>
+__device__ __forceinline__ bool fir_chunk(const ST *sig, int base, const int32_t *q, int shift, int32_t *r, uint32_t lo, uint32_t hi)
 {
+	return fir_chunk_core<MAXORD, MODE, ST>([&](int i) { return sig[sigidx(i)]; }, base, q, shift, r, lo, hi);
+}
+
+// Where a general kernel finds the samples of a channel: the padded LDS array (32- or 64-bit samples, sigidx layout), or --
+// blocks too long for the LDS -- the planar copy in HBM (ChanPrep::fmt), read through the caches
+struct SigRef {
+	const void *p;
+	uint32_t kind;      // 0: LDS int32, 1: LDS int64, 2: HBM plane
+	uint32_t fmt, n;    // kind 2: ChanPrep::fmt and the block length
+};
+__device__ __forceinline__ int64_t plane_sample(const SigRef S, int i)
+{
+	if(i < 0 || (uint32_t)i >= S.n) return 0;
+	return S.fmt == 1 ? (int64_t)((const int16_t *)S.p)[i] : S.fmt == 2 ? ((const int64_t *)S.p)[i] : (int64_t)((const int32_t *)S.p)[i];
+}
+
+// mode: 0..3 as above (wave-uniform).  lo/hi: the samples the overflow check of mode 3 looks at (predictor order ..
+// block length).  Returns the mode-3 verdict (false otherwise).
+template <int MAXORD>
+__device__ __forceinline__ bool fir_chunk_dispatch(const SigRef S, int base, const int32_t *q, int shift, int mode, int32_t *r, uint32_t lo, uint32_t hi)
+{
+	const void *sig = S.p;
+	const bool s64 = S.kind == 1;
+	if(S.kind == 2) {
+		auto ld = [&](int i) { return plane_sample(S, i); };
+		if(mode == 3) return fir_chunk_core<MAXORD, 3, int64_t>(ld, base, q, shift, r, lo, hi);
+		if(mode == 2 || S.fmt == 2) return fir_chunk_core<MAXORD, 2, int64_t>(ld, base, q, shift, r, lo, hi);
+		return fir_chunk_core<MAXORD, 1, int64_t>(ld, base, q, shift, r, lo, hi);       // (mode 0 and 1 give the same residuals)
+	}
 	if(s64) {
 		if(mode == 3) return fir_chunk<MAXORD, 3, int64_t>((const int64_t *)sig, base, q, shift, r, lo, hi);
 		return fir_chunk<MAXORD, 2, int64_t>((const int64_t *)sig, base, q, shift, r, lo, hi);
@@ -528,8 +555,8 @@ __device__ __forceinline__ uint32_t sat_add_u32(uint32_t est, uint32_t rbits)
 // stream_encoder.c:4701-5075).  Returns the estimated residual bits; Rice parameters of the best
 // partition order go to kout[0 .. 2^best_po).
 template <int MAXORD>
-__device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_t *pob, uint8_t *kout, const uint32_t *divtab,
-                                        const void *sig, bool s64, uint32_t n, uint32_t order, const int32_t *q, int shift, uint32_t wide,
+__device__ __forceinline__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_t *pob, uint8_t *kout, const uint32_t *divtab,
+                                        const SigRef sig /* by value: this function is not always inlined */, uint32_t n, uint32_t order, const int32_t *q, int shift, uint32_t wide,
                                         uint32_t sbps, const DevParams &P, uint32_t frame_max_po, uint32_t frame_min_po,
                                         uint32_t *best_po_out, int lane)
 {
@@ -555,54 +582,54 @@ __device__ uint32_t eval_candidate_wave(uint64_t *wsums, uint8_t *kcand, uint64_
 		for(uint32_t p = (uint32_t)lane; p < nparts; p += 64) wsums[p] = 0;
 		__builtin_amdgcn_wave_barrier();
 	}
-	if(direct) {
-		const uint32_t lp = 64u / g;                      // leaves per pass (power of two)
-		const uint32_t src = ((uint32_t)lane & (lp - 1)) * g, want = (uint32_t)lane / lp;
+	{
+		// one pass = 64 chunks, chunk `lane` of the pass to this lane; the FIR has a single call site (the kernel carries
+		// seven flavours of it), what happens to the 16 residuals depends on the partition geometry
+		const uint32_t lp = direct ? 64u / g : 1u;        // direct: leaves per pass (power of two)
+		const uint32_t src = direct ? ((uint32_t)lane & (lp - 1)) * g : 0u, want = direct ? (uint32_t)lane / lp : 0u;
 #pragma unroll 1
 		for(uint32_t pass = 0; pass * 64 < nchunks; pass++) {
 			const uint32_t base = (pass * 64 + (uint32_t)lane) * CHUNK;
-			uint64_t mine = 0;
-			if(base < n) {
-				int32_t r[CHUNK];
-				bad = fir_chunk_dispatch<MAXORD>(sig, s64, (int)base, qr, shift, fmode, r, order, n) || bad;
-				uint32_t acc32 = 0;
-				uint64_t acc64 = 0;
+			int32_t r[CHUNK];
+			const bool active = base < n;
+			if(active) bad = fir_chunk_dispatch<MAXORD>(sig, (int)base, qr, shift, fmode, r, order, n) || bad;
+			if(direct) {
+				uint64_t mine = 0;
+				if(active) {
+					uint32_t acc32 = 0;
+					uint64_t acc64 = 0;
+#pragma unroll
+					for(int s2 = 0; s2 < CHUNK; s2++) {
+						const uint32_t i = base + s2;
+						if(i >= order && i < n) {
+							const int32_t v = r[s2];
+							const uint32_t av = (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v);
+							if(narrow) acc32 += av; else acc64 += av;
+						}
+					}
+					mine = narrow ? (uint64_t)acc32 : acc64;
+				}
+				for(uint32_t m = 1; m < g; m <<= 1) mine += shfl_xor_u64(mine, (int)m);
+				// leaf p = pass*lp + lane/g sits in every lane of its group; lane L wants leaf L
+				const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, (int)src), hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), (int)src);
+				if(want == pass) vdirect = ((uint64_t)hi << 32) | lo;
+			}
+			else if(active) {
+				uint32_t part = base / psize, next = (part + 1) * psize;
+				uint64_t run = 0;
 #pragma unroll
 				for(int s2 = 0; s2 < CHUNK; s2++) {
 					const uint32_t i = base + s2;
-					if(i >= order && i < n) {
-						const int32_t v = r[s2];
-						const uint32_t av = (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v);
-						if(narrow) acc32 += av; else acc64 += av;
+					if(i == next) {
+						if(run) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
+						run = 0; part++; next += psize;
 					}
+					if(i >= order && i < n) { const int32_t v = r[s2]; run += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v); }
 				}
-				mine = narrow ? (uint64_t)acc32 : acc64;
+				if(run && part < nparts) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
 			}
-			for(uint32_t m = 1; m < g; m <<= 1) mine += shfl_xor_u64(mine, (int)m);
-			// leaf p = pass*lp + lane/g sits in every lane of its group; lane L wants leaf L
-			const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, (int)src), hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), (int)src);
-			if(want == pass) vdirect = ((uint64_t)hi << 32) | lo;
 		}
-		if((uint32_t)lane >= nparts) vdirect = 0;
-	}
-	else {
-		for(uint32_t cidx = (uint32_t)lane; cidx < nchunks; cidx += 64) {
-			const uint32_t base = cidx * CHUNK;
-			int32_t r[CHUNK];
-			bad = fir_chunk_dispatch<MAXORD>(sig, s64, (int)base, qr, shift, fmode, r, order, n) || bad;
-			uint32_t part = base / psize, next = (part + 1) * psize;
-			uint64_t run = 0;
-#pragma unroll
-			for(int s2 = 0; s2 < CHUNK; s2++) {
-				const uint32_t i = base + s2;
-				if(i == next) {
-					if(run) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
-					run = 0; part++; next += psize;
-				}
-				if(i >= order && i < n) { const int32_t v = r[s2]; run += (uint32_t)(v < 0 ? -(uint32_t)v : (uint32_t)v); }
-			}
-			if(run && part < nparts) atomicAdd((unsigned long long *)&wsums[part], (unsigned long long)run);
-		}
+		if(direct && (uint32_t)lane >= nparts) vdirect = 0;
 	}
 	uint32_t best_bits = 0, best_po = 0;
 	if(max_po <= 6) {

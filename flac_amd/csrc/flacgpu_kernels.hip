@@ -41,7 +41,7 @@ __device__ __forceinline__ void put_bits(uint32_t *buf, uint32_t cap_words, uint
 // byte chain), shifts its remainder past the whole spans behind it with a precomputed x^(512 m) mod P, and the
 // spans are xor-reduced: crc(A||B) = crc(A) * x^(8|B|) + crc(B) in GF(2)[x]/(x^16+x^15+x^2+1).
 constexpr uint32_t CRC_SPAN = 64;                       // bytes per span
-constexpr uint32_t CRC_MAX_SPANS = 1024 * 1024 / 64;    // frames up to 1 MiB (8 channels x 16384 samples x 33 bits = 540 KiB)
+constexpr uint32_t CRC_MAX_SPANS = 4 * 1024 * 1024 / 64;    // frames up to 4 MiB (8 channels x 65535 samples x 33 bits = 2.1 MiB)
 struct CrcTables { uint16_t tab[4][256]; uint16_t xspan[CRC_MAX_SPANS]; uint16_t xbyte[CRC_SPAN + 1]; };
 constexpr uint32_t crc_mulx(uint32_t c) { return (c & 0x8000u) ? ((c << 1) ^ 0x8005u) & 0xffffu : (c << 1) & 0xffffu; }
 constexpr uint32_t crc_mulx8(uint32_t c) { for(int b = 0; b < 8; b++) c = crc_mulx(c); return c; }
@@ -390,7 +390,8 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const DevParams P, const int3
 				stage_pass(pass);
 				if(pass == 0 && (uint32_t)tid < order) put_sample(img, cap_words, warm_pos + (uint32_t)tid * sbps, SV(tid), sbps);
 				if(base < n) {
-					(void)fir_chunk_dispatch<MAXORD>((const void *)smem, s64, (int)(CHUNK * (uint32_t)tid), q, shift, fir_mode(wide ? 1u : 0u, sbps), r, 0, 0);
+					const SigRef sref = {(const void *)smem, s64 ? 1u : 0u, 0u, 0u};
+					(void)fir_chunk_dispatch<MAXORD>(sref, (int)(CHUNK * (uint32_t)tid), q, shift, fir_mode(wide ? 1u : 0u, sbps), r, 0, 0);
 					uint32_t part = base / psize, next = (part + 1) * psize;
 					uint32_t k = sh->params[part];
 #pragma unroll
@@ -908,7 +909,7 @@ using namespace flacgpu;
 static bool pack2_applicable(const DevParams &P)
 {
 	const uint32_t ps = P.blocksize >> P.max_po;
-	return P.blocksize % CHUNK == 0 && ps >= (uint32_t)CHUNK && ps % CHUNK == 0 && ((size_t)ps << P.max_po) == P.blocksize && !P.wide_samples && !P.img_global;
+	return P.blocksize % CHUNK == 0 && ps >= (uint32_t)CHUNK && ps % CHUNK == 0 && ((size_t)ps << P.max_po) == P.blocksize && !P.wide_samples && !P.img_global && !P.stream_sig;
 }
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
@@ -930,6 +931,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 		}
 	}
 	if(f_lo < nframes) hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes - f_lo), dim3(TPB), lds, s, P, chan, nframes, tail_n, f_lo, first, dec, slots, fb, info);
+	sync_debug("pack", s);
 	return hipGetLastError();
 }
 

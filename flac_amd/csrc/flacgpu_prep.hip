@@ -448,7 +448,7 @@ bool prep3_applicable(const DevParams &P) { return P.channels == 2 && P.ms_mode 
 bool prep2_applicable(const DevParams &P)
 {
 	const uint32_t nraw = (P.channels == 2 && P.ms_mode != 0) ? 2u : (P.channels < 4 ? P.channels : 4u);
-	return P.blocksize % 16 == 0 && P.blocksize > 4 && (size_t)nraw * p2_chan_bytes(P.blocksize) <= 150 * 1024 && !P.wide_samples;
+	return P.blocksize % 16 == 0 && P.blocksize > 4 && (size_t)nraw * p2_chan_bytes(P.blocksize) <= 150 * 1024 && !P.wide_samples && !P.stream_sig;
 }
 
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s)

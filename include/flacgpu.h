@@ -59,7 +59,7 @@ typedef struct {
 	uint32_t channels;               /* 1..8 */
 	uint32_t bits_per_sample;        /* 4..32 (at 32 the side channel has 33 bits, stream_encoder.c:3831-3835) */
 	uint32_t sample_rate;
-	uint32_t blocksize;              /* 16..16384 */
+	uint32_t blocksize;              /* 16..65535 */
 	uint32_t do_mid_side_stereo;
 	uint32_t loose_mid_side_stereo;
 	uint32_t max_lpc_order;          /* 0..32; below 16 the FMA autocorrelation routines (stream_encoder.c:1058-1066), from 16 the C loop (lpc.c:133) */

@@ -427,7 +427,8 @@ def _random_config(rng):
     """one legal encoder configuration + signal, drawn over the whole range the engine accepts"""
     bps = int(rng.choice([8, 12, 16, 16, 16, 20, 24, 24, 32, int(rng.integers(4, 33))]))
     ch = int(rng.choice([1, 2, 2, 2, 3, 6, 8]))
-    blocksize = int(rng.choice([16, 17, 64, 192, 576, 1000, 1152, 2304, 4096, 4096, 4096, 4608, 8192, 16384, int(rng.integers(16, 5000))]))
+    blocksize = int(rng.choice([16, 17, 64, 192, 576, 1000, 1152, 2304, 4096, 4096, 4096, 4608, 8192, 16384, int(rng.integers(16, 5000)),
+                                int(rng.choice([16385, 32768, 65535, int(rng.integers(16385, 65536))]))]))
     lpc = int(rng.choice([0, 1, 4, 6, 8, 12, 12, 15, 16, 20, 32, int(rng.integers(0, 33))]))
     lpc = min(lpc, blocksize)
     kw = dict(blocksize=blocksize, max_lpc_order=lpc, streamable_subset=0)
@@ -452,6 +453,8 @@ def _random_config(rng):
     n = max(n, 1)
     if blocksize >= 8192 and (kw.get("exhaustive") or kw.get("prec_search")):
         n = min(n, blocksize + 100)
+    if blocksize > 16384:
+        n = min(n, blocksize + 1000)
     rate = int(rng.choice([8000, 22050, 44100, 48000, 96000, 192000, 12345]))
     return fam, n, ch, bps, rate, kw
 
@@ -471,12 +474,7 @@ def test_random_configurations(seed):
             s = flac_amd.make_settings(ch, bps, rate, 5, **kw)
         except flac_amd.FlacGpuError:
             continue                                   # the reference's init would refuse this combination, too
-        try:
-            eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=8)
-        except flac_amd.FlacGpuError as e:
-            # the documented, loud refusal: a 16384-sample block of 64-bit (33-bit side) samples does not fit the LDS
-            assert "supported range" in str(e) and kw["blocksize"] >= 8192 and bps == 32, (str(e), kw)
-            continue
+        eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=8)          # nothing make_settings accepts is refused
         try:
             data, fb = eng.encode(pcm)
         finally:
@@ -505,3 +503,16 @@ def test_longest_block_widest_search():
         data, fb = _gpu_encode(pcm, 16, 44100, 5, mid_side=1, loose_mid_side=0, max_partition_order=8, streamable_subset=0, max_batch=2, **kw)
         o = po.oracle_encode(pcm, 16, 44100, 5, mid_side=1, loose=0, max_po=8, **kw)
         assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (fam, ch)
+
+
+@pytest.mark.parametrize("blocksize", [16385, 20000, 32768, 65535])
+def test_blocks_longer_than_16384(blocksize):
+    """test/test_streams.sh:243 (-b 65535): blocks that do not fit the LDS -- the general kernels read HBM instead"""
+    for fam, ch, bps, level, kw in (("music", 2, 16, 5, {}), ("sine", 1, 16, 0, dict(max_lpc_order=32, exhaustive=1, mid_side=1)),
+                                    ("mixed", 2, 24, 8, {}), ("white", 2, 32, 5, {}), ("wasted", 3, 16, 2, {})):
+        pcm = signals.FAMILIES[fam](blocksize + 777, ch, bps)
+        if ch != 2:
+            kw = {k: v for k, v in kw.items() if k != "mid_side"}
+        data, fb = _gpu_encode(pcm, bps, 44100, level, blocksize=blocksize, streamable_subset=0, max_batch=2, **kw)
+        o = po.oracle_encode(pcm, bps, 44100, level, blocksize=blocksize, **kw)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (blocksize, fam, ch, bps, level)

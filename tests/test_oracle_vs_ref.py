@@ -371,3 +371,14 @@ def test_host_window_tables_bit_exact(ref, spec, fn, args):
                 f(want.ctypes.data, L, C.c_float(tukey_p), C.c_float(float(start)), C.c_float(float(end)))
                 assert np.array_equal(w[k].view(np.uint32), want.view(np.uint32)), (spec, L, m)
                 k += 1
+
+
+@pytest.mark.parametrize("blocksize", [16385, 20000, 32768, 65535])
+def test_blocks_longer_than_16384(ref, blocksize):
+    """test/test_streams.sh:243 (-b 65535)"""
+    for fam, ch, bps, level, kw in (("music", 2, 16, 5, {}), ("sine", 1, 16, 0, dict(max_lpc_order=32, exhaustive=1)),
+                                    ("mixed", 2, 24, 8, {}), ("white", 2, 32, 5, {}), ("wasted", 3, 16, 2, {})):
+        pcm = signals.FAMILIES[fam](blocksize + 777, ch, bps)
+        r = po.ref_encode(pcm, bps, 44100, level, blocksize=blocksize, streamable_subset=0, **kw)
+        o = po.oracle_encode(pcm, bps, 44100, level, blocksize=blocksize, **kw)
+        assert o["data"] == _frames(r), (blocksize, fam, ch, bps, level)
