@@ -61,7 +61,7 @@ void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 		WindowJob &jr = jt->jobs[nj];
 		jr.off = woff; jr.nd = n; jr.apod = a; jr.full = 1;
 		woff += (n + 3u) & ~1u;
-		jt->an_job[na] = (uint8_t)nj; jt->an_punch[na] = 0; jt->an_root[na] = (uint8_t)root; na++; nj++;
+		jt->an_job[na] = (uint16_t)nj; jt->an_punch[na] = 0; jt->an_root[na] = (uint16_t)root; na++; nj++;
 		if(P.apod_kind[a] == FLACGPU_APOD_SUBDIVIDE_TUKEY) {
 			for(uint32_t b = 2; b <= P.apod_parts[a]; b++) {
 				if(n / b <= 32) continue;                               /* :4349-4357 */
@@ -72,8 +72,8 @@ void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 					jp.part = n / b / 2; jp.dshift = (pi * n) / b;      /* :4361 */
 					jp.i0 = jp.part < n - jp.part - jp.dshift ? jp.part : n - jp.part - jp.dshift;
 					woff += (jp.nd + 3u) & ~1u;
-					jt->an_job[na] = (uint8_t)nj; jt->an_punch[na] = 0; jt->an_root[na] = (uint8_t)root; na++;
-					if(b >= 3) { jt->an_job[na] = (uint8_t)nj; jt->an_punch[na] = 1; jt->an_root[na] = (uint8_t)root; na++; }   /* :4295-4308 */
+					jt->an_job[na] = (uint16_t)nj; jt->an_punch[na] = 0; jt->an_root[na] = (uint16_t)root; na++;
+					if(b >= 3) { jt->an_job[na] = (uint16_t)nj; jt->an_punch[na] = 1; jt->an_root[na] = (uint16_t)root; na++; }   /* :4295-4308 */
 					nj++;
 				}
 			}

@@ -13,8 +13,8 @@ constexpr int CHUNK = 16;       // consecutive samples owned by one thread in FI
 constexpr int MAX_ORDER = 32;   // taps kept per candidate (FLAC__MAX_LPC_ORDER, format.h)
 constexpr int AUTOC_STRIDE = 40;// doubles per autocorrelation record (lags 0..32)
 constexpr int MAX_PO = 8;       // max residual partition order (FLAC subset limit)
-constexpr int MAX_JOBS = 24;    // windowed-data jobs per subframe (subdivide_tukey up to 6 parts)
-constexpr int MAX_ANALYSES = 40;// LPC analyses per subframe
+constexpr int MAX_JOBS = 1024;  // windowed-data jobs per subframe (one subdivide_tukey(32) makes 528)
+constexpr int MAX_ANALYSES = 2048; // LPC analyses per subframe (one subdivide_tukey(32): 1053)
 
 // flattened, device-friendly copy of flacgpu_config
 struct DevParams {
@@ -82,7 +82,8 @@ struct WindowJob {
 struct JobTable {
 	uint32_t njobs, nanalyses, wnd_floats, pad;
 	WindowJob jobs[MAX_JOBS];
-	uint8_t an_job[MAX_ANALYSES], an_punch[MAX_ANALYSES], an_root[MAX_ANALYSES];
+	uint16_t an_job[MAX_ANALYSES], an_root[MAX_ANALYSES];
+	uint8_t an_punch[MAX_ANALYSES];
 };
 void build_job_table(const DevParams &P, uint32_t n, JobTable *jt);
 

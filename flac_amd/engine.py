@@ -13,7 +13,7 @@ _LIBDIR = os.path.join(_HERE, "lib")
 ENGINE_SO = os.path.join(_LIBDIR, "libflacgpu.so")
 HOST_SO = os.path.join(_LIBDIR, "libFLACgpu.so")
 
-FLACGPU_MAX_APODIZATIONS = 8
+FLACGPU_MAX_APODIZATIONS = 32
 FGH_MAX_APODIZATIONS = 32
 
 

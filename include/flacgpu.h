@@ -25,9 +25,9 @@
 extern "C" {
 #endif
 
-#define FLACGPU_ABI_VERSION 2
+#define FLACGPU_ABI_VERSION 3
 #define FLACGPU_MAX_CHANNELS 8
-#define FLACGPU_MAX_APODIZATIONS 8
+#define FLACGPU_MAX_APODIZATIONS 32     /* FLAC__MAX_APODIZATION_FUNCTIONS */
 
 /* error codes (negative returns) */
 enum {
@@ -72,7 +72,7 @@ typedef struct {
 	uint32_t limit_min_bitrate;
 	int32_t  device;                 /* HIP device ordinal */
 	uint32_t max_batch_frames;       /* capacity of one encode call */
-	/* ABI 2: the wider model searches of process_subframe_ (stream_encoder.c:4155-4163, 4220-4243) */
+	/* ABI 2: the wider model searches of process_subframe_ (stream_encoder.c:4155-4163, 4220-4243); ABI 3: 32 apodizations */
 	uint32_t do_exhaustive_model_search;  /* -e: every fixed order 0..4 and every LPC order 1..max_lpc_order per analysis */
 	uint32_t do_qlp_coeff_prec_search;    /* -p: every coefficient precision 5..max per LPC order */
 } flacgpu_config;

@@ -48,17 +48,32 @@ def test_settings_resolution_matches_reference_defaults():
         engine.make_settings(2, 16, 44100, 8, blocksize=8192)
 
 
-def test_unsupported_configuration_is_refused_not_emulated():
-    s = engine.make_settings(2, 16, 44100, 8, apodization=";".join(["hann"] * 9))      # more window functions than the engine takes
+def test_every_apodization_the_reference_takes_reaches_the_engine_config():
+    s = engine.make_settings(2, 16, 44100, 8, apodization=";".join(["hann", "welch"] * 16))      # FLAC__MAX_APODIZATION_FUNCTIONS = 32
     cfg = engine.EngineConfig()
-    assert engine.load_host().flacgpu_host_engine_config(C.byref(s), 0, 16, C.byref(cfg)) == -1
+    assert s.num_apodizations == 32
+    assert engine.load_host().flacgpu_host_engine_config(C.byref(s), 0, 16, C.byref(cfg)) == 0
+    assert cfg.num_apodizations == 32
+
+
+def test_unsupported_configuration_is_refused_not_emulated():
+    """the engine itself refuses what it cannot do (there is no CPU path to fall back to)"""
+    s = engine.make_settings(2, 16, 44100, 8)
+    cfg = engine.EngineConfig()
+    assert engine.load_host().flacgpu_host_engine_config(C.byref(s), 0, 16, C.byref(cfg)) == 0
+    cfg.bits_per_sample = 33
+    ctx = C.c_void_p()
+    w = engine.host_windows(s, s.blocksize)
+    lib = engine.load_engine()
+    lib.flacgpu_create.restype = C.c_int
+    assert lib.flacgpu_create(C.byref(cfg), w.ctypes.data, C.byref(ctx)) == -1      # FLACGPU_ERR_UNSUPPORTED, before any device is touched
 
 
 def test_wider_searches_reach_the_engine_config():
     s = engine.make_settings(2, 16, 44100, 8, exhaustive=1, prec_search=1)
     cfg = engine.EngineConfig()
     assert engine.load_host().flacgpu_host_engine_config(C.byref(s), 0, 16, C.byref(cfg)) == 0
-    assert (cfg.abi_version, cfg.do_exhaustive_model_search, cfg.do_qlp_coeff_prec_search) == (2, 1, 1)
+    assert (cfg.abi_version, cfg.do_exhaustive_model_search, cfg.do_qlp_coeff_prec_search) == (3, 1, 1)
 
 
 def test_no_device_fails_loudly():

@@ -516,3 +516,23 @@ def test_blocks_longer_than_16384(blocksize):
         data, fb = _gpu_encode(pcm, bps, 44100, level, blocksize=blocksize, streamable_subset=0, max_batch=2, **kw)
         o = po.oracle_encode(pcm, bps, 44100, level, blocksize=blocksize, **kw)
         assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (blocksize, fam, ch, bps, level)
+
+
+def test_many_apodizations_and_deep_subdivision():
+    """-A lists up to FLAC__MAX_APODIZATION_FUNCTIONS (32) windows, and subdivide_tukey up to 32 parts (528 window jobs,
+    1053 LPC analyses per subframe)"""
+    import flac_amd
+    from oracle_from_settings import oracle_encode_settings
+    specs = [";".join(["hann", "welch", "tukey(0.3)", "gauss(0.2)", "blackman", "flattop", "nuttall", "bartlett"] * 4),
+             "subdivide_tukey(12)", "subdivide_tukey(32)", "tukey(0.5);partial_tukey(4);punchout_tukey(5);subdivide_tukey(7)"]
+    for spec in specs:
+        for ch, bps, n in ((2, 16, 4096 + 321), (1, 24, 4096 * 2)):
+            pcm = signals.music(n, ch, bps, seed=len(spec))
+            s = flac_amd.make_settings(ch, bps, 44100, 8, apodization=spec, streamable_subset=0)
+            eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=4)
+            try:
+                data, fb = eng.encode(pcm)
+            finally:
+                eng.close()
+            o = oracle_encode_settings(pcm, s)
+            assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (spec, ch, bps)

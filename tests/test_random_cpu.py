@@ -42,3 +42,17 @@ def test_random_configurations_oracle_vs_reference(seed):
         assert o["data"] == r["data"][r["header_bytes"]:], (fam, n, ch, bps, rate, kw)
         done += 1
     assert done >= 6
+
+
+def test_many_apodizations_and_deep_subdivision_oracle_vs_reference():
+    import flac_amd
+    from oracle_from_settings import oracle_encode_settings
+    specs = [";".join(["hann", "welch", "tukey(0.3)", "gauss(0.2)", "blackman", "flattop", "nuttall", "bartlett"] * 4),
+             "subdivide_tukey(12)", "subdivide_tukey(32)", "tukey(0.5);partial_tukey(4);punchout_tukey(5);subdivide_tukey(7)"]
+    for spec in specs:
+        for ch, bps, n in ((2, 16, 4096 + 321), (1, 24, 4096 * 2)):
+            pcm = signals.music(n, ch, bps, seed=len(spec))
+            s = flac_amd.make_settings(ch, bps, 44100, 8, apodization=spec, streamable_subset=0)
+            r = po.ref_encode(pcm, bps, 44100, 8, apodization=spec, streamable_subset=0)
+            o = oracle_encode_settings(pcm, s)
+            assert o["data"] == r["data"][r["header_bytes"]:], (spec, ch, bps)
