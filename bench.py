@@ -247,7 +247,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "-8 is VALU bound (~1e3 integer+fp64 ops per sample; the dominant kernel issues VALU work 86% of its cycles, "
+                         "note": "-8 is VALU bound (~1e3 integer+fp64 ops per sample; the dominant kernels issue VALU work 77-83% of their cycles, "
                                  "profiles/*pmc*); the HBM fraction is reported because the north star asks for it; traffic = FETCH_SIZE+WRITE_SIZE "
                                  "of the committed PMC pass scaled to this batch"},
         }
