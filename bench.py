@@ -107,12 +107,17 @@ def main():
     ap.add_argument("--hires", action="store_true", help="96 kHz / 24-bit stereo (BASELINE.json config 4): a side measurement")
     ap.add_argument("--exhaustive", action="store_true", help="flac -8e: not the headline workload, a side measurement")
     ap.add_argument("--prec-search", action="store_true", help="flac -8p")
+    ap.add_argument("--level", type=int, default=8, help="compression preset -0..-8 (the metric is quoted at -8: other levels are side measurements; "
+                    "-0..-2 use the preset's 1152-sample blocks)")
     ap.add_argument("--force-dist", action="store_true", help="development aid: run the multi-rank pipeline (process group, "
                     "overlapped ordered gather) even with one rank")
     args = ap.parse_args()
-    global RATE, BPS
+    global RATE, BPS, LEVEL, BLOCK
     if args.hires:
         RATE, BPS = 96000, 24
+    if args.level != 8:
+        LEVEL = args.level
+        BLOCK = 1152 if LEVEL < 3 else 4096
 
     # stdout must carry exactly one JSON line: libraries underneath (RCCL prints a version banner from C) get stderr
     sys.stdout.flush()
@@ -234,12 +239,15 @@ def main():
         except Exception:
             pass
         line = {
-            "metric": "encode Msamples/s at -8, 44.1k/16-bit stereo; bit-exact vs libFLAC" if not args.hires else "encode Msamples/s at -8, 96k/24-bit stereo (side measurement)",
+            "metric": ("encode Msamples/s at -8, 44.1k/16-bit stereo; bit-exact vs libFLAC" if not args.hires else "encode Msamples/s at -8, 96k/24-bit stereo (side measurement)")
+                      if LEVEL == 8 else "encode Msamples/s at -%d (side measurement; the metric is quoted at -8)" % LEVEL,
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": "flac -8%s%s (max LPC order 12, subdivide_tukey(3), mid/side, partition order <= 6) on %s stereo, "
-                                   "%d frames x %d samples per GPU per step, music-like synthetic PCM resident in HBM" % ("e" if args.exhaustive else "", "p" if args.prec_search else "", "96k/24-bit" if args.hires else "44.1k/16-bit", nframes, BLOCK),
+            "config": {"workload": "flac -%d%s%s (%s) on %s stereo, "
+                                   "%d frames x %d samples per GPU per step, music-like synthetic PCM resident in HBM" % (LEVEL, "e" if args.exhaustive else "", "p" if args.prec_search else "",
+                                   "max LPC order 12, subdivide_tukey(3), mid/side, partition order <= 6" if LEVEL == 8 else "the preset's settings, stream_encoder.c:117-140",
+                                   "96k/24-bit" if args.hires else "44.1k/16-bit", nframes, BLOCK),
                        "frames_per_gpu_per_step": nframes, "blocksize": BLOCK, "channels": CH, "bits_per_sample": BPS,
                        "samples_are": "inter-channel (x2 for channel-samples)", "parallelism": "frame-shard x%d + ordered RCCL gather of every step's frames to rank 0, overlapped with the next step's encode" % world,
                        "compressed_bytes_per_sample": round(out_bps, 4)},
