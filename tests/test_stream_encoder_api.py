@@ -347,3 +347,34 @@ def test_wide_samples_and_high_orders_through_the_api():
     _same_file(signals.white(4096 * 2 + 50, 2, 28), 28, 48000, 5, settings=lax + (("set_verify", 1),), planar=True)
     _same_file(signals.music(4096 * 2 + 50, 2, 16, seed=5), 16, 44100, 8, settings=lax + (("set_max_lpc_order", 32),))
     _same_file(signals.music(4096 * 2 + 50, 1, 24, seed=6), 24, 96000, 5, settings=lax + (("set_max_lpc_order", 17), ("set_do_exhaustive_model_search", 1)))
+
+
+@gpu
+@needs_ref
+def test_several_encoders_at_once(monkeypatch):
+    """four client threads, one encoder each (its own engine, HIP streams and worker thread), different settings:
+    every file identical to the reference's"""
+    import threading
+    monkeypatch.setenv("FLACGPU_BATCH_FRAMES", "4")
+    jobs = [(signals.music(4096 * 9 + 100, 2, 16, seed=1), 16, 44100, 8, ()), (signals.mixed(4096 * 7 + 5, 2, 16), 16, 44100, 5, (("set_verify", 1),)),
+            (signals.music(4096 * 5 + 50, 2, 24, seed=2), 24, 96000, 8, ()), (signals.music(1152 * 11 + 9, 1, 16, seed=3), 16, 22050, 1, ())]
+    want = [fa.encode("ref", p, b, r, l, settings=s)[0] for p, b, r, l, s in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def run(i):
+        try:
+            p, b, r, l, s = jobs[i]
+            got[i] = fa.encode("gpu", p, b, r, l, settings=s, chunk=1000 + 37 * i)[0]
+        except Exception as e:          # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    for _ in range(3):
+        ths = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs
+        for i in range(len(jobs)):
+            assert got[i] == want[i], i
