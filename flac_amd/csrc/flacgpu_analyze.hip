@@ -1386,7 +1386,18 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 		// frames of nominal length: the streaming kernel (flacgpu_autoc.hip); the short last block, and tiny blocks
 		// (lpc.c:133-157), go through the wavefront-per-job kernel above
 		uint32_t f_lo = 0;
-		if(autoc2_applicable(P)) {
+		// autoc2 runs a whole window job per lane quartet: few subframes in the batch (mono, small batches) leave most
+		// SIMDs without a wavefront, and the batch then takes one full job's time.  Below a wavefront or two per SIMD the
+		// wavefront-per-job kernel (16x the wavefronts for 1.8x the arithmetic) is the faster one.
+		static int force = -1;
+		if(force < 0) { const char *e = getenv("FLACGPU_AUTOC2"); force = e ? atoi(e) + 1 : 0; }      // 0: decide here, 1: never, 2: always
+		const uint32_t nmain2 = tail_n ? nframes - 1 : nframes;
+		const uint32_t waves2 = P.max_jobs * ((nmain2 * P.ncand + 15) / 16);
+		// measured break-even (scripts/chan_rate.py): ~640 wavefronts for the stereo mid/side flavour (four channels share
+		// the loads of a frame), ~2048 for the others
+		const bool ms4 = P.channels == 2 && P.ms_mode == 1;
+		const bool use2 = force == 2 || (force == 0 && waves2 >= (ms4 ? 640u : 2048u));
+		if(autoc2_applicable(P) && use2) {
 			f_lo = tail_n ? nframes - 1 : nframes;
 			const hipError_t e = launch_autoc2(P, pcm, win, f_lo, P.max_jobs, jtm, B.prep, B.autoc, s);
 			if(e != hipSuccess) return e;

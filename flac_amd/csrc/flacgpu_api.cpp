@@ -302,12 +302,14 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	const DevParams &P = c->P;
 	if(tail_n) {
+		// The short last block has its own job schedule and windows.  Both live in one device copy each, and the sources are
+		// pageable host memory (this context; the caller's array): wait until an earlier batch that may still be reading the
+		// device copies has drained, then copy synchronously.  Once per stream -- the price is nil.
+		if(P.num_apod && !tail_windows_host) return FLACGPU_ERR_BAD_ARG;
+		if(hipStreamSynchronize(s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		build_job_table(P, tail_n, &c->h_jobtab[1]);
-		if(hipMemcpyAsync(c->d_jobtab + 1, &c->h_jobtab[1], sizeof(JobTable), hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	}
-	if(tail_n && P.num_apod) {
-		if(!tail_windows_host) return FLACGPU_ERR_BAD_ARG;
-		if(hipMemcpyAsync(c->d_tail_windows, tail_windows_host, (size_t)P.num_apod * tail_n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(hipMemcpy(c->d_jobtab + 1, &c->h_jobtab[1], sizeof(JobTable), hipMemcpyHostToDevice) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(P.num_apod && hipMemcpy(c->d_tail_windows, tail_windows_host, (size_t)P.num_apod * tail_n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
 	c->ev = c->ev_ring[c->batch_seq % TIMING_RING]; c->pev = c->pev_ring[c->batch_seq % TIMING_RING];
 	c->batch_seq++;
