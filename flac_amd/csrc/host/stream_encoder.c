@@ -21,6 +21,7 @@
 #include <pthread.h>
 #include <limits.h>
 #include "flacgpu_host.h"
+#include "ogg.h"
 #include "FLACgpu_stream_encoder.h"
 
 /* format.c:57: the reference writes its vendor string into every VORBIS_COMMENT block.  Files are
@@ -69,6 +70,9 @@ struct FLAC__StreamEncoderProtected {
 /* ... and in FLAC__StreamEncoderPrivate: callbacks, stream bookkeeping, and here the batch staging */
 struct FLAC__StreamEncoderPrivate {
 	FLAC__StreamEncoderWriteCallback write_cb;
+	FLAC__StreamEncoderReadCallback read_cb;  /* Ogg FLAC only: the STREAMINFO page is read back at finish */
+	int is_ogg, final_batch, emit_is_last;                  /* final_batch: the batch being delivered ends the stream (its last frame closes the Ogg stream) */
+	fgh_ogg_aspect ogg;
 	FLAC__StreamEncoderSeekCallback seek_cb;
 	FLAC__StreamEncoderTellCallback tell_cb;
 	FLAC__StreamEncoderMetadataCallback metadata_cb;
@@ -127,6 +131,8 @@ static void set_defaults(FLAC__StreamEncoder *e)
 	PROT(e)->num_metadata_blocks = 0;
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	p->write_cb = 0; p->seek_cb = 0; p->tell_cb = 0; p->metadata_cb = 0; p->progress_cb = 0; p->client_data = 0;
+	p->read_cb = 0; p->is_ogg = 0; p->final_batch = 0;
+	fgh_ogg_aspect_set_defaults(&p->ogg);
 	p->seek_table = 0;
 }
 
@@ -212,8 +218,9 @@ SETTER(disable_verbatim_subframes, FLAC__bool, PROT(e)->s.disable_verbatim_subfr
 
 FLAC__bool FLAC__stream_encoder_set_ogg_serial_number(FLAC__StreamEncoder *e, long value)
 {
-	(void)e; (void)value;
-	return 0;                                 /* as a reference build without libogg (:1781-1797) */
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;      /* :1781-1797 */
+	PRIV(e)->ogg.serial_number = value;
+	return 1;
 }
 
 FLAC__bool FLAC__stream_encoder_set_compression_level(FLAC__StreamEncoder *e, uint32_t value)
@@ -259,6 +266,8 @@ FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *e, FLAC__Strea
 		memcpy(m, metadata, sizeof *m * num_blocks);
 		PROT(e)->metadata = m; PROT(e)->num_metadata_blocks = num_blocks;
 	}
+	if(num_blocks >= (1u << 16)) return 0;    /* the Ogg mapping's 16-bit header-packet count (:2228, ogg_encoder_aspect.c:75) */
+	PRIV(e)->ogg.num_metadata = num_blocks;
 	return 1;
 }
 
@@ -471,6 +480,11 @@ static int picture_is_legal(const FLAC__StreamMetadata_Picture *pic)
 /* ------------------------------------------------------------------------------------------------
  * stream output: the bookkeeping of write_frame_ / write_bitbuffer_ (stream_encoder.c:2988-3136)
  * ---------------------------------------------------------------------------------------------- */
+static int ogg_write_proxy(void *encoder, const uint8_t *buf, size_t bytes, uint32_t samples, uint32_t current_frame, void *client_data)
+{
+	FLAC__StreamEncoder *e = encoder;
+	return PRIV(e)->write_cb(e, buf, bytes, samples, current_frame, client_data) == FLAC__STREAM_ENCODER_WRITE_STATUS_OK;
+}
 static int emit(FLAC__StreamEncoder *e, const uint8_t *buf, size_t bytes, uint32_t samples)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
@@ -498,7 +512,14 @@ static int emit(FLAC__StreamEncoder *e, const uint8_t *buf, size_t bytes, uint32
 			p->first_seekpoint_to_check++;
 		}
 	}
-	if(p->write_cb(e, buf, bytes, samples, p->current_frame_number, p->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) {
+	if(p->is_ogg) {
+		/* one packet per write; pages go to the client as (header, body) write pairs (:3106-3118) */
+		if(!fgh_ogg_aspect_write(&p->ogg, buf, bytes, samples, p->current_frame_number, p->emit_is_last, ogg_write_proxy, e, p->client_data)) {
+			PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+			return 0;
+		}
+	}
+	else if(p->write_cb(e, buf, bytes, samples, p->current_frame_number, p->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) {
 		PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
 		return 0;
 	}
@@ -605,7 +626,10 @@ static int collect_slot(FLAC__StreamEncoder *e, int k)
 		}
 		const uint32_t samples = (f + 1 == b->nframes && b->tail) ? b->tail : N;
 		p->frame_blocksize = samples;
-		if(!emit(e, q, b->frame_bytes[f], samples)) return 0;
+		p->emit_is_last = p->final_batch && f + 1 == b->nframes;            /* is_last_block of write_frame_ (:3038) */
+		const int ok = emit(e, q, b->frame_bytes[f], samples);
+		p->emit_is_last = 0;
+		if(!ok) return 0;
 		q += b->frame_bytes[f];
 		p->current_frame_number++;
 		p->streaminfo.data.stream_info.total_samples += samples;
@@ -623,11 +647,27 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	flacgpu_host_settings *s = &PROT(e)->s;
 	if(PROT(e)->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
-	if(is_ogg) return FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER;     /* FLAC__HAS_OGG == 0 (:725) */
 	if(!wcb || (scb && !tcb)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS;
 	const int st = flacgpu_host_settings_resolve(s);          /* the checks and defaults of :729-829; codes are the enum's */
 	if(st != FGH_INIT_OK) return (FLAC__StreamEncoderInitStatus)st;
 
+	if(is_ogg && PROT(e)->metadata) {
+		/* no seek table in Ogg FLAC, and a VORBIS_COMMENT goes first (:831-857) */
+		uint32_t n = PROT(e)->num_metadata_blocks;
+		for(uint32_t i = 0; i < n; i++)
+			if(PROT(e)->metadata[i] && PROT(e)->metadata[i]->type == FLAC__METADATA_TYPE_SEEKTABLE) {
+				for(n--; i < n; i++) PROT(e)->metadata[i] = PROT(e)->metadata[i + 1];
+				break;
+			}
+		PROT(e)->num_metadata_blocks = n;
+		for(uint32_t i = 1; i < n; i++)
+			if(PROT(e)->metadata[i] && PROT(e)->metadata[i]->type == FLAC__METADATA_TYPE_VORBIS_COMMENT) {
+				FLAC__StreamMetadata *vc = PROT(e)->metadata[i];
+				for(; i > 0; i--) PROT(e)->metadata[i] = PROT(e)->metadata[i - 1];
+				PROT(e)->metadata[0] = vc;
+				break;
+			}
+	}
 	/* client metadata (:866-925) */
 	p->seek_table = 0;
 	if(!PROT(e)->metadata && PROT(e)->num_metadata_blocks) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
@@ -710,6 +750,12 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 	}
 
 	p->write_cb = wcb; p->seek_cb = scb; p->tell_cb = tcb; p->metadata_cb = mcb; p->client_data = client_data;
+	p->is_ogg = is_ogg; p->final_batch = 0; p->emit_is_last = 0;
+	if(is_ogg && !fgh_ogg_aspect_init(&p->ogg)) {                   /* :1121-1124 */
+		release_engine(e);
+		PROT(e)->state = FLAC__STREAM_ENCODER_OGG_ERROR;
+		return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	}
 	p->staged = 0; p->cur = 0; p->current_frame_number = 0; p->next_frame_number = 0; p->frame_blocksize = 0;
 	p->first_seekpoint_to_check = 0; p->samples_written = 0;
 	PROT(e)->streaminfo_offset = PROT(e)->seektable_offset = PROT(e)->audio_offset = 0;
@@ -757,7 +803,7 @@ FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_stream(FLAC__StreamE
                                                                    FLAC__StreamEncoderSeekCallback scb, FLAC__StreamEncoderTellCallback tcb,
                                                                    FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
 {
-	(void)rcb;
+	PRIV(e)->read_cb = rcb;
 	return init_common(e, wcb, scb, tcb, mcb, client_data, 1);
 }
 
@@ -785,6 +831,13 @@ static FLAC__StreamEncoderTellStatus file_tell(const FLAC__StreamEncoder *e, FLA
 	return FLAC__STREAM_ENCODER_TELL_STATUS_OK;
 }
 
+static FLAC__StreamEncoderReadStatus file_read(const FLAC__StreamEncoder *e, FLAC__byte buf[], size_t *bytes, void *cd)
+{
+	(void)cd;                                  /* :5245-5256 */
+	*bytes = fread(buf, 1, *bytes, PRIV(e)->file);
+	if(*bytes == 0) return feof(PRIV(e)->file) ? FLAC__STREAM_ENCODER_READ_STATUS_END_OF_STREAM : FLAC__STREAM_ENCODER_READ_STATUS_ABORT;
+	return FLAC__STREAM_ENCODER_READ_STATUS_CONTINUE;
+}
 static FLAC__StreamEncoderInitStatus init_FILE_common(FLAC__StreamEncoder *e, FILE *file, FLAC__StreamEncoderProgressCallback pcb, void *client_data, int is_ogg)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
@@ -794,6 +847,7 @@ static FLAC__StreamEncoderInitStatus init_FILE_common(FLAC__StreamEncoder *e, FI
 	p->progress_cb = pcb;
 	p->bytes_written = 0; p->samples_written = 0; p->frames_written = 0;
 	const int to_stdout = file == stdout;
+	p->read_cb = (is_ogg && !to_stdout) ? file_read : 0;
 	const FLAC__StreamEncoderInitStatus st = init_common(e, file_write, to_stdout ? 0 : file_seek, to_stdout ? 0 : file_tell, 0, client_data, is_ogg);
 	if(st != FLAC__STREAM_ENCODER_INIT_STATUS_OK) return st;
 	p->progress_cb = pcb;
@@ -951,6 +1005,64 @@ static void update_metadata(FLAC__StreamEncoder *e)
 	}
 }
 
+/* update_ogg_metadata_ (:3303-3440) with the page helpers of ogg_helper.c: read the first page back, patch MD5, total
+ * samples and min/max frame size inside its body (the STREAMINFO sits 13 bytes into the first packet), new page CRC, write it back */
+static void update_ogg_metadata(FLAC__StreamEncoder *e)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	const FLAC__StreamMetadata_StreamInfo *si = &p->streaminfo.data.stream_info;
+	const size_t prefix = 1 + 4 + 1 + 1 + 2 + 4;                       /* 0x7F "FLAC" major minor count "fLaC" */
+	uint8_t page[27 + 255 + 255 * 255];
+	if(p->seek_cb(e, 0, p->client_data) == FLAC__STREAM_ENCODER_SEEK_STATUS_UNSUPPORTED) return;
+	if(!p->read_cb) return;
+	{
+		const FLAC__StreamEncoderSeekStatus ss = p->seek_cb(e, PROT(e)->streaminfo_offset, p->client_data);
+		if(ss != FLAC__STREAM_ENCODER_SEEK_STATUS_OK) { if(ss == FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR) PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return; }
+	}
+	size_t have = 0, want = 27;
+	int stage = 0;                                                   /* 0 fixed header, 1 segment table, 2 body */
+	size_t header_len = 0, body_len = 0;
+	for(;;) {
+		while(have < want) {
+			size_t n = want - have;
+			const FLAC__StreamEncoderReadStatus rs = p->read_cb(e, page + have, &n, p->client_data);
+			if(rs == FLAC__STREAM_ENCODER_READ_STATUS_ABORT) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return; }
+			if(rs == FLAC__STREAM_ENCODER_READ_STATUS_END_OF_STREAM || n == 0) { PROT(e)->state = FLAC__STREAM_ENCODER_OGG_ERROR; return; }
+			have += n;
+		}
+		if(stage == 0) {
+			if(memcmp(page, "OggS", 4) || (page[5] & 0x01) || memcmp(page + 6, "\0\0\0\0\0\0\0\0", 8) || page[26] == 0) { PROT(e)->state = FLAC__STREAM_ENCODER_OGG_ERROR; return; }
+			header_len = 27 + page[26]; want = header_len; stage = 1;
+		}
+		else if(stage == 1) {
+			for(size_t i = 0; i < page[26]; i++) body_len += page[27 + i];
+			want = header_len + body_len; stage = 2;
+		}
+		else break;
+	}
+	uint8_t *body = page + header_len;
+	if(prefix + 4 + 18 + 16 > body_len) { PROT(e)->state = FLAC__STREAM_ENCODER_OGG_ERROR; return; }
+	memcpy(body + prefix + 4 + 18, si->md5sum, 16);
+	{
+		const FLAC__uint64 t = si->total_samples;
+		uint8_t *b = body + prefix + 4 + 13;
+		b[0] = (uint8_t)((b[0] & 0xF0) | ((t >> 32) & 0x0F));
+		b[1] = (uint8_t)(t >> 24); b[2] = (uint8_t)(t >> 16); b[3] = (uint8_t)(t >> 8); b[4] = (uint8_t)t;
+	}
+	{
+		uint8_t *b = body + prefix + 4 + 4;
+		b[0] = (uint8_t)(si->min_framesize >> 16); b[1] = (uint8_t)(si->min_framesize >> 8); b[2] = (uint8_t)si->min_framesize;
+		b[3] = (uint8_t)(si->max_framesize >> 16); b[4] = (uint8_t)(si->max_framesize >> 8); b[5] = (uint8_t)si->max_framesize;
+	}
+	fgh_ogg_page_checksum_set(page, header_len, body, body_len);
+	{
+		const FLAC__StreamEncoderSeekStatus ss = p->seek_cb(e, PROT(e)->streaminfo_offset, p->client_data);
+		if(ss != FLAC__STREAM_ENCODER_SEEK_STATUS_OK) { if(ss == FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR) PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return; }
+	}
+	if(p->write_cb(e, page, header_len, 0, 0, p->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK ||
+	   p->write_cb(e, body, body_len, 0, 0, p->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return; }
+}
+
 FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 {
 	if(!e) return 0;
@@ -970,7 +1082,9 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 			uint32_t tail = (uint32_t)(p->staged - (size_t)(nframes - 1) * N);
 			if(tail == N) tail = 0;
 			submit_slot(e, p->cur, nframes, tail);
+			p->final_batch = 1;
 			if(!collect_slot(e, p->cur)) error = 1;
+			p->final_batch = 0;
 		}
 		p->staged = 0;
 	}
@@ -984,12 +1098,13 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 	if(!p->is_being_deleted && PROT(e)->state == FLAC__STREAM_ENCODER_OK) {
 		p->current_frame_number = 0;
 		if(p->seek_cb) {
-			update_metadata(e);
+			if(p->is_ogg) update_ogg_metadata(e); else update_metadata(e);
 			if(PROT(e)->state != FLAC__STREAM_ENCODER_OK) error = 1;
 		}
 		if(p->metadata_cb) p->metadata_cb(e, &p->streaminfo, p->client_data);
 	}
 	if(p->file) { if(p->file != stdout) fclose(p->file); p->file = 0; }
+	if(p->is_ogg) fgh_ogg_aspect_finish(&p->ogg);
 	release_engine(e);
 	set_defaults(e);
 	if(!error) PROT(e)->state = FLAC__STREAM_ENCODER_UNINITIALIZED;

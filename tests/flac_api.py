@@ -182,8 +182,11 @@ class Sink:
         return self._cbs
 
 
+READ_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_size_t), C.c_void_p)
+
+
 def encode(which, pcm, bps, rate, level=5, chunk=None, planar=False, metadata=None, settings=(), seekable=True,
-           total_samples_estimate=None, to_file=None, progress=None):
+           total_samples_estimate=None, to_file=None, progress=None, ogg=False):
     """One complete client session: new -> set_* -> init -> process* -> finish -> delete.
     settings: sequence of (setter-name-without-prefix, value) applied in order after the compression level.
     Returns (file bytes, Sink or None)."""
@@ -209,7 +212,19 @@ def encode(which, pcm, bps, rate, level=5, chunk=None, planar=False, metadata=No
         sink = None
         if to_file:
             pcb = PROGRESS_CB(progress) if progress else PROGRESS_CB()
-            st = lib.FLAC__stream_encoder_init_file(e, to_file.encode(), pcb, None)
+            st = (lib.FLAC__stream_encoder_init_ogg_file if ogg else lib.FLAC__stream_encoder_init_file)(e, to_file.encode(), pcb, None)
+        elif ogg:
+            sink = Sink(seekable)
+
+            def rd(enc, buf, pbytes, cd):              # FLAC__StreamEncoderReadCallback: 0 CONTINUE, 1 END_OF_STREAM
+                data = sink.buf.read(pbytes[0])
+                C.memmove(buf, data, len(data))
+                pbytes[0] = len(data)
+                return 0 if data else 1
+
+            keep_rd = READ_CB(rd)
+            lib.FLAC__stream_encoder_init_ogg_stream.argtypes = [C.c_void_p, READ_CB, WRITE_CB, SEEK_CB, TELL_CB, META_CB, C.c_void_p]
+            st = lib.FLAC__stream_encoder_init_ogg_stream(e, keep_rd, *sink.callbacks(), None)
         else:
             sink = Sink(seekable)
             st = lib.FLAC__stream_encoder_init_stream(e, *sink.callbacks(), None)

@@ -91,7 +91,8 @@ def test_defaults_presets_and_setters_read_back_like_the_reference():
         assert g.FLAC__stream_encoder_set_total_samples_estimate(eg, 1 << 40) and r.FLAC__stream_encoder_set_total_samples_estimate(er, 1 << 40)
         assert _snapshot(g, eg) == _snapshot(r, er)
         assert g.FLAC__stream_encoder_get_resolved_state_string(eg) == r.FLAC__stream_encoder_get_resolved_state_string(er)
-        assert g.FLAC__stream_encoder_set_ogg_serial_number(eg, 5) == r.FLAC__stream_encoder_set_ogg_serial_number(er, 5) == 0
+        # the pinned reference is built without libogg and refuses (0); this library carries its own Ogg layer (host/ogg.c)
+        assert r.FLAC__stream_encoder_set_ogg_serial_number(er, 5) == 0 and g.FLAC__stream_encoder_set_ogg_serial_number(eg, 5) == 1
         assert g.FLAC__stream_encoder_finish(eg) == r.FLAC__stream_encoder_finish(er)      # legal on an uninitialised encoder
     finally:
         g.FLAC__stream_encoder_delete(eg); r.FLAC__stream_encoder_delete(er)
@@ -133,7 +134,7 @@ BAD_CONFIGS = [
     dict(settings=(("set_blocksize", 8192),)),                 # not streamable at 44.1 kHz
     dict(settings=(("set_max_lpc_order", 14),)),               # not streamable at <= 48 kHz
     dict(bps=17), dict(rate=700000),
-    dict(callbacks="nowrite"), dict(callbacks="seek-without-tell"), dict(ogg=True),
+    dict(callbacks="nowrite"), dict(callbacks="seek-without-tell"),
 ]
 
 
@@ -378,3 +379,128 @@ def test_several_encoders_at_once(monkeypatch):
         assert not errs, errs
         for i in range(len(jobs)):
             assert got[i] == want[i], i
+
+
+# ------------------------------------------------------------------------------------------------------------ Ogg FLAC
+def _ogg_crc(data):
+    """CRC-32 of an Ogg page, straight from RFC 3533: polynomial 0x04c11db7, MSB first, no reflection, init 0, no final xor"""
+    crc = 0
+    for byte in data:
+        crc ^= byte << 24
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x04c11db7) & 0xffffffff if crc & 0x80000000 else (crc << 1) & 0xffffffff
+    return crc
+
+
+def _ogg_pages(data):
+    """independent page parser: [(header_type, granule, serial, pageno, segments, body)]; checks capture pattern and CRC"""
+    pages, pos = [], 0
+    while pos < len(data):
+        assert data[pos:pos + 4] == b"OggS" and data[pos + 4] == 0, pos
+        htype = data[pos + 5]
+        granule = int.from_bytes(data[pos + 6:pos + 14], "little", signed=True)
+        serial = int.from_bytes(data[pos + 14:pos + 18], "little")
+        pageno = int.from_bytes(data[pos + 18:pos + 22], "little")
+        crc = int.from_bytes(data[pos + 22:pos + 26], "little")
+        nseg = data[pos + 26]
+        segs = list(data[pos + 27:pos + 27 + nseg])
+        body = data[pos + 27 + nseg:pos + 27 + nseg + sum(segs)]
+        page = bytearray(data[pos:pos + 27 + nseg + sum(segs)])
+        page[22:26] = b"\0\0\0\0"
+        assert _ogg_crc(page) == crc, ("page CRC", pageno)
+        pages.append((htype, granule, serial, pageno, segs, body))
+        pos += 27 + nseg + sum(segs)
+    return pages
+
+
+def _ogg_packets(pages):
+    """packets in order, each with the index of the page it ends on"""
+    packets, cur = [], b""
+    for pi, (htype, granule, serial, pageno, segs, body) in enumerate(pages):
+        assert bool(htype & 1) == bool(cur), "continued-packet flag"
+        off = 0
+        for s in segs:
+            cur += body[off:off + s]
+            off += s
+            if s < 255:
+                packets.append((cur, pi))
+                cur = b""
+    assert cur == b""
+    return packets
+
+
+@gpu
+def test_ogg_flac_container(tmp_path):
+    """FLAC__stream_encoder_init_ogg_stream / _file.  The reference here is built without libogg, so whole files are checked
+    structurally (the paging itself is pinned against libogg-written streams in test_ogg_cpu.py): page structure and CRC with
+    an independent parser, the mapping rules of ogg_encoder_aspect.c, packets == the native stream of the same encoder,
+    granule positions, the STREAMINFO patched into the first page at finish."""
+    for pcm, bps, rate, level, md, serial in ((signals.music(4096 * 23 + 777, 2, 16, seed=7), 16, 44100, 8, None, 0x1234567),
+                                              (signals.white(4096 * 3 + 5, 2, 24), 24, 96000, 5, "vc+pad", 7),
+                                              (signals.silence(4096 * 40, 1, 16), 16, 8000, 2, None, 0),
+                                              (signals.music(100, 2, 16, seed=1), 16, 44100, 5, None, 1)):
+        def mk():                # fresh blocks per session: the encoder sets is_last and fills the seek table in place
+            return [fa.padding(100), fa.vorbis_comment([b"TITLE=x"]), fa.seektable([0, 4096])] if md else None
+        meta = mk()
+        native, _ = fa.encode("gpu", pcm, bps, rate, level, metadata=mk(), chunk=3000)
+        settings = (("set_ogg_serial_number", serial),)
+        ogg, sink = fa.encode("gpu", pcm, bps, rate, level, metadata=meta, chunk=3000, ogg=True, settings=settings)
+        pages = _ogg_pages(ogg)
+        assert [p[3] for p in pages] == list(range(len(pages)))                   # page sequence numbers
+        assert all(p[2] == (serial & 0xffffffff) for p in pages)
+        assert pages[0][0] & 2 and not any(p[0] & 2 for p in pages[1:])           # exactly one beginning-of-stream page
+        assert pages[-1][0] & 4 and not any(p[0] & 4 for p in pages[:-1])         # the last page ends the stream
+        packets = _ogg_packets(pages)
+        # first packet: 0x7F "FLAC" 1.0, header-packet count, "fLaC", STREAMINFO -- alone on the first page
+        first, first_page = packets[0]
+        nmeta_client = len(meta) if meta else 0
+        assert first[:13] == b"\x7fFLAC\x01\x00" + nmeta_client.to_bytes(2, "big") + b"fLaC" and len(first) == 13 + 38 and first_page == 0
+        assert len(pages[0][5]) == len(first) and pages[0][1] == 0
+        # the native stream, cut the same way: fLaC | STREAMINFO | other metadata blocks | frames
+        blocks, pos, last = [], 4, False
+        while not last:
+            last = bool(native[pos] & 0x80)
+            ln = int.from_bytes(native[pos + 1:pos + 4], "big")
+            blocks.append(native[pos:pos + 4 + ln])
+            pos += 4 + ln
+        frames_native = native[pos:]
+        assert first[13:] == blocks[0]                                            # STREAMINFO incl. MD5 / totals patched at finish
+        if meta:
+            # no seek table in Ogg FLAC and the VORBIS_COMMENT moves to the front (stream_encoder.c:831-857); the header count
+            # is the number of blocks the client set, as in the reference (:2228)
+            keep = [b for b in blocks[1:] if b[0] & 0x7f != 3]
+            nblocks = len(keep)
+            meta_packets = packets[1:1 + nblocks]
+            assert [p[0] & 0x7f for p, _ in meta_packets] == [4, 1]
+            assert sorted(p[1:] for p, _ in meta_packets) == sorted(b[1:] for b in keep)
+            assert meta_packets[-1][0][0] & 0x80 and not meta_packets[0][0][0] & 0x80
+        else:
+            nblocks = len(blocks) - 1
+            meta_packets = packets[1:1 + nblocks]
+            assert [p for p, _ in meta_packets] == blocks[1:]
+        assert [pi for _, pi in meta_packets] == list(range(1, 1 + nblocks))          # each metadata packet flushed to its own page
+        # every metadata packet is flushed: the first audio packet starts a fresh page
+        audio = packets[1 + nblocks:]
+        assert b"".join(p for p, _ in audio) == frames_native
+        assert all(p[:2] in (b"\xff\xf8", b"\xff\xf9") for p, _ in audio)          # one frame per packet
+        if audio:
+            assert audio[0][1] > meta_packets[-1][1] if meta_packets else audio[0][1] > 0
+        # granule position of a page = samples up to the last packet ending on it; -1 if none ends there
+        N = 1152 if level < 3 else 4096
+        done = {}
+        total = 0
+        for i, (pk, pi) in enumerate(audio):
+            total = min(len(pcm), (i + 1) * N)
+            done[pi] = total
+        for pi, pg in enumerate(pages):
+            if pi in done:
+                assert pg[1] == done[pi], pi
+            elif pi > first_page and pi > (meta_packets[-1][1] if meta_packets else 0):
+                assert pg[1] == -1, pi
+        # pages close once more than 4096 body bytes are queued and four packets ended, or at 255 segments
+        for pg in pages[:-1]:
+            assert len(pg[4]) <= 255
+        # the same through init_ogg_file
+        path = str(tmp_path / ("t%d.oga" % serial))
+        data, _ = fa.encode("gpu", pcm, bps, rate, level, metadata=mk(), chunk=3000, ogg=True, settings=settings, to_file=path)
+        assert data == ogg
