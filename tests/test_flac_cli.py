@@ -1,0 +1,86 @@
+"""-m gpu: the reference's own `flac` command-line tool (src/flac, compiled unmodified into oracle/_ref by `make -C oracle cli`),
+linked against libFLACgpu.so for the encoder -- the north star's "the flac CLI links against it unchanged" -- next to the same
+tool linked against the reference library.  Same command line, same input file: the two .flac files must be identical
+(STREAMINFO with MD5, seek table, padding, Vorbis comment and every frame)."""
+import os
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+import signals
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFDIR = os.path.join(os.path.dirname(HERE), "oracle", "_ref")
+CLI_REF, CLI_GPU = os.path.join(REFDIR, "flac_cli_ref"), os.path.join(REFDIR, "flac_cli_gpu")
+needs_cli = pytest.mark.skipif(not (os.path.exists(CLI_REF) and os.path.exists(CLI_GPU)), reason="oracle/_ref CLI binaries not built")
+
+
+def _wav(path, pcm, bps, rate):
+    w = wave.open(path, "wb")
+    w.setnchannels(pcm.shape[1]); w.setsampwidth((bps + 7) // 8); w.setframerate(rate)
+    if bps == 8:
+        raw = (pcm + 128).astype(np.uint8).tobytes()
+    elif bps == 16:
+        raw = pcm.astype("<i2").tobytes()
+    elif bps == 24:
+        b = pcm.astype("<i4").tobytes()
+        raw = b"".join(b[i:i + 3] for i in range(0, len(b), 4))
+    else:
+        raw = pcm.astype("<i4").tobytes()
+    w.writeframes(raw)
+    w.close()
+
+
+def _run(cli, args, out):
+    r = subprocess.run([cli] + args + ["-f", "-o", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (cli, args, r.stderr[-2000:])
+    with open(out, "rb") as f:
+        return f.read()
+
+
+CASES = [
+    ("music", 2, 16, 44100, 3 * 44100 + 17, ["-8"]),
+    ("music", 2, 16, 44100, 2 * 44100, ["-5", "--verify"]),
+    ("mixed", 2, 16, 44100, 44100, ["-0"]),
+    ("music", 1, 16, 22050, 30000, ["-3", "-S", "0.5s", "-P", "1000"]),
+    ("music", 2, 24, 96000, 96000, ["-8", "-V", "-T", "TITLE=t", "-T", "ARTIST=a"]),
+    ("white", 2, 8, 8000, 20000, ["-6", "--lax", "-b", "1000"]),
+    ("music", 2, 16, 48000, 60000, ["-8", "-e", "-p", "--lax", "-l", "20"]),
+    ("music", 2, 32, 48000, 40000, ["-7", "-V"]),
+    ("square", 2, 16, 44100, 50000, ["-4", "-A", "tukey(0.25);partial_tukey(2)", "-r", "2,5"]),
+    ("music", 6, 16, 48000, 30000, ["-5", "--channel-map=none"]),
+]
+
+
+@needs_cli
+@pytest.mark.parametrize("case", CASES, ids=[" ".join([c[0], str(c[1]), str(c[2])] + c[5]) for c in CASES])
+def test_unmodified_flac_tool_writes_the_same_file(tmp_path, case):
+    fam, ch, bps, rate, n, args = case
+    pcm = signals.FAMILIES[fam](n, ch, bps)
+    wav = str(tmp_path / "in.wav")
+    _wav(wav, pcm, bps, rate)
+    want = _run(CLI_REF, args + [wav], str(tmp_path / "ref.flac"))
+    got = _run(CLI_GPU, args + [wav], str(tmp_path / "gpu.flac"))
+    assert len(got) == len(want)
+    assert got == want
+
+
+@needs_cli
+def test_raw_input_and_decode_back(tmp_path):
+    """raw PCM through the tool's own input staging, then the reference decoder reads our file back to the input"""
+    pcm = signals.music(70000, 2, 16, seed=9)
+    raw = str(tmp_path / "in.raw")
+    pcm.astype("<i2").tofile(raw)
+    args = ["-8", "--force-raw-format", "--endian=little", "--sign=signed", "--channels=2", "--bps=16", "--sample-rate=44100", raw]
+    want = _run(CLI_REF, args, str(tmp_path / "ref.flac"))
+    got = _run(CLI_GPU, args, str(tmp_path / "gpu.flac"))
+    assert got == want
+    out = str(tmp_path / "back.raw")
+    r = subprocess.run([CLI_REF, "-d", "--force-raw-format", "--endian=little", "--sign=signed", "-f", "-o", out, str(tmp_path / "gpu.flac")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert np.array_equal(np.fromfile(out, dtype="<i2").reshape(-1, 2), pcm.astype(np.int16))
