@@ -84,3 +84,30 @@ def test_raw_input_and_decode_back(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1000:]
     assert np.array_equal(np.fromfile(out, dtype="<i2").reshape(-1, 2), pcm.astype(np.int16))
+
+
+CXX_REF, CXX_GPU = os.path.join(REFDIR, "cxx_encode_ref"), os.path.join(REFDIR, "cxx_encode_gpu")
+
+
+@pytest.mark.skipif(not (os.path.exists(CXX_REF) and os.path.exists(CXX_GPU)), reason="oracle/_ref C++ clients not built")
+@pytest.mark.parametrize("level", [0, 5, 8])
+def test_cxx_wrapper_client(tmp_path, level):
+    """the reference's C++ wrapper (libFLAC++ FLAC::Encoder::File, compiled unmodified) under a small client, on either library:
+    same file; with init_ogg the client gets an Ogg FLAC file from this library (the pinned reference has no libogg)"""
+    pcm = signals.music(4096 * 6 + 321, 2, 16, seed=level)
+    raw = str(tmp_path / "in.raw")
+    pcm.astype("<i2").tofile(raw)
+    outs = []
+    for exe in (CXX_REF, CXX_GPU):
+        out = str(tmp_path / (os.path.basename(exe) + ".flac"))
+        r = subprocess.run([exe, raw, out, str(level)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (exe, r.stderr)
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]
+    out = str(tmp_path / "o.oga")
+    r = subprocess.run([CXX_GPU, raw, out, str(level), "ogg"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    data = open(out, "rb").read()
+    assert data[:4] == b"OggS" and data[28:33] == b"\x7fFLAC" and int.from_bytes(data[14:18], "little") == 4711
+    r = subprocess.run([CXX_REF, raw, out, str(level), "ogg"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0                     # UNSUPPORTED_CONTAINER: the reference build here has no libogg
