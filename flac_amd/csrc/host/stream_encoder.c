@@ -117,6 +117,9 @@ struct FLAC__StreamEncoderPrivate {
 	pthread_cond_t cv;
 };
 
+/* export.h:107 -- 1: this library writes Ogg FLAC (host/ogg.c) */
+int FLAC_API_SUPPORTS_OGG_FLAC = 1;
+
 #define PROT(e) ((e)->protected_)
 #define PRIV(e) ((e)->private_)
 

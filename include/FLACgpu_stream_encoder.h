@@ -146,6 +146,8 @@ typedef void (*FLAC__StreamEncoderMetadataCallback)(const FLAC__StreamEncoder *,
 typedef void (*FLAC__StreamEncoderProgressCallback)(const FLAC__StreamEncoder *, FLAC__uint64 bytes_written, FLAC__uint64 samples_written, uint32_t frames_written, uint32_t total_frames_estimate, void *client_data);
 
 /* ---- string tables ------------------------------------------------------------------------------- */
+/* 1 if the library writes Ogg FLAC (FLAC/export.h:107): it does, see flac_amd/csrc/host/ogg.c */
+extern int FLAC_API_SUPPORTS_OGG_FLAC;
 extern const char * const FLAC__StreamEncoderStateString[];
 extern const char * const FLAC__StreamEncoderInitStatusString[];
 extern const char * const FLAC__StreamEncoderReadStatusString[];

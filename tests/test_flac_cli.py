@@ -111,3 +111,16 @@ def test_cxx_wrapper_client(tmp_path, level):
     assert data[:4] == b"OggS" and data[28:33] == b"\x7fFLAC" and int.from_bytes(data[14:18], "little") == 4711
     r = subprocess.run([CXX_REF, raw, out, str(level), "ogg"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0                     # UNSUPPORTED_CONTAINER: the reference build here has no libogg
+
+
+SUITE_GPU = os.path.join(REFDIR, "api_suite_gpu")
+
+
+@pytest.mark.skipif(not os.path.exists(SUITE_GPU), reason="oracle/_ref API suite not built")
+def test_reference_encoder_api_unit_test_passes_on_this_library(tmp_path):
+    """src/test_libFLAC/encoders.c -- the reference's own unit test of the FLAC__StreamEncoder API (every setter / getter, the four
+    init layers, process, process_interleaved, finish, verify on), compiled unmodified and linked against libFLACgpu.so; this
+    library exports FLAC_API_SUPPORTS_OGG_FLAC = 1, so the suite runs its Ogg FLAC half as well"""
+    r = subprocess.run([SUITE_GPU], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("PASSED!") == 8 and "format: Ogg FLAC" in r.stdout and "ENCODER API SUITE PASSED" in r.stdout
