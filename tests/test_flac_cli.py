@@ -124,3 +124,15 @@ def test_reference_encoder_api_unit_test_passes_on_this_library(tmp_path):
     r = subprocess.run([SUITE_GPU], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count("PASSED!") == 8 and "format: Ogg FLAC" in r.stdout and "ENCODER API SUITE PASSED" in r.stdout
+
+
+SUITE_CXX_GPU = os.path.join(REFDIR, "api_suite_cxx_gpu")
+
+
+@pytest.mark.skipif(not os.path.exists(SUITE_CXX_GPU), reason="oracle/_ref C++ API suite not built")
+def test_reference_cxx_encoder_api_unit_test_passes_on_this_library(tmp_path):
+    """src/test_libFLAC++/encoders.cpp on src/libFLAC++/stream_encoder.cpp -- the reference's unit test of FLAC::Encoder::Stream /
+    ::File, both compiled unmodified, linked against libFLACgpu.so; native FLAC and Ogg FLAC halves"""
+    r = subprocess.run([SUITE_CXX_GPU], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "C++ ENCODER API SUITE PASSED" in r.stdout and "Ogg FLAC" in r.stdout and "FAILED" not in r.stdout.replace("SUITE FAILED", "")
