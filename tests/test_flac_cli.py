@@ -136,3 +136,27 @@ def test_reference_cxx_encoder_api_unit_test_passes_on_this_library(tmp_path):
     r = subprocess.run([SUITE_CXX_GPU], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-3000:]
     assert "C++ ENCODER API SUITE PASSED" in r.stdout and "Ogg FLAC" in r.stdout and "FAILED" not in r.stdout.replace("SUITE FAILED", "")
+
+
+GEN = os.path.join(REFDIR, "test_streams")
+
+
+@needs_cli
+@pytest.mark.skipif(not os.path.exists(GEN), reason="oracle/_ref/test_streams not built")
+def test_baseline_config_1_through_the_tool(tmp_path):
+    """BASELINE.json configs[0]: the reference's generator writes sine16-02/03/04.raw, and
+    `flac -5 --force-raw-format --endian=little --sign=signed --channels=1 --bps=16 --sample-rate=44100` encodes them -- the same
+    tool on either library, identical files (49 frames each); plus the generator's full-scale, wasted-bits and noise streams with
+    the options of test/test_streams.sh"""
+    subprocess.run([GEN], cwd=str(tmp_path), check=True, capture_output=True, timeout=300)
+    fmt = ["--force-raw-format", "--endian=little", "--sign=signed", "--sample-rate=44100"]
+    jobs = [("sine16-%s.raw" % nn, ["-5", "--channels=1", "--bps=16"]) for nn in ("02", "03", "04")]
+    jobs += [("fsd%d-0%d.raw" % (bps, k), ["-0", "-l", "16", "--lax", "-m", "-e", "-p", "--channels=1", "--bps=%d" % bps]) for bps in (8, 16, 24, 32) for k in (1, 4, 7)]
+    jobs += [("wbps16-01.raw", ["-0", "-l", "16", "--lax", "-m", "-e", "-p", "--channels=1", "--bps=16"]),
+             ("sine24-13.raw", ["-0", "-l", "16", "--lax", "-m", "-e", "--channels=2", "--bps=24"]),
+             ("noise.raw", ["-8", "--channels=2", "--bps=16"])]
+    for name, args in jobs:
+        src = str(tmp_path / name)
+        want = _run(CLI_REF, args + fmt + [src], str(tmp_path / "ref.flac"))
+        got = _run(CLI_GPU, args + fmt + [src], str(tmp_path / "gpu.flac"))
+        assert got == want, name
