@@ -7,11 +7,15 @@
 
 /* the 64 steps unrolled, rounds as RFC 1321 section 3.4 writes them: the chain is serial, so the only speed there is
  * to be had is in not computing table indices and branches per step */
+/* b (the x argument) is the value that arrives last in every step: everything that does not depend on it is added to `a`
+ * first, and round 2 takes its selection apart -- (z & x) | (~z & y) has disjoint terms, so they can be ADDED separately and
+ * only (z & x) waits for x */
 #define F1(x, y, z) ((z) ^ ((x) & ((y) ^ (z))))
-#define F2(x, y, z) F1(z, x, y)
-#define F3(x, y, z) ((x) ^ (y) ^ (z))
+#define F3(x, y, z) ((x) ^ ((y) ^ (z)))
 #define F4(x, y, z) ((y) ^ ((x) | ~(z)))
-#define STEP(f, a, b, c, d, w, k, s) do { (a) += f((b), (c), (d)) + (w) + (k); (a) = ((a) << (s)) | ((a) >> (32 - (s))); (a) += (b); } while(0)
+#define ROL(v, s) (((v) << (s)) | ((v) >> (32 - (s))))
+#define STEP(f, a, b, c, d, w, k, s) do { (a) += (w) + (k); (a) += f((b), (c), (d)); (a) = ROL((a), (s)); (a) += (b); } while(0)
+#define STEP2(a, b, c, d, w, k, s) do { (a) += (w) + (k) + (~(d) & (c)); (a) += ((d) & (b)); (a) = ROL((a), (s)); (a) += (b); } while(0)
 
 static void md5_block(uint32_t st[4], const uint8_t *p)
 {
@@ -22,10 +26,10 @@ static void md5_block(uint32_t st[4], const uint8_t *p)
 	STEP(F1, a, b, c, d, w[4], 0xf57c0faf, 7);   STEP(F1, d, a, b, c, w[5], 0x4787c62a, 12);  STEP(F1, c, d, a, b, w[6], 0xa8304613, 17);  STEP(F1, b, c, d, a, w[7], 0xfd469501, 22);
 	STEP(F1, a, b, c, d, w[8], 0x698098d8, 7);   STEP(F1, d, a, b, c, w[9], 0x8b44f7af, 12);  STEP(F1, c, d, a, b, w[10], 0xffff5bb1, 17); STEP(F1, b, c, d, a, w[11], 0x895cd7be, 22);
 	STEP(F1, a, b, c, d, w[12], 0x6b901122, 7);  STEP(F1, d, a, b, c, w[13], 0xfd987193, 12); STEP(F1, c, d, a, b, w[14], 0xa679438e, 17); STEP(F1, b, c, d, a, w[15], 0x49b40821, 22);
-	STEP(F2, a, b, c, d, w[1], 0xf61e2562, 5);   STEP(F2, d, a, b, c, w[6], 0xc040b340, 9);   STEP(F2, c, d, a, b, w[11], 0x265e5a51, 14); STEP(F2, b, c, d, a, w[0], 0xe9b6c7aa, 20);
-	STEP(F2, a, b, c, d, w[5], 0xd62f105d, 5);   STEP(F2, d, a, b, c, w[10], 0x02441453, 9);  STEP(F2, c, d, a, b, w[15], 0xd8a1e681, 14); STEP(F2, b, c, d, a, w[4], 0xe7d3fbc8, 20);
-	STEP(F2, a, b, c, d, w[9], 0x21e1cde6, 5);   STEP(F2, d, a, b, c, w[14], 0xc33707d6, 9);  STEP(F2, c, d, a, b, w[3], 0xf4d50d87, 14);  STEP(F2, b, c, d, a, w[8], 0x455a14ed, 20);
-	STEP(F2, a, b, c, d, w[13], 0xa9e3e905, 5);  STEP(F2, d, a, b, c, w[2], 0xfcefa3f8, 9);   STEP(F2, c, d, a, b, w[7], 0x676f02d9, 14);  STEP(F2, b, c, d, a, w[12], 0x8d2a4c8a, 20);
+	STEP2(a, b, c, d, w[1], 0xf61e2562, 5);   STEP2(d, a, b, c, w[6], 0xc040b340, 9);   STEP2(c, d, a, b, w[11], 0x265e5a51, 14); STEP2(b, c, d, a, w[0], 0xe9b6c7aa, 20);
+	STEP2(a, b, c, d, w[5], 0xd62f105d, 5);   STEP2(d, a, b, c, w[10], 0x02441453, 9);  STEP2(c, d, a, b, w[15], 0xd8a1e681, 14); STEP2(b, c, d, a, w[4], 0xe7d3fbc8, 20);
+	STEP2(a, b, c, d, w[9], 0x21e1cde6, 5);   STEP2(d, a, b, c, w[14], 0xc33707d6, 9);  STEP2(c, d, a, b, w[3], 0xf4d50d87, 14);  STEP2(b, c, d, a, w[8], 0x455a14ed, 20);
+	STEP2(a, b, c, d, w[13], 0xa9e3e905, 5);  STEP2(d, a, b, c, w[2], 0xfcefa3f8, 9);   STEP2(c, d, a, b, w[7], 0x676f02d9, 14);  STEP2(b, c, d, a, w[12], 0x8d2a4c8a, 20);
 	STEP(F3, a, b, c, d, w[5], 0xfffa3942, 4);   STEP(F3, d, a, b, c, w[8], 0x8771f681, 11);  STEP(F3, c, d, a, b, w[11], 0x6d9d6122, 16); STEP(F3, b, c, d, a, w[14], 0xfde5380c, 23);
 	STEP(F3, a, b, c, d, w[1], 0xa4beea44, 4);   STEP(F3, d, a, b, c, w[4], 0x4bdecfa9, 11);  STEP(F3, c, d, a, b, w[7], 0xf6bb4b60, 16);  STEP(F3, b, c, d, a, w[10], 0xbebfbc70, 23);
 	STEP(F3, a, b, c, d, w[13], 0x289b7ec6, 4);  STEP(F3, d, a, b, c, w[0], 0xeaa127fa, 11);  STEP(F3, c, d, a, b, w[3], 0xd4ef3085, 16);  STEP(F3, b, c, d, a, w[6], 0x04881d05, 23);
