@@ -8,6 +8,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flacgpu_dev.h"
+// log() as the reference binary gets it from glibc 2.35 on an FMA host, restated operation by operation (not the device
+// library's log: a last-place difference could flip a comparison of the model search)
+#define FLACGPU_LOG_FN __device__ __forceinline__
+#define FLACGPU_LOG_TABQ static __device__ const
+#include "flacgpu_log.h"
 
 namespace flacgpu {
 
@@ -119,7 +124,7 @@ __device__ __forceinline__ double expected_bits_scaled(double lpc_error, double 
 {
 	if(lpc_error > 0.0) {
 		// 0.5*log(x)/M_LN2 folded by -freciprocal-math into log(x) * (0.5/ln 2)
-		double bps = log(error_scale * lpc_error) * 0.7213475204444817;
+		double bps = flacgpu_log(error_scale * lpc_error) * 0.7213475204444817;
 		return bps >= 0.0 ? bps : 0.0;
 	}
 	if(lpc_error < 0.0) return 1e32;
@@ -465,7 +470,7 @@ __device__ __forceinline__ int fir_mode(uint32_t wide, uint32_t sbps) { return w
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fixed_rbps(uint64_t e, uint32_t n4)
 {
-	return e ? (float)(log(((double)e * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
+	return e ? (float)(flacgpu_log(((double)e * 0.69314718055994530942) / (double)n4) * 1.4426950408889634) : 0.0f;
 }
 // invalid: bit k set = order k got 34 bits per sample from an overflow-checked estimator (fixed_intrin_avx2.c:172, fixed.c:360)
 __device__ __forceinline__ bool emit_fixed_candidates(const DevParams &P, Candidate *c0, int *v0, const uint64_t (&e)[5], uint32_t n4, uint32_t guess,

@@ -170,6 +170,12 @@ int flacgpu_set_subbatches(flacgpu_ctx *ctx, uint32_t n);
 void *flacgpu_alloc_pinned(size_t bytes);
 void flacgpu_free_pinned(void *p);
 
+/* Test hook (tests/test_log_pin.py): evaluates on the device, for n host arguments, mode 0 the engine's log (glibc 2.35's
+ * algorithm restated, flac_amd/csrc/flacgpu_log.h), mode 1 the expected-bits expression of lpc.c:1591-1606 on
+ * (lpc_error a, error_scale b), mode 2 the fixed-predictor estimate of fixed.c:284-288 on (total_error a, data_len b)
+ * widened to double, mode 3 the device library's own log (informational).  Returns 0 or a negative FLACGPU_ERR_*. */
+int flacgpu_debug_log_kat(int device, uint32_t mode, const double *a, const double *b, size_t n, double *out);
+
 const char *flacgpu_strerror(int code);
 int flacgpu_device_count(void);
 
