@@ -4,20 +4,25 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (flacgpu_encode_batch_device: analyze -> pack -> scan/compact)
-over one batch of synthetic PCM that is already resident in HBM.  With N > 1 every rank encodes its
-own contiguous frame range (weak scaling, no data-path collective) and the step ends with the ordered
-RCCL gather of the variable-length bitstream to rank 0 (flac_amd/dist.py).
+A "step" is one pass of the hot path (flacgpu_encode_batch_device: prep -> autocorrelation -> model -> evaluation ->
+pack, frames written back to back) over one batch of synthetic PCM that is already resident in HBM.  With N > 1 every
+rank encodes its own contiguous frame range (weak scaling, no data-path collective) and the steps' frames go to rank 0
+through the ordered RCCL gather of flac_amd/dist.py (GatherPipeline: sizes exchanged once per window of steps, the
+transfers of a window overlapped with the next window's encodes; rank 0 encodes straight into the gathered stream).
 
-Prints ONE JSON line (rank 0).  `value` = inter-channel samples encoded per second by the whole job,
-in M samples/s; `roofline` prices the dominant kernel of the step (by HIP-event time) against HBM bandwidth with the
-ALGORITHMIC bytes of SURVEY.md 8d (4*C bytes of PCM in + compressed bytes out per inter-channel
-sample); `cpu_baseline` is the unmodified reference libFLAC (oracle/_ref, AVX2+FMA dispatch) timed on
-this box's host cores on a bounded sample of the same signal.
+Prints ONE JSON line (rank 0).  `value` = inter-channel samples encoded per second by the whole job, in M samples/s;
+`roofline` prices the dominant kernel of the step (by HIP-event time) against HBM bandwidth with the ALGORITHMIC bytes
+of SURVEY.md 8d (4*C bytes of PCM in + compressed bytes out per inter-channel sample); `cpu_baseline` is the
+unmodified reference libFLAC (oracle/_ref, AVX2+FMA dispatch) timed on this box's host cores: one thread, one process
+per core, and the library's own thread pool.  After the timed region (outside it) the frames of the last step are
+checked: every CRC-16 recomputed on the host, and a sample of frames compared byte for byte with the oracle.
+N = 1 also reports two side measurements with the same harness: the white-noise corpus of SURVEY.md 8d config 3
+(`white_noise`) and the `flac` default preset (`level5`).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,74 +32,130 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-LEVEL = 8
 RATE, BPS, CH = 44100, 16, 2
-BLOCK = 4096
-FRAMES_PER_GPU = 16384         # 67.1 M inter-channel samples = 25 min of audio per GPU per step (2.7 GB of HBM in all)
+FRAMES_PER_GPU = 16384         # 67.1 M inter-channel samples = 25 min of audio per GPU per step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-KERNEL_NAMES = {"prep": "prep2_kernel", "autoc": "autoc2_kernel", "model": "model_kernel", "eval": "eval_kernel",
+KERNEL_NAMES = {"prep": "prep3_kernel", "autoc": "autoc2_kernel", "model": "model_kernel", "eval": "eval_kernel",
                 "pack": "pack2_kernel", "scan_compact": "scan_kernel+compact_kernel"}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
 
 
-def synth_pcm(nframes, seed):
-    """music-like 16-bit stereo (tests/signals.py: tones + coloured noise, channels correlated)"""
+def block_of(level):
+    return 1152 if level < 3 else 4096
+
+
+def synth_pcm(nframes, seed, block, kind="music"):
+    """music-like 16-bit stereo (tests/signals.py: tones + coloured noise, channels correlated), or i.i.d. uniform white
+    noise over the full 16-bit range"""
     import signals
+    if kind == "white":
+        rng = np.random.default_rng(seed)
+        return rng.integers(-32768, 32768, size=(nframes * block, CH), dtype=np.int32)
     base_frames = min(nframes, 512)
-    base = signals.music(base_frames * BLOCK, CH, BPS, seed=seed, rate=RATE)
+    base = signals.music(base_frames * block, CH, BPS, seed=seed, rate=RATE)
     reps = (nframes + base_frames - 1) // base_frames
     if reps > 1:
-        # repeat the 48 s clip with a per-repeat gain/offset so frames are not byte-identical
+        # repeat the clip with a per-repeat gain/offset so frames are not byte-identical
         parts = []
         for r in range(reps):
             g = 1.0 - 0.07 * (r % 8)
             parts.append(np.clip(np.rint(base * g) + (r % 5) - 2, -(1 << (BPS - 1)), (1 << (BPS - 1)) - 1).astype(np.int32))
         base = np.concatenate(parts, axis=0)
-    return np.ascontiguousarray(base[: nframes * BLOCK])
+    return np.ascontiguousarray(base[: nframes * block])
 
 
-def cpu_baseline(sample_pcm, search=None):
-    """Reference libFLAC on the host cores: single thread, then many independent encoders."""
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the unmodified reference on this box's host cores (test infrastructure: oracle/_ref)
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(level, search=None):
     from oracle import pyoracle as po
-    from concurrent.futures import ThreadPoolExecutor
-    n = sample_pcm.shape[0]
-    if po.have_ref():
-        kind = "reference"
-
-        def run():
-            return po.ref_encode(sample_pcm, BPS, RATE, LEVEL, want_bytes=False, **(search or {}))["seconds"]
-    else:
-        kind = "port"
-
-        def run():
-            t0 = time.perf_counter()
-            po.oracle_encode(sample_pcm, BPS, RATE, LEVEL, **(search or {}))
-            return time.perf_counter() - t0
-    best = min(run() for _ in range(3))
-    single = n / best / 1e6
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:     # ctypes releases the GIL: independent encoders in parallel
-        list(ex.map(lambda _: run(), range(threads * 2)))
-    multi = threads * 2 * n / (time.perf_counter() - t0) / 1e6
-    # the library's own frame-parallel thread pool (flac -j N, stream_encoder.c:2151) on one longer stream
-    pool = None
-    if kind == "reference":
-        try:
-            long_pcm = np.concatenate([sample_pcm] * 8, axis=0)
-            nthr = min(threads, 32)
-            sec = min(po.ref_encode(long_pcm, BPS, RATE, LEVEL, want_bytes=False, num_threads=nthr, **(search or {}))["seconds"] for _ in range(2))
-            pool = {"value": round(long_pcm.shape[0] / sec / 1e6, 3), "threads": nthr, "how": "one stream, FLAC__stream_encoder_set_num_threads"}
-        except Exception as e:           # a reference build without threads
-            pool = {"error": str(e)}
+    rate_bin = os.path.join(ROOT, "oracle", "_ref", "ref_rate")
+    if not (po.have_ref() and os.path.exists(rate_bin)) or (search and any(search.values())):
+        # no reference build on this box (or a search the rate program has no switch for): time the library in-process on a short clip
+        pcm = synth_pcm(512 if not (search and any(search.values())) else 64, 99, block_of(level))
+
+        def run():
+            if po.have_ref():
+                return po.ref_encode(pcm, BPS, RATE, level, want_bytes=False, **(search or {}))["seconds"]
+            t0 = time.perf_counter()
+            po.oracle_encode(pcm, BPS, RATE, level, **(search or {}))
+            return time.perf_counter() - t0
+        best = min(run() for _ in range(3))
+        return {"value": round(pcm.shape[0] / best / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "reference" if po.have_ref() else "port",
+                "sample": "%d inter-channel samples of the bench signal, flac -%d, best of 3, in-memory" % (pcm.shape[0], level), "host_cpus": cores}
+    # >= 10 minutes of the bench signal as a raw 16-bit file on tmpfs (SURVEY.md 8d: input from tmpfs, output discarded)
+    clip = synth_pcm(6460, 4321, 4096).astype(np.int16)                                     # 10.0 min
+    nsamp = clip.shape[0]
+    raw = "/dev/shm/flacgpu_bench_%d.raw" % os.getpid()
+    clip.tofile(raw)
+    try:
+        def one(threads, reps):
+            o = subprocess.check_output([rate_bin, raw, str(level), str(threads), str(reps)]).decode().split()
+            return float(o[2]), float(o[3])                       # total seconds, best seconds
+        _, best1 = one(1, 3)
+        single = nsamp / best1 / 1e6
+        # (3) of SURVEY 8d: one independent single-thread process per host CPU, three encodes each, all started together
+        reps = 3
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([rate_bin, raw, str(level), "1", str(reps)], stdout=subprocess.PIPE) for _ in range(cores)]
+        outs = [p.communicate()[0].decode().split() for p in procs]
+        wall = time.perf_counter() - t0
+        allcores = cores * reps * nsamp / wall / 1e6
+        inside = cores * reps * nsamp / max(float(o[2]) for o in outs) / 1e6       # without process start-up / file read
+        # (2): the library's own frame-parallel thread pool (flac -j N) at several thread counts, best of 3 each
+        pool = {}
+        for thr in sorted(set(t for t in (8, 16, 32, 64, min(cores, 128)) if t <= max(cores, 8))):
+            try:
+                pool[thr] = round(nsamp / one(thr, 3)[1] / 1e6, 2)
+            except Exception as e:                                     # a reference build without threads
+                pool[thr] = str(e)
+        nums = {k: v for k, v in pool.items() if isinstance(v, float)}
+        best_thr = max(nums, key=nums.get) if nums else None
+    finally:
+        os.unlink(raw)
     return {
-        "value": round(single, 3), "unit": "Msamples/s", "cores": 1, "kind": kind,
-        "sample": "%d inter-channel samples (%.0f s) of the bench signal, flac -%d, best of 3, in-memory" % (n, n / RATE, LEVEL),
-        "multi": {"value": round(multi, 3), "cores": threads, "how": "independent single-thread encoders, 2 clips each"},
-        "library_thread_pool": pool,
+        "value": round(single, 3), "unit": "Msamples/s", "cores": 1, "kind": "reference",
+        "sample": "%d inter-channel samples (%.1f min) of the bench signal from a raw file on tmpfs, flac -%d with MD5, output discarded, best of 3" % (nsamp, nsamp / RATE / 60, level),
+        "all_cores": {"value": round(inside, 2), "value_incl_process_start": round(allcores, 2), "cores": cores,
+                      "how": "%d independent single-thread processes x %d encodes of the clip each, started together; value = all samples / the slowest process's encode time (the better figure for the CPU)" % (cores, reps)},
+        "library_thread_pool": {"by_threads": pool, "best_threads": best_thr, "value": nums.get(best_thr), "how": "one stream, FLAC__stream_encoder_set_num_threads, best of 3"},
         "host_cpus": cores,
     }
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# after the timed region: the frames of the last step, checked
+# ------------------------------------------------------------------------------------------------------------------
+def verify_step(pcm_h, out_bytes, fb, first_frame, level, block, nsample=96, search=None):
+    """every CRC-16 recomputed on the host; `nsample` frames (the ends of the batch, the XCD remap boundaries, random ones)
+    re-encoded by the oracle with their frame number and compared byte for byte"""
+    import ctypes as C
+    import flac_amd
+    from oracle import pyoracle as po
+    host = flac_amd.engine.load_host()
+    host.flacgpu_host_check_frame_crcs.restype = C.c_int64
+    host.flacgpu_host_check_frame_crcs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    nframes = fb.size
+    fb32 = np.ascontiguousarray(fb.astype(np.uint32))
+    assert int(fb32.sum()) == out_bytes.size, "frame lengths do not add up to the byte total"
+    bad = int(host.flacgpu_host_check_frame_crcs(out_bytes.ctypes.data, fb32.ctypes.data, nframes, min(32, os.cpu_count() or 1)))
+    offs = np.concatenate([[0], np.cumsum(fb32.astype(np.int64))])
+    rng = np.random.default_rng(5)
+    picks = {0, 1, nframes - 1, nframes - 2, nframes // 2}
+    per_xcd = nframes // 8
+    for x in range(1, 8):
+        picks.update((x * per_xcd - 1, x * per_xcd))
+    picks.update(int(v) for v in rng.integers(0, nframes, nsample))
+    picks = sorted(p for p in picks if 0 <= p < nframes)
+    mism = []
+    for f in picks:
+        want = po.oracle_encode(pcm_h[f * block:(f + 1) * block], BPS, RATE, level, first_frame=first_frame + f, **(search or {}))["data"]
+        got = out_bytes[offs[f]:offs[f + 1]].tobytes()
+        if got != want:
+            mism.append(f)
+    return {"crc16_frames_checked": nframes, "crc16_first_bad_frame": bad, "frames_compared_with_oracle": len(picks), "frames_differing": mism,
+            "ok": bad == -1 and not mism}
 
 
 def main():
@@ -104,20 +165,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the white-noise and -5 side measurements")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the last step's frames (outside the timed region)")
     ap.add_argument("--hires", action="store_true", help="96 kHz / 24-bit stereo (BASELINE.json config 4): a side measurement")
+    ap.add_argument("--white", action="store_true", help="white-noise corpus as the main measurement (side measurement)")
     ap.add_argument("--exhaustive", action="store_true", help="flac -8e: not the headline workload, a side measurement")
     ap.add_argument("--prec-search", action="store_true", help="flac -8p")
     ap.add_argument("--level", type=int, default=8, help="compression preset -0..-8 (the metric is quoted at -8: other levels are side measurements; "
                     "-0..-2 use the preset's 1152-sample blocks)")
-    ap.add_argument("--force-dist", action="store_true", help="development aid: run the multi-rank pipeline (process group, "
-                    "overlapped ordered gather) even with one rank")
+    ap.add_argument("--window", type=int, default=4, help="multi-rank: steps per gather window")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank pipeline (process group, windowed ordered gather) even with one rank")
     args = ap.parse_args()
-    global RATE, BPS, LEVEL, BLOCK
+    global RATE, BPS
     if args.hires:
         RATE, BPS = 96000, 24
-    if args.level != 8:
-        LEVEL = args.level
-        BLOCK = 1152 if LEVEL < 3 else 4096
+    LEVEL = args.level
+    BLOCK = block_of(LEVEL)
 
     # stdout must carry exactly one JSON line: libraries underneath (RCCL prints a version banner from C) get stderr
     sys.stdout.flush()
@@ -127,7 +190,7 @@ def main():
     import torch
     import torch.distributed as dist
     import flac_amd
-    from flac_amd.dist import ordered_gather
+    from flac_amd.dist import GatherPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -144,58 +207,6 @@ def main():
 
     nframes = args.frames
     search = dict(exhaustive=int(args.exhaustive), prec_search=int(args.prec_search))
-    settings = flac_amd.make_settings(CH, BPS, RATE, LEVEL, **search)
-    eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=nframes)
-
-    # this rank's shard of the corpus: frames [rank*nframes, (rank+1)*nframes)
-    pcm_h = synth_pcm(nframes, seed=1234 + rank)
-    d_pcm = torch.from_numpy(pcm_h).to(dev)
-    cap = eng.max_output_bytes(nframes)
-    first_frame = rank * nframes
-    phase_ms = []
-
-    if not multi:
-        d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-        d_fb = torch.empty(nframes, dtype=torch.int32, device=dev)
-        d_total = torch.zeros(1, dtype=torch.int64, device=dev)
-        enc_stream = torch.cuda.Stream()
-
-        def run(nsteps):
-            for _ in range(nsteps):
-                eng.encode_device(d_pcm.data_ptr(), nframes, d_out.data_ptr(), cap, d_fb.data_ptr(), d_total.data_ptr(),
-                                  first_frame_number=first_frame, stream=enc_stream.cuda_stream)
-    else:
-        # Two output buffers: the ordered RCCL gather of step k (its own stream) overlaps the encode of step k+1.
-        # Only the gather's stream is ever synchronised with the host (for the byte count it has to send).
-        enc_stream, comm_stream = torch.cuda.Stream(), torch.cuda.Stream()
-        bufs = [{"out": torch.empty(cap, dtype=torch.uint8, device=dev), "fb": torch.empty(nframes, dtype=torch.int32, device=dev),
-                 "total": torch.zeros(1, dtype=torch.int64, device=dev), "enc_done": torch.cuda.Event(), "free": torch.cuda.Event(),
-                 "used": False} for _ in range(2)]
-        d_total = bufs[0]["total"]
-
-        def launch_encode(k):
-            b = bufs[k % 2]
-            if b["used"]:
-                enc_stream.wait_event(b["free"])        # the gather that read this buffer is done
-            eng.encode_device(d_pcm.data_ptr(), nframes, b["out"].data_ptr(), cap, b["fb"].data_ptr(), b["total"].data_ptr(),
-                              first_frame_number=first_frame, stream=enc_stream.cuda_stream)
-            b["enc_done"].record(enc_stream)
-            b["used"] = True
-
-        def gather(k):
-            b = bufs[k % 2]
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(b["enc_done"])
-                nbytes = int(b["total"].item())          # host waits for encode k only; encode k+1 is already queued
-                ordered_gather(b["out"], nbytes, b["fb"], dst=0)
-                b["free"].record(comm_stream)
-
-        def run(nsteps):
-            launch_encode(0)
-            for k in range(1, nsteps):
-                launch_encode(k)
-                gather(k - 1)
-            gather(nsteps - 1)
 
     def sync():
         torch.cuda.synchronize()
@@ -203,69 +214,153 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup:
-        run(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    run(args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    # per-kernel durations of the timed steps: HIP events the engine recorded on its stream around every launch (it keeps
-    # the sets of its last 64 batches, so nothing had to sync inside the timed region)
-    for back in range(min(args.steps, 64)):
-        phase_ms.append(eng.last_phase_ms(back))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(level, kind, steps, warmup, use_dist):
+        """K timed steps of one configuration; returns the numbers and what the verification needs"""
+        block = block_of(level)
+        settings = flac_amd.make_settings(CH, BPS, RATE, level, **search)
+        eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=nframes)
+        if args.hires:
+            import signals
+            pcm_h = np.ascontiguousarray(signals.music(nframes * block, CH, BPS, seed=1234 + rank, rate=RATE))
+        else:
+            pcm_h = synth_pcm(nframes, 1234 + rank, block, kind)
+        d_pcm = torch.from_numpy(pcm_h).to(dev)
+        cap = eng.max_output_bytes(nframes)
+        first_frame = rank * nframes
+        if not use_dist:
+            d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+            d_fb = torch.empty(nframes, dtype=torch.int32, device=dev)
+            d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+            enc_stream = torch.cuda.Stream()
+            gp = None
 
-    total_bytes = int(d_total.item())
-    samples_per_step = nframes * BLOCK
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * samples_per_step * args.steps / elapsed / 1e6
+            def run(nsteps):
+                for _ in range(nsteps):
+                    eng.encode_device(d_pcm.data_ptr(), nframes, d_out.data_ptr(), cap, d_fb.data_ptr(), d_total.data_ptr(),
+                                      first_frame_number=first_frame, stream=enc_stream.cuda_stream)
+        else:
+            gp = GatherPipeline(cap, nframes, dev, window=args.window)
+            state = {"k": 0}
+
+            def run(nsteps):
+                k0 = state["k"]
+                for k in range(k0, k0 + nsteps):
+                    gp.wait_slot_free(k)
+                    out, fbt, tot = gp.slot(k)
+                    eng.encode_device(d_pcm.data_ptr(), nframes, out.data_ptr(), cap, fbt.data_ptr(), tot.data_ptr(),
+                                      first_frame_number=first_frame, stream=gp.enc_stream.cuda_stream)
+                    gp.step_done(k)
+                gp.flush()
+                # the next call starts on a window boundary
+                state["k"] = ((k0 + nsteps + gp.K - 1) // gp.K) * gp.K
+
+        if warmup:
+            run(warmup)
+        sync()
+        t0 = time.perf_counter()
+        run(steps)
+        sync()
+        elapsed = time.perf_counter() - t0
+        # per-kernel durations of the timed steps: HIP events the engine recorded on its stream around every launch (it keeps
+        # the sets of its last 64 batches, so nothing had to sync inside the timed region)
+        phase_ms = [eng.last_phase_ms(back) for back in range(min(steps, 64))]
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        res = {"elapsed": elapsed, "steps": steps, "block": block, "level": level, "kind": kind}
+        if rank == 0:
+            if gp is None:
+                total_bytes = int(d_total.item())
+                out_h = d_out[:total_bytes].cpu().numpy()
+                fb_h = d_fb.cpu().numpy()
+            else:
+                k_last = state["k"] - 1 if (steps % gp.K == 0) else (state["k"] - gp.K + steps % gp.K - 1)
+                stream, sizes, fbs = gp.gathered(k_last)
+                total_bytes = sizes[0]
+                out_h = stream[:total_bytes].cpu().numpy()            # rank 0's own frames: the head of the gathered stream
+                fb_h = fbs[0].cpu().numpy()
+                res["gathered_bytes_last_step"] = int(sum(sizes))
+                res["host_syncs"] = gp.host_syncs
+            kms = {k: float(np.mean([ph[k] for ph in phase_ms])) for k in phase_ms[0]}
+            samples_per_step = nframes * block
+            out_bps = total_bytes / samples_per_step
+            alg_bytes = samples_per_step * (4 * CH + out_bps)         # SURVEY 8d: PCM read once + frames written once
+            dom = max(kms, key=kms.get)
+            achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
+            traffic = None
+            try:
+                with open(PMC_FILE) as fh:
+                    pmc = json.load(fh)
+                for name in KERNEL_NAMES[dom].split("+"):
+                    if name in pmc["kernels"]:
+                        traffic = (traffic or 0) + int(pmc["kernels"][name]["hbm_bytes_per_frame"] * nframes)
+            except Exception:
+                pass
+            res.update(value=world * samples_per_step * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=kms, out_bps=out_bps,
+                       roofline={"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
+                                 "whole_step_frac": round(alg_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 6)})
+            if not args.no_verify:
+                res["verified"] = verify_step(pcm_h, out_h, fb_h, first_frame, level, block, search=search)
+        eng.close()
+        del d_pcm
+        torch.cuda.empty_cache()
+        return res
+
+    main_kind = "white" if args.white else "music"
+    m = measure(LEVEL, main_kind, args.steps, args.warmup, multi)
+    extras = {}
+    if world == 1 and not multi and not args.no_extras and LEVEL == 8 and not args.hires and not args.white and not any(search.values()):
+        side_steps = max(3, args.steps // 2)
+        w = measure(8, "white", side_steps, 1, False)
+        l5 = measure(5, "music", side_steps, 1, False)
+        if rank == 0:
+            for key, r, what in (("white_noise", w, "flac -8 on i.i.d. uniform 16-bit stereo white noise (SURVEY.md 8d config 3 (i)): the 32-bit side-channel path, the largest frames"),
+                                 ("level5", l5, "flac -5 (the tool's default preset) on the music-like signal")):
+                extras[key] = {"what": what, "value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"],
+                               "compressed_bytes_per_sample": round(r["out_bps"], 4), "kernel_ms": {k: round(v, 4) for k, v in r["kernel_ms"].items()},
+                               "roofline": r["roofline"], "verified_frames": r.get("verified", {}).get("frames_compared_with_oracle"),
+                               "verified_ok": r.get("verified", {}).get("ok")}
 
     if rank == 0:
-        out_bps = total_bytes / samples_per_step                 # compressed bytes per inter-channel sample
-        alg_bytes = samples_per_step * (4 * CH + out_bps)         # PCM read once + frames written once
-        kms = {k: float(np.mean([ph[k] for ph in phase_ms])) for k in phase_ms[0]}
-        dom = max(kms, key=kms.get)                               # the dominant kernel of the step
-        achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
-        traffic = None
-        try:
-            with open(PMC_FILE) as fh:
-                pmc = json.load(fh)
-            per_frame = pmc["kernels"][KERNEL_NAMES[dom]]["hbm_bytes_per_frame"]
-            traffic = int(per_frame * nframes)
-        except Exception:
-            pass
+        sig = "white noise" if args.white else "music-like synthetic PCM"
         line = {
             "metric": ("encode Msamples/s at -8, 44.1k/16-bit stereo; bit-exact vs libFLAC" if not args.hires else "encode Msamples/s at -8, 96k/24-bit stereo (side measurement)")
                       if LEVEL == 8 else "encode Msamples/s at -%d (side measurement; the metric is quoted at -8)" % LEVEL,
-            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(m["value"], 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(m["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": "flac -%d%s%s (%s) on %s stereo, "
-                                   "%d frames x %d samples per GPU per step, music-like synthetic PCM resident in HBM" % (LEVEL, "e" if args.exhaustive else "", "p" if args.prec_search else "",
+                                   "%d frames x %d samples per GPU per step, %s resident in HBM" % (LEVEL, "e" if args.exhaustive else "", "p" if args.prec_search else "",
                                    "max LPC order 12, subdivide_tukey(3), mid/side, partition order <= 6" if LEVEL == 8 else "the preset's settings, stream_encoder.c:117-140",
-                                   "96k/24-bit" if args.hires else "44.1k/16-bit", nframes, BLOCK),
-                       "frames_per_gpu_per_step": nframes, "blocksize": BLOCK, "channels": CH, "bits_per_sample": BPS,
-                       "samples_are": "inter-channel (x2 for channel-samples)", "parallelism": "frame-shard x%d + ordered RCCL gather of every step's frames to rank 0, overlapped with the next step's encode" % world,
-                       "compressed_bytes_per_sample": round(out_bps, 4)},
-            "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "-8 is VALU bound (~1e3 integer+fp64 ops per sample; the dominant kernels issue VALU work 77-83% of their cycles, "
-                                 "profiles/*pmc*); the HBM fraction is reported because the north star asks for it; traffic = FETCH_SIZE+WRITE_SIZE "
-                                 "of the committed PMC pass scaled to this batch"},
+                                   "96k/24-bit" if args.hires else "44.1k/16-bit", nframes, m["block"], sig),
+                       "frames_per_gpu_per_step": nframes, "blocksize": m["block"], "channels": CH, "bits_per_sample": BPS,
+                       "samples_are": "inter-channel (x2 for channel-samples)",
+                       "parallelism": ("frame-shard x%d + ordered RCCL gather of every step's frames to rank 0 (sizes exchanged once per window of %d steps, "
+                                       "transfers overlapped with the next window's encodes, rank 0 encodes in place)" % (world, args.window)) if multi else "one GPU, no process group",
+                       "compressed_bytes_per_sample": round(m["out_bps"], 4)},
+            "kernel_ms": {k: round(v, 4) for k, v in m["kernel_ms"].items()},
+            "roofline": dict(m["roofline"], note="-8 is VALU bound (~1e3 integer+fp64 ops per sample; the dominant kernels issue VALU work ~80% of their cycles, "
+                                                 "profiles/*pmc*); the HBM fraction is reported because the north star asks for it; traffic = (2*FETCH_SIZE+WRITE_SIZE) "
+                                                 "of the committed PMC pass scaled to this batch; whole_step_frac prices the whole step instead of its dominant kernel"),
         }
+        if "verified" in m:
+            line["verified_frames"] = m["verified"]["frames_compared_with_oracle"]
+            line["verified"] = m["verified"]
+        if multi:
+            line["gather"] = {"bytes_gathered_last_step": m.get("gathered_bytes_last_step"), "host_reads_of_sizes": m.get("host_syncs"), "window": args.window}
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pcm_h[: (512 if not (args.exhaustive or args.prec_search) else 64) * BLOCK], search)
-            line["speedup_vs_cpu_1thread"] = round(value / line["cpu_baseline"]["value"], 2)
-            line["speedup_vs_cpu_multi"] = round(value / line["cpu_baseline"]["multi"]["value"], 2)
+            cb = cpu_baseline(LEVEL, search)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_1thread"] = round(m["value"] / cb["value"], 2)
+            if "all_cores" in cb:
+                line["speedup_vs_cpu_allcores"] = round(m["value"] / cb["all_cores"]["value"], 2)
+                if cb["library_thread_pool"]["value"]:
+                    line["speedup_vs_cpu_library_pool"] = round(m["value"] / cb["library_thread_pool"]["value"], 2)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
-    eng.close()
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,280 @@
+"""flac_amd.corpus -- batch encode of a long corpus into ONE .flac, sharded over the GPUs of a node
+(BASELINE.json config 5: `flac -8` on 10 h of 44.1 kHz/16-bit stereo, RCCL gather).
+
+Every rank takes the contiguous frame range shard_range() gives it, with the frame numbers fixed up front
+(frames are independent: stream_encoder.c:3778-3807 made even the loose mid/side decision per frame), stages its
+shard from raw 16-bit file bytes on the device (flacgpu_stage_raw_device), encodes it in batches
+(flacgpu_encode_batch_device) into one device buffer, and the job ends with the ordered gather of the bitstream:
+    --gather rccl   flac_amd.dist.ordered_gather: point-to-point RCCL transfers to rank 0's HBM (the north star's form)
+    --gather host   flac_amd.dist.HostShmGather: every rank copies its shard over its own PCIe link into one shared
+                    pinned host buffer at the scanned offset
+Rank 0 then writes the stream the way FLAC__stream_encoder_finish leaves a file (stream_encoder.c:3139-3246):
+"fLaC", STREAMINFO with min/max frame size, total samples and the MD5 of the interleaved input (computed by a host
+thread while the GPUs work: one serial chain, md5.c:497), the VORBIS_COMMENT block with the vendor string, the frames.
+
+    python -m flac_amd.corpus --hours 10 --out /tmp/corpus.flac
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m flac_amd.corpus --hours 10 ...
+
+Prints one JSON line (rank 0).  The synthetic corpus is a 512-frame music-like clip repeated with an integer gain /
+offset per repetition (integer arithmetic only, so that the device and the host produce the same samples).
+"""
+import argparse
+import hashlib
+import json
+import os
+import struct
+import sys
+import threading
+import time
+
+import numpy as np
+
+RATE, BPS, CH, BLOCK = 44100, 16, 2, 4096
+BASE_FRAMES = 512
+VENDOR = b"reference libFLAC 1.5.0 20250211"        # format.c:57 (the host API writes the same string, host/stream_encoder.c)
+
+
+def base_clip(seed=1234):
+    """the 48 s clip the corpus is made of: int16 [BASE_FRAMES*BLOCK, 2] (tests/signals.py: tones + coloured noise)"""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "tests"))
+    import signals
+    return np.ascontiguousarray(signals.music(BASE_FRAMES * BLOCK, CH, BPS, seed=seed, rate=RATE).astype(np.int16))
+
+
+def rep_params(rep):
+    """gain numerator (/256) and offset of repetition `rep` of the clip"""
+    return 256 - 18 * (rep % 8), (rep % 5) - 2
+
+
+def host_frames(base, f0, f1):
+    """frames [f0, f1) of the corpus as int16 [(f1-f0)*BLOCK, 2] (numpy, integer arithmetic)"""
+    out = np.empty(((f1 - f0) * BLOCK, CH), dtype=np.int16)
+    f = f0
+    while f < f1:
+        rep, b0 = divmod(f, BASE_FRAMES)
+        nb = min(BASE_FRAMES - b0, f1 - f)
+        g, o = rep_params(rep)
+        x = base[b0 * BLOCK:(b0 + nb) * BLOCK].astype(np.int32)
+        y = np.clip(((x * g) >> 8) + o, -32768, 32767).astype(np.int16)
+        out[(f - f0) * BLOCK:(f - f0 + nb) * BLOCK] = y
+        f += nb
+    return out
+
+
+def device_frames(base_dev, f0, f1, out):
+    """the same on the device (torch int32 arithmetic), into out: int16 [(f1-f0)*BLOCK, 2]"""
+    import torch
+    f = f0
+    while f < f1:
+        rep, b0 = divmod(f, BASE_FRAMES)
+        nb = min(BASE_FRAMES - b0, f1 - f)
+        g, o = rep_params(rep)
+        x = base_dev[b0 * BLOCK:(b0 + nb) * BLOCK].to(torch.int32)
+        y = torch.clamp(torch.bitwise_right_shift(x * g, 8) + o, -32768, 32767).to(torch.int16)
+        out[(f - f0) * BLOCK:(f - f0 + nb) * BLOCK] = y
+        f += nb
+
+
+def stream_header(total_samples, min_frame, max_frame, md5):
+    """"fLaC" + STREAMINFO + the default VORBIS_COMMENT, as init_stream writes and finish patches them
+    (stream_encoder.c:1335-1425, 3139-3246; stream_encoder_framing.c:46-243)"""
+    si = struct.pack(">HH", BLOCK, BLOCK) + min_frame.to_bytes(3, "big") + max_frame.to_bytes(3, "big")
+    si += ((RATE << 44) | ((CH - 1) << 41) | ((BPS - 1) << 36) | (total_samples if total_samples < (1 << 36) else 0)).to_bytes(8, "big")
+    si += md5
+    assert len(si) == 34
+    vc = struct.pack("<I", len(VENDOR)) + VENDOR + struct.pack("<I", 0)
+    return b"fLaC" + bytes([0]) + len(si).to_bytes(3, "big") + si + bytes([0x80 | 4]) + len(vc).to_bytes(3, "big") + vc
+
+
+def encode_shard(eng, base_dev, lo, hi, batch_frames, dev, out, fb_all, enc_stream, last_frame=-1, tail=0):
+    """Stage + encode frames [lo, hi) in batches.  out: uint8 device buffer for the whole shard, fb_all: int32 [hi-lo].
+    Frame `last_frame` (the last of the stream) has only `tail` samples when tail != 0.
+    Returns the shard's byte total (host int; one host read per batch: the next batch's offset)."""
+    import torch
+    import flac_amd
+    fmt = flac_amd.raw_format(16)
+    raw = torch.empty((batch_frames * BLOCK, CH), dtype=torch.int16, device=dev)
+    pcm = torch.empty((batch_frames * BLOCK, CH), dtype=torch.int32, device=dev)
+    total_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    off = 0
+    f = lo
+    with torch.cuda.stream(enc_stream):
+        while f < hi:
+            nf = min(batch_frames, hi - f)
+            device_frames(base_dev, f, f + nf, raw)
+            short = tail if (tail and f + nf - 1 == last_frame) else 0
+            eng.stage_raw_device(raw.data_ptr(), fmt, nf * BLOCK - (BLOCK - short if short else 0), pcm.data_ptr(), None, enc_stream.cuda_stream)
+            eng.encode_device(pcm.data_ptr(), nf, out.data_ptr() + off, out.numel() - off, fb_all.data_ptr() + 4 * (f - lo), total_t.data_ptr(),
+                              first_frame_number=f, tail=short, stream=enc_stream.cuda_stream)
+            off += int(total_t.item())
+            f += nf
+    return off
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hours", type=float, default=10.0)
+    ap.add_argument("--samples", type=int, default=0, help="corpus length in inter-channel samples (overrides --hours); a last short block is encoded as such")
+    ap.add_argument("--batch-frames", type=int, default=16384)
+    ap.add_argument("--level", type=int, default=8)
+    ap.add_argument("--gather", choices=("rccl", "host"), default="rccl")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--no-md5", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the process-group path with one rank too")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args(argv)
+
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)                      # C-level banners (RCCL) must not land on the JSON line
+    import torch
+    import torch.distributed as dist
+    import flac_amd
+    from flac_amd.dist import shard_range, ordered_gather, HostShmGather
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("flac_amd.corpus needs a GPU: there is no CPU encode path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    multi = world > 1 or args.force_dist
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    total_samples = args.samples or int(round(args.hours * 3600 * RATE))
+    F = (total_samples + BLOCK - 1) // BLOCK                    # 10 h: 387598 frames, the last one 2688 samples short of a block
+    tail = total_samples - (F - 1) * BLOCK
+    tail = 0 if tail == BLOCK else tail
+    lo, hi = shard_range(F, world, rank)
+    nloc = hi - lo
+    base = base_clip(args.seed)
+    base_dev = torch.from_numpy(base).to(dev)
+
+    # the stream MD5: one serial chain over the whole interleaved input, on a host thread of rank 0, while the GPUs work
+    md5_box = {}
+
+    def md5_thread():
+        t0 = time.perf_counter()
+        h = hashlib.md5()
+        cache = {}                                         # the (gain, offset) pairs repeat with period 40
+        for f in range(0, F, BASE_FRAMES):
+            nb = min(BASE_FRAMES, F - f)
+            key = rep_params(f // BASE_FRAMES)
+            if key not in cache:
+                cache[key] = host_frames(base, f, f + BASE_FRAMES).tobytes()
+            h.update(memoryview(cache[key])[:min(nb * BLOCK, total_samples - f * BLOCK) * CH * 2])
+        md5_box["digest"] = h.digest()
+        md5_box["seconds"] = time.perf_counter() - t0
+
+    th = None
+    if rank == 0 and not args.no_md5:
+        th = threading.Thread(target=md5_thread)
+        th.start()
+
+    settings = flac_amd.make_settings(CH, BPS, RATE, args.level)
+    bf = min(args.batch_frames, max(nloc, 1))
+    eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=bf)
+    cap_frame = eng.max_output_bytes(1)
+    # the shard's frames land back to back; size the buffer for the measured density plus the worst case of one batch
+    shard_cap = nloc * 3 * BLOCK * CH // 2 + eng.max_output_bytes(bf) if nloc else 16
+    out = torch.empty(shard_cap, dtype=torch.uint8, device=dev)
+    fb_all = torch.zeros(max(nloc, 1), dtype=torch.int32, device=dev)
+    enc_stream = torch.cuda.Stream()
+    gat = None
+    if multi and args.gather == "host":
+        gat = HostShmGather(F * 3 * BLOCK * CH // 2 + (1 << 20))
+
+    def sync():
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: module load, RCCL channels
+    if nloc:
+        encode_shard(eng, base_dev, lo, min(hi, lo + min(64, nloc)), bf, dev, out, fb_all, enc_stream, F - 1, tail)
+    sync()
+    t0 = time.perf_counter()
+    nbytes = encode_shard(eng, base_dev, lo, hi, bf, dev, out, fb_all, enc_stream, F - 1, tail) if nloc else 0
+    enc_stream.synchronize()
+    t_enc = time.perf_counter() - t0
+    stream_t = allfb = None
+    host_stream = None
+    if multi and args.gather == "rccl":
+        stream_t, allfb = ordered_gather(out, nbytes, fb_all[:nloc], dst=0)
+    elif multi:
+        off, sizes = gat.gather(out, nbytes)
+        # the frame lengths are small: they still go through the collective
+        _, allfb = ordered_gather(out[:0], 0, fb_all[:nloc], dst=0)
+        if rank == 0:
+            host_stream = gat.host[:sum(sizes)]
+    else:
+        stream_t, allfb = out[:nbytes], fb_all[:nloc].to(torch.int64)
+    sync()
+    t_job = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([t_job, t_enc], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_job, t_enc = float(t[0]), float(t[1])
+
+    line = None
+    if rank == 0:
+        tw0 = time.perf_counter()
+        fbs = allfb.cpu().numpy().astype(np.uint32)
+        if host_stream is None:
+            host_stream = stream_t.cpu()
+        data = host_stream.numpy()
+        t_d2h = time.perf_counter() - tw0
+        assert fbs.size == F and int(fbs.sum()) == data.size
+        # every frame's CRC-16 rechecked on the host (crc.c:376 over the whole frame incl. header)
+        import ctypes as C
+        host = flac_amd.engine.load_host()
+        host.flacgpu_host_check_frame_crcs.restype = C.c_int64
+        host.flacgpu_host_check_frame_crcs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        tc0 = time.perf_counter()
+        bad = host.flacgpu_host_check_frame_crcs(data.ctypes.data, fbs.ctypes.data, F, min(32, os.cpu_count() or 1))
+        t_crc = time.perf_counter() - tc0
+        if th:
+            th.join()
+        digest = md5_box.get("digest", bytes(16))
+        header = stream_header(total_samples, int(fbs.min()), int(fbs.max()), digest)
+        t_write = None
+        if args.out:
+            tw = time.perf_counter()
+            with open(args.out, "wb") as f:
+                f.write(header)
+                f.write(memoryview(data))
+            t_write = time.perf_counter() - tw
+        samples = total_samples
+        line = {
+            "job": "flac -%d batch encode of a %.2f h synthetic 44.1k/16-bit stereo corpus into one stream" % (args.level, samples / RATE / 3600),
+            "n_gpus": world, "frames": F, "samples": samples, "stream_bytes": int(data.size) + len(header),
+            "compressed_bytes_per_sample": round(data.size / samples, 4),
+            "gather": ("ordered RCCL send/recv to rank 0" if args.gather == "rccl" else "device->shared pinned host buffer, every rank over its own PCIe link") if multi else "none (one rank, no process group)",
+            "encode_gather_seconds": round(t_job, 4), "encode_seconds": round(t_enc, 4),
+            "Msamples_per_s": round(samples / t_job / 1e6, 1),
+            "crc16_bad_frame": int(bad), "crc16_frames_checked": F, "crc16_seconds": round(t_crc, 3),
+            "md5": digest.hex(), "md5_seconds": round(md5_box.get("seconds", 0.0), 2),
+            "d2h_seconds": round(t_d2h, 3), "write_seconds": None if t_write is None else round(t_write, 3),
+            "min_framesize": int(fbs.min()), "max_framesize": int(fbs.max()), "out": args.out or None,
+            "header_bytes": len(header),
+        }
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    elif th:
+        th.join()
+    eng.close()
+    if gat:
+        gat.close()
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+    return line
+
+
+if __name__ == "__main__":
+    main()

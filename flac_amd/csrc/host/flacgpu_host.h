@@ -81,6 +81,9 @@ typedef struct { int status; uint32_t frame_number, channel, sample; uint64_t ab
 int flacgpu_host_verify_batch(const flacgpu_host_settings *s, const uint8_t *frames, const uint32_t *frame_bytes, uint32_t nframes, uint32_t tail,
                               uint32_t first_frame, const uint8_t *raw, uint32_t width, uint32_t nthreads, flacgpu_host_verify_result *out);
 
+/* CRC-16 footers of `nframes` frames laid out back to back: index of the first wrong one, or -1 */
+int64_t flacgpu_host_check_frame_crcs(const uint8_t *frames, const uint32_t *frame_bytes, uint64_t nframes, uint32_t nthreads);
+
 #ifdef __cplusplus
 }
 #endif

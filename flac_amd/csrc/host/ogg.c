@@ -21,12 +21,13 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include "flacgpu_host.h"
 #include "ogg.h"
 
 /* ---- CRC-32 of Ogg pages: polynomial 0x04c11db7, no reflection, initial value and final xor 0 (RFC 3533) ---- */
 static uint32_t crc_tab[256];
-static int crc_ready = 0;
+static pthread_once_t crc_once = PTHREAD_ONCE_INIT;
 static void crc_init(void)
 {
 	for(uint32_t i = 0; i < 256; i++) {
@@ -34,7 +35,6 @@ static void crc_init(void)
 		for(int k = 0; k < 8; k++) r = (r & 0x80000000u) ? (r << 1) ^ 0x04c11db7u : r << 1;
 		crc_tab[i] = r;
 	}
-	crc_ready = 1;
 }
 static uint32_t crc_update(uint32_t c, const uint8_t *p, size_t n)
 {
@@ -43,7 +43,7 @@ static uint32_t crc_update(uint32_t c, const uint8_t *p, size_t n)
 }
 void fgh_ogg_page_checksum_set(uint8_t *header, size_t header_len, const uint8_t *body, size_t body_len)
 {
-	if(!crc_ready) crc_init();
+	pthread_once(&crc_once, crc_init);         /* encoders on different threads page concurrently */
 	header[22] = header[23] = header[24] = header[25] = 0;
 	uint32_t c = crc_update(0, header, header_len);
 	c = crc_update(c, body, body_len);

@@ -286,7 +286,13 @@ FLAC__StreamDecoderState FLAC__stream_encoder_get_verify_decoder_state(const FLA
 	if(!PROT(e)->s.verify) return FLAC__STREAM_DECODER_UNINITIALIZED;
 	return PRIV(e)->gpu ? 2 : 8;
 }
-const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *e) { return FLAC__StreamEncoderStateString[PROT(e)->state]; }
+/* :2318-2330: for VERIFY_DECODER_ERROR the reference answers with its verify decoder's state string; the frame decoder here
+ * has one state to report, the one get_verify_decoder_state gives */
+const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *e)
+{
+	if(PROT(e)->state != FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR) return FLAC__StreamEncoderStateString[PROT(e)->state];
+	return "FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC";
+}
 void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *e, FLAC__uint64 *absolute_sample, uint32_t *frame_number, uint32_t *channel, uint32_t *sample, FLAC__int32 *expected, FLAC__int32 *got)
 {
 	const flacgpu_host_verify_result *v = &PRIV(e)->verify_stats;           /* :2327-2343 */
@@ -644,7 +650,7 @@ static int collect_slot(FLAC__StreamEncoder *e, int k)
 /* ------------------------------------------------------------------------------------------------
  * init (stream_encoder.c:707-1440)
  * ---------------------------------------------------------------------------------------------- */
-static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__StreamEncoderWriteCallback wcb, FLAC__StreamEncoderSeekCallback scb,
+static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__StreamEncoderReadCallback rcb, FLAC__StreamEncoderWriteCallback wcb, FLAC__StreamEncoderSeekCallback scb,
                                                  FLAC__StreamEncoderTellCallback tcb, FLAC__StreamEncoderMetadataCallback mcb, void *client_data, int is_ogg)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
@@ -705,8 +711,25 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 
 	/* the GPU engine; features it does not implement are refused, never approximated */
 	{
+		/* Blocks per GPU batch: FLACGPU_BATCH_FRAMES, or what a budget of staged sample bytes per slot buys (FLACGPU_BATCH_BYTES,
+		 * default 64 MiB: 4096 blocks of 16-bit stereo at 4096 samples, 30 of 8 x 32-bit x 65535) -- two pinned input slots of
+		 * that size and two output slots exist per encoder -- and never more than the stream is said to hold.  No frame is
+		 * delivered before its batch is full or finish() is called: INTEGRATION.md, "output latency". */
 		const char *env = getenv("FLACGPU_BATCH_FRAMES");
-		long bf = env ? strtol(env, 0, 10) : 512;
+		long bf;
+		if(env) bf = strtol(env, 0, 10);
+		else {
+			const char *eb = getenv("FLACGPU_BATCH_BYTES");
+			const double budget = eb ? strtod(eb, 0) : 64.0 * 1024 * 1024;
+			const double per_block = (double)s->blocksize * s->channels * ((s->bits_per_sample + 7) / 8);
+			bf = (long)(budget / per_block);
+			if(bf > 16384) bf = 16384;
+			if(bf < 4) bf = 4;
+		}
+		if(s->total_samples_estimate) {
+			const uint64_t need = (s->total_samples_estimate + s->blocksize - 1) / s->blocksize;
+			if(need < (uint64_t)bf) bf = (long)need;
+		}
 		if(bf < 1) bf = 1; else if(bf > 65536) bf = 65536;
 		p->batch_frames = (uint32_t)bf;
 		env = getenv("FLACGPU_VERIFY_THREADS");
@@ -752,7 +775,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 		}
 	}
 
-	p->write_cb = wcb; p->seek_cb = scb; p->tell_cb = tcb; p->metadata_cb = mcb; p->client_data = client_data;
+	p->read_cb = rcb; p->write_cb = wcb; p->seek_cb = scb; p->tell_cb = tcb; p->metadata_cb = mcb; p->client_data = client_data;    /* only once every check has passed (:1126-1131) */
 	p->is_ogg = is_ogg; p->final_batch = 0; p->emit_is_last = 0;
 	if(is_ogg && !fgh_ogg_aspect_init(&p->ogg)) {                   /* :1121-1124 */
 		release_engine(e);
@@ -800,14 +823,13 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_stream(FLAC__StreamEncoder *e, FLAC__StreamEncoderWriteCallback wcb, FLAC__StreamEncoderSeekCallback scb,
                                                                FLAC__StreamEncoderTellCallback tcb, FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
 {
-	return init_common(e, wcb, scb, tcb, mcb, client_data, 0);
+	return init_common(e, 0, wcb, scb, tcb, mcb, client_data, 0);
 }
 FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_stream(FLAC__StreamEncoder *e, FLAC__StreamEncoderReadCallback rcb, FLAC__StreamEncoderWriteCallback wcb,
                                                                    FLAC__StreamEncoderSeekCallback scb, FLAC__StreamEncoderTellCallback tcb,
                                                                    FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
 {
-	PRIV(e)->read_cb = rcb;
-	return init_common(e, wcb, scb, tcb, mcb, client_data, 1);
+	return init_common(e, rcb, wcb, scb, tcb, mcb, client_data, 1);
 }
 
 /* FILE* flavour: our own write/seek/tell callbacks plus the progress callback per frame (:5258-5327) */
@@ -816,8 +838,10 @@ static FLAC__StreamEncoderWriteStatus file_write(const FLAC__StreamEncoder *e, c
 	(void)cd; (void)frame;
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	if(fwrite(buf, 1, bytes, p->file) != bytes) return FLAC__STREAM_ENCODER_WRITE_STATUS_FATAL_ERROR;
-	if(p->progress_cb && samples > 0)     /* the counters are only advanced after we return, hence the +bytes/+samples/+1 */
-		p->progress_cb(e, p->bytes_written + bytes, p->samples_written + samples, p->frames_written + 1, p->total_frames_estimate, p->client_data);
+	/* Ogg FLAC: `samples` is always 0 at this point of the reference's callback chain (ogg_encoder_aspect.c), so it calls the
+	 * progress callback on every write, header and body pages included; the counters are only advanced after we return */
+	if(p->progress_cb && (p->is_ogg || samples > 0))
+		p->progress_cb(e, p->bytes_written + bytes, p->samples_written + samples, p->frames_written + (samples ? 1 : 0), p->total_frames_estimate, p->client_data);
 	return FLAC__STREAM_ENCODER_WRITE_STATUS_OK;
 }
 static FLAC__StreamEncoderSeekStatus file_seek(const FLAC__StreamEncoder *e, FLAC__uint64 off, void *cd)
@@ -850,8 +874,7 @@ static FLAC__StreamEncoderInitStatus init_FILE_common(FLAC__StreamEncoder *e, FI
 	p->progress_cb = pcb;
 	p->bytes_written = 0; p->samples_written = 0; p->frames_written = 0;
 	const int to_stdout = file == stdout;
-	p->read_cb = (is_ogg && !to_stdout) ? file_read : 0;
-	const FLAC__StreamEncoderInitStatus st = init_common(e, file_write, to_stdout ? 0 : file_seek, to_stdout ? 0 : file_tell, 0, client_data, is_ogg);
+	const FLAC__StreamEncoderInitStatus st = init_common(e, (is_ogg && !to_stdout) ? file_read : 0, file_write, to_stdout ? 0 : file_seek, to_stdout ? 0 : file_tell, 0, client_data, is_ogg);
 	if(st != FLAC__STREAM_ENCODER_INIT_STATUS_OK) return st;
 	p->progress_cb = pcb;
 	const uint32_t bs = PROT(e)->s.blocksize;
@@ -998,7 +1021,10 @@ static void update_metadata(FLAC__StreamEncoder *e)
 		for(uint32_t i = 0; i < p->seek_table->num_points; i++)      /* template points beyond the end become placeholders */
 			if(p->seek_table->points[i].sample_number > si->total_samples) p->seek_table->points[i].sample_number = FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER;
 		seektable_sort(p->seek_table);
-		if(p->seek_cb(e, PROT(e)->seektable_offset + 4, p->client_data) != FLAC__STREAM_ENCODER_SEEK_STATUS_OK) { PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return; }
+		{
+			const FLAC__StreamEncoderSeekStatus ss = p->seek_cb(e, PROT(e)->seektable_offset + 4, p->client_data);      /* :3262-3266 */
+			if(ss != FLAC__STREAM_ENCODER_SEEK_STATUS_OK) { if(ss == FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR) PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return; }
+		}
 		for(uint32_t i = 0; i < p->seek_table->num_points; i++) {
 			const FLAC__StreamMetadata_SeekPoint *sp = &p->seek_table->points[i];
 			for(int k = 0; k < 8; k++) { b[k] = (uint8_t)(sp->sample_number >> (56 - 8 * k)); b[8 + k] = (uint8_t)(sp->stream_offset >> (56 - 8 * k)); }

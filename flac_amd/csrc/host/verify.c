@@ -275,3 +275,65 @@ int flacgpu_host_verify_batch(const flacgpu_host_settings *s, const uint8_t *fra
 	free(offsets); free(jobs); free(th);
 	return out->status;
 }
+
+/* CRC-16 recheck of a run of frames laid out back to back (the footer of every frame, crc.c:376 over everything in
+ * front of it): the index of the first frame whose footer disagrees, or -1.  A corpus-sized stream is split over
+ * `nthreads` threads by frame ranges.  Slicing by four bytes. */
+static uint16_t crc16_t4[4][256];
+static pthread_once_t crc16_t4_once = PTHREAD_ONCE_INIT;
+static void crc16_t4_init(void)
+{
+	crc16_init();
+	for(uint32_t v = 0; v < 256; v++) {
+		uint32_t c = crc16_tab[v];
+		crc16_t4[0][v] = (uint16_t)c;
+		for(int k = 1; k < 4; k++) { c = ((c << 8) & 0xffff) ^ crc16_tab[c >> 8]; crc16_t4[k][v] = (uint16_t)c; }
+	}
+}
+static uint16_t crc16_fast(const uint8_t *p, size_t n)
+{
+	uint32_t c = 0;
+	while(n >= 4) {
+		const uint32_t a = (c >> 8) ^ p[0], b = (c & 0xff) ^ p[1];
+		c = crc16_t4[3][a] ^ crc16_t4[2][b] ^ crc16_t4[1][p[2]] ^ crc16_t4[0][p[3]];
+		p += 4; n -= 4;
+	}
+	while(n--) c = ((c << 8) & 0xffff) ^ crc16_tab[(c >> 8) ^ *p++];
+	return (uint16_t)c;
+}
+typedef struct { const uint8_t *frames; const uint32_t *fb; uint64_t lo, hi, off; int64_t bad; } crcjob;
+static void *crc_thread(void *arg)
+{
+	crcjob *J = arg;
+	const uint8_t *p = J->frames + J->off;
+	J->bad = -1;
+	for(uint64_t f = J->lo; f < J->hi; f++) {
+		const size_t len = J->fb[f];
+		if(len < 3 || crc16_fast(p, len - 2) != (uint16_t)((p[len - 2] << 8) | p[len - 1])) { J->bad = (int64_t)f; return 0; }
+		p += len;
+	}
+	return 0;
+}
+int64_t flacgpu_host_check_frame_crcs(const uint8_t *frames, const uint32_t *frame_bytes, uint64_t nframes, uint32_t nthreads)
+{
+	pthread_once(&crc16_once, crc16_init);
+	pthread_once(&crc16_t4_once, crc16_t4_init);
+	if(nthreads < 1) nthreads = 1;
+	if(nthreads > 64) nthreads = 64;
+	if(nthreads > nframes) nthreads = nframes ? (uint32_t)nframes : 1;
+	crcjob jobs[64];
+	pthread_t th[64];
+	uint64_t off = 0, f = 0;
+	for(uint32_t t = 0; t < nthreads; t++) {
+		jobs[t].frames = frames; jobs[t].fb = frame_bytes; jobs[t].lo = f; jobs[t].hi = nframes * (t + 1) / nthreads; jobs[t].off = off;
+		for(; f < jobs[t].hi; f++) off += frame_bytes[f];
+	}
+	for(uint32_t t = 1; t < nthreads; t++) if(pthread_create(&th[t], 0, crc_thread, &jobs[t]) != 0) th[t] = 0;
+	(void)crc_thread(&jobs[0]);
+	int64_t bad = jobs[0].bad;
+	for(uint32_t t = 1; t < nthreads; t++) {
+		if(th[t]) pthread_join(th[t], 0); else (void)crc_thread(&jobs[t]);
+		if(bad < 0 && jobs[t].bad >= 0) bad = jobs[t].bad;
+	}
+	return bad;
+}

@@ -2,11 +2,26 @@
 
 Frames are independent, so a corpus shards by contiguous frame ranges with NO data-path collective:
 rank r encodes frames [r*F/W, (r+1)*F/W) with the frame numbers fixed up front.  The only exchange is
-the final ORDERED gather of the variable-length bitstream to rank 0:
+the ORDERED gather of the variable-length bitstream to one rank:
     all_gather(byte totals, frame counts) -> exclusive scan -> point-to-point payload sends
 i.e. a Gatherv built from RCCL send/recv over xGMI (works identically over gloo on CPU, which is how
 tests/test_dist_cpu.py covers it).
+
+Three forms of it:
+  ordered_gather   one shot (the end of a corpus job): one tiny all_gather, ONE host read of the sizes, one batch of
+                   point-to-point transfers into a buffer the destination may preallocate.
+  GatherPipeline   steady state (bench.py, a corpus encoded in super-batches): the steps of a WINDOW are encoded
+                   back to back with no host involvement, their sizes are exchanged and read once per window, the
+                   window's transfers are posted in one batch on a communication stream, and the next window's
+                   encodes run meanwhile.  The destination's own frames are encoded straight into the gathered
+                   stream (its payload comes first), so nothing of its own is ever copied.
+  HostShmGather    the variant that scales past one GPU's links: every rank copies its shard over ITS OWN PCIe link
+                   into one shared pinned host buffer at the scanned offset; only the byte totals cross between
+                   ranks.  No rank-0 funnel (7 peers x 50 GB/s into one GPU at -8 rates).
 """
+import mmap
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -18,32 +33,45 @@ def shard_range(nframes, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def ordered_gather(payload, nbytes, frame_bytes, group=None, dst=0):
+def _exchange(meta, group):
+    """all_gather of a small int64 vector; returns the [world, len(meta)] table on the HOST (the one host sync)."""
+    world = dist.get_world_size(group)
+    flat = torch.empty(world * meta.numel(), dtype=torch.int64, device=meta.device)
+    dist.all_gather_into_tensor(flat, meta.contiguous(), group=group)
+    return flat.cpu().view(world, meta.numel())
+
+
+def ordered_gather(payload, nbytes, frame_bytes, group=None, dst=0, out=None, out_frame_bytes=None):
     """Gather variable-length encoded shards to `dst` in rank order.
 
     payload     uint8 tensor (device or CPU) whose first `nbytes` bytes are this rank's frames
+    nbytes      int, or a one-element integer tensor on payload's device (e.g. the engine's byte total: no host read here)
     frame_bytes uint32/int32 tensor [nframes_local] with the length of each local frame
-    Returns on dst: (stream uint8 tensor [total], all_frame_bytes int64 tensor [total frames]);
-    on other ranks: (None, None).
+    out / out_frame_bytes  (dst only, optional) preallocated uint8 / int64 buffers at least as large as the result
+    Returns on dst: (stream uint8 tensor [total], all_frame_bytes int64 tensor [total frames]) -- views of `out`
+    when given; on other ranks: (None, None).
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = payload.device
     nfr = int(frame_bytes.numel())
-    meta = torch.tensor([int(nbytes), nfr], dtype=torch.int64, device=dev)
-    metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    sizes = [int(m[0].item()) for m in metas]
-    counts = [int(m[1].item()) for m in metas]
+    if torch.is_tensor(nbytes):
+        meta = torch.stack([nbytes.reshape(-1)[0].to(torch.int64), torch.tensor(nfr, dtype=torch.int64, device=dev)])
+    else:
+        meta = torch.tensor([int(nbytes), nfr], dtype=torch.int64, device=dev)
+    table = _exchange(meta, group)
+    sizes = [int(v) for v in table[:, 0]]
+    counts = [int(v) for v in table[:, 1]]
     fb = frame_bytes.to(torch.int64)
     if rank == dst:
         total, totalf = sum(sizes), sum(counts)
-        stream = torch.empty(total, dtype=torch.uint8, device=dev)
-        allfb = torch.empty(totalf, dtype=torch.int64, device=dev)
+        stream = out[:total] if out is not None else torch.empty(total, dtype=torch.uint8, device=dev)
+        allfb = out_frame_bytes[:totalf] if out_frame_bytes is not None else torch.empty(totalf, dtype=torch.int64, device=dev)
         ops, off, foff = [], 0, 0
         for r in range(world):
             if r == rank:
-                stream[off:off + sizes[r]].copy_(payload[:sizes[r]])
+                if stream.data_ptr() + off != payload.data_ptr():      # (already in place when the caller encoded into `out`)
+                    stream[off:off + sizes[r]].copy_(payload[:sizes[r]])
                 allfb[foff:foff + counts[r]].copy_(fb)
             else:
                 if sizes[r]:
@@ -57,11 +85,186 @@ def ordered_gather(payload, nbytes, frame_bytes, group=None, dst=0):
                 w.wait()
         return stream, allfb
     ops = []
-    if nbytes:
-        ops.append(dist.P2POp(dist.isend, payload[:nbytes].contiguous(), dst, group))
+    if sizes[rank]:
+        ops.append(dist.P2POp(dist.isend, payload[:sizes[rank]].contiguous(), dst, group))
     if nfr:
         ops.append(dist.P2POp(dist.isend, fb.contiguous(), dst, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return None, None
+
+
+class GatherPipeline:
+    """Steady-state ordered gather for a job that encodes step after step (see the module docstring).
+
+    Per step every rank produces up to `cap_bytes` of frames and `nframes` frame lengths.  Usage, identically on all
+    ranks (the destination must be rank 0 of the group: its payload is the head of every gathered stream):
+        gp = GatherPipeline(cap_bytes, nframes, device, window=4)
+        for k in range(steps):
+            gp.wait_slot_free(k)                 # device-side wait on gp.enc_stream, never a host wait
+            out, fb, total = gp.slot(k)          # where step k must be encoded to (device tensors)
+            ... enqueue the encode of step k on gp.enc_stream ...
+            gp.step_done(k)                      # end of a window: gathers the PREVIOUS window
+        gp.flush()                               # the windows still pending
+    The gather of window w is issued only after window w+1 has been enqueued, so the one host read it needs (the
+    sizes) never leaves the encode stream without work.  On dst, gp.gathered(k) is step k's stream in rank order.
+    CPU tensors (gloo) are supported for the tests: streams and events are then no-ops.
+    """
+
+    def __init__(self, cap_bytes, nframes, device, window=4, group=None, dst=0):
+        self.group, self.dst = group, dst
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if dst != 0:
+            raise ValueError("GatherPipeline: the destination must be rank 0 of the group")
+        self.cap, self.nframes, self.K = int(cap_bytes), int(nframes), max(1, int(window))
+        self.dev = torch.device(device)
+        self.cuda = self.dev.type == "cuda"
+        self.is_dst = self.rank == dst
+        K, W = self.K, self.world
+        nslots = 2 * K                                     # two windows in flight: one being encoded, one being gathered
+        # dst: a step's gathered stream, its own payload first (encoded in place); others: just their payload
+        self.span = self.cap * (W if self.is_dst else 1)
+        self.buf = torch.empty(nslots * self.span, dtype=torch.uint8, device=self.dev)
+        self.fb = torch.empty(nslots * self.nframes, dtype=torch.int32, device=self.dev)
+        self.totals = torch.zeros(nslots, dtype=torch.int64, device=self.dev)
+        self.allfb = torch.empty(nslots * W * self.nframes, dtype=torch.int32, device=self.dev) if self.is_dst else None
+        self.sizes = [None] * nslots                       # dst: per-rank byte counts of the step in that slot (host ints)
+        if self.cuda:
+            self.enc_stream, self.comm_stream = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+            self.win_done = [torch.cuda.Event() for _ in range(2)]     # the window's encodes are finished
+            self.win_free = [torch.cuda.Event() for _ in range(2)]     # the window's buffers were read by the gather
+        self.pending = []                                  # windows enqueued but not yet gathered: (first step, steps)
+        self.enqueued = 0
+        self.gathers = 0
+        self.host_syncs = 0
+
+    def _slot(self, k):
+        return k % (2 * self.K)
+
+    def slot(self, k):
+        s = self._slot(k)
+        return (self.buf[s * self.span: s * self.span + self.cap], self.fb[s * self.nframes:(s + 1) * self.nframes], self.totals[s:s + 1])
+
+    def wait_slot_free(self, k):
+        """Device-side: the encode stream waits until the gather that last read step k's window is through."""
+        w = k // self.K
+        if self.cuda and k % self.K == 0 and w >= 2:
+            self.enc_stream.wait_event(self.win_free[w % 2])
+
+    def _close_window(self, k0, n):
+        if self.cuda:
+            self.win_done[(k0 // self.K) % 2].record(self.enc_stream)
+        self.pending.append((k0, n))
+
+    def step_done(self, k):
+        """Call after step k was enqueued."""
+        self.enqueued = k + 1
+        if (k + 1) % self.K == 0:
+            self._close_window(k + 1 - self.K, self.K)
+            if len(self.pending) > 1:
+                self._gather_window(*self.pending.pop(0))
+
+    def flush(self):
+        part = self.enqueued % self.K
+        if part:
+            self._close_window(self.enqueued - part, part)
+        while self.pending:
+            self._gather_window(*self.pending.pop(0))
+
+    def _gather_window(self, k0, n):
+        import contextlib
+        w = (k0 // self.K) % 2
+        s0 = self._slot(k0)
+        with (torch.cuda.stream(self.comm_stream) if self.cuda else contextlib.nullcontext()):
+            if self.cuda:
+                self.comm_stream.wait_event(self.win_done[w])
+            # the ONE host read of this window (the next window's encodes are already queued on the encode stream)
+            table = _exchange(self.totals[s0:s0 + n], self.group)          # [world, n]
+            self.host_syncs += 1
+            ops = []
+            for j in range(n):
+                s = s0 + j
+                sz = [int(v) for v in table[:, j]]
+                if self.is_dst:
+                    self.sizes[s] = sz
+                    base, off = s * self.span, sz[0]                         # rank 0's own payload is already there
+                    for r in range(1, self.world):
+                        if sz[r]:
+                            ops.append(dist.P2POp(dist.irecv, self.buf[base + off: base + off + sz[r]], r, self.group))
+                        a = (s * self.world + r) * self.nframes
+                        ops.append(dist.P2POp(dist.irecv, self.allfb[a:a + self.nframes], r, self.group))
+                        off += sz[r]
+                else:
+                    if sz[self.rank]:
+                        ops.append(dist.P2POp(dist.isend, self.buf[s * self.span: s * self.span + sz[self.rank]], self.dst, self.group))
+                    ops.append(dist.P2POp(dist.isend, self.fb[s * self.nframes:(s + 1) * self.nframes], self.dst, self.group))
+            if ops:
+                for wk in dist.batch_isend_irecv(ops):
+                    wk.wait()                     # stream-ordered on CUDA (the host does not block); blocking on gloo
+            if self.cuda:
+                self.win_free[w].record(self.comm_stream)
+        self.gathers += 1
+
+    def gathered(self, k):
+        """dst only, once the window of step k was gathered and the communication stream synchronised by the caller:
+        (stream bytes of step k in rank order, [per-rank byte counts], frame lengths [world, nframes])."""
+        s = self._slot(k)
+        sz = self.sizes[s]
+        fbs = self.allfb[s * self.world * self.nframes:(s + 1) * self.world * self.nframes].view(self.world, self.nframes).clone()
+        fbs[self.rank] = self.fb[s * self.nframes:(s + 1) * self.nframes]
+        return self.buf[s * self.span: s * self.span + sum(sz)], sz, fbs
+
+
+class HostShmGather:
+    """Ordered gather through ONE pinned host buffer shared by the ranks of a node (POSIX shared memory, registered
+    with the HIP runtime by every rank): rank r copies its payload device -> host at the exclusive scan of the byte
+    totals.  The transfers run on every GPU's own PCIe link at once.  Only for CUDA tensors."""
+
+    def __init__(self, capacity_bytes, group=None, name=None):
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.capacity = int(capacity_bytes)
+        self.path = "/dev/shm/%s" % (name or "flacgpu_gather_%s" % os.environ.get("MASTER_PORT", "0"))
+        if self.rank == 0:
+            with open(self.path, "wb") as f:
+                f.truncate(self.capacity)
+        dist.barrier(group)
+        self.fd = os.open(self.path, os.O_RDWR)
+        self.mm = mmap.mmap(self.fd, self.capacity)
+        self.host = torch.frombuffer(self.mm, dtype=torch.uint8)
+        self.registered = False
+        rt = torch.cuda.cudart()
+        if int(rt.cudaHostRegister(self.host.data_ptr(), self.capacity, 0)) == 0:
+            self.registered = True
+        dist.barrier(group)
+
+    def gather(self, payload, nbytes, stream=None):
+        """Every rank: copy payload[:nbytes] to the shared buffer at its scanned offset.  Returns (offset, sizes list);
+        the data is complete on all ranks after the barrier this call ends with."""
+        dev = payload.device
+        meta = nbytes.reshape(-1)[:1].to(torch.int64) if torch.is_tensor(nbytes) else torch.tensor([int(nbytes)], dtype=torch.int64, device=dev)
+        table = _exchange(meta, self.group)
+        sizes = [int(v) for v in table[:, 0]]
+        off = sum(sizes[:self.rank])
+        if off + sizes[self.rank] > self.capacity:
+            raise RuntimeError("HostShmGather: %d bytes do not fit the shared buffer" % sum(sizes))
+        with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream(dev)):
+            self.host[off:off + sizes[self.rank]].copy_(payload[:sizes[self.rank]], non_blocking=self.registered)
+        torch.cuda.current_stream(dev).synchronize() if stream is None else stream.synchronize()
+        dist.barrier(self.group)
+        return off, sizes
+
+    def close(self):
+        if self.registered:
+            torch.cuda.cudart().cudaHostUnregister(self.host.data_ptr())
+            self.registered = False
+        self.host = None
+        try:
+            self.mm.close()
+        except BufferError:
+            pass
+        os.close(self.fd)
+        dist.barrier(self.group)
+        if self.rank == 0 and os.path.exists(self.path):
+            os.unlink(self.path)

@@ -1,14 +1,16 @@
-"""world_size-2 gloo run of the multi-GPU path's only exchange step: the ordered variable-length
-gather of encoded shards to rank 0 (flac_amd/dist.py), plus the frame-range sharding rule."""
+"""world_size-2 gloo runs of the multi-GPU path's only exchange step: the ordered variable-length gather of encoded
+shards to rank 0 (flac_amd/dist.py) -- the one-shot form, the form that receives into a preallocated buffer the
+destination encoded into, and the windowed steady-state pipeline -- plus the frame-range sharding rule."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from flac_amd.dist import ordered_gather, shard_range
+from flac_amd.dist import GatherPipeline, ordered_gather, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -22,49 +24,123 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, q):
+def _shard(rank):
+    rng = np.random.default_rng(100 + rank)
+    nfr = 5 + 3 * rank
+    fb = rng.integers(14, 9000, nfr).astype(np.int32)
+    nbytes = int(fb.sum())
+    return fb, nbytes, rng.integers(0, 256, nbytes, dtype=np.uint8)
+
+
+def _step_shard(rank, k, nframes, cap):
+    """what rank `rank` 'encodes' in step k of the pipeline test"""
+    rng = np.random.default_rng(1000 * k + rank)
+    fb = rng.integers(14, cap // nframes, nframes).astype(np.int32)
+    nbytes = int(fb.sum())
+    return fb, nbytes, rng.integers(0, 256, nbytes, dtype=np.uint8)
+
+
+def _worker(rank, world, port, q, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rng = np.random.default_rng(100 + rank)
-        nfr = 5 + 3 * rank
-        fb = rng.integers(14, 9000, nfr).astype(np.int32)
-        nbytes = int(fb.sum())
-        payload = np.zeros(nbytes + 77, dtype=np.uint8)       # capacity larger than the used bytes
-        payload[:nbytes] = rng.integers(0, 256, nbytes, dtype=np.uint8)
-        stream, allfb = ordered_gather(torch.from_numpy(payload), nbytes, torch.from_numpy(fb), dst=0)
-        if rank == 0:
-            q.put((stream.numpy().tobytes(), allfb.numpy().tolist()))
+        if mode in ("oneshot", "prealloc"):
+            fb, nbytes, data = _shard(rank)
+            if mode == "oneshot":
+                payload = np.zeros(nbytes + 77, dtype=np.uint8)       # capacity larger than the used bytes
+                payload[:nbytes] = data
+                stream, allfb = ordered_gather(torch.from_numpy(payload), nbytes, torch.from_numpy(fb), dst=0)
+            else:
+                # the destination "encoded" straight into the head of the receive buffer; the byte count is a tensor
+                out = torch.zeros(200000, dtype=torch.uint8)
+                outfb = torch.zeros(64, dtype=torch.int64)
+                payload = out[:nbytes + 5] if rank == 0 else torch.zeros(nbytes + 5, dtype=torch.uint8)
+                payload[:nbytes] = torch.from_numpy(data)
+                stream, allfb = ordered_gather(payload, torch.tensor([nbytes]), torch.from_numpy(fb), dst=0, out=out if rank == 0 else None,
+                                               out_frame_bytes=outfb if rank == 0 else None)
+                if rank == 0:
+                    assert stream.data_ptr() == out.data_ptr()
+            if rank == 0:
+                q.put((stream.numpy().tobytes(), allfb.numpy().tolist()))
+            else:
+                assert stream is None and allfb is None
         else:
-            assert stream is None and allfb is None
+            window, steps = mode
+            nframes, cap = 6, 60000
+            gp = GatherPipeline(cap, nframes, "cpu", window=window)
+            got = {}
+
+            for k in range(steps):
+                gp.wait_slot_free(k)
+                out, fbt, total = gp.slot(k)
+                fb, nbytes, data = _step_shard(rank, k, nframes, cap)
+                out[:nbytes] = torch.from_numpy(data)
+                fbt.copy_(torch.from_numpy(fb))
+                total[0] = nbytes
+                before = gp.gathers
+                gp.step_done(k)
+                if rank == 0 and gp.gathers != before:
+                    # the window gathered just now is the one before the window that just closed
+                    k0 = (k + 1 - 2 * window)
+                    for kk in range(k0, k0 + window):
+                        s, sz, fbs = gp.gathered(kk)
+                        got[kk] = (s.numpy().tobytes(), sz, fbs.numpy().tolist())
+            done_before = set(got)
+            gp.flush()
+            if rank == 0:
+                for kk in range(steps):
+                    if kk not in done_before:
+                        s, sz, fbs = gp.gathered(kk)
+                        got[kk] = (s.numpy().tobytes(), sz, fbs.numpy().tolist())
+                assert gp.host_syncs == (steps + window - 1) // window         # one host read of sizes per window
+                q.put(got)
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_ordered_gather_gloo_ws2():
-    world = 2
+def _run(mode, world=2):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    got_stream, got_fb = q.get(timeout=120)
+    res = q.get(timeout=180)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=180)
         assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("mode", ["oneshot", "prealloc"])
+def test_ordered_gather_gloo_ws2(mode):
+    world = 2
+    got_stream, got_fb = _run(mode, world)
     want_stream, want_fb = b"", []
     for rank in range(world):
-        rng = np.random.default_rng(100 + rank)
-        nfr = 5 + 3 * rank
-        fb = rng.integers(14, 9000, nfr).astype(np.int32)
-        nbytes = int(fb.sum())
-        want_stream += rng.integers(0, 256, nbytes, dtype=np.uint8).tobytes()
+        fb, nbytes, data = _shard(rank)
+        want_stream += data.tobytes()
         want_fb += fb.tolist()
     assert got_fb == want_fb
     assert got_stream == want_stream
+
+
+@pytest.mark.parametrize("window,steps", [(1, 5), (3, 7), (4, 8)])
+def test_gather_pipeline_gloo_ws2(window, steps):
+    world = 2
+    got = _run((window, steps), world)
+    assert sorted(got) == list(range(steps))
+    for k in range(steps):
+        stream, sizes, fbs = got[k]
+        want = b""
+        for rank in range(world):
+            fb, nbytes, data = _step_shard(rank, k, 6, 60000)
+            want += data.tobytes()
+            assert sizes[rank] == nbytes
+            assert fbs[rank] == fb.tolist()
+        assert stream == want

@@ -89,3 +89,28 @@ def test_wide_sample_frames_verify(bps):
         o = po.oracle_encode(pcm, bps, 96000, 5)
         st, res = _verify(pcm, bps, 96000, 5, o["data"], o["frame_bytes"], streamable_subset=0)
         assert st == 0, (pattern, bps, res.status, res.frame_number)
+
+
+def test_crc_recheck_of_a_run_of_frames_finds_the_first_damaged_one():
+    """flacgpu_host_check_frame_crcs (the corpus job's and bench.py's every-frame CRC-16 recheck) on oracle frames"""
+    import ctypes as C
+    import numpy as np
+    import signals
+    from flac_amd import engine
+    from oracle import pyoracle as po
+    host = engine.load_host()
+    host.flacgpu_host_check_frame_crcs.restype = C.c_int64
+    host.flacgpu_host_check_frame_crcs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    pcm = signals.music(4096 * 37 + 900, 2, 16, seed=3)
+    enc = po.oracle_encode(pcm, 16, 44100, 5)
+    data = np.frombuffer(enc["data"], dtype=np.uint8).copy()
+    fb = np.ascontiguousarray(enc["frame_bytes"], dtype=np.uint32)
+    for threads in (1, 3, 8):
+        assert host.flacgpu_host_check_frame_crcs(data.ctypes.data, fb.ctypes.data, fb.size, threads) == -1
+    offs = np.concatenate([[0], np.cumsum(fb.astype(np.int64))])
+    for f in (0, 17, 36, fb.size - 1):
+        d = data.copy()
+        d[offs[f] + int(fb[f]) // 2] ^= 0x10
+        d[offs[min(f + 5, fb.size - 1)] + 3] ^= 0x01          # a later one as well: the FIRST is reported
+        for threads in (1, 4):
+            assert host.flacgpu_host_check_frame_crcs(d.ctypes.data, fb.ctypes.data, fb.size, threads) == f
