@@ -269,6 +269,24 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         res = {"elapsed": elapsed, "steps": steps, "block": block, "level": level, "kind": kind}
+        if rank == 0 and gp is None and not args.no_verify:
+            # side measurement, outside the timed region: the whole batch decoded again on the device and compared with its input
+            # (flacgpu_verify_batch_device: what set_verify(true) costs per batch)
+            d_res = torch.zeros(32, dtype=torch.uint8, device=dev)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            with torch.cuda.stream(enc_stream):
+                eng.verify_device(d_out.data_ptr(), d_fb.data_ptr(), nframes, d_pcm.data_ptr(), d_res.data_ptr(), first_frame_number=first_frame, stream=enc_stream.cuda_stream)
+                ev0.record(enc_stream)
+                for _ in range(reps):
+                    eng.verify_device(d_out.data_ptr(), d_fb.data_ptr(), nframes, d_pcm.data_ptr(), d_res.data_ptr(), first_frame_number=first_frame, stream=enc_stream.cuda_stream)
+                ev1.record(enc_stream)
+            enc_stream.synchronize()
+            vms = ev0.elapsed_time(ev1) / reps
+            v = flac_amd.VerifyResult.from_buffer_copy(d_res.cpu().numpy().tobytes())
+            res["device_verify"] = {"status": int(v.status), "frames_decoded_and_compared": nframes, "ms_per_batch": round(vms, 4),
+                                    "decode_Msamples_per_s": round(nframes * block / vms / 1e3, 1),
+                                    "encode_plus_verify_Msamples_per_s": round(nframes * block / (vms + elapsed / steps * 1e3) / 1e3, 1)}
         if rank == 0:
             if gp is None:
                 total_bytes = int(d_total.item())
@@ -348,6 +366,8 @@ def main():
         if "verified" in m:
             line["verified_frames"] = m["verified"]["frames_compared_with_oracle"]
             line["verified"] = m["verified"]
+        if "device_verify" in m:
+            line["device_verify"] = m["device_verify"]
         if multi:
             line["gather"] = {"bytes_gathered_last_step": m.get("gathered_bytes_last_step"), "host_reads_of_sizes": m.get("host_syncs"), "window": args.window}
         line.update(extras)

@@ -4,4 +4,4 @@ csrc/    HIP kernels + C ABI (include/flacgpu.h) and the host C layer (libFLAC A
 lib/     in-tree build outputs (libflacgpu.so, libFLACgpu.so)
 engine   ctypes binding used by tests and bench.py
 """
-from .engine import FrameEngine, FlacGpuError, make_settings, host_windows, raw_format, RawFormat  # noqa: F401
+from .engine import FrameEngine, FlacGpuError, make_settings, host_windows, raw_format, RawFormat, VerifyResult  # noqa: F401

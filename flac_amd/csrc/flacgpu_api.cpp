@@ -46,6 +46,13 @@ struct flacgpu_ctx {
 	size_t d_pcm_bytes, d_out_bytes;
 	uint32_t last_nframes;
 	bool timing_valid;
+	// the self check (flacgpu_verify.hip): state word, verdict, offsets of a caller's frames, scratch of the detail pass
+	VerifyState *d_vstate;
+	flacgpu_verify_result *d_vresult;
+	uint64_t *d_voffsets, *d_vtotal;
+	int64_t *d_vscratch;
+	uint32_t verify_on;
+	flacgpu_verify_result last_verify;
 	JobTable h_jobtab[2];        // [0] nominal blocksize, [1] the short last block of the current batch
 	JobTable *d_jobtab;          // device copies of both
 };
@@ -158,6 +165,11 @@ static void free_ctx(flacgpu_ctx *c)
 	for(int i = 0; i < FLACGPU_MAX_SUBBATCHES; i++) { if(c->sub_stream[i]) (void)hipStreamDestroy(c->sub_stream[i]); if(c->sub_done[i]) (void)hipEventDestroy(c->sub_done[i]); }
 	if(c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if(c->d_jobtab) (void)hipFree(c->d_jobtab);
+	if(c->d_vstate) (void)hipFree(c->d_vstate);
+	if(c->d_vresult) (void)hipFree(c->d_vresult);
+	if(c->d_voffsets) (void)hipFree(c->d_voffsets);
+	if(c->d_vtotal) (void)hipFree(c->d_vtotal);
+	if(c->d_vscratch) (void)hipFree(c->d_vscratch);
 	for(int r = 0; r < TIMING_RING; r++) for(int i = 0; i < 5; i++) if(c->ev_ring[r][i]) (void)hipEventDestroy(c->ev_ring[r][i]);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -460,6 +472,13 @@ static int64_t encode_staged(flacgpu_ctx *c, uint32_t nframes, uint64_t first_fr
 	hipStream_t s = c->stream;
 	int r = run_batch(c, c->d_pcm, nframes, first_frame_number, tail_n, tail_windows, c->d_out, c->d_out_bytes, nullptr, nullptr, s);
 	if(r != FLACGPU_OK) return r;
+	memset(&c->last_verify, 0, sizeof c->last_verify);
+	if(c->verify_on) {
+		// the frames are decoded again where they lie and compared with the staged input (stream_encoder.c:3000-3018)
+		if(launch_verify(c->P, c->d_out, c->d_frame_bytes, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vstate, c->d_vresult, s) != hipSuccess)
+			return FLACGPU_ERR_LAUNCH;
+		if(hipMemcpyAsync(&c->last_verify, c->d_vresult, sizeof c->last_verify, hipMemcpyDeviceToHost, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	}
 	uint64_t total = 0;
 	if(hipMemcpyAsync(frame_bytes, c->d_frame_bytes, nframes * sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	if(hipMemcpyAsync(&total, c->d_total, sizeof total, hipMemcpyDeviceToHost, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
@@ -519,6 +538,54 @@ extern "C" int64_t flacgpu_encode_batch_raw(flacgpu_ctx *c, const void *raw, con
 		if(herr) return FLACGPU_ERR_INPUT;
 	}
 	return encode_staged(c, nframes, first_frame_number, tail_n, tail_windows, out, out_cap, frame_bytes);
+}
+
+// buffers of the self check, allocated on first use
+static int ensure_verify(flacgpu_ctx *c)
+{
+	if(c->d_vstate) return FLACGPU_OK;
+	const size_t B = c->cfg.max_batch_frames;
+	bool ok = hipMalloc(&c->d_vstate, sizeof(VerifyState)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_vresult, sizeof(flacgpu_verify_result)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_voffsets, (B + 1) * sizeof(uint64_t)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_vtotal, sizeof(uint64_t)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_vscratch, (size_t)c->P.channels * c->P.blocksize * sizeof(int64_t)) == hipSuccess;
+	return ok ? FLACGPU_OK : FLACGPU_ERR_ALLOC;
+}
+
+extern "C" int flacgpu_verify_batch_device(flacgpu_ctx *c, const uint8_t *d_frames, const uint32_t *d_frame_bytes, uint32_t nframes,
+                                           uint64_t first_frame_number, uint32_t last_block_samples, const int32_t *d_pcm,
+                                           flacgpu_verify_result *d_result, void *stream)
+{
+	if(!c || !d_frames || !d_frame_bytes || !d_pcm || !d_result || nframes == 0 || nframes > c->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	const int r = ensure_verify(c);
+	if(r != FLACGPU_OK) return r;
+	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	const uint32_t tail_n = last_block_samples < c->P.blocksize ? last_block_samples : 0;
+	if(launch_scan(d_frame_bytes, nframes, c->d_voffsets, c->d_vtotal, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(launch_verify(c->P, d_frames, d_frame_bytes, c->d_voffsets, nframes, tail_n, first_frame_number, d_pcm, c->d_vscratch, c->d_vstate, d_result, s) != hipSuccess)
+		return FLACGPU_ERR_LAUNCH;
+	return FLACGPU_OK;
+}
+
+extern "C" int flacgpu_set_verify(flacgpu_ctx *c, uint32_t on)
+{
+	if(!c) return FLACGPU_ERR_BAD_ARG;
+	if(on) {
+		if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+		const int r = ensure_verify(c);
+		if(r != FLACGPU_OK) return r;
+	}
+	c->verify_on = on ? 1 : 0;
+	memset(&c->last_verify, 0, sizeof c->last_verify);
+	return FLACGPU_OK;
+}
+extern "C" int flacgpu_last_verify_result(flacgpu_ctx *c, flacgpu_verify_result *out)
+{
+	if(!c || !out) return FLACGPU_ERR_BAD_ARG;
+	*out = c->last_verify;
+	return FLACGPU_OK;
 }
 
 extern "C" int flacgpu_last_batch_info(flacgpu_ctx *c, uint32_t nframes, flacgpu_subframe_info *sub, uint8_t *channel_assignment)

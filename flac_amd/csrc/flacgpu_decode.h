@@ -1,0 +1,361 @@
+// flac_amd/csrc/flacgpu_decode.h -- a FLAC frame decoder as ONE thread of control per frame, written so that the same
+// source runs as a lane of a GPU wavefront (flacgpu_verify.hip: 64 frames per wavefront, thousands of wavefronts per
+// batch) and, for tests, as plain host code (oracle/decode_pin.cpp).  It is the encoder's self check (SURVEY.md 8f row 3:
+// FLAC__stream_encoder_set_verify): what the reference does with its own stream decoder inside write_bitbuffer_
+// (src/libFLAC/stream_encoder.c:3000-3018, verify_write_callback_ :5155-5230), i.e. the frame reader of
+// src/libFLAC/stream_decoder.c (read_frame_ :2373, read_frame_header_ :2609, read_subframe_ :2866, read_subframe_fixed_ :3082,
+// read_subframe_lpc_ :3155, read_residual_partitioned_rice_ :3299), the restoration lpc.c:978-1578 / fixed.c:571-667 and the
+// inter-channel undo stream_decoder.c:2503-2553.  Written from the format, not from that code.
+//
+// Rice decoding is serial within a subframe and the subframes of a frame are found one after the other, so the unit of
+// parallelism is the frame: a 16384-frame batch is 256 wavefronts.  The decoder pushes every decoded CODED-channel
+// sample (after the wasted-bits shift) into a SINK:
+//   * the batch kernel's sink compares it with the value the input PCM implies for that coded channel (left, right,
+//     (L+R)>>1, L-R: the decorrelation is a bijection, so "every coded channel equals its expectation" <=> "every
+//     output sample equals the input") -- no decoded sample is ever stored;
+//   * the detail pass (run for the first bad frame only) stores the channels, undoes the decorrelation and locates the
+//     first differing output sample exactly as the reference reports it.
+#ifndef FLACGPU_DECODE_H
+#define FLACGPU_DECODE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifndef FLACGPU_HD
+#define FLACGPU_HD
+#endif
+
+namespace flacgpu {
+
+// what the decoder must find in a frame header for it to belong to this stream at this position
+struct DecodeExpect {
+	uint32_t channels, bps, blocksize;       // of the stream
+	uint32_t n;                              // samples this frame must hold (the short last block has fewer)
+	uint64_t frame_number;
+};
+enum { DEC_OK = 0, DEC_MISMATCH = 1, DEC_ERROR = 2 };
+
+// ---- MSB-first bit reader over global memory: 64-bit window, refilled a 32-bit word at a time ------------------------
+struct BitReader {
+	const uint32_t *wp;            // next aligned word to load
+	const uint8_t *end;            // one past the last byte that may be read (the end of the buffer the frames lie in)
+	uint32_t pre;                  // the word in front of wp, already loaded (a lane has no other wavefront to hide its load latency behind)
+	uint64_t acc;                  // valid bits left-aligned, zeros behind them
+	uint32_t nb;                   // valid bits in acc
+	uint64_t consumed;             // bits consumed so far (from the first byte of the frame)
+	uint64_t limit;                // bits the frame body holds: reading beyond is an error
+	uint32_t bad;
+};
+FLACGPU_HD inline uint32_t br_fetch(BitReader &b)
+{
+	const uint8_t *q = (const uint8_t *)b.wp;
+	b.wp++;
+	if(q + 4 <= b.end) return __builtin_bswap32(*(const uint32_t *)q);
+	uint32_t v = 0;                                                    // the last, partial word of the buffer (and zeros beyond it)
+	for(int k = 0; k < 4; k++) if(q + k < b.end) v |= (uint32_t)q[k] << (24 - 8 * k);
+	return v;
+}
+FLACGPU_HD inline uint32_t br_load(BitReader &b) { const uint32_t v = b.pre; b.pre = br_fetch(b); return v; }
+FLACGPU_HD inline void br_refill(BitReader &b) { if(b.nb <= 32) { b.acc |= (uint64_t)br_load(b) << (32 - b.nb); b.nb += 32; } }
+// frame bytes [p, p + nbytes) inside the buffer [buf_lo, buf_hi)
+FLACGPU_HD inline void br_init(BitReader &b, const uint8_t *p, size_t nbytes, const uint8_t *buf_hi)
+{
+	const uintptr_t a = (uintptr_t)p;
+	b.wp = (const uint32_t *)(a & ~(uintptr_t)3);
+	b.end = buf_hi;
+	b.pre = br_fetch(b);
+	b.acc = 0; b.nb = 0; b.consumed = 0; b.limit = (uint64_t)nbytes * 8; b.bad = 0;
+	const uint32_t skip = (uint32_t)(a & 3) * 8;
+	br_refill(b);
+	b.acc <<= skip; b.nb -= skip;
+	br_refill(b);
+}
+FLACGPU_HD inline uint32_t br_get(BitReader &b, uint32_t n)            // 0 <= n <= 32
+{
+	if(n == 0) return 0;
+	br_refill(b);                                                      // now nb >= 33 unless the buffer ran out
+	const uint32_t v = (uint32_t)(b.acc >> (64 - n));
+	b.acc <<= n; b.nb -= n; b.consumed += n;
+	return v;
+}
+FLACGPU_HD inline int32_t br_get_signed(BitReader &b, uint32_t n)      // 1 <= n <= 32
+{
+	const uint32_t v = br_get(b, n);
+	return n >= 32 ? (int32_t)v : (int32_t)(v << (32 - n)) >> (32 - n);
+}
+FLACGPU_HD inline int64_t br_get_sample(BitReader &b, uint32_t n)      // up to 33 bits (the side channel of a 32-bit stream)
+{
+	if(n <= 32) return (int64_t)br_get_signed(b, n);
+	const uint64_t hi = br_get(b, n - 32), lo = br_get(b, 32);
+	const uint64_t v = (hi << 32) | lo;
+	return (int64_t)(v << (64 - n)) >> (64 - n);
+}
+FLACGPU_HD inline uint32_t br_unary(BitReader &b)                      // zeros in front of the next one bit
+{
+	uint32_t z = 0;
+	for(;;) {
+		br_refill(b);
+		if(b.acc != 0) {
+			const uint32_t lz = (uint32_t)__builtin_clzll(b.acc);          // < nb: the valid bits hold a one
+			z += lz;
+			b.acc <<= lz; b.acc <<= 1; b.nb -= lz + 1; b.consumed += lz + 1;
+			return z;
+		}
+		z += b.nb; b.consumed += b.nb; b.nb = 0;
+		if(b.consumed > b.limit) { b.bad = 1; return z; }              // ran off the frame: stop
+	}
+}
+
+FLACGPU_HD inline uint32_t dec_ilog2(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+
+// CRC-8 of the frame header (poly 0x07), bit by bit: at most 16 bytes per frame
+FLACGPU_HD inline uint32_t dec_crc8(const uint8_t *p, uint32_t n)
+{
+	uint32_t c = 0;
+	for(uint32_t i = 0; i < n; i++) { c ^= p[i]; for(int k = 0; k < 8; k++) c = (c & 0x80u) ? ((c << 1) ^ 0x07u) & 0xffu : (c << 1) & 0xffu; }
+	return c;
+}
+
+// CRC-16 of a whole frame body (poly 0x8005, init 0, crc.c:376), bit by bit: the detail pass only (one frame per batch at
+// most); the batch pass checks the footers with the span-parallel kernel of flacgpu_verify.hip
+FLACGPU_HD inline uint32_t dec_crc16(const uint8_t *p, size_t n)
+{
+	uint32_t c = 0;
+	for(size_t i = 0; i < n; i++) { c ^= (uint32_t)p[i] << 8; for(int k = 0; k < 8; k++) c = (c & 0x8000u) ? ((c << 1) ^ 0x8005u) & 0xffffu : (c << 1) & 0xffffu; }
+	return c;
+}
+
+struct FrameHead { uint32_t ca; uint32_t n; };
+
+// frame header: sync, blocking strategy, block size / sample rate / channel assignment / sample size codes, UTF-8 frame
+// number, optional block size and sample rate fields, CRC-8 (format: SURVEY.md appendix B)
+FLACGPU_HD inline int decode_frame_header(BitReader &b, const uint8_t *p, const DecodeExpect &E, FrameHead &H)
+{
+	if(br_get(b, 15) != 0x7ffcu || br_get(b, 1) != 0) return DEC_ERROR;           // sync + reserved, fixed-blocksize stream
+	const uint32_t bs_code = br_get(b, 4), sr_code = br_get(b, 4), ca = br_get(b, 4), bps_code = br_get(b, 3);
+	if(br_get(b, 1) != 0) return DEC_ERROR;
+	uint64_t fn;
+	{
+		const uint32_t b0 = br_get(b, 8);
+		uint32_t extra;
+		if(b0 < 0x80u) { fn = b0; extra = 0; }
+		else if((b0 & 0xe0u) == 0xc0u) { fn = b0 & 0x1fu; extra = 1; }
+		else if((b0 & 0xf0u) == 0xe0u) { fn = b0 & 0x0fu; extra = 2; }
+		else if((b0 & 0xf8u) == 0xf0u) { fn = b0 & 0x07u; extra = 3; }
+		else if((b0 & 0xfcu) == 0xf8u) { fn = b0 & 0x03u; extra = 4; }
+		else if((b0 & 0xfeu) == 0xfcu) { fn = b0 & 0x01u; extra = 5; }
+		else return DEC_ERROR;
+		for(uint32_t k = 0; k < extra; k++) { const uint32_t c = br_get(b, 8); if((c & 0xc0u) != 0x80u) return DEC_ERROR; fn = (fn << 6) | (c & 0x3fu); }
+	}
+	uint32_t bs;
+	if(bs_code == 0) return DEC_ERROR;
+	else if(bs_code == 1) bs = 192;
+	else if(bs_code <= 5) bs = 576u << (bs_code - 2);
+	else if(bs_code == 6) bs = br_get(b, 8) + 1;
+	else if(bs_code == 7) bs = br_get(b, 16) + 1;
+	else bs = 256u << (bs_code - 8);
+	if(sr_code == 12) (void)br_get(b, 8);
+	else if(sr_code == 13 || sr_code == 14) (void)br_get(b, 16);
+	else if(sr_code == 15) return DEC_ERROR;
+	const uint32_t hdr_bytes = (uint32_t)(b.consumed >> 3);
+	if(br_get(b, 8) != dec_crc8(p, hdr_bytes) || b.consumed > b.limit) return DEC_ERROR;
+	const uint32_t bps_of = bps_code == 1 ? 8u : bps_code == 2 ? 12u : bps_code == 4 ? 16u : bps_code == 5 ? 20u : bps_code == 6 ? 24u : bps_code == 7 ? 32u : 0u;
+	if(bps_code == 3) return DEC_ERROR;
+	if(fn != E.frame_number || bs != E.n || (bps_code && bps_of != E.bps)) return DEC_ERROR;
+	if((ca < 8 && ca + 1 != E.channels) || ca > 10 || (ca >= 8 && E.channels != 2)) return DEC_ERROR;
+	H.ca = ca; H.n = bs;
+	return DEC_OK;
+}
+
+// One subframe: header, then sample by sample -- constant / verbatim / warm-up / predicted (fixed predictors are FIRs with
+// binomial taps and shift 0, fixed.c:571) -- each handed to sink(i, value << wasted).  MAXORD: taps kept in registers
+// (orders above it are a decode error for this instantiation: the caller picks MAXORD from the stream's settings; 32 covers
+// the format).  ST: int32_t, or int64_t when a 33-bit sample can occur (side channel of a 32-bit stream).
+template <int MAXORD, typename ST, class SINK>
+FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_nominal, SINK &sink)
+{
+	if(br_get(b, 1) != 0) return DEC_ERROR;
+	const uint32_t type = br_get(b, 6);
+	uint32_t wasted = 0;
+	if(br_get(b, 1)) wasted = br_unary(b) + 1;
+	if(wasted >= sbps_nominal) return DEC_ERROR;
+	const uint32_t sb = sbps_nominal - wasted;
+	if(type == 0) {                                             // CONSTANT
+		const int64_t v = br_get_sample(b, sb);
+		for(uint32_t i = 0; i < n; i++) sink(i, (int64_t)((uint64_t)v << wasted));
+		return b.bad ? DEC_ERROR : DEC_OK;
+	}
+	if(type == 1) {                                             // VERBATIM
+		for(uint32_t i = 0; i < n; i++) {
+			const int64_t v = br_get_sample(b, sb);
+			sink(i, (int64_t)((uint64_t)v << wasted));
+			if(b.consumed > b.limit) return DEC_ERROR;
+		}
+		return DEC_OK;
+	}
+	uint32_t order;
+	bool lpc;
+	if(type >= 8 && type <= 12) { order = type - 8; lpc = false; }
+	else if(type >= 32) { order = type - 31; lpc = true; }
+	else return DEC_ERROR;                                      // reserved
+	if(order > n || order > (uint32_t)MAXORD) return DEC_ERROR;
+	ST h[MAXORD];                                               // h[j] = sample i-1-j
+	int32_t q[MAXORD];
+#pragma unroll
+	for(int j = 0; j < MAXORD; j++) { h[j] = 0; q[j] = 0; }
+	for(uint32_t i = 0; i < order; i++) {
+		const int64_t v = br_get_sample(b, sb);
+		sink(i, (int64_t)((uint64_t)v << wasted));
+#pragma unroll
+		for(int j = MAXORD - 1; j > 0; j--) h[j] = h[j - 1];
+		h[0] = (ST)v;
+	}
+	int32_t shift = 0;
+	bool wide_sum = true;                                       // 64-bit prediction sum
+	if(lpc) {
+		const uint32_t prec = br_get(b, 4) + 1;
+		if(prec == 16) return DEC_ERROR;
+		shift = br_get_signed(b, 5);
+		if(shift < 0) return DEC_ERROR;
+#pragma unroll
+		for(int j = 0; j < MAXORD; j++) if((uint32_t)j < order) q[j] = br_get_signed(b, prec);
+		// the reference decoder's choice of arithmetic (stream_decoder.c:3224-3232): 32-bit wrap-around when the bound fits
+		wide_sum = sb + prec + dec_ilog2(order) > 32;
+	}
+	else {
+		if(order == 1) { q[0] = 1; }
+		else if(order == 2) { q[0] = 2; q[1] = -1; }
+		else if(order == 3) { q[0] = 3; q[1] = -3; q[2] = 1; }
+		else if(order == 4) { q[0] = 4; q[1] = -6; q[2] = 4; q[3] = -1; }
+		wide_sum = sb + order > 32;                             // fixed.c:571-667: 64-bit restoration when the differences may need it
+	}
+	// residual: coding method, partition order, then per partition the Rice parameter (or the escape code and a raw width)
+	const uint32_t method = br_get(b, 2);
+	if(method > 1) return DEC_ERROR;
+	const uint32_t plen = method ? 5u : 4u, esc = method ? 31u : 15u;
+	const uint32_t po = br_get(b, 4);
+	const uint32_t psize = n >> po;
+	if(po && ((psize << po) != n || psize < order)) return DEC_ERROR;
+	if(b.consumed > b.limit) return DEC_ERROR;
+	uint32_t next_part = order, k = 0, raw = 0;                 // sample index at which the next partition starts
+	bool escaped = false;
+	uint32_t part = 0;
+	for(uint32_t i = order; i < n; i++) {
+		while(i == next_part) {                                 // (a partition 0 that holds no residual at all is legal: psize == order)
+			k = br_get(b, plen);
+			escaped = k == esc;
+			if(escaped) raw = br_get(b, 5);
+			part++;
+			next_part = po ? part * psize : n;
+		}
+		int64_t r;
+		if(escaped) r = raw ? (int64_t)br_get_signed(b, raw) : 0;
+		else {
+			const uint32_t msbs = br_unary(b);
+			const uint32_t u = (msbs << k) | br_get(b, k);
+			r = (int64_t)(int32_t)((u >> 1) ^ (0u - (u & 1u)));
+		}
+		int64_t sum = 0;
+		if(wide_sum) {
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)h[j];
+		}
+		else {
+			uint32_t s32 = 0;
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++) s32 += (uint32_t)q[j] * (uint32_t)(int32_t)h[j];
+			sum = (int64_t)(int32_t)s32;
+		}
+		const int64_t v = r + (sum >> shift);
+		sink(i, (int64_t)((uint64_t)v << wasted));
+#pragma unroll
+		for(int j = MAXORD - 1; j > 0; j--) h[j] = h[j - 1];
+		h[0] = (ST)v;
+		if(b.consumed > b.limit) return DEC_ERROR;
+	}
+	return b.bad ? DEC_ERROR : DEC_OK;
+}
+
+// after the last subframe: zero bits up to the byte boundary, and the body must end exactly where the CRC-16 starts
+FLACGPU_HD inline int decode_frame_tail(BitReader &b)
+{
+	const uint32_t rem = (uint32_t)(b.consumed & 7);
+	if(rem && br_get(b, 8 - rem) != 0) return DEC_ERROR;
+	return (b.bad || b.consumed != b.limit) ? DEC_ERROR : DEC_OK;
+}
+// nominal width of coded channel ch under channel assignment ca (the side channel carries one bit more)
+FLACGPU_HD inline uint32_t coded_bps(uint32_t bps, uint32_t ca, uint32_t ch)
+{
+	const bool side = (ca == 8 && ch == 1) || (ca == 9 && ch == 0) || (ca == 10 && ch == 1);
+	return bps + (side ? 1u : 0u);
+}
+// the value the input implies for coded channel ch at one inter-channel sample (x = the C input samples of it)
+FLACGPU_HD inline int64_t coded_expectation(const int32_t *x, uint32_t ca, uint32_t ch)
+{
+	if(ca < 8) return (int64_t)x[ch];
+	const int64_t l = x[0], r = x[1];
+	if(ca == 8) return ch == 0 ? l : l - r;
+	if(ca == 9) return ch == 0 ? l - r : r;
+	return ch == 0 ? (l + r) >> 1 : l - r;
+}
+
+// ---- the fast pass: one frame against its input; DEC_OK / DEC_MISMATCH / DEC_ERROR -------------------------------------
+// pcm: the frame's input, interleaved int32 [n][C]
+template <int MAXORD, typename ST>
+FLACGPU_HD inline int verify_frame_fast(const uint8_t *p, size_t len, const uint8_t *buf_hi, const DecodeExpect &E, const int32_t *pcm)
+{
+	if(len < 6) return DEC_ERROR;
+	BitReader b;
+	br_init(b, p, len - 2, buf_hi);
+	FrameHead H;
+	if(decode_frame_header(b, p, E, H) != DEC_OK) return DEC_ERROR;
+	const uint32_t C = E.channels;
+	uint32_t differ = 0;
+	for(uint32_t ch = 0; ch < C; ch++) {
+		const uint32_t ca = H.ca;
+		auto sink = [&](uint32_t i, int64_t v) { differ |= (uint32_t)(v != coded_expectation(pcm + (size_t)i * C, ca, ch)); };
+		if(decode_subframe<MAXORD, ST>(b, H.n, coded_bps(E.bps, H.ca, ch), sink) != DEC_OK) return DEC_ERROR;
+	}
+	if(decode_frame_tail(b) != DEC_OK) return DEC_ERROR;
+	return differ ? DEC_MISMATCH : DEC_OK;
+}
+
+// ---- the detail pass: decode into x[C][stride] (int64), undo the decorrelation (stream_decoder.c:2503-2553), find the
+// first output sample that differs from the input in stream order (sample-major, then channel) ----------------------------
+struct DecodeDetail { int32_t status; uint32_t channel, sample; int32_t expected, got; };
+template <int MAXORD, typename ST>
+FLACGPU_HD inline void verify_frame_detail(const uint8_t *p, size_t len, const uint8_t *buf_hi, const DecodeExpect &E, const int32_t *pcm,
+                                           int64_t *x, size_t stride, DecodeDetail &D)
+{
+	D.status = DEC_ERROR; D.channel = 0; D.sample = 0; D.expected = 0; D.got = 0;
+	if(len < 6 || dec_crc16(p, len - 2) != (((uint32_t)p[len - 2] << 8) | p[len - 1])) return;
+	BitReader b;
+	br_init(b, p, len - 2, buf_hi);
+	FrameHead H;
+	if(decode_frame_header(b, p, E, H) != DEC_OK) return;
+	const uint32_t C = E.channels, n = H.n;
+	for(uint32_t ch = 0; ch < C; ch++) {
+		int64_t *xc = x + (size_t)ch * stride;
+		auto sink = [&](uint32_t i, int64_t v) { xc[i] = v; };
+		if(decode_subframe<MAXORD, ST>(b, n, coded_bps(E.bps, H.ca, ch), sink) != DEC_OK) return;
+	}
+	if(decode_frame_tail(b) != DEC_OK) return;
+	if(H.ca == 8) for(uint32_t i = 0; i < n; i++) x[stride + i] = x[i] - x[stride + i];
+	else if(H.ca == 9) for(uint32_t i = 0; i < n; i++) x[i] += x[stride + i];
+	else if(H.ca == 10) for(uint32_t i = 0; i < n; i++) {
+		const int64_t sd = x[stride + i];
+		const int64_t mid = (int64_t)(((uint64_t)x[i] << 1) | ((uint64_t)sd & 1));
+		x[i] = (mid + sd) >> 1; x[stride + i] = (mid - sd) >> 1;
+	}
+	D.status = DEC_OK;
+	for(uint32_t i = 0; i < n; i++)
+		for(uint32_t ch = 0; ch < C; ch++) {
+			const int32_t want = pcm[(size_t)i * C + ch];
+			if(x[(size_t)ch * stride + i] != (int64_t)want) {
+				D.status = DEC_MISMATCH; D.channel = ch; D.sample = i; D.expected = want; D.got = (int32_t)x[(size_t)ch * stride + i];
+				return;
+			}
+		}
+}
+
+} // namespace flacgpu
+#endif

@@ -138,6 +138,11 @@ struct StageParams {
 	uint8_t map[FLACGPU_MAX_CHANNELS];   // input channel c goes to output channel map[c]
 };
 hipError_t launch_stage_raw(const StageParams &S, const void *d_raw, uint64_t nvalues, int32_t *d_pcm, uint32_t *d_err, hipStream_t s);
+// the self check (flacgpu_verify.hip, crc_check_kernel in flacgpu_kernels.hip)
+struct VerifyState { uint32_t first_bad; uint32_t pad[3]; };      // index of the first frame of the batch that failed (0xffffffff: none)
+hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s);
+hipError_t launch_verify(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t tail_n,
+                         uint64_t first, const int32_t *pcm, int64_t *scratch, VerifyState *state, flacgpu_verify_result *result, hipStream_t s);
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);
 hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,
                           uint8_t *out, uint64_t out_cap, uint32_t nframes, hipStream_t s);

@@ -898,6 +898,44 @@ __global__ __launch_bounds__(TPB) void compact_kernel(const uint8_t *__restrict_
 	if(threadIdx.x < nb - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------------------------
+// crc_check_kernel: the CRC-16 footer of every frame of a batch (crc.c:376), for the self check (flacgpu_verify.hip).
+// One wavefront per frame; a lane takes 64-byte spans of the frame a byte at a time and shifts its remainder past what
+// follows (the span algebra of frame_crc16 above); frames sit at arbitrary byte offsets, hence byte loads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void crc_check_kernel(const uint8_t *__restrict__ frames, const uint32_t *__restrict__ frame_bytes,
+                                                        const uint64_t *__restrict__ offsets, uint32_t nframes, VerifyState *__restrict__ state)
+{
+	const uint32_t f = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+	const int lane = (int)threadIdx.x & 63;
+	if(f >= nframes) return;
+	const uint32_t len = frame_bytes[f];
+	bool bad = len == 0xffffffffu || len < 3;
+	if(!bad) {
+		const uint8_t *p = frames + offsets[f];
+		const uint32_t body = len - 2;
+		const uint32_t nsp = (body + CRC_SPAN - 1) / CRC_SPAN;
+		const uint32_t last_len = body - (nsp - 1) * CRC_SPAN;
+		uint32_t c = 0;
+		for(uint32_t sp = (uint32_t)lane; sp < nsp; sp += 64) {
+			const uint8_t *q = p + (size_t)sp * CRC_SPAN;
+			const uint32_t n = sp + 1 < nsp ? CRC_SPAN : last_len;
+			uint32_t cs = 0;
+			for(uint32_t k = 0; k < n; k++) cs = ((cs << 8) & 0xffffu) ^ g_crc_tables.tab[0][(cs >> 8) ^ q[k]];
+			if(sp + 1 < nsp) {
+				const uint32_t m = nsp - 2 - sp;                  // whole spans behind this one, then the last one
+				// frames beyond the span table (4 MiB) cannot come out of this engine
+				cs = m < CRC_MAX_SPANS ? gf16_mul(gf16_mul(cs, g_crc_tables.xspan[m]), g_crc_tables.xbyte[last_len]) : 0xffffffffu;
+			}
+			c ^= cs;
+		}
+#pragma unroll
+		for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
+		bad = c != (((uint32_t)p[body] << 8) | p[body + 1]);
+	}
+	if(bad && lane == 0) atomicMin(&state->first_bad, f);
+}
+
 } // namespace flacgpu
 
 // ---------------------------------------------------------------------------------------------
@@ -952,6 +990,11 @@ hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes
 	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
 	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
 	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
+}
+hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s)
+{
+	hipLaunchKernelGGL(crc_check_kernel, dim3((nframes + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, frames, fb, offsets, nframes, state);
+	return hipGetLastError();
 }
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)
 {

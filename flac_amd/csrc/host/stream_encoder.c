@@ -111,7 +111,6 @@ struct FLAC__StreamEncoderPrivate {
 	float *tail_windows;
 	pthread_t worker;
 	int worker_started, worker_quit;
-	uint32_t verify_threads;
 	flacgpu_host_verify_result verify_stats;  /* get_verify_decoder_error_stats */
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
@@ -572,8 +571,14 @@ static void run_batch_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
 	}
 	b->total = flacgpu_encode_batch_raw(p->gpu, b->raw, &p->rawfmt, b->nframes, b->first_frame, b->tail, tw, b->out, p->out_cap, b->frame_bytes);
 	b->vres.status = 0;
-	if(b->total >= 0 && s->verify)          /* write_bitbuffer_ verifies every frame before it is written (:3000-3018) */
-		(void)flacgpu_host_verify_batch(s, b->out, b->frame_bytes, b->nframes, b->tail, b->first_frame, b->raw, p->width, p->verify_threads, &b->vres);
+	if(b->total >= 0 && s->verify) {
+		/* write_bitbuffer_ verifies every frame before it is written (:3000-3018): here the engine has decoded the batch again on
+		 * the device, next to the staged input (flacgpu_set_verify); this is its verdict */
+		flacgpu_verify_result v;
+		if(flacgpu_last_verify_result(p->gpu, &v) != FLACGPU_OK) { b->total = FLACGPU_ERR_LAUNCH; return; }
+		b->vres.status = v.status; b->vres.frame_number = v.frame_number; b->vres.channel = v.channel; b->vres.sample = v.sample;
+		b->vres.absolute_sample = v.absolute_sample; b->vres.expected = v.expected; b->vres.got = v.got;
+	}
 }
 static void *worker_main(void *arg)
 {
@@ -732,8 +737,6 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 		}
 		if(bf < 1) bf = 1; else if(bf > 65536) bf = 65536;
 		p->batch_frames = (uint32_t)bf;
-		env = getenv("FLACGPU_VERIFY_THREADS");
-		p->verify_threads = env ? (uint32_t)atoi(env) : 8;
 		memset(&p->verify_stats, 0, sizeof p->verify_stats);
 		env = getenv("FLACGPU_DEVICE");
 		const int device = env ? atoi(env) : 0;
@@ -746,6 +749,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 		}
 		if(r == FLACGPU_OK) r = flacgpu_create(&cfg, windows, &p->gpu);
 		free(windows);
+		if(r == FLACGPU_OK && s->verify) r = flacgpu_set_verify(p->gpu, 1);
 		if(r == FLACGPU_OK) {
 			p->width = (s->bits_per_sample + 7) / 8;
 			memset(&p->rawfmt, 0, sizeof p->rawfmt);

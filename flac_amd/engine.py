@@ -80,6 +80,12 @@ class SubframeInfo(C.Structure):
                 ("bits", C.c_uint32)]
 
 
+class VerifyResult(C.Structure):
+    """flacgpu_verify_result (include/flacgpu.h)"""
+    _fields_ = [("status", C.c_int32), ("frame_number", C.c_uint32), ("channel", C.c_uint32), ("sample", C.c_uint32),
+                ("absolute_sample", C.c_uint64), ("expected", C.c_int32), ("got", C.c_int32)]
+
+
 _host = None
 _engine = None
 
@@ -135,6 +141,12 @@ def load_engine():
         lib.flacgpu_encode_batch_raw.restype = C.c_int64
         lib.flacgpu_encode_batch_raw.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RawFormat), C.c_uint32, C.c_uint64, C.c_uint32,
                                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.flacgpu_verify_batch_device.restype = C.c_int
+        lib.flacgpu_verify_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.flacgpu_set_verify.restype = C.c_int
+        lib.flacgpu_set_verify.argtypes = [C.c_void_p, C.c_uint32]
+        lib.flacgpu_last_verify_result.restype = C.c_int
+        lib.flacgpu_last_verify_result.argtypes = [C.c_void_p, C.POINTER(VerifyResult)]
         lib.flacgpu_set_subbatches.restype = C.c_int
         lib.flacgpu_set_subbatches.argtypes = [C.c_void_p, C.c_uint32]
         lib.flacgpu_strerror.restype = C.c_char_p
@@ -294,6 +306,25 @@ class FrameEngine:
                                                  d_frame_bytes_ptr, d_total_ptr, stream)
         if r != 0:
             raise FlacGpuError("flacgpu_encode_batch_device: %s" % self.lib.flacgpu_strerror(r).decode())
+
+    def set_verify(self, on=True):
+        """every batch of encode()/encode_raw() is decoded again on the device and compared with its input"""
+        r = self.lib.flacgpu_set_verify(self.ctx, 1 if on else 0)
+        if r != 0:
+            raise FlacGpuError("flacgpu_set_verify: %s" % self.lib.flacgpu_strerror(r).decode())
+
+    def last_verify_result(self):
+        v = VerifyResult()
+        r = self.lib.flacgpu_last_verify_result(self.ctx, C.byref(v))
+        if r != 0:
+            raise FlacGpuError("flacgpu_last_verify_result: %s" % self.lib.flacgpu_strerror(r).decode())
+        return v
+
+    def verify_device(self, d_frames_ptr, d_frame_bytes_ptr, nframes, d_pcm_ptr, d_result_ptr, first_frame_number=0, tail=0, stream=None):
+        """flacgpu_verify_batch_device: all pointers are raw device addresses; d_result_ptr receives a VerifyResult. Asynchronous."""
+        r = self.lib.flacgpu_verify_batch_device(self.ctx, d_frames_ptr, d_frame_bytes_ptr, nframes, first_frame_number, tail, d_pcm_ptr, d_result_ptr, stream)
+        if r != 0:
+            raise FlacGpuError("flacgpu_verify_batch_device: %s" % self.lib.flacgpu_strerror(r).decode())
 
     def last_batch_info(self, nframes):
         sub = (SubframeInfo * (nframes * self.channels))()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FLACGPU_ABI_VERSION 3
+#define FLACGPU_ABI_VERSION 4
 #define FLACGPU_MAX_CHANNELS 8
 #define FLACGPU_MAX_APODIZATIONS 32     /* FLAC__MAX_APODIZATION_FUNCTIONS */
 
@@ -145,6 +145,31 @@ int64_t flacgpu_encode_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgp
                                  uint64_t first_frame_number, uint32_t last_block_samples,
                                  const float *tail_windows, uint8_t *out, size_t out_cap,
                                  uint32_t *frame_bytes);
+
+/* ---- the encoder's self check on the device (FLAC__stream_encoder_set_verify: the reference decodes every frame it wrote
+ * with its own stream decoder and compares, write_bitbuffer_ stream_encoder.c:3000-3018, verify_write_callback_ :5155-5230;
+ * the frame reader it uses is stream_decoder.c:2373-3400, the restoration lpc.c:978-1578 / fixed.c:571-667) ---- */
+typedef struct {
+	int32_t  status;           /* 0 every frame decodes back to its input; 1 audio mismatch (the fields below locate the first one
+	                              in stream order, as FLAC__stream_encoder_get_verify_decoder_error_stats reports it);
+	                              2 a frame does not decode (bad CRC, malformed header or subframe, wrong frame number / length) */
+	uint32_t frame_number;     /* of the first bad frame */
+	uint32_t channel, sample;  /* status 1: output channel and sample index within the block */
+	uint64_t absolute_sample;  /* frame_number * blocksize + sample */
+	int32_t  expected, got;
+} flacgpu_verify_result;
+
+/* Decode `nframes` frames lying back to back at d_frames (lengths d_frame_bytes, device) and compare them with d_pcm, the
+ * interleaved int32 input of exactly these frames (device; the short last block as in flacgpu_encode_batch).  Frames must
+ * carry the numbers first_frame_number, first_frame_number + 1, ...  The verdict goes to d_result (device).  Asynchronous
+ * on `stream`.  Returns 0 or a negative FLACGPU_ERR_*. */
+int flacgpu_verify_batch_device(flacgpu_ctx *ctx, const uint8_t *d_frames, const uint32_t *d_frame_bytes, uint32_t nframes,
+                                uint64_t first_frame_number, uint32_t last_block_samples, const int32_t *d_pcm,
+                                flacgpu_verify_result *d_result, void *stream);
+/* on != 0: every batch encoded through flacgpu_encode_batch / flacgpu_encode_batch_raw is verified on the device before the
+ * call returns; flacgpu_last_verify_result gives the verdict of the most recent batch (status 0 when verification is off). */
+int flacgpu_set_verify(flacgpu_ctx *ctx, uint32_t on);
+int flacgpu_last_verify_result(flacgpu_ctx *ctx, flacgpu_verify_result *out);
 
 /* Diagnostics of the most recent batch: [nframes][channels] subframe choices and the channel
  * assignment per frame (0 independent, 1 left/side, 2 right/side, 3 mid/side). Host arrays. */

@@ -1,0 +1,55 @@
+// oracle/decode_pin.cpp -- TEST INFRASTRUCTURE ONLY.
+// The product's frame decoder (flac_amd/csrc/flacgpu_decode.h: the code every lane of the GPU verify kernels runs)
+// compiled for the host and driven the way flacgpu_verify.hip drives it: the fast pass over every frame, the first
+// frame that is not OK, the detail pass on that frame.  tests/test_decode_pin.py checks it against the host frame
+// decoder (host/verify.c) and against injected damage, so that the decoder's logic is pinned without a GPU.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../flac_amd/csrc/flacgpu_decode.h"
+
+using namespace flacgpu;
+
+struct pin_result { int32_t status; uint32_t frame_number, channel, sample; uint64_t absolute_sample; int32_t expected, got; };
+
+template <int MAXORD, typename ST>
+static int run(const uint8_t *frames, const uint32_t *fb, uint32_t nframes, uint32_t C, uint32_t bps, uint32_t N, uint32_t tail, uint64_t first,
+               const int32_t *pcm, size_t total_bytes, pin_result *out)
+{
+	size_t off = 0;
+	memset(out, 0, sizeof *out);
+	for(uint32_t f = 0; f < nframes; f++) {
+		DecodeExpect E = {C, bps, N, (f + 1 == nframes && tail) ? tail : N, first + f};
+		const int32_t *fp = pcm + (size_t)f * N * C;
+		int st = verify_frame_fast<MAXORD, ST>(frames + off, fb[f], frames + total_bytes, E, fp);
+		// (on the GPU the footers are checked by their own kernel; a frame it flags is a frame that does not decode)
+		if(fb[f] >= 6 && dec_crc16(frames + off, fb[f] - 2) != (((uint32_t)frames[off + fb[f] - 2] << 8) | frames[off + fb[f] - 1])) st = DEC_ERROR;
+		if(st != DEC_OK) {
+			int64_t *x = (int64_t *)malloc(sizeof(int64_t) * (size_t)C * N);
+			DecodeDetail D;
+			verify_frame_detail<MAXORD, ST>(frames + off, fb[f], frames + total_bytes, E, fp, x, N, D);
+			free(x);
+			out->status = D.status; out->frame_number = (uint32_t)(first + f); out->channel = D.channel; out->sample = D.sample;
+			out->absolute_sample = (first + f) * N + D.sample; out->expected = D.expected; out->got = D.got;
+			// the two passes must agree on what kind of problem this is
+			if(D.status != st) out->status = 100 + 10 * st + D.status;
+			return out->status;
+		}
+		off += fb[f];
+	}
+	return 0;
+}
+
+extern "C" int decodepin_verify_batch(const uint8_t *frames, const uint32_t *fb, uint32_t nframes, uint32_t channels, uint32_t bps, uint32_t blocksize,
+                                      uint32_t tail, uint64_t first_frame, const int32_t *pcm, uint32_t maxord, pin_result *out)
+{
+	size_t total = 0;
+	for(uint32_t f = 0; f < nframes; f++) total += fb[f];
+	const bool wide = bps == 32 && channels == 2;
+#define GO(M) (wide ? run<M, int64_t>(frames, fb, nframes, channels, bps, blocksize, tail, first_frame, pcm, total, out) \
+                    : run<M, int32_t>(frames, fb, nframes, channels, bps, blocksize, tail, first_frame, pcm, total, out))
+	if(maxord <= 8) return GO(8);
+	if(maxord <= 12) return GO(12);
+	return GO(32);
+#undef GO
+}

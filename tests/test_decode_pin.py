@@ -1,0 +1,266 @@
+"""The GPU verify decoder's logic, pinned on the CPU: flac_amd/csrc/flacgpu_decode.h (the code a lane of the verify
+kernels runs) compiled for the host (oracle/libdecodepin.so) and driven like the kernels drive it, against
+ * frames of the oracle over the configuration space: everything must decode back to its input;
+ * the host frame decoder (host/verify.c, flacgpu_host_verify_batch): same verdict and the same located mismatch when
+   the input differs from what was encoded, same "does not decode" when a frame is damaged."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import signals
+from oracle import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PIN_SO = os.path.join(ROOT, "oracle", "libdecodepin.so")
+
+
+class PinResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("frame_number", C.c_uint32), ("channel", C.c_uint32), ("sample", C.c_uint32),
+                ("absolute_sample", C.c_uint64), ("expected", C.c_int32), ("got", C.c_int32)]
+
+
+class HostResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("frame_number", C.c_uint32), ("channel", C.c_uint32), ("sample", C.c_uint32),
+                ("absolute_sample", C.c_uint64), ("expected", C.c_int32), ("got", C.c_int32)]
+
+
+def _pin():
+    if not os.path.exists(PIN_SO):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    lib = C.CDLL(PIN_SO)
+    lib.decodepin_verify_batch.restype = C.c_int
+    lib.decodepin_verify_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                           C.c_void_p, C.c_uint32, C.POINTER(PinResult)]
+    return lib
+
+
+def pin_verify(data, fb, pcm, bps, blocksize, first=0, maxord=32):
+    lib = _pin()
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    n, ch = pcm.shape
+    nfr = len(fb)
+    tail = n - (nfr - 1) * blocksize
+    tail = 0 if tail == blocksize else tail
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    fbs = np.ascontiguousarray(fb, dtype=np.uint32)
+    full = np.zeros((nfr * blocksize, ch), dtype=np.int32)
+    full[:n] = pcm
+    r = PinResult()
+    st = lib.decodepin_verify_batch(buf.ctypes.data, fbs.ctypes.data, nfr, ch, bps, blocksize, tail, first, full.ctypes.data, maxord, C.byref(r))
+    return st, r
+
+
+def host_verify(data, fb, pcm, bps, blocksize, first=0):
+    from flac_amd import engine
+    host = engine.load_host()
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    n, ch = pcm.shape
+    s = engine.make_settings(ch, bps, 44100, 5, blocksize=blocksize, streamable_subset=0)
+    width = (bps + 7) // 8
+    raw = np.zeros((n, ch, 4), dtype=np.uint8)
+    raw[:] = pcm.astype("<i4").view(np.uint8).reshape(n, ch, 4)
+    raw = np.ascontiguousarray(raw[:, :, :width])
+    nfr = len(fb)
+    tail = n - (nfr - 1) * blocksize
+    tail = 0 if tail == blocksize else tail
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    fbs = np.ascontiguousarray(fb, dtype=np.uint32)
+    r = HostResult()
+    host.flacgpu_host_verify_batch.restype = C.c_int
+    host.flacgpu_host_verify_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    st = host.flacgpu_host_verify_batch(C.byref(s), buf.ctypes.data, fbs.ctypes.data, nfr, tail, first, raw.ctypes.data, width, 2, C.byref(r))
+    return st, r
+
+
+CASES = [
+    # (channels, bps, level, blocksize, nsamples, family, kwargs)
+    (2, 16, 8, 4096, 4096 * 5 + 1000, "music", {}),
+    (2, 16, 5, 4096, 4096 * 3, "white", {}),
+    (2, 16, 0, 1152, 1152 * 7 + 13, "music", {}),
+    (1, 16, 8, 4096, 4096 * 3 + 17, "music", {}),
+    (2, 24, 8, 4096, 4096 * 3 + 999, "music", {}),
+    (2, 8, 5, 4096, 4096 * 3, "music", {}),
+    (2, 32, 8, 4096, 4096 * 2 + 100, "music", {}),
+    (2, 32, 5, 4096, 4096 * 2, "white", {}),
+    (6, 16, 5, 4096, 4096 * 2 + 5, "music", {}),
+    (8, 24, 8, 2048, 2048 * 3, "music", {}),
+    (2, 16, 8, 256, 256 * 9 + 31, "music", {}),
+    (2, 16, 5, 4096, 4096 * 3, "silence", {}),
+    (2, 16, 5, 4096, 4096 * 3, "constant", {}),
+    (2, 16, 5, 4096, 4096 * 3, "wasted", {}),
+    (2, 16, 8, 4096, 4096 * 3, "square", {}),
+    (2, 20, 8, 4608, 4608 * 2 + 77, "music", {}),
+    (2, 16, 8, 16384, 16384 * 2, "music", {"max_lpc_order": 32}),
+    (2, 12, 3, 576, 576 * 5, "music", {}),
+    (2, 16, 8, 4096, 4096 * 6 + 3, "mixed", {}),
+    (2, 24, 8, 4096, 4096 * 3, "quiet", {}),
+    (2, 16, 8, 4096, 4096 * 2, "music", {"exhaustive": 1}),
+    (3, 16, 5, 1024, 1024 * 4 + 1, "white", {}),
+]
+
+
+def _signal(family, n, ch, bps, seed):
+    if family == "silence":
+        return signals.silence(n, ch, bps)
+    if family == "constant":
+        return signals.constant(n, ch, bps)
+    if family == "square":
+        return signals.fullscale_square(n, ch, bps)
+    if family == "mixed":
+        return signals.mixed(n, ch, bps, seed=seed)
+    return getattr(signals, family)(n, ch, bps, seed=seed)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dch-%db-l%d-bs%d-%s" % (c[0], c[1], c[2], c[3], c[5]))
+def test_oracle_frames_decode_back_to_their_input(case):
+    ch, bps, level, bs, n, family, kw = case
+    pcm = _signal(family, n, ch, bps, 11)
+    enc = po.oracle_encode(pcm, bps, 44100, level, first_frame=123456, blocksize=bs, **kw)
+    st, r = pin_verify(enc["data"], enc["frame_bytes"], pcm, bps, bs, first=123456)
+    assert st == 0, (st, r.frame_number, r.channel, r.sample, r.expected, r.got)
+    hst, _ = host_verify(enc["data"], enc["frame_bytes"], pcm, bps, bs, first=123456)
+    assert hst == 0
+
+
+@pytest.mark.parametrize("case", CASES[:11], ids=lambda c: "%dch-%db-l%d-bs%d-%s" % (c[0], c[1], c[2], c[3], c[5]))
+def test_mismatch_is_located_like_the_host_decoder_locates_it(case):
+    ch, bps, level, bs, n, family, kw = case
+    pcm = _signal(family, n, ch, bps, 12)
+    enc = po.oracle_encode(pcm, bps, 44100, level, first_frame=7, blocksize=bs, **kw)
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        bad = pcm.copy()
+        i, c = int(rng.integers(0, n)), int(rng.integers(0, ch))
+        bad[i, c] ^= 1 << int(rng.integers(0, bps - 1))
+        if trial % 2:                                     # a second difference later in the stream: the FIRST is reported
+            j = min(n - 1, i + int(rng.integers(1, 3 * bs)))
+            bad[j, (c + 1) % ch] ^= 1
+        st, r = pin_verify(enc["data"], enc["frame_bytes"], bad, bps, bs, first=7)
+        hst, h = host_verify(enc["data"], enc["frame_bytes"], bad, bps, bs, first=7)
+        assert st == hst == 1
+        assert (r.frame_number, r.channel, r.sample, r.absolute_sample, r.expected, r.got) == (h.frame_number, h.channel, h.sample, h.absolute_sample, h.expected, h.got)
+        assert r.frame_number == 7 + i // bs and r.sample == i % bs and r.channel == c
+
+
+@pytest.mark.parametrize("case", CASES[:6], ids=lambda c: "%dch-%db-l%d-bs%d-%s" % (c[0], c[1], c[2], c[3], c[5]))
+def test_damaged_frames_do_not_decode(case):
+    ch, bps, level, bs, n, family, kw = case
+    pcm = _signal(family, n, ch, bps, 13)
+    enc = po.oracle_encode(pcm, bps, 44100, level, blocksize=bs, **kw)
+    fb = enc["frame_bytes"]
+    offs = np.concatenate([[0], np.cumsum(fb.astype(np.int64))])
+    rng = np.random.default_rng(9)
+    for trial in range(12):
+        d = bytearray(enc["data"])
+        f = int(rng.integers(0, len(fb)))
+        pos = int(offs[f]) + int(rng.integers(0, fb[f]))
+        d[pos] ^= 1 << int(rng.integers(0, 8))
+        st, r = pin_verify(bytes(d), fb, pcm, bps, bs)
+        hst, h = host_verify(bytes(d), fb, pcm, bps, bs)
+        assert st == hst == 2 and r.frame_number == h.frame_number == f
+
+
+def test_damage_that_keeps_the_crc_is_still_caught():
+    """a frame whose CRC-16 was recomputed after the damage: the body itself must fail to decode or to match"""
+    lib = po.load_oracle()
+    pcm = signals.music(4096 * 4, 2, 16, seed=21)
+    enc = po.oracle_encode(pcm, 16, 44100, 8)
+    fb = enc["frame_bytes"]
+    offs = np.concatenate([[0], np.cumsum(fb.astype(np.int64))])
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        d = np.frombuffer(enc["data"], dtype=np.uint8).copy()
+        f = int(rng.integers(0, len(fb)))
+        pos = int(offs[f]) + int(rng.integers(6, fb[f] - 2))
+        d[pos] ^= 1 << int(rng.integers(0, 8))
+        body = d[offs[f]:offs[f + 1] - 2]
+        crc = lib.fo_crc16(body.ctypes.data, body.size)
+        d[offs[f + 1] - 2], d[offs[f + 1] - 1] = crc >> 8, crc & 0xff
+        st, r = pin_verify(d.tobytes(), fb, pcm, 16, 4096)
+        hst, h = host_verify(d.tobytes(), fb, pcm, 16, 4096)
+        assert st in (1, 2) and st == hst and r.frame_number == h.frame_number == f
+        if st == 1:
+            assert (r.channel, r.sample, r.expected, r.got) == (h.channel, h.sample, h.expected, h.got)
+
+
+class _Bits:
+    def __init__(self):
+        self.bits = []
+
+    def put(self, v, n):
+        for k in range(n - 1, -1, -1):
+            self.bits.append((v >> k) & 1)
+
+    def bytes(self):
+        b = self.bits + [0] * (-len(self.bits) % 8)
+        return bytes(int("".join(map(str, b[i:i + 8])), 2) for i in range(0, len(b), 8))
+
+
+def test_escaped_partitions_and_rice2_decode():
+    """No encoder here emits escape codes (the reference dropped do_escape_coding), so a frame is built by hand: FIXED order 2,
+    partition order 2 with an escaped partition of 9-bit raw residuals, a Rice partition, an escaped partition of width 0
+    (all zero) and a Rice partition with parameter 0; then the same as RICE2 with a 5-bit parameter of 17."""
+    lib = po.load_oracle()
+    N, order = 64, 2
+    rng = np.random.default_rng(2)
+    for method in (0, 1):
+        res = np.zeros(N, dtype=np.int64)
+        res[order:16] = rng.integers(-200, 200, 16 - order)
+        res[16:32] = rng.integers(-9, 9, 16)
+        res[32:48] = 0
+        res[48:64] = rng.integers(-2, 2, 16)
+        if method:
+            res[16:32] = rng.integers(-(1 << 19), 1 << 19, 16)
+        x = np.zeros(N, dtype=np.int64)
+        x[0], x[1] = 100, 90
+        for i in range(order, N):
+            x[i] = res[i] + 2 * x[i - 1] - x[i - 2]
+        bps = 16 if not method else 32
+        if np.abs(x).max() >= 1 << (bps - 1):
+            x[:] = 0
+        w = _Bits()
+        w.put(0x3ffe, 14); w.put(0, 1); w.put(0, 1)
+        w.put(6, 4); w.put(9, 4); w.put(0, 4); w.put(4 if bps == 16 else 7, 3); w.put(0, 1)
+        w.put(5, 8)                                    # frame number 5
+        w.put(N - 1, 8)
+        hdr = w.bytes()
+        w.put(lib.fo_crc8(hdr, len(hdr)), 8)
+        w.put(0, 1); w.put(8 + order, 6); w.put(0, 1)
+        for i in range(order):
+            w.put(int(x[i]) & ((1 << bps) - 1), bps)
+        plen, esc = (5, 31) if method else (4, 15)
+        w.put(method, 2); w.put(2, 4)
+
+        def rice(v, k):
+            u = (int(v) << 1) ^ (int(v) >> 63)
+            u &= (1 << 64) - 1
+            w.put(0, u >> k); w.put(1, 1)
+            if k:
+                w.put(u & ((1 << k) - 1), k)
+        w.put(esc, plen); w.put(9, 5)
+        for i in range(order, 16):
+            w.put(int(res[i]) & 0x1ff, 9)
+        k1 = 17 if method else 3
+        w.put(k1, plen)
+        for i in range(16, 32):
+            rice(res[i], k1)
+        w.put(esc, plen); w.put(0, 5)
+        w.put(0, plen)
+        for i in range(48, 64):
+            rice(res[i], 0)
+        body = w.bytes()
+        crc = lib.fo_crc16(body, len(body))
+        frame = body + bytes([crc >> 8, crc & 0xff])
+        pcm = x.astype(np.int32).reshape(N, 1)
+        fb = np.array([len(frame)], dtype=np.uint32)
+        st, r = pin_verify(frame, fb, pcm, bps, N, first=5)
+        assert st == 0, (method, st, r.sample, r.expected, r.got)
+        hst, _ = host_verify(frame, fb, pcm, bps, N, first=5)
+        assert hst == 0
+        bad = pcm.copy()
+        bad[40, 0] += 1                              # inside the all-zero escaped partition
+        st, r = pin_verify(frame, fb, bad, bps, N, first=5)
+        assert st == 1 and r.sample == 40 and r.got == int(x[40]) and r.expected == int(x[40]) + 1
