@@ -557,6 +557,10 @@ __global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t 
                                                     const ChanPrep *__restrict__ preps, const double *__restrict__ autoc_in,
                                                     Candidate *__restrict__ cands, int *__restrict__ valid)
 {
+	// the { invc, logc } table of the log (flacgpu_log.h) in LDS: a lane looks it up a dozen times, each at its own index
+	__shared__ uint64_t logtab[256];
+	logtab[threadIdx.x] = flacgpu_log_tab[threadIdx.x];
+	__syncthreads();
 	const uint32_t na_main = P.max_analyses;
 	const uint32_t id = blockIdx.x * TPB + threadIdx.x;
 	if(na_main == 0 || id >= nframes * P.ncand * na_main) return;
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t 
 			}
 			av[j] = v;
 		}
-		lpc_model<MAXORD>(av, max_lpc, n, pr.sbps, P, slots, vslots);
+		lpc_model<MAXORD>(av, max_lpc, n, pr.sbps, P, slots, vslots, logtab);
 	}
 	else for(uint32_t s = 0; s < aslots; s++) vslots[s] = 0;
 }
@@ -1360,7 +1364,7 @@ void sync_debug(const char *what, hipStream_t s)
 	fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr);
 }
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin, uint32_t nframes, uint32_t tail_n,
-                          const JobTable *jtm, const JobTable *jtt, const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
+                          const JobTable *jtm, const JobTable *jtt, uint32_t nsets_main, const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
 {
 	static bool attr_set = false;
 	if(!attr_set) {
@@ -1399,7 +1403,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 		const bool use2 = force == 2 || (force == 0 && waves2 >= (ms4 ? 640u : 2048u));
 		if(autoc2_applicable(P) && use2) {
 			f_lo = tail_n ? nframes - 1 : nframes;
-			const hipError_t e = launch_autoc2(P, pcm, win, f_lo, P.max_jobs, jtm, B.prep, B.autoc, s);
+			const hipError_t e = launch_autoc2(P, pcm, win, f_lo, P.max_jobs, nsets_main, jtm, B.prep, B.autoc, s);
 			if(e != hipSuccess) return e;
 		}
 		if(f_lo < nframes) {

@@ -37,6 +37,7 @@ struct flacgpu_ctx {
 	uint32_t *d_frame_bytes;     // [max_batch]
 	uint64_t *d_offsets;         // [max_batch+1]
 	uint64_t *d_total;
+	uint64_t *d_scanstate;       // [max_batch+1] status words of the fused compaction (flacgpu_kernels.hip: scan_lookback)
 	FrameInfo *d_info;           // [max_batch]
 	int32_t *d_pcm;              // staging for the host entry point
 	uint8_t *d_raw;              // raw sample bytes of flacgpu_encode_batch_raw
@@ -51,6 +52,8 @@ struct flacgpu_ctx {
 	flacgpu_verify_result *d_vresult;
 	uint64_t *d_voffsets, *d_vtotal;
 	int64_t *d_vscratch;
+	void *d_vdecoded;            // decoded coded-channel samples of a batch, lane-interleaved (flacgpu_verify.hip)
+	uint32_t *d_vfinfo;          // [max_batch] per-frame verdict of the decode pass
 	uint32_t verify_on;
 	flacgpu_verify_result last_verify;
 	JobTable h_jobtab[2];        // [0] nominal blocksize, [1] the short last block of the current batch
@@ -62,16 +65,19 @@ namespace flacgpu {
 void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 {
 	memset(jt, 0, sizeof *jt);
-	uint32_t nj = 0, na = 0, woff = 0;
+	uint32_t nj = 0, na = 0, woff = 0, ns = 0;
+	auto add_set = [&](uint32_t first, uint32_t count) { if(count) { if(ns < 8) { jt->set_first[ns] = (uint16_t)first; jt->set_count[ns] = (uint16_t)count; } ns++; } };
 	for(uint32_t a = 0; a < P.num_apod; a++) {
 		const uint32_t root = nj;
 		WindowJob &jr = jt->jobs[nj];
 		jr.off = woff; jr.nd = n; jr.apod = a; jr.full = 1;
 		woff += (n + 3u) & ~1u;
 		jt->an_job[na] = (uint16_t)nj; jt->an_punch[na] = 0; jt->an_root[na] = (uint16_t)root; na++; nj++;
+		add_set(root, 1);
 		if(P.apod_kind[a] == FLACGPU_APOD_SUBDIVIDE_TUKEY) {
 			for(uint32_t b = 2; b <= P.apod_parts[a]; b++) {
 				if(n / b <= 32) continue;                               /* :4349-4357 */
+				const uint32_t depth_first = nj;
 				for(uint32_t pi = 0; pi < b; pi++) {
 					if(nj >= (uint32_t)MAX_JOBS || na + 2 > (uint32_t)MAX_ANALYSES) continue;   /* create() rejects such configs */
 					WindowJob &jp = jt->jobs[nj];
@@ -83,10 +89,11 @@ void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 					if(b >= 3) { jt->an_job[na] = (uint16_t)nj; jt->an_punch[na] = 1; jt->an_root[na] = (uint16_t)root; na++; }   /* :4295-4308 */
 					nj++;
 				}
+				add_set(depth_first, nj - depth_first);
 			}
 		}
 	}
-	jt->njobs = nj; jt->nanalyses = na; jt->wnd_floats = woff;
+	jt->njobs = nj; jt->nanalyses = na; jt->wnd_floats = woff; jt->nsets = ns;
 }
 }
 
@@ -150,6 +157,7 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->d_frame_bytes) (void)hipFree(c->d_frame_bytes);
 	if(c->d_offsets) (void)hipFree(c->d_offsets);
 	if(c->d_total) (void)hipFree(c->d_total);
+	if(c->d_scanstate) (void)hipFree(c->d_scanstate);
 	if(c->d_info) (void)hipFree(c->d_info);
 	if(c->d_pcm) (void)hipFree(c->d_pcm);
 	if(c->d_raw) (void)hipFree(c->d_raw);
@@ -170,6 +178,8 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->d_voffsets) (void)hipFree(c->d_voffsets);
 	if(c->d_vtotal) (void)hipFree(c->d_vtotal);
 	if(c->d_vscratch) (void)hipFree(c->d_vscratch);
+	if(c->d_vdecoded) (void)hipFree(c->d_vdecoded);
+	if(c->d_vfinfo) (void)hipFree(c->d_vfinfo);
 	for(int r = 0; r < TIMING_RING; r++) for(int i = 0; i < 5; i++) if(c->ev_ring[r][i]) (void)hipEventDestroy(c->ev_ring[r][i]);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -280,6 +290,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	ok = ok && hipMalloc(&c->d_frame_bytes, B * sizeof(uint32_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_offsets, (B + 1) * sizeof(uint64_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_total, sizeof(uint64_t)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_scanstate, (B + 1) * sizeof(uint64_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_info, B * sizeof(FrameInfo)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_jobtab, 2 * sizeof(JobTable)) == hipSuccess;
 	ok = ok && hipMemcpy(c->d_jobtab, c->h_jobtab, sizeof(JobTable), hipMemcpyHostToDevice) == hipSuccess;
@@ -326,6 +337,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	c->ev = c->ev_ring[c->batch_seq % TIMING_RING]; c->pev = c->pev_ring[c->batch_seq % TIMING_RING];
 	c->batch_seq++;
 	(void)hipEventRecord(c->ev[0], s);
+	bool fused = false;
 	uint32_t nsub = c->nsub;
 	if(c->ab.dbg || nframes < 256 * nsub) nsub = 1;
 	if(nsub > 1) {
@@ -341,9 +353,9 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			AnalyzeBuffers B = c->ab;
 			B.prep += fc0; B.autoc += fc0 * P.max_jobs * AUTOC_STRIDE; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.chan_stride; B.dbg = nullptr;
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
-			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, B,
+			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
 			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, ss) != hipSuccess)
+			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, ss) != hipSuccess)
 				return FLACGPU_ERR_LAUNCH;
 			(void)hipEventRecord(c->sub_done[i], ss);
 			(void)hipStreamWaitEvent(s, c->sub_done[i], 0);
@@ -353,7 +365,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		(void)hipEventRecord(c->ev[1], s);
 	}
 	else {
-	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->ab, c->d_decisions, c->pev, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, c->ab, c->d_decisions, c->pev, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		if(c->ab.dbg) {
 			// development aid: average shader cycles per phase of the eval workgroups of this launch
 			const size_t nwg = (size_t)nframes * P.ncand;
@@ -381,7 +393,13 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			(void)hipMemsetAsync(c->ab.dbg, 0, nwg * 16 * sizeof(unsigned long long), s);
 		}
 		(void)hipEventRecord(c->ev[1], s);
-		if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		{
+			// one stream: the pack kernel writes every frame once, at its final place (fused compaction)
+			static int nofuse = -1;
+			if(nofuse < 0) nofuse = getenv("FLACGPU_NO_FUSED_COMPACT") ? 1 : 0;
+			PackOutArgs po = {d_out, out_cap, c->d_offsets, c->d_total, c->d_scanstate};
+			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, nofuse ? nullptr : &po, &fused, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		}
 		if(c->ab.dbg) {
 			// development aid: wall cycles of the pack2 workgroups between their stamps
 			unsigned long long *h = (unsigned long long *)malloc((size_t)nframes * 16 * sizeof(unsigned long long));
@@ -397,8 +415,10 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		}
 	}
 	(void)hipEventRecord(c->ev[2], s);
-	if(launch_scan(c->d_frame_bytes, nframes, c->d_offsets, c->d_total, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(launch_compact(c->d_slots, P.slot_bytes, c->d_frame_bytes, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(!fused) {
+		if(launch_scan(c->d_frame_bytes, nframes, c->d_offsets, c->d_total, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(launch_compact(c->d_slots, P.slot_bytes, c->d_frame_bytes, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	}
 	(void)hipEventRecord(c->ev[3], s);
 	if(d_fb_out && hipMemcpyAsync(d_fb_out, c->d_frame_bytes, nframes * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	if(d_total_out && hipMemcpyAsync(d_total_out, c->d_total, sizeof(uint64_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
@@ -475,7 +495,7 @@ static int64_t encode_staged(flacgpu_ctx *c, uint32_t nframes, uint64_t first_fr
 	memset(&c->last_verify, 0, sizeof c->last_verify);
 	if(c->verify_on) {
 		// the frames are decoded again where they lie and compared with the staged input (stream_encoder.c:3000-3018)
-		if(launch_verify(c->P, c->d_out, c->d_frame_bytes, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vstate, c->d_vresult, s) != hipSuccess)
+		if(launch_verify(c->P, c->d_out, c->d_frame_bytes, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, c->d_vresult, s) != hipSuccess)
 			return FLACGPU_ERR_LAUNCH;
 		if(hipMemcpyAsync(&c->last_verify, c->d_vresult, sizeof c->last_verify, hipMemcpyDeviceToHost, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
@@ -550,6 +570,8 @@ static int ensure_verify(flacgpu_ctx *c)
 	ok = ok && hipMalloc(&c->d_voffsets, (B + 1) * sizeof(uint64_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_vtotal, sizeof(uint64_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_vscratch, (size_t)c->P.channels * c->P.blocksize * sizeof(int64_t)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_vdecoded, verify_decoded_bytes(c->P, (uint32_t)B)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_vfinfo, B * sizeof(uint32_t)) == hipSuccess;
 	return ok ? FLACGPU_OK : FLACGPU_ERR_ALLOC;
 }
 
@@ -564,7 +586,7 @@ extern "C" int flacgpu_verify_batch_device(flacgpu_ctx *c, const uint8_t *d_fram
 	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
 	const uint32_t tail_n = last_block_samples < c->P.blocksize ? last_block_samples : 0;
 	if(launch_scan(d_frame_bytes, nframes, c->d_voffsets, c->d_vtotal, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(launch_verify(c->P, d_frames, d_frame_bytes, c->d_voffsets, nframes, tail_n, first_frame_number, d_pcm, c->d_vscratch, c->d_vstate, d_result, s) != hipSuccess)
+	if(launch_verify(c->P, d_frames, d_frame_bytes, c->d_voffsets, nframes, tail_n, first_frame_number, d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, d_result, s) != hipSuccess)
 		return FLACGPU_ERR_LAUNCH;
 	return FLACGPU_OK;
 }

@@ -20,6 +20,7 @@
 // fp64 VALU bound (39 fp64 operations + 11 conversions per 8 samples and lane at -8).  -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "flacgpu_dev.h"
 #include "flacgpu_devfn.h"
 
@@ -113,7 +114,11 @@ __device__ __forceinline__ void a2_store(float *tile, const A2Items &I, const A2
 		else { const double t0 = fma(w[HB + (c)], w[HB + (c) - j], w[HB + (c) + 4] * w[HB + (c) + 4 - j]); \
 		       const double t1 = fma(w[HB + (c) + 8], w[HB + (c) + 8 - j], w[HB + (c) + 12] * w[HB + (c) + 12 - j]); acc[j] += (t1 + t0); } }
 
-template <int VARIANT, int LAG, bool MS4>
+// GROUPED: a workgroup takes ONE group of 16 subframes and its wavefronts the window-job SETS of JobTable (the whole
+// block | the halves | the thirds ...: every set covers the block once), each running its jobs one after the other.  The sets
+// sweep the block at the same pace, so a PCM line is fetched from HBM once and found in the cache by the other wavefronts,
+// instead of once per pass of an independent wavefront somewhere else on the chip (-8: 3 passes, a third of the traffic).
+template <int VARIANT, int LAG, bool MS4, bool GROUPED>
 __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
                                                                             uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
                                                                             double *__restrict__ autoc_out)
@@ -124,16 +129,20 @@ __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(cons
 	float *tile = sh[wave];
 	const uint32_t nfc = nmain * P.ncand;
 	const uint32_t ngroups = (nfc + A2_ITEMS - 1) / A2_ITEMS;
-	const uint32_t wi = blockIdx.x * (TPB / 64) + wave;
-	if(wi >= jt->njobs * ngroups) return;
-	// jobs are enumerated longest first (whole block, halves, thirds ...): the long wavefronts start first
-	const uint32_t jb = wi / ngroups, fc0 = (wi - jb * ngroups) * A2_ITEMS;
-	const WindowJob jv = jt->jobs[jb];
+	uint32_t jb_lo, jb_hi, fc0;
+	if(GROUPED) {
+		if(blockIdx.x >= ngroups) return;
+		fc0 = blockIdx.x * A2_ITEMS;
+		jb_lo = jt->set_first[wave]; jb_hi = jb_lo + jt->set_count[wave];
+	}
+	else {
+		const uint32_t wi = blockIdx.x * (TPB / 64) + wave;
+		if(wi >= jt->njobs * ngroups) return;
+		// jobs are enumerated longest first (whole block, halves, thirds ...): the long wavefronts start first
+		jb_lo = wi / ngroups; jb_hi = jb_lo + 1;
+		fc0 = (wi - jb_lo * ngroups) * A2_ITEMS;
+	}
 	const uint32_t N = P.blocksize, C = P.channels;
-	A2Job J;
-	J.w = windows + (size_t)jv.apod * N;
-	J.n = N; J.nd = jv.nd; J.full = jv.full; J.part = jv.part; J.dshift = jv.dshift; J.i0 = jv.i0;
-	const uint32_t nd = jv.nd;
 	constexpr uint32_t L = VARIANT;
 	constexpr int HB = LAG - 1;
 
@@ -156,12 +165,18 @@ __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(cons
 		}
 	}
 	if(!__builtin_amdgcn_readfirstlane((int)any_lpc)) return;      // 16 constant subframes: nothing to analyse
+	const int item = lane >> 2, l = lane & 3;
+	const float *rd = tile + item * A2_IST + A2_H + l;                // rd[t] = d[tile base + t + l]
 
+	for(uint32_t jb = jb_lo; jb < jb_hi; jb++) {
+	const WindowJob jv = jt->jobs[jb];
+	A2Job J;
+	J.w = windows + (size_t)jv.apod * N;
+	J.n = N; J.nd = jv.nd; J.full = jv.full; J.part = jv.part; J.dshift = jv.dshift; J.i0 = jv.i0;
+	const uint32_t nd = jv.nd;
 	const uint32_t nb = (nd - L) / 8;
 	const uint32_t npairs12 = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
 	const uint32_t ntiles = (nb + 7) / 8;
-	const int item = lane >> 2, l = lane & 3;
-	const float *rd = tile + item * A2_IST + A2_H + l;                // rd[t] = d[tile base + t + l]
 
 	double acc[LAG];
 #pragma unroll
@@ -246,33 +261,45 @@ __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(cons
 		const uint32_t j = 4 * (uint32_t)m + (uint32_t)l;
 		if(j < lag && fc < nfc) out[j] = autoc_finish2(head, tail, tail_lo, nd, L, j, a4);
 	}
+	__builtin_amdgcn_wave_barrier();          // the tile is reused by the next job of this wavefront
+	}
 }
 #undef A2_STEP
 #undef A2_PAIR
 
 template <int VARIANT, int LAG>
-static void launch_autoc2_t(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt,
+static void launch_autoc2_t(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
                             const ChanPrep *preps, double *autoc, hipStream_t s)
 {
 	const uint32_t nfc = nmain * P.ncand, ngroups = (nfc + A2_ITEMS - 1) / A2_ITEMS;
+	const bool ms4 = P.channels == 2 && P.ms_mode == 1;
+	static int nogroup = -1;
+	if(nogroup < 0) nogroup = getenv("FLACGPU_AUTOC2_UNGROUPED") ? 1 : 0;
+	if(nsets >= 2 && nsets <= (uint32_t)(TPB / 64) && !nogroup) {
+		// one workgroup per group of subframes, one wavefront per job set
+		const dim3 grid(ngroups), block(64 * nsets);
+		if(ms4) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, true, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+		else hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, false, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+		return;
+	}
 	const uint32_t waves = njobs * ngroups;
 	const dim3 grid((waves + TPB / 64 - 1) / (TPB / 64)), block(TPB);
-	if(P.channels == 2 && P.ms_mode == 1) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
-	else hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, false>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+	if(ms4) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, true, false>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+	else hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, false, false>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
 }
 
 // true when the streaming kernel serves the nominal-length frames of this configuration
 bool autoc2_applicable(const DevParams &P) { return P.blocksize > 32 && P.max_lpc_order > 0 && P.autoc_variant != 0 && !P.wide_samples; }
 
-hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt,
+hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
                          const ChanPrep *preps, double *autoc, hipStream_t s)
 {
 	if(nmain == 0 || njobs == 0) return hipSuccess;
 	const uint32_t max_lpc = P.max_lpc_order >= P.blocksize ? P.blocksize - 1 : P.max_lpc_order;
 	const uint32_t lag = max_lpc + 1;
-	if(P.autoc_variant == 8) launch_autoc2_t<8, 8>(P, pcm, win, nmain, njobs, jt, preps, autoc, s);
-	else if(P.autoc_variant == 12) { if(lag <= 9) launch_autoc2_t<12, 9>(P, pcm, win, nmain, njobs, jt, preps, autoc, s); else launch_autoc2_t<12, 12>(P, pcm, win, nmain, njobs, jt, preps, autoc, s); }
-	else { if(lag <= 13) launch_autoc2_t<16, 13>(P, pcm, win, nmain, njobs, jt, preps, autoc, s); else launch_autoc2_t<16, 16>(P, pcm, win, nmain, njobs, jt, preps, autoc, s); }
+	if(P.autoc_variant == 8) launch_autoc2_t<8, 8>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);
+	else if(P.autoc_variant == 12) { if(lag <= 9) launch_autoc2_t<12, 9>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s); else launch_autoc2_t<12, 12>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s); }
+	else { if(lag <= 13) launch_autoc2_t<16, 13>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s); else launch_autoc2_t<16, 16>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s); }
 	return hipGetLastError();
 }
 

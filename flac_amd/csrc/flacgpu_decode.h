@@ -23,6 +23,10 @@
 #ifndef FLACGPU_HD
 #define FLACGPU_HD
 #endif
+// low 32 bits of a product of two values that fit 24 bits signed
+#ifndef FLACGPU_MUL24
+#define FLACGPU_MUL24(a, b) ((uint32_t)(a) * (uint32_t)(b))
+#endif
 
 namespace flacgpu {
 
@@ -211,6 +215,7 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 	}
 	int32_t shift = 0;
 	bool wide_sum = true;                                       // 64-bit prediction sum
+	const bool narrow24 = sb <= 24;                             // (taps have at most 15 bits)
 	if(lpc) {
 		const uint32_t prec = br_get(b, 4) + 1;
 		if(prec == 16) return DEC_ERROR;
@@ -258,6 +263,14 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 		if(wide_sum) {
 #pragma unroll
 			for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)h[j];
+		}
+		else if(narrow24) {
+			// samples and taps below 2^23 in magnitude: the low 32 bits of every product come out of the 24-bit multiplier
+			// (full rate on the GPU; a 32-bit multiply runs at a quarter of it)
+			uint32_t s32 = 0;
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++) s32 += FLACGPU_MUL24(q[j], (int32_t)h[j]);
+			sum = (int64_t)(int32_t)s32;
 		}
 		else {
 			uint32_t s32 = 0;

@@ -84,6 +84,10 @@ struct JobTable {
 	WindowJob jobs[MAX_JOBS];
 	uint16_t an_job[MAX_ANALYSES], an_root[MAX_ANALYSES];
 	uint8_t an_punch[MAX_ANALYSES];
+	// job SETS: the whole-block job of an apodization, or all partial windows of one subdivide_tukey depth -- each set covers
+	// the block exactly once (flacgpu_autoc.hip runs the sets of a group of subframes side by side); the first 8 are listed
+	uint32_t nsets;
+	uint16_t set_first[8], set_count[8];
 };
 void build_job_table(const DevParams &P, uint32_t n, JobTable *jt);
 
@@ -122,15 +126,19 @@ void sync_debug(const char *what, hipStream_t s);
 size_t analyze_lds_bytes(const DevParams &P);
 size_t pack_lds_bytes(const DevParams &P);
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin,
-                          uint32_t nframes, uint32_t tail_n, const JobTable *jt_main, const JobTable *jt_tail, const AnalyzeBuffers &B,
+                          uint32_t nframes, uint32_t tail_n, const JobTable *jt_main, const JobTable *jt_tail, uint32_t nsets_main /* JobTable::nsets of jt_main */, const AnalyzeBuffers &B,
                           SubDecision *dec, hipEvent_t *phase_ev /* [3]: after prep, autoc, model; may be null */, hipStream_t s);
 bool autoc2_applicable(const DevParams &P);
-hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt,
+hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
                          const ChanPrep *preps, double *autoc, hipStream_t s);
 bool prep2_applicable(const DevParams &P);
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s);
+// where the pack kernel may put the frames directly (fused compaction: single-pass prefix sum of the frame lengths inside the
+// kernel); with po == null or po->out == null every frame goes to its slot and launch_scan + launch_compact must follow
+struct PackOutArgs { uint8_t *out; uint64_t cap; uint64_t *offsets; uint64_t *total; uint64_t *state /* [nframes + 1] scratch */; };
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, hipStream_t s);
+                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg,
+                       const PackOutArgs *po, bool *fused_out, hipStream_t s);
 // raw sample bytes -> interleaved int32 (flacgpu_stage.hip)
 struct StageParams {
 	uint32_t bytes;          // container bytes per sample: 1, 2, 3, 4
@@ -141,8 +149,9 @@ hipError_t launch_stage_raw(const StageParams &S, const void *d_raw, uint64_t nv
 // the self check (flacgpu_verify.hip, crc_check_kernel in flacgpu_kernels.hip)
 struct VerifyState { uint32_t first_bad; uint32_t pad[3]; };      // index of the first frame of the batch that failed (0xffffffff: none)
 hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s);
+size_t verify_decoded_bytes(const DevParams &P, uint32_t max_frames);     // the lane-interleaved buffer of decoded coded-channel samples
 hipError_t launch_verify(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t tail_n,
-                         uint64_t first, const int32_t *pcm, int64_t *scratch, VerifyState *state, flacgpu_verify_result *result, hipStream_t s);
+                         uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result, hipStream_t s);
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);
 hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,
                           uint8_t *out, uint64_t out_cap, uint32_t nframes, hipStream_t s);

@@ -120,11 +120,11 @@ __device__ __forceinline__ uint32_t block_reduce_or_u32(uint32_t v, uint64_t *sc
 // recursion in registers (fully unrolled, statically indexed) -- lpc.c:176-314,1580-1630 as the
 // reference binary computes them (see oracle/flac_oracle.c for the compiled-behaviour notes)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double expected_bits_scaled(double lpc_error, double error_scale)
+__device__ __forceinline__ double expected_bits_scaled(double lpc_error, double error_scale, const uint64_t *logtab = flacgpu_log_tab)
 {
 	if(lpc_error > 0.0) {
 		// 0.5*log(x)/M_LN2 folded by -freciprocal-math into log(x) * (0.5/ln 2)
-		double bps = flacgpu_log(error_scale * lpc_error) * 0.7213475204444817;
+		double bps = flacgpu_log_with(error_scale * lpc_error, logtab) * 0.7213475204444817;
 		return bps >= 0.0 ? bps : 0.0;
 	}
 	if(lpc_error < 0.0) return 1e32;
@@ -237,7 +237,7 @@ __device__ __forceinline__ void emit_order_candidates(const float (&coef)[MAXORD
 // precision; -e emits every order 1..max as the recursion produces it; -p every precision.
 template <int MAXORD>
 __device__ void lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uint32_t n, uint32_t sbps, const DevParams &P,
-                          Candidate *slots, int *vslots)
+                          Candidate *slots, int *vslots, const uint64_t *logtab)
 {
 	const uint32_t nslots = P.norders * P.nprec;
 	for(uint32_t s = 0; s < nslots; s++) vslots[s] = 0;
@@ -291,13 +291,13 @@ __device__ void lpc_model(const double (&a)[MAXORD + 1], uint32_t max_order, uin
 		for(int idx = 0; idx < MAXORD; idx++) {
 			if((uint32_t)idx < used) {
 				const uint32_t o = (uint32_t)idx + 1;
-				const double bits = expected_bits_scaled(errs[idx], scale) * (double)(n - o) + (double)(o * overhead);
+				const double bits = expected_bits_scaled(errs[idx], scale, logtab) * (double)(n - o) + (double)(o * overhead);
 				if(bits < best_bits) { order = o; best_bits = bits; err_order = errs[idx]; }
 			}
 		}
 	}
 	// stream_encoder.c:4227-4229
-	if(expected_bits_scaled(err_order, 0.5 / (double)(n - order)) >= (double)sbps) return;
+	if(expected_bits_scaled(err_order, 0.5 / (double)(n - order), logtab) >= (double)sbps) return;
 	// coefficients of `order`: rerun the (deterministic) recursion up to that order
 	(void)levinson<MAXORD, false>(a, order, lpc, errs, nullptr);
 	float coef[MAXORD];

@@ -159,10 +159,12 @@ __device__ __forceinline__ uint32_t img_word(const uint32_t *img, uint32_t w, bo
 __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const uint16_t (*crc_tab)[256], uint32_t *crc_parts, int tid,
                                 const uint16_t *xspan_lds = nullptr, uint32_t nxspan_lds = 0, const uint16_t *xbyte_lds = nullptr, bool global_img = false)
 {
-	// spans of 64 bytes; the last (possibly short) span is followed by nothing, span s by nsp-1-s whole or short spans
+	// spans of 64 bytes; the last (possibly short) span is followed by nothing, span s by nsp-2-s whole spans and the last one:
+	// crc = (sum over the whole spans of crc_s * x^(512 (nsp-2-s))) * x^(8 last_len) + crc_last -- the shift past the last span is
+	// common to all whole spans and is applied once, after the reduction
 	const uint32_t nsp = (body_bytes + CRC_SPAN - 1) / CRC_SPAN;
 	const uint32_t last_len = body_bytes - (nsp ? nsp - 1 : 0) * CRC_SPAN;                 // 1..64 bytes
-	uint32_t c = 0;
+	uint32_t c = 0;                     // low half: whole spans, shifted among themselves; high half: the last span
 	for(uint32_t sp = (uint32_t)tid; sp < nsp; sp += TPB) {
 		const uint32_t *wp = img + sp * (CRC_SPAN / 4);
 		uint32_t cs = 0;
@@ -172,18 +174,17 @@ __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const 
 				const uint32_t v = (cs << 16) ^ img_word(wp, (uint32_t)k, global_img);
 				cs = (uint32_t)crc_tab[3][v >> 24] ^ crc_tab[2][(v >> 16) & 0xffu] ^ crc_tab[1][(v >> 8) & 0xffu] ^ crc_tab[0][v & 0xffu];
 			}
-			// behind this span: nsp-2-sp whole spans and the last one
 			const uint32_t m = nsp - 2 - sp;
-			const uint32_t xs = m < nxspan_lds ? xspan_lds[m] : g_crc_tables.xspan[m], xb = xbyte_lds ? xbyte_lds[last_len] : g_crc_tables.xbyte[last_len];
-			cs = gf16_mul(gf16_mul(cs, xs), xb);
+			const uint32_t xs = m < nxspan_lds ? xspan_lds[m] : g_crc_tables.xspan[m];
+			c ^= m ? gf16_mul(cs, xs) : cs;
 		}
 		else {
 			for(uint32_t k = 0; k < last_len; k++) {
 				const uint32_t b = (img_word(wp, k >> 2, global_img) >> (24 - 8 * (k & 3))) & 0xffu;
 				cs = ((cs << 8) & 0xffffu) ^ crc_tab[0][(cs >> 8) ^ b];
 			}
+			c ^= cs << 16;
 		}
-		c ^= cs;
 	}
 #pragma unroll
 	for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
@@ -191,7 +192,8 @@ __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const 
 	__syncthreads();
 	uint32_t crc = 0;
 	for(int w = 0; w < TPB / 64; w++) crc ^= crc_parts[w];
-	return crc;
+	const uint32_t xb = xbyte_lds ? xbyte_lds[last_len] : g_crc_tables.xbyte[last_len];
+	return gf16_mul(crc & 0xffffu, xb) ^ (crc >> 16);
 }
 
 // number of frame header bytes including the CRC-8, without building them (same cases as frame_header_bytes)
@@ -514,7 +516,64 @@ struct Pack2Shared {
 	uint16_t xspan[P2_XSPAN];
 	uint16_t xbyte[CRC_SPAN + 2];
 	uint32_t dec[FLACGPU_MAX_CHANNELS * sizeof(SubDecision) / 4];      // this frame's decision records
+	uint32_t ticket;           // fused output: the frame this workgroup took (dispatch order)
+	uint32_t excl_lo, excl_hi; // fused output: byte offset of this frame in the stream of the batch
 };
+
+// ---- fused compaction: a single-pass prefix sum of the frame lengths with decoupled look-back (Merrill & Garland) ------------
+// One 64-bit status word per frame: [63:62] 0 nothing yet, 1 this frame's length, 2 the inclusive sum up to this frame; [61:0] the
+// value.  A workgroup publishes its length the moment it is known, then one of its wavefronts walks back over its predecessors,
+// 64 at a time, adding lengths until it meets an inclusive sum.  Frames are taken in dispatch order (an atomic ticket), so every
+// predecessor is resident or finished: the walk only ever waits for workgroups that are running.
+constexpr uint64_t SCAN_VAL = (1ull << 62) - 1;
+struct PackOut {
+	uint8_t *out;              // frames back to back (null: every frame goes to its slot, scan + compact kernels follow)
+	uint64_t cap;
+	uint64_t *offsets;         // [nframes + 1]
+	uint64_t *total;
+	uint64_t *state;           // [nframes] status words, then the ticket counter; zeroed before the launch
+	uint32_t nframes_total;    // frames of the whole batch (the last one closes offsets[] / total when this kernel packs it)
+};
+__device__ __forceinline__ uint64_t scan_lookback(uint64_t *state, uint32_t f, uint64_t mine, int lane)
+{
+	uint64_t excl = 0;
+	if(f == 0) { if(lane == 0) __hip_atomic_store(&state[0], (2ull << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+	if(lane == 0) __hip_atomic_store(&state[f], (1ull << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	int64_t j = (int64_t)f - 1;
+	for(;;) {
+		const int64_t idx = j - lane;
+		uint64_t sv;
+		do {
+			sv = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+		} while(__any((int)((sv >> 62) == 0)));
+		const uint64_t incl = __ballot((int)((sv >> 62) == 2));
+		uint64_t v = sv & SCAN_VAL;
+		if(incl) {
+			const int first = __ffsll((unsigned long long)incl) - 1;      // the nearest predecessor that knows its inclusive sum
+			if(lane > first) v = 0;
+			excl += wave_reduce_add_u64(v);
+			break;
+		}
+		excl += wave_reduce_add_u64(v);
+		j -= 64;
+	}
+	if(lane == 0) __hip_atomic_store(&state[f], (2ull << 62) | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return excl;
+}
+// the finished frame image (big-endian word views in LDS) to byte address dst, whatever its alignment
+__device__ __forceinline__ void store_image(const uint32_t *img, uint8_t *dst, uint32_t nb, int tid)
+{
+	const uint32_t head = umin32((uint32_t)((4 - ((uintptr_t)dst & 3)) & 3), nb);
+	if((uint32_t)tid < head) dst[tid] = (uint8_t)(img[0] >> (24 - 8 * tid));
+	const uint32_t words = (nb - head) >> 2, sh = head * 8;
+	uint32_t *dw = (uint32_t *)(dst + head);
+	for(uint32_t w = (uint32_t)tid; w < words; w += TPB) {
+		const uint32_t be = sh ? (img[w] << sh) | (img[w + 1] >> (32 - sh)) : img[w];
+		dw[w] = __builtin_bswap32(be);
+	}
+	const uint32_t done = head + words * 4;
+	if((uint32_t)tid < nb - done) { const uint32_t k = done + (uint32_t)tid; dst[k] = (uint8_t)(img[k >> 2] >> (24 - 8 * (k & 3))); }
+}
 
 // residuals of this thread's 16 samples from the packed window A[0..15] (A[0..7] = the 16 samples in front)
 template <int NP>
@@ -577,18 +636,25 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
                                                     uint32_t nmain, uint64_t first_frame_number,
                                                     const SubDecision *__restrict__ decisions,
                                                     uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
-                                                    FrameInfo *__restrict__ info, unsigned long long *__restrict__ dbg)
+                                                    FrameInfo *__restrict__ info, unsigned long long *__restrict__ dbg, const PackOut O)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t C = P.channels, N = P.blocksize, n = N;
-	const uint32_t f = blockIdx.x;
-#define PSTAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
-	PSTAMP(0);
-	const SubDecision *dec = decisions + (size_t)f * P.ncand;
 	uint32_t *img = (uint32_t *)smem;
 	const uint32_t cap_words = P.slot_bytes / 4;
 	Pack2Shared *sh = (Pack2Shared *)(smem + P.slot_bytes + 16);
+	const bool fused = O.out != nullptr;
+	uint32_t f = blockIdx.x;
+	if(fused) {
+		// frames in dispatch order, so that the look-back at the end only waits for workgroups that have started
+		if(tid == 0) sh->ticket = atomicAdd((uint32_t *)(O.state + nmain), 1u);
+		__syncthreads();
+		f = sh->ticket;
+	}
+#define PSTAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
+	PSTAMP(0);
+	const SubDecision *dec = decisions + (size_t)f * P.ncand;
 
 	// decision records, CRC tables: one round of loads for everything the frame needs; image zeroed meanwhile
 	{
@@ -823,8 +889,25 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 		if(tid == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
 	}
-	// ---- store: image words are big-endian views, slots are byte arrays ---------------------------
-	{
+	// ---- store: image words are big-endian views, the stream is a byte array ---------------------------
+	if(fused) {
+		// this frame's place in the stream: the sum of the lengths of all frames in front of it
+		const uint32_t mine = overflow ? 0u : total_bytes;
+		if(wave == 0) {
+			const uint64_t excl = scan_lookback(O.state, f, mine, lane);
+			if(lane == 0) { sh->excl_lo = (uint32_t)excl; sh->excl_hi = (uint32_t)(excl >> 32); }
+		}
+		__syncthreads();
+		const uint64_t off = ((uint64_t)sh->excl_hi << 32) | sh->excl_lo;
+		if(mine && off + mine <= O.cap) store_image(img, O.out + off, mine, tid);
+		if(tid == 0) {
+			frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
+			O.offsets[f] = off;
+			if(f + 1 == O.nframes_total) { O.offsets[f + 1] = off + mine; *O.total = off + mine; }
+			if(info) info[f].channel_assignment = (uint8_t)ca;
+		}
+	}
+	else {
 		uint32_t *dst = (uint32_t *)(slots + (size_t)f * P.slot_bytes);
 		const uint32_t words = (umin32(total_bytes, P.slot_bytes) + 3) >> 2;
 		for(uint32_t w = (uint32_t)tid; w < words; w += TPB) dst[w] = __builtin_bswap32(img[w]);
@@ -835,6 +918,18 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 	}
 	PSTAMP(12);
 #undef PSTAMP
+}
+
+// fused output with a short last block: that frame was assembled in its slot by pack_kernel; it goes behind the others
+__global__ __launch_bounds__(TPB) void append_tail_kernel(const uint8_t *__restrict__ slot, const uint32_t *__restrict__ frame_bytes, uint32_t f, const PackOut O)
+{
+	const uint64_t prev = f ? (__hip_atomic_load(&O.state[f - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SCAN_VAL) : 0;
+	const uint32_t nbr = frame_bytes[f], nb = nbr == 0xffffffffu ? 0u : nbr;
+	if(nb && prev + nb <= O.cap) {
+		uint8_t *dst = O.out + prev;
+		for(uint32_t k = threadIdx.x; k < nb; k += TPB) dst[k] = slot[k];
+	}
+	if(threadIdx.x == 0) { O.offsets[f] = prev; O.offsets[f + 1] = prev + nb; *O.total = prev + nb; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -951,7 +1046,7 @@ static bool pack2_applicable(const DevParams &P)
 }
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                                const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, hipStream_t s)
+                                const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, const PackOutArgs *po, bool *fused_out, hipStream_t s)
 {
 	static bool attr_set = false;
 	if(!attr_set) {
@@ -961,14 +1056,25 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 		attr_set = true;
 	}
 	uint32_t f_lo = 0;
+	bool fused = false;
+	PackOut O;
+	O.out = nullptr; O.cap = 0; O.offsets = nullptr; O.total = nullptr; O.state = nullptr; O.nframes_total = nframes;
 	if constexpr(MAXORD <= 16) {                  // predictors of more than 16 taps (-l 17..32) take the general kernel
 		if(pack2_applicable(P)) {
 			f_lo = tail_n ? nframes - 1 : nframes;
 			const size_t lds2 = (size_t)P.slot_bytes + 16 + sizeof(Pack2Shared);
-			if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg);
+			if(f_lo && po && po->out) {
+				// frames written once, at their final place: no slots, no scan / compact kernels
+				fused = true;
+				O.out = po->out; O.cap = po->cap; O.offsets = po->offsets; O.total = po->total; O.state = po->state;
+				if(hipMemsetAsync(po->state, 0, ((size_t)f_lo + 1) * sizeof(uint64_t), s) != hipSuccess) return hipErrorUnknown;
+			}
+			if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O);
 		}
 	}
 	if(f_lo < nframes) hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes - f_lo), dim3(TPB), lds, s, P, chan, nframes, tail_n, f_lo, first, dec, slots, fb, info);
+	if(fused && f_lo < nframes) hipLaunchKernelGGL(append_tail_kernel, dim3(1), dim3(TPB), 0, s, slots + (size_t)f_lo * P.slot_bytes, fb, f_lo, O);
+	if(fused_out) *fused_out = fused;
 	sync_debug("pack", s);
 	return hipGetLastError();
 }
@@ -982,14 +1088,14 @@ size_t pack_lds_bytes(const DevParams &P)
 }
 
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, hipStream_t s)
+                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, const PackOutArgs *po, bool *fused_out, hipStream_t s)
 {
 	const size_t lds = pack_lds_bytes(P);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
-	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
-	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
-	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
-	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, s);
+	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, s);
+	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, s);
+	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, s);
+	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, s);
 }
 hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s)
 {

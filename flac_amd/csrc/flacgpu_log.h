@@ -38,7 +38,8 @@ FLACGPU_LOG_TABQ uint64_t flacgpu_log_tab[256] = FLACGPU_LOG_TAB;       /* { inv
 FLACGPU_LOG_FN double flacgpu_log_asdouble(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 FLACGPU_LOG_FN uint64_t flacgpu_log_asuint(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 
-FLACGPU_LOG_FN double flacgpu_log(double x)
+/* tab: the { invc, logc } table, flacgpu_log_tab or a copy of it in faster memory (the model kernel keeps one in LDS) */
+FLACGPU_LOG_FN double flacgpu_log_with(double x, const uint64_t *tab)
 {
 #define A(i) flacgpu_log_asdouble(flacgpu_log_poly[i])
 #define B(i) flacgpu_log_asdouble(flacgpu_log_poly1[i])
@@ -80,7 +81,7 @@ FLACGPU_LOG_FN double flacgpu_log(double x)
 	const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
 	const int32_t k = (int32_t)((int64_t)tmp >> 52);
 	const double z = flacgpu_log_asdouble(ix - (tmp & 0xFFF0000000000000ull));
-	const double invc = flacgpu_log_asdouble(flacgpu_log_tab[2 * i]), logc = flacgpu_log_asdouble(flacgpu_log_tab[2 * i + 1]);
+	const double invc = flacgpu_log_asdouble(tab[2 * i]), logc = flacgpu_log_asdouble(tab[2 * i + 1]);
 	const double ln2hi = flacgpu_log_asdouble(FLACGPU_LOG_LN2HI), ln2lo = flacgpu_log_asdouble(FLACGPU_LOG_LN2LO);
 	const double r = __builtin_fma(z, invc, -1.0);
 	const double kd = (double)k;
@@ -97,4 +98,5 @@ FLACGPU_LOG_FN double flacgpu_log(double x)
 #undef A
 #undef B
 }
+FLACGPU_LOG_FN double flacgpu_log(double x) { return flacgpu_log_with(x, flacgpu_log_tab); }
 #endif

@@ -3,11 +3,13 @@
 // again and compared with the samples that went in, without leaving HBM.
 //
 //   verify_kernel    ONE LANE PER FRAME (flacgpu_decode.h): a wavefront walks 64 frames in lockstep through header, subframes,
-//                    Rice codes and predictor restoration; each decoded coded-channel sample is compared on the spot with the
-//                    value the input implies for it, nothing is stored.  Rice decoding is a serial bit-dependency chain, so a
-//                    lane runs at instruction-issue latency; what is parallel is the batch: 16384 frames = 256 wavefronts, one
-//                    per CU.  The bit window and the expected sample are fetched one step ahead (no second wavefront on the
-//                    SIMD to hide a load behind).
+//                    Rice codes and predictor restoration.  Rice decoding is a serial bit-dependency chain, so a lane runs at
+//                    instruction-issue latency; what is parallel is the batch: 16384 frames = 256 wavefronts, one per CU.  A lane
+//                    therefore does nothing that waits on memory besides its own bit window (fetched one word ahead): the decoded
+//                    CODED-channel samples are stored lane-interleaved (sample i of the 64 frames of a wavefront = one 256-byte row,
+//                    fire-and-forget stores), not compared here -- 64 lanes reading 64 inputs 32 KiB apart would alias one cache set.
+//   compare_kernel   thread-parallel: rows of decoded samples through an LDS transpose against the value the input PCM implies
+//                    for that coded channel (left, right, (L+R)>>1, L-R: the decorrelation is a bijection, flacgpu_decode.h).
 //   (crc_check_kernel, flacgpu_kernels.hip: the CRC-16 footers, one wavefront per frame, spans in parallel.)
 //   verify_detail_kernel  one lane, only when a frame failed: decodes the FIRST bad frame of the batch into a scratch buffer,
 //                    undoes the inter-channel decorrelation and reports {frame, channel, sample, expected, got} of the first
@@ -18,14 +20,16 @@
 #include "flacgpu.h"
 #include "flacgpu_dev.h"
 #define FLACGPU_HD __device__
+#define FLACGPU_MUL24(a, b) ((uint32_t)__mul24((int)(a), (int)(b)))
 #include "flacgpu_decode.h"
 
 namespace flacgpu {
 
+// per-frame verdict of the decode pass: [3:0] channel assignment, bit 8 set = decodes
 template <int MAXORD, typename ST>
 __global__ __launch_bounds__(64) void verify_kernel(const DevParams P, const uint8_t *__restrict__ frames, const uint32_t *__restrict__ frame_bytes,
                                                     const uint64_t *__restrict__ offsets, uint32_t nframes, uint32_t tail_n, uint64_t first_frame_number,
-                                                    const int32_t *__restrict__ pcm, VerifyState *__restrict__ state)
+                                                    ST *__restrict__ decoded, uint32_t *__restrict__ finfo, VerifyState *__restrict__ state)
 {
 	const uint32_t f = blockIdx.x * 64u + threadIdx.x;
 	if(f >= nframes) return;
@@ -34,36 +38,61 @@ __global__ __launch_bounds__(64) void verify_kernel(const DevParams P, const uin
 	DecodeExpect E;
 	E.channels = C; E.bps = P.bps; E.blocksize = N; E.n = (tail_n && f + 1 == nframes) ? tail_n : N; E.frame_number = first_frame_number + f;
 	int st = DEC_ERROR;
-	if(fb != 0xffffffffu) {
+	uint32_t ca = 0;
+	if(fb != 0xffffffffu && fb >= 6) {
 		const uint8_t *p = frames + offsets[f];
 		const uint8_t *hi = frames + offsets[nframes];
-		const int32_t *x = pcm + (size_t)f * N * C;
-		st = DEC_OK;
-		if(fb < 6) st = DEC_ERROR;
-		else {
-			BitReader b;
-			br_init(b, p, fb - 2, hi);
-			FrameHead H;
-			if(decode_frame_header(b, p, E, H) != DEC_OK) st = DEC_ERROR;
-			else {
-				uint32_t differ = 0;
-				for(uint32_t ch = 0; ch < C && st == DEC_OK; ch++) {
-					const uint32_t ca = H.ca;
-					// the expectation of sample i is fetched while sample i-1 is being decoded
-					int64_t e_next = coded_expectation(x, ca, ch);
-					auto sink = [&](uint32_t i, int64_t v) {
-						differ |= (uint32_t)(v != e_next);
-						const uint32_t j = i + 1 < H.n ? i + 1 : i;
-						e_next = coded_expectation(x + (size_t)j * C, ca, ch);
-					};
-					if(decode_subframe<MAXORD, ST>(b, H.n, coded_bps(E.bps, ca, ch), sink) != DEC_OK) st = DEC_ERROR;
-				}
-				if(st == DEC_OK && decode_frame_tail(b) != DEC_OK) st = DEC_ERROR;
-				if(st == DEC_OK && differ) st = DEC_MISMATCH;
+		BitReader b;
+		br_init(b, p, fb - 2, hi);
+		FrameHead H;
+		if(decode_frame_header(b, p, E, H) == DEC_OK) {
+			st = DEC_OK;
+			ca = H.ca;
+			for(uint32_t ch = 0; ch < C && st == DEC_OK; ch++) {
+				ST *row = decoded + ((size_t)blockIdx.x * C + ch) * N * 64 + threadIdx.x;      // sample i of this frame: row[i * 64]
+				auto sink = [&](uint32_t i, int64_t v) { row[(size_t)i * 64] = (ST)v; };
+				if(decode_subframe<MAXORD, ST>(b, H.n, coded_bps(E.bps, ca, ch), sink) != DEC_OK) st = DEC_ERROR;
 			}
+			if(st == DEC_OK && decode_frame_tail(b) != DEC_OK) st = DEC_ERROR;
 		}
 	}
+	finfo[f] = ca | (st == DEC_OK ? 0x100u : 0u);
 	if(st != DEC_OK) atomicMin(&state->first_bad, f);
+}
+
+// decoded coded-channel samples against the input: block = the 64 frames of one decode wavefront x 64 samples
+constexpr int CMP_T = 64;
+template <typename ST>
+__global__ __launch_bounds__(TPB) void verify_compare_kernel(const DevParams P, uint32_t nframes, uint32_t tail_n, const int32_t *__restrict__ pcm,
+                                                             const ST *__restrict__ decoded, const uint32_t *__restrict__ finfo, VerifyState *__restrict__ state)
+{
+	__shared__ ST tile[CMP_T][65];
+	__shared__ uint32_t info[64];
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t wb = blockIdx.x, i0 = blockIdx.y * CMP_T;
+	const uint32_t C = P.channels, N = P.blocksize;
+	if(tid < 64) { const uint32_t f = wb * 64u + (uint32_t)tid; info[tid] = f < nframes ? finfo[f] : 0u; }
+	uint32_t badmask_lo = 0, badmask_hi = 0;                        // frames (of this wavefront's share) with a differing sample
+	for(uint32_t ch = 0; ch < C; ch++) {
+		__syncthreads();
+		const ST *rows = decoded + ((size_t)wb * C + ch) * N * 64;
+		for(int r = wave; r < CMP_T; r += TPB / 64) { const uint32_t i = i0 + (uint32_t)r; tile[r][lane] = i < N ? rows[(size_t)i * 64 + lane] : (ST)0; }
+		__syncthreads();
+		for(int fl = wave; fl < 64; fl += TPB / 64) {
+			const uint32_t f = wb * 64u + (uint32_t)fl, inf = info[fl];
+			if(f >= nframes || !(inf & 0x100u)) continue;              // (frames that did not decode are already flagged)
+			const uint32_t n = (tail_n && f + 1 == nframes) ? tail_n : N, i = i0 + (uint32_t)lane;
+			bool differ = false;
+			if(i < n) differ = (int64_t)tile[lane][fl] != coded_expectation(pcm + ((size_t)f * N + i) * C, inf & 15u, ch);
+			if(__any((int)differ)) { if(fl < 32) badmask_lo |= 1u << fl; else badmask_hi |= 1u << (fl - 32); }
+		}
+	}
+	if(lane == 0) {
+		uint32_t first = 0xffffffffu;
+		if(badmask_lo) first = (uint32_t)__ffs((int)badmask_lo) - 1;
+		else if(badmask_hi) first = 32u + (uint32_t)__ffs((int)badmask_hi) - 1;
+		if(first != 0xffffffffu) atomicMin(&state->first_bad, wb * 64u + first);
+	}
 }
 
 template <int MAXORD, typename ST>
@@ -98,23 +127,30 @@ __global__ void verify_reset_kernel(VerifyState *state) { state->first_bad = 0xf
 
 template <int MAXORD, typename ST>
 static hipError_t launch_verify_t(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t tail_n,
-                                  uint64_t first, const int32_t *pcm, int64_t *scratch, VerifyState *state, flacgpu_verify_result *result, hipStream_t s)
+                                  uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result, hipStream_t s)
 {
-	hipLaunchKernelGGL((verify_kernel<MAXORD, ST>), dim3((nframes + 63) / 64), dim3(64), 0, s, P, frames, fb, offsets, nframes, tail_n, first, pcm, state);
+	const uint32_t nwb = (nframes + 63) / 64;
+	hipLaunchKernelGGL((verify_kernel<MAXORD, ST>), dim3(nwb), dim3(64), 0, s, P, frames, fb, offsets, nframes, tail_n, first, (ST *)decoded, finfo, state);
+	hipLaunchKernelGGL((verify_compare_kernel<ST>), dim3(nwb, (P.blocksize + CMP_T - 1) / CMP_T), dim3(TPB), 0, s, P, nframes, tail_n, pcm, (const ST *)decoded, finfo, state);
 	hipLaunchKernelGGL((verify_detail_kernel<MAXORD, ST>), dim3(1), dim3(64), 0, s, P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, state, result);
 	return hipGetLastError();
 }
 
+size_t verify_decoded_bytes(const DevParams &P, uint32_t max_frames)
+{
+	const bool wide = P.bps == 32 && P.channels == 2;
+	return (size_t)((max_frames + 63) / 64) * 64 * P.channels * P.blocksize * (wide ? 8 : 4);
+}
 hipError_t launch_verify(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t tail_n,
-                         uint64_t first, const int32_t *pcm, int64_t *scratch, VerifyState *state, flacgpu_verify_result *result, hipStream_t s)
+                         uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result, hipStream_t s)
 {
 	hipLaunchKernelGGL(verify_reset_kernel, dim3(1), dim3(1), 0, s, state);
 	hipError_t e = launch_crc_check(frames, fb, offsets, nframes, state, s);
 	if(e != hipSuccess) return e;
 	const bool wide = P.bps == 32 && P.channels == 2;            // a 33-bit side channel can occur (stream_encoder.c:3831-3835)
 	const uint32_t m = P.max_lpc_order;
-#define GO(M) (wide ? launch_verify_t<M, int64_t>(P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, state, result, s) \
-                    : launch_verify_t<M, int32_t>(P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, state, result, s))
+#define GO(M) (wide ? launch_verify_t<M, int64_t>(P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, decoded, finfo, state, result, s) \
+                    : launch_verify_t<M, int32_t>(P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, decoded, finfo, state, result, s))
 	if(m <= 8) e = GO(8);
 	else if(m <= 12) e = GO(12);
 	else e = GO(32);
