@@ -963,7 +963,7 @@ __host__ __device__ inline uint32_t owner_chan_bytes(uint32_t N, bool packed)
 __host__ __device__ inline bool owner_possible(const DevParams &P) { return P.blocksize % 64 == 0 && P.blocksize / 64 >= (uint32_t)OH && P.max_lpc_order <= (uint32_t)OH && !P.wide_samples && !P.stream_sig; }
 // candidate records are staged in LDS next to the channel image when there are few of them (every preset); the wide
 // searches (-e, -p: hundreds of slots per channel) read them from global memory and keep only the valid flags in LDS
-__host__ __device__ inline bool eval_cands_in_lds(const DevParams &P) { return P.ncslots <= 48; }
+__host__ __device__ inline bool eval_cands_in_lds(const DevParams &P) { return P.ncslots <= 48 && !(P.tune_flags & 1u); }
 __host__ __device__ inline uint32_t eval_cand_bytes(const DevParams &P)
 {
 	return (eval_cands_in_lds(P) ? P.ncslots * (uint32_t)sizeof(Candidate) : 0u) + ((P.ncslots * 4 + 15u) & ~15u);

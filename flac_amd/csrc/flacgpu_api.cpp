@@ -262,6 +262,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		P.ncslots = P.nfixed + na * P.norders * P.nprec;
 	}
 	P.img_global = 0; P.stream_sig = 0;
+	P.tune_flags = getenv("FLACGPU_EVAL_CANDS_GLOBAL") ? 1u : 0u;
 	if(N > 16384 || analyze_lds_bytes(P) > 160 * 1024 - 1024) { P.stream_sig = 1; P.sig_bytes = 0; }     // the block does not fit the LDS: the general kernels read HBM
 	if(pack_lds_bytes(P) > 160 * 1024 - 1024) P.img_global = 1;            // many channels x long blocks: the frame is assembled in HBM
 	if((uint64_t)P.slot_bytes > (uint64_t)4 * 1024 * 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }      // CRC span table (flacgpu_kernels.hip)
@@ -394,11 +395,14 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		}
 		(void)hipEventRecord(c->ev[1], s);
 		{
-			// one stream: the pack kernel writes every frame once, at its final place (fused compaction)
-			static int nofuse = -1;
-			if(nofuse < 0) nofuse = getenv("FLACGPU_NO_FUSED_COMPACT") ? 1 : 0;
+			// FLACGPU_FUSED_COMPACT=1: the pack kernel writes every frame once, at its final place (single-pass prefix sum with
+			// decoupled look-back inside the kernel; no slots, no scan / compact kernels).  Off by default: measured on MI355X
+			// (profiles/r02_c_*) a frame's length is known only when its workgroup is nearly done, so the look-back waits for every
+			// earlier workgroup still packing -- pack 0.45 -> 0.60 ms per 16384 frames, more than the 0.10 ms the two kernels cost.
+			static int fuse = -1;
+			if(fuse < 0) fuse = getenv("FLACGPU_FUSED_COMPACT") ? 1 : 0;
 			PackOutArgs po = {d_out, out_cap, c->d_offsets, c->d_total, c->d_scanstate};
-			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, nofuse ? nullptr : &po, &fused, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, fuse ? &po : nullptr, &fused, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		}
 		if(c->ab.dbg) {
 			// development aid: wall cycles of the pack2 workgroups between their stamps

@@ -114,16 +114,17 @@ __device__ __forceinline__ void a2_store(float *tile, const A2Items &I, const A2
 		else { const double t0 = fma(w[HB + (c)], w[HB + (c) - j], w[HB + (c) + 4] * w[HB + (c) + 4 - j]); \
 		       const double t1 = fma(w[HB + (c) + 8], w[HB + (c) + 8 - j], w[HB + (c) + 12] * w[HB + (c) + 12 - j]); acc[j] += (t1 + t0); } }
 
-// GROUPED: a workgroup takes ONE group of 16 subframes and its wavefronts the window-job SETS of JobTable (the whole
-// block | the halves | the thirds ...: every set covers the block once), each running its jobs one after the other.  The sets
-// sweep the block at the same pace, so a PCM line is fetched from HBM once and found in the cache by the other wavefronts,
-// instead of once per pass of an independent wavefront somewhere else on the chip (-8: 3 passes, a third of the traffic).
+// GROUPED: a one-wavefront workgroup takes one window-job SET of JobTable (the whole block | the halves | the thirds ...:
+// every set covers the block once, its jobs run one after the other) of one group of 16 subframes, and the sets of a group are
+// consecutive workgroups of the SAME XCD (workgroups go round-robin over the 8 XCDs, so those are blockIdx b, b+8, b+16 ...).
+// They start together and sweep the block at the same pace: a PCM line is fetched from HBM once and found in that XCD's L2 by
+// the other sets, instead of once per pass of an unrelated wavefront elsewhere on the chip (-8: three passes).
 template <int VARIANT, int LAG, bool MS4, bool GROUPED>
 __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
                                                                             uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
                                                                             double *__restrict__ autoc_out)
 {
-	__shared__ float sh[TPB / 64][A2_ITEMS * A2_IST];
+	__shared__ float sh[GROUPED ? 1 : TPB / 64][A2_ITEMS * A2_IST];
 	const int lane = (int)threadIdx.x & 63;
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	float *tile = sh[wave];
@@ -131,9 +132,14 @@ __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(cons
 	const uint32_t ngroups = (nfc + A2_ITEMS - 1) / A2_ITEMS;
 	uint32_t jb_lo, jb_hi, fc0;
 	if(GROUPED) {
-		if(blockIdx.x >= ngroups) return;
-		fc0 = blockIdx.x * A2_ITEMS;
-		jb_lo = jt->set_first[wave]; jb_hi = jb_lo + jt->set_count[wave];
+		const uint32_t nsets = jt->nsets, b = blockIdx.x;
+		const uint32_t per_xcd = (ngroups / 8) * nsets, head = per_xcd * 8;      // blocks every XCD gets in full
+		uint32_t group, set;
+		if(b < head) { const uint32_t slot = b >> 3; group = (slot / nsets) * 8 + (b & 7); set = slot % nsets; }
+		else { const uint32_t r = b - head; group = (ngroups / 8) * 8 + r / nsets; set = r % nsets; }
+		if(group >= ngroups) return;
+		fc0 = group * A2_ITEMS;
+		jb_lo = jt->set_first[set]; jb_hi = jb_lo + jt->set_count[set];
 	}
 	else {
 		const uint32_t wi = blockIdx.x * (TPB / 64) + wave;
@@ -275,9 +281,9 @@ static void launch_autoc2_t(const DevParams &P, const int32_t *pcm, const float 
 	const bool ms4 = P.channels == 2 && P.ms_mode == 1;
 	static int nogroup = -1;
 	if(nogroup < 0) nogroup = getenv("FLACGPU_AUTOC2_UNGROUPED") ? 1 : 0;
-	if(nsets >= 2 && nsets <= (uint32_t)(TPB / 64) && !nogroup) {
-		// one workgroup per group of subframes, one wavefront per job set
-		const dim3 grid(ngroups), block(64 * nsets);
+	if(nsets >= 2 && nsets <= 8 && !nogroup) {
+		// one single-wavefront workgroup per (group of subframes, job set)
+		const dim3 grid(ngroups * nsets), block(64);
 		if(ms4) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, true, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
 		else hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, false, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
 		return;

@@ -23,9 +23,12 @@
 #ifndef FLACGPU_HD
 #define FLACGPU_HD
 #endif
-// low 32 bits of a product of two values that fit 24 bits signed
-#ifndef FLACGPU_MUL24
-#define FLACGPU_MUL24(a, b) ((uint32_t)(a) * (uint32_t)(b))
+// low 32 bits of sum_j a[j] * b[j] for values that fit 24 bits signed (the GPU has a full-rate 24-bit multiply-add)
+#ifndef FLACGPU_DOT24
+namespace flacgpu {
+template <int M> inline uint32_t dot24_plain(const int32_t (&a)[M], const int32_t (&b)[M]) { uint32_t s = 0; for(int j = 0; j < M; j++) s += (uint32_t)a[j] * (uint32_t)b[j]; return s; }
+}
+#define FLACGPU_DOT24(a, b) flacgpu::dot24_plain(a, b)
 #endif
 
 namespace flacgpu {
@@ -39,46 +42,51 @@ struct DecodeExpect {
 enum { DEC_OK = 0, DEC_MISMATCH = 1, DEC_ERROR = 2 };
 
 // ---- MSB-first bit reader over global memory: 64-bit window, refilled a 32-bit word at a time ------------------------
+// The next word is always in flight (a lane has no second wavefront to hide its load latency behind): `pre` holds it as
+// loaded, the byte swap happens when it enters the window.  Loads never leave [first aligned word of the frame, the
+// aligned word holding the buffer's last byte]: beyond that the address is clamped (what comes back is never consumed
+// legitimately -- a frame that reads past its own end is an error -- it only must not fault).
 struct BitReader {
 	const uint32_t *wp;            // next aligned word to load
-	const uint8_t *end;            // one past the last byte that may be read (the end of the buffer the frames lie in)
-	uint32_t pre;                  // the word in front of wp, already loaded (a lane has no other wavefront to hide its load latency behind)
+	const uint32_t *wlast;         // the aligned word that holds the last byte of the buffer the frames lie in
+	const uint32_t *w0;            // the aligned word that holds the first byte of the frame
+	uint32_t pre;                  // the word in front of wp, as loaded (little endian)
 	uint64_t acc;                  // valid bits left-aligned, zeros behind them
 	uint32_t nb;                   // valid bits in acc
-	uint64_t consumed;             // bits consumed so far (from the first byte of the frame)
+	uint32_t skip;                 // bits of w0 in front of the frame
 	uint64_t limit;                // bits the frame body holds: reading beyond is an error
 	uint32_t bad;
 };
 FLACGPU_HD inline uint32_t br_fetch(BitReader &b)
 {
-	const uint8_t *q = (const uint8_t *)b.wp;
+	const uint32_t *q = b.wp < b.wlast ? b.wp : b.wlast;
 	b.wp++;
-	if(q + 4 <= b.end) return __builtin_bswap32(*(const uint32_t *)q);
-	uint32_t v = 0;                                                    // the last, partial word of the buffer (and zeros beyond it)
-	for(int k = 0; k < 4; k++) if(q + k < b.end) v |= (uint32_t)q[k] << (24 - 8 * k);
-	return v;
+	return *q;
 }
-FLACGPU_HD inline uint32_t br_load(BitReader &b) { const uint32_t v = b.pre; b.pre = br_fetch(b); return v; }
+FLACGPU_HD inline uint32_t br_load(BitReader &b) { const uint32_t v = __builtin_bswap32(b.pre); b.pre = br_fetch(b); return v; }
 FLACGPU_HD inline void br_refill(BitReader &b) { if(b.nb <= 32) { b.acc |= (uint64_t)br_load(b) << (32 - b.nb); b.nb += 32; } }
-// frame bytes [p, p + nbytes) inside the buffer [buf_lo, buf_hi)
+// bits consumed so far, counted from the first byte of the frame: words taken into the window (one more is in flight)
+FLACGPU_HD inline uint64_t br_pos(const BitReader &b) { return (uint64_t)(b.wp - b.w0 - 1) * 32 - b.nb - b.skip; }
+FLACGPU_HD inline bool br_over(const BitReader &b) { return br_pos(b) > b.limit; }
+// frame bytes [p, p + nbytes) inside a buffer that ends at buf_hi
 FLACGPU_HD inline void br_init(BitReader &b, const uint8_t *p, size_t nbytes, const uint8_t *buf_hi)
 {
-	const uintptr_t a = (uintptr_t)p;
-	b.wp = (const uint32_t *)(a & ~(uintptr_t)3);
-	b.end = buf_hi;
+	const uint32_t mis = (uint32_t)((uintptr_t)p & 3);
+	b.w0 = (const uint32_t *)(p - mis);                                 // (pointer arithmetic, not an integer cast: the address space survives)
+	b.wlast = (const uint32_t *)((buf_hi - 1) - ((uintptr_t)(buf_hi - 1) & 3));
+	b.wp = b.w0;
+	b.acc = 0; b.nb = 0; b.skip = mis * 8; b.limit = (uint64_t)nbytes * 8; b.bad = 0;
 	b.pre = br_fetch(b);
-	b.acc = 0; b.nb = 0; b.consumed = 0; b.limit = (uint64_t)nbytes * 8; b.bad = 0;
-	const uint32_t skip = (uint32_t)(a & 3) * 8;
 	br_refill(b);
-	b.acc <<= skip; b.nb -= skip;
+	b.acc <<= b.skip; b.nb -= b.skip;
 	br_refill(b);
 }
 FLACGPU_HD inline uint32_t br_get(BitReader &b, uint32_t n)            // 0 <= n <= 32
 {
 	if(n == 0) return 0;
-	br_refill(b);                                                      // now nb >= 33 unless the buffer ran out
+	br_refill(b);                                                      // now nb >= 33
 	const uint32_t v = (uint32_t)(b.acc >> (64 - n));
-	b.acc <<= n; b.nb -= n; b.consumed += n;
+	b.acc <<= n; b.nb -= n;
 	return v;
 }
 FLACGPU_HD inline int32_t br_get_signed(BitReader &b, uint32_t n)      // 1 <= n <= 32
@@ -101,11 +109,11 @@ FLACGPU_HD inline uint32_t br_unary(BitReader &b)                      // zeros 
 		if(b.acc != 0) {
 			const uint32_t lz = (uint32_t)__builtin_clzll(b.acc);          // < nb: the valid bits hold a one
 			z += lz;
-			b.acc <<= lz; b.acc <<= 1; b.nb -= lz + 1; b.consumed += lz + 1;
+			b.acc <<= lz; b.acc <<= 1; b.nb -= lz + 1;
 			return z;
 		}
-		z += b.nb; b.consumed += b.nb; b.nb = 0;
-		if(b.consumed > b.limit) { b.bad = 1; return z; }              // ran off the frame: stop
+		z += b.nb; b.nb = 0;
+		if(br_over(b)) { b.bad = 1; return z; }                            // ran off the frame: stop
 	}
 }
 
@@ -160,8 +168,8 @@ FLACGPU_HD inline int decode_frame_header(BitReader &b, const uint8_t *p, const 
 	if(sr_code == 12) (void)br_get(b, 8);
 	else if(sr_code == 13 || sr_code == 14) (void)br_get(b, 16);
 	else if(sr_code == 15) return DEC_ERROR;
-	const uint32_t hdr_bytes = (uint32_t)(b.consumed >> 3);
-	if(br_get(b, 8) != dec_crc8(p, hdr_bytes) || b.consumed > b.limit) return DEC_ERROR;
+	const uint32_t hdr_bytes = (uint32_t)(br_pos(b) >> 3);
+	if(br_get(b, 8) != dec_crc8(p, hdr_bytes) || br_over(b)) return DEC_ERROR;
 	const uint32_t bps_of = bps_code == 1 ? 8u : bps_code == 2 ? 12u : bps_code == 4 ? 16u : bps_code == 5 ? 20u : bps_code == 6 ? 24u : bps_code == 7 ? 32u : 0u;
 	if(bps_code == 3) return DEC_ERROR;
 	if(fn != E.frame_number || bs != E.n || (bps_code && bps_of != E.bps)) return DEC_ERROR;
@@ -192,9 +200,8 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 		for(uint32_t i = 0; i < n; i++) {
 			const int64_t v = br_get_sample(b, sb);
 			sink(i, (int64_t)((uint64_t)v << wasted));
-			if(b.consumed > b.limit) return DEC_ERROR;
 		}
-		return DEC_OK;
+		return br_over(b) ? DEC_ERROR : DEC_OK;
 	}
 	uint32_t order;
 	bool lpc;
@@ -240,7 +247,7 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 	const uint32_t po = br_get(b, 4);
 	const uint32_t psize = n >> po;
 	if(po && ((psize << po) != n || psize < order)) return DEC_ERROR;
-	if(b.consumed > b.limit) return DEC_ERROR;
+	if(br_over(b)) return DEC_ERROR;
 	uint32_t next_part = order, k = 0, raw = 0;                 // sample index at which the next partition starts
 	bool escaped = false;
 	uint32_t part = 0;
@@ -251,7 +258,8 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 			if(escaped) raw = br_get(b, 5);
 			part++;
 			next_part = po ? part * psize : n;
-		}
+			if(br_over(b)) return DEC_ERROR;                    // (checked per partition, not per sample: a lane that runs off its
+		}                                                       //  frame reads zeros / clamped words until the partition ends)
 		int64_t r;
 		if(escaped) r = raw ? (int64_t)br_get_signed(b, raw) : 0;
 		else {
@@ -267,10 +275,10 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 		else if(narrow24) {
 			// samples and taps below 2^23 in magnitude: the low 32 bits of every product come out of the 24-bit multiplier
 			// (full rate on the GPU; a 32-bit multiply runs at a quarter of it)
-			uint32_t s32 = 0;
+			int32_t hh[MAXORD];
 #pragma unroll
-			for(int j = 0; j < MAXORD; j++) s32 += FLACGPU_MUL24(q[j], (int32_t)h[j]);
-			sum = (int64_t)(int32_t)s32;
+			for(int j = 0; j < MAXORD; j++) hh[j] = (int32_t)h[j];
+			sum = (int64_t)(int32_t)FLACGPU_DOT24(q, hh);
 		}
 		else {
 			uint32_t s32 = 0;
@@ -283,17 +291,16 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 #pragma unroll
 		for(int j = MAXORD - 1; j > 0; j--) h[j] = h[j - 1];
 		h[0] = (ST)v;
-		if(b.consumed > b.limit) return DEC_ERROR;
 	}
-	return b.bad ? DEC_ERROR : DEC_OK;
+	return (b.bad || br_over(b)) ? DEC_ERROR : DEC_OK;
 }
 
 // after the last subframe: zero bits up to the byte boundary, and the body must end exactly where the CRC-16 starts
 FLACGPU_HD inline int decode_frame_tail(BitReader &b)
 {
-	const uint32_t rem = (uint32_t)(b.consumed & 7);
+	const uint32_t rem = (uint32_t)(br_pos(b) & 7);
 	if(rem && br_get(b, 8 - rem) != 0) return DEC_ERROR;
-	return (b.bad || b.consumed != b.limit) ? DEC_ERROR : DEC_OK;
+	return (b.bad || br_pos(b) != b.limit) ? DEC_ERROR : DEC_OK;
 }
 // nominal width of coded channel ch under channel assignment ca (the side channel carries one bit more)
 FLACGPU_HD inline uint32_t coded_bps(uint32_t bps, uint32_t ca, uint32_t ch)

@@ -41,6 +41,8 @@ struct DevParams {
 	uint32_t wide_samples;     // bps > 24
 	uint32_t chan_stride;      // 32-bit words per planar channel: blocksize, or 2 * blocksize when a 33-bit channel can occur
 	uint32_t img_global;       // the worst-case frame does not fit the LDS next to the pack kernel's state: it is assembled in its HBM slot
+	uint32_t tune_flags;       // development switches (environment): bit 0 FLACGPU_EVAL_CANDS_GLOBAL: the evaluation kernel reads the
+	                           // candidate records from global memory instead of staging them in LDS
 	uint32_t stream_sig;       // a block does not fit the LDS (more than 16384 samples, or 16384 64-bit ones): the general prep and
 	                           // evaluation kernels read the samples from HBM instead of an LDS copy (sig_bytes = 0)
 };

@@ -935,17 +935,33 @@ __global__ __launch_bounds__(TPB) void append_tail_kernel(const uint8_t *__restr
 // ---------------------------------------------------------------------------------------------
 // scan + compaction
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t *__restrict__ frame_bytes, uint32_t nframes,
+// Exclusive prefix sum of the frame lengths, one workgroup: a thread sums a run of consecutive frames (16-byte loads), the
+// runs are scanned across the workgroup once, and the thread writes its frames' offsets.  (Batches of more than 64 Ki frames
+// take more than one round.)
+constexpr int SCAN_T = 1024, SCAN_PER = 16;
+__global__ __launch_bounds__(SCAN_T) void scan_kernel(const uint32_t *__restrict__ frame_bytes, uint32_t nframes,
                                                     uint64_t *__restrict__ offsets, uint64_t *__restrict__ total)
 {
-	__shared__ uint64_t wave_tot[16];
+	__shared__ uint64_t wave_tot[SCAN_T / 64];
 	__shared__ uint64_t carry;
 	const int tid = (int)threadIdx.x;
 	if(tid == 0) carry = 0;
 	__syncthreads();
-	for(uint32_t base = 0; base < nframes; base += 1024) {
-		const uint32_t i = base + (uint32_t)tid;
-		uint64_t v = i < nframes ? (frame_bytes[i] == 0xffffffffu ? 0 : frame_bytes[i]) : 0, incl = v;
+	for(uint32_t base = 0; base < nframes; base += SCAN_T * SCAN_PER) {
+		const uint32_t i0 = base + (uint32_t)tid * SCAN_PER;
+		uint32_t v[SCAN_PER];
+		if(i0 + SCAN_PER <= nframes && ((uintptr_t)frame_bytes & 15) == 0) {
+#pragma unroll
+			for(int k = 0; k < SCAN_PER / 4; k++) { const uint4 q = ((const uint4 *)(frame_bytes + i0))[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+		}
+		else {
+#pragma unroll
+			for(int k = 0; k < SCAN_PER; k++) v[k] = i0 + (uint32_t)k < nframes ? frame_bytes[i0 + k] : 0u;
+		}
+		uint64_t run = 0;
+#pragma unroll
+		for(int k = 0; k < SCAN_PER; k++) { if(v[k] == 0xffffffffu) v[k] = 0; run += v[k]; }
+		uint64_t incl = run;
 #pragma unroll
 		for(int off = 1; off < 64; off <<= 1) {
 			uint32_t lo = __shfl_up((uint32_t)incl, off), hi = __shfl_up((uint32_t)(incl >> 32), off);
@@ -954,8 +970,10 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t *__restrict__
 		if((tid & 63) == 63) wave_tot[tid >> 6] = incl;
 		__syncthreads();
 		uint64_t woff = 0, tot = 0;
-		for(int w = 0; w < 16; w++) { if(w < (tid >> 6)) woff += wave_tot[w]; tot += wave_tot[w]; }
-		if(i < nframes) offsets[i] = carry + woff + incl - v;
+		for(int w = 0; w < SCAN_T / 64; w++) { if(w < (tid >> 6)) woff += wave_tot[w]; tot += wave_tot[w]; }
+		uint64_t o = carry + woff + incl - run;
+#pragma unroll
+		for(int k = 0; k < SCAN_PER; k++) { if(i0 + (uint32_t)k < nframes) offsets[i0 + k] = o; o += v[k]; }
 		__syncthreads();
 		if(tid == 0) carry += tot;
 		__syncthreads();
@@ -1104,7 +1122,7 @@ hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uin
 }
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)
 {
-	hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, fb, nframes, offsets, total);
+	hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_T), 0, s, fb, nframes, offsets, total);
 	return hipGetLastError();
 }
 hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,

@@ -430,18 +430,8 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 				w0.z = ((uint32_t)x[4] & 0xffffu) | ((uint32_t)x[5] << 16); w0.w = ((uint32_t)x[6] & 0xffffu) | ((uint32_t)x[7] << 16);
 				w1.x = ((uint32_t)x[8] & 0xffffu) | ((uint32_t)x[9] << 16); w1.y = ((uint32_t)x[10] & 0xffffu) | ((uint32_t)x[11] << 16);
 				w1.z = ((uint32_t)x[12] & 0xffffu) | ((uint32_t)x[13] << 16); w1.w = ((uint32_t)x[14] & 0xffffu) | ((uint32_t)x[15] << 16);
-				// A lane's 32 bytes as two 16-byte stores 32 bytes apart would touch every 32-byte sector of the channel twice (once
-				// per store instruction).  Lane pairs trade halves instead: the first store of a pair covers the even lane's 32
-				// bytes, the second the odd lane's -- every sector is written by one instruction, whole.
-				const bool odd = (lane & 1) != 0;
-				uint4 p0, p1;                                  // the partner's halves
-				p0.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)w0.x, 0xB1, 0xf, 0xf, true); p0.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)w0.y, 0xB1, 0xf, 0xf, true);
-				p0.z = (uint32_t)__builtin_amdgcn_mov_dpp((int)w0.z, 0xB1, 0xf, 0xf, true); p0.w = (uint32_t)__builtin_amdgcn_mov_dpp((int)w0.w, 0xB1, 0xf, 0xf, true);
-				p1.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)w1.x, 0xB1, 0xf, 0xf, true); p1.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)w1.y, 0xB1, 0xf, 0xf, true);
-				p1.z = (uint32_t)__builtin_amdgcn_mov_dpp((int)w1.z, 0xB1, 0xf, 0xf, true); p1.w = (uint32_t)__builtin_amdgcn_mov_dpp((int)w1.w, 0xB1, 0xf, 0xf, true);
-				const uint4 s1 = odd ? p1 : w0, s2 = odd ? w1 : p0;
-				uint4 *d4 = (uint4 *)(dst + (q0 + (uint32_t)(lane & ~1) * CHUNK) / 2) + (odd ? 1 : 0);      // the pair's 64 bytes
-				d4[0] = s1; d4[2] = s2;
+				uint4 *d4 = (uint4 *)(dst + base / 2);
+				d4[0] = w0; d4[1] = w1;
 			}
 			else {
 				uint4 *d4 = (uint4 *)(dst + base);

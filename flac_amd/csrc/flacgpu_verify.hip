@@ -20,7 +20,22 @@
 #include "flacgpu.h"
 #include "flacgpu_dev.h"
 #define FLACGPU_HD __device__
-#define FLACGPU_MUL24(a, b) ((uint32_t)__mul24((int)(a), (int)(b)))
+// 24-bit multiply-adds as ONE asm statement per 4 taps (the compiler turns the __mul24 builtin back into a quarter-rate 32-bit
+// multiply when it cannot prove the operands' range, and pads separate asm statements with s_nop)
+namespace flacgpu {
+template <int M>
+__device__ __forceinline__ uint32_t dot24_asm(const int32_t (&a)[M], const int32_t (&b)[M])
+{
+	static_assert(M % 4 == 0, "taps in fours");
+	uint32_t d = 0;
+#pragma unroll
+	for(int j = 0; j < M; j += 4)
+		asm("v_mad_i32_i24 %0, %1, %2, %0\n\tv_mad_i32_i24 %0, %3, %4, %0\n\tv_mad_i32_i24 %0, %5, %6, %0\n\tv_mad_i32_i24 %0, %7, %8, %0"
+		    : "+v"(d) : "v"(a[j]), "v"(b[j]), "v"(a[j + 1]), "v"(b[j + 1]), "v"(a[j + 2]), "v"(b[j + 2]), "v"(a[j + 3]), "v"(b[j + 3]));
+	return d;
+}
+}
+#define FLACGPU_DOT24(a, b) flacgpu::dot24_asm(a, b)
 #include "flacgpu_decode.h"
 
 namespace flacgpu {
@@ -50,7 +65,7 @@ __global__ __launch_bounds__(64) void verify_kernel(const DevParams P, const uin
 			ca = H.ca;
 			for(uint32_t ch = 0; ch < C && st == DEC_OK; ch++) {
 				ST *row = decoded + ((size_t)blockIdx.x * C + ch) * N * 64 + threadIdx.x;      // sample i of this frame: row[i * 64]
-				auto sink = [&](uint32_t i, int64_t v) { row[(size_t)i * 64] = (ST)v; };
+				auto sink = [&](uint32_t, int64_t v) { *row = (ST)v; row += 64; };                // (samples arrive in order)
 				if(decode_subframe<MAXORD, ST>(b, H.n, coded_bps(E.bps, ca, ch), sink) != DEC_OK) st = DEC_ERROR;
 			}
 			if(st == DEC_OK && decode_frame_tail(b) != DEC_OK) st = DEC_ERROR;
