@@ -920,11 +920,56 @@ static int release_if_full(FLAC__StreamEncoder *e)
 
 /* range check (stream_encoder.c:2544-2547) and narrowing copy of `count` values spaced `sstride` apart in src to
  * sample slots spaced `dstride` samples apart in dst */
+#if defined(__x86_64__)
+#include <immintrin.h>
+/* 16-bit streams, the common case, eight or sixteen values per step: this loop is the one pass the caller's thread makes over
+ * its samples, so it sets the rate of the whole single-stream API once the MD5 is off (the GPU behind it is ~15x faster) */
+__attribute__((target("avx2"))) static int stage16_flat_avx2(int16_t *d, const int32_t *src, size_t count, int32_t smin, int32_t smax)
+{
+	__m256i vlo = _mm256_setzero_si256(), vhi = _mm256_setzero_si256();
+	size_t k = 0;
+	for(; k + 16 <= count; k += 16) {
+		const __m256i a = _mm256_loadu_si256((const __m256i *)(src + k)), b = _mm256_loadu_si256((const __m256i *)(src + k + 8));
+		vlo = _mm256_min_epi32(vlo, _mm256_min_epi32(a, b)); vhi = _mm256_max_epi32(vhi, _mm256_max_epi32(a, b));
+		/* (the saturating pack equals truncation for every value that passes the range check; the others fail the call) */
+		_mm256_storeu_si256((__m256i *)(d + k), _mm256_permute4x64_epi64(_mm256_packs_epi32(a, b), 0xD8));
+	}
+	int32_t lo[8], hi[8], l = 0, h = 0;
+	_mm256_storeu_si256((__m256i *)lo, vlo); _mm256_storeu_si256((__m256i *)hi, vhi);
+	for(int i = 0; i < 8; i++) { l = lo[i] < l ? lo[i] : l; h = hi[i] > h ? hi[i] : h; }
+	for(; k < count; k++) { const int32_t v = src[k]; d[k] = (int16_t)v; l = v < l ? v : l; h = v > h ? v : h; }
+	return !(l < smin || h > smax);
+}
+/* planar stereo (FLAC__stream_encoder_process): left and right arrays -> interleaved 16-bit pairs */
+__attribute__((target("avx2"))) static int stage16_stereo_avx2(int16_t *d, const int32_t *L, const int32_t *R, size_t count, int32_t smin, int32_t smax)
+{
+	__m256i vlo = _mm256_setzero_si256(), vhi = _mm256_setzero_si256();
+	const __m256i m = _mm256_set1_epi32(0xffff);
+	size_t k = 0;
+	for(; k + 8 <= count; k += 8) {
+		const __m256i a = _mm256_loadu_si256((const __m256i *)(L + k)), b = _mm256_loadu_si256((const __m256i *)(R + k));
+		vlo = _mm256_min_epi32(vlo, _mm256_min_epi32(a, b)); vhi = _mm256_max_epi32(vhi, _mm256_max_epi32(a, b));
+		_mm256_storeu_si256((__m256i *)(d + 2 * k), _mm256_or_si256(_mm256_and_si256(a, m), _mm256_slli_epi32(b, 16)));
+	}
+	int32_t lo[8], hi[8], l = 0, h = 0;
+	_mm256_storeu_si256((__m256i *)lo, vlo); _mm256_storeu_si256((__m256i *)hi, vhi);
+	for(int i = 0; i < 8; i++) { l = lo[i] < l ? lo[i] : l; h = hi[i] > h ? hi[i] : h; }
+	for(; k < count; k++) { const int32_t a = L[k], b = R[k]; d[2 * k] = (int16_t)a; d[2 * k + 1] = (int16_t)b; l = a < l ? a : l; l = b < l ? b : l; h = a > h ? a : h; h = b > h ? b : h; }
+	return !(l < smin || h > smax);
+}
+static int have_avx2(void) { static int v = -1; if(v < 0) v = __builtin_cpu_supports("avx2") ? 1 : 0; return v; }
+#else
+static int have_avx2(void) { return 0; }
+#endif
+
 static int stage_values(uint8_t *dst, size_t dstride, const int32_t *src, size_t sstride, size_t count, uint32_t width, int32_t smin, int32_t smax)
 {
 	int32_t lo = 0, hi = 0;
 	if(width == 2) {
 		int16_t *d = (int16_t *)dst;
+#if defined(__x86_64__)
+		if(dstride == 1 && sstride == 1 && have_avx2()) return stage16_flat_avx2(d, src, count, smin, smax);
+#endif
 		if(dstride == 1 && sstride == 1) for(size_t k = 0; k < count; k++) { const int32_t v = src[k]; d[k] = (int16_t)v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
 		else for(size_t k = 0; k < count; k++) { const int32_t v = src[k * sstride]; d[k * dstride] = (int16_t)v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
 	}
@@ -979,11 +1024,17 @@ FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *e, const FLAC__int3
 	while(j < samples) {
 		size_t n = cap - p->staged;
 		if(n > samples - j) n = samples - j;
-		for(uint32_t c = 0; c < C; c++)
-			if(!stage_values(p->slot[p->cur].raw + (p->staged * C + c) * p->width, C, buffer[c] + j, 1, n, p->width, smin, smax)) {
-				PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
-				return 0;
-			}
+		int ok = 1;
+#if defined(__x86_64__)
+		if(C == 2 && p->width == 2 && have_avx2()) ok = stage16_stereo_avx2((int16_t *)(p->slot[p->cur].raw + p->staged * C * p->width), buffer[0] + j, buffer[1] + j, n, smin, smax);
+		else
+#endif
+		for(uint32_t c = 0; c < C && ok; c++)
+			ok = stage_values(p->slot[p->cur].raw + (p->staged * C + c) * p->width, C, buffer[c] + j, 1, n, p->width, smin, smax);
+		if(!ok) {
+			PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+			return 0;
+		}
 		p->staged += n; j += (uint32_t)n;
 		if(!release_if_full(e)) return 0;
 	}

@@ -32,7 +32,10 @@ extern "C" {
 /* error codes (negative returns) */
 enum {
 	FLACGPU_OK = 0,
-	FLACGPU_ERR_UNSUPPORTED = -1,   /* configuration outside the engine's range (see flacgpu_create) */
+	FLACGPU_ERR_UNSUPPORTED = -1,   /* configuration outside the engine's range: channels / bits / block size / orders beyond the format's
+	                                   limits, or an apodization list that expands to more than 1024 window jobs or 2048 LPC analyses
+	                                   per subframe (e.g. two subdivide_tukey(32) in one list: the reference accepts any list of up to
+	                                   32 functions, stream_encoder.c:1940-2070; one subdivide_tukey(32) is 528 jobs / 1053 analyses) */
 	FLACGPU_ERR_NO_DEVICE = -2,     /* no HIP device / kernel image not loadable: there is NO CPU fallback */
 	FLACGPU_ERR_ALLOC = -3,         /* -> FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR */
 	FLACGPU_ERR_OUTPUT_TOO_SMALL = -4,
