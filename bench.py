@@ -67,9 +67,35 @@ def synth_pcm(nframes, seed, block, kind="music"):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the unmodified reference on this box's host cores (test infrastructure: oracle/_ref)
 # ------------------------------------------------------------------------------------------------------------------
+def usable_cpus():
+    """CPUs this process may actually use: the visible count, cut down by the scheduler affinity and by a cgroup CPU quota
+    (the GPU boxes show 256 hardware threads to a container that is allowed 16 CPUs' worth of time)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, (os.cpu_count() or 1), quota
+
+
 def cpu_baseline(level, search=None):
     from oracle import pyoracle as po
-    cores = os.cpu_count() or 1
+    cores, visible, quota = usable_cpus()
     rate_bin = os.path.join(ROOT, "oracle", "_ref", "ref_rate")
     if not (po.have_ref() and os.path.exists(rate_bin)) or (search and any(search.values())):
         # no reference build on this box (or a search the rate program has no switch for): time the library in-process on a short clip
@@ -83,7 +109,7 @@ def cpu_baseline(level, search=None):
             return time.perf_counter() - t0
         best = min(run() for _ in range(3))
         return {"value": round(pcm.shape[0] / best / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "reference" if po.have_ref() else "port",
-                "sample": "%d inter-channel samples of the bench signal, flac -%d, best of 3, in-memory" % (pcm.shape[0], level), "host_cpus": cores}
+                "sample": "%d inter-channel samples of the bench signal, flac -%d, best of 3, in-memory" % (pcm.shape[0], level), "host_cpus": visible, "usable_cpus": cores}
     # >= 10 minutes of the bench signal as a raw 16-bit file on tmpfs (input from tmpfs, output discarded)
     clip = synth_pcm(6460, 4321, 4096).astype(np.int16)                                     # 10.0 min
     nsamp = clip.shape[0]
@@ -105,7 +131,7 @@ def cpu_baseline(level, search=None):
         inside = cores * reps * nsamp / max(float(o[2]) for o in outs) / 1e6       # without process start-up / file read
         # (2): the library's own frame-parallel thread pool (flac -j N) at several thread counts, best of 3 each
         pool = {}
-        for thr in sorted(set(t for t in (8, 16, 32, 64, min(cores, 128)) if t <= max(cores, 8))):
+        for thr in sorted(set(t for t in (4, 8, 16, 32, 64, cores, 2 * cores) if 2 <= t <= max(2 * cores, 8) and t <= 128)):
             try:
                 pool[thr] = round(nsamp / one(thr, 3)[1] / 1e6, 2)
             except Exception as e:                                     # a reference build without threads
@@ -118,9 +144,10 @@ def cpu_baseline(level, search=None):
         "value": round(single, 3), "unit": "Msamples/s", "cores": 1, "kind": "reference",
         "sample": "%d inter-channel samples (%.1f min) of the bench signal from a raw file on tmpfs, flac -%d with MD5, output discarded, best of 3" % (nsamp, nsamp / RATE / 60, level),
         "all_cores": {"value": round(inside, 2), "value_incl_process_start": round(allcores, 2), "cores": cores,
-                      "how": "%d independent single-thread processes x %d encodes of the clip each, started together; value = all samples / the slowest process's encode time (the better figure for the CPU)" % (cores, reps)},
+                      "how": "%d independent single-thread processes (one per CPU this container may use: %d visible, cgroup quota %s) x %d encodes of the clip each, started together; "
+                             "value = all samples / the slowest process's encode time (the better figure for the CPU)" % (cores, visible, quota, reps)},
         "library_thread_pool": {"by_threads": pool, "best_threads": best_thr, "value": nums.get(best_thr), "how": "one stream, FLAC__stream_encoder_set_num_threads, best of 3"},
-        "host_cpus": cores,
+        "host_cpus": visible, "usable_cpus": cores, "cgroup_cpu_quota": quota,
     }
 
 
