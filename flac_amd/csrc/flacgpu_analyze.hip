@@ -913,7 +913,7 @@ __device__ uint64_t fir_abs_plain64(const uint32_t *reg, bool packed, uint32_t S
 
 // One wavefront evaluates one residual candidate on the owner layout; requires n == 64*S, S >= 16, max_po <= 6.
 template <int MAXORD>
-__device__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's region */, bool packed, uint32_t S, uint32_t n, uint32_t order, const int32_t *q, int shift,
+__device__ __forceinline__ uint32_t eval_candidate_owner(const uint32_t *reg /* this lane's region */, bool packed, uint32_t S, uint32_t n, uint32_t order, const int32_t *q, int shift,
                                          uint32_t wide /* Candidate::wide */, uint32_t sbps, uint32_t rice_limit, uint32_t max_po, uint32_t min_po, const uint32_t *divtab,
                                          uint8_t *kout, uint32_t *best_po_out, int lane)
 {
@@ -1014,7 +1014,8 @@ template <int MAXORD, int VARIANT>
 __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_SIMD : 2) void eval_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n, uint32_t cpw,
                                                                    const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                                    const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
-                                                                   const int *__restrict__ valid, SubDecision *__restrict__ decisions, unsigned long long *__restrict__ dbg)
+                                                                   const int *__restrict__ valid, SubDecision *__restrict__ decisions, unsigned long long *__restrict__ dbg,
+                                                                   uint32_t prefetch_ahead)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -1024,6 +1025,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;
 	const uint32_t N = P.blocksize;
 	const uint32_t ngrp = P.ncand / cpw;
+	uint32_t pf_tmp = 0;                  // destination of the prefetch load (see below)
 	uint32_t f, grp;
 	map_block(blockIdx.x, nframes, ngrp, f, grp);
 	const size_t fc0 = (size_t)f * P.ncand + (size_t)grp * cpw;
@@ -1158,6 +1160,31 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 		}
 		__syncthreads();
 		STAMP(1);
+		// ---- the inputs of the workgroup that will take this one's place, pulled into this XCD's L2 -------------------------------
+		// A workgroup starts with two dependent round trips to HBM (channel records; then candidate records and planar samples)
+		// before its first FIR.  Workgroups reach an XCD in launch order, prefetch_ahead of them at a time: while this one
+		// computes, it touches every 128-byte line its successor on the same XCD (block index + 8 * prefetch_ahead) will read --
+		// one load per thread, result never used -- so that the successor's round trips end in the L2.  No extra HBM traffic: a
+		// line is fetched once, by whoever asks first.
+		if(VARIANT == 0 && prefetch_ahead) {
+			const uint32_t bp = blockIdx.x + 8u * prefetch_ahead;
+			if(bp < gridDim.x) {
+				uint32_t fp, gp;
+				map_block(bp, nframes, ngrp, fp, gp);
+				const size_t fcp = (size_t)fp * P.ncand + (size_t)gp * cpw;
+				const uint32_t per = nthreads / cpw, c = (uint32_t)tid / per, t = (uint32_t)tid - c * per;       // threads of channel c
+				if(c < cpw) {
+					const size_t fc = fcp + c;
+					const uint32_t plane_lines = (N * 2 + 127) / 128, cand_lines = (cstride * (uint32_t)sizeof(Candidate) + 127) / 128, valid_lines = (cstride * 4 + 127) / 128;
+					const unsigned char *a = nullptr;
+					if(t < plane_lines) a = (const unsigned char *)(chan + fc * (size_t)P.chan_stride) + (size_t)t * 128;
+					else if(t < plane_lines + cand_lines) a = (const unsigned char *)(cands + fc * cstride) + (size_t)(t - plane_lines) * 128;
+					else if(t < plane_lines + cand_lines + valid_lines) a = (const unsigned char *)(valid + fc * cstride) + (size_t)(t - plane_lines - cand_lines) * 128;
+					else if(t == plane_lines + cand_lines + valid_lines) a = (const unsigned char *)(preps + fc);
+					if(a) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_tmp) : "v"(a) : "memory");
+				}
+			}
+		}
 
 		// ---- work items (candidate, channel): one wavefront each ---------------------------------------------------------
 		{
@@ -1261,6 +1288,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	}
 	STAMP(5);
 #undef STAMP
+	if(VARIANT == 0 && prefetch_ahead) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_tmp));      // (the prefetch's destination register stays reserved until its data is back)
 }
 
 } // namespace flacgpu
@@ -1345,10 +1373,19 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		}
 	}
 	// which flavours can occur in this batch at all (each launch serves only its own channels)
-	if(op) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
-	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+	// how many workgroups ahead the one is that takes a finishing workgroup's place on its XCD: the workgroups an XCD holds
+	static int ahead = -1;
+	if(ahead < 0) {
+		int nb = 0;
+		if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)eval_kernel<MAXORD, 0>, (int)(waves * 64), lds) != hipSuccess || nb < 1) nb = 2;
+		ahead = nb * 16;            // (measured on MI355X, profiles/r02_g_prefetch_ab.txt: 32..96 workgroups ahead are equally good, 256 is too early)
+		if(const char *e = getenv("FLACGPU_EVAL_PREFETCH")) ahead = atoi(e);
+		if(ahead < 0) ahead = 0;
+	}
+	if(op) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, (uint32_t)ahead);
+	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u);
 	if(!op || tail_n || P.max_po > 6)
-		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(gwaves * 64), lds_generic, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg);
+		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(gwaves * 64), lds_generic, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u);
 	sync_debug("eval", s);
 	return hipGetLastError();
 }

@@ -928,10 +928,19 @@ __attribute__((target("avx2"))) static int stage16_flat_avx2(int16_t *d, const i
 {
 	__m256i vlo = _mm256_setzero_si256(), vhi = _mm256_setzero_si256();
 	size_t k = 0;
+	/* (the saturating pack equals truncation for every value that passes the range check; the others fail the call) */
+	if(((uintptr_t)d & 31) == 0 && count >= 4096) {
+		/* the staging buffer is written once and read by the DMA engine: streaming stores spare the read-for-ownership */
+		for(; k + 16 <= count; k += 16) {
+			const __m256i a = _mm256_loadu_si256((const __m256i *)(src + k)), b = _mm256_loadu_si256((const __m256i *)(src + k + 8));
+			vlo = _mm256_min_epi32(vlo, _mm256_min_epi32(a, b)); vhi = _mm256_max_epi32(vhi, _mm256_max_epi32(a, b));
+			_mm256_stream_si256((__m256i *)(d + k), _mm256_permute4x64_epi64(_mm256_packs_epi32(a, b), 0xD8));
+		}
+		_mm_sfence();
+	}
 	for(; k + 16 <= count; k += 16) {
 		const __m256i a = _mm256_loadu_si256((const __m256i *)(src + k)), b = _mm256_loadu_si256((const __m256i *)(src + k + 8));
 		vlo = _mm256_min_epi32(vlo, _mm256_min_epi32(a, b)); vhi = _mm256_max_epi32(vhi, _mm256_max_epi32(a, b));
-		/* (the saturating pack equals truncation for every value that passes the range check; the others fail the call) */
 		_mm256_storeu_si256((__m256i *)(d + k), _mm256_permute4x64_epi64(_mm256_packs_epi32(a, b), 0xD8));
 	}
 	int32_t lo[8], hi[8], l = 0, h = 0;
