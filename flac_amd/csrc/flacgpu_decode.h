@@ -41,30 +41,52 @@ struct DecodeExpect {
 };
 enum { DEC_OK = 0, DEC_MISMATCH = 1, DEC_ERROR = 2 };
 
-// ---- MSB-first bit reader over global memory: 64-bit window, refilled a 32-bit word at a time ------------------------
-// The next word is always in flight (a lane has no second wavefront to hide its load latency behind): `pre` holds it as
-// loaded, the byte swap happens when it enters the window.  Loads never leave [first aligned word of the frame, the
-// aligned word holding the buffer's last byte]: beyond that the address is clamped (what comes back is never consumed
-// legitimately -- a frame that reads past its own end is an error -- it only must not fault).
+// ---- MSB-first bit reader over global memory ---------------------------------------------------------------------------
+// A 64-bit window kept as two 32-bit halves (64-bit shifts cost a lane twice as much as 32-bit ones and the lane is
+// latency bound): `ah` always holds the next 32 unread bits once nb >= 32, `al` what follows, nb = valid bits in ah:al,
+// zeros behind them.  The next word is always in flight (a lane has no second wavefront to hide its load latency
+// behind): `pre` holds it as loaded, the byte swap happens when it enters the window.  Loads never leave [first aligned
+// word of the frame, the aligned word holding the buffer's last byte]: beyond that the address is clamped (what comes
+// back is never consumed legitimately -- a frame that reads past its own end is an error -- it only must not fault).
 struct BitReader {
 	const uint32_t *wp;            // next aligned word to load
 	const uint32_t *wlast;         // the aligned word that holds the last byte of the buffer the frames lie in
 	const uint32_t *w0;            // the aligned word that holds the first byte of the frame
 	uint32_t pre;                  // the word in front of wp, as loaded (little endian)
-	uint64_t acc;                  // valid bits left-aligned, zeros behind them
-	uint32_t nb;                   // valid bits in acc
+	uint32_t ah, al;               // the window
+	uint32_t nb;                   // valid bits in it
 	uint32_t skip;                 // bits of w0 in front of the frame
 	uint64_t limit;                // bits the frame body holds: reading beyond is an error
 	uint32_t bad;
 };
+// shifts by 0..32 (a machine shift takes its count modulo 32)
+FLACGPU_HD inline uint32_t dec_shl(uint32_t v, uint32_t s) { const uint32_t a = s >> 1; return (v << a) << (s - a); }
+FLACGPU_HD inline uint32_t dec_shr(uint32_t v, uint32_t s) { const uint32_t a = s >> 1; return (v >> a) >> (s - a); }
 FLACGPU_HD inline uint32_t br_fetch(BitReader &b)
 {
 	const uint32_t *q = b.wp < b.wlast ? b.wp : b.wlast;
 	b.wp++;
 	return *q;
 }
-FLACGPU_HD inline uint32_t br_load(BitReader &b) { const uint32_t v = __builtin_bswap32(b.pre); b.pre = br_fetch(b); return v; }
-FLACGPU_HD inline void br_refill(BitReader &b) { if(b.nb <= 32) { b.acc |= (uint64_t)br_load(b) << (32 - b.nb); b.nb += 32; } }
+// takes the word in flight into the window when the low half is empty: afterwards nb >= 33
+FLACGPU_HD inline void br_refill(BitReader &b)
+{
+	if(b.nb <= 32) {
+		const uint32_t w = __builtin_bswap32(b.pre);
+		b.pre = br_fetch(b);
+		b.ah |= dec_shr(w, b.nb);                                      // (al is empty: all valid bits sit in ah)
+		b.al = dec_shl(w, 32 - b.nb);
+		b.nb += 32;
+	}
+}
+// drops t bits, 1 <= t <= 32, t <= nb
+FLACGPU_HD inline void br_drop(BitReader &b, uint32_t t)
+{
+	const uint32_t s = 32 - t;                                          // 0..31
+	b.ah = s ? (b.ah << t) | (b.al >> s) : b.al;                        // (one funnel shift on the GPU: v_alignbit_b32)
+	b.al = (b.al << (t - 1)) << 1;
+	b.nb -= t;
+}
 // bits consumed so far, counted from the first byte of the frame: words taken into the window (one more is in flight)
 FLACGPU_HD inline uint64_t br_pos(const BitReader &b) { return (uint64_t)(b.wp - b.w0 - 1) * 32 - b.nb - b.skip; }
 FLACGPU_HD inline bool br_over(const BitReader &b) { return br_pos(b) > b.limit; }
@@ -75,18 +97,18 @@ FLACGPU_HD inline void br_init(BitReader &b, const uint8_t *p, size_t nbytes, co
 	b.w0 = (const uint32_t *)(p - mis);                                 // (pointer arithmetic, not an integer cast: the address space survives)
 	b.wlast = (const uint32_t *)((buf_hi - 1) - ((uintptr_t)(buf_hi - 1) & 3));
 	b.wp = b.w0;
-	b.acc = 0; b.nb = 0; b.skip = mis * 8; b.limit = (uint64_t)nbytes * 8; b.bad = 0;
+	b.ah = 0; b.al = 0; b.nb = 0; b.skip = mis * 8; b.limit = (uint64_t)nbytes * 8; b.bad = 0;
 	b.pre = br_fetch(b);
-	br_refill(b);
-	b.acc <<= b.skip; b.nb -= b.skip;
+	br_refill(b);                                                       // nb = 32: the first word in ah
+	if(b.skip) { b.ah <<= b.skip; b.nb -= b.skip; }
 	br_refill(b);
 }
 FLACGPU_HD inline uint32_t br_get(BitReader &b, uint32_t n)            // 0 <= n <= 32
 {
 	if(n == 0) return 0;
 	br_refill(b);                                                      // now nb >= 33
-	const uint32_t v = (uint32_t)(b.acc >> (64 - n));
-	b.acc <<= n; b.nb -= n;
+	const uint32_t v = b.ah >> (32 - n);
+	br_drop(b, n);
 	return v;
 }
 FLACGPU_HD inline int32_t br_get_signed(BitReader &b, uint32_t n)      // 1 <= n <= 32
@@ -105,16 +127,31 @@ FLACGPU_HD inline uint32_t br_unary(BitReader &b)                      // zeros 
 {
 	uint32_t z = 0;
 	for(;;) {
-		br_refill(b);
-		if(b.acc != 0) {
-			const uint32_t lz = (uint32_t)__builtin_clzll(b.acc);          // < nb: the valid bits hold a one
-			z += lz;
-			b.acc <<= lz; b.acc <<= 1; b.nb -= lz + 1;
-			return z;
+		br_refill(b);                                                  // nb >= 33: ah is all valid
+		if(b.ah != 0) {
+			const uint32_t lz = (uint32_t)__builtin_clz(b.ah);
+			br_drop(b, lz + 1);
+			return z + lz;
 		}
-		z += b.nb; b.nb = 0;
+		z += 32; br_drop(b, 32);
 		if(br_over(b)) { b.bad = 1; return z; }                            // ran off the frame: stop
 	}
+}
+// one Rice-coded residual with parameter k (0..30): unary quotient, stop bit, k low bits -- in one step when the whole code
+// lies in the 32 bits at hand (nearly always), else piecewise
+FLACGPU_HD inline uint32_t br_rice(BitReader &b, uint32_t k)
+{
+	br_refill(b);
+	if(b.ah != 0) {
+		const uint32_t lz = (uint32_t)__builtin_clz(b.ah), total = lz + 1 + k;
+		if(total <= 32) {
+			const uint32_t low = k ? (b.ah >> (32 - total)) & ((1u << k) - 1u) : 0u;      // (v_bfe_u32)
+			br_drop(b, total);
+			return (lz << k) | low;
+		}
+	}
+	const uint32_t msbs = br_unary(b);
+	return (msbs << k) | br_get(b, k);
 }
 
 FLACGPU_HD inline uint32_t dec_ilog2(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
@@ -209,16 +246,19 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 	else if(type >= 32) { order = type - 31; lpc = true; }
 	else return DEC_ERROR;                                      // reserved
 	if(order > n || order > (uint32_t)MAXORD) return DEC_ERROR;
-	ST h[MAXORD];                                               // h[j] = sample i-1-j
+	// the last MAXORD samples, in slots that ROTATE instead of shifting: the residual loop below is unrolled MAXORD times and
+	// iteration s of a pass writes slot s, so every index is a constant after unrolling and no sample is ever moved
+	// (slot t holds sample i0 - MAXORD + t at the start of a pass that begins with sample i0)
+	ST h[MAXORD];
 	int32_t q[MAXORD];
 #pragma unroll
 	for(int j = 0; j < MAXORD; j++) { h[j] = 0; q[j] = 0; }
 	for(uint32_t i = 0; i < order; i++) {
 		const int64_t v = br_get_sample(b, sb);
 		sink(i, (int64_t)((uint64_t)v << wasted));
+		const uint32_t slot = i + (uint32_t)MAXORD - order;         // the first pass begins with sample `order`
 #pragma unroll
-		for(int j = MAXORD - 1; j > 0; j--) h[j] = h[j - 1];
-		h[0] = (ST)v;
+		for(int t = 0; t < MAXORD; t++) if((uint32_t)t == slot) h[t] = (ST)v;
 	}
 	int32_t shift = 0;
 	bool wide_sum = true;                                       // 64-bit prediction sum
@@ -251,47 +291,59 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 	uint32_t next_part = order, k = 0, raw = 0;                 // sample index at which the next partition starts
 	bool escaped = false;
 	uint32_t part = 0;
-	for(uint32_t i = order; i < n; i++) {
-		while(i == next_part) {                                 // (a partition 0 that holds no residual at all is legal: psize == order)
-			k = br_get(b, plen);
-			escaped = k == esc;
-			if(escaped) raw = br_get(b, 5);
-			part++;
-			next_part = po ? part * psize : n;
-			if(br_over(b)) return DEC_ERROR;                    // (checked per partition, not per sample: a lane that runs off its
-		}                                                       //  frame reads zeros / clamped words until the partition ends)
-		int64_t r;
-		if(escaped) r = raw ? (int64_t)br_get_signed(b, raw) : 0;
-		else {
-			const uint32_t msbs = br_unary(b);
-			const uint32_t u = (msbs << k) | br_get(b, k);
-			r = (int64_t)(int32_t)((u >> 1) ^ (0u - (u & 1u)));
-		}
-		int64_t sum = 0;
-		if(wide_sum) {
+	bool err = false;
+	for(uint32_t i = order; i < n && !err; ) {
+		// (the pass has ONE exit, at its end: the 24-bit multiply-add is inline asm, which the compiler treats as convergent, and
+		//  a loop with a convergent operation and a second exit is not unrolled -- the slots would become a dynamically indexed
+		//  array in scratch memory)
 #pragma unroll
-			for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)h[j];
-		}
-		else if(narrow24) {
-			// samples and taps below 2^23 in magnitude: the low 32 bits of every product come out of the 24-bit multiplier
-			// (full rate on the GPU; a 32-bit multiply runs at a quarter of it)
-			int32_t hh[MAXORD];
+		for(int s = 0; s < MAXORD; s++) {
+			if(i < n && !err) {
+				while(i == next_part && !err) {                     // (a partition 0 that holds no residual at all is legal: psize == order)
+					k = br_get(b, plen);
+					escaped = k == esc;
+					if(escaped) raw = br_get(b, 5);
+					part++;
+					next_part = po ? part * psize : n;
+					err = br_over(b);                               // (checked per partition, not per sample: a lane that runs off its
+				}                                                   //  frame reads zeros / clamped words until the partition ends)
+				int64_t r;
+				if(escaped) r = raw ? (int64_t)br_get_signed(b, raw) : 0;
+				else {
+					const uint32_t u = br_rice(b, k);
+					r = (int64_t)(int32_t)((u >> 1) ^ (0u - (u & 1u)));
+				}
+				// tap j multiplies sample i-1-j: written earlier in this pass (slot s-1-j) or left from the pass before (slot MAXORD-1-j+s)
+				ST hs[MAXORD];
 #pragma unroll
-			for(int j = 0; j < MAXORD; j++) hh[j] = (int32_t)h[j];
-			sum = (int64_t)(int32_t)FLACGPU_DOT24(q, hh);
-		}
-		else {
-			uint32_t s32 = 0;
+				for(int j = 0; j < MAXORD; j++) hs[j] = j < s ? h[s - 1 - j] : h[MAXORD - 1 - j + s];
+				int64_t sum = 0;
+				if(wide_sum) {
 #pragma unroll
-			for(int j = 0; j < MAXORD; j++) s32 += (uint32_t)q[j] * (uint32_t)(int32_t)h[j];
-			sum = (int64_t)(int32_t)s32;
-		}
-		const int64_t v = r + (sum >> shift);
-		sink(i, (int64_t)((uint64_t)v << wasted));
+					for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)hs[j];
+				}
+				else if(narrow24) {
+					// samples and taps below 2^23 in magnitude: the low 32 bits of every product come out of the 24-bit multiplier
+					// (full rate on the GPU; a 32-bit multiply runs at a quarter of it)
+					int32_t hh[MAXORD];
 #pragma unroll
-		for(int j = MAXORD - 1; j > 0; j--) h[j] = h[j - 1];
-		h[0] = (ST)v;
+					for(int j = 0; j < MAXORD; j++) hh[j] = (int32_t)hs[j];
+					sum = (int64_t)(int32_t)FLACGPU_DOT24(q, hh);
+				}
+				else {
+					uint32_t s32 = 0;
+#pragma unroll
+					for(int j = 0; j < MAXORD; j++) s32 += (uint32_t)q[j] * (uint32_t)(int32_t)hs[j];
+					sum = (int64_t)(int32_t)s32;
+				}
+				const int64_t v = r + (sum >> shift);
+				sink(i, (int64_t)((uint64_t)v << wasted));
+				h[s] = (ST)v;
+				i++;
+			}
+		}
 	}
+	if(err) return DEC_ERROR;
 	return (b.bad || br_over(b)) ? DEC_ERROR : DEC_OK;
 }
 
