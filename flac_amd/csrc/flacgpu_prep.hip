@@ -279,11 +279,12 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 	__shared__ Prep3Out outp;
 	const int tid = (int)threadIdx.x, lane = tid & 63;
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
-	const uint32_t N = P.blocksize, Q = N / 4;                            // 1024: one 16-sample chunk per lane
+	constexpr uint32_t N = 4096, Q = N / 4;                               // prep3_applicable(): 1024 = one 16-sample chunk per lane; a
+	                                                                      // constant tile stride folds every LDS address into an offset
 	const uint32_t f = blockIdx.x;
 	const uint32_t q0 = wave * Q;
 	const int2 *p = (const int2 *)(pcm + (size_t)f * N * 2) + q0;
-	const uint32_t TS = p2_ts(Q), cbytes = p2_chan_bytes(Q);
+	constexpr uint32_t TS = ((Q / CHUNK - 1 + 31) / 32) * 32 + 2, cbytes = CHUNK * TS * 4;     // p2_ts(Q), p2_chan_bytes(Q)
 	int32_t *sa = (int32_t *)(smem + (size_t)wave * 2 * cbytes), *sb = (int32_t *)(smem + (size_t)wave * 2 * cbytes + cbytes);
 	const uint32_t cstride = P.ncslots;
 
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 #pragma unroll
 			for(int k = 0; k < 5; k++) pt.e[c][k] = A.e[k];
 		}
+		__builtin_amdgcn_sched_barrier(0);                             // one channel at a time: interleaving them spills
 	}
 	__syncthreads();
 
@@ -415,6 +417,14 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 	// ---- planar channels of this quarter, shifted, straight from the registers ----------------------------------------
 	{
 		const uint32_t base = q0 + (uint32_t)lane * CHUNK;
+		// the quarter is read again from the LDS tile (conflict-free, behind the barrier) rather than kept in registers across
+		// the decision phase: holding a[], b[] alive there cost 23 spilled VGPRs = 23 KB of scratch written and read per frame
+		int32_t ra[CHUNK], rb[CHUNK];
+		{
+			const int32_t *pa = sa + lane, *pb = sb + lane;
+#pragma unroll
+			for(int k = 0; k < CHUNK; k++) { ra[k] = pa[k * TS + 1]; rb[k] = pb[k * TS + 1]; }
+		}
 #pragma unroll
 		for(int c = 0; c < 4; c++) {
 			const int32_t slot = outp.slot[c];
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 			const uint32_t wasted = outp.wasted[c];
 			int32_t x[CHUNK];
 #pragma unroll
-			for(int k = 0; k < CHUNK; k++) x[k] = (c == 0 ? a[k + 4] : c == 1 ? b[k + 4] : c == 2 ? ((a[k + 4] + b[k + 4]) >> 1) : (a[k + 4] - b[k + 4])) >> wasted;
+			for(int k = 0; k < CHUNK; k++) x[k] = (c == 0 ? ra[k] : c == 1 ? rb[k] : c == 2 ? ((ra[k] + rb[k]) >> 1) : (ra[k] - rb[k])) >> wasted;
 			uint32_t *dst = (uint32_t *)(chan + ((size_t)f * P.ncand + (uint32_t)slot) * (size_t)N);
 			if(outp.fmt[c]) {
 				uint4 w0, w1;

@@ -20,6 +20,10 @@
 #include <string.h>
 #include <pthread.h>
 #include <limits.h>
+#include <stdatomic.h>
+#include <time.h>
+#include <unistd.h>
+#include <sched.h>
 #include "flacgpu_host.h"
 #include "ogg.h"
 #include "FLACgpu_stream_encoder.h"
@@ -114,7 +118,19 @@ struct FLAC__StreamEncoderPrivate {
 	flacgpu_host_verify_result verify_stats;  /* get_verify_decoder_error_stats */
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
+	/* The MD5 is one serial chain over the whole stream (md5.c:497) and the slowest stage of a 16-bit stream (~0.65 GB/s): the
+	 * worker runs it AHEAD of the submissions, over the samples the caller has published from the slot it is still filling
+	 * (pub_slot/pub_staged, under mu), so that the chain starts with the first samples and not with the first full batch. */
+	int md5_slot;                             /* slot of the batch the chain is in */
+	size_t md5_done;                          /* inter-channel samples of that batch already hashed */
+	int pub_slot; size_t pub_staged, pub_last;
+	struct stage_pool *pool;                  /* helper threads of the narrowing copy (big process() calls only) */
+	/* FLACGPU_HOST_TIMING=1: where a stream's wall time went, printed by finish() */
+	int timing;
+	double t_init_engine, t_init_pinned, t_stage, t_wait, t_emit, t_md5, t_encode, t_release, t_start;
 };
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+#define MD5_PIECE ((size_t)1 << 16)           /* samples: the caller publishes, and the worker hashes, in pieces of at least this */
 
 /* export.h:107 -- 1: this library writes Ogg FLAC (host/ogg.c) */
 int FLAC_API_SUPPORTS_OGG_FLAC = 1;
@@ -150,6 +166,100 @@ FLAC__StreamEncoder *FLAC__stream_encoder_new(void)
 	return e;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * helper threads of the narrowing copy.  process*() is the one pass a host thread makes over the client's samples; with the
+ * MD5 off it sets the rate of the whole single-stream API (the GPU behind it is an order of magnitude faster), so calls that
+ * bring >= 256 K values are cut into one range per thread.  A helper spins for some tens of microseconds after a job (calls
+ * arrive back to back) and sleeps on the condition variable otherwise.
+ * ---------------------------------------------------------------------------------------------- */
+#define STAGE_MAX_THREADS 16
+struct stage_job { int (*fn)(const void *args, size_t lo, size_t hi); const void *args; size_t lo, hi; int ok; };
+struct stage_pool {
+	int n;                                    /* helpers */
+	pthread_t th[STAGE_MAX_THREADS];
+	struct stage_job job[STAGE_MAX_THREADS];
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	_Atomic uint64_t gen;
+	_Atomic int pending, quit;
+	struct stage_pool_arg { struct stage_pool *sp; int i; } arg[STAGE_MAX_THREADS];
+};
+static inline void cpu_relax(void)
+{
+#if defined(__x86_64__)
+	__builtin_ia32_pause();
+#endif
+}
+static void *stage_helper_main(void *a)
+{
+	struct stage_pool *sp = ((struct stage_pool_arg *)a)->sp;
+	const int i = ((struct stage_pool_arg *)a)->i;
+	uint64_t seen = 0;
+	for(;;) {
+		for(int spin = 0; spin < 4000 && atomic_load_explicit(&sp->gen, memory_order_acquire) == seen && !atomic_load_explicit(&sp->quit, memory_order_relaxed); spin++) cpu_relax();
+		if(atomic_load_explicit(&sp->gen, memory_order_acquire) == seen) {
+			pthread_mutex_lock(&sp->mu);
+			while(atomic_load_explicit(&sp->gen, memory_order_acquire) == seen && !atomic_load_explicit(&sp->quit, memory_order_relaxed)) pthread_cond_wait(&sp->cv, &sp->mu);
+			pthread_mutex_unlock(&sp->mu);
+		}
+		if(atomic_load_explicit(&sp->quit, memory_order_relaxed)) break;
+		seen = atomic_load_explicit(&sp->gen, memory_order_acquire);
+		struct stage_job *j = &sp->job[i];
+		if(j->hi > j->lo) j->ok = j->fn(j->args, j->lo, j->hi);
+		atomic_fetch_sub_explicit(&sp->pending, 1, memory_order_release);
+	}
+	return 0;
+}
+static struct stage_pool *stage_pool_create(int helpers)
+{
+	struct stage_pool *sp = calloc(1, sizeof *sp);
+	if(!sp) return 0;
+	pthread_mutex_init(&sp->mu, 0);
+	pthread_cond_init(&sp->cv, 0);
+	for(int i = 0; i < helpers; i++) {
+		sp->arg[i].sp = sp; sp->arg[i].i = i;
+		if(pthread_create(&sp->th[i], 0, stage_helper_main, &sp->arg[i]) != 0) break;
+		sp->n++;
+	}
+	if(sp->n == 0) { pthread_mutex_destroy(&sp->mu); pthread_cond_destroy(&sp->cv); free(sp); return 0; }
+	return sp;
+}
+static void stage_pool_destroy(struct stage_pool *sp)
+{
+	if(!sp) return;
+	pthread_mutex_lock(&sp->mu);
+	atomic_store(&sp->quit, 1);
+	pthread_cond_broadcast(&sp->cv);
+	pthread_mutex_unlock(&sp->mu);
+	for(int i = 0; i < sp->n; i++) pthread_join(sp->th[i], 0);
+	pthread_mutex_destroy(&sp->mu);
+	pthread_cond_destroy(&sp->cv);
+	free(sp);
+}
+/* fn(args, lo, hi) over [0, count) in ranges whose bounds are multiples of `grain`; returns the AND of the results */
+static int stage_pool_run(struct stage_pool *sp, int (*fn)(const void *, size_t, size_t), const void *args, size_t count, size_t grain)
+{
+	const int parts = sp ? sp->n + 1 : 1;
+	if(parts == 1 || count < ((size_t)1 << 18)) return fn(args, 0, count);
+	size_t per = (count / (size_t)parts + grain - 1) / grain * grain;
+	size_t lo = per < count ? per : count;                 /* the caller's own range is [0, lo) */
+	const size_t mine = lo;
+	for(int i = 0; i < sp->n; i++) {
+		size_t hi = i + 1 == sp->n ? count : (lo + per < count ? lo + per : count);
+		sp->job[i].fn = fn; sp->job[i].args = args; sp->job[i].lo = lo; sp->job[i].hi = hi; sp->job[i].ok = 1;
+		lo = hi;
+	}
+	atomic_store_explicit(&sp->pending, sp->n, memory_order_relaxed);
+	pthread_mutex_lock(&sp->mu);
+	atomic_fetch_add_explicit(&sp->gen, 1, memory_order_release);
+	pthread_cond_broadcast(&sp->cv);
+	pthread_mutex_unlock(&sp->mu);
+	int ok = fn(args, 0, mine);
+	for(unsigned spin = 0; atomic_load_explicit(&sp->pending, memory_order_acquire) > 0; spin++) { if(spin < 20000) cpu_relax(); else sched_yield(); }
+	for(int i = 0; i < sp->n; i++) ok &= sp->job[i].ok;
+	return ok;
+}
+
 static void release_engine(FLAC__StreamEncoder *e)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
@@ -163,6 +273,7 @@ static void release_engine(FLAC__StreamEncoder *e)
 		pthread_cond_destroy(&p->cv);
 		p->worker_started = 0; p->worker_quit = 0;
 	}
+	stage_pool_destroy(p->pool); p->pool = 0;
 	if(p->gpu) { flacgpu_destroy(p->gpu); p->gpu = 0; }
 	for(int i = 0; i < 2; i++) {
 		if(p->slot[i].raw) { flacgpu_free_pinned(p->slot[i].raw); p->slot[i].raw = 0; }
@@ -559,7 +670,9 @@ static void run_batch_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
 	const flacgpu_host_settings *s = &PROT(e)->s;
 	const uint32_t N = s->blocksize, C = s->channels;
 	const size_t nsamp = (size_t)(b->nframes - 1) * N + (b->tail ? b->tail : N);
-	if(s->do_md5) flacgpu_host_md5_update(&p->md5, b->raw, nsamp * C * p->width);
+	double t0 = p->timing ? now_s() : 0;
+	if(s->do_md5 && nsamp > p->md5_done) flacgpu_host_md5_update(&p->md5, b->raw + p->md5_done * C * p->width, (nsamp - p->md5_done) * C * p->width);   /* what the chain had not reached yet */
+	if(p->timing) { const double t1 = now_s(); p->t_md5 += t1 - t0; t0 = t1; }
 	const float *tw = 0;
 	if(b->tail && s->max_lpc_order > 0) {
 		/* windows are recomputed for the short block, as resize_buffers_ does at finish (:1703-1711) */
@@ -570,6 +683,7 @@ static void run_batch_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
 		tw = w;
 	}
 	b->total = flacgpu_encode_batch_raw(p->gpu, b->raw, &p->rawfmt, b->nframes, b->first_frame, b->tail, tw, b->out, p->out_cap, b->frame_bytes);
+	if(p->timing) p->t_encode += now_s() - t0;
 	b->vres.status = 0;
 	if(b->total >= 0 && s->verify) {
 		/* write_bitbuffer_ verifies every frame before it is written (:3000-3018): here the engine has decoded the batch again on
@@ -584,9 +698,33 @@ static void *worker_main(void *arg)
 {
 	FLAC__StreamEncoder *e = arg;
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	const flacgpu_host_settings *s = &PROT(e)->s;
+	const size_t full = (size_t)p->batch_frames * s->blocksize, sample_bytes = (size_t)s->channels * p->width;
 	pthread_mutex_lock(&p->mu);
 	for(;;) {
-		int k = p->slot[0].state == 1 ? 0 : p->slot[1].state == 1 ? 1 : -1;
+		int k;
+		if(s->do_md5) {
+			/* stream order: the batch the chain is in is also the next one to be submitted */
+			k = p->md5_slot;
+			if(p->slot[k].state != 1) {
+				size_t avail = p->slot[k].state == 0 && p->pub_slot == k ? p->pub_staged : 0;
+				if(avail > full) avail = full;                 /* the sample beyond the batch belongs to the next one */
+				if(avail >= p->md5_done + MD5_PIECE || (avail == full && avail > p->md5_done)) {
+					size_t n = avail - p->md5_done;
+					if(n > 16 * MD5_PIECE) n = 16 * MD5_PIECE;     /* look for a submission again every few milliseconds */
+					const uint8_t *src = p->slot[k].raw + p->md5_done * sample_bytes;
+					pthread_mutex_unlock(&p->mu);
+					const double t0 = p->timing ? now_s() : 0;
+					flacgpu_host_md5_update(&p->md5, src, n * sample_bytes);
+					if(p->timing) p->t_md5 += now_s() - t0;
+					pthread_mutex_lock(&p->mu);
+					p->md5_done += n;
+					continue;
+				}
+				k = -1;
+			}
+		}
+		else k = p->slot[0].state == 1 ? 0 : p->slot[1].state == 1 ? 1 : -1;
 		if(k < 0) {
 			if(p->worker_quit) break;
 			pthread_cond_wait(&p->cv, &p->mu);
@@ -596,6 +734,7 @@ static void *worker_main(void *arg)
 		run_batch_slot(e, &p->slot[k]);
 		pthread_mutex_lock(&p->mu);
 		p->slot[k].state = 2;
+		p->md5_slot = k ^ 1; p->md5_done = 0;
 		pthread_cond_broadcast(&p->cv);
 	}
 	pthread_mutex_unlock(&p->mu);
@@ -610,6 +749,17 @@ static void submit_slot(FLAC__StreamEncoder *e, int k, uint32_t nframes, uint32_
 	p->next_frame_number += nframes;
 	pthread_mutex_lock(&p->mu);
 	b->state = 1;
+	p->pub_slot = k ^ 1; p->pub_staged = 1; p->pub_last = 1;      /* the caller goes on in the other slot, behind the overread sample */
+	pthread_cond_broadcast(&p->cv);
+	pthread_mutex_unlock(&p->mu);
+}
+/* tell the worker how far the slot being filled has got (MD5 streams only) */
+static inline void publish_staged(FLAC__StreamEncoder *e)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	if(!PROT(e)->s.do_md5 || p->staged < p->pub_last + MD5_PIECE) return;
+	pthread_mutex_lock(&p->mu);
+	p->pub_staged = p->pub_last = p->staged;
 	pthread_cond_broadcast(&p->cv);
 	pthread_mutex_unlock(&p->mu);
 }
@@ -618,11 +768,13 @@ static int collect_slot(FLAC__StreamEncoder *e, int k)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	struct batch_slot *b = &p->slot[k];
+	double t0 = p->timing ? now_s() : 0;
 	pthread_mutex_lock(&p->mu);
 	if(b->state == 0) { pthread_mutex_unlock(&p->mu); return 1; }
 	while(b->state != 2) pthread_cond_wait(&p->cv, &p->mu);
 	b->state = 0;
 	pthread_mutex_unlock(&p->mu);
+	if(p->timing) { const double t1 = now_s(); p->t_wait += t1 - t0; t0 = t1; }
 	if(b->total < 0) {
 		fprintf(stderr, "libFLACgpu: the GPU frame engine failed: %s\n", flacgpu_strerror((int)b->total));
 		PROT(e)->state = b->total == FLACGPU_ERR_ALLOC ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
@@ -649,6 +801,7 @@ static int collect_slot(FLAC__StreamEncoder *e, int k)
 		p->streaminfo.data.stream_info.total_samples += samples;
 	}
 	p->frame_blocksize = 0;
+	if(p->timing) p->t_emit += now_s() - t0;
 	return 1;
 }
 
@@ -747,7 +900,11 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 			windows = malloc(sizeof(float) * s->num_apodizations * s->blocksize);
 			if(!windows) r = FLACGPU_ERR_ALLOC; else flacgpu_host_windows(s, s->blocksize, windows);
 		}
+		p->timing = getenv("FLACGPU_HOST_TIMING") != 0;
+		p->t_init_engine = p->t_init_pinned = p->t_stage = p->t_wait = p->t_emit = p->t_md5 = p->t_encode = p->t_release = 0;
+		p->t_start = now_s();
 		if(r == FLACGPU_OK) r = flacgpu_create(&cfg, windows, &p->gpu);
+		p->t_init_engine = now_s() - p->t_start;
 		free(windows);
 		if(r == FLACGPU_OK && s->verify) r = flacgpu_set_verify(p->gpu, 1);
 		if(r == FLACGPU_OK) {
@@ -761,6 +918,18 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 				p->slot[i].frame_bytes = malloc(sizeof(uint32_t) * p->batch_frames);
 				p->slot[i].state = 0;
 				if(!p->slot[i].raw || !p->slot[i].out || !p->slot[i].frame_bytes) r = FLACGPU_ERR_ALLOC;
+			}
+			p->t_init_pinned = now_s() - p->t_start - p->t_init_engine;
+			p->md5_slot = 0; p->md5_done = 0; p->pub_slot = 0; p->pub_staged = p->pub_last = 0;
+			if(r == FLACGPU_OK) {
+				/* helper threads for the narrowing copy of big process() calls: FLACGPU_STAGE_THREADS (the caller's thread included;
+				 * default 4, 1 = none) */
+				const char *et = getenv("FLACGPU_STAGE_THREADS");
+				long nt = et ? strtol(et, 0, 10) : 4;
+				const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+				if(nt > ncpu) nt = ncpu;
+				if(nt > STAGE_MAX_THREADS) nt = STAGE_MAX_THREADS;
+				p->pool = nt > 1 ? stage_pool_create((int)nt - 1) : 0;          /* no pool is not an error: the caller's thread does it all */
 			}
 			if(r == FLACGPU_OK) {
 				pthread_mutex_init(&p->mu, 0);
@@ -928,8 +1097,10 @@ __attribute__((target("avx2"))) static int stage16_flat_avx2(int16_t *d, const i
 {
 	__m256i vlo = _mm256_setzero_si256(), vhi = _mm256_setzero_si256();
 	size_t k = 0;
+	int32_t l = 0, h = 0;
+	if(count >= 4096) for(; ((uintptr_t)(d + k) & 31) != 0; k++) { const int32_t v = src[k]; d[k] = (int16_t)v; l = v < l ? v : l; h = v > h ? v : h; }
 	/* (the saturating pack equals truncation for every value that passes the range check; the others fail the call) */
-	if(((uintptr_t)d & 31) == 0 && count >= 4096) {
+	if(((uintptr_t)(d + k) & 31) == 0 && count >= 4096) {
 		/* the staging buffer is written once and read by the DMA engine: streaming stores spare the read-for-ownership */
 		for(; k + 16 <= count; k += 16) {
 			const __m256i a = _mm256_loadu_si256((const __m256i *)(src + k)), b = _mm256_loadu_si256((const __m256i *)(src + k + 8));
@@ -943,7 +1114,7 @@ __attribute__((target("avx2"))) static int stage16_flat_avx2(int16_t *d, const i
 		vlo = _mm256_min_epi32(vlo, _mm256_min_epi32(a, b)); vhi = _mm256_max_epi32(vhi, _mm256_max_epi32(a, b));
 		_mm256_storeu_si256((__m256i *)(d + k), _mm256_permute4x64_epi64(_mm256_packs_epi32(a, b), 0xD8));
 	}
-	int32_t lo[8], hi[8], l = 0, h = 0;
+	int32_t lo[8], hi[8];
 	_mm256_storeu_si256((__m256i *)lo, vlo); _mm256_storeu_si256((__m256i *)hi, vhi);
 	for(int i = 0; i < 8; i++) { l = lo[i] < l ? lo[i] : l; h = hi[i] > h ? hi[i] : h; }
 	for(; k < count; k++) { const int32_t v = src[k]; d[k] = (int16_t)v; l = v < l ? v : l; h = v > h ? v : h; }
@@ -966,7 +1137,7 @@ __attribute__((target("avx2"))) static int stage16_stereo_avx2(int16_t *d, const
 	for(; k < count; k++) { const int32_t a = L[k], b = R[k]; d[2 * k] = (int16_t)a; d[2 * k + 1] = (int16_t)b; l = a < l ? a : l; l = b < l ? b : l; h = a > h ? a : h; h = b > h ? b : h; }
 	return !(l < smin || h > smax);
 }
-static int have_avx2(void) { static int v = -1; if(v < 0) v = __builtin_cpu_supports("avx2") ? 1 : 0; return v; }
+static int have_avx2(void) { return __builtin_cpu_supports("avx2") ? 1 : 0; }      /* reads the flags libgcc cached at load time */
 #else
 static int have_avx2(void) { return 0; }
 #endif
@@ -1000,6 +1171,26 @@ static int stage_values(uint8_t *dst, size_t dstride, const int32_t *src, size_t
 	return !(lo < smin || hi > smax);
 }
 
+/* the two shapes of a process() call as ranges for stage_pool_run */
+struct stage_flat_args { uint8_t *dst; const int32_t *src; uint32_t width; int32_t smin, smax; };
+static int stage_flat_range(const void *a_, size_t lo, size_t hi)
+{
+	const struct stage_flat_args *a = a_;
+	return stage_values(a->dst + lo * a->width, 1, a->src + lo, 1, hi - lo, a->width, a->smin, a->smax);
+}
+struct stage_planar_args { uint8_t *dst; const int32_t * const *src; uint32_t width, channels; int32_t smin, smax; };
+static int stage_planar_range(const void *a_, size_t lo, size_t hi)
+{
+	const struct stage_planar_args *a = a_;
+	const uint32_t C = a->channels;
+#if defined(__x86_64__)
+	if(C == 2 && a->width == 2 && have_avx2()) return stage16_stereo_avx2((int16_t *)(a->dst + lo * 4), a->src[0] + lo, a->src[1] + lo, hi - lo, a->smin, a->smax);
+#endif
+	int ok = 1;
+	for(uint32_t c = 0; c < C && ok; c++) ok = stage_values(a->dst + (lo * C + c) * a->width, C, a->src[c] + lo, 1, hi - lo, a->width, a->smin, a->smax);
+	return ok;
+}
+
 FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, const FLAC__int32 buffer[], uint32_t samples)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
@@ -1011,11 +1202,16 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, cons
 	while(j < samples) {
 		size_t n = cap - p->staged;
 		if(n > samples - j) n = samples - j;
-		if(!stage_values(p->slot[p->cur].raw + p->staged * C * p->width, 1, buffer + (size_t)j * C, 1, n * C, p->width, smin, smax)) {
+		const double t0 = p->timing ? now_s() : 0;
+		const struct stage_flat_args a = { p->slot[p->cur].raw + p->staged * C * p->width, buffer + (size_t)j * C, p->width, smin, smax };
+		const int ok = stage_pool_run(p->pool, stage_flat_range, &a, n * C, 64);
+		if(p->timing) p->t_stage += now_s() - t0;
+		if(!ok) {
 			PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
 			return 0;
 		}
 		p->staged += n; j += (uint32_t)n;
+		publish_staged(e);
 		if(!release_if_full(e)) return 0;
 	}
 	return 1;
@@ -1029,22 +1225,22 @@ FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *e, const FLAC__int3
 	const int32_t smax = INT32_MAX >> (32 - bps), smin = INT32_MIN >> (32 - bps);
 	const size_t cap = (size_t)p->batch_frames * N + 1;
 	for(uint32_t c = 0; c < C; c++) if(!buffer[c]) return 0;
+	const int32_t *chan[FLACGPU_MAX_CHANNELS];
 	uint32_t j = 0;
 	while(j < samples) {
 		size_t n = cap - p->staged;
 		if(n > samples - j) n = samples - j;
-		int ok = 1;
-#if defined(__x86_64__)
-		if(C == 2 && p->width == 2 && have_avx2()) ok = stage16_stereo_avx2((int16_t *)(p->slot[p->cur].raw + p->staged * C * p->width), buffer[0] + j, buffer[1] + j, n, smin, smax);
-		else
-#endif
-		for(uint32_t c = 0; c < C && ok; c++)
-			ok = stage_values(p->slot[p->cur].raw + (p->staged * C + c) * p->width, C, buffer[c] + j, 1, n, p->width, smin, smax);
+		const double t0 = p->timing ? now_s() : 0;
+		for(uint32_t c = 0; c < C; c++) chan[c] = buffer[c] + j;
+		const struct stage_planar_args a = { p->slot[p->cur].raw + p->staged * C * p->width, chan, p->width, C, smin, smax };
+		const int ok = stage_pool_run(p->pool, stage_planar_range, &a, n, 64);
+		if(p->timing) p->t_stage += now_s() - t0;
 		if(!ok) {
 			PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
 			return 0;
 		}
 		p->staged += n; j += (uint32_t)n;
+		publish_staged(e);
 		if(!release_if_full(e)) return 0;
 	}
 	return 1;
@@ -1198,7 +1394,15 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 	}
 	if(p->file) { if(p->file != stdout) fclose(p->file); p->file = 0; }
 	if(p->is_ogg) fgh_ogg_aspect_finish(&p->ogg);
+	const int timing = p->timing;
+	const double t_rel = timing ? now_s() : 0;
 	release_engine(e);
+	if(timing) {
+		const double t1 = now_s();
+		fprintf(stderr, "libFLACgpu timing (s): total %.4f | init: engine %.4f pinned %.4f | caller: stage %.4f wait %.4f deliver %.4f | worker: md5 %.4f encode %.4f | release %.4f\n",
+		        t1 - p->t_start, p->t_init_engine, p->t_init_pinned, p->t_stage, p->t_wait, p->t_emit, p->t_md5, p->t_encode, t1 - t_rel);
+		p->timing = 0;
+	}
 	set_defaults(e);
 	if(!error) PROT(e)->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
 	return !error;

@@ -28,8 +28,11 @@ outs = {}
 for name, cmd in (("reference, 1 thread", [ref, "-8"]), ("reference, -j 8", [ref, "-8", "-j", "8"]), ("libFLACgpu", [gpu, "-8"]), ("libFLACgpu (again)", [gpu, "-8"])):
     out = "/tmp/cli_rate_%s.flac" % ("gpu" if "gpu" in name.lower() else "ref")
     t0 = time.perf_counter()
-    r = subprocess.run(cmd + ["-s", "-f", "-o", out, path], capture_output=True, text=True)
+    r = subprocess.run(cmd + ["-s", "-f", "-o", out, path], capture_output=True, text=True, env=dict(os.environ, FLACGPU_HOST_TIMING="1"))
     dt = time.perf_counter() - t0
+    for line in r.stderr.splitlines():
+        if "timing" in line:
+            print("    " + line)
     if r.returncode != 0:
         print("%-22s failed: %s" % (name, r.stderr[-300:]))
         continue

@@ -1,0 +1,164 @@
+"""The host API layer's batch pipeline on a machine without a GPU: stream_encoder.c against tests/fake_engine (a stand-in
+for libflacgpu.so that writes checkable records instead of FLAC frames -- test infrastructure, see its header).
+
+What is pinned here: frames come out in stream order, each built from exactly its own samples (narrowing copy, with and
+without the helper threads; batch boundaries and the overread sample; short last block), the STREAMINFO MD5 equals the MD5
+of the little-endian sample bytes however the chain was cut into pieces (ahead of the submissions or not), total samples and
+min/max frame size are those of the stream.  The same cases run against the real engine in tests/test_stream_encoder_api.py
+(-m gpu), where the frames are FLAC and are compared with the reference's files."""
+import hashlib
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FAKE_DIR = os.path.join(HERE, "fake_engine")
+FAKE_SO = os.path.join(FAKE_DIR, "libflacgpu.so")
+
+
+def _build():
+    src = os.path.join(FAKE_DIR, "fake_engine.c")
+    if not os.path.exists(FAKE_SO) or os.path.getmtime(FAKE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), src, "-o", FAKE_SO])
+
+
+def fnv1a(b):
+    h = 2166136261
+    for x in np.frombuffer(b, dtype=np.uint8).tolist():
+        h = ((h ^ x) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+CHILD = r'''
+import os, sys, json, hashlib
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import flac_api
+case = json.loads(sys.argv[1])
+rng = np.random.default_rng(case["seed"])
+bps, ch, n = case["bps"], case["channels"], case["samples"]
+pcm = rng.integers(-(1 << (bps - 1)), 1 << (bps - 1), size=(n, ch), dtype=np.int64).astype(np.int32)
+settings = [("set_blocksize", case["blocksize"]), ("set_do_md5", case["md5"])]
+data, sink = flac_api.encode("gpu", pcm, bps, 44100, level=5, chunk=case["chunk"], planar=case["planar"], settings=settings)
+sys.stdout.buffer.write(data)
+'''
+
+
+def run_case(case, env_extra):
+    _build()
+    import json
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = FAKE_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, json.dumps(case)], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return out.stdout
+
+
+def expected_stream(case):
+    rng = np.random.default_rng(case["seed"])
+    bps, ch, n, N = case["bps"], case["channels"], case["samples"], case["blocksize"]
+    pcm = rng.integers(-(1 << (bps - 1)), 1 << (bps - 1), size=(n, ch), dtype=np.int64).astype(np.int32)
+    w = (bps + 7) // 8
+    raw = pcm.astype("<i4").view(np.uint8).reshape(n, ch, 4)[:, :, :w].tobytes()
+    frames = []
+    for f in range((n + N - 1) // N):
+        a, b = f * N, min(n, (f + 1) * N)
+        h = fnv1a(raw[a * ch * w:b * ch * w])
+        frames.append(b"FK\0\0" + struct.pack("<III", f, b - a, h) + b"\xEE" * (f % 5))
+    return raw, frames
+
+
+def check(case, env_extra):
+    data = run_case(case, env_extra)
+    raw, frames = expected_stream(case)
+    assert data[:4] == b"fLaC"
+    assert data[4] == 0 and data[5:8] == b"\0\0\x22"                      # STREAMINFO, not last, 34 bytes
+    si = data[8:42]
+    N, n = case["blocksize"], case["samples"]
+    min_bs, max_bs = struct.unpack(">HH", si[:4])
+    assert (min_bs, max_bs) == (N, N)
+    min_fs, max_fs = int.from_bytes(si[4:7], "big"), int.from_bytes(si[7:10], "big")
+    assert (min_fs, max_fs) == (min(map(len, frames)), max(map(len, frames)))
+    packed = int.from_bytes(si[10:18], "big")
+    assert packed & ((1 << 36) - 1) == n
+    assert (packed >> 36) & 31 == case["bps"] - 1 and (packed >> 41) & 7 == case["channels"] - 1
+    assert si[18:34] == (hashlib.md5(raw).digest() if case["md5"] else bytes(16))
+    # the VORBIS_COMMENT the layer adds, then the records
+    assert data[42] == 0x84
+    vlen = int.from_bytes(data[43:46], "big")
+    body = data[46 + vlen:]
+    assert body == b"".join(frames)
+
+
+BASE = dict(seed=1, bps=16, channels=2, blocksize=256, samples=256 * 37 + 100, chunk=None, planar=False, md5=1)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 7, 64])
+@pytest.mark.parametrize("md5", [0, 1])
+def test_batches_and_md5(batch, md5):
+    check(dict(BASE, md5=md5), {"FLACGPU_BATCH_FRAMES": str(batch)})
+
+
+@pytest.mark.parametrize("chunk", [1, 255, 256, 257, 1000, [3, 5000, 17]])
+def test_chunkings(chunk):
+    check(dict(BASE, chunk=chunk, samples=256 * 9 + 255), {"FLACGPU_BATCH_FRAMES": "4"})
+
+
+@pytest.mark.parametrize("planar", [False, True])
+@pytest.mark.parametrize("bps,channels", [(8, 1), (16, 2), (24, 2), (32, 3), (16, 6)])
+def test_widths_and_layouts(planar, bps, channels):
+    check(dict(BASE, bps=bps, channels=channels, planar=planar, chunk=777), {"FLACGPU_BATCH_FRAMES": "5"})
+
+
+@pytest.mark.parametrize("threads", [1, 2, 4, 7])
+@pytest.mark.parametrize("planar", [False, True])
+def test_helper_threads_and_running_md5(threads, planar):
+    """calls big enough for the helper threads (>= 2^18 values each) and batches long enough for the MD5 chain to run ahead of
+    the submissions (pieces of 2^16 samples); the engine's pause lets the caller get ahead of the worker"""
+    N = 4096
+    case = dict(BASE, blocksize=N, samples=N * 150 + 1234, chunk=[N * 40 + 1, 200001, N * 64], planar=planar, seed=5)
+    check(case, {"FLACGPU_BATCH_FRAMES": "48", "FLACGPU_STAGE_THREADS": str(threads), "FAKE_ENGINE_DELAY_US": "3000"})
+
+
+def test_exact_multiple_and_tiny():
+    check(dict(BASE, samples=256 * 8), {"FLACGPU_BATCH_FRAMES": "4"})        # last block exactly full, batch exactly full
+    check(dict(BASE, samples=1), {"FLACGPU_BATCH_FRAMES": "4"})
+    check(dict(BASE, samples=256), {"FLACGPU_BATCH_FRAMES": "1"})
+
+
+def test_out_of_range_sample_is_refused_by_every_thread():
+    """a value outside the stream's range fails the call (stream_encoder.c:2544-2547) wherever in the call it sits"""
+    _build()
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, ctypes as C
+import flac_api
+lib = flac_api.lib_for("gpu")
+bad = 0
+for pos in (0, 100000, 262143, 300000, 524287):
+    e = lib.FLAC__stream_encoder_new()
+    lib.FLAC__stream_encoder_set_channels(e, 2); lib.FLAC__stream_encoder_set_bits_per_sample(e, 16); lib.FLAC__stream_encoder_set_sample_rate(e, 44100)
+    sink = flac_api.Sink()
+    assert lib.FLAC__stream_encoder_init_stream(e, *sink.callbacks(), None) == 0
+    pcm = np.zeros((262144, 2), dtype=np.int32)
+    pcm.reshape(-1)[pos] = 40000
+    ok = lib.FLAC__stream_encoder_process_interleaved(e, pcm.ctypes.data, len(pcm))
+    st = lib.FLAC__stream_encoder_get_state(e)
+    bad += (not ok) and st == 5                                   # FLAC__STREAM_ENCODER_CLIENT_ERROR
+    lib.FLAC__stream_encoder_finish(e); lib.FLAC__stream_encoder_delete(e)
+print(bad)
+''' % {"root": ROOT}
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = FAKE_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env["FLACGPU_STAGE_THREADS"] = "4"
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    assert out.stdout.strip() == b"5"
