@@ -4,6 +4,8 @@
 // CPU implementation behind these entry points: without a usable HIP device flacgpu_create()
 // fails with FLACGPU_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -123,6 +125,19 @@ extern "C" void *flacgpu_alloc_pinned(size_t bytes)
 	return p;
 }
 extern "C" void flacgpu_free_pinned(void *p) { if(p) (void)hipHostFree(p); }
+extern "C" int flacgpu_host_register(void *p, size_t bytes)
+{
+	if(!p || !bytes) return FLACGPU_ERR_BAD_ARG;
+	return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? FLACGPU_OK : FLACGPU_ERR_ALLOC;
+}
+extern "C" void flacgpu_host_unregister(void *p) { if(p) (void)hipHostUnregister(p); }
+extern "C" int flacgpu_device_probe(void)
+{
+	const int fd = open("/dev/kfd", O_RDWR | O_CLOEXEC);
+	if(fd < 0) return 0;
+	close(fd);
+	return 1;
+}
 
 extern "C" const char *flacgpu_strerror(int code)
 {
@@ -185,11 +200,18 @@ static void free_ctx(flacgpu_ctx *c)
 	delete c;
 }
 
-extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, flacgpu_ctx **out)
+// worst-case frame: header + per channel (verbatim size + Rice estimate slack of N/2 bits + side info), a multiple of 16
+static uint64_t worst_case_frame_bytes(uint32_t C, uint32_t N, uint32_t bps)
 {
-	if(!cfg || !out || cfg->abi_version != FLACGPU_ABI_VERSION) return FLACGPU_ERR_BAD_ARG;
-	*out = nullptr;
-	// ---- supported range (everything else is a documented, loud failure; no CPU fallback) ----
+	const uint64_t per_ch_bits = (uint64_t)N * (bps + 1) + N / 2 + 8 + 32 + 16 * 33 + 9 + 6 + 5 * (1u << MAX_PO);
+	const uint64_t bytes = 16 + C * ((per_ch_bits + 7) / 8) + 2 + 16;
+	return (bytes + 15) & ~(uint64_t)15;
+}
+
+// ---- supported range (everything else is a documented, loud failure; no CPU fallback) ----
+static int check_config(const flacgpu_config *cfg)
+{
+	if(!cfg || cfg->abi_version != FLACGPU_ABI_VERSION) return FLACGPU_ERR_BAD_ARG;
 	if(cfg->channels < 1 || cfg->channels > FLACGPU_MAX_CHANNELS) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->bits_per_sample < 4 || cfg->bits_per_sample > 32) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->blocksize < 16 || cfg->blocksize > 65535) return FLACGPU_ERR_UNSUPPORTED;          // FLAC__MAX_BLOCK_SIZE
@@ -197,22 +219,16 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	if(cfg->max_lpc_order > 0 && (cfg->qlp_coeff_precision < 5 || cfg->qlp_coeff_precision > 15)) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->max_residual_partition_order > MAX_PO) return FLACGPU_ERR_UNSUPPORTED;
 	if(cfg->max_lpc_order > 0 && (cfg->num_apodizations < 1 || cfg->num_apodizations > FLACGPU_MAX_APODIZATIONS)) return FLACGPU_ERR_UNSUPPORTED;
-	if(cfg->max_lpc_order > 0 && !windows) return FLACGPU_ERR_BAD_ARG;
 	if(cfg->max_batch_frames < 1) return FLACGPU_ERR_BAD_ARG;
 	for(uint32_t a = 0; a < cfg->num_apodizations && cfg->max_lpc_order > 0; a++)
 		if(cfg->apodizations[a].kind == FLACGPU_APOD_SUBDIVIDE_TUKEY && cfg->apodizations[a].parts < 2) return FLACGPU_ERR_BAD_ARG;
+	return FLACGPU_OK;
+}
 
-	int ndev = 0;
-	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return FLACGPU_ERR_NO_DEVICE;
-	if(hipSetDevice(cfg->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
-
-	flacgpu_ctx *c = new(std::nothrow) flacgpu_ctx();
-	if(!c) return FLACGPU_ERR_ALLOC;
-	memset(c, 0, sizeof *c);
-	c->cfg = *cfg;
-	c->device = cfg->device;
-
-	DevParams &P = c->P;
+// the kernels' view of a (range-checked) configuration; UNSUPPORTED for what does not fit the engine's tables or the LDS
+static int fill_params(const flacgpu_config *cfg, DevParams &P, JobTable *jobtab)
+{
+	memset(&P, 0, sizeof P);
 	const uint32_t C = cfg->channels, N = cfg->blocksize, bps = cfg->bits_per_sample;
 	P.channels = C; P.bps = bps; P.sample_rate = cfg->sample_rate; P.blocksize = N;
 	// stream_encoder.c:737-741: mid/side only for stereo; loose only with mid/side
@@ -233,12 +249,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	P.autoc_variant = cfg->max_lpc_order < 8 ? 8u : cfg->max_lpc_order < 12 ? 12u : cfg->max_lpc_order < 16 ? 16u : 0u;
 	P.disable_constant = cfg->disable_constant_subframes; P.disable_fixed = cfg->disable_fixed_subframes;
 	P.disable_verbatim = cfg->disable_verbatim_subframes; P.limit_min_bitrate = cfg->limit_min_bitrate;
-	// worst-case frame: header + per channel (verbatim size + Rice estimate slack of N/2 bits + side info)
-	{
-		const uint64_t per_ch_bits = (uint64_t)N * (bps + 1) + N / 2 + 8 + 32 + 16 * 33 + 9 + 6 + 5 * (1u << MAX_PO);
-		uint64_t bytes = 16 + C * ((per_ch_bits + 7) / 8) + 2 + 16;
-		P.slot_bytes = (uint32_t)((bytes + 15) & ~(uint64_t)15);
-	}
+	P.slot_bytes = (uint32_t)worst_case_frame_bytes(C, N, bps);
 	{
 		const uint32_t maxidx = 32 + ((N + 15u) & ~15u) + 16u + 16u;
 		P.sig_bytes = ((maxidx + ((maxidx >> 4) << 1) + 8) * 4 + 15) & ~15u;
@@ -251,8 +262,8 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 			if(P.apod_kind[a] == FLACGPU_APOD_SUBDIVIDE_TUKEY)
 				for(uint32_t b = 2; b <= P.apod_parts[a]; b++) { if(N / b <= 32) continue; nj += b; na += b >= 3 ? 2 * b : b; }
 		}
-		if(nj > (uint32_t)MAX_JOBS || na > (uint32_t)MAX_ANALYSES) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
-		build_job_table(P, N, &c->h_jobtab[0]);
+		if(nj > (uint32_t)MAX_JOBS || na > (uint32_t)MAX_ANALYSES) return FLACGPU_ERR_UNSUPPORTED;
+		build_job_table(P, N, jobtab);
 		P.max_jobs = nj ? nj : 1; P.max_analyses = na;
 		P.exhaustive = cfg->do_exhaustive_model_search ? 1 : 0;
 		P.prec_search = cfg->do_qlp_coeff_prec_search && cfg->max_lpc_order > 0 ? 1 : 0;
@@ -265,8 +276,44 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	P.tune_flags = getenv("FLACGPU_EVAL_CANDS_GLOBAL") ? 1u : 0u;
 	if(N > 16384 || analyze_lds_bytes(P) > 160 * 1024 - 1024) { P.stream_sig = 1; P.sig_bytes = 0; }     // the block does not fit the LDS: the general kernels read HBM
 	if(pack_lds_bytes(P) > 160 * 1024 - 1024) P.img_global = 1;            // many channels x long blocks: the frame is assembled in HBM
-	if((uint64_t)P.slot_bytes > (uint64_t)4 * 1024 * 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }      // CRC span table (flacgpu_kernels.hip)
-	if(analyze_lds_bytes(P) > 160 * 1024 - 1024 || pack_lds_bytes(P) > 160 * 1024 - 1024) { delete c; return FLACGPU_ERR_UNSUPPORTED; }
+	if((uint64_t)P.slot_bytes > (uint64_t)4 * 1024 * 1024) return FLACGPU_ERR_UNSUPPORTED;      // CRC span table (flacgpu_kernels.hip)
+	if(analyze_lds_bytes(P) > 160 * 1024 - 1024 || pack_lds_bytes(P) > 160 * 1024 - 1024) return FLACGPU_ERR_UNSUPPORTED;
+	return FLACGPU_OK;
+}
+
+extern "C" int flacgpu_config_check(const flacgpu_config *cfg)
+{
+	int r = check_config(cfg);
+	if(r != FLACGPU_OK) return r;
+	DevParams P;
+	JobTable *jt = new(std::nothrow) JobTable;
+	if(!jt) return FLACGPU_ERR_ALLOC;
+	r = fill_params(cfg, P, jt);
+	delete jt;
+	return r;
+}
+
+extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, flacgpu_ctx **out)
+{
+	if(!out) return FLACGPU_ERR_BAD_ARG;
+	*out = nullptr;
+	int r = check_config(cfg);
+	if(r != FLACGPU_OK) return r;
+	if(cfg->max_lpc_order > 0 && !windows) return FLACGPU_ERR_BAD_ARG;
+
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return FLACGPU_ERR_NO_DEVICE;
+	if(hipSetDevice(cfg->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+
+	flacgpu_ctx *c = new(std::nothrow) flacgpu_ctx();
+	if(!c) return FLACGPU_ERR_ALLOC;
+	memset(c, 0, sizeof *c);
+	c->cfg = *cfg;
+	c->device = cfg->device;
+	r = fill_params(cfg, c->P, &c->h_jobtab[0]);
+	if(r != FLACGPU_OK) { delete c; return r; }
+	DevParams &P = c->P;
+	const uint32_t N = cfg->blocksize;
 
 	bool ok = true;
 	ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -315,6 +362,10 @@ extern "C" void flacgpu_destroy(flacgpu_ctx *ctx) { free_ctx(ctx); }
 extern "C" size_t flacgpu_max_output_bytes(const flacgpu_ctx *ctx, uint32_t nframes)
 {
 	return ctx ? (size_t)nframes * ctx->P.slot_bytes : 0;
+}
+extern "C" size_t flacgpu_config_max_output_bytes(const flacgpu_config *cfg, uint32_t nframes)
+{
+	return cfg ? (size_t)nframes * (size_t)worst_case_frame_bytes(cfg->channels, cfg->blocksize, cfg->bits_per_sample) : 0;
 }
 
 static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uint64_t first, uint32_t tail_n,

@@ -125,6 +125,18 @@ struct FLAC__StreamEncoderPrivate {
 	size_t md5_done;                          /* inter-channel samples of that batch already hashed */
 	int pub_slot; size_t pub_staged, pub_last;
 	struct stage_pool *pool;                  /* helper threads of the narrowing copy (big process() calls only) */
+	/* Bring-up.  Starting the HIP runtime, creating the engine and page-locking the slots takes a fresh process 0.2-0.3 s -- as
+	 * long as a 30-minute stream then takes to encode -- so init_*() hands it to a thread of its own and returns; the caller
+	 * stages into the (not yet page-locked) slots and the worker runs the MD5 chain meanwhile, and the first batch waits for the
+	 * engine.  A failure after init_*() has returned surfaces as a failed process()/finish() with an error state and a message
+	 * on stderr.  When the device node is missing, or with FLACGPU_SYNC_INIT=1, bring-up runs inside init_*() and fails there. */
+	int engine_on;                            /* init_*() succeeded and finish() has not run yet */
+	pthread_t bring_th;
+	int bring_started, bring_done, bring_result;
+	flacgpu_config bring_cfg;
+	size_t raw_bytes;
+	int registered[4];
+	double t_bring_wait;
 	/* FLACGPU_HOST_TIMING=1: where a stream's wall time went, printed by finish() */
 	int timing;
 	double t_init_engine, t_init_pinned, t_stage, t_wait, t_emit, t_md5, t_encode, t_release, t_start;
@@ -263,6 +275,7 @@ static int stage_pool_run(struct stage_pool *sp, int (*fn)(const void *, size_t,
 static void release_engine(FLAC__StreamEncoder *e)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	if(p->bring_started) { pthread_join(p->bring_th, 0); p->bring_started = 0; }
 	if(p->worker_started) {
 		pthread_mutex_lock(&p->mu);
 		p->worker_quit = 1;
@@ -274,13 +287,17 @@ static void release_engine(FLAC__StreamEncoder *e)
 		p->worker_started = 0; p->worker_quit = 0;
 	}
 	stage_pool_destroy(p->pool); p->pool = 0;
-	if(p->gpu) { flacgpu_destroy(p->gpu); p->gpu = 0; }
 	for(int i = 0; i < 2; i++) {
-		if(p->slot[i].raw) { flacgpu_free_pinned(p->slot[i].raw); p->slot[i].raw = 0; }
-		if(p->slot[i].out) { flacgpu_free_pinned(p->slot[i].out); p->slot[i].out = 0; }
+		if(p->registered[2 * i]) flacgpu_host_unregister(p->slot[i].raw);
+		if(p->registered[2 * i + 1]) flacgpu_host_unregister(p->slot[i].out);
+		p->registered[2 * i] = p->registered[2 * i + 1] = 0;
+		free(p->slot[i].raw); p->slot[i].raw = 0;
+		free(p->slot[i].out); p->slot[i].out = 0;
 		free(p->slot[i].frame_bytes); p->slot[i].frame_bytes = 0;
 		p->slot[i].state = 0;
 	}
+	if(p->gpu) { flacgpu_destroy(p->gpu); p->gpu = 0; }
+	p->engine_on = 0; p->bring_done = 0;
 	p->out_cap = 0;
 	free(p->tail_windows); p->tail_windows = 0;
 	p->staged = 0; p->cur = 0;
@@ -673,6 +690,11 @@ static void run_batch_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
 	double t0 = p->timing ? now_s() : 0;
 	if(s->do_md5 && nsamp > p->md5_done) flacgpu_host_md5_update(&p->md5, b->raw + p->md5_done * C * p->width, (nsamp - p->md5_done) * C * p->width);   /* what the chain had not reached yet */
 	if(p->timing) { const double t1 = now_s(); p->t_md5 += t1 - t0; t0 = t1; }
+	pthread_mutex_lock(&p->mu);
+	while(!p->bring_done) pthread_cond_wait(&p->cv, &p->mu);
+	pthread_mutex_unlock(&p->mu);
+	if(p->timing) { const double t1 = now_s(); p->t_bring_wait += t1 - t0; t0 = t1; }
+	if(p->bring_result != FLACGPU_OK) { b->total = p->bring_result; return; }
 	const float *tw = 0;
 	if(b->tail && s->max_lpc_order > 0) {
 		/* windows are recomputed for the short block, as resize_buffers_ does at finish (:1703-1711) */
@@ -694,6 +716,41 @@ static void run_batch_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
 		b->vres.absolute_sample = v.absolute_sample; b->vres.expected = v.expected; b->vres.got = v.got;
 	}
 }
+/* HIP runtime, engine, page-locked slots: on a thread of its own (see bring_* in the private struct), or inside init_*() */
+static void *bringup_main(void *arg)
+{
+	FLAC__StreamEncoder *e = arg;
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	const flacgpu_host_settings *s = &PROT(e)->s;
+	const double t0 = now_s();
+	flacgpu_ctx *gpu = 0;
+	int r = FLACGPU_OK;
+	float *windows = 0;
+	if(s->max_lpc_order > 0) {
+		windows = malloc(sizeof(float) * s->num_apodizations * s->blocksize);
+		if(!windows) r = FLACGPU_ERR_ALLOC; else flacgpu_host_windows(s, s->blocksize, windows);
+	}
+	if(r == FLACGPU_OK) r = flacgpu_create(&p->bring_cfg, windows, &gpu);
+	free(windows);
+	if(r == FLACGPU_OK && s->verify) r = flacgpu_set_verify(gpu, 1);
+	const double t1 = now_s();
+	if(r == FLACGPU_OK)
+		for(int i = 0; i < 2; i++) {        /* a slot that cannot be page-locked still works: its copies are staged by the runtime */
+			p->registered[2 * i] = flacgpu_host_register(p->slot[i].raw, p->raw_bytes) == FLACGPU_OK;
+			p->registered[2 * i + 1] = flacgpu_host_register(p->slot[i].out, p->out_cap) == FLACGPU_OK;
+		}
+	if(r != FLACGPU_OK) {
+		fprintf(stderr, "libFLACgpu: cannot create the GPU frame engine: %s\n", flacgpu_strerror(r));
+		if(gpu) { flacgpu_destroy(gpu); gpu = 0; }
+	}
+	p->t_init_engine = t1 - t0; p->t_init_pinned = now_s() - t1;
+	pthread_mutex_lock(&p->mu);
+	p->gpu = gpu; p->bring_result = r; p->bring_done = 1;
+	pthread_cond_broadcast(&p->cv);
+	pthread_mutex_unlock(&p->mu);
+	return 0;
+}
+
 static void *worker_main(void *arg)
 {
 	FLAC__StreamEncoder *e = arg;
@@ -870,15 +927,17 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 	/* the GPU engine; features it does not implement are refused, never approximated */
 	{
 		/* Blocks per GPU batch: FLACGPU_BATCH_FRAMES, or what a budget of staged sample bytes per slot buys (FLACGPU_BATCH_BYTES,
-		 * default 64 MiB: 4096 blocks of 16-bit stereo at 4096 samples, 30 of 8 x 32-bit x 65535) -- two pinned input slots of
-		 * that size and two output slots exist per encoder -- and never more than the stream is said to hold.  No frame is
-		 * delivered before its batch is full or finish() is called: INTEGRATION.md, "output latency". */
+		 * default 16 MiB: 1024 blocks of 16-bit stereo at 4096 samples, 7 of 8 x 32-bit x 65535) -- two page-locked input slots of
+		 * that size and two output slots exist per encoder -- and never more than the stream is said to hold.  Measured on one
+		 * 16-bit stereo stream: page-locking and releasing the slots costs more than bigger batches win back on the GPU, which is
+		 * an order of magnitude ahead of the host either way (64 MiB: 0.88 G samples/s, 16 MiB: 1.37 G).  No frame is delivered
+		 * before its batch is full or finish() is called: INTEGRATION.md, "output latency". */
 		const char *env = getenv("FLACGPU_BATCH_FRAMES");
 		long bf;
 		if(env) bf = strtol(env, 0, 10);
 		else {
 			const char *eb = getenv("FLACGPU_BATCH_BYTES");
-			const double budget = eb ? strtod(eb, 0) : 64.0 * 1024 * 1024;
+			const double budget = eb ? strtod(eb, 0) : 16.0 * 1024 * 1024;
 			const double per_block = (double)s->blocksize * s->channels * ((s->bits_per_sample + 7) / 8);
 			bf = (long)(budget / per_block);
 			if(bf > 16384) bf = 16384;
@@ -893,51 +952,60 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 		memset(&p->verify_stats, 0, sizeof p->verify_stats);
 		env = getenv("FLACGPU_DEVICE");
 		const int device = env ? atoi(env) : 0;
-		flacgpu_config cfg;
-		int r = flacgpu_host_engine_config(s, device, p->batch_frames, &cfg);
-		float *windows = 0;
-		if(r == FLACGPU_OK && s->max_lpc_order > 0) {
-			windows = malloc(sizeof(float) * s->num_apodizations * s->blocksize);
-			if(!windows) r = FLACGPU_ERR_ALLOC; else flacgpu_host_windows(s, s->blocksize, windows);
-		}
 		p->timing = getenv("FLACGPU_HOST_TIMING") != 0;
-		p->t_init_engine = p->t_init_pinned = p->t_stage = p->t_wait = p->t_emit = p->t_md5 = p->t_encode = p->t_release = 0;
+		p->t_init_engine = p->t_init_pinned = p->t_stage = p->t_wait = p->t_emit = p->t_md5 = p->t_encode = p->t_release = p->t_bring_wait = 0;
 		p->t_start = now_s();
-		if(r == FLACGPU_OK) r = flacgpu_create(&cfg, windows, &p->gpu);
-		p->t_init_engine = now_s() - p->t_start;
-		free(windows);
-		if(r == FLACGPU_OK && s->verify) r = flacgpu_set_verify(p->gpu, 1);
+		int r = flacgpu_host_engine_config(s, device, p->batch_frames, &p->bring_cfg);
+		if(r == FLACGPU_OK) r = flacgpu_config_check(&p->bring_cfg);       /* what the engine refuses, it refuses here, not on the bring-up thread */
 		if(r == FLACGPU_OK) {
 			p->width = (s->bits_per_sample + 7) / 8;
 			memset(&p->rawfmt, 0, sizeof p->rawfmt);
 			p->rawfmt.container_bits = 8 * p->width;            /* little endian, signed, right-justified */
-			p->out_cap = flacgpu_max_output_bytes(p->gpu, p->batch_frames);
+			p->out_cap = flacgpu_config_max_output_bytes(&p->bring_cfg, p->batch_frames);
+			p->raw_bytes = (size_t)p->width * s->channels * ((size_t)p->batch_frames * s->blocksize + 1);
 			for(int i = 0; i < 2; i++) {
-				p->slot[i].raw = flacgpu_alloc_pinned((size_t)p->width * s->channels * ((size_t)p->batch_frames * s->blocksize + 1));
-				p->slot[i].out = flacgpu_alloc_pinned(p->out_cap);
+				void *a = 0, *b = 0;
+				if(posix_memalign(&a, 4096, p->raw_bytes) != 0) a = 0;
+				if(posix_memalign(&b, 4096, p->out_cap) != 0) b = 0;
+				p->slot[i].raw = a; p->slot[i].out = b;
 				p->slot[i].frame_bytes = malloc(sizeof(uint32_t) * p->batch_frames);
 				p->slot[i].state = 0;
+				p->registered[2 * i] = p->registered[2 * i + 1] = 0;
 				if(!p->slot[i].raw || !p->slot[i].out || !p->slot[i].frame_bytes) r = FLACGPU_ERR_ALLOC;
 			}
-			p->t_init_pinned = now_s() - p->t_start - p->t_init_engine;
-			p->md5_slot = 0; p->md5_done = 0; p->pub_slot = 0; p->pub_staged = p->pub_last = 0;
-			if(r == FLACGPU_OK) {
-				/* helper threads for the narrowing copy of big process() calls: FLACGPU_STAGE_THREADS (the caller's thread included;
-				 * default 4, 1 = none) */
-				const char *et = getenv("FLACGPU_STAGE_THREADS");
-				long nt = et ? strtol(et, 0, 10) : 4;
-				const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-				if(nt > ncpu) nt = ncpu;
-				if(nt > STAGE_MAX_THREADS) nt = STAGE_MAX_THREADS;
-				p->pool = nt > 1 ? stage_pool_create((int)nt - 1) : 0;          /* no pool is not an error: the caller's thread does it all */
+		}
+		p->md5_slot = 0; p->md5_done = 0; p->pub_slot = 0; p->pub_staged = p->pub_last = 0;
+		p->bring_started = 0; p->bring_done = 0; p->bring_result = FLACGPU_OK;
+		if(r == FLACGPU_OK) {
+			pthread_mutex_init(&p->mu, 0);
+			pthread_cond_init(&p->cv, 0);
+			p->worker_quit = 0;
+			if(pthread_create(&p->worker, 0, worker_main, e) == 0) p->worker_started = 1;
+			else { pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv); r = FLACGPU_ERR_ALLOC; }
+		}
+		if(r == FLACGPU_OK) {
+			/* on its own thread when a device node is there to be opened; otherwise here, so that the error is init's */
+			const char *es = getenv("FLACGPU_SYNC_INIT");
+			const int async = !(es && atoi(es)) && flacgpu_device_probe();
+			if(async && pthread_create(&p->bring_th, 0, bringup_main, e) == 0) p->bring_started = 1;
+			else {
+				bringup_main(e);
+				r = p->bring_result;
+				if(r != FLACGPU_OK) {          /* (bringup_main has said why) */
+					release_engine(e);
+					PROT(e)->state = r == FLACGPU_ERR_ALLOC ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+					return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+				}
 			}
-			if(r == FLACGPU_OK) {
-				pthread_mutex_init(&p->mu, 0);
-				pthread_cond_init(&p->cv, 0);
-				p->worker_quit = 0;
-				if(pthread_create(&p->worker, 0, worker_main, e) == 0) p->worker_started = 1;
-				else { pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv); r = FLACGPU_ERR_ALLOC; }
-			}
+			/* helper threads for the narrowing copy of big process() calls: FLACGPU_STAGE_THREADS (the caller's thread included;
+			 * default 4, 1 = none) */
+			const char *et = getenv("FLACGPU_STAGE_THREADS");
+			long nt = et ? strtol(et, 0, 10) : 4;
+			const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+			if(nt > ncpu) nt = ncpu;
+			if(nt > STAGE_MAX_THREADS) nt = STAGE_MAX_THREADS;
+			p->pool = nt > 1 ? stage_pool_create((int)nt - 1) : 0;          /* no pool is not an error: the caller's thread does it all */
+			p->engine_on = 1;
 		}
 		if(r != FLACGPU_OK) {
 			fprintf(stderr, "libFLACgpu: cannot create the GPU frame engine: %s\n", flacgpu_strerror(r));
@@ -1362,7 +1430,7 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 		if(p->file) { if(p->file != stdout) fclose(p->file); p->file = 0; }
 		return 1;
 	}
-	if(PROT(e)->state == FLAC__STREAM_ENCODER_OK && !p->is_being_deleted && p->gpu) {
+	if(PROT(e)->state == FLAC__STREAM_ENCODER_OK && !p->is_being_deleted && p->engine_on) {
 		/* the batch in flight, then everything still staged: full blocks and the final one (short, or exactly full) */
 		if(!collect_slot(e, p->cur ^ 1)) error = 1;
 		if(!error && p->staged) {
@@ -1383,7 +1451,7 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 		while(p->slot[0].state == 1 || p->slot[1].state == 1) pthread_cond_wait(&p->cv, &p->mu);
 		pthread_mutex_unlock(&p->mu);
 	}
-	if(PROT(e)->s.do_md5 && p->gpu) flacgpu_host_md5_final(&p->md5, p->streaminfo.data.stream_info.md5sum);
+	if(PROT(e)->s.do_md5 && p->engine_on) flacgpu_host_md5_final(&p->md5, p->streaminfo.data.stream_info.md5sum);
 	if(!p->is_being_deleted && PROT(e)->state == FLAC__STREAM_ENCODER_OK) {
 		p->current_frame_number = 0;
 		if(p->seek_cb) {
@@ -1399,8 +1467,8 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 	release_engine(e);
 	if(timing) {
 		const double t1 = now_s();
-		fprintf(stderr, "libFLACgpu timing (s): total %.4f | init: engine %.4f pinned %.4f | caller: stage %.4f wait %.4f deliver %.4f | worker: md5 %.4f encode %.4f | release %.4f\n",
-		        t1 - p->t_start, p->t_init_engine, p->t_init_pinned, p->t_stage, p->t_wait, p->t_emit, p->t_md5, p->t_encode, t1 - t_rel);
+		fprintf(stderr, "libFLACgpu timing (s): total %.4f | init: engine %.4f pinned %.4f | caller: stage %.4f wait %.4f deliver %.4f | worker: md5 %.4f wait-for-engine %.4f encode %.4f | release %.4f\n",
+		        t1 - p->t_start, p->t_init_engine, p->t_init_pinned, p->t_stage, p->t_wait, p->t_emit, p->t_md5, p->t_bring_wait, p->t_encode, t1 - t_rel);
 		p->timing = 0;
 	}
 	set_defaults(e);

@@ -197,6 +197,18 @@ int flacgpu_set_subbatches(flacgpu_ctx *ctx, uint32_t n);
  * at full PCIe rate and asynchronously).  NULL when no device/runtime is available. */
 void *flacgpu_alloc_pinned(size_t bytes);
 void flacgpu_free_pinned(void *p);
+/* The same for memory the caller already owns (page-locks it in place; contents untouched, writers may carry on).  The host API
+ * layer fills ordinary memory while the HIP runtime is still starting on another thread and registers it afterwards. */
+int flacgpu_host_register(void *p, size_t bytes);
+void flacgpu_host_unregister(void *p);
+/* The configuration checks of flacgpu_create without a device: FLACGPU_OK, or the FLACGPU_ERR_UNSUPPORTED / _BAD_ARG that
+ * flacgpu_create would return for this configuration.  Touches no HIP state. */
+int flacgpu_config_check(const flacgpu_config *cfg);
+/* flacgpu_max_output_bytes() before an engine exists: the same worst case from the configuration alone (0: cfg is NULL). */
+size_t flacgpu_config_max_output_bytes(const flacgpu_config *cfg, uint32_t nframes);
+/* 1 when the kernel driver's device node can be opened by this process -- a cheap hint that flacgpu_create may succeed, taken
+ * WITHOUT starting the HIP runtime (which costs a fresh process 0.1-0.2 s); 0 means flacgpu_create will report NO_DEVICE. */
+int flacgpu_device_probe(void);
 
 /* Test hook (tests/test_log_pin.py): evaluates on the device, for n host arguments, mode 0 the engine's log (glibc 2.35's
  * algorithm restated, flac_amd/csrc/flacgpu_log.h), mode 1 the expected-bits expression of lpc.c:1591-1606 on

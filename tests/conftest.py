@@ -24,6 +24,23 @@ def pytest_configure(config):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "flac_amd", "csrc")])
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first():
+    """Load torch's HIP runtime before libflacgpu.so loads one.  The torch wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7, asked for by libtorch_hip as plain "libamdhip64.so"); libflacgpu.so asks for libamdhip64.so.7.  With torch
+    first, the loader satisfies our request with torch's copy -- one runtime in the process.  With ours first (the system's
+    /opt/rocm copy), torch's request does not match the loaded SONAME and a SECOND runtime is mapped; its device enumeration
+    then answered "No HIP GPUs are available" on some boxes (seen when a test file was run on its own, never in a full run,
+    where an earlier test imports torch first).  bench.py and flac_amd/corpus.py import torch at the top for the same reason."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:            # no torch, no GPU: the CPU tests do not care
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def ref():
     from oracle import pyoracle as po

@@ -15,10 +15,17 @@
 
 struct flacgpu_ctx { flacgpu_config cfg; uint32_t verify; };
 
+static void pause_us(const char *env)
+{
+	const char *d = getenv(env);
+	if(d) { struct timespec ts = {atol(d) / 1000000, 1000L * (atol(d) % 1000000)}; nanosleep(&ts, 0); }
+}
 int flacgpu_create(const flacgpu_config *cfg, const float *windows, flacgpu_ctx **out)
 {
 	(void)windows;
 	if(!cfg || !out || cfg->abi_version != FLACGPU_ABI_VERSION) return FLACGPU_ERR_BAD_ARG;
+	pause_us("FAKE_ENGINE_CREATE_DELAY_US");                      /* a fresh process spends 0.1-0.2 s here on the real thing */
+	if(getenv("FAKE_ENGINE_FAIL_CREATE")) return FLACGPU_ERR_NO_DEVICE;
 	flacgpu_ctx *c = calloc(1, sizeof *c);
 	if(!c) return FLACGPU_ERR_ALLOC;
 	c->cfg = *cfg;
@@ -29,6 +36,11 @@ void flacgpu_destroy(flacgpu_ctx *ctx) { free(ctx); }
 size_t flacgpu_max_output_bytes(const flacgpu_ctx *ctx, uint32_t nframes) { (void)ctx; return (size_t)nframes * 32; }
 void *flacgpu_alloc_pinned(size_t bytes) { void *p = 0; if(posix_memalign(&p, 4096, bytes ? bytes : 1) != 0) return 0; memset(p, 0, bytes); return p; }   /* touched, as page-locked memory is */
 void flacgpu_free_pinned(void *p) { free(p); }
+int flacgpu_host_register(void *p, size_t bytes) { (void)p; (void)bytes; return getenv("FAKE_ENGINE_FAIL_REGISTER") ? FLACGPU_ERR_ALLOC : FLACGPU_OK; }
+void flacgpu_host_unregister(void *p) { (void)p; }
+int flacgpu_device_probe(void) { return getenv("FAKE_ENGINE_NO_PROBE") ? 0 : 1; }
+int flacgpu_config_check(const flacgpu_config *cfg) { return cfg && cfg->abi_version == FLACGPU_ABI_VERSION ? FLACGPU_OK : FLACGPU_ERR_BAD_ARG; }
+size_t flacgpu_config_max_output_bytes(const flacgpu_config *cfg, uint32_t nframes) { (void)cfg; return (size_t)nframes * 32; }
 const char *flacgpu_strerror(int code) { (void)code; return "fake engine"; }
 int flacgpu_set_verify(flacgpu_ctx *ctx, uint32_t on) { ctx->verify = on; return FLACGPU_OK; }
 int flacgpu_last_verify_result(flacgpu_ctx *ctx, flacgpu_verify_result *out) { (void)ctx; memset(out, 0, sizeof *out); return FLACGPU_OK; }
@@ -42,8 +54,7 @@ int64_t flacgpu_encode_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgp
 	const uint8_t *p = raw;
 	size_t total = 0;
 	/* a GPU batch takes a few milliseconds: leave the other threads time to run ahead (FAKE_ENGINE_DELAY_US) */
-	const char *d = getenv("FAKE_ENGINE_DELAY_US");
-	if(d) { struct timespec ts = {0, 1000L * atol(d)}; nanosleep(&ts, 0); }
+	pause_us("FAKE_ENGINE_DELAY_US");
 	for(uint32_t f = 0; f < nframes; f++) {
 		const uint32_t n = (f + 1 == nframes && last_block_samples) ? last_block_samples : N;
 		const size_t bytes = (size_t)n * C * w;

@@ -162,3 +162,70 @@ print(bad)
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     assert out.stdout.strip() == b"5"
+
+
+# ---- bring-up on its own thread (HIP runtime + engine + page-locking while the caller already stages) -------------------
+def test_slow_bring_up_changes_nothing():
+    """the engine appears 0.3 s after init returned: the caller has staged several batches by then, the MD5 chain ran ahead"""
+    N = 4096
+    case = dict(BASE, blocksize=N, samples=N * 100 + 17, chunk=N * 10, seed=8)
+    check(case, {"FLACGPU_BATCH_FRAMES": "16", "FAKE_ENGINE_CREATE_DELAY_US": "300000"})
+    check(case, {"FLACGPU_BATCH_FRAMES": "16", "FAKE_ENGINE_CREATE_DELAY_US": "100000", "FLACGPU_SYNC_INIT": "1"})
+    check(case, {"FLACGPU_BATCH_FRAMES": "16", "FAKE_ENGINE_FAIL_REGISTER": "1"})          # slots that cannot be page-locked still work
+
+
+FAIL_CHILD = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import flac_api
+lib = flac_api.lib_for("gpu")
+e = lib.FLAC__stream_encoder_new()
+lib.FLAC__stream_encoder_set_channels(e, 2); lib.FLAC__stream_encoder_set_bits_per_sample(e, 16); lib.FLAC__stream_encoder_set_sample_rate(e, 44100)
+sink = flac_api.Sink()
+st = lib.FLAC__stream_encoder_init_stream(e, *sink.callbacks(), None)
+state_after_init = lib.FLAC__stream_encoder_get_state(e)
+ok_process = ok_finish = None
+if st == 0 and sys.argv[1] == "encode":
+    pcm = np.zeros((4096 * 40, 2), dtype=np.int32)
+    ok_process = bool(lib.FLAC__stream_encoder_process_interleaved(e, pcm.ctypes.data, len(pcm)))
+    state_after_process = lib.FLAC__stream_encoder_get_state(e)
+    ok_finish = bool(lib.FLAC__stream_encoder_finish(e))
+    print(st, state_after_init, ok_process, state_after_process, ok_finish)
+else:
+    print(st, state_after_init)
+lib.FLAC__stream_encoder_delete(e)            # with the bring-up thread possibly still in flight
+'''
+
+
+def _fail_child(mode, env_extra):
+    _build()
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = FAKE_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", FAIL_CHILD % {"root": ROOT}, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return out.stdout.decode().split(), out.stderr.decode()
+
+
+def test_engine_failure_is_loud_wherever_it_surfaces():
+    # no device node, or synchronous bring-up asked for: init itself fails (ENCODER_ERROR = 1) with an error state
+    for env in ({"FAKE_ENGINE_FAIL_CREATE": "1", "FAKE_ENGINE_NO_PROBE": "1"}, {"FAKE_ENGINE_FAIL_CREATE": "1", "FLACGPU_SYNC_INIT": "1"}):
+        out, err = _fail_child("encode", env)
+        assert out[0] == "1" and out[1] != "0" and "cannot create the GPU frame engine" in err
+    # a device node that opens but an engine that does not come up: init has returned OK by then; the first call that needs a
+    # frame fails, the state is an error state, stderr says why -- and nothing was written beyond the metadata
+    out, err = _fail_child("encode", {"FAKE_ENGINE_FAIL_CREATE": "1", "FLACGPU_BATCH_FRAMES": "8", "FAKE_ENGINE_CREATE_DELAY_US": "50000"})
+    st, s_init, ok_process, s_proc, ok_finish = out
+    assert st == "0" and s_init == "0"
+    assert ok_process == "False" and s_proc != "0" and "cannot create the GPU frame engine" in err
+    assert ok_finish == "True"               # the reference's rule: finish() after a failed process() has nothing left to fail (:1649)
+    # a stream shorter than one batch meets the failure in finish()
+    out, err = _fail_child("encode", {"FAKE_ENGINE_FAIL_CREATE": "1", "FLACGPU_BATCH_FRAMES": "64"})
+    st, s_init, ok_process, s_proc, ok_finish = out
+    assert (st, s_init, ok_process, s_proc, ok_finish) == ("0", "0", "True", "0", "False") and "cannot create the GPU frame engine" in err
+
+
+def test_delete_while_the_engine_is_still_coming_up():
+    out, err = _fail_child("nothing", {"FAKE_ENGINE_CREATE_DELAY_US": "200000"})
+    assert out == ["0", "0"]
