@@ -123,6 +123,7 @@ struct FLAC__StreamEncoderPrivate {
 	 * (pub_slot/pub_staged, under mu), so that the chain starts with the first samples and not with the first full batch. */
 	int md5_slot;                             /* slot of the batch the chain is in */
 	size_t md5_done;                          /* inter-channel samples of that batch already hashed */
+	size_t md5_ahead;                         /* ... and of the batch after it (only while the first batch waits for the engine) */
 	int pub_slot; size_t pub_staged, pub_last;
 	struct stage_pool *pool;                  /* helper threads of the narrowing copy (big process() calls only) */
 	/* Bring-up.  Starting the HIP runtime, creating the engine and page-locking the slots takes a fresh process 0.2-0.3 s -- as
@@ -136,6 +137,8 @@ struct FLAC__StreamEncoderPrivate {
 	flacgpu_config bring_cfg;
 	size_t raw_bytes;
 	int registered[4];
+	float *windows; size_t wcount;            /* the engine's window tables (host copy) */
+	int engine_failed;                        /* an engine call failed: this engine is not parked */
 	double t_bring_wait;
 	/* FLACGPU_HOST_TIMING=1: where a stream's wall time went, printed by finish() */
 	int timing;
@@ -272,6 +275,69 @@ static int stage_pool_run(struct stage_pool *sp, int (*fn)(const void *, size_t,
 	return ok;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * One parked engine per process.  Creating an engine costs 30 ms in a warm process (device buffers, 17 streams, 500 events),
+ * releasing it and its page-locked slots 40 ms: together as long as 130 M samples take to pass through it.  A program that
+ * encodes one stream after another with the same settings -- `flac *.wav` is one -- gets the previous stream's engine and
+ * slots back instead.  finish() parks them here when the stream ended without an engine error; init_*() takes them when the
+ * configuration is the same (window tables compared float by float) and the parked capacity is at least what it needs.  A
+ * parked engine is never destroyed by the library: it is replaced by a newer one, or goes with the process.
+ * FLACGPU_ENGINE_CACHE=0 switches the parking off.
+ * ---------------------------------------------------------------------------------------------- */
+struct engine_bundle {
+	flacgpu_ctx *gpu;
+	flacgpu_config cfg;
+	float *windows; size_t wcount;
+	uint8_t *raw[2], *out[2];
+	uint32_t *fb[2];
+	int registered[4];
+	size_t raw_bytes, out_cap;
+};
+static pthread_mutex_t g_park_mu = PTHREAD_MUTEX_INITIALIZER;
+static struct engine_bundle g_park;
+static int g_park_valid;
+static int parking_enabled(void) { const char *v = getenv("FLACGPU_ENGINE_CACHE"); return !(v && atoi(v) == 0); }
+static void bundle_destroy(struct engine_bundle *b)
+{
+	for(int i = 0; i < 2; i++) {
+		if(b->registered[2 * i]) flacgpu_host_unregister(b->raw[i]);
+		if(b->registered[2 * i + 1]) flacgpu_host_unregister(b->out[i]);
+		free(b->raw[i]); free(b->out[i]); free(b->fb[i]);
+	}
+	free(b->windows);
+	if(b->gpu) flacgpu_destroy(b->gpu);
+	memset(b, 0, sizeof *b);
+}
+/* the parked engine if it serves `cfg` (capacity: at least cfg->max_batch_frames) with these window tables */
+static int park_take(const flacgpu_config *cfg, const float *windows, size_t wcount, size_t raw_bytes, size_t out_cap, struct engine_bundle *out)
+{
+	int hit = 0;
+	pthread_mutex_lock(&g_park_mu);
+	if(g_park_valid) {
+		flacgpu_config a = g_park.cfg, b = *cfg;
+		const int roomy = a.max_batch_frames >= b.max_batch_frames && g_park.raw_bytes >= raw_bytes && g_park.out_cap >= out_cap;
+		a.max_batch_frames = b.max_batch_frames = 0;
+		if(roomy && memcmp(&a, &b, sizeof a) == 0 && g_park.wcount == wcount && (wcount == 0 || memcmp(g_park.windows, windows, wcount * sizeof(float)) == 0)) {
+			*out = g_park;
+			g_park_valid = 0;
+			hit = 1;
+		}
+	}
+	pthread_mutex_unlock(&g_park_mu);
+	return hit;
+}
+static void park_put(struct engine_bundle *b)
+{
+	struct engine_bundle old;
+	int had;
+	pthread_mutex_lock(&g_park_mu);
+	had = g_park_valid; old = g_park;
+	g_park = *b; g_park_valid = 1;
+	pthread_mutex_unlock(&g_park_mu);
+	if(had) bundle_destroy(&old);
+	memset(b, 0, sizeof *b);
+}
+
 static void release_engine(FLAC__StreamEncoder *e)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
@@ -287,17 +353,21 @@ static void release_engine(FLAC__StreamEncoder *e)
 		p->worker_started = 0; p->worker_quit = 0;
 	}
 	stage_pool_destroy(p->pool); p->pool = 0;
-	for(int i = 0; i < 2; i++) {
-		if(p->registered[2 * i]) flacgpu_host_unregister(p->slot[i].raw);
-		if(p->registered[2 * i + 1]) flacgpu_host_unregister(p->slot[i].out);
-		p->registered[2 * i] = p->registered[2 * i + 1] = 0;
-		free(p->slot[i].raw); p->slot[i].raw = 0;
-		free(p->slot[i].out); p->slot[i].out = 0;
-		free(p->slot[i].frame_bytes); p->slot[i].frame_bytes = 0;
-		p->slot[i].state = 0;
+	{
+		struct engine_bundle b;
+		memset(&b, 0, sizeof b);
+		b.gpu = p->gpu; b.cfg = p->bring_cfg; b.windows = p->windows; b.wcount = p->wcount; b.raw_bytes = p->raw_bytes; b.out_cap = p->out_cap;
+		for(int i = 0; i < 2; i++) {
+			b.raw[i] = p->slot[i].raw; b.out[i] = p->slot[i].out; b.fb[i] = p->slot[i].frame_bytes;
+			b.registered[2 * i] = p->registered[2 * i]; b.registered[2 * i + 1] = p->registered[2 * i + 1];
+			p->slot[i].raw = 0; p->slot[i].out = 0; p->slot[i].frame_bytes = 0; p->slot[i].state = 0;
+			p->registered[2 * i] = p->registered[2 * i + 1] = 0;
+		}
+		p->gpu = 0; p->windows = 0; p->wcount = 0;
+		if(b.gpu && !p->engine_failed && b.raw[0] && b.raw[1] && b.out[0] && b.out[1] && b.fb[0] && b.fb[1] && parking_enabled()) park_put(&b);
+		else bundle_destroy(&b);
 	}
-	if(p->gpu) { flacgpu_destroy(p->gpu); p->gpu = 0; }
-	p->engine_on = 0; p->bring_done = 0;
+	p->engine_on = 0; p->bring_done = 0; p->engine_failed = 0;
 	p->out_cap = 0;
 	free(p->tail_windows); p->tail_windows = 0;
 	p->staged = 0; p->cur = 0;
@@ -685,16 +755,8 @@ static void run_batch_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	const flacgpu_host_settings *s = &PROT(e)->s;
-	const uint32_t N = s->blocksize, C = s->channels;
-	const size_t nsamp = (size_t)(b->nframes - 1) * N + (b->tail ? b->tail : N);
-	double t0 = p->timing ? now_s() : 0;
-	if(s->do_md5 && nsamp > p->md5_done) flacgpu_host_md5_update(&p->md5, b->raw + p->md5_done * C * p->width, (nsamp - p->md5_done) * C * p->width);   /* what the chain had not reached yet */
-	if(p->timing) { const double t1 = now_s(); p->t_md5 += t1 - t0; t0 = t1; }
-	pthread_mutex_lock(&p->mu);
-	while(!p->bring_done) pthread_cond_wait(&p->cv, &p->mu);
-	pthread_mutex_unlock(&p->mu);
-	if(p->timing) { const double t1 = now_s(); p->t_bring_wait += t1 - t0; t0 = t1; }
-	if(p->bring_result != FLACGPU_OK) { b->total = p->bring_result; return; }
+	const double t0 = p->timing ? now_s() : 0;
+	if(p->bring_result != FLACGPU_OK) { b->total = p->bring_result; return; }       /* (the worker has waited for bring_done) */
 	const float *tw = 0;
 	if(b->tail && s->max_lpc_order > 0) {
 		/* windows are recomputed for the short block, as resize_buffers_ does at finish (:1703-1711) */
@@ -731,7 +793,7 @@ static void *bringup_main(void *arg)
 		if(!windows) r = FLACGPU_ERR_ALLOC; else flacgpu_host_windows(s, s->blocksize, windows);
 	}
 	if(r == FLACGPU_OK) r = flacgpu_create(&p->bring_cfg, windows, &gpu);
-	free(windows);
+	p->windows = windows; p->wcount = windows ? (size_t)s->num_apodizations * s->blocksize : 0;     /* kept: the key of a parked engine */
 	if(r == FLACGPU_OK && s->verify) r = flacgpu_set_verify(gpu, 1);
 	const double t1 = now_s();
 	if(r == FLACGPU_OK)
@@ -759,39 +821,59 @@ static void *worker_main(void *arg)
 	const size_t full = (size_t)p->batch_frames * s->blocksize, sample_bytes = (size_t)s->channels * p->width;
 	pthread_mutex_lock(&p->mu);
 	for(;;) {
-		int k;
+		int k = -1;
 		if(s->do_md5) {
-			/* stream order: the batch the chain is in is also the next one to be submitted */
-			k = p->md5_slot;
-			if(p->slot[k].state != 1) {
-				size_t avail = p->slot[k].state == 0 && p->pub_slot == k ? p->pub_staged : 0;
-				if(avail > full) avail = full;                 /* the sample beyond the batch belongs to the next one */
-				if(avail >= p->md5_done + MD5_PIECE || (avail == full && avail > p->md5_done)) {
-					size_t n = avail - p->md5_done;
-					if(n > 16 * MD5_PIECE) n = 16 * MD5_PIECE;     /* look for a submission again every few milliseconds */
-					const uint8_t *src = p->slot[k].raw + p->md5_done * sample_bytes;
-					pthread_mutex_unlock(&p->mu);
-					const double t0 = p->timing ? now_s() : 0;
-					flacgpu_host_md5_update(&p->md5, src, n * sample_bytes);
-					if(p->timing) p->t_md5 += now_s() - t0;
-					pthread_mutex_lock(&p->mu);
-					p->md5_done += n;
-					continue;
+			/* Stream order: the batch the chain is in (md5_slot) is also the next one to be submitted.  While it is being filled the
+			 * chain follows the caller's published progress; once it is submitted the chain finishes it; and while the engine is
+			 * still coming up the chain carries on into the other slot (md5_ahead), which the caller is filling by then. */
+			const int cur = p->md5_slot;
+			const struct batch_slot *b = &p->slot[cur];
+			int slot_to_hash = -1;
+			size_t from = 0, n = 0;
+			if(b->state == 1) {
+				const size_t nsamp = (size_t)(b->nframes - 1) * s->blocksize + (b->tail ? b->tail : s->blocksize);
+				if(p->md5_done < nsamp) { slot_to_hash = cur; from = p->md5_done; n = nsamp - from; }
+				else if(p->bring_done) k = cur;
+				else {
+					const int o = cur ^ 1;
+					size_t avail = p->slot[o].state == 0 && p->pub_slot == o ? p->pub_staged : 0;
+					if(avail > full) avail = full;
+					if(avail >= p->md5_ahead + MD5_PIECE || (avail == full && avail > p->md5_ahead)) { slot_to_hash = o; from = p->md5_ahead; n = avail - from; }
 				}
-				k = -1;
+			}
+			else {
+				size_t avail = b->state == 0 && p->pub_slot == cur ? p->pub_staged : 0;
+				if(avail > full) avail = full;                 /* the sample beyond the batch belongs to the next one */
+				if(avail >= p->md5_done + MD5_PIECE || (avail == full && avail > p->md5_done)) { slot_to_hash = cur; from = p->md5_done; n = avail - from; }
+			}
+			if(slot_to_hash >= 0) {
+				if(p->slot[slot_to_hash].state != 1 && n > 16 * MD5_PIECE) n = 16 * MD5_PIECE;      /* look for a submission again every few milliseconds */
+				const uint8_t *src = p->slot[slot_to_hash].raw + from * sample_bytes;
+				pthread_mutex_unlock(&p->mu);
+				const double t0 = p->timing ? now_s() : 0;
+				flacgpu_host_md5_update(&p->md5, src, n * sample_bytes);
+				if(p->timing) p->t_md5 += now_s() - t0;
+				pthread_mutex_lock(&p->mu);
+				if(slot_to_hash == cur) p->md5_done += n; else p->md5_ahead += n;
+				continue;
 			}
 		}
-		else k = p->slot[0].state == 1 ? 0 : p->slot[1].state == 1 ? 1 : -1;
+		else {
+			k = p->slot[0].state == 1 ? 0 : p->slot[1].state == 1 ? 1 : -1;
+			if(k >= 0 && !p->bring_done) k = -2;              /* a batch is waiting for the engine */
+		}
 		if(k < 0) {
-			if(p->worker_quit) break;
+			if(p->worker_quit && k == -1) break;
+			const double t0 = p->timing ? now_s() : 0;
 			pthread_cond_wait(&p->cv, &p->mu);
+			if(p->timing && !p->bring_done) p->t_bring_wait += now_s() - t0;
 			continue;
 		}
 		pthread_mutex_unlock(&p->mu);
 		run_batch_slot(e, &p->slot[k]);
 		pthread_mutex_lock(&p->mu);
 		p->slot[k].state = 2;
-		p->md5_slot = k ^ 1; p->md5_done = 0;
+		p->md5_slot = k ^ 1; p->md5_done = p->md5_ahead; p->md5_ahead = 0;
 		pthread_cond_broadcast(&p->cv);
 	}
 	pthread_mutex_unlock(&p->mu);
@@ -833,6 +915,7 @@ static int collect_slot(FLAC__StreamEncoder *e, int k)
 	pthread_mutex_unlock(&p->mu);
 	if(p->timing) { const double t1 = now_s(); p->t_wait += t1 - t0; t0 = t1; }
 	if(b->total < 0) {
+		p->engine_failed = 1;
 		fprintf(stderr, "libFLACgpu: the GPU frame engine failed: %s\n", flacgpu_strerror((int)b->total));
 		PROT(e)->state = b->total == FLACGPU_ERR_ALLOC ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
 		return 0;
@@ -955,6 +1038,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 		p->timing = getenv("FLACGPU_HOST_TIMING") != 0;
 		p->t_init_engine = p->t_init_pinned = p->t_stage = p->t_wait = p->t_emit = p->t_md5 = p->t_encode = p->t_release = p->t_bring_wait = 0;
 		p->t_start = now_s();
+		int parked = 0;
 		int r = flacgpu_host_engine_config(s, device, p->batch_frames, &p->bring_cfg);
 		if(r == FLACGPU_OK) r = flacgpu_config_check(&p->bring_cfg);       /* what the engine refuses, it refuses here, not on the bring-up thread */
 		if(r == FLACGPU_OK) {
@@ -963,7 +1047,27 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 			p->rawfmt.container_bits = 8 * p->width;            /* little endian, signed, right-justified */
 			p->out_cap = flacgpu_config_max_output_bytes(&p->bring_cfg, p->batch_frames);
 			p->raw_bytes = (size_t)p->width * s->channels * ((size_t)p->batch_frames * s->blocksize + 1);
-			for(int i = 0; i < 2; i++) {
+			p->windows = 0; p->wcount = 0; p->engine_failed = 0;
+			pthread_mutex_lock(&g_park_mu);
+			const int maybe = g_park_valid && parking_enabled();
+			pthread_mutex_unlock(&g_park_mu);
+			if(maybe) {
+				const size_t wcount = s->max_lpc_order > 0 ? (size_t)s->num_apodizations * s->blocksize : 0;
+				float *w = wcount ? malloc(sizeof(float) * wcount) : 0;
+				struct engine_bundle b;
+				if(wcount && w) flacgpu_host_windows(s, s->blocksize, w);
+				if((!wcount || w) && park_take(&p->bring_cfg, w, wcount, p->raw_bytes, p->out_cap, &b)) {
+					parked = 1;
+					p->gpu = b.gpu; p->bring_cfg = b.cfg; p->windows = b.windows; p->wcount = b.wcount; p->raw_bytes = b.raw_bytes; p->out_cap = b.out_cap;
+					for(int i = 0; i < 2; i++) {
+						p->slot[i].raw = b.raw[i]; p->slot[i].out = b.out[i]; p->slot[i].frame_bytes = b.fb[i]; p->slot[i].state = 0;
+						p->registered[2 * i] = b.registered[2 * i]; p->registered[2 * i + 1] = b.registered[2 * i + 1];
+					}
+					r = flacgpu_set_verify(p->gpu, s->verify ? 1 : 0);
+				}
+				free(w);
+			}
+			for(int i = 0; i < 2 && !parked; i++) {
 				void *a = 0, *b = 0;
 				if(posix_memalign(&a, 4096, p->raw_bytes) != 0) a = 0;
 				if(posix_memalign(&b, 4096, p->out_cap) != 0) b = 0;
@@ -974,7 +1078,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 				if(!p->slot[i].raw || !p->slot[i].out || !p->slot[i].frame_bytes) r = FLACGPU_ERR_ALLOC;
 			}
 		}
-		p->md5_slot = 0; p->md5_done = 0; p->pub_slot = 0; p->pub_staged = p->pub_last = 0;
+		p->md5_slot = 0; p->md5_done = 0; p->md5_ahead = 0; p->pub_slot = 0; p->pub_staged = p->pub_last = 0;
 		p->bring_started = 0; p->bring_done = 0; p->bring_result = FLACGPU_OK;
 		if(r == FLACGPU_OK) {
 			pthread_mutex_init(&p->mu, 0);
@@ -987,7 +1091,8 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 			/* on its own thread when a device node is there to be opened; otherwise here, so that the error is init's */
 			const char *es = getenv("FLACGPU_SYNC_INIT");
 			const int async = !(es && atoi(es)) && flacgpu_device_probe();
-			if(async && pthread_create(&p->bring_th, 0, bringup_main, e) == 0) p->bring_started = 1;
+			if(parked) p->bring_done = 1;                       /* the previous stream's engine: nothing to bring up */
+			else if(async && pthread_create(&p->bring_th, 0, bringup_main, e) == 0) p->bring_started = 1;
 			else {
 				bringup_main(e);
 				r = p->bring_result;

@@ -39,3 +39,21 @@ for name, cmd in (("reference, 1 thread", [ref, "-8"]), ("reference, -j 8", [ref
     outs[name] = open(out, "rb").read()
     print("%-22s %6.2f s  %7.1f M samples/s" % (name, dt, n / dt / 1e6))
 print("files identical:", outs.get("reference, 1 thread") == outs.get("libFLACgpu"))
+
+# several files in one command: one process, one encoder after another (the second and third get the first one's engine)
+import shutil
+paths = []
+for i in range(3):
+    q = "/tmp/cli_rate_%d.wav" % i
+    shutil.copy(path, q)
+    paths.append(q)
+for name, cmd in (("reference -j 8, 3 files", [ref, "-8", "-j", "8"]), ("libFLACgpu, 3 files", [gpu, "-8"])):
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd + ["-s", "-f"] + paths, capture_output=True, text=True, env=dict(os.environ, FLACGPU_HOST_TIMING="1"))
+    dt = time.perf_counter() - t0
+    for line in r.stderr.splitlines():
+        if "timing" in line:
+            print("    " + line)
+    print("%-24s %6.2f s  %7.1f M samples/s  rc=%d" % (name, dt, 3 * n / dt / 1e6, r.returncode))
+    outs[name] = [open(q[:-4] + ".flac", "rb").read() for q in paths]
+print("3-file outputs identical:", outs.get("reference -j 8, 3 files") == outs.get("libFLACgpu, 3 files"))

@@ -14,6 +14,9 @@
 #include "flacgpu.h"
 
 struct flacgpu_ctx { flacgpu_config cfg; uint32_t verify; };
+static int g_creates, g_destroys;
+int fake_engine_creates(void) { return g_creates; }
+int fake_engine_destroys(void) { return g_destroys; }
 
 static void pause_us(const char *env)
 {
@@ -30,9 +33,10 @@ int flacgpu_create(const flacgpu_config *cfg, const float *windows, flacgpu_ctx 
 	if(!c) return FLACGPU_ERR_ALLOC;
 	c->cfg = *cfg;
 	*out = c;
+	g_creates++;
 	return FLACGPU_OK;
 }
-void flacgpu_destroy(flacgpu_ctx *ctx) { free(ctx); }
+void flacgpu_destroy(flacgpu_ctx *ctx) { if(ctx) g_destroys++; free(ctx); }
 size_t flacgpu_max_output_bytes(const flacgpu_ctx *ctx, uint32_t nframes) { (void)ctx; return (size_t)nframes * 32; }
 void *flacgpu_alloc_pinned(size_t bytes) { void *p = 0; if(posix_memalign(&p, 4096, bytes ? bytes : 1) != 0) return 0; memset(p, 0, bytes); return p; }   /* touched, as page-locked memory is */
 void flacgpu_free_pinned(void *p) { free(p); }
@@ -53,6 +57,7 @@ int64_t flacgpu_encode_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgp
 	const uint32_t N = ctx->cfg.blocksize, C = ctx->cfg.channels, w = fmt->container_bits / 8;
 	const uint8_t *p = raw;
 	size_t total = 0;
+	if(nframes > ctx->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
 	/* a GPU batch takes a few milliseconds: leave the other threads time to run ahead (FAKE_ENGINE_DELAY_US) */
 	pause_us("FAKE_ENGINE_DELAY_US");
 	for(uint32_t f = 0; f < nframes; f++) {

@@ -229,3 +229,73 @@ def test_engine_failure_is_loud_wherever_it_surfaces():
 def test_delete_while_the_engine_is_still_coming_up():
     out, err = _fail_child("nothing", {"FAKE_ENGINE_CREATE_DELAY_US": "200000"})
     assert out == ["0", "0"]
+
+
+# ---- the parked engine: one stream after another in one process ------------------------------------------------------------
+PARK_CHILD = r'''
+import os, sys, json, ctypes as C
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import flac_api
+fake = C.CDLL(os.path.join(%(fake)r, "libflacgpu.so"))
+jobs = json.loads(sys.argv[1])
+out = []
+for job in jobs:
+    rng = np.random.default_rng(job["seed"])
+    pcm = rng.integers(-32768, 32768, size=(job["samples"], 2), dtype=np.int64).astype(np.int32)
+    settings = [("set_blocksize", job["blocksize"])] + [tuple(x) for x in job.get("settings", [])]
+    data, sink = flac_api.encode("gpu", pcm, 16, 44100, level=job.get("level", 5), chunk=5000, settings=settings,
+                                 total_samples_estimate=job.get("estimate"))
+    out.append({"len": len(data), "md5": data[26:42].hex(), "creates": fake.fake_engine_creates(), "destroys": fake.fake_engine_destroys(),
+                "frames": data.count(bytes([70, 75, 0, 0]))})
+print(json.dumps(out))
+'''
+
+
+def _park(jobs, env_extra=()):
+    import json
+    _build()
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = FAKE_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env["FLACGPU_BATCH_FRAMES"] = "16"
+    env.update(dict(env_extra))
+    out = subprocess.run([sys.executable, "-c", PARK_CHILD % {"root": ROOT, "fake": FAKE_DIR}, json.dumps(jobs)], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return json.loads(out.stdout)
+
+
+def _md5_of(job):
+    rng = np.random.default_rng(job["seed"])
+    pcm = rng.integers(-32768, 32768, size=(job["samples"], 2), dtype=np.int64).astype(np.int32)
+    return hashlib.md5(pcm.astype("<i2").tobytes()).hexdigest()
+
+
+def test_next_stream_with_the_same_settings_gets_the_parked_engine():
+    a = dict(seed=1, samples=256 * 40 + 3, blocksize=256)
+    b = dict(seed=2, samples=256 * 70, blocksize=256)
+    c = dict(seed=3, samples=256 * 5, blocksize=256, estimate=256 * 5)        # wants 5-frame batches: the parked 16-frame engine serves it
+    r = _park([a, b, c])
+    assert [x["creates"] for x in r] == [1, 1, 1] and r[-1]["destroys"] == 0
+    assert [x["md5"] for x in r] == [_md5_of(a), _md5_of(b), _md5_of(c)]
+    assert [x["frames"] for x in r] == [41, 70, 5]
+
+
+def test_other_settings_get_their_own_engine_and_replace_the_parked_one():
+    a = dict(seed=1, samples=256 * 20, blocksize=256)
+    b = dict(seed=2, samples=512 * 20, blocksize=512)                         # other block size
+    c = dict(seed=3, samples=512 * 20, blocksize=512, level=8)                # other preset: other windows, orders
+    r = _park([a, b, c, c])
+    assert [x["creates"] for x in r] == [1, 2, 3, 3]
+    assert [x["destroys"] for x in r] == [0, 1, 2, 2]                        # the older engine goes when a newer one is parked
+    assert [x["md5"] for x in r] == [_md5_of(a), _md5_of(b), _md5_of(c), _md5_of(c)]
+    # a bigger stream than the parked engine was built for: a new engine
+    small = dict(seed=5, samples=256 * 4, blocksize=256, estimate=256 * 4)
+    r = _park([small, a])
+    assert [x["creates"] for x in r] == [1, 2]
+
+
+def test_parking_can_be_switched_off():
+    a = dict(seed=1, samples=256 * 20, blocksize=256)
+    r = _park([a, a], {"FLACGPU_ENGINE_CACHE": "0"})
+    assert [x["creates"] for x in r] == [1, 2] and [x["destroys"] for x in r] == [1, 2]
