@@ -42,7 +42,11 @@ __device__ __forceinline__ void put_bits(uint32_t *buf, uint32_t cap_words, uint
 // spans are xor-reduced: crc(A||B) = crc(A) * x^(8|B|) + crc(B) in GF(2)[x]/(x^16+x^15+x^2+1).
 constexpr uint32_t CRC_SPAN = 64;                       // bytes per span
 constexpr uint32_t CRC_MAX_SPANS = 4 * 1024 * 1024 / 64;    // frames up to 4 MiB (8 channels x 65535 samples x 33 bits = 2.1 MiB)
-struct CrcTables { uint16_t tab[4][256]; uint16_t xspan[CRC_MAX_SPANS]; uint16_t xbyte[CRC_SPAN + 1]; };
+// pack2_kernel cuts its LDS image into 44-byte spans instead: 11 words per lane is an ODD word stride, so the 64 lanes of a
+// wavefront read 64 different banks (a 16-word stride puts them on 4 banks: every image read a 16-way conflict)
+constexpr uint32_t CRC2_SPAN = 44, CRC2_WORDS = 11;
+constexpr uint32_t CRC2_MAX_SPANS = 4096;                // x 44 bytes = 176 KiB: more than an LDS image can be
+struct CrcTables { uint16_t tab[4][256]; uint16_t xspan[CRC_MAX_SPANS]; uint16_t xbyte[CRC_SPAN + 1]; uint16_t xspan44[CRC2_MAX_SPANS]; };
 constexpr uint32_t crc_mulx(uint32_t c) { return (c & 0x8000u) ? ((c << 1) ^ 0x8005u) & 0xffffu : (c << 1) & 0xffffu; }
 constexpr uint32_t crc_mulx8(uint32_t c) { for(int b = 0; b < 8; b++) c = crc_mulx(c); return c; }
 constexpr CrcTables make_crc_tables()
@@ -61,6 +65,14 @@ constexpr CrcTables make_crc_tables()
 		t.xspan[m] = (uint16_t)c;
 		// c *= xs  (schoolbook product mod P)
 		uint32_t r = 0, b = xs;
+		for(int i = 0; i < 16; i++) { r = crc_mulx(r); if(b & 0x8000u) r ^= c; b = (b << 1) & 0xffffu; }
+		c = r;
+	}
+	const uint32_t xs44 = t.xbyte[CRC2_SPAN];                                                  // x^352
+	c = 1;
+	for(uint32_t m = 0; m < CRC2_MAX_SPANS; m++) {
+		t.xspan44[m] = (uint16_t)c;
+		uint32_t r = 0, b = xs44;
 		for(int i = 0; i < 16; i++) { r = crc_mulx(r); if(b & 0x8000u) r ^= c; b = (b << 1) & 0xffffu; }
 		c = r;
 	}
@@ -194,6 +206,54 @@ __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const 
 	for(int w = 0; w < TPB / 64; w++) crc ^= crc_parts[w];
 	const uint32_t xb = xbyte_lds ? xbyte_lds[last_len] : g_crc_tables.xbyte[last_len];
 	return gf16_mul(crc & 0xffffu, xb) ^ (crc >> 16);
+}
+
+// The same for pack2_kernel's LDS image: 44-byte spans (conflict-free reads, see CRC2_SPAN); every lane loads its eleven words
+// at once and runs them under a predicate, the lane with the short last span included -- that span used to be a byte-serial
+// chain of up to 64 dependent LDS round trips which the whole workgroup waited for at the barrier.
+__device__ __forceinline__ uint32_t frame_crc16_p2(const uint32_t *img, uint32_t body_bytes, const uint16_t (*crc_tab)[256], uint32_t *crc_parts, int tid,
+                                                   const uint16_t *xspan_lds, uint32_t nxspan_lds, const uint16_t *xbyte_lds)
+{
+	const uint32_t nsp = (body_bytes + CRC2_SPAN - 1) / CRC2_SPAN;
+	const uint32_t last_len = body_bytes - (nsp ? nsp - 1 : 0) * CRC2_SPAN;                // 1..44 bytes
+	uint32_t c = 0;                     // low half: whole spans, shifted among themselves; high half: the last span
+	for(uint32_t sp = (uint32_t)tid; sp < nsp; sp += TPB) {
+		const uint32_t *wp = img + sp * CRC2_WORDS;
+		uint32_t w[CRC2_WORDS];
+#pragma unroll
+		for(int k = 0; k < (int)CRC2_WORDS; k++) w[k] = wp[k];             // (past the last span: still inside the workgroup's LDS, never used)
+		const bool last = sp + 1 == nsp;
+		const uint32_t nw = last ? last_len >> 2 : CRC2_WORDS;
+		uint32_t cs = 0, tailw = 0;
+#pragma unroll
+		for(int k = 0; k < (int)CRC2_WORDS; k++) {
+			if((uint32_t)k < nw) {
+				const uint32_t v = (cs << 16) ^ w[k];
+				cs = (uint32_t)crc_tab[3][v >> 24] ^ crc_tab[2][(v >> 16) & 0xffu] ^ crc_tab[1][(v >> 8) & 0xffu] ^ crc_tab[0][v & 0xffu];
+			}
+			else if((uint32_t)k == nw) tailw = w[k];
+		}
+		if(last) {
+			const uint32_t nb = last_len & 3u;
+			for(uint32_t j = 0; j < nb; j++) {
+				const uint32_t b = (tailw >> (24 - 8 * j)) & 0xffu;
+				cs = ((cs << 8) & 0xffffu) ^ crc_tab[0][(cs >> 8) ^ b];
+			}
+			c ^= cs << 16;
+		}
+		else {
+			const uint32_t m = nsp - 2 - sp;
+			const uint32_t xs = m < nxspan_lds ? xspan_lds[m] : g_crc_tables.xspan44[m];
+			c ^= m ? gf16_mul(cs, xs) : cs;
+		}
+	}
+#pragma unroll
+	for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
+	if((tid & 63) == 0) crc_parts[tid >> 6] = c;
+	__syncthreads();
+	uint32_t crc = 0;
+	for(int w = 0; w < TPB / 64; w++) crc ^= crc_parts[w];
+	return gf16_mul(crc & 0xffffu, xbyte_lds[last_len]) ^ (crc >> 16);
 }
 
 // number of frame header bytes including the CRC-8, without building them (same cases as frame_header_bytes)
@@ -661,7 +721,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 		const uint32_t ndw = P.ncand * (uint32_t)(sizeof(SubDecision) / 4);
 		for(uint32_t w = (uint32_t)tid; w < ndw; w += TPB) sh->dec[w] = ((const uint32_t *)dec)[w];
 		for(uint32_t w = (uint32_t)tid; w < 4 * 256 / 2; w += TPB) ((uint32_t *)sh->crc_tab)[w] = ((const uint32_t *)g_crc_tables.tab)[w];
-		for(uint32_t w = (uint32_t)tid; w < P2_XSPAN / 2; w += TPB) ((uint32_t *)sh->xspan)[w] = ((const uint32_t *)g_crc_tables.xspan)[w];
+		for(uint32_t w = (uint32_t)tid; w < P2_XSPAN / 2; w += TPB) ((uint32_t *)sh->xspan)[w] = ((const uint32_t *)g_crc_tables.xspan44)[w];
 		if(tid < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[tid] = ((const uint32_t *)g_crc_tables.xbyte)[tid];
 		for(uint32_t w = (uint32_t)tid; w < cap_words + 2; w += TPB) img[w] = 0;
 	}
@@ -677,10 +737,11 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 		if(b1 < mn) { mn = b1; ca = 1; }
 		if(b2 < mn) { mn = b2; ca = 2; }
 		if(b3 < mn) { mn = b3; ca = 3; }
+		ca = (uint32_t)__builtin_amdgcn_readfirstlane((int)ca);        // the same in every lane: say so, and what follows is scalar code
 		left = ca == 2 ? 3 : ca == 3 ? 2 : 0;
 		right = ca == 0 ? 1 : ca == 2 ? 1 : 3;
 	}
-	else if(P.ms_mode == 2) ca = ldec[0].which >= 2 ? 3 : 0;
+	else if(P.ms_mode == 2) ca = (uint32_t)__builtin_amdgcn_readfirstlane(ldec[0].which >= 2 ? 3 : 0);
 	const uint32_t frame_number = (uint32_t)(first_frame_number + f);
 	if(tid == 64) {
 		// one lane (of a wavefront that has no other single-lane duties) builds and writes the header while the others go on
@@ -693,9 +754,12 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 	for(uint32_t s = 0; s < C; s++) {
 		const uint32_t di = P.ms_mode == 1 ? (s == 0 ? left : right) : s;
 		const SubDecision *d = ldec + di;
-		const uint32_t which = d->which, type = d->type, order = d->order, wasted = d->wasted;
+		// the decision record is one for the whole workgroup: its fields are made scalars, so that the header arithmetic, the tap
+		// set-up and the branches on type / order / format below are scalar code and not 64-lane selects
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+		const uint32_t which = UNI(d->which), type = UNI(d->type), order = UNI(d->order), wasted = UNI(d->wasted);
 		const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
-		const bool fmt16 = d->fmt == 1;            // 16-bit pairs: sbps <= 16, or a side channel whose samples all fit int16
+		const bool fmt16 = UNI(d->fmt) == 1;       // 16-bit pairs: sbps <= 16, or a side channel whose samples all fit int16
 		const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + di) * N);
 		const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : type == 2 ? (0x10u | (order << 1)) : (0x40u | ((order - 1) << 1));
 		if(tid == 0) {
@@ -729,23 +793,20 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 		else {
 			const uint32_t warm_pos = pos;
 			pos += order * sbps;
-			const int shift = type == 3 ? d->shift : 0;
+			const int shift = type == 3 ? (int)__builtin_amdgcn_readfirstlane((int)d->shift) : 0;
 			bool wide = false;
 			if(type == 3) {
-				const uint32_t precision = d->precision;
+				const uint32_t precision = UNI(d->precision);
 				if(tid == 0) {
 					or_bits(img, cap_words, pos, precision - 1, 4);
 					or_bits(img, cap_words, pos + 4, (uint32_t)shift & 31u, 5);
 				}
 				if((uint32_t)tid < order) or_bits(img, cap_words, pos + 9 + (uint32_t)tid * precision, (uint32_t)d->q[tid] & ((1u << precision) - 1u), precision);
 				pos += 9 + order * precision;
-				uint32_t abs_sum = 0;
-				for(uint32_t i = 0; i < order; i++) abs_sum += (uint32_t)abs(d->q[i]);
-				wide = silog2_i64((int64_t)(((uint64_t)1 << (sbps - 1)) * abs_sum)) > 32;
 			}
-			const uint32_t po = d->po, plen = d->rice2 ? 5u : 4u;
+			const uint32_t po = UNI(d->po), rice2 = UNI(d->rice2), plen = rice2 ? 5u : 4u;
 			if(tid == 0) {
-				or_bits(img, cap_words, pos, d->rice2 ? 1u : 0u, 2);
+				or_bits(img, cap_words, pos, rice2 ? 1u : 0u, 2);
 				or_bits(img, cap_words, pos + 2, po, 4);
 			}
 			pos += 6;
@@ -760,6 +821,14 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 				else if(order == 3) c = j == 0 ? 3 : j == 1 ? -3 : j == 2 ? 1 : 0;
 				else if(order == 4) c = j == 0 ? 4 : j == 1 ? -6 : j == 2 ? 4 : j == 3 ? -1 : 0;
 				q[j] = c;
+			}
+			if(type == 3) {
+				// lpc.c:942-976's residual-width bound, from the taps now in registers (they were read one dependent LDS round trip at a time)
+				uint32_t abs_sum = 0;
+#pragma unroll
+				for(int j = 0; j < MAXORD; j++) abs_sum += (uint32_t)j < order ? (uint32_t)abs(q[j]) : 0u;
+				abs_sum = UNI(abs_sum);
+				wide = silog2_i64((int64_t)(((uint64_t)1 << (sbps - 1)) * abs_sum)) > 32;
 			}
 			const uint32_t psize = n >> po;
 			PSTAMP(2 + 4 * s);
@@ -884,7 +953,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 	const uint32_t total_bytes = body_bytes + 2;
 	const bool overflow = total_bytes > P.slot_bytes;
 	{
-		const uint32_t crc = frame_crc16(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, tid, sh->xspan, P2_XSPAN, sh->xbyte);
+		const uint32_t crc = frame_crc16_p2(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, tid, sh->xspan, P2_XSPAN, sh->xbyte);
 		PSTAMP(11);
 		if(tid == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
@@ -918,6 +987,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 	}
 	PSTAMP(12);
 #undef PSTAMP
+#undef UNI
 }
 
 // fused output with a short last block: that frame was assembled in its slot by pack_kernel; it goes behind the others
