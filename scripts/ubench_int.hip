@@ -88,6 +88,23 @@ __global__ __launch_bounds__(256) void k<CvtF64>(uint32_t *out, const uint32_t *
 	for(int u = 0; u < UNR; u++) r += a[u];
 	out[blockIdx.x * 256 + t] = (uint32_t)r;
 }
+#define F64OP(name, str) struct name {}; \
+template <> __global__ __launch_bounds__(256) void k<name>(uint32_t *out, const uint32_t *in, int n) \
+{ \
+	const int t = threadIdx.x; \
+	double a[UNR]; \
+	for(int u = 0; u < UNR; u++) a[u] = 1.0 + 1e-9 * (double)in[(t + u) & 255]; \
+	const double b = 1.0 + 1e-12 * (double)in[(t + 77) & 255], c = 1e-12 * (double)in[(t + 99) & 255]; \
+	for(int it = 0; it < n; it++) { \
+		_Pragma("unroll") for(int u = 0; u < UNR; u++) asm volatile(str : "+v"(a[u]) : "v"(b), "v"(c)); \
+	} \
+	double r = 0; \
+	for(int u = 0; u < UNR; u++) r += a[u]; \
+	out[blockIdx.x * 256 + t] = (uint32_t)r; \
+}
+F64OP(FmaF64, "v_fma_f64 %0, %0, %1, %2")
+F64OP(MulF64, "v_mul_f64 %0, %0, %1")
+F64OP(AddF64, "v_add_f64 %0, %0, %1")
 template <class O>
 static void run(const char *name, uint32_t *out, const uint32_t *in)
 {
@@ -116,6 +133,6 @@ int main()
 	(void)hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice);
 	R(AddU32); R(SubU32); R(Ashr); R(MaxI32); R(BfeI32); R(Alignbit); R(Add3); R(MulLo); R(MadU24); R(MadI24); R(CvtF32I32); R(MulF32); R(Xor);
 	R(LshlOr); R(LshlAdd); R(Perm); R(Dot2); R(Dot4); R(PkMad16); R(PkAdd16); R(SadU32); R(MulHi); R(Mov); R(Cndmask); R(AddCo); R(Ffbh); R(Lshrrev); R(Max3); R(Med3);
-	R(Mad64); R(CvtF64);
+	R(Mad64); R(CvtF64); R(FmaF64); R(MulF64); R(AddF64);
 	return 0;
 }
