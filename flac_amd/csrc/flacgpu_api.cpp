@@ -56,6 +56,11 @@ struct flacgpu_ctx {
 	int64_t *d_vscratch;
 	void *d_vdecoded;            // decoded coded-channel samples of a batch, lane-interleaved (flacgpu_verify.hip)
 	uint32_t *d_vfinfo;          // [max_batch] per-frame verdict of the decode pass
+	uint32_t *d_vhints;          // [max_batch][channels][HINT_RUNS] run starts written by the pack kernel (flacgpu_decode_hinted.h)
+	uint32_t *d_vfstat;          // [max_batch] verdict of the hinted pass: 0 verified, 1 to be decoded sequentially
+	// the batch the hints in d_vhints describe: they are used when exactly these frames come back to be verified
+	const uint8_t *hint_out; uint32_t hint_nframes, hint_count; uint64_t hint_first;
+	int force_hints;             // FLACGPU_VERIFY_FORCE_HINTS=1 (tests): use them whatever frames are handed in; =0: never
 	uint32_t verify_on;
 	flacgpu_verify_result last_verify;
 	JobTable h_jobtab[2];        // [0] nominal blocksize, [1] the short last block of the current batch
@@ -195,6 +200,8 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->d_vscratch) (void)hipFree(c->d_vscratch);
 	if(c->d_vdecoded) (void)hipFree(c->d_vdecoded);
 	if(c->d_vfinfo) (void)hipFree(c->d_vfinfo);
+	if(c->d_vhints) (void)hipFree(c->d_vhints);
+	if(c->d_vfstat) (void)hipFree(c->d_vfstat);
 	for(int r = 0; r < TIMING_RING; r++) for(int i = 0; i < 5; i++) if(c->ev_ring[r][i]) (void)hipEventDestroy(c->ev_ring[r][i]);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -407,11 +414,12 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
 			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
 			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, ss) != hipSuccess)
+			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, nullptr, nullptr, ss) != hipSuccess)
 				return FLACGPU_ERR_LAUNCH;
 			(void)hipEventRecord(c->sub_done[i], ss);
 			(void)hipStreamWaitEvent(s, c->sub_done[i], 0);
 		}
+		c->hint_count = 0;
 		// the per-kernel events of the single-stream path are not meaningful here
 		for(int i = 0; i < 3; i++) (void)hipEventRecord(c->pev[i], s);
 		(void)hipEventRecord(c->ev[1], s);
@@ -453,7 +461,9 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			static int fuse = -1;
 			if(fuse < 0) fuse = getenv("FLACGPU_FUSED_COMPACT") ? 1 : 0;
 			PackOutArgs po = {d_out, out_cap, c->d_offsets, c->d_total, c->d_scanstate};
-			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, fuse ? &po : nullptr, &fused, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			uint32_t hinted = 0;
+			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, fuse ? &po : nullptr, &fused, c->d_vhints, &hinted, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			c->hint_out = d_out; c->hint_nframes = nframes; c->hint_first = first; c->hint_count = hinted;
 		}
 		if(c->ab.dbg) {
 			// development aid: wall cycles of the pack2 workgroups between their stamps
@@ -540,6 +550,16 @@ static int ensure_host_staging(flacgpu_ctx *c, uint32_t nframes)
 	}
 	return FLACGPU_OK;
 }
+// how many leading frames of this verify call the hints in d_vhints describe: they were written by the pack kernel for the last
+// batch this engine encoded, and they are used when that batch comes back (same buffer, same frames).  The hinted pass does not
+// trust them -- stale hints cost time, not correctness.
+static uint32_t hints_for(const flacgpu_ctx *c, const uint8_t *d_frames, uint32_t nframes, uint64_t first)
+{
+	if(!c->d_vhints || c->hint_count == 0 || c->force_hints == 0) return 0;
+	if(c->force_hints == 1) return c->hint_count < nframes ? c->hint_count : nframes;
+	if(d_frames != c->hint_out || nframes != c->hint_nframes || first != c->hint_first) return 0;
+	return c->hint_count;
+}
 // encode c->d_pcm (already filled on the engine's stream) and bring the frames back
 static int64_t encode_staged(flacgpu_ctx *c, uint32_t nframes, uint64_t first_frame_number, uint32_t tail_n, const float *tail_windows,
                              uint8_t *out, size_t out_cap, uint32_t *frame_bytes)
@@ -550,7 +570,8 @@ static int64_t encode_staged(flacgpu_ctx *c, uint32_t nframes, uint64_t first_fr
 	memset(&c->last_verify, 0, sizeof c->last_verify);
 	if(c->verify_on) {
 		// the frames are decoded again where they lie and compared with the staged input (stream_encoder.c:3000-3018)
-		if(launch_verify(c->P, c->d_out, c->d_frame_bytes, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, c->d_vresult, s) != hipSuccess)
+		if(launch_verify(c->P, c->d_out, c->d_frame_bytes, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, c->d_vresult,
+		                 c->d_vhints, hints_for(c, c->d_out, nframes, first_frame_number), c->d_vfstat, s) != hipSuccess)
 			return FLACGPU_ERR_LAUNCH;
 		if(hipMemcpyAsync(&c->last_verify, c->d_vresult, sizeof c->last_verify, hipMemcpyDeviceToHost, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
@@ -627,6 +648,15 @@ static int ensure_verify(flacgpu_ctx *c)
 	ok = ok && hipMalloc(&c->d_vscratch, (size_t)c->P.channels * c->P.blocksize * sizeof(int64_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_vdecoded, verify_decoded_bytes(c->P, (uint32_t)B)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_vfinfo, B * sizeof(uint32_t)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_vfstat, B * sizeof(uint32_t)) == hipSuccess;
+	{
+		const char *e = getenv("FLACGPU_VERIFY_FORCE_HINTS");
+		c->force_hints = e ? (atoi(e) ? 1 : 0) : -1;
+		// blocks of up to 4096 samples whose frame image and signal fit a workgroup's LDS share are verified a run per thread
+		if(c->force_hints != 0 && verify_hinted_covers(c->P))
+			ok = ok && hipMalloc(&c->d_vhints, B * c->P.channels * HINT_RUNS * sizeof(uint32_t)) == hipSuccess;
+	}
+	c->hint_count = 0;
 	return ok ? FLACGPU_OK : FLACGPU_ERR_ALLOC;
 }
 
@@ -641,8 +671,20 @@ extern "C" int flacgpu_verify_batch_device(flacgpu_ctx *c, const uint8_t *d_fram
 	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
 	const uint32_t tail_n = last_block_samples < c->P.blocksize ? last_block_samples : 0;
 	if(launch_scan(d_frame_bytes, nframes, c->d_voffsets, c->d_vtotal, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(launch_verify(c->P, d_frames, d_frame_bytes, c->d_voffsets, nframes, tail_n, first_frame_number, d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, d_result, s) != hipSuccess)
+	if(launch_verify(c->P, d_frames, d_frame_bytes, c->d_voffsets, nframes, tail_n, first_frame_number, d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, d_result,
+	                 c->d_vhints, hints_for(c, d_frames, nframes, first_frame_number), c->d_vfstat, s) != hipSuccess)
 		return FLACGPU_ERR_LAUNCH;
+	return FLACGPU_OK;
+}
+
+// frames of the last verify call that the thread-per-run pass vouched for (the others were decoded sequentially); synchronises
+extern "C" int flacgpu_debug_verify_hinted_frames(flacgpu_ctx *c, uint32_t *out)
+{
+	if(!c || !out || !c->d_vstate) return FLACGPU_ERR_BAD_ARG;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	VerifyState h;
+	if(hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, c->d_vstate, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	*out = h.hinted_ok;
 	return FLACGPU_OK;
 }
 

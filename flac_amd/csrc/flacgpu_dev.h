@@ -140,7 +140,11 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 struct PackOutArgs { uint8_t *out; uint64_t cap; uint64_t *offsets; uint64_t *total; uint64_t *state /* [nframes + 1] scratch */; };
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg,
-                       const PackOutArgs *po, bool *fused_out, hipStream_t s);
+                       const PackOutArgs *po, bool *fused_out, uint32_t *hints, uint32_t *hinted_frames, hipStream_t s);
+// hints (null: none wanted): [frame][channel][HINT_RUNS] bit offset, from the frame's first byte, at which the codes of each
+// 16-sample run of a residual-coded subframe start (the partition's parameter field when the run opens a partition) -- what the
+// hinted verify pass decodes from (flacgpu_decode_hinted.h).  *hinted_frames: the leading frames that got them.
+constexpr uint32_t HINT_RUNS = 256;
 // raw sample bytes -> interleaved int32 (flacgpu_stage.hip)
 struct StageParams {
 	uint32_t bytes;          // container bytes per sample: 1, 2, 3, 4
@@ -149,11 +153,15 @@ struct StageParams {
 };
 hipError_t launch_stage_raw(const StageParams &S, const void *d_raw, uint64_t nvalues, int32_t *d_pcm, uint32_t *d_err, hipStream_t s);
 // the self check (flacgpu_verify.hip, crc_check_kernel in flacgpu_kernels.hip)
-struct VerifyState { uint32_t first_bad; uint32_t pad[3]; };      // index of the first frame of the batch that failed (0xffffffff: none)
+struct VerifyState { uint32_t first_bad; uint32_t hinted_ok; uint32_t pad[2]; };      // index of the first frame of the batch that failed (0xffffffff: none); frames the hinted pass verified
 hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s);
+bool verify_hinted_covers(const DevParams &P);        // this configuration's frames can go through the thread-per-run verify pass
 size_t verify_decoded_bytes(const DevParams &P, uint32_t max_frames);     // the lane-interleaved buffer of decoded coded-channel samples
+// hints / nhinted: the pack kernel's run starts for the first nhinted frames (null / 0: none) -- those frames go through the
+// thread-per-run pass first and only the ones it cannot vouch for are decoded sequentially; fstat: [nframes] scratch
 hipError_t launch_verify(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t tail_n,
-                         uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result, hipStream_t s);
+                         uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result,
+                         const uint32_t *hints, uint32_t nhinted, uint32_t *fstat, hipStream_t s);
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);
 hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,
                           uint8_t *out, uint64_t out_cap, uint32_t nframes, hipStream_t s);

@@ -696,7 +696,8 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
                                                     uint32_t nmain, uint64_t first_frame_number,
                                                     const SubDecision *__restrict__ decisions,
                                                     uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
-                                                    FrameInfo *__restrict__ info, unsigned long long *__restrict__ dbg, const PackOut O)
+                                                    FrameInfo *__restrict__ info, unsigned long long *__restrict__ dbg, const PackOut O,
+                                                    uint32_t *__restrict__ hints)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -923,6 +924,8 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 				PSTAMP(4 + 4 * s);
 				if(active) {
 					uint32_t p = pos + woff + incl - mybits;
+					// the verify pass decodes a run per thread (flacgpu_decode_hinted.h): it is told where this one starts
+					if(hints && base0 == 0) hints[((size_t)f * C + s) * HINT_RUNS + (uint32_t)tid] = p;
 					if(starts) { or_bits(img, cap_words, p, k, plen); p += plen; }
 #pragma unroll
 					for(int t = 0; t < CHUNK; t++) {
@@ -1134,7 +1137,8 @@ static bool pack2_applicable(const DevParams &P)
 }
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                                const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, const PackOutArgs *po, bool *fused_out, hipStream_t s)
+                                const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, const PackOutArgs *po, bool *fused_out,
+                                uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
 {
 	static bool attr_set = false;
 	if(!attr_set) {
@@ -1145,6 +1149,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 	}
 	uint32_t f_lo = 0;
 	bool fused = false;
+	if(hinted_frames) *hinted_frames = 0;
 	PackOut O;
 	O.out = nullptr; O.cap = 0; O.offsets = nullptr; O.total = nullptr; O.state = nullptr; O.nframes_total = nframes;
 	if constexpr(MAXORD <= 16) {                  // predictors of more than 16 taps (-l 17..32) take the general kernel
@@ -1157,7 +1162,8 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 				O.out = po->out; O.cap = po->cap; O.offsets = po->offsets; O.total = po->total; O.state = po->state;
 				if(hipMemsetAsync(po->state, 0, ((size_t)f_lo + 1) * sizeof(uint64_t), s) != hipSuccess) return hipErrorUnknown;
 			}
-			if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O);
+			if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			if(hinted_frames) *hinted_frames = hints ? f_lo : 0;
 		}
 	}
 	if(f_lo < nframes) hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes - f_lo), dim3(TPB), lds, s, P, chan, nframes, tail_n, f_lo, first, dec, slots, fb, info);
@@ -1176,14 +1182,16 @@ size_t pack_lds_bytes(const DevParams &P)
 }
 
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, const PackOutArgs *po, bool *fused_out, hipStream_t s)
+                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, const PackOutArgs *po, bool *fused_out,
+                       uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
 {
 	const size_t lds = pack_lds_bytes(P);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
-	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, s);
-	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, s);
-	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, s);
-	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, s);
+	if(P.blocksize > HINT_RUNS * CHUNK) hints = nullptr;          // one run per thread and pass: blocks of up to 4096 samples
+	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
 }
 hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s)
 {

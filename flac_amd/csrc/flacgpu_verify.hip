@@ -37,17 +37,130 @@ __device__ __forceinline__ uint32_t dot24_asm(const int32_t (&a)[M], const int32
 }
 #define FLACGPU_DOT24(a, b) flacgpu::dot24_asm(a, b)
 #include "flacgpu_decode.h"
+#include "flacgpu_decode_hinted.h"
 
 namespace flacgpu {
+static_assert(HINT_RUNS == HINT_MAX_RUNS && HINT_RUN == CHUNK, "the pack kernel's runs are the hinted pass's runs");
+
+// ---- the hinted pass: a workgroup per frame, a thread per 16-sample run (flacgpu_decode_hinted.h has the reasoning and every
+// decision; this kernel is its steps with the per-run work spread over the threads).  fstat[f] = 0: the frame is verified;
+// 1: it goes to the sequential decoder below.
+struct HintedShared { uint32_t hs[HINT_RUNS + 1]; uint32_t ends[HINT_RUNS]; int32_t q[HINT_MAX_ORDER]; };
+static size_t hinted_lds_bytes(const DevParams &P) { return (size_t)(16 + P.blocksize) * 4 + sizeof(HintedShared); }
+
+template <int MAXORD>
+__global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, const uint8_t *__restrict__ frames, const uint32_t *__restrict__ frame_bytes,
+                                                            const uint64_t *__restrict__ offsets, uint32_t nframes, uint32_t nhinted, uint64_t first_frame_number,
+                                                            const int32_t *__restrict__ pcm, const uint32_t *__restrict__ hints, uint32_t *__restrict__ fstat,
+                                                            VerifyState *__restrict__ state)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const uint32_t f = blockIdx.x, tid = threadIdx.x;
+	const uint32_t C = P.channels, N = P.blocksize;
+	const uint32_t fb = f < nhinted ? frame_bytes[f] : 0xffffffffu;
+	if(fb == 0xffffffffu || fb < 6 || fb > P.slot_bytes) { if(tid == 0) fstat[f] = 1; return; }        // (the same for every thread)
+	int32_t *y = (int32_t *)smem;
+	HintedShared *sh = (HintedShared *)(y + 16 + N);
+	// The frame is read where it lies, as aligned words of global memory: it was written a moment ago and sits in the L2.  (An LDS
+	// copy behind the generic pointers of BitReader / PeekSrc does not compile with this toolchain: the local-to-generic cast's null
+	// check comes out as an instruction the assembler rejects.)
+	const uint8_t *p = frames + offsets[f], *hi = frames + offsets[nframes];
+	const uint32_t mis = (uint32_t)((uintptr_t)p & 3);
+	const uint32_t *w0g = (const uint32_t *)(p - mis);
+	const uint32_t nw = (mis + fb + 3) / 4, avail = (uint32_t)(((hi - 1) - (p - mis)) / 4) + 1;        // words up to the one holding the buffer's last byte
+	if(tid < 16) y[tid] = 0;
+	PeekSrc S;
+	S.w0 = w0g; S.nwords = nw + 2 < avail ? nw + 2 : avail; S.skip = mis * 8; S.limit = (fb - 2) * 8;
+	DecodeExpect E;
+	E.channels = C; E.bps = P.bps; E.blocksize = N; E.n = N; E.frame_number = first_frame_number + f;
+	FrameHead FH;
+	uint32_t pos;
+	{
+		BitReader b;
+		br_init_at(b, S, 0);
+		if(decode_frame_header(b, p, E, FH) != DEC_OK) { if(tid == 0) fstat[f] = 1; return; }
+		pos = (uint32_t)br_pos(b);
+	}
+	const uint32_t n = FH.n, nruns = n / HINT_RUN;
+	uint32_t suspect = 0;
+	bool bail = false;
+	for(uint32_t ch = 0; ch < C; ch++) {
+		const HintedSub H = hinted_subframe_head(S, pos, coded_bps(E.bps, FH.ca, ch), n);         // (every thread: the same answer)
+		if(!H.ok || H.order > (uint32_t)MAXORD) { bail = true; break; }
+		// the signal the input implies for this coded channel, shifted down by the wasted bits (which must be zero in it)
+		for(uint32_t i = tid; i < n; i += TPB) {
+			const int64_t v = coded_expectation(pcm + ((size_t)f * N + i) * C, FH.ca, ch);
+			const int64_t ys = v >> H.wasted;
+			suspect |= (uint32_t)((v & (((int64_t)1 << H.wasted) - 1)) != 0) | (uint32_t)(ys != (int64_t)(int32_t)ys);
+			y[16 + i] = (int32_t)ys;
+		}
+		if(H.type >= 2) {
+			if(tid < nruns) sh->hs[tid] = hints[((size_t)f * C + ch) * HINT_RUNS + tid];
+			if(tid < HINT_MAX_ORDER) sh->q[tid] = tid >= H.order ? 0 : H.type == 3 ? peek_signed(S, H.pos_q + tid * H.prec, H.prec) : hinted_fixed_tap(H.order, tid);
+		}
+		__syncthreads();
+		if(H.type == 0) {
+			const int32_t v = peek_signed(S, H.pos_body, H.sb);
+			for(uint32_t i = tid; i < n; i += TPB) suspect |= (uint32_t)(y[16 + i] != v);
+			pos = H.end_fixed;
+		}
+		else if(H.type == 1) {
+			for(uint32_t i = tid; i < n; i += TPB) suspect |= (uint32_t)(peek_signed(S, H.pos_body + i * H.sb, H.sb) != y[16 + i]);
+			pos = H.end_fixed;
+		}
+		else {
+			if(tid < H.order) suspect |= (uint32_t)(peek_signed(S, H.pos_body + tid * H.sb, H.sb) != y[16 + tid]);
+			if(tid == 0) suspect |= (uint32_t)(sh->hs[0] != H.r0);
+			if(tid < nruns) {
+				const uint32_t t = tid, part = (t * HINT_RUN) / H.psize, t0 = part * H.psize / HINT_RUN;
+				const uint32_t kpos = sh->hs[t0], mystart = sh->hs[t];
+				uint32_t e = 0xffffffffu;
+				if(kpos + H.plen > S.limit || mystart > S.limit) suspect = 1;
+				else {
+					const uint32_t k = peek_bits(S, kpos, H.plen);
+					if(k == H.esc) suspect = 1;                     // raw partitions: the sequential decoder's business
+					else {
+						int32_t yw[32], q[MAXORD];
+#pragma unroll
+						for(int u = 0; u < 32; u++) yw[u] = y[t * HINT_RUN + (uint32_t)u];
+#pragma unroll
+						for(int j = 0; j < MAXORD; j++) q[j] = sh->q[j];
+						suspect |= hinted_run<MAXORD, int32_t>(S, mystart + (t == t0 ? H.plen : 0), k, t == 0 ? H.order : 0, yw, q, H, &e);
+					}
+				}
+				sh->ends[t] = e;
+			}
+			__syncthreads();
+			if(tid + 1 < nruns) suspect |= (uint32_t)(sh->ends[tid] != sh->hs[tid + 1]);
+			pos = sh->ends[nruns - 1];
+		}
+		__syncthreads();                                        // y, hs, ends, q are rewritten for the next channel
+	}
+	if(!bail) {
+		// zero bits up to the byte boundary, and the body ends exactly where the CRC-16 starts
+		const uint32_t rem = pos & 7u;
+		if(pos > S.limit) suspect = 1;
+		else if(rem && peek_bits(S, pos, 8 - rem) != 0) suspect = 1;
+		else if(pos + (rem ? 8 - rem : 0) != S.limit) suspect = 1;
+	}
+	else suspect = 1;
+	const int any = __syncthreads_or((int)suspect);
+	if(tid == 0) {
+		fstat[f] = any ? 1u : 0u;
+		if(!any) atomicAdd(&state->hinted_ok, 1u);
+	}
+}
 
 // per-frame verdict of the decode pass: [3:0] channel assignment, bit 8 set = decodes
 template <int MAXORD, typename ST>
 __global__ __launch_bounds__(64) void verify_kernel(const DevParams P, const uint8_t *__restrict__ frames, const uint32_t *__restrict__ frame_bytes,
                                                     const uint64_t *__restrict__ offsets, uint32_t nframes, uint32_t tail_n, uint64_t first_frame_number,
-                                                    ST *__restrict__ decoded, uint32_t *__restrict__ finfo, VerifyState *__restrict__ state)
+                                                    ST *__restrict__ decoded, uint32_t *__restrict__ finfo, VerifyState *__restrict__ state,
+                                                    const uint32_t *__restrict__ fstat)
 {
 	const uint32_t f = blockIdx.x * 64u + threadIdx.x;
 	if(f >= nframes) return;
+	if(fstat && fstat[f] == 0) { finfo[f] = 0x200u; return; }          // verified by the hinted pass: nothing to decode, nothing to compare
 	const uint32_t fb = frame_bytes[f];
 	const uint32_t C = P.channels, N = P.blocksize;
 	DecodeExpect E;
@@ -86,7 +199,9 @@ __global__ __launch_bounds__(TPB) void verify_compare_kernel(const DevParams P, 
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t wb = blockIdx.x, i0 = blockIdx.y * CMP_T;
 	const uint32_t C = P.channels, N = P.blocksize;
-	if(tid < 64) { const uint32_t f = wb * 64u + (uint32_t)tid; info[tid] = f < nframes ? finfo[f] : 0u; }
+	uint32_t mine = 0;
+	if(tid < 64) { const uint32_t f = wb * 64u + (uint32_t)tid; mine = f < nframes ? finfo[f] : 0u; info[tid] = mine; }
+	if(!__syncthreads_or((int)(mine & 0x100u))) return;            // none of these 64 frames was decoded here (hinted pass, or not decodable)
 	uint32_t badmask_lo = 0, badmask_hi = 0;                        // frames (of this wavefront's share) with a differing sample
 	for(uint32_t ch = 0; ch < C; ch++) {
 		__syncthreads();
@@ -138,14 +253,15 @@ __global__ __launch_bounds__(64) void verify_detail_kernel(const DevParams P, co
 	*result = R;
 }
 
-__global__ void verify_reset_kernel(VerifyState *state) { state->first_bad = 0xffffffffu; }
+__global__ void verify_reset_kernel(VerifyState *state) { state->first_bad = 0xffffffffu; state->hinted_ok = 0; }
 
 template <int MAXORD, typename ST>
 static hipError_t launch_verify_t(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t tail_n,
-                                  uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result, hipStream_t s)
+                                  uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result,
+                                  const uint32_t *fstat, hipStream_t s)
 {
 	const uint32_t nwb = (nframes + 63) / 64;
-	hipLaunchKernelGGL((verify_kernel<MAXORD, ST>), dim3(nwb), dim3(64), 0, s, P, frames, fb, offsets, nframes, tail_n, first, (ST *)decoded, finfo, state);
+	hipLaunchKernelGGL((verify_kernel<MAXORD, ST>), dim3(nwb), dim3(64), 0, s, P, frames, fb, offsets, nframes, tail_n, first, (ST *)decoded, finfo, state, fstat);
 	hipLaunchKernelGGL((verify_compare_kernel<ST>), dim3(nwb, (P.blocksize + CMP_T - 1) / CMP_T), dim3(TPB), 0, s, P, nframes, tail_n, pcm, (const ST *)decoded, finfo, state);
 	hipLaunchKernelGGL((verify_detail_kernel<MAXORD, ST>), dim3(1), dim3(64), 0, s, P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, state, result);
 	return hipGetLastError();
@@ -156,16 +272,45 @@ size_t verify_decoded_bytes(const DevParams &P, uint32_t max_frames)
 	const bool wide = P.bps == 32 && P.channels == 2;
 	return (size_t)((max_frames + 63) / 64) * 64 * P.channels * P.blocksize * (wide ? 8 : 4);
 }
+bool verify_hinted_covers(const DevParams &P)
+{
+	const bool wide = P.bps == 32 && P.channels == 2;
+	return !wide && P.blocksize % HINT_RUN == 0 && P.blocksize / HINT_RUN <= HINT_MAX_RUNS && P.max_lpc_order <= HINT_MAX_ORDER && hinted_lds_bytes(P) <= 64 * 1024;
+}
+template <int MAXORD>
+static hipError_t launch_hinted_t(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t nhinted, uint64_t first,
+                                  const int32_t *pcm, const uint32_t *hints, uint32_t *fstat, VerifyState *state, hipStream_t s)
+{
+	static bool attr_set = false;
+	if(!attr_set) {
+		const hipError_t e = hipFuncSetAttribute((const void *)verify_hinted_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		if(e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL((verify_hinted_kernel<MAXORD>), dim3(nframes), dim3(TPB), hinted_lds_bytes(P), s, P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state);
+	return hipGetLastError();
+}
 hipError_t launch_verify(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t tail_n,
-                         uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result, hipStream_t s)
+                         uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result,
+                         const uint32_t *hints, uint32_t nhinted, uint32_t *fstat, hipStream_t s)
 {
 	hipLaunchKernelGGL(verify_reset_kernel, dim3(1), dim3(1), 0, s, state);
 	hipError_t e = launch_crc_check(frames, fb, offsets, nframes, state, s);
 	if(e != hipSuccess) return e;
 	const bool wide = P.bps == 32 && P.channels == 2;            // a 33-bit side channel can occur (stream_encoder.c:3831-3835)
 	const uint32_t m = P.max_lpc_order;
-#define GO(M) (wide ? launch_verify_t<M, int64_t>(P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, decoded, finfo, state, result, s) \
-                    : launch_verify_t<M, int32_t>(P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, decoded, finfo, state, result, s))
+	// frames the pack kernel left hints for: a thread per run first; what that pass cannot vouch for is decoded sequentially below
+	if(tail_n && nhinted >= nframes) nhinted = nframes - 1;      // (the short last block never has hints)
+	if(!hints || !fstat || !verify_hinted_covers(P)) nhinted = 0;
+	if(nhinted) {
+		if(m <= 8) e = launch_hinted_t<8>(P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, s);
+		else if(m <= 12) e = launch_hinted_t<12>(P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, s);
+		else e = launch_hinted_t<16>(P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, s);
+		if(e != hipSuccess) return e;
+	}
+	else fstat = nullptr;
+#define GO(M) (wide ? launch_verify_t<M, int64_t>(P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, decoded, finfo, state, result, fstat, s) \
+                    : launch_verify_t<M, int32_t>(P, frames, fb, offsets, nframes, tail_n, first, pcm, scratch, decoded, finfo, state, result, fstat, s))
 	if(m <= 8) e = GO(8);
 	else if(m <= 12) e = GO(12);
 	else e = GO(32);

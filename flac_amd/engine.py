@@ -326,6 +326,15 @@ class FrameEngine:
         if r != 0:
             raise FlacGpuError("flacgpu_verify_batch_device: %s" % self.lib.flacgpu_strerror(r).decode())
 
+    def verify_hinted_frames(self):
+        """development aid: frames of the most recent verify call that the thread-per-run pass vouched for (synchronises)"""
+        n = C.c_uint32(0)
+        self.lib.flacgpu_debug_verify_hinted_frames.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        r = self.lib.flacgpu_debug_verify_hinted_frames(self.ctx, C.byref(n))
+        if r != 0:
+            raise FlacGpuError("flacgpu_debug_verify_hinted_frames: %s" % self.lib.flacgpu_strerror(r).decode())
+        return int(n.value)
+
     def last_batch_info(self, nframes):
         sub = (SubframeInfo * (nframes * self.channels))()
         ca = np.zeros(nframes, dtype=np.uint8)

@@ -215,6 +215,9 @@ int flacgpu_device_probe(void);
  * (lpc_error a, error_scale b), mode 2 the fixed-predictor estimate of fixed.c:284-288 on (total_error a, data_len b)
  * widened to double, mode 3 the device library's own log (informational).  Returns 0 or a negative FLACGPU_ERR_*. */
 int flacgpu_debug_log_kat(int device, uint32_t mode, const double *a, const double *b, size_t n, double *out);
+/* Development aid: how many frames of the most recent verify call were verified by the thread-per-run pass; the
+ * rest went through the sequential decoder.  Synchronises the device. */
+int flacgpu_debug_verify_hinted_frames(flacgpu_ctx *ctx, uint32_t *out);
 
 const char *flacgpu_strerror(int code);
 int flacgpu_device_count(void);

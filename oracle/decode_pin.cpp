@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "../flac_amd/csrc/flacgpu_decode.h"
+#include "../flac_amd/csrc/flacgpu_decode_hinted.h"
 
 using namespace flacgpu;
 
@@ -52,4 +53,41 @@ extern "C" int decodepin_verify_batch(const uint8_t *frames, const uint32_t *fb,
 	if(maxord <= 12) return GO(12);
 	return GO(32);
 #undef GO
+}
+
+// ---- the hinted pass (flacgpu_decode_hinted.h): per-frame verdicts 0 verified / 1 suspect, with the hints given -----------------
+// hints: [nframes][channels][HINT_MAX_RUNS]
+extern "C" int decodepin_make_hints(const uint8_t *frames, const uint32_t *fb, uint32_t nframes, uint32_t channels, uint32_t bps, uint32_t blocksize,
+                                    uint32_t tail, uint64_t first_frame, uint32_t *hints, uint8_t *covered)
+{
+	size_t total = 0, off = 0;
+	for(uint32_t f = 0; f < nframes; f++) total += fb[f];
+	int n = 0;
+	for(uint32_t f = 0; f < nframes; f++) {
+		DecodeExpect E = {channels, bps, blocksize, (f + 1 == nframes && tail) ? tail : blocksize, first_frame + f};
+		covered[f] = make_hints_host(frames + off, fb[f], frames + total, E, hints + (size_t)f * channels * HINT_MAX_RUNS) == 0;
+		n += covered[f];
+		off += fb[f];
+	}
+	return n;
+}
+extern "C" int decodepin_verify_hinted(const uint8_t *frames, const uint32_t *fb, uint32_t nframes, uint32_t channels, uint32_t bps, uint32_t blocksize,
+                                       uint32_t tail, uint64_t first_frame, const int32_t *pcm, const uint32_t *hints, uint32_t maxord, uint8_t *suspect)
+{
+	size_t total = 0, off = 0;
+	for(uint32_t f = 0; f < nframes; f++) total += fb[f];
+	int n = 0;
+	for(uint32_t f = 0; f < nframes; f++) {
+		DecodeExpect E = {channels, bps, blocksize, (f + 1 == nframes && tail) ? tail : blocksize, first_frame + f};
+		const int32_t *fp = pcm + (size_t)f * blocksize * channels;
+		const uint32_t *h = hints + (size_t)f * channels * HINT_MAX_RUNS;
+		int st;
+		if(maxord <= 8) st = verify_frame_hinted_host<8>(frames + off, fb[f], frames + total, E, fp, h);
+		else if(maxord <= 12) st = verify_frame_hinted_host<12>(frames + off, fb[f], frames + total, E, fp, h);
+		else st = verify_frame_hinted_host<16>(frames + off, fb[f], frames + total, E, fp, h);
+		suspect[f] = (uint8_t)st;
+		n += st;
+		off += fb[f];
+	}
+	return n;
 }

@@ -264,3 +264,146 @@ def test_escaped_partitions_and_rice2_decode():
         bad[40, 0] += 1                              # inside the all-zero escaped partition
         st, r = pin_verify(frame, fb, bad, bps, N, first=5)
         assert st == 1 and r.sample == 40 and r.got == int(x[40]) and r.expected == int(x[40]) + 1
+
+
+# ---- the hinted pass (flacgpu_decode_hinted.h): a thread per 16-sample run, hints from the pack kernel, hints NOT trusted --------
+HRUNS = 256
+
+
+def _hinted_lib():
+    lib = _pin()
+    lib.decodepin_make_hints.restype = C.c_int
+    lib.decodepin_make_hints.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.decodepin_verify_hinted.restype = C.c_int
+    lib.decodepin_verify_hinted.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                            C.c_uint32, C.c_void_p]
+    return lib
+
+
+def _frames_args(data, fb, pcm, blocksize):
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    n, ch = pcm.shape
+    nfr = len(fb)
+    tail = n - (nfr - 1) * blocksize
+    tail = 0 if tail == blocksize else tail
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    fbs = np.ascontiguousarray(fb, dtype=np.uint32)
+    full = np.zeros((nfr * blocksize, ch), dtype=np.int32)
+    full[:n] = pcm
+    return buf, fbs, full, nfr, ch, tail
+
+
+def make_hints(data, fb, pcm, bps, blocksize, first=0):
+    lib = _hinted_lib()
+    buf, fbs, full, nfr, ch, tail = _frames_args(data, fb, pcm, blocksize)
+    hints = np.zeros((nfr, ch, HRUNS), dtype=np.uint32)
+    covered = np.zeros(nfr, dtype=np.uint8)
+    lib.decodepin_make_hints(buf.ctypes.data, fbs.ctypes.data, nfr, ch, bps, blocksize, tail, first, hints.ctypes.data, covered.ctypes.data)
+    return hints, covered.astype(bool)
+
+
+def hinted_verify(data, fb, pcm, bps, blocksize, hints, first=0, maxord=16):
+    lib = _hinted_lib()
+    buf, fbs, full, nfr, ch, tail = _frames_args(data, fb, pcm, blocksize)
+    hints = np.ascontiguousarray(hints, dtype=np.uint32)
+    suspect = np.zeros(nfr, dtype=np.uint8)
+    lib.decodepin_verify_hinted(buf.ctypes.data, fbs.ctypes.data, nfr, ch, bps, blocksize, tail, first, full.ctypes.data, hints.ctypes.data, maxord, suspect.ctypes.data)
+    return suspect.astype(bool)
+
+
+def _per_frame_sequential(data, fb, pcm, bps, bs, first=0):
+    """the sequential decoder's verdict for every frame on its own: True = fine"""
+    offs = np.concatenate([[0], np.cumsum(np.asarray(fb, dtype=np.int64))])
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    ok = []
+    for f in range(len(fb)):
+        part = pcm[f * bs:(f + 1) * bs]
+        st, _ = pin_verify(bytes(data[offs[f]:offs[f + 1]]), fb[f:f + 1], part, bps, len(part) if len(part) < bs else bs, first=first + f)
+        ok.append(st == 0)
+    return np.array(ok)
+
+
+# configurations the hinted pass covers: blocks of up to 4096 samples in whole 16-sample runs, orders up to 16, at most 32 bits
+HINTED_CASES = [c for c in CASES if c[3] <= 4096 and c[3] % 16 == 0 and "max_lpc_order" not in c[6]]
+
+
+@pytest.mark.parametrize("case", HINTED_CASES, ids=lambda c: "%dch-%db-l%d-bs%d-%s" % (c[0], c[1], c[2], c[3], c[5]))
+def test_hinted_pass_accepts_the_oracles_frames_with_honest_hints(case):
+    ch, bps, level, bs, n, family, kw = case
+    pcm = _signal(family, n, ch, bps, 31)
+    enc = po.oracle_encode(pcm, bps, 44100, level, first_frame=77, blocksize=bs, **kw)
+    hints, covered = make_hints(enc["data"], enc["frame_bytes"], pcm, bps, bs, first=77)
+    suspect = hinted_verify(enc["data"], enc["frame_bytes"], pcm, bps, bs, hints, first=77)
+    nfull = n // bs
+    wide = bps == 32 and ch == 2                      # a 33-bit side channel can occur: such subframes are the sequential decoder's
+    for f in range(len(covered)):
+        if f < nfull and covered[f] and not wide:
+            assert not suspect[f], f
+    if not wide:
+        assert covered[:nfull].all()                   # every full frame of these configurations is within the pass
+
+
+@pytest.mark.parametrize("case", HINTED_CASES[:8], ids=lambda c: "%dch-%db-l%d-bs%d-%s" % (c[0], c[1], c[2], c[3], c[5]))
+def test_hinted_pass_flags_every_changed_sample(case):
+    ch, bps, level, bs, n, family, kw = case
+    pcm = _signal(family, n, ch, bps, 32)
+    enc = po.oracle_encode(pcm, bps, 44100, level, blocksize=bs, **kw)
+    hints, covered = make_hints(enc["data"], enc["frame_bytes"], pcm, bps, bs)
+    rng = np.random.default_rng(8)
+    for trial in range(12):
+        bad = pcm.copy()
+        i, c = int(rng.integers(0, (n // bs) * bs)), int(rng.integers(0, ch))
+        bad[i, c] ^= 1 << int(rng.integers(0, bps - 1))
+        suspect = hinted_verify(enc["data"], enc["frame_bytes"], bad, bps, bs, hints)
+        assert suspect[i // bs]
+        others = np.delete(np.arange(len(suspect)), i // bs)
+        assert not suspect[others][covered[others] & (others < n // bs)].any() or (bps == 32 and ch == 2)
+
+
+def test_hinted_pass_is_sound_under_damage_and_arbitrary_hints():
+    """whatever is done to the frame bytes (CRC aside: its own kernel checks that) or to the hints: a frame the hinted pass
+    accepts is a frame the sequential decoder accepts"""
+    rng = np.random.default_rng(2024)
+    pcm = signals.music(4096 * 6, 2, 16, seed=41)
+    for level in (8, 5, 2):
+        bs = 4096 if level >= 3 else 1152
+        pcm_l = pcm[:(len(pcm) // bs) * bs]
+        enc = po.oracle_encode(pcm_l, 16, 44100, level, blocksize=bs)
+        fb = enc["frame_bytes"]
+        offs = np.concatenate([[0], np.cumsum(fb.astype(np.int64))])
+        hints, covered = make_hints(enc["data"], fb, pcm_l, 16, bs)
+        if bs % 16 == 0:
+            assert covered.all()
+        accepted_damaged = 0
+        for trial in range(150):
+            d = np.frombuffer(enc["data"], dtype=np.uint8).copy()
+            h = hints.copy()
+            f = int(rng.integers(0, len(fb)))
+            kind = trial % 5
+            if kind in (0, 1):                                    # a flipped bit anywhere in the body
+                pos = int(offs[f]) + int(rng.integers(0, fb[f] - 2))
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+            if kind in (1, 2):                                    # a hint moved by a few bits
+                c, t = int(rng.integers(0, 2)), int(rng.integers(0, bs // 16))
+                h[f, c, t] = max(0, int(h[f, c, t]) + int(rng.integers(-40, 41)))
+            if kind == 3:                                         # hints of another frame
+                h[f] = hints[(f + 1) % len(fb)]
+            if kind == 4:                                         # random hints
+                h[f] = rng.integers(0, 8 * int(fb[f]), size=h[f].shape, dtype=np.uint32)
+            suspect = hinted_verify(d.tobytes(), fb, pcm_l, 16, bs, h)
+            seq_ok = _per_frame_sequential(d.tobytes(), fb, pcm_l, 16, bs)
+            # (the sequential verdict here ignores the CRC-16, as the hinted pass does: compare bodies)
+            for g in range(len(fb)):
+                if not suspect[g]:
+                    body_ok = seq_ok[g]
+                    if not body_ok:
+                        # the only way the sequential pin rejects what the hinted pass accepts is the CRC footer it also checks
+                        dd = d[offs[g]:offs[g + 1]]
+                        lib = po.load_oracle()
+                        crc = lib.fo_crc16(dd[:-2].ctypes.data, dd.size - 2)
+                        assert (int(dd[-2]) << 8 | int(dd[-1])) != crc, (level, trial, g)
+                        accepted_damaged += 1
+            if kind in (2, 3, 4) and bs % 16 == 0:
+                assert suspect[f] or np.array_equal(h[f], hints[f])   # wrong hints never verify a frame
+        # a flipped bit that the hinted pass accepts must be one that changes nothing but the CRC's validity: there is none in the body
+        assert accepted_damaged == 0

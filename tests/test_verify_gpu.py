@@ -154,3 +154,120 @@ def test_large_batch_verifies_and_one_damaged_frame_in_16384_is_found():
         assert v.status == 2 and v.frame_number == 1000 + f
     finally:
         eng.close()
+
+
+# ---- the hinted pass (flacgpu_decode_hinted.h, verify_hinted_kernel): a thread per 16-sample run, from the pack kernel's hints -----
+def _encode_on_device(eng, pcm, nfr, first):
+    import torch
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    cap = eng.max_output_bytes(nfr)
+    d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    d_fb = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+    d_total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    eng.encode_device(d_pcm.data_ptr(), nfr, d_out.data_ptr(), cap, d_fb.data_ptr(), d_total.data_ptr(), first_frame_number=first)
+    torch.cuda.synchronize()
+    return d_pcm, d_out, d_fb, int(d_total.item())
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dch-%db-l%d-bs%d-%s" % (c[0], c[1], c[2], c[3], c[5]))
+def test_hinted_pass_vouches_for_the_frames_it_covers(case):
+    """verify right after the encode, on the encode's own output: the frames of configurations the pass covers (blocks of up to 4096
+    samples in whole 16-sample runs, orders up to 16, no 33-bit side channel) never reach the sequential decoder"""
+    import torch
+    ch, bps, level, bs, n, family, kw = case
+    nfr = n // bs                                              # full blocks only: the short last block is the general pack kernel's
+    pcm = _signal(family, n, ch, bps, 33)[:nfr * bs]
+    s = flac_amd.make_settings(ch, bps, 44100, level, blocksize=bs, streamable_subset=0, **{k: v for k, v in kw.items() if k in ("max_lpc_order", "exhaustive")})
+    eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=nfr)
+    try:
+        eng.set_verify(True)                                   # (allocates the verify buffers, the hints among them)
+        d_pcm, d_out, d_fb, total = _encode_on_device(eng, pcm, nfr, 500)
+        d_res = torch.zeros(32, dtype=torch.uint8, device="cuda")
+        eng.verify_device(d_out.data_ptr(), d_fb.data_ptr(), nfr, d_pcm.data_ptr(), d_res.data_ptr(), first_frame_number=500)
+        torch.cuda.synchronize()
+        assert _vr(d_res).status == 0
+        hinted = eng.verify_hinted_frames()
+        covered = bs <= 4096 and bs % 16 == 0 and not (bps == 32 and ch == 2) and kw.get("max_lpc_order", 0) <= 16
+        if bs == 4096 and covered and ch <= 2:
+            assert hinted == nfr, (hinted, nfr)                 # (smaller blocks may pick partitions shorter than a run: those frames go the long way)
+        elif not covered:
+            assert hinted == 0
+    finally:
+        eng.close()
+
+
+def test_hinted_pass_and_sequential_decoder_give_one_verdict(monkeypatch):
+    """FLACGPU_VERIFY_FORCE_HINTS=1: the hints of the last encode are used whatever frames are handed in -- here copies with a
+    changed input sample, a flipped bit (the CRC re-made, so that the body itself must give it away), hints that belong to other
+    frames: the verdict and its location are the host decoder's, and the frames the pass vouched for are all the others"""
+    import torch
+    from oracle import pyoracle as po
+    monkeypatch.setenv("FLACGPU_VERIFY_FORCE_HINTS", "1")
+    lib = po.load_oracle()
+    rng = np.random.default_rng(77)
+    for level, bps in ((8, 16), (5, 16), (8, 24)):
+        nfr, bs = 24, 4096
+        pcm = signals.music(bs * nfr, 2, bps, seed=50 + level)
+        eng = flac_amd.FrameEngine(flac_amd.make_settings(2, bps, 44100, level), device=0, max_batch_frames=nfr)
+        try:
+            eng.set_verify(True)
+            d_pcm, d_out, d_fb, total = _encode_on_device(eng, pcm, nfr, 9)
+            data = d_out[:total].cpu().numpy().tobytes()
+            fb = d_fb.cpu().numpy().astype(np.uint32)
+            offs = np.concatenate([[0], np.cumsum(fb.astype(np.int64))])
+            v = _device_verify(eng, data, fb, pcm, bs, first=9)          # a copy of the frames: forced hints
+            assert v.status == 0 and eng.verify_hinted_frames() == nfr
+            for trial in range(8):
+                bad = pcm.copy()
+                i, c = int(rng.integers(0, bs * nfr)), int(rng.integers(0, 2))
+                bad[i, c] ^= 1 << int(rng.integers(0, bps - 1))
+                v = _device_verify(eng, data, fb, bad, bs, first=9)
+                hst, h = host_verify(data, fb, bad, bps, bs, first=9)
+                assert v.status == hst == 1
+                assert (v.frame_number, v.channel, v.sample, v.expected, v.got) == (h.frame_number, h.channel, h.sample, h.expected, h.got)
+                assert eng.verify_hinted_frames() == nfr - 1
+            for trial in range(12):
+                d = np.frombuffer(data, dtype=np.uint8).copy()
+                f = int(rng.integers(0, nfr))
+                pos = int(offs[f]) + int(rng.integers(6, fb[f] - 2))
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+                body = d[offs[f]:offs[f + 1] - 2]
+                crc = lib.fo_crc16(body.ctypes.data, body.size)
+                d[offs[f + 1] - 2], d[offs[f + 1] - 1] = crc >> 8, crc & 0xff
+                v = _device_verify(eng, d.tobytes(), fb, pcm, bs, first=9)
+                hst, h = host_verify(d.tobytes(), fb, pcm, bps, bs, first=9)
+                assert v.status == hst and v.status in (1, 2) and v.frame_number == h.frame_number == 9 + f
+                if hst == 1:
+                    assert (v.channel, v.sample, v.expected, v.got) == (h.channel, h.sample, h.expected, h.got)
+                assert eng.verify_hinted_frames() == nfr - 1
+            # another batch's frames under this batch's hints: nothing is vouched for wrongly, the batch still verifies (sequentially)
+            pcm2 = signals.music(bs * nfr, 2, bps, seed=90 + level)
+            eng2 = flac_amd.FrameEngine(flac_amd.make_settings(2, bps, 44100, level), device=0, max_batch_frames=nfr)
+            data2, fb2 = eng2.encode(pcm2, first_frame_number=9)
+            eng2.close()
+            v = _device_verify(eng, data2, fb2, pcm2, bs, first=9)
+            assert v.status == 0
+            assert eng.verify_hinted_frames() < nfr            # (a frame of silence could chain by accident; music does not)
+        finally:
+            eng.close()
+
+
+def test_in_place_damage_after_the_encode_is_found_through_the_hinted_path():
+    import torch
+    nfr, bs = 512, 4096
+    pcm = np.concatenate([signals.music(bs * 128, 2, 16, seed=61)] * 4, axis=0)
+    eng = flac_amd.FrameEngine(flac_amd.make_settings(2, 16, 44100, 8), device=0, max_batch_frames=nfr)
+    try:
+        eng.set_verify(True)
+        d_pcm, d_out, d_fb, total = _encode_on_device(eng, pcm, nfr, 0)
+        d_res = torch.zeros(32, dtype=torch.uint8, device="cuda")
+        offs = torch.cumsum(d_fb.to(torch.int64), 0)
+        d_out[int(offs[300].item()) + 200] ^= 0x10               # frame 301
+        d_pcm[bs * 100 + 7, 1] += 1                              # frame 100: the first problem in stream order
+        eng.verify_device(d_out.data_ptr(), d_fb.data_ptr(), nfr, d_pcm.data_ptr(), d_res.data_ptr(), first_frame_number=0)
+        torch.cuda.synchronize()
+        v = _vr(d_res)
+        assert (v.status, v.frame_number, v.channel, v.sample) == (1, 100, 1, 7)
+        assert eng.verify_hinted_frames() == nfr - 2
+    finally:
+        eng.close()
