@@ -688,7 +688,9 @@ __device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[32], const int32
 	}
 }
 
-template <int MAXORD>
+// HINTS: the instantiation that also leaves its run starts behind for the verify pass (four more registers, which cost the
+// 8-tap instance its fifth workgroup per CU: only paid when verification is on)
+template <int MAXORD, bool HINTS>
 #ifndef PACK2_WAVES
 #define PACK2_WAVES 4
 #endif
@@ -925,7 +927,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 				if(active) {
 					uint32_t p = pos + woff + incl - mybits;
 					// the verify pass decodes a run per thread (flacgpu_decode_hinted.h): it is told where this one starts
-					if(hints && base0 == 0) hints[((size_t)f * C + s) * HINT_RUNS + (uint32_t)tid] = p;
+					if(HINTS && base0 == 0) hints[((size_t)f * C + s) * HINT_RUNS + (uint32_t)tid] = p;
 					if(starts) { or_bits(img, cap_words, p, k, plen); p += plen; }
 #pragma unroll
 					for(int t = 0; t < CHUNK; t++) {
@@ -1086,40 +1088,79 @@ __global__ __launch_bounds__(TPB) void compact_kernel(const uint8_t *__restrict_
 
 // ---------------------------------------------------------------------------------------------
 // crc_check_kernel: the CRC-16 footer of every frame of a batch (crc.c:376), for the self check (flacgpu_verify.hip).
-// One wavefront per frame; a lane takes 64-byte spans of the frame a byte at a time and shifts its remainder past what
-// follows (the span algebra of frame_crc16 above); frames sit at arbitrary byte offsets, hence byte loads.
+// One workgroup per frame.  Frames sit at arbitrary byte offsets of the output stream, but a CRC that starts at zero does not
+// see leading zero bytes: the frame is read as the ALIGNED words it lies in, with the bytes in front of it masked to zero, in
+// 44-byte spans (the span algebra of frame_crc16_p2: a word at a time through four 256-entry tables kept in LDS, a lane's
+// remainder shifted past the spans behind it, the short last span as words plus at most three bytes).
+// (The first version of this kernel read bytes with a table in global memory, a 64-step dependent chain per lane: 0.60 ms per
+// 16384 frames, as long as everything else the verify pass does.)
 // ---------------------------------------------------------------------------------------------
+// x^e mod P for the rare frame that is longer than the span table: square and multiply
+__device__ inline uint32_t gf16_xpow(uint64_t e)
+{
+	uint32_t r = 1, b = 2;
+	while(e) { if(e & 1) r = gf16_mul(r, b); b = gf16_mul(b, b); e >>= 1; }
+	return r;
+}
 __global__ __launch_bounds__(TPB) void crc_check_kernel(const uint8_t *__restrict__ frames, const uint32_t *__restrict__ frame_bytes,
                                                         const uint64_t *__restrict__ offsets, uint32_t nframes, VerifyState *__restrict__ state)
 {
-	const uint32_t f = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-	const int lane = (int)threadIdx.x & 63;
-	if(f >= nframes) return;
+	__shared__ uint16_t tab[4][256];
+	__shared__ uint32_t parts[TPB / 64];
+	const uint32_t f = blockIdx.x;
+	const int tid = (int)threadIdx.x;
 	const uint32_t len = frame_bytes[f];
-	bool bad = len == 0xffffffffu || len < 3;
-	if(!bad) {
-		const uint8_t *p = frames + offsets[f];
-		const uint32_t body = len - 2;
-		const uint32_t nsp = (body + CRC_SPAN - 1) / CRC_SPAN;
-		const uint32_t last_len = body - (nsp - 1) * CRC_SPAN;
-		uint32_t c = 0;
-		for(uint32_t sp = (uint32_t)lane; sp < nsp; sp += 64) {
-			const uint8_t *q = p + (size_t)sp * CRC_SPAN;
-			const uint32_t n = sp + 1 < nsp ? CRC_SPAN : last_len;
-			uint32_t cs = 0;
-			for(uint32_t k = 0; k < n; k++) cs = ((cs << 8) & 0xffffu) ^ g_crc_tables.tab[0][(cs >> 8) ^ q[k]];
-			if(sp + 1 < nsp) {
-				const uint32_t m = nsp - 2 - sp;                  // whole spans behind this one, then the last one
-				// frames beyond the span table (4 MiB) cannot come out of this engine
-				cs = m < CRC_MAX_SPANS ? gf16_mul(gf16_mul(cs, g_crc_tables.xspan[m]), g_crc_tables.xbyte[last_len]) : 0xffffffffu;
-			}
-			c ^= cs;
-		}
+	if(len == 0xffffffffu || len < 3) { if(tid == 0) atomicMin(&state->first_bad, f); return; }          // (the same for every thread)
+	for(uint32_t w = (uint32_t)tid; w < 4 * 256 / 2; w += TPB) ((uint32_t *)tab)[w] = ((const uint32_t *)g_crc_tables.tab)[w];
+	__syncthreads();
+	const uint8_t *p = frames + offsets[f];
+	const uint32_t mis = (uint32_t)((uintptr_t)p & 3), body = len - 2;
+	const uint32_t *w0 = (const uint32_t *)(p - mis);
+	const uint32_t total = mis + body;                                   // bytes of the aligned array that count
+	const uint32_t nsp = (total + CRC2_SPAN - 1) / CRC2_SPAN;
+	const uint32_t last_len = total - (nsp - 1) * CRC2_SPAN;             // 1..44
+	uint32_t c = 0;                     // low half: whole spans, shifted among themselves; high half: the last span
+	for(uint32_t sp = (uint32_t)tid; sp < nsp; sp += TPB) {
+		const uint32_t *wp = w0 + (size_t)sp * CRC2_WORDS;
+		const bool last = sp + 1 == nsp;
+		const uint32_t nload = last ? (last_len + 3) >> 2 : CRC2_WORDS;   // (nothing is read behind the word that holds the frame's last byte)
+		uint32_t w[CRC2_WORDS];
 #pragma unroll
-		for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
-		bad = c != (((uint32_t)p[body] << 8) | p[body + 1]);
+		for(int k = 0; k < (int)CRC2_WORDS; k++) w[k] = (uint32_t)k < nload ? __builtin_bswap32(wp[k]) : 0u;
+		if(sp == 0 && mis) w[0] &= 0xffffffffu >> (8 * mis);
+		const uint32_t nw = last ? last_len >> 2 : CRC2_WORDS;
+		uint32_t cs = 0, tailw = 0;
+#pragma unroll
+		for(int k = 0; k < (int)CRC2_WORDS; k++) {
+			if((uint32_t)k < nw) {
+				const uint32_t v = (cs << 16) ^ w[k];
+				cs = (uint32_t)tab[3][v >> 24] ^ tab[2][(v >> 16) & 0xffu] ^ tab[1][(v >> 8) & 0xffu] ^ tab[0][v & 0xffu];
+			}
+			else if((uint32_t)k == nw) tailw = w[k];
+		}
+		if(last) {
+			const uint32_t nb = last_len & 3u;
+			for(uint32_t j = 0; j < nb; j++) {
+				const uint32_t b = (tailw >> (24 - 8 * j)) & 0xffu;
+				cs = ((cs << 8) & 0xffffu) ^ tab[0][(cs >> 8) ^ b];
+			}
+			c ^= cs << 16;
+		}
+		else {
+			const uint32_t m = nsp - 2 - sp;                              // whole spans behind this one, then the last one
+			c ^= m == 0 ? cs : gf16_mul(cs, m < CRC2_MAX_SPANS ? (uint32_t)g_crc_tables.xspan44[m] : gf16_xpow((uint64_t)m * CRC2_SPAN * 8));
+		}
 	}
-	if(bad && lane == 0) atomicMin(&state->first_bad, f);
+#pragma unroll
+	for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
+	if((tid & 63) == 0) parts[tid >> 6] = c;
+	__syncthreads();
+	if(tid == 0) {
+		uint32_t crc = 0;
+		for(int w = 0; w < TPB / 64; w++) crc ^= parts[w];
+		crc = gf16_mul(crc & 0xffffu, g_crc_tables.xbyte[last_len]) ^ (crc >> 16);
+		if(crc != (((uint32_t)p[body] << 8) | p[body + 1])) atomicMin(&state->first_bad, f);
+	}
 }
 
 } // namespace flacgpu
@@ -1143,7 +1184,10 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 	static bool attr_set = false;
 	if(!attr_set) {
 		hipError_t e = hipFuncSetAttribute((const void *)pack_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if constexpr(MAXORD <= 16) { if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); }
+		if constexpr(MAXORD <= 16) {
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		}
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
@@ -1162,7 +1206,8 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 				O.out = po->out; O.cap = po->cap; O.offsets = po->offsets; O.total = po->total; O.state = po->state;
 				if(hipMemsetAsync(po->state, 0, ((size_t)f_lo + 1) * sizeof(uint64_t), s) != hipSuccess) return hipErrorUnknown;
 			}
-			if(f_lo) hipLaunchKernelGGL(pack2_kernel<MAXORD>, dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
 			if(hinted_frames) *hinted_frames = hints ? f_lo : 0;
 		}
 	}
@@ -1195,7 +1240,7 @@ hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes
 }
 hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s)
 {
-	hipLaunchKernelGGL(crc_check_kernel, dim3((nframes + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, frames, fb, offsets, nframes, state);
+	hipLaunchKernelGGL(crc_check_kernel, dim3(nframes), dim3(TPB), 0, s, frames, fb, offsets, nframes, state);
 	return hipGetLastError();
 }
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)

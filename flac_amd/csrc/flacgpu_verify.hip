@@ -46,7 +46,10 @@ static_assert(HINT_RUNS == HINT_MAX_RUNS && HINT_RUN == CHUNK, "the pack kernel'
 // decision; this kernel is its steps with the per-run work spread over the threads).  fstat[f] = 0: the frame is verified;
 // 1: it goes to the sequential decoder below.
 struct HintedShared { uint32_t hs[HINT_RUNS + 1]; uint32_t ends[HINT_RUNS]; int32_t q[HINT_MAX_ORDER]; };
-static size_t hinted_lds_bytes(const DevParams &P) { return (size_t)(16 + P.blocksize) * 4 + sizeof(HintedShared); }
+// the coded channels the input implies are staged in LDS: all of them in one pass over the PCM when they fit next to four other
+// workgroups (stereo does), else channel by channel
+__host__ __device__ inline bool hinted_stage_all(const DevParams &P) { return (size_t)P.channels * (16 + P.blocksize) * 4 <= 36 * 1024; }
+static size_t hinted_lds_bytes(const DevParams &P) { return (size_t)(hinted_stage_all(P) ? P.channels : 1) * (16 + P.blocksize) * 4 + sizeof(HintedShared); }
 
 template <int MAXORD>
 __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, const uint8_t *__restrict__ frames, const uint32_t *__restrict__ frame_bytes,
@@ -59,8 +62,9 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 	const uint32_t C = P.channels, N = P.blocksize;
 	const uint32_t fb = f < nhinted ? frame_bytes[f] : 0xffffffffu;
 	if(fb == 0xffffffffu || fb < 6 || fb > P.slot_bytes) { if(tid == 0) fstat[f] = 1; return; }        // (the same for every thread)
-	int32_t *y = (int32_t *)smem;
-	HintedShared *sh = (HintedShared *)(y + 16 + N);
+	const bool stage_all = hinted_stage_all(P);
+	int32_t *ybase = (int32_t *)smem;                               // [channels or 1][16 + N]: the value the input implies, NOT yet shifted by the wasted bits
+	HintedShared *sh = (HintedShared *)(ybase + (size_t)(stage_all ? C : 1) * (16 + N));
 	// The frame is read where it lies, as aligned words of global memory: it was written a moment ago and sits in the L2.  (An LDS
 	// copy behind the generic pointers of BitReader / PeekSrc does not compile with this toolchain: the local-to-generic cast's null
 	// check comes out as an instruction the assembler rejects.)
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 	const uint32_t mis = (uint32_t)((uintptr_t)p & 3);
 	const uint32_t *w0g = (const uint32_t *)(p - mis);
 	const uint32_t nw = (mis + fb + 3) / 4, avail = (uint32_t)(((hi - 1) - (p - mis)) / 4) + 1;        // words up to the one holding the buffer's last byte
-	if(tid < 16) y[tid] = 0;
+	for(uint32_t t = tid; t < 16 * (stage_all ? C : 1); t += TPB) ybase[(t >> 4) * (16 + N) + (t & 15)] = 0;
 	PeekSrc S;
 	S.w0 = w0g; S.nwords = nw + 2 < avail ? nw + 2 : avail; S.skip = mis * 8; S.limit = (fb - 2) * 8;
 	DecodeExpect E;
@@ -84,15 +88,42 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 	const uint32_t n = FH.n, nruns = n / HINT_RUN;
 	uint32_t suspect = 0;
 	bool bail = false;
+	if(stage_all) {
+		// one pass over the frame's input for all its coded channels
+		for(uint32_t i = tid; i < n; i += TPB) {
+			const int32_t *x = pcm + ((size_t)f * N + i) * C;
+			if(C == 2) {
+				const int2 lr = *(const int2 *)x;
+				const int32_t xx[2] = {lr.x, lr.y};
+#pragma unroll
+				for(uint32_t ch = 0; ch < 2; ch++) {
+					const int64_t v = coded_expectation(xx, FH.ca, ch);
+					suspect |= (uint32_t)(v != (int64_t)(int32_t)v);
+					ybase[ch * (16 + N) + 16 + i] = (int32_t)v;
+				}
+			}
+			else for(uint32_t ch = 0; ch < C; ch++) ybase[ch * (16 + N) + 16 + i] = x[ch];      // (independent channels)
+		}
+	}
 	for(uint32_t ch = 0; ch < C; ch++) {
 		const HintedSub H = hinted_subframe_head(S, pos, coded_bps(E.bps, FH.ca, ch), n);         // (every thread: the same answer)
 		if(!H.ok || H.order > (uint32_t)MAXORD) { bail = true; break; }
-		// the signal the input implies for this coded channel, shifted down by the wasted bits (which must be zero in it)
-		for(uint32_t i = tid; i < n; i += TPB) {
-			const int64_t v = coded_expectation(pcm + ((size_t)f * N + i) * C, FH.ca, ch);
-			const int64_t ys = v >> H.wasted;
-			suspect |= (uint32_t)((v & (((int64_t)1 << H.wasted) - 1)) != 0) | (uint32_t)(ys != (int64_t)(int32_t)ys);
-			y[16 + i] = (int32_t)ys;
+		int32_t *y = ybase + (stage_all ? (size_t)ch * (16 + N) : 0);
+		if(!stage_all)
+			for(uint32_t i = tid; i < n; i += TPB) {
+				const int64_t v = coded_expectation(pcm + ((size_t)f * N + i) * C, FH.ca, ch);
+				suspect |= (uint32_t)(v != (int64_t)(int32_t)v);
+				y[16 + i] = (int32_t)v;
+			}
+		__syncthreads();
+		// the subframe's own signal is that value shifted down by the wasted bits, which must be zero in it (in place: a thread
+		// shifts the samples it staged)
+		if(H.wasted) {
+			for(uint32_t i = tid; i < n; i += TPB) {
+				const int32_t v = y[16 + i];
+				suspect |= (uint32_t)((v & (int32_t)((1u << H.wasted) - 1u)) != 0);
+				y[16 + i] = v >> H.wasted;
+			}
 		}
 		if(H.type >= 2) {
 			if(tid < nruns) sh->hs[tid] = hints[((size_t)f * C + ch) * HINT_RUNS + tid];
