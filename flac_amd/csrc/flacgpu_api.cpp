@@ -571,7 +571,7 @@ static int64_t encode_staged(flacgpu_ctx *c, uint32_t nframes, uint64_t first_fr
 	if(c->verify_on) {
 		// the frames are decoded again where they lie and compared with the staged input (stream_encoder.c:3000-3018)
 		if(launch_verify(c->P, c->d_out, c->d_frame_bytes, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, c->d_vresult,
-		                 c->d_vhints, hints_for(c, c->d_out, nframes, first_frame_number), c->d_vfstat, s) != hipSuccess)
+		                 c->d_vhints, hints_for(c, c->d_out, nframes, first_frame_number), c->d_vfstat, c->ab.dbg, s) != hipSuccess)
 			return FLACGPU_ERR_LAUNCH;
 		if(hipMemcpyAsync(&c->last_verify, c->d_vresult, sizeof c->last_verify, hipMemcpyDeviceToHost, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
@@ -672,7 +672,7 @@ extern "C" int flacgpu_verify_batch_device(flacgpu_ctx *c, const uint8_t *d_fram
 	const uint32_t tail_n = last_block_samples < c->P.blocksize ? last_block_samples : 0;
 	if(launch_scan(d_frame_bytes, nframes, c->d_voffsets, c->d_vtotal, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	if(launch_verify(c->P, d_frames, d_frame_bytes, c->d_voffsets, nframes, tail_n, first_frame_number, d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, d_result,
-	                 c->d_vhints, hints_for(c, d_frames, nframes, first_frame_number), c->d_vfstat, s) != hipSuccess)
+	                 c->d_vhints, hints_for(c, d_frames, nframes, first_frame_number), c->d_vfstat, c->ab.dbg, s) != hipSuccess)
 		return FLACGPU_ERR_LAUNCH;
 	return FLACGPU_OK;
 }

@@ -69,6 +69,84 @@ FLACGPU_HD inline void br_init_at(BitReader &b, const PeekSrc &S, uint32_t pos)
 	br_refill(b);
 }
 
+// ---- the frame header from five words loaded at once (decode_frame_header reads it through the bit reader and checks its CRC-8
+// byte by byte from memory: a dozen dependent round trips, which was a third of a hinted workgroup's life).  Same checks, same
+// verdicts (tests/test_decode_pin.py compares the two on valid, damaged and random headers); a header is at most 16 bytes, which
+// with up to three bytes of misalignment in front lie in five aligned words.
+struct HeadWords { uint32_t w[5]; };
+FLACGPU_HD inline HeadWords hinted_head_words(const PeekSrc &S)
+{
+	HeadWords W;
+#pragma unroll
+	for(int k = 0; k < 5; k++) W.w[k] = peek_word(S, (uint32_t)k);
+	return W;
+}
+// n bits (1..32) at bit a (misalignment included) of the five words, a + n <= 160
+FLACGPU_HD inline uint32_t head_bits(const HeadWords &W, uint32_t a, uint32_t n)
+{
+	const uint32_t wi = a >> 5, o = a & 31u;
+	uint32_t hi = W.w[0], lo = W.w[1];
+#pragma unroll
+	for(int k = 1; k < 4; k++) if(wi == (uint32_t)k) { hi = W.w[k]; lo = W.w[k + 1]; }
+	if(wi >= 4) { hi = W.w[4]; lo = 0; }
+	const uint64_t v = ((uint64_t)hi << 32) | lo;
+	return (uint32_t)((v << o) >> (64 - n));
+}
+// one byte through CRC-8 (poly 0x07): c * x^8 mod P, the columns of the matrix written out
+FLACGPU_HD inline uint32_t crc8_byte(uint32_t c)
+{
+	uint32_t t = 0;
+#pragma unroll
+	for(int k = 0; k < 6; k++) t ^= ((c >> k) & 1u) ? (0x07u << k) : 0u;
+	t ^= (c & 0x40u) ? 0xC7u : 0u;
+	t ^= (c & 0x80u) ? 0x89u : 0u;
+	return t & 0xffu;
+}
+FLACGPU_HD inline int hinted_frame_header(const PeekSrc &S, const DecodeExpect &E, FrameHead &H, uint32_t *pos_out)
+{
+	const HeadWords W = hinted_head_words(S);
+	uint32_t pos = 0;                                               // bits consumed, from the frame's first byte
+#define HGET(n) (pos += (n), head_bits(W, S.skip + pos - (n), (n)))
+	if(HGET(15) != 0x7ffcu || HGET(1) != 0) return DEC_ERROR;
+	const uint32_t bs_code = HGET(4), sr_code = HGET(4), ca = HGET(4), bps_code = HGET(3);
+	if(HGET(1) != 0) return DEC_ERROR;
+	uint64_t fn;
+	{
+		const uint32_t b0 = HGET(8);
+		uint32_t extra;
+		if(b0 < 0x80u) { fn = b0; extra = 0; }
+		else if((b0 & 0xe0u) == 0xc0u) { fn = b0 & 0x1fu; extra = 1; }
+		else if((b0 & 0xf0u) == 0xe0u) { fn = b0 & 0x0fu; extra = 2; }
+		else if((b0 & 0xf8u) == 0xf0u) { fn = b0 & 0x07u; extra = 3; }
+		else if((b0 & 0xfcu) == 0xf8u) { fn = b0 & 0x03u; extra = 4; }
+		else if((b0 & 0xfeu) == 0xfcu) { fn = b0 & 0x01u; extra = 5; }
+		else return DEC_ERROR;
+		for(uint32_t k = 0; k < extra; k++) { const uint32_t c = HGET(8); if((c & 0xc0u) != 0x80u) return DEC_ERROR; fn = (fn << 6) | (c & 0x3fu); }
+	}
+	uint32_t bs;
+	if(bs_code == 0) return DEC_ERROR;
+	else if(bs_code == 1) bs = 192;
+	else if(bs_code <= 5) bs = 576u << (bs_code - 2);
+	else if(bs_code == 6) bs = HGET(8) + 1;
+	else if(bs_code == 7) bs = HGET(16) + 1;
+	else bs = 256u << (bs_code - 8);
+	if(sr_code == 12) (void)HGET(8);
+	else if(sr_code == 13 || sr_code == 14) (void)HGET(16);
+	else if(sr_code == 15) return DEC_ERROR;
+	const uint32_t hdr_bytes = pos >> 3;                             // at most 15
+	uint32_t crc = 0;
+	for(uint32_t i = 0; i < hdr_bytes; i++) crc = crc8_byte(crc ^ head_bits(W, S.skip + 8 * i, 8));
+	if(HGET(8) != crc || pos > S.limit) return DEC_ERROR;
+#undef HGET
+	const uint32_t bps_of = bps_code == 1 ? 8u : bps_code == 2 ? 12u : bps_code == 4 ? 16u : bps_code == 5 ? 20u : bps_code == 6 ? 24u : bps_code == 7 ? 32u : 0u;
+	if(bps_code == 3) return DEC_ERROR;
+	if(fn != E.frame_number || bs != E.n || (bps_code && bps_of != E.bps)) return DEC_ERROR;
+	if((ca < 8 && ca + 1 != E.channels) || ca > 10 || (ca >= 8 && E.channels != 2)) return DEC_ERROR;
+	H.ca = ca; H.n = bs;
+	*pos_out = pos;
+	return DEC_OK;
+}
+
 // what a subframe header says, read by peeking (every field's position follows from the fields in front of it)
 struct HintedSub {
 	uint32_t ok;                   // 0: malformed, or outside what this pass covers -> the frame is suspect
@@ -148,9 +226,10 @@ FLACGPU_HD inline int32_t hinted_fixed_tap(uint32_t order, uint32_t j)
 // Run t of a subframe: decode its codes (samples [16t, 16t+16) from `first` on: run 0 starts behind the warm-up samples) from
 // bit `start` with parameter k, compare them with the residuals the signal implies.  yw[0..31] = y[16t-16 .. 16t+15] (values in
 // front of sample 0 are never used).  Returns 0 when every residual agrees; *end = the bit behind the run's last code.
-template <int MAXORD, typename ST>
-FLACGPU_HD inline uint32_t hinted_run(const PeekSrc &S, uint32_t start, uint32_t k, uint32_t first, const ST (&yw)[32], const int32_t (&q)[MAXORD],
-                                      const HintedSub &H, uint32_t *end)
+// MODE 0: 64-bit prediction sum (H.wide_sum); 1: 32-bit sum from the 24-bit multiplier (H.narrow24); 2: 32-bit sum, 32-bit multiplies
+template <int MAXORD, typename ST, int MODE>
+FLACGPU_HD inline uint32_t hinted_run_mode(const PeekSrc &S, uint32_t start, uint32_t k, uint32_t first, const ST (&yw)[32], const int32_t (&q)[MAXORD],
+                                           const HintedSub &H, uint32_t *end)
 {
 	BitReader b;
 	br_init_at(b, S, start);
@@ -159,30 +238,45 @@ FLACGPU_HD inline uint32_t hinted_run(const PeekSrc &S, uint32_t start, uint32_t
 	for(int s = 0; s < (int)HINT_RUN; s++) {
 		if((uint32_t)s >= first) {
 			const uint32_t u = br_rice(b, k);
-			const int64_t r = (int64_t)(int32_t)((u >> 1) ^ (0u - (u & 1u)));
-			int64_t sum = 0;
-			if(H.wide_sum) {
+			const int32_t r = (int32_t)((u >> 1) ^ (0u - (u & 1u)));
+			if(MODE == 0) {
+				int64_t sum = 0;
 #pragma unroll
 				for(int j = 0; j < MAXORD; j++) sum += (int64_t)q[j] * (int64_t)yw[16 + s - 1 - j];
-			}
-			else if(H.narrow24) {
-				int32_t hh[MAXORD];
-#pragma unroll
-				for(int j = 0; j < MAXORD; j++) hh[j] = (int32_t)yw[16 + s - 1 - j];
-				sum = (int64_t)(int32_t)FLACGPU_DOT24(q, hh);
+				bad |= (uint32_t)((int64_t)yw[16 + s] - (sum >> H.shift) != (int64_t)r);
 			}
 			else {
 				uint32_t s32 = 0;
+				if(MODE == 1) {
+					int32_t hh[MAXORD];
 #pragma unroll
-				for(int j = 0; j < MAXORD; j++) s32 += (uint32_t)q[j] * (uint32_t)(int32_t)yw[16 + s - 1 - j];
-				sum = (int64_t)(int32_t)s32;
+					for(int j = 0; j < MAXORD; j++) hh[j] = (int32_t)yw[16 + s - 1 - j];
+					s32 = FLACGPU_DOT24(q, hh);
+				}
+				else {
+#pragma unroll
+					for(int j = 0; j < MAXORD; j++) s32 += (uint32_t)q[j] * (uint32_t)(int32_t)yw[16 + s - 1 - j];
+				}
+				// y - pred == r as integers: the 32-bit difference must not have wrapped
+				const int32_t pred = (int32_t)s32 >> H.shift;
+				int32_t d;
+				const bool ovf = __builtin_sub_overflow((int32_t)yw[16 + s], pred, &d);
+				bad |= (uint32_t)ovf | (uint32_t)(d != r);
 			}
-			bad |= (uint32_t)((int64_t)yw[16 + s] - (sum >> H.shift) != r);
 		}
 	}
 	bad |= b.bad | (uint32_t)br_over(b);
 	*end = (uint32_t)br_pos(b);
 	return bad;
+}
+template <int MAXORD, typename ST>
+FLACGPU_HD inline uint32_t hinted_run(const PeekSrc &S, uint32_t start, uint32_t k, uint32_t first, const ST (&yw)[32], const int32_t (&q)[MAXORD],
+                                      const HintedSub &H, uint32_t *end)
+{
+	// (one decision per run, three straight-line bodies: the choice inside the unrolled loop cost two branches per sample)
+	if(H.wide_sum) return hinted_run_mode<MAXORD, ST, 0>(S, start, k, first, yw, q, H, end);
+	if(H.narrow24) return hinted_run_mode<MAXORD, ST, 1>(S, start, k, first, yw, q, H, end);
+	return hinted_run_mode<MAXORD, ST, 2>(S, start, k, first, yw, q, H, end);
 }
 
 #ifndef __HIPCC__
@@ -195,11 +289,11 @@ inline int verify_frame_hinted_host(const uint8_t *p, size_t len, const uint8_t 
 	if(len < 6 || E.n % HINT_RUN != 0 || E.n / HINT_RUN > HINT_MAX_RUNS || E.n > E.blocksize) return 1;
 	BitReader b;
 	br_init(b, p, len - 2, buf_hi);
-	FrameHead FH;
-	if(decode_frame_header(b, p, E, FH) != DEC_OK) return 1;
 	PeekSrc S;
 	S.w0 = b.w0; S.nwords = (uint32_t)(b.wlast - b.w0) + 1; S.skip = b.skip; S.limit = (uint32_t)b.limit;
-	uint32_t pos = (uint32_t)br_pos(b);
+	FrameHead FH;
+	uint32_t pos = 0;
+	if(hinted_frame_header(S, E, FH, &pos) != DEC_OK) return 1;
 	const uint32_t C = E.channels, n = FH.n, nruns = n / HINT_RUN;
 	int32_t *y = new int32_t[n + 16];
 	uint32_t *ends = new uint32_t[HINT_MAX_RUNS];

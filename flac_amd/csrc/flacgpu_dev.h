@@ -161,7 +161,7 @@ size_t verify_decoded_bytes(const DevParams &P, uint32_t max_frames);     // the
 // thread-per-run pass first and only the ones it cannot vouch for are decoded sequentially; fstat: [nframes] scratch
 hipError_t launch_verify(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t tail_n,
                          uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result,
-                         const uint32_t *hints, uint32_t nhinted, uint32_t *fstat, hipStream_t s);
+                         const uint32_t *hints, uint32_t nhinted, uint32_t *fstat, unsigned long long *dbg, hipStream_t s);
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s);
 hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,
                           uint8_t *out, uint64_t out_cap, uint32_t nframes, hipStream_t s);

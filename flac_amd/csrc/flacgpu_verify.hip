@@ -17,6 +17,8 @@
 // Integer / bit work, latency bound by construction; no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "flacgpu.h"
 #include "flacgpu_dev.h"
 #define FLACGPU_HD __device__
@@ -45,7 +47,7 @@ static_assert(HINT_RUNS == HINT_MAX_RUNS && HINT_RUN == CHUNK, "the pack kernel'
 // ---- the hinted pass: a workgroup per frame, a thread per 16-sample run (flacgpu_decode_hinted.h has the reasoning and every
 // decision; this kernel is its steps with the per-run work spread over the threads).  fstat[f] = 0: the frame is verified;
 // 1: it goes to the sequential decoder below.
-struct HintedShared { uint32_t hs[HINT_RUNS + 1]; uint32_t ends[HINT_RUNS]; int32_t q[HINT_MAX_ORDER]; };
+struct HintedShared { uint32_t hs[HINT_RUNS + 1]; uint32_t ends[HINT_RUNS]; int32_t q[HINT_MAX_ORDER]; uint32_t head[4]; };
 // the coded channels the input implies are staged in LDS: all of them in one pass over the PCM when they fit next to four other
 // workgroups (stereo does), else channel by channel
 __host__ __device__ inline bool hinted_stage_all(const DevParams &P) { return (size_t)P.channels * (16 + P.blocksize) * 4 <= 36 * 1024; }
@@ -55,14 +57,33 @@ template <int MAXORD>
 __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, const uint8_t *__restrict__ frames, const uint32_t *__restrict__ frame_bytes,
                                                             const uint64_t *__restrict__ offsets, uint32_t nframes, uint32_t nhinted, uint64_t first_frame_number,
                                                             const int32_t *__restrict__ pcm, const uint32_t *__restrict__ hints, uint32_t *__restrict__ fstat,
-                                                            VerifyState *__restrict__ state)
+                                                            VerifyState *__restrict__ state, unsigned long long *__restrict__ dbg, uint32_t prefetch_ahead)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
+	// The workgroup's first act is to wait for its 32 KB of input from HBM: a quarter of its life.  It also touches the input of the
+	// workgroup that will follow it on this CU (one discarded load per 128-byte line), so that that one's wait ends in the L2 / MALL.
+	uint32_t pf = 0;
+	if(prefetch_ahead && f + prefetch_ahead < nhinted) {
+		const unsigned char *a = (const unsigned char *)(pcm + (size_t)(f + prefetch_ahead) * P.blocksize * P.channels);
+		const uint32_t lines = (P.blocksize * P.channels * 4 + 127) / 128;
+		for(uint32_t l = tid; l < lines; l += TPB) { const unsigned char *q = a + (size_t)l * 128; asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(q) : "memory"); }
+	}
+#define VSTAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
+	VSTAMP(0);
 	const uint32_t C = P.channels, N = P.blocksize;
-	const uint32_t fb = f < nhinted ? frame_bytes[f] : 0xffffffffu;
-	if(fb == 0xffffffffu || fb < 6 || fb > P.slot_bytes) { if(tid == 0) fstat[f] = 1; return; }        // (the same for every thread)
 	const bool stage_all = hinted_stage_all(P);
+	// stereo: this thread's share of the frame's input is asked for before anything else (16 independent loads: nothing they need
+	// depends on the frame), so that they are under way while the frame's length, place and header are read
+	constexpr int PRE = (int)(HINT_MAX_RUNS * HINT_RUN / TPB);
+	int2 lr[PRE];
+	const bool pre = stage_all && C == 2 && f < nhinted;
+	if(pre) {
+#pragma unroll
+		for(int k = 0; k < PRE; k++) { const uint32_t i = tid + (uint32_t)k * TPB; lr[k] = i < N ? *(const int2 *)(pcm + ((size_t)f * N + i) * 2) : make_int2(0, 0); }
+	}
+	const uint32_t fb = f < nhinted ? frame_bytes[f] : 0xffffffffu;
+	if(fb == 0xffffffffu || fb < 6 || fb > P.slot_bytes) { if(tid == 0) fstat[f] = 1; asm volatile("s_waitcnt vmcnt(0)" :: "v"(pf)); return; }        // (the same for every thread)
 	int32_t *ybase = (int32_t *)smem;                               // [channels or 1][16 + N]: the value the input implies, NOT yet shifted by the wasted bits
 	HintedShared *sh = (HintedShared *)(ybase + (size_t)(stage_all ? C : 1) * (16 + N));
 	// The frame is read where it lies, as aligned words of global memory: it was written a moment ago and sits in the L2.  (An LDS
@@ -77,38 +98,54 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 	S.w0 = w0g; S.nwords = nw + 2 < avail ? nw + 2 : avail; S.skip = mis * 8; S.limit = (fb - 2) * 8;
 	DecodeExpect E;
 	E.channels = C; E.bps = P.bps; E.blocksize = N; E.n = N; E.frame_number = first_frame_number + f;
-	FrameHead FH;
-	uint32_t pos;
-	{
-		BitReader b;
-		br_init_at(b, S, 0);
-		if(decode_frame_header(b, p, E, FH) != DEC_OK) { if(tid == 0) fstat[f] = 1; return; }
-		pos = (uint32_t)br_pos(b);
+	// the frame header: the first wavefront reads it for all
+	if(tid < 64) {
+		FrameHead FH0;
+		FH0.ca = 0; FH0.n = 0;
+		uint32_t hpos = 0;
+		const int st = hinted_frame_header(S, E, FH0, &hpos);
+		if(tid == 0) { sh->head[0] = (uint32_t)st; sh->head[1] = FH0.ca; sh->head[2] = FH0.n; sh->head[3] = hpos; }
 	}
+	__syncthreads();
+	if(sh->head[0] != (uint32_t)DEC_OK) { if(tid == 0) fstat[f] = 1; asm volatile("s_waitcnt vmcnt(0)" :: "v"(pf)); return; }
+	FrameHead FH;
+	FH.ca = sh->head[1]; FH.n = sh->head[2];
+	uint32_t pos = sh->head[3];
 	const uint32_t n = FH.n, nruns = n / HINT_RUN;
 	uint32_t suspect = 0;
 	bool bail = false;
+	VSTAMP(1);
 	if(stage_all) {
 		// one pass over the frame's input for all its coded channels
-		for(uint32_t i = tid; i < n; i += TPB) {
-			const int32_t *x = pcm + ((size_t)f * N + i) * C;
-			if(C == 2) {
-				const int2 lr = *(const int2 *)x;
-				const int32_t xx[2] = {lr.x, lr.y};
+		if(pre) {
 #pragma unroll
-				for(uint32_t ch = 0; ch < 2; ch++) {
-					const int64_t v = coded_expectation(xx, FH.ca, ch);
-					suspect |= (uint32_t)(v != (int64_t)(int32_t)v);
-					ybase[ch * (16 + N) + 16 + i] = (int32_t)v;
+			for(int k = 0; k < PRE; k++) {
+				const uint32_t i = tid + (uint32_t)k * TPB;
+				if(i < n) {
+					const int32_t xx[2] = {lr[k].x, lr[k].y};
+#pragma unroll
+					for(uint32_t ch = 0; ch < 2; ch++) {
+						const int64_t v = coded_expectation(xx, FH.ca, ch);
+						suspect |= (uint32_t)(v != (int64_t)(int32_t)v);
+						ybase[ch * (16 + N) + 16 + i] = (int32_t)v;
+					}
 				}
 			}
-			else for(uint32_t ch = 0; ch < C; ch++) ybase[ch * (16 + N) + 16 + i] = x[ch];      // (independent channels)
+		}
+		else for(uint32_t i = tid; i < n; i += TPB) {
+			const int32_t *x = pcm + ((size_t)f * N + i) * C;
+			for(uint32_t ch = 0; ch < C; ch++) {
+				const int64_t v = coded_expectation(x, FH.ca, ch);
+				suspect |= (uint32_t)(v != (int64_t)(int32_t)v);
+				ybase[ch * (16 + N) + 16 + i] = (int32_t)v;
+			}
 		}
 	}
 	for(uint32_t ch = 0; ch < C; ch++) {
 		const HintedSub H = hinted_subframe_head(S, pos, coded_bps(E.bps, FH.ca, ch), n);         // (every thread: the same answer)
 		if(!H.ok || H.order > (uint32_t)MAXORD) { bail = true; break; }
 		int32_t *y = ybase + (stage_all ? (size_t)ch * (16 + N) : 0);
+		if(ch < 2) VSTAMP(2 + 5 * ch);
 		if(!stage_all)
 			for(uint32_t i = tid; i < n; i += TPB) {
 				const int64_t v = coded_expectation(pcm + ((size_t)f * N + i) * C, FH.ca, ch);
@@ -116,6 +153,7 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 				y[16 + i] = (int32_t)v;
 			}
 		__syncthreads();
+		if(ch < 2) VSTAMP(3 + 5 * ch);
 		// the subframe's own signal is that value shifted down by the wasted bits, which must be zero in it (in place: a thread
 		// shifts the samples it staged)
 		if(H.wasted) {
@@ -140,6 +178,7 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 			pos = H.end_fixed;
 		}
 		else {
+			if(ch < 2) VSTAMP(4 + 5 * ch);
 			if(tid < H.order) suspect |= (uint32_t)(peek_signed(S, H.pos_body + tid * H.sb, H.sb) != y[16 + tid]);
 			if(tid == 0) suspect |= (uint32_t)(sh->hs[0] != H.r0);
 			if(tid < nruns) {
@@ -161,7 +200,9 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 				}
 				sh->ends[t] = e;
 			}
+			if(ch < 2) VSTAMP(5 + 5 * ch);
 			__syncthreads();
+			if(ch < 2) VSTAMP(6 + 5 * ch);
 			if(tid + 1 < nruns) suspect |= (uint32_t)(sh->ends[tid] != sh->hs[tid + 1]);
 			pos = sh->ends[nruns - 1];
 		}
@@ -180,6 +221,9 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 		fstat[f] = any ? 1u : 0u;
 		if(!any) atomicAdd(&state->hinted_ok, 1u);
 	}
+	VSTAMP(12);
+	asm volatile("s_waitcnt vmcnt(0)" :: "v"(pf));
+#undef VSTAMP
 }
 
 // per-frame verdict of the decode pass: [3:0] channel assignment, bit 8 set = decodes
@@ -310,20 +354,42 @@ bool verify_hinted_covers(const DevParams &P)
 }
 template <int MAXORD>
 static hipError_t launch_hinted_t(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t nhinted, uint64_t first,
-                                  const int32_t *pcm, const uint32_t *hints, uint32_t *fstat, VerifyState *state, hipStream_t s)
+                                  const int32_t *pcm, const uint32_t *hints, uint32_t *fstat, VerifyState *state, unsigned long long *dbg, hipStream_t s)
 {
 	static bool attr_set = false;
+	static uint32_t ahead = 0;
 	if(!attr_set) {
+		// workgroups resident at a time = the distance to the one that takes this one's place
+		int per_cu = 0, cus = 256;
+		hipDeviceProp_t prop;
+		int dev = 0;
+		if(hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+		if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)verify_hinted_kernel<MAXORD>, TPB, hinted_lds_bytes(P)) != hipSuccess || per_cu < 1) per_cu = 4;
+		const char *e2 = getenv("FLACGPU_VERIFY_PREFETCH");
+		ahead = e2 ? (uint32_t)atoi(e2) : (uint32_t)(per_cu * cus);
 		const hipError_t e = hipFuncSetAttribute((const void *)verify_hinted_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL((verify_hinted_kernel<MAXORD>), dim3(nframes), dim3(TPB), hinted_lds_bytes(P), s, P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state);
+	hipLaunchKernelGGL((verify_hinted_kernel<MAXORD>), dim3(nframes), dim3(TPB), hinted_lds_bytes(P), s, P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, dbg, ahead);
+	if(dbg) {
+		// development aid (FLACGPU_DEBUG_TIMING=1): shader-clock ticks between the stamps of the hinted workgroups
+		unsigned long long *h = (unsigned long long *)malloc((size_t)nhinted * 16 * sizeof(unsigned long long));
+		if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, dbg, (size_t)nhinted * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+			double acc[13] = {0}; size_t cnt[13] = {0};
+			for(size_t w = 0; w < nhinted; w++) { int prev = 0; for(int k = 1; k < 13; k++) if(h[w * 16 + k] && h[w * 16 + prev]) { acc[k] += (double)(h[w * 16 + k] - h[w * 16 + prev]); cnt[k]++; prev = k; } }
+			fprintf(stderr, "[flacgpu] hinted verify stamps (avg ticks since previous stamp):");
+			for(int k = 1; k < 13; k++) fprintf(stderr, " %d:%.0f", k, cnt[k] ? acc[k] / cnt[k] : 0.0);
+			fprintf(stderr, "\n");
+		}
+		free(h);
+		(void)hipMemsetAsync(dbg, 0, (size_t)nhinted * 16 * sizeof(unsigned long long), s);
+	}
 	return hipGetLastError();
 }
 hipError_t launch_verify(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t tail_n,
                          uint64_t first, const int32_t *pcm, int64_t *scratch, void *decoded, uint32_t *finfo, VerifyState *state, flacgpu_verify_result *result,
-                         const uint32_t *hints, uint32_t nhinted, uint32_t *fstat, hipStream_t s)
+                         const uint32_t *hints, uint32_t nhinted, uint32_t *fstat, unsigned long long *dbg, hipStream_t s)
 {
 	hipLaunchKernelGGL(verify_reset_kernel, dim3(1), dim3(1), 0, s, state);
 	hipError_t e = launch_crc_check(frames, fb, offsets, nframes, state, s);
@@ -334,9 +400,9 @@ hipError_t launch_verify(const DevParams &P, const uint8_t *frames, const uint32
 	if(tail_n && nhinted >= nframes) nhinted = nframes - 1;      // (the short last block never has hints)
 	if(!hints || !fstat || !verify_hinted_covers(P)) nhinted = 0;
 	if(nhinted) {
-		if(m <= 8) e = launch_hinted_t<8>(P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, s);
-		else if(m <= 12) e = launch_hinted_t<12>(P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, s);
-		else e = launch_hinted_t<16>(P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, s);
+		if(m <= 8) e = launch_hinted_t<8>(P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, dbg, s);
+		else if(m <= 12) e = launch_hinted_t<12>(P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, dbg, s);
+		else e = launch_hinted_t<16>(P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, dbg, s);
 		if(e != hipSuccess) return e;
 	}
 	else fstat = nullptr;

@@ -91,3 +91,24 @@ extern "C" int decodepin_verify_hinted(const uint8_t *frames, const uint32_t *fb
 	}
 	return n;
 }
+
+// the two frame-header parsers (bit reader + bytes from memory; five words at once) on one frame: returns
+// (status of decode_frame_header) | (status of hinted_frame_header << 8) | (1 << 16 when both accept but disagree on ca / n / position)
+extern "C" int decodepin_header_both(const uint8_t *frame, uint32_t len, uint32_t lead, uint32_t channels, uint32_t bps, uint32_t blocksize, uint32_t n, uint64_t frame_number)
+{
+	// `frame` holds `lead` stray bytes in front of the frame (its alignment is the caller's choice) and slack behind it
+	const uint8_t *p = frame + lead;
+	DecodeExpect E = {channels, bps, blocksize, n, frame_number};
+	BitReader b;
+	br_init(b, p, len - 2, p + len + 16);
+	FrameHead A, B;
+	A.ca = A.n = B.ca = B.n = 0;
+	const int sa = decode_frame_header(b, p, E, A);
+	PeekSrc S;
+	S.w0 = b.w0; S.nwords = (uint32_t)(b.wlast - b.w0) + 1; S.skip = b.skip; S.limit = (uint32_t)b.limit;
+	uint32_t pos = 0;
+	const int sb = hinted_frame_header(S, E, B, &pos);
+	int r = sa | (sb << 8);
+	if(sa == DEC_OK && sb == DEC_OK && (A.ca != B.ca || A.n != B.n || pos != (uint32_t)br_pos(b))) r |= 1 << 16;
+	return r;
+}

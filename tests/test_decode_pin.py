@@ -407,3 +407,44 @@ def test_hinted_pass_is_sound_under_damage_and_arbitrary_hints():
                 assert suspect[f] or np.array_equal(h[f], hints[f])   # wrong hints never verify a frame
         # a flipped bit that the hinted pass accepts must be one that changes nothing but the CRC's validity: there is none in the body
         assert accepted_damaged == 0
+
+
+def test_the_two_frame_header_parsers_agree():
+    """hinted_frame_header (five words at once) against decode_frame_header (the bit reader): every frame number length, block
+    size and sample rate code the encoder can emit, at every alignment; and the same verdict on every single-bit flip of a header
+    and on random bytes"""
+    lib = _pin()
+    lib.decodepin_header_both.restype = C.c_int
+    lib.decodepin_header_both.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+    rng = np.random.default_rng(3)
+    seen_ok = 0
+    for bs, rate, bps, ch in ((4096, 44100, 16, 2), (1152, 48000, 24, 2), (4000, 44100, 16, 1), (200, 12345, 8, 2), (65535, 96000, 32, 3), (256, 655350, 12, 6),
+                              (4608, 8000, 20, 2), (16, 11025, 16, 8)):
+        n = bs * 2
+        pcm = signals.music(n, ch, bps, seed=bs)
+        for first in (0, 127, 128, 2047, 2048, 65535, 65536, 2 ** 21 - 1, 2 ** 21, 2 ** 26 - 1, 2 ** 26, 2 ** 31 - 2):
+            enc = po.oracle_encode(pcm[:bs], bps, rate, 2, first_frame=first, blocksize=bs)
+            frame = np.frombuffer(enc["data"], dtype=np.uint8)
+            for lead in range(4):
+                buf = np.concatenate([np.full(lead, 0x5A, np.uint8), frame, np.zeros(32, np.uint8)])
+                # (the buffer itself is 16-byte aligned by numpy: `lead` sets the frame's alignment)
+                r = lib.decodepin_header_both(buf.ctypes.data, len(frame), lead, ch, bps, bs, bs, first)
+                assert r == 0, (bs, rate, bps, ch, first, lead, hex(r))
+                seen_ok += 1
+            # every single-bit flip of the first 16 bytes, and a wrong expectation: the two parsers fail or pass together
+            for bit in range(16 * 8):
+                d = frame.copy()
+                d[bit // 8] ^= 0x80 >> (bit % 8)
+                buf = np.concatenate([np.full(1, 0x5A, np.uint8), d, np.zeros(32, np.uint8)])
+                r = lib.decodepin_header_both(buf.ctypes.data, len(d), 1, ch, bps, bs, bs, first)
+                assert (r & 0xff) == ((r >> 8) & 0xff) and not (r >> 16), (bs, first, bit, hex(r))
+            r = lib.decodepin_header_both(buf.ctypes.data, len(frame), 1, ch, bps, bs, bs, first + 1)
+            assert (r & 0xff) == ((r >> 8) & 0xff) == 2
+    for trial in range(3000):
+        d = rng.integers(0, 256, size=64, dtype=np.uint8)
+        d[0], d[1] = 0xff, 0xf8                                   # let most of them past the sync code
+        lead = int(rng.integers(0, 4))
+        buf = np.concatenate([np.full(lead, 0x11, np.uint8), d, np.zeros(32, np.uint8)])
+        r = lib.decodepin_header_both(buf.ctypes.data, 64, lead, 2, 16, 4096, 4096, int(rng.integers(0, 200)))
+        assert (r & 0xff) == ((r >> 8) & 0xff) and not (r >> 16), (trial, hex(r))
+    assert seen_ok > 300
