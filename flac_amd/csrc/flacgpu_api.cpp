@@ -360,6 +360,22 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		if(ok && getenv("FLACGPU_DEBUG_TIMING")) { ok = hipMalloc(&c->ab.dbg, nfc * 16 * sizeof(unsigned long long)) == hipSuccess; if(ok) (void)hipMemset(c->ab.dbg, 0, nfc * 16 * sizeof(unsigned long long)); }
 	}
 	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
+	if(getenv("FLACGPU_POISON")) {
+		// development aid (tests/test_gpu_parity.py): every scratch buffer starts out as garbage instead of the zeros fresh device
+		// memory happens to hold, so that a kernel reading what no kernel wrote shows up as a parity failure
+		const size_t nfc = B * P.ncand, ncs = P.ncslots;
+		(void)hipMemset(c->d_decisions, 0xA5, B * P.ncand * sizeof(SubDecision));
+		(void)hipMemset(c->d_slots, 0xA5, B * P.slot_bytes);
+		(void)hipMemset(c->d_frame_bytes, 0xA5, B * sizeof(uint32_t));
+		(void)hipMemset(c->d_offsets, 0xA5, (B + 1) * sizeof(uint64_t));
+		(void)hipMemset(c->d_info, 0xA5, B * sizeof(FrameInfo));
+		(void)hipMemset(c->ab.prep, 0xA5, nfc * sizeof(ChanPrep));
+		(void)hipMemset(c->ab.autoc, 0xA5, nfc * P.max_jobs * AUTOC_STRIDE * sizeof(double));
+		(void)hipMemset(c->ab.cands, 0xA5, nfc * ncs * sizeof(Candidate));
+		(void)hipMemset(c->ab.valid, 0xA5, nfc * ncs * sizeof(int));
+		(void)hipMemset(c->ab.chan, 0xA5, nfc * P.chan_stride * sizeof(int32_t));
+		(void)hipDeviceSynchronize();
+	}
 	*out = c;
 	return FLACGPU_OK;
 }

@@ -102,9 +102,8 @@ FLACGPU_HD inline uint32_t crc8_byte(uint32_t c)
 	t ^= (c & 0x80u) ? 0x89u : 0u;
 	return t & 0xffu;
 }
-FLACGPU_HD inline int hinted_frame_header(const PeekSrc &S, const DecodeExpect &E, FrameHead &H, uint32_t *pos_out)
+FLACGPU_HD inline int hinted_frame_header_w(const HeadWords &W, const PeekSrc &S, const DecodeExpect &E, FrameHead &H, uint32_t *pos_out)
 {
-	const HeadWords W = hinted_head_words(S);
 	uint32_t pos = 0;                                               // bits consumed, from the frame's first byte
 #define HGET(n) (pos += (n), head_bits(W, S.skip + pos - (n), (n)))
 	if(HGET(15) != 0x7ffcu || HGET(1) != 0) return DEC_ERROR;
@@ -145,6 +144,12 @@ FLACGPU_HD inline int hinted_frame_header(const PeekSrc &S, const DecodeExpect &
 	H.ca = ca; H.n = bs;
 	*pos_out = pos;
 	return DEC_OK;
+}
+
+FLACGPU_HD inline int hinted_frame_header(const PeekSrc &S, const DecodeExpect &E, FrameHead &H, uint32_t *pos_out)
+{
+	const HeadWords W = hinted_head_words(S);
+	return hinted_frame_header_w(W, S, E, H, pos_out);
 }
 
 // what a subframe header says, read by peeking (every field's position follows from the fields in front of it)

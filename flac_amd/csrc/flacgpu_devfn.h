@@ -482,8 +482,8 @@ __device__ __forceinline__ bool emit_fixed_candidates(const DevParams &P, Candid
 		const uint64_t eo = order == 0 ? e[0] : order == 1 ? e[1] : order == 2 ? e[2] : order == 3 ? e[3] : e[4];
 		const bool ok = allowed && !((invalid >> order) & 1u) && !(fixed_rbps(eo, n4) >= (float)sbps);
 		any = any || ok;
-		if(lane < 16) {                                               // every kernel flavour keeps at least 8 taps
-			int32_t c = 0;
+		if(lane < MAX_ORDER) {                                        // ALL taps of the record: the 32-tap flavours of the evaluation and pack kernels read
+			int32_t c = 0;                                            // them all (taps 16..31 were left as they lay: zero in fresh memory, anything in reused memory)
 			if(order == 1) c = lane == 0 ? 1 : 0;
 			else if(order == 2) c = lane == 0 ? 2 : lane == 1 ? -1 : 0;
 			else if(order == 3) c = lane == 0 ? 3 : lane == 1 ? -3 : lane == 2 ? 1 : 0;

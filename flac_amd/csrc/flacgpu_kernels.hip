@@ -721,12 +721,23 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 
 	// decision records, CRC tables: one round of loads for everything the frame needs; image zeroed meanwhile
 	{
+		// (straight-line, every load unconditional with its index clamped: as loops with their own bounds these were five basic blocks,
+		//  each ending in a wait for its own load -- five round trips where one will do)
+		constexpr uint32_t DEC_ROUNDS = (FLACGPU_MAX_CHANNELS * (uint32_t)(sizeof(SubDecision) / 4) + TPB - 1) / TPB;
+		static_assert(P2_XSPAN / 2 == TPB && 4 * 256 / 2 == 2 * TPB && (CRC_SPAN + 2) / 2 <= TPB, "one pass of the workgroup per table");
 		const uint32_t ndw = P.ncand * (uint32_t)(sizeof(SubDecision) / 4);
-		for(uint32_t w = (uint32_t)tid; w < ndw; w += TPB) sh->dec[w] = ((const uint32_t *)dec)[w];
-		for(uint32_t w = (uint32_t)tid; w < 4 * 256 / 2; w += TPB) ((uint32_t *)sh->crc_tab)[w] = ((const uint32_t *)g_crc_tables.tab)[w];
-		for(uint32_t w = (uint32_t)tid; w < P2_XSPAN / 2; w += TPB) ((uint32_t *)sh->xspan)[w] = ((const uint32_t *)g_crc_tables.xspan44)[w];
-		if(tid < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[tid] = ((const uint32_t *)g_crc_tables.xbyte)[tid];
+		const uint32_t *decw = (const uint32_t *)dec, *tab32 = (const uint32_t *)g_crc_tables.tab, *xs32 = (const uint32_t *)g_crc_tables.xspan44,
+		               *xb32 = (const uint32_t *)g_crc_tables.xbyte;
+		uint32_t dv[DEC_ROUNDS];
+#pragma unroll
+		for(uint32_t k = 0; k < DEC_ROUNDS; k++) { const uint32_t w = (uint32_t)tid + k * TPB; dv[k] = decw[w < ndw ? w : ndw - 1]; }
+		const uint32_t t0 = tab32[tid], t1 = tab32[tid + TPB], xv = xs32[tid], bv = xb32[tid < (int)(CRC_SPAN + 2) / 2 ? tid : 0];
 		for(uint32_t w = (uint32_t)tid; w < cap_words + 2; w += TPB) img[w] = 0;
+#pragma unroll
+		for(uint32_t k = 0; k < DEC_ROUNDS; k++) { const uint32_t w = (uint32_t)tid + k * TPB; if(w < ndw) sh->dec[w] = dv[k]; }
+		((uint32_t *)sh->crc_tab)[tid] = t0; ((uint32_t *)sh->crc_tab)[tid + TPB] = t1;
+		((uint32_t *)sh->xspan)[tid] = xv;
+		if(tid < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[tid] = bv;
 	}
 	__syncthreads();
 	PSTAMP(1);

@@ -61,29 +61,15 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
-	// The workgroup's first act is to wait for its 32 KB of input from HBM: a quarter of its life.  It also touches the input of the
-	// workgroup that will follow it on this CU (one discarded load per 128-byte line), so that that one's wait ends in the L2 / MALL.
-	uint32_t pf = 0;
-	if(prefetch_ahead && f + prefetch_ahead < nhinted) {
-		const unsigned char *a = (const unsigned char *)(pcm + (size_t)(f + prefetch_ahead) * P.blocksize * P.channels);
-		const uint32_t lines = (P.blocksize * P.channels * 4 + 127) / 128;
-		for(uint32_t l = tid; l < lines; l += TPB) { const unsigned char *q = a + (size_t)l * 128; asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(q) : "memory"); }
-	}
+	// (The workgroup's first act is to wait for its 32 KB of input from HBM, a quarter of its life: it also touches the input of the
+	// workgroup that will follow it on this CU -- one discarded load per 128-byte line -- so that that one's wait ends in the L2 / MALL.)
 #define VSTAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
 	VSTAMP(0);
 	const uint32_t C = P.channels, N = P.blocksize;
 	const bool stage_all = hinted_stage_all(P);
-	// stereo: this thread's share of the frame's input is asked for before anything else (16 independent loads: nothing they need
-	// depends on the frame), so that they are under way while the frame's length, place and header are read
-	constexpr int PRE = (int)(HINT_MAX_RUNS * HINT_RUN / TPB);
-	int2 lr[PRE];
-	const bool pre = stage_all && C == 2 && f < nhinted;
-	if(pre) {
-#pragma unroll
-		for(int k = 0; k < PRE; k++) { const uint32_t i = tid + (uint32_t)k * TPB; lr[k] = i < N ? *(const int2 *)(pcm + ((size_t)f * N + i) * 2) : make_int2(0, 0); }
-	}
 	const uint32_t fb = f < nhinted ? frame_bytes[f] : 0xffffffffu;
-	if(fb == 0xffffffffu || fb < 6 || fb > P.slot_bytes) { if(tid == 0) fstat[f] = 1; asm volatile("s_waitcnt vmcnt(0)" :: "v"(pf)); return; }        // (the same for every thread)
+	if(fb == 0xffffffffu || fb < 6 || fb > P.slot_bytes) { if(tid == 0) fstat[f] = 1; return; }        // (the same for every thread)
+	VSTAMP(13);
 	int32_t *ybase = (int32_t *)smem;                               // [channels or 1][16 + N]: the value the input implies, NOT yet shifted by the wasted bits
 	HintedShared *sh = (HintedShared *)(ybase + (size_t)(stage_all ? C : 1) * (16 + N));
 	// The frame is read where it lies, as aligned words of global memory: it was written a moment ago and sits in the L2.  (An LDS
@@ -98,14 +84,38 @@ __global__ __launch_bounds__(TPB) void verify_hinted_kernel(const DevParams P, c
 	S.w0 = w0g; S.nwords = nw + 2 < avail ? nw + 2 : avail; S.skip = mis * 8; S.limit = (fb - 2) * 8;
 	DecodeExpect E;
 	E.channels = C; E.bps = P.bps; E.blocksize = N; E.n = N; E.frame_number = first_frame_number + f;
+	// Order of the loads: a wait for one load is a wait for every load issued before it.  The five words of the frame header go
+	// first, then the thread's share of the frame's input (stereo: 16 independent loads), then the touch of the successor's input --
+	// so that the header is parsed while the input is still on its way.
+	const HeadWords HW = hinted_head_words(S);
+	constexpr int PRE = (int)(HINT_MAX_RUNS * HINT_RUN / TPB);
+	int2 lr[PRE];
+	const bool pre = stage_all && C == 2;
+	if(pre) {
+#pragma unroll
+		for(int k = 0; k < PRE; k++) {
+			// (the index is clamped, not the load made conditional: a load under a condition is followed by a wait for it, sixteen
+			//  times over -- that alone was 15 k of the workgroup's 90 k ticks)
+			const uint32_t i = tid + (uint32_t)k * TPB;
+			lr[k] = *(const int2 *)(pcm + ((size_t)f * N + (i < N ? i : N - 1)) * 2);
+		}
+	}
+	uint32_t pf = 0;
+	if(prefetch_ahead && f + prefetch_ahead < nhinted) {
+		const unsigned char *a = (const unsigned char *)(pcm + (size_t)(f + prefetch_ahead) * P.blocksize * P.channels);
+		const uint32_t lines = (P.blocksize * P.channels * 4 + 127) / 128;
+		for(uint32_t l = tid; l < lines; l += TPB) { const unsigned char *q = a + (size_t)l * 128; asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(q) : "memory"); }
+	}
 	// the frame header: the first wavefront reads it for all
+	VSTAMP(14);
 	if(tid < 64) {
 		FrameHead FH0;
 		FH0.ca = 0; FH0.n = 0;
 		uint32_t hpos = 0;
-		const int st = hinted_frame_header(S, E, FH0, &hpos);
+		const int st = hinted_frame_header_w(HW, S, E, FH0, &hpos);
 		if(tid == 0) { sh->head[0] = (uint32_t)st; sh->head[1] = FH0.ca; sh->head[2] = FH0.n; sh->head[3] = hpos; }
 	}
+	VSTAMP(15);
 	__syncthreads();
 	if(sh->head[0] != (uint32_t)DEC_OK) { if(tid == 0) fstat[f] = 1; asm volatile("s_waitcnt vmcnt(0)" :: "v"(pf)); return; }
 	FrameHead FH;
@@ -376,10 +386,10 @@ static hipError_t launch_hinted_t(const DevParams &P, const uint8_t *frames, con
 		// development aid (FLACGPU_DEBUG_TIMING=1): shader-clock ticks between the stamps of the hinted workgroups
 		unsigned long long *h = (unsigned long long *)malloc((size_t)nhinted * 16 * sizeof(unsigned long long));
 		if(h && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, dbg, (size_t)nhinted * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-			double acc[13] = {0}; size_t cnt[13] = {0};
-			for(size_t w = 0; w < nhinted; w++) { int prev = 0; for(int k = 1; k < 13; k++) if(h[w * 16 + k] && h[w * 16 + prev]) { acc[k] += (double)(h[w * 16 + k] - h[w * 16 + prev]); cnt[k]++; prev = k; } }
-			fprintf(stderr, "[flacgpu] hinted verify stamps (avg ticks since previous stamp):");
-			for(int k = 1; k < 13; k++) fprintf(stderr, " %d:%.0f", k, cnt[k] ? acc[k] / cnt[k] : 0.0);
+			double acc[16] = {0}; size_t cnt[16] = {0};
+			for(size_t w = 0; w < nhinted; w++) for(int k = 1; k < 16; k++) if(h[w * 16 + k] && h[w * 16]) { acc[k] += (double)(h[w * 16 + k] - h[w * 16]); cnt[k]++; }
+			fprintf(stderr, "[flacgpu] hinted verify stamps (avg ticks since the workgroup's start; 13-15 lie inside 0..1):");
+			for(int k = 1; k < 16; k++) fprintf(stderr, " %d:%.0f", k, cnt[k] ? acc[k] / cnt[k] : 0.0);
 			fprintf(stderr, "\n");
 		}
 		free(h);

@@ -536,3 +536,26 @@ def test_many_apodizations_and_deep_subdivision():
                 eng.close()
             o = oracle_encode_settings(pcm, s)
             assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (spec, ch, bps)
+
+
+def test_parity_with_poisoned_scratch_memory(monkeypatch):
+    """FLACGPU_POISON=1: an engine's scratch buffers start as 0xA5 garbage instead of the zeros fresh device memory happens to
+    hold.  A kernel that reads what no kernel wrote (round 2 found one: taps 16..31 of the fixed-predictor records, read by the
+    32-tap kernels, visible only when a process reused freed device memory) fails parity here, whatever ran before."""
+    monkeypatch.setenv("FLACGPU_POISON", "1")
+    for bs in (19, 33):
+        test_tiny_blocks_all_orders(bs)
+    for level in (0, 3, 5, 8):
+        test_gpu_matches_oracle_per_frame(level)
+    test_high_orders_with_searches(32)
+    test_short_last_block(1)
+    test_short_last_block(4095)
+    test_wide_samples(32)
+    test_wide_samples(25)
+    test_limit_min_bitrate_and_channel_counts()
+    test_wider_model_searches_match_oracle(8, (1, 1))
+    test_frames_larger_than_the_lds(8, 24, 16384)
+    test_blocks_longer_than_16384(65535)
+    test_many_apodizations_and_deep_subdivision()
+    for seed in range(6):
+        test_random_configurations(seed)
