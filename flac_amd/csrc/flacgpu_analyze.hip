@@ -580,15 +580,26 @@ __global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t 
 		const bool punch = jt->an_punch[a] != 0;
 		const double *aj = autoc_in + ((size_t)fc * P.max_jobs + jb) * AUTOC_STRIDE;
 		const double *ar = autoc_in + ((size_t)fc * P.max_jobs + rt) * AUTOC_STRIDE;
-		double av[MAXORD + 1];
+		double av[MAXORD + 1], rv[MAXORD + 1];
+		// (every lag is loaded, wanted or not -- a row of the table has AUTOC_STRIDE > MAXORD entries -- so that the loads go out
+		//  together: a load under a condition is followed by a wait for it, and there were 2 (MAXORD + 1) of those in a row)
+		static_assert(MAXORD < (int)AUTOC_STRIDE, "a row holds every lag of this flavour");
+#pragma unroll
+		for(int j = 0; j <= MAXORD; j++) av[j] = aj[j];
+#pragma unroll
+		for(int j = 0; j <= MAXORD; j++) rv[j] = 0.0;
+		if(punch) {                                                  // (one block under one condition: its loads still go out together)
+#pragma unroll
+			for(int j = 0; j <= MAXORD; j++) rv[j] = ar[j];
+		}
 #pragma unroll
 		for(int j = 0; j <= MAXORD; j++) {
 			double v = 0.0;
 			if((uint32_t)j < lag) {
-				v = aj[j];
+				v = av[j];
 				// punch-out: root - partial for lags < max_order only; lag max_order keeps the partial's value
 				// (stream_encoder.c:4339-4340,4370-4371)
-				if(punch && (uint32_t)j < max_lpc) v = ar[j] - v;
+				if(punch && (uint32_t)j < max_lpc) v = rv[j] - v;
 			}
 			av[j] = v;
 		}
@@ -1067,6 +1078,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	}
 	if(tid < EVAL_CPW_MAX * EVAL_MAX_WAVES) { (&sh->wbest_bits[0][0])[tid] = 0xffffffffu; (&sh->wbest_ci[0][0])[tid] = 0xffffffffu; (&sh->wbest_po[0][0])[tid] = 0; }
 	__syncthreads();
+	STAMP(6);
 	uint32_t nmine = 0, nwork = 0;
 	{
 		uint32_t o = 0;
@@ -1088,6 +1100,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 			sh->divtab[t] = ps > o ? 0x40000u / (ps - o) : 0;
 		}
 		__syncthreads();         // ctx offsets visible
+		STAMP(7);
 		// ---- candidate records and the channel signals into LDS -------------------------------------------------------
 		for(uint32_t c = 0; c < cpw; c++) {
 			const EvalChan &E = sh->ch[c];
@@ -1102,6 +1115,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 				int *vd = (int *)(ctx + img_bytes + cand_valid_off);
 				for(uint32_t t = (uint32_t)tid; t < E.nan; t += nthreads) vd[t] = valid[fc * cstride + t];
 			}
+			if(c < 2) STAMP(10 + 2 * c);
 			const uint32_t *src = (const uint32_t *)(chan + fc * (size_t)P.chan_stride);       // planar channel, already shifted (ChanPrep::fmt)
 			const uint32_t srcfmt = E.pr.fmt;
 			if(VARIANT != 2) {

@@ -462,6 +462,12 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 					if(nv) fprintf(stderr, "[flacgpu] eval variant %d: %zu WGs, avg %.0f ticks each, first start -> last end %.0f ticks, mean concurrency %.1f WGs\n",
 					               v - 1, nv, dur / nv, (double)(t1 - t0), dur / (double)(t1 - t0));
 				}
+				{
+					double fa[16] = {0}; size_t fn[16] = {0};
+					for(size_t w = 0; w < nwg; w++) for(int k = 1; k < 16; k++) if(k != 9 && h[w * 16 + k] && h[w * 16]) { fa[k] += (double)(h[w * 16 + k] - h[w * 16]); fn[k]++; }
+					fprintf(stderr, "[flacgpu] eval stamps (avg ticks since the workgroup's start): facts+barrier 6:%.0f  offsets+divtab+barrier 7:%.0f  ch0 records copied 10:%.0f  ch1 records copied 12:%.0f  signals in LDS 1:%.0f  first candidate 2:%.0f  all candidates 4:%.0f  end 5:%.0f\n",
+					        fn[6] ? fa[6] / fn[6] : 0, fn[7] ? fa[7] / fn[7] : 0, fn[10] ? fa[10] / fn[10] : 0, fn[12] ? fa[12] / fn[12] : 0, fn[1] ? fa[1] / fn[1] : 0, fn[2] ? fa[2] / fn[2] : 0, fn[4] ? fa[4] / fn[4] : 0, fn[5] ? fa[5] / fn[5] : 0);
+				}
 				fprintf(stderr, "[flacgpu] eval phases (avg s_memtime ticks per WG): load %.0f  cand0 %.0f  round1->round2 %.0f  rest %.0f  decide %.0f\n",
 				        cnt[1] ? acc[1] / cnt[1] : 0, cnt[2] ? acc[2] / cnt[2] : 0, cnt[3] ? acc[3] / cnt[3] : 0, cnt[4] ? acc[4] / cnt[4] : 0, cnt[5] ? acc[5] / cnt[5] : 0);
 			}

@@ -1137,7 +1137,8 @@ __global__ __launch_bounds__(TPB) void crc_check_kernel(const uint8_t *__restric
 		const uint32_t nload = last ? (last_len + 3) >> 2 : CRC2_WORDS;   // (nothing is read behind the word that holds the frame's last byte)
 		uint32_t w[CRC2_WORDS];
 #pragma unroll
-		for(int k = 0; k < (int)CRC2_WORDS; k++) w[k] = (uint32_t)k < nload ? __builtin_bswap32(wp[k]) : 0u;
+		for(int k = 0; k < (int)CRC2_WORDS; k++) w[k] = __builtin_bswap32(wp[(uint32_t)k < nload ? (uint32_t)k : nload - 1]);      // (index clamped, load unconditional:
+		                                                                                                                         //  eleven loads in flight, not one after the other)
 		if(sp == 0 && mis) w[0] &= 0xffffffffu >> (8 * mis);
 		const uint32_t nw = last ? last_len >> 2 : CRC2_WORDS;
 		uint32_t cs = 0, tailw = 0;
