@@ -12,7 +12,7 @@ asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-s
                      capture_output=True, text=True).stdout.split("\n")
 start = None
 for i, line in enumerate(asm):
-    if line.startswith("_ZN7flacgpu") and line.rstrip().endswith(":") and "Lfunc" not in line:
+    if line.startswith("_ZN7flacgpu") and ": " in line and "; @" in line:
         start, name = i, line.split(":")[0]
     elif start is not None and "s_endpgm" in line:
         body = asm[start:i]
