@@ -62,34 +62,52 @@ __device__ __forceinline__ void a2_index(const A2Job &J, int32_t i, uint32_t &sr
 __device__ __forceinline__ float a2_value(int32_t v, uint32_t wasted, float wt) { return __builtin_fmaf((float)(v >> wasted), wt, 0.0f); }
 
 struct A2Items {
-	const int32_t *ptr[A2_ITEMS];     // MS4: ptr[0..3] = the four frames; else one per subframe
+	const int32_t *ptr[A2_ITEMS];     // SRC 1: ptr[0..3] = the four frames; SRC 2: ptr[0..7] = the eight frames; SRC 0: one per subframe
 	uint32_t which[A2_ITEMS];
 	uint32_t wasted[A2_ITEMS];
 };
 
-template <bool MS4>
+// SRC: how the 16 subframes of a wavefront map to the interleaved PCM.
+//   0  anything: one load per subframe and sample (pick_channel)
+//   1  stereo with a full mid/side search: four frames x {L, R, M, S}, one 8-byte load per frame and sample feeds four subframes
+//   2  stereo with two candidate channels per frame -- no mid/side search (-3), or the loose one (-1, -4: prep has picked L/R or
+//      M/S per frame) --: eight frames x 2, one 8-byte load per frame and sample feeds both
+template <int SRC>
 struct A2Fetch {
-	int32_t v[MS4 ? 8 : A2_ITEMS];
+	int32_t v[SRC == 1 ? 8 : A2_ITEMS];
 	float wt;
 };
-template <bool MS4>
-__device__ __forceinline__ void a2_fetch(const A2Job &J, const A2Items &I, uint32_t C, int32_t i, A2Fetch<MS4> &F)
+__device__ __forceinline__ int32_t a2_pick2(int32_t l, int32_t r, uint32_t which) { return which == 0 ? l : which == 1 ? r : which == 2 ? ((l + r) >> 1) : (l - r); }
+template <int SRC>
+__device__ __forceinline__ void a2_fetch(const A2Job &J, const A2Items &I, uint32_t C, int32_t i, A2Fetch<SRC> &F)
 {
 	uint32_t src;
 	a2_index(J, i, src, F.wt);
-	if(MS4) {
+	if(SRC == 1) {
 #pragma unroll
 		for(int fr = 0; fr < 4; fr++) { const int2 lr = ((const int2 *)I.ptr[fr])[src]; F.v[2 * fr] = lr.x; F.v[2 * fr + 1] = lr.y; }
+	}
+	else if(SRC == 2) {
+#pragma unroll
+		for(int fr = 0; fr < 8; fr++) { const int2 lr = ((const int2 *)I.ptr[fr])[src]; F.v[2 * fr] = lr.x; F.v[2 * fr + 1] = lr.y; }
 	}
 	else {
 #pragma unroll
 		for(int t = 0; t < A2_ITEMS; t++) F.v[t] = pick_channel(I.ptr[t], C, src, I.which[t]);
 	}
 }
-template <bool MS4>
-__device__ __forceinline__ void a2_store(float *tile, const A2Items &I, const A2Fetch<MS4> &F, int slot)
+template <int SRC>
+__device__ __forceinline__ void a2_store(float *tile, const A2Items &I, const A2Fetch<SRC> &F, int slot)
 {
-	if(MS4) {
+	if(SRC == 2) {
+#pragma unroll
+		for(int fr = 0; fr < 8; fr++) {
+			const int32_t l = F.v[2 * fr], r = F.v[2 * fr + 1];
+			tile[(2 * fr + 0) * A2_IST + slot] = a2_value(a2_pick2(l, r, I.which[2 * fr + 0]), I.wasted[2 * fr + 0], F.wt);
+			tile[(2 * fr + 1) * A2_IST + slot] = a2_value(a2_pick2(l, r, I.which[2 * fr + 1]), I.wasted[2 * fr + 1], F.wt);
+		}
+	}
+	else if(SRC == 1) {
 #pragma unroll
 		for(int fr = 0; fr < 4; fr++) {
 			const int32_t l = F.v[2 * fr], r = F.v[2 * fr + 1];
@@ -119,8 +137,8 @@ __device__ __forceinline__ void a2_store(float *tile, const A2Items &I, const A2
 // consecutive workgroups of the SAME XCD (workgroups go round-robin over the 8 XCDs, so those are blockIdx b, b+8, b+16 ...).
 // They start together and sweep the block at the same pace: a PCM line is fetched from HBM once and found in that XCD's L2 by
 // the other sets, instead of once per pass of an unrelated wavefront elsewhere on the chip (-8: three passes).
-template <int VARIANT, int LAG, bool MS4, bool GROUPED>
-__global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
+template <int VARIANT, int LAG, int SRC, bool GROUPED>
+__global__ __launch_bounds__(TPB, (VARIANT == 8 && SRC != 0) ? 4 : AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
                                                                             uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
                                                                             double *__restrict__ autoc_out)
 {
@@ -161,12 +179,13 @@ __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(cons
 		I.wasted[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.wasted);
 		I.which[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.which);
 		any_lpc |= pr.flags & PREP_LPC;
-		if(!MS4) I.ptr[t] = pcm + (size_t)(fc / P.ncand) * N * C;
+		if(SRC == 0) I.ptr[t] = pcm + (size_t)(fc / P.ncand) * N * C;
 	}
-	if(MS4) {
+	if(SRC != 0) {
+		constexpr int PER = SRC == 1 ? 4 : 2;                      // subframes per frame
 #pragma unroll
-		for(int fr = 0; fr < 4; fr++) {
-			const uint32_t f = fc0 / 4 + (uint32_t)fr < nmain ? fc0 / 4 + (uint32_t)fr : nmain - 1;
+		for(int fr = 0; fr < A2_ITEMS / PER; fr++) {
+			const uint32_t f = fc0 / PER + (uint32_t)fr < nmain ? fc0 / PER + (uint32_t)fr : nmain - 1;
 			I.ptr[fr] = pcm + (size_t)f * N * C;
 		}
 	}
@@ -190,12 +209,12 @@ __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(cons
 
 	// history of tile 0: d[L-16, L)
 	{
-		A2Fetch<MS4> H;
-		a2_fetch<MS4>(J, I, C, (int32_t)L - A2_H + (lane & 15), H);
-		if(lane < A2_H) a2_store<MS4>(tile, I, H, lane);
+		A2Fetch<SRC> H;
+		a2_fetch<SRC>(J, I, C, (int32_t)L - A2_H + (lane & 15), H);
+		if(lane < A2_H) a2_store<SRC>(tile, I, H, lane);
 	}
-	A2Fetch<MS4> F;
-	a2_fetch<MS4>(J, I, C, (int32_t)L + lane, F);
+	A2Fetch<SRC> F;
+	a2_fetch<SRC>(J, I, C, (int32_t)L + lane, F);
 	for(uint32_t t = 0; t < ntiles; t++) {
 		if(t) {
 			// the last 16 samples become the history of the next tile (one wavefront: LDS operations execute in order)
@@ -206,8 +225,8 @@ __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(cons
 #pragma unroll
 			for(int u = 0; u < 4; u++) tile[item * A2_IST + 4 * l + u] = hv[u];
 		}
-		a2_store<MS4>(tile, I, F, A2_H + lane);
-		if(t + 1 < ntiles) a2_fetch<MS4>(J, I, C, (int32_t)(L + A2_T * (t + 1)) + lane, F);
+		a2_store<SRC>(tile, I, F, A2_H + lane);
+		if(t + 1 < ntiles) a2_fetch<SRC>(J, I, C, (int32_t)(L + A2_T * (t + 1)) + lane, F);
 		__builtin_amdgcn_wave_barrier();
 		const uint32_t k0 = 8 * t;
 		const uint32_t ksteps = nb - k0 < 8 ? nb - k0 : 8;
@@ -238,10 +257,10 @@ __global__ __launch_bounds__(TPB, AUTOC2_WAVES_PER_SIMD) void autoc2_kernel(cons
 	// ---- head d[0,16) and tail d[nd-24, nd) of every subframe as plain copies (the tile is dead now) --------------
 	const uint32_t tail_lo = nd - 24;               // nd > 32
 	{
-		A2Fetch<MS4> H;
+		A2Fetch<SRC> H;
 		const int u = lane < 40 ? lane : 39;
-		a2_fetch<MS4>(J, I, C, u < 16 ? u : (int32_t)tail_lo + (u - 16), H);
-		if(lane < 40) a2_store<MS4>(tile, I, H, lane);
+		a2_fetch<SRC>(J, I, C, u < 16 ? u : (int32_t)tail_lo + (u - 16), H);
+		if(lane < 40) a2_store<SRC>(tile, I, H, lane);
 	}
 	__builtin_amdgcn_wave_barrier();
 	// lane (subframe, l) finishes lags l, l+4, l+8, l+12: the four lane accumulators of a lag sit in one quad
@@ -278,20 +297,22 @@ static void launch_autoc2_t(const DevParams &P, const int32_t *pcm, const float 
                             const ChanPrep *preps, double *autoc, hipStream_t s)
 {
 	const uint32_t nfc = nmain * P.ncand, ngroups = (nfc + A2_ITEMS - 1) / A2_ITEMS;
-	const bool ms4 = P.channels == 2 && P.ms_mode == 1;
+	const bool ms4 = P.channels == 2 && P.ms_mode == 1, st2 = P.channels == 2 && P.ncand == 2;
 	static int nogroup = -1;
 	if(nogroup < 0) nogroup = getenv("FLACGPU_AUTOC2_UNGROUPED") ? 1 : 0;
 	if(nsets >= 2 && nsets <= 8 && !nogroup) {
 		// one single-wavefront workgroup per (group of subframes, job set)
 		const dim3 grid(ngroups * nsets), block(64);
-		if(ms4) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, true, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
-		else hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, false, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+		if(ms4) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, 1, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+		else if(st2) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, 2, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+		else hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, 0, true>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
 		return;
 	}
 	const uint32_t waves = njobs * ngroups;
 	const dim3 grid((waves + TPB / 64 - 1) / (TPB / 64)), block(TPB);
-	if(ms4) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, true, false>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
-	else hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, false, false>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+	if(ms4) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, 1, false>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+	else if(st2) hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, 2, false>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
+	else hipLaunchKernelGGL((autoc2_kernel<VARIANT, LAG, 0, false>), grid, block, 0, s, P, pcm, win, nmain, jt, preps, autoc);
 }
 
 // true when the streaming kernel serves the nominal-length frames of this configuration

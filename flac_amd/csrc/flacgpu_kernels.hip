@@ -211,13 +211,14 @@ __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const 
 // The same for pack2_kernel's LDS image: 44-byte spans (conflict-free reads, see CRC2_SPAN); every lane loads its eleven words
 // at once and runs them under a predicate, the lane with the short last span included -- that span used to be a byte-serial
 // chain of up to 64 dependent LDS round trips which the whole workgroup waited for at the barrier.
+template <int NT>
 __device__ __forceinline__ uint32_t frame_crc16_p2(const uint32_t *img, uint32_t body_bytes, const uint16_t (*crc_tab)[256], uint32_t *crc_parts, int tid,
                                                    const uint16_t *xspan_lds, uint32_t nxspan_lds, const uint16_t *xbyte_lds)
 {
 	const uint32_t nsp = (body_bytes + CRC2_SPAN - 1) / CRC2_SPAN;
 	const uint32_t last_len = body_bytes - (nsp ? nsp - 1 : 0) * CRC2_SPAN;                // 1..44 bytes
 	uint32_t c = 0;                     // low half: whole spans, shifted among themselves; high half: the last span
-	for(uint32_t sp = (uint32_t)tid; sp < nsp; sp += TPB) {
+	for(uint32_t sp = (uint32_t)tid; sp < nsp; sp += NT) {
 		const uint32_t *wp = img + sp * CRC2_WORDS;
 		uint32_t w[CRC2_WORDS];
 #pragma unroll
@@ -252,7 +253,7 @@ __device__ __forceinline__ uint32_t frame_crc16_p2(const uint32_t *img, uint32_t
 	if((tid & 63) == 0) crc_parts[tid >> 6] = c;
 	__syncthreads();
 	uint32_t crc = 0;
-	for(int w = 0; w < TPB / 64; w++) crc ^= crc_parts[w];
+	for(int w = 0; w < NT / 64; w++) crc ^= crc_parts[w];
 	return gf16_mul(crc & 0xffffu, xbyte_lds[last_len]) ^ (crc >> 16);
 }
 
@@ -621,13 +622,14 @@ __device__ __forceinline__ uint64_t scan_lookback(uint64_t *state, uint32_t f, u
 	return excl;
 }
 // the finished frame image (big-endian word views in LDS) to byte address dst, whatever its alignment
+template <int NT = TPB>
 __device__ __forceinline__ void store_image(const uint32_t *img, uint8_t *dst, uint32_t nb, int tid)
 {
 	const uint32_t head = umin32((uint32_t)((4 - ((uintptr_t)dst & 3)) & 3), nb);
 	if((uint32_t)tid < head) dst[tid] = (uint8_t)(img[0] >> (24 - 8 * tid));
 	const uint32_t words = (nb - head) >> 2, sh = head * 8;
 	uint32_t *dw = (uint32_t *)(dst + head);
-	for(uint32_t w = (uint32_t)tid; w < words; w += TPB) {
+	for(uint32_t w = (uint32_t)tid; w < words; w += NT) {
 		const uint32_t be = sh ? (img[w] << sh) | (img[w + 1] >> (32 - sh)) : img[w];
 		dw[w] = __builtin_bswap32(be);
 	}
@@ -690,11 +692,13 @@ __device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[32], const int32
 
 // HINTS: the instantiation that also leaves its run starts behind for the verify pass (four more registers, which cost the
 // 8-tap instance its fifth workgroup per CU: only paid when verification is on)
-template <int MAXORD, bool HINTS>
+// NT: threads of the workgroup = 16-sample runs per pass: 256 for blocks of up to 4096 samples, 128 for the 1152-sample blocks of
+// -0 .. -2 (72 runs: 256 threads would idle three in four)
+template <int MAXORD, bool HINTS, int NT>
 #ifndef PACK2_WAVES
 #define PACK2_WAVES 4
 #endif
-__global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams P, const int32_t *__restrict__ chan,
+__global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams P, const int32_t *__restrict__ chan,
                                                     uint32_t nmain, uint64_t first_frame_number,
                                                     const SubDecision *__restrict__ decisions,
                                                     uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
@@ -723,20 +727,28 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 	{
 		// (straight-line, every load unconditional with its index clamped: as loops with their own bounds these were five basic blocks,
 		//  each ending in a wait for its own load -- five round trips where one will do)
-		constexpr uint32_t DEC_ROUNDS = (FLACGPU_MAX_CHANNELS * (uint32_t)(sizeof(SubDecision) / 4) + TPB - 1) / TPB;
-		static_assert(P2_XSPAN / 2 == TPB && 4 * 256 / 2 == 2 * TPB && (CRC_SPAN + 2) / 2 <= TPB, "one pass of the workgroup per table");
+		constexpr uint32_t DEC_ROUNDS = (FLACGPU_MAX_CHANNELS * (uint32_t)(sizeof(SubDecision) / 4) + NT - 1) / NT;
+		constexpr uint32_t TAB_ROUNDS = (4 * 256 / 2) / NT, XS_ROUNDS = (P2_XSPAN / 2) / NT;
+		static_assert((4 * 256 / 2) % NT == 0 && (P2_XSPAN / 2) % NT == 0 && (CRC_SPAN + 2) / 2 <= NT, "whole passes of the workgroup per table");
 		const uint32_t ndw = P.ncand * (uint32_t)(sizeof(SubDecision) / 4);
 		const uint32_t *decw = (const uint32_t *)dec, *tab32 = (const uint32_t *)g_crc_tables.tab, *xs32 = (const uint32_t *)g_crc_tables.xspan44,
 		               *xb32 = (const uint32_t *)g_crc_tables.xbyte;
 		uint32_t dv[DEC_ROUNDS];
 #pragma unroll
-		for(uint32_t k = 0; k < DEC_ROUNDS; k++) { const uint32_t w = (uint32_t)tid + k * TPB; dv[k] = decw[w < ndw ? w : ndw - 1]; }
-		const uint32_t t0 = tab32[tid], t1 = tab32[tid + TPB], xv = xs32[tid], bv = xb32[tid < (int)(CRC_SPAN + 2) / 2 ? tid : 0];
-		for(uint32_t w = (uint32_t)tid; w < cap_words + 2; w += TPB) img[w] = 0;
+		for(uint32_t k = 0; k < DEC_ROUNDS; k++) { const uint32_t w = (uint32_t)tid + k * NT; dv[k] = decw[w < ndw ? w : ndw - 1]; }
+		uint32_t tv[TAB_ROUNDS], xv[XS_ROUNDS];
 #pragma unroll
-		for(uint32_t k = 0; k < DEC_ROUNDS; k++) { const uint32_t w = (uint32_t)tid + k * TPB; if(w < ndw) sh->dec[w] = dv[k]; }
-		((uint32_t *)sh->crc_tab)[tid] = t0; ((uint32_t *)sh->crc_tab)[tid + TPB] = t1;
-		((uint32_t *)sh->xspan)[tid] = xv;
+		for(uint32_t k = 0; k < TAB_ROUNDS; k++) tv[k] = tab32[(uint32_t)tid + k * NT];
+#pragma unroll
+		for(uint32_t k = 0; k < XS_ROUNDS; k++) xv[k] = xs32[(uint32_t)tid + k * NT];
+		const uint32_t bv = xb32[tid < (int)(CRC_SPAN + 2) / 2 ? tid : 0];
+		for(uint32_t w = (uint32_t)tid; w < cap_words + 2; w += NT) img[w] = 0;
+#pragma unroll
+		for(uint32_t k = 0; k < DEC_ROUNDS; k++) { const uint32_t w = (uint32_t)tid + k * NT; if(w < ndw) sh->dec[w] = dv[k]; }
+#pragma unroll
+		for(uint32_t k = 0; k < TAB_ROUNDS; k++) ((uint32_t *)sh->crc_tab)[(uint32_t)tid + k * NT] = tv[k];
+#pragma unroll
+		for(uint32_t k = 0; k < XS_ROUNDS; k++) ((uint32_t *)sh->xspan)[(uint32_t)tid + k * NT] = xv[k];
 		if(tid < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[tid] = bv;
 	}
 	__syncthreads();
@@ -787,7 +799,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 			pos += sbps;
 		}
 		else if(type == 1) {
-			for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * TPB) {
+			for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * NT) {
 				int32_t x[CHUNK];
 				if(fmt16) {
 					const uint4 a = ((const uint4 *)src)[base / 8], b = ((const uint4 *)src)[base / 8 + 1];
@@ -847,7 +859,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 			const uint32_t psize = n >> po;
 			PSTAMP(2 + 4 * s);
 			const int fmode = fir_mode(wide, sbps);
-			for(uint32_t base0 = 0; base0 < n; base0 += CHUNK * TPB) {
+			for(uint32_t base0 = 0; base0 < n; base0 += CHUNK * NT) {
 				const uint32_t base = base0 + CHUNK * (uint32_t)tid;
 				const bool active = base < n;
 				int32_t r[CHUNK];
@@ -932,7 +944,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 				__syncthreads();
 				uint32_t woff = 0, total = 0;
 #pragma unroll
-				for(int w = 0; w < TPB / 64; w++) { const uint32_t tw = sh->wtot[scan_buf][w]; if(w < wave) woff += tw; total += tw; }
+				for(int w = 0; w < NT / 64; w++) { const uint32_t tw = sh->wtot[scan_buf][w]; if(w < wave) woff += tw; total += tw; }
 				scan_buf ^= 1;
 				PSTAMP(4 + 4 * s);
 				if(active) {
@@ -969,7 +981,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 	const uint32_t total_bytes = body_bytes + 2;
 	const bool overflow = total_bytes > P.slot_bytes;
 	{
-		const uint32_t crc = frame_crc16_p2(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, tid, sh->xspan, P2_XSPAN, sh->xbyte);
+		const uint32_t crc = frame_crc16_p2<NT>(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, tid, sh->xspan, P2_XSPAN, sh->xbyte);
 		PSTAMP(11);
 		if(tid == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
@@ -984,7 +996,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 		}
 		__syncthreads();
 		const uint64_t off = ((uint64_t)sh->excl_hi << 32) | sh->excl_lo;
-		if(mine && off + mine <= O.cap) store_image(img, O.out + off, mine, tid);
+		if(mine && off + mine <= O.cap) store_image<NT>(img, O.out + off, mine, tid);
 		if(tid == 0) {
 			frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
 			O.offsets[f] = off;
@@ -995,7 +1007,7 @@ __global__ __launch_bounds__(TPB, PACK2_WAVES) void pack2_kernel(const DevParams
 	else {
 		uint32_t *dst = (uint32_t *)(slots + (size_t)f * P.slot_bytes);
 		const uint32_t words = (umin32(total_bytes, P.slot_bytes) + 3) >> 2;
-		for(uint32_t w = (uint32_t)tid; w < words; w += TPB) dst[w] = __builtin_bswap32(img[w]);
+		for(uint32_t w = (uint32_t)tid; w < words; w += NT) dst[w] = __builtin_bswap32(img[w]);
 		if(tid == 0) {
 			frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
 			if(info) info[f].channel_assignment = (uint8_t)ca;
@@ -1197,8 +1209,10 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 	if(!attr_set) {
 		hipError_t e = hipFuncSetAttribute((const void *)pack_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if constexpr(MAXORD <= 16) {
-			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, true, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, TPB / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, true, TPB / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		}
 		if(e != hipSuccess) return e;
 		attr_set = true;
@@ -1218,8 +1232,12 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 				O.out = po->out; O.cap = po->cap; O.offsets = po->offsets; O.total = po->total; O.state = po->state;
 				if(hipMemsetAsync(po->state, 0, ((size_t)f_lo + 1) * sizeof(uint64_t), s) != hipSuccess) return hipErrorUnknown;
 			}
-			if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
-			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			// half the threads for blocks that half of them cover in one pass (the 1152-sample blocks of -0 .. -2: 72 runs)
+			const bool half = P.blocksize <= CHUNK * (TPB / 2);
+			if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
 			if(hinted_frames) *hinted_frames = hints ? f_lo : 0;
 		}
 	}

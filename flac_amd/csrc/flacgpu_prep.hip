@@ -19,7 +19,7 @@
 namespace flacgpu {
 
 #ifndef P2_WAVES
-#define P2_WAVES 4
+#define P2_WAVES 3
 #endif
 
 struct Prep2Acc {
@@ -69,7 +69,11 @@ __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_c
 }
 
 // WIDE: per-run partial sums may exceed 32 bits (more than 20 bits per sample)
-template <bool WIDE>
+// NFIX: the block size when it is one of the presets' (4096, 1152), else 0 = read it from the parameters.  A constant block size
+// makes the LDS tile stride a constant and folds the tile addresses into instruction offsets: with the stride in a register the
+// kernel spilled 27 VGPRs (the story of prep3_kernel below, which serves stereo with a mid/side search; this one serves the
+// presets without one, -0 and -3, the loose ones, -1 and -4 at 1152, and everything that is not stereo).
+template <bool WIDE, uint32_t NFIX>
 __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
                                                     ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
                                                     int32_t *__restrict__ chan)
@@ -79,14 +83,14 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 	__shared__ uint32_t sh_loose_ms;
 	const int tid = (int)threadIdx.x, lane = tid & 63;
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6), nthreads = blockDim.x;
-	const uint32_t C = P.channels, N = P.blocksize, n = N;          // n % 16 == 0 (prep2_applicable)
+	const uint32_t C = P.channels, N = NFIX ? NFIX : P.blocksize, n = N;          // n % 16 == 0 (prep2_applicable)
 	const uint32_t f = blockIdx.x;
 	const int32_t *frame_pcm = pcm + (size_t)f * N * C;
 	const bool stereo_ms = C == 2 && P.ms_mode != 0;
 	const uint32_t G = stereo_ms ? 2u : (C < 4 ? C : 4u);            // raw channels staged per round
 	const uint32_t cstride = P.ncslots;
 	const uint32_t nchunks = n / CHUNK;
-	const uint32_t TS = p2_ts(n), cbytes = p2_chan_bytes(n);
+	const uint32_t TS = NFIX ? ((NFIX / CHUNK - 1 + 31) / 32) * 32 + 2 : p2_ts(n), cbytes = CHUNK * TS * 4;       // (p2_ts, p2_chan_bytes)
 	const bool need_flags = P.limit_min_bitrate || P.ms_mode == 2;
 
 	for(uint32_t c0 = 0; c0 < C; c0 += G) {
@@ -100,6 +104,8 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 				int32_t *sl = (int32_t *)smem, *sr = (int32_t *)(smem + cbytes);
 				const int2 *p = (const int2 *)frame_pcm;
 				uint32_t a = a0;
+				// (eight loads in flight per thread: rolled, this loop was a load, a wait and two LDS stores per trip)
+#pragma unroll 8
 				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads, a += nthreads / 16) { const int2 lr = p[i]; sl[a] = lr.x; sr[a] = lr.y; }
 			}
 			else {
@@ -466,8 +472,10 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	if(nmain == 0) return hipSuccess;
 	static bool attr_set = false;
 	if(!attr_set) {
-		hipError_t e = hipFuncSetAttribute((const void *)prep2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		hipError_t e = hipSuccess;
+#define P2ATTR(W, NF) if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep2_kernel<W, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)
+		P2ATTR(false, 0); P2ATTR(false, 1152); P2ATTR(false, 4096); P2ATTR(true, 0); P2ATTR(true, 1152); P2ATTR(true, 4096);
+#undef P2ATTR
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
@@ -488,8 +496,10 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
 	const uint32_t waves = stereo_ms ? 4u : nraw;
 	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize);
-	if(P.bps > 20) hipLaunchKernelGGL(prep2_kernel<true>, dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
-	else hipLaunchKernelGGL(prep2_kernel<false>, dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
+#define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan)
+	if(P.bps > 20) { if(P.blocksize == 4096) P2GO(true, 4096); else if(P.blocksize == 1152) P2GO(true, 1152); else P2GO(true, 0); }
+	else { if(P.blocksize == 4096) P2GO(false, 4096); else if(P.blocksize == 1152) P2GO(false, 1152); else P2GO(false, 0); }
+#undef P2GO
 	return hipGetLastError();
 }
 
