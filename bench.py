@@ -345,19 +345,22 @@ def main():
             alg_bytes = samples_per_step * (4 * CH + out_bps)         # PCM read once + frames written once
             dom = max(kms, key=kms.get)
             achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
-            traffic = None
+            traffic = valu_busy = None
             try:
                 with open(PMC_FILE) as fh:
                     pmc = json.load(fh)
                 for name in KERNEL_NAMES[dom].split("+"):
                     if name in pmc["kernels"]:
                         traffic = (traffic or 0) + int(pmc["kernels"][name]["hbm_bytes_per_frame"] * nframes)
+                        valu_busy = pmc["kernels"][name].get("valu_busy_frac", valu_busy)
             except Exception:
                 pass
             res.update(value=world * samples_per_step * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=kms, out_bps=out_bps,
                        roofline={"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
-                                 "whole_step_frac": round(alg_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 6)})
+                                 "whole_step_frac": round(alg_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 6),
+                                 # what actually bounds this kernel: the share of its cycles in which it issues VALU work (committed PMC pass)
+                                 "valu_busy_frac_of_committed_pmc_pass": valu_busy})
             if not args.no_verify:
                 res["verified"] = verify_step(pcm_h, out_h, fb_h, first_frame, level, block, search=search)
         eng.close()
