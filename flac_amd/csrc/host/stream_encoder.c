@@ -695,6 +695,8 @@ static int emit(FLAC__StreamEncoder *e, const uint8_t *buf, size_t bytes, uint32
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	FLAC__uint64 pos = 0;
+	/* (the tell callback is called where write_frame_ calls it: for a metadata write, :3054, and -- once, lazily -- for a frame
+	 * that holds a seek point of the template, :3083; not in front of every frame) */
 	if(samples == 0) {
 		/* watch STREAMINFO and the first SEEKTABLE go by to learn their offsets */
 		const unsigned type = buf[0] & 0x7f;
