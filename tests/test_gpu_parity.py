@@ -462,7 +462,8 @@ def _random_config(rng):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FLACGPU_TEST_SEEDS", "40"))))
 def test_random_configurations(seed):
     """seeded sweep over the configuration space (block size, width, channels, orders, partition orders, apodizations,
-    searches, disable switches, short last blocks): GPU == oracle driven by the same resolved settings"""
+    searches, disable switches, short last blocks): GPU == oracle driven by the same resolved settings, and the device's own
+    verify pass accepts every batch"""
     import flac_amd
     from oracle_from_settings import oracle_encode_settings
     rng = np.random.default_rng(1000 + seed)
@@ -476,7 +477,13 @@ def test_random_configurations(seed):
             continue                                   # the reference's init would refuse this combination, too
         eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=8)          # nothing make_settings accepts is refused
         try:
+            eng.set_verify(True)                       # every batch is decoded again on the device (the hinted pass where it applies)
             data, fb = eng.encode(pcm)
+            v = eng.last_verify_result()
+            in_range = int(pcm.min()) >= -(1 << (bps - 1)) and int(pcm.max()) < (1 << (bps - 1))
+            # (a test signal that does not fit the stream's width -- `constant` is 1234 at any width -- encodes like the reference
+            #  encodes it and need not decode back to itself: a predicted subframe carries it, a verbatim one truncates it)
+            assert v.status == 0 if in_range else v.status in (0, 1), ("verify", v.status, v.frame_number, v.channel, v.sample, fam, n, ch, bps, rate, kw)
         finally:
             eng.close()
         o = oracle_encode_settings(pcm, s)
