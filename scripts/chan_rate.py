@@ -14,7 +14,10 @@ import flac_amd  # noqa: E402
 import signals  # noqa: E402
 
 NF, N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 4096
+ONLY = os.environ.get("CHAN_ONLY")             # e.g. CHAN_ONLY=mono under a profiler
 for ch, kw, name in ((1, {}, "mono"), (2, dict(mid_side=0), "stereo, no mid/side"), (2, {}, "stereo -8"), (6, {}, "5.1")):
+    if ONLY and not name.startswith(ONLY):
+        continue
     base = signals.music(64 * N, ch, 16, seed=5)
     pcm = np.tile(base, ((NF + 63) // 64, 1))[: NF * N]
     eng = flac_amd.FrameEngine(flac_amd.make_settings(ch, 16, 48000, 8, **kw), device=0, max_batch_frames=NF)
