@@ -303,7 +303,7 @@ __global__ __launch_bounds__(TPB) void prep_kernel(const DevParams P, const int3
 	if(tid == 0) {
 		ChanPrep pr;
 		pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
-		pr.constant = (int32_t)constant; pr.constant_hi = (int32_t)(constant >> 32); pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.pad[0] = pr.pad[1] = 0;
+		pr.constant = (int32_t)constant; pr.constant_hi = (int32_t)(constant >> 32); pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.handled = 0; pr.pad = 0;
 		preps[fc] = pr;
 	}
 }
@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 		E.nan = P.nfixed + ((pr.flags & PREP_LPC) ? jt->nanalyses * aslots : 0);       // candidate slots of this channel
 		E.any = (!(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || E.nan > P.nfixed)) ? 1u : 0u;
 		const int kind = !E.any ? 0 : owner ? 0 : 2;
-		E.mine = kind == VARIANT ? 1u : 0u;
+		E.mine = (kind == VARIANT && pr.handled != EVG_HANDLED) ? 1u : 0u;       // (evalg_kernel ran first and took what it could)
 		E.packed = (VARIANT == 0 && pr.fmt && (S % 2 == 0)) ? 1u : 0u;
 		E.stride = owner_stride_words(S, E.packed != 0);
 	}
@@ -1395,6 +1395,10 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		ahead = nb * 16;            // (measured on MI355X, profiles/r02_g_prefetch_ab.txt: 32..96 workgroups ahead are equally good, 256 is too early)
 		if(const char *e = getenv("FLACGPU_EVAL_PREFETCH")) ahead = atoi(e);
 		if(ahead < 0) ahead = 0;
+	}
+	if(op && evalg_applicable(P)) {
+		const hipError_t e = launch_evalg(P, tail_n ? nframes - 1 : nframes, jtm, B, dec, s);
+		if(e != hipSuccess) return e;
 	}
 	if(op) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, (uint32_t)ahead);
 	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u);

@@ -105,8 +105,10 @@ struct ChanPrep {
 	uint32_t fmt;              // planar channel copy: 1 = 16-bit pairs (every sample fits int16: sbps <= 16, or a quiet side
 	                           // channel), 0 = 32-bit samples, 2 = 64-bit samples (sbps 33)
 	int32_t constant_hi;       // bits 32.. of a 33-bit constant
-	uint32_t pad[2];
+	uint32_t handled;          // written 0 by the prep kernels; EVG_HANDLED once evalg_kernel (flacgpu_evalg.hip) has decided the channel
+	uint32_t pad;
 };
+constexpr uint32_t EVG_HANDLED = 0x600Du;
 struct AnalyzeBuffers {
 	ChanPrep *prep;            // [frames*ncand]
 	double *autoc;             // [frames*ncand][max_jobs][AUTOC_STRIDE]
@@ -133,6 +135,8 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 bool autoc2_applicable(const DevParams &P);
 hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
                          const ChanPrep *preps, double *autoc, hipStream_t s);
+bool evalg_applicable(const DevParams &P);
+hipError_t launch_evalg(const DevParams &P, uint32_t nmain, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);
 bool prep2_applicable(const DevParams &P);
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s);
 // where the pack kernel may put the frames directly (fused compaction: single-pass prefix sum of the frame lengths inside the

@@ -1,0 +1,452 @@
+// flac_amd/csrc/flacgpu_evalg.hip -- the residual evaluation of process_subframe_ (stream_encoder.c:4147-4290) for the
+// case every preset produces: one WAVEFRONT per (frame, candidate channel), every residual candidate of the channel
+// evaluated by that one wavefront.
+//
+// Why (round 3): the wavefront-per-candidate kernel (flacgpu_analyze.hip: eval_kernel<.,0>) is bound by the number of VALU
+// instructions it issues, and a third of them were not arithmetic the reference asks for: every candidate formed the
+// same shifted sample words from the same LDS image, formed x + bias per sample, evaluated 448 Rice nodes for a tree
+// of 127, and paid its own dispatch.  Here
+//   * lane L owns samples [L*S, (L+1)*S) of the block (same owner layout), and the candidates of a channel are taken
+//     TWO AT A TIME through the block: the sample words and their one-sample-shifted companions are loaded / formed once
+//     per pair;
+//   * the sample itself rides in the tap chain: with t = sum_k q_k x[i-k] - 2^s x[i] (one more 16-bit tap, -2^s fits
+//     int16 for s <= 15) the residual is -(t >> s) exactly (arithmetic shift; 2^s x[i] is a multiple of 2^s), so
+//     |residual| = |((t + 2^31) >> s logical) - 2^(31-s)| is one v_sad_u32 against a constant -- no x + bias per sample.
+//     Exact as long as t does not leave 32 bits: checked per candidate from its coefficients
+//     (2^(sbps-1) * (sum|q| + 2^s) < 2^31); a channel with a candidate that fails it is left to eval_kernel;
+//   * the taps, shifts and biases of the pair live in SGPRs (v_dot2_i32_i16 takes one scalar operand);
+//   * the Rice search (stream_encoder.c:4701-5075) of a pair evaluates every node of both partition trees ONCE: the leaf
+//     sums go through one prefix sum over the lanes into LDS, a node's sum is the difference of two entries, and the
+//     2 x 127 nodes are spread over four lane passes (leaves of candidate 0 | leaves of candidate 1 | the two
+//     32-node levels | everything above) instead of seven passes per candidate;
+//   * no workgroup: a wavefront has its own LDS image and meets nobody (no barriers).
+// Same integers as eval_kernel throughout (same FIR low 32 bits, same |residual| sums, same set_partitioned_rice_
+// arithmetic, same first-minimum tie rule).  Channels this kernel does not take -- 17..25-bit samples, 64-bit or
+// overflow-checked candidates, sums that leave the 32-bit Rice arithmetic, block lengths whose lane runs are no
+// multiple of 16 -- stay with eval_kernel, which is launched after it and skips what ChanPrep::handled marks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "flacgpu_dev.h"
+#include "flacgpu_devfn.h"
+
+namespace flacgpu {
+
+#ifndef EVALG_WAVES_PER_SIMD
+#define EVALG_WAVES_PER_SIMD 4
+#endif
+
+constexpr int EG_OH = 16;                 // history samples in front of a lane's run (the owner layout of eval_kernel)
+constexpr int EG_MAXC = 32;               // candidate slots of a channel this kernel takes (lane c holds candidate c's record)
+
+// ---- DPP helpers (the compiler sees these, so it places the wait states itself) --------------------------------------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+	return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside a row of 16, then the row totals
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+	v = dpp_add<0x111, 0xf>(v);            // row_shr:1
+	v = dpp_add<0x112, 0xf>(v);            // row_shr:2
+	v = dpp_add<0x114, 0xf>(v);            // row_shr:4
+	v = dpp_add<0x118, 0xf>(v);            // row_shr:8
+	v = dpp_add<0x142, 0xa>(v);            // row_bcast:15 into rows 1 and 3
+	v = dpp_add<0x143, 0xc>(v);            // row_bcast:31 into rows 2 and 3
+	return v;
+}
+// the same without the last step: lanes 31 and 63 end with the totals of their halves
+__device__ __forceinline__ uint32_t half_scan_incl(uint32_t v)
+{
+	v = dpp_add<0x111, 0xf>(v);
+	v = dpp_add<0x112, 0xf>(v);
+	v = dpp_add<0x114, 0xf>(v);
+	v = dpp_add<0x118, 0xf>(v);
+	v = dpp_add<0x142, 0xa>(v);
+	return v;
+}
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// ---- the FIR of one candidate over one 16-sample piece of every lane's run ------------------------------------------
+// AA[j]: the word holding samples (2j - 14, 2j - 13) relative to the piece start, BB[m] = samples (2m - 13, 2m - 12).
+// Folded taps c_0 = -2^shift, c_j = q[j-1]; Q[p] = (c_2p << 16) | (c_2p+1 & 0xffff): the high half multiplies the nearer
+// sample.  Sample s of the piece: pairs p = 0..NPF-1 are (x[s-2p], x[s-2p-1]) = AA[(s+13)/2 - p] for odd s,
+// BB[s/2 + 6 - p] for even s.  NPF dependent v_dot2_i32_i16 and the logical shift are ONE asm statement (between separate
+// statements the compiler pads every dependent pair with an s_nop, flacgpu_devfn.h: dot2_chain_lshr).
+template <int NPF>
+__device__ __forceinline__ uint32_t dot2_chain_s(const uint32_t (&W)[NPF], const uint32_t (&Q)[7], uint32_t sum0, uint32_t shift)
+{
+	uint32_t d;
+	if constexpr(NPF == 1) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_lshrrev_b32 %0, %4, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "s"(shift));
+	if constexpr(NPF == 2) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_lshrrev_b32 %0, %6, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "s"(shift));
+	if constexpr(NPF == 3) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_lshrrev_b32 %0, %8, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "v"(W[2]), "s"(Q[2]), "s"(shift));
+	if constexpr(NPF == 4) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_lshrrev_b32 %0, %10, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "v"(W[2]), "s"(Q[2]), "v"(W[3]), "s"(Q[3]), "s"(shift));
+	if constexpr(NPF == 5) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_lshrrev_b32 %0, %12, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "v"(W[2]), "s"(Q[2]), "v"(W[3]), "s"(Q[3]), "v"(W[4]), "s"(Q[4]), "s"(shift));
+	if constexpr(NPF == 6) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_lshrrev_b32 %0, %14, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "v"(W[2]), "s"(Q[2]), "v"(W[3]), "s"(Q[3]), "v"(W[4]), "s"(Q[4]), "v"(W[5]), "s"(Q[5]), "s"(shift));
+	if constexpr(NPF == 7) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_dot2_i32_i16 %0, %14, %15, %0\n\tv_lshrrev_b32 %0, %16, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "v"(W[2]), "s"(Q[2]), "v"(W[3]), "s"(Q[3]), "v"(W[4]), "s"(Q[4]), "v"(W[5]), "s"(Q[5]), "v"(W[6]), "s"(Q[6]), "s"(shift));
+	return d;
+}
+__device__ __forceinline__ uint32_t sad_u32_s(uint32_t a, uint32_t b_uniform, uint32_t c)       // |a - b| + c, b in an SGPR
+{
+	uint32_t d;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+	return d;
+}
+// FIRST: the piece that opens the block -- lane 0's first `order` samples are warm-up, not residual
+template <int NPF, bool FIRST>
+__device__ __forceinline__ uint32_t fir16_folded(const uint32_t (&AA)[15], const uint32_t (&BB)[14], const uint32_t (&Q)[7], uint32_t shift, uint32_t bias, uint32_t order,
+                                                 bool lane0, uint32_t sum0, uint32_t acc)
+{
+#pragma unroll
+	for(int s = 0; s < 16; s++) {
+		uint32_t W[NPF];
+#pragma unroll
+		for(int p = 0; p < NPF; p++) W[p] = (s & 1) ? AA[(s + 13) / 2 - p] : BB[s / 2 + 6 - p];
+		uint32_t pb = dot2_chain_s<NPF>(W, Q, sum0, shift);
+		if(FIRST && s < 2 * NPF - 1) { if(lane0 && (uint32_t)s < order) pb = bias; }
+		acc = sad_u32_s(pb, bias, acc);
+	}
+	return acc;
+}
+template <bool FIRST>
+__device__ __forceinline__ uint32_t fir16_dispatch(uint32_t npf, const uint32_t (&AA)[15], const uint32_t (&BB)[14], const uint32_t (&Q)[7], uint32_t shift, uint32_t bias,
+                                                   uint32_t order, bool lane0, uint32_t sum0, uint32_t acc)
+{
+	switch(npf) {
+	case 1: return fir16_folded<1, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 2: return fir16_folded<2, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 3: return fir16_folded<3, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 4: return fir16_folded<4, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 5: return fir16_folded<5, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 6: return fir16_folded<6, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	default: return fir16_folded<7, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	}
+}
+__device__ __forceinline__ void load_piece(const uint32_t *w /* word of sample (piece start - 14) */, uint32_t (&AA)[15], uint32_t (&BB)[14])
+{
+#pragma unroll
+	for(int j = 0; j < 15; j++) AA[j] = w[j];
+#pragma unroll
+	for(int m = 0; m < 14; m++) BB[m] = __builtin_amdgcn_alignbit(AA[m + 1], AA[m], 16);
+}
+
+// one slot of the pair: a residual candidate's folded taps and scalars, all wave-uniform
+struct EgSlot { uint32_t Q[7]; uint32_t shift, bias, order, npf, precision, ci; };
+
+// ---- one node pass of the Rice search ---------------------------------------------------------------------------
+// lane constants of a pass: LDS byte offsets of the two prefix-sum entries whose difference is twice the node's
+// |residual| sum; nsf9 = samples of a full partition at this level + 9 (0: the lane has no node in this pass);
+// dtoff = byte offset of the level's row of the divisor table; p0 = the node is partition 0 (`order` samples short)
+struct EgPass { uint32_t a_start, a_end, nsf9, dtoff; bool p0; };
+// set_partitioned_rice_ (stream_encoder.c:4997-5046) on sum2 = 2 * sum, sum < 2^29, without branches:
+//   k    = ilog2(((sum - 1) * div) >> 18) + 1 for sum >= 2 and a non-zero quotient, else 0; div = 0x40000 / ns
+//   bits = 4 + (1 + k) * ns + (k ? sum >> (k - 1) : sum << 1) - (ns >> 1)              (:4929-4950, the estimate)
+// with (sum - 1) * div >> 18 == mul_hi(2 * (sum - 1), div << 13), and ilog2(x) + 1 == the binary exponent of (float)x
+// (x < 2^20 here: exact).  ns - (ns >> 1) + 4 == (ns + 9) >> 1.
+__device__ __forceinline__ void rice_pass(const unsigned char *lds, const EgPass &C, uint32_t ord_lane /* this lane's candidate's order */, uint32_t rl1, uint32_t &k, uint32_t &bits)
+{
+	const uint32_t o = C.p0 ? ord_lane : 0u;
+	const uint32_t ns9 = C.nsf9 - o;                                       // (a lane without a node has nsf9 = 0, p0 = false and a zero sum:
+	const uint32_t ns = ns9 - 9u;                                          //  k = 0 and bits = 0 whatever ns wraps to)
+	const uint32_t dsh = *(const uint32_t *)(lds + C.dtoff + o * 4u);
+	const uint32_t sum2 = *(const uint32_t *)(lds + C.a_end) - *(const uint32_t *)(lds + C.a_start);
+	const uint32_t a2 = (sum2 > 2u ? sum2 : 2u) - 2u;
+	const uint32_t x = __umulhi(a2, dsh);
+	uint32_t kk = (uint32_t)__builtin_amdgcn_frexp_expf((float)x);          // 0 for x == 0
+	kk = umin32(kk, rl1);
+	k = kk;
+	bits = __umul24(kk, ns) + (ns9 >> 1) + (sum2 >> kk);
+}
+
+// LDS of one wavefront: [owner image][prefix sums 2 x 66][divisor table 7 x (MAXORD + 1)][best parameters 64 B]
+template <int MAXORD>
+__host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N)
+{
+	const uint32_t S = N / 64, w = ((S + EG_OH) / 2) | 1u;
+	return ((64 * w * 4 + 64 + 15u) & ~15u) + 2 * 66 * 4 + 7 * (MAXORD + 1) * 4 + 64;
+}
+
+template <int MAXORD>
+__global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nchan /* channels of the frames of nominal length */,
+                                                                          const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
+                                                                          const int *__restrict__ valid, SubDecision *__restrict__ decisions)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = (int)threadIdx.x;
+	// blocks reach the XCDs round-robin: keep a frame's channels on one XCD, spread the expensive ones (map as eval_kernel does)
+	const uint32_t fc = blockIdx.x;
+	if(fc >= nchan) return;
+	const uint32_t n = P.blocksize, S = n / 64;
+	const ChanPrep pr = preps[fc];
+	const uint32_t aslots = P.norders * P.nprec, cstride = P.ncslots;
+	const uint32_t nan = P.nfixed + ((pr.flags & PREP_LPC) ? jt->nanalyses * aslots : 0);
+	const bool any = !(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || nan > P.nfixed);
+	// partition order limits of the frame (stream_encoder.c:3759-3761)
+	uint32_t frame_max_po = 0;
+	{ uint32_t b = n; while(!(b & 1)) { frame_max_po++; b >>= 1; } if(frame_max_po > 15) frame_max_po = 15; }
+	frame_max_po = umin32(frame_max_po, P.max_po);
+	const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
+	const uint32_t psize = n >> frame_max_po;
+	const bool narrow = (pr.sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
+	if(!any || pr.fmt != 1 || !narrow || nan > (uint32_t)EG_MAXC || frame_max_po > 6) return;
+
+	// ---- candidate records: lane c holds candidate c -------------------------------------------------------------------
+	uint32_t Qv[7];
+	uint32_t c_order = 0, c_shift = 0, c_prec = 0;
+	bool c_valid = false, c_ok = true;
+	{
+#pragma unroll
+		for(int p = 0; p < 7; p++) Qv[p] = 0;
+		if((uint32_t)lane < nan) {
+			const size_t ix = (size_t)fc * cstride + (uint32_t)lane;
+			c_valid = valid[ix] != 0;
+			if(c_valid) {
+				const Candidate *cd = cands + ix;
+				c_order = cd->order; c_shift = (uint32_t)cd->shift; c_prec = cd->precision;
+				int32_t t[14];
+				uint32_t abs_sum = 0;
+#pragma unroll
+				for(int j = 0; j < 13; j++) {
+					int32_t q = 0;
+					if(j < MAXORD) { q = cd->q[j]; if((uint32_t)j >= c_order) q = 0; }
+					t[j + 1] = q;
+					abs_sum += (uint32_t)(q < 0 ? -q : q);
+				}
+				c_ok = cd->wide == 0 && c_order <= (uint32_t)MAXORD && c_shift <= 15u
+				       && (((uint64_t)abs_sum + (1u << (c_shift & 15u))) << (pr.sbps - 1)) < (1ull << 31);
+				t[0] = -(int32_t)(1u << (c_shift & 15u));
+#pragma unroll
+				for(int p = 0; p < 7; p++) Qv[p] = ((uint32_t)t[2 * p] << 16) | ((uint32_t)t[2 * p + 1] & 0xffffu);
+			}
+		}
+	}
+	if(__any((int)!c_ok)) return;
+	uint64_t vmask = __ballot((int)c_valid);
+	if(vmask == 0) return;                                                   // (any said otherwise; eval_kernel decides such a channel)
+
+	// ---- LDS of this wavefront --------------------------------------------------------------------------------------------
+	const uint32_t stride = ((S + EG_OH) / 2) | 1u;
+	uint32_t *sigw = (uint32_t *)smem;
+	const uint32_t img_bytes = (64 * stride * 4 + 64 + 15u) & ~15u;
+	uint32_t *ps = (uint32_t *)(smem + img_bytes);                           // [2][66]
+	uint32_t *dt = ps + 2 * 66;                                              // [7][MAXORD + 1]: (0x40000 / ((S << m) - o)) << 13
+	uint8_t *kbest = (uint8_t *)(dt + 7 * (MAXORD + 1));
+	const uint32_t ps_off = img_bytes, dt_off = img_bytes + 2 * 66 * 4;
+
+	// the planar channel (16-bit pairs) into the lane-owner image: 8 samples = one 16-byte piece = 4 words of ONE lane's run
+	// (S is a multiple of 16), written again as the next lane's history when they are among the run's last 16
+	{
+		const uint4 *src = (const uint4 *)(chan + (size_t)fc * P.chan_stride);
+		if(lane < EG_OH / 2) sigw[lane] = 0;                                   // lane 0's history
+		const uint32_t nvec = n / 8, vps = S / 8;                              // pieces per lane run
+		const bool spow2 = (vps & (vps - 1)) == 0;
+		const uint32_t vlog = ilog2_u32(vps);
+#pragma unroll 4
+		for(uint32_t m = (uint32_t)lane; m < nvec; m += 64) {
+			const uint4 pv = src[m];
+			const uint32_t Lo = spow2 ? m >> vlog : m / vps, r = m - Lo * vps;          // run, piece of the run
+			uint32_t *d = sigw + Lo * stride + EG_OH / 2 + 4 * r;
+			d[0] = pv.x; d[1] = pv.y; d[2] = pv.z; d[3] = pv.w;
+			if(r + 2 >= vps && Lo + 1 < 64) {
+				uint32_t *h = sigw + (Lo + 1) * stride + 4 * (r + 2 - vps);
+				h[0] = pv.x; h[1] = pv.y; h[2] = pv.z; h[3] = pv.w;
+			}
+		}
+	}
+	// the divisor table: entry (m, o) for partitions of 2^m lane runs, `o` samples short
+	const uint32_t e = 6 - frame_max_po, D = frame_max_po - frame_min_po;
+	for(uint32_t t = (uint32_t)lane; t < 7 * (MAXORD + 1); t += 64) {
+		const uint32_t m = t / (MAXORD + 1), o = t - m * (MAXORD + 1), full = S << m;
+		dt[t] = full > o ? (0x40000u / (full - o)) << 13 : 0u;
+	}
+	if(lane < 2) ps[lane * 66] = 0;
+
+	// ---- lane constants of the node passes ---------------------------------------------------------------------------------
+	// level m: nodes of 2^m lanes, partition order frame_max_po - (m - e); searched when e <= m <= e + D
+	EgPass PA, PC, PD;
+	uint32_t mD;
+	{
+		const uint32_t half = (uint32_t)lane >> 5, j = (uint32_t)lane & 31u;
+		const bool a0 = e == 0;
+		PA.a_start = ps_off + (uint32_t)lane * 4; PA.a_end = PA.a_start + 4;          // (pass B: + 66 * 4)
+		PA.nsf9 = a0 ? S + 9 : 0; PA.dtoff = dt_off; PA.p0 = a0 && lane == 0;
+		const bool a1 = e <= 1 && 1 <= e + D;
+		PC.a_start = ps_off + (half * 66 + 2 * j) * 4; PC.a_end = PC.a_start + 8;
+		PC.nsf9 = a1 ? 2 * S + 9 : 0; PC.dtoff = dt_off + (MAXORD + 1) * 4; PC.p0 = a1 && j == 0;
+		mD = j < 16 ? 2u : j < 24 ? 3u : j < 28 ? 4u : j < 30 ? 5u : j < 31 ? 6u : 7u;
+		const uint32_t idx = j - (32u - (128u >> mD));                                 // (mD == 7: unused)
+		const bool aD = mD <= 6 && e <= mD && mD <= e + D;
+		PD.a_start = ps_off + (half * 66 + (aD ? idx << mD : 0u)) * 4; PD.a_end = PD.a_start + (aD ? (4u << mD) : 0u);
+		PD.nsf9 = aD ? (S << mD) + 9 : 0; PD.dtoff = dt_off + (aD ? mD : 0u) * (MAXORD + 1) * 4; PD.p0 = aD && idx == 0;
+		if(!aD) mD = 7;
+	}
+	const uint32_t rl1 = P.rice_limit - 1;
+	const uint32_t sbps = pr.sbps, hdr = 8 + pr.wasted;
+	const uint32_t *reg = sigw + (uint32_t)lane * stride;                           // this lane's region: 8 history words, then its run
+	const uint32_t npieces = S / 16;
+	const uint32_t sum0 = 0x80000000u;
+	__builtin_amdgcn_wave_barrier();
+
+	// ---- the candidates, two at a time, in the reference's evaluation order ---------------------------------------------------
+	uint32_t best_est = 0xffffffffu, best_ci = 0xffffffffu, best_po = 0;
+	while(vmask) {
+		EgSlot A, B;
+		const uint32_t ci0 = (uint32_t)__builtin_ctzll(vmask);
+		vmask &= vmask - 1;
+		const bool two = vmask != 0;
+		const uint32_t ci1 = two ? (uint32_t)__builtin_ctzll(vmask) : ci0;
+		if(two) vmask &= vmask - 1;
+#pragma unroll
+		for(int p = 0; p < 7; p++) { A.Q[p] = rdlane(Qv[p], ci0); B.Q[p] = rdlane(Qv[p], ci1); }
+		A.shift = rdlane(c_shift, ci0); B.shift = rdlane(c_shift, ci1);
+		A.order = rdlane(c_order, ci0); B.order = rdlane(c_order, ci1);
+		A.precision = rdlane(c_prec, ci0); B.precision = rdlane(c_prec, ci1);
+		A.bias = 0x80000000u >> A.shift; B.bias = 0x80000000u >> B.shift;
+		A.npf = (A.order + 2) / 2; B.npf = (B.order + 2) / 2;
+		A.ci = ci0; B.ci = ci1;
+
+		uint32_t v0 = 0, v1 = 0;
+		{
+			uint32_t AA[15], BB[14];
+			load_piece(reg + 1, AA, BB);
+			v0 = fir16_dispatch<true>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, lane == 0, sum0, v0);
+			if(two) v1 = fir16_dispatch<true>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, lane == 0, sum0, v1);
+		}
+#pragma unroll 1
+		for(uint32_t c = 1; c < npieces; c++) {
+			uint32_t AA[15], BB[14];
+			load_piece(reg + 1 + 8 * c, AA, BB);
+			v0 = fir16_dispatch<false>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+			if(two) v1 = fir16_dispatch<false>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+		}
+		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_kernel's (nothing was written yet)
+		if(__any((int)((v0 | v1) >= (1u << 23)))) return;
+
+		// ---- Rice search of the pair ---------------------------------------------------------------------------------------
+		ps[1 + lane] = wave_scan_incl(v0 << 1);
+		ps[66 + 1 + lane] = wave_scan_incl(v1 << 1);
+		__builtin_amdgcn_wave_barrier();
+		uint32_t tot0[7], tot1[7];                                                // per level m: total bits of the level (uniform)
+#pragma unroll
+		for(int m = 0; m < 7; m++) { tot0[m] = 0; tot1[m] = 0; }
+		uint32_t kA = 0, kB = 0, kC = 0, kD = 0, b;
+		if(e == 0) {
+			rice_pass(smem, PA, A.order, rl1, kA, b);
+			tot0[0] = rdlane(wave_scan_incl(b), 63);
+			EgPass PB = PA; PB.a_start += 66 * 4; PB.a_end += 66 * 4;
+			rice_pass(smem, PB, B.order, rl1, kB, b);
+			tot1[0] = rdlane(wave_scan_incl(b), 63);
+		}
+		const uint32_t ord_lane = lane < 32 ? A.order : B.order;
+		if(e <= 1 && 1 <= e + D) {
+			rice_pass(smem, PC, ord_lane, rl1, kC, b);
+			b = half_scan_incl(b);
+			tot0[1] = rdlane(b, 31); tot1[1] = rdlane(b, 63);
+		}
+		if(e + D >= 2) {
+			rice_pass(smem, PD, ord_lane, rl1, kD, b);
+			// the levels sit in aligned lane groups of their own size (16 | 8 | 4 | 2 | 1): each total is read at the butterfly
+			// stage that has summed exactly its group
+			tot0[6] = rdlane(b, 30); tot1[6] = rdlane(b, 62);
+			b = bfly_add<0>(b); tot0[5] = rdlane(b, 28); tot1[5] = rdlane(b, 60);
+			b = bfly_add<1>(b); tot0[4] = rdlane(b, 24); tot1[4] = rdlane(b, 56);
+			b = bfly_add<2>(b); tot0[3] = rdlane(b, 16); tot1[3] = rdlane(b, 48);
+			b = bfly_add<3>(b); tot0[2] = rdlane(b, 0); tot1[2] = rdlane(b, 32);
+		}
+		__builtin_amdgcn_wave_barrier();                                          // (the prefix sums are rewritten by the next pair)
+
+		// strict <, highest order first: ties keep the higher order (stream_encoder.c:4735-4763)
+#pragma unroll
+		for(int slot = 0; slot < 2; slot++) {
+			if(slot == 1 && !two) break;
+			const EgSlot &X = slot ? B : A;
+			uint32_t bb = 0, bm = 0;
+			bool have = false;
+#pragma unroll
+			for(int m = 0; m < 7; m++) {
+				if((uint32_t)m >= e && (uint32_t)m - e <= D) {
+					const uint32_t bits = 6 + (slot ? tot1[m] : tot0[m]);
+					if(!have || bits < bb) { bb = bits; bm = (uint32_t)m; have = true; }
+				}
+			}
+			const uint32_t est = X.ci < P.nfixed ? sat_add_u32(hdr + X.order * sbps, bb) : sat_add_u32(hdr + 4 + 5 + X.order * (X.precision + sbps), bb);
+			// candidates are met in increasing order; strict <: the earlier one keeps a tie (stream_encoder.c:4191,4266)
+			if(est > 0 && est < best_est) {
+				best_est = est; best_ci = X.ci; best_po = frame_max_po - (bm - e);
+				const uint32_t half = (uint32_t)lane >> 5, j = (uint32_t)lane & 31u;
+				if(bm == 0) kbest[lane] = (uint8_t)(slot ? kB : kA);
+				else if(bm == 1) { if(half == (uint32_t)slot) kbest[j] = (uint8_t)kC; }
+				else if(half == (uint32_t)slot && mD == bm) kbest[j - (32u - (128u >> bm))] = (uint8_t)kD;
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+	}
+
+	// ---- the decision: first minimum in the reference's evaluation order (verbatim -> constant | fixed -> LPC) ----------------
+	{
+		const uint32_t wasted = pr.wasted;
+		SubDecision *dec = decisions + fc;
+		uint32_t best_type = 1, best_order = 0, dpo = 0, best_precision = 0;
+		int32_t best_shift = 0;
+		uint32_t best_bits = pr.verbatim_bits;
+		// (PREP_CONSTANT channels never get here: `any` is false for them)
+		if(best_ci != 0xffffffffu && best_est < best_bits) {
+			best_bits = best_est; dpo = best_po;
+			best_type = best_ci < P.nfixed ? 2 : 3;
+			best_order = rdlane(c_order, best_ci); best_precision = rdlane(c_prec, best_ci); best_shift = (int32_t)rdlane(c_shift, best_ci);
+		}
+		if(best_bits == 0xffffffffu) { best_type = 1; best_bits = hdr + n * sbps; }   // stream_encoder.c:4281
+		uint32_t rice2 = 0;
+		if(best_type >= 2) {
+			uint32_t big = 0;
+			if((uint32_t)lane < (1u << dpo)) {
+				const uint8_t kk = kbest[lane];
+				dec->params[lane] = kk;
+				if(kk >= 15) big = 1;
+			}
+			rice2 = __any((int)big) ? 1u : 0u;                         // stream_encoder.c:4786-4791
+		}
+		if(lane < MAX_ORDER) dec->q[lane] = best_type == 3 && lane < MAXORD ? cands[(size_t)fc * cstride + best_ci].q[lane] : 0;
+		if(lane == 0) {
+			dec->bits = best_bits;
+			dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
+			dec->po = (uint8_t)dpo; dec->rice2 = (uint8_t)rice2; dec->precision = (uint8_t)best_precision;
+			dec->shift = (int8_t)best_shift; dec->which = (uint8_t)pr.which;
+			dec->constant = 0; dec->constant_hi = 0; dec->fmt = pr.fmt;
+			preps[fc].handled = EVG_HANDLED;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------------------------
+bool evalg_applicable(const DevParams &P)
+{
+	static int off = -1;
+	if(off < 0) off = getenv("FLACGPU_NO_EVALG") ? 1 : 0;
+	const uint32_t S = P.blocksize / 64;
+	return !off && P.blocksize % 64 == 0 && S >= 16 && S % 16 == 0 && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC
+	       && P.max_po - (P.max_po > 6 ? P.max_po - 6 : 0) <= 6 && P.blocksize <= 16384;
+}
+hipError_t launch_evalg(const DevParams &P, uint32_t nmain, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
+{
+	if(nmain == 0) return hipSuccess;
+	const uint32_t nchan = nmain * P.ncand;
+	if(P.max_lpc_order <= 8) {
+		const uint32_t lds = evalg_lds_bytes<8>(P.blocksize);
+		static bool set = false;
+		if(!set) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) return e; set = true; }
+		hipLaunchKernelGGL(evalg_kernel<8>, dim3(nchan), dim3(64), lds, s, P, B.chan, nchan, jt, B.prep, B.cands, B.valid, dec);
+	}
+	else {
+		const uint32_t lds = evalg_lds_bytes<12>(P.blocksize);
+		static bool set = false;
+		if(!set) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) return e; set = true; }
+		hipLaunchKernelGGL(evalg_kernel<12>, dim3(nchan), dim3(64), lds, s, P, B.chan, nchan, jt, B.prep, B.cands, B.valid, dec);
+	}
+	return hipGetLastError();
+}
+
+} // namespace flacgpu

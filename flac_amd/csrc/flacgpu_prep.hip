@@ -225,7 +225,7 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 		if(lane == 0) {
 			ChanPrep pr;
 			pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
-			pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.pad[0] = pr.pad[1] = 0;
+			pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.handled = 0; pr.pad = 0;
 			preps[fc] = pr;
 		}
 		// ---- planar channel, shifted ---------------------------------------------------------------------------
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 			if(lane == 0) {
 				ChanPrep pr;
 				pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = N; pr.flags = flags; pr.fixed_order = fixed_order;
-				pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.pad[0] = pr.pad[1] = 0;
+				pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.handled = 0; pr.pad = 0;
 				preps[fc] = pr;
 			}
 		}

@@ -1,0 +1,52 @@
+#!/bin/bash
+# One GPU-box visit, parameterised (replaces the per-visit scripts of earlier rounds).  Everything lands under
+# gpurun_out/<tag>/ as text.  usage: scripts/gpu_visit.sh <tag> <step> [<step> ...]
+#   tests            the GPU parity suite (FLACGPU_POISON=1)
+#   tests:<expr>     pytest -k <expr>
+#   bench[:args]     bench.py [args] -> bench<i>.json          (":" separates, "," stands for a blank inside args)
+#   env:K=V          export K=V for the steps that follow (env:-K unsets)
+#   prof[:args]      rocprofv3 --kernel-trace --stats of bench.py --steps 5 --warmup 2 --no-cpu-baseline [args]
+#   pmc[:args]       the PMC passes (SQ instruction counters, FETCH_SIZE, WRITE_SIZE; 4096-frame launches)
+#   ab:<rounds>[:args]  alternate flac_amd/lib (A) and build/alt_lib (B) engines, scripts/gpu_ab.sh
+#   sh:<file>        run another script of scripts/
+set -u
+TAG=${1:-visit}; shift || true
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+i=0
+for step in "$@"; do
+  i=$((i+1))
+  kind=${step%%:*}; arg=""; [ "$kind" != "$step" ] && arg=${step#*:}; arg=${arg//,/ }
+  case $kind in
+    env) if [ "${arg:0:1}" = "-" ]; then unset ${arg:1}; else export "$arg"; fi; echo "[$i] env $arg" ;;
+    tests)
+      if [ -n "$arg" ]; then FLACGPU_POISON=1 timeout 1500 python -m pytest tests -x -q -m gpu -k "$arg" > $OUT/pytest_$i.log 2>&1
+      else FLACGPU_POISON=1 timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest_$i.log 2>&1; fi
+      echo "[$i] pytest rc=$?"; tail -4 $OUT/pytest_$i.log ;;
+    bench)
+      timeout 900 python bench.py $arg > $OUT/bench_$i.json 2> $OUT/bench_$i.err; echo "[$i] bench $arg rc=$?"; cat $OUT/bench_$i.json; tail -2 $OUT/bench_$i.err ;;
+    prof)
+      timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof$i -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline $arg > $OUT/prof_bench_$i.json 2> $OUT/prof_$i.err
+      echo "[$i] prof rc=$?"
+      DB=$(ls $OUT/prof$i/*.db 2>/dev/null | head -1)
+      [ -n "$DB" ] && python scripts/rocpd_summary.py $DB > $OUT/kernel_stats_$i.txt && cat $OUT/kernel_stats_$i.txt
+      rm -rf $OUT/prof$i ;;
+    pmc)
+      j=0
+      for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+                 "SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE GRBM_COUNT" \
+                 "FETCH_SIZE" "WRITE_SIZE"; do
+        j=$((j+1))
+        timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$j -o p$j -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --frames 4096 $arg > $OUT/pmc$j.json 2> $OUT/pmc$j.err
+        echo "[$i] pmc pass $j rc=$? : $SET"
+        DB=$(ls $OUT/pmc$j/*.db 2>/dev/null | head -1)
+        [ -n "$DB" ] && python scripts/rocpd_pmc.py $DB >> $OUT/pmc_counters_$i.txt
+        rm -rf $OUT/pmc$j
+      done
+      cat $OUT/pmc_counters_$i.txt ;;
+    ab) r=${arg%% *}; rest=""; [ "$r" != "$arg" ] && rest=${arg#* }; bash scripts/gpu_ab.sh $r $rest 2>&1 | tee $OUT/ab_$i.txt ;;
+    sh) bash scripts/$arg 2>&1 | tee $OUT/sh_$i.txt ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
