@@ -555,8 +555,9 @@ template <int MAXORD>
 __global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t nframes, uint32_t tail_n,
                                                     const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                     const ChanPrep *__restrict__ preps, const double *__restrict__ autoc_in,
-                                                    Candidate *__restrict__ cands, int *__restrict__ valid)
+                                                    Candidate *__restrict__ cands, int *__restrict__ valid, uint32_t *__restrict__ nleft)
 {
+	if(nleft && blockIdx.x == 0 && threadIdx.x == 0) *nleft = 0;        // the list evalg_kernel fills for eval_list_kernel starts empty
 	// the { invc, logc } table of the log (flacgpu_log.h) in LDS: a lane looks it up a dozen times, each at its own index
 	__shared__ uint64_t logtab[256];
 	logtab[threadIdx.x] = flacgpu_log_tab[threadIdx.x];
@@ -1021,14 +1022,15 @@ __host__ __device__ inline EvalLayout eval_layout(const DevParams &P, uint32_t w
 // (channel, candidate) are dealt to the wavefronts round-robin, rotating the channel from round to round so that the
 // expensive channel (side: 17-bit samples, no dot2) is spread evenly.  nwaves is a multiple of 4 wherever possible:
 // a 5-wavefront workgroup puts two wavefronts on one SIMD and the dispatcher then fits only 2 such workgroups per CU.
+// (the body of the kernel as a function of the (frame, channel group) it serves: eval_kernel runs it once per workgroup,
+//  eval_list_kernel in a loop over the channels evalg_kernel left behind)
 template <int MAXORD, int VARIANT>
-__global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_SIMD : 2) void eval_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n, uint32_t cpw,
-                                                                   const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
-                                                                   const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
-                                                                   const int *__restrict__ valid, SubDecision *__restrict__ decisions, unsigned long long *__restrict__ dbg,
-                                                                   uint32_t prefetch_ahead)
+__device__ __forceinline__ void eval_body(const DevParams &P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n, uint32_t cpw,
+                                          const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
+                                          const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
+                                          const int *__restrict__ valid, SubDecision *__restrict__ decisions, unsigned long long *__restrict__ dbg,
+                                          uint32_t prefetch_ahead, uint32_t f, uint32_t grp, unsigned char *smem)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = (int)threadIdx.x, lane = tid & 63;
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
 #define STAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
@@ -1037,8 +1039,6 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 	const uint32_t N = P.blocksize;
 	const uint32_t ngrp = P.ncand / cpw;
 	uint32_t pf_tmp = 0;                  // destination of the prefetch load (see below)
-	uint32_t f, grp;
-	map_block(blockIdx.x, nframes, ngrp, f, grp);
 	const size_t fc0 = (size_t)f * P.ncand + (size_t)grp * cpw;
 	const bool is_tail = tail_n != 0 && f == nframes - 1;
 	const JobTable *jt = is_tail ? jt_tail : jt_main;
@@ -1304,6 +1304,36 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_
 #undef STAMP
 	if(VARIANT == 0 && prefetch_ahead) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_tmp));      // (the prefetch's destination register stays reserved until its data is back)
 }
+template <int MAXORD, int VARIANT>
+__global__ __launch_bounds__(EVAL_MAX_WAVES * 64, VARIANT == 0 ? EVAL_WAVES_PER_SIMD : 2) void eval_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n, uint32_t cpw,
+                                                                   const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
+                                                                   const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
+                                                                   const int *__restrict__ valid, SubDecision *__restrict__ decisions, unsigned long long *__restrict__ dbg,
+                                                                   uint32_t prefetch_ahead)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint32_t f, grp;
+	map_block(blockIdx.x, nframes, P.ncand / cpw, f, grp);
+	eval_body<MAXORD, VARIANT>(P, chan, nframes, tail_n, cpw, jt_main, jt_tail, preps, cands, valid, decisions, dbg, prefetch_ahead, f, grp, smem);
+}
+// The channels evalg_kernel (flacgpu_evalg.hip) did not decide -- it lists them -- one at a time, a fixed grid looping over the
+// list: normally the list is empty or short, and a grid sized for the worst case would cost more to dispatch (88 us per 16384
+// frames) than the work it finds.
+template <int MAXORD>
+__global__ __launch_bounds__(EVAL_MAX_WAVES * 64, EVAL_WAVES_PER_SIMD) void eval_list_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
+                                                                   const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
+                                                                   const ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
+                                                                   const int *__restrict__ valid, SubDecision *__restrict__ decisions,
+                                                                   const uint32_t *__restrict__ left, const uint32_t *__restrict__ nleft)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const uint32_t count = *nleft;
+	for(uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+		const uint32_t fc = left[e];
+		eval_body<MAXORD, 0>(P, chan, nframes, tail_n, 1u, jt_main, jt_tail, preps, cands, valid, decisions, nullptr, 0u, fc / P.ncand, fc % P.ncand, smem);
+		__syncthreads();
+	}
+}
 
 } // namespace flacgpu
 
@@ -1367,8 +1397,9 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	}
 	if(P.max_analyses) {
 		const uint32_t lanes = nframes * P.ncand * P.max_analyses;
-		hipLaunchKernelGGL(model_kernel<MAXORD>, dim3((lanes + TPB - 1) / TPB), dim3(TPB), 0, s, P, nframes, tail_n, jtm, jtt, B.prep, B.autoc, B.cands, B.valid);
+		hipLaunchKernelGGL(model_kernel<MAXORD>, dim3((lanes + TPB - 1) / TPB), dim3(TPB), 0, s, P, nframes, tail_n, jtm, jtt, B.prep, B.autoc, B.cands, B.valid, B.nleft);
 	}
+	else (void)hipMemsetAsync(B.nleft, 0, sizeof(uint32_t), s);
 	sync_debug("model", s);
 	if(pev) (void)hipEventRecord(pev[2], s);
 	uint32_t cpw, waves;
@@ -1396,11 +1427,22 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		if(const char *e = getenv("FLACGPU_EVAL_PREFETCH")) ahead = atoi(e);
 		if(ahead < 0) ahead = 0;
 	}
-	if(op && evalg_applicable(P)) {
-		const hipError_t e = launch_evalg(P, tail_n ? nframes - 1 : nframes, jtm, B, dec, s);
+	if(op && evalg_applicable(P) && !B.dbg) {
+		// one wavefront per channel (flacgpu_evalg.hip); what it lists as not its own goes through the workgroup-per-channel body
+		// above, a fixed grid looping over the list
+		const hipError_t e = launch_evalg(P, nframes, tail_n, jtm, B, dec, s);
 		if(e != hipSuccess) return e;
+		static bool lset = false;
+		if(!lset) {
+			const hipError_t e2 = hipFuncSetAttribute((const void *)eval_list_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e2 != hipSuccess) return e2;
+			lset = true;
+		}
+		const uint32_t lw = P.ncslots >= 8 ? 8u : 4u;
+		const uint32_t grid = nframes * P.ncand < 1024u ? nframes * P.ncand : 1024u;
+		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(lw * 64), eval_layout(P, lw, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
 	}
-	if(op) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, (uint32_t)ahead);
+	else if(op) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, (uint32_t)ahead);
 	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u);
 	if(!op || tail_n || P.max_po > 6)
 		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(gwaves * 64), lds_generic, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u);

@@ -115,6 +115,7 @@ struct AnalyzeBuffers {
 	Candidate *cands;          // [frames*ncand][ncslots]: fixed orders, then analysis a / order / precision (DevParams::ncslots)
 	int *valid;                // same shape
 	int32_t *chan;             // [frames*ncand][blocksize] planar channel signals, wasted bits shifted out (ChanPrep::fmt)
+	uint32_t *left, *nleft;    // [frames*ncand] channels evalg_kernel left to eval_list_kernel, and their count (zeroed by the model kernel)
 	unsigned long long *dbg;   // FLACGPU_DEBUG_TIMING=1: [frames*ncand][16] s_memtime stamps of the eval kernel (else null)
 };
 constexpr int FLACGPU_MAX_SUBBATCHES = 8;   // streams a batch may be split over (FLACGPU_SUBBATCHES / flacgpu_set_subbatches)
@@ -136,7 +137,7 @@ bool autoc2_applicable(const DevParams &P);
 hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
                          const ChanPrep *preps, double *autoc, hipStream_t s);
 bool evalg_applicable(const DevParams &P);
-hipError_t launch_evalg(const DevParams &P, uint32_t nmain, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);
+hipError_t launch_evalg(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);
 bool prep2_applicable(const DevParams &P);
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s);
 // where the pack kernel may put the frames directly (fused compaction: single-pass prefix sum of the frame lengths inside the

@@ -36,7 +36,6 @@ namespace flacgpu {
 #define EVALG_WAVES_PER_SIMD 4
 #endif
 
-constexpr int EG_OH = 16;                 // history samples in front of a lane's run (the owner layout of eval_kernel)
 constexpr int EG_MAXC = 32;               // candidate slots of a channel this kernel takes (lane c holds candidate c's record)
 
 // ---- DPP helpers (the compiler sees these, so it places the wait states itself) --------------------------------------
@@ -123,10 +122,27 @@ __device__ __forceinline__ uint32_t fir16_dispatch(uint32_t npf, const uint32_t 
 	default: return fir16_folded<7, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
 	}
 }
-__device__ __forceinline__ void load_piece(const uint32_t *w /* word of sample (piece start - 14) */, uint32_t (&AA)[15], uint32_t (&BB)[14])
+// LDS image of a channel, TRANSPOSED: word j of lane L's run at (j * 65 + L + 1) -- the 64 lanes reading "their word j" read 64
+// consecutive words (no bank conflict, no padding per lane), and the word in front of a run is the last word of the run of
+// lane L - 1: column L.  Column 0 is lane 0's history: zero.  8.3 KB per 4096-sample channel (the per-lane regions with their
+// own history copies took 10.5 KB: one wavefront more per SIMD).
+constexpr uint32_t EG_ROW = 65 * 4;      // bytes per row
+// base: byte address of word (first sample of the piece - 14 samples) in the lane's column; rows at immediate offsets
+__device__ __forceinline__ void load_piece(const unsigned char *base, uint32_t (&AA)[15], uint32_t (&BB)[14])
 {
 #pragma unroll
-	for(int j = 0; j < 15; j++) AA[j] = w[j];
+	for(int j = 0; j < 15; j++) AA[j] = *(const uint32_t *)(base + j * EG_ROW);
+#pragma unroll
+	for(int m = 0; m < 14; m++) BB[m] = __builtin_amdgcn_alignbit(AA[m + 1], AA[m], 16);
+}
+// the piece that opens the block: the 7 words in front of the run come from the previous lane's column
+__device__ __forceinline__ void load_piece_first(const unsigned char *own /* word 0 of the run */, const unsigned char *hist /* word (run words - 7) of the previous column */,
+                                                 uint32_t (&AA)[15], uint32_t (&BB)[14])
+{
+#pragma unroll
+	for(int j = 0; j < 7; j++) AA[j] = *(const uint32_t *)(hist + j * EG_ROW);
+#pragma unroll
+	for(int j = 7; j < 15; j++) AA[j] = *(const uint32_t *)(own + (j - 7) * EG_ROW);
 #pragma unroll
 	for(int m = 0; m < 14; m++) BB[m] = __builtin_amdgcn_alignbit(AA[m + 1], AA[m], 16);
 }
@@ -159,28 +175,52 @@ __device__ __forceinline__ void rice_pass(const unsigned char *lds, const EgPass
 	bits = __umul24(kk, ns) + (ns9 >> 1) + (sum2 >> kk);
 }
 
-// LDS of one wavefront: [owner image][prefix sums 2 x 66][divisor table 7 x (MAXORD + 1)][best parameters 64 B]
+// LDS of one wavefront: [image (S/2 rows of 65 words)][prefix sums 2 x 66][divisor table 7 x (MAXORD + 1)][best parameters 64 B]
 template <int MAXORD>
 __host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N)
 {
-	const uint32_t S = N / 64, w = ((S + EG_OH) / 2) | 1u;
-	return ((64 * w * 4 + 64 + 15u) & ~15u) + 2 * 66 * 4 + 7 * (MAXORD + 1) * 4 + 64;
+	return (N / 128) * EG_ROW + 2 * 66 * 4 + 7 * (MAXORD + 1) * 4 + 64;
 }
+constexpr int EG_PIECES_AHEAD = 8;        // 16-byte pieces of the planar channel a lane has in flight before its first use (8 = a 4096-sample block)
 
 template <int MAXORD>
-__global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nchan /* channels of the frames of nominal length */,
+__global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
                                                                           const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
-                                                                          const int *__restrict__ valid, SubDecision *__restrict__ decisions)
+                                                                          const int *__restrict__ valid, SubDecision *__restrict__ decisions,
+                                                                          uint32_t *__restrict__ left, uint32_t *__restrict__ nleft)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = (int)threadIdx.x;
-	// blocks reach the XCDs round-robin: keep a frame's channels on one XCD, spread the expensive ones (map as eval_kernel does)
 	const uint32_t fc = blockIdx.x;
-	if(fc >= nchan) return;
 	const uint32_t n = P.blocksize, S = n / 64;
-	const ChanPrep pr = preps[fc];
 	const uint32_t aslots = P.norders * P.nprec, cstride = P.ncslots;
-	const uint32_t nan = P.nfixed + ((pr.flags & PREP_LPC) ? jt->nanalyses * aslots : 0);
+	// what this kernel does not take goes on eval_list_kernel's list
+#define EG_LEAVE() do { if(lane == 0) left[atomicAdd(nleft, 1u)] = fc; return; } while(0)
+	if(tail_n != 0 && fc / P.ncand == nframes - 1) EG_LEAVE();              // the short last block
+
+	// ---- every load from HBM goes out before the first use: one round trip, not three ------------------------------------
+	const ChanPrep pr = preps[fc];
+	const uint32_t nanalyses = jt->nanalyses;
+	int c_vflag = 0;
+	uint32_t c_order = 0, c_shift = 0, c_prec = 0, c_wide = 0;
+	int32_t cq[13];
+#pragma unroll
+	for(int j = 0; j < 13; j++) cq[j] = 0;
+	if((uint32_t)lane < cstride) {                                            // lane c holds candidate c (cstride <= EG_MAXC)
+		const size_t ix = (size_t)fc * cstride + (uint32_t)lane;
+		c_vflag = valid[ix];
+		const Candidate *cd = cands + ix;
+		c_order = cd->order; c_shift = (uint32_t)cd->shift; c_prec = cd->precision; c_wide = cd->wide;
+#pragma unroll
+		for(int j = 0; j < MAXORD; j++) cq[j] = cd->q[j];
+	}
+	const uint4 *src = (const uint4 *)(chan + (size_t)fc * P.chan_stride);
+	const uint32_t nvec = n / 8, vps = S / 8;                                 // 16-byte pieces of the block, of a lane's run
+	uint4 pv[EG_PIECES_AHEAD];
+#pragma unroll
+	for(int i = 0; i < EG_PIECES_AHEAD; i++) { const uint32_t m = (uint32_t)lane + 64u * (uint32_t)i; if(m < nvec) pv[i] = src[m]; }
+
+	const uint32_t nan = P.nfixed + ((pr.flags & PREP_LPC) ? nanalyses * aslots : 0);
 	const bool any = !(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || nan > P.nfixed);
 	// partition order limits of the frame (stream_encoder.c:3759-3761)
 	uint32_t frame_max_po = 0;
@@ -189,69 +229,62 @@ __global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const D
 	const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
 	const uint32_t psize = n >> frame_max_po;
 	const bool narrow = (pr.sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
-	if(!any || pr.fmt != 1 || !narrow || nan > (uint32_t)EG_MAXC || frame_max_po > 6) return;
+	const uint32_t sbps = pr.sbps, hdr = 8 + pr.wasted;
+	uint32_t best_est = 0xffffffffu, best_ci = 0xffffffffu, best_po = 0;
+	uint8_t *kbest = smem + evalg_lds_bytes<MAXORD>(n) - 64;
 
-	// ---- candidate records: lane c holds candidate c -------------------------------------------------------------------
+	if(any) {
+	if(pr.fmt != 1 || !narrow || frame_max_po > 6) EG_LEAVE();
+
+	// ---- candidate records: folded taps, and whether this kernel's arithmetic is exact for them --------------------------------
 	uint32_t Qv[7];
-	uint32_t c_order = 0, c_shift = 0, c_prec = 0;
-	bool c_valid = false, c_ok = true;
+	const bool c_valid = (uint32_t)lane < nan && c_vflag != 0;
+	bool c_ok = true;
 	{
+		int32_t t[14];
+		uint32_t abs_sum = 0;
 #pragma unroll
-		for(int p = 0; p < 7; p++) Qv[p] = 0;
-		if((uint32_t)lane < nan) {
-			const size_t ix = (size_t)fc * cstride + (uint32_t)lane;
-			c_valid = valid[ix] != 0;
-			if(c_valid) {
-				const Candidate *cd = cands + ix;
-				c_order = cd->order; c_shift = (uint32_t)cd->shift; c_prec = cd->precision;
-				int32_t t[14];
-				uint32_t abs_sum = 0;
-#pragma unroll
-				for(int j = 0; j < 13; j++) {
-					int32_t q = 0;
-					if(j < MAXORD) { q = cd->q[j]; if((uint32_t)j >= c_order) q = 0; }
-					t[j + 1] = q;
-					abs_sum += (uint32_t)(q < 0 ? -q : q);
-				}
-				c_ok = cd->wide == 0 && c_order <= (uint32_t)MAXORD && c_shift <= 15u
-				       && (((uint64_t)abs_sum + (1u << (c_shift & 15u))) << (pr.sbps - 1)) < (1ull << 31);
-				t[0] = -(int32_t)(1u << (c_shift & 15u));
-#pragma unroll
-				for(int p = 0; p < 7; p++) Qv[p] = ((uint32_t)t[2 * p] << 16) | ((uint32_t)t[2 * p + 1] & 0xffffu);
-			}
+		for(int j = 0; j < 13; j++) {
+			const int32_t q = (uint32_t)j < c_order ? cq[j] : 0;
+			t[j + 1] = q;
+			abs_sum += (uint32_t)(q < 0 ? -q : q);
 		}
+		t[0] = -(int32_t)(1u << (c_shift & 15u));
+#pragma unroll
+		for(int p = 0; p < 7; p++) Qv[p] = ((uint32_t)t[2 * p] << 16) | ((uint32_t)t[2 * p + 1] & 0xffffu);
+		if(c_valid) c_ok = c_wide == 0 && c_order <= (uint32_t)MAXORD && c_shift <= 15u
+		                   && (((uint64_t)abs_sum + (1u << (c_shift & 15u))) << (sbps - 1)) < (1ull << 31);
 	}
-	if(__any((int)!c_ok)) return;
+	if(__any((int)!c_ok)) EG_LEAVE();
 	uint64_t vmask = __ballot((int)c_valid);
-	if(vmask == 0) return;                                                   // (any said otherwise; eval_kernel decides such a channel)
 
 	// ---- LDS of this wavefront --------------------------------------------------------------------------------------------
-	const uint32_t stride = ((S + EG_OH) / 2) | 1u;
-	uint32_t *sigw = (uint32_t *)smem;
-	const uint32_t img_bytes = (64 * stride * 4 + 64 + 15u) & ~15u;
+	const uint32_t rows = S / 2;
+	const uint32_t img_bytes = rows * EG_ROW;
 	uint32_t *ps = (uint32_t *)(smem + img_bytes);                           // [2][66]
 	uint32_t *dt = ps + 2 * 66;                                              // [7][MAXORD + 1]: (0x40000 / ((S << m) - o)) << 13
-	uint8_t *kbest = (uint8_t *)(dt + 7 * (MAXORD + 1));
 	const uint32_t ps_off = img_bytes, dt_off = img_bytes + 2 * 66 * 4;
 
-	// the planar channel (16-bit pairs) into the lane-owner image: 8 samples = one 16-byte piece = 4 words of ONE lane's run
-	// (S is a multiple of 16), written again as the next lane's history when they are among the run's last 16
+	// the planar channel (16-bit pairs) into the image: a 16-byte piece is four consecutive words of ONE lane's run (S is a
+	// multiple of 16)
 	{
-		const uint4 *src = (const uint4 *)(chan + (size_t)fc * P.chan_stride);
-		if(lane < EG_OH / 2) sigw[lane] = 0;                                   // lane 0's history
-		const uint32_t nvec = n / 8, vps = S / 8;                              // pieces per lane run
 		const bool spow2 = (vps & (vps - 1)) == 0;
 		const uint32_t vlog = ilog2_u32(vps);
-#pragma unroll 4
-		for(uint32_t m = (uint32_t)lane; m < nvec; m += 64) {
-			const uint4 pv = src[m];
-			const uint32_t Lo = spow2 ? m >> vlog : m / vps, r = m - Lo * vps;          // run, piece of the run
-			uint32_t *d = sigw + Lo * stride + EG_OH / 2 + 4 * r;
-			d[0] = pv.x; d[1] = pv.y; d[2] = pv.z; d[3] = pv.w;
-			if(r + 2 >= vps && Lo + 1 < 64) {
-				uint32_t *h = sigw + (Lo + 1) * stride + 4 * (r + 2 - vps);
-				h[0] = pv.x; h[1] = pv.y; h[2] = pv.z; h[3] = pv.w;
+		if(lane < 8) *(uint32_t *)(smem + (rows - 8 + (uint32_t)lane) * EG_ROW) = 0;      // column 0: lane 0's history
+#pragma unroll
+		for(int i = 0; i < EG_PIECES_AHEAD; i++) {
+			const uint32_t m = (uint32_t)lane + 64u * (uint32_t)i;
+			if(m < nvec) {
+				const uint32_t Lo = spow2 ? m >> vlog : m / vps, r = m - Lo * vps;          // run, piece of the run
+				unsigned char *d = smem + (Lo + 1) * 4 + 4 * r * EG_ROW;
+				*(uint32_t *)(d) = pv[i].x; *(uint32_t *)(d + EG_ROW) = pv[i].y; *(uint32_t *)(d + 2 * EG_ROW) = pv[i].z; *(uint32_t *)(d + 3 * EG_ROW) = pv[i].w;
 			}
+		}
+		for(uint32_t m = (uint32_t)lane + 64u * EG_PIECES_AHEAD; m < nvec; m += 64) {          // blocks of more than 4096 samples
+			const uint4 v = src[m];
+			const uint32_t Lo = spow2 ? m >> vlog : m / vps, r = m - Lo * vps;
+			unsigned char *d = smem + (Lo + 1) * 4 + 4 * r * EG_ROW;
+			*(uint32_t *)(d) = v.x; *(uint32_t *)(d + EG_ROW) = v.y; *(uint32_t *)(d + 2 * EG_ROW) = v.z; *(uint32_t *)(d + 3 * EG_ROW) = v.w;
 		}
 	}
 	// the divisor table: entry (m, o) for partitions of 2^m lane runs, `o` samples short
@@ -282,14 +315,13 @@ __global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const D
 		if(!aD) mD = 7;
 	}
 	const uint32_t rl1 = P.rice_limit - 1;
-	const uint32_t sbps = pr.sbps, hdr = 8 + pr.wasted;
-	const uint32_t *reg = sigw + (uint32_t)lane * stride;                           // this lane's region: 8 history words, then its run
+	const unsigned char *own = smem + ((uint32_t)lane + 1) * 4;                      // word 0 of this lane's run
+	const unsigned char *hist = smem + (uint32_t)lane * 4 + (rows - 7) * EG_ROW;     // 7 words in front of it: the previous column's last
 	const uint32_t npieces = S / 16;
 	const uint32_t sum0 = 0x80000000u;
 	__builtin_amdgcn_wave_barrier();
 
-	// ---- the candidates, two at a time, in the reference's evaluation order ---------------------------------------------------
-	uint32_t best_est = 0xffffffffu, best_ci = 0xffffffffu, best_po = 0;
+	// ---- the candidates, two at a time ----------------------------------------------------------------------------------------
 	while(vmask) {
 		EgSlot A, B;
 		const uint32_t ci0 = (uint32_t)__builtin_ctzll(vmask);
@@ -309,19 +341,19 @@ __global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const D
 		uint32_t v0 = 0, v1 = 0;
 		{
 			uint32_t AA[15], BB[14];
-			load_piece(reg + 1, AA, BB);
+			load_piece_first(own, hist, AA, BB);
 			v0 = fir16_dispatch<true>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, lane == 0, sum0, v0);
 			if(two) v1 = fir16_dispatch<true>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, lane == 0, sum0, v1);
 		}
 #pragma unroll 1
 		for(uint32_t c = 1; c < npieces; c++) {
 			uint32_t AA[15], BB[14];
-			load_piece(reg + 1 + 8 * c, AA, BB);
+			load_piece(own + (8 * c - 7) * EG_ROW, AA, BB);
 			v0 = fir16_dispatch<false>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
 			if(two) v1 = fir16_dispatch<false>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
 		}
-		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_kernel's (nothing was written yet)
-		if(__any((int)((v0 | v1) >= (1u << 23)))) return;
+		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_list_kernel's (nothing was written yet)
+		if(__any((int)((v0 | v1) >= (1u << 23)))) EG_LEAVE();
 
 		// ---- Rice search of the pair ---------------------------------------------------------------------------------------
 		ps[1 + lane] = wave_scan_incl(v0 << 1);
@@ -382,15 +414,19 @@ __global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const D
 			}
 		}
 	}
+	}       // any
 
 	// ---- the decision: first minimum in the reference's evaluation order (verbatim -> constant | fixed -> LPC) ----------------
 	{
 		const uint32_t wasted = pr.wasted;
 		SubDecision *dec = decisions + fc;
 		uint32_t best_type = 1, best_order = 0, dpo = 0, best_precision = 0;
-		int32_t best_shift = 0;
+		int32_t best_shift = 0, best_constant = 0, best_constant_hi = 0;
 		uint32_t best_bits = pr.verbatim_bits;
-		// (PREP_CONSTANT channels never get here: `any` is false for them)
+		if(pr.flags & PREP_CONSTANT) {
+			const uint32_t bits = hdr + sbps;
+			if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_constant_hi = pr.constant_hi; best_bits = bits; }
+		}
 		if(best_ci != 0xffffffffu && best_est < best_bits) {
 			best_bits = best_est; dpo = best_po;
 			best_type = best_ci < P.nfixed ? 2 : 3;
@@ -407,16 +443,22 @@ __global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const D
 			}
 			rice2 = __any((int)big) ? 1u : 0u;                         // stream_encoder.c:4786-4791
 		}
-		if(lane < MAX_ORDER) dec->q[lane] = best_type == 3 && lane < MAXORD ? cands[(size_t)fc * cstride + best_ci].q[lane] : 0;
+		if(lane < MAX_ORDER) {
+			int32_t qv = 0;
+#pragma unroll
+			for(int j = 0; j < MAXORD; j++) { const int32_t t = (int32_t)rdlane((uint32_t)cq[j], best_ci & 63u); if(lane == j) qv = t; }
+			dec->q[lane] = best_type == 3 ? qv : 0;
+		}
 		if(lane == 0) {
 			dec->bits = best_bits;
 			dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
 			dec->po = (uint8_t)dpo; dec->rice2 = (uint8_t)rice2; dec->precision = (uint8_t)best_precision;
 			dec->shift = (int8_t)best_shift; dec->which = (uint8_t)pr.which;
-			dec->constant = 0; dec->constant_hi = 0; dec->fmt = pr.fmt;
+			dec->constant = best_constant; dec->constant_hi = best_constant_hi; dec->fmt = pr.fmt;
 			preps[fc].handled = EVG_HANDLED;
 		}
 	}
+#undef EG_LEAVE
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -427,24 +469,23 @@ bool evalg_applicable(const DevParams &P)
 	static int off = -1;
 	if(off < 0) off = getenv("FLACGPU_NO_EVALG") ? 1 : 0;
 	const uint32_t S = P.blocksize / 64;
-	return !off && P.blocksize % 64 == 0 && S >= 16 && S % 16 == 0 && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC
-	       && P.max_po - (P.max_po > 6 ? P.max_po - 6 : 0) <= 6 && P.blocksize <= 16384;
+	return !off && P.blocksize % 64 == 0 && S >= 16 && S % 16 == 0 && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC && P.blocksize <= 16384;
 }
-hipError_t launch_evalg(const DevParams &P, uint32_t nmain, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
+hipError_t launch_evalg(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
 {
-	if(nmain == 0) return hipSuccess;
-	const uint32_t nchan = nmain * P.ncand;
+	if(nframes == 0) return hipSuccess;
+	const uint32_t nchan = nframes * P.ncand;
 	if(P.max_lpc_order <= 8) {
 		const uint32_t lds = evalg_lds_bytes<8>(P.blocksize);
 		static bool set = false;
 		if(!set) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) return e; set = true; }
-		hipLaunchKernelGGL(evalg_kernel<8>, dim3(nchan), dim3(64), lds, s, P, B.chan, nchan, jt, B.prep, B.cands, B.valid, dec);
+		hipLaunchKernelGGL(evalg_kernel<8>, dim3(nchan), dim3(64), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
 	}
 	else {
 		const uint32_t lds = evalg_lds_bytes<12>(P.blocksize);
 		static bool set = false;
 		if(!set) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) return e; set = true; }
-		hipLaunchKernelGGL(evalg_kernel<12>, dim3(nchan), dim3(64), lds, s, P, B.chan, nchan, jt, B.prep, B.cands, B.valid, dec);
+		hipLaunchKernelGGL(evalg_kernel<12>, dim3(nchan), dim3(64), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
 	}
 	return hipGetLastError();
 }
