@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--level", type=int, default=8, help="compression preset -0..-8 (the metric is quoted at -8: other levels are side measurements; "
                     "-0..-2 use the preset's 1152-sample blocks)")
     ap.add_argument("--window", type=int, default=4, help="multi-rank: steps per gather window")
+    ap.add_argument("--gather", choices=("rccl", "hostshm"), default="rccl", help="multi-rank: how a step's frames reach their destination -- rccl: point-to-point over xGMI "
+                    "into rank 0's HBM (the north star's gather); hostshm: every rank copies over its own PCIe link into one shared pinned host buffer")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank pipeline (process group, windowed ordered gather) even with one rank")
     args = ap.parse_args()
     global RATE, BPS
@@ -217,7 +219,7 @@ def main():
     import torch
     import torch.distributed as dist
     import flac_amd
-    from flac_amd.dist import GatherPipeline
+    from flac_amd.dist import GatherPipeline, HostShmPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -266,7 +268,19 @@ def main():
                     eng.encode_device(d_pcm.data_ptr(), nframes, d_out.data_ptr(), cap, d_fb.data_ptr(), d_total.data_ptr(),
                                       first_frame_number=first_frame, stream=enc_stream.cuda_stream)
         else:
-            gp = GatherPipeline(cap, nframes, dev, window=args.window)
+            if args.gather == "hostshm":
+                # room per rank and step in the shared host buffer: what one step of this signal really takes, plus a quarter
+                # (the worst case, every frame VERBATIM, would pin 2 windows x world x 288 MB per step)
+                d_probe = torch.empty(cap, dtype=torch.uint8, device=dev)
+                d_pfb = torch.empty(nframes, dtype=torch.int32, device=dev)
+                d_ptot = torch.zeros(1, dtype=torch.int64, device=dev)
+                eng.encode_device(d_pcm.data_ptr(), nframes, d_probe.data_ptr(), cap, d_pfb.data_ptr(), d_ptot.data_ptr(), first_frame_number=first_frame, stream=0)
+                torch.cuda.synchronize()
+                hcap = (int(d_ptot.item()) * 5 // 4 + 4095) & ~4095
+                del d_probe, d_pfb, d_ptot
+                gp = HostShmPipeline(cap, nframes, dev, window=args.window, host_cap_bytes=hcap)
+            else:
+                gp = GatherPipeline(cap, nframes, dev, window=args.window)
             state = {"k": 0}
 
             def run(nsteps):
@@ -284,6 +298,7 @@ def main():
         if warmup:
             run(warmup)
         sync()
+        nwin_warm = len(gp.win_log) if gp is not None else 0
         t0 = time.perf_counter()
         run(steps)
         sync()
@@ -336,9 +351,14 @@ def main():
                 stream, sizes, fbs = gp.gathered(k_last)
                 total_bytes = sizes[0]
                 out_h = stream[:total_bytes].cpu().numpy()            # rank 0's own frames: the head of the gathered stream
-                fb_h = fbs[0].cpu().numpy()
+                fb_h = (fbs[0] if fbs.dim() == 2 else fbs).cpu().numpy()
                 res["gathered_bytes_last_step"] = int(sum(sizes))
                 res["host_syncs"] = gp.host_syncs
+                # the windows of the timed steps, as rank 0 saw them: bytes it received (rccl) or copied out (hostshm) and the time
+                # their transfers took on its communication stream -- next to ms_per_step this says whether the gather or the
+                # encode set the pace
+                res["gather_windows"] = gp.window_stats()[nwin_warm:]
+                res["gather_backend"] = gp.backend
             kms = {k: float(np.mean([ph[k] for ph in phase_ms])) for k in phase_ms[0]}
             samples_per_step = nframes * block
             out_bps = total_bytes / samples_per_step
@@ -363,6 +383,8 @@ def main():
                                  "valu_busy_frac_of_committed_pmc_pass": valu_busy})
             if not args.no_verify:
                 res["verified"] = verify_step(pcm_h, out_h, fb_h, first_frame, level, block, search=search)
+        if gp is not None and hasattr(gp, "close"):
+            gp.close()
         eng.close()
         del d_pcm
         torch.cuda.empty_cache()
@@ -398,7 +420,9 @@ def main():
                        "frames_per_gpu_per_step": nframes, "blocksize": m["block"], "channels": CH, "bits_per_sample": BPS,
                        "samples_are": "inter-channel (x2 for channel-samples)",
                        "parallelism": ("frame-shard x%d + ordered RCCL gather of every step's frames to rank 0 (sizes exchanged once per window of %d steps, "
-                                       "transfers overlapped with the next window's encodes, rank 0 encodes in place)" % (world, args.window)) if multi else "one GPU, no process group",
+                                       "transfers overlapped with the next window's encodes, rank 0 encodes in place)" % (world, args.window) if args.gather == "rccl" else
+                                       "frame-shard x%d + every rank copies each step's frames over its own PCIe link into one shared pinned host buffer at the scanned offset "
+                                       "(sizes exchanged once per window of %d steps)" % (world, args.window)) if multi else "one GPU, no process group",
                        "compressed_bytes_per_sample": round(m["out_bps"], 4)},
             "kernel_ms": {k: round(v, 4) for k, v in m["kernel_ms"].items()},
             "roofline": dict(m["roofline"], note="-8 is VALU bound (~1e3 integer+fp64 ops per sample; the dominant kernels issue VALU work ~80% of their cycles, "
@@ -411,7 +435,15 @@ def main():
         if "device_verify" in m:
             line["device_verify"] = m["device_verify"]
         if multi:
-            line["gather"] = {"bytes_gathered_last_step": m.get("gathered_bytes_last_step"), "host_reads_of_sizes": m.get("host_syncs"), "window": args.window}
+            wins = m.get("gather_windows") or []
+            wms = [w["ms"] for w in wins if w["ms"] is not None]
+            line["gather"] = {"mode": args.gather, "backend": m.get("gather_backend"), "world_size_seen": dist.get_world_size(), "window": args.window,
+                              "bytes_gathered_last_step": m.get("gathered_bytes_last_step"), "host_reads_of_sizes": m.get("host_syncs"),
+                              "windows": wins,
+                              "rank0_transfer_ms_per_step": round(sum(wms) / max(1, sum(w["steps"] for w in wins)), 4) if wms else None,
+                              "rank0_transfer_GBps": round(sum(w["bytes"] for w in wins) / (sum(wms) * 1e-3) / 1e9, 2) if wms and sum(wms) > 0 else None,
+                              "note": "ms = time a window's transfers occupied rank 0's communication stream (they run beside the next window's encodes); "
+                                      "if rank0_transfer_ms_per_step approaches ms_per_step the gather sets the pace"}
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(LEVEL, search)

@@ -21,6 +21,7 @@ Three forms of it:
 """
 import mmap
 import os
+import secrets
 
 import torch
 import torch.distributed as dist
@@ -121,6 +122,7 @@ class GatherPipeline:
         self.dev = torch.device(device)
         self.cuda = self.dev.type == "cuda"
         self.is_dst = self.rank == dst
+        self.backend = dist.get_backend(group)
         K, W = self.K, self.world
         nslots = 2 * K                                     # two windows in flight: one being encoded, one being gathered
         # dst: a step's gathered stream, its own payload first (encoded in place); others: just their payload
@@ -138,6 +140,15 @@ class GatherPipeline:
         self.enqueued = 0
         self.gathers = 0
         self.host_syncs = 0
+        self.win_log = []                                  # per gathered window: [first step, steps, bytes moved by this rank, event0, event1]
+
+    def window_stats(self):
+        """Per gathered window, after the communication stream was synchronised: first step, steps, the bytes this rank
+        received (dst) or sent (others), and the milliseconds its transfers took on the communication stream (None on CPU)."""
+        out = []
+        for k0, n, nbytes, e0, e1 in self.win_log:
+            out.append({"first_step": k0, "steps": n, "bytes": nbytes, "ms": round(e0.elapsed_time(e1), 4) if e0 is not None else None})
+        return out
 
     def _slot(self, k):
         return k % (2 * self.K)
@@ -183,9 +194,11 @@ class GatherPipeline:
             table = _exchange(self.totals[s0:s0 + n], self.group)          # [world, n]
             self.host_syncs += 1
             ops = []
+            moved = 0
             for j in range(n):
                 s = s0 + j
                 sz = [int(v) for v in table[:, j]]
+                moved += sum(sz[1:]) if self.is_dst else sz[self.rank]
                 if self.is_dst:
                     self.sizes[s] = sz
                     base, off = s * self.span, sz[0]                         # rank 0's own payload is already there
@@ -199,11 +212,17 @@ class GatherPipeline:
                     if sz[self.rank]:
                         ops.append(dist.P2POp(dist.isend, self.buf[s * self.span: s * self.span + sz[self.rank]], self.dst, self.group))
                     ops.append(dist.P2POp(dist.isend, self.fb[s * self.nframes:(s + 1) * self.nframes], self.dst, self.group))
+            e0 = e1 = None
+            if self.cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.comm_stream)
             if ops:
                 for wk in dist.batch_isend_irecv(ops):
                     wk.wait()                     # stream-ordered on CUDA (the host does not block); blocking on gloo
             if self.cuda:
+                e1.record(self.comm_stream)
                 self.win_free[w].record(self.comm_stream)
+            self.win_log.append([k0, n, moved, e0, e1])
         self.gathers += 1
 
     def gathered(self, k):
@@ -216,27 +235,43 @@ class GatherPipeline:
         return self.buf[s * self.span: s * self.span + sum(sz)], sz, fbs
 
 
+def _shm_create(capacity, group, prefix="flacgpu_gather"):
+    """Rank 0 creates the shared file under /dev/shm -- unpredictable name, O_EXCL | O_NOFOLLOW, mode 0600, so that no other
+    local user can plant a link there or read the stream -- and tells the others its name; every rank maps it."""
+    rank = dist.get_rank(group)
+    names = [None]
+    if rank == 0:
+        path = "/dev/shm/%s_%d_%s" % (prefix, os.getpid(), secrets.token_hex(8))
+        fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+        os.ftruncate(fd, capacity)
+        names[0] = path
+    dist.broadcast_object_list(names, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    path = names[0]
+    if rank != 0:
+        fd = os.open(path, os.O_RDWR | os.O_NOFOLLOW)
+    mm = mmap.mmap(fd, capacity)
+    return path, fd, mm
+
+
+def _host_register(host):
+    try:
+        return int(torch.cuda.cudart().cudaHostRegister(host.data_ptr(), host.numel(), 0)) == 0
+    except Exception:
+        return False
+
+
 class HostShmGather:
     """Ordered gather through ONE pinned host buffer shared by the ranks of a node (POSIX shared memory, registered
     with the HIP runtime by every rank): rank r copies its payload device -> host at the exclusive scan of the byte
-    totals.  The transfers run on every GPU's own PCIe link at once.  Only for CUDA tensors."""
+    totals.  The transfers run on every GPU's own PCIe link at once.  CPU tensors (the gloo tests) copy plainly."""
 
-    def __init__(self, capacity_bytes, group=None, name=None):
+    def __init__(self, capacity_bytes, group=None):
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.capacity = int(capacity_bytes)
-        self.path = "/dev/shm/%s" % (name or "flacgpu_gather_%s" % os.environ.get("MASTER_PORT", "0"))
-        if self.rank == 0:
-            with open(self.path, "wb") as f:
-                f.truncate(self.capacity)
-        dist.barrier(group)
-        self.fd = os.open(self.path, os.O_RDWR)
-        self.mm = mmap.mmap(self.fd, self.capacity)
+        self.path, self.fd, self.mm = _shm_create(self.capacity, group)
         self.host = torch.frombuffer(self.mm, dtype=torch.uint8)
-        self.registered = False
-        rt = torch.cuda.cudart()
-        if int(rt.cudaHostRegister(self.host.data_ptr(), self.capacity, 0)) == 0:
-            self.registered = True
+        self.registered = torch.cuda.is_available() and _host_register(self.host)
         dist.barrier(group)
 
     def gather(self, payload, nbytes, stream=None):
@@ -249,11 +284,91 @@ class HostShmGather:
         off = sum(sizes[:self.rank])
         if off + sizes[self.rank] > self.capacity:
             raise RuntimeError("HostShmGather: %d bytes do not fit the shared buffer" % sum(sizes))
-        with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream(dev)):
-            self.host[off:off + sizes[self.rank]].copy_(payload[:sizes[self.rank]], non_blocking=self.registered)
-        torch.cuda.current_stream(dev).synchronize() if stream is None else stream.synchronize()
+        if dev.type == "cuda":
+            with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream(dev)):
+                self.host[off:off + sizes[self.rank]].copy_(payload[:sizes[self.rank]], non_blocking=self.registered)
+            torch.cuda.current_stream(dev).synchronize() if stream is None else stream.synchronize()
+        else:
+            self.host[off:off + sizes[self.rank]].copy_(payload[:sizes[self.rank]])
         dist.barrier(self.group)
         return off, sizes
+
+    def close(self):
+        if self.registered:
+            torch.cuda.cudart().cudaHostUnregister(self.host.data_ptr())
+            self.registered = False
+        self.host = None
+        try:
+            self.mm.close()
+        except BufferError:
+            pass
+        os.close(self.fd)
+        dist.barrier(self.group)
+        if self.rank == 0 and os.path.exists(self.path):
+            os.unlink(self.path)
+
+
+class HostShmPipeline(GatherPipeline):
+    """GatherPipeline whose destination is the shared pinned host buffer of HostShmGather instead of rank 0's HBM: same
+    calls, same windows, same single host read of the sizes per window -- but a window's transfers are device -> host copies,
+    every rank over its own PCIe link, to (slot base + exclusive scan of the step's byte totals).  For a corpus whose stream
+    must end in host memory anyway, and the diagnostic twin of the RCCL funnel (bench.py --gather hostshm).
+    host_cap_bytes: room per rank and step in the host buffer (the slot of a step is world * host_cap_bytes)."""
+
+    def __init__(self, cap_bytes, nframes, device, window=4, group=None, host_cap_bytes=None):
+        self.hcap = int(host_cap_bytes or cap_bytes)
+        super().__init__(cap_bytes, nframes, device, window=window, group=group, dst=0)
+        nslots = 2 * self.K
+        # (every rank keeps only its own payload on the device: the base class sized rank 0's slots for the whole stream)
+        if self.is_dst and self.world > 1:
+            self.span = self.cap
+            self.buf = torch.empty(nslots * self.span, dtype=torch.uint8, device=self.dev)
+        self.hspan = self.world * self.hcap
+        self.path, self.fd, self.mm = _shm_create(nslots * self.hspan, group, "flacgpu_pipe")
+        self.host = torch.frombuffer(self.mm, dtype=torch.uint8)
+        self.registered = self.cuda and _host_register(self.host)
+        self.hfb = None
+        self.all_sizes = [None] * nslots                    # every rank knows every rank's byte counts of the step in a slot
+        self.backend = "hostshm+" + self.backend
+        dist.barrier(group)
+
+    def _gather_window(self, k0, n):
+        import contextlib
+        w = (k0 // self.K) % 2
+        s0 = self._slot(k0)
+        with (torch.cuda.stream(self.comm_stream) if self.cuda else contextlib.nullcontext()):
+            if self.cuda:
+                self.comm_stream.wait_event(self.win_done[w])
+            table = _exchange(self.totals[s0:s0 + n], self.group)          # [world, n]: the ONE host read of this window
+            self.host_syncs += 1
+            e0 = e1 = None
+            if self.cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.comm_stream)
+            moved = 0
+            for j in range(n):
+                s = s0 + j
+                sz = [int(v) for v in table[:, j]]
+                self.all_sizes[s] = sz
+                if sum(sz) > self.hspan:
+                    raise RuntimeError("HostShmPipeline: a step's %d bytes do not fit its slot of %d" % (sum(sz), self.hspan))
+                off = s * self.hspan + sum(sz[:self.rank])
+                mine = sz[self.rank]
+                if mine:
+                    self.host[off:off + mine].copy_(self.buf[s * self.span: s * self.span + mine], non_blocking=self.registered)
+                moved += mine
+            if self.cuda:
+                e1.record(self.comm_stream)
+                self.win_free[w].record(self.comm_stream)
+            self.win_log.append([k0, n, moved, e0, e1])
+        self.gathers += 1
+
+    def gathered(self, k):
+        """Any rank, once every rank has synchronised its communication stream and a barrier was passed: (step k's stream in
+        rank order -- a view of the shared host buffer --, [per-rank byte counts], this rank's frame lengths)."""
+        s = self._slot(k)
+        sz = self.all_sizes[s]
+        return self.host[s * self.hspan: s * self.hspan + sum(sz)], sz, self.fb[s * self.nframes:(s + 1) * self.nframes]
 
     def close(self):
         if self.registered:

@@ -1,4 +1,4 @@
-"""world_size-2 gloo runs of the multi-GPU path's only exchange step: the ordered variable-length gather of encoded
+"""gloo runs (world sizes 2, 4 and 8) of the multi-GPU path's only exchange step: the ordered variable-length gather of encoded
 shards to rank 0 (flac_amd/dist.py) -- the one-shot form, the form that receives into a preallocated buffer the
 destination encoded into, and the windowed steady-state pipeline -- plus the frame-range sharding rule."""
 import os
@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from flac_amd.dist import GatherPipeline, ordered_gather, shard_range
+from flac_amd.dist import GatherPipeline, HostShmGather, HostShmPipeline, ordered_gather, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -26,7 +26,7 @@ def test_shard_range_partitions_exactly():
 
 def _shard(rank):
     rng = np.random.default_rng(100 + rank)
-    nfr = 5 + 3 * rank
+    nfr = 0 if rank == 2 else 5 + 3 * rank                                # ragged; rank 2 (world >= 4) has no frame at all
     fb = rng.integers(14, 9000, nfr).astype(np.int32)
     nbytes = int(fb.sum())
     return fb, nbytes, rng.integers(0, 256, nbytes, dtype=np.uint8)
@@ -36,6 +36,8 @@ def _step_shard(rank, k, nframes, cap):
     """what rank `rank` 'encodes' in step k of the pipeline test"""
     rng = np.random.default_rng(1000 * k + rank)
     fb = rng.integers(14, cap // nframes, nframes).astype(np.int32)
+    if rank == 3 and k % 2 == 1:
+        fb[:] = 0                                                           # a rank that produced nothing in this step
     nbytes = int(fb.sum())
     return fb, nbytes, rng.integers(0, 256, nbytes, dtype=np.uint8)
 
@@ -53,8 +55,8 @@ def _worker(rank, world, port, q, mode):
                 stream, allfb = ordered_gather(torch.from_numpy(payload), nbytes, torch.from_numpy(fb), dst=0)
             else:
                 # the destination "encoded" straight into the head of the receive buffer; the byte count is a tensor
-                out = torch.zeros(200000, dtype=torch.uint8)
-                outfb = torch.zeros(64, dtype=torch.int64)
+                out = torch.zeros(2000000, dtype=torch.uint8)
+                outfb = torch.zeros(256, dtype=torch.int64)
                 payload = out[:nbytes + 5] if rank == 0 else torch.zeros(nbytes + 5, dtype=torch.uint8)
                 payload[:nbytes] = torch.from_numpy(data)
                 stream, allfb = ordered_gather(payload, torch.tensor([nbytes]), torch.from_numpy(fb), dst=0, out=out if rank == 0 else None,
@@ -65,6 +67,37 @@ def _worker(rank, world, port, q, mode):
                 q.put((stream.numpy().tobytes(), allfb.numpy().tolist()))
             else:
                 assert stream is None and allfb is None
+        elif mode == "hostshm":
+            fb, nbytes, data = _shard(rank)
+            hs = HostShmGather(1 << 20)
+            off, sizes = hs.gather(torch.from_numpy(np.concatenate([data, np.zeros(9, np.uint8)])), nbytes)
+            if rank == 0:
+                q.put((hs.host[:sum(sizes)].numpy().tobytes(), sizes, oct(os.stat(hs.path).st_mode & 0o777)))
+            hs.close()
+        elif mode[0] == "hostpipe":
+            _, window, steps = mode
+            nframes, cap = 6, 60000
+            gp = HostShmPipeline(cap, nframes, "cpu", window=window)
+            for k in range(steps):
+                gp.wait_slot_free(k)
+                out, fbt, total = gp.slot(k)
+                fb, nbytes, data = _step_shard(rank, k, nframes, cap)
+                out[:nbytes] = torch.from_numpy(data)
+                fbt.copy_(torch.from_numpy(fb))
+                total[0] = nbytes
+                gp.step_done(k)
+            gp.flush()
+            dist.barrier()
+            # the last two windows are still in their slots: every rank sees the same bytes
+            got = {}
+            for kk in range(max(0, ((steps - 1) // window - 1) * window), steps):
+                sv, sz, _ = gp.gathered(kk)
+                got[kk] = (sv.numpy().tobytes(), sz)
+            if rank == world - 1:
+                q.put(got)
+            assert gp.host_syncs == (steps + window - 1) // window
+            assert len(gp.window_stats()) == gp.gathers
+            gp.close()
         else:
             window, steps = mode
             nframes, cap = 6, 60000
@@ -110,9 +143,9 @@ def _run(mode, world=2):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    res = q.get(timeout=180)
+    res = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=180)
+        p.join(timeout=300)
         assert p.exitcode == 0
     return res
 
@@ -143,4 +176,58 @@ def test_gather_pipeline_gloo_ws2(window, steps):
             want += data.tobytes()
             assert sizes[rank] == nbytes
             assert fbs[rank] == fb.tolist()
+        assert stream == want
+
+
+# ---- more than one predecessor per rank: the cumulative offsets of ranks >= 2 ----------------------------------------------------
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("mode", ["oneshot", "prealloc"])
+def test_ordered_gather_gloo_ragged(world, mode):
+    got_stream, got_fb = _run(mode, world)
+    want_stream, want_fb = b"", []
+    for rank in range(world):
+        fb, nbytes, data = _shard(rank)
+        want_stream += data.tobytes()
+        want_fb += fb.tolist()
+    assert got_fb == want_fb
+    assert got_stream == want_stream
+
+
+def _check_pipeline(got, world, steps):
+    assert sorted(got) == list(range(steps))
+    for k in range(steps):
+        stream, sizes, fbs = got[k]
+        want = b""
+        for rank in range(world):
+            fb, nbytes, data = _step_shard(rank, k, 6, 60000)
+            want += data.tobytes()
+            assert sizes[rank] == nbytes
+            assert fbs[rank] == fb.tolist()
+        assert stream == want
+
+
+@pytest.mark.parametrize("world,window,steps", [(4, 3, 7), (4, 4, 9), (8, 2, 5), (8, 4, 6)])
+def test_gather_pipeline_gloo_many_ranks(world, window, steps):
+    """window counts that do not divide the step count, a rank (3) that has nothing to send every other step"""
+    _check_pipeline(_run((window, steps), world), world, steps)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_host_shm_gather_gloo(world):
+    stream, sizes, mode = _run("hostshm", world)
+    want = b"".join(_shard(r)[2].tobytes() for r in range(world))
+    assert stream == want and sizes == [_shard(r)[1] for r in range(world)]
+    assert mode == "0o600"                                   # nobody else may read the stream
+
+
+@pytest.mark.parametrize("world,window,steps", [(2, 2, 5), (4, 3, 7), (8, 2, 4)])
+def test_host_shm_pipeline_gloo(world, window, steps):
+    got = _run(("hostpipe", window, steps), world)
+    assert max(got) == steps - 1
+    for k, (stream, sizes) in got.items():
+        want = b""
+        for rank in range(world):
+            fb, nbytes, data = _step_shard(rank, k, 6, 60000)
+            want += data.tobytes()
+            assert sizes[rank] == nbytes
         assert stream == want
