@@ -35,10 +35,8 @@ VENDOR = b"reference libFLAC 1.5.0 20250211"        # format.c:57 (the host API 
 
 
 def base_clip(seed=1234):
-    """the 48 s clip the corpus is made of: int16 [BASE_FRAMES*BLOCK, 2] (tests/signals.py: tones + coloured noise)"""
-    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(here, "tests"))
-    import signals
+    """the 48 s clip the corpus is made of: int16 [BASE_FRAMES*BLOCK, 2] (flac_amd/signals.py: tones + coloured noise)"""
+    from . import signals
     return np.ascontiguousarray(signals.music(BASE_FRAMES * BLOCK, CH, BPS, seed=seed, rate=RATE).astype(np.int16))
 
 

@@ -683,6 +683,13 @@ static int ensure_verify(flacgpu_ctx *c)
 			ok = ok && hipMalloc(&c->d_vhints, B * c->P.channels * HINT_RUNS * sizeof(uint32_t)) == hipSuccess;
 	}
 	c->hint_count = 0;
+	if(!ok) {
+		// all or nothing: d_vstate is the "allocated" mark, and a later call must not find it set next to buffers that are not there
+		void **bufs[] = {(void **)&c->d_vstate, (void **)&c->d_vresult, (void **)&c->d_voffsets, (void **)&c->d_vtotal, (void **)&c->d_vscratch, (void **)&c->d_vdecoded,
+		                 (void **)&c->d_vfinfo, (void **)&c->d_vfstat, (void **)&c->d_vhints};
+		for(void **b : bufs) { if(*b) (void)hipFree(*b); *b = nullptr; }
+		(void)hipGetLastError();
+	}
 	return ok ? FLACGPU_OK : FLACGPU_ERR_ALLOC;
 }
 

@@ -155,6 +155,26 @@ FLACGPU_HD inline uint32_t br_rice(BitReader &b, uint32_t k)
 }
 
 FLACGPU_HD inline uint32_t dec_ilog2(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+// FLAC__bitmath_silog2 (bitmath.c): bits of a two's complement number
+FLACGPU_HD inline uint32_t dec_silog2(int64_t v)
+{
+	if(v == 0) return 0;
+	if(v == -1) return 2;
+	if(v < 0) v = -(v + 1);
+	return 63u - (uint32_t)__builtin_clzll((unsigned long long)v) + 2;
+}
+// The reference decoder's choice between 32-bit wrap-around restoration and the 64-bit sum (stream_decoder.c:3240-3246, 1.5.0):
+// FLAC__lpc_restore_signal when FLAC__lpc_max_residual_bps and FLAC__lpc_max_prediction_before_shift_bps (lpc.c:942-968, both
+// built on the sum of the taps' magnitudes) are at most 32, FLAC__lpc_restore_signal_wide otherwise.  For the in-range audio
+// an encoder produces the two restorations agree wherever either rule picks the narrow one; the rule is restated exactly so
+// that a frame from anywhere (flacgpu_verify_batch_device takes any bytes) decodes as the reference decodes it.
+FLACGPU_HD inline bool dec_lpc_needs_wide_sum(uint32_t sb, uint64_t abs_sum_of_taps, int32_t shift)
+{
+	const uint64_t maxabs = (uint64_t)1 << (sb - 1);
+	const uint64_t before = maxabs * abs_sum_of_taps;                                   // lpc.c:942-950
+	const uint64_t after = (uint64_t)(-1 * ((-1 * (int64_t)before) >> shift));         // lpc.c:965
+	return !(dec_silog2((int64_t)(maxabs + after)) <= 32 && dec_silog2((int64_t)before) <= 32);
+}
 
 // CRC-8 of the frame header (poly 0x07), bit by bit: at most 16 bytes per frame
 FLACGPU_HD inline uint32_t dec_crc8(const uint8_t *p, uint32_t n)
@@ -270,8 +290,10 @@ FLACGPU_HD inline int decode_subframe(BitReader &b, uint32_t n, uint32_t sbps_no
 		if(shift < 0) return DEC_ERROR;
 #pragma unroll
 		for(int j = 0; j < MAXORD; j++) if((uint32_t)j < order) q[j] = br_get_signed(b, prec);
-		// the reference decoder's choice of arithmetic (stream_decoder.c:3224-3232): 32-bit wrap-around when the bound fits
-		wide_sum = sb + prec + dec_ilog2(order) > 32;
+		uint64_t abs_sum = 0;
+#pragma unroll
+		for(int j = 0; j < MAXORD; j++) if((uint32_t)j < order) abs_sum += (uint32_t)(q[j] < 0 ? -q[j] : q[j]);
+		wide_sum = dec_lpc_needs_wide_sum(sb, abs_sum, shift);
 	}
 	else {
 		if(order == 1) { q[0] = 1; }

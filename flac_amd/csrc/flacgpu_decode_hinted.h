@@ -203,7 +203,10 @@ FLACGPU_HD inline HintedSub hinted_subframe_head(const PeekSrc &S, uint32_t pos,
 		if(H.shift < 0) return H;
 		H.pos_q = p + 9;
 		p += 9 + H.order * H.prec;
-		H.wide_sum = H.sb + H.prec + dec_ilog2(H.order) > 32;       // stream_decoder.c:3224-3232
+		if(p > S.limit) return H;
+		uint64_t abs_sum = 0;
+		for(uint32_t j = 0; j < H.order; j++) { const int32_t t = peek_signed(S, H.pos_q + j * H.prec, H.prec); abs_sum += (uint32_t)(t < 0 ? -t : t); }
+		H.wide_sum = dec_lpc_needs_wide_sum(H.sb, abs_sum, H.shift);      // stream_decoder.c:3240-3246
 	}
 	else H.wide_sum = H.sb + H.order > 32;                          // fixed.c:571-667
 	if(p + 6 > S.limit) return H;

@@ -13,6 +13,12 @@
  * is the same on any IEEE machine -- the device included: no dependence on the ROCm device library's log.
  * Constants: flacgpu_log_data.h (scripts/extract_glibc_log_data.py).
  *
+ * Provenance and licence: the algorithm and its constants are the GNU C Library's (glibc 2.35, sysdeps/ieee754/dbl-64/
+ * e_log.c and e_log_data.c, Copyright (C) 2018-2022 Free Software Foundation, Inc., contributed by Arm Ltd.), distributed
+ * under the GNU Lesser General Public License, version 2.1 or later.  This restatement and the extracted table
+ * (flacgpu_log_data.h) are a derived work of that code and are offered under the same terms (LGPL-2.1-or-later), whatever
+ * licence the rest of this repository carries; the reference itself (libFLAC) is BSD-3-Clause and contains none of it.
+ *
  * Pinned: tests/test_log_pin.py compares this function, compiled for the host, with the libm of the box on >= 10^8
  * arguments bit for bit (CPU), and the device instantiation with the same libm on >= 10^7 (GPU).
  *

@@ -134,6 +134,12 @@ struct FLAC__StreamEncoderPrivate {
 	int engine_on;                            /* init_*() succeeded and finish() has not run yet */
 	pthread_t bring_th;
 	int bring_started, bring_done, bring_result;
+	/* Asynchronous bring-up and the client's output: init_*() has not written "fLaC" and the metadata blocks yet when it
+	 * returns with the engine still coming up -- they go out in front of the first frame (emit()), or from finish() for a
+	 * stream without one, once the engine is known to be there.  An engine that fails to come up (device memory, a kernel
+	 * image the device cannot load) then fails the stream before a single byte reached the client's file, as the reference's
+	 * init would have (a client that branches on the init status must not be left with a half-written file). */
+	int preamble_pending, preamble_has_vc;
 	flacgpu_config bring_cfg;
 	size_t raw_bytes;
 	int registered[4];
@@ -481,7 +487,7 @@ FLAC__StreamEncoderState FLAC__stream_encoder_get_state(const FLAC__StreamEncode
 FLAC__StreamDecoderState FLAC__stream_encoder_get_verify_decoder_state(const FLAC__StreamEncoder *e)
 {
 	if(!PROT(e)->s.verify) return FLAC__STREAM_DECODER_UNINITIALIZED;
-	return PRIV(e)->gpu ? 2 : 8;
+	return PRIV(e)->engine_on ? 2 : 8;            /* (not on the engine pointer: the bring-up thread sets it, under the lock, some time after init) */
 }
 /* :2318-2330: for VERIFY_DECODER_ERROR the reference answers with its verify decoder's state string; the frame decoder here
  * has one state to report, the one get_verify_decoder_state gives */
@@ -691,10 +697,15 @@ static int ogg_write_proxy(void *encoder, const uint8_t *buf, size_t bytes, uint
 	FLAC__StreamEncoder *e = encoder;
 	return PRIV(e)->write_cb(e, buf, bytes, samples, current_frame, client_data) == FLAC__STREAM_ENCODER_WRITE_STATUS_OK;
 }
+static FLAC__StreamEncoderInitStatus write_preamble(FLAC__StreamEncoder *e);
 static int emit(FLAC__StreamEncoder *e, const uint8_t *buf, size_t bytes, uint32_t samples)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	FLAC__uint64 pos = 0;
+	if(p->preamble_pending) {            /* the first frame of a stream whose engine came up beside init_*(): the stream's head first */
+		p->preamble_pending = 0;
+		if(write_preamble(e) != FLAC__STREAM_ENCODER_INIT_STATUS_OK) return 0;
+	}
 	/* (the tell callback is called where write_frame_ calls it: for a metadata write, :3054, and -- once, lazily -- for a frame
 	 * that holds a seek point of the template, :3083; not in front of every frame) */
 	if(samples == 0) {
@@ -1066,6 +1077,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 						p->registered[2 * i] = b.registered[2 * i]; p->registered[2 * i + 1] = b.registered[2 * i + 1];
 					}
 					r = flacgpu_set_verify(p->gpu, s->verify ? 1 : 0);
+					if(r != FLACGPU_OK) p->engine_failed = 1;       /* do not park it again: the next stream gets a fresh engine */
 				}
 				free(w);
 			}
@@ -1135,9 +1147,19 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 	PROT(e)->streaminfo_offset = PROT(e)->seektable_offset = PROT(e)->audio_offset = 0;
 	PROT(e)->state = FLAC__STREAM_ENCODER_OK;
 
-	/* "fLaC", STREAMINFO with the unknowns zeroed, a VORBIS_COMMENT if the client gave none, client blocks (:1335-1425) */
-	if(!emit(e, (const uint8_t *)"fLaC", 4, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
 	memset(&p->streaminfo, 0, sizeof p->streaminfo);
+	if(s->do_md5) flacgpu_host_md5_init(&p->md5);
+	p->preamble_has_vc = has_vc;
+	p->preamble_pending = 0;
+	if(p->bring_started) { p->preamble_pending = 1; return FLAC__STREAM_ENCODER_INIT_STATUS_OK; }      /* (see preamble_pending) */
+	return write_preamble(e);
+}
+/* "fLaC", STREAMINFO with the unknowns zeroed, a VORBIS_COMMENT if the client gave none, client blocks (:1335-1425) */
+static FLAC__StreamEncoderInitStatus write_preamble(FLAC__StreamEncoder *e)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	const flacgpu_host_settings *s = &PROT(e)->s;
+	if(!emit(e, (const uint8_t *)"fLaC", 4, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
 	p->streaminfo.type = FLAC__METADATA_TYPE_STREAMINFO;
 	p->streaminfo.is_last = 0;
 	p->streaminfo.length = 34;
@@ -1145,11 +1167,10 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 	si->min_blocksize = si->max_blocksize = s->blocksize;
 	si->sample_rate = s->sample_rate; si->channels = s->channels; si->bits_per_sample = s->bits_per_sample;
 	si->total_samples = s->total_samples_estimate;
-	if(s->do_md5) flacgpu_host_md5_init(&p->md5);
 	if(!emit_block(e, &p->streaminfo)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
 	si->min_framesize = (1u << 24) - 1;
 	si->total_samples = 0;
-	if(!has_vc) {
+	if(!p->preamble_has_vc) {
 		FLAC__StreamMetadata vc;
 		memset(&vc, 0, sizeof vc);
 		vc.type = FLAC__METADATA_TYPE_VORBIS_COMMENT;
@@ -1558,6 +1579,17 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 		while(p->slot[0].state == 1 || p->slot[1].state == 1) pthread_cond_wait(&p->cv, &p->mu);
 		pthread_mutex_unlock(&p->mu);
 	}
+	if(p->preamble_pending && !p->is_being_deleted && PROT(e)->state == FLAC__STREAM_ENCODER_OK) {
+		/* no frame went out (an empty stream): its head still has to, provided the engine did come up */
+		if(p->bring_started) { pthread_join(p->bring_th, 0); p->bring_started = 0; }
+		p->preamble_pending = 0;
+		if(p->bring_result != FLACGPU_OK) {
+			PROT(e)->state = p->bring_result == FLACGPU_ERR_ALLOC ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+			error = 1;
+		}
+		else if(write_preamble(e) != FLAC__STREAM_ENCODER_INIT_STATUS_OK) error = 1;
+	}
+	p->preamble_pending = 0;
 	if(PROT(e)->s.do_md5 && p->engine_on) flacgpu_host_md5_final(&p->md5, p->streaminfo.data.stream_info.md5sum);
 	if(!p->is_being_deleted && PROT(e)->state == FLAC__STREAM_ENCODER_OK) {
 		p->current_frame_number = 0;

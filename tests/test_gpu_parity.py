@@ -99,7 +99,9 @@ def test_batches_and_frame_numbers():
     one, fb1 = _gpu_encode(pcm, 16, 44100, 5, max_batch=64)
     many, fb2 = _gpu_encode(pcm, 16, 44100, 5, max_batch=5)
     assert one == many and np.array_equal(fb1, fb2)
-    for first in (0x7E, 0x7FE, 0xFFFE, 0x1FFFFE):
+    # every UTF-8 length class of the frame number, each crossed inside the batch: 1->2, 2->3, 3->4, 4->5, 5->6 bytes
+    # (bitwriter.c:810-845; 0x4000000 opens the 6-byte class, 0x7ffffffe is the last pair of 31-bit numbers)
+    for first in (0x7E, 0x7FE, 0xFFFE, 0x1FFFFE, 0x3FFFFFE, 0x7FFFFFFC):
         data, _ = _gpu_encode(pcm[:4096 * 4], 16, 44100, 5, first_frame=first)
         assert data == po.oracle_encode(pcm[:4096 * 4], 16, 44100, 5, first_frame=first)["data"]
 
@@ -459,12 +461,15 @@ def _random_config(rng):
     return fam, n, ch, bps, rate, kw
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FLACGPU_TEST_SEEDS", "40"))))
-def test_random_configurations(seed):
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FLACGPU_TEST_SEEDS", "200"))))
+def test_random_configurations(seed, monkeypatch):
     """seeded sweep over the configuration space (block size, width, channels, orders, partition orders, apodizations,
-    searches, disable switches, short last blocks): GPU == oracle driven by the same resolved settings, and the device's own
-    verify pass accepts every batch"""
+    searches, disable switches, short last blocks): GPU == oracle driven by the same resolved settings, the device's own
+    verify pass accepts every batch, and every engine starts from poisoned scratch memory (FLACGPU_POISON: a kernel that reads
+    what no kernel wrote fails here)"""
     import flac_amd
+    if monkeypatch is not None:
+        monkeypatch.setenv("FLACGPU_POISON", "1")
     from oracle_from_settings import oracle_encode_settings
     rng = np.random.default_rng(1000 + seed)
     done = 0
@@ -565,4 +570,4 @@ def test_parity_with_poisoned_scratch_memory(monkeypatch):
     test_blocks_longer_than_16384(65535)
     test_many_apodizations_and_deep_subdivision()
     for seed in range(6):
-        test_random_configurations(seed)
+        test_random_configurations(seed, None)

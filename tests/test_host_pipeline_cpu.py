@@ -191,7 +191,7 @@ if st == 0 and sys.argv[1] == "encode":
     ok_process = bool(lib.FLAC__stream_encoder_process_interleaved(e, pcm.ctypes.data, len(pcm)))
     state_after_process = lib.FLAC__stream_encoder_get_state(e)
     ok_finish = bool(lib.FLAC__stream_encoder_finish(e))
-    print(st, state_after_init, ok_process, state_after_process, ok_finish)
+    print(st, state_after_init, ok_process, state_after_process, ok_finish, len(sink.buf.getvalue()))
 else:
     print(st, state_after_init)
 lib.FLAC__stream_encoder_delete(e)            # with the bring-up thread possibly still in flight
@@ -214,16 +214,29 @@ def test_engine_failure_is_loud_wherever_it_surfaces():
         out, err = _fail_child("encode", env)
         assert out[0] == "1" and out[1] != "0" and "cannot create the GPU frame engine" in err
     # a device node that opens but an engine that does not come up: init has returned OK by then; the first call that needs a
-    # frame fails, the state is an error state, stderr says why -- and nothing was written beyond the metadata
+    # frame fails, the state is an error state, stderr says why -- and NOT ONE BYTE reached the client's output: the stream's head
+    # ("fLaC", STREAMINFO, ...) is held back until the engine is known to be there (no half-written file)
     out, err = _fail_child("encode", {"FAKE_ENGINE_FAIL_CREATE": "1", "FLACGPU_BATCH_FRAMES": "8", "FAKE_ENGINE_CREATE_DELAY_US": "50000"})
-    st, s_init, ok_process, s_proc, ok_finish = out
+    st, s_init, ok_process, s_proc, ok_finish, written = out
     assert st == "0" and s_init == "0"
     assert ok_process == "False" and s_proc != "0" and "cannot create the GPU frame engine" in err
     assert ok_finish == "True"               # the reference's rule: finish() after a failed process() has nothing left to fail (:1649)
+    assert written == "0"
     # a stream shorter than one batch meets the failure in finish()
     out, err = _fail_child("encode", {"FAKE_ENGINE_FAIL_CREATE": "1", "FLACGPU_BATCH_FRAMES": "64"})
-    st, s_init, ok_process, s_proc, ok_finish = out
-    assert (st, s_init, ok_process, s_proc, ok_finish) == ("0", "0", "True", "0", "False") and "cannot create the GPU frame engine" in err
+    st, s_init, ok_process, s_proc, ok_finish, written = out
+    assert (st, s_init, ok_process, s_proc, ok_finish, written) == ("0", "0", "True", "0", "False", "0") and "cannot create the GPU frame engine" in err
+    # the synchronous flavours fail in init, before any byte as well
+    out, err = _fail_child("encode", {"FAKE_ENGINE_FAIL_CREATE": "1", "FLACGPU_SYNC_INIT": "1"})
+    assert out[0] == "1"
+
+
+def test_empty_stream_with_asynchronous_bring_up():
+    """no sample at all: the head of the stream goes out from finish(), once the engine is up"""
+    case = dict(BASE, samples=0)
+    data = run_case(case, {"FAKE_ENGINE_CREATE_DELAY_US": "100000"})
+    assert data[:4] == b"fLaC" and data[4] == 0 and data[42] == 0x84
+    assert data == run_case(case, {"FLACGPU_SYNC_INIT": "1"})
 
 
 def test_delete_while_the_engine_is_still_coming_up():
