@@ -139,7 +139,8 @@ hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *wi
 bool evalg_applicable(const DevParams &P);
 hipError_t launch_evalg(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);
 bool prep2_applicable(const DevParams &P);
-hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s);
+bool prep2_decides(const DevParams &P);      // prep2_kernel also evaluates and decides (no LPC search: -0 .. -2)
+hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);
 // where the pack kernel may put the frames directly (fused compaction: single-pass prefix sum of the frame lengths inside the
 // kernel); with po == null or po->out == null every frame goes to its slot and launch_scan + launch_compact must follow
 struct PackOutArgs { uint8_t *out; uint64_t cap; uint64_t *offsets; uint64_t *total; uint64_t *state /* [nframes + 1] scratch */; };

@@ -553,6 +553,82 @@ __device__ __forceinline__ uint32_t sat_add_u32(uint32_t est, uint32_t rbits)
 	return rbits < 0xffffffffu - est ? est + rbits : 0xffffffffu;
 }
 
+// The same search when every lane sum is small (< 2^23, so that nothing can wrap or saturate and 32-bit arithmetic
+// is exact): the 2^(max_po+1)-1 nodes of the partition tree are spread over the lanes -- leaf p on lane p, the
+// merged partitions of the lower orders on the lanes after each other -- their sums come from ONE prefix sum over
+// the lanes, and each lane evaluates at most two nodes instead of one node per partition order.
+// set_partitioned_rice_ (stream_encoder.c:4997-5046) without branches, for sum < 2^23: mean-based parameter
+// k = ilog2(((sum-1)*div) >> 18) + 1 (0 when that quotient is 0 or sum < 2), then the closed-form bit count
+__device__ __forceinline__ void rice_node_small(uint32_t sum, uint32_t ns, uint32_t div, uint32_t rice_limit_m1, uint32_t &k, uint32_t &bits)
+{
+	const uint32_t sm1 = (sum > 1u ? sum : 1u) - 1u;
+	const uint32_t x = (uint32_t)(((uint64_t)sm1 * div) >> 18);                  // < 2^23
+	uint32_t kk = 32u - umin32((uint32_t)__clz((int)x), 32u);   // __clz(0) = 32
+	kk = umin32(kk, rice_limit_m1);
+	k = kk;
+	bits = 4 + (1 + kk) * ns + ((sum << 1) >> kk) - (ns >> 1);
+}
+// Rice search over the partition orders as ONE butterfly: after exchange stage m every lane holds the |residual|
+// sum of its aligned group of 2^m lanes, i.e. of "its" partition at order max_po - (m - e); it evaluates that node
+// right there (all lanes of a group redundantly -- redundancy is free in SIMD) and the per-order bit totals ride along
+// through the remaining stages, so that at the end every lane holds every order's total.  No prefix sums, no
+// gathers; DPP adds for the first four stages.  Requires every lane sum < 2^23 (32-bit arithmetic exact).
+__device__ __forceinline__ uint32_t rice_search_nodes(uint32_t v, uint32_t e, uint32_t n, uint32_t order, uint32_t max_po, uint32_t min_po,
+                                                      uint32_t rice_limit, const uint32_t *divtab, uint8_t *kout, uint32_t *best_po_out, int lane)
+{
+	const uint32_t D = max_po - min_po;                     // number of lower orders searched
+	const uint32_t rl1 = rice_limit - 1;
+	uint32_t tm[7], km[7];
+#pragma unroll
+	for(int m = 0; m < 7; m++) { tm[m] = 0; km[m] = 0; }
+#pragma unroll
+	for(int m = 0; m < 7; m++) {
+		if((uint32_t)m >= e && (uint32_t)m - e <= D) {
+			// node of this lane at partition order po: partition index lane >> m; partition 0 is `order` samples short
+			const uint32_t po = max_po - ((uint32_t)m - e);
+			const uint32_t nsf = n >> po;
+			const uint32_t d0 = divtab[po * (MAX_ORDER + 1)], d1 = divtab[po * (MAX_ORDER + 1) + order];
+			const bool p0 = (uint32_t)lane < (1u << m);
+			rice_node_small(v, p0 ? nsf - order : nsf, p0 ? d1 : d0, rl1, km[m], tm[m]);
+		}
+		if(m < 6) {
+			if(m == 0) { v = bfly_add<0>(v); }
+			if(m == 1) { v = bfly_add<1>(v); }
+			if(m == 2) { v = bfly_add<2>(v); }
+			if(m == 3) { v = bfly_add<3>(v); }
+			if(m == 4) { v = bfly_add<4>(v); }
+			if(m == 5) { v = bfly_add<5>(v); }
+#pragma unroll
+			for(int j = 0; j <= m; j++) {
+				if(m == 0) tm[j] = bfly_add<0>(tm[j]);
+				if(m == 1) tm[j] = bfly_add<1>(tm[j]);
+				if(m == 2) tm[j] = bfly_add<2>(tm[j]);
+				if(m == 3) tm[j] = bfly_add<3>(tm[j]);
+				if(m == 4) tm[j] = bfly_add<4>(tm[j]);
+				if(m == 5) tm[j] = bfly_add<5>(tm[j]);
+			}
+		}
+	}
+	// strict <, highest order first: ties keep the higher order (stream_encoder.c:4735-4763); all uniform by now
+	uint32_t best_bits = 0, best_m = 0;
+	bool have = false;
+#pragma unroll
+	for(int m = 0; m < 7; m++) {
+		if((uint32_t)m >= e && (uint32_t)m - e <= D) {
+			const uint32_t bits = 6 + (uint32_t)__builtin_amdgcn_readfirstlane((int)tm[m]);
+			if(!have || bits < best_bits) { best_bits = bits; best_m = (uint32_t)m; have = true; }
+		}
+	}
+	uint32_t kk = km[0];
+#pragma unroll
+	for(int m = 1; m < 7; m++) if((uint32_t)m == best_m) kk = km[m];
+	if(((uint32_t)lane & ((1u << best_m) - 1u)) == 0) kout[(uint32_t)lane >> best_m] = (uint8_t)kk;
+	__builtin_amdgcn_wave_barrier();
+	*best_po_out = max_po - (best_m - e);
+	return best_bits;
+}
+
+
 // One WAVEFRONT evaluates one residual candidate (fixed or LPC) without any workgroup barrier:
 // integer FIR out of LDS (lane owns S consecutive samples), |residual| per partition, the flat tree of
 // merged sums, Rice parameter and bit estimate per partition, best partition order

@@ -22,6 +22,7 @@ namespace flacgpu {
 #define P2_WAVES 3
 #endif
 
+constexpr uint32_t P2_DIVTAB_BYTES = ((MAX_PO + 1) * (MAX_ORDER + 1) * 4 + 15) & ~15u;
 struct Prep2Acc {
 	uint32_t orv, diff;
 	uint32_t mag;              // OR of x ^ (x >> 31): every sample fits int16 iff (mag >> wasted) < 2^15
@@ -40,8 +41,11 @@ __host__ __device__ inline uint32_t p2_chan_bytes(uint32_t n) { return CHUNK * p
 // signal the reference computes (it shifts in place first) are these sums >> wasted, exactly.
 // |d_k[i]| = |d_(k-1)[i] - d_(k-1)[i-1]| is one v_sad_u32 on the sign-flipped (order preserving) operands.
 // MAG: also collect Prep2Acc::mag (the side channel: 17 bits wide, but quiet enough for the packed 16-bit kernels most of the time)
-template <bool WIDE, bool MAG = false>
-__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_chunk, int32_t first, Prep2Acc &A)
+// PARTS (the presets without an LPC search, prep2_kernel<.,.,true>): cs[k] = this chunk's sum for order k, as added to A.e[k];
+// ex[k] = what the residual of order k has IN FRONT of sample 4 (samples k..3: the predictor estimate skips them, the residual
+// of the chosen order does not, stream_encoder.c:4100 vs :4456)
+template <bool WIDE, bool MAG = false, bool PARTS = false>
+__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_chunk, int32_t first, Prep2Acc &A, uint32_t *cs = nullptr, uint32_t *ex = nullptr)
 {
 	constexpr uint32_t M = 0x80000000u;
 	uint32_t s[5] = {0, 0, 0, 0, 0};
@@ -57,7 +61,12 @@ __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_c
 		const int32_t d1 = a0 - x[t + 3], d2 = d1 - d1p, d3 = d2 - d2p;
 		uint32_t t0 = sad_u32(xb, M, 0), t1 = sad_u32(xb, xbp, 0), t2 = sad_u32((uint32_t)d1 ^ M, (uint32_t)d1p ^ M, 0),
 		         t3 = sad_u32((uint32_t)d2 ^ M, (uint32_t)d2p ^ M, 0), t4 = sad_u32((uint32_t)d3 ^ M, (uint32_t)d3p ^ M, 0);
-		if(t < 4) { if(first_chunk) { t0 = t1 = t2 = t3 = t4 = 0; } }          // the sums start at sample 4 (stream_encoder.c:4100)
+		if(t < 4) {
+			if(first_chunk) {
+				if(PARTS) { ex[0] += t0; if(t >= 1) ex[1] += t1; if(t >= 2) ex[2] += t2; if(t >= 3) ex[3] += t3; }
+				t0 = t1 = t2 = t3 = t4 = 0;                                        // the sums start at sample 4 (stream_encoder.c:4100)
+			}
+		}
 		if(WIDE) { A.e[0] += t0; A.e[1] += t1; A.e[2] += t2; A.e[3] += t3; A.e[4] += t4; }
 		else { s[0] += t0; s[1] += t1; s[2] += t2; s[3] += t3; s[4] += t4; }
 		d1p = d1; d2p = d2; d3p = d3; xbp = xb;
@@ -65,6 +74,10 @@ __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_c
 	if(!WIDE) {
 #pragma unroll
 		for(int k = 0; k < 5; k++) A.e[k] += s[k];
+		if(PARTS) {
+#pragma unroll
+			for(int k = 0; k < 5; k++) cs[k] = s[k];
+		}
 	}
 }
 
@@ -73,10 +86,15 @@ __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_c
 // makes the LDS tile stride a constant and folds the tile addresses into instruction offsets: with the stride in a register the
 // kernel spilled 27 VGPRs (the story of prep3_kernel below, which serves stereo with a mid/side search; this one serves the
 // presets without one, -0 and -3, the loose ones, -1 and -4 at 1152, and everything that is not stereo).
-template <bool WIDE, uint32_t NFIX>
+// DECIDE (prep2_decides()): no LPC search and one fixed order per subframe (-0, -1, -2): the residual of the guessed order is the
+// very difference signal whose sums this kernel has just taken, chunk by chunk -- so it also runs the Rice search on the partition
+// sums it can add up from them (find_best_partition_order_, stream_encoder.c:4701-5075), compares with VERBATIM / CONSTANT and
+// writes the SubDecision itself: no evaluation kernel, no second pass over the block.  A channel whose sums leave the 32-bit node
+// arithmetic goes on eval_list_kernel's list instead.
+template <bool WIDE, uint32_t NFIX, bool DECIDE>
 __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
                                                     ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
-                                                    int32_t *__restrict__ chan)
+                                                    int32_t *__restrict__ chan, SubDecision *__restrict__ decisions, uint32_t *__restrict__ left, uint32_t *__restrict__ nleft)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	__shared__ uint32_t sh_alleq[FLACGPU_MAX_CHANNELS];
@@ -92,10 +110,23 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 	const uint32_t nchunks = n / CHUNK;
 	const uint32_t TS = NFIX ? ((NFIX / CHUNK - 1 + 31) / 32) * 32 + 2 : p2_ts(n), cbytes = CHUNK * TS * 4;       // (p2_ts, p2_chan_bytes)
 	const bool need_flags = P.limit_min_bitrate || P.ms_mode == 2;
+	// DECIDE: [divisor table][per wavefront: chunk sums 5 x nchunks | the first chunk's extras 8 | Rice parameters 64 B] behind the staged channels
+	const uint32_t dz_base = (stereo_ms ? 2u : (C < 4 ? C : 4u)) * cbytes;
+	uint32_t *dz_divtab = (uint32_t *)(smem + dz_base);
+	const uint32_t dz_wbytes = (5 * nchunks + 8) * 4 + 64;
+	uint32_t *dz_csum = (uint32_t *)(smem + dz_base + P2_DIVTAB_BYTES + (size_t)wave * dz_wbytes);
+	uint32_t *dz_extra = dz_csum + 5 * nchunks;
+	uint8_t *dz_kout = (uint8_t *)(dz_extra + 8);
 
 	for(uint32_t c0 = 0; c0 < C; c0 += G) {
 		const uint32_t nraw = C - c0 < G ? C - c0 : G;
 		__syncthreads();
+		if(DECIDE && c0 == 0) {
+			for(uint32_t t = (uint32_t)tid; t < (MAX_PO + 1) * (MAX_ORDER + 1); t += nthreads) {
+				const uint32_t po = t / (MAX_ORDER + 1), o = t - po * (MAX_ORDER + 1), ps = n >> po;
+				dz_divtab[t] = ps > o ? 0x40000u / (ps - o) : 0;
+			}
+		}
 		// ---- stage the raw channels -------------------------------------------------------------------------
 		if(tid < CHUNK) for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * cbytes))[(uint32_t)tid * TS] = 0;
 		{
@@ -161,7 +192,18 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 #pragma unroll
 					for(int k = 0; k < 20; k++) x[k] = mode == 0 ? a[k] : mode == 1 ? b[k] : mode == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
 				}
-				if(mode == 3) prep2_chunk<WIDE, true>(x, ch == 0, first, A);
+				if(DECIDE) {
+					uint32_t cs[5], ex[5] = {0, 0, 0, 0, 0};
+					if(mode == 3) prep2_chunk<WIDE, true, true>(x, ch == 0, first, A, cs, ex);
+					else prep2_chunk<WIDE, false, true>(x, ch == 0, first, A, cs, ex);
+#pragma unroll
+					for(int k = 0; k < 5; k++) dz_csum[(uint32_t)k * nchunks + ch] = cs[k];
+					if(ch == 0) {
+#pragma unroll
+						for(int k = 0; k < 5; k++) dz_extra[k] = ex[k];
+					}
+				}
+				else if(mode == 3) prep2_chunk<WIDE, true>(x, ch == 0, first, A);
 				else prep2_chunk<WIDE>(x, ch == 0, first, A);
 			}
 			A.orv = wave_or_u32(A.orv);
@@ -222,10 +264,65 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 		}
 		const uint32_t fmt = (sbps <= 16 || (A.mag >> wasted) < 32768u) ? 1u : 0u;
 		const size_t fc = (size_t)f * P.ncand + cand;
+		uint32_t handled = 0;
+		if(DECIDE) {
+			// first minimum in the reference's evaluation order (verbatim -> constant | the fixed order), as eval_kernel decides it
+			const uint32_t hdr = 8 + wasted;
+			uint32_t best_type = 1, best_bits = verbatim_bits, dpo = 0, rice2 = 0;
+			int32_t best_constant = 0;
+			bool leave = false;
+			if(flags & PREP_CONSTANT) {
+				const uint32_t bits = hdr + sbps;
+				if(bits < best_bits) { best_type = 0; best_constant = constant; best_bits = bits; }
+			}
+			if(flags & PREP_FIXED_VALID) {
+				uint32_t fmax = 0;
+				{ uint32_t b = n; while(!(b & 1)) { fmax++; b >>= 1; } if(fmax > 15) fmax = 15; }
+				fmax = umin32(fmax, P.max_po);                                         // (<= 6: prep2_decides)
+				const uint32_t fmin = umin32(P.min_po, fmax), e = 6 - fmax, cpp = (n >> fmax) / CHUNK;
+				__builtin_amdgcn_wave_barrier();                                       // this wavefront's chunk sums are in LDS
+				uint32_t v = 0;
+				if(((uint32_t)lane & ((1u << e) - 1u)) == 0) {
+					const uint32_t pidx = (uint32_t)lane >> e;
+					const uint32_t *cs = dz_csum + fixed_order * nchunks + pidx * cpp;
+					uint64_t sum = 0;
+					for(uint32_t c = 0; c < cpp; c++) sum += cs[c];
+					if(pidx == 0) sum += dz_extra[fixed_order];
+					sum >>= wasted;
+					v = sum >= (1u << 23) ? (1u << 23) : (uint32_t)sum;
+				}
+				if(__any((int)(v >= (1u << 23)))) leave = true;
+				else {
+					uint32_t po = 0;
+					const uint32_t rbits = rice_search_nodes(v, e, n, fixed_order, fmax, fmin, P.rice_limit, dz_divtab, dz_kout, &po, lane);
+					const uint32_t est = sat_add_u32(hdr + fixed_order * sbps, rbits);
+					if(est > 0 && est < best_bits) { best_type = 2; best_bits = est; dpo = po; }
+				}
+			}
+			if(leave) { if(lane == 0) left[atomicAdd(nleft, 1u)] = (uint32_t)fc; }
+			else {
+				if(best_bits == 0xffffffffu) { best_type = 1; best_bits = hdr + n * sbps; }   // stream_encoder.c:4281
+				SubDecision *dec = decisions + fc;
+				if(best_type == 2) {
+					uint32_t big = 0;
+					if((uint32_t)lane < (1u << dpo)) { const uint8_t kk = dz_kout[lane]; dec->params[lane] = kk; if(kk >= 15) big = 1; }
+					rice2 = __any((int)big) ? 1u : 0u;                         // stream_encoder.c:4786-4791
+				}
+				if(lane < MAX_ORDER) dec->q[lane] = 0;
+				if(lane == 0) {
+					dec->bits = best_bits;
+					dec->type = (uint8_t)best_type; dec->order = (uint8_t)(best_type == 2 ? fixed_order : 0); dec->wasted = (uint8_t)wasted;
+					dec->po = (uint8_t)dpo; dec->rice2 = (uint8_t)rice2; dec->precision = 0;
+					dec->shift = 0; dec->which = (uint8_t)which;
+					dec->constant = best_constant; dec->constant_hi = best_constant >> 31; dec->fmt = fmt;
+				}
+				handled = EVG_HANDLED;
+			}
+		}
 		if(lane == 0) {
 			ChanPrep pr;
 			pr.which = which; pr.wasted = wasted; pr.sbps = sbps; pr.n = n; pr.flags = flags; pr.fixed_order = fixed_order;
-			pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.handled = 0; pr.pad = 0;
+			pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.handled = handled; pr.pad = 0;
 			preps[fc] = pr;
 		}
 		// ---- planar channel, shifted ---------------------------------------------------------------------------
@@ -467,14 +564,35 @@ bool prep2_applicable(const DevParams &P)
 	return P.blocksize % 16 == 0 && P.blocksize > 4 && (size_t)nraw * p2_chan_bytes(P.blocksize) <= 150 * 1024 && !P.wide_samples && !P.stream_sig;
 }
 
-hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, hipStream_t s)
+// prep2_kernel<.,.,true>: the presets whose only residual candidate is the guessed fixed order.  The leaf partitions must be whole
+// 16-sample chunks, the partition sums the reference's 32-bit ones (stream_encoder.c:4814), and eval_list_kernel (the lane-owner
+// evaluation) must be able to take what this kernel leaves behind.
+bool prep2_decides(const DevParams &P)
+{
+	static int off = -1;
+	if(off < 0) off = getenv("FLACGPU_NO_PREP_DECIDE") ? 1 : 0;
+	if(off || !prep2_applicable(P) || prep3_applicable(P)) return false;
+	if(P.max_lpc_order != 0 || P.nfixed != 1 || P.ncslots != 1 || P.bps > 16 || P.tune_flags) return false;
+	const uint32_t n = P.blocksize;
+	uint32_t fmax = 0;
+	{ uint32_t b = n; while(!(b & 1)) { fmax++; b >>= 1; } }
+	if(fmax > P.max_po) fmax = P.max_po;
+	if(fmax > 6 || n % 64 != 0 || n / 64 < 16 || (n / 64) % 2 != 0) return false;
+	const uint32_t psize = n >> fmax;
+	uint32_t lg = 0;
+	while((2u << lg) <= psize) lg++;
+	return psize % CHUNK == 0 && (P.bps + 1 + 4) < 32 - lg;
+}
+
+hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
 {
 	if(nmain == 0) return hipSuccess;
 	static bool attr_set = false;
 	if(!attr_set) {
 		hipError_t e = hipSuccess;
-#define P2ATTR(W, NF) if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep2_kernel<W, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)
-		P2ATTR(false, 0); P2ATTR(false, 1152); P2ATTR(false, 4096); P2ATTR(true, 0); P2ATTR(true, 1152); P2ATTR(true, 4096);
+#define P2ATTR(W, NF, DZ) if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep2_kernel<W, NF, DZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)
+		P2ATTR(false, 0, false); P2ATTR(false, 1152, false); P2ATTR(false, 4096, false); P2ATTR(true, 0, false); P2ATTR(true, 1152, false); P2ATTR(true, 4096, false);
+		P2ATTR(false, 0, true); P2ATTR(false, 1152, true);
 #undef P2ATTR
 		if(e != hipSuccess) return e;
 		attr_set = true;
@@ -496,7 +614,15 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
 	const uint32_t waves = stereo_ms ? 4u : nraw;
 	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize);
-#define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan)
+#define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft)
+	if(prep2_decides(P)) {
+		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
+		(void)hipMemsetAsync(B.nleft, 0, sizeof(uint32_t), s);
+		const size_t ldz = lds + P2_DIVTAB_BYTES + (size_t)waves * ((5 * (P.blocksize / CHUNK) + 8) * 4 + 64);
+		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
+		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
+		return hipGetLastError();
+	}
 	if(P.bps > 20) { if(P.blocksize == 4096) P2GO(true, 4096); else if(P.blocksize == 1152) P2GO(true, 1152); else P2GO(true, 0); }
 	else { if(P.blocksize == 4096) P2GO(false, 4096); else if(P.blocksize == 1152) P2GO(false, 1152); else P2GO(false, 0); }
 #undef P2GO

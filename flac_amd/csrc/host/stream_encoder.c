@@ -72,6 +72,7 @@ struct FLAC__StreamEncoderProtected {
 };
 
 /* ... and in FLAC__StreamEncoderPrivate: callbacks, stream bookkeeping, and here the batch staging */
+#define FLACGPU_PRE_MAX_SEGS 1024            /* "fLaC" + STREAMINFO + a VORBIS_COMMENT + the client's blocks: one segment each (beyond: written by init itself) */
 struct FLAC__StreamEncoderPrivate {
 	FLAC__StreamEncoderWriteCallback write_cb;
 	FLAC__StreamEncoderReadCallback read_cb;  /* Ogg FLAC only: the STREAMINFO page is read back at finish */
@@ -139,7 +140,10 @@ struct FLAC__StreamEncoderPrivate {
 	 * stream without one, once the engine is known to be there.  An engine that fails to come up (device memory, a kernel
 	 * image the device cannot load) then fails the stream before a single byte reached the client's file, as the reference's
 	 * init would have (a client that branches on the init status must not be left with a half-written file). */
-	int preamble_pending, preamble_has_vc;
+	int preamble_pending;
+	uint8_t *pre_buf;                         /* the head, serialised by init_*() -- a client may free its metadata objects as soon as init has */
+	size_t pre_len[FLACGPU_PRE_MAX_SEGS];     /* returned (the reference has written them by then; `flac` does exactly that) -- one write per segment */
+	uint32_t pre_nseg;
 	flacgpu_config bring_cfg;
 	size_t raw_bytes;
 	int registered[4];
@@ -1149,40 +1153,79 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 
 	memset(&p->streaminfo, 0, sizeof p->streaminfo);
 	if(s->do_md5) flacgpu_host_md5_init(&p->md5);
-	p->preamble_has_vc = has_vc;
-	p->preamble_pending = 0;
-	if(p->bring_started) { p->preamble_pending = 1; return FLAC__STREAM_ENCODER_INIT_STATUS_OK; }      /* (see preamble_pending) */
-	return write_preamble(e);
+	/* "fLaC", STREAMINFO with the unknowns zeroed, a VORBIS_COMMENT if the client gave none, client blocks (:1335-1425): serialised
+	 * now, written now -- or, with the engine still coming up on its own thread, in front of the first frame (see preamble_pending) */
+	{
+		bytebuf b = {0, 0, 0, 0};
+		int ok = 1;
+		p->pre_nseg = 0;
+		bb_put(&b, "fLaC", 4);
+		p->pre_len[p->pre_nseg++] = 4;
+		p->streaminfo.type = FLAC__METADATA_TYPE_STREAMINFO;
+		p->streaminfo.is_last = 0;
+		p->streaminfo.length = 34;
+		FLAC__StreamMetadata_StreamInfo *si = &p->streaminfo.data.stream_info;
+		si->min_blocksize = si->max_blocksize = s->blocksize;
+		si->sample_rate = s->sample_rate; si->channels = s->channels; si->bits_per_sample = s->bits_per_sample;
+		si->total_samples = s->total_samples_estimate;
+		size_t at = b.n;
+		ok = serialise_block(&p->streaminfo, &b);
+		p->pre_len[p->pre_nseg++] = b.n - at;
+		si->min_framesize = (1u << 24) - 1;
+		si->total_samples = 0;
+		if(ok && !has_vc) {
+			FLAC__StreamMetadata vc;
+			memset(&vc, 0, sizeof vc);
+			vc.type = FLAC__METADATA_TYPE_VORBIS_COMMENT;
+			vc.is_last = PROT(e)->num_metadata_blocks == 0;
+			vc.length = 8;
+			at = b.n;
+			ok = serialise_block(&vc, &b);
+			p->pre_len[p->pre_nseg++] = b.n - at;
+		}
+		int deferrable = PROT(e)->num_metadata_blocks + 3 <= FLACGPU_PRE_MAX_SEGS;
+		for(uint32_t i = 0; ok && deferrable && i < PROT(e)->num_metadata_blocks; i++) {
+			PROT(e)->metadata[i]->is_last = i + 1 == PROT(e)->num_metadata_blocks;
+			at = b.n;
+			ok = serialise_block(PROT(e)->metadata[i], &b);
+			p->pre_len[p->pre_nseg++] = b.n - at;
+		}
+		if(!ok) {
+			PROT(e)->state = b.bad ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+			free(b.p);
+			return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+		}
+		p->pre_buf = b.p;
+		p->preamble_pending = 0;
+		if(p->bring_started && deferrable) { p->preamble_pending = 1; return FLAC__STREAM_ENCODER_INIT_STATUS_OK; }
+		if(write_preamble(e) != FLAC__STREAM_ENCODER_INIT_STATUS_OK) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+		if(!deferrable) {
+			/* (more blocks than segments: written here, one by one; such a stream waits for its engine first) */
+			if(p->bring_started) { pthread_join(p->bring_th, 0); p->bring_started = 0; if(p->bring_result != FLACGPU_OK) { PROT(e)->state = FLAC__STREAM_ENCODER_FRAMING_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; } }
+			for(uint32_t i = 0; i < PROT(e)->num_metadata_blocks; i++) {
+				PROT(e)->metadata[i]->is_last = i + 1 == PROT(e)->num_metadata_blocks;
+				if(!emit_block(e, PROT(e)->metadata[i])) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+			}
+			if(p->tell_cb && p->tell_cb(e, &PROT(e)->audio_offset, p->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) {
+				PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+				return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+			}
+		}
+		return FLAC__STREAM_ENCODER_INIT_STATUS_OK;
+	}
 }
-/* "fLaC", STREAMINFO with the unknowns zeroed, a VORBIS_COMMENT if the client gave none, client blocks (:1335-1425) */
+/* the serialised head goes to the client, one write per block as the reference writes them */
 static FLAC__StreamEncoderInitStatus write_preamble(FLAC__StreamEncoder *e)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
-	const flacgpu_host_settings *s = &PROT(e)->s;
-	if(!emit(e, (const uint8_t *)"fLaC", 4, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
-	p->streaminfo.type = FLAC__METADATA_TYPE_STREAMINFO;
-	p->streaminfo.is_last = 0;
-	p->streaminfo.length = 34;
-	FLAC__StreamMetadata_StreamInfo *si = &p->streaminfo.data.stream_info;
-	si->min_blocksize = si->max_blocksize = s->blocksize;
-	si->sample_rate = s->sample_rate; si->channels = s->channels; si->bits_per_sample = s->bits_per_sample;
-	si->total_samples = s->total_samples_estimate;
-	if(!emit_block(e, &p->streaminfo)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
-	si->min_framesize = (1u << 24) - 1;
-	si->total_samples = 0;
-	if(!p->preamble_has_vc) {
-		FLAC__StreamMetadata vc;
-		memset(&vc, 0, sizeof vc);
-		vc.type = FLAC__METADATA_TYPE_VORBIS_COMMENT;
-		vc.is_last = PROT(e)->num_metadata_blocks == 0;
-		vc.length = 8;
-		if(!emit_block(e, &vc)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
-	}
-	for(uint32_t i = 0; i < PROT(e)->num_metadata_blocks; i++) {
-		PROT(e)->metadata[i]->is_last = i + 1 == PROT(e)->num_metadata_blocks;
-		if(!emit_block(e, PROT(e)->metadata[i])) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
-	}
-	if(p->tell_cb && p->tell_cb(e, &PROT(e)->audio_offset, p->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) {
+	size_t at = 0;
+	int ok = 1;
+	for(uint32_t i = 0; ok && i < p->pre_nseg; i++) { ok = emit(e, p->pre_buf + at, p->pre_len[i], 0); at += p->pre_len[i]; }
+	free(p->pre_buf); p->pre_buf = 0;
+	const int all = p->pre_nseg >= 2 + PROT(e)->num_metadata_blocks;          /* (every block was a segment) */
+	p->pre_nseg = 0;
+	if(!ok) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	if(all && p->tell_cb && p->tell_cb(e, &PROT(e)->audio_offset, p->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) {
 		PROT(e)->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
 		return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
 	}
@@ -1590,6 +1633,7 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 		else if(write_preamble(e) != FLAC__STREAM_ENCODER_INIT_STATUS_OK) error = 1;
 	}
 	p->preamble_pending = 0;
+	free(p->pre_buf); p->pre_buf = 0; p->pre_nseg = 0;
 	if(PROT(e)->s.do_md5 && p->engine_on) flacgpu_host_md5_final(&p->md5, p->streaminfo.data.stream_info.md5sum);
 	if(!p->is_being_deleted && PROT(e)->state == FLAC__STREAM_ENCODER_OK) {
 		p->current_frame_number = 0;

@@ -312,3 +312,28 @@ def test_parking_can_be_switched_off():
     a = dict(seed=1, samples=256 * 20, blocksize=256)
     r = _park([a, a], {"FLACGPU_ENGINE_CACHE": "0"})
     assert [x["creates"] for x in r] == [1, 2] and [x["destroys"] for x in r] == [1, 2]
+
+
+DROPIN_FLAC = os.path.join(ROOT, "oracle", "_ref", "dropin", "flac")
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN_FLAC), reason="oracle/_ref/dropin/flac not built (no /root/reference on this box)")
+def test_client_that_frees_its_metadata_right_after_init(tmp_path):
+    """the reference's `flac` tool deletes its metadata objects as soon as init_*() has returned (src/flac/encode.c:2172) -- the
+    head of the stream is serialised inside init, even when it is written later (asynchronous bring-up): same file either way"""
+    import wave
+    _build()
+    rng = np.random.default_rng(3)
+    pcm = rng.integers(-20000, 20000, size=(4096 * 9 + 500, 2), dtype=np.int64).astype("<i2")
+    wav = str(tmp_path / "a.wav")
+    w = wave.open(wav, "wb"); w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100); w.writeframes(pcm.tobytes()); w.close()
+    outs = []
+    for extra in ({"FAKE_ENGINE_CREATE_DELAY_US": "100000"}, {"FLACGPU_SYNC_INIT": "1"}):
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = FAKE_DIR + os.pathsep + os.path.join(ROOT, "flac_amd", "lib") + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+        env.update(extra)
+        out = str(tmp_path / ("o%d.flac" % len(outs)))
+        r = subprocess.run([DROPIN_FLAC, "-s", "-f", "-5", "-T", "TITLE=x", "-S", "4x", "--padding=100", "-o", out, wav], env=env, capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and outs[0][:4] == b"fLaC"
