@@ -557,7 +557,7 @@ __global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t 
                                                     const ChanPrep *__restrict__ preps, const double *__restrict__ autoc_in,
                                                     Candidate *__restrict__ cands, int *__restrict__ valid, uint32_t *__restrict__ nleft)
 {
-	if(nleft && blockIdx.x == 0 && threadIdx.x == 0) *nleft = 0;        // the list evalg_kernel fills for eval_list_kernel starts empty
+	if(nleft && blockIdx.x == 0 && threadIdx.x == 0) { nleft[0] = 0; nleft[1] = 0; }       // the lists of the evaluation kernels start empty
 	// the { invc, logc } table of the log (flacgpu_log.h) in LDS: a lane looks it up a dozen times, each at its own index
 	__shared__ uint64_t logtab[256];
 	logtab[threadIdx.x] = flacgpu_log_tab[threadIdx.x];
@@ -1330,7 +1330,7 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		const uint32_t lanes = nframes * P.ncand * P.max_analyses;
 		hipLaunchKernelGGL(model_kernel<MAXORD>, dim3((lanes + TPB - 1) / TPB), dim3(TPB), 0, s, P, nframes, tail_n, jtm, jtt, B.prep, B.autoc, B.cands, B.valid, B.nleft);
 	}
-	else if(!(prep2_applicable(P) && prep2_decides(P))) (void)hipMemsetAsync(B.nleft, 0, sizeof(uint32_t), s);      // (a deciding prep kernel has started the list)
+	else if(!(prep2_applicable(P) && prep2_decides(P))) (void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);      // (a deciding prep kernel has started the list)
 	sync_debug("model", s);
 	if(pev) (void)hipEventRecord(pev[2], s);
 	uint32_t cpw, waves;
@@ -1373,19 +1373,30 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(4 * 64), eval_layout(P, 4, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
 	}
 	else if(op && evalg_applicable(P) && !B.dbg) {
-		// one wavefront per channel (flacgpu_evalg.hip); what it lists as not its own goes through the workgroup-per-channel body
-		// above, a fixed grid looping over the list
-		const hipError_t e = launch_evalg(P, nframes, tail_n, jtm, B, dec, s);
-		if(e != hipSuccess) return e;
+		// one wavefront per channel: 16-bit pairs (flacgpu_evalg.hip), then the 32-bit channels it listed (flacgpu_evalw.hip) -- or
+		// those straight away when the stream has more than 16 bits --, and what neither takes through the workgroup-per-channel
+		// body above, a fixed grid looping over the last list
+		const uint32_t *last_list, *last_count;
+		if(P.bps <= 16) {
+			hipError_t e = launch_evalg(P, nframes, tail_n, jtm, B, dec, s);
+			if(e == hipSuccess) e = launch_evalw(P, nframes, tail_n, jtm, B, dec, B.left, B.nleft, B.left2, B.nleft + 1, s);
+			if(e != hipSuccess) return e;
+			last_list = B.left2; last_count = B.nleft + 1;
+		}
+		else {
+			const hipError_t e = launch_evalw(P, nframes, tail_n, jtm, B, dec, nullptr, nullptr, B.left, B.nleft, s);
+			if(e != hipSuccess) return e;
+			last_list = B.left; last_count = B.nleft;
+		}
 		static bool lset = false;
 		if(!lset) {
 			const hipError_t e2 = hipFuncSetAttribute((const void *)eval_list_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 			if(e2 != hipSuccess) return e2;
 			lset = true;
 		}
-		const uint32_t lw = P.ncslots >= 8 ? 8u : 4u;
+		const uint32_t lw = 4u;
 		const uint32_t grid = nframes * P.ncand < 1024u ? nframes * P.ncand : 1024u;
-		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(lw * 64), eval_layout(P, lw, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
+		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(lw * 64), eval_layout(P, lw, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, last_list, last_count);
 	}
 	else if(op) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, (uint32_t)ahead);
 	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u);

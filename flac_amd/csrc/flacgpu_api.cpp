@@ -189,6 +189,7 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->ab.valid) (void)hipFree(c->ab.valid);
 	if(c->ab.chan) (void)hipFree(c->ab.chan);
 	if(c->ab.left) (void)hipFree(c->ab.left);
+	if(c->ab.left2) (void)hipFree(c->ab.left2);
 	if(c->ab.nleft) (void)hipFree(c->ab.nleft);
 	if(c->ab.dbg) (void)hipFree(c->ab.dbg);
 	for(int r = 0; r < TIMING_RING; r++) for(int i = 0; i < 3; i++) if(c->pev_ring[r][i]) (void)hipEventDestroy(c->pev_ring[r][i]);
@@ -360,7 +361,8 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		ok = ok && hipMalloc(&c->ab.valid, nfc * ncs * sizeof(int)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.chan, nfc * P.chan_stride * sizeof(int32_t)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.left, nfc * sizeof(uint32_t)) == hipSuccess;
-		ok = ok && hipMalloc(&c->ab.nleft, FLACGPU_MAX_SUBBATCHES * sizeof(uint32_t)) == hipSuccess;
+		ok = ok && hipMalloc(&c->ab.left2, nfc * sizeof(uint32_t)) == hipSuccess;
+		ok = ok && hipMalloc(&c->ab.nleft, 2 * FLACGPU_MAX_SUBBATCHES * sizeof(uint32_t)) == hipSuccess;
 		if(ok && getenv("FLACGPU_DEBUG_TIMING")) { ok = hipMalloc(&c->ab.dbg, nfc * 16 * sizeof(unsigned long long)) == hipSuccess; if(ok) (void)hipMemset(c->ab.dbg, 0, nfc * 16 * sizeof(unsigned long long)); }
 	}
 	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
@@ -430,7 +432,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			(void)hipStreamWaitEvent(ss, c->ev_fork, 0);
 			const size_t fc0 = (size_t)f0 * P.ncand, ncs = P.ncslots;
 			AnalyzeBuffers B = c->ab;
-			B.prep += fc0; B.autoc += fc0 * P.max_jobs * AUTOC_STRIDE; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.chan_stride; B.left += fc0; B.nleft += i; B.dbg = nullptr;
+			B.prep += fc0; B.autoc += fc0 * P.max_jobs * AUTOC_STRIDE; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.chan_stride; B.left += fc0; B.left2 += fc0; B.nleft += 2 * i; B.dbg = nullptr;
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
 			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
 			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;

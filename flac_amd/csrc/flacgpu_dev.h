@@ -115,7 +115,8 @@ struct AnalyzeBuffers {
 	Candidate *cands;          // [frames*ncand][ncslots]: fixed orders, then analysis a / order / precision (DevParams::ncslots)
 	int *valid;                // same shape
 	int32_t *chan;             // [frames*ncand][blocksize] planar channel signals, wasted bits shifted out (ChanPrep::fmt)
-	uint32_t *left, *nleft;    // [frames*ncand] channels evalg_kernel left to eval_list_kernel, and their count (zeroed by the model kernel)
+	uint32_t *left, *left2, *nleft; // two lists [frames*ncand] of channels a wavefront-per-channel evaluation kernel left to the next kernel in line
+	                           // (evalg -> evalw -> eval_list_kernel), and their counts nleft[0], nleft[1] (zeroed by the model kernel)
 	unsigned long long *dbg;   // FLACGPU_DEBUG_TIMING=1: [frames*ncand][16] s_memtime stamps of the eval kernel (else null)
 };
 constexpr int FLACGPU_MAX_SUBBATCHES = 8;   // streams a batch may be split over (FLACGPU_SUBBATCHES / flacgpu_set_subbatches)
@@ -138,6 +139,9 @@ hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *wi
                          const ChanPrep *preps, double *autoc, hipStream_t s);
 bool evalg_applicable(const DevParams &P);
 hipError_t launch_evalg(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);
+// 32-bit planar channels (flacgpu_evalw.hip): every channel of the batch (in_list == null), or the channels of a list
+hipError_t launch_evalw(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec,
+                        const uint32_t *in_list, const uint32_t *in_count, uint32_t *out_list, uint32_t *out_count, hipStream_t s);
 bool prep2_applicable(const DevParams &P);
 bool prep2_decides(const DevParams &P);      // prep2_kernel also evaluates and decides (no LPC search: -0 .. -2)
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);

@@ -27,45 +27,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include "flacgpu_dev.h"
-#include "flacgpu_devfn.h"
+#include "flacgpu_evalg.h"
 
 namespace flacgpu {
-
-#ifndef EVALG_WAVES_PER_SIMD
-#define EVALG_WAVES_PER_SIMD 4
-#endif
-
-constexpr int EG_MAXC = 32;               // candidate slots of a channel this kernel takes (lane c holds candidate c's record)
-
-// ---- DPP helpers (the compiler sees these, so it places the wait states itself) --------------------------------------
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
-{
-	return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
-}
-// inclusive prefix sum over the 64 lanes: Hillis-Steele inside a row of 16, then the row totals
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
-{
-	v = dpp_add<0x111, 0xf>(v);            // row_shr:1
-	v = dpp_add<0x112, 0xf>(v);            // row_shr:2
-	v = dpp_add<0x114, 0xf>(v);            // row_shr:4
-	v = dpp_add<0x118, 0xf>(v);            // row_shr:8
-	v = dpp_add<0x142, 0xa>(v);            // row_bcast:15 into rows 1 and 3
-	v = dpp_add<0x143, 0xc>(v);            // row_bcast:31 into rows 2 and 3
-	return v;
-}
-// the same without the last step: lanes 31 and 63 end with the totals of their halves
-__device__ __forceinline__ uint32_t half_scan_incl(uint32_t v)
-{
-	v = dpp_add<0x111, 0xf>(v);
-	v = dpp_add<0x112, 0xf>(v);
-	v = dpp_add<0x114, 0xf>(v);
-	v = dpp_add<0x118, 0xf>(v);
-	v = dpp_add<0x142, 0xa>(v);
-	return v;
-}
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
 // ---- the FIR of one candidate over one 16-sample piece of every lane's run ------------------------------------------
 // AA[j]: the word holding samples (2j - 14, 2j - 13) relative to the piece start, BB[m] = samples (2m - 13, 2m - 12).
@@ -122,11 +86,6 @@ __device__ __forceinline__ uint32_t fir16_dispatch(uint32_t npf, const uint32_t 
 	default: return fir16_folded<7, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
 	}
 }
-// LDS image of a channel, TRANSPOSED: word j of lane L's run at (j * 65 + L + 1) -- the 64 lanes reading "their word j" read 64
-// consecutive words (no bank conflict, no padding per lane), and the word in front of a run is the last word of the run of
-// lane L - 1: column L.  Column 0 is lane 0's history: zero.  8.3 KB per 4096-sample channel (the per-lane regions with their
-// own history copies took 10.5 KB: one wavefront more per SIMD).
-constexpr uint32_t EG_ROW = 65 * 4;      // bytes per row
 // base: byte address of word (first sample of the piece - 14 samples) in the lane's column; rows at immediate offsets
 __device__ __forceinline__ void load_piece(const unsigned char *base, uint32_t (&AA)[15], uint32_t (&BB)[14])
 {
@@ -150,54 +109,19 @@ __device__ __forceinline__ void load_piece_first(const unsigned char *own /* wor
 // one slot of the pair: a residual candidate's folded taps and scalars, all wave-uniform
 struct EgSlot { uint32_t Q[7]; uint32_t shift, bias, order, npf, precision, ci; };
 
-// ---- one node pass of the Rice search ---------------------------------------------------------------------------
-// lane constants of a pass: LDS byte offsets of the two prefix-sum entries whose difference is twice the node's
-// |residual| sum; nsf9 = samples of a full partition at this level + 9 (0: the lane has no node in this pass);
-// dtoff = byte offset of the level's row of the divisor table; p0 = the node is partition 0 (`order` samples short)
-struct EgPass { uint32_t a_start, a_end, nsf9, dtoff; bool p0; };
-// set_partitioned_rice_ (stream_encoder.c:4997-5046) on sum2 = 2 * sum, sum < 2^29, without branches:
-//   k    = ilog2(((sum - 1) * div) >> 18) + 1 for sum >= 2 and a non-zero quotient, else 0; div = 0x40000 / ns
-//   bits = 4 + (1 + k) * ns + (k ? sum >> (k - 1) : sum << 1) - (ns >> 1)              (:4929-4950, the estimate)
-// with (sum - 1) * div >> 18 == mul_hi(2 * (sum - 1), div << 13), and ilog2(x) + 1 == the binary exponent of (float)x
-// (x < 2^20 here: exact).  ns - (ns >> 1) + 4 == (ns + 9) >> 1.
-__device__ __forceinline__ void rice_pass(const unsigned char *lds, const EgPass &C, uint32_t ord_lane /* this lane's candidate's order */, uint32_t rl1, uint32_t &k, uint32_t &bits)
-{
-	const uint32_t o = C.p0 ? ord_lane : 0u;
-	const uint32_t ns9 = C.nsf9 - o;                                       // (a lane without a node has nsf9 = 0, p0 = false and a zero sum:
-	const uint32_t ns = ns9 - 9u;                                          //  k = 0 and bits = 0 whatever ns wraps to)
-	const uint32_t dsh = *(const uint32_t *)(lds + C.dtoff + o * 4u);
-	const uint32_t sum2 = *(const uint32_t *)(lds + C.a_end) - *(const uint32_t *)(lds + C.a_start);
-	const uint32_t a2 = (sum2 > 2u ? sum2 : 2u) - 2u;
-	const uint32_t x = __umulhi(a2, dsh);
-	uint32_t kk = (uint32_t)__builtin_amdgcn_frexp_expf((float)x);          // 0 for x == 0
-	kk = umin32(kk, rl1);
-	k = kk;
-	bits = __umul24(kk, ns) + (ns9 >> 1) + (sum2 >> kk);
-}
-
-// LDS of one wavefront: [image (S/2 rows of 65 words)][prefix sums 2 x 66][divisor table 7 x (MAXORD + 1)][best parameters 64 B]
+// LDS of one wavefront: [image (S/2 rows of 65 words)][prefix sums | divisor table | best parameters (flacgpu_evalg.h)]
 template <int MAXORD>
-__host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N)
-{
-	return (N / 128) * EG_ROW + 2 * 66 * 4 + 7 * (MAXORD + 1) * 4 + 64;
-}
+__host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N) { return (N / 128) * EG_ROW + eg_tail_bytes<MAXORD>(); }
 constexpr int EG_PIECES_AHEAD = 8;        // 16-byte pieces of the planar channel a lane has in flight before its first use (8 = a 4096-sample block)
 
+// returns false when the channel is not this kernel's (the caller lists it)
 template <int MAXORD>
-__global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
-                                                                          const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
-                                                                          const int *__restrict__ valid, SubDecision *__restrict__ decisions,
-                                                                          uint32_t *__restrict__ left, uint32_t *__restrict__ nleft)
+__device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__restrict__ chan, const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps,
+                                           const Candidate *__restrict__ cands, const int *__restrict__ valid, SubDecision *__restrict__ decisions, uint32_t fc,
+                                           unsigned char *smem, int lane)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int lane = (int)threadIdx.x;
-	const uint32_t fc = blockIdx.x;
 	const uint32_t n = P.blocksize, S = n / 64;
 	const uint32_t aslots = P.norders * P.nprec, cstride = P.ncslots;
-	// what this kernel does not take goes on eval_list_kernel's list
-#define EG_LEAVE() do { if(lane == 0) left[atomicAdd(nleft, 1u)] = fc; return; } while(0)
-	if(tail_n != 0 && fc / P.ncand == nframes - 1) EG_LEAVE();              // the short last block
-
 	// ---- every load from HBM goes out before the first use: one round trip, not three ------------------------------------
 	const ChanPrep pr = preps[fc];
 	const uint32_t nanalyses = jt->nanalyses;
@@ -230,11 +154,12 @@ __global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const D
 	const uint32_t psize = n >> frame_max_po;
 	const bool narrow = (pr.sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
 	const uint32_t sbps = pr.sbps, hdr = 8 + pr.wasted;
-	uint32_t best_est = 0xffffffffu, best_ci = 0xffffffffu, best_po = 0;
 	uint8_t *kbest = smem + evalg_lds_bytes<MAXORD>(n) - 64;
+	EgSearch R;
+	R.best_est = 0xffffffffu; R.best_ci = 0xffffffffu; R.best_po = 0;
 
 	if(any) {
-	if(pr.fmt != 1 || !narrow || frame_max_po > 6) EG_LEAVE();
+	if(pr.fmt != 1 || !narrow || frame_max_po > 6) return false;
 
 	// ---- candidate records: folded taps, and whether this kernel's arithmetic is exact for them --------------------------------
 	uint32_t Qv[7];
@@ -255,16 +180,12 @@ __global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const D
 		if(c_valid) c_ok = c_wide == 0 && c_order <= (uint32_t)MAXORD && c_shift <= 15u
 		                   && (((uint64_t)abs_sum + (1u << (c_shift & 15u))) << (sbps - 1)) < (1ull << 31);
 	}
-	if(__any((int)!c_ok)) EG_LEAVE();
+	if(__any((int)!c_ok)) return false;
 	uint64_t vmask = __ballot((int)c_valid);
 
 	// ---- LDS of this wavefront --------------------------------------------------------------------------------------------
 	const uint32_t rows = S / 2;
 	const uint32_t img_bytes = rows * EG_ROW;
-	uint32_t *ps = (uint32_t *)(smem + img_bytes);                           // [2][66]
-	uint32_t *dt = ps + 2 * 66;                                              // [7][MAXORD + 1]: (0x40000 / ((S << m) - o)) << 13
-	const uint32_t ps_off = img_bytes, dt_off = img_bytes + 2 * 66 * 4;
-
 	// the planar channel (16-bit pairs) into the image: a 16-byte piece is four consecutive words of ONE lane's run (S is a
 	// multiple of 16)
 	{
@@ -287,34 +208,7 @@ __global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const D
 			*(uint32_t *)(d) = v.x; *(uint32_t *)(d + EG_ROW) = v.y; *(uint32_t *)(d + 2 * EG_ROW) = v.z; *(uint32_t *)(d + 3 * EG_ROW) = v.w;
 		}
 	}
-	// the divisor table: entry (m, o) for partitions of 2^m lane runs, `o` samples short
-	const uint32_t e = 6 - frame_max_po, D = frame_max_po - frame_min_po;
-	for(uint32_t t = (uint32_t)lane; t < 7 * (MAXORD + 1); t += 64) {
-		const uint32_t m = t / (MAXORD + 1), o = t - m * (MAXORD + 1), full = S << m;
-		dt[t] = full > o ? (0x40000u / (full - o)) << 13 : 0u;
-	}
-	if(lane < 2) ps[lane * 66] = 0;
-
-	// ---- lane constants of the node passes ---------------------------------------------------------------------------------
-	// level m: nodes of 2^m lanes, partition order frame_max_po - (m - e); searched when e <= m <= e + D
-	EgPass PA, PC, PD;
-	uint32_t mD;
-	{
-		const uint32_t half = (uint32_t)lane >> 5, j = (uint32_t)lane & 31u;
-		const bool a0 = e == 0;
-		PA.a_start = ps_off + (uint32_t)lane * 4; PA.a_end = PA.a_start + 4;          // (pass B: + 66 * 4)
-		PA.nsf9 = a0 ? S + 9 : 0; PA.dtoff = dt_off; PA.p0 = a0 && lane == 0;
-		const bool a1 = e <= 1 && 1 <= e + D;
-		PC.a_start = ps_off + (half * 66 + 2 * j) * 4; PC.a_end = PC.a_start + 8;
-		PC.nsf9 = a1 ? 2 * S + 9 : 0; PC.dtoff = dt_off + (MAXORD + 1) * 4; PC.p0 = a1 && j == 0;
-		mD = j < 16 ? 2u : j < 24 ? 3u : j < 28 ? 4u : j < 30 ? 5u : j < 31 ? 6u : 7u;
-		const uint32_t idx = j - (32u - (128u >> mD));                                 // (mD == 7: unused)
-		const bool aD = mD <= 6 && e <= mD && mD <= e + D;
-		PD.a_start = ps_off + (half * 66 + (aD ? idx << mD : 0u)) * 4; PD.a_end = PD.a_start + (aD ? (4u << mD) : 0u);
-		PD.nsf9 = aD ? (S << mD) + 9 : 0; PD.dtoff = dt_off + (aD ? mD : 0u) * (MAXORD + 1) * 4; PD.p0 = aD && idx == 0;
-		if(!aD) mD = 7;
-	}
-	const uint32_t rl1 = P.rice_limit - 1;
+	eg_search_setup<MAXORD>(R, smem, img_bytes, S, frame_max_po, frame_min_po, P.rice_limit, lane);
 	const unsigned char *own = smem + ((uint32_t)lane + 1) * 4;                      // word 0 of this lane's run
 	const unsigned char *hist = smem + (uint32_t)lane * 4 + (rows - 7) * EG_ROW;     // 7 words in front of it: the previous column's last
 	const uint32_t npieces = S / 16;
@@ -353,112 +247,29 @@ __global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const D
 			if(two) v1 = fir16_dispatch<false>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
 		}
 		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_list_kernel's (nothing was written yet)
-		if(__any((int)((v0 | v1) >= (1u << 23)))) EG_LEAVE();
-
-		// ---- Rice search of the pair ---------------------------------------------------------------------------------------
-		ps[1 + lane] = wave_scan_incl(v0 << 1);
-		ps[66 + 1 + lane] = wave_scan_incl(v1 << 1);
-		__builtin_amdgcn_wave_barrier();
-		uint32_t tot0[7], tot1[7];                                                // per level m: total bits of the level (uniform)
-#pragma unroll
-		for(int m = 0; m < 7; m++) { tot0[m] = 0; tot1[m] = 0; }
-		uint32_t kA = 0, kB = 0, kC = 0, kD = 0, b;
-		if(e == 0) {
-			rice_pass(smem, PA, A.order, rl1, kA, b);
-			tot0[0] = rdlane(wave_scan_incl(b), 63);
-			EgPass PB = PA; PB.a_start += 66 * 4; PB.a_end += 66 * 4;
-			rice_pass(smem, PB, B.order, rl1, kB, b);
-			tot1[0] = rdlane(wave_scan_incl(b), 63);
-		}
-		const uint32_t ord_lane = lane < 32 ? A.order : B.order;
-		if(e <= 1 && 1 <= e + D) {
-			rice_pass(smem, PC, ord_lane, rl1, kC, b);
-			b = half_scan_incl(b);
-			tot0[1] = rdlane(b, 31); tot1[1] = rdlane(b, 63);
-		}
-		if(e + D >= 2) {
-			rice_pass(smem, PD, ord_lane, rl1, kD, b);
-			// the levels sit in aligned lane groups of their own size (16 | 8 | 4 | 2 | 1): each total is read at the butterfly
-			// stage that has summed exactly its group
-			tot0[6] = rdlane(b, 30); tot1[6] = rdlane(b, 62);
-			b = bfly_add<0>(b); tot0[5] = rdlane(b, 28); tot1[5] = rdlane(b, 60);
-			b = bfly_add<1>(b); tot0[4] = rdlane(b, 24); tot1[4] = rdlane(b, 56);
-			b = bfly_add<2>(b); tot0[3] = rdlane(b, 16); tot1[3] = rdlane(b, 48);
-			b = bfly_add<3>(b); tot0[2] = rdlane(b, 0); tot1[2] = rdlane(b, 32);
-		}
-		__builtin_amdgcn_wave_barrier();                                          // (the prefix sums are rewritten by the next pair)
-
-		// strict <, highest order first: ties keep the higher order (stream_encoder.c:4735-4763)
-#pragma unroll
-		for(int slot = 0; slot < 2; slot++) {
-			if(slot == 1 && !two) break;
-			const EgSlot &X = slot ? B : A;
-			uint32_t bb = 0, bm = 0;
-			bool have = false;
-#pragma unroll
-			for(int m = 0; m < 7; m++) {
-				if((uint32_t)m >= e && (uint32_t)m - e <= D) {
-					const uint32_t bits = 6 + (slot ? tot1[m] : tot0[m]);
-					if(!have || bits < bb) { bb = bits; bm = (uint32_t)m; have = true; }
-				}
-			}
-			const uint32_t est = X.ci < P.nfixed ? sat_add_u32(hdr + X.order * sbps, bb) : sat_add_u32(hdr + 4 + 5 + X.order * (X.precision + sbps), bb);
-			// candidates are met in increasing order; strict <: the earlier one keeps a tie (stream_encoder.c:4191,4266)
-			if(est > 0 && est < best_est) {
-				best_est = est; best_ci = X.ci; best_po = frame_max_po - (bm - e);
-				const uint32_t half = (uint32_t)lane >> 5, j = (uint32_t)lane & 31u;
-				if(bm == 0) kbest[lane] = (uint8_t)(slot ? kB : kA);
-				else if(bm == 1) { if(half == (uint32_t)slot) kbest[j] = (uint8_t)kC; }
-				else if(half == (uint32_t)slot && mD == bm) kbest[j - (32u - (128u >> bm))] = (uint8_t)kD;
-				__builtin_amdgcn_wave_barrier();
-			}
-		}
+		if(__any((int)((v0 | v1) >= (1u << 23)))) return false;
+		EgCand CA, CB;
+		CA.order = A.order; CA.precision = A.precision; CA.ci = A.ci; CB.order = B.order; CB.precision = B.precision; CB.ci = B.ci;
+		eg_pair_search(R, smem, kbest, v0, v1, CA, CB, two, P.nfixed, hdr, sbps, lane);
 	}
 	}       // any
 
-	// ---- the decision: first minimum in the reference's evaluation order (verbatim -> constant | fixed -> LPC) ----------------
-	{
-		const uint32_t wasted = pr.wasted;
-		SubDecision *dec = decisions + fc;
-		uint32_t best_type = 1, best_order = 0, dpo = 0, best_precision = 0;
-		int32_t best_shift = 0, best_constant = 0, best_constant_hi = 0;
-		uint32_t best_bits = pr.verbatim_bits;
-		if(pr.flags & PREP_CONSTANT) {
-			const uint32_t bits = hdr + sbps;
-			if(bits < best_bits) { best_type = 0; best_constant = pr.constant; best_constant_hi = pr.constant_hi; best_bits = bits; }
-		}
-		if(best_ci != 0xffffffffu && best_est < best_bits) {
-			best_bits = best_est; dpo = best_po;
-			best_type = best_ci < P.nfixed ? 2 : 3;
-			best_order = rdlane(c_order, best_ci); best_precision = rdlane(c_prec, best_ci); best_shift = (int32_t)rdlane(c_shift, best_ci);
-		}
-		if(best_bits == 0xffffffffu) { best_type = 1; best_bits = hdr + n * sbps; }   // stream_encoder.c:4281
-		uint32_t rice2 = 0;
-		if(best_type >= 2) {
-			uint32_t big = 0;
-			if((uint32_t)lane < (1u << dpo)) {
-				const uint8_t kk = kbest[lane];
-				dec->params[lane] = kk;
-				if(kk >= 15) big = 1;
-			}
-			rice2 = __any((int)big) ? 1u : 0u;                         // stream_encoder.c:4786-4791
-		}
-		if(lane < MAX_ORDER) {
-			int32_t qv = 0;
-#pragma unroll
-			for(int j = 0; j < MAXORD; j++) { const int32_t t = (int32_t)rdlane((uint32_t)cq[j], best_ci & 63u); if(lane == j) qv = t; }
-			dec->q[lane] = best_type == 3 ? qv : 0;
-		}
-		if(lane == 0) {
-			dec->bits = best_bits;
-			dec->type = (uint8_t)best_type; dec->order = (uint8_t)best_order; dec->wasted = (uint8_t)wasted;
-			dec->po = (uint8_t)dpo; dec->rice2 = (uint8_t)rice2; dec->precision = (uint8_t)best_precision;
-			dec->shift = (int8_t)best_shift; dec->which = (uint8_t)pr.which;
-			dec->constant = best_constant; dec->constant_hi = best_constant_hi; dec->fmt = pr.fmt;
-			preps[fc].handled = EVG_HANDLED;
-		}
-	}
-#undef EG_LEAVE
+	eg_decide<MAXORD>(R, P, pr, n, kbest, c_order, c_prec, c_shift, cq, decisions + fc, preps + fc, lane);
+	return true;
+}
+
+template <int MAXORD>
+__global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
+                                                                          const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
+                                                                          const int *__restrict__ valid, SubDecision *__restrict__ decisions,
+                                                                          uint32_t *__restrict__ left, uint32_t *__restrict__ nleft)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = (int)threadIdx.x;
+	const uint32_t fc = blockIdx.x;
+	// what this kernel does not take -- the short last block first of all -- goes on the next kernel's list
+	const bool tail = tail_n != 0 && fc / P.ncand == nframes - 1;
+	if(tail || !evalg_body<MAXORD>(P, chan, jt, preps, cands, valid, decisions, fc, smem, lane)) { if(lane == 0) left[atomicAdd(nleft, 1u)] = fc; }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -617,7 +617,7 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 #define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft)
 	if(prep2_decides(P)) {
 		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
-		(void)hipMemsetAsync(B.nleft, 0, sizeof(uint32_t), s);
+		(void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
 		const size_t ldz = lds + P2_DIVTAB_BYTES + (size_t)waves * ((5 * (P.blocksize / CHUNK) + 8) * 4 + 64);
 		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
 		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
