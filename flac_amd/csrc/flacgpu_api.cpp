@@ -65,6 +65,20 @@ struct flacgpu_ctx {
 	flacgpu_verify_result last_verify;
 	JobTable h_jobtab[2];        // [0] nominal blocksize, [1] the short last block of the current batch
 	JobTable *d_jobtab;          // device copies of both
+	// the asynchronous entry (flacgpu_submit_batch_raw / flacgpu_collect): a ring of batches in flight
+	struct AsyncSlot {
+		uint8_t *d_raw, *d_out;                 // this batch's input bytes and finished frames on the device
+		size_t d_raw_bytes, d_out_bytes;
+		uint32_t *d_fb; uint64_t *d_total; uint32_t *d_err; flacgpu_verify_result *d_vres;
+		struct Host { uint64_t total; uint32_t err; uint32_t pad; flacgpu_verify_result vres; } *h;     // page-locked: where the small results land
+		uint32_t *h_fb;                         // page-locked [max_batch]
+		hipEvent_t ev_in, ev_done, ev_small, ev_pay;
+		uint8_t *out; size_t out_cap; uint32_t *frame_bytes; uint32_t nframes; int check_shift;
+		bool pay_by_kernel;                     // the frames were written to `out` by payload_copy_kernel (page-locked `out`)
+	} as[FLACGPU_ASYNC_SLOTS];
+	hipStream_t s_in, s_small, s_pay;           // input copies | lengths and totals back | payloads back
+	uint64_t sub_seq, col_seq;
+	bool async_ready;
 };
 
 namespace flacgpu {
@@ -155,6 +169,7 @@ extern "C" const char *flacgpu_strerror(int code)
 		case FLACGPU_ERR_LAUNCH: return "kernel launch or execution failed";
 		case FLACGPU_ERR_BAD_ARG: return "bad argument";
 		case FLACGPU_ERR_INPUT: return "raw sample data has non-zero bits below its declared shift";
+		case FLACGPU_ERR_BUSY: return "too many batches in flight: collect one first";
 		default: return "unknown error";
 	}
 }
@@ -188,6 +203,24 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->ab.cands) (void)hipFree(c->ab.cands);
 	if(c->ab.valid) (void)hipFree(c->ab.valid);
 	if(c->ab.chan) (void)hipFree(c->ab.chan);
+	for(int i = 0; i < FLACGPU_ASYNC_SLOTS; i++) {
+		flacgpu_ctx::AsyncSlot &a = c->as[i];
+		if(a.d_raw) (void)hipFree(a.d_raw);
+		if(a.d_out) (void)hipFree(a.d_out);
+		if(a.d_fb) (void)hipFree(a.d_fb);
+		if(a.d_total) (void)hipFree(a.d_total);
+		if(a.d_err) (void)hipFree(a.d_err);
+		if(a.d_vres) (void)hipFree(a.d_vres);
+		if(a.h) (void)hipHostFree(a.h);
+		if(a.h_fb) (void)hipHostFree(a.h_fb);
+		if(a.ev_in) (void)hipEventDestroy(a.ev_in);
+		if(a.ev_done) (void)hipEventDestroy(a.ev_done);
+		if(a.ev_small) (void)hipEventDestroy(a.ev_small);
+		if(a.ev_pay) (void)hipEventDestroy(a.ev_pay);
+	}
+	if(c->s_in) (void)hipStreamDestroy(c->s_in);
+	if(c->s_small) (void)hipStreamDestroy(c->s_small);
+	if(c->s_pay) (void)hipStreamDestroy(c->s_pay);
 	if(c->ab.left) (void)hipFree(c->ab.left);
 	if(c->ab.left2) (void)hipFree(c->ab.left2);
 	if(c->ab.nleft) (void)hipFree(c->ab.nleft);
@@ -662,6 +695,145 @@ extern "C" int64_t flacgpu_encode_batch_raw(flacgpu_ctx *c, const void *raw, con
 		if(herr) return FLACGPU_ERR_INPUT;
 	}
 	return encode_staged(c, nframes, first_frame_number, tail_n, tail_windows, out, out_cap, frame_bytes);
+}
+
+// ---- the asynchronous entry -------------------------------------------------------------------------------------------------
+// The frames of a batch, device -> page-locked host memory, by a small grid of its own stream: the byte total is read on the device
+// (no host round trip between the kernels and the read-back), and the copy engines stay with the input -- on this platform
+// input and output copies queued as hipMemcpyAsync took turns on one engine (profiles/r03_j_async_trace.txt: 2.4 + 1.45 ms per
+// 8192-frame batch, one after the other), whereas a copy kernel and a copy engine run side by side.
+__global__ __launch_bounds__(256) void payload_copy_kernel(const uint8_t *__restrict__ src, const uint64_t *__restrict__ d_total, uint8_t *__restrict__ dst, uint64_t cap)
+{
+	uint64_t total = *d_total;
+	if(total > cap) total = 0;                                          // (reported by flacgpu_collect; nothing is written)
+	const uint64_t nvec = total / 16;
+	const uint4 *s4 = (const uint4 *)src;
+	uint4 *d4 = (uint4 *)dst;
+	for(uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x * blockDim.x) d4[i] = s4[i];
+	if(blockIdx.x == 0) for(uint64_t i = nvec * 16 + threadIdx.x; i < total; i += blockDim.x) dst[i] = src[i];
+}
+static int ensure_verify(flacgpu_ctx *c);
+static int async_prepare(flacgpu_ctx *c)
+{
+	if(c->async_ready) return FLACGPU_OK;
+	const size_t B = c->cfg.max_batch_frames;
+	bool ok = hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking) == hipSuccess;
+	ok = ok && hipStreamCreateWithFlags(&c->s_small, hipStreamNonBlocking) == hipSuccess;
+	ok = ok && hipStreamCreateWithFlags(&c->s_pay, hipStreamNonBlocking) == hipSuccess;
+	for(int i = 0; i < FLACGPU_ASYNC_SLOTS && ok; i++) {
+		flacgpu_ctx::AsyncSlot &a = c->as[i];
+		ok = ok && hipMalloc(&a.d_fb, B * sizeof(uint32_t)) == hipSuccess;
+		ok = ok && hipMalloc(&a.d_total, sizeof(uint64_t)) == hipSuccess;
+		ok = ok && hipMalloc(&a.d_err, sizeof(uint32_t)) == hipSuccess;
+		ok = ok && hipMalloc(&a.d_vres, sizeof(flacgpu_verify_result)) == hipSuccess;
+		ok = ok && hipHostMalloc((void **)&a.h, sizeof *a.h, hipHostMallocDefault) == hipSuccess;
+		ok = ok && hipHostMalloc((void **)&a.h_fb, B * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&a.ev_in, hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&a.ev_done, hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&a.ev_small, hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&a.ev_pay, hipEventDisableTiming) == hipSuccess;
+	}
+	if(!ok) return FLACGPU_ERR_ALLOC;
+	c->async_ready = true;
+	return FLACGPU_OK;
+}
+extern "C" int flacgpu_in_flight(const flacgpu_ctx *c) { return c ? (int)(c->sub_seq - c->col_seq) : 0; }
+
+extern "C" int flacgpu_submit_batch_raw(flacgpu_ctx *c, const void *raw, const flacgpu_raw_format *fmt, uint32_t nframes,
+                                        uint64_t first_frame_number, uint32_t last_block_samples, const float *tail_windows,
+                                        uint8_t *out, size_t out_cap, uint32_t *frame_bytes)
+{
+	if(!c || !raw || !out || !frame_bytes || nframes == 0 || nframes > c->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
+	if(c->sub_seq - c->col_seq >= FLACGPU_ASYNC_SLOTS) return FLACGPU_ERR_BUSY;
+	StageParams S;
+	int r = make_stage_params(c, fmt, &S);
+	if(r != FLACGPU_OK) return r;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	r = async_prepare(c);
+	if(r != FLACGPU_OK) return r;
+	const DevParams &P = c->P;
+	const uint32_t tail_n = last_block_samples < P.blocksize ? last_block_samples : 0;
+	const size_t nsamp = (size_t)(nframes - 1) * P.blocksize + (tail_n ? tail_n : P.blocksize);
+	r = ensure_host_staging(c, nframes);                 // (the shared int32 staging buffer; the engine's own d_out is not used here)
+	if(r != FLACGPU_OK) return r;
+	if(c->verify_on) { r = ensure_verify(c); if(r != FLACGPU_OK) return r; }
+	flacgpu_ctx::AsyncSlot &a = c->as[c->sub_seq % FLACGPU_ASYNC_SLOTS];
+	const size_t raw_bytes = nsamp * P.channels * S.bytes, out_bytes = (size_t)nframes * P.slot_bytes;
+	if(a.d_raw_bytes < raw_bytes) {
+		if(a.d_raw) (void)hipFree(a.d_raw);
+		a.d_raw = nullptr; a.d_raw_bytes = 0;
+		if(hipMalloc(&a.d_raw, raw_bytes) != hipSuccess) return FLACGPU_ERR_ALLOC;
+		a.d_raw_bytes = raw_bytes;
+	}
+	if(a.d_out_bytes < out_bytes) {
+		if(a.d_out) (void)hipFree(a.d_out);
+		a.d_out = nullptr; a.d_out_bytes = 0;
+		if(hipMalloc(&a.d_out, out_bytes) != hipSuccess) return FLACGPU_ERR_ALLOC;
+		a.d_out_bytes = out_bytes;
+	}
+	hipStream_t s = c->stream;
+	// input: its own stream, so that it runs beside the kernels of the batches in front
+	if(hipMemcpyAsync(a.d_raw, raw, raw_bytes, hipMemcpyHostToDevice, c->s_in) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipEventRecord(a.ev_in, c->s_in) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	// kernels: the engine's stream, batch after batch
+	if(hipStreamWaitEvent(s, a.ev_in, 0) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipMemsetAsync(a.d_err, 0, sizeof(uint32_t), s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(launch_stage_raw(S, a.d_raw, (uint64_t)nsamp * P.channels, c->d_pcm, a.d_err, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	r = run_batch(c, c->d_pcm, nframes, first_frame_number, tail_n, tail_windows, a.d_out, a.d_out_bytes, a.d_fb, a.d_total, s);
+	if(r != FLACGPU_OK) return r;
+	if(c->verify_on) {
+		if(launch_verify(c->P, a.d_out, c->d_frame_bytes, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, c->d_vresult,
+		                 c->d_vhints, hints_for(c, a.d_out, nframes, first_frame_number), c->d_vfstat, c->ab.dbg, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(hipMemcpyAsync(a.d_vres, c->d_vresult, sizeof(flacgpu_verify_result), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	}
+	if(hipEventRecord(a.ev_done, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	// lengths, total, verdicts: back on a stream of their own (the payload follows from flacgpu_collect, once its size is known)
+	if(hipStreamWaitEvent(c->s_small, a.ev_done, 0) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipMemcpyAsync(a.h_fb, a.d_fb, nframes * sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipMemcpyAsync(&a.h->total, a.d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipMemcpyAsync(&a.h->err, a.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(c->verify_on && hipMemcpyAsync(&a.h->vres, a.d_vres, sizeof(flacgpu_verify_result), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipEventRecord(a.ev_small, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	// the frames themselves: by the copy kernel when `out` is page-locked (hipHostMalloc / hipHostRegister) and 16-byte aligned,
+	// otherwise by a copy from flacgpu_collect once the total is known on the host
+	a.pay_by_kernel = false;
+	{
+		void *dptr = nullptr;
+		static int off = -1;
+		if(off < 0) off = getenv("FLACGPU_NO_COPY_KERNEL") ? 1 : 0;
+		if(!off && ((uintptr_t)out & 15u) == 0 && hipHostGetDevicePointer(&dptr, out, 0) == hipSuccess && dptr) {
+			if(hipStreamWaitEvent(c->s_pay, a.ev_done, 0) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			hipLaunchKernelGGL(payload_copy_kernel, dim3(256), dim3(256), 0, c->s_pay, a.d_out, a.d_total, (uint8_t *)dptr, (uint64_t)out_cap);
+			if(hipGetLastError() != hipSuccess || hipEventRecord(a.ev_pay, c->s_pay) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			a.pay_by_kernel = true;
+		}
+		else (void)hipGetLastError();
+	}
+	a.out = out; a.out_cap = out_cap; a.frame_bytes = frame_bytes; a.nframes = nframes; a.check_shift = S.shift != 0;
+	c->sub_seq++;
+	return FLACGPU_OK;
+}
+
+extern "C" int64_t flacgpu_collect(flacgpu_ctx *c)
+{
+	if(!c || c->sub_seq == c->col_seq) return FLACGPU_ERR_BAD_ARG;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	flacgpu_ctx::AsyncSlot &a = c->as[c->col_seq % FLACGPU_ASYNC_SLOTS];
+	c->col_seq++;                                         // (whatever happens below, this batch is no longer in flight)
+	if(hipEventSynchronize(a.ev_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	memset(&c->last_verify, 0, sizeof c->last_verify);
+	if(c->verify_on) c->last_verify = a.h->vres;
+	if(a.check_shift && a.h->err) return FLACGPU_ERR_INPUT;
+	memcpy(a.frame_bytes, a.h_fb, a.nframes * sizeof(uint32_t));
+	for(uint32_t i = 0; i < a.nframes; i++) if(a.h_fb[i] == 0xffffffffu) return FLACGPU_ERR_LAUNCH;
+	const uint64_t total = a.h->total;
+	if(a.pay_by_kernel) { if(hipEventSynchronize(a.ev_pay) != hipSuccess) return FLACGPU_ERR_LAUNCH; }
+	if(total > a.out_cap) return FLACGPU_ERR_OUTPUT_TOO_SMALL;
+	if(!a.pay_by_kernel) {
+		if(hipMemcpyAsync(a.out, a.d_out, total, hipMemcpyDeviceToHost, c->s_pay) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(hipStreamSynchronize(c->s_pay) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	}
+	return (int64_t)total;
 }
 
 // buffers of the self check, allocated on first use

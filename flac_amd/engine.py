@@ -151,6 +151,13 @@ def load_engine():
         lib.flacgpu_set_subbatches.argtypes = [C.c_void_p, C.c_uint32]
         lib.flacgpu_strerror.restype = C.c_char_p
         lib.flacgpu_strerror.argtypes = [C.c_int]
+        lib.flacgpu_submit_batch_raw.restype = C.c_int
+        lib.flacgpu_submit_batch_raw.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RawFormat), C.c_uint32, C.c_uint64, C.c_uint32,
+                                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.flacgpu_collect.restype = C.c_int64
+        lib.flacgpu_collect.argtypes = [C.c_void_p]
+        lib.flacgpu_in_flight.restype = C.c_int
+        lib.flacgpu_in_flight.argtypes = [C.c_void_p]
         lib.flacgpu_device_count.restype = C.c_int
         _engine = lib
     return _engine

@@ -41,7 +41,8 @@ enum {
 	FLACGPU_ERR_OUTPUT_TOO_SMALL = -4,
 	FLACGPU_ERR_LAUNCH = -5,        /* -> FLAC__STREAM_ENCODER_FRAMING_ERROR */
 	FLACGPU_ERR_BAD_ARG = -6,
-	FLACGPU_ERR_INPUT = -7          /* raw input violates its declared format (non-zero bits below `shift`) */
+	FLACGPU_ERR_INPUT = -7,         /* raw input violates its declared format (non-zero bits below `shift`) */
+	FLACGPU_ERR_BUSY = -8           /* flacgpu_submit_batch_raw: FLACGPU_ASYNC_SLOTS batches are in flight -- collect one first */
 };
 
 /* apodization kinds as the frame engine sees them (stream_encoder.c:4318-4392): every window
@@ -201,6 +202,23 @@ void flacgpu_free_pinned(void *p);
  * layer fills ordinary memory while the HIP runtime is still starting on another thread and registers it afterwards. */
 int flacgpu_host_register(void *p, size_t bytes);
 void flacgpu_host_unregister(void *p);
+/* ---- the asynchronous entry: what the task ring of the reference's frame-parallel encoder is for (stream_encoder.c:1134-1238,
+ * 3530-3574: 2*threads+2 frames in flight, drained in order) -- here per BATCH.  flacgpu_submit_batch_raw() enqueues everything a
+ * batch needs and returns at once: the raw bytes go to the device on a copy stream of their own, the kernels run on the engine's
+ * stream behind them, the frame lengths and the byte total come back on a third.  Up to FLACGPU_ASYNC_SLOTS batches may be in
+ * flight (each has its own device buffers for input and output; the kernels' scratch is shared: they run one batch after the
+ * other anyway), so the copy of batch k+1 and the read-back of batch k-1 run beside the kernels of batch k.
+ * flacgpu_collect() waits for the OLDEST batch in flight, copies its frames to the `out` given at submission and returns their
+ * byte total (or the batch's error).  `raw`, `out` and `frame_bytes` must stay valid until the batch is collected; page-locked
+ * memory (flacgpu_alloc_pinned / flacgpu_host_register) makes the copies truly asynchronous.  Arguments as for
+ * flacgpu_encode_batch_raw.  Submissions and collections of one engine must come from one thread at a time. */
+#define FLACGPU_ASYNC_SLOTS 4
+int flacgpu_submit_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgpu_raw_format *fmt, uint32_t nframes,
+                             uint64_t first_frame_number, uint32_t last_block_samples, const float *tail_windows,
+                             uint8_t *out, size_t out_cap, uint32_t *frame_bytes);     /* 0, or a negative FLACGPU_ERR_* (nothing enqueued) */
+int64_t flacgpu_collect(flacgpu_ctx *ctx);         /* bytes of the oldest batch, or a negative FLACGPU_ERR_* (FLACGPU_ERR_BAD_ARG: none in flight) */
+int flacgpu_in_flight(const flacgpu_ctx *ctx);     /* batches submitted and not yet collected */
+
 /* The configuration checks of flacgpu_create without a device: FLACGPU_OK, or the FLACGPU_ERR_UNSUPPORTED / _BAD_ARG that
  * flacgpu_create would return for this configuration.  Touches no HIP state. */
 int flacgpu_config_check(const flacgpu_config *cfg);

@@ -48,6 +48,34 @@ for name, call in (("int32 host block (flacgpu_encode_batch)", lambda: lib.flacg
     dt = (time.perf_counter() - t0) / reps
     print("%-48s %7.2f ms per %d frames  %8.1f M samples/s (PCIe inclusive, D2H of the frames included)" % (name, dt * 1e3, NF, NF * N / dt / 1e6))
 
+# The asynchronous entry: ONE engine, ONE host thread, up to FLACGPU_ASYNC_SLOTS batches in flight -- the input copy of batch k+1
+# and the read-back of batch k-1 run beside the kernels of batch k (flacgpu_submit_batch_raw / flacgpu_collect)
+DEPTH = 4
+srcs = [p16] + [pinned(raw) for _ in range(DEPTH - 1)]
+outs = [out_p] + [lib.flacgpu_alloc_pinned(cap) for _ in range(DEPTH - 1)]
+fbs = [np.empty(NF, dtype=np.uint32) for _ in range(DEPTH)]
+for depth in (1, 2, 3, 4):
+    def run(nb):
+        sub = col = 0
+        tot = 0
+        while col < nb:
+            while sub < nb and sub - col < depth:
+                k = sub % DEPTH
+                r = lib.flacgpu_submit_batch_raw(eng.ctx, srcs[k], C.byref(fmt), NF, sub * NF, 0, None, outs[k], cap, fbs[k].ctypes.data)
+                assert r == 0, r
+                sub += 1
+            r = lib.flacgpu_collect(eng.ctx)
+            assert r > 0, r
+            tot += r
+            col += 1
+        return tot
+    run(2)
+    reps = 12
+    t0 = time.perf_counter()
+    run(reps)
+    dt = (time.perf_counter() - t0) / reps
+    print("%-48s %7.2f ms per %d frames  %8.1f M samples/s (one engine, one host thread)" % ("submit/collect, %d batch(es) in flight" % depth, dt * 1e3, NF, NF * N / dt / 1e6))
+
 # Two engines, two host threads: each call is synchronous on its own HIP stream (H2D copy -> kernels -> D2H copy), so two
 # callers overlap one another's copies and kernels -- the pipelined use of the ABI (a corpus encoder keeps two batches in flight).
 import threading  # noqa: E402

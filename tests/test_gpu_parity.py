@@ -571,3 +571,57 @@ def test_parity_with_poisoned_scratch_memory(monkeypatch):
     test_many_apodizations_and_deep_subdivision()
     for seed in range(6):
         test_random_configurations(seed, None)
+
+
+def test_asynchronous_entry_matches_the_synchronous_one():
+    """flacgpu_submit_batch_raw / flacgpu_collect: several batches in flight (their own device buffers, the input copies and the
+    read-backs beside the kernels), collected in order -- the same bytes as one synchronous call per batch, a short last block and
+    device verification included; a fifth submission is refused, a collect with nothing in flight as well"""
+    import flac_amd
+    from rawfmt import to_raw
+    N, NF = 4096, 24
+    pcm = signals.music(N * NF * 5 + 777, 2, 16, seed=21)
+    eng = _engine(2, 16, 44100, 8, max_batch=NF)
+    try:
+        eng.set_verify(True)
+        lib = eng.lib
+        fmt = flac_amd.raw_format(16)
+        cap = eng.max_output_bytes(NF)
+        batches = []
+        pos, first = 0, 0
+        while pos < pcm.shape[0]:
+            part = pcm[pos:pos + N * NF]
+            nfr = (part.shape[0] + N - 1) // N
+            tail = part.shape[0] - (nfr - 1) * N
+            batches.append((np.ascontiguousarray(to_raw(part, 16)), nfr, first, 0 if tail == N else tail))
+            pos += part.shape[0]
+            first += nfr
+        assert len(batches) == 6
+        want = []
+        for raw, nfr, first, tail in batches:
+            data, fb = eng.encode_raw(raw, fmt, first_frame_number=first)
+            want.append((data, fb.tolist()))
+        assert lib.flacgpu_collect(eng.ctx) == -6                       # nothing in flight: FLACGPU_ERR_BAD_ARG
+        outs = [np.zeros(cap, dtype=np.uint8) for _ in batches]
+        fbs = [np.zeros(nfr, dtype=np.uint32) for _, nfr, _, _ in batches]
+        tws = [eng._tail_windows(tail) if tail else None for _, _, _, tail in batches]
+        sub = col = 0
+        while col < len(batches):
+            while sub < len(batches) and sub - col < 4:
+                raw, nfr, first, tail = batches[sub]
+                tw = tws[sub]
+                r = lib.flacgpu_submit_batch_raw(eng.ctx, raw.ctypes.data, C.byref(fmt), nfr, first, tail or N, tw.ctypes.data if tw is not None else None,
+                                                 outs[sub].ctypes.data, cap, fbs[sub].ctypes.data)
+                assert r == 0, r
+                sub += 1
+            if sub - col == 4 and sub < len(batches):
+                raw, nfr, first, tail = batches[sub]
+                assert lib.flacgpu_submit_batch_raw(eng.ctx, raw.ctypes.data, C.byref(fmt), nfr, first, tail or N, None, outs[sub].ctypes.data, cap, fbs[sub].ctypes.data) == -8   # BUSY
+            assert lib.flacgpu_in_flight(eng.ctx) == sub - col
+            total = lib.flacgpu_collect(eng.ctx)
+            assert total == len(want[col][0]), (col, total)
+            assert outs[col][:total].tobytes() == want[col][0] and fbs[col].tolist() == want[col][1]
+            assert eng.last_verify_result().status == 0
+            col += 1
+    finally:
+        eng.close()
