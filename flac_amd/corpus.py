@@ -110,8 +110,121 @@ def encode_shard(eng, base_dev, lo, hi, batch_frames, dev, out, fb_all, enc_stre
     return off
 
 
+def md5_many(buffers):
+    """MD5 of each buffer (bytes-like, contiguous), eight chains at a time on one thread (flac_amd/csrc/host/md5.c: AVX2, a chain per
+    32-bit lane): a corpus of many tracks needs one digest per track, and one chain alone is serial"""
+    import ctypes as C
+    import flac_amd
+    lib = flac_amd.engine.load_host()
+    lib.flacgpu_host_md5_many.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_void_p]
+    lib.flacgpu_host_md5_many.restype = None
+    n = len(buffers)
+    views = [np.frombuffer(b, dtype=np.uint8) for b in buffers]
+    ptrs = (C.c_void_p * n)(*[v.ctypes.data if v.size else 0 for v in views])
+    lens = (C.c_size_t * n)(*[v.size for v in views])
+    out = np.zeros((n, 16), dtype=np.uint8)
+    lib.flacgpu_host_md5_many(ptrs, lens, n, out.ctypes.data)
+    return [out[i].tobytes() for i in range(n)]
+
+
+def track_ranges(F, ntracks):
+    """frames [lo, hi) of each track: equal shares of the corpus, earlier tracks take the remainder"""
+    base, rem = divmod(F, ntracks)
+    out, lo = [], 0
+    for t in range(ntracks):
+        hi = lo + base + (1 if t < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_stream, want_md5=True, md5_threads=1):
+    """The corpus as `ntracks` separate streams (BASELINE config 5 as an album shelf rather than one file): every track's frames are
+    numbered from 0 and get their own STREAMINFO (total samples, min/max frame size, MD5 of the track's samples).  One engine call
+    per track (frame numbers of a call are consecutive).  Returns (list of (header, frames uint8 tensor view), timings)."""
+    import torch
+    import flac_amd
+    fmt = flac_amd.raw_format(16)
+    ranges = track_ranges(F, ntracks)
+    tail = total_samples - (F - 1) * BLOCK
+    tail = 0 if tail == BLOCK else tail
+    maxf = max(hi - lo for lo, hi in ranges)
+    raw = torch.empty((maxf * BLOCK, CH), dtype=torch.int16, device=dev)
+    pcm = torch.empty((maxf * BLOCK, CH), dtype=torch.int32, device=dev)
+    cap = F * 3 * BLOCK * CH // 2 + eng.max_output_bytes(maxf)
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    fb_all = torch.zeros(F, dtype=torch.int32, device=dev)
+    totals = torch.zeros(ntracks, dtype=torch.int64, device=dev)
+    offs = [0]
+    t0 = time.perf_counter()
+    with torch.cuda.stream(enc_stream):
+        for t, (lo, hi) in enumerate(ranges):
+            nf = hi - lo
+            if nf == 0:
+                offs.append(offs[-1])
+                continue
+            device_frames(base_dev, lo, hi, raw)
+            short = tail if (tail and hi == F) else 0
+            eng.stage_raw_device(raw.data_ptr(), fmt, nf * BLOCK - (BLOCK - short if short else 0), pcm.data_ptr(), None, enc_stream.cuda_stream)
+            eng.encode_device(pcm.data_ptr(), nf, out.data_ptr() + offs[-1], out.numel() - offs[-1], fb_all.data_ptr() + 4 * lo, totals.data_ptr() + 8 * t,
+                              first_frame_number=0, tail=short, stream=enc_stream.cuda_stream)
+            offs.append(offs[-1] + int(totals[t].item()))
+    enc_stream.synchronize()
+    t_enc = time.perf_counter() - t0
+    # the digests: the tracks' sample bytes on the host, eight tracks per pass
+    t1 = time.perf_counter()
+    digests = [bytes(16)] * ntracks
+    if want_md5:
+        cache = {}
+        bufs = []
+        for lo, hi in ranges:
+            parts = []
+            f = lo
+            while f < hi:
+                rep, b0 = divmod(f, BASE_FRAMES)
+                nb = min(BASE_FRAMES - b0, hi - f)
+                key = rep_params(rep)
+                if key not in cache:
+                    cache[key] = host_frames(base, rep * BASE_FRAMES, (rep + 1) * BASE_FRAMES)
+                nsamp = min(nb * BLOCK, total_samples - f * BLOCK)
+                parts.append(cache[key][b0 * BLOCK:b0 * BLOCK + nsamp])
+                f += nb
+            bufs.append(np.ascontiguousarray(np.concatenate(parts, axis=0)) if parts else np.zeros((0, CH), np.int16))
+        t_prep = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        if md5_threads > 1:
+            # (several hashing threads, each eight chains wide: ctypes releases the GIL inside the call)
+            chunks = [list(range(i, ntracks, md5_threads)) for i in range(md5_threads)]
+            res = {}
+
+            def work(idx):
+                for i, d in zip(idx, md5_many([bufs[i] for i in idx])):
+                    res[i] = d
+            ths = [threading.Thread(target=work, args=(c,)) for c in chunks if c]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            digests = [res[i] for i in range(ntracks)]
+        else:
+            digests = md5_many(bufs)
+        t_md5 = time.perf_counter() - t2
+    else:
+        t_prep = t_md5 = 0.0
+    fbs = fb_all.cpu().numpy().astype(np.uint32)
+    streams = []
+    for t, (lo, hi) in enumerate(ranges):
+        nsamp = min(hi * BLOCK, total_samples) - lo * BLOCK if hi > lo else 0
+        f = fbs[lo:hi]
+        header = stream_header(nsamp, int(f.min()) if f.size else 0, int(f.max()) if f.size else 0, digests[t])
+        streams.append((header, out[offs[t]:offs[t + 1]], f))
+    return streams, {"encode_seconds": t_enc, "md5_prepare_seconds": t_prep, "md5_seconds": t_md5}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--tracks", type=int, default=0, help="encode the corpus as this many separate streams (one file per track, each with its own STREAMINFO and MD5) on one GPU")
+    ap.add_argument("--md5-threads", type=int, default=1, help="--tracks: host threads hashing the tracks (each eight chains wide)")
     ap.add_argument("--hours", type=float, default=10.0)
     ap.add_argument("--samples", type=int, default=0, help="corpus length in inter-channel samples (overrides --hours); a last short block is encoded as such")
     ap.add_argument("--batch-frames", type=int, default=16384)
@@ -173,6 +286,46 @@ def main(argv=None):
     if rank == 0 and not args.no_md5:
         th = threading.Thread(target=md5_thread)
         th.start()
+
+    if args.tracks:
+        if multi:
+            raise SystemExit("--tracks runs on one GPU (tracks shard like frames do; not wired to the process group)")
+        settings = flac_amd.make_settings(CH, BPS, RATE, args.level)
+        ranges = track_ranges(F, args.tracks)
+        eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=max(hi - lo for lo, hi in ranges))
+        enc_stream = torch.cuda.Stream()
+        encode_tracks(eng, base, base_dev, min(F, 2 * args.tracks), min(total_samples, 2 * args.tracks * BLOCK), args.tracks, dev, enc_stream, want_md5=False)       # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        streams, tm = encode_tracks(eng, base, base_dev, F, total_samples, args.tracks, dev, enc_stream, want_md5=not args.no_md5, md5_threads=args.md5_threads)
+        t_job = time.perf_counter() - t0
+        import ctypes as C
+        host = flac_amd.engine.load_host()
+        host.flacgpu_host_check_frame_crcs.restype = C.c_int64
+        host.flacgpu_host_check_frame_crcs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        bad_tracks, nbytes, t_write = 0, 0, 0.0
+        for t, (header, frames, fbs) in enumerate(streams):
+            data = frames.cpu().numpy()
+            nbytes += data.size + len(header)
+            if fbs.size and host.flacgpu_host_check_frame_crcs(data.ctypes.data, np.ascontiguousarray(fbs).ctypes.data, fbs.size, 4) != -1:
+                bad_tracks += 1
+            if args.out:
+                tw = time.perf_counter()
+                with open("%s.%04d.flac" % (args.out, t), "wb") as f:
+                    f.write(header)
+                    f.write(memoryview(data))
+                t_write += time.perf_counter() - tw
+        line = {"job": "flac -%d batch encode of a %.2f h synthetic 44.1k/16-bit stereo corpus into %d streams (one per track)" % (args.level, total_samples / RATE / 3600, args.tracks),
+                "n_gpus": 1, "tracks": args.tracks, "frames": F, "samples": total_samples, "bytes": nbytes,
+                "encode_seconds": round(tm["encode_seconds"], 4), "Msamples_per_s_encode": round(total_samples / tm["encode_seconds"] / 1e6, 1),
+                "md5": "one digest per track, eight chains per pass (AVX2), %d host thread(s)" % args.md5_threads if not args.no_md5 else None,
+                "md5_seconds": round(tm["md5_seconds"], 3), "md5_prepare_seconds": round(tm["md5_prepare_seconds"], 3),
+                "md5_Msamples_per_s": round(total_samples / tm["md5_seconds"] / 1e6, 1) if tm["md5_seconds"] else None,
+                "job_seconds": round(t_job, 3), "tracks_with_a_bad_crc16": bad_tracks, "write_seconds": round(t_write, 3) if args.out else None,
+                "first_track_md5": streams[0][0][8 + 18:8 + 34].hex()}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        eng.close()
+        return line
 
     settings = flac_amd.make_settings(CH, BPS, RATE, args.level)
     bf = min(args.batch_frames, max(nloc, 1))

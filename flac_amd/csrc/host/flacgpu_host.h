@@ -71,6 +71,10 @@ typedef struct { uint32_t state[4]; uint64_t nbytes; uint8_t block[64]; } flacgp
 void flacgpu_host_md5_init(flacgpu_host_md5 *m);
 void flacgpu_host_md5_update(flacgpu_host_md5 *m, const void *data, size_t len);
 void flacgpu_host_md5_final(flacgpu_host_md5 *m, uint8_t digest[16]);
+/* eight chains at once (AVX2, one per 32-bit lane): a corpus is many streams, each with its own digest */
+int flacgpu_host_md5_x8_available(void);
+void flacgpu_host_md5_x8_blocks(flacgpu_host_md5 *const m[8], const void *const data[8], size_t nblocks);    /* every context at a block boundary */
+void flacgpu_host_md5_many(const void *const *data, const size_t *len, uint32_t n, uint8_t (*digest)[16]);
 /* feeds `samples` inter-channel samples of interleaved int32 PCM as bytes_per_sample-byte little-endian */
 void flacgpu_host_md5_pcm(flacgpu_host_md5 *m, const int32_t *interleaved, uint32_t channels, size_t samples, uint32_t bytes_per_sample);
 

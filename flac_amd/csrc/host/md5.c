@@ -89,3 +89,113 @@ void flacgpu_host_md5_pcm(flacgpu_host_md5 *m, const int32_t *x, uint32_t channe
 	}
 	if(fill) flacgpu_host_md5_update(m, buf, fill);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Eight chains at once.  One MD5 chain is serial (64 dependent steps per 64 bytes: ~1 GB/s on this host whatever one does), but a
+ * corpus is many streams, each with its own STREAMINFO digest, and eight independent chains fit the eight 32-bit lanes of an AVX2
+ * register: the same 64 steps, each on eight states.  flacgpu_host_md5_x8_blocks() advances eight contexts by the same number of
+ * whole blocks; flacgpu_host_md5_many() hashes any number of buffers, eight at a time over their common length, the rest of each
+ * on the single-chain routine.  Same digests as FLAC__MD5Final (tests/test_kat.py, tests/test_md5_multi.py).
+ * ---------------------------------------------------------------------------------------------------------------------- */
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+#define MD5_HAVE_X8 1
+#define VROL(v, s) _mm256_or_si256(_mm256_slli_epi32((v), (s)), _mm256_srli_epi32((v), 32 - (s)))
+#define VADD(x, y) _mm256_add_epi32((x), (y))
+#define VF1(x, y, z) _mm256_xor_si256((z), _mm256_and_si256((x), _mm256_xor_si256((y), (z))))
+#define VF2(x, y, z) _mm256_xor_si256((y), _mm256_and_si256((z), _mm256_xor_si256((x), (y))))
+#define VF3(x, y, z) _mm256_xor_si256((x), _mm256_xor_si256((y), (z)))
+#define VF4(x, y, z) _mm256_xor_si256((y), _mm256_or_si256((x), _mm256_xor_si256((z), ones)))
+#define VSTEP(f, a, b, c, d, w, k, s) do { (a) = VADD(VADD((a), VADD((w), _mm256_set1_epi32((int)(k)))), f((b), (c), (d))); (a) = VADD(VROL((a), (s)), (b)); } while(0)
+
+__attribute__((target("avx2")))
+static void transpose8(__m256i r[8])
+{
+	const __m256i t0 = _mm256_unpacklo_epi32(r[0], r[1]), t1 = _mm256_unpackhi_epi32(r[0], r[1]), t2 = _mm256_unpacklo_epi32(r[2], r[3]), t3 = _mm256_unpackhi_epi32(r[2], r[3]);
+	const __m256i t4 = _mm256_unpacklo_epi32(r[4], r[5]), t5 = _mm256_unpackhi_epi32(r[4], r[5]), t6 = _mm256_unpacklo_epi32(r[6], r[7]), t7 = _mm256_unpackhi_epi32(r[6], r[7]);
+	const __m256i u0 = _mm256_unpacklo_epi64(t0, t2), u1 = _mm256_unpackhi_epi64(t0, t2), u2 = _mm256_unpacklo_epi64(t1, t3), u3 = _mm256_unpackhi_epi64(t1, t3);
+	const __m256i u4 = _mm256_unpacklo_epi64(t4, t6), u5 = _mm256_unpackhi_epi64(t4, t6), u6 = _mm256_unpacklo_epi64(t5, t7), u7 = _mm256_unpackhi_epi64(t5, t7);
+	r[0] = _mm256_permute2x128_si256(u0, u4, 0x20); r[1] = _mm256_permute2x128_si256(u1, u5, 0x20); r[2] = _mm256_permute2x128_si256(u2, u6, 0x20); r[3] = _mm256_permute2x128_si256(u3, u7, 0x20);
+	r[4] = _mm256_permute2x128_si256(u0, u4, 0x31); r[5] = _mm256_permute2x128_si256(u1, u5, 0x31); r[6] = _mm256_permute2x128_si256(u2, u6, 0x31); r[7] = _mm256_permute2x128_si256(u3, u7, 0x31);
+}
+__attribute__((target("avx2")))
+static void md5_x8_blocks(uint32_t *st[8], const uint8_t *const p[8], size_t nblocks)
+{
+	const __m256i ones = _mm256_set1_epi32(-1);
+	__m256i S[8];
+	for(int k = 0; k < 8; k++) S[k] = _mm256_castsi128_si256(_mm_loadu_si128((const __m128i *)st[k]));
+	transpose8(S);                                   /* S[0..3] = a, b, c, d of the eight chains */
+	__m256i A = S[0], B = S[1], C = S[2], D = S[3];
+	for(size_t blk = 0; blk < nblocks; blk++) {
+		__m256i w[16];
+		for(int k = 0; k < 8; k++) { w[k] = _mm256_loadu_si256((const __m256i *)(p[k] + 64 * blk)); w[8 + k] = _mm256_loadu_si256((const __m256i *)(p[k] + 64 * blk + 32)); }
+		transpose8(w); transpose8(w + 8);             /* w[i] = word i of the eight blocks (x86 is little endian, as MD5 is) */
+		__m256i a = A, b = B, c = C, d = D;
+		VSTEP(VF1, a, b, c, d, w[0], 0xd76aa478, 7);   VSTEP(VF1, d, a, b, c, w[1], 0xe8c7b756, 12);  VSTEP(VF1, c, d, a, b, w[2], 0x242070db, 17);  VSTEP(VF1, b, c, d, a, w[3], 0xc1bdceee, 22);
+		VSTEP(VF1, a, b, c, d, w[4], 0xf57c0faf, 7);   VSTEP(VF1, d, a, b, c, w[5], 0x4787c62a, 12);  VSTEP(VF1, c, d, a, b, w[6], 0xa8304613, 17);  VSTEP(VF1, b, c, d, a, w[7], 0xfd469501, 22);
+		VSTEP(VF1, a, b, c, d, w[8], 0x698098d8, 7);   VSTEP(VF1, d, a, b, c, w[9], 0x8b44f7af, 12);  VSTEP(VF1, c, d, a, b, w[10], 0xffff5bb1, 17); VSTEP(VF1, b, c, d, a, w[11], 0x895cd7be, 22);
+		VSTEP(VF1, a, b, c, d, w[12], 0x6b901122, 7);  VSTEP(VF1, d, a, b, c, w[13], 0xfd987193, 12); VSTEP(VF1, c, d, a, b, w[14], 0xa679438e, 17); VSTEP(VF1, b, c, d, a, w[15], 0x49b40821, 22);
+		VSTEP(VF2, a, b, c, d, w[1], 0xf61e2562, 5);   VSTEP(VF2, d, a, b, c, w[6], 0xc040b340, 9);   VSTEP(VF2, c, d, a, b, w[11], 0x265e5a51, 14); VSTEP(VF2, b, c, d, a, w[0], 0xe9b6c7aa, 20);
+		VSTEP(VF2, a, b, c, d, w[5], 0xd62f105d, 5);   VSTEP(VF2, d, a, b, c, w[10], 0x02441453, 9);  VSTEP(VF2, c, d, a, b, w[15], 0xd8a1e681, 14); VSTEP(VF2, b, c, d, a, w[4], 0xe7d3fbc8, 20);
+		VSTEP(VF2, a, b, c, d, w[9], 0x21e1cde6, 5);   VSTEP(VF2, d, a, b, c, w[14], 0xc33707d6, 9);  VSTEP(VF2, c, d, a, b, w[3], 0xf4d50d87, 14);  VSTEP(VF2, b, c, d, a, w[8], 0x455a14ed, 20);
+		VSTEP(VF2, a, b, c, d, w[13], 0xa9e3e905, 5);  VSTEP(VF2, d, a, b, c, w[2], 0xfcefa3f8, 9);   VSTEP(VF2, c, d, a, b, w[7], 0x676f02d9, 14);  VSTEP(VF2, b, c, d, a, w[12], 0x8d2a4c8a, 20);
+		VSTEP(VF3, a, b, c, d, w[5], 0xfffa3942, 4);   VSTEP(VF3, d, a, b, c, w[8], 0x8771f681, 11);  VSTEP(VF3, c, d, a, b, w[11], 0x6d9d6122, 16); VSTEP(VF3, b, c, d, a, w[14], 0xfde5380c, 23);
+		VSTEP(VF3, a, b, c, d, w[1], 0xa4beea44, 4);   VSTEP(VF3, d, a, b, c, w[4], 0x4bdecfa9, 11);  VSTEP(VF3, c, d, a, b, w[7], 0xf6bb4b60, 16);  VSTEP(VF3, b, c, d, a, w[10], 0xbebfbc70, 23);
+		VSTEP(VF3, a, b, c, d, w[13], 0x289b7ec6, 4);  VSTEP(VF3, d, a, b, c, w[0], 0xeaa127fa, 11);  VSTEP(VF3, c, d, a, b, w[3], 0xd4ef3085, 16);  VSTEP(VF3, b, c, d, a, w[6], 0x04881d05, 23);
+		VSTEP(VF3, a, b, c, d, w[9], 0xd9d4d039, 4);   VSTEP(VF3, d, a, b, c, w[12], 0xe6db99e5, 11); VSTEP(VF3, c, d, a, b, w[15], 0x1fa27cf8, 16); VSTEP(VF3, b, c, d, a, w[2], 0xc4ac5665, 23);
+		VSTEP(VF4, a, b, c, d, w[0], 0xf4292244, 6);   VSTEP(VF4, d, a, b, c, w[7], 0x432aff97, 10);  VSTEP(VF4, c, d, a, b, w[14], 0xab9423a7, 15); VSTEP(VF4, b, c, d, a, w[5], 0xfc93a039, 21);
+		VSTEP(VF4, a, b, c, d, w[12], 0x655b59c3, 6);  VSTEP(VF4, d, a, b, c, w[3], 0x8f0ccc92, 10);  VSTEP(VF4, c, d, a, b, w[10], 0xffeff47d, 15); VSTEP(VF4, b, c, d, a, w[1], 0x85845dd1, 21);
+		VSTEP(VF4, a, b, c, d, w[8], 0x6fa87e4f, 6);   VSTEP(VF4, d, a, b, c, w[15], 0xfe2ce6e0, 10); VSTEP(VF4, c, d, a, b, w[6], 0xa3014314, 15);  VSTEP(VF4, b, c, d, a, w[13], 0x4e0811a1, 21);
+		VSTEP(VF4, a, b, c, d, w[4], 0xf7537e82, 6);   VSTEP(VF4, d, a, b, c, w[11], 0xbd3af235, 10); VSTEP(VF4, c, d, a, b, w[2], 0x2ad7d2bb, 15);  VSTEP(VF4, b, c, d, a, w[9], 0xeb86d391, 21);
+		A = VADD(A, a); B = VADD(B, b); C = VADD(C, c); D = VADD(D, d);
+	}
+	S[0] = A; S[1] = B; S[2] = C; S[3] = D;
+	S[4] = S[5] = S[6] = S[7] = _mm256_setzero_si256();
+	transpose8(S);
+	for(int k = 0; k < 8; k++) _mm_storeu_si128((__m128i *)st[k], _mm256_castsi256_si128(S[k]));
+}
+#endif
+
+int flacgpu_host_md5_x8_available(void)
+{
+#ifdef MD5_HAVE_X8
+	return __builtin_cpu_supports("avx2") ? 1 : 0;
+#else
+	return 0;
+#endif
+}
+/* advance eight contexts, each at a block boundary (nbytes % 64 == 0), by nblocks whole blocks of their data */
+void flacgpu_host_md5_x8_blocks(flacgpu_host_md5 *const m[8], const void *const data[8], size_t nblocks)
+{
+	if(nblocks == 0) return;
+#ifdef MD5_HAVE_X8
+	int aligned = 1;
+	for(int k = 0; k < 8; k++) if(m[k]->nbytes & 63) aligned = 0;
+	if(aligned && flacgpu_host_md5_x8_available()) {
+		uint32_t *st[8];
+		const uint8_t *p[8];
+		for(int k = 0; k < 8; k++) { st[k] = m[k]->state; p[k] = (const uint8_t *)data[k]; }
+		md5_x8_blocks(st, p, nblocks);
+		for(int k = 0; k < 8; k++) m[k]->nbytes += 64 * (uint64_t)nblocks;
+		return;
+	}
+#endif
+	for(int k = 0; k < 8; k++) flacgpu_host_md5_update(m[k], data[k], 64 * nblocks);
+}
+/* MD5 of n buffers: digest[i] = MD5(data[i][0 .. len[i])) */
+void flacgpu_host_md5_many(const void *const *data, const size_t *len, uint32_t n, uint8_t (*digest)[16])
+{
+	uint32_t i = 0;
+	for(; i + 8 <= n; i += 8) {
+		flacgpu_host_md5 ctx[8], *mp[8];
+		const void *dp[8];
+		size_t common = (size_t)-1;
+		for(int k = 0; k < 8; k++) { flacgpu_host_md5_init(&ctx[k]); mp[k] = &ctx[k]; dp[k] = data[i + k]; if(len[i + k] / 64 < common) common = len[i + k] / 64; }
+		flacgpu_host_md5_x8_blocks(mp, dp, common);
+		for(int k = 0; k < 8; k++) {
+			flacgpu_host_md5_update(&ctx[k], (const uint8_t *)data[i + k] + 64 * common, len[i + k] - 64 * common);
+			flacgpu_host_md5_final(&ctx[k], digest[i + k]);
+		}
+	}
+	for(; i < n; i++) { flacgpu_host_md5 c; flacgpu_host_md5_init(&c); flacgpu_host_md5_update(&c, data[i], len[i]); flacgpu_host_md5_final(&c, digest[i]); }
+}

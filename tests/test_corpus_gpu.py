@@ -46,3 +46,26 @@ def test_corpus_job_equals_the_reference_file(tmp_path):
     # the shared-pinned-host-buffer gather
     h, c = _run(tmp_path, "host", "--samples", str(samples), "--force-dist", "--gather", "host", "--batch-frames", "1024")
     assert c == want
+
+
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref/libFLAC_ref.so not built on this box")
+def test_corpus_as_tracks_equals_the_reference_files(tmp_path):
+    """--tracks: the corpus as separate streams, frame numbers restarting per track, a STREAMINFO and an MD5 per track (the digests
+    eight chains at a time): every track file is the reference's file for that track's samples"""
+    from flac_amd import corpus as co
+    samples = 60 * 44100 + 777
+    ntracks = 11                                       # 646 frames in 11 tracks: 59 / 58 frames each, the last one with the short block
+    base = co.base_clip()
+    nfr = (samples + co.BLOCK - 1) // co.BLOCK
+    pcm = co.host_frames(base, 0, nfr)[:samples].astype(np.int32)
+    out = str(tmp_path / "shelf")
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, "-m", "flac_amd.corpus", "--out", out, "--samples", str(samples), "--tracks", str(ntracks), "--md5-threads", "2"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["tracks"] == ntracks and line["tracks_with_a_bad_crc16"] == 0
+    for t, (lo, hi) in enumerate(co.track_ranges(nfr, ntracks)):
+        want = po.ref_encode_file(pcm[lo * co.BLOCK:min(hi * co.BLOCK, samples)], 16, 44100, 8, str(tmp_path / "ref.flac"), do_md5=1)
+        with open("%s.%04d.flac" % (out, t), "rb") as f:
+            assert f.read() == want, "track %d" % t
