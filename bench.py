@@ -35,8 +35,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 RATE, BPS, CH = 44100, 16, 2
 FRAMES_PER_GPU = 16384         # 67.1 M inter-channel samples = 25 min of audio per GPU per step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-KERNEL_NAMES = {"prep": "prep3_kernel", "autoc": "autoc2_kernel", "model": "model_kernel", "eval": "eval_kernel",
+KERNEL_NAMES = {"prep": "prep3_kernel", "autoc": "autoc2_kernel", "model": "model_kernel", "eval": "evalg_kernel+evalw_kernel+eval_list_kernel",
                 "pack": "pack2_kernel", "scan_compact": "scan_kernel+compact_kernel"}
+SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md: 2.4 GHz peak engine clock.  A SIMD issues one wave64 VALU instruction per 4 cycles
+VALU_ISSUE_PEAK = SIMDS * CLOCK_GHZ / 4      # G wavefront-instructions per second, the whole chip
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
 
 
@@ -365,22 +367,43 @@ def main():
             alg_bytes = samples_per_step * (4 * CH + out_bps)         # PCM read once + frames written once
             dom = max(kms, key=kms.get)
             achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
-            traffic = valu_busy = None
+            traffic = valu_busy = traffic_step = None
+            valu = {}
             try:
                 with open(PMC_FILE) as fh:
                     pmc = json.load(fh)
-                for name in KERNEL_NAMES[dom].split("+"):
-                    if name in pmc["kernels"]:
-                        traffic = (traffic or 0) + int(pmc["kernels"][name]["hbm_bytes_per_frame"] * nframes)
-                        valu_busy = pmc["kernels"][name].get("valu_busy_frac", valu_busy)
+                if level == 8 and not args.hires and kind == "music" and pmc.get("blocksize", 4096) == block:
+                    # (the committed counter passes are of this workload; other workloads report no counter-derived figures)
+                    for name in KERNEL_NAMES[dom].split("+"):
+                        if name in pmc["kernels"]:
+                            traffic = (traffic or 0) + int(pmc["kernels"][name]["hbm_bytes_per_frame"] * nframes)
+                            valu_busy = max(valu_busy or 0.0, pmc["kernels"][name].get("valu_busy_frac", 0.0))
+                    traffic_step = int(sum(v["hbm_bytes_per_frame"] for k, v in pmc["kernels"].items() if any(k in names.split("+") for names in KERNEL_NAMES.values())) * nframes)
+                    for ph, names in KERNEL_NAMES.items():
+                        ips = sum(pmc["kernels"][nm].get("valu_wave_insts_per_sample", 0.0) for nm in names.split("+") if nm in pmc["kernels"])
+                        if ips and kms.get(ph):
+                            ach = ips * samples_per_step / (kms[ph] * 1e-3) / 1e9
+                            valu[ph] = {"kernel": names, "wave_insts_per_sample": round(ips, 4), "ms": round(kms[ph], 4), "achieved_Ginst_per_s": round(ach, 1),
+                                        "frac_of_issue_peak": round(ach / VALU_ISSUE_PEAK, 4)}
             except Exception:
                 pass
             res.update(value=world * samples_per_step * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=kms, out_bps=out_bps,
                        roofline={"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
                                  "whole_step_frac": round(alg_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 6),
+                                 # every kernel of the step, not only the dominant one: HBM-side bytes of the committed counter pass and
+                                 # how many times the algorithmic bytes that is (the wasted re-reads between the kernels)
+                                 "traffic_whole_step": traffic_step,
+                                 "traffic_whole_step_over_algorithmic": round(traffic_step / alg_bytes, 3) if traffic_step else None,
                                  # what actually bounds this kernel: the share of its cycles in which it issues VALU work (committed PMC pass)
                                  "valu_busy_frac_of_committed_pmc_pass": valu_busy})
+            if valu:
+                tot_i = sum(v["wave_insts_per_sample"] for v in valu.values())
+                res["roofline_valu"] = {"bound": "valu issue", "peak": VALU_ISSUE_PEAK, "unit": "G wavefront-instructions/s",
+                                        "peak_is": "%d SIMDs x %.1f GHz / 4 cycles per wave64 instruction" % (SIMDS, CLOCK_GHZ),
+                                        "per_kernel": valu, "wave_insts_per_sample_whole_step": round(tot_i, 3),
+                                        "whole_step_frac_of_issue_peak": round(tot_i * samples_per_step / (elapsed / steps) / 1e9 / VALU_ISSUE_PEAK, 4),
+                                        "source": "SQ_INSTS_VALU of the committed counter pass (profiles/pmc_traffic.json) x this run's HIP-event kernel times"}
             if not args.no_verify:
                 res["verified"] = verify_step(pcm_h, out_h, fb_h, first_frame, level, block, search=search)
         if gp is not None and hasattr(gp, "close"):
@@ -397,9 +420,17 @@ def main():
         side_steps = max(3, args.steps // 2)
         w = measure(8, "white", side_steps, 1, False)
         l5 = measure(5, "music", side_steps, 1, False)
+        l0 = measure(0, "music", side_steps, 1, False)
+        args.hires = True
+        RATE, BPS = 96000, 24
+        hr = measure(8, "music", max(3, side_steps // 2), 1, False)
+        args.hires = False
+        RATE, BPS = 44100, 16
         if rank == 0:
             for key, r, what in (("white_noise", w, "flac -8 on i.i.d. uniform 16-bit stereo white noise (SURVEY.md 8d config 3 (i)): the 32-bit side-channel path, the largest frames"),
-                                 ("level5", l5, "flac -5 (the tool's default preset) on the music-like signal")):
+                                 ("level5", l5, "flac -5 (the tool's default preset) on the music-like signal"),
+                                 ("level0", l0, "flac -0 (fixed predictors only, 1152-sample blocks, no mid/side) on the music-like signal"),
+                                 ("hires", hr, "flac -8 on 96 kHz / 24-bit stereo (BASELINE.json config 4: the wide-sample residual path), 4096-sample blocks")):
                 extras[key] = {"what": what, "value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"],
                                "compressed_bytes_per_sample": round(r["out_bps"], 4), "kernel_ms": {k: round(v, 4) for k, v in r["kernel_ms"].items()},
                                "roofline": r["roofline"], "verified_frames": r.get("verified", {}).get("frames_compared_with_oracle"),
