@@ -72,6 +72,7 @@ struct FLAC__StreamEncoderProtected {
 };
 
 /* ... and in FLAC__StreamEncoderPrivate: callbacks, stream bookkeeping, and here the batch staging */
+#define NSLOT 4                              /* batch slots (<= FLACGPU_ASYNC_SLOTS + 1: one is always the caller's) */
 #define FLACGPU_PRE_MAX_SEGS 1024            /* "fLaC" + STREAMINFO + a VORBIS_COMMENT + the client's blocks: one segment each (beyond: written by init itself) */
 struct FLAC__StreamEncoderPrivate {
 	FLAC__StreamEncoderWriteCallback write_cb;
@@ -93,9 +94,12 @@ struct FLAC__StreamEncoderPrivate {
 	uint32_t first_seekpoint_to_check;
 	flacgpu_host_md5 md5;
 	int is_being_deleted;
-	/* GPU batches.  Two slots: the caller's thread fills one with sample BYTES (little endian, ceil(bps/8) wide: at
-	 * once the input format of the MD5 (:3448) and a raw format the engine stages on the device), while the worker
-	 * thread runs MD5 + the GPU encode of the other; frames are delivered on the caller's thread, in stream order. */
+	/* GPU batches.  A ring of NSLOT slots: the caller's thread fills one with sample BYTES (little endian, ceil(bps/8) wide: at
+	 * once the input format of the MD5 (:3448) and a raw format the engine stages on the device), while the worker thread
+	 * runs the MD5 chain and hands the slots behind it to the engine's asynchronous entry (flacgpu_submit_batch_raw: up to
+	 * NSLOT - 1 batches in flight, their input copies and read-backs beside the kernels of the batches in front) and collects
+	 * them in order; frames are delivered on the caller's thread, in stream order -- the reference's ring of 2*threads+2 frame
+	 * tasks (stream_encoder.c:1134-1238, 3530-3574), per batch. */
 	flacgpu_ctx *gpu;
 	uint32_t batch_frames;
 	uint32_t width;                           /* bytes per staged sample */
@@ -107,8 +111,9 @@ struct FLAC__StreamEncoderPrivate {
 		uint32_t nframes, tail, first_frame;  /* the submitted batch */
 		int64_t total;                        /* result: bytes, or a negative FLACGPU_ERR_* */
 		flacgpu_host_verify_result vres;      /* set_verify: the first frame of the batch that does not decode back to its input */
-		int state;                            /* 0 being filled / free, 1 submitted, 2 done */
-	} slot[2];
+		int state;                            /* 0 being filled / free, 1 handed to the worker, 3 in flight on the engine, 2 done */
+	} slot[NSLOT];
+	int inflight, col_slot;                   /* worker: batches on the engine, and the slot of the oldest of them */
 	int cur;                                  /* slot the caller is filling */
 	size_t staged;                            /* inter-channel samples in slot[cur] */
 	size_t out_cap;
@@ -146,7 +151,7 @@ struct FLAC__StreamEncoderPrivate {
 	uint32_t pre_nseg;
 	flacgpu_config bring_cfg;
 	size_t raw_bytes;
-	int registered[4];
+	int registered[2 * NSLOT];
 	float *windows; size_t wcount;            /* the engine's window tables (host copy) */
 	int engine_failed;                        /* an engine call failed: this engine is not parked */
 	double t_bring_wait;
@@ -298,9 +303,9 @@ struct engine_bundle {
 	flacgpu_ctx *gpu;
 	flacgpu_config cfg;
 	float *windows; size_t wcount;
-	uint8_t *raw[2], *out[2];
-	uint32_t *fb[2];
-	int registered[4];
+	uint8_t *raw[NSLOT], *out[NSLOT];
+	uint32_t *fb[NSLOT];
+	int registered[2 * NSLOT];
 	size_t raw_bytes, out_cap;
 };
 static pthread_mutex_t g_park_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -309,7 +314,7 @@ static int g_park_valid;
 static int parking_enabled(void) { const char *v = getenv("FLACGPU_ENGINE_CACHE"); return !(v && atoi(v) == 0); }
 static void bundle_destroy(struct engine_bundle *b)
 {
-	for(int i = 0; i < 2; i++) {
+	for(int i = 0; i < NSLOT; i++) {
 		if(b->registered[2 * i]) flacgpu_host_unregister(b->raw[i]);
 		if(b->registered[2 * i + 1]) flacgpu_host_unregister(b->out[i]);
 		free(b->raw[i]); free(b->out[i]); free(b->fb[i]);
@@ -367,20 +372,22 @@ static void release_engine(FLAC__StreamEncoder *e)
 		struct engine_bundle b;
 		memset(&b, 0, sizeof b);
 		b.gpu = p->gpu; b.cfg = p->bring_cfg; b.windows = p->windows; b.wcount = p->wcount; b.raw_bytes = p->raw_bytes; b.out_cap = p->out_cap;
-		for(int i = 0; i < 2; i++) {
+		int whole = 1;
+		for(int i = 0; i < NSLOT; i++) {
 			b.raw[i] = p->slot[i].raw; b.out[i] = p->slot[i].out; b.fb[i] = p->slot[i].frame_bytes;
+			if(!b.raw[i] || !b.out[i] || !b.fb[i]) whole = 0;
 			b.registered[2 * i] = p->registered[2 * i]; b.registered[2 * i + 1] = p->registered[2 * i + 1];
 			p->slot[i].raw = 0; p->slot[i].out = 0; p->slot[i].frame_bytes = 0; p->slot[i].state = 0;
 			p->registered[2 * i] = p->registered[2 * i + 1] = 0;
 		}
 		p->gpu = 0; p->windows = 0; p->wcount = 0;
-		if(b.gpu && !p->engine_failed && b.raw[0] && b.raw[1] && b.out[0] && b.out[1] && b.fb[0] && b.fb[1] && parking_enabled()) park_put(&b);
+		if(b.gpu && !p->engine_failed && whole && parking_enabled()) park_put(&b);
 		else bundle_destroy(&b);
 	}
 	p->engine_on = 0; p->bring_done = 0; p->engine_failed = 0;
 	p->out_cap = 0;
 	free(p->tail_windows); p->tail_windows = 0;
-	p->staged = 0; p->cur = 0;
+	p->staged = 0; p->cur = 0; p->inflight = 0; p->col_slot = 0;
 	if(PROT(e)->metadata) { free(PROT(e)->metadata); PROT(e)->metadata = 0; PROT(e)->num_metadata_blocks = 0; }
 }
 
@@ -767,25 +774,37 @@ static int emit_block(FLAC__StreamEncoder *e, const FLAC__StreamMetadata *m)
 	return ok;
 }
 
-/* The worker: MD5 over exactly the sample bytes being encoded, in stream order (:3448), then the GPU encode. */
-static void run_batch_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
+/* The worker hands a batch to the engine's asynchronous entry (the MD5 chain has been over exactly its sample bytes, in stream
+ * order, :3448).  Returns 0 when nothing went in flight (b->total holds the error). */
+static int engine_submit_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
 {
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	const flacgpu_host_settings *s = &PROT(e)->s;
 	const double t0 = p->timing ? now_s() : 0;
-	if(p->bring_result != FLACGPU_OK) { b->total = p->bring_result; return; }       /* (the worker has waited for bring_done) */
+	if(p->bring_result != FLACGPU_OK) { b->total = p->bring_result; return 0; }       /* (the worker has waited for bring_done) */
 	const float *tw = 0;
 	if(b->tail && s->max_lpc_order > 0) {
 		/* windows are recomputed for the short block, as resize_buffers_ does at finish (:1703-1711) */
 		float *w = realloc(p->tail_windows, sizeof(float) * s->num_apodizations * b->tail);
-		if(!w) { b->total = FLACGPU_ERR_ALLOC; return; }
+		if(!w) { b->total = FLACGPU_ERR_ALLOC; return 0; }
 		p->tail_windows = w;
 		flacgpu_host_windows(s, b->tail, w);
 		tw = w;
 	}
-	b->total = flacgpu_encode_batch_raw(p->gpu, b->raw, &p->rawfmt, b->nframes, b->first_frame, b->tail, tw, b->out, p->out_cap, b->frame_bytes);
-	if(p->timing) p->t_encode += now_s() - t0;
 	b->vres.status = 0;
+	const int r = flacgpu_submit_batch_raw(p->gpu, b->raw, &p->rawfmt, b->nframes, b->first_frame, b->tail, tw, b->out, p->out_cap, b->frame_bytes);
+	if(p->timing) p->t_encode += now_s() - t0;
+	if(r != FLACGPU_OK) { b->total = r; return 0; }
+	return 1;
+}
+/* the oldest batch in flight comes back (the worker; blocks until the engine has it) */
+static void engine_collect_slot(FLAC__StreamEncoder *e, struct batch_slot *b)
+{
+	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
+	const flacgpu_host_settings *s = &PROT(e)->s;
+	const double t0 = p->timing ? now_s() : 0;
+	b->total = flacgpu_collect(p->gpu);
+	if(p->timing) p->t_encode += now_s() - t0;
 	if(b->total >= 0 && s->verify) {
 		/* write_bitbuffer_ verifies every frame before it is written (:3000-3018): here the engine has decoded the batch again on
 		 * the device, next to the staged input (flacgpu_set_verify); this is its verdict */
@@ -814,7 +833,7 @@ static void *bringup_main(void *arg)
 	if(r == FLACGPU_OK && s->verify) r = flacgpu_set_verify(gpu, 1);
 	const double t1 = now_s();
 	if(r == FLACGPU_OK)
-		for(int i = 0; i < 2; i++) {        /* a slot that cannot be page-locked still works: its copies are staged by the runtime */
+		for(int i = 0; i < NSLOT; i++) {    /* a slot that cannot be page-locked still works: its copies are staged by the runtime */
 			p->registered[2 * i] = flacgpu_host_register(p->slot[i].raw, p->raw_bytes) == FLACGPU_OK;
 			p->registered[2 * i + 1] = flacgpu_host_register(p->slot[i].out, p->out_cap) == FLACGPU_OK;
 		}
@@ -852,7 +871,7 @@ static void *worker_main(void *arg)
 				if(p->md5_done < nsamp) { slot_to_hash = cur; from = p->md5_done; n = nsamp - from; }
 				else if(p->bring_done) k = cur;
 				else {
-					const int o = cur ^ 1;
+					const int o = (cur + 1) % NSLOT;
 					size_t avail = p->slot[o].state == 0 && p->pub_slot == o ? p->pub_staged : 0;
 					if(avail > full) avail = full;
 					if(avail >= p->md5_ahead + MD5_PIECE || (avail == full && avail > p->md5_ahead)) { slot_to_hash = o; from = p->md5_ahead; n = avail - from; }
@@ -876,22 +895,37 @@ static void *worker_main(void *arg)
 			}
 		}
 		else {
-			k = p->slot[0].state == 1 ? 0 : p->slot[1].state == 1 ? 1 : -1;
+			k = p->slot[p->md5_slot].state == 1 ? p->md5_slot : -1;       /* stream order: md5_slot is the next batch for the engine, MD5 or not */
 			if(k >= 0 && !p->bring_done) k = -2;              /* a batch is waiting for the engine */
 		}
-		if(k < 0) {
-			if(p->worker_quit && k == -1) break;
+		if(k >= 0 && p->inflight < NSLOT - 1) {
+			/* into flight: its input copy starts now, beside the kernels of the batches in front */
+			pthread_mutex_unlock(&p->mu);
+			const int went = engine_submit_slot(e, &p->slot[k]);
+			pthread_mutex_lock(&p->mu);
+			if(went) { if(p->inflight++ == 0) p->col_slot = k; p->slot[k].state = 3; }
+			else p->slot[k].state = 2;                        /* (b->total says why) */
+			p->md5_slot = (k + 1) % NSLOT; p->md5_done = p->md5_ahead; p->md5_ahead = 0;
+			pthread_cond_broadcast(&p->cv);
+			continue;
+		}
+		if(p->inflight > 0) {
+			/* nothing to hand over (or the engine's ring is full): the oldest batch in flight comes back */
+			const int c = p->col_slot;
+			pthread_mutex_unlock(&p->mu);
+			engine_collect_slot(e, &p->slot[c]);
+			pthread_mutex_lock(&p->mu);
+			p->slot[c].state = 2;
+			p->inflight--; p->col_slot = (c + 1) % NSLOT;
+			pthread_cond_broadcast(&p->cv);
+			continue;
+		}
+		if(p->worker_quit && k == -1) break;
+		{
 			const double t0 = p->timing ? now_s() : 0;
 			pthread_cond_wait(&p->cv, &p->mu);
 			if(p->timing && !p->bring_done) p->t_bring_wait += now_s() - t0;
-			continue;
 		}
-		pthread_mutex_unlock(&p->mu);
-		run_batch_slot(e, &p->slot[k]);
-		pthread_mutex_lock(&p->mu);
-		p->slot[k].state = 2;
-		p->md5_slot = k ^ 1; p->md5_done = p->md5_ahead; p->md5_ahead = 0;
-		pthread_cond_broadcast(&p->cv);
 	}
 	pthread_mutex_unlock(&p->mu);
 	return 0;
@@ -905,7 +939,7 @@ static void submit_slot(FLAC__StreamEncoder *e, int k, uint32_t nframes, uint32_
 	p->next_frame_number += nframes;
 	pthread_mutex_lock(&p->mu);
 	b->state = 1;
-	p->pub_slot = k ^ 1; p->pub_staged = 1; p->pub_last = 1;      /* the caller goes on in the other slot, behind the overread sample */
+	p->pub_slot = (k + 1) % NSLOT; p->pub_staged = 1; p->pub_last = 1;      /* the caller goes on in the next slot, behind the overread sample */
 	pthread_cond_broadcast(&p->cv);
 	pthread_mutex_unlock(&p->mu);
 }
@@ -1076,7 +1110,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 				if((!wcount || w) && park_take(&p->bring_cfg, w, wcount, p->raw_bytes, p->out_cap, &b)) {
 					parked = 1;
 					p->gpu = b.gpu; p->bring_cfg = b.cfg; p->windows = b.windows; p->wcount = b.wcount; p->raw_bytes = b.raw_bytes; p->out_cap = b.out_cap;
-					for(int i = 0; i < 2; i++) {
+					for(int i = 0; i < NSLOT; i++) {
 						p->slot[i].raw = b.raw[i]; p->slot[i].out = b.out[i]; p->slot[i].frame_bytes = b.fb[i]; p->slot[i].state = 0;
 						p->registered[2 * i] = b.registered[2 * i]; p->registered[2 * i + 1] = b.registered[2 * i + 1];
 					}
@@ -1085,7 +1119,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 				}
 				free(w);
 			}
-			for(int i = 0; i < 2 && !parked; i++) {
+			for(int i = 0; i < NSLOT && !parked; i++) {
 				void *a = 0, *b = 0;
 				if(posix_memalign(&a, 4096, p->raw_bytes) != 0) a = 0;
 				if(posix_memalign(&b, 4096, p->out_cap) != 0) b = 0;
@@ -1096,7 +1130,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 				if(!p->slot[i].raw || !p->slot[i].out || !p->slot[i].frame_bytes) r = FLACGPU_ERR_ALLOC;
 			}
 		}
-		p->md5_slot = 0; p->md5_done = 0; p->md5_ahead = 0; p->pub_slot = 0; p->pub_staged = p->pub_last = 0;
+		p->md5_slot = 0; p->md5_done = 0; p->md5_ahead = 0; p->pub_slot = 0; p->pub_staged = p->pub_last = 0; p->inflight = 0; p->col_slot = 0;
 		p->bring_started = 0; p->bring_done = 0; p->bring_result = FLACGPU_OK;
 		if(r == FLACGPU_OK) {
 			pthread_mutex_init(&p->mu, 0);
@@ -1315,9 +1349,9 @@ static int release_if_full(FLAC__StreamEncoder *e)
 	const uint32_t N = PROT(e)->s.blocksize, C = PROT(e)->s.channels;
 	const size_t full = (size_t)p->batch_frames * N;
 	if(p->staged <= full) return 1;            /* one sample beyond the batch must exist (the overread) */
-	const int k = p->cur, o = k ^ 1;
-	/* the other slot's batch comes first in the stream: deliver it, then this one goes to the worker and the caller
-	 * carries on filling the other slot, starting with the overread sample */
+	const int k = p->cur, o = (k + 1) % NSLOT;
+	/* the next slot of the ring holds the oldest batch still out (NSLOT - 1 batches back): deliver it, then this one goes to
+	 * the worker and the caller carries on filling that slot, starting with the overread sample */
 	if(!collect_slot(e, o)) return 0;
 	memcpy(p->slot[o].raw, p->slot[k].raw + full * C * p->width, (size_t)C * p->width);
 	submit_slot(e, k, p->batch_frames, 0);
@@ -1603,7 +1637,7 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 	}
 	if(PROT(e)->state == FLAC__STREAM_ENCODER_OK && !p->is_being_deleted && p->engine_on) {
 		/* the batch in flight, then everything still staged: full blocks and the final one (short, or exactly full) */
-		if(!collect_slot(e, p->cur ^ 1)) error = 1;
+		for(int i = 1; i < NSLOT && !error; i++) if(!collect_slot(e, (p->cur + i) % NSLOT)) error = 1;      /* oldest first */
 		if(!error && p->staged) {
 			const uint32_t N = PROT(e)->s.blocksize;
 			const uint32_t nframes = (uint32_t)((p->staged + N - 1) / N);
@@ -1619,7 +1653,12 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 	else if(p->worker_started) {
 		/* an encoder that is torn down or already failed: let the worker drain, deliver nothing */
 		pthread_mutex_lock(&p->mu);
-		while(p->slot[0].state == 1 || p->slot[1].state == 1) pthread_cond_wait(&p->cv, &p->mu);
+		for(;;) {
+			int busy = 0;
+			for(int i = 0; i < NSLOT; i++) if(p->slot[i].state == 1 || p->slot[i].state == 3) busy = 1;
+			if(!busy) break;
+			pthread_cond_wait(&p->cv, &p->mu);
+		}
 		pthread_mutex_unlock(&p->mu);
 	}
 	if(p->preamble_pending && !p->is_being_deleted && PROT(e)->state == FLAC__STREAM_ENCODER_OK) {

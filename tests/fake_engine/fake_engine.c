@@ -13,7 +13,8 @@
 #include <time.h>
 #include "flacgpu.h"
 
-struct flacgpu_ctx { flacgpu_config cfg; uint32_t verify; };
+struct fake_job { const void *raw; flacgpu_raw_format fmt; uint32_t nframes; uint64_t first; uint32_t last; uint8_t *out; size_t out_cap; uint32_t *fb; };
+struct flacgpu_ctx { flacgpu_config cfg; uint32_t verify; struct fake_job q[FLACGPU_ASYNC_SLOTS]; uint64_t sub, col; };
 static int g_creates, g_destroys;
 int fake_engine_creates(void) { return g_creates; }
 int fake_engine_destroys(void) { return g_destroys; }
@@ -77,3 +78,26 @@ int64_t flacgpu_encode_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgp
 	}
 	return (int64_t)total;
 }
+
+/* the asynchronous entry: a submission is only NOTED -- the raw bytes are read when the batch is collected, as late as the real
+ * engine's copy engine may read them, so that a host layer that reuses a slot before collecting it is caught by the records */
+int flacgpu_submit_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgpu_raw_format *fmt, uint32_t nframes, uint64_t first_frame_number, uint32_t last_block_samples,
+                             const float *tail_windows, uint8_t *out, size_t out_cap, uint32_t *frame_bytes)
+{
+	(void)tail_windows;
+	if(ctx->sub - ctx->col >= FLACGPU_ASYNC_SLOTS) return FLACGPU_ERR_BUSY;
+	if(nframes > ctx->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
+	if(getenv("FAKE_ENGINE_FAIL_SUBMIT")) return FLACGPU_ERR_LAUNCH;
+	struct fake_job *j = &ctx->q[ctx->sub % FLACGPU_ASYNC_SLOTS];
+	j->raw = raw; j->fmt = *fmt; j->nframes = nframes; j->first = first_frame_number; j->last = last_block_samples; j->out = out; j->out_cap = out_cap; j->fb = frame_bytes;
+	ctx->sub++;
+	return FLACGPU_OK;
+}
+int64_t flacgpu_collect(flacgpu_ctx *ctx)
+{
+	if(ctx->sub == ctx->col) return FLACGPU_ERR_BAD_ARG;
+	const struct fake_job j = ctx->q[ctx->col % FLACGPU_ASYNC_SLOTS];
+	ctx->col++;
+	return flacgpu_encode_batch_raw(ctx, j.raw, &j.fmt, j.nframes, j.first, j.last, 0, j.out, j.out_cap, j.fb);
+}
+int flacgpu_in_flight(const flacgpu_ctx *ctx) { return (int)(ctx->sub - ctx->col); }

@@ -337,3 +337,23 @@ def test_client_that_frees_its_metadata_right_after_init(tmp_path):
         assert r.returncode == 0, r.stderr.decode()
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and outs[0][:4] == b"fLaC"
+
+
+# ---- the ring of batch slots on the engine's asynchronous entry (round 3) ----------------------------------------------------------
+@pytest.mark.parametrize("md5", [0, 1])
+@pytest.mark.parametrize("batch,delay_us", [(1, 0), (2, 3000), (3, 500), (5, 20000)])
+def test_ring_of_batches_in_flight(batch, delay_us, md5):
+    """a slow engine (the caller runs NSLOT - 1 batches ahead and then waits), a fast one, tiny batches that lap the ring many times:
+    same records in the same order, the MD5 chain still over exactly the stream's bytes.  The fake engine reads a batch's raw bytes
+    only when it is collected: a slot reused too early would show in the records' checksums."""
+    case = dict(BASE, md5=md5, samples=256 * 41 + 13, chunk=700)
+    env = {"FLACGPU_BATCH_FRAMES": str(batch)}
+    if delay_us:
+        env["FAKE_ENGINE_DELAY_US"] = str(delay_us)
+    check(case, env)
+
+
+def test_a_refused_submission_fails_the_stream():
+    out, err = _fail_child("encode", {"FAKE_ENGINE_FAIL_SUBMIT": "1", "FLACGPU_BATCH_FRAMES": "8", "FLACGPU_SYNC_INIT": "1"})
+    st, s_init, ok_process, s_proc, ok_finish, written = out
+    assert st == "0" and ok_process == "False" and s_proc != "0" and "the GPU frame engine failed" in err
