@@ -567,6 +567,10 @@ bool prep2_applicable(const DevParams &P)
 // prep2_kernel<.,.,true>: the presets whose only residual candidate is the guessed fixed order.  The leaf partitions must be whole
 // 16-sample chunks, the partition sums the reference's 32-bit ones (stream_encoder.c:4814), and eval_list_kernel (the lane-owner
 // evaluation) must be able to take what this kernel leaves behind.
+static size_t prep2_decide_lds(const DevParams &P, uint32_t nraw, uint32_t waves)
+{
+	return (size_t)nraw * p2_chan_bytes(P.blocksize) + P2_DIVTAB_BYTES + (size_t)waves * ((5 * (P.blocksize / CHUNK) + 8) * 4 + 64);
+}
 bool prep2_decides(const DevParams &P)
 {
 	static int off = -1;
@@ -581,7 +585,11 @@ bool prep2_decides(const DevParams &P)
 	const uint32_t psize = n >> fmax;
 	uint32_t lg = 0;
 	while((2u << lg) <= psize) lg++;
-	return psize % CHUNK == 0 && (P.bps + 1 + 4) < 32 - lg;
+	if(!(psize % CHUNK == 0 && (P.bps + 1 + 4) < 32 - lg)) return false;
+	// the chunk sums of every wavefront behind the staged channels must still fit the LDS (6 channels x 8192 samples do not)
+	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;
+	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u), waves = stereo_ms ? 4u : nraw;
+	return prep2_decide_lds(P, nraw, waves) <= 150 * 1024;
 }
 
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
@@ -618,7 +626,7 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	if(prep2_decides(P)) {
 		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
 		(void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
-		const size_t ldz = lds + P2_DIVTAB_BYTES + (size_t)waves * ((5 * (P.blocksize / CHUNK) + 8) * 4 + 64);
+		const size_t ldz = prep2_decide_lds(P, nraw, waves);
 		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
 		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
 		return hipGetLastError();
