@@ -110,16 +110,21 @@ __device__ __forceinline__ void load_piece_first(const unsigned char *own /* wor
 struct EgSlot { uint32_t Q[7]; uint32_t shift, bias, order, npf, precision, ci; };
 
 // LDS of one wavefront: [image (S/2 rows of 65 words)][prefix sums | divisor table | best parameters (flacgpu_evalg.h)]
+// WPC wavefronts share a channel's image and split its candidates between them (each has its own search state; the better of their
+// first minima wins): an experiment in occupancy (the LDS image allows four one-wavefront channels per SIMD), opt-in, see launch_evalg.
 template <int MAXORD>
-__host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N) { return (N / 128) * EG_ROW + eg_tail_bytes<MAXORD>(); }
-constexpr int EG_PIECES_AHEAD = 8;        // 16-byte pieces of the planar channel a lane has in flight before its first use (8 = a 4096-sample block)
+__host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N, uint32_t wpc = 1) { return (N / 128) * EG_ROW + wpc * eg_tail_bytes<MAXORD>() + 64; }
+constexpr int EG_PIECES_AHEAD = 8;        // 16-byte pieces of the planar channel a lane has in flight before its first use (8 = a 4096-sample block at WPC 1)
 
 // returns false when the channel is not this kernel's (the caller lists it)
-template <int MAXORD>
+template <int MAXORD, int WPC>
 __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__restrict__ chan, const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps,
                                            const Candidate *__restrict__ cands, const int *__restrict__ valid, SubDecision *__restrict__ decisions, uint32_t fc,
-                                           unsigned char *smem, int lane)
+                                           unsigned char *smem, int tid)
 {
+	const int lane = tid & 63;
+	const uint32_t wave = WPC > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) : 0u;
+	constexpr int AHEAD = EG_PIECES_AHEAD / WPC;
 	const uint32_t n = P.blocksize, S = n / 64;
 	const uint32_t aslots = P.norders * P.nprec, cstride = P.ncslots;
 	// ---- every load from HBM goes out before the first use: one round trip, not three ------------------------------------
@@ -140,9 +145,9 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	}
 	const uint4 *src = (const uint4 *)(chan + (size_t)fc * P.chan_stride);
 	const uint32_t nvec = n / 8, vps = S / 8;                                 // 16-byte pieces of the block, of a lane's run
-	uint4 pv[EG_PIECES_AHEAD];
+	uint4 pv[AHEAD];
 #pragma unroll
-	for(int i = 0; i < EG_PIECES_AHEAD; i++) { const uint32_t m = (uint32_t)lane + 64u * (uint32_t)i; if(m < nvec) pv[i] = src[m]; }
+	for(int i = 0; i < AHEAD; i++) { const uint32_t m = (uint32_t)tid + 64u * WPC * (uint32_t)i; if(m < nvec) pv[i] = src[m]; }
 
 	const uint32_t nan = P.nfixed + ((pr.flags & PREP_LPC) ? nanalyses * aslots : 0);
 	const bool any = !(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || nan > P.nfixed);
@@ -154,7 +159,9 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	const uint32_t psize = n >> frame_max_po;
 	const bool narrow = (pr.sbps + 4) < (32 - ilog2_u32(psize));               // stream_encoder.c:4814-4817
 	const uint32_t sbps = pr.sbps, hdr = 8 + pr.wasted;
-	uint8_t *kbest = smem + evalg_lds_bytes<MAXORD>(n) - 64;
+	const uint32_t tail_off = (S / 2) * EG_ROW + wave * eg_tail_bytes<MAXORD>();           // this wavefront's search state behind the shared image
+	uint8_t *kbest = smem + tail_off + eg_tail_bytes<MAXORD>() - 64;
+	uint32_t *merge = (uint32_t *)(smem + (S / 2) * EG_ROW + WPC * eg_tail_bytes<MAXORD>());      // [WPC][4]: best estimate, candidate, left?, -
 	EgSearch R;
 	R.best_est = 0xffffffffu; R.best_ci = 0xffffffffu; R.best_po = 0;
 
@@ -191,29 +198,39 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	{
 		const bool spow2 = (vps & (vps - 1)) == 0;
 		const uint32_t vlog = ilog2_u32(vps);
-		if(lane < 8) *(uint32_t *)(smem + (rows - 8 + (uint32_t)lane) * EG_ROW) = 0;      // column 0: lane 0's history
+		if(tid < 8) *(uint32_t *)(smem + (rows - 8 + (uint32_t)tid) * EG_ROW) = 0;      // column 0: lane 0's history
 #pragma unroll
-		for(int i = 0; i < EG_PIECES_AHEAD; i++) {
-			const uint32_t m = (uint32_t)lane + 64u * (uint32_t)i;
+		for(int i = 0; i < AHEAD; i++) {
+			const uint32_t m = (uint32_t)tid + 64u * WPC * (uint32_t)i;
 			if(m < nvec) {
 				const uint32_t Lo = spow2 ? m >> vlog : m / vps, r = m - Lo * vps;          // run, piece of the run
 				unsigned char *d = smem + (Lo + 1) * 4 + 4 * r * EG_ROW;
 				*(uint32_t *)(d) = pv[i].x; *(uint32_t *)(d + EG_ROW) = pv[i].y; *(uint32_t *)(d + 2 * EG_ROW) = pv[i].z; *(uint32_t *)(d + 3 * EG_ROW) = pv[i].w;
 			}
 		}
-		for(uint32_t m = (uint32_t)lane + 64u * EG_PIECES_AHEAD; m < nvec; m += 64) {          // blocks of more than 4096 samples
+		for(uint32_t m = (uint32_t)tid + 64u * WPC * AHEAD; m < nvec; m += 64 * WPC) {          // blocks of more than 4096 samples
 			const uint4 v = src[m];
 			const uint32_t Lo = spow2 ? m >> vlog : m / vps, r = m - Lo * vps;
 			unsigned char *d = smem + (Lo + 1) * 4 + 4 * r * EG_ROW;
 			*(uint32_t *)(d) = v.x; *(uint32_t *)(d + EG_ROW) = v.y; *(uint32_t *)(d + 2 * EG_ROW) = v.z; *(uint32_t *)(d + 3 * EG_ROW) = v.w;
 		}
 	}
-	eg_search_setup<MAXORD>(R, smem, img_bytes, S, frame_max_po, frame_min_po, P.rice_limit, lane);
+	eg_search_setup<MAXORD>(R, smem, tail_off, S, frame_max_po, frame_min_po, P.rice_limit, lane);
+	(void)img_bytes;
 	const unsigned char *own = smem + ((uint32_t)lane + 1) * 4;                      // word 0 of this lane's run
 	const unsigned char *hist = smem + (uint32_t)lane * 4 + (rows - 7) * EG_ROW;     // 7 words in front of it: the previous column's last
 	const uint32_t npieces = S / 16;
 	const uint32_t sum0 = 0x80000000u;
-	__builtin_amdgcn_wave_barrier();
+	if(WPC > 1) {
+		__syncthreads();                                                          // the image is whole
+		// the channel's candidates in halves: this wavefront's are the `mine` lowest (wave 0) or the rest (wave 1) of the valid ones
+		const uint32_t nv = (uint32_t)__builtin_popcountll(vmask), first = (nv + 1) / 2;
+		uint64_t m = vmask, lo = 0;
+		for(uint32_t i = 0; i < first; i++) { lo |= m & (0 - m); m &= m - 1; }
+		vmask = wave == 0 ? lo : m;
+	}
+	else __builtin_amdgcn_wave_barrier();
+	bool leave = false;
 
 	// ---- the candidates, two at a time ----------------------------------------------------------------------------------------
 	while(vmask) {
@@ -247,29 +264,40 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 			if(two) v1 = fir16_dispatch<false>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
 		}
 		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_list_kernel's (nothing was written yet)
-		if(__any((int)((v0 | v1) >= (1u << 23)))) return false;
+		if(__any((int)((v0 | v1) >= (1u << 23)))) { if(WPC == 1) return false; leave = true; break; }
 		EgCand CA, CB;
 		CA.order = A.order; CA.precision = A.precision; CA.ci = A.ci; CB.order = B.order; CB.precision = B.precision; CB.ci = B.ci;
 		eg_pair_search(R, smem, kbest, v0, v1, CA, CB, two, P.nfixed, hdr, sbps, lane);
 	}
+	if(WPC > 1) {
+		// the better first minimum of the two halves (an equal estimate: the earlier candidate, stream_encoder.c:4191,4266); a half
+		// that met sums beyond the node arithmetic sends the whole channel to the list
+		if(lane == 0) { merge[4 * wave] = R.best_est; merge[4 * wave + 1] = R.best_ci; merge[4 * wave + 2] = leave ? 1u : 0u; }
+		__syncthreads();
+		if(merge[2] | merge[6]) return false;
+		const uint32_t oe = merge[4 * (wave ^ 1u)], oc = merge[4 * (wave ^ 1u) + 1];
+		const bool mine = R.best_est < oe || (R.best_est == oe && (R.best_ci < oc || (R.best_ci == oc && wave == 0)));
+		if(!mine) return true;                                                    // (the other wavefront writes the decision)
+	}
 	}       // any
+	else if(WPC > 1 && wave != 0) return true;                                    // a channel without candidates: wavefront 0 decides it
 
 	eg_decide<MAXORD>(R, P, pr, n, kbest, c_order, c_prec, c_shift, cq, decisions + fc, preps + fc, lane);
 	return true;
 }
 
-template <int MAXORD>
-__global__ __launch_bounds__(64, EVALG_WAVES_PER_SIMD) void evalg_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
+template <int MAXORD, int WPC>
+__global__ __launch_bounds__(64 * WPC, EVALG_WAVES_PER_SIMD) void evalg_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
                                                                           const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
                                                                           const int *__restrict__ valid, SubDecision *__restrict__ decisions,
                                                                           uint32_t *__restrict__ left, uint32_t *__restrict__ nleft)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int lane = (int)threadIdx.x;
+	const int tid = (int)threadIdx.x;
 	const uint32_t fc = blockIdx.x;
 	// what this kernel does not take -- the short last block first of all -- goes on the next kernel's list
 	const bool tail = tail_n != 0 && fc / P.ncand == nframes - 1;
-	if(tail || !evalg_body<MAXORD>(P, chan, jt, preps, cands, valid, decisions, fc, smem, lane)) { if(lane == 0) left[atomicAdd(nleft, 1u)] = fc; }
+	if(tail || !evalg_body<MAXORD, WPC>(P, chan, jt, preps, cands, valid, decisions, fc, smem, tid)) { if(tid == 0) left[atomicAdd(nleft, 1u)] = fc; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -282,23 +310,26 @@ bool evalg_applicable(const DevParams &P)
 	const uint32_t S = P.blocksize / 64;
 	return !off && P.blocksize % 64 == 0 && S >= 16 && S % 16 == 0 && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC && P.blocksize <= 16384;
 }
+template <int MAXORD, int WPC>
+static hipError_t launch_evalg_t(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
+{
+	const uint32_t lds = evalg_lds_bytes<MAXORD>(P.blocksize, WPC);
+	static bool set = false;
+	if(!set) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<MAXORD, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) return e; set = true; }
+	hipLaunchKernelGGL((evalg_kernel<MAXORD, WPC>), dim3(nframes * P.ncand), dim3(64 * WPC), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
+	return hipGetLastError();
+}
 hipError_t launch_evalg(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
 {
 	if(nframes == 0) return hipSuccess;
-	const uint32_t nchan = nframes * P.ncand;
-	if(P.max_lpc_order <= 8) {
-		const uint32_t lds = evalg_lds_bytes<8>(P.blocksize);
-		static bool set = false;
-		if(!set) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) return e; set = true; }
-		hipLaunchKernelGGL(evalg_kernel<8>, dim3(nchan), dim3(64), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
-	}
-	else {
-		const uint32_t lds = evalg_lds_bytes<12>(P.blocksize);
-		static bool set = false;
-		if(!set) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) return e; set = true; }
-		hipLaunchKernelGGL(evalg_kernel<12>, dim3(nchan), dim3(64), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
-	}
-	return hipGetLastError();
+	// FLACGPU_EVAL_WPC=2: two wavefronts share a channel's image and halve its candidates (5 wavefronts per SIMD instead of 4).
+	// Measured and left off: same bytes, 2 % slower at -8 (profiles/r03_s_wpc_ab.txt: 0.923-0.929 ms against 0.882-0.910) -- the
+	// kernel's idle quarter is not a lack of wavefronts
+	static int wpc = 0;
+	if(!wpc) { const char *e = getenv("FLACGPU_EVAL_WPC"); wpc = e && atoi(e) == 2 ? 2 : 1; }
+	const bool two = wpc == 2 && P.ncslots >= 4;
+	if(P.max_lpc_order <= 8) return two ? launch_evalg_t<8, 2>(P, nframes, tail_n, jt, B, dec, s) : launch_evalg_t<8, 1>(P, nframes, tail_n, jt, B, dec, s);
+	return two ? launch_evalg_t<12, 2>(P, nframes, tail_n, jt, B, dec, s) : launch_evalg_t<12, 1>(P, nframes, tail_n, jt, B, dec, s);
 }
 
 } // namespace flacgpu

@@ -625,3 +625,20 @@ def test_asynchronous_entry_matches_the_synchronous_one():
             col += 1
     finally:
         eng.close()
+
+
+def test_two_wavefronts_per_channel_variant():
+    """FLACGPU_EVAL_WPC=2 (evalg_kernel<., 2>: two wavefronts share a channel's image and halve its candidates; opt-in, read once per
+    process): a fresh interpreter encodes the -8 and -6 cases with it and must produce the oracle's bytes"""
+    import subprocess, sys
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, flac_amd, signals\n"
+            "from oracle import pyoracle as po\n"
+            "for level, seed in ((8, 3), (6, 4)):\n"
+            "    pcm = signals.music(4096 * 9 + 123, 2, 16, seed=seed)\n"
+            "    eng = flac_amd.FrameEngine(flac_amd.make_settings(2, 16, 44100, level), device=0, max_batch_frames=16)\n"
+            "    data, fb = eng.encode(pcm); eng.close()\n"
+            "    assert data == po.oracle_encode(pcm, 16, 44100, level)['data'], level\n"
+            "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLACGPU_EVAL_WPC="2"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
