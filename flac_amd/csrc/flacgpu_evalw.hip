@@ -55,23 +55,23 @@ __device__ __forceinline__ uint32_t mad24_chain_s(const int32_t *xr /* xr[-1 - j
 	return d;
 }
 template <int NT>
-__device__ __forceinline__ uint64_t mad64_chain_s(const int32_t *xr, const uint32_t (&q)[12])
+__device__ __forceinline__ uint64_t mad64_chain_s(const int32_t *xr, const uint32_t (&q)[12], uint64_t init)
 {
 	uint64_t d;
 	if constexpr(NT == 4)
-		asm("v_mad_i64_i32 %0, vcc, %1, %2, 0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0"
-		    : "=&v"(d) : "v"(xr[-1]), "s"(q[0]), "v"(xr[-2]), "s"(q[1]), "v"(xr[-3]), "s"(q[2]), "v"(xr[-4]), "s"(q[3]) : "vcc");
+		asm("v_mad_i64_i32 %0, vcc, %1, %2, %9\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0"
+		    : "=&v"(d) : "v"(xr[-1]), "s"(q[0]), "v"(xr[-2]), "s"(q[1]), "v"(xr[-3]), "s"(q[2]), "v"(xr[-4]), "s"(q[3]), "v"(init) : "vcc");
 	if constexpr(NT == 8)
-		asm("v_mad_i64_i32 %0, vcc, %1, %2, 0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\t"
+		asm("v_mad_i64_i32 %0, vcc, %1, %2, %17\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\t"
 		    "v_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0\n\tv_mad_i64_i32 %0, vcc, %15, %16, %0"
 		    : "=&v"(d) : "v"(xr[-1]), "s"(q[0]), "v"(xr[-2]), "s"(q[1]), "v"(xr[-3]), "s"(q[2]), "v"(xr[-4]), "s"(q[3]), "v"(xr[-5]), "s"(q[4]), "v"(xr[-6]), "s"(q[5]),
-		      "v"(xr[-7]), "s"(q[6]), "v"(xr[-8]), "s"(q[7]) : "vcc");
+		      "v"(xr[-7]), "s"(q[6]), "v"(xr[-8]), "s"(q[7]), "v"(init) : "vcc");
 	if constexpr(NT == 12)
-		asm("v_mad_i64_i32 %0, vcc, %1, %2, 0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\t"
+		asm("v_mad_i64_i32 %0, vcc, %1, %2, %25\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\t"
 		    "v_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0\n\tv_mad_i64_i32 %0, vcc, %15, %16, %0\n\t"
 		    "v_mad_i64_i32 %0, vcc, %17, %18, %0\n\tv_mad_i64_i32 %0, vcc, %19, %20, %0\n\tv_mad_i64_i32 %0, vcc, %21, %22, %0\n\tv_mad_i64_i32 %0, vcc, %23, %24, %0"
 		    : "=&v"(d) : "v"(xr[-1]), "s"(q[0]), "v"(xr[-2]), "s"(q[1]), "v"(xr[-3]), "s"(q[2]), "v"(xr[-4]), "s"(q[3]), "v"(xr[-5]), "s"(q[4]), "v"(xr[-6]), "s"(q[5]),
-		      "v"(xr[-7]), "s"(q[6]), "v"(xr[-8]), "s"(q[7]), "v"(xr[-9]), "s"(q[8]), "v"(xr[-10]), "s"(q[9]), "v"(xr[-11]), "s"(q[10]), "v"(xr[-12]), "s"(q[11]) : "vcc");
+		      "v"(xr[-7]), "s"(q[6]), "v"(xr[-8]), "s"(q[7]), "v"(xr[-9]), "s"(q[8]), "v"(xr[-10]), "s"(q[9]), "v"(xr[-11]), "s"(q[10]), "v"(xr[-12]), "s"(q[11]), "v"(init) : "vcc");
 	return d;
 }
 __device__ __forceinline__ uint32_t sad_u32_vs(uint32_t a, uint32_t b_uniform, uint32_t c)
@@ -89,6 +89,7 @@ template <int NT, bool WIDE, bool FIRST>
 __device__ __forceinline__ uint32_t fir16_w(const int32_t (&x)[28], const uint32_t (&xm)[16], const EwSlot &C, bool lane0, uint32_t sum0)
 {
 	uint32_t acc = 0;
+	const uint64_t init64 = (uint64_t)0x80000000u << C.shift;
 #pragma unroll
 	for(int s = 0; s < 16; s++) {
 		if constexpr(!WIDE) {
@@ -97,8 +98,10 @@ __device__ __forceinline__ uint32_t fir16_w(const int32_t (&x)[28], const uint32
 			acc = sad_u32_vs(pb, C.bias, acc);
 		}
 		else {
-			const uint64_t sum = mad64_chain_s<NT>(&x[12 + s], C.q);
-			uint32_t pm = __builtin_amdgcn_alignbit((uint32_t)(sum >> 32), (uint32_t)sum, C.shift) ^ 0x80000000u;
+			// the chain starts at 2^31 << shift: the low word of (sum >> shift) then comes out with its sign bit flipped, ready for the
+			// unsigned |x - p| (adding 2^31 modulo 2^32 is that flip)
+			const uint64_t sum = mad64_chain_s<NT>(&x[12 + s], C.q, init64);
+			uint32_t pm = __builtin_amdgcn_alignbit((uint32_t)(sum >> 32), (uint32_t)sum, C.shift);
 			if(FIRST && s < NT) { if(lane0 && (uint32_t)s < C.order) pm = xm[s]; }
 			acc = sad_u32(xm[s], pm, acc);
 		}
