@@ -1274,6 +1274,7 @@ __global__ __launch_bounds__(EVAL_MAX_WAVES * 64, EVAL_WAVES_PER_SIMD) void eval
 using namespace flacgpu;
 
 namespace flacgpu {
+static uint32_t ilog2_host(uint32_t v) { uint32_t l = 0; while(v >>= 1) l++; return l; }
 // (channels per workgroup, wavefronts per workgroup) of the owner-layout evaluation
 static void eval_shape(const DevParams &P, uint32_t &cpw, uint32_t &waves)
 {
@@ -1315,6 +1316,18 @@ size_t analyze_lds_bytes(const DevParams &P)
 	return a > d ? (a > g ? a : g) : (d > g ? d : g);
 }
 
+// A 16-bit stream whose leaf partitions are so long that the reference sums them in 64 bits (stream_encoder.c:4814: few partitions
+// of a long block) has no channel evalg_kernel takes (it wants the 32-bit sums) and none evalw_kernel takes (it wants 32-bit
+// planes): everything would travel through both lists to eval_list_kernel's fixed grid.  Such streams keep the round-2 launch.
+static bool evalg_worthwhile(const DevParams &P)
+{
+	if(P.bps > 16) return true;
+	uint32_t fmax = 0;
+	{ uint32_t b = P.blocksize; while(b && !(b & 1)) { fmax++; b >>= 1; } }
+	if(fmax > P.max_po) fmax = P.max_po;
+	const uint32_t psize = P.blocksize >> fmax;
+	return (P.bps + 4) < 32 - ilog2_host(psize);
+}
 template <int MAXORD>
 static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, const JobTable *jtm, const JobTable *jtt,
                                     const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
@@ -1372,7 +1385,7 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		const uint32_t grid = nframes * P.ncand < 1024u ? nframes * P.ncand : 1024u;
 		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(4 * 64), eval_layout(P, 4, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
 	}
-	else if(op && evalg_applicable(P) && !B.dbg) {
+	else if(op && evalg_applicable(P) && !B.dbg && evalg_worthwhile(P)) {
 		// one wavefront per channel: 16-bit pairs (flacgpu_evalg.hip), then the 32-bit channels it listed (flacgpu_evalw.hip) -- or
 		// those straight away when the stream has more than 16 bits --, and what neither takes through the workgroup-per-channel
 		// body above, a fixed grid looping over the last list
