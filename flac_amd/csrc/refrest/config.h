@@ -9,8 +9,14 @@
 #define CPU_IS_BIG_ENDIAN 0
 #define WORDS_BIGENDIAN 0
 #define ENABLE_64_BIT_WORDS 1
+/* HAS_OGG=1 on the make command line (flac_amd/csrc/Makefile) builds the reference's Ogg decoder half against the system's libogg */
+#ifdef FLACGPU_DROPIN_HAS_OGG
+#define OGG_FOUND 1
+#define FLAC__HAS_OGG 1
+#else
 #define OGG_FOUND 0
 #define FLAC__HAS_OGG 0
+#endif
 #define FLAC__HAS_X86INTRIN 1
 #define FLAC__HAS_NEONINTRIN 0
 #define FLAC__HAS_A64NEONINTRIN 0

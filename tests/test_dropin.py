@@ -101,3 +101,31 @@ def test_already_linked_flac_encodes_the_same_files_with_either_library(tmp_path
     out = str(tmp_path / "back.wav")
     r = _run(REFD, ["-s", "-f", "-d", "-o", out, b])
     assert r.returncode == 0 and open(out, "rb").read() == open(wav, "rb").read()
+
+
+@needs
+def test_ogg_capability_flag_describes_the_encoder_only(tmp_path):
+    """INTEGRATION.md, "What the binary drop-in does not do": libogg is not under /root/reference, so the reference's decoder and
+    metadata halves are compiled into the drop-in with FLAC__HAS_OGG 0 while the encoder (this project's, with its own paging) does
+    write Ogg FLAC.  FLAC_API_SUPPORTS_OGG_FLAC = 1 is therefore true of the encoder only: the decoder's init_ogg_* answer
+    UNSUPPORTED_CONTAINER (stream_decoder.c:383: what a libFLAC built without libogg answers), cleanly and before touching the file."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(OURS, "libFLAC.so.14"))
+    assert ctypes.c_int.in_dll(lib, "FLAC_API_SUPPORTS_OGG_FLAC").value == 1
+    lib.FLAC__stream_decoder_new.restype = ctypes.c_void_p
+    lib.FLAC__stream_decoder_init_ogg_file.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.FLAC__stream_decoder_init_file.argtypes = lib.FLAC__stream_decoder_init_ogg_file.argtypes
+    lib.FLAC__stream_decoder_delete.argtypes = [ctypes.c_void_p]
+    WR = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+    ER = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
+    wr, er = WR(lambda *a: 0), ER(lambda *a: None)
+    p = tmp_path / "x.oga"
+    p.write_bytes(b"OggS" + bytes(60))
+    dec = lib.FLAC__stream_decoder_new()
+    assert dec
+    rc = lib.FLAC__stream_decoder_init_ogg_file(dec, str(p).encode(), ctypes.cast(wr, ctypes.c_void_p), None, ctypes.cast(er, ctypes.c_void_p), None)
+    assert rc == 1                  # FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER
+    # the decoder object is still usable for native FLAC
+    rc = lib.FLAC__stream_decoder_init_file(dec, str(p).encode(), ctypes.cast(wr, ctypes.c_void_p), None, ctypes.cast(er, ctypes.c_void_p), None)
+    assert rc == 0
+    lib.FLAC__stream_decoder_delete(dec)
