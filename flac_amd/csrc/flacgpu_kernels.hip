@@ -569,6 +569,15 @@ __device__ __forceinline__ void or_bits(uint32_t *buf, uint32_t cap_words, uint3
 	atomicOr(&buf[w + 1], (uint32_t)t);
 }
 
+// The same for a code inside a run that is known to end inside the image (no clamp), from 32-bit shifts that take their count
+// from the low five bits of pos themselves: hi = X >> o, lo = {X, 0} >> o, X = the code left-aligned in a word
+__device__ __forceinline__ void or_code_fit(uint32_t *buf, uint32_t pos, uint32_t x_left)
+{
+	uint32_t *w = (uint32_t *)((unsigned char *)buf + ((pos >> 3) & ~3u));
+	atomicOr(w, x_left >> (pos & 31));
+	atomicOr(w + 1, __builtin_amdgcn_alignbit(x_left, 0u, pos & 31));
+}
+
 constexpr uint32_t P2_XSPAN = 512;           // span shifts kept in LDS (frames up to 32 KiB; longer ones read the global table)
 struct Pack2Shared {
 	uint32_t wtot[2][TPB / 64];
@@ -696,7 +705,7 @@ __device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[32], const int32
 // -0 .. -2 (72 runs: 256 threads would idle three in four)
 template <int MAXORD, bool HINTS, int NT>
 #ifndef PACK2_WAVES
-#define PACK2_WAVES 4
+#define PACK2_WAVES 5
 #endif
 __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams P, const int32_t *__restrict__ chan,
                                                     uint32_t nmain, uint64_t first_frame_number,
@@ -859,6 +868,10 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 			const uint32_t psize = n >> po;
 			PSTAMP(2 + 4 * s);
 			const int fmode = fir_mode(wide, sbps);
+			// warm-up samples, verbatim: lane i fetches sample i itself and writes it when the residual passes are through (thread 0 used
+			// to write them one after the other out of its window: a serial stretch of `order` LDS round trips in front of the barrier)
+			uint32_t warm_v = 0;
+			if((uint32_t)tid < order) warm_v = fmt16 ? (uint32_t)(int32_t)((const int16_t *)src)[tid] : src[tid];
 			for(uint32_t base0 = 0; base0 < n; base0 += CHUNK * NT) {
 				const uint32_t base = base0 + CHUNK * (uint32_t)tid;
 				const bool active = base < n;
@@ -875,13 +888,6 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 							uint4 h0 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);
 							if(base) { h0 = ((const uint4 *)src)[base / 8 - 2]; h1 = ((const uint4 *)src)[base / 8 - 1]; }
 							A[0] = h0.x; A[1] = h0.y; A[2] = h0.z; A[3] = h0.w; A[4] = h1.x; A[5] = h1.y; A[6] = h1.z; A[7] = h1.w;
-						}
-						if(base == 0 && order) {
-							// warm-up samples, verbatim (thread 0 of pass 0 holds them)
-							for(uint32_t i = 0; i < order; i++) {
-								const uint32_t wv = A[8 + i / 2];
-								or_bits(img, cap_words, warm_pos + i * sbps, (uint32_t)((i & 1) ? ((int32_t)wv >> 16) : (int32_t)(int16_t)(wv & 0xffffu)) & smask, sbps);
-							}
 						}
 						if(!wide) {
 							const uint32_t np = (order + 1) / 2;
@@ -910,12 +916,6 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 							const uint4 a = ((const uint4 *)src)[base / 4 + kk];
 							x[16 + 4 * kk] = (int32_t)a.x; x[16 + 4 * kk + 1] = (int32_t)a.y; x[16 + 4 * kk + 2] = (int32_t)a.z; x[16 + 4 * kk + 3] = (int32_t)a.w;
 						}
-						if(base == 0 && order) for(uint32_t i = 0; i < order; i++) {
-							uint32_t v = 0;
-#pragma unroll
-							for(int kk = 0; kk < CHUNK; kk++) if((uint32_t)kk == i) v = (uint32_t)x[16 + kk];
-							or_bits(img, cap_words, warm_pos + i * sbps, v & smask, sbps);
-						}
 						if(fmode == 0) {
 							if(MAXORD >= 16 && order > 12) pack_fir_i32<MAXORD >= 16 ? 16 : 4, 0>(x, q, shift, r);
 							else if(MAXORD >= 12 && order > 8) pack_fir_i32<MAXORD >= 12 ? 12 : 4, 0>(x, q, shift, r);
@@ -935,6 +935,7 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 						const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
 						const uint32_t cb = (u >> k) + 1 + k;
 						mybits += (base == 0 && (uint32_t)t < order) ? 0u : cb;
+						r[t] = (int32_t)u;                 // the write phase wants the folded value, not the residual
 					}
 				}
 				PSTAMP(3 + 4 * s);
@@ -952,19 +953,25 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 					// the verify pass decodes a run per thread (flacgpu_decode_hinted.h): it is told where this one starts
 					if(HINTS && base0 == 0) hints[((size_t)f * C + s) * HINT_RUNS + (uint32_t)tid] = p;
 					if(starts) { or_bits(img, cap_words, p, k, plen); p += plen; }
+					// a run that ends inside the image writes without clamping its word index; one that does not belongs to a frame
+					// that overflows its slot and is discarded (frame_bytes = ~0): its codes are not written at all
+					if(pos + woff + incl <= cap_words * 32u) {
+						const uint32_t stop = 1u << k, low = stop - 1u, lsh = 31u - k;
 #pragma unroll
-					for(int t = 0; t < CHUNK; t++) {
-						if(!(base == 0 && (uint32_t)t < order)) {
-							const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
-							const uint32_t msbs = u >> k;
-							or_bits(img, cap_words, p + msbs, (1u << k) | (u & ((1u << k) - 1u)), k + 1);
-							p += msbs + 1 + k;
+						for(int t = 0; t < CHUNK; t++) {
+							if(!(base == 0 && (uint32_t)t < order)) {
+								const uint32_t u = (uint32_t)r[t];
+								p += u >> k;
+								or_code_fit(img, p, ((u & low) | stop) << lsh);
+								p += 1 + k;
+							}
 						}
 					}
 				}
 				pos += total;
 				PSTAMP(5 + 4 * s);
 			}
+			if((uint32_t)tid < order) or_bits(img, cap_words, warm_pos + (uint32_t)tid * sbps, warm_v & smask, sbps);
 		}
 		if(tid == 0 && info) {
 			flacgpu_subframe_info *si = &info[f].sub[s];

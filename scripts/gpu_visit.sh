@@ -45,6 +45,7 @@ for step in "$@"; do
         rm -rf $OUT/pmc$j
       done
       cat $OUT/pmc_counters_$i.txt ;;
+    abn) r=${arg%% *}; rest=""; [ "$r" != "$arg" ] && rest=${arg#* }; bash scripts/gpu_abn.sh $r $rest 2>&1 | tee $OUT/abn_$i.txt ;;
     ab) r=${arg%% *}; rest=""; [ "$r" != "$arg" ] && rest=${arg#* }; bash scripts/gpu_ab.sh $r $rest 2>&1 | tee $OUT/ab_$i.txt ;;
     sh) bash scripts/$arg 2>&1 | tee $OUT/sh_$i.txt ;;
     *) echo "unknown step $step" ;;
