@@ -552,7 +552,14 @@ __global__ __launch_bounds__(TPB, AUTOC_WAVES_PER_SIMD) void autoc_kernel(const 
 // model_kernel
 // ---------------------------------------------------------------------------------------------------------
 template <int MAXORD>
-__global__ __launch_bounds__(TPB) void model_kernel(const DevParams P, uint32_t nframes, uint32_t tail_n,
+// A lane runs a whole Levinson-Durbin recursion and the quantisation searches behind it: a long dependent fp64 chain, latency bound.
+// Left alone the compiler takes 189 registers for the 12-tap instance (two wavefronts per SIMD); bounded to 128 it spills nothing
+// that matters and four wavefronts hide each other's latency: 0.087 -> 0.070 ms per 16384 frames (five: spills, 0.138;
+// profiles/r03_z_model_waves_ab.txt).  The instances for more than 12 taps keep their registers (they would spill their tap arrays).
+#ifndef MODEL_WAVES_PER_SIMD
+#define MODEL_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(TPB, MAXORD <= 12 ? MODEL_WAVES_PER_SIMD : 2) void model_kernel(const DevParams P, uint32_t nframes, uint32_t tail_n,
                                                     const JobTable *__restrict__ jt_main, const JobTable *__restrict__ jt_tail,
                                                     const ChanPrep *__restrict__ preps, const double *__restrict__ autoc_in,
                                                     Candidate *__restrict__ cands, int *__restrict__ valid, uint32_t *__restrict__ nleft)
