@@ -14,6 +14,9 @@ TAG=${1:-visit}; shift || true
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# a box whose GPU does not answer a trivial kernel within a minute, or whose test step fails, gets no further steps: a visit once
+# spent 25 GPU-minutes in the timeouts of counter passes behind a memory fault in the first process
+timeout 90 python -c "import torch; print('gpu ok', float(torch.ones(4, device='cuda').sum()))" || { echo "GPU health check failed: visit abandoned"; exit 3; }
 i=0
 for step in "$@"; do
   i=$((i+1))
@@ -23,7 +26,8 @@ for step in "$@"; do
     tests)
       if [ -n "$arg" ]; then FLACGPU_POISON=1 timeout 1500 python -m pytest tests -x -q -m gpu -k "$arg" > $OUT/pytest_$i.log 2>&1
       else FLACGPU_POISON=1 timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest_$i.log 2>&1; fi
-      echo "[$i] pytest rc=$?"; tail -4 $OUT/pytest_$i.log ;;
+      rc=$?; echo "[$i] pytest rc=$rc"; tail -4 $OUT/pytest_$i.log
+      [ $rc -ne 0 ] && { echo "test step failed: visit abandoned"; exit 4; } ;;
     bench)
       timeout 900 python bench.py $arg > $OUT/bench_$i.json 2> $OUT/bench_$i.err; echo "[$i] bench $arg rc=$?"; cat $OUT/bench_$i.json; tail -2 $OUT/bench_$i.err ;;
     prof)
