@@ -460,6 +460,8 @@ def main():
                                                  "profiles/*pmc*); the HBM fraction is reported because the north star asks for it; traffic = (2*FETCH_SIZE+WRITE_SIZE) "
                                                  "of the committed PMC pass scaled to this batch; whole_step_frac prices the whole step instead of its dominant kernel"),
         }
+        if "roofline_valu" in m:
+            line["roofline_valu"] = m["roofline_valu"]
         if "verified" in m:
             line["verified_frames"] = m["verified"]["frames_compared_with_oracle"]
             line["verified"] = m["verified"]

@@ -646,13 +646,24 @@ __device__ __forceinline__ void store_image(const uint32_t *img, uint8_t *dst, u
 	if((uint32_t)tid < nb - done) { const uint32_t k = done + (uint32_t)tid; dst[k] = (uint8_t)(img[k >> 2] >> (24 - 8 * (k & 3))); }
 }
 
-// residuals of this thread's 16 samples from the packed window A[0..15] (A[0..7] = the 16 samples in front)
+// dot2_chain_lshr (flacgpu_devfn.h) with the tap pairs in scalar registers: they are the same for the whole subframe
 template <int NP>
-__device__ __forceinline__ void pack_fir_packed(const uint32_t (&A)[16], const int32_t *q, uint32_t shift, int32_t (&r)[CHUNK])
+__device__ __forceinline__ uint32_t dot2_chain_lshr_s(const uint32_t (&W)[NP], const uint32_t (&Q)[8], int32_t sum0, uint32_t shift)
 {
-	uint32_t Q[NP], B[15];
-#pragma unroll
-	for(int p = 0; p < NP; p++) Q[p] = ((uint32_t)q[2 * p] << 16) | ((uint32_t)q[2 * p + 1] & 0xffffu);
+	uint32_t d;
+	static_assert(NP == 2 || NP == 4 || NP == 6 || NP == 8, "instantiated pair counts");
+	if constexpr(NP == 2) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_lshrrev_b32 %0, %6, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "s"(shift));
+	if constexpr(NP == 4) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_lshrrev_b32 %0, %10, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "v"(W[2]), "s"(Q[2]), "v"(W[3]), "s"(Q[3]), "s"(shift));
+	if constexpr(NP == 6) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_lshrrev_b32 %0, %14, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "v"(W[2]), "s"(Q[2]), "v"(W[3]), "s"(Q[3]), "v"(W[4]), "s"(Q[4]), "v"(W[5]), "s"(Q[5]), "s"(shift));
+	if constexpr(NP == 8) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_dot2_i32_i16 %0, %6, %7, %0\n\tv_dot2_i32_i16 %0, %8, %9, %0\n\tv_dot2_i32_i16 %0, %10, %11, %0\n\tv_dot2_i32_i16 %0, %12, %13, %0\n\tv_dot2_i32_i16 %0, %14, %15, %0\n\tv_dot2_i32_i16 %0, %16, %17, %0\n\tv_lshrrev_b32 %0, %18, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "v"(W[2]), "s"(Q[2]), "v"(W[3]), "s"(Q[3]), "v"(W[4]), "s"(Q[4]), "v"(W[5]), "s"(Q[5]), "v"(W[6]), "s"(Q[6]), "v"(W[7]), "s"(Q[7]), "s"(shift));
+	return d;
+}
+// residuals of this thread's 16 samples from the packed window A[0..15] (A[0..7] = the 16 samples in front); Q[p] = taps 2p, 2p+1 as
+// an int16 pair, wave-uniform
+template <int NP>
+__device__ __forceinline__ void pack_fir_packed(const uint32_t (&A)[16], const uint32_t (&Q)[8], uint32_t shift, int32_t (&r)[CHUNK])
+{
+	uint32_t B[15];
 #pragma unroll
 	for(int m = 0; m < 15; m++) B[m] = __builtin_amdgcn_alignbit(A[m + 1], A[m], 16);
 	const uint32_t bias = 0x80000000u >> shift;
@@ -663,7 +674,7 @@ __device__ __forceinline__ void pack_fir_packed(const uint32_t (&A)[16], const i
 		uint32_t W[NP];
 #pragma unroll
 		for(int p = 0; p < NP; p++) W[p] = (u & 1) ? B[(u - 3) / 2 - p] : A[(u - 2) / 2 - p];
-		const uint32_t pb = dot2_chain_lshr<NP>(W, Q, sum0, shift);                     // prediction + bias (see flacgpu_devfn.h)
+		const uint32_t pb = dot2_chain_lshr_s<NP>(W, Q, sum0, shift);                   // prediction + bias (see flacgpu_devfn.h)
 		const uint32_t xb = bias + (uint32_t)((u & 1) ? ((int32_t)A[u / 2] >> 16) : (int32_t)(int16_t)(A[u / 2] & 0xffffu));
 		r[s] = (int32_t)(xb - pb);
 	}
@@ -715,7 +726,7 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
                                                     uint32_t *__restrict__ hints)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave: a scalar register)
 	const uint32_t C = P.channels, N = P.blocksize, n = N;
 	uint32_t *img = (uint32_t *)smem;
 	const uint32_t cap_words = P.slot_bytes / 4;
@@ -728,6 +739,7 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 		__syncthreads();
 		f = sh->ticket;
 	}
+	f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);        // (the same in every lane either way: the frame's addresses are scalar registers)
 #define PSTAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
 	PSTAMP(0);
 	const SubDecision *dec = decisions + (size_t)f * P.ncand;
@@ -865,13 +877,16 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 				abs_sum = UNI(abs_sum);
 				wide = silog2_i64((int64_t)(((uint64_t)1 << (sbps - 1)) * abs_sum)) > 32;
 			}
+			// the taps as int16 pairs in scalar registers for the packed-sample chains (they are the subframe's, not the thread's)
+			uint32_t QP[8];
+#pragma unroll
+			for(int pp = 0; pp < 8; pp++) {
+				const uint32_t hi = 2 * pp < MAXORD ? (uint32_t)q[2 * pp < MAXORD ? 2 * pp : 0] : 0u, lo = 2 * pp + 1 < MAXORD ? (uint32_t)q[2 * pp + 1 < MAXORD ? 2 * pp + 1 : 0] : 0u;
+				QP[pp] = 2 * pp < MAXORD ? UNI((hi << 16) | (lo & 0xffffu)) : 0u;
+			}
 			const uint32_t psize = n >> po;
 			PSTAMP(2 + 4 * s);
 			const int fmode = fir_mode(wide, sbps);
-			// warm-up samples, verbatim: lane i fetches sample i itself and writes it when the residual passes are through (thread 0 used
-			// to write them one after the other out of its window: a serial stretch of `order` LDS round trips in front of the barrier)
-			uint32_t warm_v = 0;
-			if((uint32_t)tid < order) warm_v = fmt16 ? (uint32_t)(int32_t)((const int16_t *)src)[tid] : src[tid];
 			for(uint32_t base0 = 0; base0 < n; base0 += CHUNK * NT) {
 				const uint32_t base = base0 + CHUNK * (uint32_t)tid;
 				const bool active = base < n;
@@ -891,10 +906,10 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 						}
 						if(!wide) {
 							const uint32_t np = (order + 1) / 2;
-							if(MAXORD >= 16 && np > 6) pack_fir_packed<MAXORD >= 16 ? 8 : 2>(A, q, (uint32_t)shift, r);
-							else if(MAXORD >= 12 && np > 4) pack_fir_packed<MAXORD >= 12 ? 6 : 2>(A, q, (uint32_t)shift, r);
-							else if(np > 2) pack_fir_packed<4>(A, q, (uint32_t)shift, r);
-							else pack_fir_packed<2>(A, q, (uint32_t)shift, r);
+							if(MAXORD >= 16 && np > 6) pack_fir_packed<MAXORD >= 16 ? 8 : 2>(A, QP, (uint32_t)shift, r);
+							else if(MAXORD >= 12 && np > 4) pack_fir_packed<MAXORD >= 12 ? 6 : 2>(A, QP, (uint32_t)shift, r);
+							else if(np > 2) pack_fir_packed<4>(A, QP, (uint32_t)shift, r);
+							else pack_fir_packed<2>(A, QP, (uint32_t)shift, r);
 						}
 						else {
 							int32_t x[32];
@@ -946,6 +961,7 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 				uint32_t woff = 0, total = 0;
 #pragma unroll
 				for(int w = 0; w < NT / 64; w++) { const uint32_t tw = sh->wtot[scan_buf][w]; if(w < wave) woff += tw; total += tw; }
+				woff = UNI(woff); total = UNI(total);          // the same in every lane of a wavefront: the running bit position stays a scalar
 				scan_buf ^= 1;
 				PSTAMP(4 + 4 * s);
 				if(active) {
@@ -956,13 +972,15 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 					// a run that ends inside the image writes without clamping its word index; one that does not belongs to a frame
 					// that overflows its slot and is discarded (frame_bytes = ~0): its codes are not written at all
 					if(pos + woff + incl <= cap_words * 32u) {
-						const uint32_t stop = 1u << k, low = stop - 1u, lsh = 31u - k;
+						// the code left-aligned in a word: stop bit, then the k low bits of u.  u << (31 - k) puts them there; what it leaves in
+						// bit 31 (bit k of u) is covered by the stop bit, everything above has left the word
+						const uint32_t lsh = 31u - k;
 #pragma unroll
 						for(int t = 0; t < CHUNK; t++) {
 							if(!(base == 0 && (uint32_t)t < order)) {
 								const uint32_t u = (uint32_t)r[t];
 								p += u >> k;
-								or_code_fit(img, p, ((u & low) | stop) << lsh);
+								or_code_fit(img, p, (u << lsh) | 0x80000000u);
 								p += 1 + k;
 							}
 						}
@@ -971,7 +989,13 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 				pos += total;
 				PSTAMP(5 + 4 * s);
 			}
-			if((uint32_t)tid < order) or_bits(img, cap_words, warm_pos + (uint32_t)tid * sbps, warm_v & smask, sbps);
+			// warm-up samples, verbatim: lane i of the first wavefront fetches sample i itself (thread 0 used to write them one after the
+			// other out of its window: a serial stretch of `order` LDS round trips in front of the barrier everybody waits at); the lines
+			// were read by thread 0 a moment ago
+			if((uint32_t)tid < order) {
+				const uint32_t warm_v = fmt16 ? (uint32_t)(int32_t)((const int16_t *)src)[tid] : src[tid];
+				or_bits(img, cap_words, warm_pos + (uint32_t)tid * sbps, warm_v & smask, sbps);
+			}
 		}
 		if(tid == 0 && info) {
 			flacgpu_subframe_info *si = &info[f].sub[s];
