@@ -11,8 +11,8 @@ import wave
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import signals  # noqa: E402
+sys.path.insert(0, ROOT)
+from flac_amd import signals  # noqa: E402
 
 minutes = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 base = signals.music(44100 * 60, 2, 16, seed=11)
