@@ -33,8 +33,12 @@ struct Prep2Acc {
 // samples in front of the block), rows P2_TS(n) words apart.  A lane that owns the 16 samples of chunk t reads
 // row r at column t+1 -- consecutive lanes, consecutive words, no address arithmetic (ds_read offsets); the staging
 // store of 32 consecutive samples hits 32 banks because the row stride is 2 mod 32.
-__host__ __device__ inline uint32_t p2_ts(uint32_t n) { const uint32_t nch = (n + CHUNK - 1) / CHUNK; return ((nch - 1 + 31) / 32) * 32 + 2; }
-__host__ __device__ inline uint32_t p2_chan_bytes(uint32_t n) { return CHUNK * p2_ts(n) * 4; }
+__host__ __device__ inline uint32_t p2_ts(uint32_t n, uint32_t ch = CHUNK) { const uint32_t nch = (n + ch - 1) / ch; return ((nch - 1 + 31) / 32) * 32 + 2; }
+__host__ __device__ inline uint32_t p2_chan_bytes(uint32_t n, uint32_t ch = CHUNK) { return ch * p2_ts(n, ch) * 4; }
+// The chunk a lane owns in prep2_kernel: 16 samples, except for the 1152-sample blocks of the presets -0 .. -2, where 16 makes 72
+// chunks -- a full pass of the wavefront and one with eight lanes -- and 18 makes 64: one pass, every lane busy.  (1152 = 18 * 64, and
+// every partition the Rice search may ask for, 1152 >> 0..6, is a whole number of 18-sample chunks.)
+__host__ __device__ constexpr uint32_t p2_chunk_len(uint32_t blocksize) { return blocksize == 1152 ? 18u : (uint32_t)CHUNK; }
 
 // statistics of the 16 samples x[4..19] of a chunk (x[0..3] = the four samples in front of them).
 // Sums are taken on the UNSHIFTED signal: every |difference| is a multiple of 2^wasted, so the sums of the shifted
@@ -44,8 +48,8 @@ __host__ __device__ inline uint32_t p2_chan_bytes(uint32_t n) { return CHUNK * p
 // PARTS (the presets without an LPC search, prep2_kernel<.,.,true>): cs[k] = this chunk's sum for order k, as added to A.e[k];
 // ex[k] = what the residual of order k has IN FRONT of sample 4 (samples k..3: the predictor estimate skips them, the residual
 // of the chosen order does not, stream_encoder.c:4100 vs :4456)
-template <bool WIDE, bool MAG = false, bool PARTS = false>
-__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_chunk, int32_t first, Prep2Acc &A, uint32_t *cs = nullptr, uint32_t *ex = nullptr)
+template <bool WIDE, bool MAG = false, bool PARTS = false, int CH = CHUNK>
+__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[CH + 4], bool first_chunk, int32_t first, Prep2Acc &A, uint32_t *cs = nullptr, uint32_t *ex = nullptr)
 {
 	constexpr uint32_t M = 0x80000000u;
 	uint32_t s[5] = {0, 0, 0, 0, 0};
@@ -53,7 +57,7 @@ __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[20], bool first_c
 	int32_t d1p = x[3] - x[2], d2p = (x[3] - x[2]) - (x[2] - x[1]), d3p = ((x[3] - x[2]) - (x[2] - x[1])) - ((x[2] - x[1]) - (x[1] - x[0]));
 	uint32_t xbp = (uint32_t)x[3] ^ M;
 #pragma unroll
-	for(int t = 0; t < CHUNK; t++) {
+	for(int t = 0; t < CH; t++) {
 		const int32_t a0 = x[t + 4];
 		A.orv |= (uint32_t)a0; A.diff |= (uint32_t)(a0 ^ first);
 		if(MAG) A.mag |= (uint32_t)(a0 ^ (a0 >> 31));
@@ -107,8 +111,9 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 	const bool stereo_ms = C == 2 && P.ms_mode != 0;
 	const uint32_t G = stereo_ms ? 2u : (C < 4 ? C : 4u);            // raw channels staged per round
 	const uint32_t cstride = P.ncslots;
-	const uint32_t nchunks = n / CHUNK;
-	const uint32_t TS = NFIX ? ((NFIX / CHUNK - 1 + 31) / 32) * 32 + 2 : p2_ts(n), cbytes = CHUNK * TS * 4;       // (p2_ts, p2_chan_bytes)
+	constexpr uint32_t CH = p2_chunk_len(NFIX);                          // samples a lane owns per pass (18 for the 1152-sample blocks)
+	const uint32_t nchunks = n / CH;
+	const uint32_t TS = NFIX ? ((NFIX / CH - 1 + 31) / 32) * 32 + 2 : p2_ts(n), cbytes = CH * TS * 4;       // (p2_ts, p2_chan_bytes)
 	const bool need_flags = P.limit_min_bitrate || P.ms_mode == 2;
 	// DECIDE: [divisor table][per wavefront: chunk sums 5 x nchunks | the first chunk's extras 8 | Rice parameters 64 B] behind the staged channels
 	const uint32_t dz_base = (stereo_ms ? 2u : (C < 4 ? C : 4u)) * cbytes;
@@ -128,8 +133,23 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 			}
 		}
 		// ---- stage the raw channels -------------------------------------------------------------------------
-		if(tid < CHUNK) for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * cbytes))[(uint32_t)tid * TS] = 0;
-		{
+		if(tid < (int)CH) for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * cbytes))[(uint32_t)tid * TS] = 0;
+		if(CH != CHUNK) {
+			// sample i: row i % CH, column i / CH + 1 (the division by a constant is a multiply; nine trips per thread at 1152 / 128)
+			if(C == 2) {
+				int32_t *sl = (int32_t *)smem, *sr = (int32_t *)(smem + cbytes);
+				const int2 *p = (const int2 *)frame_pcm;
+#pragma unroll 9
+				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) { const uint32_t c = i / CH, a = (i - c * CH) * TS + c + 1; const int2 lr = p[i]; sl[a] = lr.x; sr[a] = lr.y; }
+			}
+			else {
+				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) {
+					const uint32_t c = i / CH, a = (i - c * CH) * TS + c + 1;
+					for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * cbytes))[a] = frame_pcm[(size_t)i * C + c0 + r];
+				}
+			}
+		}
+		else {
 			const uint32_t a0 = ((uint32_t)tid & 15u) * TS + ((uint32_t)tid >> 4) + 1;     // sample i = tid; i += nthreads moves nthreads/16 columns
 			if(C == 2) {
 				int32_t *sl = (int32_t *)smem, *sr = (int32_t *)(smem + cbytes);
@@ -167,21 +187,21 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 				first = mode == 0 ? a : mode == 1 ? b : mode == 2 ? ((a + b) >> 1) : (a - b);
 			}
 			for(uint32_t ch = (uint32_t)lane; ch < nchunks; ch += 64) {
-				// x[k] = sample 16*ch - 4 + k: rows 12..15 of column ch, then rows 0..15 of column ch+1
+				// x[k] = sample CH*ch - 4 + k: the last four rows of column ch, then the CH rows of column ch+1
 				const int32_t *pa = sa + ch, *pb = sb + ch;
-				int32_t x[20];
+				int32_t x[CH + 4];
 				if(mode == 0 && !loose_here) {
 #pragma unroll
-					for(int k = 0; k < 20; k++) x[k] = k < 4 ? pa[(12 + k) * TS] : pa[(k - 4) * TS + 1];
+					for(int k = 0; k < (int)CH + 4; k++) x[k] = k < 4 ? pa[(CH - 4 + k) * TS] : pa[(k - 4) * TS + 1];
 				}
 				else {
-					int32_t a[20], b[20];
+					int32_t a[CH + 4], b[CH + 4];
 #pragma unroll
-					for(int k = 0; k < 20; k++) { a[k] = k < 4 ? pa[(12 + k) * TS] : pa[(k - 4) * TS + 1]; b[k] = k < 4 ? pb[(12 + k) * TS] : pb[(k - 4) * TS + 1]; }
+					for(int k = 0; k < (int)CH + 4; k++) { a[k] = k < 4 ? pa[(CH - 4 + k) * TS] : pa[(k - 4) * TS + 1]; b[k] = k < 4 ? pb[(CH - 4 + k) * TS] : pb[(k - 4) * TS + 1]; }
 					if(loose_here) {
 						// loose mid/side (stream_encoder.c:3778-3807), bps < 25
 #pragma unroll
-						for(int t = 0; t < CHUNK; t++) {
+						for(int t = 0; t < (int)CH; t++) {
 							if(t > 0 || ch > 0) {
 								const int32_t pl = a[t + 4] - a[t + 3], pr = b[t + 4] - b[t + 3];
 								lr_sum += (uint64_t)(uint32_t)(abs(pl) + abs(pr));
@@ -190,12 +210,12 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 						}
 					}
 #pragma unroll
-					for(int k = 0; k < 20; k++) x[k] = mode == 0 ? a[k] : mode == 1 ? b[k] : mode == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
+					for(int k = 0; k < (int)CH + 4; k++) x[k] = mode == 0 ? a[k] : mode == 1 ? b[k] : mode == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
 				}
 				if(DECIDE) {
 					uint32_t cs[5], ex[5] = {0, 0, 0, 0, 0};
-					if(mode == 3) prep2_chunk<WIDE, true, true>(x, ch == 0, first, A, cs, ex);
-					else prep2_chunk<WIDE, false, true>(x, ch == 0, first, A, cs, ex);
+					if(mode == 3) prep2_chunk<WIDE, true, true, (int)CH>(x, ch == 0, first, A, cs, ex);
+					else prep2_chunk<WIDE, false, true, (int)CH>(x, ch == 0, first, A, cs, ex);
 #pragma unroll
 					for(int k = 0; k < 5; k++) dz_csum[(uint32_t)k * nchunks + ch] = cs[k];
 					if(ch == 0) {
@@ -203,8 +223,8 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 						for(int k = 0; k < 5; k++) dz_extra[k] = ex[k];
 					}
 				}
-				else if(mode == 3) prep2_chunk<WIDE, true>(x, ch == 0, first, A);
-				else prep2_chunk<WIDE>(x, ch == 0, first, A);
+				else if(mode == 3) prep2_chunk<WIDE, true, false, (int)CH>(x, ch == 0, first, A);
+				else prep2_chunk<WIDE, false, false, (int)CH>(x, ch == 0, first, A);
 			}
 			A.orv = wave_or_u32(A.orv);
 			A.diff = wave_or_u32(A.diff);
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 				uint32_t fmax = 0;
 				{ uint32_t b = n; while(!(b & 1)) { fmax++; b >>= 1; } if(fmax > 15) fmax = 15; }
 				fmax = umin32(fmax, P.max_po);                                         // (<= 6: prep2_decides)
-				const uint32_t fmin = umin32(P.min_po, fmax), e = 6 - fmax, cpp = (n >> fmax) / CHUNK;
+				const uint32_t fmin = umin32(P.min_po, fmax), e = 6 - fmax, cpp = (n >> fmax) / CH;
 				__builtin_amdgcn_wave_barrier();                                       // this wavefront's chunk sums are in LDS
 				uint32_t v = 0;
 				if(((uint32_t)lane & ((1u << e) - 1u)) == 0) {
@@ -328,17 +348,28 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 		// ---- planar channel, shifted ---------------------------------------------------------------------------
 		uint32_t *dst = (uint32_t *)(chan + fc * (size_t)N);
 		for(uint32_t ch = (uint32_t)lane; ch < nchunks; ch += 64) {
-			const uint32_t base = ch * CHUNK;
+			const uint32_t base = ch * CH;
 			const int32_t *pa = sa + ch + 1, *pb = sb + ch + 1;
-			int32_t x[CHUNK];
+			int32_t x[CH];
 #pragma unroll
-			for(int k = 0; k < CHUNK; k++) {
+			for(int k = 0; k < (int)CH; k++) {
 				const int32_t a = pa[k * TS];
 				int32_t v = a;
 				if(mode != 0) { const int32_t b = pb[k * TS]; v = mode == 1 ? b : mode == 2 ? ((a + b) >> 1) : (a - b); }
 				x[k] = v >> wasted;
 			}
-			if(fmt) {
+			if(CH != CHUNK) {
+				// 18 samples: nine words of pairs (or eighteen words) at a 36-byte (72-byte) lane stride: plain word stores
+				if(fmt) {
+#pragma unroll
+					for(int j = 0; j < (int)CH / 2; j++) dst[base / 2 + j] = ((uint32_t)x[2 * j] & 0xffffu) | ((uint32_t)x[2 * j + 1] << 16);
+				}
+				else {
+#pragma unroll
+					for(int j = 0; j < (int)CH; j++) dst[base + j] = (uint32_t)x[j];
+				}
+			}
+			else if(fmt) {
 				uint4 w0, w1;
 				w0.x = ((uint32_t)x[0] & 0xffffu) | ((uint32_t)x[1] << 16); w0.y = ((uint32_t)x[2] & 0xffffu) | ((uint32_t)x[3] << 16);
 				w0.z = ((uint32_t)x[4] & 0xffffu) | ((uint32_t)x[5] << 16); w0.w = ((uint32_t)x[6] & 0xffffu) | ((uint32_t)x[7] << 16);
@@ -569,7 +600,8 @@ bool prep2_applicable(const DevParams &P)
 // evaluation) must be able to take what this kernel leaves behind.
 static size_t prep2_decide_lds(const DevParams &P, uint32_t nraw, uint32_t waves)
 {
-	return (size_t)nraw * p2_chan_bytes(P.blocksize) + P2_DIVTAB_BYTES + (size_t)waves * ((5 * (P.blocksize / CHUNK) + 8) * 4 + 64);
+	const uint32_t ch = p2_chunk_len(P.blocksize);
+	return (size_t)nraw * p2_chan_bytes(P.blocksize, ch) + P2_DIVTAB_BYTES + (size_t)waves * ((5 * (P.blocksize / ch) + 8) * 4 + 64);
 }
 bool prep2_decides(const DevParams &P)
 {
@@ -585,7 +617,7 @@ bool prep2_decides(const DevParams &P)
 	const uint32_t psize = n >> fmax;
 	uint32_t lg = 0;
 	while((2u << lg) <= psize) lg++;
-	if(!(psize % CHUNK == 0 && (P.bps + 1 + 4) < 32 - lg)) return false;
+	if(!(psize % p2_chunk_len(n) == 0 && (P.bps + 1 + 4) < 32 - lg)) return false;
 	// the chunk sums of every wavefront behind the staged channels must still fit the LDS (6 channels x 8192 samples do not)
 	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u), waves = stereo_ms ? 4u : nraw;
@@ -621,7 +653,7 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
 	const uint32_t waves = stereo_ms ? 4u : nraw;
-	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize);
+	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize, p2_chunk_len(P.blocksize));
 #define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft)
 	if(prep2_decides(P)) {
 		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
