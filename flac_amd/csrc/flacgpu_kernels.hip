@@ -660,16 +660,17 @@ __device__ __forceinline__ uint32_t dot2_chain_lshr_s(const uint32_t (&W)[NP], c
 }
 // residuals of this thread's 16 samples from the packed window A[0..15] (A[0..7] = the 16 samples in front); Q[p] = taps 2p, 2p+1 as
 // an int16 pair, wave-uniform
-template <int NP>
-__device__ __forceinline__ void pack_fir_packed(const uint32_t (&A)[16], const uint32_t (&Q)[8], uint32_t shift, int32_t (&r)[CHUNK])
+// RUN: samples of the run (16, or 18 for the 1152-sample blocks: an even number, so a run is whole words of pairs)
+template <int NP, int RUN = CHUNK>
+__device__ __forceinline__ void pack_fir_packed(const uint32_t (&A)[8 + RUN / 2], const uint32_t (&Q)[8], uint32_t shift, int32_t (&r)[RUN])
 {
-	uint32_t B[15];
+	uint32_t B[7 + RUN / 2];
 #pragma unroll
-	for(int m = 0; m < 15; m++) B[m] = __builtin_amdgcn_alignbit(A[m + 1], A[m], 16);
+	for(int m = 0; m < 7 + RUN / 2; m++) B[m] = __builtin_amdgcn_alignbit(A[m + 1], A[m], 16);
 	const uint32_t bias = 0x80000000u >> shift;
 	const int32_t sum0 = (int32_t)0x80000000;
 #pragma unroll
-	for(int s = 0; s < CHUNK; s++) {
+	for(int s = 0; s < RUN; s++) {
 		const int u = 16 + s;
 		uint32_t W[NP];
 #pragma unroll
@@ -681,14 +682,14 @@ __device__ __forceinline__ void pack_fir_packed(const uint32_t (&A)[16], const u
 }
 // the same from 32-bit samples x[0..31] (x[16+s] = own sample s): FMODE 0 v_mad_i32_i24, 1 32-bit multiplies (lpc.c:321),
 // 2 64-bit accumulate (lpc.c:582)
-template <int NT, int FMODE>
-__device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[32], const int32_t *qg, int shift, int32_t (&r)[CHUNK])
+template <int NT, int FMODE, int RUN = CHUNK>
+__device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[16 + RUN], const int32_t *qg, int shift, int32_t (&r)[RUN])
 {
 	int32_t q[NT];
 #pragma unroll
 	for(int j = 0; j < NT; j++) q[j] = qg[j];
 #pragma unroll
-	for(int s = 0; s < CHUNK; s++) {
+	for(int s = 0; s < RUN; s++) {
 		if(FMODE == 0) {
 			uint32_t pb;
 			if(NT == 16) pb = mad24_chain<8, true>(&x[16 + s - 9], &q[8], mad24_chain<8, false>(&x[16 + s - 1], &q[0], 0, 0), (uint32_t)shift);
@@ -714,11 +715,15 @@ __device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[32], const int32
 // 8-tap instance its fifth workgroup per CU: only paid when verification is on)
 // NT: threads of the workgroup = 16-sample runs per pass: 256 for blocks of up to 4096 samples, 128 for the 1152-sample blocks of
 // -0 .. -2 (72 runs: 256 threads would idle three in four)
-template <int MAXORD, bool HINTS, int NT>
+// RUN: samples a thread owns per pass.  16; 18 for the 1152-sample blocks of -0 .. -2 (64 runs: ONE wavefront per frame, every lane
+// busy, instead of 72 runs on two wavefronts of which the second has eight lanes to do; without the verify hints, whose decoder
+// counts in 16-sample runs)
+template <int MAXORD, bool HINTS, int NT, int RUN = CHUNK>
 #ifndef PACK2_WAVES
 #define PACK2_WAVES 5
 #endif
-__global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams P, const int32_t *__restrict__ chan,
+__global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel(      // (one-wavefront workgroups: the LDS image allows four per SIMD, no more)
+                                                    const DevParams P, const int32_t *__restrict__ chan,
                                                     uint32_t nmain, uint64_t first_frame_number,
                                                     const SubDecision *__restrict__ decisions,
                                                     uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
@@ -790,8 +795,8 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 	}
 	else if(P.ms_mode == 2) ca = (uint32_t)__builtin_amdgcn_readfirstlane(ldec[0].which >= 2 ? 3 : 0);
 	const uint32_t frame_number = (uint32_t)(first_frame_number + f);
-	if(tid == 64) {
-		// one lane (of a wavefront that has no other single-lane duties) builds and writes the header while the others go on
+	if(tid == (NT > 64 ? 64 : 1)) {
+		// one lane (of a wavefront that has no other single-lane duties, where there is more than one) builds and writes the header while the others go on
 		(void)frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { or_bits(img, cap_words, 8 * k, byte, 8); });
 	}
 	uint32_t pos = 8 * frame_header_len(P, n, frame_number);
@@ -820,9 +825,20 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 			pos += sbps;
 		}
 		else if(type == 1) {
-			for(uint32_t base = CHUNK * (uint32_t)tid; base < n; base += CHUNK * NT) {
-				int32_t x[CHUNK];
-				if(fmt16) {
+			for(uint32_t base = RUN * (uint32_t)tid; base < n; base += RUN * NT) {
+				int32_t x[RUN];
+				if(RUN != CHUNK) {
+					// (runs of 18: word loads, a run starts at a multiple of 36 or 72 bytes)
+					if(fmt16) {
+#pragma unroll
+						for(int k = 0; k < RUN; k++) { const uint32_t w = src[base / 2 + (k >> 1)]; x[k] = (k & 1) ? ((int32_t)w >> 16) : (int32_t)(int16_t)(w & 0xffffu); }
+					}
+					else {
+#pragma unroll
+						for(int k = 0; k < RUN; k++) x[k] = (int32_t)src[base + k];
+					}
+				}
+				else if(fmt16) {
 					const uint4 a = ((const uint4 *)src)[base / 8], b = ((const uint4 *)src)[base / 8 + 1];
 					const uint32_t wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -833,7 +849,7 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 					for(int k = 0; k < 4; k++) { const uint4 a = ((const uint4 *)src)[base / 4 + k]; x[4 * k] = (int32_t)a.x; x[4 * k + 1] = (int32_t)a.y; x[4 * k + 2] = (int32_t)a.z; x[4 * k + 3] = (int32_t)a.w; }
 				}
 #pragma unroll
-				for(int k = 0; k < CHUNK; k++) or_bits(img, cap_words, pos + (base + (uint32_t)k) * sbps, (uint32_t)x[k] & smask, sbps);
+				for(int k = 0; k < RUN; k++) or_bits(img, cap_words, pos + (base + (uint32_t)k) * sbps, (uint32_t)x[k] & smask, sbps);
 			}
 			pos += n * sbps;
 		}
@@ -887,17 +903,24 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 			const uint32_t psize = n >> po;
 			PSTAMP(2 + 4 * s);
 			const int fmode = fir_mode(wide, sbps);
-			for(uint32_t base0 = 0; base0 < n; base0 += CHUNK * NT) {
-				const uint32_t base = base0 + CHUNK * (uint32_t)tid;
+			for(uint32_t base0 = 0; base0 < n; base0 += RUN * NT) {
+				const uint32_t base = base0 + RUN * (uint32_t)tid;
 				const bool active = base < n;
-				int32_t r[CHUNK];
+				int32_t r[RUN];
 				uint32_t mybits = 0, k = 0;
 				bool starts = false;
 				if(active) {
 					if(fmt16) {
 						// window words: A[0..7] = samples base-16..base-1, A[8..15] = own
-						uint32_t A[16];
-						{
+						uint32_t A[8 + RUN / 2];
+						if(RUN != CHUNK) {
+							// nine own words behind eight of history, all at word alignment
+#pragma unroll
+							for(int m = 0; m < RUN / 2; m++) A[8 + m] = src[base / 2 + m];
+#pragma unroll
+							for(int m = 0; m < 8; m++) A[m] = base ? src[base / 2 - 8 + m] : 0u;
+						}
+						else {
 							const uint4 c0 = ((const uint4 *)src)[base / 8], c1 = ((const uint4 *)src)[base / 8 + 1];
 							A[8] = c0.x; A[9] = c0.y; A[10] = c0.z; A[11] = c0.w; A[12] = c1.x; A[13] = c1.y; A[14] = c1.z; A[15] = c1.w;
 							uint4 h0 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);
@@ -906,20 +929,27 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 						}
 						if(!wide) {
 							const uint32_t np = (order + 1) / 2;
-							if(MAXORD >= 16 && np > 6) pack_fir_packed<MAXORD >= 16 ? 8 : 2>(A, QP, (uint32_t)shift, r);
-							else if(MAXORD >= 12 && np > 4) pack_fir_packed<MAXORD >= 12 ? 6 : 2>(A, QP, (uint32_t)shift, r);
-							else if(np > 2) pack_fir_packed<4>(A, QP, (uint32_t)shift, r);
-							else pack_fir_packed<2>(A, QP, (uint32_t)shift, r);
+							if(MAXORD >= 16 && np > 6) pack_fir_packed<MAXORD >= 16 ? 8 : 2, RUN>(A, QP, (uint32_t)shift, r);
+							else if(MAXORD >= 12 && np > 4) pack_fir_packed<MAXORD >= 12 ? 6 : 2, RUN>(A, QP, (uint32_t)shift, r);
+							else if(np > 2) pack_fir_packed<4, RUN>(A, QP, (uint32_t)shift, r);
+							else pack_fir_packed<2, RUN>(A, QP, (uint32_t)shift, r);
 						}
 						else {
-							int32_t x[32];
+							int32_t x[16 + RUN];
 #pragma unroll
-							for(int kk = 0; kk < 32; kk++) x[kk] = (kk & 1) ? ((int32_t)A[kk >> 1] >> 16) : (int32_t)(int16_t)(A[kk >> 1] & 0xffffu);
-							pack_fir_i32<MAXORD, 2>(x, q, shift, r);
+							for(int kk = 0; kk < 16 + RUN; kk++) x[kk] = (kk & 1) ? ((int32_t)A[kk >> 1] >> 16) : (int32_t)(int16_t)(A[kk >> 1] & 0xffffu);
+							pack_fir_i32<MAXORD, 2, RUN>(x, q, shift, r);
 						}
 					}
 					else {
-						int32_t x[32];
+						int32_t x[16 + RUN];
+						if(RUN != CHUNK) {
+#pragma unroll
+							for(int kk = 0; kk < 16; kk++) x[kk] = base ? (int32_t)src[base - 16 + kk] : 0;
+#pragma unroll
+							for(int kk = 0; kk < RUN; kk++) x[16 + kk] = (int32_t)src[base + kk];
+						}
+						else {
 #pragma unroll
 						for(int kk = 0; kk < 4; kk++) {
 							uint4 a = make_uint4(0, 0, 0, 0);
@@ -931,14 +961,15 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 							const uint4 a = ((const uint4 *)src)[base / 4 + kk];
 							x[16 + 4 * kk] = (int32_t)a.x; x[16 + 4 * kk + 1] = (int32_t)a.y; x[16 + 4 * kk + 2] = (int32_t)a.z; x[16 + 4 * kk + 3] = (int32_t)a.w;
 						}
-						if(fmode == 0) {
-							if(MAXORD >= 16 && order > 12) pack_fir_i32<MAXORD >= 16 ? 16 : 4, 0>(x, q, shift, r);
-							else if(MAXORD >= 12 && order > 8) pack_fir_i32<MAXORD >= 12 ? 12 : 4, 0>(x, q, shift, r);
-							else if(order > 4) pack_fir_i32<8, 0>(x, q, shift, r);
-							else pack_fir_i32<4, 0>(x, q, shift, r);
 						}
-						else if(fmode == 1) pack_fir_i32<MAXORD, 1>(x, q, shift, r);
-						else pack_fir_i32<MAXORD, 2>(x, q, shift, r);
+						if(fmode == 0) {
+							if(MAXORD >= 16 && order > 12) pack_fir_i32<MAXORD >= 16 ? 16 : 4, 0, RUN>(x, q, shift, r);
+							else if(MAXORD >= 12 && order > 8) pack_fir_i32<MAXORD >= 12 ? 12 : 4, 0, RUN>(x, q, shift, r);
+							else if(order > 4) pack_fir_i32<8, 0, RUN>(x, q, shift, r);
+							else pack_fir_i32<4, 0, RUN>(x, q, shift, r);
+						}
+						else if(fmode == 1) pack_fir_i32<MAXORD, 1, RUN>(x, q, shift, r);
+						else pack_fir_i32<MAXORD, 2, RUN>(x, q, shift, r);
 					}
 					// Rice code sizes: the whole run lies in one partition (partition sizes are multiples of 16)
 					const uint32_t part = base / psize;
@@ -946,7 +977,7 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 					starts = base == part * psize;
 					if(starts) mybits = plen;
 #pragma unroll
-					for(int t = 0; t < CHUNK; t++) {
+					for(int t = 0; t < RUN; t++) {
 						const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
 						const uint32_t cb = (u >> k) + 1 + k;
 						mybits += (base == 0 && (uint32_t)t < order) ? 0u : cb;
@@ -976,7 +1007,7 @@ __global__ __launch_bounds__(NT, PACK2_WAVES) void pack2_kernel(const DevParams 
 						// bit 31 (bit k of u) is covered by the stop bit, everything above has left the word
 						const uint32_t lsh = 31u - k;
 #pragma unroll
-						for(int t = 0; t < CHUNK; t++) {
+						for(int t = 0; t < RUN; t++) {
 							if(!(base == 0 && (uint32_t)t < order)) {
 								const uint32_t u = (uint32_t)r[t];
 								p += u >> k;
@@ -1244,6 +1275,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, true, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, TPB / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, true, TPB / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, 64, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		}
 		if(e != hipSuccess) return e;
 		attr_set = true;
@@ -1265,7 +1297,12 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			}
 			// half the threads for blocks that half of them cover in one pass (the 1152-sample blocks of -0 .. -2: 72 runs)
 			const bool half = P.blocksize <= CHUNK * (TPB / 2);
-			if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			// the presets' 1152-sample blocks: 64 runs of 18 samples, one wavefront per frame (not with the verify hints: their decoder
+			// counts in 16-sample runs; FLACGPU_NO_RUN18=1: the 128-thread instance, for A/B runs)
+			static const bool no_run18 = getenv("FLACGPU_NO_RUN18") != nullptr;
+			const bool run18 = P.blocksize == 1152 && !hints && !no_run18 && (1152u >> P.max_po) % 18u == 0;
+			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
 			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
 			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
 			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
