@@ -36,6 +36,7 @@ struct flacgpu_ctx {
 	float *d_tail_windows;       // [num_apod][blocksize] scratch for the short last block
 	SubDecision *d_decisions;    // [max_batch][ncand]
 	uint8_t *d_slots;            // [max_batch][slot_bytes]
+	uint8_t *d_ffdone;           // [max_batch] ff_kernel's per-frame marks (allocated when that kernel can take this stream)
 	uint32_t *d_frame_bytes;     // [max_batch]
 	uint64_t *d_offsets;         // [max_batch+1]
 	uint64_t *d_total;
@@ -189,6 +190,7 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->d_tail_windows) (void)hipFree(c->d_tail_windows);
 	if(c->d_decisions) (void)hipFree(c->d_decisions);
 	if(c->d_slots) (void)hipFree(c->d_slots);
+	if(c->d_ffdone) (void)hipFree(c->d_ffdone);
 	if(c->d_frame_bytes) (void)hipFree(c->d_frame_bytes);
 	if(c->d_offsets) (void)hipFree(c->d_offsets);
 	if(c->d_total) (void)hipFree(c->d_total);
@@ -396,6 +398,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		ok = ok && hipMalloc(&c->ab.left, nfc * sizeof(uint32_t)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.left2, nfc * sizeof(uint32_t)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.nleft, 2 * FLACGPU_MAX_SUBBATCHES * sizeof(uint32_t)) == hipSuccess;
+		if(ok && ff_applicable(P)) ok = hipMalloc(&c->d_ffdone, B) == hipSuccess;
 		if(ok && getenv("FLACGPU_DEBUG_TIMING")) { ok = hipMalloc(&c->ab.dbg, nfc * 16 * sizeof(unsigned long long)) == hipSuccess; if(ok) (void)hipMemset(c->ab.dbg, 0, nfc * 16 * sizeof(unsigned long long)); }
 	}
 	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
@@ -453,7 +456,13 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	(void)hipEventRecord(c->ev[0], s);
 	bool fused = false;
 	uint32_t nsub = c->nsub;
-	if(c->ab.dbg || nframes < 256 * nsub) nsub = 1;
+	// ff_kernel (one kernel for the whole frame, flacgpu_kernels.hip) where it applies: not with the verify hints (the decoder wants
+	// the pack kernel's run starts), not with the debug stamps, not with the fused output; one stream
+	static int fuse_env = -1;
+	if(fuse_env < 0) fuse_env = getenv("FLACGPU_FUSED_COMPACT") ? 1 : 0;
+	const bool ff = c->d_ffdone && !c->d_vhints && !c->ab.dbg && !fuse_env;
+	c->ab.ff_done = ff ? c->d_ffdone : nullptr; c->ab.ff_slots = c->d_slots; c->ab.ff_fb = c->d_frame_bytes; c->ab.ff_info = c->d_info; c->ab.ff_first = first;
+	if(c->ab.dbg || nframes < 256 * nsub || ff) nsub = 1;
 	if(nsub > 1) {
 		// Independent sub-batches on their own streams: the latency-bound kernels of one (prep, model, pack) fill the
 		// gaps of the VALU-bound kernels of another (autoc, eval).  Every buffer is indexed by frame, so a sub-batch
@@ -469,7 +478,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
 			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
 			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, nullptr, nullptr, ss) != hipSuccess)
+			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ss) != hipSuccess)
 				return FLACGPU_ERR_LAUNCH;
 			(void)hipEventRecord(c->sub_done[i], ss);
 			(void)hipStreamWaitEvent(s, c->sub_done[i], 0);
@@ -523,7 +532,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			if(fuse < 0) fuse = getenv("FLACGPU_FUSED_COMPACT") ? 1 : 0;
 			PackOutArgs po = {d_out, out_cap, c->d_offsets, c->d_total, c->d_scanstate};
 			uint32_t hinted = 0;
-			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, fuse ? &po : nullptr, &fused, c->d_vhints, &hinted, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, fuse ? &po : nullptr, &fused, c->d_vhints, &hinted, c->ab.ff_done, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 			c->hint_out = d_out; c->hint_nframes = nframes; c->hint_first = first; c->hint_count = hinted;
 		}
 		if(c->ab.dbg) {

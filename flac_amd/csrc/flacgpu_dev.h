@@ -118,6 +118,12 @@ struct AnalyzeBuffers {
 	uint32_t *left, *left2, *nleft; // two lists [frames*ncand] of channels a wavefront-per-channel evaluation kernel left to the next kernel in line
 	                           // (evalg -> evalw -> eval_list_kernel), and their counts nleft[0], nleft[1] (zeroed by the model kernel)
 	unsigned long long *dbg;   // FLACGPU_DEBUG_TIMING=1: [frames*ncand][16] s_memtime stamps of the eval kernel (else null)
+	// ff_kernel (flacgpu_kernels.hip) in front of the prep kernel: where it writes the frames it takes, and its per-frame marks
+	// (1: written, the other kernels' workgroups skip the frame); ff_done null: not this batch
+	uint8_t *ff_done, *ff_slots;
+	uint32_t *ff_fb;
+	struct FrameInfo *ff_info;
+	uint64_t ff_first;
 };
 constexpr int FLACGPU_MAX_SUBBATCHES = 8;   // streams a batch may be split over (FLACGPU_SUBBATCHES / flacgpu_set_subbatches)
 constexpr int EVAL_MAX_WAVES = 8;   // wavefronts per eval workgroup (one residual candidate each per round)
@@ -150,7 +156,10 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 struct PackOutArgs { uint8_t *out; uint64_t cap; uint64_t *offsets; uint64_t *total; uint64_t *state /* [nframes + 1] scratch */; };
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg,
-                       const PackOutArgs *po, bool *fused_out, uint32_t *hints, uint32_t *hinted_frames, hipStream_t s);
+                       const PackOutArgs *po, bool *fused_out, uint32_t *hints, uint32_t *hinted_frames, const uint8_t *skip, hipStream_t s);
+// the one-kernel path of the presets without an LPC search on 16-bit stereo in 1152-sample blocks (flacgpu_kernels.hip: ff_kernel)
+bool ff_applicable(const DevParams &P);
+hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, uint8_t *done, hipStream_t s);
 // hints (null: none wanted): [frame][channel][HINT_RUNS] bit offset, from the frame's first byte, at which the codes of each
 // 16-sample run of a residual-coded subframe start (the partition's parameter field when the run opens a partition) -- what the
 // hinted verify pass decodes from (flacgpu_decode_hinted.h).  *hinted_frames: the leading frames that got them.

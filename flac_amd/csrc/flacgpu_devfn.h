@@ -506,6 +506,60 @@ __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) 
 	return d;
 }
 
+// ---- difference sums of a run of samples (the prep kernels, flacgpu_prep.hip, and ff_kernel, flacgpu_kernels.hip) ----
+struct Prep2Acc {
+	uint32_t orv, diff;
+	uint32_t mag;              // OR of x ^ (x >> 31): every sample fits int16 iff (mag >> wasted) < 2^15
+	uint64_t e[5];
+};
+
+
+// statistics of the 16 samples x[4..19] of a chunk (x[0..3] = the four samples in front of them).
+// Sums are taken on the UNSHIFTED signal: every |difference| is a multiple of 2^wasted, so the sums of the shifted
+// signal the reference computes (it shifts in place first) are these sums >> wasted, exactly.
+// |d_k[i]| = |d_(k-1)[i] - d_(k-1)[i-1]| is one v_sad_u32 on the sign-flipped (order preserving) operands.
+// MAG: also collect Prep2Acc::mag (the side channel: 17 bits wide, but quiet enough for the packed 16-bit kernels most of the time)
+// PARTS (the presets without an LPC search, prep2_kernel<.,.,true>): cs[k] = this chunk's sum for order k, as added to A.e[k];
+// ex[k] = what the residual of order k has IN FRONT of sample 4 (samples k..3: the predictor estimate skips them, the residual
+// of the chosen order does not, stream_encoder.c:4100 vs :4456)
+template <bool WIDE, bool MAG = false, bool PARTS = false, int CH = CHUNK>
+__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[CH + 4], bool first_chunk, int32_t first, Prep2Acc &A, uint32_t *cs = nullptr, uint32_t *ex = nullptr)
+{
+	constexpr uint32_t M = 0x80000000u;
+	uint32_t s[5] = {0, 0, 0, 0, 0};
+	// differences at the three samples in front of the chunk
+	int32_t d1p = x[3] - x[2], d2p = (x[3] - x[2]) - (x[2] - x[1]), d3p = ((x[3] - x[2]) - (x[2] - x[1])) - ((x[2] - x[1]) - (x[1] - x[0]));
+	uint32_t xbp = (uint32_t)x[3] ^ M;
+#pragma unroll
+	for(int t = 0; t < CH; t++) {
+		const int32_t a0 = x[t + 4];
+		A.orv |= (uint32_t)a0; A.diff |= (uint32_t)(a0 ^ first);
+		if(MAG) A.mag |= (uint32_t)(a0 ^ (a0 >> 31));
+		const uint32_t xb = (uint32_t)a0 ^ M;
+		const int32_t d1 = a0 - x[t + 3], d2 = d1 - d1p, d3 = d2 - d2p;
+		uint32_t t0 = sad_u32(xb, M, 0), t1 = sad_u32(xb, xbp, 0), t2 = sad_u32((uint32_t)d1 ^ M, (uint32_t)d1p ^ M, 0),
+		         t3 = sad_u32((uint32_t)d2 ^ M, (uint32_t)d2p ^ M, 0), t4 = sad_u32((uint32_t)d3 ^ M, (uint32_t)d3p ^ M, 0);
+		if(t < 4) {
+			if(first_chunk) {
+				if(PARTS) { ex[0] += t0; if(t >= 1) ex[1] += t1; if(t >= 2) ex[2] += t2; if(t >= 3) ex[3] += t3; }
+				t0 = t1 = t2 = t3 = t4 = 0;                                        // the sums start at sample 4 (stream_encoder.c:4100)
+			}
+		}
+		if(WIDE) { A.e[0] += t0; A.e[1] += t1; A.e[2] += t2; A.e[3] += t3; A.e[4] += t4; }
+		else { s[0] += t0; s[1] += t1; s[2] += t2; s[3] += t3; s[4] += t4; }
+		d1p = d1; d2p = d2; d3p = d3; xbp = xb;
+	}
+	if(!WIDE) {
+#pragma unroll
+		for(int k = 0; k < 5; k++) A.e[k] += s[k];
+		if(PARTS) {
+#pragma unroll
+			for(int k = 0; k < 5; k++) cs[k] = s[k];
+		}
+	}
+}
+
+
 // NP dependent v_dot2_i32_i16 and the logical shift as ONE asm statement: between separate asm statements the
 // compiler pads every dependent pair with an s_nop, and its own v_dot2c form costs a v_mov per sample.
 template <int NP>

@@ -728,9 +728,10 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
                                                     const SubDecision *__restrict__ decisions,
                                                     uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
                                                     FrameInfo *__restrict__ info, unsigned long long *__restrict__ dbg, const PackOut O,
-                                                    uint32_t *__restrict__ hints)
+                                                    uint32_t *__restrict__ hints, const uint8_t *__restrict__ skip)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	if(skip && skip[blockIdx.x]) return;                      // ff_kernel has written this frame (never with the fused output: launch_pack_t)
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave: a scalar register)
 	const uint32_t C = P.channels, N = P.blocksize, n = N;
 	uint32_t *img = (uint32_t *)smem;
@@ -1080,6 +1081,340 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 #undef UNI
 }
 
+// ---------------------------------------------------------------------------------------------
+// ff_kernel: the presets without an LPC search (-0, -1, -2) on 16-bit stereo in their 1152-sample blocks -- ONE kernel, one
+// wavefront per frame, everything in registers.
+// ---------------------------------------------------------------------------------------------
+// For these presets a subframe's only residual candidate is the fixed predictor of the guessed order (prep2_kernel<.,.,DECIDE>,
+// flacgpu_prep.hip), and prep, decision and pack of a 1152-sample frame are more per-frame work than per-sample work: three
+// kernels, a planar copy and a decision record through HBM, workgroups of two to four wavefronts that meet at barriers.  Here a
+// lane owns the 18 samples [18 L, 18 L + 18) of both channels (1152 = 64 x 18) from the load to the last Rice code:
+//   coalesced load -> transposed LDS tile (left and right as an int16 pair per word) -> 22 words per lane (4 in front) ->
+//   difference sums of every candidate channel (prep2_chunk) -> wasted bits, order guess, CONSTANT / VERBATIM / FIXED with the
+//   Rice search on the lane's own sums (rice_search_nodes: a lane's 18 samples are exactly one of the 64 leaves) -> channel
+//   assignment -> frame header, subframes (residual = the k-th difference of registers), CRC-16, slot.
+// Same decisions and bytes as prep2_kernel + eval_list_kernel + pack2_kernel (stream_encoder.c:3747-4043, 4100-4140, 4701-5075;
+// stream_encoder_framing.c:245-594).  A frame whose sums leave the 32-bit node arithmetic is left alone (done[f] = 0): the
+// three-kernel path, whose workgroups skip the frames marked done, takes it.
+constexpr int FF_N = 1152, FF_RUN = 18, FF_TS = 66, FF_TILE_BYTES = FF_RUN * FF_TS * 4;
+constexpr uint32_t FF_XSPAN = 128;                         // span shifts kept in LDS: frames of up to 5.6 KB (these are 4.7 KB at most)
+struct FFShared {
+	uint16_t crc_tab[4][256];
+	uint16_t xspan[FF_XSPAN];
+	uint16_t xbyte[CRC_SPAN + 2];
+	uint32_t crc_parts[2];
+	uint32_t divtab[7 * (MAX_ORDER + 1)];                   // rows 0..6 (partition orders), columns 0..4 used
+	uint8_t kout[4][64];                                   // Rice parameters of the four candidate channels
+};
+struct FFDec { uint32_t which, type, order, wasted, sbps, bits, po, rice2; int32_t constant; };
+__host__ __device__ inline uint32_t ff_tile_bytes(uint32_t slot_bytes) { const uint32_t img = (slot_bytes + 8 + 15) & ~15u; return img > (uint32_t)FF_TILE_BYTES ? img : (uint32_t)FF_TILE_BYTES; }
+
+// the candidate channel `which` (0 left, 1 right, 2 mid, 3 side) of this lane's window
+// (the window stays packed, left in the low and right in the high half of a word: 22 registers instead of 44 across the kernel)
+__device__ __forceinline__ void ff_channel(const uint32_t (&w)[FF_RUN + 4], uint32_t which, int32_t (&x)[FF_RUN + 4])
+{
+#pragma unroll
+	for(int k = 0; k < FF_RUN + 4; k++) {
+		const int32_t a = (int32_t)(int16_t)(w[k] & 0xffffu), b = (int32_t)w[k] >> 16;
+		x[k] = which == 0 ? a : which == 1 ? b : which == 2 ? ((a + b) >> 1) : (a - b);
+	}
+}
+// statistics and decision of one candidate channel; false: the channel's sums leave the search's 32-bit arithmetic
+__device__ __forceinline__ bool ff_decide(const DevParams &P, uint32_t which, const int32_t (&x)[FF_RUN + 4], bool disable_constant, FFShared *sh, int lane, FFDec &D, uint32_t &alleq)
+{
+	constexpr uint32_t n = FF_N;
+	Prep2Acc A;
+	A.orv = 0; A.diff = 0; A.mag = 0;
+#pragma unroll
+	for(int k = 0; k < 5; k++) A.e[k] = 0;
+	const int32_t first = (int32_t)__builtin_amdgcn_readfirstlane(x[4]);          // sample 0 of the block (lane 0's first own sample)
+	uint32_t cs[5], ex[5] = {0, 0, 0, 0, 0};
+	prep2_chunk<false, false, true, FF_RUN>(x, lane == 0, first, A, cs, ex);
+	const uint32_t orv = wave_or_u32(A.orv), diff = wave_or_u32(A.diff);
+	uint64_t e[5];
+#pragma unroll
+	for(int k = 0; k < 5; k++) e[k] = wave_sum_u32((uint32_t)A.e[k]);            // < 2^31: 1152 fourth differences of 17-bit samples
+	alleq = diff == 0 ? 1u : 0u;
+	uint32_t wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
+	if(wasted > P.bps) wasted = P.bps;
+	const uint32_t sbps = P.bps - wasted + (which == 3 ? 1 : 0);
+	const uint32_t verbatim_bits = P.disable_verbatim ? 0xffffffffu : 8 + wasted + n * sbps;
+	const uint32_t n4 = n - 4;
+	const uint64_t e0 = e[0] >> wasted, e1 = e[1] >> wasted, e2 = e[2] >> wasted, e3 = e[3] >> wasted, e4 = e[4] >> wasted;
+	uint32_t guess_fixed;
+	{
+		const uint64_t m34 = e3 < e4 ? e3 : e4, m234 = e2 < m34 ? e2 : m34, m1234 = e1 < m234 ? e1 : m234;
+		if(e0 <= m1234) guess_fixed = 0;
+		else if(e1 <= m234) guess_fixed = 1;
+		else if(e2 <= m34) guess_fixed = 2;
+		else if(e3 <= e4) guess_fixed = 3;
+		else guess_fixed = 4;
+	}
+	const bool is_constant = !disable_constant && diff == 0;               // stream_encoder.c:4111-4140
+	const int32_t constant = first >> wasted;
+	const bool fixed_allowed = !is_constant && (!P.disable_fixed || verbatim_bits == 0xffffffffu);      // (max_lpc_order == 0 here)
+	const uint32_t fixed_order = fixed_allowed ? guess_fixed : 0;
+	const uint64_t eg = guess_fixed == 0 ? e0 : guess_fixed == 1 ? e1 : guess_fixed == 2 ? e2 : guess_fixed == 3 ? e3 : e4;
+	const bool fixed_valid = fixed_allowed && !(fixed_rbps(eg, n4) >= (float)sbps);
+	// first minimum in the reference's evaluation order: verbatim -> constant | the fixed order (prep2_kernel<.,.,DECIDE>)
+	const uint32_t hdr = 8 + wasted;
+	D.which = which; D.wasted = wasted; D.sbps = sbps;
+	D.type = 1; D.bits = verbatim_bits; D.po = 0; D.rice2 = 0; D.order = 0; D.constant = 0;
+	if(is_constant) {
+		const uint32_t bits = hdr + sbps;
+		if(bits < D.bits) { D.type = 0; D.constant = constant; D.bits = bits; }
+	}
+	if(fixed_valid) {
+		uint32_t fmax = umin32(7u, P.max_po);                                 // 1152 = 2^7 * 9; <= 6 (prep2_decides)
+		const uint32_t fmin = umin32(P.min_po, fmax), ee = 6 - fmax;
+		// this lane's 18 samples are one of the 64 leaves of the search: the chunk sum of the chosen order (what the residual has in front
+		// of sample 4 added on lane 0), shifted like the signal
+		uint32_t v = fixed_order == 0 ? cs[0] : fixed_order == 1 ? cs[1] : fixed_order == 2 ? cs[2] : fixed_order == 3 ? cs[3] : cs[4];
+		if(lane == 0) v += fixed_order == 0 ? ex[0] : fixed_order == 1 ? ex[1] : fixed_order == 2 ? ex[2] : fixed_order == 3 ? ex[3] : ex[4];
+		v >>= wasted;
+		if(__any((int)(v >= ((1u << 23) >> ee)))) return false;              // (a leaf partition is 2^ee lanes: its sum stays below 2^23)
+		uint32_t po = 0;
+		const uint32_t rbits = rice_search_nodes(v, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
+		const uint32_t est = sat_add_u32(hdr + fixed_order * sbps, rbits);
+		if(est > 0 && est < D.bits) { D.type = 2; D.bits = est; D.po = po; D.order = fixed_order; }
+	}
+	if(D.bits == 0xffffffffu) { D.type = 1; D.bits = hdr + n * sbps; }       // stream_encoder.c:4281
+	if(D.type == 2) {
+		uint32_t big = 0;
+		if((uint32_t)lane < (1u << D.po)) big = sh->kout[which][lane] >= 15 ? 1u : 0u;
+		D.rice2 = __any((int)big) ? 1u : 0u;                                  // stream_encoder.c:4786-4791
+	}
+	// the record is the same in every lane: scalar registers
+#define FFUNI(x) x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x))
+	FFUNI(D.type); FFUNI(D.order); FFUNI(D.wasted); FFUNI(D.sbps); FFUNI(D.bits); FFUNI(D.po); FFUNI(D.rice2);
+	D.constant = __builtin_amdgcn_readfirstlane(D.constant);
+#undef FFUNI
+	return true;
+}
+
+#ifndef FF_WAVES
+#define FF_WAVES 4
+#endif
+template <int MS>       // DevParams::ms_mode
+__global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint64_t first_frame_number,
+                                                 uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, FrameInfo *__restrict__ info, uint8_t *__restrict__ done)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = (int)threadIdx.x;
+	const uint32_t f = blockIdx.x;
+	constexpr uint32_t n = FF_N;
+	uint32_t *tile = (uint32_t *)smem;                                        // the transposed tile, later the frame image
+	FFShared *sh = (FFShared *)(smem + ff_tile_bytes(P.slot_bytes));
+	// ---- every load of the frame at once: samples (coalesced), CRC tables -----------------------------------------------------
+	int2 v[FF_RUN];
+	{
+		const int2 *p = (const int2 *)(pcm + (size_t)f * n * 2);
+#pragma unroll
+		for(int k = 0; k < FF_RUN; k++) v[k] = p[(uint32_t)lane + 64u * (uint32_t)k];
+		const uint32_t *tab32 = (const uint32_t *)g_crc_tables.tab, *xs32 = (const uint32_t *)g_crc_tables.xspan44, *xb32 = (const uint32_t *)g_crc_tables.xbyte;
+		uint32_t tv[8];
+#pragma unroll
+		for(int k = 0; k < 8; k++) tv[k] = tab32[(uint32_t)lane + 64u * (uint32_t)k];
+		const uint32_t xv = xs32[lane], bv = xb32[lane < (int)(CRC_SPAN + 2) / 2 ? lane : 0];
+#pragma unroll
+		for(int k = 0; k < 8; k++) ((uint32_t *)sh->crc_tab)[(uint32_t)lane + 64u * (uint32_t)k] = tv[k];
+		((uint32_t *)sh->xspan)[lane] = xv;
+		if(lane < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[lane] = bv;
+		if(lane < 35) { const uint32_t po = (uint32_t)lane / 5u, o = (uint32_t)lane - po * 5u; sh->divtab[po * (MAX_ORDER + 1) + o] = 0x40000u / ((n >> po) - o); }
+		if(lane < FF_RUN) tile[lane * FF_TS] = 0;                             // column 0: the samples in front of the block
+#pragma unroll
+		for(int k = 0; k < FF_RUN; k++) {
+			const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k, c = i / FF_RUN, r = i - c * FF_RUN;
+			tile[r * FF_TS + c + 1] = ((uint32_t)v[k].x & 0xffffu) | ((uint32_t)v[k].y << 16);
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	uint32_t w[FF_RUN + 4];
+#pragma unroll
+	for(int k = 0; k < FF_RUN + 4; k++) w[k] = k < 4 ? tile[(FF_RUN - 4 + k) * FF_TS + lane] : tile[(k - 4) * FF_TS + lane + 1];
+	__builtin_amdgcn_wave_barrier();                                          // the tile is the frame image from here on
+
+	// ---- candidate channels --------------------------------------------------------------------------------------------------
+	FFDec D[4];
+	uint32_t ca = 0, li = 0, ri = 1;
+	bool ok = true;
+	{
+		uint32_t alleq_l = 0, dummy = 0;
+		bool dc = P.disable_constant != 0;
+		int32_t x[FF_RUN + 4];
+		if(MS == 2) {
+			// loose mid/side (stream_encoder.c:3778-3807): left/right or mid/side for the whole frame, from first differences
+			uint32_t lr = 0, ms = 0;
+#pragma unroll
+			for(int t = 0; t < FF_RUN; t++) {
+				if(t > 0 || lane > 0) {
+					const int32_t pl = ((int32_t)(int16_t)(w[t + 4] & 0xffffu)) - ((int32_t)(int16_t)(w[t + 3] & 0xffffu)), pr = ((int32_t)w[t + 4] >> 16) - ((int32_t)w[t + 3] >> 16);
+					lr += (uint32_t)(abs(pl) + abs(pr));
+					ms += (uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
+				}
+			}
+			const uint64_t lrs = wave_sum_u50((uint64_t)lr), mss = wave_sum_u50((uint64_t)ms);
+			const bool use_ms = !(lrs < mss);
+			if(P.limit_min_bitrate) {
+				// (the all-equal flag of the left channel decides whether the second subframe may be CONSTANT, stream_encoder.c:3874-3879)
+				uint32_t dl = 0;
+#pragma unroll
+				for(int t = 0; t < FF_RUN; t++) dl |= (w[t + 4] ^ w[4]) & 0xffffu;
+				const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[4]);
+				dl |= (w[4] ^ fl) & 0xffffu;
+				alleq_l = wave_or_u32(dl) == 0 ? 1u : 0u;
+			}
+			li = use_ms ? 2 : 0; ri = use_ms ? 3 : 1; ca = use_ms ? 3 : 0;
+			ff_channel(w, li, x);
+			ok = ff_decide(P, li, x, dc, sh, lane, D[li], dummy);
+			if(ok) {
+				// prep2_kernel: with the loose search only the right channel proper (which == 1) can lose its CONSTANT
+				if(P.limit_min_bitrate && !dc && ri == 1 && alleq_l) dc = true;
+				ff_channel(w, ri, x);
+				ok = ff_decide(P, ri, x, dc, sh, lane, D[ri], dummy);
+			}
+		}
+		else {
+			ff_channel(w, 0, x);
+			ok = ff_decide(P, 0, x, dc, sh, lane, D[0], alleq_l);
+			// every channel but the first: no CONSTANT when all the ones in front are constant (stream_encoder.c:3874-3879)
+			const bool dc_rest = dc || (P.limit_min_bitrate && alleq_l);
+			if(ok) { ff_channel(w, 1, x); ok = ff_decide(P, 1, x, dc_rest, sh, lane, D[1], dummy); }
+			if(MS == 1) {
+				if(ok) { ff_channel(w, 2, x); ok = ff_decide(P, 2, x, dc_rest, sh, lane, D[2], dummy); }
+				if(ok) { ff_channel(w, 3, x); ok = ff_decide(P, 3, x, dc_rest, sh, lane, D[3], dummy); }
+				if(ok) {
+					// channel assignment (stream_encoder.c:3944-3972)
+					const uint32_t b0 = D[0].bits + D[1].bits, b1 = D[0].bits + D[3].bits, b2 = D[1].bits + D[3].bits, b3 = D[2].bits + D[3].bits;
+					uint32_t mn = b0;
+					if(b1 < mn) { mn = b1; ca = 1; }
+					if(b2 < mn) { mn = b2; ca = 2; }
+					if(b3 < mn) { mn = b3; ca = 3; }
+					li = ca == 2 ? 3 : ca == 3 ? 2 : 0;
+					ri = ca == 0 ? 1 : ca == 2 ? 1 : 3;
+				}
+			}
+		}
+	}
+	if(!ok) { if(lane == 0) done[f] = 0; return; }
+
+	// ---- the frame -----------------------------------------------------------------------------------------------------------
+	uint32_t *img = tile;
+	const uint32_t cap_words = P.slot_bytes / 4;
+	for(uint32_t w = (uint32_t)lane; w < cap_words + 2; w += 64) img[w] = 0;
+	__builtin_amdgcn_wave_barrier();
+	const uint32_t frame_number = (uint32_t)(first_frame_number + f);
+	if(lane == 1) (void)frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { or_bits(img, cap_words, 8 * k, byte, 8); });
+	uint32_t pos = 8 * frame_header_len(P, n, frame_number);
+	for(int s = 0; s < 2; s++) {
+		const uint32_t di = s == 0 ? li : ri;
+		FFDec d = di == 0 ? D[0] : di == 1 ? D[1] : di == 2 ? D[2] : D[3];
+		const uint32_t type = d.type, order = d.order, wasted = d.wasted, sbps = d.sbps;
+		int32_t x[FF_RUN + 4];
+		ff_channel(w, di, x);
+#pragma unroll
+		for(int k = 0; k < FF_RUN + 4; k++) x[k] >>= wasted;
+		const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : (0x10u | (order << 1));
+		if(lane == 0) {
+			or_bits(img, cap_words, pos, type_bits | (wasted ? 1u : 0u), 8);
+			if(wasted) or_bits(img, cap_words, pos + 8 + (wasted - 1), 1, 1);
+		}
+		pos += 8 + wasted;
+		const uint32_t smask = sbps >= 32 ? 0xffffffffu : (1u << sbps) - 1u;
+		if(type == 0) {
+			if(lane == 0) or_bits(img, cap_words, pos, (uint32_t)d.constant & smask, sbps);
+			pos += sbps;
+		}
+		else if(type == 1) {
+#pragma unroll
+			for(int k = 0; k < FF_RUN; k++) or_bits(img, cap_words, pos + ((uint32_t)lane * FF_RUN + (uint32_t)k) * sbps, (uint32_t)x[k + 4] & smask, sbps);
+			pos += n * sbps;
+		}
+		else {
+			// warm-up samples, verbatim (lane 0 holds them)
+			if(lane == 0) {
+#pragma unroll
+				for(int i = 0; i < 4; i++) if((uint32_t)i < order) or_bits(img, cap_words, pos + (uint32_t)i * sbps, (uint32_t)x[4 + i] & smask, sbps);
+			}
+			pos += order * sbps;
+			const uint32_t po = d.po, rice2 = d.rice2, plen = rice2 ? 5u : 4u;
+			if(lane == 0) {
+				or_bits(img, cap_words, pos, rice2 ? 1u : 0u, 2);
+				or_bits(img, cap_words, pos + 2, po, 4);
+			}
+			pos += 6;
+			// the residual of the fixed predictor of this order = the order-th difference (fixed.c:470)
+			int32_t r[FF_RUN];
+			{
+				int32_t dd[FF_RUN + 4];
+#pragma unroll
+				for(int k = 0; k < FF_RUN + 4; k++) dd[k] = x[k];
+#pragma unroll
+				for(int o = 1; o <= 4; o++) {
+					if((uint32_t)o <= order) {
+#pragma unroll
+						for(int k = FF_RUN + 3; k >= o; k--) dd[k] = dd[k] - dd[k - 1];
+					}
+				}
+#pragma unroll
+				for(int t = 0; t < FF_RUN; t++) r[t] = dd[t + 4];
+			}
+			const uint32_t psize = n >> po, base = (uint32_t)lane * FF_RUN;
+			const uint32_t part = base / psize;
+			const uint32_t k = sh->kout[di][part];
+			const bool starts = base == part * psize;
+			uint32_t mybits = starts ? plen : 0u;
+#pragma unroll
+			for(int t = 0; t < FF_RUN; t++) {
+				const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
+				const uint32_t cb = (u >> k) + 1 + k;
+				mybits += (lane == 0 && (uint32_t)t < order) ? 0u : cb;
+				r[t] = (int32_t)u;
+			}
+			const uint32_t incl = wave_scan_incl_dpp(mybits);
+			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			uint32_t p = pos + incl - mybits;
+			if(starts) { or_bits(img, cap_words, p, k, plen); p += plen; }
+			if(pos + incl <= cap_words * 32u) {
+				const uint32_t lsh = 31u - k;
+#pragma unroll
+				for(int t = 0; t < FF_RUN; t++) {
+					if(!(lane == 0 && (uint32_t)t < order)) {
+						const uint32_t u = (uint32_t)r[t];
+						p += u >> k;
+						or_code_fit(img, p, (u << lsh) | 0x80000000u);
+						p += 1 + k;
+					}
+				}
+			}
+			pos += total;
+		}
+		if(lane == 0 && info) {
+			flacgpu_subframe_info *si = &info[f].sub[s];
+			si->type = (uint8_t)type; si->order = (uint8_t)order; si->wasted_bits = (uint8_t)wasted;
+			si->partition_order = (uint8_t)d.po; si->rice2 = (uint8_t)d.rice2; si->precision = 0; si->shift = 0;
+			si->pad = 0; si->bits = d.bits;
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	// ---- zero-pad to a byte, CRC-16, footer, slot (stream_encoder.c:3720-3734) -------------------------------------------------
+	const uint32_t body_bytes = (pos + 7) >> 3, total_bytes = body_bytes + 2;
+	const bool overflow = total_bytes > P.slot_bytes;
+	{
+		const uint32_t crc = frame_crc16_p2<64>(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, lane, sh->xspan, FF_XSPAN, sh->xbyte);
+		if(lane == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
+		__syncthreads();
+	}
+	uint32_t *dst = (uint32_t *)(slots + (size_t)f * P.slot_bytes);
+	const uint32_t words = (umin32(total_bytes, P.slot_bytes) + 3) >> 2;
+	for(uint32_t w = (uint32_t)lane; w < words; w += 64) dst[w] = __builtin_bswap32(img[w]);
+	if(lane == 0) {
+		frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
+		if(info) info[f].channel_assignment = (uint8_t)ca;
+		done[f] = 1;
+	}
+}
+
 // fused output with a short last block: that frame was assembled in its slot by pack_kernel; it goes behind the others
 __global__ __launch_bounds__(TPB) void append_tail_kernel(const uint8_t *__restrict__ slot, const uint32_t *__restrict__ frame_bytes, uint32_t f, const PackOut O)
 {
@@ -1265,7 +1600,7 @@ static bool pack2_applicable(const DevParams &P)
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                                 const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, const PackOutArgs *po, bool *fused_out,
-                                uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
+                                uint32_t *hints, uint32_t *hinted_frames, const uint8_t *skip, hipStream_t s)
 {
 	static bool attr_set = false;
 	if(!attr_set) {
@@ -1301,11 +1636,11 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			// counts in 16-sample runs; FLACGPU_NO_RUN18=1: the 128-thread instance, for A/B runs)
 			static const bool no_run18 = getenv("FLACGPU_NO_RUN18") != nullptr;
 			const bool run18 = P.blocksize == 1152 && !hints && !no_run18 && (1152u >> P.max_po) % 18u == 0;
-			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
-			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
-			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
-			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
-			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
+			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
+			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
+			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
+			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
 			if(hinted_frames) *hinted_frames = hints ? f_lo : 0;
 		}
 	}
@@ -1326,15 +1661,32 @@ size_t pack_lds_bytes(const DevParams &P)
 
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, const PackOutArgs *po, bool *fused_out,
-                       uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
+                       uint32_t *hints, uint32_t *hinted_frames, const uint8_t *skip, hipStream_t s)
 {
 	const size_t lds = pack_lds_bytes(P);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
 	if(P.blocksize > HINT_RUNS * CHUNK) hints = nullptr;          // one run per thread and pass: blocks of up to 4096 samples
-	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
-	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
-	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
-	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, skip, s);
+	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, skip, s);
+	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, skip, s);
+	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, skip, s);
+}
+// ff_kernel takes 16-bit stereo in 1152-sample blocks when the prep kernel could decide the subframes itself (no LPC search, one
+// fixed order) and pack2_kernel could pack them; not with the verify hints (their decoder wants pack2_kernel's run starts)
+bool ff_applicable(const DevParams &P)
+{
+	static const bool off = getenv("FLACGPU_NO_FF") != nullptr;
+	return !off && P.channels == 2 && P.bps <= 16 && P.blocksize == FF_N && P.ncand == (P.ms_mode == 1 ? 4u : 2u) && prep2_decides(P) && pack2_applicable(P)
+	       && (1152u >> P.max_po) % 18u == 0 && ff_tile_bytes(P.slot_bytes) + sizeof(FFShared) <= 40 * 1024;
+}
+hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, uint8_t *done, hipStream_t s)
+{
+	if(nmain == 0) return hipSuccess;
+	const size_t lds = ff_tile_bytes(P.slot_bytes) + sizeof(FFShared);
+	if(P.ms_mode == 0) hipLaunchKernelGGL(ff_kernel<0>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done);
+	else if(P.ms_mode == 1) hipLaunchKernelGGL(ff_kernel<1>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done);
+	else hipLaunchKernelGGL(ff_kernel<2>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done);
+	return hipGetLastError();
 }
 hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s)
 {

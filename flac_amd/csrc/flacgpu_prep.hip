@@ -23,12 +23,6 @@ namespace flacgpu {
 #endif
 
 constexpr uint32_t P2_DIVTAB_BYTES = ((MAX_PO + 1) * (MAX_ORDER + 1) * 4 + 15) & ~15u;
-struct Prep2Acc {
-	uint32_t orv, diff;
-	uint32_t mag;              // OR of x ^ (x >> 31): every sample fits int16 iff (mag >> wasted) < 2^15
-	uint64_t e[5];
-};
-
 // LDS image of one raw channel, transposed: sample i sits in row i%16, column i/16 + 1 (column 0 holds zeros: the
 // samples in front of the block), rows P2_TS(n) words apart.  A lane that owns the 16 samples of chunk t reads
 // row r at column t+1 -- consecutive lanes, consecutive words, no address arithmetic (ds_read offsets); the staging
@@ -39,51 +33,6 @@ __host__ __device__ inline uint32_t p2_chan_bytes(uint32_t n, uint32_t ch = CHUN
 // chunks -- a full pass of the wavefront and one with eight lanes -- and 18 makes 64: one pass, every lane busy.  (1152 = 18 * 64, and
 // every partition the Rice search may ask for, 1152 >> 0..6, is a whole number of 18-sample chunks.)
 __host__ __device__ constexpr uint32_t p2_chunk_len(uint32_t blocksize) { return blocksize == 1152 ? 18u : (uint32_t)CHUNK; }
-
-// statistics of the 16 samples x[4..19] of a chunk (x[0..3] = the four samples in front of them).
-// Sums are taken on the UNSHIFTED signal: every |difference| is a multiple of 2^wasted, so the sums of the shifted
-// signal the reference computes (it shifts in place first) are these sums >> wasted, exactly.
-// |d_k[i]| = |d_(k-1)[i] - d_(k-1)[i-1]| is one v_sad_u32 on the sign-flipped (order preserving) operands.
-// MAG: also collect Prep2Acc::mag (the side channel: 17 bits wide, but quiet enough for the packed 16-bit kernels most of the time)
-// PARTS (the presets without an LPC search, prep2_kernel<.,.,true>): cs[k] = this chunk's sum for order k, as added to A.e[k];
-// ex[k] = what the residual of order k has IN FRONT of sample 4 (samples k..3: the predictor estimate skips them, the residual
-// of the chosen order does not, stream_encoder.c:4100 vs :4456)
-template <bool WIDE, bool MAG = false, bool PARTS = false, int CH = CHUNK>
-__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[CH + 4], bool first_chunk, int32_t first, Prep2Acc &A, uint32_t *cs = nullptr, uint32_t *ex = nullptr)
-{
-	constexpr uint32_t M = 0x80000000u;
-	uint32_t s[5] = {0, 0, 0, 0, 0};
-	// differences at the three samples in front of the chunk
-	int32_t d1p = x[3] - x[2], d2p = (x[3] - x[2]) - (x[2] - x[1]), d3p = ((x[3] - x[2]) - (x[2] - x[1])) - ((x[2] - x[1]) - (x[1] - x[0]));
-	uint32_t xbp = (uint32_t)x[3] ^ M;
-#pragma unroll
-	for(int t = 0; t < CH; t++) {
-		const int32_t a0 = x[t + 4];
-		A.orv |= (uint32_t)a0; A.diff |= (uint32_t)(a0 ^ first);
-		if(MAG) A.mag |= (uint32_t)(a0 ^ (a0 >> 31));
-		const uint32_t xb = (uint32_t)a0 ^ M;
-		const int32_t d1 = a0 - x[t + 3], d2 = d1 - d1p, d3 = d2 - d2p;
-		uint32_t t0 = sad_u32(xb, M, 0), t1 = sad_u32(xb, xbp, 0), t2 = sad_u32((uint32_t)d1 ^ M, (uint32_t)d1p ^ M, 0),
-		         t3 = sad_u32((uint32_t)d2 ^ M, (uint32_t)d2p ^ M, 0), t4 = sad_u32((uint32_t)d3 ^ M, (uint32_t)d3p ^ M, 0);
-		if(t < 4) {
-			if(first_chunk) {
-				if(PARTS) { ex[0] += t0; if(t >= 1) ex[1] += t1; if(t >= 2) ex[2] += t2; if(t >= 3) ex[3] += t3; }
-				t0 = t1 = t2 = t3 = t4 = 0;                                        // the sums start at sample 4 (stream_encoder.c:4100)
-			}
-		}
-		if(WIDE) { A.e[0] += t0; A.e[1] += t1; A.e[2] += t2; A.e[3] += t3; A.e[4] += t4; }
-		else { s[0] += t0; s[1] += t1; s[2] += t2; s[3] += t3; s[4] += t4; }
-		d1p = d1; d2p = d2; d3p = d3; xbp = xb;
-	}
-	if(!WIDE) {
-#pragma unroll
-		for(int k = 0; k < 5; k++) A.e[k] += s[k];
-		if(PARTS) {
-#pragma unroll
-			for(int k = 0; k < 5; k++) cs[k] = s[k];
-		}
-	}
-}
 
 // WIDE: per-run partial sums may exceed 32 bits (more than 20 bits per sample)
 // NFIX: the block size when it is one of the presets' (4096, 1152), else 0 = read it from the parameters.  A constant block size
@@ -98,9 +47,11 @@ __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[CH + 4], bool fir
 template <bool WIDE, uint32_t NFIX, bool DECIDE>
 __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
                                                     ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
-                                                    int32_t *__restrict__ chan, SubDecision *__restrict__ decisions, uint32_t *__restrict__ left, uint32_t *__restrict__ nleft)
+                                                    int32_t *__restrict__ chan, SubDecision *__restrict__ decisions, uint32_t *__restrict__ left, uint32_t *__restrict__ nleft,
+                                                    const uint8_t *__restrict__ skip)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	if(skip && skip[blockIdx.x]) return;                      // ff_kernel (flacgpu_kernels.hip) has written this frame
 	__shared__ uint32_t sh_alleq[FLACGPU_MAX_CHANNELS];
 	__shared__ uint32_t sh_loose_ms;
 	const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -654,13 +605,13 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
 	const uint32_t waves = stereo_ms ? 4u : nraw;
 	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize, p2_chunk_len(P.blocksize));
-#define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft)
+#define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft, B.ff_done)
 	if(prep2_decides(P)) {
 		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
 		(void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
 		const size_t ldz = prep2_decide_lds(P, nraw, waves);
-		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
-		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
+		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft, B.ff_done);
+		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft, B.ff_done);
 		return hipGetLastError();
 	}
 	if(P.bps > 20) { if(P.blocksize == 4096) P2GO(true, 4096); else if(P.blocksize == 1152) P2GO(true, 1152); else P2GO(true, 0); }
