@@ -1352,7 +1352,7 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	}
 	else if(!(prep2_applicable(P) && prep2_decides(P))) (void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);      // (a deciding prep kernel has started the list)
 	sync_debug("model", s);
-	if(pev) (void)hipEventRecord(pev[2], s);
+	if(pev && P.max_analyses) (void)hipEventRecord(pev[2], s);       // (no LPC analyses: no kernel since pev[0]; flacgpu_batch_phase_ms knows)
 	uint32_t cpw, waves;
 	eval_shape(P, cpw, waves);
 	const uint32_t gwaves = eval_waves_generic(P);
@@ -1491,7 +1491,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 		}
 	}
 	sync_debug("autoc", s);
-	if(pev) (void)hipEventRecord(pev[1], s);
+	if(pev && P.max_analyses) (void)hipEventRecord(pev[1], s);       // (an event record costs the stream ~4 us: a tenth of a -0 step for two empty phases)
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
 	if(m <= 8) return launch_model_eval<8>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);
 	if(m <= 12) return launch_model_eval<12>(P, pcm, nframes, tail_n, jtm, jtt, B, dec, pev, s);

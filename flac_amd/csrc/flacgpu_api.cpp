@@ -126,7 +126,9 @@ extern "C" int flacgpu_batch_phase_ms(flacgpu_ctx *c, uint32_t batches_ago, floa
 	const size_t slot = (size_t)((c->batch_seq - 1 - batches_ago) % TIMING_RING);
 	hipEvent_t *ev = c->ev_ring[slot], *pev = c->pev_ring[slot];
 	if(hipEventSynchronize(ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	hipEvent_t seq[7] = {ev[0], pev[0], pev[1], pev[2], ev[1], ev[2], ev[3]};
+	// without LPC analyses nothing is launched between the prep and the evaluation phase, and no event is recorded there
+	const bool lpc = c->P.max_analyses != 0;
+	hipEvent_t seq[7] = {ev[0], pev[0], lpc ? pev[1] : pev[0], lpc ? pev[2] : pev[0], ev[1], ev[2], ev[3]};
 	for(int i = 0; i < 6; i++) if(hipEventElapsedTime(&ms[i], seq[i], seq[i + 1]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	return FLACGPU_OK;
 }

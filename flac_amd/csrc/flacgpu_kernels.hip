@@ -1193,7 +1193,7 @@ __device__ __forceinline__ bool ff_decide(const DevParams &P, uint32_t which, co
 }
 
 #ifndef FF_WAVES
-#define FF_WAVES 4
+#define FF_WAVES 3           // 150..168 registers, no spills; 4 (128 registers, 76..176 bytes of spills) is 3..10 % slower (profiles/r03_l2_ff_waves_ab.txt)
 #endif
 template <int MS>       // DevParams::ms_mode
 __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint64_t first_frame_number,
@@ -1235,8 +1235,8 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	__builtin_amdgcn_wave_barrier();                                          // the tile is the frame image from here on
 
 	// ---- candidate channels --------------------------------------------------------------------------------------------------
-	FFDec D[4];
-	uint32_t ca = 0, li = 0, ri = 1;
+	FFDec DL, DR;                                                             // the two subframes of the frame, in stream order
+	uint32_t ca = 0;
 	bool ok = true;
 	{
 		uint32_t alleq_l = 0, dummy = 0;
@@ -1264,34 +1264,38 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 				dl |= (w[4] ^ fl) & 0xffffu;
 				alleq_l = wave_or_u32(dl) == 0 ? 1u : 0u;
 			}
-			li = use_ms ? 2 : 0; ri = use_ms ? 3 : 1; ca = use_ms ? 3 : 0;
+			const uint32_t li = use_ms ? 2 : 0, ri = use_ms ? 3 : 1;
+			ca = use_ms ? 3 : 0;
 			ff_channel(w, li, x);
-			ok = ff_decide(P, li, x, dc, sh, lane, D[li], dummy);
+			ok = ff_decide(P, li, x, dc, sh, lane, DL, dummy);
 			if(ok) {
 				// prep2_kernel: with the loose search only the right channel proper (which == 1) can lose its CONSTANT
 				if(P.limit_min_bitrate && !dc && ri == 1 && alleq_l) dc = true;
 				ff_channel(w, ri, x);
-				ok = ff_decide(P, ri, x, dc, sh, lane, D[ri], dummy);
+				ok = ff_decide(P, ri, x, dc, sh, lane, DR, dummy);
 			}
 		}
 		else {
+			FFDec d0, d1;
 			ff_channel(w, 0, x);
-			ok = ff_decide(P, 0, x, dc, sh, lane, D[0], alleq_l);
+			ok = ff_decide(P, 0, x, dc, sh, lane, d0, alleq_l);
 			// every channel but the first: no CONSTANT when all the ones in front are constant (stream_encoder.c:3874-3879)
 			const bool dc_rest = dc || (P.limit_min_bitrate && alleq_l);
-			if(ok) { ff_channel(w, 1, x); ok = ff_decide(P, 1, x, dc_rest, sh, lane, D[1], dummy); }
+			if(ok) { ff_channel(w, 1, x); ok = ff_decide(P, 1, x, dc_rest, sh, lane, d1, dummy); }
+			DL = d0; DR = d1;
 			if(MS == 1) {
-				if(ok) { ff_channel(w, 2, x); ok = ff_decide(P, 2, x, dc_rest, sh, lane, D[2], dummy); }
-				if(ok) { ff_channel(w, 3, x); ok = ff_decide(P, 3, x, dc_rest, sh, lane, D[3], dummy); }
+				FFDec d2, d3;
+				if(ok) { ff_channel(w, 2, x); ok = ff_decide(P, 2, x, dc_rest, sh, lane, d2, dummy); }
+				if(ok) { ff_channel(w, 3, x); ok = ff_decide(P, 3, x, dc_rest, sh, lane, d3, dummy); }
 				if(ok) {
 					// channel assignment (stream_encoder.c:3944-3972)
-					const uint32_t b0 = D[0].bits + D[1].bits, b1 = D[0].bits + D[3].bits, b2 = D[1].bits + D[3].bits, b3 = D[2].bits + D[3].bits;
+					const uint32_t b0 = d0.bits + d1.bits, b1 = d0.bits + d3.bits, b2 = d1.bits + d3.bits, b3 = d2.bits + d3.bits;
 					uint32_t mn = b0;
 					if(b1 < mn) { mn = b1; ca = 1; }
 					if(b2 < mn) { mn = b2; ca = 2; }
 					if(b3 < mn) { mn = b3; ca = 3; }
-					li = ca == 2 ? 3 : ca == 3 ? 2 : 0;
-					ri = ca == 0 ? 1 : ca == 2 ? 1 : 3;
+					DL = ca == 2 ? d3 : ca == 3 ? d2 : d0;
+					DR = ca == 0 ? d1 : ca == 2 ? d1 : d3;
 				}
 			}
 		}
@@ -1307,8 +1311,8 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	if(lane == 1) (void)frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { or_bits(img, cap_words, 8 * k, byte, 8); });
 	uint32_t pos = 8 * frame_header_len(P, n, frame_number);
 	for(int s = 0; s < 2; s++) {
-		const uint32_t di = s == 0 ? li : ri;
-		FFDec d = di == 0 ? D[0] : di == 1 ? D[1] : di == 2 ? D[2] : D[3];
+		const FFDec d = s == 0 ? DL : DR;
+		const uint32_t di = d.which;
 		const uint32_t type = d.type, order = d.order, wasted = d.wasted, sbps = d.sbps;
 		int32_t x[FF_RUN + 4];
 		ff_channel(w, di, x);
