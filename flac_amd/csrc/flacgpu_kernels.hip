@@ -1107,6 +1107,11 @@ struct FFShared {
 	uint8_t kout[4][64];                                   // Rice parameters of the four candidate channels
 };
 struct FFDec { uint32_t which, type, order, wasted, sbps, bits, po, rice2; int32_t constant; };
+// 0x40000 / ((1152 >> po) - order), po = 0..6, order = 0..4: the divisors of set_partitioned_rice_'s mean (stream_encoder.c:5018)
+struct FFDiv { uint32_t v[35]; };
+constexpr FFDiv make_ff_div() { FFDiv t{}; for(uint32_t i = 0; i < 35; i++) t.v[i] = 0x40000u / ((1152u >> (i / 5u)) - (i % 5u)); return t; }
+__device__ const FFDiv g_ff_div_tab = make_ff_div();
+#define g_ff_div g_ff_div_tab.v
 __host__ __device__ inline uint32_t ff_tile_bytes(uint32_t slot_bytes) { const uint32_t img = (slot_bytes + 8 + 15) & ~15u; return img > (uint32_t)FF_TILE_BYTES ? img : (uint32_t)FF_TILE_BYTES; }
 
 // the candidate channel `which` (0 left, 1 right, 2 mid, 3 side) of this lane's window
@@ -1155,7 +1160,13 @@ __device__ __forceinline__ bool ff_decide(const DevParams &P, uint32_t which, co
 	const bool fixed_allowed = !is_constant && (!P.disable_fixed || verbatim_bits == 0xffffffffu);      // (max_lpc_order == 0 here)
 	const uint32_t fixed_order = fixed_allowed ? guess_fixed : 0;
 	const uint64_t eg = guess_fixed == 0 ? e0 : guess_fixed == 1 ? e1 : guess_fixed == 2 ? e2 : guess_fixed == 3 ? e3 : e4;
-	const bool fixed_valid = fixed_allowed && !(fixed_rbps(eg, n4) >= (float)sbps);
+	// fixed.c:299 / stream_encoder.c:4169: the order is skipped when log2(ln2 * e / n4), as a float, reaches the sample width.  Below
+	// e = n4 * 2^(sbps-1) that logarithm is under sbps - 1.5 whatever the rounding: no need to take it (it is a hundred fp64
+	// instructions, flacgpu_log.h); music never gets near
+	bool too_wide;
+	if(sbps >= 1 && eg < ((uint64_t)n4 << (sbps - 1))) too_wide = false;
+	else too_wide = fixed_rbps(eg, n4) >= (float)sbps;
+	const bool fixed_valid = fixed_allowed && !too_wide;
 	// first minimum in the reference's evaluation order: verbatim -> constant | the fixed order (prep2_kernel<.,.,DECIDE>)
 	const uint32_t hdr = 8 + wasted;
 	D.which = which; D.wasted = wasted; D.sbps = sbps;
@@ -1220,7 +1231,7 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 		for(int k = 0; k < 8; k++) ((uint32_t *)sh->crc_tab)[(uint32_t)lane + 64u * (uint32_t)k] = tv[k];
 		((uint32_t *)sh->xspan)[lane] = xv;
 		if(lane < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[lane] = bv;
-		if(lane < 35) { const uint32_t po = (uint32_t)lane / 5u, o = (uint32_t)lane - po * 5u; sh->divtab[po * (MAX_ORDER + 1) + o] = 0x40000u / ((n >> po) - o); }
+		if(lane < 35) { const uint32_t po = (uint32_t)lane / 5u, o = (uint32_t)lane - po * 5u; sh->divtab[po * (MAX_ORDER + 1) + o] = g_ff_div[lane]; }
 		if(lane < FF_RUN) tile[lane * FF_TS] = 0;                             // column 0: the samples in front of the block
 #pragma unroll
 		for(int k = 0; k < FF_RUN; k++) {
