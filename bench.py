@@ -388,7 +388,8 @@ def main():
             except Exception:
                 pass
             res.update(value=world * samples_per_step * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=kms, out_bps=out_bps,
-                       roofline={"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       roofline={"bound": "hbm", "kernel": KERNEL_NAMES[dom] if not (dom == "prep" and level < 4) else
+                                 ("ff_kernel (prep2_kernel, eval_list_kernel and pack2_kernel take what it leaves)" if level < 3 else "prep2_kernel"), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
                                  "whole_step_frac": round(alg_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 6),
                                  # every kernel of the step, not only the dominant one: HBM-side bytes of the committed counter pass and
