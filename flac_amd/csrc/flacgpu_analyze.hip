@@ -1448,7 +1448,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 	if(B.ff_done) {
 		// the presets without an LPC search on 16-bit stereo: one kernel writes the frames of nominal length; what it leaves (marks 0) is
 		// taken by the kernels below, whose workgroups skip the frames marked 1
-		const hipError_t e = launch_ff(P, pcm, tail_n ? nframes - 1 : nframes, B.ff_first, B.ff_slots, B.ff_fb, B.ff_info, B.ff_done, s);
+		const hipError_t e = launch_ff(P, pcm, tail_n ? nframes - 1 : nframes, B.ff_first, B.ff_slots, B.ff_fb, B.ff_info, B.ff_done, B.nleft, s);
 		if(e != hipSuccess) return e;
 	}
 	{

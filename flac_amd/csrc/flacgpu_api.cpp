@@ -25,6 +25,7 @@ struct flacgpu_ctx {
 	// HIP events of the last TIMING_RING batches (so that a caller can read per-kernel times of a run of batches
 	// afterwards, without a host sync in between); ev/pev point at the set of the current batch
 	hipEvent_t ev_ring[TIMING_RING][5], pev_ring[TIMING_RING][3];
+	bool ev1_skipped[TIMING_RING];   // the batch ran ff_kernel: nothing to time between the prep and the pack phase, ev[1] was not recorded
 	hipEvent_t *ev;              // start, after analyze, after pack, after compact, spare
 	hipEvent_t *pev;             // inside the analysis: after prep, after autoc, after model
 	uint64_t batch_seq;          // batches launched so far
@@ -128,7 +129,7 @@ extern "C" int flacgpu_batch_phase_ms(flacgpu_ctx *c, uint32_t batches_ago, floa
 	if(hipEventSynchronize(ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	// without LPC analyses nothing is launched between the prep and the evaluation phase, and no event is recorded there
 	const bool lpc = c->P.max_analyses != 0;
-	hipEvent_t seq[7] = {ev[0], pev[0], lpc ? pev[1] : pev[0], lpc ? pev[2] : pev[0], ev[1], ev[2], ev[3]};
+	hipEvent_t seq[7] = {ev[0], pev[0], lpc ? pev[1] : pev[0], lpc ? pev[2] : pev[0], c->ev1_skipped[slot] ? pev[0] : ev[1], ev[2], ev[3]};
 	for(int i = 0; i < 6; i++) if(hipEventElapsedTime(&ms[i], seq[i], seq[i + 1]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	return FLACGPU_OK;
 }
@@ -454,6 +455,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		if(P.num_apod && hipMemcpy(c->d_tail_windows, tail_windows_host, (size_t)P.num_apod * tail_n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
 	c->ev = c->ev_ring[c->batch_seq % TIMING_RING]; c->pev = c->pev_ring[c->batch_seq % TIMING_RING];
+	const size_t ring_slot = c->batch_seq % TIMING_RING;
 	c->batch_seq++;
 	(void)hipEventRecord(c->ev[0], s);
 	bool fused = false;
@@ -465,6 +467,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	const bool ff = c->d_ffdone && !c->d_vhints && !c->ab.dbg && !fuse_env;
 	c->ab.ff_done = ff ? c->d_ffdone : nullptr; c->ab.ff_slots = c->d_slots; c->ab.ff_fb = c->d_frame_bytes; c->ab.ff_info = c->d_info; c->ab.ff_first = first;
 	if(c->ab.dbg || nframes < 256 * nsub || ff) nsub = 1;
+	c->ev1_skipped[ring_slot] = ff;
 	if(nsub > 1) {
 		// Independent sub-batches on their own streams: the latency-bound kernels of one (prep, model, pack) fill the
 		// gaps of the VALU-bound kernels of another (autoc, eval).  Every buffer is indexed by frame, so a sub-batch
@@ -524,7 +527,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			free(h);
 			(void)hipMemsetAsync(c->ab.dbg, 0, nwg * 16 * sizeof(unsigned long long), s);
 		}
-		(void)hipEventRecord(c->ev[1], s);
+		if(!ff) (void)hipEventRecord(c->ev[1], s);          // (an event record costs the stream ~4 us: 2 % of a -0 step)
 		{
 			// FLACGPU_FUSED_COMPACT=1: the pack kernel writes every frame once, at its final place (single-pass prefix sum with
 			// decoupled look-back inside the kernel; no slots, no scan / compact kernels).  Off by default: measured on MI355X
@@ -946,8 +949,9 @@ extern "C" int flacgpu_last_batch_kernel_ms(flacgpu_ctx *c, float *analyze_ms, f
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	if(hipEventSynchronize(c->ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	float a = 0, p = 0, k = 0;
-	if(hipEventElapsedTime(&a, c->ev[0], c->ev[1]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(hipEventElapsedTime(&p, c->ev[1], c->ev[2]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	hipEvent_t e1 = c->ev1_skipped[(c->batch_seq - 1) % TIMING_RING] ? c->pev[0] : c->ev[1];
+	if(hipEventElapsedTime(&a, c->ev[0], e1) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipEventElapsedTime(&p, e1, c->ev[2]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	if(hipEventElapsedTime(&k, c->ev[2], c->ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	if(analyze_ms) *analyze_ms = a;
 	if(pack_ms) *pack_ms = p;

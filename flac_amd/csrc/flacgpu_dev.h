@@ -159,7 +159,7 @@ hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes
                        const PackOutArgs *po, bool *fused_out, uint32_t *hints, uint32_t *hinted_frames, const uint8_t *skip, hipStream_t s);
 // the one-kernel path of the presets without an LPC search on 16-bit stereo in 1152-sample blocks (flacgpu_kernels.hip: ff_kernel)
 bool ff_applicable(const DevParams &P);
-hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, uint8_t *done, hipStream_t s);
+hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, uint8_t *done, uint32_t *nleft, hipStream_t s);
 // hints (null: none wanted): [frame][channel][HINT_RUNS] bit offset, from the frame's first byte, at which the codes of each
 // 16-sample run of a residual-coded subframe start (the partition's parameter field when the run opens a partition) -- what the
 // hinted verify pass decodes from (flacgpu_decode_hinted.h).  *hinted_frames: the leading frames that got them.

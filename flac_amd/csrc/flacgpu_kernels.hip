@@ -211,10 +211,13 @@ __device__ uint32_t frame_crc16(const uint32_t *img, uint32_t body_bytes, const 
 // The same for pack2_kernel's LDS image: 44-byte spans (conflict-free reads, see CRC2_SPAN); every lane loads its eleven words
 // at once and runs them under a predicate, the lane with the short last span included -- that span used to be a byte-serial
 // chain of up to 64 dependent LDS round trips which the whole workgroup waited for at the barrier.
-template <int NT>
+// SPANW: words per span, odd.  11 (the table g_crc_tables.xspan44 behind the LDS copy); ff_kernel: 13 with its own table, all of it in LDS
+// (its frames of ~3 KB are 66..69 spans of 44 bytes -- a second pass of the wavefront for two to five lanes -- and 56..59 of 52)
+template <int NT, int SPANW = (int)CRC2_WORDS>
 __device__ __forceinline__ uint32_t frame_crc16_p2(const uint32_t *img, uint32_t body_bytes, const uint16_t (*crc_tab)[256], uint32_t *crc_parts, int tid,
                                                    const uint16_t *xspan_lds, uint32_t nxspan_lds, const uint16_t *xbyte_lds)
 {
+	constexpr uint32_t CRC2_SPAN = 4 * SPANW, CRC2_WORDS = SPANW;          // (shadow the 11-word constants)
 	const uint32_t nsp = (body_bytes + CRC2_SPAN - 1) / CRC2_SPAN;
 	const uint32_t last_len = body_bytes - (nsp ? nsp - 1 : 0) * CRC2_SPAN;                // 1..44 bytes
 	uint32_t c = 0;                     // low half: whole spans, shifted among themselves; high half: the last span
@@ -244,7 +247,7 @@ __device__ __forceinline__ uint32_t frame_crc16_p2(const uint32_t *img, uint32_t
 		}
 		else {
 			const uint32_t m = nsp - 2 - sp;
-			const uint32_t xs = m < nxspan_lds ? xspan_lds[m] : g_crc_tables.xspan44[m];
+			const uint32_t xs = (SPANW != 11 || m < nxspan_lds) ? xspan_lds[m] : g_crc_tables.xspan44[m];
 			c ^= m ? gf16_mul(cs, xs) : cs;
 		}
 	}
@@ -1107,6 +1110,23 @@ struct FFShared {
 	uint8_t kout[4][64];                                   // Rice parameters of the four candidate channels
 };
 struct FFDec { uint32_t which, type, order, wasted, sbps, bits, po, rice2; int32_t constant; };
+// x^(416 m) mod P, m = 0..127: the span shifts of frame_crc16_p2<64, 13> (52-byte spans)
+struct FFSpan { uint16_t x[FF_XSPAN]; };
+constexpr FFSpan make_ff_span()
+{
+	FFSpan t{};
+	uint32_t xs = 1;
+	for(int r = 0; r < 52; r++) xs = crc_mulx8(xs);                          // x^416
+	uint32_t c = 1;
+	for(uint32_t m = 0; m < FF_XSPAN; m++) {
+		t.x[m] = (uint16_t)c;
+		uint32_t r = 0, b = xs;
+		for(int i = 0; i < 16; i++) { r = crc_mulx(r); if(b & 0x8000u) r ^= c; b = (b << 1) & 0xffffu; }
+		c = r;
+	}
+	return t;
+}
+__device__ const FFSpan g_ff_span = make_ff_span();
 // 0x40000 / ((1152 >> po) - order), po = 0..6, order = 0..4: the divisors of set_partitioned_rice_'s mean (stream_encoder.c:5018)
 struct FFDiv { uint32_t v[35]; };
 constexpr FFDiv make_ff_div() { FFDiv t{}; for(uint32_t i = 0; i < 35; i++) t.v[i] = 0x40000u / ((1152u >> (i / 5u)) - (i % 5u)); return t; }
@@ -1208,11 +1228,13 @@ __device__ __forceinline__ bool ff_decide(const DevParams &P, uint32_t which, co
 #endif
 template <int MS>       // DevParams::ms_mode
 __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint64_t first_frame_number,
-                                                 uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, FrameInfo *__restrict__ info, uint8_t *__restrict__ done)
+                                                 uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, FrameInfo *__restrict__ info, uint8_t *__restrict__ done,
+                                                 uint32_t *__restrict__ nleft)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = (int)threadIdx.x;
 	const uint32_t f = blockIdx.x;
+	if(f == 0 && lane == 0) { nleft[0] = 0; nleft[1] = 0; }                   // the lists of the kernels behind this one start empty (no memset in between)
 	constexpr uint32_t n = FF_N;
 	uint32_t *tile = (uint32_t *)smem;                                        // the transposed tile, later the frame image
 	FFShared *sh = (FFShared *)(smem + ff_tile_bytes(P.slot_bytes));
@@ -1222,7 +1244,7 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 		const int2 *p = (const int2 *)(pcm + (size_t)f * n * 2);
 #pragma unroll
 		for(int k = 0; k < FF_RUN; k++) v[k] = p[(uint32_t)lane + 64u * (uint32_t)k];
-		const uint32_t *tab32 = (const uint32_t *)g_crc_tables.tab, *xs32 = (const uint32_t *)g_crc_tables.xspan44, *xb32 = (const uint32_t *)g_crc_tables.xbyte;
+		const uint32_t *tab32 = (const uint32_t *)g_crc_tables.tab, *xs32 = (const uint32_t *)g_ff_span.x, *xb32 = (const uint32_t *)g_crc_tables.xbyte;
 		uint32_t tv[8];
 #pragma unroll
 		for(int k = 0; k < 8; k++) tv[k] = tab32[(uint32_t)lane + 64u * (uint32_t)k];
@@ -1416,7 +1438,7 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	const uint32_t body_bytes = (pos + 7) >> 3, total_bytes = body_bytes + 2;
 	const bool overflow = total_bytes > P.slot_bytes;
 	{
-		const uint32_t crc = frame_crc16_p2<64>(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, lane, sh->xspan, FF_XSPAN, sh->xbyte);
+		const uint32_t crc = frame_crc16_p2<64, 13>(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, lane, sh->xspan, FF_XSPAN, sh->xbyte);
 		if(lane == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
 	}
@@ -1692,15 +1714,15 @@ bool ff_applicable(const DevParams &P)
 {
 	static const bool off = getenv("FLACGPU_NO_FF") != nullptr;
 	return !off && P.channels == 2 && P.bps <= 16 && P.blocksize == FF_N && P.ncand == (P.ms_mode == 1 ? 4u : 2u) && prep2_decides(P) && pack2_applicable(P)
-	       && (1152u >> P.max_po) % 18u == 0 && ff_tile_bytes(P.slot_bytes) + sizeof(FFShared) <= 40 * 1024;
+	       && (1152u >> P.max_po) % 18u == 0 && P.slot_bytes <= 52 * FF_XSPAN - 64;      // (every span shift of a frame in the LDS table)
 }
-hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, uint8_t *done, hipStream_t s)
+hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, uint8_t *done, uint32_t *nleft, hipStream_t s)
 {
 	if(nmain == 0) return hipSuccess;
 	const size_t lds = ff_tile_bytes(P.slot_bytes) + sizeof(FFShared);
-	if(P.ms_mode == 0) hipLaunchKernelGGL(ff_kernel<0>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done);
-	else if(P.ms_mode == 1) hipLaunchKernelGGL(ff_kernel<1>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done);
-	else hipLaunchKernelGGL(ff_kernel<2>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done);
+	if(P.ms_mode == 0) hipLaunchKernelGGL(ff_kernel<0>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done, nleft);
+	else if(P.ms_mode == 1) hipLaunchKernelGGL(ff_kernel<1>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done, nleft);
+	else hipLaunchKernelGGL(ff_kernel<2>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done, nleft);
 	return hipGetLastError();
 }
 hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s)

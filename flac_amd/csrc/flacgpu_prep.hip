@@ -577,7 +577,11 @@ bool prep2_decides(const DevParams &P)
 
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
 {
-	if(nmain == 0) return hipSuccess;
+	if(nmain == 0) {
+		// a batch that is only a short last block: the list the deciding prep kernel would have started must still start empty
+		if(prep2_decides(P)) (void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
+		return hipSuccess;
+	}
 	static bool attr_set = false;
 	if(!attr_set) {
 		hipError_t e = hipSuccess;
@@ -608,7 +612,7 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 #define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft, B.ff_done)
 	if(prep2_decides(P)) {
 		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
-		(void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
+		if(!B.ff_done || nmain == 0) (void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);      // (ff_kernel, launched in front, has zeroed them)
 		const size_t ldz = prep2_decide_lds(P, nraw, waves);
 		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft, B.ff_done);
 		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft, B.ff_done);
