@@ -27,7 +27,7 @@ for step in "$@"; do
       if [ -n "$arg" ]; then FLACGPU_POISON=1 timeout 1500 python -m pytest tests -x -q -m gpu -k "$arg" > $OUT/pytest_$i.log 2>&1
       else FLACGPU_POISON=1 timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest_$i.log 2>&1; fi
       rc=$?; echo "[$i] pytest rc=$rc"; tail -4 $OUT/pytest_$i.log
-      [ $rc -ne 0 ] && { echo "test step failed: visit abandoned"; exit 4; } ;;
+      if [ $rc -ne 0 ]; then echo "test step failed: visit abandoned"; exit 4; fi ;;
     bench)
       timeout 900 python bench.py $arg > $OUT/bench_$i.json 2> $OUT/bench_$i.err; echo "[$i] bench $arg rc=$?"; cat $OUT/bench_$i.json; tail -2 $OUT/bench_$i.err ;;
     prof)

@@ -642,3 +642,34 @@ def test_two_wavefronts_per_channel_variant():
             "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLACGPU_EVAL_WPC="2"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_one_kernel_path_and_what_it_leaves(level):
+    """ff_kernel (-0 .. -2 on 16-bit stereo, 1152-sample blocks: one kernel per batch) takes a frame only when its partition sums
+    stay inside the search's 32-bit arithmetic; with `-r 0` a lane's 18 samples may sum to 2^17 at most, which full-scale noise
+    exceeds and music does not: a stream of both has frames written by that kernel next to frames it left to the three-kernel
+    path, whose workgroups skip the marked ones.  Same bytes as the oracle, with the default partition orders too."""
+    quiet, loud = signals.music(1152 * 7, 2, 16, seed=21), signals.white(1152 * 6 + 500, 2, 16, seed=22)
+    pcm = np.concatenate([quiet[: 1152 * 3], loud[: 1152 * 4], quiet[1152 * 3:], loud[1152 * 4:]])
+    for kw, okw in ((dict(min_partition_order=0, max_partition_order=0), dict(min_po=0, max_po=0)), ({}, {})):
+        data, fb = _gpu_encode(pcm, 16, 44100, level, max_batch=8, **kw)
+        o = po.oracle_encode(pcm, 16, 44100, level, **okw)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (level, kw)
+
+
+def test_three_kernel_path_of_the_fast_presets():
+    """FLACGPU_NO_FF=1 (read once per process): -0 .. -2 on 16-bit stereo through prep2_kernel<., 1152, DECIDE>, eval_list_kernel and
+    pack2_kernel<., 64, 18>, the path ff_kernel falls back to -- a fresh interpreter must produce the oracle's bytes with it"""
+    import subprocess, sys
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, flac_amd, signals\n"
+            "from oracle import pyoracle as po\n"
+            "for level, seed in ((0, 5), (1, 6), (2, 7)):\n"
+            "    pcm = signals.music(1152 * 21 + 77, 2, 16, seed=seed)\n"
+            "    eng = flac_amd.FrameEngine(flac_amd.make_settings(2, 16, 44100, level), device=0, max_batch_frames=16)\n"
+            "    data, fb = eng.encode(pcm); eng.close()\n"
+            "    assert data == po.oracle_encode(pcm, 16, 44100, level)['data'], level\n"
+            "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLACGPU_NO_FF="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
