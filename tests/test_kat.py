@@ -116,3 +116,21 @@ def test_frame_header_utf8_and_crc8():
         hdr_len = 4 + len(u)
         assert _crc8_ref(d[:hdr_len]) == d[hdr_len]
         assert _crc16_ref(d[:-2]) == int.from_bytes(d[-2:], "big")
+
+
+def test_the_residual_width_check_needs_no_logarithm_far_below_its_threshold():
+    """ff_kernel (flacgpu_kernels.hip) skips fixed.c:299's logarithm when the error sum e is below n4 * 2^(sbps-1): there
+    log2(ln2 * e / n4) < sbps - 1.5, so the float it becomes cannot reach sbps whatever the rounding.  Pinned here on the boundary
+    of every width the kernel sees (n4 = 1148: a 1152-sample block)."""
+    import math
+    import numpy as np
+    n4 = 1148
+    for sbps in range(1, 18):
+        for e in (1, (n4 << (sbps - 1)) // 2, (n4 << (sbps - 1)) - 1):
+            if e < 1:
+                continue
+            rbps = np.float32(math.log(0.69314718055994530942 * e / n4) / 0.69314718055994530942)
+            assert rbps < np.float32(sbps) - np.float32(1.4), (sbps, e, rbps)
+        # and at twice the bound the estimate is still below the width: the kernel's exact branch decides there
+        e2 = n4 << sbps
+        assert np.float32(math.log(0.69314718055994530942 * e2 / n4) / 0.69314718055994530942) < np.float32(sbps)
