@@ -42,6 +42,12 @@ __device__ __forceinline__ uint32_t mad24_chain_s(const int32_t *xr /* xr[-1 - j
 		    "v_mad_i32_i24 %0, %18, %19, %0\n\tv_lshrrev_b32 %0, %20, %0"
 		    : "=&v"(d) : "v"(sum0), "v"(xr[-1]), "s"(q[0]), "v"(xr[-2]), "s"(q[1]), "v"(xr[-3]), "s"(q[2]), "v"(xr[-4]), "s"(q[3]), "v"(xr[-5]), "s"(q[4]), "v"(xr[-6]), "s"(q[5]),
 		      "v"(xr[-7]), "s"(q[6]), "v"(xr[-8]), "s"(q[7]), "v"(xr[0]), "s"(negpow), "s"(shift));
+	if constexpr(NT == 10)
+		asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\t"
+		    "v_mad_i32_i24 %0, %10, %11, %0\n\tv_mad_i32_i24 %0, %12, %13, %0\n\tv_mad_i32_i24 %0, %14, %15, %0\n\tv_mad_i32_i24 %0, %16, %17, %0\n\t"
+		    "v_mad_i32_i24 %0, %18, %19, %0\n\tv_mad_i32_i24 %0, %20, %21, %0\n\tv_mad_i32_i24 %0, %22, %23, %0\n\tv_lshrrev_b32 %0, %24, %0"
+		    : "=&v"(d) : "v"(sum0), "v"(xr[-1]), "s"(q[0]), "v"(xr[-2]), "s"(q[1]), "v"(xr[-3]), "s"(q[2]), "v"(xr[-4]), "s"(q[3]), "v"(xr[-5]), "s"(q[4]), "v"(xr[-6]), "s"(q[5]),
+		      "v"(xr[-7]), "s"(q[6]), "v"(xr[-8]), "s"(q[7]), "v"(xr[-9]), "s"(q[8]), "v"(xr[-10]), "s"(q[9]), "v"(xr[0]), "s"(negpow), "s"(shift));
 	if constexpr(NT == 12) {
 		uint32_t t;
 		asm("v_mad_i32_i24 %0, %2, %3, %1\n\tv_mad_i32_i24 %0, %4, %5, %0\n\tv_mad_i32_i24 %0, %6, %7, %0\n\tv_mad_i32_i24 %0, %8, %9, %0\n\t"
@@ -66,6 +72,12 @@ __device__ __forceinline__ uint64_t mad64_chain_s(const int32_t *xr, const uint3
 		    "v_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0\n\tv_mad_i64_i32 %0, vcc, %15, %16, %0"
 		    : "=&v"(d) : "v"(xr[-1]), "s"(q[0]), "v"(xr[-2]), "s"(q[1]), "v"(xr[-3]), "s"(q[2]), "v"(xr[-4]), "s"(q[3]), "v"(xr[-5]), "s"(q[4]), "v"(xr[-6]), "s"(q[5]),
 		      "v"(xr[-7]), "s"(q[6]), "v"(xr[-8]), "s"(q[7]), "v"(init) : "vcc");
+	if constexpr(NT == 10)
+		asm("v_mad_i64_i32 %0, vcc, %1, %2, %21\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\t"
+		    "v_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0\n\tv_mad_i64_i32 %0, vcc, %15, %16, %0\n\t"
+		    "v_mad_i64_i32 %0, vcc, %17, %18, %0\n\tv_mad_i64_i32 %0, vcc, %19, %20, %0"
+		    : "=&v"(d) : "v"(xr[-1]), "s"(q[0]), "v"(xr[-2]), "s"(q[1]), "v"(xr[-3]), "s"(q[2]), "v"(xr[-4]), "s"(q[3]), "v"(xr[-5]), "s"(q[4]), "v"(xr[-6]), "s"(q[5]),
+		      "v"(xr[-7]), "s"(q[6]), "v"(xr[-8]), "s"(q[7]), "v"(xr[-9]), "s"(q[8]), "v"(xr[-10]), "s"(q[9]), "v"(init) : "vcc");
 	if constexpr(NT == 12)
 		asm("v_mad_i64_i32 %0, vcc, %1, %2, %25\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\t"
 		    "v_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0\n\tv_mad_i64_i32 %0, vcc, %15, %16, %0\n\t"
@@ -114,10 +126,12 @@ __device__ __forceinline__ uint32_t fir16_w_dispatch(const int32_t (&x)[28], con
 	if(C.wide) {
 		if(C.nt == 4) return fir16_w<4, true, FIRST>(x, xm, C, lane0, sum0);
 		if(C.nt == 8) return fir16_w<8, true, FIRST>(x, xm, C, lane0, sum0);
+		if(C.nt == 10) return fir16_w<10, true, FIRST>(x, xm, C, lane0, sum0);
 		return fir16_w<12, true, FIRST>(x, xm, C, lane0, sum0);
 	}
 	if(C.nt == 4) return fir16_w<4, false, FIRST>(x, xm, C, lane0, sum0);
 	if(C.nt == 8) return fir16_w<8, false, FIRST>(x, xm, C, lane0, sum0);
+	if(C.nt == 10) return fir16_w<10, false, FIRST>(x, xm, C, lane0, sum0);      // (96 kHz / 24-bit music at -8: three in five winners have order 10)
 	return fir16_w<12, false, FIRST>(x, xm, C, lane0, sum0);
 }
 
@@ -236,7 +250,7 @@ __device__ __forceinline__ bool evalw_body(const DevParams &P, const int32_t *__
 		A.wide = rdlane(c_wide, ci0); B.wide = rdlane(c_wide, ci1);
 		A.bias = 0x80000000u >> A.shift; B.bias = 0x80000000u >> B.shift;
 		A.negpow = 0u - (1u << A.shift); B.negpow = 0u - (1u << B.shift);
-		A.nt = A.order <= 4 ? 4u : (MAXORD <= 8 || A.order <= 8) ? 8u : 12u; B.nt = B.order <= 4 ? 4u : (MAXORD <= 8 || B.order <= 8) ? 8u : 12u;
+		A.nt = A.order <= 4 ? 4u : (MAXORD <= 8 || A.order <= 8) ? 8u : A.order <= 10 ? 10u : 12u; B.nt = B.order <= 4 ? 4u : (MAXORD <= 8 || B.order <= 8) ? 8u : B.order <= 10 ? 10u : 12u;
 		A.ci = ci0; B.ci = ci1;
 
 		uint64_t s0 = 0, s1 = 0;
