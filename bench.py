@@ -421,7 +421,7 @@ def main():
         side_steps = max(3, args.steps // 2)
         w = measure(8, "white", side_steps, 1, False)
         l5 = measure(5, "music", side_steps, 1, False)
-        l0 = measure(0, "music", side_steps, 1, False)
+        l0 = measure(0, "music", 4 * side_steps, 2, False)       # (0.2 ms steps: five of them are a millisecond, too short a stretch to time)
         args.hires = True
         RATE, BPS = 96000, 24
         hr = measure(8, "music", max(3, side_steps // 2), 1, False)
