@@ -1445,12 +1445,6 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 		if(e != hipSuccess) return e;
 		attr_set = true;
 	}
-	if(B.ff_done) {
-		// the presets without an LPC search on 16-bit stereo: one kernel writes the frames of nominal length; what it leaves (marks 0) is
-		// taken by the kernels below, whose workgroups skip the frames marked 1
-		const hipError_t e = launch_ff(P, pcm, tail_n ? nframes - 1 : nframes, B.ff_first, B.ff_slots, B.ff_fb, B.ff_info, B.ff_done, B.nleft, s);
-		if(e != hipSuccess) return e;
-	}
 	{
 		// frames of nominal length: one workgroup per frame (flacgpu_prep.hip); the short last block, and block sizes that
 		// kernel does not take, go through the workgroup-per-subframe kernel above

@@ -25,7 +25,8 @@ struct flacgpu_ctx {
 	// HIP events of the last TIMING_RING batches (so that a caller can read per-kernel times of a run of batches
 	// afterwards, without a host sync in between); ev/pev point at the set of the current batch
 	hipEvent_t ev_ring[TIMING_RING][5], pev_ring[TIMING_RING][3];
-	bool ev1_skipped[TIMING_RING];   // the batch ran ff_kernel: nothing to time between the prep and the pack phase, ev[1] was not recorded
+	hipEvent_t seq_ring[TIMING_RING][7];   // the seven phase boundaries of each batch: which of its events closes which phase (an event record costs
+	                                       // the stream ~4 us, so phases that launch nothing share the event of the phase in front)
 	hipEvent_t *ev;              // start, after analyze, after pack, after compact, spare
 	hipEvent_t *pev;             // inside the analysis: after prep, after autoc, after model
 	uint64_t batch_seq;          // batches launched so far
@@ -37,11 +38,15 @@ struct flacgpu_ctx {
 	float *d_tail_windows;       // [num_apod][blocksize] scratch for the short last block
 	SubDecision *d_decisions;    // [max_batch][ncand]
 	uint8_t *d_slots;            // [max_batch][slot_bytes]
-	uint8_t *d_ffdone;           // [max_batch] ff_kernel's per-frame marks (allocated when that kernel can take this stream)
+	bool ff_ok;                  // ff_kernel (one kernel per batch: -0 .. -2 on 16-bit stereo) can take this stream
 	uint32_t *d_frame_bytes;     // [max_batch]
 	uint64_t *d_offsets;         // [max_batch+1]
 	uint64_t *d_total;
-	uint64_t *d_scanstate;       // [max_batch+1] status words of the fused compaction (flacgpu_kernels.hip: scan_lookback)
+	// the fused output (flacgpu_kernels.hip: PackOut): tagged frame lengths, segment totals and starts, arrival counters, the ticket
+	uint64_t *d_fo_fstate, *d_fo_sstate, *d_fo_sprefix, *d_fo_scount;
+	uint32_t *d_fo_fall, *d_fo_nfall;
+	size_t fo_frames, fo_segs;
+	uint32_t fo_epoch, fo_spin_limit;
 	FrameInfo *d_info;           // [max_batch]
 	int32_t *d_pcm;              // staging for the host entry point
 	uint8_t *d_raw;              // raw sample bytes of flacgpu_encode_batch_raw
@@ -125,12 +130,12 @@ extern "C" int flacgpu_batch_phase_ms(flacgpu_ctx *c, uint32_t batches_ago, floa
 	if(!c || !ms || !c->timing_valid || batches_ago >= (uint32_t)TIMING_RING || batches_ago >= c->batch_seq) return FLACGPU_ERR_BAD_ARG;
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	const size_t slot = (size_t)((c->batch_seq - 1 - batches_ago) % TIMING_RING);
-	hipEvent_t *ev = c->ev_ring[slot], *pev = c->pev_ring[slot];
-	if(hipEventSynchronize(ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	// without LPC analyses nothing is launched between the prep and the evaluation phase, and no event is recorded there
-	const bool lpc = c->P.max_analyses != 0;
-	hipEvent_t seq[7] = {ev[0], pev[0], lpc ? pev[1] : pev[0], lpc ? pev[2] : pev[0], c->ev1_skipped[slot] ? pev[0] : ev[1], ev[2], ev[3]};
-	for(int i = 0; i < 6; i++) if(hipEventElapsedTime(&ms[i], seq[i], seq[i + 1]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	hipEvent_t *seq = c->seq_ring[slot];
+	if(hipEventSynchronize(seq[6]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	for(int i = 0; i < 6; i++) {
+		ms[i] = 0.0f;
+		if(seq[i] != seq[i + 1] && hipEventElapsedTime(&ms[i], seq[i], seq[i + 1]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	}
 	return FLACGPU_OK;
 }
 extern "C" int flacgpu_last_batch_phase_ms(flacgpu_ctx *c, float ms[6]) { return flacgpu_batch_phase_ms(c, 0, ms); }
@@ -193,11 +198,15 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->d_tail_windows) (void)hipFree(c->d_tail_windows);
 	if(c->d_decisions) (void)hipFree(c->d_decisions);
 	if(c->d_slots) (void)hipFree(c->d_slots);
-	if(c->d_ffdone) (void)hipFree(c->d_ffdone);
 	if(c->d_frame_bytes) (void)hipFree(c->d_frame_bytes);
 	if(c->d_offsets) (void)hipFree(c->d_offsets);
 	if(c->d_total) (void)hipFree(c->d_total);
-	if(c->d_scanstate) (void)hipFree(c->d_scanstate);
+	if(c->d_fo_fstate) (void)hipFree(c->d_fo_fstate);
+	if(c->d_fo_sstate) (void)hipFree(c->d_fo_sstate);
+	if(c->d_fo_sprefix) (void)hipFree(c->d_fo_sprefix);
+	if(c->d_fo_scount) (void)hipFree(c->d_fo_scount);
+	if(c->d_fo_fall) (void)hipFree(c->d_fo_fall);
+	if(c->d_fo_nfall) (void)hipFree(c->d_fo_nfall);
 	if(c->d_info) (void)hipFree(c->d_info);
 	if(c->d_pcm) (void)hipFree(c->d_pcm);
 	if(c->d_raw) (void)hipFree(c->d_raw);
@@ -386,7 +395,20 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	ok = ok && hipMalloc(&c->d_frame_bytes, B * sizeof(uint32_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_offsets, (B + 1) * sizeof(uint64_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_total, sizeof(uint64_t)) == hipSuccess;
-	ok = ok && hipMalloc(&c->d_scanstate, (B + 1) * sizeof(uint64_t)) == hipSuccess;
+	{
+		// fused output: zeroed here, once (epoch 0 is never used), and whenever the epoch wraps
+		c->fo_frames = (B + 63) & ~(size_t)63; c->fo_segs = c->fo_frames / 64; c->fo_epoch = 0;
+		ok = ok && hipMalloc(&c->d_fo_fstate, c->fo_frames * sizeof(uint64_t)) == hipSuccess && hipMemset(c->d_fo_fstate, 0, c->fo_frames * sizeof(uint64_t)) == hipSuccess;
+		ok = ok && hipMalloc(&c->d_fo_sstate, c->fo_segs * sizeof(uint64_t)) == hipSuccess && hipMemset(c->d_fo_sstate, 0, c->fo_segs * sizeof(uint64_t)) == hipSuccess;
+		ok = ok && hipMalloc(&c->d_fo_scount, c->fo_segs * sizeof(uint64_t)) == hipSuccess && hipMemset(c->d_fo_scount, 0, c->fo_segs * sizeof(uint64_t)) == hipSuccess;
+		ok = ok && hipMalloc(&c->d_fo_sprefix, c->fo_segs * sizeof(uint64_t)) == hipSuccess && hipMemset(c->d_fo_sprefix, 0, c->fo_segs * sizeof(uint64_t)) == hipSuccess;
+		ok = ok && hipMalloc(&c->d_fo_fall, c->fo_frames * sizeof(uint32_t)) == hipSuccess;
+		ok = ok && hipMalloc(&c->d_fo_nfall, 2 * sizeof(uint32_t)) == hipSuccess && hipMemset(c->d_fo_nfall, 0, 2 * sizeof(uint32_t)) == hipSuccess;
+		// a poll is three loads and a short sleep, ~1 us: a frame gives up after a few milliseconds (FLACGPU_FUSED_SPIN_LIMIT=0: at once
+		// -- the tests' way to the slot + fo_fixup_kernel route)
+		c->fo_spin_limit = 4096;
+		if(const char *e = getenv("FLACGPU_FUSED_SPIN_LIMIT")) c->fo_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
+	}
 	ok = ok && hipMalloc(&c->d_info, B * sizeof(FrameInfo)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_jobtab, 2 * sizeof(JobTable)) == hipSuccess;
 	ok = ok && hipMemcpy(c->d_jobtab, c->h_jobtab, sizeof(JobTable), hipMemcpyHostToDevice) == hipSuccess;
@@ -401,7 +423,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		ok = ok && hipMalloc(&c->ab.left, nfc * sizeof(uint32_t)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.left2, nfc * sizeof(uint32_t)) == hipSuccess;
 		ok = ok && hipMalloc(&c->ab.nleft, 2 * FLACGPU_MAX_SUBBATCHES * sizeof(uint32_t)) == hipSuccess;
-		if(ok && ff_applicable(P)) ok = hipMalloc(&c->d_ffdone, B) == hipSuccess;
+		c->ff_ok = ff_applicable(P);
 		if(ok && getenv("FLACGPU_DEBUG_TIMING")) { ok = hipMalloc(&c->ab.dbg, nfc * 16 * sizeof(unsigned long long)) == hipSuccess; if(ok) (void)hipMemset(c->ab.dbg, 0, nfc * 16 * sizeof(unsigned long long)); }
 	}
 	if(!ok) { free_ctx(c); return FLACGPU_ERR_ALLOC; }
@@ -456,19 +478,63 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	}
 	c->ev = c->ev_ring[c->batch_seq % TIMING_RING]; c->pev = c->pev_ring[c->batch_seq % TIMING_RING];
 	const size_t ring_slot = c->batch_seq % TIMING_RING;
+	hipEvent_t *seq = c->seq_ring[ring_slot];
 	c->batch_seq++;
 	(void)hipEventRecord(c->ev[0], s);
 	bool fused = false;
 	uint32_t nsub = c->nsub;
+	// The fused output (flacgpu_kernels.hip, PackOut): the pack kernels (pack2_kernel, ff_kernel) write every frame once, at its
+	// final place; no slots, no scan / compact kernels.  FLACGPU_NO_FUSED_COMPACT=1: the two-kernel compaction, for A/B runs and the
+	// parity tests of that path.
+	static int fuse = -1;
+	if(fuse < 0) fuse = getenv("FLACGPU_NO_FUSED_COMPACT") ? 0 : 1;
+	PackOutArgs po = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+	if(fuse && nframes <= c->fo_frames) {
+		// (the epoch is committed below, once a kernel has really run with it: its fix-up kernel is what prepares the other bank)
+		uint32_t epoch = c->fo_epoch + 1;
+		if(epoch >= (1u << 24)) {
+			// the tags have gone round: start again from clean words (once in sixteen million batches)
+			if(hipMemsetAsync(c->d_fo_fstate, 0, c->fo_frames * sizeof(uint64_t), s) != hipSuccess || hipMemsetAsync(c->d_fo_sstate, 0, c->fo_segs * sizeof(uint64_t), s) != hipSuccess ||
+			   hipMemsetAsync(c->d_fo_sprefix, 0, c->fo_segs * sizeof(uint64_t), s) != hipSuccess || hipMemsetAsync(c->d_fo_nfall, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			c->fo_epoch = 0; epoch = 1;
+		}
+		po = PackOutArgs{d_out, out_cap, c->d_offsets, c->d_total, c->d_fo_fstate, c->d_fo_sstate, c->d_fo_sprefix, c->d_fo_scount, c->d_fo_fall, c->d_fo_nfall, epoch, c->fo_spin_limit};
+	}
 	// ff_kernel (one kernel for the whole frame, flacgpu_kernels.hip) where it applies: not with the verify hints (the decoder wants
-	// the pack kernel's run starts), not with the debug stamps, not with the fused output; one stream
-	static int fuse_env = -1;
-	if(fuse_env < 0) fuse_env = getenv("FLACGPU_FUSED_COMPACT") ? 1 : 0;
-	const bool ff = c->d_ffdone && !c->d_vhints && !c->ab.dbg && !fuse_env;
-	c->ab.ff_done = ff ? c->d_ffdone : nullptr; c->ab.ff_slots = c->d_slots; c->ab.ff_fb = c->d_frame_bytes; c->ab.ff_info = c->d_info; c->ab.ff_first = first;
+	// the pack kernel's run starts), not with the debug stamps; one stream
+	const bool ff = c->ff_ok && !c->d_vhints && !c->ab.dbg;
 	if(c->ab.dbg || nframes < 256 * nsub || ff) nsub = 1;
-	c->ev1_skipped[ring_slot] = ff;
-	if(nsub > 1) {
+	const bool lpc = P.max_analyses != 0;
+	if(ff) {
+		// every frame of nominal length in ONE launch; a short last block goes through the general kernels as a batch of its own
+		// (every buffer is indexed by frame: the same launches on offset pointers) and then, with the fused output, behind the others
+		const uint32_t nmain = tail_n ? nframes - 1 : nframes;
+		if(launch_ff(P, d_pcm, nmain, first, c->d_slots, c->d_frame_bytes, c->d_info, po.out ? &po : nullptr, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		fused = po.out != nullptr && nmain != 0;
+		hipEvent_t after_main = c->ev[3];
+		if(tail_n) {
+			(void)hipEventRecord(c->pev[0], s);
+			after_main = c->pev[0];
+			const size_t fc0 = (size_t)nmain * P.ncand, ncs = P.ncslots;
+			AnalyzeBuffers B = c->ab;
+			B.prep += fc0; B.autoc += fc0 * P.max_jobs * AUTOC_STRIDE; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.chan_stride; B.left += fc0; B.left2 += fc0; B.dbg = nullptr;
+			if(launch_analyze(P, d_pcm + (size_t)nmain * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, 1, tail_n, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
+			                  c->d_decisions + fc0, nullptr, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			if(launch_pack(P, B.chan, 1, tail_n, first + nmain, c->d_decisions + fc0, c->d_slots + (size_t)nmain * P.slot_bytes, c->d_frame_bytes + nmain, c->d_info + nmain, nullptr, nullptr, nullptr, nullptr, nullptr, s) != hipSuccess)
+				return FLACGPU_ERR_LAUNCH;
+			if(fused && launch_append_tail(c->d_slots + (size_t)nmain * P.slot_bytes, c->d_frame_bytes, nmain, &po, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		}
+		c->hint_count = 0;
+		// (the kernel's time is booked under "prep", a short last block's under "pack", the two-kernel compaction's under its own name)
+		seq[0] = c->ev[0]; seq[1] = seq[2] = seq[3] = seq[4] = after_main;
+		if(fused) seq[5] = seq[6] = c->ev[3];
+		else {
+			if(tail_n) { (void)hipEventRecord(c->ev[2], s); seq[5] = c->ev[2]; }
+			else { (void)hipEventRecord(c->pev[0], s); seq[1] = seq[2] = seq[3] = seq[4] = seq[5] = c->pev[0]; }
+			seq[6] = c->ev[3];
+		}
+	}
+	else if(nsub > 1) {
 		// Independent sub-batches on their own streams: the latency-bound kernels of one (prep, model, pack) fill the
 		// gaps of the VALU-bound kernels of another (autoc, eval).  Every buffer is indexed by frame, so a sub-batch
 		// is the same launches on offset pointers; they join before the scan over all frame lengths.
@@ -483,18 +549,18 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
 			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
 			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ss) != hipSuccess)
+			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, nullptr, nullptr, ss) != hipSuccess)
 				return FLACGPU_ERR_LAUNCH;
 			(void)hipEventRecord(c->sub_done[i], ss);
 			(void)hipStreamWaitEvent(s, c->sub_done[i], 0);
 		}
 		c->hint_count = 0;
-		// the per-kernel events of the single-stream path are not meaningful here
-		for(int i = 0; i < 3; i++) (void)hipEventRecord(c->pev[i], s);
-		(void)hipEventRecord(c->ev[1], s);
+		// the per-kernel events of the single-stream path are not meaningful here: everything is booked under "pack"
+		(void)hipEventRecord(c->ev[2], s);
+		seq[0] = seq[1] = seq[2] = seq[3] = seq[4] = c->ev[0]; seq[5] = c->ev[2]; seq[6] = c->ev[3];
 	}
 	else {
-	if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, c->ab, c->d_decisions, c->pev, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, c->ab, c->d_decisions, c->pev, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		if(c->ab.dbg) {
 			// development aid: average shader cycles per phase of the eval workgroups of this launch
 			const size_t nwg = (size_t)nframes * P.ncand;
@@ -527,17 +593,11 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			free(h);
 			(void)hipMemsetAsync(c->ab.dbg, 0, nwg * 16 * sizeof(unsigned long long), s);
 		}
-		if(!ff) (void)hipEventRecord(c->ev[1], s);          // (an event record costs the stream ~4 us: 2 % of a -0 step)
+		(void)hipEventRecord(c->ev[1], s);
 		{
-			// FLACGPU_FUSED_COMPACT=1: the pack kernel writes every frame once, at its final place (single-pass prefix sum with
-			// decoupled look-back inside the kernel; no slots, no scan / compact kernels).  Off by default: measured on MI355X
-			// (profiles/r02_c_*) a frame's length is known only when its workgroup is nearly done, so the look-back waits for every
-			// earlier workgroup still packing -- pack 0.45 -> 0.60 ms per 16384 frames, more than the 0.10 ms the two kernels cost.
-			static int fuse = -1;
-			if(fuse < 0) fuse = getenv("FLACGPU_FUSED_COMPACT") ? 1 : 0;
-			PackOutArgs po = {d_out, out_cap, c->d_offsets, c->d_total, c->d_scanstate};
 			uint32_t hinted = 0;
-			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, fuse ? &po : nullptr, &fused, c->d_vhints, &hinted, c->ab.ff_done, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			// (not with the debug stamps: they are indexed by workgroup, the fused output takes frames in dispatch order)
+			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, po.out && !c->ab.dbg ? &po : nullptr, &fused, c->d_vhints, &hinted, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 			c->hint_out = d_out; c->hint_nframes = nframes; c->hint_first = first; c->hint_count = hinted;
 		}
 		if(c->ab.dbg) {
@@ -553,8 +613,12 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			free(h);
 			(void)hipMemsetAsync(c->ab.dbg, 0, (size_t)nframes * P.ncand * 16 * sizeof(unsigned long long), s);
 		}
+		// without LPC analyses nothing is launched between the prep and the evaluation phase, and no event is recorded there
+		seq[0] = c->ev[0]; seq[1] = c->pev[0]; seq[2] = lpc ? c->pev[1] : c->pev[0]; seq[3] = lpc ? c->pev[2] : c->pev[0]; seq[4] = c->ev[1];
+		if(fused) seq[5] = seq[6] = c->ev[3];
+		else { (void)hipEventRecord(c->ev[2], s); seq[5] = c->ev[2]; seq[6] = c->ev[3]; }
 	}
-	(void)hipEventRecord(c->ev[2], s);
+	if(fused) c->fo_epoch = po.epoch;
 	if(!fused) {
 		if(launch_scan(c->d_frame_bytes, nframes, c->d_offsets, c->d_total, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		if(launch_compact(c->d_slots, P.slot_bytes, c->d_frame_bytes, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
@@ -947,12 +1011,10 @@ extern "C" int flacgpu_last_batch_kernel_ms(flacgpu_ctx *c, float *analyze_ms, f
 {
 	if(!c || !c->timing_valid) return FLACGPU_ERR_BAD_ARG;
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
-	if(hipEventSynchronize(c->ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	float a = 0, p = 0, k = 0;
-	hipEvent_t e1 = c->ev1_skipped[(c->batch_seq - 1) % TIMING_RING] ? c->pev[0] : c->ev[1];
-	if(hipEventElapsedTime(&a, c->ev[0], e1) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(hipEventElapsedTime(&p, e1, c->ev[2]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(hipEventElapsedTime(&k, c->ev[2], c->ev[3]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	float ms[6];
+	const int r = flacgpu_batch_phase_ms(c, 0, ms);
+	if(r != FLACGPU_OK) return r;
+	const float a = ms[0] + ms[1] + ms[2] + ms[3], p = ms[4], k = ms[5];
 	if(analyze_ms) *analyze_ms = a;
 	if(pack_ms) *pack_ms = p;
 	if(compact_ms) *compact_ms = k;

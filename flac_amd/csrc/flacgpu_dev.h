@@ -118,12 +118,6 @@ struct AnalyzeBuffers {
 	uint32_t *left, *left2, *nleft; // two lists [frames*ncand] of channels a wavefront-per-channel evaluation kernel left to the next kernel in line
 	                           // (evalg -> evalw -> eval_list_kernel), and their counts nleft[0], nleft[1] (zeroed by the model kernel)
 	unsigned long long *dbg;   // FLACGPU_DEBUG_TIMING=1: [frames*ncand][16] s_memtime stamps of the eval kernel (else null)
-	// ff_kernel (flacgpu_kernels.hip) in front of the prep kernel: where it writes the frames it takes, and its per-frame marks
-	// (1: written, the other kernels' workgroups skip the frame); ff_done null: not this batch
-	uint8_t *ff_done, *ff_slots;
-	uint32_t *ff_fb;
-	struct FrameInfo *ff_info;
-	uint64_t ff_first;
 };
 constexpr int FLACGPU_MAX_SUBBATCHES = 8;   // streams a batch may be split over (FLACGPU_SUBBATCHES / flacgpu_set_subbatches)
 constexpr int EVAL_MAX_WAVES = 8;   // wavefronts per eval workgroup (one residual candidate each per round)
@@ -151,15 +145,21 @@ hipError_t launch_evalw(const DevParams &P, uint32_t nframes, uint32_t tail_n, c
 bool prep2_applicable(const DevParams &P);
 bool prep2_decides(const DevParams &P);      // prep2_kernel also evaluates and decides (no LPC search: -0 .. -2)
 hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);
-// where the pack kernel may put the frames directly (fused compaction: single-pass prefix sum of the frame lengths inside the
-// kernel); with po == null or po->out == null every frame goes to its slot and launch_scan + launch_compact must follow
-struct PackOutArgs { uint8_t *out; uint64_t cap; uint64_t *offsets; uint64_t *total; uint64_t *state /* [nframes + 1] scratch */; };
+// where the pack kernel / ff_kernel may put the frames directly (fused output: flacgpu_kernels.hip, PackOut); with po == null or
+// po->out == null every frame goes to its slot and launch_scan + launch_compact must follow.  fstate / fall [max frames rounded up
+// to 64], sstate / sprefix / scount [max frames / 64 rounded up], nfall [2]: zeroed once when they are allocated (the tagged words
+// carry the epoch of their batch, the counters are zeroed by their last user); epoch: 1 .. 2^24 - 1, +1 for every launch;
+// spin_limit: polls before a frame gives up waiting for the ones in front of it and takes the slot + fo_place_kernel route
+struct PackOutArgs { uint8_t *out; uint64_t cap; uint64_t *offsets; uint64_t *total; uint64_t *fstate, *sstate, *sprefix, *scount; uint32_t *fall, *nfall; uint32_t epoch, spin_limit; };
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg,
-                       const PackOutArgs *po, bool *fused_out, uint32_t *hints, uint32_t *hinted_frames, const uint8_t *skip, hipStream_t s);
-// the one-kernel path of the presets without an LPC search on 16-bit stereo in 1152-sample blocks (flacgpu_kernels.hip: ff_kernel)
+                       const PackOutArgs *po, bool *fused_out, uint32_t *hints, uint32_t *hinted_frames, hipStream_t s);
+// the one-kernel path of the presets without an LPC search on 16-bit stereo in 1152-sample blocks (flacgpu_kernels.hip: ff_kernel):
+// every frame of nominal length of the batch; po as for launch_pack
 bool ff_applicable(const DevParams &P);
-hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, uint8_t *done, uint32_t *nleft, hipStream_t s);
+hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, const PackOutArgs *po, hipStream_t s);
+// fused output, short last block: frame f, assembled in its slot by the general kernels, goes behind the frames of nominal length
+hipError_t launch_append_tail(const uint8_t *slot, const uint32_t *fb, uint32_t f, const PackOutArgs *po, hipStream_t s);
 // hints (null: none wanted): [frame][channel][HINT_RUNS] bit offset, from the frame's first byte, at which the codes of each
 // 16-sample run of a residual-coded subframe start (the partition's parameter field when the run opens a partition) -- what the
 // hinted verify pass decodes from (flacgpu_decode_hinted.h).  *hinted_frames: the leading frames that got them.

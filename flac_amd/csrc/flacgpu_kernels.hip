@@ -15,6 +15,7 @@
 // fp64 sections must round exactly like the reference binary.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "flacgpu_dev.h"
 
 #include "flacgpu_devfn.h"
@@ -589,49 +590,110 @@ struct Pack2Shared {
 	uint16_t xspan[P2_XSPAN];
 	uint16_t xbyte[CRC_SPAN + 2];
 	uint32_t dec[FLACGPU_MAX_CHANNELS * sizeof(SubDecision) / 4];      // this frame's decision records
-	uint32_t ticket;           // fused output: the frame this workgroup took (dispatch order)
-	uint32_t excl_lo, excl_hi; // fused output: byte offset of this frame in the stream of the batch
+	uint32_t placed;           // fused output: the frames in front turned up in time, and
+	uint32_t excl_lo, excl_hi; // the byte offset of this frame in the stream of the batch
 };
 
-// ---- fused compaction: a single-pass prefix sum of the frame lengths with decoupled look-back (Merrill & Garland) ------------
-// One 64-bit status word per frame: [63:62] 0 nothing yet, 1 this frame's length, 2 the inclusive sum up to this frame; [61:0] the
-// value.  A workgroup publishes its length the moment it is known, then one of its wavefronts walks back over its predecessors,
-// 64 at a time, adding lengths until it meets an inclusive sum.  Frames are taken in dispatch order (an atomic ticket), so every
-// predecessor is resident or finished: the walk only ever waits for workgroups that are running.
-constexpr uint64_t SCAN_VAL = (1ull << 62) - 1;
+// ---- fused output: every frame is written once, at its final place in the stream of the batch ---------------------------------
+// A frame's place is the sum of the lengths of all frames in front of it.  Round 2 tried the textbook single-pass scan with
+// decoupled look-back (Merrill & Garland) at the END of the pack workgroups and lost (pack 0.45 -> 0.60 ms): thousands of
+// workgroups of one dispatch round reach their look-back together, none of them has a predecessor that already knows its prefix,
+// and the prefix then travels through them as a chain.  This version has no chain:
+//   * a frame PUBLISHES its length the moment it is known -- before the CRC and the store: a tagged word of its own, and one
+//     64-bit atomic add of {1, length} to a counter of its SEGMENT of 64 frames that nobody polls;
+//   * whoever finds 63 arrivals in front of it in that counter has the segment's total in the value that came back, and
+//     publishes it (tagged) -- also long before anybody asks;
+//   * at its end a frame adds up, with all its loads in flight at once and nothing to wait for in the normal case, the lengths in
+//     front of it in its own segment and the totals of the segments in front, 64 per step, nearest first.  The first frame of a
+//     segment leaves its offset behind as the segment's START: a walk that meets a known start stops there, so however long the
+//     batch, a frame looks at one or two rows of 64 totals.
+// What it buys depends on the kernel (profiles/r04_e_*, r04_f_*): pack2_kernel (-3 .. -8: five workgroups of four wavefronts per
+// CU, a frame's length known four fifths through) 0.26 + 0.09 ms of scan and compaction -> 0.30 ms; ff_kernel (-0 .. -2: one
+// wavefront per frame, 26 us from load to store) 0.106 + 0.039 -> 0.177 ms -- a hop between two CUs is 2-5 us under load
+// (MI355X_MICROARCH.md, handoff-1to1), a wavefront that waits for two of them at the end of 26 us is a SIMD with three wavefronts
+// instead of four for a fifth of the time.  So ff_kernel only PUBLISHES (O.out null, O.fstate set), and fo_place_kernel behind it
+// is a compaction that finds its offsets in the published words: no scan kernel, no waiting wavefront.
+//   (Two versions that did not survive: frames taken in dispatch order off an atomic ticket -- one word saturates at ~88 M
+//   fetch-adds/s, 0.19 ms for the 16384 workgroups of a -0 batch; and the segment totals as atomic accumulators that the readers
+//   poll -- readers and atomics fight for the lines: pack2_kernel 0.30 -> 0.88 ms.)
+// Nothing here depends on the order or the placement of the workgroups for its RESULT, and nothing for its termination either:
+// a frame waits only for words that workgroups with lower indices publish without waiting for anybody -- on this chip they were
+// dispatched earlier (observed, not promised) --, and every wait is bounded: a frame whose predecessors do not turn up in time
+// (PackOut::spin_limit polls) goes to its SLOT, as without the fused output, and onto a list; fo_place_kernel behind the pack kernel
+// places the listed frames (in a normal run: none, and the kernel is a handful of idle workgroups).
+// Words are tagged with the batch's epoch instead of being zeroed per batch: [63:40] epoch (never 0), [39:0] value.
+constexpr uint64_t FO_VAL = (1ull << 40) - 1;
 struct PackOut {
-	uint8_t *out;              // frames back to back (null: every frame goes to its slot, scan + compact kernels follow)
+	uint8_t *out;              // frames back to back (null: every frame goes to its slot)
 	uint64_t cap;
 	uint64_t *offsets;         // [nframes + 1]
 	uint64_t *total;
-	uint64_t *state;           // [nframes] status words, then the ticket counter; zeroed before the launch
-	uint32_t nframes_total;    // frames of the whole batch (the last one closes offsets[] / total when this kernel packs it)
+	uint64_t *fstate;          // [frames] tagged length of every frame (null: nothing is published, scan + compact kernels follow)
+	uint64_t *sstate;          // [segments] tagged total of every segment of 64 frames
+	uint64_t *sprefix;         // [segments] tagged offset of a segment's first frame
+	uint64_t *scount;          // [segments] {arrivals, bytes} so far (whoever completes a segment zeroes it again)
+	uint32_t *fall;            // [frames] the frames that gave up waiting and went to their slots
+	uint32_t *nfall;           // [2] how many, by epoch parity (fo_place_kernel zeroes the other one for the next batch)
+	uint32_t epoch;            // 1 .. 2^24 - 1
+	uint32_t spin_limit;       // polls before a frame gives up waiting for the frames in front of it
 };
-__device__ __forceinline__ uint64_t scan_lookback(uint64_t *state, uint32_t f, uint64_t mine, int lane)
+__device__ __forceinline__ uint64_t fo_word(uint32_t epoch, uint64_t v) { return ((uint64_t)epoch << 40) | v; }
+__device__ __forceinline__ bool fo_ready(uint64_t w, uint32_t epoch) { return (uint32_t)(w >> 40) == epoch; }
+__device__ __forceinline__ uint64_t fo_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fo_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane: the frame's length is known.  Returns the segment's counter as it was in front of this frame.
+__device__ __forceinline__ uint64_t fo_publish(const PackOut &O, uint32_t f, uint32_t bytes)
 {
+	fo_store(&O.fstate[f], fo_word(O.epoch, bytes));
+	return __hip_atomic_fetch_add(&O.scount[f >> 6], (1ull << 40) | (uint64_t)bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the same lane, later (the counter's value has had time to come back): the frame that completes its segment publishes the total
+__device__ __forceinline__ void fo_close_segment(const PackOut &O, uint32_t f, uint32_t nmain, uint32_t bytes, uint64_t before)
+{
+	const uint32_t seg = f >> 6, members = umin32(64u, nmain - seg * 64u);
+	if((uint32_t)(before >> 40) + 1u != members) return;
+	fo_store(&O.sstate[seg], fo_word(O.epoch, (before & FO_VAL) + bytes));
+	fo_store(&O.scount[seg], 0ull);
+}
+// a whole wavefront, at the end of frame f: the sum of the lengths of all frames in front of it; false: they did not turn up in time
+__device__ __forceinline__ bool fo_exclusive(const PackOut &O, uint32_t f, int lane, uint64_t &excl_out)
+{
+	const uint32_t seg = f >> 6, within = f & 63u, ep = O.epoch;
+	const uint64_t none = fo_word(ep, 0);
+	uint64_t a, b, c;
+	int64_t s0 = (int64_t)seg - 1;
 	uint64_t excl = 0;
-	if(f == 0) { if(lane == 0) __hip_atomic_store(&state[0], (2ull << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
-	if(lane == 0) __hip_atomic_store(&state[f], (1ull << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	int64_t j = (int64_t)f - 1;
+	uint32_t polls = 0;
+	// the frames in front of this one in its segment, and the first row of segments in front of it: one round of loads
+	bool first_row = true;
 	for(;;) {
-		const int64_t idx = j - lane;
-		uint64_t sv;
-		do {
-			sv = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
-		} while(__any((int)((sv >> 62) == 0)));
-		const uint64_t incl = __ballot((int)((sv >> 62) == 2));
-		uint64_t v = sv & SCAN_VAL;
-		if(incl) {
-			const int first = __ffsll((unsigned long long)incl) - 1;      // the nearest predecessor that knows its inclusive sum
-			if(lane > first) v = 0;
-			excl += wave_reduce_add_u64(v);
-			break;
+		const int64_t idx = s0 - lane;               // this lane's segment of the row (below 0: in front of the batch -- a known start of 0)
+		a = first_row && (uint32_t)lane < within ? fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)lane]) : none;
+		b = idx >= 0 ? fo_load(&O.sstate[idx]) : none;
+		c = idx >= 0 ? fo_load(&O.sprefix[idx]) : none;
+		uint32_t j;
+		for(;;) {
+			const uint64_t cm = __ballot((int)fo_ready(c, ep)), bm = __ballot((int)fo_ready(b, ep));
+			j = cm ? (uint32_t)(__ffsll((unsigned long long)cm) - 1) : 64u;      // the nearest segment whose start is known
+			const uint64_t need = j >= 63u ? ~0ull : ((2ull << j) - 1ull);
+			if((bm & need) == need && !__any((int)!fo_ready(a, ep))) break;
+			if(polls++ >= O.spin_limit) return false;
+			__builtin_amdgcn_s_sleep(8);
+			// (only the words that are missing are asked for again: thousands of pollers on whole rows are traffic of their own)
+			if(!fo_ready(a, ep)) a = fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)lane]);
+			if(!fo_ready(b, ep)) b = fo_load(&O.sstate[idx]);
+			if(!fo_ready(c, ep) && (uint32_t)lane <= 4u) c = fo_load(&O.sprefix[idx]);
 		}
+		uint64_t v = a & FO_VAL;
+		if((uint32_t)lane <= j) v += b & FO_VAL;
+		if((uint32_t)lane == j) v += c & FO_VAL;
 		excl += wave_reduce_add_u64(v);
-		j -= 64;
+		if(j < 64u) break;
+		s0 -= 64; first_row = false;
 	}
-	if(lane == 0) __hip_atomic_store(&state[f], (2ull << 62) | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return excl;
+	if(within == 0 && lane == 0) fo_store(&O.sprefix[seg], fo_word(ep, excl));
+	excl_out = excl;
+	return true;
 }
 // the finished frame image (big-endian word views in LDS) to byte address dst, whatever its alignment
 template <int NT = TPB>
@@ -731,10 +793,9 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
                                                     const SubDecision *__restrict__ decisions,
                                                     uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
                                                     FrameInfo *__restrict__ info, unsigned long long *__restrict__ dbg, const PackOut O,
-                                                    uint32_t *__restrict__ hints, const uint8_t *__restrict__ skip)
+                                                    uint32_t *__restrict__ hints)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	if(skip && skip[blockIdx.x]) return;                      // ff_kernel has written this frame (never with the fused output: launch_pack_t)
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave: a scalar register)
 	const uint32_t C = P.channels, N = P.blocksize, n = N;
 	uint32_t *img = (uint32_t *)smem;
@@ -742,13 +803,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 	Pack2Shared *sh = (Pack2Shared *)(smem + P.slot_bytes + 16);
 	const bool fused = O.out != nullptr;
 	uint32_t f = blockIdx.x;
-	if(fused) {
-		// frames in dispatch order, so that the look-back at the end only waits for workgroups that have started
-		if(tid == 0) sh->ticket = atomicAdd((uint32_t *)(O.state + nmain), 1u);
-		__syncthreads();
-		f = sh->ticket;
-	}
-	f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);        // (the same in every lane either way: the frame's addresses are scalar registers)
+	f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);        // (the frame's addresses are scalar registers)
 #define PSTAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
 	PSTAMP(0);
 	const SubDecision *dec = decisions + (size_t)f * P.ncand;
@@ -1046,6 +1101,10 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 	const uint32_t body_bytes = (pos + 7) >> 3;
 	const uint32_t total_bytes = body_bytes + 2;
 	const bool overflow = total_bytes > P.slot_bytes;
+	const uint32_t mine = overflow ? 0u : total_bytes;
+	// fused output: the frame's length goes out now, ahead of the CRC and the store
+	uint64_t before = 0;
+	if(fused && tid == NT - 64) before = fo_publish(O, f, mine);
 	{
 		const uint32_t crc = frame_crc16_p2<NT>(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, tid, sh->xspan, P2_XSPAN, sh->xbyte);
 		PSTAMP(11);
@@ -1054,19 +1113,32 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 	}
 	// ---- store: image words are big-endian views, the stream is a byte array ---------------------------
 	if(fused) {
+		if(tid == NT - 64) fo_close_segment(O, f, nmain, mine, before);          // (the counter has had the CRC to come back)
 		// this frame's place in the stream: the sum of the lengths of all frames in front of it
-		const uint32_t mine = overflow ? 0u : total_bytes;
 		if(wave == 0) {
-			const uint64_t excl = scan_lookback(O.state, f, mine, lane);
-			if(lane == 0) { sh->excl_lo = (uint32_t)excl; sh->excl_hi = (uint32_t)(excl >> 32); }
+			uint64_t excl = 0;
+			const bool placed = fo_exclusive(O, f, lane, excl);
+			if(lane == 0) { sh->excl_lo = (uint32_t)excl; sh->excl_hi = (uint32_t)(excl >> 32); sh->placed = placed ? 1u : 0u; }
 		}
 		__syncthreads();
 		const uint64_t off = ((uint64_t)sh->excl_hi << 32) | sh->excl_lo;
-		if(mine && off + mine <= O.cap) store_image<NT>(img, O.out + off, mine, tid);
+		const bool placed = sh->placed != 0;
+		if(placed) {
+			if(mine && off + mine <= O.cap) store_image<NT>(img, O.out + off, mine, tid);
+		}
+		else {
+			// (they did not: the frame goes to its slot and onto fo_fixup_kernel's list)
+			uint32_t *dst = (uint32_t *)(slots + (size_t)f * P.slot_bytes);
+			const uint32_t words = (umin32(total_bytes, P.slot_bytes) + 3) >> 2;
+			for(uint32_t w = (uint32_t)tid; w < words; w += NT) dst[w] = __builtin_bswap32(img[w]);
+		}
 		if(tid == 0) {
 			frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
-			O.offsets[f] = off;
-			if(f + 1 == O.nframes_total) { O.offsets[f + 1] = off + mine; *O.total = off + mine; }
+			if(placed) {
+				O.offsets[f] = off;
+				if(f + 1 == nmain) { O.offsets[f + 1] = off + mine; *O.total = off + mine; }      // (a short last block goes behind: append_tail_kernel)
+			}
+			else O.fall[atomicAdd(&O.nfall[O.epoch & 1u], 1u)] = f;
 			if(info) info[f].channel_assignment = (uint8_t)ca;
 		}
 	}
@@ -1097,8 +1169,10 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 //   Rice search on the lane's own sums (rice_search_nodes: a lane's 18 samples are exactly one of the 64 leaves) -> channel
 //   assignment -> frame header, subframes (residual = the k-th difference of registers), CRC-16, slot.
 // Same decisions and bytes as prep2_kernel + eval_list_kernel + pack2_kernel (stream_encoder.c:3747-4043, 4100-4140, 4701-5075;
-// stream_encoder_framing.c:245-594).  A frame whose sums leave the 32-bit node arithmetic is left alone (done[f] = 0): the
-// three-kernel path, whose workgroups skip the frames marked done, takes it.
+// stream_encoder_framing.c:245-594).  A channel whose sums leave the 32-bit node arithmetic of rice_search_nodes (no 16-bit signal
+// a fixed predictor was GUESSED for gets there with the presets' partition orders; a hand-picked -r 6 on a pathological burst
+// can) takes ff_rice_search_wide below instead: every frame of nominal length is this kernel's, and with the fused output
+// (PackOut) a batch of the fast presets is ONE launch.
 constexpr int FF_N = 1152, FF_RUN = 18, FF_TS = 66, FF_TILE_BYTES = FF_RUN * FF_TS * 4;
 constexpr uint32_t FF_XSPAN = 128;                         // span shifts kept in LDS: frames of up to 5.6 KB (these are 4.7 KB at most)
 struct FFShared {
@@ -1108,6 +1182,7 @@ struct FFShared {
 	uint32_t crc_parts[2];
 	uint32_t divtab[7 * (MAX_ORDER + 1)];                   // rows 0..6 (partition orders), columns 0..4 used
 	uint8_t kout[4][64];                                   // Rice parameters of the four candidate channels
+	uint32_t rec[4][12];                                   // their decision records (FFDec, word by word), between the decision loop and the frame
 };
 struct FFDec { uint32_t which, type, order, wasted, sbps, bits, po, rice2; int32_t constant; };
 // x^(416 m) mod P, m = 0..127: the span shifts of frame_crc16_p2<64, 13> (52-byte spans)
@@ -1144,8 +1219,42 @@ __device__ __forceinline__ void ff_channel(const uint32_t (&w)[FF_RUN + 4], uint
 		x[k] = which == 0 ? a : which == 1 ? b : which == 2 ? ((a + b) >> 1) : (a - b);
 	}
 }
-// statistics and decision of one candidate channel; false: the channel's sums leave the search's 32-bit arithmetic
-__device__ __forceinline__ bool ff_decide(const DevParams &P, uint32_t which, const int32_t (&x)[FF_RUN + 4], bool disable_constant, FFShared *sh, int lane, FFDec &D, uint32_t &alleq)
+// find_best_partition_order_ / set_partitioned_rice_ (stream_encoder.c:4701-4795, 4997-5046) on the lanes' leaf sums in 64-bit
+// arithmetic, one partition per lane and order: the rare path of ff_decide (nothing here is tuned).  leaf: 64 words of LDS.
+// (not inlined: four copies of it in the straight-line code of ff_kernel<1> cost that kernel 30 spilled registers.  Everything goes in
+// and out through scalars and LDS -- a pointer to a thread-private object handed to a function that is not inlined read back
+// zeros here, DESIGN.md -- and the partition order comes back in the high half of the result)
+__device__ __noinline__ uint64_t ff_rice_search_wide(uint32_t v, uint32_t n, uint32_t order, uint32_t max_po, uint32_t min_po, uint32_t rice_limit,
+                                                     const uint32_t *divtab, uint32_t *leaf, uint8_t *kout, int lane)
+{
+	leaf[lane] = v;
+	__builtin_amdgcn_wave_barrier();
+	uint32_t best_bits = 0, best_po = 0, kbest = 0;
+	for(int po = (int)max_po; po >= (int)min_po; po--) {
+		const uint32_t nleaf = 64u >> po;
+		uint32_t k = 0;
+		uint64_t b = 0;
+		if((uint32_t)lane < (1u << po)) {
+			uint64_t sum = 0;
+			for(uint32_t j = 0; j < nleaf; j++) sum += leaf[(uint32_t)lane * nleaf + j];
+			const uint32_t o = lane == 0 ? order : 0u, ns = (n >> po) - o, div = divtab[(uint32_t)po * (MAX_ORDER + 1) + o];
+			if(sum < 2 || (((sum - 1) * div) >> 18) == 0) k = 0;
+			else k = ilog2_u64(((sum - 1) * div) >> 18) + 1;
+			if(k >= rice_limit) k = rice_limit - 1;
+			b = 4 + (uint64_t)(1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
+			if(b > 0xffffffffull) b = 0xffffffffull;
+		}
+		const uint64_t tot = 6 + wave_reduce_add_u64(b);
+		const uint32_t bits = tot >= 0xffffffffull ? 0xffffffffu : (uint32_t)tot;
+		if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = (uint32_t)po; kbest = k; }       // strict <, highest order first (:4735-4763)
+	}
+	if((uint32_t)lane < (1u << best_po)) kout[lane] = (uint8_t)kbest;
+	__builtin_amdgcn_wave_barrier();
+	return ((uint64_t)best_po << 32) | best_bits;
+}
+
+// statistics and decision of one candidate channel
+__device__ __forceinline__ void ff_decide(const DevParams &P, uint32_t which, const int32_t (&x)[FF_RUN + 4], bool disable_constant, FFShared *sh, uint32_t *leaf, int lane, FFDec &D, uint32_t &alleq)
 {
 	constexpr uint32_t n = FF_N;
 	Prep2Acc A;
@@ -1203,9 +1312,13 @@ __device__ __forceinline__ bool ff_decide(const DevParams &P, uint32_t which, co
 		uint32_t v = fixed_order == 0 ? cs[0] : fixed_order == 1 ? cs[1] : fixed_order == 2 ? cs[2] : fixed_order == 3 ? cs[3] : cs[4];
 		if(lane == 0) v += fixed_order == 0 ? ex[0] : fixed_order == 1 ? ex[1] : fixed_order == 2 ? ex[2] : fixed_order == 3 ? ex[3] : ex[4];
 		v >>= wasted;
-		if(__any((int)(v >= ((1u << 23) >> ee)))) return false;              // (a leaf partition is 2^ee lanes: its sum stays below 2^23)
-		uint32_t po = 0;
-		const uint32_t rbits = rice_search_nodes(v, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
+		uint32_t po = 0, rbits;
+		// (a leaf partition is 2^ee lanes: rice_search_nodes wants its sum below 2^23)
+		if(__any((int)(v >= ((1u << 23) >> ee)))) {
+			const uint64_t r = ff_rice_search_wide(v, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, leaf, sh->kout[which], lane);
+			rbits = (uint32_t)r; po = (uint32_t)(r >> 32);
+		}
+		else rbits = rice_search_nodes(v, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
 		const uint32_t est = sat_add_u32(hdr + fixed_order * sbps, rbits);
 		if(est > 0 && est < D.bits) { D.type = 2; D.bits = est; D.po = po; D.order = fixed_order; }
 	}
@@ -1220,21 +1333,136 @@ __device__ __forceinline__ bool ff_decide(const DevParams &P, uint32_t which, co
 	FFUNI(D.type); FFUNI(D.order); FFUNI(D.wasted); FFUNI(D.sbps); FFUNI(D.bits); FFUNI(D.po); FFUNI(D.rice2);
 	D.constant = __builtin_amdgcn_readfirstlane(D.constant);
 #undef FFUNI
-	return true;
 }
 
 #ifndef FF_WAVES
-#define FF_WAVES 3           // 150..168 registers, no spills; 4 (128 registers, 76..176 bytes of spills) is 3..10 % slower (profiles/r03_l2_ff_waves_ab.txt)
+#define FF_WAVES 4           // (the LDS allows four wavefronts per SIMD)
 #endif
+// ff_channel with the channel a scalar register: a branch per flavour instead of three selects per word
+__device__ __forceinline__ void ff_channel_u(const uint32_t (&w)[FF_RUN + 4], uint32_t which, int32_t (&x)[FF_RUN + 4])
+{
+	if(which == 0) ff_channel(w, 0, x);
+	else if(which == 1) ff_channel(w, 1, x);
+	else if(which == 2) ff_channel(w, 2, x);
+	else ff_channel(w, 3, x);
+}
+// one subframe's share of the frame, before a bit of it is written: the folded residuals u (FIXED), the lane's Rice parameter,
+// where in the subframe's residual section the lane's codes start, and the subframe's length in bits (everything but u uniform)
+struct FFSub { uint32_t k, excl, end, bits; bool starts; };
+__device__ __forceinline__ void ff_subframe_sizes(const uint32_t (&w)[FF_RUN + 4], const FFDec &d, const FFShared *sh, int lane, uint32_t (&u)[FF_RUN], FFSub &S)
+{
+	constexpr uint32_t n = FF_N;
+	S.k = 0; S.excl = 0; S.end = 0; S.starts = false;
+	if(d.type == 0) { S.bits = 8 + d.wasted + d.sbps; return; }
+	if(d.type == 1) { S.bits = 8 + d.wasted + n * d.sbps; return; }
+	// the residual of the fixed predictor of this order = the order-th difference (fixed.c:470) of the shifted channel
+	int32_t dd[FF_RUN + 4];
+	ff_channel_u(w, d.which, dd);
+	if(d.wasted) {
+#pragma unroll
+		for(int t = 0; t < FF_RUN + 4; t++) dd[t] >>= d.wasted;
+	}
+#pragma unroll
+	for(int o = 1; o <= 4; o++) {
+		if((uint32_t)o <= d.order) {
+#pragma unroll
+			for(int t = FF_RUN + 3; t >= o; t--) dd[t] = dd[t] - dd[t - 1];
+		}
+	}
+	const uint32_t psize = n >> d.po, base = (uint32_t)lane * FF_RUN, part = base / psize;
+	const uint32_t k = sh->kout[d.which][part];
+	S.k = k;
+	S.starts = base == part * psize;
+	// code sizes: (u >> k) + 1 + k each; the warm-up samples (the first `order` of lane 0) have none
+	const uint32_t skip = lane == 0 ? d.order : 0u;
+	uint32_t q = 0;
+#pragma unroll
+	for(int t = 0; t < FF_RUN; t++) {
+		const int32_t r = dd[t + 4];
+		uint32_t f = ((uint32_t)r << 1) ^ (uint32_t)(r >> 31);
+		if(t < 4 && (uint32_t)t < skip) f = 0;
+		u[t] = f;
+		q += f >> k;
+	}
+	const uint32_t mybits = q + ((uint32_t)FF_RUN - skip) * (1u + k) + (S.starts ? (d.rice2 ? 5u : 4u) : 0u);
+	const uint32_t incl = wave_scan_incl_dpp(mybits);
+	S.excl = incl - mybits; S.end = incl;
+	S.bits = 8 + d.wasted + d.order * d.sbps + 6 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+}
+// ... and its bits, at bit `pos` of the zeroed frame image (stream_encoder_framing.c:393-594, bitwriter.c:575-706)
+__device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t cap_words, uint32_t pos, const uint32_t (&w)[FF_RUN + 4], const FFDec &d, const uint32_t (&u)[FF_RUN], const FFSub &S, int lane)
+{
+	const uint32_t type = d.type, order = d.order, wasted = d.wasted, sbps = d.sbps;
+	const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : (0x10u | (order << 1));
+	if(lane == 0) {
+		or_bits(img, cap_words, pos, type_bits | (wasted ? 1u : 0u), 8);
+		if(wasted) or_bits(img, cap_words, pos + 8 + (wasted - 1), 1, 1);
+	}
+	pos += 8 + wasted;
+	const uint32_t smask = sbps >= 32 ? 0xffffffffu : (1u << sbps) - 1u;
+	if(type == 0) {
+		if(lane == 0) or_bits(img, cap_words, pos, (uint32_t)d.constant & smask, sbps);
+		return;
+	}
+	if(type == 1) {
+		int32_t x[FF_RUN + 4];
+		ff_channel_u(w, d.which, x);
+#pragma unroll
+		for(int t = 0; t < FF_RUN; t++) or_bits(img, cap_words, pos + ((uint32_t)lane * FF_RUN + (uint32_t)t) * sbps, (uint32_t)(x[t + 4] >> wasted) & smask, sbps);
+		return;
+	}
+	if(lane == 0) {
+		// warm-up samples, verbatim (lane 0 holds them), and the entropy coding header
+#pragma unroll
+		for(int i = 0; i < 4; i++) {
+			if((uint32_t)i < order) {
+				const uint32_t wi = w[4 + i];
+				const int32_t a = (int32_t)(int16_t)(wi & 0xffffu), b = (int32_t)wi >> 16;
+				const int32_t xv = d.which == 0 ? a : d.which == 1 ? b : d.which == 2 ? ((a + b) >> 1) : (a - b);
+				or_bits(img, cap_words, pos + (uint32_t)i * sbps, (uint32_t)(xv >> wasted) & smask, sbps);
+			}
+		}
+		or_bits(img, cap_words, pos + order * sbps, d.rice2 ? 1u : 0u, 2);
+		or_bits(img, cap_words, pos + order * sbps + 2, d.po, 4);
+	}
+	pos += order * sbps + 6;
+	const uint32_t k = S.k, kp1 = k + 1u;
+	uint32_t p = pos + S.excl;
+	if(S.starts) { const uint32_t plen = d.rice2 ? 5u : 4u; or_bits(img, cap_words, p, k, plen); p += plen; }
+	// a run that ends inside the image writes without clamping its word index; one that does not belongs to a frame that overflows
+	// its slot and is discarded (frame_bytes = ~0): its codes are not written at all
+	if(pos + S.end <= cap_words * 32u) {
+		// the code left-aligned in a word: stop bit, then the k low bits of u.  u << (31 - k) puts them there; what it leaves in bit 31
+		// (bit k of u) is covered by the stop bit, everything above has left the word.  at = the bit the stop bit goes to: the one
+		// before's, plus that code's 1 + k bits, plus this one's zeros -- one v_add3 (a warm-up position has neither)
+		const uint32_t lsh = 31u - k, skip = lane == 0 ? order : 0u;
+		uint32_t at = p - kp1;
+#pragma unroll
+		for(int t = 0; t < FF_RUN; t++) {
+			const uint32_t ut = u[t];
+			if(t < 4) {
+				// (lane 0's warm-up positions: no code)
+				const bool gone = (uint32_t)t < skip;
+				const uint32_t adv = gone ? 0u : kp1;
+				at = at + adv + (ut >> k);
+				if(!gone) or_code_fit(img, at, (ut << lsh) | 0x80000000u);
+			}
+			else {
+				at = at + kp1 + (ut >> k);
+				or_code_fit(img, at, (ut << lsh) | 0x80000000u);
+			}
+		}
+	}
+}
+
 template <int MS>       // DevParams::ms_mode
 __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint64_t first_frame_number,
-                                                 uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, FrameInfo *__restrict__ info, uint8_t *__restrict__ done,
-                                                 uint32_t *__restrict__ nleft)
+                                                 uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, FrameInfo *__restrict__ info, const PackOut O)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = (int)threadIdx.x;
+	const bool fused = O.out != nullptr, publish = O.fstate != nullptr;
 	const uint32_t f = blockIdx.x;
-	if(f == 0 && lane == 0) { nleft[0] = 0; nleft[1] = 0; }                   // the lists of the kernels behind this one start empty (no memset in between)
 	constexpr uint32_t n = FF_N;
 	uint32_t *tile = (uint32_t *)smem;                                        // the transposed tile, later the frame image
 	FFShared *sh = (FFShared *)(smem + ff_tile_bytes(P.slot_bytes));
@@ -1255,10 +1483,14 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 		if(lane < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[lane] = bv;
 		if(lane < 35) { const uint32_t po = (uint32_t)lane / 5u, o = (uint32_t)lane - po * 5u; sh->divtab[po * (MAX_ORDER + 1) + o] = g_ff_div[lane]; }
 		if(lane < FF_RUN) tile[lane * FF_TS] = 0;                             // column 0: the samples in front of the block
+		// sample i = lane + 64 k goes to row i % 18, column i / 18 + 1: 64 = 3 * 18 + 10, so from one k to the next the column grows by
+		// three and the row by ten, with a carry -- one division per lane instead of one per sample
+		uint32_t c = (uint32_t)lane / FF_RUN, r = (uint32_t)lane - c * FF_RUN;
 #pragma unroll
 		for(int k = 0; k < FF_RUN; k++) {
-			const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k, c = i / FF_RUN, r = i - c * FF_RUN;
 			tile[r * FF_TS + c + 1] = ((uint32_t)v[k].x & 0xffffu) | ((uint32_t)v[k].y << 16);
+			r += 10; c += 3;
+			if(r >= (uint32_t)FF_RUN) { r -= FF_RUN; c += 1; }
 		}
 	}
 	__builtin_amdgcn_wave_barrier();
@@ -1267,180 +1499,147 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	for(int k = 0; k < FF_RUN + 4; k++) w[k] = k < 4 ? tile[(FF_RUN - 4 + k) * FF_TS + lane] : tile[(k - 4) * FF_TS + lane + 1];
 	__builtin_amdgcn_wave_barrier();                                          // the tile is the frame image from here on
 
-	// ---- candidate channels --------------------------------------------------------------------------------------------------
-	FFDec DL, DR;                                                             // the two subframes of the frame, in stream order
+	// ---- candidate channels: one pass of a loop each (the decision records wait in LDS) ------------------------------------------
 	uint32_t ca = 0;
-	bool ok = true;
-	{
-		uint32_t alleq_l = 0, dummy = 0;
-		bool dc = P.disable_constant != 0;
-		int32_t x[FF_RUN + 4];
-		if(MS == 2) {
-			// loose mid/side (stream_encoder.c:3778-3807): left/right or mid/side for the whole frame, from first differences
-			uint32_t lr = 0, ms = 0;
+	uint32_t *leaf = tile;                                                    // (scratch of the wide Rice search: the tile is free until the image is zeroed)
+	uint32_t li = 0, ri = 1;                                                  // MS == 2: the pair the loose search picked
+	uint32_t alleq_l = 0;
+	if(MS == 2) {
+		// loose mid/side (stream_encoder.c:3778-3807): left/right or mid/side for the whole frame, from first differences
+		uint32_t lr = 0, ms = 0;
 #pragma unroll
-			for(int t = 0; t < FF_RUN; t++) {
-				if(t > 0 || lane > 0) {
-					const int32_t pl = ((int32_t)(int16_t)(w[t + 4] & 0xffffu)) - ((int32_t)(int16_t)(w[t + 3] & 0xffffu)), pr = ((int32_t)w[t + 4] >> 16) - ((int32_t)w[t + 3] >> 16);
-					lr += (uint32_t)(abs(pl) + abs(pr));
-					ms += (uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
-				}
-			}
-			const uint64_t lrs = wave_sum_u50((uint64_t)lr), mss = wave_sum_u50((uint64_t)ms);
-			const bool use_ms = !(lrs < mss);
-			if(P.limit_min_bitrate) {
-				// (the all-equal flag of the left channel decides whether the second subframe may be CONSTANT, stream_encoder.c:3874-3879)
-				uint32_t dl = 0;
-#pragma unroll
-				for(int t = 0; t < FF_RUN; t++) dl |= (w[t + 4] ^ w[4]) & 0xffffu;
-				const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[4]);
-				dl |= (w[4] ^ fl) & 0xffffu;
-				alleq_l = wave_or_u32(dl) == 0 ? 1u : 0u;
-			}
-			const uint32_t li = use_ms ? 2 : 0, ri = use_ms ? 3 : 1;
-			ca = use_ms ? 3 : 0;
-			ff_channel(w, li, x);
-			ok = ff_decide(P, li, x, dc, sh, lane, DL, dummy);
-			if(ok) {
-				// prep2_kernel: with the loose search only the right channel proper (which == 1) can lose its CONSTANT
-				if(P.limit_min_bitrate && !dc && ri == 1 && alleq_l) dc = true;
-				ff_channel(w, ri, x);
-				ok = ff_decide(P, ri, x, dc, sh, lane, DR, dummy);
+		for(int t = 0; t < FF_RUN; t++) {
+			if(t > 0 || lane > 0) {
+				const int32_t pl = ((int32_t)(int16_t)(w[t + 4] & 0xffffu)) - ((int32_t)(int16_t)(w[t + 3] & 0xffffu)), pr = ((int32_t)w[t + 4] >> 16) - ((int32_t)w[t + 3] >> 16);
+				lr += (uint32_t)(abs(pl) + abs(pr));
+				ms += (uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
 			}
 		}
-		else {
-			FFDec d0, d1;
-			ff_channel(w, 0, x);
-			ok = ff_decide(P, 0, x, dc, sh, lane, d0, alleq_l);
-			// every channel but the first: no CONSTANT when all the ones in front are constant (stream_encoder.c:3874-3879)
-			const bool dc_rest = dc || (P.limit_min_bitrate && alleq_l);
-			if(ok) { ff_channel(w, 1, x); ok = ff_decide(P, 1, x, dc_rest, sh, lane, d1, dummy); }
-			DL = d0; DR = d1;
-			if(MS == 1) {
-				FFDec d2, d3;
-				if(ok) { ff_channel(w, 2, x); ok = ff_decide(P, 2, x, dc_rest, sh, lane, d2, dummy); }
-				if(ok) { ff_channel(w, 3, x); ok = ff_decide(P, 3, x, dc_rest, sh, lane, d3, dummy); }
-				if(ok) {
-					// channel assignment (stream_encoder.c:3944-3972)
-					const uint32_t b0 = d0.bits + d1.bits, b1 = d0.bits + d3.bits, b2 = d1.bits + d3.bits, b3 = d2.bits + d3.bits;
-					uint32_t mn = b0;
-					if(b1 < mn) { mn = b1; ca = 1; }
-					if(b2 < mn) { mn = b2; ca = 2; }
-					if(b3 < mn) { mn = b3; ca = 3; }
-					DL = ca == 2 ? d3 : ca == 3 ? d2 : d0;
-					DR = ca == 0 ? d1 : ca == 2 ? d1 : d3;
-				}
+		const uint64_t lrs = wave_sum_u50((uint64_t)lr), mss = wave_sum_u50((uint64_t)ms);
+		const bool use_ms = !(lrs < mss);
+		if(P.limit_min_bitrate) {
+			// (the all-equal flag of the left channel decides whether the second subframe may be CONSTANT, stream_encoder.c:3874-3879)
+			uint32_t dl = 0;
+#pragma unroll
+			for(int t = 0; t < FF_RUN; t++) dl |= (w[t + 4] ^ w[4]) & 0xffffu;
+			const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[4]);
+			dl |= (w[4] ^ fl) & 0xffffu;
+			alleq_l = wave_or_u32(dl) == 0 ? 1u : 0u;
+		}
+		li = use_ms ? 2 : 0; ri = use_ms ? 3 : 1;
+		ca = use_ms ? 3 : 0;
+	}
+	{
+		constexpr uint32_t NC = MS == 1 ? 4u : 2u;
+		bool dc = P.disable_constant != 0;
+#pragma unroll 1
+		for(uint32_t ci = 0; ci < NC; ci++) {
+			const uint32_t which = MS == 2 ? (ci ? ri : li) : ci;
+			if(ci) {
+				// every channel but the first: no CONSTANT when all the ones in front are constant (stream_encoder.c:3874-3879); with the
+				// loose search only the right channel proper (which == 1) can lose its CONSTANT (prep2_kernel)
+				if(MS == 2) { if(P.limit_min_bitrate && which == 1 && alleq_l) dc = true; }
+				else if(P.limit_min_bitrate && alleq_l) dc = true;
+			}
+			// (the window is the same in every pass, and so are its unpacked halves, their mean and their difference: the compiler
+			//  would keep all four, 88 registers, across the loop -- the empty asm makes the words look new in every pass)
+#pragma unroll
+			for(int k = 0; k < FF_RUN + 4; k++) asm volatile("" : "+v"(w[k]));
+			int32_t x[FF_RUN + 4];
+			ff_channel_u(w, which, x);
+			FFDec D;
+			uint32_t alleq = 0;
+			ff_decide(P, which, x, dc, sh, leaf, lane, D, alleq);
+			if(ci == 0 && MS != 2) alleq_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)alleq);
+			if(lane == 0) {
+				uint32_t *rec = sh->rec[ci];
+				rec[0] = D.which; rec[1] = D.type; rec[2] = D.order; rec[3] = D.wasted; rec[4] = D.sbps; rec[5] = D.bits; rec[6] = D.po; rec[7] = D.rice2; rec[8] = (uint32_t)D.constant;
 			}
 		}
 	}
-	if(!ok) { if(lane == 0) done[f] = 0; return; }
+	__builtin_amdgcn_wave_barrier();
+	FFDec DL, DR;                                                             // the two subframes of the frame, in stream order
+	{
+		uint32_t l = 0, r = 1;
+		if(MS == 1) {
+			// channel assignment (stream_encoder.c:3944-3972)
+			const uint32_t b0 = sh->rec[0][5], b1 = sh->rec[1][5], b2 = sh->rec[2][5], b3 = sh->rec[3][5];
+			const uint32_t s0 = b0 + b1, s1 = b0 + b3, s2 = b1 + b3, s3 = b2 + b3;
+			uint32_t mn = s0;
+			if(s1 < mn) { mn = s1; ca = 1; }
+			if(s2 < mn) { mn = s2; ca = 2; }
+			if(s3 < mn) { mn = s3; ca = 3; }
+			ca = (uint32_t)__builtin_amdgcn_readfirstlane((int)ca);
+			l = ca == 2 ? 3 : ca == 3 ? 2 : 0;
+			r = ca == 0 ? 1 : ca == 2 ? 1 : 3;
+		}
+#define FFLOAD(D, i) do { const uint32_t *rec = sh->rec[i]; D.which = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[0]); D.type = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[1]); \
+		D.order = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[2]); D.wasted = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[3]); D.sbps = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[4]); \
+		D.bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[5]); D.po = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[6]); D.rice2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[7]); \
+		D.constant = __builtin_amdgcn_readfirstlane((int)rec[8]); } while(0)
+		FFLOAD(DL, l); FFLOAD(DR, r);
+#undef FFLOAD
+	}
+
+	// ---- the frame's length, before a bit of it is written: with the fused output it goes out now, long before anybody asks ------
+	const uint32_t frame_number = (uint32_t)(first_frame_number + f);
+	const uint32_t pos0 = 8 * frame_header_len(P, n, frame_number);
+	uint32_t uL[FF_RUN], uR[FF_RUN];
+	FFSub SL, SR;
+	ff_subframe_sizes(w, DL, sh, lane, uL, SL);
+	ff_subframe_sizes(w, DR, sh, lane, uR, SR);
+	const uint32_t pos = pos0 + SL.bits + SR.bits;
+	const uint32_t body_bytes = (pos + 7) >> 3, total_bytes = body_bytes + 2;
+	const bool overflow = total_bytes > P.slot_bytes;
+	const uint32_t mine = overflow ? 0u : total_bytes;
+	uint64_t before = 0;
+	if(publish && lane == 0) before = fo_publish(O, f, mine);
 
 	// ---- the frame -----------------------------------------------------------------------------------------------------------
 	uint32_t *img = tile;
 	const uint32_t cap_words = P.slot_bytes / 4;
-	for(uint32_t w = (uint32_t)lane; w < cap_words + 2; w += 64) img[w] = 0;
+	{
+		// (slot_bytes is a multiple of 16, and the image has 16 bytes to spare behind it: whole 16-byte stores)
+		uint4 *img4 = (uint4 *)img;
+		for(uint32_t q = (uint32_t)lane; q < cap_words / 4 + 1; q += 64) img4[q] = make_uint4(0, 0, 0, 0);
+	}
 	__builtin_amdgcn_wave_barrier();
-	const uint32_t frame_number = (uint32_t)(first_frame_number + f);
 	if(lane == 1) (void)frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { or_bits(img, cap_words, 8 * k, byte, 8); });
-	uint32_t pos = 8 * frame_header_len(P, n, frame_number);
-	for(int s = 0; s < 2; s++) {
-		const FFDec d = s == 0 ? DL : DR;
-		const uint32_t di = d.which;
-		const uint32_t type = d.type, order = d.order, wasted = d.wasted, sbps = d.sbps;
-		int32_t x[FF_RUN + 4];
-		ff_channel(w, di, x);
+	ff_subframe_write(img, cap_words, pos0, w, DL, uL, SL, lane);
+	ff_subframe_write(img, cap_words, pos0 + SL.bits, w, DR, uR, SR, lane);
+	if(lane == 0 && info) {
 #pragma unroll
-		for(int k = 0; k < FF_RUN + 4; k++) x[k] >>= wasted;
-		const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : (0x10u | (order << 1));
-		if(lane == 0) {
-			or_bits(img, cap_words, pos, type_bits | (wasted ? 1u : 0u), 8);
-			if(wasted) or_bits(img, cap_words, pos + 8 + (wasted - 1), 1, 1);
-		}
-		pos += 8 + wasted;
-		const uint32_t smask = sbps >= 32 ? 0xffffffffu : (1u << sbps) - 1u;
-		if(type == 0) {
-			if(lane == 0) or_bits(img, cap_words, pos, (uint32_t)d.constant & smask, sbps);
-			pos += sbps;
-		}
-		else if(type == 1) {
-#pragma unroll
-			for(int k = 0; k < FF_RUN; k++) or_bits(img, cap_words, pos + ((uint32_t)lane * FF_RUN + (uint32_t)k) * sbps, (uint32_t)x[k + 4] & smask, sbps);
-			pos += n * sbps;
-		}
-		else {
-			// warm-up samples, verbatim (lane 0 holds them)
-			if(lane == 0) {
-#pragma unroll
-				for(int i = 0; i < 4; i++) if((uint32_t)i < order) or_bits(img, cap_words, pos + (uint32_t)i * sbps, (uint32_t)x[4 + i] & smask, sbps);
-			}
-			pos += order * sbps;
-			const uint32_t po = d.po, rice2 = d.rice2, plen = rice2 ? 5u : 4u;
-			if(lane == 0) {
-				or_bits(img, cap_words, pos, rice2 ? 1u : 0u, 2);
-				or_bits(img, cap_words, pos + 2, po, 4);
-			}
-			pos += 6;
-			// the residual of the fixed predictor of this order = the order-th difference (fixed.c:470)
-			int32_t r[FF_RUN];
-			{
-				int32_t dd[FF_RUN + 4];
-#pragma unroll
-				for(int k = 0; k < FF_RUN + 4; k++) dd[k] = x[k];
-#pragma unroll
-				for(int o = 1; o <= 4; o++) {
-					if((uint32_t)o <= order) {
-#pragma unroll
-						for(int k = FF_RUN + 3; k >= o; k--) dd[k] = dd[k] - dd[k - 1];
-					}
-				}
-#pragma unroll
-				for(int t = 0; t < FF_RUN; t++) r[t] = dd[t + 4];
-			}
-			const uint32_t psize = n >> po, base = (uint32_t)lane * FF_RUN;
-			const uint32_t part = base / psize;
-			const uint32_t k = sh->kout[di][part];
-			const bool starts = base == part * psize;
-			uint32_t mybits = starts ? plen : 0u;
-#pragma unroll
-			for(int t = 0; t < FF_RUN; t++) {
-				const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
-				const uint32_t cb = (u >> k) + 1 + k;
-				mybits += (lane == 0 && (uint32_t)t < order) ? 0u : cb;
-				r[t] = (int32_t)u;
-			}
-			const uint32_t incl = wave_scan_incl_dpp(mybits);
-			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-			uint32_t p = pos + incl - mybits;
-			if(starts) { or_bits(img, cap_words, p, k, plen); p += plen; }
-			if(pos + incl <= cap_words * 32u) {
-				const uint32_t lsh = 31u - k;
-#pragma unroll
-				for(int t = 0; t < FF_RUN; t++) {
-					if(!(lane == 0 && (uint32_t)t < order)) {
-						const uint32_t u = (uint32_t)r[t];
-						p += u >> k;
-						or_code_fit(img, p, (u << lsh) | 0x80000000u);
-						p += 1 + k;
-					}
-				}
-			}
-			pos += total;
-		}
-		if(lane == 0 && info) {
+		for(int s = 0; s < 2; s++) {
+			const FFDec &d = s ? DR : DL;
 			flacgpu_subframe_info *si = &info[f].sub[s];
-			si->type = (uint8_t)type; si->order = (uint8_t)order; si->wasted_bits = (uint8_t)wasted;
+			si->type = (uint8_t)d.type; si->order = (uint8_t)d.order; si->wasted_bits = (uint8_t)d.wasted;
 			si->partition_order = (uint8_t)d.po; si->rice2 = (uint8_t)d.rice2; si->precision = 0; si->shift = 0;
 			si->pad = 0; si->bits = d.bits;
 		}
 	}
 	__builtin_amdgcn_wave_barrier();
-	// ---- zero-pad to a byte, CRC-16, footer, slot (stream_encoder.c:3720-3734) -------------------------------------------------
-	const uint32_t body_bytes = (pos + 7) >> 3, total_bytes = body_bytes + 2;
-	const bool overflow = total_bytes > P.slot_bytes;
+	// ---- zero-pad to a byte, CRC-16, footer (stream_encoder.c:3720-3734) --------------------------------------------------------
 	{
 		const uint32_t crc = frame_crc16_p2<64, 13>(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, lane, sh->xspan, FF_XSPAN, sh->xbyte);
 		if(lane == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
+	}
+	if(publish && lane == 0) fo_close_segment(O, f, nmain, mine, before);    // (the counter has had the write phase and the CRC to come back)
+	if(fused) {
+		// this frame's place in the stream: the sum of the lengths of all frames in front of it
+		uint64_t off = 0;
+		if(fo_exclusive(O, f, lane, off)) {
+			if(mine && off + mine <= O.cap) store_image<64>(img, O.out + off, mine, lane);
+			if(lane == 0) {
+				frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
+				O.offsets[f] = off;
+				if(f + 1 == nmain) { O.offsets[f + 1] = off + mine; *O.total = off + mine; }
+				if(info) info[f].channel_assignment = (uint8_t)ca;
+			}
+			return;
+		}
+		// (they did not turn up in time: the frame goes to its slot, below, and onto fo_fixup_kernel's list)
+		if(lane == 0) O.fall[atomicAdd(&O.nfall[O.epoch & 1u], 1u)] = f;
 	}
 	uint32_t *dst = (uint32_t *)(slots + (size_t)f * P.slot_bytes);
 	const uint32_t words = (umin32(total_bytes, P.slot_bytes) + 3) >> 2;
@@ -1448,14 +1647,61 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	if(lane == 0) {
 		frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
 		if(info) info[f].channel_assignment = (uint8_t)ca;
-		done[f] = 1;
+	}
+}
+
+// fo_place_kernel: frames that sit in their slots go to their places in the stream; their offsets are plain sums of published
+// words (every length is out and every segment closed once the pack kernel is done).  LISTED: the frames of PackOut::fall (the
+// ones that gave up waiting -- in a normal run none: a fixed grid of idle workgroups); else every frame of the batch, a workgroup
+// each (behind ff_kernel, which only publishes: this is the compaction, without a scan kernel in front of it).
+constexpr int FO_PLACE_GRID = 64;
+template <bool LISTED>
+__global__ __launch_bounds__(TPB) void fo_place_kernel(const PackOut O, uint32_t nmain, const uint8_t *__restrict__ slots, uint32_t slot_bytes, const uint32_t *__restrict__ frame_bytes)
+{
+	__shared__ uint64_t part[TPB / 64];
+	const int tid = (int)threadIdx.x;
+	uint32_t count = nmain;
+	if(LISTED) {
+		count = __hip_atomic_load(&O.nfall[O.epoch & 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if(blockIdx.x == 0 && tid == 0) __hip_atomic_store(&O.nfall[(O.epoch + 1u) & 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next batch's counter
+	}
+	for(uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+		const uint32_t f = LISTED ? O.fall[i] : i;
+		const uint32_t seg = f >> 6;
+		uint64_t s = 0;
+		for(uint32_t g = (uint32_t)tid; g < seg; g += TPB) s += fo_load(&O.sstate[g]) & FO_VAL;
+		if((uint32_t)tid < (f & 63u)) s += fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)tid]) & FO_VAL;
+		s = wave_reduce_add_u64(s);
+		__syncthreads();
+		if((tid & 63) == 0) part[tid >> 6] = s;
+		__syncthreads();
+		uint64_t off = 0;
+		for(int w = 0; w < TPB / 64; w++) off += part[w];
+		const uint32_t nbr = frame_bytes[f], nb = nbr == 0xffffffffu ? 0u : nbr;
+		if(nb && off + nb <= O.cap) {
+			// head bytes up to 4-byte alignment of the destination, then aligned words assembled from two source words (compact_kernel)
+			const uint8_t *src = slots + (size_t)f * slot_bytes;
+			uint8_t *dst = O.out + off;
+			const uint32_t head = umin32((uint32_t)((4 - ((uintptr_t)dst & 3)) & 3), nb);
+			if((uint32_t)tid < head) dst[tid] = src[tid];
+			const uint32_t words = (nb - head) >> 2, sh = head * 8;
+			const uint32_t *sw = (const uint32_t *)src;
+			uint32_t *dw = (uint32_t *)(dst + head);
+			for(uint32_t w = (uint32_t)tid; w < words; w += TPB) dw[w] = sh == 0 ? sw[w] : (sw[w] >> sh) | (sw[w + 1] << (32 - sh));
+			const uint32_t done = head + words * 4;
+			if((uint32_t)tid < nb - done) dst[done + (uint32_t)tid] = src[done + (uint32_t)tid];
+		}
+		if(tid == 0) {
+			O.offsets[f] = off;
+			if(f + 1 == nmain) { O.offsets[f + 1] = off + nb; *O.total = off + nb; }
+		}
 	}
 }
 
 // fused output with a short last block: that frame was assembled in its slot by pack_kernel; it goes behind the others
 __global__ __launch_bounds__(TPB) void append_tail_kernel(const uint8_t *__restrict__ slot, const uint32_t *__restrict__ frame_bytes, uint32_t f, const PackOut O)
 {
-	const uint64_t prev = f ? (__hip_atomic_load(&O.state[f - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SCAN_VAL) : 0;
+	const uint64_t prev = f ? *O.total : 0;                 // (the last frame of nominal length has left the stream's length so far)
 	const uint32_t nbr = frame_bytes[f], nb = nbr == 0xffffffffu ? 0u : nbr;
 	if(nb && prev + nb <= O.cap) {
 		uint8_t *dst = O.out + prev;
@@ -1634,10 +1880,21 @@ static bool pack2_applicable(const DevParams &P)
 	const uint32_t ps = P.blocksize >> P.max_po;
 	return P.blocksize % CHUNK == 0 && ps >= (uint32_t)CHUNK && ps % CHUNK == 0 && ((size_t)ps << P.max_po) == P.blocksize && !P.wide_samples && !P.img_global && !P.stream_sig;
 }
+static PackOut make_pack_out(const PackOutArgs *po)
+{
+	PackOut O;
+	memset(&O, 0, sizeof O);
+	if(po && po->out) {
+		O.out = po->out; O.cap = po->cap; O.offsets = po->offsets; O.total = po->total;
+		O.fstate = po->fstate; O.sstate = po->sstate; O.sprefix = po->sprefix; O.scount = po->scount; O.fall = po->fall; O.nfall = po->nfall;
+		O.epoch = po->epoch; O.spin_limit = po->spin_limit;
+	}
+	return O;
+}
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                                 const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, const PackOutArgs *po, bool *fused_out,
-                                uint32_t *hints, uint32_t *hinted_frames, const uint8_t *skip, hipStream_t s)
+                                uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
 {
 	static bool attr_set = false;
 	if(!attr_set) {
@@ -1655,8 +1912,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 	uint32_t f_lo = 0;
 	bool fused = false;
 	if(hinted_frames) *hinted_frames = 0;
-	PackOut O;
-	O.out = nullptr; O.cap = 0; O.offsets = nullptr; O.total = nullptr; O.state = nullptr; O.nframes_total = nframes;
+	PackOut O = make_pack_out(nullptr);
 	if constexpr(MAXORD <= 16) {                  // predictors of more than 16 taps (-l 17..32) take the general kernel
 		if(pack2_applicable(P)) {
 			f_lo = tail_n ? nframes - 1 : nframes;
@@ -1664,8 +1920,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			if(f_lo && po && po->out) {
 				// frames written once, at their final place: no slots, no scan / compact kernels
 				fused = true;
-				O.out = po->out; O.cap = po->cap; O.offsets = po->offsets; O.total = po->total; O.state = po->state;
-				if(hipMemsetAsync(po->state, 0, ((size_t)f_lo + 1) * sizeof(uint64_t), s) != hipSuccess) return hipErrorUnknown;
+				O = make_pack_out(po);
 			}
 			// half the threads for blocks that half of them cover in one pass (the 1152-sample blocks of -0 .. -2: 72 runs)
 			const bool half = P.blocksize <= CHUNK * (TPB / 2);
@@ -1673,12 +1928,13 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			// counts in 16-sample runs; FLACGPU_NO_RUN18=1: the 128-thread instance, for A/B runs)
 			static const bool no_run18 = getenv("FLACGPU_NO_RUN18") != nullptr;
 			const bool run18 = P.blocksize == 1152 && !hints && !no_run18 && (1152u >> P.max_po) % 18u == 0;
-			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
-			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
-			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
-			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
-			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints, fused ? nullptr : skip);
+			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
 			if(hinted_frames) *hinted_frames = hints ? f_lo : 0;
+			if(fused) hipLaunchKernelGGL(fo_place_kernel<true>, dim3(FO_PLACE_GRID), dim3(TPB), 0, s, O, f_lo, slots, P.slot_bytes, fb);
 		}
 	}
 	if(f_lo < nframes) hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes - f_lo), dim3(TPB), lds, s, P, chan, nframes, tail_n, f_lo, first, dec, slots, fb, info);
@@ -1698,15 +1954,15 @@ size_t pack_lds_bytes(const DevParams &P)
 
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, const PackOutArgs *po, bool *fused_out,
-                       uint32_t *hints, uint32_t *hinted_frames, const uint8_t *skip, hipStream_t s)
+                       uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
 {
 	const size_t lds = pack_lds_bytes(P);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
 	if(P.blocksize > HINT_RUNS * CHUNK) hints = nullptr;          // one run per thread and pass: blocks of up to 4096 samples
-	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, skip, s);
-	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, skip, s);
-	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, skip, s);
-	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, skip, s);
+	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
 }
 // ff_kernel takes 16-bit stereo in 1152-sample blocks when the prep kernel could decide the subframes itself (no LPC search, one
 // fixed order) and pack2_kernel could pack them; not with the verify hints (their decoder wants pack2_kernel's run starts)
@@ -1716,13 +1972,29 @@ bool ff_applicable(const DevParams &P)
 	return !off && P.channels == 2 && P.bps <= 16 && P.blocksize == FF_N && P.ncand == (P.ms_mode == 1 ? 4u : 2u) && prep2_decides(P) && pack2_applicable(P)
 	       && (1152u >> P.max_po) % 18u == 0 && P.slot_bytes <= 52 * FF_XSPAN - 64;      // (every span shift of a frame in the LDS table)
 }
-hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, uint8_t *done, uint32_t *nleft, hipStream_t s)
+hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, const PackOutArgs *po, hipStream_t s)
 {
 	if(nmain == 0) return hipSuccess;
 	const size_t lds = ff_tile_bytes(P.slot_bytes) + sizeof(FFShared);
-	if(P.ms_mode == 0) hipLaunchKernelGGL(ff_kernel<0>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done, nleft);
-	else if(P.ms_mode == 1) hipLaunchKernelGGL(ff_kernel<1>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done, nleft);
-	else hipLaunchKernelGGL(ff_kernel<2>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, done, nleft);
+	static const bool ff_fused = getenv("FLACGPU_FF_FUSED") != nullptr;
+	const PackOut Oplace = make_pack_out(po);
+	PackOut O = Oplace;
+	if(!ff_fused) O.out = nullptr;                  // publish only
+	if(P.ms_mode == 0) hipLaunchKernelGGL(ff_kernel<0>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O);
+	else if(P.ms_mode == 1) hipLaunchKernelGGL(ff_kernel<1>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O);
+	else hipLaunchKernelGGL(ff_kernel<2>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O);
+	if(po && po->out) {
+		// the compaction, offsets from the words the kernel has published (FLACGPU_FF_FUSED=1: the kernel places its frames itself
+		// and only the ones that gave up waiting are left for here -- the slower way on this chip, see PackOut)
+		if(O.out) hipLaunchKernelGGL(fo_place_kernel<true>, dim3(FO_PLACE_GRID), dim3(TPB), 0, s, O, nmain, slots, P.slot_bytes, fb);
+		else hipLaunchKernelGGL(fo_place_kernel<false>, dim3(nmain), dim3(TPB), 0, s, Oplace, nmain, slots, P.slot_bytes, fb);
+	}
+	sync_debug("ff", s);
+	return hipGetLastError();
+}
+hipError_t launch_append_tail(const uint8_t *slot, const uint32_t *fb, uint32_t f, const PackOutArgs *po, hipStream_t s)
+{
+	hipLaunchKernelGGL(append_tail_kernel, dim3(1), dim3(TPB), 0, s, slot, fb, f, make_pack_out(po));
 	return hipGetLastError();
 }
 hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s)

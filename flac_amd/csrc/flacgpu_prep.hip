@@ -47,11 +47,9 @@ __host__ __device__ constexpr uint32_t p2_chunk_len(uint32_t blocksize) { return
 template <bool WIDE, uint32_t NFIX, bool DECIDE>
 __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
                                                     ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
-                                                    int32_t *__restrict__ chan, SubDecision *__restrict__ decisions, uint32_t *__restrict__ left, uint32_t *__restrict__ nleft,
-                                                    const uint8_t *__restrict__ skip)
+                                                    int32_t *__restrict__ chan, SubDecision *__restrict__ decisions, uint32_t *__restrict__ left, uint32_t *__restrict__ nleft)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	if(skip && skip[blockIdx.x]) return;                      // ff_kernel (flacgpu_kernels.hip) has written this frame
 	__shared__ uint32_t sh_alleq[FLACGPU_MAX_CHANNELS];
 	__shared__ uint32_t sh_loose_ms;
 	const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -609,13 +607,13 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
 	const uint32_t waves = stereo_ms ? 4u : nraw;
 	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize, p2_chunk_len(P.blocksize));
-#define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft, B.ff_done)
+#define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft)
 	if(prep2_decides(P)) {
 		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
-		if(!B.ff_done || nmain == 0) (void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);      // (ff_kernel, launched in front, has zeroed them)
+		(void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
 		const size_t ldz = prep2_decide_lds(P, nraw, waves);
-		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft, B.ff_done);
-		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft, B.ff_done);
+		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
+		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
 		return hipGetLastError();
 	}
 	if(P.bps > 20) { if(P.blocksize == 4096) P2GO(true, 4096); else if(P.blocksize == 1152) P2GO(true, 1152); else P2GO(true, 0); }

@@ -114,6 +114,8 @@ struct FLAC__StreamEncoderPrivate {
 		int state;                            /* 0 being filled / free, 1 handed to the worker, 3 in flight on the engine, 2 done */
 	} slot[NSLOT];
 	int inflight, col_slot;                   /* worker: batches on the engine, and the slot of the oldest of them */
+	int submit_failed;                        /* worker: a submission failed (its error code): nothing goes to the engine after it, so the
+	                                           * batches in flight always occupy consecutive ring slots from col_slot on */
 	int cur;                                  /* slot the caller is filling */
 	size_t staged;                            /* inter-channel samples in slot[cur] */
 	size_t out_cap;
@@ -387,7 +389,7 @@ static void release_engine(FLAC__StreamEncoder *e)
 	p->engine_on = 0; p->bring_done = 0; p->engine_failed = 0;
 	p->out_cap = 0;
 	free(p->tail_windows); p->tail_windows = 0;
-	p->staged = 0; p->cur = 0; p->inflight = 0; p->col_slot = 0;
+	p->staged = 0; p->cur = 0; p->inflight = 0; p->col_slot = 0; p->submit_failed = 0;
 	if(PROT(e)->metadata) { free(PROT(e)->metadata); PROT(e)->metadata = 0; PROT(e)->num_metadata_blocks = 0; }
 }
 
@@ -714,8 +716,14 @@ static int emit(FLAC__StreamEncoder *e, const uint8_t *buf, size_t bytes, uint32
 	struct FLAC__StreamEncoderPrivate *p = PRIV(e);
 	FLAC__uint64 pos = 0;
 	if(p->preamble_pending) {            /* the first frame of a stream whose engine came up beside init_*(): the stream's head first */
-		p->preamble_pending = 0;
-		if(write_preamble(e) != FLAC__STREAM_ENCODER_INIT_STATUS_OK) return 0;
+		/* (the metadata packets are not the stream's last block and have no block size, whatever the frame that triggered them is:
+		 * an Ogg stream whose first frame is also its last must not close on its STREAMINFO page) */
+		const int is_last = p->emit_is_last;
+		const uint32_t fbs = p->frame_blocksize;
+		p->preamble_pending = 0; p->emit_is_last = 0; p->frame_blocksize = 0;
+		const FLAC__StreamEncoderInitStatus st = write_preamble(e);
+		p->emit_is_last = is_last; p->frame_blocksize = fbs;
+		if(st != FLAC__STREAM_ENCODER_INIT_STATUS_OK) return 0;
 	}
 	/* (the tell callback is called where write_frame_ calls it: for a metadata write, :3054, and -- once, lazily -- for a frame
 	 * that holds a seek point of the template, :3083; not in front of every frame) */
@@ -900,11 +908,20 @@ static void *worker_main(void *arg)
 		}
 		if(k >= 0 && p->inflight < NSLOT - 1) {
 			/* into flight: its input copy starts now, beside the kernels of the batches in front */
-			pthread_mutex_unlock(&p->mu);
-			const int went = engine_submit_slot(e, &p->slot[k]);
-			pthread_mutex_lock(&p->mu);
+			int went = 0;
+			if(p->submit_failed) p->slot[k].total = p->submit_failed;      /* the stream has failed: every later batch fails the same way, unsubmitted */
+			else {
+				pthread_mutex_unlock(&p->mu);
+				went = engine_submit_slot(e, &p->slot[k]);
+				pthread_mutex_lock(&p->mu);
+			}
 			if(went) { if(p->inflight++ == 0) p->col_slot = k; p->slot[k].state = 3; }
-			else p->slot[k].state = 2;                        /* (b->total says why) */
+			else {
+				/* (b->total says why.)  The batches in front stay in flight and are collected in order; this one and all behind it are
+				 * failed results, so that col_slot + 1 is always the next batch in flight */
+				if(!p->submit_failed) p->submit_failed = p->slot[k].total < 0 ? (int)p->slot[k].total : FLACGPU_ERR_LAUNCH;
+				p->slot[k].state = 2;
+			}
 			p->md5_slot = (k + 1) % NSLOT; p->md5_done = p->md5_ahead; p->md5_ahead = 0;
 			pthread_cond_broadcast(&p->cv);
 			continue;
@@ -1130,7 +1147,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 				if(!p->slot[i].raw || !p->slot[i].out || !p->slot[i].frame_bytes) r = FLACGPU_ERR_ALLOC;
 			}
 		}
-		p->md5_slot = 0; p->md5_done = 0; p->md5_ahead = 0; p->pub_slot = 0; p->pub_staged = p->pub_last = 0; p->inflight = 0; p->col_slot = 0;
+		p->md5_slot = 0; p->md5_done = 0; p->md5_ahead = 0; p->pub_slot = 0; p->pub_staged = p->pub_last = 0; p->inflight = 0; p->col_slot = 0; p->submit_failed = 0;
 		p->bring_started = 0; p->bring_done = 0; p->bring_result = FLACGPU_OK;
 		if(r == FLACGPU_OK) {
 			pthread_mutex_init(&p->mu, 0);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel register / LDS / scratch usage as the compiler reports it (development aid)
 # usage: scripts/kernel_resources.sh flac_amd/csrc/flacgpu_analyze.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fconstexpr-steps=50000000 -Iinclude -Iflac_amd/csrc -c "$1" -o /tmp/kr.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fconstexpr-steps=50000000 -Iinclude -Iflac_amd/csrc -c "$1" ${@:2} -o /tmp/kr.o \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys, re
 cur = None

@@ -14,7 +14,7 @@
 #include "flacgpu.h"
 
 struct fake_job { const void *raw; flacgpu_raw_format fmt; uint32_t nframes; uint64_t first; uint32_t last; uint8_t *out; size_t out_cap; uint32_t *fb; };
-struct flacgpu_ctx { flacgpu_config cfg; uint32_t verify; struct fake_job q[FLACGPU_ASYNC_SLOTS]; uint64_t sub, col; };
+struct flacgpu_ctx { flacgpu_config cfg; uint32_t verify; struct fake_job q[FLACGPU_ASYNC_SLOTS]; uint64_t sub, col; unsigned submit_calls; };
 static int g_creates, g_destroys;
 int fake_engine_creates(void) { return g_creates; }
 int fake_engine_destroys(void) { return g_destroys; }
@@ -88,6 +88,12 @@ int flacgpu_submit_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgpu_ra
 	if(ctx->sub - ctx->col >= FLACGPU_ASYNC_SLOTS) return FLACGPU_ERR_BUSY;
 	if(nframes > ctx->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
 	if(getenv("FAKE_ENGINE_FAIL_SUBMIT")) return FLACGPU_ERR_LAUNCH;
+	{
+		/* FAKE_ENGINE_FAIL_SUBMIT_NTH=n: only the n-th submission (1-based) of this engine is refused, the ones around it go through */
+		const char *nth = getenv("FAKE_ENGINE_FAIL_SUBMIT_NTH");
+		ctx->submit_calls++;
+		if(nth && ctx->submit_calls == (unsigned)atoi(nth)) return FLACGPU_ERR_LAUNCH;
+	}
 	struct fake_job *j = &ctx->q[ctx->sub % FLACGPU_ASYNC_SLOTS];
 	j->raw = raw; j->fmt = *fmt; j->nframes = nframes; j->first = first_frame_number; j->last = last_block_samples; j->out = out; j->out_cap = out_cap; j->fb = frame_bytes;
 	ctx->sub++;

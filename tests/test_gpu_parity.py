@@ -673,3 +673,62 @@ def test_three_kernel_path_of_the_fast_presets():
             "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLACGPU_NO_FF="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("level,nframes,bs,tail", [(0, 8400, 1152, 0), (2, 4300, 1152, 321), (5, 4400, 4096, 0), (8, 700, 4096, 1000)])
+def test_fused_output_over_many_segments(level, nframes, bs, tail):
+    """The fused output (flacgpu_kernels.hip, PackOut: frames written once, at their final place; lengths published early, segment
+    totals of 64 frames, segment starts) on batches of more than 64 segments, where a frame's walk over the segments in front of
+    it crosses rows and meets known starts -- ff_kernel at -0 / -2, pack2_kernel at -5 / -8, with and without a short last block
+    behind the frames of nominal length.  A repeating signal with per-repetition gain keeps the synthesis cheap and no two frames
+    alike; bytes and frame lengths equal the oracle's."""
+    base = signals.music(bs * 50, 2, 16, seed=40 + level).astype(np.int64)
+    n = nframes * bs + tail
+    reps = -(-n // len(base))
+    pcm = np.concatenate([(base * (1000 - 3 * (r % 200))) // 1000 for r in range(reps)])[:n].astype(np.int32)
+    eng = _engine(2, 16, 44100, level, max_batch=nframes + 1)
+    try:
+        for _ in range(2):                       # twice: the second batch finds the first one's (stale) words in the state arrays
+            data, fb = eng.encode(pcm)
+    finally:
+        eng.close()
+    o = po.oracle_encode(pcm, 16, 44100, level)
+    assert np.array_equal(fb, o["frame_bytes"])
+    assert data == o["data"]
+
+
+def test_two_kernel_compaction_path():
+    """FLACGPU_NO_FUSED_COMPACT=1 (read once per process): every frame to its slot, scan_kernel + compact_kernel behind the pack
+    kernels -- what sub-batches on several streams and the debug stamps still use; a fresh interpreter must produce the oracle's bytes"""
+    import subprocess, sys
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, flac_amd, signals\n"
+            "from oracle import pyoracle as po\n"
+            "for level, bs, seed in ((0, 1152, 5), (2, 1152, 6), (5, 4096, 7), (8, 4096, 8)):\n"
+            "    pcm = signals.music(bs * 70 + 77, 2, 16, seed=seed)\n"
+            "    eng = flac_amd.FrameEngine(flac_amd.make_settings(2, 16, 44100, level), device=0, max_batch_frames=128)\n"
+            "    data, fb = eng.encode(pcm); eng.close()\n"
+            "    assert data == po.oracle_encode(pcm, 16, 44100, level)['data'], level\n"
+            "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLACGPU_NO_FUSED_COMPACT="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_fused_output_when_frames_give_up_waiting():
+    """FLACGPU_FUSED_SPIN_LIMIT=0 (read when an engine is created): a frame whose predecessors' lengths are not there at its first
+    look goes to its slot and onto the list of fo_fixup_kernel, which places it behind the pack kernel -- the route that keeps the
+    fused output independent of the order in which the chip starts workgroups.  Same bytes; -0 / -2 (ff_kernel) and -5 / -8
+    (pack2_kernel), a short last block behind them."""
+    import subprocess, sys
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, flac_amd, signals\n"
+            "from oracle import pyoracle as po\n"
+            "for level, bs, nfr, seed in ((0, 1152, 1500, 5), (2, 1152, 700, 6), (5, 4096, 400, 7), (8, 4096, 150, 8)):\n"
+            "    pcm = signals.music(bs * nfr + 77, 2, 16, seed=seed)\n"
+            "    eng = flac_amd.FrameEngine(flac_amd.make_settings(2, 16, 44100, level), device=0, max_batch_frames=nfr + 1)\n"
+            "    data, fb = eng.encode(pcm); data2, fb2 = eng.encode(pcm); eng.close()\n"
+            "    o = po.oracle_encode(pcm, 16, 44100, level)\n"
+            "    assert data == o['data'] and data2 == o['data'], level\n"
+            "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLACGPU_FUSED_SPIN_LIMIT="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -192,6 +192,30 @@ if st == 0 and sys.argv[1] == "encode":
     state_after_process = lib.FLAC__stream_encoder_get_state(e)
     ok_finish = bool(lib.FLAC__stream_encoder_finish(e))
     print(st, state_after_init, ok_process, state_after_process, ok_finish, len(sink.buf.getvalue()))
+elif st == 0 and sys.argv[1] == "encode_records":
+    # many small calls, so that batches are submitted while earlier ones are in flight; then look at the records that came out
+    import struct
+    pcm = np.zeros((4096 * 40, 2), dtype=np.int32)
+    ok_process = True
+    for a in range(0, len(pcm), 4096):
+        part = np.ascontiguousarray(pcm[a:a + 4096])
+        if not lib.FLAC__stream_encoder_process_interleaved(e, part.ctypes.data, len(part)):
+            ok_process = False
+            break
+    state_after_process = lib.FLAC__stream_encoder_get_state(e)
+    ok_finish = bool(lib.FLAC__stream_encoder_finish(e))
+    data = sink.buf.getvalue()
+    body = data[data.find(b"FK\0\0"):] if b"FK\0\0" in data else b""
+    recs, pos, garbage = [], 0, 0
+    while pos < len(body):
+        if body[pos:pos + 4] != b"FK\0\0" or pos + 16 > len(body):
+            garbage = 1
+            break
+        fn, n, h = struct.unpack("<III", body[pos + 4:pos + 16])
+        recs.append(fn)
+        pos += 16 + fn %% 5
+    garbage |= int(any(sz > (1 << 20) for sz, _, _ in sink.calls))
+    print(st, state_after_init, ok_process, state_after_process, ok_finish, len(data), len(recs), recs == list(range(len(recs))), garbage)
 else:
     print(st, state_after_init)
 lib.FLAC__stream_encoder_delete(e)            # with the bring-up thread possibly still in flight
@@ -237,6 +261,41 @@ def test_empty_stream_with_asynchronous_bring_up():
     data = run_case(case, {"FAKE_ENGINE_CREATE_DELAY_US": "100000"})
     assert data[:4] == b"fLaC" and data[4] == 0 and data[42] == 0x84
     assert data == run_case(case, {"FLACGPU_SYNC_INIT": "1"})
+
+
+OGG_CHILD = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import flac_api
+pcm = np.zeros((int(sys.argv[1]), 2), dtype=np.int32)
+data, sink = flac_api.encode("gpu", pcm, 16, 44100, level=5, settings=[("set_blocksize", 256), ("set_ogg_serial_number", 77)], ogg=True)
+sys.stdout.buffer.write(data)
+'''
+
+
+@pytest.mark.parametrize("samples", [100, 256, 300])
+def test_ogg_stream_of_one_frame_with_asynchronous_bring_up(samples):
+    """ADVICE r03: the stream's head is written from inside the first frame's emit when the engine came up beside init_*(); for a
+    stream whose first frame is also its last, the metadata packets must not inherit that frame's is_last_block (the BOS page
+    carried the EOS flag).  Same bytes as the synchronous bring-up; flags: BOS on the first page only, EOS on the last only."""
+    _build()
+    outs = []
+    for extra in ({"FAKE_ENGINE_CREATE_DELAY_US": "50000"}, {"FLACGPU_SYNC_INIT": "1"}):
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = FAKE_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+        env.update(extra)
+        out = subprocess.run([sys.executable, "-c", OGG_CHILD % {"root": ROOT}, str(samples)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        outs.append(out.stdout)
+    assert outs[0] == outs[1]
+    flags, pos, d = [], 0, outs[0]
+    while pos < len(d):
+        assert d[pos:pos + 4] == b"OggS"
+        flags.append(d[pos + 5])
+        nseg = d[pos + 26]
+        pos += 27 + nseg + sum(d[pos + 27:pos + 27 + nseg])
+    assert flags[0] == 2 and all(f == 0 for f in flags[1:-1]) and flags[-1] == 4
 
 
 def test_delete_while_the_engine_is_still_coming_up():
@@ -351,6 +410,19 @@ def test_ring_of_batches_in_flight(batch, delay_us, md5):
     if delay_us:
         env["FAKE_ENGINE_DELAY_US"] = str(delay_us)
     check(case, env)
+
+
+@pytest.mark.parametrize("nth", [1, 2, 3, 4])
+def test_one_refused_submission_among_good_ones_fails_the_stream_cleanly(nth):
+    """only the n-th submission is refused while earlier batches are in flight and later ones would go through.  The
+    frames in front of the failed batch are delivered in order (whole records, none from a slot that was never filled), process()
+    fails, finish() returns (no hang in the drain loop)."""
+    out, err = _fail_child("encode_records", {"FAKE_ENGINE_FAIL_SUBMIT_NTH": str(nth), "FLACGPU_BATCH_FRAMES": "4", "FLACGPU_SYNC_INIT": "1",
+                                               "FAKE_ENGINE_DELAY_US": "2000"})
+    st, s_init, ok_process, s_proc, ok_finish, written, nrec, in_order, garbage = out
+    assert st == "0" and ok_process == "False" and s_proc != "0" and "the GPU frame engine failed" in err
+    assert garbage == "0" and in_order == "True"
+    assert int(nrec) == 4 * (nth - 1)                  # exactly the batches in front of the refused one
 
 
 def test_a_refused_submission_fails_the_stream():
