@@ -47,6 +47,7 @@ struct flacgpu_ctx {
 	uint32_t *d_fo_fall, *d_fo_nfall;
 	size_t fo_frames, fo_segs;
 	uint32_t fo_epoch, fo_spin_limit;
+	int ff_lag;                  // FLACGPU_FF_LAG (launch_ff): -1 not set -- ff_kernel batches take the two-kernel compaction
 	FrameInfo *d_info;           // [max_batch]
 	int32_t *d_pcm;              // staging for the host entry point
 	uint8_t *d_raw;              // raw sample bytes of flacgpu_encode_batch_raw
@@ -391,7 +392,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	ok = ok && hipMalloc(&c->d_windows, wbytes) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_tail_windows, wbytes) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_decisions, B * P.ncand * sizeof(SubDecision)) == hipSuccess;
-	ok = ok && hipMalloc(&c->d_slots, B * P.slot_bytes) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_slots, B * P.slot_bytes + 64) == hipSuccess;       // (+64: fo_copy_slot reads whole 16-byte pieces behind a frame)
 	ok = ok && hipMalloc(&c->d_frame_bytes, B * sizeof(uint32_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_offsets, (B + 1) * sizeof(uint64_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_total, sizeof(uint64_t)) == hipSuccess;
@@ -408,6 +409,8 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		// -- the tests' way to the slot + fo_fixup_kernel route)
 		c->fo_spin_limit = 4096;
 		if(const char *e = getenv("FLACGPU_FUSED_SPIN_LIMIT")) c->fo_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
+		c->ff_lag = -1;
+		if(const char *e = getenv("FLACGPU_FF_LAG")) c->ff_lag = atoi(e);
 	}
 	ok = ok && hipMalloc(&c->d_info, B * sizeof(FrameInfo)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_jobtab, 2 * sizeof(JobTable)) == hipSuccess;
@@ -488,7 +491,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	// parity tests of that path.
 	static int fuse = -1;
 	if(fuse < 0) fuse = getenv("FLACGPU_NO_FUSED_COMPACT") ? 0 : 1;
-	PackOutArgs po = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+	PackOutArgs po = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
 	if(fuse && nframes <= c->fo_frames) {
 		// (the epoch is committed below, once a kernel has really run with it: its fix-up kernel is what prepares the other bank)
 		uint32_t epoch = c->fo_epoch + 1;
@@ -498,7 +501,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			   hipMemsetAsync(c->d_fo_sprefix, 0, c->fo_segs * sizeof(uint64_t), s) != hipSuccess || hipMemsetAsync(c->d_fo_nfall, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 			c->fo_epoch = 0; epoch = 1;
 		}
-		po = PackOutArgs{d_out, out_cap, c->d_offsets, c->d_total, c->d_fo_fstate, c->d_fo_sstate, c->d_fo_sprefix, c->d_fo_scount, c->d_fo_fall, c->d_fo_nfall, epoch, c->fo_spin_limit};
+		po = PackOutArgs{d_out, out_cap, c->d_offsets, c->d_total, c->d_fo_fstate, c->d_fo_sstate, c->d_fo_sprefix, c->d_fo_scount, c->d_fo_fall, c->d_fo_nfall, epoch, c->fo_spin_limit, c->ff_lag > 0 ? (uint32_t)c->ff_lag : 0u};
 	}
 	// ff_kernel (one kernel for the whole frame, flacgpu_kernels.hip) where it applies: not with the verify hints (the decoder wants
 	// the pack kernel's run starts), not with the debug stamps; one stream
@@ -509,8 +512,9 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		// every frame of nominal length in ONE launch; a short last block goes through the general kernels as a batch of its own
 		// (every buffer is indexed by frame: the same launches on offset pointers) and then, with the fused output, behind the others
 		const uint32_t nmain = tail_n ? nframes - 1 : nframes;
-		if(launch_ff(P, d_pcm, nmain, first, c->d_slots, c->d_frame_bytes, c->d_info, po.out ? &po : nullptr, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-		fused = po.out != nullptr && nmain != 0;
+		const bool ffpo = po.out != nullptr && c->ff_lag >= 0;          // (the kernel places its frames itself only when asked to: launch_ff)
+		if(launch_ff(P, d_pcm, nmain, first, c->d_slots, c->d_frame_bytes, c->d_info, ffpo ? &po : nullptr, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		fused = ffpo && nmain != 0;
 		hipEvent_t after_main = c->ev[3];
 		if(tail_n) {
 			(void)hipEventRecord(c->pev[0], s);

@@ -150,7 +150,7 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 // to 64], sstate / sprefix / scount [max frames / 64 rounded up], nfall [2]: zeroed once when they are allocated (the tagged words
 // carry the epoch of their batch, the counters are zeroed by their last user); epoch: 1 .. 2^24 - 1, +1 for every launch;
 // spin_limit: polls before a frame gives up waiting for the ones in front of it and takes the slot + fo_place_kernel route
-struct PackOutArgs { uint8_t *out; uint64_t cap; uint64_t *offsets; uint64_t *total; uint64_t *fstate, *sstate, *sprefix, *scount; uint32_t *fall, *nfall; uint32_t epoch, spin_limit; };
+struct PackOutArgs { uint8_t *out; uint64_t cap; uint64_t *offsets; uint64_t *total; uint64_t *fstate, *sstate, *sprefix, *scount; uint32_t *fall, *nfall; uint32_t epoch, spin_limit, lag /* launch_ff */; };
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
                        const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg,
                        const PackOutArgs *po, bool *fused_out, uint32_t *hints, uint32_t *hinted_frames, hipStream_t s);

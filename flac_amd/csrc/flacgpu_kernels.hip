@@ -15,6 +15,7 @@
 // fp64 sections must round exactly like the reference binary.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "flacgpu_dev.h"
 
@@ -607,12 +608,12 @@ struct Pack2Shared {
 //     front of it in its own segment and the totals of the segments in front, 64 per step, nearest first.  The first frame of a
 //     segment leaves its offset behind as the segment's START: a walk that meets a known start stops there, so however long the
 //     batch, a frame looks at one or two rows of 64 totals.
-// What it buys depends on the kernel (profiles/r04_e_*, r04_f_*): pack2_kernel (-3 .. -8: five workgroups of four wavefronts per
-// CU, a frame's length known four fifths through) 0.26 + 0.09 ms of scan and compaction -> 0.30 ms; ff_kernel (-0 .. -2: one
-// wavefront per frame, 26 us from load to store) 0.106 + 0.039 -> 0.177 ms -- a hop between two CUs is 2-5 us under load
-// (MI355X_MICROARCH.md, handoff-1to1), a wavefront that waits for two of them at the end of 26 us is a SIMD with three wavefronts
-// instead of four for a fifth of the time.  So ff_kernel only PUBLISHES (O.out null, O.fstate set), and fo_place_kernel behind it
-// is a compaction that finds its offsets in the published words: no scan kernel, no waiting wavefront.
+// What it buys depends on the kernel (profiles/r04_g_fused_ab.txt, r04_h_ff_lag_ab.txt): pack2_kernel (-3 .. -8: five workgroups
+// of four wavefronts per CU, a frame's length known four fifths through) 0.26 + 0.09 ms of scan and compaction -> 0.30 ms;
+// ff_kernel (-0 .. -2: one wavefront per frame, 26 us from load to store) 0.106 + 0.039 -> 0.157 ms -- a hop between two CUs is
+// 2-5 us under load (MI355X_MICROARCH.md, handoff-1to1), and a wavefront that waits for two of them at the end of 26 us is a SIMD
+// with three wavefronts instead of four for a fifth of the time.  So ff_kernel keeps its slots and the two small kernels by
+// default; what it can do instead (launch_ff) is place, from each wavefront, the frame of 2048 frames ago.
 //   (Two versions that did not survive: frames taken in dispatch order off an atomic ticket -- one word saturates at ~88 M
 //   fetch-adds/s, 0.19 ms for the 16384 workgroups of a -0 batch; and the segment totals as atomic accumulators that the readers
 //   poll -- readers and atomics fight for the lines: pack2_kernel 0.30 -> 0.88 ms.)
@@ -623,6 +624,8 @@ struct Pack2Shared {
 // places the listed frames (in a normal run: none, and the kernel is a handful of idle workgroups).
 // Words are tagged with the batch's epoch instead of being zeroed per batch: [63:40] epoch (never 0), [39:0] value.
 constexpr uint64_t FO_VAL = (1ull << 40) - 1;
+// a frame's word, bit 39: its bytes are in its slot as well, for whoever places it from there (ff_kernel with PackOut::lag)
+constexpr uint64_t FO_STORED = 1ull << 39, FO_LEN = FO_STORED - 1;
 struct PackOut {
 	uint8_t *out;              // frames back to back (null: every frame goes to its slot)
 	uint64_t cap;
@@ -636,6 +639,7 @@ struct PackOut {
 	uint32_t *nfall;           // [2] how many, by epoch parity (fo_place_kernel zeroes the other one for the next batch)
 	uint32_t epoch;            // 1 .. 2^24 - 1
 	uint32_t spin_limit;       // polls before a frame gives up waiting for the frames in front of it
+	uint32_t lag;              // ff_kernel: the wavefront of frame f places frame f - lag (0: nobody places anything inside the kernel)
 };
 __device__ __forceinline__ uint64_t fo_word(uint32_t epoch, uint64_t v) { return ((uint64_t)epoch << 40) | v; }
 __device__ __forceinline__ bool fo_ready(uint64_t w, uint32_t epoch) { return (uint32_t)(w >> 40) == epoch; }
@@ -656,9 +660,11 @@ __device__ __forceinline__ void fo_close_segment(const PackOut &O, uint32_t f, u
 	fo_store(&O.scount[seg], 0ull);
 }
 // a whole wavefront, at the end of frame f: the sum of the lengths of all frames in front of it; false: they did not turn up in time
-__device__ __forceinline__ bool fo_exclusive(const PackOut &O, uint32_t f, int lane, uint64_t &excl_out)
+// WITH_OWN: the frame's own length is asked for as well (the deferred compaction of ff_kernel places somebody else's frame)
+template <bool WITH_OWN = false>
+__device__ __forceinline__ bool fo_exclusive(const PackOut &O, uint32_t f, int lane, uint64_t &excl_out, uint32_t *own_bytes = nullptr)
 {
-	const uint32_t seg = f >> 6, within = f & 63u, ep = O.epoch;
+	const uint32_t seg = f >> 6, within = f & 63u, ep = O.epoch, nrow = within + (WITH_OWN ? 1u : 0u);
 	const uint64_t none = fo_word(ep, 0);
 	uint64_t a, b, c;
 	int64_t s0 = (int64_t)seg - 1;
@@ -668,7 +674,7 @@ __device__ __forceinline__ bool fo_exclusive(const PackOut &O, uint32_t f, int l
 	bool first_row = true;
 	for(;;) {
 		const int64_t idx = s0 - lane;               // this lane's segment of the row (below 0: in front of the batch -- a known start of 0)
-		a = first_row && (uint32_t)lane < within ? fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)lane]) : none;
+		a = first_row && (uint32_t)lane < nrow ? fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)lane]) : none;
 		b = idx >= 0 ? fo_load(&O.sstate[idx]) : none;
 		c = idx >= 0 ? fo_load(&O.sprefix[idx]) : none;
 		uint32_t j;
@@ -676,15 +682,18 @@ __device__ __forceinline__ bool fo_exclusive(const PackOut &O, uint32_t f, int l
 			const uint64_t cm = __ballot((int)fo_ready(c, ep)), bm = __ballot((int)fo_ready(b, ep));
 			j = cm ? (uint32_t)(__ffsll((unsigned long long)cm) - 1) : 64u;      // the nearest segment whose start is known
 			const uint64_t need = j >= 63u ? ~0ull : ((2ull << j) - 1ull);
-			if((bm & need) == need && !__any((int)!fo_ready(a, ep))) break;
+			// (WITH_OWN: the frame itself must also have its bytes in its slot)
+			const bool a_ok = fo_ready(a, ep) && !(WITH_OWN && first_row && (uint32_t)lane == within && !(a & FO_STORED));
+			if((bm & need) == need && !__any((int)!a_ok)) break;
 			if(polls++ >= O.spin_limit) return false;
 			__builtin_amdgcn_s_sleep(8);
 			// (only the words that are missing are asked for again: thousands of pollers on whole rows are traffic of their own)
-			if(!fo_ready(a, ep)) a = fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)lane]);
+			if(!a_ok) a = fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)lane]);
 			if(!fo_ready(b, ep)) b = fo_load(&O.sstate[idx]);
 			if(!fo_ready(c, ep) && (uint32_t)lane <= 4u) c = fo_load(&O.sprefix[idx]);
 		}
-		uint64_t v = a & FO_VAL;
+		if(WITH_OWN && first_row) *own_bytes = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, (int)within);      // (a length has 32 bits)
+		uint64_t v = (uint32_t)lane < within ? a & FO_LEN : 0ull;
 		if((uint32_t)lane <= j) v += b & FO_VAL;
 		if((uint32_t)lane == j) v += c & FO_VAL;
 		excl += wave_reduce_add_u64(v);
@@ -695,6 +704,42 @@ __device__ __forceinline__ bool fo_exclusive(const PackOut &O, uint32_t f, int l
 	excl_out = excl;
 	return true;
 }
+// 16 bytes straight to / from memory (sc0 sc1: write-through stores, loads that no cache of this CU serves): what a frame that
+// another CU will read inside the same launch is stored and read with (MI355X_MICROARCH.md: "sc0 sc1 stores and loads both sides")
+typedef uint32_t fo_u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) volatile fo_u4 *fo_gv4;
+typedef __attribute__((address_space(1))) const volatile fo_u4 *fo_cgv4;
+typedef __attribute__((address_space(1))) const volatile uint32_t *fo_cgv1;
+
+// a frame as it lies in its slot (little-endian bytes, 16-byte aligned, written by another wavefront of this launch) to byte
+// address dst, whatever its alignment: a lane takes 12 words per pass -- three 16-byte loads and the word behind them -- shifts
+// them into the destination's word grid and stores three times 16 bytes; head and tail bytes one by one
+__device__ __forceinline__ void fo_copy_slot(const uint8_t *src, uint8_t *dst, uint32_t nb, int lane)
+{
+	const uint32_t head = umin32((uint32_t)((4 - ((uintptr_t)dst & 3)) & 3), nb);
+	if((uint32_t)lane < head) dst[lane] = (uint8_t)(*(fo_cgv1)(src) >> (8 * (uint32_t)lane));
+	const uint32_t words = (nb - head) >> 2, shb = head;               // destination word w = source bytes [head + 4 w, head + 4 w + 4)
+	uint32_t *dw = (uint32_t *)(dst + head);
+	for(uint32_t w0 = 12u * (uint32_t)lane; w0 < words; w0 += 12u * 64u) {
+		const fo_u4 a = *(fo_cgv4)(src + 4 * w0), b = *(fo_cgv4)(src + 4 * w0 + 16), c = *(fo_cgv4)(src + 4 * w0 + 32);
+		const uint32_t e = *(fo_cgv1)(src + 4 * w0 + 48);                // (inside the slot: slots end 16 bytes behind the longest frame)
+		const uint32_t in[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e};
+		uint32_t o[12];
+#pragma unroll
+		for(int k = 0; k < 12; k++) o[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], shb);
+		if(w0 + 12 <= words) {
+			uint4 *d4 = (uint4 *)(dw + w0);                                // (4-byte aligned: the hardware takes dword-aligned 16-byte stores)
+			d4[0] = make_uint4(o[0], o[1], o[2], o[3]); d4[1] = make_uint4(o[4], o[5], o[6], o[7]); d4[2] = make_uint4(o[8], o[9], o[10], o[11]);
+		}
+		else {
+#pragma unroll
+			for(int k = 0; k < 12; k++) if(w0 + (uint32_t)k < words) dw[w0 + k] = o[k];
+		}
+	}
+	const uint32_t done = head + words * 4;
+	if((uint32_t)lane < nb - done) { const uint32_t k = done + (uint32_t)lane; dst[k] = (uint8_t)(*(fo_cgv1)(src + (k & ~3u)) >> (8 * (k & 3u))); }
+}
+
 // the finished frame image (big-endian word views in LDS) to byte address dst, whatever its alignment
 template <int NT = TPB>
 __device__ __forceinline__ void store_image(const uint32_t *img, uint8_t *dst, uint32_t nb, int tid)
@@ -1461,7 +1506,7 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = (int)threadIdx.x;
-	const bool fused = O.out != nullptr, publish = O.fstate != nullptr;
+	const bool publish = O.fstate != nullptr;
 	const uint32_t f = blockIdx.x;
 	constexpr uint32_t n = FF_N;
 	uint32_t *tile = (uint32_t *)smem;                                        // the transposed tile, later the frame image
@@ -1625,52 +1670,64 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 		__syncthreads();
 	}
 	if(publish && lane == 0) fo_close_segment(O, f, nmain, mine, before);    // (the counter has had the write phase and the CRC to come back)
-	if(fused) {
-		// this frame's place in the stream: the sum of the lengths of all frames in front of it
-		uint64_t off = 0;
-		if(fo_exclusive(O, f, lane, off)) {
-			if(mine && off + mine <= O.cap) store_image<64>(img, O.out + off, mine, lane);
-			if(lane == 0) {
-				frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
-				O.offsets[f] = off;
-				if(f + 1 == nmain) { O.offsets[f + 1] = off + mine; *O.total = off + mine; }
-				if(info) info[f].channel_assignment = (uint8_t)ca;
-			}
-			return;
-		}
-		// (they did not turn up in time: the frame goes to its slot, below, and onto fo_fixup_kernel's list)
-		if(lane == 0) O.fall[atomicAdd(&O.nfall[O.epoch & 1u], 1u)] = f;
-	}
-	uint32_t *dst = (uint32_t *)(slots + (size_t)f * P.slot_bytes);
+	uint8_t *slot = slots + (size_t)f * P.slot_bytes;
 	const uint32_t words = (umin32(total_bytes, P.slot_bytes) + 3) >> 2;
-	for(uint32_t w = (uint32_t)lane; w < words; w += 64) dst[w] = __builtin_bswap32(img[w]);
+	if(O.lag) {
+		// (another wavefront of this launch will read the slot: write-through stores, 16 bytes a lane)
+		const fo_u4 *img4 = (const fo_u4 *)img;
+		for(uint32_t q = (uint32_t)lane; q < (words + 3) >> 2; q += 64) {
+			fo_u4 v = img4[q];
+			v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+			*(fo_gv4)(slot + 16 * q) = v;
+		}
+		// ... and once they have left (MI355X_MICROARCH.md: write-through payload -> vmcnt(0) -> flag) the frame's word says so
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if(lane == 0) fo_store(&O.fstate[f], fo_word(O.epoch, (uint64_t)mine | FO_STORED));
+	}
+	else {
+		uint32_t *dst = (uint32_t *)slot;
+		for(uint32_t w = (uint32_t)lane; w < words; w += 64) dst[w] = __builtin_bswap32(img[w]);
+	}
 	if(lane == 0) {
 		frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
 		if(info) info[f].channel_assignment = (uint8_t)ca;
+	}
+	// ---- the compaction rides along: this wavefront places the frame `lag` frames back, whose length, predecessors and bytes have
+	// been out for a dozen microseconds -- nothing to wait for (PackOut).  The last `lag` frames of the batch are fo_place_kernel's.
+	if(O.lag && f >= O.lag) {
+		const uint32_t g = f - O.lag;
+		uint64_t off = 0;
+		uint32_t nb = 0;
+		if(fo_exclusive<true>(O, g, lane, off, &nb)) {
+			if(nb && off + nb <= O.cap) fo_copy_slot(slots + (size_t)g * P.slot_bytes, O.out + off, nb, lane);
+			if(lane == 0) O.offsets[g] = off;
+		}
+		else if(lane == 0) O.fall[atomicAdd(&O.nfall[O.epoch & 1u], 1u)] = g;
 	}
 }
 
 // fo_place_kernel: frames that sit in their slots go to their places in the stream; their offsets are plain sums of published
 // words (every length is out and every segment closed once the pack kernel is done).  LISTED: the frames of PackOut::fall (the
-// ones that gave up waiting -- in a normal run none: a fixed grid of idle workgroups); else every frame of the batch, a workgroup
-// each (behind ff_kernel, which only publishes: this is the compaction, without a scan kernel in front of it).
+// ones that gave up waiting -- in a normal run none: a fixed grid of idle workgroups); else the frames [first, nmain) of the batch,
+// a workgroup each (behind ff_kernel, which places all but its last PackOut::lag frames itself: no scan kernel, and a compaction
+// kernel for an eighth of the batch).
 constexpr int FO_PLACE_GRID = 64;
 template <bool LISTED>
-__global__ __launch_bounds__(TPB) void fo_place_kernel(const PackOut O, uint32_t nmain, const uint8_t *__restrict__ slots, uint32_t slot_bytes, const uint32_t *__restrict__ frame_bytes)
+__global__ __launch_bounds__(TPB) void fo_place_kernel(const PackOut O, uint32_t first, uint32_t nmain, const uint8_t *__restrict__ slots, uint32_t slot_bytes, const uint32_t *__restrict__ frame_bytes)
 {
 	__shared__ uint64_t part[TPB / 64];
 	const int tid = (int)threadIdx.x;
-	uint32_t count = nmain;
+	uint32_t count = nmain - first;
 	if(LISTED) {
 		count = __hip_atomic_load(&O.nfall[O.epoch & 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if(blockIdx.x == 0 && tid == 0) __hip_atomic_store(&O.nfall[(O.epoch + 1u) & 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next batch's counter
 	}
 	for(uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-		const uint32_t f = LISTED ? O.fall[i] : i;
+		const uint32_t f = LISTED ? O.fall[i] : first + i;
 		const uint32_t seg = f >> 6;
 		uint64_t s = 0;
 		for(uint32_t g = (uint32_t)tid; g < seg; g += TPB) s += fo_load(&O.sstate[g]) & FO_VAL;
-		if((uint32_t)tid < (f & 63u)) s += fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)tid]) & FO_VAL;
+		if((uint32_t)tid < (f & 63u)) s += fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)tid]) & FO_LEN;
 		s = wave_reduce_add_u64(s);
 		__syncthreads();
 		if((tid & 63) == 0) part[tid >> 6] = s;
@@ -1887,7 +1944,7 @@ static PackOut make_pack_out(const PackOutArgs *po)
 	if(po && po->out) {
 		O.out = po->out; O.cap = po->cap; O.offsets = po->offsets; O.total = po->total;
 		O.fstate = po->fstate; O.sstate = po->sstate; O.sprefix = po->sprefix; O.scount = po->scount; O.fall = po->fall; O.nfall = po->nfall;
-		O.epoch = po->epoch; O.spin_limit = po->spin_limit;
+		O.epoch = po->epoch; O.spin_limit = po->spin_limit; O.lag = 0;
 	}
 	return O;
 }
@@ -1934,7 +1991,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
 			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
 			if(hinted_frames) *hinted_frames = hints ? f_lo : 0;
-			if(fused) hipLaunchKernelGGL(fo_place_kernel<true>, dim3(FO_PLACE_GRID), dim3(TPB), 0, s, O, f_lo, slots, P.slot_bytes, fb);
+			if(fused) hipLaunchKernelGGL(fo_place_kernel<true>, dim3(FO_PLACE_GRID), dim3(TPB), 0, s, O, 0u, f_lo, slots, P.slot_bytes, fb);
 		}
 	}
 	if(f_lo < nframes) hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes - f_lo), dim3(TPB), lds, s, P, chan, nframes, tail_n, f_lo, first, dec, slots, fb, info);
@@ -1976,18 +2033,24 @@ hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uin
 {
 	if(nmain == 0) return hipSuccess;
 	const size_t lds = ff_tile_bytes(P.slot_bytes) + sizeof(FFShared);
-	static const bool ff_fused = getenv("FLACGPU_FF_FUSED") != nullptr;
+	// How the frames get to their places.  Default: every frame to its slot, scan_kernel + compact_kernel behind this one (the caller,
+	// with po == null).  FLACGPU_FF_LAG=n (opt-in, po != null): the kernel publishes its lengths and the wavefront of frame f places
+	// frame f - n, whose length, predecessors and bytes have been out for a dozen microseconds; the last n frames, and with n = 0 all
+	// of them, are fo_place_kernel's.  Measured (profiles/r04_h_ff_lag_ab.txt, 16384 frames, ms per step, two kernels / lag 2048 /
+	// lag 0): -0 0.156 / 0.158 / 0.161, -1 0.164 / 0.165 / 0.169, -2 0.194 / 0.185 / 0.195 -- a kernel of one-wavefront workgroups
+	// that live 26 us pays for every extra round trip (the write-through slot stores, the loads of the frame it places) with a
+	// wavefront slot that is not computing; only -2, whose wavefronts live longer, comes out ahead.  And a wavefront that places its
+	// OWN frame and waits for the lengths in front of it (what pack2_kernel does) was the slowest: 0.167 at -0.
 	const PackOut Oplace = make_pack_out(po);
 	PackOut O = Oplace;
-	if(!ff_fused) O.out = nullptr;                  // publish only
+	if(po && po->out) { O.lag = po->lag < nmain ? po->lag : 0u; if(!O.lag) O.out = nullptr; }       // (lag 0: publish only)
 	if(P.ms_mode == 0) hipLaunchKernelGGL(ff_kernel<0>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O);
 	else if(P.ms_mode == 1) hipLaunchKernelGGL(ff_kernel<1>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O);
 	else hipLaunchKernelGGL(ff_kernel<2>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O);
 	if(po && po->out) {
-		// the compaction, offsets from the words the kernel has published (FLACGPU_FF_FUSED=1: the kernel places its frames itself
-		// and only the ones that gave up waiting are left for here -- the slower way on this chip, see PackOut)
-		if(O.out) hipLaunchKernelGGL(fo_place_kernel<true>, dim3(FO_PLACE_GRID), dim3(TPB), 0, s, O, nmain, slots, P.slot_bytes, fb);
-		else hipLaunchKernelGGL(fo_place_kernel<false>, dim3(nmain), dim3(TPB), 0, s, Oplace, nmain, slots, P.slot_bytes, fb);
+		const uint32_t firstp = O.lag ? nmain - O.lag : 0u;
+		hipLaunchKernelGGL(fo_place_kernel<false>, dim3(nmain - firstp), dim3(TPB), 0, s, Oplace, firstp, nmain, slots, P.slot_bytes, fb);
+		hipLaunchKernelGGL(fo_place_kernel<true>, dim3(FO_PLACE_GRID), dim3(TPB), 0, s, Oplace, 0u, nmain, slots, P.slot_bytes, fb);
 	}
 	sync_debug("ff", s);
 	return hipGetLastError();

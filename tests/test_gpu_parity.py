@@ -714,21 +714,32 @@ def test_two_kernel_compaction_path():
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
-def test_fused_output_when_frames_give_up_waiting():
-    """FLACGPU_FUSED_SPIN_LIMIT=0 (read when an engine is created): a frame whose predecessors' lengths are not there at its first
-    look goes to its slot and onto the list of fo_fixup_kernel, which places it behind the pack kernel -- the route that keeps the
-    fused output independent of the order in which the chip starts workgroups.  Same bytes; -0 / -2 (ff_kernel) and -5 / -8
-    (pack2_kernel), a short last block behind them."""
+def _fresh_interpreter_cases(env, cases="((0, 1152, 1500, 5), (2, 1152, 700, 6), (5, 4096, 400, 7), (8, 4096, 150, 8))"):
     import subprocess, sys
     code = ("import sys; sys.path[:0] = [%r, %r]\n"
             "import numpy as np, flac_amd, signals\n"
             "from oracle import pyoracle as po\n"
-            "for level, bs, nfr, seed in ((0, 1152, 1500, 5), (2, 1152, 700, 6), (5, 4096, 400, 7), (8, 4096, 150, 8)):\n"
+            "for level, bs, nfr, seed in " + cases + ":\n"
             "    pcm = signals.music(bs * nfr + 77, 2, 16, seed=seed)\n"
             "    eng = flac_amd.FrameEngine(flac_amd.make_settings(2, 16, 44100, level), device=0, max_batch_frames=nfr + 1)\n"
             "    data, fb = eng.encode(pcm); data2, fb2 = eng.encode(pcm); eng.close()\n"
             "    o = po.oracle_encode(pcm, 16, 44100, level)\n"
             "    assert data == o['data'] and data2 == o['data'], level\n"
             "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLACGPU_FUSED_SPIN_LIMIT="0"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_fused_output_when_frames_give_up_waiting():
+    """FLACGPU_FUSED_SPIN_LIMIT=0 (read when an engine is created): a frame whose predecessors' lengths are not there at its first
+    look goes to its slot and onto the list of fo_place_kernel, which places it behind the pack kernel -- the route that keeps the
+    fused output independent of the order in which the chip starts workgroups.  Same bytes; -5 / -8 (pack2_kernel places its own
+    frames) and -0 / -2 with FLACGPU_FF_LAG (ff_kernel places the frame of n frames ago), a short last block behind them."""
+    _fresh_interpreter_cases({"FLACGPU_FUSED_SPIN_LIMIT": "0", "FLACGPU_FF_LAG": "256"})
+
+
+@pytest.mark.parametrize("lag", [0, 64, 2048])
+def test_ff_kernel_places_the_frames_of_some_frames_ago(lag):
+    """FLACGPU_FF_LAG=n (opt-in, launch_ff): ff_kernel publishes its lengths and the wavefront of frame f copies frame f - n from its
+    slot to its place; the last n frames (n = 0, or a batch of no more than n frames: all of them) are fo_place_kernel's."""
+    _fresh_interpreter_cases({"FLACGPU_FF_LAG": str(lag)}, "((0, 1152, 5000, 5), (1, 1152, 900, 9), (2, 1152, 1500, 6))")
