@@ -66,6 +66,15 @@ def synth_pcm(nframes, seed, block, kind="music"):
     return np.ascontiguousarray(base[: nframes * block])
 
 
+def rank_pcm(rank, nframes, block, kind, hires):
+    """the synthetic PCM rank `rank` encodes in every step (seed 1234 + rank): what measure() puts into HBM, and what rank 0
+    regenerates after the timed region to check the frames it gathered from that rank"""
+    if hires:
+        import signals
+        return np.ascontiguousarray(signals.music(nframes * block, CH, BPS, seed=1234 + rank, rate=RATE))
+    return synth_pcm(nframes, 1234 + rank, block, kind)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the unmodified reference on this box's host cores (test infrastructure: oracle/_ref)
 # ------------------------------------------------------------------------------------------------------------------
@@ -167,7 +176,10 @@ def verify_step(pcm_h, out_bytes, fb, first_frame, level, block, nsample=96, sea
     host.flacgpu_host_check_frame_crcs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
     nframes = fb.size
     fb32 = np.ascontiguousarray(fb.astype(np.uint32))
-    assert int(fb32.sum()) == out_bytes.size, "frame lengths do not add up to the byte total"
+    if int(fb32.astype(np.int64).sum()) != out_bytes.size:
+        return {"crc16_frames_checked": 0, "crc16_first_bad_frame": 0, "frames_compared_with_oracle": 0, "frames_differing": [], "ok": False,
+                "error": "frame lengths add up to %d bytes, the segment has %d" % (int(fb32.astype(np.int64).sum()), out_bytes.size)}
+    out_bytes = np.ascontiguousarray(out_bytes)
     bad = int(host.flacgpu_host_check_frame_crcs(out_bytes.ctypes.data, fb32.ctypes.data, nframes, min(32, os.cpu_count() or 1)))
     offs = np.concatenate([[0], np.cumsum(fb32.astype(np.int64))])
     rng = np.random.default_rng(5)
@@ -187,6 +199,28 @@ def verify_step(pcm_h, out_bytes, fb, first_frame, level, block, nsample=96, sea
             "ok": bad == -1 and not mism}
 
 
+def verify_ranks(stream, sizes, fbs, nframes, level, block, kind="music", hires=False, search=None, nsample=16):
+    """The multi-rank line's check (the reference drains its frames in order, stream_encoder.c:3530-3574: so must the gather):
+    `stream` holds the frames of every rank of ONE step in rank order, sizes[r] bytes from rank r, fbs[r] its frame lengths.
+    Rank r's segment must be the frames r*nframes .. (r+1)*nframes - 1 of the job: every CRC-16 is recomputed, and frames of
+    EVERY rank's segment (its ends, the XCD boundaries, `nsample` random ones) are encoded again by the oracle from that rank's
+    PCM (rank_pcm) with their job-wide frame numbers and compared byte for byte."""
+    per_rank, off = [], 0
+    for r, sz in enumerate(sizes):
+        seg = stream[off:off + sz]
+        v = verify_step(rank_pcm(r, nframes, block, kind, hires), seg, np.asarray(fbs[r]), r * nframes, level, block, nsample=nsample, search=search)
+        v["rank"] = r
+        per_rank.append(v)
+        off += sz
+    bad = [v["rank"] for v in per_rank if not v["ok"]]
+    return {"ranks_checked": len(per_rank), "ok": not bad and off == len(stream), "ranks_failing": bad,
+            "crc16_frames_checked": sum(v["crc16_frames_checked"] for v in per_rank),
+            "frames_compared_with_oracle": sum(v["frames_compared_with_oracle"] for v in per_rank),
+            "frames_differing": [[v["rank"], f] for v in per_rank for f in v["frames_differing"]],
+            "crc16_first_bad_frame": next(([v["rank"], v["crc16_first_bad_frame"]] for v in per_rank if v["crc16_first_bad_frame"] != -1), -1),
+            "errors": [[v["rank"], v["error"]] for v in per_rank if "error" in v]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,8 +237,9 @@ def main():
     ap.add_argument("--level", type=int, default=8, help="compression preset -0..-8 (the metric is quoted at -8: other levels are side measurements; "
                     "-0..-2 use the preset's 1152-sample blocks)")
     ap.add_argument("--window", type=int, default=4, help="multi-rank: steps per gather window")
-    ap.add_argument("--gather", choices=("rccl", "hostshm"), default="rccl", help="multi-rank: how a step's frames reach their destination -- rccl: point-to-point over xGMI "
-                    "into rank 0's HBM (the north star's gather); hostshm: every rank copies over its own PCIe link into one shared pinned host buffer")
+    ap.add_argument("--gather", choices=("rccl", "hostshm", "none"), default="rccl", help="multi-rank: how a step's frames reach their destination -- rccl: point-to-point over xGMI "
+                    "into rank 0's HBM (the north star's gather); hostshm: every rank copies over its own PCIe link into one shared pinned host buffer; "
+                    "none: they stay where they were encoded (encode-only scaling: what the funnel costs is this line against the rccl one)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank pipeline (process group, windowed ordered gather) even with one rank")
     args = ap.parse_args()
     global RATE, BPS
@@ -250,15 +285,11 @@ def main():
         block = block_of(level)
         settings = flac_amd.make_settings(CH, BPS, RATE, level, **search)
         eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=nframes)
-        if args.hires:
-            import signals
-            pcm_h = np.ascontiguousarray(signals.music(nframes * block, CH, BPS, seed=1234 + rank, rate=RATE))
-        else:
-            pcm_h = synth_pcm(nframes, 1234 + rank, block, kind)
+        pcm_h = rank_pcm(rank, nframes, block, kind, args.hires)
         d_pcm = torch.from_numpy(pcm_h).to(dev)
         cap = eng.max_output_bytes(nframes)
         first_frame = rank * nframes
-        if not use_dist:
+        if not use_dist or args.gather == "none":
             d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
             d_fb = torch.empty(nframes, dtype=torch.int32, device=dev)
             d_total = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -343,6 +374,32 @@ def main():
                                     "ms_per_batch_lane_per_frame": round(seq_ms, 4),
                                     "decode_Msamples_per_s": round(nframes * block / vms / 1e3, 1),
                                     "encode_plus_verify_Msamples_per_s": round(nframes * block / (vms + elapsed / steps * 1e3) / 1e3, 1)}
+        verified = None
+        if use_dist and not args.no_verify:
+            # the multi-rank check, outside the timed region: EVERY rank's frames of the last step
+            if gp is None:
+                # --gather none: nothing was moved; every rank checks its own frames where they lie and rank 0 collects the verdicts
+                tb = int(d_total.item())
+                mine = verify_step(pcm_h, d_out[:tb].cpu().numpy(), d_fb.cpu().numpy(), first_frame, level, block, nsample=16, search=search)
+                flags = torch.tensor([1 if mine["ok"] else 0, mine["crc16_frames_checked"], mine["frames_compared_with_oracle"]], dtype=torch.int64, device=dev)
+                table = torch.empty(world * 3, dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(table, flags)
+                table = table.cpu().view(world, 3)
+                verified = {"ranks_checked": world, "ok": bool(table[:, 0].min().item() == 1), "ranks_failing": [r for r in range(world) if table[r, 0].item() != 1],
+                            "crc16_frames_checked": int(table[:, 1].sum()), "frames_compared_with_oracle": int(table[:, 2].sum()),
+                            "how": "no gather: every rank checked its own frames (CRC-16 of all, oracle on a sample, frame numbers rank * frames + f)"}
+            else:
+                k_last = state["k"] - 1 if (steps % gp.K == 0) else (state["k"] - gp.K + steps % gp.K - 1)
+                if args.gather == "hostshm":
+                    # (the shared host buffer holds every rank's bytes, but a rank knows only its own frame lengths: they are collected here)
+                    _, _, myfb = gp.gathered(k_last)
+                    allfb = torch.empty(world * nframes, dtype=torch.int32, device=dev)
+                    dist.all_gather_into_tensor(allfb, myfb.contiguous().to(torch.int32))
+                if rank == 0:
+                    stream, sizes, fbs = gp.gathered(k_last)
+                    if args.gather == "hostshm":
+                        fbs = allfb.view(world, nframes)
+                    verified = verify_ranks(stream[:sum(sizes)].cpu().numpy(), sizes, fbs.cpu().numpy(), nframes, level, block, kind, args.hires, search)
         if rank == 0:
             if gp is None:
                 total_bytes = int(d_total.item())
@@ -405,7 +462,9 @@ def main():
                                         "per_kernel": valu, "wave_insts_per_sample_whole_step": round(tot_i, 3),
                                         "whole_step_frac_of_issue_peak": round(tot_i * samples_per_step / (elapsed / steps) / 1e9 / VALU_ISSUE_PEAK, 4),
                                         "source": "SQ_INSTS_VALU of the committed counter pass (profiles/pmc_traffic.json) x this run's HIP-event kernel times"}
-            if not args.no_verify:
+            if verified is not None:
+                res["verified"] = verified
+            elif not args.no_verify:
                 res["verified"] = verify_step(pcm_h, out_h, fb_h, first_frame, level, block, search=search)
         if gp is not None and hasattr(gp, "close"):
             gp.close()
@@ -451,7 +510,11 @@ def main():
                                    "96k/24-bit" if args.hires else "44.1k/16-bit", nframes, m["block"], sig),
                        "frames_per_gpu_per_step": nframes, "blocksize": m["block"], "channels": CH, "bits_per_sample": BPS,
                        "samples_are": "inter-channel (x2 for channel-samples)",
-                       "parallelism": ("frame-shard x%d + ordered RCCL gather of every step's frames to rank 0 (sizes exchanged once per window of %d steps, "
+                       "input": "every step encodes the SAME resident batch again (%.0f MB of int32 PCM per GPU: larger than the 256 MB Infinity Cache, so it streams from "
+                                "HBM every step, but it is one buffer, not a corpus)" % (nframes * m["block"] * CH * 4 / 1e6),
+                       "parallelism": ("frame-shard x%d, no gather: every rank's frames stay in its HBM (encode-only scaling; the difference to the rccl line is the funnel)" % world
+                                       if args.gather == "none" else
+                                       "frame-shard x%d + ordered RCCL gather of every step's frames to rank 0 (sizes exchanged once per window of %d steps, "
                                        "transfers overlapped with the next window's encodes, rank 0 encodes in place)" % (world, args.window) if args.gather == "rccl" else
                                        "frame-shard x%d + every rank copies each step's frames over its own PCIe link into one shared pinned host buffer at the scanned offset "
                                        "(sizes exchanged once per window of %d steps)" % (world, args.window)) if multi else "one GPU, no process group",
