@@ -262,6 +262,72 @@ __device__ __forceinline__ uint32_t frame_crc16_p2(const uint32_t *img, uint32_t
 	return gf16_mul(crc & 0xffffu, xbyte_lds[last_len]) ^ (crc >> 16);
 }
 
+// Round 4's form of the same for pack2_kernel and ff_kernel: spans aligned to the END of the frame.  The body is padded with its
+// zero bytes to a whole word (the image is zero behind it), spans of SPANW words are counted back from that word, and the first
+// one reaches in front of the image, where zeros lie (P2_IMG_PAD: a CRC that starts at zero does not see leading zeros) -- so
+// every span is whole, every lane runs the same SPANW unconditional steps, and there is neither a short last span nor a byte
+// loop; the padding's factor x^(8 z) comes off at the end by its inverse (x is a unit modulo P: P(0) = 1).  A byte's table
+// address is one SDWA shift (v_lshlrev_b32 with a byte select; the tables sit at a fixed LDS address, which goes into the
+// instruction's offset field): 9 VALU instructions and 4 LDS reads per word where the round-3 form had 13 + predication
+// (profiles/r04_l_crc_ab.txt).
+constexpr uint32_t crc_gfmul_c(uint32_t a, uint32_t b) { uint32_t r = 0; for(int i = 0; i < 16; i++) { r = crc_mulx(r); if(b & 0x8000u) r ^= a; b = (b << 1) & 0xffffu; } return r; }
+constexpr uint32_t CRC_XINV1 = 0xC002u;                   // x^-1 = x^15 + x^14 + x  (x * that = x^16 + x^15 + x^2 = 1 mod P)
+constexpr uint32_t crc_xinv8() { uint32_t r = 1; for(int i = 0; i < 8; i++) r = crc_gfmul_c(r, CRC_XINV1); return r; }
+static_assert(crc_gfmul_c(2u, CRC_XINV1) == 1u, "x * x^-1 = 1 mod x^16+x^15+x^2+1");
+constexpr uint32_t CRC_XINV8 = crc_xinv8(), CRC_XINV16 = crc_gfmul_c(CRC_XINV8, CRC_XINV8), CRC_XINV24 = crc_gfmul_c(CRC_XINV16, CRC_XINV8);
+static_assert(crc_gfmul_c(CRC_XINV8, crc_mulx8(1)) == 1u, "x^8 * x^-8 = 1");
+template <int B>
+__device__ __forceinline__ uint32_t byte_times2(uint32_t v, uint32_t one)       // 2 * byte B of v
+{
+	uint32_t d;
+	if constexpr(B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(one), "v"(v));
+	if constexpr(B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(one), "v"(v));
+	if constexpr(B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(one), "v"(v));
+	if constexpr(B == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(one), "v"(v));
+	return d;
+}
+// The four 256-entry tables (uint16_t [4][256]) sit at LDS ADDRESS 0 -- the start of the kernel's dynamic LDS, which has no static
+// LDS in front of it (lds_base_is_zero() checks) --, so that a table address is the shifted byte itself and the table's offset
+// goes into the instruction's offset field; img[-SPANW .. -1] must be readable zeros.  Ends with a barrier.
+typedef __attribute__((address_space(3))) const uint16_t *lds_u16p;
+__device__ __forceinline__ bool lds_base_is_zero(const unsigned char *smem) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)smem == 0u; }
+template <int NT, int SPANW>
+__device__ __forceinline__ uint32_t frame_crc16_end(const uint32_t *img, uint32_t body_bytes, uint32_t *crc_parts, int tid,
+                                                    const uint16_t *xspan_lds, uint32_t nxspan_lds, const uint16_t *xspan_global)
+{
+	const uint32_t W = (body_bytes + 3) >> 2, z = W * 4 - body_bytes;
+	const uint32_t nsp = (W + SPANW - 1) / SPANW;
+	uint32_t one = 1;
+	asm volatile("" : "+v"(one));                                            // (a register: the SDWA form takes no literal)
+	uint32_t c = 0;
+	for(uint32_t sp = (uint32_t)tid; sp < nsp; sp += NT) {
+		const uint32_t *wp = img + (int32_t)W - (int32_t)(SPANW * (nsp - sp));
+		uint32_t w[SPANW];
+#pragma unroll
+		for(int k = 0; k < SPANW; k++) w[k] = wp[k];
+		uint32_t cs = 0;
+#pragma unroll
+		for(int k = 0; k < SPANW; k++) {
+			const uint32_t v = (cs << 16) ^ w[k];
+			cs = (uint32_t)*(lds_u16p)(uintptr_t)(byte_times2<3>(v, one) + 3 * 512) ^ *(lds_u16p)(uintptr_t)(byte_times2<2>(v, one) + 2 * 512)
+			     ^ *(lds_u16p)(uintptr_t)(byte_times2<1>(v, one) + 512) ^ *(lds_u16p)(uintptr_t)byte_times2<0>(v, one);
+		}
+		const uint32_t m = nsp - 1 - sp;                                     // whole spans behind this one
+		const uint32_t xs = m < nxspan_lds ? xspan_lds[m] : xspan_global[m];
+		c ^= m ? gf16_mul(cs, xs) : cs;
+	}
+#pragma unroll
+	for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
+	if(NT > 64) {
+		if((tid & 63) == 0) crc_parts[tid >> 6] = c;
+		__syncthreads();
+		c = 0;
+		for(int wv = 0; wv < NT / 64; wv++) c ^= crc_parts[wv];
+	}
+	else __syncthreads();
+	return z == 0 ? c : gf16_mul(c, z == 1 ? CRC_XINV8 : z == 2 ? CRC_XINV16 : CRC_XINV24);
+}
+
 // number of frame header bytes including the CRC-8, without building them (same cases as frame_header_bytes)
 __device__ __forceinline__ uint32_t frame_header_len(const DevParams &P, uint32_t n, uint32_t v)
 {
@@ -583,11 +649,12 @@ __device__ __forceinline__ void or_code_fit(uint32_t *buf, uint32_t pos, uint32_
 	atomicOr(w + 1, __builtin_amdgcn_alignbit(x_left, 0u, pos & 31));
 }
 
-constexpr uint32_t P2_XSPAN = 512;           // span shifts kept in LDS (frames up to 32 KiB; longer ones read the global table)
+constexpr uint32_t P2_XSPAN = 512;           // span shifts kept in LDS (frames up to 22 KiB; longer ones read the global table)
+constexpr uint32_t P2_IMG_PAD = 64;          // zero bytes in front of the frame image (frame_crc16_end reads up to a span in front of it)
 struct Pack2Shared {
+	uint16_t crc_tab[4][256];                              // (first: at a fixed LDS address, see frame_crc16_end)
 	uint32_t wtot[2][TPB / 64];
 	uint32_t crc_parts[TPB / 64];
-	uint16_t crc_tab[4][256];
 	uint16_t xspan[P2_XSPAN];
 	uint16_t xbyte[CRC_SPAN + 2];
 	uint32_t dec[FLACGPU_MAX_CHANNELS * sizeof(SubDecision) / 4];      // this frame's decision records
@@ -843,9 +910,12 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave: a scalar register)
 	const uint32_t C = P.channels, N = P.blocksize, n = N;
-	uint32_t *img = (uint32_t *)smem;
+	// LDS: [tables and small state][64 zero bytes][frame image: slot_bytes + 16]
+	constexpr uint32_t IMG_OFF = (uint32_t)((sizeof(Pack2Shared) + 15) & ~(size_t)15) + P2_IMG_PAD;
+	Pack2Shared *sh = (Pack2Shared *)smem;
+	uint32_t *img = (uint32_t *)(smem + IMG_OFF);
 	const uint32_t cap_words = P.slot_bytes / 4;
-	Pack2Shared *sh = (Pack2Shared *)(smem + P.slot_bytes + 16);
+	if(!lds_base_is_zero(smem)) __builtin_trap();             // (frame_crc16_end addresses the CRC tables absolutely)
 	const bool fused = O.out != nullptr;
 	uint32_t f = blockIdx.x;
 	f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);        // (the frame's addresses are scalar registers)
@@ -872,7 +942,11 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 #pragma unroll
 		for(uint32_t k = 0; k < XS_ROUNDS; k++) xv[k] = xs32[(uint32_t)tid + k * NT];
 		const uint32_t bv = xb32[tid < (int)(CRC_SPAN + 2) / 2 ? tid : 0];
-		for(uint32_t w = (uint32_t)tid; w < cap_words + 2; w += NT) img[w] = 0;
+		{
+			// (16 bytes a store: the pad in front, the image and the 16 bytes behind it; slot_bytes is a multiple of 16)
+			uint4 *z4 = (uint4 *)(smem + IMG_OFF - P2_IMG_PAD);
+			for(uint32_t q = (uint32_t)tid; q < P2_IMG_PAD / 16 + cap_words / 4 + 1; q += NT) z4[q] = make_uint4(0, 0, 0, 0);
+		}
 #pragma unroll
 		for(uint32_t k = 0; k < DEC_ROUNDS; k++) { const uint32_t w = (uint32_t)tid + k * NT; if(w < ndw) sh->dec[w] = dv[k]; }
 #pragma unroll
@@ -1151,7 +1225,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 	uint64_t before = 0;
 	if(fused && tid == NT - 64) before = fo_publish(O, f, mine);
 	{
-		const uint32_t crc = frame_crc16_p2<NT>(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, tid, sh->xspan, P2_XSPAN, sh->xbyte);
+		const uint32_t crc = frame_crc16_end<NT, (int)CRC2_WORDS>(img, overflow ? 0 : body_bytes, sh->crc_parts, tid, sh->xspan, P2_XSPAN, g_crc_tables.xspan44);
 		PSTAMP(11);
 		if(tid == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
@@ -1509,8 +1583,11 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	const bool publish = O.fstate != nullptr;
 	const uint32_t f = blockIdx.x;
 	constexpr uint32_t n = FF_N;
-	uint32_t *tile = (uint32_t *)smem;                                        // the transposed tile, later the frame image
-	FFShared *sh = (FFShared *)(smem + ff_tile_bytes(P.slot_bytes));
+	// LDS: [tables and small state][64 zero bytes][the transposed tile, later the frame image]
+	constexpr uint32_t IMG_OFF = (uint32_t)((sizeof(FFShared) + 15) & ~(size_t)15) + P2_IMG_PAD;
+	FFShared *sh = (FFShared *)smem;
+	uint32_t *tile = (uint32_t *)(smem + IMG_OFF);
+	if(!lds_base_is_zero(smem)) __builtin_trap();             // (frame_crc16_end addresses the CRC tables absolutely)
 	// ---- every load of the frame at once: samples (coalesced), CRC tables -----------------------------------------------------
 	int2 v[FF_RUN];
 	{
@@ -1645,8 +1722,8 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	const uint32_t cap_words = P.slot_bytes / 4;
 	{
 		// (slot_bytes is a multiple of 16, and the image has 16 bytes to spare behind it: whole 16-byte stores)
-		uint4 *img4 = (uint4 *)img;
-		for(uint32_t q = (uint32_t)lane; q < cap_words / 4 + 1; q += 64) img4[q] = make_uint4(0, 0, 0, 0);
+		uint4 *img4 = (uint4 *)(smem + IMG_OFF - P2_IMG_PAD);          // (and the pad in front of it: frame_crc16_end)
+		for(uint32_t q = (uint32_t)lane; q < P2_IMG_PAD / 16 + cap_words / 4 + 1; q += 64) img4[q] = make_uint4(0, 0, 0, 0);
 	}
 	__builtin_amdgcn_wave_barrier();
 	if(lane == 1) (void)frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { or_bits(img, cap_words, 8 * k, byte, 8); });
@@ -1665,7 +1742,7 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	__builtin_amdgcn_wave_barrier();
 	// ---- zero-pad to a byte, CRC-16, footer (stream_encoder.c:3720-3734) --------------------------------------------------------
 	{
-		const uint32_t crc = frame_crc16_p2<64, 13>(img, overflow ? 0 : body_bytes, sh->crc_tab, sh->crc_parts, lane, sh->xspan, FF_XSPAN, sh->xbyte);
+		const uint32_t crc = frame_crc16_end<64, 13>(img, overflow ? 0 : body_bytes, sh->crc_parts, lane, sh->xspan, FF_XSPAN, g_ff_span.x);
 		if(lane == 0) or_bits(img, cap_words, body_bytes * 8, crc, 16);
 		__syncthreads();
 	}
@@ -1973,7 +2050,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 	if constexpr(MAXORD <= 16) {                  // predictors of more than 16 taps (-l 17..32) take the general kernel
 		if(pack2_applicable(P)) {
 			f_lo = tail_n ? nframes - 1 : nframes;
-			const size_t lds2 = (size_t)P.slot_bytes + 16 + sizeof(Pack2Shared);
+			const size_t lds2 = ((sizeof(Pack2Shared) + 15) & ~(size_t)15) + P2_IMG_PAD + (size_t)P.slot_bytes + 16;
 			if(f_lo && po && po->out) {
 				// frames written once, at their final place: no slots, no scan / compact kernels
 				fused = true;
@@ -2005,7 +2082,7 @@ namespace flacgpu {
 size_t pack_lds_bytes(const DevParams &P)
 {
 	if(P.img_global) return (size_t)pack_pass_sig_bytes(P) + sizeof(PackShared);
-	const size_t a = (size_t)pack_pass_sig_bytes(P) + P.slot_bytes + sizeof(PackShared), b = (size_t)P.slot_bytes + 16 + sizeof(Pack2Shared);
+	const size_t a = (size_t)pack_pass_sig_bytes(P) + P.slot_bytes + sizeof(PackShared), b = ((sizeof(Pack2Shared) + 15) & ~(size_t)15) + P2_IMG_PAD + (size_t)P.slot_bytes + 16;
 	return a > b ? a : b;
 }
 
@@ -2032,7 +2109,7 @@ bool ff_applicable(const DevParams &P)
 hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, const PackOutArgs *po, hipStream_t s)
 {
 	if(nmain == 0) return hipSuccess;
-	const size_t lds = ff_tile_bytes(P.slot_bytes) + sizeof(FFShared);
+	const size_t lds = ((sizeof(FFShared) + 15) & ~(size_t)15) + P2_IMG_PAD + ff_tile_bytes(P.slot_bytes);
 	// How the frames get to their places.  Default: every frame to its slot, scan_kernel + compact_kernel behind this one (the caller,
 	// with po == null).  FLACGPU_FF_LAG=n (opt-in, po != null): the kernel publishes its lengths and the wavefront of frame f places
 	// frame f - n, whose length, predecessors and bytes have been out for a dozen microseconds; the last n frames, and with n = 0 all
