@@ -1588,38 +1588,38 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	FFShared *sh = (FFShared *)smem;
 	uint32_t *tile = (uint32_t *)(smem + IMG_OFF);
 	if(!lds_base_is_zero(smem)) __builtin_trap();             // (frame_crc16_end addresses the CRC tables absolutely)
-	// ---- every load of the frame at once: samples (coalesced), CRC tables -----------------------------------------------------
-	int2 v[FF_RUN];
+	// ---- every load of the frame at once: samples, CRC tables -------------------------------------------------------------------
+	// A lane loads the 18 samples it owns straight from the interleaved block: nine 16-byte loads of 144 consecutive bytes (the
+	// wavefront as a whole reads its 9216 bytes once; a 16-byte piece never straddles a cache line).  Round 3 loaded coalesced and
+	// transposed through an LDS tile: 18 loads, 18 address computations with a division by 18, 18 LDS writes, 22 LDS reads and
+	// two wavefront barriers -- a tenth of the kernel's instructions for a layout change the memory system does as well
+	// (profiles/r04_n_ff_direct_loads_ab.txt).  The four samples in front of a lane's run are its left neighbour's last four:
+	// a DPP shift by one lane (lane 0 gets zeros: the start of the block).
+	uint32_t w[FF_RUN + 4];
 	{
-		const int2 *p = (const int2 *)(pcm + (size_t)f * n * 2);
+		const fo_u4 *p = (const fo_u4 *)(pcm + (size_t)f * n * 2) + (uint32_t)lane * (FF_RUN / 2);
+		fo_u4 v[FF_RUN / 2];
 #pragma unroll
-		for(int k = 0; k < FF_RUN; k++) v[k] = p[(uint32_t)lane + 64u * (uint32_t)k];
-		const uint32_t *tab32 = (const uint32_t *)g_crc_tables.tab, *xs32 = (const uint32_t *)g_ff_span.x, *xb32 = (const uint32_t *)g_crc_tables.xbyte;
+		for(int k = 0; k < FF_RUN / 2; k++) v[k] = p[k];
+		const uint32_t *tab32 = (const uint32_t *)g_crc_tables.tab, *xs32 = (const uint32_t *)g_ff_span.x;
 		uint32_t tv[8];
 #pragma unroll
 		for(int k = 0; k < 8; k++) tv[k] = tab32[(uint32_t)lane + 64u * (uint32_t)k];
-		const uint32_t xv = xs32[lane], bv = xb32[lane < (int)(CRC_SPAN + 2) / 2 ? lane : 0];
+		const uint32_t xv = xs32[lane];
 #pragma unroll
 		for(int k = 0; k < 8; k++) ((uint32_t *)sh->crc_tab)[(uint32_t)lane + 64u * (uint32_t)k] = tv[k];
 		((uint32_t *)sh->xspan)[lane] = xv;
-		if(lane < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[lane] = bv;
 		if(lane < 35) { const uint32_t po = (uint32_t)lane / 5u, o = (uint32_t)lane - po * 5u; sh->divtab[po * (MAX_ORDER + 1) + o] = g_ff_div[lane]; }
-		if(lane < FF_RUN) tile[lane * FF_TS] = 0;                             // column 0: the samples in front of the block
-		// sample i = lane + 64 k goes to row i % 18, column i / 18 + 1: 64 = 3 * 18 + 10, so from one k to the next the column grows by
-		// three and the row by ten, with a carry -- one division per lane instead of one per sample
-		uint32_t c = (uint32_t)lane / FF_RUN, r = (uint32_t)lane - c * FF_RUN;
+		// left in the low half, right in the high half of a word: one byte permute per sample
 #pragma unroll
-		for(int k = 0; k < FF_RUN; k++) {
-			tile[r * FF_TS + c + 1] = ((uint32_t)v[k].x & 0xffffu) | ((uint32_t)v[k].y << 16);
-			r += 10; c += 3;
-			if(r >= (uint32_t)FF_RUN) { r -= FF_RUN; c += 1; }
+		for(int k = 0; k < FF_RUN / 2; k++) {
+			w[4 + 2 * k] = __builtin_amdgcn_perm(v[k].y, v[k].x, 0x05040100u);
+			w[4 + 2 * k + 1] = __builtin_amdgcn_perm(v[k].w, v[k].z, 0x05040100u);
 		}
+#pragma unroll
+		for(int k = 0; k < 4; k++) w[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[FF_RUN + k], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 	}
 	__builtin_amdgcn_wave_barrier();
-	uint32_t w[FF_RUN + 4];
-#pragma unroll
-	for(int k = 0; k < FF_RUN + 4; k++) w[k] = k < 4 ? tile[(FF_RUN - 4 + k) * FF_TS + lane] : tile[(k - 4) * FF_TS + lane + 1];
-	__builtin_amdgcn_wave_barrier();                                          // the tile is the frame image from here on
 
 	// ---- candidate channels: one pass of a loop each (the decision records wait in LDS) ------------------------------------------
 	uint32_t ca = 0;
@@ -1802,15 +1802,16 @@ __global__ __launch_bounds__(TPB) void fo_place_kernel(const PackOut O, uint32_t
 	for(uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
 		const uint32_t f = LISTED ? O.fall[i] : first + i;
 		const uint32_t seg = f >> 6;
-		uint64_t s = 0;
-		for(uint32_t g = (uint32_t)tid; g < seg; g += TPB) s += fo_load(&O.sstate[g]) & FO_VAL;
-		if((uint32_t)tid < (f & 63u)) s += fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)tid]) & FO_LEN;
-		s = wave_reduce_add_u64(s);
+		if(LISTED) __syncthreads();                                           // (part[0] of the pass before has been read)
+		if(tid < 64) {
+			// one wavefront adds up: the totals of the segments in front (all loads in flight at once), the lengths in front in its own
+			uint64_t s = (uint32_t)tid < (f & 63u) ? fo_load(&O.fstate[(size_t)seg * 64 + (uint32_t)tid]) & FO_LEN : 0ull;
+			for(uint32_t g = (uint32_t)tid; g < seg; g += 64) s += fo_load(&O.sstate[g]) & FO_VAL;
+			s = wave_reduce_add_u64(s);
+			if(tid == 0) part[0] = s;
+		}
 		__syncthreads();
-		if((tid & 63) == 0) part[tid >> 6] = s;
-		__syncthreads();
-		uint64_t off = 0;
-		for(int w = 0; w < TPB / 64; w++) off += part[w];
+		const uint64_t off = part[0];
 		const uint32_t nbr = frame_bytes[f], nb = nbr == 0xffffffffu ? 0u : nbr;
 		if(nb && off + nb <= O.cap) {
 			// head bytes up to 4-byte alignment of the destination, then aligned words assembled from two source words (compact_kernel)
