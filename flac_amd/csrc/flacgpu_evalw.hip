@@ -135,17 +135,24 @@ __device__ __forceinline__ uint32_t fir16_w_dispatch(const int32_t (&x)[28], con
 	return fir16_w<12, false, FIRST>(x, xm, C, lane0, sum0);
 }
 
-// LDS of one wavefront: [image (S rows of 65 words)][prefix sums | divisor table | best parameters (flacgpu_evalg.h)]
+// LDS of a channel: [image (S rows of 65 words)][per wavefront: prefix sums | divisor table | best parameters (flacgpu_evalg.h)][merge]
+// WPC = 2: two wavefronts share a channel's image and halve its candidates between them (each with its own search state; the better
+// of their first minima wins).  A 4096-sample image of 32-bit samples is 16.6 KB: one wavefront per image is 2.25 wavefronts per
+// SIMD, and the kernel -- a dependent chain of multiply-adds per sample, like flacgpu_evalg.hip's -- then issues at 0.64 of the
+// chip's rate (profiles/r04_a_pmc_counters_hires_before.txt); two per image are four per SIMD.  (The 16-bit kernel has the same
+// option and does not need it: its images are half the size.)
 template <int MAXORD>
-__host__ __device__ inline uint32_t evalw_lds_bytes(uint32_t N) { return (N / 64) * EG_ROW + eg_tail_bytes<MAXORD>(); }
+__host__ __device__ inline uint32_t evalw_lds_bytes(uint32_t N, uint32_t wpc = 1) { return (N / 64) * EG_ROW + wpc * eg_tail_bytes<MAXORD>() + 64; }
 constexpr int EW_PIECES_AHEAD = 8;
 
 // returns false when the channel is not this kernel's (the caller lists it)
-template <int MAXORD>
+template <int MAXORD, int WPC>
 __device__ __forceinline__ bool evalw_body(const DevParams &P, const int32_t *__restrict__ chan, const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps,
                                            const Candidate *__restrict__ cands, const int *__restrict__ valid, SubDecision *__restrict__ decisions, uint32_t fc,
-                                           unsigned char *smem, int lane)
+                                           unsigned char *smem, int tid)
 {
+	const int lane = tid & 63;
+	const uint32_t wave = WPC > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) : 0u;
 	const uint32_t n = P.blocksize, S = n / 64;
 	const uint32_t aslots = P.norders * P.nprec, cstride = P.ncslots;
 	// ---- every load from HBM goes out before the first use ------------------------------------------------------------------
@@ -168,7 +175,7 @@ __device__ __forceinline__ bool evalw_body(const DevParams &P, const int32_t *__
 	const uint32_t nvec = n / 4, vps = S / 4;                                 // 16-byte pieces (4 samples) of the block, of a lane's run
 	uint4 pv[EW_PIECES_AHEAD];
 #pragma unroll
-	for(int i = 0; i < EW_PIECES_AHEAD; i++) { const uint32_t m = (uint32_t)lane + 64u * (uint32_t)i; if(m < nvec) pv[i] = src[m]; }
+	for(int i = 0; i < EW_PIECES_AHEAD; i++) { const uint32_t m = (uint32_t)tid + 64u * WPC * (uint32_t)i; if(m < nvec) pv[i] = src[m]; }
 
 	const uint32_t nan = P.nfixed + ((pr.flags & PREP_LPC) ? nanalyses * aslots : 0);
 	const bool any = !(pr.flags & PREP_CONSTANT) && ((pr.flags & PREP_FIXED_VALID) || nan > P.nfixed);
@@ -177,7 +184,9 @@ __device__ __forceinline__ bool evalw_body(const DevParams &P, const int32_t *__
 	frame_max_po = umin32(frame_max_po, P.max_po);
 	const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
 	const uint32_t sbps = pr.sbps, hdr = 8 + pr.wasted;
-	uint8_t *kbest = smem + evalw_lds_bytes<MAXORD>(n) - 64;
+	const uint32_t tail_off = S * EG_ROW + wave * eg_tail_bytes<MAXORD>();      // this wavefront's search state behind the shared image
+	uint8_t *kbest = smem + tail_off + eg_tail_bytes<MAXORD>() - 64;
+	uint32_t *merge = (uint32_t *)(smem + S * EG_ROW + WPC * eg_tail_bytes<MAXORD>());     // [WPC][4]: best estimate, candidate, left?, -
 	EgSearch R;
 	R.best_est = 0xffffffffu; R.best_ci = 0xffffffffu; R.best_po = 0;
 
@@ -206,33 +215,42 @@ __device__ __forceinline__ bool evalw_body(const DevParams &P, const int32_t *__
 	uint64_t vmask = __ballot((int)c_valid);
 
 	// ---- LDS of this wavefront: word j of lane L's run (one sample) at (j * 65 + L + 1); column 0 = lane 0's history: zero ----------
-	const uint32_t rows = S, img_bytes = rows * EG_ROW;
+	const uint32_t rows = S;
 	{
 		const bool spow2 = (vps & (vps - 1)) == 0;
 		const uint32_t vlog = ilog2_u32(vps);
-		if(lane < 16) *(uint32_t *)(smem + (rows - 16 + (uint32_t)lane) * EG_ROW) = 0;
+		if(tid < 16) *(uint32_t *)(smem + (rows - 16 + (uint32_t)tid) * EG_ROW) = 0;
 #pragma unroll
 		for(int i = 0; i < EW_PIECES_AHEAD; i++) {
-			const uint32_t m = (uint32_t)lane + 64u * (uint32_t)i;
+			const uint32_t m = (uint32_t)tid + 64u * WPC * (uint32_t)i;
 			if(m < nvec) {
 				const uint32_t Lo = spow2 ? m >> vlog : m / vps, r = m - Lo * vps;
 				unsigned char *d = smem + (Lo + 1) * 4 + 4 * r * EG_ROW;
 				*(uint32_t *)(d) = pv[i].x; *(uint32_t *)(d + EG_ROW) = pv[i].y; *(uint32_t *)(d + 2 * EG_ROW) = pv[i].z; *(uint32_t *)(d + 3 * EG_ROW) = pv[i].w;
 			}
 		}
-		for(uint32_t m = (uint32_t)lane + 64u * EW_PIECES_AHEAD; m < nvec; m += 64) {
+		for(uint32_t m = (uint32_t)tid + 64u * WPC * EW_PIECES_AHEAD; m < nvec; m += 64 * WPC) {
 			const uint4 v = src[m];
 			const uint32_t Lo = spow2 ? m >> vlog : m / vps, r = m - Lo * vps;
 			unsigned char *d = smem + (Lo + 1) * 4 + 4 * r * EG_ROW;
 			*(uint32_t *)(d) = v.x; *(uint32_t *)(d + EG_ROW) = v.y; *(uint32_t *)(d + 2 * EG_ROW) = v.z; *(uint32_t *)(d + 3 * EG_ROW) = v.w;
 		}
 	}
-	eg_search_setup<MAXORD>(R, smem, img_bytes, S, frame_max_po, frame_min_po, P.rice_limit, lane);
+	eg_search_setup<MAXORD>(R, smem, tail_off, S, frame_max_po, frame_min_po, P.rice_limit, lane);
 	const unsigned char *own = smem + ((uint32_t)lane + 1) * 4;                      // sample 0 of this lane's run
 	const unsigned char *hist = smem + (uint32_t)lane * 4 + (rows - 12) * EG_ROW;    // the 12 samples in front of it: the previous column's last
 	const uint32_t npieces = S / 16;
 	const uint32_t sum0 = 0x80000000u;
-	__builtin_amdgcn_wave_barrier();
+	if(WPC > 1) {
+		__syncthreads();                                                          // the image is whole
+		// the channel's candidates in halves: this wavefront's are the lowest (wave 0) or the rest (wave 1) of the valid ones
+		const uint32_t nv = (uint32_t)__builtin_popcountll(vmask), first = (nv + 1) / 2;
+		uint64_t m = vmask, lo = 0;
+		for(uint32_t i = 0; i < first; i++) { lo |= m & (0 - m); m &= m - 1; }
+		vmask = wave == 0 ? lo : m;
+	}
+	else __builtin_amdgcn_wave_barrier();
+	bool leave = false;
 
 	// ---- the candidates, two at a time ----------------------------------------------------------------------------------------
 	while(vmask) {
@@ -277,12 +295,23 @@ __device__ __forceinline__ bool evalw_body(const DevParams &P, const int32_t *__
 			if(two) s1 += fir16_w_dispatch<false>(x, xm, B, false, sum0);
 		}
 		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_list_kernel's (nothing was written yet)
-		if(__any((int)((s0 | s1) >= (1ull << 23)))) return false;
+		if(__any((int)((s0 | s1) >= (1ull << 23)))) { if(WPC == 1) return false; leave = true; break; }
 		EgCand CA, CB;
 		CA.order = A.order; CA.precision = A.precision; CA.ci = A.ci; CB.order = B.order; CB.precision = B.precision; CB.ci = B.ci;
 		eg_pair_search(R, smem, kbest, (uint32_t)s0, (uint32_t)s1, CA, CB, two, P.nfixed, hdr, sbps, lane);
 	}
+	if(WPC > 1) {
+		// the better first minimum of the two halves (an equal estimate: the earlier candidate, stream_encoder.c:4191,4266); a half
+		// that met sums beyond the node arithmetic sends the whole channel to the list
+		if(lane == 0) { merge[4 * wave] = R.best_est; merge[4 * wave + 1] = R.best_ci; merge[4 * wave + 2] = leave ? 1u : 0u; }
+		__syncthreads();
+		if(merge[2] | merge[6]) return false;
+		const uint32_t oe = merge[4 * (wave ^ 1u)], oc = merge[4 * (wave ^ 1u) + 1];
+		const bool mine = R.best_est < oe || (R.best_est == oe && (R.best_ci < oc || (R.best_ci == oc && wave == 0)));
+		if(!mine) return true;                                                    // (the other wavefront writes the decision)
+	}
 	}       // any
+	else if(WPC > 1 && wave != 0) return true;                                    // a channel without candidates: wavefront 0 decides it
 
 	eg_decide<MAXORD>(R, P, pr, n, kbest, c_order, c_prec, c_shift, cq, decisions + fc, preps + fc, lane);
 	return true;
@@ -290,28 +319,29 @@ __device__ __forceinline__ bool evalw_body(const DevParams &P, const int32_t *__
 
 // LIST: the channels come from a list (what flacgpu_evalg.hip's kernel left: the 32-bit channels of a 16-bit stream), a fixed grid
 // of wavefronts looping over it; otherwise one wavefront per channel of the batch (24-bit streams: every channel is one of these)
-template <int MAXORD, bool LIST>
-__global__ __launch_bounds__(64, EVALW_WAVES_PER_SIMD) void evalw_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
+template <int MAXORD, bool LIST, int WPC>
+__global__ __launch_bounds__(64 * WPC, WPC > 1 ? 4 : EVALW_WAVES_PER_SIMD) void evalw_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
                                                                           const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
                                                                           const int *__restrict__ valid, SubDecision *__restrict__ decisions,
                                                                           const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count,
                                                                           uint32_t *__restrict__ left, uint32_t *__restrict__ nleft)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int lane = (int)threadIdx.x;
+	const int tid = (int)threadIdx.x;
+	static_assert(!(LIST && WPC > 1), "the list flavour runs one wavefront per channel");
 	if(LIST) {
 		const uint32_t count = *in_count;
 		for(uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
 			const uint32_t fc = in_list[e];
 			const bool tail = tail_n != 0 && fc / P.ncand == nframes - 1;
-			if(tail || !evalw_body<MAXORD>(P, chan, jt, preps, cands, valid, decisions, fc, smem, lane)) { if(lane == 0) left[atomicAdd(nleft, 1u)] = fc; }
+			if(tail || !evalw_body<MAXORD, WPC>(P, chan, jt, preps, cands, valid, decisions, fc, smem, tid)) { if(tid == 0) left[atomicAdd(nleft, 1u)] = fc; }
 			__builtin_amdgcn_wave_barrier();
 		}
 	}
 	else {
 		const uint32_t fc = blockIdx.x;
 		const bool tail = tail_n != 0 && fc / P.ncand == nframes - 1;
-		if(tail || !evalw_body<MAXORD>(P, chan, jt, preps, cands, valid, decisions, fc, smem, lane)) { if(lane == 0) left[atomicAdd(nleft, 1u)] = fc; }
+		if(tail || !evalw_body<MAXORD, WPC>(P, chan, jt, preps, cands, valid, decisions, fc, smem, tid)) { if(tid == 0) left[atomicAdd(nleft, 1u)] = fc; }
 	}
 }
 
@@ -322,11 +352,11 @@ template <int MAXORD>
 static hipError_t launch_evalw_t(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec,
                                  const uint32_t *in_list, const uint32_t *in_count, uint32_t *out_list, uint32_t *out_count, hipStream_t s)
 {
-	const uint32_t lds = evalw_lds_bytes<MAXORD>(P.blocksize);
 	static bool set = false;
 	if(!set) {
-		hipError_t e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		hipError_t e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e != hipSuccess) return e;
 		set = true;
 	}
@@ -334,14 +364,23 @@ static hipError_t launch_evalw_t(const DevParams &P, uint32_t nframes, uint32_t 
 	if(in_list) {
 		// as many wavefronts as the chip holds of them: an empty list costs a few microseconds, a full one (white noise: the side
 		// channel of every frame) keeps every SIMD busy
+		const uint32_t lds = evalw_lds_bytes<MAXORD>(P.blocksize);
 		uint32_t per_cu = (160u * 1024u) / lds;
 		if(per_cu > 4u * EVALW_WAVES_PER_SIMD) per_cu = 4u * EVALW_WAVES_PER_SIMD;
 		if(per_cu < 1) per_cu = 1;
 		uint32_t grid = 256u * per_cu;
 		if(grid > nchan) grid = nchan;
-		hipLaunchKernelGGL((evalw_kernel<MAXORD, true>), dim3(grid), dim3(64), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, in_list, in_count, out_list, out_count);
+		hipLaunchKernelGGL((evalw_kernel<MAXORD, true, 1>), dim3(grid), dim3(64), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, in_list, in_count, out_list, out_count);
 	}
-	else hipLaunchKernelGGL((evalw_kernel<MAXORD, false>), dim3(nchan), dim3(64), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, nullptr, nullptr, out_list, out_count);
+	else {
+		// every channel of the batch (streams of more than 16 bits): two wavefronts per channel (FLACGPU_EVALW_WPC=1: one, for A/B runs)
+		static int wpc = 0;
+		if(!wpc) { const char *e = getenv("FLACGPU_EVALW_WPC"); wpc = e && atoi(e) == 1 ? 1 : 2; }
+		if(wpc == 2 && P.ncslots >= 4)
+			hipLaunchKernelGGL((evalw_kernel<MAXORD, false, 2>), dim3(nchan), dim3(128), evalw_lds_bytes<MAXORD>(P.blocksize, 2), s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, nullptr, nullptr, out_list, out_count);
+		else
+			hipLaunchKernelGGL((evalw_kernel<MAXORD, false, 1>), dim3(nchan), dim3(64), evalw_lds_bytes<MAXORD>(P.blocksize), s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, nullptr, nullptr, out_list, out_count);
+	}
 	return hipGetLastError();
 }
 hipError_t launch_evalw(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec,
