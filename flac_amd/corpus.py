@@ -138,7 +138,7 @@ def track_ranges(F, ntracks):
     return out
 
 
-def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_stream, want_md5=True, md5_threads=1):
+def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_stream, want_md5=True, md5_threads=1, md5_where="host"):
     """The corpus as `ntracks` separate streams (BASELINE config 5 as an album shelf rather than one file): every track's frames are
     numbered from 0 and get their own STREAMINFO (total samples, min/max frame size, MD5 of the track's samples).  One engine call
     per track (frame numbers of a call are consecutive).  Returns (list of (header, frames uint8 tensor view), timings)."""
@@ -149,32 +149,65 @@ def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_strea
     tail = total_samples - (F - 1) * BLOCK
     tail = 0 if tail == BLOCK else tail
     maxf = max(hi - lo for lo, hi in ranges)
-    raw = torch.empty((maxf * BLOCK, CH), dtype=torch.int16, device=dev)
+    on_device = want_md5 and md5_where == "device"
+    # md5_where == "device": the whole corpus's sample bytes stay staged in HBM (6.4 GB for ten hours) and are hashed there, one lane
+    # per track (flacgpu_md5.hip), beside the encodes -- no host copy of the samples, no host threads
+    raw_all = torch.empty((F * BLOCK, CH), dtype=torch.int16, device=dev) if on_device else None
+    raw = None if on_device else torch.empty((maxf * BLOCK, CH), dtype=torch.int16, device=dev)
     pcm = torch.empty((maxf * BLOCK, CH), dtype=torch.int32, device=dev)
-    cap = F * 3 * BLOCK * CH // 2 + eng.max_output_bytes(maxf)
-    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    # Every track is a stream of its own, so nothing has to be packed behind its predecessor: track t is encoded to where its frames
+    # would start if every frame in front took its worst case (a few GB of the 288 for a ten-hour corpus), the engine calls go out
+    # back to back, and the tracks' byte totals are read ONCE, at the end (round 3 read one per track before it could place the next:
+    # encode_seconds was host round trips, not the engine -- ADVICE r03)
+    slot = eng.max_output_bytes(1)
+    out = torch.empty(F * slot, dtype=torch.uint8, device=dev)
     fb_all = torch.zeros(F, dtype=torch.int32, device=dev)
     totals = torch.zeros(ntracks, dtype=torch.int64, device=dev)
-    offs = [0]
+    starts = [lo * slot for lo, _ in ranges]
     t0 = time.perf_counter()
+    staged_all = None
     with torch.cuda.stream(enc_stream):
+        if on_device:
+            # the corpus's sample bytes, all of them, before the first encode: the digests' chains can then start at once
+            device_frames(base_dev, 0, F, raw_all)
+            staged_all = torch.cuda.Event()
+            staged_all.record(enc_stream)
         for t, (lo, hi) in enumerate(ranges):
             nf = hi - lo
             if nf == 0:
-                offs.append(offs[-1])
                 continue
-            device_frames(base_dev, lo, hi, raw)
+            traw = raw_all[lo * BLOCK:hi * BLOCK] if on_device else raw
+            if not on_device:
+                device_frames(base_dev, lo, hi, traw)
             short = tail if (tail and hi == F) else 0
-            eng.stage_raw_device(raw.data_ptr(), fmt, nf * BLOCK - (BLOCK - short if short else 0), pcm.data_ptr(), None, enc_stream.cuda_stream)
-            eng.encode_device(pcm.data_ptr(), nf, out.data_ptr() + offs[-1], out.numel() - offs[-1], fb_all.data_ptr() + 4 * lo, totals.data_ptr() + 8 * t,
+            eng.stage_raw_device(traw.data_ptr(), fmt, nf * BLOCK - (BLOCK - short if short else 0), pcm.data_ptr(), None, enc_stream.cuda_stream)
+            eng.encode_device(pcm.data_ptr(), nf, out.data_ptr() + starts[t], nf * slot, fb_all.data_ptr() + 4 * lo, totals.data_ptr() + 8 * t,
                               first_frame_number=0, tail=short, stream=enc_stream.cuda_stream)
-            offs.append(offs[-1] + int(totals[t].item()))
-    enc_stream.synchronize()
-    t_enc = time.perf_counter() - t0
+    t_dev_md5 = 0.0
+    dev_digests = None
+    if on_device:
+        # behind the encodes on the same stream (the chains of 120 tracks are two wavefronts: they neither wait for nor slow the encodes much,
+        # but the samples must be staged first); synchronous on the stream, so it also stands for the end of the encodes
+        tm0 = time.perf_counter()
+        offs_b = [lo * BLOCK * CH * 2 for lo, _ in ranges]
+        lens_b = [max(0, (min(hi * BLOCK, total_samples) - lo * BLOCK)) * CH * 2 if hi > lo else 0 for lo, hi in ranges]
+        # behind the encodes, on their stream (beside them, on a stream of its own, the two wavefronts of 120 chains took twice as long
+        # and the job with them: profiles/r04_q_md5_device_overlapped.txt)
+        enc_stream.synchronize()
+        t_enc = time.perf_counter() - t0
+        tm0 = time.perf_counter()
+        dev_digests = flac_amd.engine.md5_many_device(raw_all.data_ptr(), offs_b, lens_b, device=dev.index or 0, stream=enc_stream.cuda_stream)
+        t_dev_md5 = time.perf_counter() - tm0
+    else:
+        enc_stream.synchronize()
+        t_enc = time.perf_counter() - t0
+    tot_h = totals.cpu().tolist()
     # the digests: the tracks' sample bytes on the host, eight tracks per pass
     t1 = time.perf_counter()
     digests = [bytes(16)] * ntracks
-    if want_md5:
+    if on_device:
+        digests, t_prep, t_md5 = dev_digests, 0.0, t_dev_md5
+    elif want_md5:
         cache = {}
         bufs = []
         for lo, hi in ranges:
@@ -217,14 +250,18 @@ def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_strea
         nsamp = min(hi * BLOCK, total_samples) - lo * BLOCK if hi > lo else 0
         f = fbs[lo:hi]
         header = stream_header(nsamp, int(f.min()) if f.size else 0, int(f.max()) if f.size else 0, digests[t])
-        streams.append((header, out[offs[t]:offs[t + 1]], f))
-    return streams, {"encode_seconds": t_enc, "md5_prepare_seconds": t_prep, "md5_seconds": t_md5}
+        streams.append((header, out[starts[t]:starts[t] + int(tot_h[t])], f))
+    return streams, {"encode_seconds": t_enc, "md5_prepare_seconds": t_prep, "md5_seconds": t_md5, "host_reads_of_totals": 1}
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--tracks", type=int, default=0, help="encode the corpus as this many separate streams (one file per track, each with its own STREAMINFO and MD5) on one GPU")
     ap.add_argument("--md5-threads", type=int, default=1, help="--tracks: host threads hashing the tracks (each eight chains wide)")
+    ap.add_argument("--md5", choices=("auto", "host", "device"), default="auto", help="--tracks: where the tracks' digests are computed -- device: one lane per track on the "
+                    "staged sample bytes in HBM (flacgpu_md5.hip); host: AVX2, eight chains per pass, --md5-threads threads; auto: the device from 256 tracks up "
+                    "(a chain is serial: 120 tracks are two wavefronts at ~30-50 MB/s per lane, 1.1-1.8 s for ten hours; 1000 tracks hash in 0.09 s -- "
+                    "profiles/r04_s_md5_device.txt)")
     ap.add_argument("--hours", type=float, default=10.0)
     ap.add_argument("--samples", type=int, default=0, help="corpus length in inter-channel samples (overrides --hours); a last short block is encoded as such")
     ap.add_argument("--batch-frames", type=int, default=16384)
@@ -296,8 +333,10 @@ def main(argv=None):
         enc_stream = torch.cuda.Stream()
         encode_tracks(eng, base, base_dev, min(F, 2 * args.tracks), min(total_samples, 2 * args.tracks * BLOCK), args.tracks, dev, enc_stream, want_md5=False)       # warm-up
         torch.cuda.synchronize()
+        if args.md5 == "auto":
+            args.md5 = "device" if args.tracks >= 256 else "host"
         t0 = time.perf_counter()
-        streams, tm = encode_tracks(eng, base, base_dev, F, total_samples, args.tracks, dev, enc_stream, want_md5=not args.no_md5, md5_threads=args.md5_threads)
+        streams, tm = encode_tracks(eng, base, base_dev, F, total_samples, args.tracks, dev, enc_stream, want_md5=not args.no_md5, md5_threads=args.md5_threads, md5_where=args.md5)
         t_job = time.perf_counter() - t0
         import ctypes as C
         host = flac_amd.engine.load_host()
@@ -318,7 +357,8 @@ def main(argv=None):
         line = {"job": "flac -%d batch encode of a %.2f h synthetic 44.1k/16-bit stereo corpus into %d streams (one per track)" % (args.level, total_samples / RATE / 3600, args.tracks),
                 "n_gpus": 1, "tracks": args.tracks, "frames": F, "samples": total_samples, "bytes": nbytes,
                 "encode_seconds": round(tm["encode_seconds"], 4), "Msamples_per_s_encode": round(total_samples / tm["encode_seconds"] / 1e6, 1),
-                "md5": "one digest per track, eight chains per pass (AVX2), %d host thread(s)" % args.md5_threads if not args.no_md5 else None,
+                "md5": None if args.no_md5 else "one digest per track, on the device: one lane per track over the staged sample bytes in HBM" if args.md5 == "device" else
+                       "one digest per track, eight chains per pass (AVX2), %d host thread(s)" % args.md5_threads,
                 "md5_seconds": round(tm["md5_seconds"], 3), "md5_prepare_seconds": round(tm["md5_prepare_seconds"], 3),
                 "md5_Msamples_per_s": round(total_samples / tm["md5_seconds"] / 1e6, 1) if tm["md5_seconds"] else None,
                 "job_seconds": round(t_job, 3), "tracks_with_a_bad_crc16": bad_tracks, "write_seconds": round(t_write, 3) if args.out else None,

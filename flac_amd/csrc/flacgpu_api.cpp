@@ -815,12 +815,46 @@ static int async_prepare(flacgpu_ctx *c)
 		ok = ok && hipEventCreateWithFlags(&a.ev_small, hipEventDisableTiming) == hipSuccess;
 		ok = ok && hipEventCreateWithFlags(&a.ev_pay, hipEventDisableTiming) == hipSuccess;
 	}
-	if(!ok) return FLACGPU_ERR_ALLOC;
+	if(!ok) {
+		// all or nothing: a later call starts from null fields again instead of creating streams and buffers over the ones of this attempt
+		for(int i = 0; i < FLACGPU_ASYNC_SLOTS; i++) {
+			flacgpu_ctx::AsyncSlot &a = c->as[i];
+			if(a.d_fb) (void)hipFree(a.d_fb);
+			if(a.d_total) (void)hipFree(a.d_total);
+			if(a.d_err) (void)hipFree(a.d_err);
+			if(a.d_vres) (void)hipFree(a.d_vres);
+			if(a.h) (void)hipHostFree(a.h);
+			if(a.h_fb) (void)hipHostFree(a.h_fb);
+			if(a.ev_in) (void)hipEventDestroy(a.ev_in);
+			if(a.ev_done) (void)hipEventDestroy(a.ev_done);
+			if(a.ev_small) (void)hipEventDestroy(a.ev_small);
+			if(a.ev_pay) (void)hipEventDestroy(a.ev_pay);
+			a.d_fb = nullptr; a.d_total = nullptr; a.d_err = nullptr; a.d_vres = nullptr; a.h = nullptr; a.h_fb = nullptr;
+			a.ev_in = a.ev_done = a.ev_small = a.ev_pay = nullptr;
+		}
+		if(c->s_in) (void)hipStreamDestroy(c->s_in);
+		if(c->s_small) (void)hipStreamDestroy(c->s_small);
+		if(c->s_pay) (void)hipStreamDestroy(c->s_pay);
+		c->s_in = c->s_small = c->s_pay = nullptr;
+		(void)hipGetLastError();
+		return FLACGPU_ERR_ALLOC;
+	}
 	c->async_ready = true;
 	return FLACGPU_OK;
 }
 extern "C" int flacgpu_in_flight(const flacgpu_ctx *c) { return c ? (int)(c->sub_seq - c->col_seq) : 0; }
 
+// a submission that fails half way: what it has already enqueued (copies from the caller's `raw`, kernels, the copy kernel into the
+// caller's `out`) is waited for before the error goes back, so that "an error: nothing of this batch is in flight" holds
+static int submit_drain(flacgpu_ctx *c, int code)
+{
+	if(c->s_in) (void)hipStreamSynchronize(c->s_in);
+	(void)hipStreamSynchronize(c->stream);
+	if(c->s_small) (void)hipStreamSynchronize(c->s_small);
+	if(c->s_pay) (void)hipStreamSynchronize(c->s_pay);
+	(void)hipGetLastError();
+	return code;
+}
 extern "C" int flacgpu_submit_batch_raw(flacgpu_ctx *c, const void *raw, const flacgpu_raw_format *fmt, uint32_t nframes,
                                         uint64_t first_frame_number, uint32_t last_block_samples, const float *tail_windows,
                                         uint8_t *out, size_t out_cap, uint32_t *frame_bytes)
@@ -855,27 +889,27 @@ extern "C" int flacgpu_submit_batch_raw(flacgpu_ctx *c, const void *raw, const f
 	}
 	hipStream_t s = c->stream;
 	// input: its own stream, so that it runs beside the kernels of the batches in front
-	if(hipMemcpyAsync(a.d_raw, raw, raw_bytes, hipMemcpyHostToDevice, c->s_in) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(hipEventRecord(a.ev_in, c->s_in) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipMemcpyAsync(a.d_raw, raw, raw_bytes, hipMemcpyHostToDevice, c->s_in) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
+	if(hipEventRecord(a.ev_in, c->s_in) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 	// kernels: the engine's stream, batch after batch
-	if(hipStreamWaitEvent(s, a.ev_in, 0) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(hipMemsetAsync(a.d_err, 0, sizeof(uint32_t), s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(launch_stage_raw(S, a.d_raw, (uint64_t)nsamp * P.channels, c->d_pcm, a.d_err, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipStreamWaitEvent(s, a.ev_in, 0) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
+	if(hipMemsetAsync(a.d_err, 0, sizeof(uint32_t), s) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
+	if(launch_stage_raw(S, a.d_raw, (uint64_t)nsamp * P.channels, c->d_pcm, a.d_err, s) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 	r = run_batch(c, c->d_pcm, nframes, first_frame_number, tail_n, tail_windows, a.d_out, a.d_out_bytes, a.d_fb, a.d_total, s);
-	if(r != FLACGPU_OK) return r;
+	if(r != FLACGPU_OK) return submit_drain(c, r);
 	if(c->verify_on) {
 		if(launch_verify(c->P, a.d_out, c->d_frame_bytes, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, c->d_vresult,
-		                 c->d_vhints, hints_for(c, a.d_out, nframes, first_frame_number), c->d_vfstat, c->ab.dbg, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-		if(hipMemcpyAsync(a.d_vres, c->d_vresult, sizeof(flacgpu_verify_result), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		                 c->d_vhints, hints_for(c, a.d_out, nframes, first_frame_number), c->d_vfstat, c->ab.dbg, s) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
+		if(hipMemcpyAsync(a.d_vres, c->d_vresult, sizeof(flacgpu_verify_result), hipMemcpyDeviceToDevice, s) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 	}
-	if(hipEventRecord(a.ev_done, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipEventRecord(a.ev_done, s) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 	// lengths, total, verdicts: back on a stream of their own (the payload follows from flacgpu_collect, once its size is known)
-	if(hipStreamWaitEvent(c->s_small, a.ev_done, 0) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(hipMemcpyAsync(a.h_fb, a.d_fb, nframes * sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(hipMemcpyAsync(&a.h->total, a.d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(hipMemcpyAsync(&a.h->err, a.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(c->verify_on && hipMemcpyAsync(&a.h->vres, a.d_vres, sizeof(flacgpu_verify_result), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(hipEventRecord(a.ev_small, c->s_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(hipStreamWaitEvent(c->s_small, a.ev_done, 0) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
+	if(hipMemcpyAsync(a.h_fb, a.d_fb, nframes * sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
+	if(hipMemcpyAsync(&a.h->total, a.d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
+	if(hipMemcpyAsync(&a.h->err, a.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
+	if(c->verify_on && hipMemcpyAsync(&a.h->vres, a.d_vres, sizeof(flacgpu_verify_result), hipMemcpyDeviceToHost, c->s_small) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
+	if(hipEventRecord(a.ev_small, c->s_small) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 	// the frames themselves: by the copy kernel when `out` is page-locked (hipHostMalloc / hipHostRegister) and 16-byte aligned,
 	// otherwise by a copy from flacgpu_collect once the total is known on the host
 	a.pay_by_kernel = false;
@@ -884,9 +918,9 @@ extern "C" int flacgpu_submit_batch_raw(flacgpu_ctx *c, const void *raw, const f
 		static int off = -1;
 		if(off < 0) off = getenv("FLACGPU_NO_COPY_KERNEL") ? 1 : 0;
 		if(!off && ((uintptr_t)out & 15u) == 0 && hipHostGetDevicePointer(&dptr, out, 0) == hipSuccess && dptr) {
-			if(hipStreamWaitEvent(c->s_pay, a.ev_done, 0) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			if(hipStreamWaitEvent(c->s_pay, a.ev_done, 0) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 			hipLaunchKernelGGL(payload_copy_kernel, dim3(256), dim3(256), 0, c->s_pay, a.d_out, a.d_total, (uint8_t *)dptr, (uint64_t)out_cap);
-			if(hipGetLastError() != hipSuccess || hipEventRecord(a.ev_pay, c->s_pay) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			if(hipGetLastError() != hipSuccess || hipEventRecord(a.ev_pay, c->s_pay) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 			a.pay_by_kernel = true;
 		}
 		else (void)hipGetLastError();
@@ -902,14 +936,17 @@ extern "C" int64_t flacgpu_collect(flacgpu_ctx *c)
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	flacgpu_ctx::AsyncSlot &a = c->as[c->col_seq % FLACGPU_ASYNC_SLOTS];
 	c->col_seq++;                                         // (whatever happens below, this batch is no longer in flight)
-	if(hipEventSynchronize(a.ev_small) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	// (the payload copy kernel may still be writing the caller's `out` while the small results are already here: whatever this call
+	//  returns, it returns only when nothing of the batch touches the caller's memory any more -- ADVICE r03)
+	const bool small_ok = hipEventSynchronize(a.ev_small) == hipSuccess;
+	const bool pay_ok = !a.pay_by_kernel || hipEventSynchronize(a.ev_pay) == hipSuccess;
+	if(!small_ok || !pay_ok) return FLACGPU_ERR_LAUNCH;
 	memset(&c->last_verify, 0, sizeof c->last_verify);
 	if(c->verify_on) c->last_verify = a.h->vres;
 	if(a.check_shift && a.h->err) return FLACGPU_ERR_INPUT;
 	memcpy(a.frame_bytes, a.h_fb, a.nframes * sizeof(uint32_t));
 	for(uint32_t i = 0; i < a.nframes; i++) if(a.h_fb[i] == 0xffffffffu) return FLACGPU_ERR_LAUNCH;
 	const uint64_t total = a.h->total;
-	if(a.pay_by_kernel) { if(hipEventSynchronize(a.ev_pay) != hipSuccess) return FLACGPU_ERR_LAUNCH; }
 	if(total > a.out_cap) return FLACGPU_ERR_OUTPUT_TOO_SMALL;
 	if(!a.pay_by_kernel) {
 		if(hipMemcpyAsync(a.out, a.d_out, total, hipMemcpyDeviceToHost, c->s_pay) != hipSuccess) return FLACGPU_ERR_LAUNCH;

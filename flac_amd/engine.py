@@ -207,6 +207,23 @@ def host_windows(settings, blocksize):
     return w
 
 
+def md5_many_device(d_base_ptr, offsets, lengths, device=0, stream=None):
+    """MD5 digests of len(offsets) byte ranges of device memory (flacgpu_md5_many_device: one lane per stream, for a corpus of many
+    streams whose sample bytes are staged in HBM anyway).  d_base_ptr: raw device address; returns a list of 16-byte digests."""
+    import numpy as np
+    lib = load_engine()
+    lib.flacgpu_md5_many_device.restype = C.c_int
+    lib.flacgpu_md5_many_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    n = len(offsets)
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lens = np.ascontiguousarray(lengths, dtype=np.uint64)
+    out = np.zeros((max(n, 1), 16), dtype=np.uint8)
+    r = lib.flacgpu_md5_many_device(device, d_base_ptr, offs.ctypes.data, lens.ctypes.data, n, out.ctypes.data, stream)
+    if r != 0:
+        raise FlacGpuError("flacgpu_md5_many_device: %s" % lib.flacgpu_strerror(r).decode())
+    return [out[i].tobytes() for i in range(n)]
+
+
 class FrameEngine:
     """One GPU frame engine for one stream configuration (flacgpu_create .. flacgpu_destroy)."""
 

@@ -143,6 +143,14 @@ typedef struct {
 int flacgpu_stage_raw_device(flacgpu_ctx *ctx, const void *d_raw, const flacgpu_raw_format *fmt, uint64_t wide_samples,
                              int32_t *d_pcm, uint32_t *d_error, void *stream);
 
+/* The MD5 digests of n byte ranges of DEVICE memory, d_base + offsets[i] .. + lengths[i] (any alignment, any length, zero
+ * included) -- the sample bytes of n streams as they lie staged in HBM: what FLAC__stream_encoder_finish() puts into each
+ * stream's STREAMINFO (the reference hashes them on the host as they pass, src/libFLAC/stream_encoder.c:3448, :3666-3686;
+ * src/libFLAC/md5.c:60-222 is the transform).  One lane per stream: worth it for a corpus of many streams, not for one.
+ * offsets, lengths: host arrays [n]; digests: host [n][16].  Synchronous on `stream` (may be NULL). */
+int flacgpu_md5_many_device(int device, const void *d_base, const uint64_t *offsets, const uint64_t *lengths, uint32_t n,
+                            uint8_t *digests, void *stream);
+
 /* flacgpu_encode_batch() from raw HOST sample bytes: copies the raw bytes (2 bytes per 16-bit sample instead of 4),
  * stages them on the device and encodes.  Returns FLACGPU_ERR_INPUT for a shift violation. */
 int64_t flacgpu_encode_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgpu_raw_format *fmt, uint32_t nframes,

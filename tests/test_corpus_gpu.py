@@ -48,10 +48,12 @@ def test_corpus_job_equals_the_reference_file(tmp_path):
     assert c == want
 
 
+@pytest.mark.parametrize("md5", ["device", "host"])
 @pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref/libFLAC_ref.so not built on this box")
-def test_corpus_as_tracks_equals_the_reference_files(tmp_path):
+def test_corpus_as_tracks_equals_the_reference_files(tmp_path, md5):
     """--tracks: the corpus as separate streams, frame numbers restarting per track, a STREAMINFO and an MD5 per track (the digests
-    eight chains at a time): every track file is the reference's file for that track's samples"""
+    on the device, one lane per track over the staged sample bytes, or on the host, eight chains at a time): every track file is
+    the reference's file for that track's samples"""
     from flac_amd import corpus as co
     samples = 60 * 44100 + 777
     ntracks = 11                                       # 646 frames in 11 tracks: 59 / 58 frames each, the last one with the short block
@@ -60,7 +62,7 @@ def test_corpus_as_tracks_equals_the_reference_files(tmp_path):
     pcm = co.host_frames(base, 0, nfr)[:samples].astype(np.int32)
     out = str(tmp_path / "shelf")
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, "-m", "flac_amd.corpus", "--out", out, "--samples", str(samples), "--tracks", str(ntracks), "--md5-threads", "2"],
+    r = subprocess.run([sys.executable, "-m", "flac_amd.corpus", "--out", out, "--samples", str(samples), "--tracks", str(ntracks), "--md5-threads", "2", "--md5", md5],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
