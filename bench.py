@@ -35,8 +35,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 RATE, BPS, CH = 44100, 16, 2
 FRAMES_PER_GPU = 16384         # 67.1 M inter-channel samples = 25 min of audio per GPU per step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-KERNEL_NAMES = {"prep": "prep3_kernel", "autoc": "autoc2_kernel", "model": "model_kernel", "eval": "evalg_kernel+evalw_kernel+eval_list_kernel",
-                "pack": "pack2_kernel", "scan_compact": "scan_kernel+compact_kernel"}
+# which kernels a phase of flacgpu_batch_phase_ms covers (the ones a workload does not launch are not in its counter pass)
+KERNEL_NAMES = {"prep": "ff_kernel+prep3_kernel+prep2_kernel+prep_kernel", "autoc": "autoc2_kernel+autoc_kernel", "model": "model_kernel",
+                "eval": "evalg_kernel+evalw_kernel+eval_list_kernel+eval_kernel", "pack": "pack2_kernel+fo_place_kernel+pack_kernel", "scan_compact": "scan_kernel+compact_kernel"}
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md: 2.4 GHz peak engine clock.  A SIMD issues one wave64 VALU instruction per 4 cycles
 VALU_ISSUE_PEAK = SIMDS * CLOCK_GHZ / 4      # G wavefront-instructions per second, the whole chip
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
@@ -44,6 +45,30 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per 
 
 def block_of(level):
     return 1152 if level < 3 else 4096
+
+
+def pmc_workload(level, kind, hires):
+    """the committed counter pass of a workload (profiles/pmc_traffic.json <- scripts/pmc_to_traffic.py), and whether a kernel source was
+    edited since it was taken (git blob hashes recorded next to the counters)"""
+    key = "hires8" if hires and level == 8 else "white8" if kind == "white" and level == 8 else "level%d" % level if kind == "music" and not hires else None
+    try:
+        with open(PMC_FILE) as fh:
+            pmc = json.load(fh)
+    except Exception:
+        return None, None, None
+    w = (pmc.get("workloads") or {}).get(key)
+    if not w:
+        return None, None, None
+    import hashlib
+    stale = []
+    for rel, h in (pmc.get("source_hashes") or {}).items():
+        try:
+            data = open(os.path.join(ROOT, rel), "rb").read()
+            if hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest() != h:
+                stale.append(rel)
+        except OSError:
+            stale.append(rel)
+    return w, key, stale
 
 
 def synth_pcm(nframes, seed, block, kind="music"):
@@ -426,27 +451,25 @@ def main():
             achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
             traffic = valu_busy = traffic_step = None
             valu = {}
-            try:
-                with open(PMC_FILE) as fh:
-                    pmc = json.load(fh)
-                if level == 8 and not args.hires and kind == "music" and pmc.get("blocksize", 4096) == block:
-                    # (the committed counter passes are of this workload; other workloads report no counter-derived figures)
-                    for name in KERNEL_NAMES[dom].split("+"):
-                        if name in pmc["kernels"]:
-                            traffic = (traffic or 0) + int(pmc["kernels"][name]["hbm_bytes_per_frame"] * nframes)
-                            valu_busy = max(valu_busy or 0.0, pmc["kernels"][name].get("valu_busy_frac", 0.0))
-                    traffic_step = int(sum(v["hbm_bytes_per_frame"] for k, v in pmc["kernels"].items() if any(k in names.split("+") for names in KERNEL_NAMES.values())) * nframes)
-                    for ph, names in KERNEL_NAMES.items():
-                        ips = sum(pmc["kernels"][nm].get("valu_wave_insts_per_sample", 0.0) for nm in names.split("+") if nm in pmc["kernels"])
-                        if ips and kms.get(ph):
-                            ach = ips * samples_per_step / (kms[ph] * 1e-3) / 1e9
-                            valu[ph] = {"kernel": names, "wave_insts_per_sample": round(ips, 4), "ms": round(kms[ph], 4), "achieved_Ginst_per_s": round(ach, 1),
-                                        "frac_of_issue_peak": round(ach / VALU_ISSUE_PEAK, 4)}
-            except Exception:
-                pass
+            pw, pkey, pstale = pmc_workload(level, kind, args.hires)
+            if pw and pw.get("blocksize") == block and not any(search.values()):
+                # counter-derived figures: the committed pass of THIS workload (bytes and instructions per frame scale with the batch)
+                K = pw["kernels"]
+                for name in KERNEL_NAMES[dom].split("+"):
+                    if name in K:
+                        traffic = (traffic or 0) + int(K[name]["hbm_bytes_per_frame"] * nframes)
+                        valu_busy = max(valu_busy or 0.0, K[name].get("valu_busy_frac", 0.0))
+                step_kernels = set(n for names in KERNEL_NAMES.values() for n in names.split("+"))
+                traffic_step = int(sum(v["hbm_bytes_per_frame"] for k, v in K.items() if k in step_kernels) * nframes)
+                for ph, names in KERNEL_NAMES.items():
+                    ips = sum(K[nm].get("valu_wave_insts_per_sample", 0.0) for nm in names.split("+") if nm in K)
+                    if ips and kms.get(ph):
+                        ach = ips * samples_per_step / (kms[ph] * 1e-3) / 1e9
+                        valu[ph] = {"kernel": "+".join(nm for nm in names.split("+") if nm in K), "wave_insts_per_sample": round(ips, 4), "ms": round(kms[ph], 4),
+                                    "achieved_Ginst_per_s": round(ach, 1), "frac_of_issue_peak": round(ach / VALU_ISSUE_PEAK, 4)}
             res.update(value=world * samples_per_step * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=kms, out_bps=out_bps,
-                       roofline={"bound": "hbm", "kernel": KERNEL_NAMES[dom] if not (dom == "prep" and level < 4) else
-                                 ("ff_kernel (prep2_kernel, eval_list_kernel and pack2_kernel take what it leaves)" if level < 3 else "prep2_kernel"), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       roofline={"bound": "hbm", "kernel": ("+".join(nm for nm in KERNEL_NAMES[dom].split("+") if pw and nm in pw["kernels"]) or KERNEL_NAMES[dom]),
+                                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
                                  "whole_step_frac": round(alg_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 6),
                                  # every kernel of the step, not only the dominant one: HBM-side bytes of the committed counter pass and
@@ -454,7 +477,9 @@ def main():
                                  "traffic_whole_step": traffic_step,
                                  "traffic_whole_step_over_algorithmic": round(traffic_step / alg_bytes, 3) if traffic_step else None,
                                  # what actually bounds this kernel: the share of its cycles in which it issues VALU work (committed PMC pass)
-                                 "valu_busy_frac_of_committed_pmc_pass": valu_busy})
+                                 "valu_busy_frac_of_committed_pmc_pass": valu_busy,
+                                 # which counter pass, and the kernel sources edited since it was taken (none: the counters are this tree's)
+                                 "pmc_workload": pkey, "stale": bool(pstale) if pkey else None, "stale_sources": pstale if pstale else None})
             if valu:
                 tot_i = sum(v["wave_insts_per_sample"] for v in valu.values())
                 res["roofline_valu"] = {"bound": "valu issue", "peak": VALU_ISSUE_PEAK, "unit": "G wavefront-instructions/s",
@@ -493,7 +518,7 @@ def main():
                                  ("hires", hr, "flac -8 on 96 kHz / 24-bit stereo (BASELINE.json config 4: the wide-sample residual path), 4096-sample blocks")):
                 extras[key] = {"what": what, "value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"],
                                "compressed_bytes_per_sample": round(r["out_bps"], 4), "kernel_ms": {k: round(v, 4) for k, v in r["kernel_ms"].items()},
-                               "roofline": r["roofline"], "verified_frames": r.get("verified", {}).get("frames_compared_with_oracle"),
+                               "roofline": r["roofline"], "roofline_valu": r.get("roofline_valu"), "verified_frames": r.get("verified", {}).get("frames_compared_with_oracle"),
                                "verified_ok": r.get("verified", {}).get("ok")}
 
     if rank == 0:

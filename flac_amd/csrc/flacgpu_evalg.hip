@@ -57,12 +57,14 @@ __device__ __forceinline__ uint32_t sad_u32_s(uint32_t a, uint32_t b_uniform, ui
 	return d;
 }
 // FIRST: the piece that opens the block -- lane 0's first `order` samples are warm-up, not residual
-template <int NPF, bool FIRST>
+// NV: samples of the piece that belong to the lane's run (16; 8 for the half piece that ends a run of 16 k + 8 samples: blocks of
+// 4608 samples)
+template <int NPF, bool FIRST, int NV = 16>
 __device__ __forceinline__ uint32_t fir16_folded(const uint32_t (&AA)[15], const uint32_t (&BB)[14], const uint32_t (&Q)[7], uint32_t shift, uint32_t bias, uint32_t order,
                                                  bool lane0, uint32_t sum0, uint32_t acc)
 {
 #pragma unroll
-	for(int s = 0; s < 16; s++) {
+	for(int s = 0; s < NV; s++) {
 		uint32_t W[NPF];
 #pragma unroll
 		for(int p = 0; p < NPF; p++) W[p] = (s & 1) ? AA[(s + 13) / 2 - p] : BB[s / 2 + 6 - p];
@@ -72,18 +74,18 @@ __device__ __forceinline__ uint32_t fir16_folded(const uint32_t (&AA)[15], const
 	}
 	return acc;
 }
-template <bool FIRST>
+template <bool FIRST, int NV = 16>
 __device__ __forceinline__ uint32_t fir16_dispatch(uint32_t npf, const uint32_t (&AA)[15], const uint32_t (&BB)[14], const uint32_t (&Q)[7], uint32_t shift, uint32_t bias,
                                                    uint32_t order, bool lane0, uint32_t sum0, uint32_t acc)
 {
 	switch(npf) {
-	case 1: return fir16_folded<1, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 2: return fir16_folded<2, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 3: return fir16_folded<3, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 4: return fir16_folded<4, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 5: return fir16_folded<5, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 6: return fir16_folded<6, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	default: return fir16_folded<7, FIRST>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 1: return fir16_folded<1, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 2: return fir16_folded<2, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 3: return fir16_folded<3, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 4: return fir16_folded<4, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 5: return fir16_folded<5, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	case 6: return fir16_folded<6, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	default: return fir16_folded<7, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
 	}
 }
 // base: byte address of word (first sample of the piece - 14 samples) in the lane's column; rows at immediate offsets
@@ -113,7 +115,7 @@ struct EgSlot { uint32_t Q[7]; uint32_t shift, bias, order, npf, precision, ci; 
 // WPC wavefronts share a channel's image and split its candidates between them (each has its own search state; the better of their
 // first minima wins): an experiment in occupancy (the LDS image allows four one-wavefront channels per SIMD), opt-in, see launch_evalg.
 template <int MAXORD>
-__host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N, uint32_t wpc = 1) { return (N / 128) * EG_ROW + wpc * eg_tail_bytes<MAXORD>() + 64; }
+__host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N, uint32_t wpc = 1) { return (N / 128) * EG_ROW + wpc * eg_tail_bytes<MAXORD>() + 64 + 128; }      // (+128: the half piece of a 16 k + 8 run loads four rows behind the image)
 constexpr int EG_PIECES_AHEAD = 8;        // 16-byte pieces of the planar channel a lane has in flight before its first use (8 = a 4096-sample block at WPC 1)
 
 // returns false when the channel is not this kernel's (the caller lists it)
@@ -219,7 +221,7 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	(void)img_bytes;
 	const unsigned char *own = smem + ((uint32_t)lane + 1) * 4;                      // word 0 of this lane's run
 	const unsigned char *hist = smem + (uint32_t)lane * 4 + (rows - 7) * EG_ROW;     // 7 words in front of it: the previous column's last
-	const uint32_t npieces = S / 16;
+	const uint32_t npieces = S / 16;                                                   // whole 16-sample pieces of a run; S % 16 == 8: a half piece behind them
 	const uint32_t sum0 = 0x80000000u;
 	if(WPC > 1) {
 		__syncthreads();                                                          // the image is whole
@@ -262,6 +264,13 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 			load_piece(own + (8 * c - 7) * EG_ROW, AA, BB);
 			v0 = fir16_dispatch<false>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
 			if(two) v1 = fir16_dispatch<false>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+		}
+		if(S & 8u) {
+			// the half piece that ends the run (the words it loads behind the run are never used)
+			uint32_t AA[15], BB[14];
+			load_piece(own + (8 * npieces - 7) * EG_ROW, AA, BB);
+			v0 = fir16_dispatch<false, 8>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+			if(two) v1 = fir16_dispatch<false, 8>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
 		}
 		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_list_kernel's (nothing was written yet)
 		if(__any((int)((v0 | v1) >= (1u << 23)))) { if(WPC == 1) return false; leave = true; break; }
@@ -308,7 +317,7 @@ bool evalg_applicable(const DevParams &P)
 	static int off = -1;
 	if(off < 0) off = getenv("FLACGPU_NO_EVALG") ? 1 : 0;
 	const uint32_t S = P.blocksize / 64;
-	return !off && P.blocksize % 64 == 0 && S >= 16 && S % 16 == 0 && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC && P.blocksize <= 16384;
+	return !off && P.blocksize % 64 == 0 && S >= 16 && S % 8 == 0 && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC && P.blocksize <= 16384;
 }
 template <int MAXORD, int WPC>
 static hipError_t launch_evalg_t(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)

@@ -97,13 +97,14 @@ __device__ __forceinline__ uint32_t sad_u32_vs(uint32_t a, uint32_t b_uniform, u
 struct EwSlot { uint32_t q[12]; uint32_t shift, bias, negpow, order, nt, wide, precision, ci; };
 
 // the |residual| sum of one candidate over one 16-sample piece of every lane's run
-template <int NT, bool WIDE, bool FIRST>
+// NV: samples of the piece that belong to the lane's run (16; 8 for the half piece that ends a run of 16 k + 8 samples)
+template <int NT, bool WIDE, bool FIRST, int NV = 16>
 __device__ __forceinline__ uint32_t fir16_w(const int32_t (&x)[28], const uint32_t (&xm)[16], const EwSlot &C, bool lane0, uint32_t sum0)
 {
 	uint32_t acc = 0;
 	const uint64_t init64 = (uint64_t)0x80000000u << C.shift;
 #pragma unroll
-	for(int s = 0; s < 16; s++) {
+	for(int s = 0; s < NV; s++) {
 		if constexpr(!WIDE) {
 			uint32_t pb = mad24_chain_s<NT>(&x[12 + s], C.q, C.negpow, sum0, C.shift);
 			if(FIRST && s < NT) { if(lane0 && (uint32_t)s < C.order) pb = C.bias; }
@@ -120,19 +121,19 @@ __device__ __forceinline__ uint32_t fir16_w(const int32_t (&x)[28], const uint32
 	}
 	return acc;
 }
-template <bool FIRST>
+template <bool FIRST, int NV = 16>
 __device__ __forceinline__ uint32_t fir16_w_dispatch(const int32_t (&x)[28], const uint32_t (&xm)[16], const EwSlot &C, bool lane0, uint32_t sum0)
 {
 	if(C.wide) {
-		if(C.nt == 4) return fir16_w<4, true, FIRST>(x, xm, C, lane0, sum0);
-		if(C.nt == 8) return fir16_w<8, true, FIRST>(x, xm, C, lane0, sum0);
-		if(C.nt == 10) return fir16_w<10, true, FIRST>(x, xm, C, lane0, sum0);
-		return fir16_w<12, true, FIRST>(x, xm, C, lane0, sum0);
+		if(C.nt == 4) return fir16_w<4, true, FIRST, NV>(x, xm, C, lane0, sum0);
+		if(C.nt == 8) return fir16_w<8, true, FIRST, NV>(x, xm, C, lane0, sum0);
+		if(C.nt == 10) return fir16_w<10, true, FIRST, NV>(x, xm, C, lane0, sum0);
+		return fir16_w<12, true, FIRST, NV>(x, xm, C, lane0, sum0);
 	}
-	if(C.nt == 4) return fir16_w<4, false, FIRST>(x, xm, C, lane0, sum0);
-	if(C.nt == 8) return fir16_w<8, false, FIRST>(x, xm, C, lane0, sum0);
-	if(C.nt == 10) return fir16_w<10, false, FIRST>(x, xm, C, lane0, sum0);      // (96 kHz / 24-bit music at -8: three in five winners have order 10)
-	return fir16_w<12, false, FIRST>(x, xm, C, lane0, sum0);
+	if(C.nt == 4) return fir16_w<4, false, FIRST, NV>(x, xm, C, lane0, sum0);
+	if(C.nt == 8) return fir16_w<8, false, FIRST, NV>(x, xm, C, lane0, sum0);
+	if(C.nt == 10) return fir16_w<10, false, FIRST, NV>(x, xm, C, lane0, sum0);      // (96 kHz / 24-bit music at -8: three in five winners have order 10)
+	return fir16_w<12, false, FIRST, NV>(x, xm, C, lane0, sum0);
 }
 
 // LDS of a channel: [image (S rows of 65 words)][per wavefront: prefix sums | divisor table | best parameters (flacgpu_evalg.h)][merge]
@@ -293,6 +294,18 @@ __device__ __forceinline__ bool evalw_body(const DevParams &P, const int32_t *__
 			for(int k = 0; k < 16; k++) xm[k] = (uint32_t)x[12 + k] ^ 0x80000000u;
 			s0 += fir16_w_dispatch<false>(x, xm, A, false, sum0);
 			if(two) s1 += fir16_w_dispatch<false>(x, xm, B, false, sum0);
+		}
+		if(S & 8u) {
+			// the half piece that ends a run of 16 k + 8 samples (blocks of 4608): its eight samples and the twelve in front of them
+			int32_t x[28];
+			uint32_t xm[16];
+			const unsigned char *b = own + (16 * npieces - 12) * EG_ROW;
+#pragma unroll
+			for(int k = 0; k < 28; k++) x[k] = k < 20 ? *(const int32_t *)(b + k * EG_ROW) : 0;
+#pragma unroll
+			for(int k = 0; k < 16; k++) xm[k] = (uint32_t)x[12 + k] ^ 0x80000000u;
+			s0 += fir16_w_dispatch<false, 8>(x, xm, A, false, sum0);
+			if(two) s1 += fir16_w_dispatch<false, 8>(x, xm, B, false, sum0);
 		}
 		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_list_kernel's (nothing was written yet)
 		if(__any((int)((s0 | s1) >= (1ull << 23)))) { if(WPC == 1) return false; leave = true; break; }

@@ -1078,7 +1078,8 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 	/* the GPU engine; features it does not implement are refused, never approximated */
 	{
 		/* Blocks per GPU batch: FLACGPU_BATCH_FRAMES, or what a budget of staged sample bytes per slot buys (FLACGPU_BATCH_BYTES,
-		 * default 16 MiB: 1024 blocks of 16-bit stereo at 4096 samples, 7 of 8 x 32-bit x 65535) -- two page-locked input slots of
+		 * default 16 MiB -- 64 MiB for a stream that announces at least a GiB of samples --: 1024 blocks of 16-bit stereo at 4096 samples,
+		 * 7 of 8 x 32-bit x 65535) -- page-locked input slots of
 		 * that size and two output slots exist per encoder -- and never more than the stream is said to hold.  Measured on one
 		 * 16-bit stereo stream: page-locking and releasing the slots costs more than bigger batches win back on the GPU, which is
 		 * an order of magnitude ahead of the host either way (64 MiB: 0.88 G samples/s, 16 MiB: 1.37 G).  No frame is delivered
@@ -1088,8 +1089,12 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 		if(env) bf = strtol(env, 0, 10);
 		else {
 			const char *eb = getenv("FLACGPU_BATCH_BYTES");
-			const double budget = eb ? strtod(eb, 0) : 16.0 * 1024 * 1024;
 			const double per_block = (double)s->blocksize * s->channels * ((s->bits_per_sample + 7) / 8);
+			/* a stream that says it is long (total_samples_estimate: the reference's tool always says) gets 64 MiB slots: the kernels reach
+			 * their large-batch rate there (profiles/r03_api_batch.txt: 16 / 32 / 64 / 128 MiB = 6.7 / 8.1 / 8.5 / 7.7 G samples/s), and
+			 * four slots' worth of page-locking is paid once in sixteen batches or more */
+			const int is_long = s->total_samples_estimate && (double)s->total_samples_estimate * s->channels * ((s->bits_per_sample + 7) / 8) >= 16.0 * 64.0 * 1024 * 1024;
+			const double budget = eb ? strtod(eb, 0) : (is_long ? 64.0 : 16.0) * 1024 * 1024;
 			bf = (long)(budget / per_block);
 			if(bf > 16384) bf = 16384;
 			if(bf < 4) bf = 4;
