@@ -106,6 +106,18 @@ def test_batches_and_frame_numbers():
         assert data == po.oracle_encode(pcm[:4096 * 4], 16, 44100, 5, first_frame=first)["data"]
 
 
+@pytest.mark.parametrize("level", [0, 1, 2, 8])
+def test_frame_numbers_of_the_one_kernel_path_and_the_fused_output(level):
+    """ff_kernel (-0 .. -2) and pack2_kernel with the fused output (-8) write their own frame headers: every UTF-8 length class of the
+    frame number, each crossed inside the batch (only the -5 path had this test), with a short last block behind"""
+    bs = 1152 if level < 3 else 4096
+    pcm = signals.music(bs * 5 + 77, 2, 16, seed=31 + level)
+    for first in (0x7E, 0x7FE, 0xFFFE, 0x1FFFFE, 0x3FFFFFE, 0x7FFFFFFA):
+        data, fb = _gpu_encode(pcm, 16, 44100, level, first_frame=first)
+        o = po.oracle_encode(pcm, 16, 44100, level, first_frame=first)
+        assert data == o["data"] and np.array_equal(fb, o["frame_bytes"]), (level, hex(first))
+
+
 def test_limit_min_bitrate_and_channel_counts():
     for level in (0, 2, 5, 8):
         for pcm in (signals.silence(4096 * 3, 2, 16), signals.mixed(4096 * 6, 2, 16), signals.silence(4096 * 2, 1, 16)):
