@@ -1848,50 +1848,37 @@ __global__ __launch_bounds__(TPB) void append_tail_kernel(const uint8_t *__restr
 // ---------------------------------------------------------------------------------------------
 // scan + compaction
 // ---------------------------------------------------------------------------------------------
-// Exclusive prefix sum of the frame lengths, one workgroup: a thread sums a run of consecutive frames (16-byte loads), the
-// runs are scanned across the workgroup once, and the thread writes its frames' offsets.  (Batches of more than 64 Ki frames
-// take more than one round.)
-constexpr int SCAN_T = 1024, SCAN_PER = 16;
+// Exclusive prefix sum of the frame lengths.  A workgroup of 1024 threads takes a CHUNK of 1024 frames (one per thread), and the
+// chunks do not wait for each other: a chunk first adds up, on its own, everything in front of it (a batch of 16384 frames is 16
+// chunks: fifteen loads per thread at most, all in flight at once), then scans its own lengths and writes its offsets.  Round 3's
+// version was ONE workgroup walking the batch 16 lengths a thread: 12 us of latency in front of the compaction of a -0 step that
+// takes 150; this one is 4-5.  (The redundant sums grow with the square of the batch: 65536 frames are 64 chunks, 63 loads per
+// thread in the last one -- still microseconds.)
+constexpr int SCAN_T = 1024;
 __global__ __launch_bounds__(SCAN_T) void scan_kernel(const uint32_t *__restrict__ frame_bytes, uint32_t nframes,
                                                     uint64_t *__restrict__ offsets, uint64_t *__restrict__ total)
 {
-	__shared__ uint64_t wave_tot[SCAN_T / 64];
-	__shared__ uint64_t carry;
-	const int tid = (int)threadIdx.x;
-	if(tid == 0) carry = 0;
-	__syncthreads();
-	for(uint32_t base = 0; base < nframes; base += SCAN_T * SCAN_PER) {
-		const uint32_t i0 = base + (uint32_t)tid * SCAN_PER;
-		uint32_t v[SCAN_PER];
-		if(i0 + SCAN_PER <= nframes && ((uintptr_t)frame_bytes & 15) == 0) {
+	__shared__ uint64_t wave_front[SCAN_T / 64], wave_own[SCAN_T / 64];
+	const int tid = (int)threadIdx.x, wave = tid >> 6;
+	const uint32_t c0 = blockIdx.x * SCAN_T, i = c0 + (uint32_t)tid;
+	// this thread's share of everything in front of the chunk (an overflowing frame's 0xffffffff counts as nothing, as in the compaction)
+	uint64_t front = 0;
+	for(uint32_t g = (uint32_t)tid; g < c0; g += SCAN_T) { const uint32_t v = frame_bytes[g]; front += v == 0xffffffffu ? 0u : v; }
+	uint32_t mine = i < nframes ? frame_bytes[i] : 0u;
+	if(mine == 0xffffffffu) mine = 0;
+	front = wave_reduce_add_u64(front);
+	uint64_t incl = mine;
 #pragma unroll
-			for(int k = 0; k < SCAN_PER / 4; k++) { const uint4 q = ((const uint4 *)(frame_bytes + i0))[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
-		}
-		else {
-#pragma unroll
-			for(int k = 0; k < SCAN_PER; k++) v[k] = i0 + (uint32_t)k < nframes ? frame_bytes[i0 + k] : 0u;
-		}
-		uint64_t run = 0;
-#pragma unroll
-		for(int k = 0; k < SCAN_PER; k++) { if(v[k] == 0xffffffffu) v[k] = 0; run += v[k]; }
-		uint64_t incl = run;
-#pragma unroll
-		for(int off = 1; off < 64; off <<= 1) {
-			uint32_t lo = __shfl_up((uint32_t)incl, off), hi = __shfl_up((uint32_t)(incl >> 32), off);
-			if((tid & 63) >= off) incl += ((uint64_t)hi << 32) | lo;
-		}
-		if((tid & 63) == 63) wave_tot[tid >> 6] = incl;
-		__syncthreads();
-		uint64_t woff = 0, tot = 0;
-		for(int w = 0; w < SCAN_T / 64; w++) { if(w < (tid >> 6)) woff += wave_tot[w]; tot += wave_tot[w]; }
-		uint64_t o = carry + woff + incl - run;
-#pragma unroll
-		for(int k = 0; k < SCAN_PER; k++) { if(i0 + (uint32_t)k < nframes) offsets[i0 + k] = o; o += v[k]; }
-		__syncthreads();
-		if(tid == 0) carry += tot;
-		__syncthreads();
+	for(int off = 1; off < 64; off <<= 1) {
+		const uint32_t lo = __shfl_up((uint32_t)incl, off), hi = __shfl_up((uint32_t)(incl >> 32), off);
+		if((tid & 63) >= off) incl += ((uint64_t)hi << 32) | lo;
 	}
-	if(tid == 0) { offsets[nframes] = carry; *total = carry; }
+	if((tid & 63) == 63) { wave_front[wave] = front; wave_own[wave] = incl; }
+	__syncthreads();
+	uint64_t o = incl - mine;
+	for(int w = 0; w < SCAN_T / 64; w++) { o += wave_front[w]; if(w < wave) o += wave_own[w]; }
+	if(i < nframes) offsets[i] = o;
+	if(i + 1 == nframes) { offsets[nframes] = o + mine; *total = o + mine; }
 }
 
 __global__ __launch_bounds__(TPB) void compact_kernel(const uint8_t *__restrict__ slots, uint32_t slot_bytes,
@@ -2145,7 +2132,8 @@ hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uin
 }
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)
 {
-	hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_T), 0, s, fb, nframes, offsets, total);
+	if(nframes == 0) return hipSuccess;
+	hipLaunchKernelGGL(scan_kernel, dim3((nframes + SCAN_T - 1) / SCAN_T), dim3(SCAN_T), 0, s, fb, nframes, offsets, total);
 	return hipGetLastError();
 }
 hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,
