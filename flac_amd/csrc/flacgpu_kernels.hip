@@ -291,6 +291,16 @@ __device__ __forceinline__ uint32_t byte_times2(uint32_t v, uint32_t one)       
 // goes into the instruction's offset field; img[-SPANW .. -1] must be readable zeros.  Ends with a barrier.
 typedef __attribute__((address_space(3))) const uint16_t *lds_u16p;
 __device__ __forceinline__ bool lds_base_is_zero(const unsigned char *smem) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)smem == 0u; }
+// a * b modulo P for frame_crc16_end: the 31-bit carry-less product by Horner (a bit of b as a mask, one and-xor), then its high
+// half folded back through the CRC tables at LDS address 0 (tab[0][v] = v x^16, tab[1][v] = v x^24 mod P): 3 instructions a bit
+// and 6 for the fold, where the shift-and-reduce loop of gf16_mul takes 6 a bit
+__device__ __forceinline__ uint32_t gf16_mul_tab(uint32_t a, uint32_t b, uint32_t one)
+{
+	uint32_t p = 0;
+#pragma unroll
+	for(int i = 15; i >= 0; i--) p = (p << 1) ^ (a & (uint32_t)__builtin_amdgcn_sbfe((int)b, i, 1));
+	return (p & 0xffffu) ^ *(lds_u16p)(uintptr_t)byte_times2<2>(p, one) ^ *(lds_u16p)(uintptr_t)(byte_times2<3>(p, one) + 512);
+}
 template <int NT, int SPANW>
 __device__ __forceinline__ uint32_t frame_crc16_end(const uint32_t *img, uint32_t body_bytes, uint32_t *crc_parts, int tid,
                                                     const uint16_t *xspan_lds, uint32_t nxspan_lds, const uint16_t *xspan_global)
@@ -314,7 +324,7 @@ __device__ __forceinline__ uint32_t frame_crc16_end(const uint32_t *img, uint32_
 		}
 		const uint32_t m = nsp - 1 - sp;                                     // whole spans behind this one
 		const uint32_t xs = m < nxspan_lds ? xspan_lds[m] : xspan_global[m];
-		c ^= m ? gf16_mul(cs, xs) : cs;
+		c ^= gf16_mul_tab(cs, xs, one);                                        // (the last span's factor is x^0 = 1)
 	}
 #pragma unroll
 	for(int off = 32; off >= 1; off >>= 1) c ^= __shfl_xor(c, off);
@@ -325,7 +335,7 @@ __device__ __forceinline__ uint32_t frame_crc16_end(const uint32_t *img, uint32_
 		for(int wv = 0; wv < NT / 64; wv++) c ^= crc_parts[wv];
 	}
 	else __syncthreads();
-	return z == 0 ? c : gf16_mul(c, z == 1 ? CRC_XINV8 : z == 2 ? CRC_XINV16 : CRC_XINV24);
+	return gf16_mul_tab(c, z == 0 ? 1u : z == 1 ? CRC_XINV8 : z == 2 ? CRC_XINV16 : CRC_XINV24, one);
 }
 
 // number of frame header bytes including the CRC-8, without building them (same cases as frame_header_bytes)
