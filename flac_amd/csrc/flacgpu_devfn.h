@@ -627,10 +627,14 @@ __device__ __forceinline__ void rice_node_small(uint32_t sum, uint32_t ns, uint3
 // right there (all lanes of a group redundantly -- redundancy is free in SIMD) and the per-order bit totals ride along
 // through the remaining stages, so that at the end every lane holds every order's total.  No prefix sums, no
 // gathers; DPP adds for the first four stages.  Requires every lane sum < 2^23 (32-bit arithmetic exact).
-__device__ __forceinline__ uint32_t rice_search_nodes(uint32_t v, uint32_t e, uint32_t n, uint32_t order, uint32_t max_po, uint32_t min_po,
+// CE / CD: e and D when they are known at compile time (-1: not) -- the levels outside [e, e + D] and the butterflies that would carry
+// their (zero) totals along then vanish from the code
+template <int CE = -1, int CD = -1>
+__device__ __forceinline__ uint32_t rice_search_nodes(uint32_t v, uint32_t e_rt, uint32_t n, uint32_t order, uint32_t max_po, uint32_t min_po,
                                                       uint32_t rice_limit, const uint32_t *divtab, uint8_t *kout, uint32_t *best_po_out, int lane)
 {
-	const uint32_t D = max_po - min_po;                     // number of lower orders searched
+	const uint32_t e = CE >= 0 ? (uint32_t)CE : e_rt;
+	const uint32_t D = CD >= 0 ? (uint32_t)CD : max_po - min_po;                     // number of lower orders searched
 	const uint32_t rl1 = rice_limit - 1;
 	uint32_t tm[7], km[7];
 #pragma unroll
@@ -654,6 +658,7 @@ __device__ __forceinline__ uint32_t rice_search_nodes(uint32_t v, uint32_t e, ui
 			if(m == 5) { v = bfly_add<5>(v); }
 #pragma unroll
 			for(int j = 0; j <= m; j++) {
+				if(CE >= 0 && (j < CE || j > CE + CD)) continue;       // (a level that is not searched has no total to carry)
 				if(m == 0) tm[j] = bfly_add<0>(tm[j]);
 				if(m == 1) tm[j] = bfly_add<1>(tm[j]);
 				if(m == 2) tm[j] = bfly_add<2>(tm[j]);

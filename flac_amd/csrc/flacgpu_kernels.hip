@@ -1382,7 +1382,8 @@ __device__ __noinline__ uint64_t ff_rice_search_wide(uint32_t v, uint32_t n, uin
 	return ((uint64_t)best_po << 32) | best_bits;
 }
 
-// statistics and decision of one candidate channel
+// statistics and decision of one candidate channel (CPO: the partition order range when it is the presets' 0..3, else -1)
+template <int CPO>
 __device__ __forceinline__ void ff_decide(const DevParams &P, uint32_t which, const int32_t (&x)[FF_RUN + 4], bool disable_constant, FFShared *sh, uint32_t *leaf, int lane, FFDec &D, uint32_t &alleq)
 {
 	constexpr uint32_t n = FF_N;
@@ -1447,6 +1448,7 @@ __device__ __forceinline__ void ff_decide(const DevParams &P, uint32_t which, co
 			const uint64_t r = ff_rice_search_wide(v, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, leaf, sh->kout[which], lane);
 			rbits = (uint32_t)r; po = (uint32_t)(r >> 32);
 		}
+		else if(CPO == 3) rbits = rice_search_nodes<3, 3>(v, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
 		else rbits = rice_search_nodes(v, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
 		const uint32_t est = sat_add_u32(hdr + fixed_order * sbps, rbits);
 		if(est > 0 && est < D.bits) { D.type = 2; D.bits = est; D.po = po; D.order = fixed_order; }
@@ -1584,7 +1586,7 @@ __device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t cap_wo
 	}
 }
 
-template <int MS>       // DevParams::ms_mode
+template <int MS, int CPO>       // DevParams::ms_mode; partition orders 0..CPO known at compile time (3: what -0 .. -2 set), or -1
 __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint64_t first_frame_number,
                                                  uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, FrameInfo *__restrict__ info, const PackOut O)
 {
@@ -1681,7 +1683,7 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 			ff_channel_u(w, which, x);
 			FFDec D;
 			uint32_t alleq = 0;
-			ff_decide(P, which, x, dc, sh, leaf, lane, D, alleq);
+			ff_decide<CPO>(P, which, x, dc, sh, leaf, lane, D, alleq);
 			if(ci == 0 && MS != 2) alleq_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)alleq);
 			if(lane == 0) {
 				uint32_t *rec = sh->rec[ci];
@@ -2119,9 +2121,13 @@ hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uin
 	const PackOut Oplace = make_pack_out(po);
 	PackOut O = Oplace;
 	if(po && po->out) { O.lag = po->lag < nmain ? po->lag : 0u; if(!O.lag) O.out = nullptr; }       // (lag 0: publish only)
-	if(P.ms_mode == 0) hipLaunchKernelGGL(ff_kernel<0>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O);
-	else if(P.ms_mode == 1) hipLaunchKernelGGL(ff_kernel<1>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O);
-	else hipLaunchKernelGGL(ff_kernel<2>, dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O);
+	const bool preset_po = P.max_po == 3 && P.min_po == 0;               // (stream_encoder.c:117-133: what the presets -0 .. -2 set)
+#define FFGO(MS_) do { if(preset_po) hipLaunchKernelGGL((ff_kernel<MS_, 3>), dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O); \
+                       else hipLaunchKernelGGL((ff_kernel<MS_, -1>), dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O); } while(0)
+	if(P.ms_mode == 0) FFGO(0);
+	else if(P.ms_mode == 1) FFGO(1);
+	else FFGO(2);
+#undef FFGO
 	if(po && po->out) {
 		const uint32_t firstp = O.lag ? nmain - O.lag : 0u;
 		hipLaunchKernelGGL(fo_place_kernel<false>, dim3(nmain - firstp), dim3(TPB), 0, s, Oplace, firstp, nmain, slots, P.slot_bytes, fb);
