@@ -159,6 +159,21 @@ __device__ __forceinline__ uint32_t frame_header_gen(const DevParams &P, uint32_
 	sink(nb, crc);
 	return nb + 1;
 }
+// the same as four big-endian words of the frame image (hw[0] = bytes 0..3 ...; the header is 16 bytes at most: 4 + 6 + 2 + 2 + 1,
+// zero behind its end), from wave-uniform inputs: every byte is appended to a 128-bit scalar accumulator, so the whole header is
+// scalar code and the wavefront spends one select and one LDS store on it (a lane that builds it byte by byte into the image makes
+// the whole wavefront issue a hundred vector instructions)
+__device__ __forceinline__ uint32_t frame_header_words(const DevParams &P, uint32_t n, uint32_t ca, uint32_t frame_number, uint32_t (&hw)[4])
+{
+	uint64_t hi = 0, lo = 0;
+	const uint32_t nb = frame_header_gen(P, n, ca, frame_number, [&](uint32_t, uint32_t byte) { hi = (hi << 8) | (lo >> 56); lo = (lo << 8) | (uint64_t)(byte & 0xffu); });
+	// left-align the nb bytes in the 16
+	const uint32_t sh = 8u * (16u - nb);                     // 24 .. 88 bits
+	if(sh >= 64u) { hi = lo << (sh - 64u); lo = 0; }
+	else { hi = (hi << sh) | (lo >> (64u - sh)); lo <<= sh; }
+	hw[0] = (uint32_t)(hi >> 32); hw[1] = (uint32_t)hi; hw[2] = (uint32_t)(lo >> 32); hw[3] = (uint32_t)lo;
+	return nb;
+}
 __device__ uint32_t frame_header_bytes(const DevParams &P, uint32_t n, uint32_t ca, uint32_t frame_number, uint8_t (&hb)[16])
 {
 	return frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { hb[k] = (uint8_t)byte; });
@@ -1738,7 +1753,13 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 		for(uint32_t q = (uint32_t)lane; q < P2_IMG_PAD / 16 + cap_words / 4 + 1; q += 64) img4[q] = make_uint4(0, 0, 0, 0);
 	}
 	__builtin_amdgcn_wave_barrier();
-	if(lane == 1) (void)frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { or_bits(img, cap_words, 8 * k, byte, 8); });
+	{
+		// the frame header: scalar code, then lanes 0..3 store a word each (the image is all zeros; the subframes OR into it behind this)
+		uint32_t hw[4];
+		(void)frame_header_words(P, n, ca, frame_number, hw);
+		if(lane < 4) img[lane] = lane == 0 ? hw[0] : lane == 1 ? hw[1] : lane == 2 ? hw[2] : hw[3];
+		__builtin_amdgcn_wave_barrier();
+	}
 	ff_subframe_write(img, cap_words, pos0, w, DL, uL, SL, lane);
 	ff_subframe_write(img, cap_words, pos0 + SL.bits, w, DR, uR, SR, lane);
 	if(lane == 0 && info) {
