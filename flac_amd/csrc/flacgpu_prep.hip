@@ -424,8 +424,12 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 		A.orv = 0; A.diff = 0; A.mag = 0;
 #pragma unroll
 		for(int k = 0; k < 5; k++) A.e[k] = 0;
-		if(c == 3) prep2_chunk<WIDE, true>(x, first_chunk, first, A);
-		else prep2_chunk<WIDE>(x, first_chunk, first, A);
+		// (a lane's 16 samples are summed in 32 bits whatever the sample width this kernel serves: a fourth difference of 25-bit
+		//  samples -- the side channel of a 24-bit stream -- is below 2^28, sixteen of them below 2^32; only the totals across lanes
+		//  and wavefronts need more.  Round 3 added every |difference| in 64 bits for such streams: two instructions instead of one,
+		//  twenty times per sample and channel)
+		if(c == 3) prep2_chunk<false, true>(x, first_chunk, first, A);
+		else prep2_chunk<false>(x, first_chunk, first, A);
 		A.orv = wave_or_u32(A.orv);
 		A.diff = wave_or_u32(A.diff);
 		if(c == 3) A.mag = wave_or_u32(A.mag);
