@@ -37,6 +37,7 @@ struct flacgpu_ctx {
 	float *d_windows;            // [num_apod][blocksize]
 	float *d_tail_windows;       // [num_apod][blocksize] scratch for the short last block
 	SubDecision *d_decisions;    // [max_batch][ncand]
+	uint8_t *d_plan;             // [max_batch] pack_plan_stride(P): what pack2_kernel packs from (flacgpu_dev.h: PackSub)
 	uint8_t *d_slots;            // [max_batch][slot_bytes]
 	bool ff_ok;                  // ff_kernel (one kernel per batch: -0 .. -2 on 16-bit stereo) can take this stream
 	uint32_t *d_frame_bytes;     // [max_batch]
@@ -198,6 +199,7 @@ static void free_ctx(flacgpu_ctx *c)
 	if(c->d_windows) (void)hipFree(c->d_windows);
 	if(c->d_tail_windows) (void)hipFree(c->d_tail_windows);
 	if(c->d_decisions) (void)hipFree(c->d_decisions);
+	if(c->d_plan) (void)hipFree(c->d_plan);
 	if(c->d_slots) (void)hipFree(c->d_slots);
 	if(c->d_frame_bytes) (void)hipFree(c->d_frame_bytes);
 	if(c->d_offsets) (void)hipFree(c->d_offsets);
@@ -392,6 +394,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	ok = ok && hipMalloc(&c->d_windows, wbytes) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_tail_windows, wbytes) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_decisions, B * P.ncand * sizeof(SubDecision)) == hipSuccess;
+	ok = ok && hipMalloc(&c->d_plan, B * pack_plan_stride(P)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_slots, B * P.slot_bytes + 64) == hipSuccess;       // (+64: fo_copy_slot reads whole 16-byte pieces behind a frame)
 	ok = ok && hipMalloc(&c->d_frame_bytes, B * sizeof(uint32_t)) == hipSuccess;
 	ok = ok && hipMalloc(&c->d_offsets, (B + 1) * sizeof(uint64_t)) == hipSuccess;
@@ -435,6 +438,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		// memory happens to hold, so that a kernel reading what no kernel wrote shows up as a parity failure
 		const size_t nfc = B * P.ncand, ncs = P.ncslots;
 		(void)hipMemset(c->d_decisions, 0xA5, B * P.ncand * sizeof(SubDecision));
+		(void)hipMemset(c->d_plan, 0xA5, B * pack_plan_stride(P));
 		(void)hipMemset(c->d_slots, 0xA5, B * P.slot_bytes);
 		(void)hipMemset(c->d_frame_bytes, 0xA5, B * sizeof(uint32_t));
 		(void)hipMemset(c->d_offsets, 0xA5, (B + 1) * sizeof(uint64_t));
@@ -524,7 +528,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			B.prep += fc0; B.autoc += fc0 * P.max_jobs * AUTOC_STRIDE; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.chan_stride; B.left += fc0; B.left2 += fc0; B.dbg = nullptr;
 			if(launch_analyze(P, d_pcm + (size_t)nmain * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, 1, tail_n, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
 			                  c->d_decisions + fc0, nullptr, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-			if(launch_pack(P, B.chan, 1, tail_n, first + nmain, c->d_decisions + fc0, c->d_slots + (size_t)nmain * P.slot_bytes, c->d_frame_bytes + nmain, c->d_info + nmain, nullptr, nullptr, nullptr, nullptr, nullptr, s) != hipSuccess)
+			if(launch_pack(P, B.chan, 1, tail_n, first + nmain, c->d_decisions + fc0, c->d_plan + (size_t)nmain * pack_plan_stride(P), c->d_slots + (size_t)nmain * P.slot_bytes, c->d_frame_bytes + nmain, c->d_info + nmain, nullptr, nullptr, nullptr, nullptr, nullptr, s) != hipSuccess)
 				return FLACGPU_ERR_LAUNCH;
 			if(fused && launch_append_tail(c->d_slots + (size_t)nmain * P.slot_bytes, c->d_frame_bytes, nmain, &po, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		}
@@ -553,7 +557,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
 			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
 			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, nullptr, nullptr, ss) != hipSuccess)
+			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_plan + (size_t)f0 * pack_plan_stride(P), c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, nullptr, nullptr, ss) != hipSuccess)
 				return FLACGPU_ERR_LAUNCH;
 			(void)hipEventRecord(c->sub_done[i], ss);
 			(void)hipStreamWaitEvent(s, c->sub_done[i], 0);
@@ -601,7 +605,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		{
 			uint32_t hinted = 0;
 			// (not with the debug stamps: they are indexed by workgroup, the fused output takes frames in dispatch order)
-			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, po.out && !c->ab.dbg ? &po : nullptr, &fused, c->d_vhints, &hinted, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_plan, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, po.out && !c->ab.dbg ? &po : nullptr, &fused, c->d_vhints, &hinted, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 			c->hint_out = d_out; c->hint_nframes = nframes; c->hint_first = first; c->hint_count = hinted;
 		}
 		if(c->ab.dbg) {

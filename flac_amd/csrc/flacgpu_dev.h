@@ -151,8 +151,33 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 // carry the epoch of their batch, the counters are zeroed by their last user); epoch: 1 .. 2^24 - 1, +1 for every launch;
 // spin_limit: polls before a frame gives up waiting for the ones in front of it and takes the slot + fo_place_kernel route
 struct PackOutArgs { uint8_t *out; uint64_t cap; uint64_t *offsets; uint64_t *total; uint64_t *fstate, *sstate, *sprefix, *scount; uint32_t *fall, *nfall; uint32_t epoch, spin_limit, lag /* launch_ff */; };
+// What pack2_kernel packs from: pack_plan_kernel (one lane per frame) turns the decision records of the two (C) winning candidate
+// channels of a frame into records whose fields are ready to use -- every field wave-uniform for the pack workgroup, which takes
+// them with scalar loads: no decision logic, no LDS copy of the records, no single-lane header assembly in the pack kernel.
+struct PackSub {                       // 192 bytes
+	uint32_t di;                       // candidate channel the samples come from
+	uint32_t type, order, wasted;      // SubDecision's
+	uint32_t sbps, smask;              // sample width of the subframe, (1 << sbps) - 1
+	uint32_t fmt16;                    // planar copy holds 16-bit pairs
+	int32_t shift;                     // quantisation shift (0 for the fixed predictors)
+	uint32_t fmode;                    // FIR arithmetic on 32-bit samples: 0 v_mad_i32_i24, 1 32-bit products, 2 64-bit sums (fir_mode)
+	uint32_t po, rice2;
+	uint32_t type_byte;                // the subframe header byte (stream_encoder_framing.c:393-594), wasted-bits flag included
+	uint32_t constant;                 // CONSTANT: the sample, masked to sbps bits
+	uint32_t b_bits;                   // bits of B
+	uint32_t bits;                     // SubDecision::bits (flacgpu_subframe_info)
+	uint32_t pad;
+	uint32_t QP[8];                    // taps 2p, 2p+1 as an int16 pair (the packed-sample chains)
+	uint32_t B[8];                     // what stands between the warm-up samples and the first partition, MSB first: LPC precision, shift and
+	                                   // coefficients (up to 16 of 15 bits), then the Rice method and the partition order
+	int32_t q[16];                     // taps (zero from `order` on)
+};                                     // (the Rice parameters stay in the decision record: SubDecision::params, a byte per thread)
+struct PackHead { uint32_t hw[4]; uint32_t hdr_bytes; uint32_t ca; uint32_t pad[2]; };      // frame header as big-endian words, its length
+static_assert(sizeof(PackSub) == 192 && sizeof(PackHead) == 32, "scalar-load friendly records");
+inline size_t pack_plan_stride(const DevParams &P) { return sizeof(PackHead) + (size_t)P.channels * sizeof(PackSub); }
+// plan: [nframes] records of pack_plan_stride(P) bytes (scratch of the pack kernels)
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg,
+                       const SubDecision *dec, uint8_t *plan, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg,
                        const PackOutArgs *po, bool *fused_out, uint32_t *hints, uint32_t *hinted_frames, hipStream_t s);
 // the one-kernel path of the presets without an LPC search on 16-bit stereo in 1152-sample blocks (flacgpu_kernels.hip: ff_kernel):
 // every frame of nominal length of the batch; po as for launch_pack

@@ -674,6 +674,16 @@ __device__ __forceinline__ void or_code_fit(uint32_t *buf, uint32_t pos, uint32_
 	atomicOr(w + 1, __builtin_amdgcn_alignbit(x_left, 0u, pos & 31));
 }
 
+// The same with the image at a known LDS byte address (the workgroup's LDS starts at 0, lds_base_is_zero: pack2_kernel, ff_kernel):
+// the constant goes into the instruction's offset field instead of being added to every word address
+typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
+__device__ __forceinline__ void or_code_abs(uint32_t img_abs, uint32_t pos, uint32_t x_left)
+{
+	lds_u32p w = (lds_u32p)(uintptr_t)(((pos >> 3) & ~3u) + img_abs);
+	(void)__hip_atomic_fetch_or(w, x_left >> (pos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	(void)__hip_atomic_fetch_or(w + 1, __builtin_amdgcn_alignbit(x_left, 0u, pos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 constexpr uint32_t P2_XSPAN = 512;           // span shifts kept in LDS (frames up to 22 KiB; longer ones read the global table)
 constexpr uint32_t P2_IMG_PAD = 64;          // zero bytes in front of the frame image (frame_crc16_end reads up to a span in front of it)
 struct Pack2Shared {
@@ -682,7 +692,6 @@ struct Pack2Shared {
 	uint32_t crc_parts[TPB / 64];
 	uint16_t xspan[P2_XSPAN];
 	uint16_t xbyte[CRC_SPAN + 2];
-	uint32_t dec[FLACGPU_MAX_CHANNELS * sizeof(SubDecision) / 4];      // this frame's decision records
 	uint32_t placed;           // fused output: the frames in front turned up in time, and
 	uint32_t excl_lo, excl_hi; // the byte offset of this frame in the stream of the batch
 };
@@ -920,16 +929,116 @@ __device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[16 + RUN], const
 // RUN: samples a thread owns per pass.  16; 18 for the 1152-sample blocks of -0 .. -2 (64 runs: ONE wavefront per frame, every lane
 // busy, instead of 72 runs on two wavefronts of which the second has eight lanes to do; without the verify hints, whose decoder
 // counts in 16-sample runs)
+// pack_plan_kernel: sixteen lanes per frame of nominal length (lane j = tap j of a subframe's predictor), four frames per wavefront.
+// Channel assignment (stream_encoder.c:3944-3972), the frame header (stream_encoder_framing.c:245-391) as four words, and per
+// subframe a PackSub (flacgpu_dev.h): the winning record's fields, its taps as int16 pairs, and everything between the warm-up
+// samples and the first Rice partition as a ready bit string.  pack2_kernel used to do this itself, four wavefronts each, as
+// chains of LDS round trips and scalar decision trees between its barriers: a third of the kernel's wall time per workgroup.
+// (Small on purpose: a kernel of this size runs each of its instructions once per CU, from a cold instruction cache -- the first
+//  version, one lane per frame with its loops unrolled, took 14 us for 16384 frames of which a wavefront's own work was 2.5.)
+constexpr uint32_t PLAN_LANES = 16, PLAN_FRAMES = 64 / PLAN_LANES;
+__global__ __launch_bounds__(64) void pack_plan_kernel(const DevParams P, uint32_t nmain, uint64_t first_frame_number,
+                                                       const SubDecision *__restrict__ decisions, uint8_t *__restrict__ plan, uint32_t stride,
+                                                       FrameInfo *__restrict__ info)
+{
+	__shared__ uint32_t shB[PLAN_FRAMES][10];                // a subframe's bit string under construction (8 words + 2 of or_bits' slack)
+	const uint32_t j = threadIdx.x % PLAN_LANES, g = threadIdx.x / PLAN_LANES;
+	const uint32_t f_raw = blockIdx.x * PLAN_FRAMES + g;
+	const bool live = f_raw < nmain;
+	const uint32_t f = live ? f_raw : nmain - 1;             // (lanes of a frame past the end go along and store nothing: shuffles below)
+	const uint32_t C = P.channels, N = P.blocksize;
+	const SubDecision *dec = decisions + (size_t)f * P.ncand;
+	uint32_t ca = 0, left = 0, right = 1;
+	if(P.ms_mode == 1) {
+		const uint32_t b0 = dec[0].bits + dec[1].bits, b1 = dec[0].bits + dec[3].bits, b2 = dec[1].bits + dec[3].bits, b3 = dec[2].bits + dec[3].bits;
+		uint32_t mn = b0;
+		if(b1 < mn) { mn = b1; ca = 1; }
+		if(b2 < mn) { mn = b2; ca = 2; }
+		if(b3 < mn) { mn = b3; ca = 3; }
+		left = ca == 2 ? 3 : ca == 3 ? 2 : 0;
+		right = ca == 0 ? 1 : ca == 2 ? 1 : 3;
+	}
+	else if(P.ms_mode == 2) ca = dec[0].which >= 2 ? 3 : 0;
+	PackHead *H = (PackHead *)(plan + (size_t)f * stride);
+	if(live && j == 0) {
+		uint32_t hw[4];
+		const uint32_t nb = frame_header_words(P, N, ca, (uint32_t)(first_frame_number + f), hw);
+		*(uint4 *)H->hw = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+		*(uint4 *)&H->hdr_bytes = make_uint4(nb, ca, 0u, 0u);
+		if(info) info[f].channel_assignment = (uint8_t)ca;
+	}
+	PackSub *S = (PackSub *)(H + 1);
+#pragma unroll 1
+	for(uint32_t s = 0; s < C; s++, S++) {
+		const uint32_t di = P.ms_mode == 1 ? (s == 0 ? left : right) : s;
+		const SubDecision *d = dec + di;
+		const uint32_t which = d->which, type = d->type, order = d->order, wasted = d->wasted, po = d->po, rice2 = d->rice2, precision = d->precision;
+		const int32_t shift = type == 3 ? (int32_t)d->shift : 0;
+		const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
+		const uint32_t smask = sbps >= 32 ? 0xffffffffu : (1u << sbps) - 1u;
+		const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : type == 2 ? (0x10u | (order << 1)) : (0x40u | ((order - 1) << 1));
+		// this lane's tap (fixed.c:470: the fixed predictors are FIRs with binomial taps and shift 0)
+		int32_t c = 0;
+		if(type == 3) c = d->q[j];
+		else if(type == 2) {
+			// row `order` of (-1)^j * binomial(order, j + 1), orders 1..4: 1 | 2 -1 | 3 -3 1 | 4 -6 4 -1
+			const int32_t tab = order == 1 ? 0x0001 : order == 2 ? 0x00f2 : order == 3 ? 0x01d3 : order == 4 ? 0xf4a4 : 0;
+			c = j < 4 ? (int32_t)((uint32_t)tab << (28 - 4 * j)) >> 28 : 0;
+		}
+		if(j >= order) c = 0;
+		// lpc.c:942-976's residual-width bound: the sum of the taps' magnitudes, over the frame's sixteen lanes
+		uint32_t abs_sum = (uint32_t)abs(c);
+#pragma unroll
+		for(int m = 1; m < (int)PLAN_LANES; m <<= 1) abs_sum += (uint32_t)__shfl_xor((int)abs_sum, m, PLAN_LANES);
+		const bool wide = type == 3 && silog2_i64((int64_t)(((uint64_t)1 << (sbps - 1)) * abs_sum)) > 32;
+		const int32_t c_next = __shfl_down(c, 1, PLAN_LANES);
+		// the bit string between the warm-up samples and the first partition: [precision-1:4][shift:5][coefficients] (LPC), then the
+		// Rice method and the partition order; every lane ORs its piece into the wavefront's copy
+		if(j < 10) shB[g][j] = 0;
+		__builtin_amdgcn_wave_barrier();
+		uint32_t b_bits = 0;
+		if(type == 3) {
+			if(j == 0) { or_bits(shB[g], 8, 0, precision - 1, 4); or_bits(shB[g], 8, 4, (uint32_t)shift & 31u, 5); }
+			if(j < order) or_bits(shB[g], 8, 9 + j * precision, (uint32_t)c & ((1u << precision) - 1u), precision);
+			b_bits = 9 + order * precision;
+		}
+		if(type >= 2) {
+			if(j == 1) { or_bits(shB[g], 8, b_bits, rice2 ? 1u : 0u, 2); or_bits(shB[g], 8, b_bits + 2, po, 4); }
+			b_bits += 6;
+		}
+		__builtin_amdgcn_wave_barrier();
+		if(live) {
+			if(j == 0) {
+				*(uint4 *)&S->di = make_uint4(di, type, order, wasted);
+				*(uint4 *)&S->sbps = make_uint4(sbps, smask, d->fmt == 1 ? 1u : 0u, (uint32_t)shift);
+				*(uint4 *)&S->fmode = make_uint4((uint32_t)fir_mode(wide ? 1u : 0u, sbps), po, rice2, type_bits | (wasted ? 1u : 0u));
+				*(uint4 *)&S->constant = make_uint4((uint32_t)d->constant & smask, b_bits, d->bits, 0u);
+				if(info) {
+					flacgpu_subframe_info *si = &info[f].sub[s];
+					si->type = (uint8_t)type; si->order = (uint8_t)order; si->wasted_bits = (uint8_t)wasted;
+					si->partition_order = (uint8_t)po; si->rice2 = (uint8_t)rice2; si->precision = (uint8_t)precision; si->shift = d->shift;
+					si->pad = 0; si->bits = d->bits;
+				}
+			}
+			if((j & 1) == 0) S->QP[j >> 1] = ((uint32_t)c << 16) | ((uint32_t)c_next & 0xffffu);
+			S->q[j] = c;
+			if(j < 8) S->B[j] = shB[g][j];
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+// HINTS / NT / RUN: see above
 template <int MAXORD, bool HINTS, int NT, int RUN = CHUNK>
 #ifndef PACK2_WAVES
 #define PACK2_WAVES 5
 #endif
 __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel(      // (one-wavefront workgroups: the LDS image allows four per SIMD, no more)
                                                     const DevParams P, const int32_t *__restrict__ chan,
-                                                    uint32_t nmain, uint64_t first_frame_number,
+                                                    uint32_t nmain, const uint8_t *__restrict__ plan, uint32_t plan_stride,
                                                     const SubDecision *__restrict__ decisions,
                                                     uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes,
-                                                    FrameInfo *__restrict__ info, unsigned long long *__restrict__ dbg, const PackOut O,
+                                                    unsigned long long *__restrict__ dbg, const PackOut O,
                                                     uint32_t *__restrict__ hints)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -945,22 +1054,38 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 	uint32_t f = blockIdx.x;
 	f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);        // (the frame's addresses are scalar registers)
 #define PSTAMP(k) do { if(dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)clock64(); } while(0)
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 	PSTAMP(0);
-	const SubDecision *dec = decisions + (size_t)f * P.ncand;
-
-	// decision records, CRC tables: one round of loads for everything the frame needs; image zeroed meanwhile
+	// the frame's plan (pack_plan_kernel): every field the same for the whole workgroup, i.e. scalar loads
+	const PackHead *H = (const PackHead *)(plan + (size_t)f * plan_stride);
+	const PackSub *subs = (const PackSub *)(H + 1);
+	const uint32_t hwv = H->hw[tid & 3];
+	uint32_t pos = 8 * H->hdr_bytes;
+	// What the subframe loop will wait for, asked for now: the plan's lines (into the scalar cache: a first touch of a line is a trip
+	// to the L2, a thousand cycles and more under load, and the loop below would make one per subframe on its critical path) and the
+	// lines of this thread's first run of the first two subframes (from HBM: the planar channels were written a millisecond ago).
+	// The values are consumed behind the barrier so that the loads are not dropped.
+	uint32_t touch_s = 0, touch_v = 0;
 	{
-		// (straight-line, every load unconditional with its index clamped: as loops with their own bounds these were five basic blocks,
-		//  each ending in a wait for its own load -- five round trips where one will do)
-		constexpr uint32_t DEC_ROUNDS = (FLACGPU_MAX_CHANNELS * (uint32_t)(sizeof(SubDecision) / 4) + NT - 1) / NT;
+		const uint32_t *pw = (const uint32_t *)H;
+		const uint32_t nlines = (plan_stride + 63u) / 64u;
+#pragma unroll
+		for(uint32_t l = 1; l < 7; l++) touch_s ^= pw[16u * (l < nlines ? l : 0u)];
+		const uint32_t c2 = C < 2u ? C : 2u;
+#pragma unroll
+		for(uint32_t s = 0; s < 2; s++) {
+			const PackSub *d = subs + (s < c2 ? s : 0u);
+			const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + d->di) * N);
+			const uint32_t b = RUN * (uint32_t)tid;
+			touch_v ^= src[(b < n ? b : 0u) >> (d->fmt16 ? 1 : 0)];
+		}
+	}
+
+	// CRC tables: one round of loads; image zeroed meanwhile
+	{
 		constexpr uint32_t TAB_ROUNDS = (4 * 256 / 2) / NT, XS_ROUNDS = (P2_XSPAN / 2) / NT;
 		static_assert((4 * 256 / 2) % NT == 0 && (P2_XSPAN / 2) % NT == 0 && (CRC_SPAN + 2) / 2 <= NT, "whole passes of the workgroup per table");
-		const uint32_t ndw = P.ncand * (uint32_t)(sizeof(SubDecision) / 4);
-		const uint32_t *decw = (const uint32_t *)dec, *tab32 = (const uint32_t *)g_crc_tables.tab, *xs32 = (const uint32_t *)g_crc_tables.xspan44,
-		               *xb32 = (const uint32_t *)g_crc_tables.xbyte;
-		uint32_t dv[DEC_ROUNDS];
-#pragma unroll
-		for(uint32_t k = 0; k < DEC_ROUNDS; k++) { const uint32_t w = (uint32_t)tid + k * NT; dv[k] = decw[w < ndw ? w : ndw - 1]; }
+		const uint32_t *tab32 = (const uint32_t *)g_crc_tables.tab, *xs32 = (const uint32_t *)g_crc_tables.xspan44, *xb32 = (const uint32_t *)g_crc_tables.xbyte;
 		uint32_t tv[TAB_ROUNDS], xv[XS_ROUNDS];
 #pragma unroll
 		for(uint32_t k = 0; k < TAB_ROUNDS; k++) tv[k] = tab32[(uint32_t)tid + k * NT];
@@ -973,58 +1098,32 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 			for(uint32_t q = (uint32_t)tid; q < P2_IMG_PAD / 16 + cap_words / 4 + 1; q += NT) z4[q] = make_uint4(0, 0, 0, 0);
 		}
 #pragma unroll
-		for(uint32_t k = 0; k < DEC_ROUNDS; k++) { const uint32_t w = (uint32_t)tid + k * NT; if(w < ndw) sh->dec[w] = dv[k]; }
-#pragma unroll
 		for(uint32_t k = 0; k < TAB_ROUNDS; k++) ((uint32_t *)sh->crc_tab)[(uint32_t)tid + k * NT] = tv[k];
 #pragma unroll
 		for(uint32_t k = 0; k < XS_ROUNDS; k++) ((uint32_t *)sh->xspan)[(uint32_t)tid + k * NT] = xv[k];
 		if(tid < (int)(CRC_SPAN + 2) / 2) ((uint32_t *)sh->xbyte)[tid] = bv;
 	}
 	__syncthreads();
+	asm volatile("" :: "s"(touch_s), "v"(touch_v));
 	PSTAMP(1);
-	const SubDecision *ldec = (const SubDecision *)sh->dec;
-	// channel assignment (stream_encoder.c:3944-3972), by every thread from the LDS copies
-	uint32_t ca = 0, left = 0, right = 1;
-	if(P.ms_mode == 1) {
-		const uint32_t b0 = ldec[0].bits + ldec[1].bits, b1 = ldec[0].bits + ldec[3].bits,
-		               b2 = ldec[1].bits + ldec[3].bits, b3 = ldec[2].bits + ldec[3].bits;
-		uint32_t mn = b0;
-		if(b1 < mn) { mn = b1; ca = 1; }
-		if(b2 < mn) { mn = b2; ca = 2; }
-		if(b3 < mn) { mn = b3; ca = 3; }
-		ca = (uint32_t)__builtin_amdgcn_readfirstlane((int)ca);        // the same in every lane: say so, and what follows is scalar code
-		left = ca == 2 ? 3 : ca == 3 ? 2 : 0;
-		right = ca == 0 ? 1 : ca == 2 ? 1 : 3;
-	}
-	else if(P.ms_mode == 2) ca = (uint32_t)__builtin_amdgcn_readfirstlane(ldec[0].which >= 2 ? 3 : 0);
-	const uint32_t frame_number = (uint32_t)(first_frame_number + f);
-	if(tid == (NT > 64 ? 64 : 1)) {
-		// one lane (of a wavefront that has no other single-lane duties, where there is more than one) builds and writes the header while the others go on
-		(void)frame_header_gen(P, n, ca, frame_number, [&](uint32_t k, uint32_t byte) { or_bits(img, cap_words, 8 * k, byte, 8); });
-	}
-	uint32_t pos = 8 * frame_header_len(P, n, frame_number);
+	// the frame header: four words (zero behind its end) by four lanes of a wavefront that has no other single-lane duties
+	if(tid >= (NT > 64 ? 64 : 0) && tid < (NT > 64 ? 64 : 0) + 4) atomicOr(&img[tid & 3], hwv);
 	uint32_t scan_buf = 0;
 
 	// ---- subframes (stream_encoder_framing.c:393-594) -------------------------------------------
 	for(uint32_t s = 0; s < C; s++) {
-		const uint32_t di = P.ms_mode == 1 ? (s == 0 ? left : right) : s;
-		const SubDecision *d = ldec + di;
-		// the decision record is one for the whole workgroup: its fields are made scalars, so that the header arithmetic, the tap
-		// set-up and the branches on type / order / format below are scalar code and not 64-lane selects
-#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-		const uint32_t which = UNI(d->which), type = UNI(d->type), order = UNI(d->order), wasted = UNI(d->wasted);
-		const uint32_t sbps = P.bps - wasted + (which == C + 1 ? 1 : 0);
-		const bool fmt16 = UNI(d->fmt) == 1;       // 16-bit pairs: sbps <= 16, or a side channel whose samples all fit int16
-		const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + di) * N);
-		const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : type == 2 ? (0x10u | (order << 1)) : (0x40u | ((order - 1) << 1));
+		const PackSub *d = subs + s;
+		const uint32_t type = d->type, order = d->order, wasted = d->wasted, sbps = d->sbps, smask = d->smask;
+		const bool fmt16 = d->fmt16 != 0;       // 16-bit pairs: sbps <= 16, or a side channel whose samples all fit int16
+		const uint32_t *src = (const uint32_t *)(chan + ((size_t)f * P.ncand + d->di) * N);
+		const uint8_t *rice_params = decisions[(size_t)f * P.ncand + d->di].params;
 		if(tid == 0) {
-			or_bits(img, cap_words, pos, type_bits | (wasted ? 1u : 0u), 8);
+			or_bits(img, cap_words, pos, d->type_byte, 8);
 			if(wasted) or_bits(img, cap_words, pos + 8 + (wasted - 1), 1, 1);
 		}
 		pos += 8 + wasted;
-		const uint32_t smask = sbps >= 32 ? 0xffffffffu : (1u << sbps) - 1u;
 		if(type == 0) {
-			if(tid == 0) or_bits(img, cap_words, pos, (uint32_t)d->constant & smask, sbps);
+			if(tid == 0) or_bits(img, cap_words, pos, d->constant, sbps);
 			pos += sbps;
 		}
 		else if(type == 1) {
@@ -1059,60 +1158,32 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 		else {
 			const uint32_t warm_pos = pos;
 			pos += order * sbps;
-			const int shift = type == 3 ? (int)__builtin_amdgcn_readfirstlane((int)d->shift) : 0;
-			bool wide = false;
-			if(type == 3) {
-				const uint32_t precision = UNI(d->precision);
-				if(tid == 0) {
-					or_bits(img, cap_words, pos, precision - 1, 4);
-					or_bits(img, cap_words, pos + 4, (uint32_t)shift & 31u, 5);
-				}
-				if((uint32_t)tid < order) or_bits(img, cap_words, pos + 9 + (uint32_t)tid * precision, (uint32_t)d->q[tid] & ((1u << precision) - 1u), precision);
-				pos += 9 + order * precision;
-			}
-			const uint32_t po = UNI(d->po), rice2 = UNI(d->rice2), plen = rice2 ? 5u : 4u;
-			if(tid == 0) {
-				or_bits(img, cap_words, pos, rice2 ? 1u : 0u, 2);
-				or_bits(img, cap_words, pos + 2, po, 4);
-			}
-			pos += 6;
-			// taps (fixed.c:470: the fixed predictors are FIRs with binomial taps and shift 0)
-			int32_t q[MAXORD];
-#pragma unroll
-			for(int j = 0; j < MAXORD; j++) {
-				int32_t c = 0;
-				if(type == 3) c = j < MAX_ORDER ? d->q[j] : 0;
-				else if(order == 1) c = j == 0 ? 1 : 0;
-				else if(order == 2) c = j == 0 ? 2 : j == 1 ? -1 : 0;
-				else if(order == 3) c = j == 0 ? 3 : j == 1 ? -3 : j == 2 ? 1 : 0;
-				else if(order == 4) c = j == 0 ? 4 : j == 1 ? -6 : j == 2 ? 4 : j == 3 ? -1 : 0;
-				q[j] = c;
-			}
-			if(type == 3) {
-				// lpc.c:942-976's residual-width bound, from the taps now in registers (they were read one dependent LDS round trip at a time)
-				uint32_t abs_sum = 0;
-#pragma unroll
-				for(int j = 0; j < MAXORD; j++) abs_sum += (uint32_t)j < order ? (uint32_t)abs(q[j]) : 0u;
-				abs_sum = UNI(abs_sum);
-				wide = silog2_i64((int64_t)(((uint64_t)1 << (sbps - 1)) * abs_sum)) > 32;
-			}
+			// LPC precision, shift, coefficients; Rice method and partition order: the plan's bit string, a word per lane
+			const uint32_t b_bits = d->b_bits, b_pos = pos;
+			const uint32_t b_word = d->B[tid & 7];             // (written behind the residual: the load has the FIR to come back)
+			pos += b_bits;
+			const int shift = d->shift;
+			const uint32_t po = d->po, plen = d->rice2 ? 5u : 4u;
+			const int fmode = (int)d->fmode;
+			const bool wide = fmode == 2;
 			// the taps as int16 pairs in scalar registers for the packed-sample chains (they are the subframe's, not the thread's)
 			uint32_t QP[8];
 #pragma unroll
-			for(int pp = 0; pp < 8; pp++) {
-				const uint32_t hi = 2 * pp < MAXORD ? (uint32_t)q[2 * pp < MAXORD ? 2 * pp : 0] : 0u, lo = 2 * pp + 1 < MAXORD ? (uint32_t)q[2 * pp + 1 < MAXORD ? 2 * pp + 1 : 0] : 0u;
-				QP[pp] = 2 * pp < MAXORD ? UNI((hi << 16) | (lo & 0xffffu)) : 0u;
-			}
+			for(int pp = 0; pp < 8; pp++) QP[pp] = 2 * pp < MAXORD ? d->QP[pp] : 0u;
+			const int32_t *q = d->q;
 			const uint32_t psize = n >> po;
 			PSTAMP(2 + 4 * s);
-			const int fmode = fir_mode(wide, sbps);
 			for(uint32_t base0 = 0; base0 < n; base0 += RUN * NT) {
-				const uint32_t base = base0 + RUN * (uint32_t)tid;
-				const bool active = base < n;
+				// (a thread without a run in this pass -- block sizes that are not a multiple of the workgroup's samples -- computes the
+				//  block's last run again and writes nothing: no branch around the arithmetic, no registers that are defined on one side only)
+				const bool head_wave = base0 == 0 && wave == 0;
+				const uint32_t base_own = base0 + RUN * (uint32_t)tid;
+				const bool active = base_own < n;
+				const uint32_t base = active ? base_own : n - RUN;
 				int32_t r[RUN];
 				uint32_t mybits = 0, k = 0;
 				bool starts = false;
-				if(active) {
+				{
 					if(fmt16) {
 						// window words: A[0..7] = samples base-16..base-1, A[8..15] = own
 						uint32_t A[8 + RUN / 2];
@@ -1176,16 +1247,33 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 					}
 					// Rice code sizes: the whole run lies in one partition (partition sizes are multiples of 16)
 					const uint32_t part = base / psize;
-					k = d->params[part];
+					k = rice_params[part];
 					starts = base == part * psize;
 					if(starts) mybits = plen;
+					// (the block's first run: its first `order` samples are the warm-up samples and have no code -- one thread of one
+					//  wavefront; that wavefront runs the guarded loops, the others the plain ones)
+					const uint32_t kp1 = k + 1u;
+					uint32_t zeros = 0;
+					if(head_wave) {
+						const uint32_t skip = base == 0 ? order : 0u;
 #pragma unroll
-					for(int t = 0; t < RUN; t++) {
-						const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
-						const uint32_t cb = (u >> k) + 1 + k;
-						mybits += (base == 0 && (uint32_t)t < order) ? 0u : cb;
-						r[t] = (int32_t)u;                 // the write phase wants the folded value, not the residual
+						for(int t = 0; t < RUN; t++) {
+							const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
+							r[t] = (int32_t)u;                 // the write phase wants the folded value, not the residual
+							zeros += (t < MAXORD && (uint32_t)t < skip) ? 0u : u >> k;
+						}
+						mybits += zeros + ((uint32_t)RUN - skip) * kp1;
 					}
+					else {
+#pragma unroll
+						for(int t = 0; t < RUN; t++) {
+							const uint32_t u = ((uint32_t)r[t] << 1) ^ (uint32_t)(r[t] >> 31);
+							r[t] = (int32_t)u;
+							zeros += u >> k;
+						}
+						mybits += zeros + (uint32_t)RUN * kp1;
+					}
+					if(!active) mybits = 0;
 				}
 				PSTAMP(3 + 4 * s);
 				// bit offset of this thread: wavefront scan + wavefront totals through LDS
@@ -1208,14 +1296,29 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 					if(pos + woff + incl <= cap_words * 32u) {
 						// the code left-aligned in a word: stop bit, then the k low bits of u.  u << (31 - k) puts them there; what it leaves in
 						// bit 31 (bit k of u) is covered by the stop bit, everything above has left the word
-						const uint32_t lsh = 31u - k;
+						// at = the bit the stop bit goes to: the one before's, plus that code's 1 + k bits, plus this one's zeros
+						const uint32_t lsh = 31u - k, kp1 = k + 1u;
+						uint32_t at = p - kp1;
+						if(head_wave) {
+							const uint32_t skip = base == 0 ? order : 0u;
 #pragma unroll
-						for(int t = 0; t < RUN; t++) {
-							if(!(base == 0 && (uint32_t)t < order)) {
+							for(int t = 0; t < RUN; t++) {
 								const uint32_t u = (uint32_t)r[t];
-								p += u >> k;
-								or_code_fit(img, p, (u << lsh) | 0x80000000u);
-								p += 1 + k;
+								if(t < MAXORD) {
+									// (a warm-up position: nothing is added, nothing is written -- by selects, not by branches)
+									const bool gone = (uint32_t)t < skip;
+									at = at + (gone ? 0u : kp1) + (gone ? 0u : u >> k);
+									or_code_abs(IMG_OFF, at, gone ? 0u : (u << lsh) | 0x80000000u);
+								}
+								else { at = at + kp1 + (u >> k); or_code_abs(IMG_OFF, at, (u << lsh) | 0x80000000u); }
+							}
+						}
+						else {
+#pragma unroll
+							for(int t = 0; t < RUN; t++) {
+								const uint32_t u = (uint32_t)r[t];
+								at = at + kp1 + (u >> k);
+								or_code_abs(IMG_OFF, at, (u << lsh) | 0x80000000u);
 							}
 						}
 					}
@@ -1230,12 +1333,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 				const uint32_t warm_v = fmt16 ? (uint32_t)(int32_t)((const int16_t *)src)[tid] : src[tid];
 				or_bits(img, cap_words, warm_pos + (uint32_t)tid * sbps, warm_v & smask, sbps);
 			}
-		}
-		if(tid == 0 && info) {
-			flacgpu_subframe_info *si = &info[f].sub[s];
-			si->type = (uint8_t)type; si->order = (uint8_t)order; si->wasted_bits = (uint8_t)wasted;
-			si->partition_order = d->po; si->rice2 = d->rice2; si->precision = d->precision; si->shift = d->shift;
-			si->pad = 0; si->bits = d->bits;
+			if((uint32_t)tid < (b_bits + 31u) >> 5) or_bits(img, cap_words, b_pos + 32u * (uint32_t)tid, b_word, 32);
 		}
 	}
 	__syncthreads();
@@ -1283,7 +1381,6 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 				if(f + 1 == nmain) { O.offsets[f + 1] = off + mine; *O.total = off + mine; }      // (a short last block goes behind: append_tail_kernel)
 			}
 			else O.fall[atomicAdd(&O.nfall[O.epoch & 1u], 1u)] = f;
-			if(info) info[f].channel_assignment = (uint8_t)ca;
 		}
 	}
 	else {
@@ -1292,7 +1389,6 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 		for(uint32_t w = (uint32_t)tid; w < words; w += NT) dst[w] = __builtin_bswap32(img[w]);
 		if(tid == 0) {
 			frame_bytes[f] = overflow ? 0xffffffffu : total_bytes;
-			if(info) info[f].channel_assignment = (uint8_t)ca;
 		}
 	}
 	PSTAMP(12);
@@ -1536,7 +1632,7 @@ __device__ __forceinline__ void ff_subframe_sizes(const uint32_t (&w)[FF_RUN + 4
 	S.bits = 8 + d.wasted + d.order * d.sbps + 6 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 // ... and its bits, at bit `pos` of the zeroed frame image (stream_encoder_framing.c:393-594, bitwriter.c:575-706)
-__device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t cap_words, uint32_t pos, const uint32_t (&w)[FF_RUN + 4], const FFDec &d, const uint32_t (&u)[FF_RUN], const FFSub &S, int lane)
+__device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t img_abs /* LDS byte address of img */, uint32_t cap_words, uint32_t pos, const uint32_t (&w)[FF_RUN + 4], const FFDec &d, const uint32_t (&u)[FF_RUN], const FFSub &S, int lane)
 {
 	const uint32_t type = d.type, order = d.order, wasted = d.wasted, sbps = d.sbps;
 	const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : (0x10u | (order << 1));
@@ -1591,11 +1687,11 @@ __device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t cap_wo
 				const bool gone = (uint32_t)t < skip;
 				const uint32_t adv = gone ? 0u : kp1;
 				at = at + adv + (ut >> k);
-				if(!gone) or_code_fit(img, at, (ut << lsh) | 0x80000000u);
+				if(!gone) or_code_abs(img_abs, at, (ut << lsh) | 0x80000000u);
 			}
 			else {
 				at = at + kp1 + (ut >> k);
-				or_code_fit(img, at, (ut << lsh) | 0x80000000u);
+				or_code_abs(img_abs, at, (ut << lsh) | 0x80000000u);
 			}
 		}
 	}
@@ -1760,8 +1856,8 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 		if(lane < 4) img[lane] = lane == 0 ? hw[0] : lane == 1 ? hw[1] : lane == 2 ? hw[2] : hw[3];
 		__builtin_amdgcn_wave_barrier();
 	}
-	ff_subframe_write(img, cap_words, pos0, w, DL, uL, SL, lane);
-	ff_subframe_write(img, cap_words, pos0 + SL.bits, w, DR, uR, SR, lane);
+	ff_subframe_write(img, IMG_OFF, cap_words, pos0, w, DL, uL, SL, lane);
+	ff_subframe_write(img, IMG_OFF, cap_words, pos0 + SL.bits, w, DR, uR, SR, lane);
 	if(lane == 0 && info) {
 #pragma unroll
 		for(int s = 0; s < 2; s++) {
@@ -2048,7 +2144,7 @@ static PackOut make_pack_out(const PackOutArgs *po)
 }
 template <int MAXORD>
 static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                                const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, const PackOutArgs *po, bool *fused_out,
+                                const SubDecision *dec, uint8_t *plan, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, const PackOutArgs *po, bool *fused_out,
                                 uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
 {
 	static bool attr_set = false;
@@ -2082,12 +2178,14 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			// the presets' 1152-sample blocks: 64 runs of 18 samples, one wavefront per frame (not with the verify hints: their decoder
 			// counts in 16-sample runs; FLACGPU_NO_RUN18=1: the 128-thread instance, for A/B runs)
 			static const bool no_run18 = getenv("FLACGPU_NO_RUN18") != nullptr;
+			const uint32_t pstride = (uint32_t)pack_plan_stride(P);
+			if(f_lo) hipLaunchKernelGGL(pack_plan_kernel, dim3((f_lo + PLAN_FRAMES - 1) / PLAN_FRAMES), dim3(64), 0, s, P, f_lo, first, dec, plan, pstride, info);
 			const bool run18 = P.blocksize == 1152 && !hints && !no_run18 && (1152u >> P.max_po) % 18u == 0;
-			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
-			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
-			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
-			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
-			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, first, dec, slots, fb, info, dbg, O, hints);
+			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
+			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
+			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
+			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
+			else if(f_lo) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
 			if(hinted_frames) *hinted_frames = hints ? f_lo : 0;
 			if(fused) hipLaunchKernelGGL(fo_place_kernel<true>, dim3(FO_PLACE_GRID), dim3(TPB), 0, s, O, 0u, f_lo, slots, P.slot_bytes, fb);
 		}
@@ -2108,16 +2206,16 @@ size_t pack_lds_bytes(const DevParams &P)
 }
 
 hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes, uint32_t tail_n, uint64_t first,
-                       const SubDecision *dec, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, const PackOutArgs *po, bool *fused_out,
+                       const SubDecision *dec, uint8_t *plan, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, const PackOutArgs *po, bool *fused_out,
                        uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
 {
 	const size_t lds = pack_lds_bytes(P);
 	const uint32_t m = P.max_lpc_order > 4 ? P.max_lpc_order : 4;
 	if(P.blocksize > HINT_RUNS * CHUNK) hints = nullptr;          // one run per thread and pass: blocks of up to 4096 samples
-	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
-	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
-	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
-	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	if(m <= 8) return launch_pack_t<8>(P, chan, nframes, tail_n, first, dec, plan, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	if(m <= 12) return launch_pack_t<12>(P, chan, nframes, tail_n, first, dec, plan, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	if(m <= 16) return launch_pack_t<16>(P, chan, nframes, tail_n, first, dec, plan, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
+	return launch_pack_t<32>(P, chan, nframes, tail_n, first, dec, plan, slots, fb, info, dbg, lds, po, fused_out, hints, hinted_frames, s);
 }
 // ff_kernel takes 16-bit stereo in 1152-sample blocks when the prep kernel could decide the subframes itself (no LPC search, one
 // fixed order) and pack2_kernel could pack them; not with the verify hints (their decoder wants pack2_kernel's run starts)
