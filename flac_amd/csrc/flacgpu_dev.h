@@ -166,7 +166,7 @@ struct PackSub {                       // 192 bytes
 	uint32_t constant;                 // CONSTANT: the sample, masked to sbps bits
 	uint32_t b_bits;                   // bits of B
 	uint32_t bits;                     // SubDecision::bits (flacgpu_subframe_info)
-	uint32_t pad;
+	uint32_t inv_psize;                // ceil(2^32 / partition size): sample index / partition size = mul_hi(index, inv_psize), exact below 2^16
 	uint32_t QP[8];                    // taps 2p, 2p+1 as an int16 pair (the packed-sample chains)
 	uint32_t B[8];                     // what stands between the warm-up samples and the first partition, MSB first: LPC precision, shift and
 	                                   // coefficients (up to 16 of 15 bits), then the Rice method and the partition order

@@ -29,6 +29,7 @@ __device__ __forceinline__ uint32_t silog2_i64(int64_t v)
 	return ilog2_u64((uint64_t)v) + 2;
 }
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 // LDS signal layout: rows of 16 samples padded to 18 words so that the per-thread sliding window
 // (thread t owns samples [16t,16t+16)) reads conflict-free; 32 zero samples in front so that a

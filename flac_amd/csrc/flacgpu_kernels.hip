@@ -929,6 +929,91 @@ __device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[16 + RUN], const
 // RUN: samples a thread owns per pass.  16; 18 for the 1152-sample blocks of -0 .. -2 (64 runs: ONE wavefront per frame, every lane
 // busy, instead of 72 runs on two wavefronts of which the second has eight lanes to do; without the verify hints, whose decoder
 // counts in 16-sample runs)
+// The frame header of a frame of nominal length, split into what the stream fixes (computed on the host per launch: the cases
+// of frame_header_gen above) and what the frame brings (channel assignment, frame number, CRC-8)
+struct HdrConst {
+	uint32_t b2;               // block size code << 4 | sample rate code
+	uint32_t bps_code2;        // sample size code << 1
+	uint32_t tail;             // the bytes behind the frame number -- block size, sample rate: 0..4 of them -- left-aligned
+	uint32_t tail_n;
+};
+static HdrConst make_hdr_const(const DevParams &P)
+{
+	HdrConst h;
+	const uint32_t n = P.blocksize, sr = P.sample_rate;
+	uint32_t bs_code, bs_hint = 0, sr_code, sr_hint = 0, bps_code;
+	switch(n) {
+		case 192: bs_code = 1; break; case 576: bs_code = 2; break; case 1152: bs_code = 3; break;
+		case 2304: bs_code = 4; break; case 4608: bs_code = 5; break; case 256: bs_code = 8; break;
+		case 512: bs_code = 9; break; case 1024: bs_code = 10; break; case 2048: bs_code = 11; break;
+		case 4096: bs_code = 12; break; case 8192: bs_code = 13; break; case 16384: bs_code = 14; break;
+		case 32768: bs_code = 15; break;
+		default: bs_hint = bs_code = (n <= 0x100) ? 6 : 7; break;
+	}
+	switch(sr) {
+		case 88200: sr_code = 1; break; case 176400: sr_code = 2; break; case 192000: sr_code = 3; break;
+		case 8000: sr_code = 4; break; case 16000: sr_code = 5; break; case 22050: sr_code = 6; break;
+		case 24000: sr_code = 7; break; case 32000: sr_code = 8; break; case 44100: sr_code = 9; break;
+		case 48000: sr_code = 10; break; case 96000: sr_code = 11; break;
+		default:
+			if(sr <= 255000 && sr % 1000 == 0) sr_hint = sr_code = 12;
+			else if(sr <= 655350 && sr % 10 == 0) sr_hint = sr_code = 14;
+			else if(sr <= 0xffff) sr_hint = sr_code = 13;
+			else sr_code = 0;
+			break;
+	}
+	switch(P.bps) {
+		case 8: bps_code = 1; break; case 12: bps_code = 2; break; case 16: bps_code = 4; break;
+		case 20: bps_code = 5; break; case 24: bps_code = 6; break; case 32: bps_code = 7; break;
+		default: bps_code = 0; break;
+	}
+	uint8_t t[4] = {0, 0, 0, 0};
+	uint32_t tn = 0;
+	if(bs_hint == 6) t[tn++] = (uint8_t)(n - 1);
+	else if(bs_hint == 7) { t[tn++] = (uint8_t)((n - 1) >> 8); t[tn++] = (uint8_t)(n - 1); }
+	if(sr_hint == 12) t[tn++] = (uint8_t)(sr / 1000);
+	else if(sr_hint == 13) { t[tn++] = (uint8_t)(sr >> 8); t[tn++] = (uint8_t)sr; }
+	else if(sr_hint == 14) { t[tn++] = (uint8_t)((sr / 10) >> 8); t[tn++] = (uint8_t)(sr / 10); }
+	h.b2 = (bs_code << 4) | sr_code; h.bps_code2 = bps_code << 1;
+	h.tail = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3]; h.tail_n = tn;
+	return h;
+}
+// ... and assembled by sixteen lanes, lane j = byte j (4 + 6 + 4 + 1 bytes at most).  The CRC-8 (poly x^8 + x^2 + x + 1, crc.c:366) of
+// a byte string is the sum of its bytes times x^(8 * bytes behind them, the CRC's own place included): every lane multiplies its
+// byte up, the lanes add.  Returns this lane's word of the header (valid in lanes 0, 4, 8, 12: bytes j .. j+3, zero behind the
+// header's end); nb: the header's length.
+__device__ __forceinline__ uint32_t frame_header_lanes(const HdrConst &hc, uint32_t C, uint32_t ca, uint32_t v, uint32_t j, uint32_t &nb)
+{
+	const uint32_t nu = v < 0x80 ? 1u : v < 0x800 ? 2u : v < 0x10000 ? 3u : v < 0x200000 ? 4u : v < 0x4000000 ? 5u : 6u;      // bitwriter.c:832
+	const uint32_t nbody = 4 + nu + hc.tail_n;
+	uint32_t byte = 0;
+	if(j == 0) byte = 0xff;
+	else if(j == 1) byte = 0xf8;
+	else if(j == 2) byte = hc.b2;
+	else if(j == 3) byte = ((ca == 0 ? C - 1 : 7 + ca) << 4) | hc.bps_code2;
+	else if(j < 4 + nu) {
+		const uint32_t k = j - 4, sh = 6 * (nu - 1 - k);
+		const uint32_t bits = sh < 32 ? v >> sh : 0u;
+		byte = nu == 1 ? v : k == 0 ? ((0xffu << (8 - nu)) & 0xffu) | bits : 0x80u | (bits & 0x3fu);
+	}
+	else if(j < nbody) byte = (hc.tail >> (24 - 8 * (j - 4 - nu))) & 0xffu;
+	// this byte's share of the CRC
+	uint32_t c = j < nbody ? byte : 0u;
+	for(uint32_t m = j; m < nbody; m++) {
+		// c * x^8 mod x^8+x^2+x+1: x^8 = x^2+x+1, applied twice (the first product has 10 bits)
+		const uint32_t w = c ^ (c << 1) ^ (c << 2), hi = w >> 8;
+		c = (w ^ hi ^ (hi << 1) ^ (hi << 2)) & 0xffu;
+	}
+#pragma unroll
+	for(int m = 1; m < 16; m <<= 1) c ^= (uint32_t)__shfl_xor((int)c, m, 16);
+	if(j == nbody) byte = c;
+	uint32_t word = byte << (24 - 8 * (j & 3));
+	word |= (uint32_t)__shfl_xor((int)word, 1, 16);
+	word |= (uint32_t)__shfl_xor((int)word, 2, 16);
+	nb = nbody + 1;
+	return word;
+}
+
 // pack_plan_kernel: sixteen lanes per frame of nominal length (lane j = tap j of a subframe's predictor), four frames per wavefront.
 // Channel assignment (stream_encoder.c:3944-3972), the frame header (stream_encoder_framing.c:245-391) as four words, and per
 // subframe a PackSub (flacgpu_dev.h): the winning record's fields, its taps as int16 pairs, and everything between the warm-up
@@ -937,7 +1022,7 @@ __device__ __forceinline__ void pack_fir_i32(const int32_t (&x)[16 + RUN], const
 // (Small on purpose: a kernel of this size runs each of its instructions once per CU, from a cold instruction cache -- the first
 //  version, one lane per frame with its loops unrolled, took 14 us for 16384 frames of which a wavefront's own work was 2.5.)
 constexpr uint32_t PLAN_LANES = 16, PLAN_FRAMES = 64 / PLAN_LANES;
-__global__ __launch_bounds__(64) void pack_plan_kernel(const DevParams P, uint32_t nmain, uint64_t first_frame_number,
+__global__ __launch_bounds__(64) void pack_plan_kernel(const DevParams P, const HdrConst hc, uint32_t nmain, uint64_t first_frame_number,
                                                        const SubDecision *__restrict__ decisions, uint8_t *__restrict__ plan, uint32_t stride,
                                                        FrameInfo *__restrict__ info)
 {
@@ -960,12 +1045,14 @@ __global__ __launch_bounds__(64) void pack_plan_kernel(const DevParams P, uint32
 	}
 	else if(P.ms_mode == 2) ca = dec[0].which >= 2 ? 3 : 0;
 	PackHead *H = (PackHead *)(plan + (size_t)f * stride);
-	if(live && j == 0) {
-		uint32_t hw[4];
-		const uint32_t nb = frame_header_words(P, N, ca, (uint32_t)(first_frame_number + f), hw);
-		*(uint4 *)H->hw = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-		*(uint4 *)&H->hdr_bytes = make_uint4(nb, ca, 0u, 0u);
-		if(info) info[f].channel_assignment = (uint8_t)ca;
+	{
+		uint32_t nb;
+		const uint32_t word = frame_header_lanes(hc, C, ca, (uint32_t)(first_frame_number + f), j, nb);
+		if(live && (j & 3) == 0) H->hw[j >> 2] = word;
+		if(live && j == 0) {
+			*(uint4 *)&H->hdr_bytes = make_uint4(nb, ca, 0u, 0u);
+			if(info) info[f].channel_assignment = (uint8_t)ca;
+		}
 	}
 	PackSub *S = (PackSub *)(H + 1);
 #pragma unroll 1
@@ -1012,7 +1099,7 @@ __global__ __launch_bounds__(64) void pack_plan_kernel(const DevParams P, uint32
 				*(uint4 *)&S->di = make_uint4(di, type, order, wasted);
 				*(uint4 *)&S->sbps = make_uint4(sbps, smask, d->fmt == 1 ? 1u : 0u, (uint32_t)shift);
 				*(uint4 *)&S->fmode = make_uint4((uint32_t)fir_mode(wide ? 1u : 0u, sbps), po, rice2, type_bits | (wasted ? 1u : 0u));
-				*(uint4 *)&S->constant = make_uint4((uint32_t)d->constant & smask, b_bits, d->bits, 0u);
+				*(uint4 *)&S->constant = make_uint4((uint32_t)d->constant & smask, b_bits, d->bits, 0xffffffffu / umax32(N >> (po & 15u), 1u) + 1u);
 				if(info) {
 					flacgpu_subframe_info *si = &info[f].sub[s];
 					si->type = (uint8_t)type; si->order = (uint8_t)order; si->wasted_bits = (uint8_t)wasted;
@@ -1171,7 +1258,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 #pragma unroll
 			for(int pp = 0; pp < 8; pp++) QP[pp] = 2 * pp < MAXORD ? d->QP[pp] : 0u;
 			const int32_t *q = d->q;
-			const uint32_t psize = n >> po;
+			const uint32_t psize = n >> po, inv_psize = d->inv_psize;
 			PSTAMP(2 + 4 * s);
 			for(uint32_t base0 = 0; base0 < n; base0 += RUN * NT) {
 				// (a thread without a run in this pass -- block sizes that are not a multiple of the workgroup's samples -- computes the
@@ -1246,7 +1333,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel( 
 						else pack_fir_i32<MAXORD, 2, RUN>(x, q, shift, r);
 					}
 					// Rice code sizes: the whole run lies in one partition (partition sizes are multiples of 16)
-					const uint32_t part = base / psize;
+					const uint32_t part = __umulhi(base, inv_psize);        // = base / psize
 					k = rice_params[part];
 					starts = base == part * psize;
 					if(starts) mybits = plen;
@@ -2179,7 +2266,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			// counts in 16-sample runs; FLACGPU_NO_RUN18=1: the 128-thread instance, for A/B runs)
 			static const bool no_run18 = getenv("FLACGPU_NO_RUN18") != nullptr;
 			const uint32_t pstride = (uint32_t)pack_plan_stride(P);
-			if(f_lo) hipLaunchKernelGGL(pack_plan_kernel, dim3((f_lo + PLAN_FRAMES - 1) / PLAN_FRAMES), dim3(64), 0, s, P, f_lo, first, dec, plan, pstride, info);
+			if(f_lo) hipLaunchKernelGGL(pack_plan_kernel, dim3((f_lo + PLAN_FRAMES - 1) / PLAN_FRAMES), dim3(64), 0, s, P, make_hdr_const(P), f_lo, first, dec, plan, pstride, info);
 			const bool run18 = P.blocksize == 1152 && !hints && !no_run18 && (1152u >> P.max_po) % 18u == 0;
 			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
 			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
