@@ -36,7 +36,7 @@ RATE, BPS, CH = 44100, 16, 2
 FRAMES_PER_GPU = 16384         # 67.1 M inter-channel samples = 25 min of audio per GPU per step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # which kernels a phase of flacgpu_batch_phase_ms covers (the ones a workload does not launch are not in its counter pass)
-KERNEL_NAMES = {"prep": "ff_kernel+prep3_kernel+prep2_kernel+prep_kernel", "autoc": "autoc2_kernel+autoc_kernel", "model": "model_kernel",
+KERNEL_NAMES = {"prep": "ff_kernel+prep3_kernel+prep2_kernel+prep_kernel", "autoc": "autoc3_kernel+autoc2_kernel+autoc_kernel", "model": "model_kernel",
                 "eval": "evalg_kernel+evalw_kernel+eval_list_kernel+eval_kernel", "pack": "pack2_kernel+pack_plan_kernel+fo_place_kernel+pack_kernel", "scan_compact": "scan_kernel+compact_kernel"}
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md: 2.4 GHz peak engine clock.  A SIMD issues one wave64 VALU instruction per 4 cycles
 VALU_ISSUE_PEAK = SIMDS * CLOCK_GHZ / 4      # G wavefront-instructions per second, the whole chip

@@ -292,6 +292,183 @@ __global__ __launch_bounds__(TPB, (VARIANT == 8 && SRC != 0) ? 4 : AUTOC2_WAVES_
 #undef A2_STEP
 #undef A2_PAIR
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// autoc3_kernel: the same routine with a lane per SUBFRAME (round 4).  The four vector lanes l of the reference's accumulators
+// (above: four GPU lanes of a quartet, each converting and reading the same floats again) are one GPU lane's acc[lag][l]: a sample
+// is read from LDS and converted to fp64 ONCE per subframe, not once per l -- a quarter of the conversions and LDS reads, and the
+// fill of the tile (wasted-bits shift, int -> float, window multiply) is a quarter per lane of compute as well.  Same operations
+// on the same values in the same order per accumulator; 23 % fewer instructions per sample.
+// A wavefront takes one window job of 64 consecutive subframes = 16 stereo frames x {L, R, M, S}; its tile holds 32 new samples
+// per subframe (row stride 41 words: the 64 lanes reading "their" sample hit 32 banks twice), the history of a lag chain stays
+// in registers.  Two wavefronts per SIMD (104 registers of accumulators + 88 of window), each with 52 independent chains.
+// Stereo with a full mid/side search only (every preset from -5 up on stereo input); the other sources keep autoc2_kernel.
+constexpr int A3_T = 32;             // new samples per tile = 4 chain steps
+constexpr int A3_ST = 41;            // words per subframe row (>= 40: head + tail of the finish)
+constexpr int A3_ITEMS = 64;         // subframes per wavefront
+struct A3Fetch { int2 v[8]; float wt; };
+__device__ __forceinline__ void a3_fetch(const A2Job &J, const int2 *__restrict__ pcm2, uint32_t N, uint32_t f0, uint32_t nmain, uint32_t half, int32_t i, A3Fetch &F)
+{
+	uint32_t src;
+	a2_index(J, i, src, F.wt);
+#pragma unroll
+	for(int q = 0; q < 8; q++) {
+		const uint32_t fr = f0 + 2u * (uint32_t)q + half, f = fr < nmain ? fr : nmain - 1;
+		F.v[q] = pcm2[(size_t)f * N + src];
+	}
+}
+// any_wasted: some subframe of the wavefront has wasted bits (wave-uniform; without, the shifts and their counts are not issued)
+__device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /* [16]: the four wasted-bits counts of a frame, a byte each */, bool any_wasted, uint32_t half, const A3Fetch &F, uint32_t col)
+{
+	if(any_wasted) {
+#pragma unroll
+		for(int q = 0; q < 8; q++) {
+			const uint32_t fr = 2u * (uint32_t)q + half, w4 = wasted4[fr];
+			const int32_t l = F.v[q].x, r = F.v[q].y;
+			float *row = tile + fr * 4u * A3_ST + col;
+			row[0 * A3_ST] = a2_value(l, w4 & 0xffu, F.wt);
+			row[1 * A3_ST] = a2_value(r, (w4 >> 8) & 0xffu, F.wt);
+			row[2 * A3_ST] = a2_value((l + r) >> 1, (w4 >> 16) & 0xffu, F.wt);
+			row[3 * A3_ST] = a2_value(l - r, w4 >> 24, F.wt);
+		}
+	}
+	else {
+#pragma unroll
+		for(int q = 0; q < 8; q++) {
+			const uint32_t fr = 2u * (uint32_t)q + half;
+			const int32_t l = F.v[q].x, r = F.v[q].y;
+			float *row = tile + fr * 4u * A3_ST + col;
+			row[0 * A3_ST] = a2_value(l, 0u, F.wt);
+			row[1 * A3_ST] = a2_value(r, 0u, F.wt);
+			row[2 * A3_ST] = a2_value((l + r) >> 1, 0u, F.wt);
+			row[3 * A3_ST] = a2_value(l - r, 0u, F.wt);
+		}
+	}
+}
+// one chain step (lpc_intrin_fma.c:46,61) / two steps of the lag-12 routine as compiled (:54), for the four vector lanes l:
+// W(c) = d[first sample of the step + c] of this lane's subframe
+#define A3_STEP(c) _Pragma("unroll") for(int l = 0; l < 4; l++) { _Pragma("unroll") for(int j = 0; j < LAG; j++) \
+		acc[j][l] += fma(w[HB + (c) + l], w[HB + (c) + l - j], w[HB + (c) + l + 4] * w[HB + (c) + l + 4 - j]); }
+#define A3_PAIR(c) _Pragma("unroll") for(int l = 0; l < 4; l++) { _Pragma("unroll") for(int j = 0; j < LAG; j++) { \
+		if(j == 8) acc[j][l] += fma(w[HB + (c) + l], (w[HB + (c) + l - 8] + w[HB + (c) + l + 8]), w[HB + (c) + l + 4] * (w[HB + (c) + l - 4] + w[HB + (c) + l + 12])); \
+		else { const double t0 = fma(w[HB + (c) + l], w[HB + (c) + l - j], w[HB + (c) + l + 4] * w[HB + (c) + l + 4 - j]); \
+		       const double t1 = fma(w[HB + (c) + l + 8], w[HB + (c) + l + 8 - j], w[HB + (c) + l + 12] * w[HB + (c) + l + 12 - j]); acc[j][l] += (t1 + t0); } } }
+
+template <int VARIANT, int LAG>
+__global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
+                                                       uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
+                                                       double *__restrict__ autoc_out)
+{
+	__shared__ float tile[A3_ITEMS * A3_ST];
+	__shared__ uint32_t wasted4[A3_ITEMS / 4];
+	const int lane = (int)threadIdx.x;
+	const uint32_t nfc = nmain * 4u, ngroups = (nfc + A3_ITEMS - 1) / A3_ITEMS;
+	// jobs are enumerated longest first (whole block, halves, thirds ...): the long wavefronts start first
+	const uint32_t jb = blockIdx.x / ngroups, fc0 = (blockIdx.x - jb * ngroups) * A3_ITEMS, f0 = fc0 / 4u;
+	const uint32_t N = P.blocksize;
+	constexpr uint32_t L = VARIANT;
+	constexpr int HB = LAG - 1;
+	const uint32_t fc = fc0 + (uint32_t)lane;
+	bool any_wasted;
+	{
+		const ChanPrep pr = preps[fc < nfc ? fc : nfc - 1];
+		((uint8_t *)wasted4)[lane] = (uint8_t)pr.wasted;
+		if(!__any((int)(pr.flags & PREP_LPC))) return;             // 64 constant subframes: nothing to analyse
+		any_wasted = __any((int)(pr.wasted != 0)) != 0;
+	}
+	const uint32_t half = (uint32_t)lane >> 5, sl = (uint32_t)lane & 31u;
+	const int2 *pcm2 = (const int2 *)pcm;
+	const float *row = tile + lane * A3_ST;
+	__builtin_amdgcn_wave_barrier();
+
+	const WindowJob jv = jt->jobs[jb];
+	A2Job J;
+	J.w = windows + (size_t)jv.apod * N;
+	J.n = N; J.nd = jv.nd; J.full = jv.full; J.part = jv.part; J.dshift = jv.dshift; J.i0 = jv.i0;
+	const uint32_t nd = jv.nd;
+	const uint32_t nb = (nd - L) / 8;
+	const uint32_t npairs12 = nb > 2 ? ((nb - 3) & ~1u) / 2 + 1 : 0;
+	const uint32_t ntiles = (nb + 3) / 4;
+
+	double acc[LAG][4];
+#pragma unroll
+	for(int j = 0; j < LAG; j++) { acc[j][0] = 0.0; acc[j][1] = 0.0; acc[j][2] = 0.0; acc[j][3] = 0.0; }
+	double w[HB + A3_T];              // w[HB + c] = d[first sample of the tile + c]
+	A3Fetch F;
+	// the samples in front of the first step: d[L - 16, L)
+	a3_fetch(J, pcm2, N, f0, nmain, half, (int32_t)L - 16 + (int32_t)(sl & 15u), F);
+	if(sl < 16) a3_store(tile, wasted4, any_wasted, half, F, sl);
+	a3_fetch(J, pcm2, N, f0, nmain, half, (int32_t)L + (int32_t)sl, F);
+	__builtin_amdgcn_wave_barrier();
+#pragma unroll
+	for(int u = 0; u < HB; u++) w[A3_T + u] = (double)row[16 - HB + u];
+	for(uint32_t t = 0; t < ntiles; t++) {
+		__builtin_amdgcn_wave_barrier();
+		a3_store(tile, wasted4, any_wasted, half, F, sl);
+		if(t + 1 < ntiles) a3_fetch(J, pcm2, N, f0, nmain, half, (int32_t)(L + A3_T * (t + 1)) + (int32_t)sl, F);
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for(int u = 0; u < HB; u++) w[u] = w[A3_T + u];
+#pragma unroll
+		for(int u = 0; u < A3_T; u++) w[HB + u] = (double)row[u];
+		const uint32_t k0 = 4 * t;
+		const uint32_t ksteps = nb - k0 < 4 ? nb - k0 : 4;
+		if(VARIANT == 12) {
+#pragma unroll
+			for(int kk = 0; kk < 4; kk += 2) {
+				if((uint32_t)kk + 2 <= ksteps && k0 + (uint32_t)kk + 2 <= 2 * npairs12) { A3_PAIR(8 * kk); }
+				else {
+					if((uint32_t)kk < ksteps) { A3_STEP(8 * kk); }
+					if((uint32_t)kk + 1 < ksteps) { A3_STEP(8 * kk + 8); }
+				}
+			}
+		}
+		else {
+#pragma unroll
+			for(int kk = 0; kk < 4; kk++) if((uint32_t)kk < ksteps) { A3_STEP(8 * kk); }
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+
+	// ---- head d[0,16) and tail d[nd-24, nd) of every subframe as plain copies (the tile is dead now) --------------
+	const uint32_t tail_lo = nd - 24;               // nd > 32
+	{
+		a3_fetch(J, pcm2, N, f0, nmain, half, sl < 16 ? (int32_t)sl : (int32_t)(tail_lo + (sl - 16)), F);
+		a3_store(tile, wasted4, any_wasted, half, F, sl);
+		a3_fetch(J, pcm2, N, f0, nmain, half, (int32_t)(tail_lo + 16 + (sl & 7u)), F);
+		if(sl < 8) a3_store(tile, wasted4, any_wasted, half, F, 32 + sl);
+	}
+	__builtin_amdgcn_wave_barrier();
+	const uint32_t max_lpc = P.max_lpc_order >= N ? N - 1 : P.max_lpc_order;
+	const uint32_t lag = max_lpc + 1;
+	double *out = autoc_out + ((size_t)(fc < nfc ? fc : nfc - 1) * P.max_jobs + jb) * AUTOC_STRIDE;
+#pragma unroll
+	for(int j = 0; j < LAG; j++) {
+		if((uint32_t)j < lag) {
+			const double a4[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+			const double r = autoc_finish2(row, row + 16, tail_lo, nd, L, (uint32_t)j, a4);
+			if(fc < nfc) out[j] = r;
+		}
+	}
+}
+#undef A3_STEP
+#undef A3_PAIR
+
+// the lane-per-subframe kernel: stereo with a full mid/side search, and enough subframes for two wavefronts per SIMD
+static bool autoc3_wanted(const DevParams &P, uint32_t nmain, uint32_t njobs)
+{
+	static int mode = -1;
+	if(mode < 0) { const char *e = getenv("FLACGPU_AUTOC3"); mode = e ? atoi(e) : 2; }      // 0: never, 1: whenever it applies, 2: when it fills the chip
+	if(mode == 0 || !(P.channels == 2 && P.ms_mode == 1 && P.ncand == 4) || P.blocksize < 64) return false;
+	const uint32_t waves = njobs * ((nmain * 4u + A3_ITEMS - 1) / A3_ITEMS);
+	return mode == 1 || waves >= 2048u;
+}
+template <int VARIANT, int LAG>
+static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s)
+{
+	const uint32_t ngroups = (nmain * 4u + A3_ITEMS - 1) / A3_ITEMS;
+	hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG>), dim3(njobs * ngroups), dim3(64), 0, s, P, pcm, win, nmain, jt, preps, autoc);
+}
+
 template <int VARIANT, int LAG>
 static void launch_autoc2_t(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
                             const ChanPrep *preps, double *autoc, hipStream_t s)
@@ -324,6 +501,13 @@ hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *wi
 	if(nmain == 0 || njobs == 0) return hipSuccess;
 	const uint32_t max_lpc = P.max_lpc_order >= P.blocksize ? P.blocksize - 1 : P.max_lpc_order;
 	const uint32_t lag = max_lpc + 1;
+	// (lags 10..12 of the lag-12 routine and 14..16 of the lag-16 one would spill: they stay with autoc2_kernel)
+	if(autoc3_wanted(P, nmain, njobs) && (P.autoc_variant == 8 || (P.autoc_variant == 12 && lag <= 9) || (P.autoc_variant == 16 && lag <= 13))) {
+		if(P.autoc_variant == 8) launch_autoc3_t<8, 8>(P, pcm, win, nmain, njobs, jt, preps, autoc, s);
+		else if(P.autoc_variant == 12) launch_autoc3_t<12, 9>(P, pcm, win, nmain, njobs, jt, preps, autoc, s);
+		else launch_autoc3_t<16, 13>(P, pcm, win, nmain, njobs, jt, preps, autoc, s);
+		return hipGetLastError();
+	}
 	if(P.autoc_variant == 8) launch_autoc2_t<8, 8>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);
 	else if(P.autoc_variant == 12) { if(lag <= 9) launch_autoc2_t<12, 9>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s); else launch_autoc2_t<12, 12>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s); }
 	else { if(lag <= 13) launch_autoc2_t<16, 13>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s); else launch_autoc2_t<16, 16>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s); }
