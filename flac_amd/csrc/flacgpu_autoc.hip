@@ -353,7 +353,12 @@ __device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /*
 		else { const double t0 = fma(w[HB + (c) + l], w[HB + (c) + l - j], w[HB + (c) + l + 4] * w[HB + (c) + l + 4 - j]); \
 		       const double t1 = fma(w[HB + (c) + l + 8], w[HB + (c) + l + 8 - j], w[HB + (c) + l + 12] * w[HB + (c) + l + 12 - j]); acc[j][l] += (t1 + t0); } } }
 
-template <int VARIANT, int LAG>
+// SETS: a wavefront takes a window-job SET (the whole block | the halves | the thirds: each covers the block once, JobTable) and
+// the sets of a group of subframes are consecutive workgroups of the same XCD that sweep the block side by side, as in
+// autoc2_kernel<..., GROUPED>: a PCM line is fetched from HBM once and found in that XCD's L2 by the other sets.  Without: a
+// wavefront per job (twice the wavefronts, half as long: the chip's two-per-SIMD slots fill evenly, and every job fetches its own
+// lines -- 75 KB per frame instead of 42).
+template <int VARIANT, int LAG, bool SETS>
 __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
                                                        uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
                                                        double *__restrict__ autoc_out)
@@ -362,8 +367,23 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 	__shared__ uint32_t wasted4[A3_ITEMS / 4];
 	const int lane = (int)threadIdx.x;
 	const uint32_t nfc = nmain * 4u, ngroups = (nfc + A3_ITEMS - 1) / A3_ITEMS;
-	// jobs are enumerated longest first (whole block, halves, thirds ...): the long wavefronts start first
-	const uint32_t jb = blockIdx.x / ngroups, fc0 = (blockIdx.x - jb * ngroups) * A3_ITEMS, f0 = fc0 / 4u;
+	uint32_t jb_lo, jb_hi, fc0;
+	if(SETS) {
+		const uint32_t nsets = jt->nsets, b = blockIdx.x;
+		const uint32_t per_xcd = (ngroups / 8) * nsets, head = per_xcd * 8;      // blocks every XCD gets in full
+		uint32_t group, set;
+		if(b < head) { const uint32_t slot = b >> 3; group = (slot / nsets) * 8 + (b & 7); set = slot % nsets; }
+		else { const uint32_t r = b - head; group = (ngroups / 8) * 8 + r / nsets; set = r % nsets; }
+		if(group >= ngroups) return;
+		fc0 = group * A3_ITEMS;
+		jb_lo = jt->set_first[set]; jb_hi = jb_lo + jt->set_count[set];
+	}
+	else {
+		// jobs are enumerated longest first (whole block, halves, thirds ...): the long wavefronts start first
+		jb_lo = blockIdx.x / ngroups; jb_hi = jb_lo + 1;
+		fc0 = (blockIdx.x - jb_lo * ngroups) * A3_ITEMS;
+	}
+	const uint32_t f0 = fc0 / 4u;
 	const uint32_t N = P.blocksize;
 	constexpr uint32_t L = VARIANT;
 	constexpr int HB = LAG - 1;
@@ -380,6 +400,8 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 	const float *row = tile + lane * A3_ST;
 	__builtin_amdgcn_wave_barrier();
 
+#pragma unroll 1
+	for(uint32_t jb = jb_lo; jb < jb_hi; jb++) {
 	const WindowJob jv = jt->jobs[jb];
 	A2Job J;
 	J.w = windows + (size_t)jv.apod * N;
@@ -449,6 +471,8 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 			if(fc < nfc) out[j] = r;
 		}
 	}
+	__builtin_amdgcn_wave_barrier();          // the tile is reused by the next job of this wavefront
+	}
 }
 #undef A3_STEP
 #undef A3_PAIR
@@ -463,10 +487,13 @@ static bool autoc3_wanted(const DevParams &P, uint32_t nmain, uint32_t njobs)
 	return mode == 1 || waves >= 2048u;
 }
 template <int VARIANT, int LAG>
-static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s)
+static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s)
 {
 	const uint32_t ngroups = (nmain * 4u + A3_ITEMS - 1) / A3_ITEMS;
-	hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG>), dim3(njobs * ngroups), dim3(64), 0, s, P, pcm, win, nmain, jt, preps, autoc);
+	static int sets = -1;
+	if(sets < 0) { const char *e = getenv("FLACGPU_AUTOC3_SETS"); sets = e ? atoi(e) : 1; }
+	if(sets && nsets >= 2 && nsets <= 8) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true>), dim3(nsets * ngroups), dim3(64), 0, s, P, pcm, win, nmain, jt, preps, autoc);
+	else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false>), dim3(njobs * ngroups), dim3(64), 0, s, P, pcm, win, nmain, jt, preps, autoc);
 }
 
 template <int VARIANT, int LAG>
@@ -503,9 +530,9 @@ hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *wi
 	const uint32_t lag = max_lpc + 1;
 	// (lags 10..12 of the lag-12 routine and 14..16 of the lag-16 one would spill: they stay with autoc2_kernel)
 	if(autoc3_wanted(P, nmain, njobs) && (P.autoc_variant == 8 || (P.autoc_variant == 12 && lag <= 9) || (P.autoc_variant == 16 && lag <= 13))) {
-		if(P.autoc_variant == 8) launch_autoc3_t<8, 8>(P, pcm, win, nmain, njobs, jt, preps, autoc, s);
-		else if(P.autoc_variant == 12) launch_autoc3_t<12, 9>(P, pcm, win, nmain, njobs, jt, preps, autoc, s);
-		else launch_autoc3_t<16, 13>(P, pcm, win, nmain, njobs, jt, preps, autoc, s);
+		if(P.autoc_variant == 8) launch_autoc3_t<8, 8>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);
+		else if(P.autoc_variant == 12) launch_autoc3_t<12, 9>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);
+		else launch_autoc3_t<16, 13>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);
 		return hipGetLastError();
 	}
 	if(P.autoc_variant == 8) launch_autoc2_t<8, 8>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);

@@ -755,3 +755,35 @@ def test_ff_kernel_places_the_frames_of_some_frames_ago(lag):
     """FLACGPU_FF_LAG=n (opt-in, launch_ff): ff_kernel publishes its lengths and the wavefront of frame f copies frame f - n from its
     slot to its place; the last n frames (n = 0, or a batch of no more than n frames: all of them) are fo_place_kernel's."""
     _fresh_interpreter_cases({"FLACGPU_FF_LAG": str(lag)}, "((0, 1152, 5000, 5), (1, 1152, 900, 9), (2, 1152, 1500, 6))")
+
+
+def test_autoc3_kernel_a_lane_per_subframe():
+    """FLACGPU_AUTOC3=1 (flacgpu_autoc.hip: autoc3_kernel whenever it applies, not only from 2048 wavefronts up -- the batch sizes of
+    the tests are far below): stereo with a mid/side search, the three routines it instantiates (lag 8: -l 6; lag 12: -5; lag 16:
+    -8), whole and partial windows, block sizes whose job lengths leave 1..3 chain steps in the last tile, wasted bits in one and in
+    all channels, a pure tone (the ill-conditioned case that pins the association order), 24-bit samples, frame counts that do not
+    fill the last wavefront's sixteen frames.  Same bytes as the oracle."""
+    import subprocess, sys
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, flac_amd, signals\n"
+            "from oracle import pyoracle as po\n"
+            "def run(pcm, bps, level, ekw={}, okw={}):\n"
+            "    eng = flac_amd.FrameEngine(flac_amd.make_settings(2, bps, 44100, level, **ekw), device=0, max_batch_frames=64)\n"
+            "    data, fb = eng.encode(pcm); eng.close()\n"
+            "    o = po.oracle_encode(pcm, bps, 44100, level, **okw)\n"
+            "    assert data == o['data'], (level, ekw)\n"
+            "for level in (5, 8):\n"
+            "    for bs, nfr in ((4096, 37), (4608, 21), (1152, 50), (576, 19), (4000, 17)):\n"
+            "        run(signals.music(bs * nfr + 77, 2, 16, seed=bs + level), 16, level, dict(blocksize=bs), dict(blocksize=bs))\n"
+            "    run(signals.wasted(4096 * 18, 2, 16), 16, level)\n"
+            "    w = signals.music(4096 * 18, 2, 16, seed=3); w[:, 0] = (w[:, 0] >> 2) << 2\n"
+            "    run(w, 16, level)\n"
+            "    run(signals.sine(4096 * 20, 2, 16, freq=1000.0), 16, level)\n"
+            "    run(signals.slow(4096 * 18, 2, 24), 24, level)\n"
+            "run(signals.music(4096 * 33, 2, 16, seed=11), 16, 8, dict(max_lpc_order=6), dict(max_lpc_order=6))\n"
+            "run(signals.music(4096 * 33, 2, 16, seed=12), 16, 8, dict(apodization='subdivide_tukey(2)'), dict(apod=('subdivide_tukey', 2)))\n"
+            "run(signals.music(4096 * 33, 2, 16, seed=14), 16, 5, dict(apodization='subdivide_tukey(5)'), dict(apod=('subdivide_tukey', 5)))\n"
+            "run(signals.music(4096 * 33, 2, 16, seed=13), 16, 3, dict(mid_side=1, loose_mid_side=0), dict(mid_side=1, loose=0))\n"
+            "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLACGPU_AUTOC3="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
