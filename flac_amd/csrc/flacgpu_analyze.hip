@@ -1476,7 +1476,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 		const bool use2 = force == 2 || (force == 0 && waves2 >= (ms4 ? 640u : 2048u));
 		if(autoc2_applicable(P) && use2) {
 			f_lo = tail_n ? nframes - 1 : nframes;
-			const hipError_t e = launch_autoc2(P, pcm, win, f_lo, P.max_jobs, nsets_main, jtm, B.prep, B.autoc, s);
+			const hipError_t e = launch_autoc2(P, pcm, B.chan, win, f_lo, P.max_jobs, nsets_main, jtm, B.prep, B.autoc, s);
 			if(e != hipSuccess) return e;
 		}
 		if(f_lo < nframes) {

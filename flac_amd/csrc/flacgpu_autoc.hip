@@ -306,6 +306,9 @@ constexpr int A3_T = 32;             // new samples per tile = 4 chain steps
 constexpr int A3_ST = 41;            // words per subframe row (>= 40: head + tail of the finish)
 constexpr int A3_ITEMS = 64;         // subframes per wavefront
 struct A3Fetch { int2 v[8]; float wt; };
+// PLANES: left and right come from the planar channels the prep kernel left behind (16-bit input: 16-bit pairs, wasted bits
+// shifted out -- a quarter of the interleaved 32-bit PCM's bytes per frame and sweep) instead of from the PCM
+template <bool PLANES>
 __device__ __forceinline__ void a3_fetch(const A2Job &J, const int2 *__restrict__ pcm2, uint32_t N, uint32_t f0, uint32_t nmain, uint32_t half, int32_t i, A3Fetch &F)
 {
 	uint32_t src;
@@ -313,17 +316,23 @@ __device__ __forceinline__ void a3_fetch(const A2Job &J, const int2 *__restrict_
 #pragma unroll
 	for(int q = 0; q < 8; q++) {
 		const uint32_t fr = f0 + 2u * (uint32_t)q + half, f = fr < nmain ? fr : nmain - 1;
-		F.v[q] = pcm2[(size_t)f * N + src];
+		if(PLANES) {
+			const int16_t *pl = (const int16_t *)((const int32_t *)pcm2 + (size_t)f * 4u * N);      // (pcm2: the planar channels here)
+			F.v[q] = make_int2((int)pl[src], (int)pl[2u * N + src]);
+		}
+		else F.v[q] = pcm2[(size_t)f * N + src];
 	}
 }
 // any_wasted: some subframe of the wavefront has wasted bits (wave-uniform; without, the shifts and their counts are not issued)
+template <bool PLANES>
 __device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /* [16]: the four wasted-bits counts of a frame, a byte each */, bool any_wasted, uint32_t half, const A3Fetch &F, uint32_t col)
 {
 	if(any_wasted) {
 #pragma unroll
 		for(int q = 0; q < 8; q++) {
 			const uint32_t fr = 2u * (uint32_t)q + half, w4 = wasted4[fr];
-			const int32_t l = F.v[q].x, r = F.v[q].y;
+			// (a plane's samples come without their channel's wasted bits: put the zeros back for mid and side)
+			const int32_t l = PLANES ? (int32_t)((uint32_t)F.v[q].x << (w4 & 0xffu)) : F.v[q].x, r = PLANES ? (int32_t)((uint32_t)F.v[q].y << ((w4 >> 8) & 0xffu)) : F.v[q].y;
 			float *row = tile + fr * 4u * A3_ST + col;
 			row[0 * A3_ST] = a2_value(l, w4 & 0xffu, F.wt);
 			row[1 * A3_ST] = a2_value(r, (w4 >> 8) & 0xffu, F.wt);
@@ -358,7 +367,7 @@ __device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /*
 // autoc2_kernel<..., GROUPED>: a PCM line is fetched from HBM once and found in that XCD's L2 by the other sets.  Without: a
 // wavefront per job (twice the wavefronts, half as long: the chip's two-per-SIMD slots fill evenly, and every job fetches its own
 // lines -- 75 KB per frame instead of 42).
-template <int VARIANT, int LAG, bool SETS>
+template <int VARIANT, int LAG, bool SETS, bool PLANES>
 __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
                                                        uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
                                                        double *__restrict__ autoc_out)
@@ -417,16 +426,16 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 	double w[HB + A3_T];              // w[HB + c] = d[first sample of the tile + c]
 	A3Fetch F;
 	// the samples in front of the first step: d[L - 16, L)
-	a3_fetch(J, pcm2, N, f0, nmain, half, (int32_t)L - 16 + (int32_t)(sl & 15u), F);
-	if(sl < 16) a3_store(tile, wasted4, any_wasted, half, F, sl);
-	a3_fetch(J, pcm2, N, f0, nmain, half, (int32_t)L + (int32_t)sl, F);
+	a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (int32_t)L - 16 + (int32_t)(sl & 15u), F);
+	if(sl < 16) a3_store<PLANES>(tile, wasted4, any_wasted, half, F, sl);
+	a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (int32_t)L + (int32_t)sl, F);
 	__builtin_amdgcn_wave_barrier();
 #pragma unroll
 	for(int u = 0; u < HB; u++) w[A3_T + u] = (double)row[16 - HB + u];
 	for(uint32_t t = 0; t < ntiles; t++) {
 		__builtin_amdgcn_wave_barrier();
-		a3_store(tile, wasted4, any_wasted, half, F, sl);
-		if(t + 1 < ntiles) a3_fetch(J, pcm2, N, f0, nmain, half, (int32_t)(L + A3_T * (t + 1)) + (int32_t)sl, F);
+		a3_store<PLANES>(tile, wasted4, any_wasted, half, F, sl);
+		if(t + 1 < ntiles) a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (int32_t)(L + A3_T * (t + 1)) + (int32_t)sl, F);
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll
 		for(int u = 0; u < HB; u++) w[u] = w[A3_T + u];
@@ -454,10 +463,10 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 	// ---- head d[0,16) and tail d[nd-24, nd) of every subframe as plain copies (the tile is dead now) --------------
 	const uint32_t tail_lo = nd - 24;               // nd > 32
 	{
-		a3_fetch(J, pcm2, N, f0, nmain, half, sl < 16 ? (int32_t)sl : (int32_t)(tail_lo + (sl - 16)), F);
-		a3_store(tile, wasted4, any_wasted, half, F, sl);
-		a3_fetch(J, pcm2, N, f0, nmain, half, (int32_t)(tail_lo + 16 + (sl & 7u)), F);
-		if(sl < 8) a3_store(tile, wasted4, any_wasted, half, F, 32 + sl);
+		a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, sl < 16 ? (int32_t)sl : (int32_t)(tail_lo + (sl - 16)), F);
+		a3_store<PLANES>(tile, wasted4, any_wasted, half, F, sl);
+		a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (int32_t)(tail_lo + 16 + (sl & 7u)), F);
+		if(sl < 8) a3_store<PLANES>(tile, wasted4, any_wasted, half, F, 32 + sl);
 	}
 	__builtin_amdgcn_wave_barrier();
 	const uint32_t max_lpc = P.max_lpc_order >= N ? N - 1 : P.max_lpc_order;
@@ -487,13 +496,22 @@ static bool autoc3_wanted(const DevParams &P, uint32_t nmain, uint32_t njobs)
 	return mode == 1 || waves >= 2048u;
 }
 template <int VARIANT, int LAG>
-static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s)
+static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const int32_t *chan, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s)
 {
 	const uint32_t ngroups = (nmain * 4u + A3_ITEMS - 1) / A3_ITEMS;
 	static int sets = -1;
 	if(sets < 0) { const char *e = getenv("FLACGPU_AUTOC3_SETS"); sets = e ? atoi(e) : 1; }
-	if(sets && nsets >= 2 && nsets <= 8) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true>), dim3(nsets * ngroups), dim3(64), 0, s, P, pcm, win, nmain, jt, preps, autoc);
-	else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false>), dim3(njobs * ngroups), dim3(64), 0, s, P, pcm, win, nmain, jt, preps, autoc);
+	// 16-bit input: the prep kernel's left and right planes are 16-bit pairs (ChanPrep::fmt = 1 whenever sbps <= 16) -- read those
+	static int planes = -1;
+	if(planes < 0) { const char *e = getenv("FLACGPU_AUTOC3_PLANES"); planes = e ? atoi(e) : 1; }
+	const bool pl = planes && chan && P.bps <= 16;
+	const int32_t *src = pl ? chan : pcm;
+	if(sets && nsets >= 2 && nsets <= 8) {
+		if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, true>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
+		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, false>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
+	}
+	else if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, true>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
+	else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, false>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
 }
 
 template <int VARIANT, int LAG>
@@ -522,7 +540,7 @@ static void launch_autoc2_t(const DevParams &P, const int32_t *pcm, const float 
 // true when the streaming kernel serves the nominal-length frames of this configuration
 bool autoc2_applicable(const DevParams &P) { return P.blocksize > 32 && P.max_lpc_order > 0 && P.autoc_variant != 0 && !P.wide_samples; }
 
-hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
+hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const int32_t *chan, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
                          const ChanPrep *preps, double *autoc, hipStream_t s)
 {
 	if(nmain == 0 || njobs == 0) return hipSuccess;
@@ -530,9 +548,9 @@ hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *wi
 	const uint32_t lag = max_lpc + 1;
 	// (lags 10..12 of the lag-12 routine and 14..16 of the lag-16 one would spill: they stay with autoc2_kernel)
 	if(autoc3_wanted(P, nmain, njobs) && (P.autoc_variant == 8 || (P.autoc_variant == 12 && lag <= 9) || (P.autoc_variant == 16 && lag <= 13))) {
-		if(P.autoc_variant == 8) launch_autoc3_t<8, 8>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);
-		else if(P.autoc_variant == 12) launch_autoc3_t<12, 9>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);
-		else launch_autoc3_t<16, 13>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);
+		if(P.autoc_variant == 8) launch_autoc3_t<8, 8>(P, pcm, chan, win, nmain, njobs, nsets, jt, preps, autoc, s);
+		else if(P.autoc_variant == 12) launch_autoc3_t<12, 9>(P, pcm, chan, win, nmain, njobs, nsets, jt, preps, autoc, s);
+		else launch_autoc3_t<16, 13>(P, pcm, chan, win, nmain, njobs, nsets, jt, preps, autoc, s);
 		return hipGetLastError();
 	}
 	if(P.autoc_variant == 8) launch_autoc2_t<8, 8>(P, pcm, win, nmain, njobs, nsets, jt, preps, autoc, s);

@@ -135,7 +135,8 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
                           uint32_t nframes, uint32_t tail_n, const JobTable *jt_main, const JobTable *jt_tail, uint32_t nsets_main /* JobTable::nsets of jt_main */, const AnalyzeBuffers &B,
                           SubDecision *dec, hipEvent_t *phase_ev /* [3]: after prep, autoc, model; may be null */, hipStream_t s);
 bool autoc2_applicable(const DevParams &P);
-hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
+// chan: the planar channels of the prep kernel (AnalyzeBuffers::chan), or null: autoc3_kernel reads left / right from them when they are 16-bit pairs
+hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const int32_t *chan, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
                          const ChanPrep *preps, double *autoc, hipStream_t s);
 bool evalg_applicable(const DevParams &P);
 hipError_t launch_evalg(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);

@@ -780,6 +780,9 @@ def test_autoc3_kernel_a_lane_per_subframe():
             "    run(w, 16, level)\n"
             "    run(signals.sine(4096 * 20, 2, 16, freq=1000.0), 16, level)\n"
             "    run(signals.slow(4096 * 18, 2, 24), 24, level)\n"
+            "    c = signals.music(4096 * 18, 2, 16, seed=5); c[:, 1] = 1234; c[4096 * 9:, 0] = -7\n"
+            "    run(c, 16, level)\n"
+            "    run(signals.mixed(4096 * 35 + 99, 2, 16), 16, level)\n"
             "run(signals.music(4096 * 33, 2, 16, seed=11), 16, 8, dict(max_lpc_order=6), dict(max_lpc_order=6))\n"
             "run(signals.music(4096 * 33, 2, 16, seed=12), 16, 8, dict(apodization='subdivide_tukey(2)'), dict(apod=('subdivide_tukey', 2)))\n"
             "run(signals.music(4096 * 33, 2, 16, seed=14), 16, 5, dict(apodization='subdivide_tukey(5)'), dict(apod=('subdivide_tukey', 5)))\n"
