@@ -6,8 +6,8 @@
 #   bench[:args]     bench.py [args] -> bench<i>.json          (":" separates, "," stands for a blank inside args)
 #   env:K=V          export K=V for the steps that follow (env:-K unsets)
 #   prof[:args]      rocprofv3 --kernel-trace --stats of bench.py --steps 5 --warmup 2 --no-cpu-baseline [args]
-#   pmc[:args]       the PMC passes (SQ instruction counters, FETCH_SIZE, WRITE_SIZE; 4096-frame launches; FLACGPU_AUTOC3=1: the
-#                    autocorrelation kernel of the full-size batch, whatever the launch size)
+#   pmc[:args]       the PMC passes (SQ instruction counters, FETCH_SIZE, WRITE_SIZE) at the bench's own batch size: the kernels
+#                    the bench line runs (launch_autoc2 picks by the number of wavefronts)
 #   ab:<rounds>[:args]  alternate flac_amd/lib (A) and build/alt_lib (B) engines, scripts/gpu_ab.sh
 #   sh:<file>        run another script of scripts/
 set -u
@@ -43,7 +43,7 @@ for step in "$@"; do
                  "SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE GRBM_COUNT" \
                  "FETCH_SIZE" "WRITE_SIZE"; do
         j=$((j+1))
-        FLACGPU_AUTOC3=1 timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$j -o p$j -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-verify --frames 4096 $arg > $OUT/pmc$j.json 2> $OUT/pmc$j.err
+        timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$j -o p$j -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-verify $arg > $OUT/pmc$j.json 2> $OUT/pmc$j.err
         echo "[$i] pmc pass $j rc=$? : $SET"
         DB=$(ls $OUT/pmc$j/*.db 2>/dev/null | head -1)
         [ -n "$DB" ] && python scripts/rocpd_pmc.py $DB >> $OUT/pmc_counters_$i.txt
