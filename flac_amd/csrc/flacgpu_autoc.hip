@@ -308,19 +308,29 @@ constexpr int A3_ITEMS = 64;         // subframes per wavefront
 struct A3Fetch { int2 v[8]; float wt; };
 // PLANES: left and right come from the planar channels the prep kernel left behind (16-bit input: 16-bit pairs, wasted bits
 // shifted out -- a quarter of the interleaved 32-bit PCM's bytes per frame and sweep) instead of from the PCM
+// (addresses: a wave-uniform base -- the group's first frame -- plus a 32-bit byte offset per lane, 16 frames at most: the loads
+//  take the scalar base and a one-register offset instead of 64-bit address arithmetic per load)
 template <bool PLANES>
 __device__ __forceinline__ void a3_fetch(const A2Job &J, const int2 *__restrict__ pcm2, uint32_t N, uint32_t f0, uint32_t nmain, uint32_t half, int32_t i, A3Fetch &F)
 {
 	uint32_t src;
 	a2_index(J, i, src, F.wt);
+	const uint32_t last = nmain - 1u - f0;                  // (f0 < nmain)
+	if(PLANES) {
+		const char *gl = (const char *)((const int32_t *)pcm2 + (size_t)f0 * 4u * N), *gr = gl + (size_t)N * 4u;      // (pcm2: the planar channels here)
 #pragma unroll
-	for(int q = 0; q < 8; q++) {
-		const uint32_t fr = f0 + 2u * (uint32_t)q + half, f = fr < nmain ? fr : nmain - 1;
-		if(PLANES) {
-			const int16_t *pl = (const int16_t *)((const int32_t *)pcm2 + (size_t)f * 4u * N);      // (pcm2: the planar channels here)
-			F.v[q] = make_int2((int)pl[src], (int)pl[2u * N + src]);
+		for(int q = 0; q < 8; q++) {
+			const uint32_t fr = umin32(2u * (uint32_t)q + half, last), off = fr * 16u * N + 2u * src;
+			F.v[q] = make_int2((int)*(const int16_t *)(gl + off), (int)*(const int16_t *)(gr + off));
 		}
-		else F.v[q] = pcm2[(size_t)f * N + src];
+	}
+	else {
+		const char *g = (const char *)(pcm2 + (size_t)f0 * N);
+#pragma unroll
+		for(int q = 0; q < 8; q++) {
+			const uint32_t fr = umin32(2u * (uint32_t)q + half, last), off = (fr * N + src) * 8u;
+			F.v[q] = *(const int2 *)(g + off);
+		}
 	}
 }
 // any_wasted: some subframe of the wavefront has wasted bits (wave-uniform; without, the shifts and their counts are not issued)
@@ -345,10 +355,12 @@ __device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /*
 		for(int q = 0; q < 8; q++) {
 			const uint32_t fr = 2u * (uint32_t)q + half;
 			const int32_t l = F.v[q].x, r = F.v[q].y;
+			int32_t lr = l + r;
+			if(PLANES) asm("v_add_u32 %0, %1, %2" : "=v"(lr) : "v"(l), "v"(r));      // (the compiler, knowing both fit 16 bits, builds the mid sample from four 16-bit operations instead of an add and a shift)
 			float *row = tile + fr * 4u * A3_ST + col;
 			row[0 * A3_ST] = a2_value(l, 0u, F.wt);
 			row[1 * A3_ST] = a2_value(r, 0u, F.wt);
-			row[2 * A3_ST] = a2_value((l + r) >> 1, 0u, F.wt);
+			row[2 * A3_ST] = a2_value(lr >> 1, 0u, F.wt);
 			row[3 * A3_ST] = a2_value(l - r, 0u, F.wt);
 		}
 	}
