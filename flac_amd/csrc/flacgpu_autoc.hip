@@ -2,7 +2,11 @@
 // FLAC__lpc_window_data{,_partial} -> FLAC__lpc_compute_autocorrelation, stream_encoder.c:4318-4392, lpc.c:68-94,
 // lpc_intrin_fma.c:46-72) for all frames of nominal length.
 //
-// Parallel shape: a WAVEFRONT takes one window job (whole block, a half, a third ...) of 16 consecutive
+// Two kernels with the same arithmetic: autoc2_kernel (below; lane = (subframe, vector lane of the reference's accumulators)) and
+// autoc3_kernel (further down; lane = subframe: a quarter of the conversions and LDS reads, the one the full-size batches of the
+// presets with several window jobs run -- launch_autoc2 picks).
+//
+// autoc2_kernel's parallel shape: a WAVEFRONT takes one window job (whole block, a half, a third ...) of 16 consecutive
 // (frame, candidate channel) subframes.  Lane = (subframe s = lane/4, vector lane l = lane%4) and carries the
 // accumulators of ALL lags of "its" AVX lane l of the reference routine: the reference keeps, per lag j, a 4-wide
 // fp64 vector acc_j and steps it 8 samples at a time,
