@@ -248,7 +248,8 @@ def verify_ranks(stream, sizes, fbs, nframes, level, block, kind="music", hires=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node.  Not under a launcher and N > 1: bench.py starts its N ranks itself "
+                    "(flac_amd.dist.ensure_ranks -> torch.distributed.run); under one, N must equal its WORLD_SIZE (else exit code 3)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
@@ -266,7 +267,16 @@ def main():
                     "into rank 0's HBM (the north star's gather); hostshm: every rank copies over its own PCIe link into one shared pinned host buffer; "
                     "none: they stay where they were encoded (encode-only scaling: what the funnel costs is this line against the rccl one)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank pipeline (process group, windowed ordered gather) even with one rank")
+    ap.add_argument("--no-side-gathers", action="store_true", help="multi-rank rccl line: skip the encode-only (--gather none) and hostshm figures measured beside it in the same run")
     args = ap.parse_args()
+    # one call, N workers: `python bench.py --gpus 8` starts its eight ranks itself (and never prints n_gpus: 8 from fewer)
+    from flac_amd.dist import ensure_ranks, check_world
+    launched_by = "a launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "bench.py itself"
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        os.environ["FLACGPU_BENCH_SELF_LAUNCHED"] = "1"
+    elif os.environ.get("FLACGPU_BENCH_SELF_LAUNCHED") == "1":
+        launched_by = "bench.py --gpus %d (flac_amd.dist.ensure_ranks -> torch.distributed.run)" % (args.gpus or 1)
+    rank, local_rank, world = ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     global RATE, BPS
     if args.hires:
         RATE, BPS = 96000, 24
@@ -283,11 +293,11 @@ def main():
     import flac_amd
     from flac_amd.dist import GatherPipeline, HostShmPipeline
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d wants device %d, %d visible\n" % (rank, local_rank, torch.cuda.device_count()))
+        raise SystemExit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
@@ -295,6 +305,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        check_world(args.gpus)
 
     nframes = args.frames
     search = dict(exhaustive=int(args.exhaustive), prec_search=int(args.prec_search))
@@ -305,8 +316,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(level, kind, steps, warmup, use_dist):
+    def measure(level, kind, steps, warmup, use_dist, gather=None):
         """K timed steps of one configuration; returns the numbers and what the verification needs"""
+        gather = gather or args.gather
         block = block_of(level)
         settings = flac_amd.make_settings(CH, BPS, RATE, level, **search)
         eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=nframes)
@@ -314,7 +326,7 @@ def main():
         d_pcm = torch.from_numpy(pcm_h).to(dev)
         cap = eng.max_output_bytes(nframes)
         first_frame = rank * nframes
-        if not use_dist or args.gather == "none":
+        if not use_dist or gather == "none":
             d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
             d_fb = torch.empty(nframes, dtype=torch.int32, device=dev)
             d_total = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -326,7 +338,7 @@ def main():
                     eng.encode_device(d_pcm.data_ptr(), nframes, d_out.data_ptr(), cap, d_fb.data_ptr(), d_total.data_ptr(),
                                       first_frame_number=first_frame, stream=enc_stream.cuda_stream)
         else:
-            if args.gather == "hostshm":
+            if gather == "hostshm":
                 # room per rank and step in the shared host buffer: what one step of this signal really takes, plus a quarter
                 # (the worst case, every frame VERBATIM, would pin 2 windows x world x 288 MB per step)
                 d_probe = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -369,7 +381,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         res = {"elapsed": elapsed, "steps": steps, "block": block, "level": level, "kind": kind}
-        if rank == 0 and gp is None and not args.no_verify:
+        if rank == 0 and gp is None and not use_dist and not args.no_verify:
             # side measurement, outside the timed region: the whole batch decoded again on the device and compared with its input
             # (flacgpu_verify_batch_device: what set_verify(true) costs per batch)
             d_res = torch.zeros(32, dtype=torch.uint8, device=dev)
@@ -415,14 +427,14 @@ def main():
                             "how": "no gather: every rank checked its own frames (CRC-16 of all, oracle on a sample, frame numbers rank * frames + f)"}
             else:
                 k_last = state["k"] - 1 if (steps % gp.K == 0) else (state["k"] - gp.K + steps % gp.K - 1)
-                if args.gather == "hostshm":
+                if gather == "hostshm":
                     # (the shared host buffer holds every rank's bytes, but a rank knows only its own frame lengths: they are collected here)
                     _, _, myfb = gp.gathered(k_last)
                     allfb = torch.empty(world * nframes, dtype=torch.int32, device=dev)
                     dist.all_gather_into_tensor(allfb, myfb.contiguous().to(torch.int32))
                 if rank == 0:
                     stream, sizes, fbs = gp.gathered(k_last)
-                    if args.gather == "hostshm":
+                    if gather == "hostshm":
                         fbs = allfb.view(world, nframes)
                     verified = verify_ranks(stream[:sum(sizes)].cpu().numpy(), sizes, fbs.cpu().numpy(), nframes, level, block, kind, args.hires, search)
         if rank == 0:
@@ -501,6 +513,35 @@ def main():
     main_kind = "white" if args.white else "music"
     m = measure(LEVEL, main_kind, args.steps, args.warmup, multi)
     extras = {}
+    side = {}
+    if multi and args.gather == "rccl" and not args.no_side_gathers:
+        # the same job twice more in the same run, so that a sub-linear rccl figure splits into encode scaling and funnel without
+        # a second command: the frames stay where they were encoded (`encode_only`), and every rank copies them over its own PCIe
+        # link into one shared pinned host buffer (`hostshm`).  Every rank's frames are checked in both.
+        side_steps = max(args.window, args.steps // 2)
+        eo = measure(LEVEL, main_kind, side_steps, 1, True, "none")
+        # the shared host buffer lives in /dev/shm: rank 0 looks whether the windows fit there and tells the others
+        need = 2 * args.window * world * ((int(m.get("gathered_bytes_last_step") or 0) // max(1, world)) * 5 // 4 + 4096) if rank == 0 else 0
+        verdict = [None]
+        if rank == 0:
+            try:
+                st = os.statvfs("/dev/shm")
+                free = st.f_bavail * st.f_frsize
+                verdict[0] = None if need + (256 << 20) <= free else "the windows need %d MB of /dev/shm, %d MB free" % (need >> 20, free >> 20)
+            except OSError as e:
+                verdict[0] = "no /dev/shm: %s" % e
+        dist.broadcast_object_list(verdict, src=0)
+        hs = measure(LEVEL, main_kind, side_steps, 1, True, "hostshm") if verdict[0] is None else None
+        if rank == 0:
+            def side_line(r, how):
+                wins = r.get("gather_windows") or []
+                wms = [w["ms"] for w in wins if w["ms"] is not None]
+                return {"value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"], "how": how,
+                        "verified": {k: r["verified"][k] for k in ("ranks_checked", "ok", "ranks_failing", "crc16_frames_checked", "frames_compared_with_oracle")} if r.get("verified") else None,
+                        "rank0_transfer_ms_per_step": round(sum(wms) / max(1, sum(w["steps"] for w in wins)), 4) if wms else None}
+            side["encode_only"] = side_line(eo, "--gather none in the same run: every rank's frames stay in its HBM; rccl value / this = what the funnel into rank 0 costs")
+            side["hostshm"] = side_line(hs, "--gather hostshm in the same run: every rank copies its frames over its own PCIe link into one shared pinned host buffer") \
+                if hs is not None else {"skipped": verdict[0]}
     if world == 1 and not multi and not args.no_extras and LEVEL == 8 and not args.hires and not args.white and not any(search.values()):
         side_steps = max(3, args.steps // 2)
         w = measure(8, "white", side_steps, 1, False)
@@ -526,7 +567,7 @@ def main():
         line = {
             "metric": ("encode Msamples/s at -8, 44.1k/16-bit stereo; bit-exact vs libFLAC" if not args.hires else "encode Msamples/s at -8, 96k/24-bit stereo (side measurement)")
                       if LEVEL == 8 else "encode Msamples/s at -%d (side measurement; the metric is quoted at -8)" % LEVEL,
-            "value": round(m["value"], 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(m["value"], 3), "unit": "Msamples/s", "n_gpus": world, "launched_by": launched_by, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(m["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": "flac -%d%s%s (%s) on %s stereo, "
@@ -567,6 +608,7 @@ def main():
                               "note": "ms = time a window's transfers occupied rank 0's communication stream (they run beside the next window's encodes); "
                                       "if rank0_transfer_ms_per_step approaches ms_per_step the gather sets the pace"}
         line.update(extras)
+        line.update(side)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(LEVEL, search)
             line["cpu_baseline"] = cb

@@ -13,6 +13,7 @@ Rank 0 then writes the stream the way FLAC__stream_encoder_finish leaves a file 
 thread while the GPUs work: one serial chain, md5.c:497), the VORBIS_COMMENT block with the vendor string, the frames.
 
     python -m flac_amd.corpus --hours 10 --out /tmp/corpus.flac
+    python -m flac_amd.corpus --gpus 8 --hours 10 ...          (starts its eight ranks itself: flac_amd.dist.ensure_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m flac_amd.corpus --hours 10 ...
 
 Prints one JSON line (rank 0).  The synthetic corpus is a 512-frame music-like clip repeated with an integer gain /
@@ -271,7 +272,11 @@ def main(argv=None):
     ap.add_argument("--no-md5", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the process-group path with one rank too")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; not under a launcher and N > 1: the job starts its N ranks itself "
+                    "(flac_amd.dist.ensure_ranks); under one, N must equal its WORLD_SIZE")
     args = ap.parse_args(argv)
+    from flac_amd.dist import ensure_ranks, check_world
+    rank, local_rank, world = ensure_ranks(args.gpus, "flac_amd.corpus", sys.argv[1:] if argv is None else list(argv), module=True)
 
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -281,9 +286,6 @@ def main(argv=None):
     import flac_amd
     from flac_amd.dist import shard_range, ordered_gather, HostShmGather
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("flac_amd.corpus needs a GPU: there is no CPU encode path")
     torch.cuda.set_device(local_rank)
@@ -293,6 +295,7 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29534")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        check_world(args.gpus)
 
     total_samples = args.samples or int(round(args.hours * 3600 * RATE))
     F = (total_samples + BLOCK - 1) // BLOCK                    # 10 h: 387598 frames, the last one 2688 samples short of a block

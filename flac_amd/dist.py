@@ -22,9 +22,85 @@ Three forms of it:
 import mmap
 import os
 import secrets
+import socket
+import sys
 
 import torch
 import torch.distributed as dist
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one call, N workers (the reference: FLAC__stream_encoder_set_num_threads, stream_encoder.c:2151 -- one call starts the
+# workers, frames come out in order, :3530-3574).  A job's command line says `--gpus N`; if it was not started under a
+# launcher already it starts its N ranks itself.
+# ------------------------------------------------------------------------------------------------------------------
+EXIT_BAD_WORLD = 3           # --gpus N disagrees with the launcher's world size, or fewer than N devices are visible
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(nproc, script, argv, port=None, python=None, module=False):
+    """The command that runs `script argv...` (module=True: `-m script`) as `nproc` ranks of one node, one rank per GPU
+    (torch.distributed.run: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_* in every rank's environment) -- exactly what the round
+    driver types for N > 1."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port or free_port()))] + (["-m"] if module else []) + [script] + list(argv)
+
+
+def visible_devices():
+    try:
+        return int(torch.cuda.device_count()) if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+def ensure_ranks(nproc, script, argv, need_devices=True, env=None, _exec=None, module=False):
+    """Call first thing in a job's main(): returns (rank, local_rank, world) of THIS process, having made sure the job runs
+    as `nproc` ranks.
+      * started under a launcher (WORLD_SIZE set): the launcher's world size must equal `nproc` when `nproc` is given --
+        otherwise the process ends with EXIT_BAD_WORLD (a line that says n_gpus: 8 must come from 8 ranks);
+      * not under a launcher and nproc in (None, 1): one rank, no process group;
+      * not under a launcher and nproc > 1: refuse (EXIT_BAD_WORLD) when fewer than nproc devices are visible
+        (need_devices), else REPLACE this process by the launcher (launch_command) -- stdout, stderr, signals and the exit
+        code are the launcher's, so rank 0's one JSON line is the command's one line.
+    `_exec` is for the tests (a function taking the command instead of os.execvpe)."""
+    env = os.environ if env is None else env
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if nproc is not None and int(nproc) != world:
+            sys.stderr.write("flac_amd.dist: --gpus %d but the launcher started %d ranks (WORLD_SIZE)\n" % (int(nproc), world))
+            raise SystemExit(EXIT_BAD_WORLD)
+        return int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), world
+    if nproc is None or int(nproc) <= 1:
+        return 0, 0, 1
+    nproc = int(nproc)
+    if need_devices:
+        have = visible_devices()
+        if have < nproc:
+            sys.stderr.write("flac_amd.dist: --gpus %d but %d HIP device(s) visible\n" % (nproc, have))
+            raise SystemExit(EXIT_BAD_WORLD)
+    cmd = launch_command(nproc, script, argv, module=module)
+    child_env = dict(env)
+    child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL across processes)
+    child_env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // nproc)))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if _exec is not None:
+        return _exec(cmd, child_env)
+    os.execvpe(cmd[0], cmd, child_env)
+
+
+def check_world(nproc, group=None):
+    """After init_process_group: the group really has the size the command line asked for."""
+    world = dist.get_world_size(group)
+    if nproc is not None and world != int(nproc):
+        sys.stderr.write("flac_amd.dist: the process group has %d ranks, the job asked for %d\n" % (world, int(nproc)))
+        raise SystemExit(EXIT_BAD_WORLD)
+    return world
 
 
 def shard_range(nframes, world, rank):
