@@ -128,6 +128,135 @@ def md5_many(buffers):
     return [out[i].tobytes() for i in range(n)]
 
 
+def md5_many_mt(ptrs, lens, nthreads):
+    """MD5 of len(ptrs) byte ranges of host memory on `nthreads` host threads (flac_amd/csrc/host/md5.c: flacgpu_host_md5_many_mt --
+    groups of sixteen chains per AVX-512 register, or eight per AVX2 register, a group per work item); the GIL is released inside"""
+    import ctypes as C
+    import flac_amd
+    lib = flac_amd.engine.load_host()
+    lib.flacgpu_host_md5_many_mt.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_void_p, C.c_uint32]
+    lib.flacgpu_host_md5_many_mt.restype = None
+    n = len(ptrs)
+    cp = (C.c_void_p * n)(*ptrs)
+    cl = (C.c_size_t * n)(*lens)
+    out = np.zeros((n, 16), dtype=np.uint8)
+    lib.flacgpu_host_md5_many_mt(cp, cl, n, out.ctypes.data, max(1, int(nthreads)))
+    return [out[i].tobytes() for i in range(n)]
+
+
+def usable_cpus():
+    """CPUs this process may really use (affinity and cgroup quota: the GPU boxes show 256 hardware threads to a container allowed 16)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def host_corpus(base, F, total_samples):
+    """the whole corpus as the job finds it when its input comes from the host -- the tracks' sample bytes as read from their files --
+    in ONE page-locked buffer: int16 [F*BLOCK, 2] (the frames behind total_samples are never read)"""
+    import torch
+    buf = torch.empty((F * BLOCK, CH), dtype=torch.int16, pin_memory=True)
+    arr = buf.numpy()
+    cache = {}
+    for f in range(0, F, BASE_FRAMES):
+        nb = min(BASE_FRAMES, F - f)
+        key = rep_params(f // BASE_FRAMES)
+        if key not in cache:
+            cache[key] = host_frames(base, f, f + BASE_FRAMES)
+        arr[f * BLOCK:(f + nb) * BLOCK] = cache[key][:nb * BLOCK]
+    return buf
+
+
+def check_hbm(dev, need_bytes, what):
+    """a clear refusal instead of an out-of-memory error half way (the corpus-sized buffers were allocated unchecked)"""
+    import torch
+    free, total = torch.cuda.mem_get_info(dev)
+    if need_bytes + (1 << 30) > free:
+        raise SystemExit("flac_amd.corpus: %s needs %.1f GB of HBM, %.1f GB free of %.1f -- encode the corpus in parts (--hours) or from the host (--input host)"
+                         % (what, need_bytes / 1e9, free / 1e9, total / 1e9))
+
+
+def encode_tracks_from_host(eng, hbuf, F, total_samples, ntracks, dev, enc_stream, want_md5=True, md5_threads=0):
+    """The corpus as `ntracks` separate streams, input in page-locked host memory (the tracks' sample bytes as their files hold them).
+    The reference hashes what it encodes on the way in (FLAC__MD5Accumulate per block, stream_encoder.c:3666-3686 -> md5.c:497); here
+    the two run side by side: host threads hash the tracks straight from the input buffer (no copy, no "prepare": sixteen or eight
+    chains per thread, flacgpu_host_md5_many_mt) while the copy engine moves them to the device track by track and the engine stages
+    and encodes each as its bytes arrive.  One read of the tracks' byte totals at the end."""
+    import torch
+    import flac_amd
+    fmt = flac_amd.raw_format(16)
+    ranges = track_ranges(F, ntracks)
+    tail = total_samples - (F - 1) * BLOCK
+    tail = 0 if tail == BLOCK else tail
+    maxf = max(hi - lo for lo, hi in ranges)
+    slot = eng.max_output_bytes(1)
+    check_hbm(dev, F * BLOCK * CH * 2 + F * slot + maxf * BLOCK * CH * 4, "the corpus (sample bytes + worst-case frames)")
+    raw_all = torch.empty((F * BLOCK, CH), dtype=torch.int16, device=dev)
+    pcm = torch.empty((maxf * BLOCK, CH), dtype=torch.int32, device=dev)
+    out = torch.empty(F * slot, dtype=torch.uint8, device=dev)
+    fb_all = torch.zeros(F, dtype=torch.int32, device=dev)
+    totals = torch.zeros(ntracks, dtype=torch.int64, device=dev)
+    starts = [lo * slot for lo, _ in ranges]
+    copy_stream = torch.cuda.Stream()
+    arrived = [torch.cuda.Event() for _ in ranges]
+    harr = hbuf.numpy()
+    t0 = time.perf_counter()
+    box = {}
+    th = None
+    if want_md5:
+        ptrs = [harr[lo * BLOCK:].ctypes.data if hi > lo else 0 for lo, hi in ranges]
+        lens = [max(0, (min(hi * BLOCK, total_samples) - lo * BLOCK)) * CH * 2 if hi > lo else 0 for lo, hi in ranges]
+
+        def hash_all():
+            tm = time.perf_counter()
+            box["digests"] = md5_many_mt(ptrs, lens, md5_threads or usable_cpus())
+            box["seconds"] = time.perf_counter() - tm
+        th = threading.Thread(target=hash_all)
+        th.start()
+    with torch.cuda.stream(copy_stream):
+        for t, (lo, hi) in enumerate(ranges):
+            if hi > lo:
+                raw_all[lo * BLOCK:hi * BLOCK].copy_(hbuf[lo * BLOCK:hi * BLOCK], non_blocking=True)
+            arrived[t].record(copy_stream)
+    with torch.cuda.stream(enc_stream):
+        for t, (lo, hi) in enumerate(ranges):
+            nf = hi - lo
+            if nf == 0:
+                continue
+            enc_stream.wait_event(arrived[t])
+            short = tail if (tail and hi == F) else 0
+            eng.stage_raw_device(raw_all[lo * BLOCK:].data_ptr(), fmt, nf * BLOCK - (BLOCK - short if short else 0), pcm.data_ptr(), None, enc_stream.cuda_stream)
+            eng.encode_device(pcm.data_ptr(), nf, out.data_ptr() + starts[t], nf * slot, fb_all.data_ptr() + 4 * lo, totals.data_ptr() + 8 * t,
+                              first_frame_number=0, tail=short, stream=enc_stream.cuda_stream)
+    copy_stream.synchronize()
+    t_copy = time.perf_counter() - t0
+    enc_stream.synchronize()
+    t_enc = time.perf_counter() - t0
+    if th:
+        th.join()
+    t_all = time.perf_counter() - t0
+    tot_h = totals.cpu().tolist()
+    digests = box.get("digests", [bytes(16)] * ntracks)
+    fbs = fb_all.cpu().numpy().astype(np.uint32)
+    streams = []
+    for t, (lo, hi) in enumerate(ranges):
+        nsamp = min(hi * BLOCK, total_samples) - lo * BLOCK if hi > lo else 0
+        f = fbs[lo:hi]
+        header = stream_header(nsamp, int(f.min()) if f.size else 0, int(f.max()) if f.size else 0, digests[t])
+        streams.append((header, out[starts[t]:starts[t] + int(tot_h[t])], f))
+    return streams, {"encode_seconds": t_enc, "h2d_seconds": t_copy, "md5_prepare_seconds": 0.0, "md5_seconds": box.get("seconds", 0.0), "hash_and_encode_seconds": t_all,
+                     "host_reads_of_totals": 1, "md5_threads": (md5_threads or usable_cpus()) if want_md5 else 0}
+
+
 def track_ranges(F, ntracks):
     """frames [lo, hi) of each track: equal shares of the corpus, earlier tracks take the remainder"""
     base, rem = divmod(F, ntracks)
@@ -152,7 +281,8 @@ def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_strea
     maxf = max(hi - lo for lo, hi in ranges)
     on_device = want_md5 and md5_where == "device"
     # md5_where == "device": the whole corpus's sample bytes stay staged in HBM (6.4 GB for ten hours) and are hashed there, one lane
-    # per track (flacgpu_md5.hip), beside the encodes -- no host copy of the samples, no host threads
+    # per track (flacgpu_md5.hip), BEHIND the encodes on their stream -- no host copy of the samples, no host threads
+    check_hbm(dev, (F * BLOCK * CH * 2 if on_device else maxf * BLOCK * CH * 2) + F * eng.max_output_bytes(1) + maxf * BLOCK * CH * 4, "the corpus (sample bytes + worst-case frames)")
     raw_all = torch.empty((F * BLOCK, CH), dtype=torch.int16, device=dev) if on_device else None
     raw = None if on_device else torch.empty((maxf * BLOCK, CH), dtype=torch.int16, device=dev)
     pcm = torch.empty((maxf * BLOCK, CH), dtype=torch.int32, device=dev)
@@ -166,13 +296,10 @@ def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_strea
     totals = torch.zeros(ntracks, dtype=torch.int64, device=dev)
     starts = [lo * slot for lo, _ in ranges]
     t0 = time.perf_counter()
-    staged_all = None
     with torch.cuda.stream(enc_stream):
         if on_device:
-            # the corpus's sample bytes, all of them, before the first encode: the digests' chains can then start at once
+            # the corpus's sample bytes, all of them, before the first encode
             device_frames(base_dev, 0, F, raw_all)
-            staged_all = torch.cuda.Event()
-            staged_all.record(enc_stream)
         for t, (lo, hi) in enumerate(ranges):
             nf = hi - lo
             if nf == 0:
@@ -187,9 +314,6 @@ def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_strea
     t_dev_md5 = 0.0
     dev_digests = None
     if on_device:
-        # behind the encodes on the same stream (the chains of 120 tracks are two wavefronts: they neither wait for nor slow the encodes much,
-        # but the samples must be staged first); synchronous on the stream, so it also stands for the end of the encodes
-        tm0 = time.perf_counter()
         offs_b = [lo * BLOCK * CH * 2 for lo, _ in ranges]
         lens_b = [max(0, (min(hi * BLOCK, total_samples) - lo * BLOCK)) * CH * 2 if hi > lo else 0 for lo, hi in ranges]
         # behind the encodes, on their stream (beside them, on a stream of its own, the two wavefronts of 120 chains took twice as long
@@ -258,7 +382,11 @@ def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_strea
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--tracks", type=int, default=0, help="encode the corpus as this many separate streams (one file per track, each with its own STREAMINFO and MD5) on one GPU")
-    ap.add_argument("--md5-threads", type=int, default=1, help="--tracks: host threads hashing the tracks (each eight chains wide)")
+    ap.add_argument("--md5-threads", type=int, default=0, help="--tracks: host threads hashing the tracks (0: every CPU this process may use with --input host, "
+                    "one with --input device)")
+    ap.add_argument("--input", choices=("host", "device"), default="host", help="--tracks: where the job finds the tracks' sample bytes -- host: in one page-locked host "
+                    "buffer, as read from their files (copied to the device track by track beside the encodes, hashed by host threads straight from that buffer); "
+                    "device: generated in HBM (the round-4 job: no copy, digests on the device or from a second host copy)")
     ap.add_argument("--md5", choices=("auto", "host", "device"), default="auto", help="--tracks: where the tracks' digests are computed -- device: one lane per track on the "
                     "staged sample bytes in HBM (flacgpu_md5.hip); host: AVX2, eight chains per pass, --md5-threads threads; auto: the device from 256 tracks up "
                     "(a chain is serial: 120 tracks are two wavefronts at ~30-50 MB/s per lane, 1.1-1.8 s for ten hours; 1000 tracks hash in 0.09 s -- "
@@ -336,11 +464,24 @@ def main(argv=None):
         enc_stream = torch.cuda.Stream()
         encode_tracks(eng, base, base_dev, min(F, 2 * args.tracks), min(total_samples, 2 * args.tracks * BLOCK), args.tracks, dev, enc_stream, want_md5=False)       # warm-up
         torch.cuda.synchronize()
-        if args.md5 == "auto":
-            args.md5 = "device" if args.tracks >= 256 else "host"
-        t0 = time.perf_counter()
-        streams, tm = encode_tracks(eng, base, base_dev, F, total_samples, args.tracks, dev, enc_stream, want_md5=not args.no_md5, md5_threads=args.md5_threads, md5_where=args.md5)
-        t_job = time.perf_counter() - t0
+        if args.input == "host":
+            # the input, as a job that reads files would hold it when the clock starts: every track's sample bytes in page-locked host memory
+            tg = time.perf_counter()
+            hbuf = host_corpus(base, F, total_samples)
+            t_gen = time.perf_counter() - tg
+            args.md5 = "host"
+            t0 = time.perf_counter()
+            streams, tm = encode_tracks_from_host(eng, hbuf, F, total_samples, args.tracks, dev, enc_stream, want_md5=not args.no_md5, md5_threads=args.md5_threads)
+            t_job = time.perf_counter() - t0
+            args.md5_threads = tm["md5_threads"]
+        else:
+            t_gen = None
+            args.md5_threads = args.md5_threads or 1
+            if args.md5 == "auto":
+                args.md5 = "device" if args.tracks >= 256 else "host"
+            t0 = time.perf_counter()
+            streams, tm = encode_tracks(eng, base, base_dev, F, total_samples, args.tracks, dev, enc_stream, want_md5=not args.no_md5, md5_threads=args.md5_threads, md5_where=args.md5)
+            t_job = time.perf_counter() - t0
         import ctypes as C
         host = flac_amd.engine.load_host()
         host.flacgpu_host_check_frame_crcs.restype = C.c_int64
@@ -359,13 +500,16 @@ def main(argv=None):
                 t_write += time.perf_counter() - tw
         line = {"job": "flac -%d batch encode of a %.2f h synthetic 44.1k/16-bit stereo corpus into %d streams (one per track)" % (args.level, total_samples / RATE / 3600, args.tracks),
                 "n_gpus": 1, "tracks": args.tracks, "frames": F, "samples": total_samples, "bytes": nbytes,
+                "input": "page-locked host memory (generated before the clock started: %.2f s)" % t_gen if t_gen is not None else "generated in HBM",
+                "h2d_seconds": round(tm["h2d_seconds"], 4) if "h2d_seconds" in tm else None,
                 "encode_seconds": round(tm["encode_seconds"], 4), "Msamples_per_s_encode": round(total_samples / tm["encode_seconds"] / 1e6, 1),
                 "md5": None if args.no_md5 else "one digest per track, on the device: one lane per track over the staged sample bytes in HBM" if args.md5 == "device" else
-                       "one digest per track, eight chains per pass (AVX2), %d host thread(s)" % args.md5_threads,
+                       "one digest per track, %s chains per register, %d host thread(s)%s" % ("16 (AVX-512) or 8 (AVX2)" if args.input == "host" else "eight", args.md5_threads,
+                                                                                             ", straight from the input buffer, beside the copies and the encodes" if args.input == "host" else ""),
                 "md5_seconds": round(tm["md5_seconds"], 3), "md5_prepare_seconds": round(tm["md5_prepare_seconds"], 3),
                 "md5_Msamples_per_s": round(total_samples / tm["md5_seconds"] / 1e6, 1) if tm["md5_seconds"] else None,
                 "job_seconds": round(t_job, 3), "tracks_with_a_bad_crc16": bad_tracks, "write_seconds": round(t_write, 3) if args.out else None,
-                "first_track_md5": streams[0][0][8 + 18:8 + 34].hex()}
+                "first_track_md5": streams[0][0][8 + 18:8 + 34].hex(), "track_md5": [h[8 + 18:8 + 34].hex() for h, _, _ in streams]}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
         eng.close()
         return line

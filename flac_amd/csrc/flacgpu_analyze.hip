@@ -1302,8 +1302,7 @@ static void eval_shape(const DevParams &P, uint32_t &cpw, uint32_t &waves)
 		waves = (nc + rounds - 1) / rounds;
 		if(nc >= 4) waves = waves >= 8 ? 8 : 4;
 	}
-	static int fw = -1, fc = -1;
-	if(fw < 0) { const char *e = getenv("FLACGPU_EVAL_WAVES"); fw = e ? atoi(e) : 0; e = getenv("FLACGPU_EVAL_CPW"); fc = e ? atoi(e) : 0; }
+	const int fw = tune().eval_waves, fc = tune().eval_cpw;
 	if(fc > 0 && fc <= EVAL_CPW_MAX && P.ncand % (uint32_t)fc == 0) cpw = (uint32_t)fc;
 	if(fw > 0 && fw <= EVAL_MAX_WAVES) waves = (uint32_t)fw;
 	while(owner_possible(P) && cpw > 1 && eval_layout(P, waves, cpw, false).total > 64 * 1024) cpw /= 2;     // keep at least 2 workgroups per CU
@@ -1339,14 +1338,15 @@ template <int MAXORD>
 static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, const JobTable *jtm, const JobTable *jtt,
                                     const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
 {
-	static bool attr_set = false;
-	if(!attr_set) {
+	static bool attr_set[64];
+	if(first_on_device(attr_set)) {
 		hipError_t e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e != hipSuccess) return e;
-		attr_set = true;
+		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)eval_list_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
 	}
 	if(P.max_analyses) {
+		note_launch(K_MODEL);
 		const uint32_t lanes = nframes * P.ncand * P.max_analyses;
 		hipLaunchKernelGGL(model_kernel<MAXORD>, dim3((lanes + TPB - 1) / TPB), dim3(TPB), 0, s, P, nframes, tail_n, jtm, jtt, B.prep, B.autoc, B.cands, B.valid, B.nleft);
 	}
@@ -1370,24 +1370,21 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 	}
 	// which flavours can occur in this batch at all (each launch serves only its own channels)
 	// how many workgroups ahead the one is that takes a finishing workgroup's place on its XCD: the workgroups an XCD holds
-	static int ahead = -1;
+	int ahead = tune().eval_prefetch;
 	if(ahead < 0) {
-		int nb = 0;
-		if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)eval_kernel<MAXORD, 0>, (int)(waves * 64), lds) != hipSuccess || nb < 1) nb = 2;
-		ahead = nb * 16;            // (measured on MI355X, profiles/r02_g_prefetch_ab.txt: 32..96 workgroups ahead are equally good, 256 is too early)
-		if(const char *e = getenv("FLACGPU_EVAL_PREFETCH")) ahead = atoi(e);
-		if(ahead < 0) ahead = 0;
+		static thread_local int derived = -1;        // (per thread: no shared write; the figure is a property of the kernel and the chip)
+		if(derived < 0) {
+			int nb = 0;
+			if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)eval_kernel<MAXORD, 0>, (int)(waves * 64), lds) != hipSuccess || nb < 1) nb = 2;
+			derived = nb * 16;      // (measured on MI355X, profiles/r02_g_prefetch_ab.txt: 32..96 workgroups ahead are equally good, 256 is too early)
+		}
+		ahead = derived;
 	}
 	const bool pdz = prep2_applicable(P) && prep2_decides(P) && op && !B.dbg;
 	if(pdz) {
 		// the prep kernel has decided the frames of nominal length (flacgpu_prep.hip: DECIDE); the short last block and what it listed
 		// go through the lane-owner body
-		static bool lset = false;
-		if(!lset) {
-			const hipError_t e2 = hipFuncSetAttribute((const void *)eval_list_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-			if(e2 != hipSuccess) return e2;
-			lset = true;
-		}
+		note_launch(K_EVAL_LIST);
 		if(tail_n) hipLaunchKernelGGL(list_append_kernel, dim3(1), dim3(64), 0, s, (nframes - 1) * P.ncand, P.ncand, B.left, B.nleft);
 		const uint32_t grid = nframes * P.ncand < 1024u ? nframes * P.ncand : 1024u;
 		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(4 * 64), eval_layout(P, 4, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
@@ -1408,20 +1405,15 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 			if(e != hipSuccess) return e;
 			last_list = B.left; last_count = B.nleft;
 		}
-		static bool lset = false;
-		if(!lset) {
-			const hipError_t e2 = hipFuncSetAttribute((const void *)eval_list_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-			if(e2 != hipSuccess) return e2;
-			lset = true;
-		}
+		note_launch(K_EVAL_LIST);
 		const uint32_t lw = 4u;
 		const uint32_t grid = nframes * P.ncand < 1024u ? nframes * P.ncand : 1024u;
 		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(lw * 64), eval_layout(P, lw, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, last_list, last_count);
 	}
-	else if(op) hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, (uint32_t)ahead);
-	else hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u);
+	else if(op) { note_launch(K_EVAL); hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, (uint32_t)ahead); }
+	else { note_launch(K_EVAL); hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u); }
 	if(!op || tail_n || P.max_po > 6)
-		hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(gwaves * 64), lds_generic, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u);
+		{ note_launch(K_EVAL); hipLaunchKernelGGL((eval_kernel<MAXORD, 2>), dim3(nframes * P.ncand), dim3(gwaves * 64), lds_generic, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u); }
 	sync_debug("eval", s);
 	return hipGetLastError();
 }
@@ -1429,9 +1421,7 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 // FLACGPU_SYNC_DEBUG=1: wait for every kernel and name the one that faults (development aid)
 void sync_debug(const char *what, hipStream_t s)
 {
-	static int on = -1;
-	if(on < 0) on = getenv("FLACGPU_SYNC_DEBUG") ? 1 : 0;
-	if(!on) return;
+	if(!tune().sync_debug) return;
 	fprintf(stderr, "[flacgpu] %s ...", what); fflush(stderr);
 	const hipError_t e = hipStreamSynchronize(s);
 	fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr);
@@ -1439,11 +1429,10 @@ void sync_debug(const char *what, hipStream_t s)
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin, uint32_t nframes, uint32_t tail_n,
                           const JobTable *jtm, const JobTable *jtt, uint32_t nsets_main, const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
 {
-	static bool attr_set = false;
-	if(!attr_set) {
+	static bool attr_set[64];
+	if(first_on_device(attr_set)) {
 		hipError_t e = hipFuncSetAttribute((const void *)prep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e != hipSuccess) return e;
-		attr_set = true;
+		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
 	}
 	{
 		// frames of nominal length: one workgroup per frame (flacgpu_prep.hip); the short last block, and block sizes that
@@ -1455,7 +1444,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 			if(e != hipSuccess) return e;
 		}
 		if(f_lo < nframes)
-			hipLaunchKernelGGL(prep_kernel<0>, dim3((nframes - f_lo) * P.ncand), dim3(TPB), P.sig_bytes, s, P, pcm, nframes, tail_n, f_lo, B.prep, B.cands, B.valid, B.chan);
+			{ note_launch(K_PREP); hipLaunchKernelGGL(prep_kernel<0>, dim3((nframes - f_lo) * P.ncand), dim3(TPB), P.sig_bytes, s, P, pcm, nframes, tail_n, f_lo, B.prep, B.cands, B.valid, B.chan); }
 	}
 	sync_debug("prep", s);
 	if(pev) (void)hipEventRecord(pev[0], s);
@@ -1466,8 +1455,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 		// autoc2 runs a whole window job per lane quartet: few subframes in the batch (mono, small batches) leave most
 		// SIMDs without a wavefront, and the batch then takes one full job's time.  Below a wavefront or two per SIMD the
 		// wavefront-per-job kernel (16x the wavefronts for 1.8x the arithmetic) is the faster one.
-		static int force = -1;
-		if(force < 0) { const char *e = getenv("FLACGPU_AUTOC2"); force = e ? atoi(e) + 1 : 0; }      // 0: decide here, 1: never, 2: always
+		const int force = tune().autoc2_force;      // FLACGPU_AUTOC2 + 1 -- 0: decide here, 1: never, 2: always
 		const uint32_t nmain2 = tail_n ? nframes - 1 : nframes;
 		const uint32_t waves2 = P.max_jobs * ((nmain2 * P.ncand + 15) / 16);
 		// measured break-even (scripts/chan_rate.py): ~640 wavefronts for the stereo mid/side flavour (four channels share
@@ -1481,6 +1469,7 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 		}
 		if(f_lo < nframes) {
 			const uint32_t items = (nframes - f_lo) * P.ncand * P.max_jobs;
+			note_launch(K_AUTOC);
 			hipLaunchKernelGGL(autoc_kernel<0>, dim3((items + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, P, pcm, win, tailwin, nframes, tail_n, f_lo, jtm, jtt, B.prep, B.autoc);
 		}
 	}

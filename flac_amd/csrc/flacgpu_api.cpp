@@ -48,6 +48,9 @@ struct flacgpu_ctx {
 	uint32_t *d_fo_fall, *d_fo_nfall;
 	size_t fo_frames, fo_segs;
 	uint32_t fo_epoch, fo_spin_limit;
+	uint32_t fo_last_fused;      // epoch of the last batch whose frames really went through the fused output (its fo_place_kernel zeroed the
+	                             // fall-back counter of the epoch behind it; an epoch spent on a batch that did not fuse breaks that chain)
+	bool fo_dirty;               // a batch that used the fused-output words ended in an error: the next one starts from clean words
 	int ff_lag;                  // FLACGPU_FF_LAG (launch_ff): -1 not set -- ff_kernel batches take the two-kernel compaction
 	FrameInfo *d_info;           // [max_batch]
 	int32_t *d_pcm;              // staging for the host entry point
@@ -88,9 +91,39 @@ struct flacgpu_ctx {
 	hipStream_t s_in, s_small, s_pay;           // input copies | lengths and totals back | payloads back
 	uint64_t sub_seq, col_seq;
 	bool async_ready;
+	Tune tune;                   // the development switches of this context (environment at flacgpu_create) and what its last batch launched
+	uint32_t last_launched;
 };
 
 namespace flacgpu {
+static Tune read_tune(int device)
+{
+	Tune t;
+	memset(&t, 0, sizeof t);
+	auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+	auto set = [](const char *name) { return getenv(name) ? 1 : 0; };
+	t.autoc3_mode = num("FLACGPU_AUTOC3", 2); t.autoc3_sets = num("FLACGPU_AUTOC3_SETS", 1); t.autoc3_planes = num("FLACGPU_AUTOC3_PLANES", 1);
+	t.autoc2_ungrouped = set("FLACGPU_AUTOC2_UNGROUPED");
+	{ const char *e = getenv("FLACGPU_AUTOC2"); t.autoc2_force = e ? atoi(e) + 1 : 0; }
+	t.no_ff = set("FLACGPU_NO_FF"); t.no_run18 = set("FLACGPU_NO_RUN18"); t.no_prep3 = set("FLACGPU_NO_PREP3"); t.no_prep_decide = set("FLACGPU_NO_PREP_DECIDE");
+	t.no_evalg = set("FLACGPU_NO_EVALG"); t.no_fast1 = set("FLACGPU_NO_FAST1");
+	t.eval_wpc = num("FLACGPU_EVAL_WPC", 1) == 2 ? 2 : 1; t.evalw_wpc = num("FLACGPU_EVALW_WPC", 2) == 1 ? 1 : 2;
+	t.eval_waves = num("FLACGPU_EVAL_WAVES", 0); t.eval_cpw = num("FLACGPU_EVAL_CPW", 0); t.eval_prefetch = num("FLACGPU_EVAL_PREFETCH", -1);
+	t.sync_debug = set("FLACGPU_SYNC_DEBUG"); t.no_fused = set("FLACGPU_NO_FUSED_COMPACT"); t.no_copy_kernel = set("FLACGPU_NO_COPY_KERNEL");
+	t.cands_global = set("FLACGPU_EVAL_CANDS_GLOBAL");
+	t.device = device;
+	return t;
+}
+static thread_local Tune *g_tune = nullptr;
+Tune &tune()
+{
+	if(g_tune) return *g_tune;
+	static thread_local Tune dflt = read_tune(0);
+	return dflt;
+}
+// an entry point of a context runs under its switches
+struct TuneScope { Tune *prev; explicit TuneScope(Tune *t) : prev(g_tune) { g_tune = t; } ~TuneScope() { g_tune = prev; } };
+
 // The apply_apodization_ state machine (stream_encoder.c:4293-4392) unrolled into a static schedule.
 void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 {
@@ -333,7 +366,7 @@ static int fill_params(const flacgpu_config *cfg, DevParams &P, JobTable *jobtab
 		P.ncslots = P.nfixed + na * P.norders * P.nprec;
 	}
 	P.img_global = 0; P.stream_sig = 0;
-	P.tune_flags = getenv("FLACGPU_EVAL_CANDS_GLOBAL") ? 1u : 0u;
+	P.tune_flags = tune().cands_global ? 1u : 0u;
 	if(N > 16384 || analyze_lds_bytes(P) > 160 * 1024 - 1024) { P.stream_sig = 1; P.sig_bytes = 0; }     // the block does not fit the LDS: the general kernels read HBM
 	if(pack_lds_bytes(P) > 160 * 1024 - 1024) P.img_global = 1;            // many channels x long blocks: the frame is assembled in HBM
 	if((uint64_t)P.slot_bytes > (uint64_t)4 * 1024 * 1024) return FLACGPU_ERR_UNSUPPORTED;      // CRC span table (flacgpu_kernels.hip)
@@ -370,6 +403,8 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	memset(c, 0, sizeof *c);
 	c->cfg = *cfg;
 	c->device = cfg->device;
+	c->tune = read_tune(cfg->device);
+	TuneScope tune_scope(&c->tune);
 	r = fill_params(cfg, c->P, &c->h_jobtab[0]);
 	if(r != FLACGPU_OK) { delete c; return r; }
 	DevParams &P = c->P;
@@ -407,7 +442,7 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 		ok = ok && hipMalloc(&c->d_fo_scount, c->fo_segs * sizeof(uint64_t)) == hipSuccess && hipMemset(c->d_fo_scount, 0, c->fo_segs * sizeof(uint64_t)) == hipSuccess;
 		ok = ok && hipMalloc(&c->d_fo_sprefix, c->fo_segs * sizeof(uint64_t)) == hipSuccess && hipMemset(c->d_fo_sprefix, 0, c->fo_segs * sizeof(uint64_t)) == hipSuccess;
 		ok = ok && hipMalloc(&c->d_fo_fall, c->fo_frames * sizeof(uint32_t)) == hipSuccess;
-		ok = ok && hipMalloc(&c->d_fo_nfall, 2 * sizeof(uint32_t)) == hipSuccess && hipMemset(c->d_fo_nfall, 0, 2 * sizeof(uint32_t)) == hipSuccess;
+		ok = ok && hipMalloc(&c->d_fo_nfall, 4 * sizeof(uint32_t)) == hipSuccess && hipMemset(c->d_fo_nfall, 0, 4 * sizeof(uint32_t)) == hipSuccess;
 		// a poll is three loads and a short sleep, ~1 us: a frame gives up after a few milliseconds (FLACGPU_FUSED_SPIN_LIMIT=0: at once
 		// -- the tests' way to the slot + fo_fixup_kernel route)
 		c->fo_spin_limit = 4096;
@@ -472,6 +507,9 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	if(!c || !d_pcm || !d_out || nframes == 0 || nframes > c->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
 	if(tail_n >= c->P.blocksize) tail_n = 0;
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	TuneScope tune_scope(&c->tune);
+	c->tune.launched = 0;
+	struct KeepLaunched { flacgpu_ctx *c; ~KeepLaunched() { c->last_launched = c->tune.launched; } } keep_launched{c};
 	const DevParams &P = c->P;
 	if(tail_n) {
 		// The short last block has its own job schedule and windows.  Both live in one device copy each, and the sources are
@@ -493,19 +531,26 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	// The fused output (flacgpu_kernels.hip, PackOut): the pack kernels (pack2_kernel, ff_kernel) write every frame once, at its
 	// final place; no slots, no scan / compact kernels.  FLACGPU_NO_FUSED_COMPACT=1: the two-kernel compaction, for A/B runs and the
 	// parity tests of that path.
-	static int fuse = -1;
-	if(fuse < 0) fuse = getenv("FLACGPU_NO_FUSED_COMPACT") ? 0 : 1;
+	const int fuse = c->tune.no_fused ? 0 : 1;
 	PackOutArgs po = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
 	if(fuse && nframes <= c->fo_frames) {
-		// (the epoch is committed below, once a kernel has really run with it: its fix-up kernel is what prepares the other bank)
 		uint32_t epoch = c->fo_epoch + 1;
-		if(epoch >= (1u << 24)) {
-			// the tags have gone round: start again from clean words (once in sixteen million batches)
+		if(epoch >= (1u << 24) || c->fo_dirty) {
+			// the tags have gone round: start again from clean words (once in sixteen million batches) -- or the batch before ended in an
+			// error with kernels of it possibly run: counters its last users would have zeroed may not be zero
 			if(hipMemsetAsync(c->d_fo_fstate, 0, c->fo_frames * sizeof(uint64_t), s) != hipSuccess || hipMemsetAsync(c->d_fo_sstate, 0, c->fo_segs * sizeof(uint64_t), s) != hipSuccess ||
+			   hipMemsetAsync(c->d_fo_scount, 0, c->fo_segs * sizeof(uint64_t), s) != hipSuccess ||
 			   hipMemsetAsync(c->d_fo_sprefix, 0, c->fo_segs * sizeof(uint64_t), s) != hipSuccess || hipMemsetAsync(c->d_fo_nfall, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-			c->fo_epoch = 0; epoch = 1;
+			c->fo_epoch = 0; epoch = 1; c->fo_last_fused = 0;
 		}
+		else if(c->fo_last_fused + 1 != epoch && hipMemsetAsync(c->d_fo_nfall, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		po = PackOutArgs{d_out, out_cap, c->d_offsets, c->d_total, c->d_fo_fstate, c->d_fo_sstate, c->d_fo_sprefix, c->d_fo_scount, c->d_fo_fall, c->d_fo_nfall, epoch, c->fo_spin_limit, c->ff_lag > 0 ? (uint32_t)c->ff_lag : 0u};
+		// The epoch is spent from here on, whether or not the launches below succeed: a kernel that tagged words with it may have run
+		// before a later launch fails, and the next batch must not take those words for its own.  An unused epoch costs
+		// nothing: the tags only have to differ from batch to batch.  (The arrival counters are zeroed by their last user; a batch
+		// that aborted half way may leave some non-zero: fo_dirty makes the next batch start from clean words.)
+		c->fo_epoch = epoch;
+		c->fo_dirty = true;          // (until every launch of this batch has been enqueued)
 	}
 	// ff_kernel (one kernel for the whole frame, flacgpu_kernels.hip) where it applies: not with the verify hints (the decoder wants
 	// the pack kernel's run starts), not with the debug stamps; one stream
@@ -626,7 +671,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		if(fused) seq[5] = seq[6] = c->ev[3];
 		else { (void)hipEventRecord(c->ev[2], s); seq[5] = c->ev[2]; seq[6] = c->ev[3]; }
 	}
-	if(fused) c->fo_epoch = po.epoch;
+	if(fused) { note_launch(K_FUSED_OUTPUT); c->fo_last_fused = po.epoch; }
 	if(!fused) {
 		if(launch_scan(c->d_frame_bytes, nframes, c->d_offsets, c->d_total, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		if(launch_compact(c->d_slots, P.slot_bytes, c->d_frame_bytes, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
@@ -636,6 +681,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	if(d_total_out && hipMemcpyAsync(d_total_out, c->d_total, sizeof(uint64_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	c->last_nframes = nframes;
 	c->timing_valid = true;
+	c->fo_dirty = false;
 	return FLACGPU_OK;
 }
 
@@ -712,6 +758,7 @@ static int64_t encode_staged(flacgpu_ctx *c, uint32_t nframes, uint64_t first_fr
                              uint8_t *out, size_t out_cap, uint32_t *frame_bytes)
 {
 	hipStream_t s = c->stream;
+	TuneScope tune_scope(&c->tune);
 	int r = run_batch(c, c->d_pcm, nframes, first_frame_number, tail_n, tail_windows, c->d_out, c->d_out_bytes, nullptr, nullptr, s);
 	if(r != FLACGPU_OK) return r;
 	memset(&c->last_verify, 0, sizeof c->last_verify);
@@ -869,6 +916,7 @@ extern "C" int flacgpu_submit_batch_raw(flacgpu_ctx *c, const void *raw, const f
 	int r = make_stage_params(c, fmt, &S);
 	if(r != FLACGPU_OK) return r;
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	TuneScope tune_scope(&c->tune);
 	r = async_prepare(c);
 	if(r != FLACGPU_OK) return r;
 	const DevParams &P = c->P;
@@ -919,8 +967,7 @@ extern "C" int flacgpu_submit_batch_raw(flacgpu_ctx *c, const void *raw, const f
 	a.pay_by_kernel = false;
 	{
 		void *dptr = nullptr;
-		static int off = -1;
-		if(off < 0) off = getenv("FLACGPU_NO_COPY_KERNEL") ? 1 : 0;
+		const int off = c->tune.no_copy_kernel;
 		if(!off && ((uintptr_t)out & 15u) == 0 && hipHostGetDevicePointer(&dptr, out, 0) == hipSuccess && dptr) {
 			if(hipStreamWaitEvent(c->s_pay, a.ev_done, 0) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 			hipLaunchKernelGGL(payload_copy_kernel, dim3(256), dim3(256), 0, c->s_pay, a.d_out, a.d_total, (uint8_t *)dptr, (uint64_t)out_cap);
@@ -998,6 +1045,7 @@ extern "C" int flacgpu_verify_batch_device(flacgpu_ctx *c, const uint8_t *d_fram
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	const int r = ensure_verify(c);
 	if(r != FLACGPU_OK) return r;
+	TuneScope tune_scope(&c->tune);
 	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
 	const uint32_t tail_n = last_block_samples < c->P.blocksize ? last_block_samples : 0;
 	if(launch_scan(d_frame_bytes, nframes, c->d_voffsets, c->d_vtotal, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
@@ -1049,6 +1097,35 @@ extern "C" int flacgpu_last_batch_info(flacgpu_ctx *c, uint32_t nframes, flacgpu
 		if(channel_assignment) channel_assignment[f] = h[f].channel_assignment;
 	}
 	free(h);
+	return FLACGPU_OK;
+}
+
+// which kernels the last batch launched (K_* of flacgpu_dev.h; flacgpu_kernel_bit_name names a bit) -- what the tests that pin a
+// kernel selection assert on
+extern "C" int flacgpu_last_batch_kernels(const flacgpu_ctx *c, uint32_t *mask)
+{
+	if(!c || !mask) return FLACGPU_ERR_BAD_ARG;
+	*mask = c->last_launched;
+	return FLACGPU_OK;
+}
+extern "C" const char *flacgpu_kernel_bit_name(uint32_t bit)
+{
+	static const char *const names[] = {"ff_kernel", "prep3_kernel", "prep2_kernel", "prep_kernel", "autoc3_kernel", "autoc2_kernel", "autoc_kernel", "model_kernel",
+		"evalg_kernel", "evalw_kernel", "eval_list_kernel", "eval_kernel", "pack_plan_kernel", "pack2_kernel", "pack_kernel", "fo_place_kernel", "scan_kernel", "compact_kernel",
+		"append_tail_kernel", "pack2_kernel<run18>", "autoc3_kernel<SETS>", "autoc3_kernel<PLANES>", "fused_output", "prep2_kernel<DECIDE>", "prep1_kernel", "autoc1_kernel", "evalg1_kernel"};
+	return bit < sizeof names / sizeof names[0] ? names[bit] : nullptr;
+}
+// frames that gave up waiting in the fused output (PackOut, flacgpu_kernels.hip) and were placed from their slots by fo_place_kernel:
+// all of them since the context was created, and the most of any one batch.  Zero in a healthy run; a non-zero count is time (up
+// to spin_limit polls per frame), never bytes.  Synchronises the device.
+extern "C" int flacgpu_fused_fallbacks(flacgpu_ctx *c, uint32_t *total, uint32_t *max_in_a_batch)
+{
+	if(!c) return FLACGPU_ERR_BAD_ARG;
+	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+	uint32_t h[4] = {0, 0, 0, 0};
+	if(hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, c->d_fo_nfall, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(total) *total = h[2];
+	if(max_in_a_batch) *max_in_a_batch = h[3];
 	return FLACGPU_OK;
 }
 

@@ -505,8 +505,7 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 // the lane-per-subframe kernel: stereo with a full mid/side search, and enough subframes for two wavefronts per SIMD
 static bool autoc3_wanted(const DevParams &P, uint32_t nmain, uint32_t njobs)
 {
-	static int mode = -1;
-	if(mode < 0) { const char *e = getenv("FLACGPU_AUTOC3"); mode = e ? atoi(e) : 2; }      // 0: never, 1: whenever it applies, 2: when it fills the chip
+	const int mode = tune().autoc3_mode;      // FLACGPU_AUTOC3 = 0: never, 1: whenever it applies, 2: when it fills the chip
 	if(mode == 0 || !(P.channels == 2 && P.ms_mode == 1 && P.ncand == 4) || P.blocksize < 64) return false;
 	const uint32_t waves = njobs * ((nmain * 4u + A3_ITEMS - 1) / A3_ITEMS);
 	return mode == 1 || waves >= 2048u;
@@ -515,13 +514,12 @@ template <int VARIANT, int LAG>
 static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const int32_t *chan, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s)
 {
 	const uint32_t ngroups = (nmain * 4u + A3_ITEMS - 1) / A3_ITEMS;
-	static int sets = -1;
-	if(sets < 0) { const char *e = getenv("FLACGPU_AUTOC3_SETS"); sets = e ? atoi(e) : 1; }
+	const int sets = tune().autoc3_sets;
 	// 16-bit input: the prep kernel's left and right planes are 16-bit pairs (ChanPrep::fmt = 1 whenever sbps <= 16) -- read those
-	static int planes = -1;
-	if(planes < 0) { const char *e = getenv("FLACGPU_AUTOC3_PLANES"); planes = e ? atoi(e) : 1; }
+	const int planes = tune().autoc3_planes;
 	const bool pl = planes && chan && P.bps <= 16;
 	const int32_t *src = pl ? chan : pcm;
+	note_launch(K_AUTOC3 | (pl ? K_AUTOC3_PLANES : 0u) | (sets && nsets >= 2 && nsets <= 8 ? K_AUTOC3_SETS : 0u));
 	if(sets && nsets >= 2 && nsets <= 8) {
 		if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, true>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
 		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, false>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
@@ -536,8 +534,8 @@ static void launch_autoc2_t(const DevParams &P, const int32_t *pcm, const float 
 {
 	const uint32_t nfc = nmain * P.ncand, ngroups = (nfc + A2_ITEMS - 1) / A2_ITEMS;
 	const bool ms4 = P.channels == 2 && P.ms_mode == 1, st2 = P.channels == 2 && P.ncand == 2;
-	static int nogroup = -1;
-	if(nogroup < 0) nogroup = getenv("FLACGPU_AUTOC2_UNGROUPED") ? 1 : 0;
+	const int nogroup = tune().autoc2_ungrouped;
+	note_launch(K_AUTOC2);
 	if(nsets >= 2 && nsets <= 8 && !nogroup) {
 		// one single-wavefront workgroup per (group of subframes, job set)
 		const dim3 grid(ngroups * nsets), block(64);

@@ -128,6 +128,32 @@ struct FrameInfo {
 	uint8_t pad[3];
 };
 
+// ---- development / A-B switches and the record of what a batch launched -----------------------------------------------------
+// The switches are read from the environment when a CONTEXT is created (flacgpu_create), not once per process: two engines of one
+// process may differ, nothing is a function static shared by threads, and the per-device kernel attributes (dynamic LDS size) are
+// set once per device, not once per process.  tune() is the calling thread's current context's copy while one of its
+// entry points runs (flacgpu_api.cpp: TuneScope), else a per-thread copy read from the environment.
+enum : uint32_t {
+	K_FF = 1u << 0, K_PREP3 = 1u << 1, K_PREP2 = 1u << 2, K_PREP = 1u << 3, K_AUTOC3 = 1u << 4, K_AUTOC2 = 1u << 5, K_AUTOC = 1u << 6, K_MODEL = 1u << 7,
+	K_EVALG = 1u << 8, K_EVALW = 1u << 9, K_EVAL_LIST = 1u << 10, K_EVAL = 1u << 11, K_PACK_PLAN = 1u << 12, K_PACK2 = 1u << 13, K_PACK = 1u << 14,
+	K_FO_PLACE = 1u << 15, K_SCAN = 1u << 16, K_COMPACT = 1u << 17, K_APPEND_TAIL = 1u << 18, K_PACK2_RUN18 = 1u << 19, K_AUTOC3_SETS = 1u << 20,
+	K_AUTOC3_PLANES = 1u << 21, K_FUSED_OUTPUT = 1u << 22, K_PREP2_DECIDE = 1u << 23, K_PREP1 = 1u << 24, K_AUTOC1 = 1u << 25, K_EVALG1 = 1u << 26
+};
+struct Tune {
+	int autoc3_mode;           // FLACGPU_AUTOC3: 0 never, 1 whenever it applies, 2 (default) when it fills the chip
+	int autoc3_sets, autoc3_planes, autoc2_ungrouped;
+	int autoc2_force;          // FLACGPU_AUTOC2: 0 decide per batch, 1 never, 2 always
+	int no_ff, no_run18, no_prep3, no_prep_decide, no_evalg, no_fast1;
+	int eval_wpc, evalw_wpc, eval_waves, eval_cpw, eval_prefetch /* -1: derive */;
+	int sync_debug, no_fused, no_copy_kernel, cands_global;
+	int device;                // the context's device: index of the per-device "attributes set" flags
+	uint32_t launched;         // K_* of every kernel launched since the batch began
+};
+Tune &tune();
+inline void note_launch(uint32_t k) { tune().launched |= k; }
+// true exactly once per (call site's flag array, device): the hipFuncSetAttribute calls of a launch function
+inline bool first_on_device(bool (&done)[64]) { const int d = tune().device & 63; if(done[d]) return false; done[d] = true; return true; }
+
 void sync_debug(const char *what, hipStream_t s);
 size_t analyze_lds_bytes(const DevParams &P);
 size_t pack_lds_bytes(const DevParams &P);

@@ -314,8 +314,7 @@ __global__ __launch_bounds__(64 * WPC, EVALG_WAVES_PER_SIMD) void evalg_kernel(c
 // ---------------------------------------------------------------------------------------------------------
 bool evalg_applicable(const DevParams &P)
 {
-	static int off = -1;
-	if(off < 0) off = getenv("FLACGPU_NO_EVALG") ? 1 : 0;
+	const int off = tune().no_evalg;
 	const uint32_t S = P.blocksize / 64;
 	return !off && P.blocksize % 64 == 0 && S >= 16 && S % 8 == 0 && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC && P.blocksize <= 16384;
 }
@@ -323,8 +322,9 @@ template <int MAXORD, int WPC>
 static hipError_t launch_evalg_t(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
 {
 	const uint32_t lds = evalg_lds_bytes<MAXORD>(P.blocksize, WPC);
-	static bool set = false;
-	if(!set) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<MAXORD, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) return e; set = true; }
+	static bool set[64];
+	if(first_on_device(set)) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<MAXORD, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) { set[tune().device & 63] = false; return e; } }
+	note_launch(K_EVALG);
 	hipLaunchKernelGGL((evalg_kernel<MAXORD, WPC>), dim3(nframes * P.ncand), dim3(64 * WPC), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
 	return hipGetLastError();
 }
@@ -334,8 +334,7 @@ hipError_t launch_evalg(const DevParams &P, uint32_t nframes, uint32_t tail_n, c
 	// FLACGPU_EVAL_WPC=2: two wavefronts share a channel's image and halve its candidates (5 wavefronts per SIMD instead of 4).
 	// Measured and left off: same bytes, 2 % slower at -8 (profiles/r03_s_wpc_ab.txt: 0.923-0.929 ms against 0.882-0.910) -- the
 	// kernel's idle quarter is not a lack of wavefronts
-	static int wpc = 0;
-	if(!wpc) { const char *e = getenv("FLACGPU_EVAL_WPC"); wpc = e && atoi(e) == 2 ? 2 : 1; }
+	const int wpc = tune().eval_wpc;
 	const bool two = wpc == 2 && P.ncslots >= 4;
 	if(P.max_lpc_order <= 8) return two ? launch_evalg_t<8, 2>(P, nframes, tail_n, jt, B, dec, s) : launch_evalg_t<8, 1>(P, nframes, tail_n, jt, B, dec, s);
 	return two ? launch_evalg_t<12, 2>(P, nframes, tail_n, jt, B, dec, s) : launch_evalg_t<12, 1>(P, nframes, tail_n, jt, B, dec, s);

@@ -365,14 +365,14 @@ template <int MAXORD>
 static hipError_t launch_evalw_t(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec,
                                  const uint32_t *in_list, const uint32_t *in_count, uint32_t *out_list, uint32_t *out_count, hipStream_t s)
 {
-	static bool set = false;
-	if(!set) {
+	static bool set[64];
+	if(first_on_device(set)) {
 		hipError_t e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e != hipSuccess) return e;
-		set = true;
+		if(e != hipSuccess) { set[tune().device & 63] = false; return e; }
 	}
+	note_launch(K_EVALW);
 	const uint32_t nchan = nframes * P.ncand;
 	if(in_list) {
 		// as many wavefronts as the chip holds of them: an empty list costs a few microseconds, a full one (white noise: the side
@@ -387,8 +387,7 @@ static hipError_t launch_evalw_t(const DevParams &P, uint32_t nframes, uint32_t 
 	}
 	else {
 		// every channel of the batch (streams of more than 16 bits): two wavefronts per channel (FLACGPU_EVALW_WPC=1: one, for A/B runs)
-		static int wpc = 0;
-		if(!wpc) { const char *e = getenv("FLACGPU_EVALW_WPC"); wpc = e && atoi(e) == 1 ? 1 : 2; }
+		const int wpc = tune().evalw_wpc;
 		if(wpc == 2 && P.ncslots >= 4)
 			hipLaunchKernelGGL((evalw_kernel<MAXORD, false, 2>), dim3(nchan), dim3(128), evalw_lds_bytes<MAXORD>(P.blocksize, 2), s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, nullptr, nullptr, out_list, out_count);
 		else

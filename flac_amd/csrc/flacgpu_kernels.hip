@@ -737,7 +737,8 @@ struct PackOut {
 	uint64_t *sprefix;         // [segments] tagged offset of a segment's first frame
 	uint64_t *scount;          // [segments] {arrivals, bytes} so far (whoever completes a segment zeroes it again)
 	uint32_t *fall;            // [frames] the frames that gave up waiting and went to their slots
-	uint32_t *nfall;           // [2] how many, by epoch parity (fo_place_kernel zeroes the other one for the next batch)
+	uint32_t *nfall;           // [4] how many, by epoch parity (fo_place_kernel zeroes the other one for the next batch); [2] all of them since the
+	                           // context was created, [3] the most of any one batch
 	uint32_t epoch;            // 1 .. 2^24 - 1
 	uint32_t spin_limit;       // polls before a frame gives up waiting for the frames in front of it
 	uint32_t lag;              // ff_kernel: the wavefront of frame f places frame f - lag (0: nobody places anything inside the kernel)
@@ -2013,7 +2014,11 @@ __global__ __launch_bounds__(TPB) void fo_place_kernel(const PackOut O, uint32_t
 	uint32_t count = nmain - first;
 	if(LISTED) {
 		count = __hip_atomic_load(&O.nfall[O.epoch & 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if(blockIdx.x == 0 && tid == 0) __hip_atomic_store(&O.nfall[(O.epoch + 1u) & 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next batch's counter
+		if(blockIdx.x == 0 && tid == 0) {
+			__hip_atomic_store(&O.nfall[(O.epoch + 1u) & 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next batch's counter
+			// what the waits cost is invisible in the bytes: frames that gave up are counted for flacgpu_fused_fallbacks
+			if(count) { atomicAdd(&O.nfall[2], count); atomicMax(&O.nfall[3], count); }
+		}
 	}
 	for(uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
 		const uint32_t f = LISTED ? O.fall[i] : first + i;
@@ -2234,8 +2239,8 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
                                 const SubDecision *dec, uint8_t *plan, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, const PackOutArgs *po, bool *fused_out,
                                 uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
 {
-	static bool attr_set = false;
-	if(!attr_set) {
+	static bool attr_set[64];
+	if(first_on_device(attr_set)) {
 		hipError_t e = hipFuncSetAttribute((const void *)pack_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if constexpr(MAXORD <= 16) {
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
@@ -2244,8 +2249,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, true, TPB / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, 64, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		}
-		if(e != hipSuccess) return e;
-		attr_set = true;
+		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
 	}
 	uint32_t f_lo = 0;
 	bool fused = false;
@@ -2264,10 +2268,11 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			const bool half = P.blocksize <= CHUNK * (TPB / 2);
 			// the presets' 1152-sample blocks: 64 runs of 18 samples, one wavefront per frame (not with the verify hints: their decoder
 			// counts in 16-sample runs; FLACGPU_NO_RUN18=1: the 128-thread instance, for A/B runs)
-			static const bool no_run18 = getenv("FLACGPU_NO_RUN18") != nullptr;
+			const bool no_run18 = tune().no_run18 != 0;
 			const uint32_t pstride = (uint32_t)pack_plan_stride(P);
 			if(f_lo) hipLaunchKernelGGL(pack_plan_kernel, dim3((f_lo + PLAN_FRAMES - 1) / PLAN_FRAMES), dim3(64), 0, s, P, make_hdr_const(P), f_lo, first, dec, plan, pstride, info);
 			const bool run18 = P.blocksize == 1152 && !hints && !no_run18 && (1152u >> P.max_po) % 18u == 0;
+			if(f_lo) note_launch(K_PACK_PLAN | K_PACK2 | (run18 ? K_PACK2_RUN18 : 0u) | (fused ? K_FO_PLACE : 0u));
 			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
 			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
 			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
@@ -2277,6 +2282,7 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			if(fused) hipLaunchKernelGGL(fo_place_kernel<true>, dim3(FO_PLACE_GRID), dim3(TPB), 0, s, O, 0u, f_lo, slots, P.slot_bytes, fb);
 		}
 	}
+	if(f_lo < nframes) note_launch(K_PACK | (fused ? K_APPEND_TAIL : 0u));
 	if(f_lo < nframes) hipLaunchKernelGGL(pack_kernel<MAXORD>, dim3(nframes - f_lo), dim3(TPB), lds, s, P, chan, nframes, tail_n, f_lo, first, dec, slots, fb, info);
 	if(fused && f_lo < nframes) hipLaunchKernelGGL(append_tail_kernel, dim3(1), dim3(TPB), 0, s, slots + (size_t)f_lo * P.slot_bytes, fb, f_lo, O);
 	if(fused_out) *fused_out = fused;
@@ -2308,7 +2314,7 @@ hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes
 // fixed order) and pack2_kernel could pack them; not with the verify hints (their decoder wants pack2_kernel's run starts)
 bool ff_applicable(const DevParams &P)
 {
-	static const bool off = getenv("FLACGPU_NO_FF") != nullptr;
+	const bool off = tune().no_ff != 0;
 	return !off && P.channels == 2 && P.bps <= 16 && P.blocksize == FF_N && P.ncand == (P.ms_mode == 1 ? 4u : 2u) && prep2_decides(P) && pack2_applicable(P)
 	       && (1152u >> P.max_po) % 18u == 0 && P.slot_bytes <= 52 * FF_XSPAN - 64;      // (every span shift of a frame in the LDS table)
 }
@@ -2324,6 +2330,7 @@ hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uin
 	// that live 26 us pays for every extra round trip (the write-through slot stores, the loads of the frame it places) with a
 	// wavefront slot that is not computing; only -2, whose wavefronts live longer, comes out ahead.  And a wavefront that places its
 	// OWN frame and waits for the lengths in front of it (what pack2_kernel does) was the slowest: 0.167 at -0.
+	note_launch(K_FF | (po && po->out ? K_FO_PLACE : 0u));
 	const PackOut Oplace = make_pack_out(po);
 	PackOut O = Oplace;
 	if(po && po->out) { O.lag = po->lag < nmain ? po->lag : 0u; if(!O.lag) O.out = nullptr; }       // (lag 0: publish only)
@@ -2355,12 +2362,14 @@ hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uin
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)
 {
 	if(nframes == 0) return hipSuccess;
+	note_launch(K_SCAN);
 	hipLaunchKernelGGL(scan_kernel, dim3((nframes + SCAN_T - 1) / SCAN_T), dim3(SCAN_T), 0, s, fb, nframes, offsets, total);
 	return hipGetLastError();
 }
 hipError_t launch_compact(const uint8_t *slots, uint32_t slot_bytes, const uint32_t *fb, const uint64_t *offsets,
                           uint8_t *out, uint64_t out_cap, uint32_t nframes, hipStream_t s)
 {
+	note_launch(K_COMPACT);
 	hipLaunchKernelGGL(compact_kernel, dim3(nframes), dim3(TPB), 0, s, slots, slot_bytes, fb, offsets, out, out_cap);
 	return hipGetLastError();
 }

@@ -558,8 +558,7 @@ static size_t prep2_decide_lds(const DevParams &P, uint32_t nraw, uint32_t waves
 }
 bool prep2_decides(const DevParams &P)
 {
-	static int off = -1;
-	if(off < 0) off = getenv("FLACGPU_NO_PREP_DECIDE") ? 1 : 0;
+	const int off = tune().no_prep_decide;
 	if(off || !prep2_applicable(P) || prep3_applicable(P)) return false;
 	if(P.max_lpc_order != 0 || P.nfixed != 1 || P.ncslots != 1 || P.bps > 16 || P.tune_flags) return false;
 	const uint32_t n = P.blocksize;
@@ -584,24 +583,23 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 		if(prep2_decides(P)) (void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
 		return hipSuccess;
 	}
-	static bool attr_set = false;
-	if(!attr_set) {
+	static bool attr_set[64];
+	if(first_on_device(attr_set)) {
 		hipError_t e = hipSuccess;
 #define P2ATTR(W, NF, DZ) if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep2_kernel<W, NF, DZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)
 		P2ATTR(false, 0, false); P2ATTR(false, 1152, false); P2ATTR(false, 4096, false); P2ATTR(true, 0, false); P2ATTR(true, 1152, false); P2ATTR(true, 4096, false);
 		P2ATTR(false, 0, true); P2ATTR(false, 1152, true);
 #undef P2ATTR
-		if(e != hipSuccess) return e;
-		attr_set = true;
+		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
 	}
-	if(prep3_applicable(P) && !getenv("FLACGPU_NO_PREP3")) {
-		static bool attr3 = false;
-		if(!attr3) {
+	if(prep3_applicable(P) && !tune().no_prep3) {
+		static bool attr3[64];
+		if(first_on_device(attr3)) {
 			hipError_t e = hipFuncSetAttribute((const void *)prep3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-			if(e != hipSuccess) return e;
-			attr3 = true;
+			if(e != hipSuccess) { attr3[tune().device & 63] = false; return e; }
 		}
+		note_launch(K_PREP3);
 		const size_t lds3 = 8 * (size_t)p2_chan_bytes(P.blocksize / 4);
 		if(P.bps > 20) hipLaunchKernelGGL(prep3_kernel<true>, dim3(nmain), dim3(TPB), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
 		else hipLaunchKernelGGL(prep3_kernel<false>, dim3(nmain), dim3(TPB), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
@@ -612,7 +610,9 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	const uint32_t waves = stereo_ms ? 4u : nraw;
 	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize, p2_chunk_len(P.blocksize));
 #define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft)
+	note_launch(K_PREP2);
 	if(prep2_decides(P)) {
+		note_launch(K_PREP2_DECIDE);
 		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
 		(void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
 		const size_t ldz = prep2_decide_lds(P, nraw, waves);

@@ -75,6 +75,8 @@ void flacgpu_host_md5_final(flacgpu_host_md5 *m, uint8_t digest[16]);
 int flacgpu_host_md5_x8_available(void);
 void flacgpu_host_md5_x8_blocks(flacgpu_host_md5 *const m[8], const void *const data[8], size_t nblocks);    /* every context at a block boundary */
 void flacgpu_host_md5_many(const void *const *data, const size_t *len, uint32_t n, uint8_t (*digest)[16]);
+int flacgpu_host_md5_x16_available(void);
+void flacgpu_host_md5_many_mt(const void *const *data, const size_t *len, uint32_t n, uint8_t (*digest)[16], uint32_t nthreads);   /* the same on host threads, a group of chains per work item */
 /* feeds `samples` inter-channel samples of interleaved int32 PCM as bytes_per_sample-byte little-endian */
 void flacgpu_host_md5_pcm(flacgpu_host_md5 *m, const int32_t *interleaved, uint32_t channels, size_t samples, uint32_t bytes_per_sample);
 

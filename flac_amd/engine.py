@@ -367,6 +367,26 @@ class FrameEngine:
             raise FlacGpuError("flacgpu_last_batch_info: %s" % self.lib.flacgpu_strerror(r).decode())
         return sub, ca
 
+    def last_batch_kernels(self):
+        """names of the kernels (families / flavours) the most recent batch launched (flacgpu_last_batch_kernels)"""
+        m = C.c_uint32(0)
+        self.lib.flacgpu_last_batch_kernels.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        self.lib.flacgpu_kernel_bit_name.argtypes = [C.c_uint32]
+        self.lib.flacgpu_kernel_bit_name.restype = C.c_char_p
+        r = self.lib.flacgpu_last_batch_kernels(self.ctx, C.byref(m))
+        if r != 0:
+            raise FlacGpuError("flacgpu_last_batch_kernels: %s" % self.lib.flacgpu_strerror(r).decode())
+        return {self.lib.flacgpu_kernel_bit_name(b).decode() for b in range(32) if m.value >> b & 1 and self.lib.flacgpu_kernel_bit_name(b)}
+
+    def fused_fallbacks(self):
+        """(frames that gave up waiting in the fused output since the engine was created, the most of any one batch); synchronises"""
+        t, mx = C.c_uint32(0), C.c_uint32(0)
+        self.lib.flacgpu_fused_fallbacks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        r = self.lib.flacgpu_fused_fallbacks(self.ctx, C.byref(t), C.byref(mx))
+        if r != 0:
+            raise FlacGpuError("flacgpu_fused_fallbacks: %s" % self.lib.flacgpu_strerror(r).decode())
+        return int(t.value), int(mx.value)
+
     def set_subbatches(self, n):
         r = self.lib.flacgpu_set_subbatches(self.ctx, n)
         if r != 0:

@@ -198,6 +198,16 @@ int flacgpu_last_batch_phase_ms(flacgpu_ctx *ctx, float ms[6]);
 /* The same for the batch launched `batches_ago` batches before the last one (0 = the last; the engine keeps the
  * events of its 64 most recent batches), so that a run of batches can be timed without a host sync in between. */
 int flacgpu_batch_phase_ms(flacgpu_ctx *ctx, uint32_t batches_ago, float ms[6]);
+/* Which kernels the most recent batch launched: a bit per kernel (family / flavour); flacgpu_kernel_bit_name(bit) names bit
+ * `bit` (NULL past the last).  The engine picks kernels by stream shape and batch size; tests that pin a
+ * selection -- "the full-size -8 batch runs autoc3_kernel<SETS,PLANES> and the fused output" -- assert on this. */
+int flacgpu_last_batch_kernels(const flacgpu_ctx *ctx, uint32_t *mask);
+const char *flacgpu_kernel_bit_name(uint32_t bit);
+/* The fused output (frames written once, at their final place) never waits unboundedly: a frame whose predecessors' lengths do
+ * not turn up within FLACGPU_FUSED_SPIN_LIMIT polls goes to its slot and is placed by a kernel behind the pack kernel.  Such
+ * frames cost time, never bytes; this counts them: all since the context was created, and the most of any one batch (zero in a
+ * healthy run).  Synchronises the device. */
+int flacgpu_fused_fallbacks(flacgpu_ctx *ctx, uint32_t *total, uint32_t *max_in_a_batch);
 /* Split every batch into n (1..8) sub-batches that run on separate HIP streams inside the engine and join before the
  * frame compaction (default 1, or the FLACGPU_SUBBATCHES environment variable).  Output is identical. */
 int flacgpu_set_subbatches(flacgpu_ctx *ctx, uint32_t n);

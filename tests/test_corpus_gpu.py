@@ -48,7 +48,7 @@ def test_corpus_job_equals_the_reference_file(tmp_path):
     assert c == want
 
 
-@pytest.mark.parametrize("md5", ["device", "host"])
+@pytest.mark.parametrize("md5", ["device", "host", "from-host"])
 @pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref/libFLAC_ref.so not built on this box")
 def test_corpus_as_tracks_equals_the_reference_files(tmp_path, md5):
     """--tracks: the corpus as separate streams, frame numbers restarting per track, a STREAMINFO and an MD5 per track (the digests
@@ -62,11 +62,17 @@ def test_corpus_as_tracks_equals_the_reference_files(tmp_path, md5):
     pcm = co.host_frames(base, 0, nfr)[:samples].astype(np.int32)
     out = str(tmp_path / "shelf")
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, "-m", "flac_amd.corpus", "--out", out, "--samples", str(samples), "--tracks", str(ntracks), "--md5-threads", "2", "--md5", md5],
+    # from-host: the job's input in page-locked host memory, copied to the device track by track beside the encodes and hashed by host
+    # threads straight from that buffer (the default since round 5); device / host: the input generated in HBM (round 4's job)
+    how = ["--input", "host", "--md5-threads", "3"] if md5 == "from-host" else ["--input", "device", "--md5-threads", "2", "--md5", md5]
+    r = subprocess.run([sys.executable, "-m", "flac_amd.corpus", "--out", out, "--samples", str(samples), "--tracks", str(ntracks)] + how,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["tracks"] == ntracks and line["tracks_with_a_bad_crc16"] == 0
+    import hashlib
+    for t, (lo, hi) in enumerate(co.track_ranges(nfr, ntracks)):
+        assert line["track_md5"][t] == hashlib.md5(pcm[lo * co.BLOCK:min(hi * co.BLOCK, samples)].astype("<i2").tobytes()).hexdigest(), t
     for t, (lo, hi) in enumerate(co.track_ranges(nfr, ntracks)):
         want = po.ref_encode_file(pcm[lo * co.BLOCK:min(hi * co.BLOCK, samples)], 16, 44100, 8, str(tmp_path / "ref.flac"), do_md5=1)
         with open("%s.%04d.flac" % (out, t), "rb") as f:
