@@ -149,23 +149,41 @@ __global__ __launch_bounds__(64) void md5_many_kernel(const uint8_t *__restrict_
 
 using namespace flacgpu;
 
-// include/flacgpu.h: digests of n byte ranges of device memory, d_base + offsets[i] .. + lengths[i]; arrays on the host, digests to the host
+// include/flacgpu.h: digests of n byte ranges of device memory, d_base + offsets[i] .. + lengths[i]; arrays on the host, digests to the host.
+// d_base must be 4-byte aligned (the kernel reads the aligned word a range starts in: with an aligned base that word lies inside the
+// caller's allocation whatever the range's own alignment); that the ranges lie inside the allocation is the caller's business, as
+// with any pointer + length.  The small device scratch (offsets, lengths, digests) is kept per device and grows on demand: no
+// hipMalloc / hipFree -- a device-wide synchronisation -- per call.
+#include <mutex>
+namespace {
+struct Md5Scratch { void *p = nullptr; size_t cap = 0; };
+std::mutex g_md5_mu;
+Md5Scratch g_md5_scratch[64];
+}
 extern "C" int flacgpu_md5_many_device(int device, const void *d_base, const uint64_t *offsets, const uint64_t *lengths, uint32_t n, uint8_t *digests, void *stream)
 {
 	if(n == 0) return FLACGPU_OK;
-	if(!d_base || !offsets || !lengths || !digests) return FLACGPU_ERR_BAD_ARG;
+	if(!d_base || !offsets || !lengths || !digests || ((uintptr_t)d_base & 3u) || device < 0 || device >= 64) return FLACGPU_ERR_BAD_ARG;
 	if(hipSetDevice(device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	hipStream_t s = (hipStream_t)stream;
-	uint64_t *d_meta = nullptr;
-	uint8_t *d_dig = nullptr;
-	if(hipMalloc(&d_meta, (size_t)n * 16) != hipSuccess) return FLACGPU_ERR_ALLOC;
-	if(hipMalloc(&d_dig, (size_t)n * 16) != hipSuccess) { (void)hipFree(d_meta); return FLACGPU_ERR_ALLOC; }
+	// one call per device at a time uses the scratch (the call is synchronous on its stream anyway)
+	std::lock_guard<std::mutex> lock(g_md5_mu);
+	Md5Scratch &sc = g_md5_scratch[device];
+	const size_t need = (size_t)n * 32;
+	if(sc.cap < need) {
+		if(sc.p) (void)hipFree(sc.p);
+		sc.p = nullptr; sc.cap = 0;
+		const size_t cap = need < 65536 ? 65536 : need;
+		if(hipMalloc(&sc.p, cap) != hipSuccess) return FLACGPU_ERR_ALLOC;
+		sc.cap = cap;
+	}
+	uint64_t *d_meta = (uint64_t *)sc.p;
+	uint8_t *d_dig = (uint8_t *)sc.p + (size_t)n * 16;
 	int r = FLACGPU_OK;
 	if(hipMemcpyAsync(d_meta, offsets, (size_t)n * 8, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(d_meta + n, lengths, (size_t)n * 8, hipMemcpyHostToDevice, s) != hipSuccess) r = FLACGPU_ERR_LAUNCH;
 	if(r == FLACGPU_OK) {
 		hipLaunchKernelGGL(md5_many_kernel, dim3((n + 63) / 64), dim3(64), 0, s, (const uint8_t *)d_base, d_meta, d_meta + n, n, d_dig);
 		if(hipGetLastError() != hipSuccess || hipMemcpyAsync(digests, d_dig, (size_t)n * 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) r = FLACGPU_ERR_LAUNCH;
 	}
-	(void)hipFree(d_meta); (void)hipFree(d_dig);
 	return r;
 }

@@ -147,7 +147,9 @@ int flacgpu_stage_raw_device(flacgpu_ctx *ctx, const void *d_raw, const flacgpu_
  * included) -- the sample bytes of n streams as they lie staged in HBM: what FLAC__stream_encoder_finish() puts into each
  * stream's STREAMINFO (the reference hashes them on the host as they pass, src/libFLAC/stream_encoder.c:3448, :3666-3686;
  * src/libFLAC/md5.c:60-222 is the transform).  One lane per stream: worth it for a corpus of many streams, not for one.
- * offsets, lengths: host arrays [n]; digests: host [n][16].  Synchronous on `stream` (may be NULL). */
+ * offsets, lengths: host arrays [n]; digests: host [n][16].  Synchronous on `stream` (may be NULL).
+ * d_base must be 4-byte aligned (FLACGPU_ERR_BAD_ARG otherwise; the ranges themselves may start anywhere); the ranges must
+ * lie inside the caller's allocation. */
 int flacgpu_md5_many_device(int device, const void *d_base, const uint64_t *offsets, const uint64_t *lengths, uint32_t n,
                             uint8_t *digests, void *stream);
 
