@@ -400,6 +400,8 @@ def main(argv=None):
     ap.add_argument("--no-md5", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the process-group path with one rank too")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--check-md5", action="store_true", help="--tracks --input host: after the job (outside its clock) every track's digest is computed again with hashlib "
+                    "from the input buffer and compared")
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; not under a launcher and N > 1: the job starts its N ranks itself "
                     "(flac_amd.dist.ensure_ranks); under one, N must equal its WORLD_SIZE")
     args = ap.parse_args(argv)
@@ -474,8 +476,17 @@ def main(argv=None):
             streams, tm = encode_tracks_from_host(eng, hbuf, F, total_samples, args.tracks, dev, enc_stream, want_md5=not args.no_md5, md5_threads=args.md5_threads)
             t_job = time.perf_counter() - t0
             args.md5_threads = tm["md5_threads"]
+            md5_check = None
+            if args.check_md5 and not args.no_md5:
+                harr = hbuf.numpy()
+                bad = 0
+                for t, (lo, hi) in enumerate(track_ranges(F, args.tracks)):
+                    want = hashlib.md5(memoryview(harr[lo * BLOCK:min(hi * BLOCK, total_samples)]).cast("B")).digest() if hi > lo else hashlib.md5(b"").digest()
+                    bad += want != streams[t][0][8 + 18:8 + 34]
+                md5_check = {"tracks_compared_with_hashlib": args.tracks, "digests_differing": int(bad)}
         else:
             t_gen = None
+            md5_check = None
             args.md5_threads = args.md5_threads or 1
             if args.md5 == "auto":
                 args.md5 = "device" if args.tracks >= 256 else "host"
@@ -509,7 +520,7 @@ def main(argv=None):
                 "md5_seconds": round(tm["md5_seconds"], 3), "md5_prepare_seconds": round(tm["md5_prepare_seconds"], 3),
                 "md5_Msamples_per_s": round(total_samples / tm["md5_seconds"] / 1e6, 1) if tm["md5_seconds"] else None,
                 "job_seconds": round(t_job, 3), "tracks_with_a_bad_crc16": bad_tracks, "write_seconds": round(t_write, 3) if args.out else None,
-                "first_track_md5": streams[0][0][8 + 18:8 + 34].hex(), "track_md5": [h[8 + 18:8 + 34].hex() for h, _, _ in streams]}
+                "md5_check": md5_check, "first_track_md5": streams[0][0][8 + 18:8 + 34].hex(), "track_md5": [h[8 + 18:8 + 34].hex() for h, _, _ in streams]}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
         eng.close()
         return line

@@ -157,6 +157,8 @@ void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 		}
 	}
 	jt->njobs = nj; jt->nanalyses = na; jt->wnd_floats = woff; jt->nsets = ns;
+	for(uint32_t m = 0; m < 7; m++)
+		for(uint32_t o = 0; o < 13; o++) { const uint32_t full = (n / 64u) << m; jt->eg_div[m][o] = full > o ? (0x40000u / (full - o)) << 13 : 0u; }
 }
 }
 

@@ -369,6 +369,33 @@ __device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /*
 		}
 	}
 }
+// IND (round 5): the 64 subframes of a wavefront are 64 INDEPENDENT candidate channels -- mono, stereo without a mid/side search or
+// with the loose one, 3..8 channels: rows fc0 .. fc0 + 63 of the batch's (frame, candidate channel) list, whatever frames they
+// belong to -- each read from its own planar copy (the prep kernels leave every candidate channel behind, wasted bits shifted
+// out: 16-bit pairs where the subframe fits, ChanPrep::fmt, else 32-bit words).  Lane (half, sl) fills column sl of the rows
+// 2 q + half: 32 loads of 2 or 4 bytes where the mid/side flavours have 8 of 8 or 4 -- next to 203 fp64-bound VALU instructions
+// per 8 samples and subframe that is noise, and every channel layout gets the lane-per-subframe arithmetic (mono's
+// autocorrelation took 0.59 ms per 16384 frames for ONE channel with autoc2_kernel's general source, stereo's four take 0.70).
+struct A3FetchInd { int32_t v[32]; float wt; };
+// is16: bit q set = row 2 q + half holds 16-bit pairs (this lane's half)
+__device__ __forceinline__ void a3_fetch_ind(const A2Job &J, const int32_t *__restrict__ chan, uint32_t stride_words, uint32_t fc0, uint32_t nfc, uint32_t half, uint32_t is16, int32_t i, A3FetchInd &F)
+{
+	uint32_t src;
+	a2_index(J, i, src, F.wt);
+	const uint32_t last = nfc - 1u - fc0;                   // (fc0 < nfc)
+	const char *g = (const char *)(chan + (size_t)fc0 * stride_words);
+#pragma unroll
+	for(int q = 0; q < 32; q++) {
+		const uint32_t row = umin32(2u * (uint32_t)q + half, last);
+		const char *p = g + (size_t)row * stride_words * 4u;
+		F.v[q] = (is16 >> q) & 1u ? (int32_t)*(const int16_t *)(p + 2u * src) : *(const int32_t *)(p + 4u * src);
+	}
+}
+__device__ __forceinline__ void a3_store_ind(float *tile, uint32_t half, const A3FetchInd &F, uint32_t col)
+{
+#pragma unroll
+	for(int q = 0; q < 32; q++) tile[(2u * (uint32_t)q + half) * A3_ST + col] = a2_value(F.v[q], 0u, F.wt);
+}
 // one chain step (lpc_intrin_fma.c:46,61) / two steps of the lag-12 routine as compiled (:54), for the four vector lanes l:
 // W(c) = d[first sample of the step + c] of this lane's subframe
 #define A3_STEP(c) _Pragma("unroll") for(int l = 0; l < 4; l++) { _Pragma("unroll") for(int j = 0; j < LAG; j++) \
@@ -383,15 +410,18 @@ __device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /*
 // autoc2_kernel<..., GROUPED>: a PCM line is fetched from HBM once and found in that XCD's L2 by the other sets.  Without: a
 // wavefront per job (twice the wavefronts, half as long: the chip's two-per-SIMD slots fill evenly, and every job fetches its own
 // lines -- 75 KB per frame instead of 42).
-template <int VARIANT, int LAG, bool SETS, bool PLANES>
+// SRC: 0 stereo with a full mid/side search from the interleaved PCM, 1 the same from the left / right planes (PLANES), 2 independent
+// subframes from their planes (IND)
+template <int VARIANT, int LAG, bool SETS, int SRC>
 __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
                                                        uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
                                                        double *__restrict__ autoc_out)
 {
 	__shared__ float tile[A3_ITEMS * A3_ST];
 	__shared__ uint32_t wasted4[A3_ITEMS / 4];
+	constexpr bool PLANES = SRC == 1, IND = SRC == 2;
 	const int lane = (int)threadIdx.x;
-	const uint32_t nfc = nmain * 4u, ngroups = (nfc + A3_ITEMS - 1) / A3_ITEMS;
+	const uint32_t nfc = nmain * (IND ? P.ncand : 4u), ngroups = (nfc + A3_ITEMS - 1) / A3_ITEMS;
 	uint32_t jb_lo, jb_hi, fc0;
 	if(SETS) {
 		const uint32_t nsets = jt->nsets, b = blockIdx.x;
@@ -414,13 +444,22 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 	constexpr int HB = LAG - 1;
 	const uint32_t fc = fc0 + (uint32_t)lane;
 	bool any_wasted;
+	uint32_t is16 = 0;
+	const uint32_t half = (uint32_t)lane >> 5, sl = (uint32_t)lane & 31u;
 	{
 		const ChanPrep pr = preps[fc < nfc ? fc : nfc - 1];
 		((uint8_t *)wasted4)[lane] = (uint8_t)pr.wasted;
 		if(!__any((int)(pr.flags & PREP_LPC))) return;             // 64 constant subframes: nothing to analyse
 		any_wasted = __any((int)(pr.wasted != 0)) != 0;
+		if(IND) {
+			// which rows hold 16-bit pairs: bit q of this lane's word = row 2 q + half
+			const uint64_t b = __ballot((int)(pr.fmt == 1u));
+			uint32_t ev = 0, od = 0;
+#pragma unroll
+			for(int q = 0; q < 32; q++) { ev |= (uint32_t)((b >> (2 * q)) & 1ull) << q; od |= (uint32_t)((b >> (2 * q + 1)) & 1ull) << q; }
+			is16 = half ? od : ev;
+		}
 	}
-	const uint32_t half = (uint32_t)lane >> 5, sl = (uint32_t)lane & 31u;
 	const int2 *pcm2 = (const int2 *)pcm;
 	const float *row = tile + lane * A3_ST;
 	__builtin_amdgcn_wave_barrier();
@@ -439,19 +478,23 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 	double acc[LAG][4];
 #pragma unroll
 	for(int j = 0; j < LAG; j++) { acc[j][0] = 0.0; acc[j][1] = 0.0; acc[j][2] = 0.0; acc[j][3] = 0.0; }
+#define A3_FETCH(idx) do { if constexpr(IND) a3_fetch_ind(J, pcm, P.chan_stride, fc0, nfc, half, is16, (idx), G); else a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (idx), F); } while(0)
+#define A3_STORE(col) do { if constexpr(IND) a3_store_ind(tile, half, G, (col)); else a3_store<PLANES>(tile, wasted4, any_wasted, half, F, (col)); } while(0)
 	double w[HB + A3_T];              // w[HB + c] = d[first sample of the tile + c]
 	A3Fetch F;
+	A3FetchInd G;
+	(void)F; (void)G;
 	// the samples in front of the first step: d[L - 16, L)
-	a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (int32_t)L - 16 + (int32_t)(sl & 15u), F);
-	if(sl < 16) a3_store<PLANES>(tile, wasted4, any_wasted, half, F, sl);
-	a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (int32_t)L + (int32_t)sl, F);
+	A3_FETCH((int32_t)L - 16 + (int32_t)(sl & 15u));
+	if(sl < 16) A3_STORE(sl);
+	A3_FETCH((int32_t)L + (int32_t)sl);
 	__builtin_amdgcn_wave_barrier();
 #pragma unroll
 	for(int u = 0; u < HB; u++) w[A3_T + u] = (double)row[16 - HB + u];
 	for(uint32_t t = 0; t < ntiles; t++) {
 		__builtin_amdgcn_wave_barrier();
-		a3_store<PLANES>(tile, wasted4, any_wasted, half, F, sl);
-		if(t + 1 < ntiles) a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (int32_t)(L + A3_T * (t + 1)) + (int32_t)sl, F);
+		A3_STORE(sl);
+		if(t + 1 < ntiles) A3_FETCH((int32_t)(L + A3_T * (t + 1)) + (int32_t)sl);
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll
 		for(int u = 0; u < HB; u++) w[u] = w[A3_T + u];
@@ -479,12 +522,14 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 	// ---- head d[0,16) and tail d[nd-24, nd) of every subframe as plain copies (the tile is dead now) --------------
 	const uint32_t tail_lo = nd - 24;               // nd > 32
 	{
-		a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, sl < 16 ? (int32_t)sl : (int32_t)(tail_lo + (sl - 16)), F);
-		a3_store<PLANES>(tile, wasted4, any_wasted, half, F, sl);
-		a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (int32_t)(tail_lo + 16 + (sl & 7u)), F);
-		if(sl < 8) a3_store<PLANES>(tile, wasted4, any_wasted, half, F, 32 + sl);
+		A3_FETCH(sl < 16 ? (int32_t)sl : (int32_t)(tail_lo + (sl - 16)));
+		A3_STORE(sl);
+		A3_FETCH((int32_t)(tail_lo + 16 + (sl & 7u)));
+		if(sl < 8) A3_STORE(32 + sl);
 	}
 	__builtin_amdgcn_wave_barrier();
+#undef A3_FETCH
+#undef A3_STORE
 	const uint32_t max_lpc = P.max_lpc_order >= N ? N - 1 : P.max_lpc_order;
 	const uint32_t lag = max_lpc + 1;
 	double *out = autoc_out + ((size_t)(fc < nfc ? fc : nfc - 1) * P.max_jobs + jb) * AUTOC_STRIDE;
@@ -502,30 +547,41 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 #undef A3_STEP
 #undef A3_PAIR
 
-// the lane-per-subframe kernel: stereo with a full mid/side search, and enough subframes for two wavefronts per SIMD
-static bool autoc3_wanted(const DevParams &P, uint32_t nmain, uint32_t njobs)
+// the lane-per-subframe kernel: stereo with a full mid/side search and enough subframes for two wavefronts per SIMD (below that
+// autoc2_kernel's mid/side flavour, four times as fine-grained, is the faster one); every other channel layout from the planes
+// (IND) as soon as half the SIMDs get a wavefront -- autoc2_kernel's general source is three times slower per channel
+static bool autoc3_ms(const DevParams &P) { return P.channels == 2 && P.ms_mode == 1 && P.ncand == 4; }
+static bool autoc3_wanted(const DevParams &P, const int32_t *chan, uint32_t nmain, uint32_t njobs)
 {
 	const int mode = tune().autoc3_mode;      // FLACGPU_AUTOC3 = 0: never, 1: whenever it applies, 2: when it fills the chip
-	if(mode == 0 || !(P.channels == 2 && P.ms_mode == 1 && P.ncand == 4) || P.blocksize < 64) return false;
-	const uint32_t waves = njobs * ((nmain * 4u + A3_ITEMS - 1) / A3_ITEMS);
-	return mode == 1 || waves >= 2048u;
+	if(mode == 0 || P.blocksize < 64) return false;
+	if(!autoc3_ms(P) && (!chan || tune().no_fast1)) return false;
+	const uint32_t waves = njobs * ((nmain * P.ncand + A3_ITEMS - 1) / A3_ITEMS);
+	return mode == 1 || waves >= (autoc3_ms(P) ? 2048u : 512u);
 }
 template <int VARIANT, int LAG>
 static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const int32_t *chan, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s)
 {
-	const uint32_t ngroups = (nmain * 4u + A3_ITEMS - 1) / A3_ITEMS;
+	const uint32_t ngroups = (nmain * P.ncand + A3_ITEMS - 1) / A3_ITEMS;
 	const int sets = tune().autoc3_sets;
+	if(!autoc3_ms(P)) {
+		// independent subframes from their planes.  A wavefront per job: the channels of a group are not one frame's, the sets' trick
+		// of sharing a frame's lines in the L2 does not apply -- and the many short wavefronts fill the chip better for few channels
+		note_launch(K_AUTOC3 | K_AUTOC3_PLANES | K_AUTOC1);
+		hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 2>), dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
+		return;
+	}
 	// 16-bit input: the prep kernel's left and right planes are 16-bit pairs (ChanPrep::fmt = 1 whenever sbps <= 16) -- read those
 	const int planes = tune().autoc3_planes;
 	const bool pl = planes && chan && P.bps <= 16;
 	const int32_t *src = pl ? chan : pcm;
 	note_launch(K_AUTOC3 | (pl ? K_AUTOC3_PLANES : 0u) | (sets && nsets >= 2 && nsets <= 8 ? K_AUTOC3_SETS : 0u));
 	if(sets && nsets >= 2 && nsets <= 8) {
-		if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, true>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
-		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, false>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
+		if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 1>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
+		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 0>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
 	}
-	else if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, true>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
-	else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, false>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
+	else if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 1>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
+	else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 0>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
 }
 
 template <int VARIANT, int LAG>
@@ -561,7 +617,7 @@ hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const int32_t *
 	const uint32_t max_lpc = P.max_lpc_order >= P.blocksize ? P.blocksize - 1 : P.max_lpc_order;
 	const uint32_t lag = max_lpc + 1;
 	// (lags 10..12 of the lag-12 routine and 14..16 of the lag-16 one would spill: they stay with autoc2_kernel)
-	if(autoc3_wanted(P, nmain, njobs) && (P.autoc_variant == 8 || (P.autoc_variant == 12 && lag <= 9) || (P.autoc_variant == 16 && lag <= 13))) {
+	if(autoc3_wanted(P, chan, nmain, njobs) && (P.autoc_variant == 8 || (P.autoc_variant == 12 && lag <= 9) || (P.autoc_variant == 16 && lag <= 13))) {
 		if(P.autoc_variant == 8) launch_autoc3_t<8, 8>(P, pcm, chan, win, nmain, njobs, nsets, jt, preps, autoc, s);
 		else if(P.autoc_variant == 12) launch_autoc3_t<12, 9>(P, pcm, chan, win, nmain, njobs, nsets, jt, preps, autoc, s);
 		else launch_autoc3_t<16, 13>(P, pcm, chan, win, nmain, njobs, nsets, jt, preps, autoc, s);

@@ -90,6 +90,11 @@ struct JobTable {
 	// the block exactly once (flacgpu_autoc.hip runs the sets of a group of subframes side by side); the first 8 are listed
 	uint32_t nsets;
 	uint16_t set_first[8], set_count[8];
+	// the Rice search of the wavefront-per-channel evaluation kernels (flacgpu_evalg.h: rice_pass): for a node of 2^m lane runs of
+	// S = n / 64 samples, `o` of them warm-up samples, (0x40000 / (ns)) << 13 with ns = (S << m) - o -- the integer reciprocal of
+	// set_partitioned_rice_ (stream_encoder.c:5020), a function of the block size alone: built here, once, instead of 91 integer
+	// divisions per channel in the kernels (round 5)
+	uint32_t eg_div[7][13];
 };
 void build_job_table(const DevParams &P, uint32_t n, JobTable *jt);
 

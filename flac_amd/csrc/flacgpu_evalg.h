@@ -69,7 +69,10 @@ __device__ __forceinline__ void rice_pass(const unsigned char *lds, const EgPass
 	const uint32_t sum2 = *(const uint32_t *)(lds + C.a_end) - *(const uint32_t *)(lds + C.a_start);
 	const uint32_t a2 = (sum2 > 2u ? sum2 : 2u) - 2u;
 	const uint32_t x = __umulhi(a2, dsh);
-	uint32_t kk = (uint32_t)__builtin_amdgcn_frexp_expf((float)x);          // 0 for x == 0
+	// ilog2(x) + 1, 0 for x == 0 (x < 2^20): the leading-zero count of 2 x + 1 is that of x less one, and 31 for x == 0.  (Round 4 took
+	// the exponent of (float)x: the compiler saw a 64-bit product behind x and built the float with its 64-bit sequence, seven
+	// instructions where this is three -- profiles/r05_evalg_isa_histogram.txt)
+	uint32_t kk = 31u - (uint32_t)__builtin_clz((x << 1) | 1u);
 	kk = umin32(kk, rl1);
 	k = kk;
 	bits = __umul24(kk, ns) + (ns9 >> 1) + (sum2 >> kk);
@@ -87,15 +90,16 @@ struct EgSearch {
 };
 // tables and lane constants; level m: nodes of 2^m lanes, partition order frame_max_po - (m - e); searched when e <= m <= e + D
 template <int MAXORD>
-__device__ __forceinline__ void eg_search_setup(EgSearch &R, unsigned char *smem, uint32_t img_bytes, uint32_t S, uint32_t frame_max_po, uint32_t frame_min_po, uint32_t rice_limit, int lane)
+__device__ __forceinline__ void eg_search_setup(EgSearch &R, unsigned char *smem, uint32_t img_bytes, uint32_t S, uint32_t frame_max_po, uint32_t frame_min_po, uint32_t rice_limit, int lane,
+                                                const JobTable *__restrict__ jt)
 {
 	uint32_t *ps = (uint32_t *)(smem + img_bytes);                           // [2][66]
 	uint32_t *dt = ps + 2 * 66;                                              // [7][MAXORD + 1]: (0x40000 / ((S << m) - o)) << 13
 	const uint32_t ps_off = img_bytes, dt_off = img_bytes + 2 * 66 * 4;
 	const uint32_t e = 6 - frame_max_po, D = frame_max_po - frame_min_po;
 	for(uint32_t t = (uint32_t)lane; t < 7 * (MAXORD + 1); t += 64) {
-		const uint32_t m = t / (MAXORD + 1), o = t - m * (MAXORD + 1), full = S << m;
-		dt[t] = full > o ? (0x40000u / (full - o)) << 13 : 0u;
+		const uint32_t m = t / (MAXORD + 1), o = t - m * (MAXORD + 1);
+		dt[t] = jt->eg_div[m][o];                                            // (0x40000 / ((S << m) - o)) << 13, from the host (JobTable)
 	}
 	if(lane < 2) ps[lane * 66] = 0;
 	const uint32_t half = (uint32_t)lane >> 5, j = (uint32_t)lane & 31u;

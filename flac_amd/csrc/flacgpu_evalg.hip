@@ -217,7 +217,7 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 			*(uint32_t *)(d) = v.x; *(uint32_t *)(d + EG_ROW) = v.y; *(uint32_t *)(d + 2 * EG_ROW) = v.z; *(uint32_t *)(d + 3 * EG_ROW) = v.w;
 		}
 	}
-	eg_search_setup<MAXORD>(R, smem, tail_off, S, frame_max_po, frame_min_po, P.rice_limit, lane);
+	eg_search_setup<MAXORD>(R, smem, tail_off, S, frame_max_po, frame_min_po, P.rice_limit, lane, jt);
 	(void)img_bytes;
 	const unsigned char *own = smem + ((uint32_t)lane + 1) * 4;                      // word 0 of this lane's run
 	const unsigned char *hist = smem + (uint32_t)lane * 4 + (rows - 7) * EG_ROW;     // 7 words in front of it: the previous column's last

@@ -237,7 +237,7 @@ __device__ __forceinline__ bool evalw_body(const DevParams &P, const int32_t *__
 			*(uint32_t *)(d) = v.x; *(uint32_t *)(d + EG_ROW) = v.y; *(uint32_t *)(d + 2 * EG_ROW) = v.z; *(uint32_t *)(d + 3 * EG_ROW) = v.w;
 		}
 	}
-	eg_search_setup<MAXORD>(R, smem, tail_off, S, frame_max_po, frame_min_po, P.rice_limit, lane);
+	eg_search_setup<MAXORD>(R, smem, tail_off, S, frame_max_po, frame_min_po, P.rice_limit, lane, jt);
 	const unsigned char *own = smem + ((uint32_t)lane + 1) * 4;                      // sample 0 of this lane's run
 	const unsigned char *hist = smem + (uint32_t)lane * 4 + (rows - 12) * EG_ROW;    // the 12 samples in front of it: the previous column's last
 	const uint32_t npieces = S / 16;

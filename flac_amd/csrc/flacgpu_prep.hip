@@ -92,9 +92,16 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) { const uint32_t c = i / CH, a = (i - c * CH) * TS + c + 1; const int2 lr = p[i]; sl[a] = lr.x; sr[a] = lr.y; }
 			}
 			else {
+				int32_t *s0 = (int32_t *)smem, *s1 = (int32_t *)(smem + cbytes), *s2 = (int32_t *)(smem + 2 * (size_t)cbytes), *s3 = (int32_t *)(smem + 3 * (size_t)cbytes);
+#pragma unroll 4
 				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads) {
 					const uint32_t c = i / CH, a = (i - c * CH) * TS + c + 1;
-					for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * cbytes))[a] = frame_pcm[(size_t)i * C + c0 + r];
+					const int32_t *p = frame_pcm + (size_t)i * C + c0;
+					const int32_t v0 = p[0], v1 = nraw > 1 ? p[1] : 0, v2 = nraw > 2 ? p[2] : 0, v3 = nraw > 3 ? p[3] : 0;
+					s0[a] = v0;
+					if(nraw > 1) s1[a] = v1;
+					if(nraw > 2) s2[a] = v2;
+					if(nraw > 3) s3[a] = v3;
 				}
 			}
 		}
@@ -109,9 +116,20 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads, a += nthreads / 16) { const int2 lr = p[i]; sl[a] = lr.x; sr[a] = lr.y; }
 			}
 			else {
+				// mono, 3..8 channels (up to four raw channels per round): a thread takes sample i of every channel of the round --
+				// neighbouring words of one line --, four samples in flight per thread (round 4: a rolled loop of single loads by one
+				// wavefront per channel: mono's prep took longer than stereo's four channels, profiles/r04_t_chan_rate.txt)
 				uint32_t a = a0;
-				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads, a += nthreads / 16)
-					for(uint32_t r = 0; r < nraw; r++) ((int32_t *)(smem + (size_t)r * cbytes))[a] = frame_pcm[(size_t)i * C + c0 + r];
+				int32_t *s0 = (int32_t *)smem, *s1 = (int32_t *)(smem + cbytes), *s2 = (int32_t *)(smem + 2 * (size_t)cbytes), *s3 = (int32_t *)(smem + 3 * (size_t)cbytes);
+#pragma unroll 4
+				for(uint32_t i = (uint32_t)tid; i < n; i += nthreads, a += nthreads / 16) {
+					const int32_t *p = frame_pcm + (size_t)i * C + c0;
+					const int32_t v0 = p[0], v1 = nraw > 1 ? p[1] : 0, v2 = nraw > 2 ? p[2] : 0, v3 = nraw > 3 ? p[3] : 0;
+					s0[a] = v0;
+					if(nraw > 1) s1[a] = v1;
+					if(nraw > 2) s2[a] = v2;
+					if(nraw > 3) s3[a] = v3;
+				}
 			}
 		}
 		__syncthreads();
@@ -607,7 +625,10 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	}
 	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
-	const uint32_t waves = stereo_ms ? 4u : nraw;
+	// wavefronts that own a channel (one per raw channel of a round; four with mid/side: L, R, M, S); the workgroup always has four, so
+	// that the staging of a frame is the work of 256 threads whatever the channel count (tune().no_fast1: round 4's shape, for A/B runs)
+	const uint32_t active = stereo_ms ? 4u : nraw;
+	const uint32_t waves = tune().no_fast1 ? active : 4u;
 	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize, p2_chunk_len(P.blocksize));
 #define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft)
 	note_launch(K_PREP2);
@@ -615,7 +636,7 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 		note_launch(K_PREP2_DECIDE);
 		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
 		(void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
-		const size_t ldz = prep2_decide_lds(P, nraw, waves);
+		const size_t ldz = prep2_decide_lds(P, nraw, active);
 		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
 		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
 		return hipGetLastError();

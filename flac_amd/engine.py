@@ -10,7 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_HERE, "lib")
-ENGINE_SO = os.path.join(_LIBDIR, "libflacgpu.so")
+# (FLACGPU_ENGINE_SO: another build of the same library, for same-box A/B runs of a kernel change -- scripts/ab_engine.py)
+ENGINE_SO = os.environ.get("FLACGPU_ENGINE_SO") or os.path.join(_LIBDIR, "libflacgpu.so")
 HOST_SO = os.path.join(_LIBDIR, "libFLACgpu.so")
 
 FLACGPU_MAX_APODIZATIONS = 32

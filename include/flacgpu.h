@@ -257,6 +257,11 @@ int flacgpu_debug_log_kat(int device, uint32_t mode, const double *a, const doub
  * rest went through the sequential decoder.  Synchronises the device. */
 int flacgpu_debug_verify_hinted_frames(flacgpu_ctx *ctx, uint32_t *out);
 
+/* Development aid (bench.py: the clock under each workload): one wavefront that, nsamples times, times a sleep of 130 048 shader
+ * cycles against the constant 100 MHz counter.  d_out: device buffer [nsamples][4] uint64 {start, sleep in 100 MHz ticks, sleep in
+ * s_memtime ticks, nominal cycles}.  Asynchronous on `stream`: launch it on a stream of its own beside the work to be observed. */
+int flacgpu_debug_clock_probe(int device, void *stream, uint32_t nsamples, uint64_t *d_out);
+
 const char *flacgpu_strerror(int code);
 int flacgpu_device_count(void);
 

@@ -3,8 +3,10 @@
 VERDICT r04: the bench's -8 step runs autoc3_kernel<16,13,SETS,PLANES> + prep3_kernel + evalg_kernel + pack2_kernel with the fused
 output, but autoc3_kernel is chosen only from 2048 wavefronts up (5462 frames at -8), so the golden digests of the real reference,
 the seeded sweep and the full-size configuration tests all ran autoc2_kernel in the driver's suite.  Here:
-  * every golden case and 50 seeds of the configuration sweep again with FLACGPU_AUTOC3=1 (the switch is read per context since
-    round 5, flacgpu_api.cpp: read_tune -- no fresh interpreter needed), counting the engines that really launched autoc3_kernel;
+  * every golden case and 50 seeds of the configuration sweep again with FLACGPU_AUTOC2=1 FLACGPU_AUTOC3=1 (the switches are read
+    per context since round 5, flacgpu_api.cpp: read_tune -- no fresh interpreter needed), counting the engines that really
+    launched autoc3_kernel (flacgpu_last_batch_kernels).  Round 4's forced test set FLACGPU_AUTOC3=1 alone: at its batch sizes
+    launch_analyze never reached launch_autoc2, and autoc3_kernel never ran in it -- found with the kernel record, fixed there too;
   * one 5504-frame -8 batch of the bench signal under the DEFAULT selection, every byte compared with the oracle (not sampled),
     with the kernels the batch launched asserted (flacgpu_last_batch_kernels)."""
 import hashlib
@@ -26,6 +28,13 @@ with open(os.path.join(os.path.dirname(__file__), "golden", "frames.json")) as f
 SEEN = {"autoc3": 0, "engines": 0}
 
 
+def _force_autoc3(monkeypatch):
+    """the streaming autocorrelation kernels whatever the batch size (FLACGPU_AUTOC2=1: launch_analyze otherwise gives batches of fewer
+    than 640 wavefronts to the wavefront-per-job kernel), and of the two the lane-per-subframe one wherever it applies (FLACGPU_AUTOC3=1)"""
+    monkeypatch.setenv("FLACGPU_AUTOC2", "1")
+    monkeypatch.setenv("FLACGPU_AUTOC3", "1")
+
+
 def _encode(pcm, bps, rate, level, max_batch=2048, **kw):
     import flac_amd
     eng = flac_amd.FrameEngine(flac_amd.make_settings(pcm.shape[1], bps, rate, level, **kw), device=0, max_batch_frames=max_batch)
@@ -38,7 +47,7 @@ def _encode(pcm, bps, rate, level, max_batch=2048, **kw):
 
 @pytest.mark.parametrize("case", golden_cases(), ids=case_key)
 def test_reference_golden_with_the_lane_per_subframe_autocorrelation(case, monkeypatch):
-    monkeypatch.setenv("FLACGPU_AUTOC3", "1")
+    _force_autoc3(monkeypatch)
     want = GOLDEN[case_key(case)]
     data, fb, kernels = _encode(case_pcm(case), case["bps"], case["rate"], case["level"], **case_search(case))
     SEEN["engines"] += 1
@@ -55,7 +64,7 @@ def test_the_forced_kernel_really_ran():
 @pytest.mark.parametrize("seed", range(50))
 def test_random_configurations_with_the_lane_per_subframe_autocorrelation(seed, monkeypatch):
     import test_gpu_parity as tp
-    monkeypatch.setenv("FLACGPU_AUTOC3", "1")
+    _force_autoc3(monkeypatch)
     tp.test_random_configurations(seed, monkeypatch)
 
 
@@ -100,7 +109,7 @@ def test_full_size_level8_batch_under_the_default_selection_equals_the_oracle_en
 
 
 @pytest.mark.parametrize("level,nfr,block,want,never", [
-    (5, 2304, 4096, {"prep3_kernel", "autoc2_kernel", "evalg_kernel", "pack2_kernel", "fused_output"}, {"autoc3_kernel"}),
+    (5, 4608, 4096, {"prep3_kernel", "autoc2_kernel", "evalg_kernel", "pack2_kernel", "fused_output"}, {"autoc3_kernel", "autoc_kernel"}),
     (0, 4608, 1152, {"ff_kernel", "scan_kernel", "compact_kernel"}, {"pack2_kernel", "prep2_kernel"}),
 ])
 def test_other_presets_selection_and_bytes(level, nfr, block, want, never):
