@@ -246,6 +246,49 @@ def verify_ranks(stream, sizes, fbs, nframes, level, block, kind="music", hires=
             "errors": [[v["rank"], v["error"]] for v in per_rank if "error" in v]}
 
 
+def clock_probe(dev_index, run, busy_seconds=0.12):
+    """The engine clock the chip holds while `run(n)` keeps it busy (the VALU yardstick assumed the 2.4 GHz peak): a
+    one-wavefront kernel on a side stream times sleeps of 130 048 shader cycles against the constant 100 MHz counter
+    (flacgpu_debug_clock_probe), ~16 k samples per second, beside steps of the workload; the same once more on the idle chip.
+    Outside every timed region."""
+    import ctypes as C
+    import torch
+    import flac_amd
+    lib = flac_amd.engine.load_engine()
+    lib.flacgpu_debug_clock_probe.restype = C.c_int
+    lib.flacgpu_debug_clock_probe.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+    side = torch.cuda.Stream()
+
+    def one(busy):
+        n = 1500                                    # ~90-100 ms of probing
+        buf = torch.zeros(n * 4, dtype=torch.int64, device="cuda:%d" % dev_index)
+        torch.cuda.synchronize()
+        if lib.flacgpu_debug_clock_probe(dev_index, side.cuda_stream, n, buf.data_ptr()) != 0:
+            return None
+        if busy:
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < busy_seconds:
+                run(4)
+        torch.cuda.synchronize()
+        a = buf.cpu().numpy().reshape(n, 4).astype(np.float64)
+        a = a[a[:, 1] > 0]
+        if not len(a):
+            return None
+        mhz = a[:, 3] / a[:, 1] * 100.0             # nominal cycles of the sleep / its length in 100 MHz ticks
+        memtime_mhz = a[:, 2] / a[:, 1] * 100.0
+        # (the first and last samples may lie outside the busy stretch: the middle 80 %)
+        lo, hi = len(mhz) // 10, len(mhz) - len(mhz) // 10
+        m = mhz[lo:hi] if busy else mhz
+        return {"mhz_mean": round(float(m.mean()), 1), "mhz_min": round(float(m.min()), 1), "mhz_p10": round(float(np.percentile(m, 10)), 1), "mhz_max": round(float(m.max()), 1),
+                "samples": int(len(m)), "s_memtime_mhz_mean": round(float(memtime_mhz[lo:hi].mean()), 1)}
+    busy, idle = one(True), one(False)
+    if busy is None:
+        return None
+    busy["idle_mhz_mean"] = idle["mhz_mean"] if idle else None
+    busy["how"] = "16 x s_sleep 127 = 130048 shader cycles timed against s_memrealtime (100 MHz) by one wavefront on a side stream, beside steps of this workload"
+    return busy
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node.  Not under a launcher and N > 1: bench.py starts its N ranks itself "
@@ -267,6 +310,7 @@ def main():
                     "into rank 0's HBM (the north star's gather); hostshm: every rank copies over its own PCIe link into one shared pinned host buffer; "
                     "none: they stay where they were encoded (encode-only scaling: what the funnel costs is this line against the rccl one)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank pipeline (process group, windowed ordered gather) even with one rank")
+    ap.add_argument("--no-clock", action="store_true", help="skip the engine-clock probe (outside the timed region)")
     ap.add_argument("--no-side-gathers", action="store_true", help="multi-rank rccl line: skip the encode-only (--gather none) and hostshm figures measured beside it in the same run")
     args = ap.parse_args()
     # one call, N workers: `python bench.py --gpus 8` starts its eight ranks itself (and never prints n_gpus: 8 from fewer)
@@ -411,6 +455,11 @@ def main():
                                     "ms_per_batch_lane_per_frame": round(seq_ms, 4),
                                     "decode_Msamples_per_s": round(nframes * block / vms / 1e3, 1),
                                     "encode_plus_verify_Msamples_per_s": round(nframes * block / (vms + elapsed / steps * 1e3) / 1e3, 1)}
+        if rank == 0 and gp is None and not use_dist and not args.no_clock:
+            try:
+                res["clock"] = clock_probe(local_rank, run)
+            except Exception as e:                     # (a development aid must not take the line down)
+                res["clock"] = {"error": str(e)}
         verified = None
         if use_dist and not args.no_verify:
             # the multi-rank check, outside the timed region: EVERY rank's frames of the last step
@@ -499,6 +548,17 @@ def main():
                                         "per_kernel": valu, "wave_insts_per_sample_whole_step": round(tot_i, 3),
                                         "whole_step_frac_of_issue_peak": round(tot_i * samples_per_step / (elapsed / steps) / 1e9 / VALU_ISSUE_PEAK, 4),
                                         "source": "SQ_INSTS_VALU of the committed counter pass (profiles/pmc_traffic.json) x this run's HIP-event kernel times"}
+                ck = res.get("clock") or {}
+                if ck.get("mhz_mean"):
+                    # the same against the clock the chip really held under this workload (clock_probe): the peak above assumes 2.4 GHz
+                    peak_m = SIMDS * ck["mhz_mean"] / 1000.0 / 4
+                    res["roofline_valu"]["at_measured_clock"] = {
+                        "clock_mhz": ck["mhz_mean"], "peak": round(peak_m, 1),
+                        "whole_step_frac_of_issue_peak": round(tot_i * samples_per_step / (elapsed / steps) / 1e9 / peak_m, 4),
+                        "per_kernel_frac": {k: round(v["achieved_Ginst_per_s"] / peak_m, 4) for k, v in valu.items()},
+                        "cycles_per_wave_instruction_whole_step": round(SIMDS * ck["mhz_mean"] * 1e6 * (elapsed / steps) / (tot_i * samples_per_step), 3),
+                        "note": "4 cycles per wave64 instruction is the full-rate figure; per-class rates measured on this chip (scripts/ubench_valu.hip) "
+                                "are 3.0-3.4 for add / shift / xor / mov and 4.2-5.4 for dot2 / sad / perm / fp64 at an ASSUMED 2.4 GHz -- scale those by clock_mhz / 2400"}
             if verified is not None:
                 res["verified"] = verified
             elif not args.no_verify:
@@ -559,7 +619,7 @@ def main():
                                  ("hires", hr, "flac -8 on 96 kHz / 24-bit stereo (BASELINE.json config 4: the wide-sample residual path), 4096-sample blocks")):
                 extras[key] = {"what": what, "value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"],
                                "compressed_bytes_per_sample": round(r["out_bps"], 4), "kernel_ms": {k: round(v, 4) for k, v in r["kernel_ms"].items()},
-                               "roofline": r["roofline"], "roofline_valu": r.get("roofline_valu"), "verified_frames": r.get("verified", {}).get("frames_compared_with_oracle"),
+                               "clock": r.get("clock"), "roofline": r["roofline"], "roofline_valu": r.get("roofline_valu"), "verified_frames": r.get("verified", {}).get("frames_compared_with_oracle"),
                                "verified_ok": r.get("verified", {}).get("ok")}
 
     if rank == 0:
@@ -586,6 +646,7 @@ def main():
                                        "(sizes exchanged once per window of %d steps)" % (world, args.window)) if multi else "one GPU, no process group",
                        "compressed_bytes_per_sample": round(m["out_bps"], 4)},
             "kernel_ms": {k: round(v, 4) for k, v in m["kernel_ms"].items()},
+            "clock": m.get("clock"),
             "roofline": dict(m["roofline"], note="-8 is VALU bound (~1e3 integer+fp64 ops per sample; the dominant kernels issue VALU work ~80% of their cycles, "
                                                  "profiles/*pmc*); the HBM fraction is reported because the north star asks for it; traffic = (2*FETCH_SIZE+WRITE_SIZE) "
                                                  "of the committed PMC pass scaled to this batch; whole_step_frac prices the whole step instead of its dominant kernel"),

@@ -377,18 +377,36 @@ __device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /*
 // per 8 samples and subframe that is noise, and every channel layout gets the lane-per-subframe arithmetic (mono's
 // autocorrelation took 0.59 ms per 16384 frames for ONE channel with autoc2_kernel's general source, stereo's four take 0.70).
 struct A3FetchInd { int32_t v[32]; float wt; };
-// is16: bit q set = row 2 q + half holds 16-bit pairs (this lane's half)
-__device__ __forceinline__ void a3_fetch_ind(const A2Job &J, const int32_t *__restrict__ chan, uint32_t stride_words, uint32_t fc0, uint32_t nfc, uint32_t half, uint32_t is16, int32_t i, A3FetchInd &F)
+// kind (wave-uniform): 1 every row of the group holds 16-bit pairs and the group is whole, 0 the same with 32-bit words, 2 anything
+// else (a mix of the two -- wasted bits bring a 24-bit channel under 16 --, or the batch's last group: rows beyond it repeat the last).
+// The whole-group paths address a row as the group's scalar base + one 32-bit offset that moves by a scalar step per row pair: an add
+// and a load per row (the general path: a clamp, a 64-bit multiply-add, a select and two predicated loads -- as much VALU work again
+// as the arithmetic of the tile); is16: bit q set = row 2 q + half holds 16-bit pairs (this lane's half)
+__device__ __forceinline__ void a3_fetch_ind(const A2Job &J, const int32_t *__restrict__ chan, uint32_t stride_words, uint32_t fc0, uint32_t nfc, uint32_t half, uint32_t is16, uint32_t kind,
+                                             int32_t i, A3FetchInd &F)
 {
 	uint32_t src;
 	a2_index(J, i, src, F.wt);
-	const uint32_t last = nfc - 1u - fc0;                   // (fc0 < nfc)
 	const char *g = (const char *)(chan + (size_t)fc0 * stride_words);
+	const uint32_t step = stride_words * 8u;                // two rows on
+	if(kind == 1u) {
+		uint32_t off = half * stride_words * 4u + 2u * src;
 #pragma unroll
-	for(int q = 0; q < 32; q++) {
-		const uint32_t row = umin32(2u * (uint32_t)q + half, last);
-		const char *p = g + (size_t)row * stride_words * 4u;
-		F.v[q] = (is16 >> q) & 1u ? (int32_t)*(const int16_t *)(p + 2u * src) : *(const int32_t *)(p + 4u * src);
+		for(int q = 0; q < 32; q++) { F.v[q] = (int32_t)*(const int16_t *)(g + off); off += step; }
+	}
+	else if(kind == 0u) {
+		uint32_t off = half * stride_words * 4u + 4u * src;
+#pragma unroll
+		for(int q = 0; q < 32; q++) { F.v[q] = *(const int32_t *)(g + off); off += step; }
+	}
+	else {
+		const uint32_t last = nfc - 1u - fc0;               // (fc0 < nfc)
+#pragma unroll
+		for(int q = 0; q < 32; q++) {
+			const uint32_t row = umin32(2u * (uint32_t)q + half, last);
+			const char *p = g + (size_t)row * stride_words * 4u;
+			F.v[q] = (is16 >> q) & 1u ? (int32_t)*(const int16_t *)(p + 2u * src) : *(const int32_t *)(p + 4u * src);
+		}
 	}
 }
 __device__ __forceinline__ void a3_store_ind(float *tile, uint32_t half, const A3FetchInd &F, uint32_t col)
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 	constexpr int HB = LAG - 1;
 	const uint32_t fc = fc0 + (uint32_t)lane;
 	bool any_wasted;
-	uint32_t is16 = 0;
+	uint32_t is16 = 0, kind = 2;
 	const uint32_t half = (uint32_t)lane >> 5, sl = (uint32_t)lane & 31u;
 	{
 		const ChanPrep pr = preps[fc < nfc ? fc : nfc - 1];
@@ -458,6 +476,8 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 #pragma unroll
 			for(int q = 0; q < 32; q++) { ev |= (uint32_t)((b >> (2 * q)) & 1ull) << q; od |= (uint32_t)((b >> (2 * q + 1)) & 1ull) << q; }
 			is16 = half ? od : ev;
+			// (a row beyond the batch's last subframe reads as a copy of the last: its lane's result is not stored)
+			if(fc0 + A3_ITEMS <= nfc) kind = b == ~0ull ? 1u : b == 0ull ? 0u : 2u;
 		}
 	}
 	const int2 *pcm2 = (const int2 *)pcm;
@@ -478,7 +498,7 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 	double acc[LAG][4];
 #pragma unroll
 	for(int j = 0; j < LAG; j++) { acc[j][0] = 0.0; acc[j][1] = 0.0; acc[j][2] = 0.0; acc[j][3] = 0.0; }
-#define A3_FETCH(idx) do { if constexpr(IND) a3_fetch_ind(J, pcm, P.chan_stride, fc0, nfc, half, is16, (idx), G); else a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (idx), F); } while(0)
+#define A3_FETCH(idx) do { if constexpr(IND) a3_fetch_ind(J, pcm, P.chan_stride, fc0, nfc, half, is16, kind, (idx), G); else a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (idx), F); } while(0)
 #define A3_STORE(col) do { if constexpr(IND) a3_store_ind(tile, half, G, (col)); else a3_store<PLANES>(tile, wasted4, any_wasted, half, F, (col)); } while(0)
 	double w[HB + A3_T];              // w[HB + c] = d[first sample of the tile + c]
 	A3Fetch F;
@@ -498,13 +518,16 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll
 		for(int u = 0; u < HB; u++) w[u] = w[A3_T + u];
-#pragma unroll
-		for(int u = 0; u < A3_T; u++) w[HB + u] = (double)row[u];
+		// (the tile's samples are converted where the chain first wants them, eight -- sixteen -- at a time: converted all at once up
+		//  front, the 32 doubles of the tile were live next to the 104 accumulators through the whole tile: 256 registers and spills
+		//  in the flavours with the wider fetch.  Same values, same operations.)
 		const uint32_t k0 = 4 * t;
 		const uint32_t ksteps = nb - k0 < 4 ? nb - k0 : 4;
 		if(VARIANT == 12) {
 #pragma unroll
 			for(int kk = 0; kk < 4; kk += 2) {
+#pragma unroll
+				for(int u = 0; u < 16; u++) w[HB + 8 * kk + u] = (double)row[8 * kk + u];
 				if((uint32_t)kk + 2 <= ksteps && k0 + (uint32_t)kk + 2 <= 2 * npairs12) { A3_PAIR(8 * kk); }
 				else {
 					if((uint32_t)kk < ksteps) { A3_STEP(8 * kk); }
@@ -514,7 +537,11 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 		}
 		else {
 #pragma unroll
-			for(int kk = 0; kk < 4; kk++) if((uint32_t)kk < ksteps) { A3_STEP(8 * kk); }
+			for(int kk = 0; kk < 4; kk++) {
+#pragma unroll
+				for(int u = 0; u < 8; u++) w[HB + 8 * kk + u] = (double)row[8 * kk + u];
+				if((uint32_t)kk < ksteps) { A3_STEP(8 * kk); }
+			}
 		}
 	}
 	__builtin_amdgcn_wave_barrier();
@@ -557,7 +584,7 @@ static bool autoc3_wanted(const DevParams &P, const int32_t *chan, uint32_t nmai
 	if(mode == 0 || P.blocksize < 64) return false;
 	if(!autoc3_ms(P) && (!chan || tune().no_fast1)) return false;
 	const uint32_t waves = njobs * ((nmain * P.ncand + A3_ITEMS - 1) / A3_ITEMS);
-	return mode == 1 || waves >= (autoc3_ms(P) ? 2048u : 512u);
+	return mode == 1 || waves >= (autoc3_ms(P) ? 2048u : 128u);
 }
 template <int VARIANT, int LAG>
 static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const int32_t *chan, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s)

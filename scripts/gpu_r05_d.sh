@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 5, visit d: prep4_kernel + autoc3_kernel<IND> with uniform fetch paths; the int8 MFMA FIR microbenchmark; A/B of the headline against the tree of visit b
+mkdir -p gpurun_out/r05_d
+export TMPDIR=/tmp
+(time timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -40) > gpurun_out/r05_d/pytest.log 2>&1
+timeout 120 build/ubench_mfma_fir > gpurun_out/r05_d/mfma_fir_ubench.txt 2>&1
+FLACGPU_NO_FAST1=1 timeout 300 python scripts/chan_rate.py 16384 > gpurun_out/r05_d/chan_rate_nofast1.txt 2>&1
+timeout 300 python scripts/chan_rate.py 16384 > gpurun_out/r05_d/chan_rate.txt 2>&1
+timeout 300 python scripts/chan_rate.py 4096 > gpurun_out/r05_d/chan_rate_4096.txt 2>&1
+timeout 600 python scripts/ab_engine.py flac_amd/lib/libflacgpu_prev.so flac_amd/lib/libflacgpu.so 2 > gpurun_out/r05_d/ab_headline.txt 2>&1
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r05_d/bench.json 2> gpurun_out/r05_d/bench.err
+tail -5 gpurun_out/r05_d/pytest.log; cat gpurun_out/r05_d/chan_rate.txt gpurun_out/r05_d/mfma_fir_ubench.txt

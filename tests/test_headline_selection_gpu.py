@@ -120,3 +120,72 @@ def test_other_presets_selection_and_bytes(level, nfr, block, want, never):
     assert want <= kernels and not (never & kernels), sorted(kernels)
     odata, ofb = _oracle_parallel(pcm, level, block)
     assert np.array_equal(fb, ofb) and data == odata
+
+
+LAYOUTS = [
+    ("mono", 1, 16, {}, "music"), ("stereo, independent", 2, 16, dict(mid_side=0), "music"), ("stereo, loose mid/side", 2, 16, dict(mid_side=1, loose_mid_side=1), "music"),
+    ("3 channels", 3, 16, {}, "mixed"), ("5.1", 6, 16, {}, "music"), ("8 channels, 24-bit", 8, 24, {}, "music"), ("mono, 24-bit with wasted bits", 1, 24, {}, "wasted"),
+    ("stereo 20-bit, independent, one channel with wasted bits", 2, 20, dict(mid_side=0), "music"), ("mono, pure tone", 1, 16, {}, "sine"),
+]
+
+
+@pytest.mark.parametrize("name,ch,bps,kw,fam", LAYOUTS, ids=[l[0] for l in LAYOUTS])
+def test_lane_per_subframe_autocorrelation_of_independent_channels(name, ch, bps, kw, fam, monkeypatch):
+    """autoc3_kernel<IND> and prep4_kernel (round 5): every channel layout that is not stereo with a full mid/side search -- 64 independent subframes per
+    wavefront, each read from its own planar copy (16-bit pairs or 32-bit words, per subframe) -- forced at test size, -8 and -5,
+    block sizes whose job lengths leave 1..3 chain steps in the last tile, subframe counts that do not fill the last wavefront; same
+    bytes as the oracle, and the kernel record says it ran"""
+    _force_autoc3(monkeypatch)
+    import flac_amd
+    for level, bs, nfr in ((8, 4096, 21), (5, 4096, 13), (8, 4608, 5), (8, 1152, 30), (5, 576, 11)):
+        pcm = signals.FAMILIES[fam](bs * nfr + 77, ch, bps)
+        if "one channel with wasted bits" in name:
+            pcm[:, 1] = (pcm[:, 1] >> 5) << 5
+        ekw = dict(kw, blocksize=bs)
+        okw = dict(blocksize=bs)
+        if "mid_side" in kw:
+            okw.update(mid_side=kw["mid_side"], loose=kw.get("loose_mid_side", 0))
+        eng = flac_amd.FrameEngine(flac_amd.make_settings(ch, bps, 48000, level, **ekw), device=0, max_batch_frames=64)
+        try:
+            data, fb = eng.encode(pcm)
+            kernels = eng.last_batch_kernels()
+        finally:
+            eng.close()
+        o = po.oracle_encode(pcm, bps, 48000, level, **okw)
+        assert "autoc3_kernel<IND>" in kernels, (name, level, bs, sorted(kernels))
+        if bs == 4096 and "loose" not in name:
+            assert "prep4_kernel" in kernels, (name, level, sorted(kernels))     # (the quarter-per-wavefront prep kernel of independent channels)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (name, level, bs)
+
+
+@pytest.mark.parametrize("ch,bps", [(1, 16), (2, 16), (6, 16), (8, 24), (3, 12), (1, 24)])
+def test_independent_channel_kernels_edge_signals(ch, bps, monkeypatch):
+    """prep4_kernel / autoc3_kernel<IND> on the signals that exercise the prep decisions: constant and silent channels (CONSTANT, the
+    all-equal test across the four quarters of a frame), limit_min_bitrate (the last channel of an all-constant frame must not be
+    CONSTANT), wasted bits per channel, disabled subframe types, a short last block behind the frames of nominal length"""
+    _force_autoc3(monkeypatch)
+    import flac_amd
+    n = 4096 * 9 + 333
+    rng = np.random.default_rng(ch * 100 + bps)
+    base = signals.music(n, ch, bps, seed=ch + bps)
+    variants = []
+    v = base.copy(); v[:, -1] = 77; variants.append(("last channel constant", v, {}))
+    v = np.zeros_like(base); v[:] = -3; variants.append(("every channel constant", v, dict(limit_min_bitrate=1)))
+    v = base.copy(); v[:, 0] = 5; v[4096 * 3 + 1000:, 0] = 6; variants.append(("a step inside a quarter", v, {}))
+    v = base.copy(); v[:, 0] = 5; v[4096 * 2 + 2048:, 0] = 9; variants.append(("a step on a quarter's boundary", v, dict(limit_min_bitrate=1)))
+    v = (base >> 3) << 3; variants.append(("wasted bits everywhere", v, {}))
+    v = base.copy(); v[:, 0] = (v[:, 0] >> 6) << 6; variants.append(("wasted bits in one channel", v, dict(disable=(1, 0, 0))))
+    variants.append(("no fixed subframes", base, dict(disable=(0, 1, 0))))
+    variants.append(("silence", np.zeros_like(base), dict(disable=(0, 0, 1))))
+    from oracle_from_settings import oracle_encode_settings
+    for what, pcm, kw in variants:
+        s = flac_amd.make_settings(ch, bps, 44100, 8, mid_side=0, **kw)
+        eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=16)
+        try:
+            data, fb = eng.encode(pcm)
+            kernels = eng.last_batch_kernels()
+        finally:
+            eng.close()
+        assert "prep4_kernel" in kernels, (what, sorted(kernels))
+        o = oracle_encode_settings(pcm, s)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (what, ch, bps)
