@@ -779,11 +779,12 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 #undef P2ATTR
 		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
 	}
-	if(prep4_applicable(P) && !tune().no_fast1 && !prep2_decides(P)) {
+	if(prep4_applicable(P) && !tune().no_fast1 && !tune().no_prep4 && !prep2_decides(P)) {
 		static bool attr4[64];
 		if(first_on_device(attr4)) {
-			hipError_t e = hipFuncSetAttribute((const void *)prep4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			// (eight channels: 135 KB of tiles; the kernel's static LDS -- the four partial records -- is 1.7 KB, so not the 159 KB the others ask for)
+			hipError_t e = hipFuncSetAttribute((const void *)prep4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
 			if(e != hipSuccess) { attr4[tune().device & 63] = false; return e; }
 		}
 		note_launch(K_PREP1);

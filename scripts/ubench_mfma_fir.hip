@@ -206,6 +206,107 @@ __global__ __launch_bounds__(64, 4) void mfma_kernel(const int16_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// mfma4: the same products with the 16 rows of a tile used as 4 candidates x 4 SAMPLE PHASES.  Column j of B is the window that ends
+// at sample i0 + 4 j + 3 (16 bytes per plane: 13 taps + 3 phases), row 4 c + ph of A holds candidate c's taps moved 3 - ph places
+// down the window, so D[4 c + ph][j] is t of sample i0 + 4 j + ph: a tile covers 64 SAMPLES x 4 candidates, a lane (j, c) ends up with
+// four consecutive samples of ONE candidate in its four result registers (one shift count, one bias per lane), B is loaded once per
+// 64 samples for all candidate sets, and 10 candidates fill 10 of 12 rows-of-four instead of 10 of 16 rows.  64 samples are one
+// leaf partition of the -8 Rice search at 4096-sample blocks: the tile's sum over the 16 lanes of a candidate is a leaf sum.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NSETS>
+__global__ __launch_bounds__(64, 4) void mfma4_kernel(const int16_t *__restrict__ x, const Cands *__restrict__ cands, uint64_t *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	unsigned char *lo = smem, *hi = smem + PLANE;
+	uint32_t *leaf = (uint32_t *)(smem + 2 * PLANE);               // [4 * NSETS candidates][64 leaves]
+	const int lane = (int)threadIdx.x;
+	const uint32_t ch = blockIdx.x;
+	{
+		const uint4 *src = (const uint4 *)(x + (size_t)ch * N);
+		for(uint32_t m = (uint32_t)lane; m < N / 8; m += 64) {
+			const uint4 v = src[m];
+			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+			uint32_t l0 = 0, l1 = 0, h0 = 0, h1 = 0;
+#pragma unroll
+			for(int k = 0; k < 8; k++) {
+				const int32_t s = (int16_t)(w[k >> 1] >> (16 * (k & 1)));
+				const uint32_t xl = ((uint32_t)s & 0xffu) ^ 0x80u, xh = ((uint32_t)(s >> 8)) & 0xffu;
+				if(7 - k < 4) { l0 |= xl << (8 * (7 - k)); h0 |= xh << (8 * (7 - k)); } else { l1 |= xl << (8 * (3 - k)); h1 |= xh << (8 * (3 - k)); }
+			}
+			*(uint2 *)(lo + (N - 8 - 8 * m)) = make_uint2(l0, l1);
+			*(uint2 *)(hi + (N - 8 - 8 * m)) = make_uint2(h0, h1);
+		}
+		if(lane < 16) { *(uint32_t *)(lo + N + 4 * lane) = 0x80808080u; *(uint32_t *)(hi + N + 4 * lane) = 0; }
+	}
+	// A operands: lane (row = lane % 16 = 4 c + ph, kb = lane / 16): window places k'' = 8 (kb & 1) .. + 7; tap index k = k'' - (3 - ph)
+	const uint32_t row = (uint32_t)lane & 15u, kb = (uint32_t)lane >> 4, ac = row >> 2, ph = row & 3u;
+	uint64_t a_mid[NSETS], a_hh[NSETS], a_ll[NSETS];
+	v4i kinit[NSETS];
+	uint32_t sh[NSETS], bias[NSETS];
+#pragma unroll
+	for(int st = 0; st < NSETS; st++) {
+		a_mid[st] = 0; a_hh[st] = 0; a_ll[st] = 0;
+		const uint32_t ci = 4u * (uint32_t)st + ac;
+#pragma unroll
+		for(int kk = 0; kk < 8; kk++) {
+			const int32_t k = (int32_t)(8 * (kb & 1u)) + kk - (3 - (int32_t)ph);
+			const int32_t c = k >= 0 && k < 16 ? (int32_t)cands->c[ci][k] : 0;
+			const int32_t chh = (c + 128) >> 8, cll = c - chh * 256;
+			const uint64_t bh = (uint64_t)((uint32_t)chh & 0xffu) << (8 * kk), bl = (uint64_t)((uint32_t)cll & 0xffu) << (8 * kk);
+			if(kb < 2) { a_mid[st] |= bh; a_ll[st] |= bl; } else { a_mid[st] |= bl; a_hh[st] |= bh; }
+		}
+		// this lane's results: candidate 4 st + kb (D row 4 kb + r = candidate kb of the set, phase r)
+		const uint32_t cr = 4u * (uint32_t)st + kb;
+		sh[st] = cands->shift[cr]; bias[st] = 0x80000000u >> sh[st];
+		int32_t cs = 0;
+#pragma unroll
+		for(int k = 0; k < 16; k++) cs += cands->c[cr][k];
+		const int32_t k0 = (int32_t)(0x80000000u + (uint32_t)(128 * cs));
+		kinit[st] = v4i{k0, k0, k0, k0};
+	}
+	__syncthreads();
+	const v4i zero = {0, 0, 0, 0};
+	const uint32_t j = (uint32_t)lane & 15u;
+	const unsigned char *plane = (kb < 2 ? lo : hi) + 8 * (kb & 1u);
+#pragma unroll 2
+	for(uint32_t i0 = 0; i0 < N; i0 += 64) {
+		const uint32_t pos = (uint32_t)(N - 1) - (i0 + 4u * j + 3u);             // the window of column j ends at sample i0 + 4 j + 3
+		const unsigned char *p = plane + pos;
+		const uint32_t al = (uint32_t)(uintptr_t)p & 3u;
+		const uint32_t *pw = (const uint32_t *)(p - al);
+		const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+		const uint32_t b0 = __builtin_amdgcn_alignbyte(w1, w0, al), b1 = __builtin_amdgcn_alignbyte(w2, w1, al);
+		const long b = (long)(((uint64_t)b1 << 32) | b0);
+#pragma unroll
+		for(int st = 0; st < NSETS; st++) {
+			const v4i hh = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a_hh[st], b, zero, 0, 0, 0);
+			const v4i mid = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a_mid[st], b, zero, 0, 0, 0);
+			const v4i ll = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a_ll[st], b, kinit[st], 0, 0, 0);
+			uint32_t acc = 0;
+#pragma unroll
+			for(int r = 0; r < 4; r++) {
+				const uint32_t t = ((uint32_t)hh[r] << 16) + (((uint32_t)mid[r] << 8) + (uint32_t)ll[r]);
+				const uint32_t pb = t >> sh[st];
+				acc += pb > bias[st] ? pb - bias[st] : bias[st] - pb;
+			}
+			// the leaf's sum of this lane's candidate: over the 16 lanes of its row group
+			acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x111, 0xf, 0xf, false);      // row_shr:1
+			acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x112, 0xf, 0xf, false);      // row_shr:2
+			acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x114, 0xf, 0xf, false);      // row_shr:4
+			acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x118, 0xf, 0xf, false);      // row_shr:8
+			if(j == 15) leaf[(4u * (uint32_t)st + kb) * 64u + (i0 >> 6)] = acc;
+		}
+	}
+	__syncthreads();
+	// (the real kernel hands leaf[c][lane] to the Rice search; here: the block's totals)
+	for(uint32_t c = 0; c < 4u * NSETS; c++) {
+		uint64_t t = leaf[c * 64u + (uint32_t)lane];
+		for(int o = 32; o; o >>= 1) t += __shfl_xor(t, o);
+		if(lane == 0) out[(size_t)ch * MAXC + c] = t;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 int main(int argc, char **argv)
 {
 	const uint32_t nch = argc > 1 ? (uint32_t)atoi(argv[1]) : 65536;          // channels = wavefronts (16384 stereo frames x L, R, M, S)
@@ -275,6 +376,20 @@ int main(int argc, char **argv)
 		const int bad = check("mfma", 16);
 		printf("mfma   16-row tiles : %7.3f ms per launch   %s\n", ms, bad ? "RESULTS DIFFER" : "results = reference");
 		for(uint32_t nc : {10u, 12u, 16u}) printf("mfma   %2u useful rows: %6.3f ns SIMD time per candidate-sample\n", nc, ms * 1e6 * 1024.0 / ((double)nch * N * nc));
+	}
+	for(int nsets : {3, 4}) {
+		CK(hipMemset(dout, 0, (size_t)nch * MAXC * 8));
+		const size_t lds4 = 2 * PLANE + (size_t)4 * nsets * 64 * 4;
+		auto go = [&]() { if(nsets == 3) hipLaunchKernelGGL(mfma4_kernel<3>, dim3(nch), dim3(64), lds4, 0, dx, dc, dout); else hipLaunchKernelGGL(mfma4_kernel<4>, dim3(nch), dim3(64), lds4, 0, dx, dc, dout); };
+		for(int w = 0; w < 2; w++) go();
+		CK(hipEventRecord(e0));
+		const int reps = 5;
+		for(int w = 0; w < reps; w++) go();
+		CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+		float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+		const int bad = check("mfma4", 4u * (uint32_t)nsets);
+		printf("mfma4  %d sets of 4 candidates x 4 sample phases (64-sample tiles): %7.3f ms per launch   %s\n", nsets, ms, bad ? "RESULTS DIFFER" : "results = reference");
+		for(uint32_t nc : {10u, 12u, 16u}) if(nc <= 4u * (uint32_t)nsets && nc > 4u * (uint32_t)(nsets - 1)) printf("mfma4  %2u useful candidates of %d: %6.3f ns SIMD time per candidate-sample\n", nc, 4 * nsets, ms * 1e6 * 1024.0 / ((double)nch * N * nc));
 	}
 	return 0;
 }
