@@ -563,6 +563,13 @@ def main():
                 res["verified"] = verified
             elif not args.no_verify:
                 res["verified"] = verify_step(pcm_h, out_h, fb_h, first_frame, level, block, search=search)
+        if rank == 0:
+            try:
+                # frames that gave up waiting in the fused output (placed from their slots by fo_place_kernel): time, never bytes
+                tot_fb, max_fb = eng.fused_fallbacks()
+                res["fused_output_fallback_frames"] = {"since_the_engine_was_created": tot_fb, "most_in_one_batch": max_fb}
+            except Exception as e:
+                res["fused_output_fallback_frames"] = {"error": str(e)}
         if gp is not None and hasattr(gp, "close"):
             gp.close()
         eng.close()
@@ -647,6 +654,7 @@ def main():
                        "compressed_bytes_per_sample": round(m["out_bps"], 4)},
             "kernel_ms": {k: round(v, 4) for k, v in m["kernel_ms"].items()},
             "clock": m.get("clock"),
+            "fused_output_fallback_frames": m.get("fused_output_fallback_frames"),
             "roofline": dict(m["roofline"], note="-8 is VALU bound (~1e3 integer+fp64 ops per sample; the dominant kernels issue VALU work ~80% of their cycles, "
                                                  "profiles/*pmc*); the HBM fraction is reported because the north star asks for it; traffic = (2*FETCH_SIZE+WRITE_SIZE) "
                                                  "of the committed PMC pass scaled to this batch; whole_step_frac prices the whole step instead of its dominant kernel"),

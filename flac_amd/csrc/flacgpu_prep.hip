@@ -572,7 +572,7 @@ struct Prep4Part { uint32_t orv[FLACGPU_MAX_CHANNELS], diff[FLACGPU_MAX_CHANNELS
 struct Prep4Out { uint32_t wasted[FLACGPU_MAX_CHANNELS], fmt[FLACGPU_MAX_CHANNELS]; };
 
 template <bool WIDE>
-__global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
+__global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint32_t G,
                                                        ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
                                                        int32_t *__restrict__ chan)
 {
@@ -587,137 +587,153 @@ __global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const 
 	const uint32_t q0 = wave * Q;
 	const int32_t *p = pcm + ((size_t)f * N + q0) * C;                      // this quarter: Q * C consecutive words
 	constexpr uint32_t TS = ((Q / CHUNK - 1 + 31) / 32) * 32 + 2, cbytes = CHUNK * TS * 4;     // p2_ts(Q), p2_chan_bytes(Q)
-	unsigned char *tiles = smem + (size_t)wave * C * cbytes;               // [C] tiles of this wavefront
+	unsigned char *tiles = smem + (size_t)wave * G * cbytes;               // [G] tiles of this wavefront
 	const uint32_t cstride = P.ncslots;
-
-	// ---- stage this quarter: word m = sample m / C of channel m % C -> tile[channel] row i % 16, column i / 16 + 1 --------------
-	{
-		const uint32_t nwords = Q * C;
-		const uint32_t cinv = C > 1 ? 0xffffffffu / C + 1u : 0u;                 // ceil(2^32 / C)
-		for(uint32_t m0 = 0; m0 < nwords; m0 += 64 * 16) {
-			int32_t v[16];
-#pragma unroll
-			for(int r = 0; r < 16; r++) v[r] = p[m0 + (uint32_t)lane + 64u * (uint32_t)r];       // (Q * C is a multiple of 1024)
-#pragma unroll
-			for(int r = 0; r < 16; r++) {
-				const uint32_t m = m0 + (uint32_t)lane + 64u * (uint32_t)r;
-				const uint32_t i = C == 1 ? m : __umulhi(m, cinv), c = m - i * C;       // m / C (m < 8192: the reciprocal is exact)
-				((int32_t *)(tiles + (size_t)c * cbytes))[(i & 15u) * TS + (i >> 4) + 1] = v[r];
-			}
-		}
-		// column 0 = the four samples in front of the quarter (rows 12..15), zeros in front of the block
-		for(uint32_t t = (uint32_t)lane; t < CHUNK * C; t += 64) {
-			const uint32_t c = t / CHUNK, r = t - c * CHUNK;
-			int32_t h = 0;
-			if(r >= 12 && wave) h = p[((int32_t)r - 16) * (int32_t)C + (int32_t)c];
-			((int32_t *)(tiles + (size_t)c * cbytes))[r * TS] = h;
-		}
-	}
-	__builtin_amdgcn_wave_barrier();
-
-	// ---- statistics over this quarter, channel by channel: one 16-sample chunk per lane -----------------------------------------
 	const bool first_chunk = wave == 0 && lane == 0;
-#pragma unroll 1
-	for(uint32_t c = 0; c < C; c++) {
-		const int32_t *pa = (const int32_t *)(tiles + (size_t)c * cbytes) + lane;
-		int32_t x[20];
-#pragma unroll
-		for(int k = 0; k < 20; k++) x[k] = k < 4 ? pa[(12 + k) * TS] : pa[(k - 4) * TS + 1];
-		const int32_t first = __builtin_amdgcn_readfirstlane(x[4]);      // this quarter's first sample
-		Prep2Acc A;
-		A.orv = 0; A.diff = 0; A.mag = 0;
-#pragma unroll
-		for(int k = 0; k < 5; k++) A.e[k] = 0;
-		prep2_chunk<false>(x, first_chunk, first, A);                      // (a lane's sixteen differences fit 32 bits at any width served here)
-		A.orv = wave_or_u32(A.orv);
-		A.diff = wave_or_u32(A.diff);
-#pragma unroll
-		for(int k = 0; k < 5; k++) A.e[k] = WIDE ? wave_sum_u50(A.e[k]) : (uint64_t)wave_sum_u32((uint32_t)A.e[k]);
-		if(lane == 0) {
-			Prep4Part &pt = part[wave];
-			pt.orv[c] = A.orv; pt.diff[c] = A.diff; pt.first[c] = first;
-#pragma unroll
-			for(int k = 0; k < 5; k++) pt.e[c][k] = A.e[k];
-		}
-	}
-	__syncthreads();
 
-	// ---- wavefront w decides the channels w, w + 4 (every lane holds the totals) ----------------------------------------------
-	// limit_min_bitrate (stream_encoder.c:3874-3879): the last channel is not CONSTANT when every channel in front of it is
-	bool others_constant = true;
-	for(uint32_t c = 0; c + 1 < C; c++)
-		for(int w = 0; w < TPB / 64; w++) others_constant = others_constant && part[w].diff[c] == 0 && part[w].first[c] == part[0].first[c];
+	// The channels in rounds of G (all of them at once up to four; 5.1 in two rounds of three, 7 and 8 channels in two of four): the
+	// tiles of a round are 17 KB per channel -- six channels at once left ONE workgroup per CU, one wavefront per SIMD, and the kernel
+	// waited for its loads (1.16 ms per 16384 frames of 5.1; profiles/r05_f_chan_rate.txt)
 #pragma unroll 1
-	for(uint32_t c = wave; c < C; c += TPB / 64) {
-		uint32_t orv = 0, diff = 0;
-		uint64_t e[5] = {0, 0, 0, 0, 0};
-		const int32_t f0 = part[0].first[c];
-		for(int w = 0; w < TPB / 64; w++) {
-			orv |= part[w].orv[c];
-			diff |= part[w].diff[c] | (uint32_t)(part[w].first[c] ^ f0);
-			for(int k = 0; k < 5; k++) e[k] += part[w].e[c][k];
-		}
-		uint32_t wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
-		if(wasted > P.bps) wasted = P.bps;
-		const uint32_t sbps = P.bps - wasted;
-		const uint32_t fmt = sbps <= 16 ? 1u : 0u;
-		if(lane == 0) { outp.wasted[c] = wasted; outp.fmt[c] = fmt; }
-		bool disable_constant = P.disable_constant != 0;
-		if(P.limit_min_bitrate && !disable_constant && c + 1 == C && others_constant) disable_constant = true;
-		uint32_t flags = 0, fixed_order = 0;
-		int32_t constant = 0;
-		const uint32_t verbatim_bits = P.disable_verbatim ? 0xffffffffu : 8 + wasted + N * sbps;
-		const uint32_t n4 = N - 4;
-		const uint64_t es[5] = {e[0] >> wasted, e[1] >> wasted, e[2] >> wasted, e[3] >> wasted, e[4] >> wasted};
-		uint32_t guess_fixed;
+	for(uint32_t cg = 0; cg < C; cg += G) {
+		const uint32_t ng = C - cg < G ? C - cg : G;
+		if(cg) __syncthreads();                                             // (the planes of the round before have been written from the tiles)
+		// ---- stage this quarter's words of the round's channels: sample i -> tile[channel - cg] row i % 16, column i / 16 + 1 --------
 		{
-			const uint64_t m34 = es[3] < es[4] ? es[3] : es[4], m234 = es[2] < m34 ? es[2] : m34, m1234 = es[1] < m234 ? es[1] : m234;
-			if(es[0] <= m1234) guess_fixed = 0;
-			else if(es[1] <= m234) guess_fixed = 1;
-			else if(es[2] <= m34) guess_fixed = 2;
-			else if(es[3] <= es[4]) guess_fixed = 3;
-			else guess_fixed = 4;
-		}
-		const bool is_constant = !disable_constant && diff == 0;
-		const size_t fc = (size_t)f * P.ncand + c;
-		if(is_constant) { flags |= PREP_CONSTANT; constant = f0 >> wasted; }
-		else if(P.max_lpc_order > 0) flags |= PREP_LPC;
-		const bool fixed_allowed = !is_constant && (!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu));
-		fixed_order = fixed_allowed ? guess_fixed : 0;
-		if(emit_fixed_candidates(P, &cands[fc * cstride], &valid[fc * cstride], es, n4, guess_fixed, fixed_allowed, sbps, lane)) flags |= PREP_FIXED_VALID;
-		if(lane == 0) {
-			ChanPrep pr;
-			pr.which = c; pr.wasted = wasted; pr.sbps = sbps; pr.n = N; pr.flags = flags; pr.fixed_order = fixed_order;
-			pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.handled = 0; pr.pad = 0;
-			preps[fc] = pr;
-		}
-	}
-	__syncthreads();
-
-	// ---- planar channels of this quarter, shifted: the tiles are read again (conflict-free, behind the barrier) -------------------
-	{
-		const uint32_t base = q0 + (uint32_t)lane * CHUNK;
-#pragma unroll 1
-		for(uint32_t c = 0; c < C; c++) {
-			const int32_t *pa = (const int32_t *)(tiles + (size_t)c * cbytes) + lane;
-			const uint32_t wasted = outp.wasted[c];
-			int32_t x[CHUNK];
+			const uint32_t nwords = Q * ng;
+			const uint32_t ginv = ng > 1 ? 0xffffffffu / ng + 1u : 0u;           // ceil(2^32 / ng)
+			for(uint32_t m0 = 0; m0 < nwords; m0 += 64 * 16) {
+				int32_t v[16];
 #pragma unroll
-			for(int k = 0; k < CHUNK; k++) x[k] = pa[k * TS + 1] >> wasted;
-			uint32_t *dst = (uint32_t *)(chan + ((size_t)f * P.ncand + c) * (size_t)N);
-			if(outp.fmt[c]) {
-				uint4 w0, w1;
-				w0.x = ((uint32_t)x[0] & 0xffffu) | ((uint32_t)x[1] << 16); w0.y = ((uint32_t)x[2] & 0xffffu) | ((uint32_t)x[3] << 16);
-				w0.z = ((uint32_t)x[4] & 0xffffu) | ((uint32_t)x[5] << 16); w0.w = ((uint32_t)x[6] & 0xffffu) | ((uint32_t)x[7] << 16);
-				w1.x = ((uint32_t)x[8] & 0xffffu) | ((uint32_t)x[9] << 16); w1.y = ((uint32_t)x[10] & 0xffffu) | ((uint32_t)x[11] << 16);
-				w1.z = ((uint32_t)x[12] & 0xffffu) | ((uint32_t)x[13] << 16); w1.w = ((uint32_t)x[14] & 0xffffu) | ((uint32_t)x[15] << 16);
-				uint4 *d4 = (uint4 *)(dst + base / 2);
-				d4[0] = w0; d4[1] = w1;
+				for(int r = 0; r < 16; r++) {
+					const uint32_t m = m0 + (uint32_t)lane + 64u * (uint32_t)r;   // (Q * ng is a multiple of 1024)
+					const uint32_t i = ng == 1 ? m : __umulhi(m, ginv), c = m - i * ng;      // m / ng (m < 4096: the reciprocal is exact)
+					v[r] = p[i * C + cg + c];
+				}
+#pragma unroll
+				for(int r = 0; r < 16; r++) {
+					const uint32_t m = m0 + (uint32_t)lane + 64u * (uint32_t)r;
+					const uint32_t i = ng == 1 ? m : __umulhi(m, ginv), c = m - i * ng;
+					((int32_t *)(tiles + (size_t)c * cbytes))[(i & 15u) * TS + (i >> 4) + 1] = v[r];
+				}
 			}
-			else {
-				uint4 *d4 = (uint4 *)(dst + base);
+			// column 0 = the four samples in front of the quarter (rows 12..15), zeros in front of the block
+			for(uint32_t t = (uint32_t)lane; t < CHUNK * ng; t += 64) {
+				const uint32_t c = t / CHUNK, r = t - c * CHUNK;
+				int32_t h = 0;
+				if(r >= 12 && wave) h = p[((int32_t)r - 16) * (int32_t)C + (int32_t)(cg + c)];
+				((int32_t *)(tiles + (size_t)c * cbytes))[r * TS] = h;
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+
+		// ---- statistics over this quarter, channel by channel: one 16-sample chunk per lane ---------------------------------------
+#pragma unroll 1
+		for(uint32_t cl = 0; cl < ng; cl++) {
+			const uint32_t c = cg + cl;
+			const int32_t *pa = (const int32_t *)(tiles + (size_t)cl * cbytes) + lane;
+			int32_t x[20];
 #pragma unroll
-				for(int k = 0; k < 4; k++) { uint4 w; w.x = (uint32_t)x[4 * k]; w.y = (uint32_t)x[4 * k + 1]; w.z = (uint32_t)x[4 * k + 2]; w.w = (uint32_t)x[4 * k + 3]; d4[k] = w; }
+			for(int k = 0; k < 20; k++) x[k] = k < 4 ? pa[(12 + k) * TS] : pa[(k - 4) * TS + 1];
+			const int32_t first = __builtin_amdgcn_readfirstlane(x[4]);      // this quarter's first sample
+			Prep2Acc A;
+			A.orv = 0; A.diff = 0; A.mag = 0;
+#pragma unroll
+			for(int k = 0; k < 5; k++) A.e[k] = 0;
+			prep2_chunk<false>(x, first_chunk, first, A);                      // (a lane's sixteen differences fit 32 bits at any width served here)
+			A.orv = wave_or_u32(A.orv);
+			A.diff = wave_or_u32(A.diff);
+#pragma unroll
+			for(int k = 0; k < 5; k++) A.e[k] = WIDE ? wave_sum_u50(A.e[k]) : (uint64_t)wave_sum_u32((uint32_t)A.e[k]);
+			if(lane == 0) {
+				Prep4Part &pt = part[wave];
+				pt.orv[c] = A.orv; pt.diff[c] = A.diff; pt.first[c] = first;
+#pragma unroll
+				for(int k = 0; k < 5; k++) pt.e[c][k] = A.e[k];
+			}
+		}
+		__syncthreads();
+
+		// ---- wavefront w decides the round's channels cg + w (every lane holds the totals) -------------------------------------------
+		for(uint32_t c = cg + wave; c < cg + ng; c += TPB / 64) {
+			uint32_t orv = 0, diff = 0;
+			uint64_t e[5] = {0, 0, 0, 0, 0};
+			const int32_t f0 = part[0].first[c];
+			for(int w = 0; w < TPB / 64; w++) {
+				orv |= part[w].orv[c];
+				diff |= part[w].diff[c] | (uint32_t)(part[w].first[c] ^ f0);
+				for(int k = 0; k < 5; k++) e[k] += part[w].e[c][k];
+			}
+			uint32_t wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
+			if(wasted > P.bps) wasted = P.bps;
+			const uint32_t sbps = P.bps - wasted;
+			const uint32_t fmt = sbps <= 16 ? 1u : 0u;
+			if(lane == 0) { outp.wasted[c] = wasted; outp.fmt[c] = fmt; }
+			bool disable_constant = P.disable_constant != 0;
+			if(P.limit_min_bitrate && !disable_constant && c + 1 == C) {
+				// limit_min_bitrate (stream_encoder.c:3874-3879): the last channel is not CONSTANT when every channel in front of it is
+				// (the last channel is in the last round: the records of all the others are there)
+				bool others_constant = true;
+				for(uint32_t o = 0; o + 1 < C; o++)
+					for(int w = 0; w < TPB / 64; w++) others_constant = others_constant && part[w].diff[o] == 0 && part[w].first[o] == part[0].first[o];
+				if(others_constant) disable_constant = true;
+			}
+			uint32_t flags = 0, fixed_order = 0;
+			int32_t constant = 0;
+			const uint32_t verbatim_bits = P.disable_verbatim ? 0xffffffffu : 8 + wasted + N * sbps;
+			const uint32_t n4 = N - 4;
+			const uint64_t es[5] = {e[0] >> wasted, e[1] >> wasted, e[2] >> wasted, e[3] >> wasted, e[4] >> wasted};
+			uint32_t guess_fixed;
+			{
+				const uint64_t m34 = es[3] < es[4] ? es[3] : es[4], m234 = es[2] < m34 ? es[2] : m34, m1234 = es[1] < m234 ? es[1] : m234;
+				if(es[0] <= m1234) guess_fixed = 0;
+				else if(es[1] <= m234) guess_fixed = 1;
+				else if(es[2] <= m34) guess_fixed = 2;
+				else if(es[3] <= es[4]) guess_fixed = 3;
+				else guess_fixed = 4;
+			}
+			const bool is_constant = !disable_constant && diff == 0;
+			const size_t fc = (size_t)f * P.ncand + c;
+			if(is_constant) { flags |= PREP_CONSTANT; constant = f0 >> wasted; }
+			else if(P.max_lpc_order > 0) flags |= PREP_LPC;
+			const bool fixed_allowed = !is_constant && (!P.disable_fixed || (P.max_lpc_order == 0 && verbatim_bits == 0xffffffffu));
+			fixed_order = fixed_allowed ? guess_fixed : 0;
+			if(emit_fixed_candidates(P, &cands[fc * cstride], &valid[fc * cstride], es, n4, guess_fixed, fixed_allowed, sbps, lane)) flags |= PREP_FIXED_VALID;
+			if(lane == 0) {
+				ChanPrep pr;
+				pr.which = c; pr.wasted = wasted; pr.sbps = sbps; pr.n = N; pr.flags = flags; pr.fixed_order = fixed_order;
+				pr.constant = constant; pr.verbatim_bits = verbatim_bits; pr.fmt = fmt; pr.constant_hi = constant >> 31; pr.handled = 0; pr.pad = 0;
+				preps[fc] = pr;
+			}
+		}
+		__syncthreads();
+
+		// ---- planar channels of this quarter, shifted: the tiles are read again (conflict-free, behind the barrier) -----------------
+		{
+			const uint32_t base = q0 + (uint32_t)lane * CHUNK;
+#pragma unroll 1
+			for(uint32_t cl = 0; cl < ng; cl++) {
+				const uint32_t c = cg + cl;
+				const int32_t *pa = (const int32_t *)(tiles + (size_t)cl * cbytes) + lane;
+				const uint32_t wasted = outp.wasted[c];
+				int32_t x[CHUNK];
+#pragma unroll
+				for(int k = 0; k < CHUNK; k++) x[k] = pa[k * TS + 1] >> wasted;
+				uint32_t *dst = (uint32_t *)(chan + ((size_t)f * P.ncand + c) * (size_t)N);
+				if(outp.fmt[c]) {
+					uint4 w0, w1;
+					w0.x = ((uint32_t)x[0] & 0xffffu) | ((uint32_t)x[1] << 16); w0.y = ((uint32_t)x[2] & 0xffffu) | ((uint32_t)x[3] << 16);
+					w0.z = ((uint32_t)x[4] & 0xffffu) | ((uint32_t)x[5] << 16); w0.w = ((uint32_t)x[6] & 0xffffu) | ((uint32_t)x[7] << 16);
+					w1.x = ((uint32_t)x[8] & 0xffffu) | ((uint32_t)x[9] << 16); w1.y = ((uint32_t)x[10] & 0xffffu) | ((uint32_t)x[11] << 16);
+					w1.z = ((uint32_t)x[12] & 0xffffu) | ((uint32_t)x[13] << 16); w1.w = ((uint32_t)x[14] & 0xffffu) | ((uint32_t)x[15] << 16);
+					uint4 *d4 = (uint4 *)(dst + base / 2);
+					d4[0] = w0; d4[1] = w1;
+				}
+				else {
+					uint4 *d4 = (uint4 *)(dst + base);
+#pragma unroll
+					for(int k = 0; k < 4; k++) { uint4 w; w.x = (uint32_t)x[4 * k]; w.y = (uint32_t)x[4 * k + 1]; w.z = (uint32_t)x[4 * k + 2]; w.w = (uint32_t)x[4 * k + 3]; d4[k] = w; }
+				}
 			}
 		}
 	}
@@ -782,15 +798,17 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	if(prep4_applicable(P) && !tune().no_fast1 && !tune().no_prep4 && !prep2_decides(P)) {
 		static bool attr4[64];
 		if(first_on_device(attr4)) {
-			// (eight channels: 135 KB of tiles; the kernel's static LDS -- the four partial records -- is 1.7 KB, so not the 159 KB the others ask for)
-			hipError_t e = hipFuncSetAttribute((const void *)prep4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+			// (at most four channels' tiles at a time: 68 KB; the kernel's static LDS -- the four partial records -- is 1.7 KB)
+			hipError_t e = hipFuncSetAttribute((const void *)prep4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
 			if(e != hipSuccess) { attr4[tune().device & 63] = false; return e; }
 		}
 		note_launch(K_PREP1);
-		const size_t lds4 = 4 * (size_t)P.channels * p2_chan_bytes(P.blocksize / 4);
-		if(P.bps > 20) hipLaunchKernelGGL(prep4_kernel<true>, dim3(nmain), dim3(TPB), lds4, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
-		else hipLaunchKernelGGL(prep4_kernel<false>, dim3(nmain), dim3(TPB), lds4, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
+		// channels per round: all of them up to four, else the rounds as even as they come (5, 6 -> 3; 7, 8 -> 4)
+		const uint32_t C = P.channels, G = C <= 4 ? C : (C + 1) / 2;
+		const size_t lds4 = 4 * (size_t)G * p2_chan_bytes(P.blocksize / 4);
+		if(P.bps > 20) hipLaunchKernelGGL(prep4_kernel<true>, dim3(nmain), dim3(TPB), lds4, s, P, pcm, nmain, G, B.prep, B.cands, B.valid, B.chan);
+		else hipLaunchKernelGGL(prep4_kernel<false>, dim3(nmain), dim3(TPB), lds4, s, P, pcm, nmain, G, B.prep, B.cands, B.valid, B.chan);
 		return hipGetLastError();
 	}
 	if(prep3_applicable(P) && !tune().no_prep3) {
