@@ -425,6 +425,12 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         res = {"elapsed": elapsed, "steps": steps, "block": block, "level": level, "kind": kind}
+        if rank == 0 and gp is None and not use_dist and not args.no_clock:
+            try:
+                res["clock"] = clock_probe(local_rank, run)
+            except Exception as e:                     # (a development aid must not take the line down; before the verify side measurement,
+                                                       #  behind which the pack kernel also writes the verify pass's hints)
+                res["clock"] = {"error": str(e)}
         if rank == 0 and gp is None and not use_dist and not args.no_verify:
             # side measurement, outside the timed region: the whole batch decoded again on the device and compared with its input
             # (flacgpu_verify_batch_device: what set_verify(true) costs per batch)
@@ -455,11 +461,6 @@ def main():
                                     "ms_per_batch_lane_per_frame": round(seq_ms, 4),
                                     "decode_Msamples_per_s": round(nframes * block / vms / 1e3, 1),
                                     "encode_plus_verify_Msamples_per_s": round(nframes * block / (vms + elapsed / steps * 1e3) / 1e3, 1)}
-        if rank == 0 and gp is None and not use_dist and not args.no_clock:
-            try:
-                res["clock"] = clock_probe(local_rank, run)
-            except Exception as e:                     # (a development aid must not take the line down)
-                res["clock"] = {"error": str(e)}
         verified = None
         if use_dist and not args.no_verify:
             # the multi-rank check, outside the timed region: EVERY rank's frames of the last step

@@ -43,7 +43,7 @@ for step in "$@"; do
                  "SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE GRBM_COUNT" \
                  "FETCH_SIZE" "WRITE_SIZE"; do
         j=$((j+1))
-        timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$j -o p$j -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-verify $arg > $OUT/pmc$j.json 2> $OUT/pmc$j.err
+        timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$j -o p$j -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-verify --no-clock $arg > $OUT/pmc$j.json 2> $OUT/pmc$j.err
         echo "[$i] pmc pass $j rc=$? : $SET"
         DB=$(ls $OUT/pmc$j/*.db 2>/dev/null | head -1)
         [ -n "$DB" ] && python scripts/rocpd_pmc.py $DB >> $OUT/pmc_counters_$i.txt
