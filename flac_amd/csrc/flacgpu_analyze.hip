@@ -1467,6 +1467,12 @@ hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *w
 			const hipError_t e = launch_autoc2(P, pcm, B.chan, win, f_lo, P.max_jobs, nsets_main, jtm, B.prep, B.autoc, s);
 			if(e != hipSuccess) return e;
 		}
+		else if(autoc4_applicable(P) && (force == 2 || (force == 0 && P.max_jobs * ((nmain2 * P.ncand + 63) / 64) >= 128u))) {
+			// -l 16 and up: the reference's plain loop, a lane per subframe (from 128 wavefronts up; the wavefront-per-job kernel below)
+			f_lo = tail_n ? nframes - 1 : nframes;
+			const hipError_t e = launch_autoc4(P, B.chan, win, f_lo, P.max_jobs, jtm, B.prep, B.autoc, s);
+			if(e != hipSuccess) return e;
+		}
 		if(f_lo < nframes) {
 			const uint32_t items = (nframes - f_lo) * P.ncand * P.max_jobs;
 			note_launch(K_AUTOC);

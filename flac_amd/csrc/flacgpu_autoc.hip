@@ -574,6 +574,97 @@ __global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const 
 #undef A3_STEP
 #undef A3_PAIR
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// autoc4_kernel (round 5): the PLAIN loop of lpc.c:133-157 with a lane per subframe -- what the reference runs when lag > 16, i.e.
+// from -l 16 up (stream_encoder.c:1058-1066 picks an FMA routine only below):
+//     for sample: d = data[sample]; for coeff < lag: autoc[coeff] += d * data[sample + coeff]
+// per lag a plain sequence of additions in increasing sample order (every product of two floats is exact in a double, so one
+// v_fma_f64 is the reference's multiply and add).  Written backwards, autoc[c] += data[i - c] * data[i] for i = 0 .. n - 1 with
+// zeros in front of the block, it is the same terms in the same order per lag, and the shape of autoc3_kernel: lane = subframe, LAG
+// accumulators per lane, a sliding window of LAG - 1 earlier samples in registers, the samples streaming through the same 32-sample
+// tile filled from the candidate channels' planes (IND source: every layout, stereo with mid/side included -- its four planes are
+// there).  Samples past the job's end arrive as +0 (weight 0) and add nothing: no head, no tail, no finish.  LAG FMAs per sample
+// and subframe: 17 at -l 16 (the -8 routines: 19.5 operations), 33 at -l 32.  The wavefront-per-job kernel this replaces ran one
+// LANE per lag, 4096 dependent FMAs deep: 2.24 ms per 4096 frames at -8 -l 16 against 0.24 for -8 (profiles/r05_i_order_rate.txt).
+template <int LAG>
+__global__ __launch_bounds__(64, 2) void autoc4_kernel(const DevParams P, const int32_t *__restrict__ chan, const float *__restrict__ windows,
+                                                       uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
+                                                       double *__restrict__ autoc_out)
+{
+	__shared__ float tile[A3_ITEMS * A3_ST];
+	const int lane = (int)threadIdx.x;
+	const uint32_t nfc = nmain * P.ncand, ngroups = (nfc + A3_ITEMS - 1) / A3_ITEMS;
+	const uint32_t jb = blockIdx.x / ngroups;                             // jobs longest first: the long wavefronts start first
+	const uint32_t fc0 = (blockIdx.x - jb * ngroups) * A3_ITEMS;
+	const uint32_t N = P.blocksize;
+	constexpr int HB = LAG - 1;
+	const uint32_t fc = fc0 + (uint32_t)lane;
+	const uint32_t half = (uint32_t)lane >> 5, sl = (uint32_t)lane & 31u;
+	uint32_t is16 = 0, kind = 2;
+	{
+		const ChanPrep pr = preps[fc < nfc ? fc : nfc - 1];
+		if(!__any((int)(pr.flags & PREP_LPC))) return;
+		const uint64_t b = __ballot((int)(pr.fmt == 1u));
+		uint32_t ev = 0, od = 0;
+#pragma unroll
+		for(int q = 0; q < 32; q++) { ev |= (uint32_t)((b >> (2 * q)) & 1ull) << q; od |= (uint32_t)((b >> (2 * q + 1)) & 1ull) << q; }
+		is16 = half ? od : ev;
+		if(fc0 + A3_ITEMS <= nfc) kind = b == ~0ull ? 1u : b == 0ull ? 0u : 2u;
+	}
+	const float *row = tile + lane * A3_ST;
+	const WindowJob jv = jt->jobs[jb];
+	A2Job J;
+	J.w = windows + (size_t)jv.apod * N;
+	J.n = N; J.nd = jv.nd; J.full = jv.full; J.part = jv.part; J.dshift = jv.dshift; J.i0 = jv.i0;
+	const uint32_t nd = jv.nd, ntiles = (nd + A3_T - 1) / A3_T;
+	double acc[LAG];
+#pragma unroll
+	for(int j = 0; j < LAG; j++) acc[j] = 0.0;
+	double w[HB + A3_T];                  // w[HB + c] = d[first sample of the tile + c]; w[0 .. HB) the samples in front of it
+#pragma unroll
+	for(int u = 0; u < HB; u++) w[A3_T + u] = 0.0;
+	A3FetchInd G;
+	a3_fetch_ind(J, chan, P.chan_stride, fc0, nfc, half, is16, kind, (int32_t)sl, G);
+	for(uint32_t t = 0; t < ntiles; t++) {
+		__builtin_amdgcn_wave_barrier();
+		a3_store_ind(tile, half, G, sl);
+		if(t + 1 < ntiles) a3_fetch_ind(J, chan, P.chan_stride, fc0, nfc, half, is16, kind, (int32_t)(A3_T * (t + 1) + sl), G);
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for(int u = 0; u < HB; u++) w[u] = w[A3_T + u];
+#pragma unroll
+		for(int k8 = 0; k8 < A3_T; k8 += 8) {
+#pragma unroll
+			for(int u = 0; u < 8; u++) w[HB + k8 + u] = (double)row[k8 + u];
+#pragma unroll
+			for(int u = 0; u < 8; u++) {
+#pragma unroll
+				for(int c = 0; c < LAG; c++) acc[c] = fma(w[HB + k8 + u - c], w[HB + k8 + u], acc[c]);
+			}
+		}
+	}
+	const uint32_t max_lpc = P.max_lpc_order >= N ? N - 1 : P.max_lpc_order;
+	const uint32_t lag = max_lpc + 1;
+	double *out = autoc_out + ((size_t)(fc < nfc ? fc : nfc - 1) * P.max_jobs + jb) * AUTOC_STRIDE;
+	if(fc < nfc) {
+#pragma unroll
+		for(int j = 0; j < LAG; j++) if((uint32_t)j < lag) out[j] = acc[j];
+	}
+}
+// from -l 16 up, blocks longer than 32 samples, every candidate channel's plane there
+bool autoc4_applicable(const DevParams &P) { return P.blocksize >= 64 && P.max_lpc_order >= 16 && P.autoc_variant == 0 && !P.wide_samples && !tune().no_fast1; }
+hipError_t launch_autoc4(const DevParams &P, const int32_t *chan, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s)
+{
+	if(nmain == 0 || njobs == 0) return hipSuccess;
+	const uint32_t max_lpc = P.max_lpc_order >= P.blocksize ? P.blocksize - 1 : P.max_lpc_order;
+	const uint32_t lag = max_lpc + 1, ngroups = (nmain * P.ncand + A3_ITEMS - 1) / A3_ITEMS;
+	note_launch(K_AUTOC1);
+	if(lag <= 17) hipLaunchKernelGGL(autoc4_kernel<17>, dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
+	else if(lag <= 25) hipLaunchKernelGGL(autoc4_kernel<25>, dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
+	else hipLaunchKernelGGL(autoc4_kernel<33>, dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
+	return hipGetLastError();
+}
+
 // the lane-per-subframe kernel: stereo with a full mid/side search and enough subframes for two wavefronts per SIMD (below that
 // autoc2_kernel's mid/side flavour, four times as fine-grained, is the faster one); every other channel layout from the planes
 // (IND) as soon as half the SIMDs get a wavefront -- autoc2_kernel's general source is three times slower per channel

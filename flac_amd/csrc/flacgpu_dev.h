@@ -169,6 +169,9 @@ bool autoc2_applicable(const DevParams &P);
 // chan: the planar channels of the prep kernel (AnalyzeBuffers::chan), or null: autoc3_kernel reads left / right from them when they are 16-bit pairs
 hipError_t launch_autoc2(const DevParams &P, const int32_t *pcm, const int32_t *chan, const float *win, uint32_t nmain, uint32_t njobs, uint32_t nsets, const JobTable *jt,
                          const ChanPrep *preps, double *autoc, hipStream_t s);
+// the plain autocorrelation loop of -l 16 and up with a lane per subframe (flacgpu_autoc.hip: autoc4_kernel); chan: AnalyzeBuffers::chan
+bool autoc4_applicable(const DevParams &P);
+hipError_t launch_autoc4(const DevParams &P, const int32_t *chan, const float *win, uint32_t nmain, uint32_t njobs, const JobTable *jt, const ChanPrep *preps, double *autoc, hipStream_t s);
 bool evalg_applicable(const DevParams &P);
 hipError_t launch_evalg(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s);
 // 32-bit planar channels (flacgpu_evalw.hip): every channel of the batch (in_list == null), or the channels of a list

@@ -189,3 +189,30 @@ def test_independent_channel_kernels_edge_signals(ch, bps, monkeypatch):
         assert "prep4_kernel" in kernels, (what, sorted(kernels))
         o = oracle_encode_settings(pcm, s)
         assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (what, ch, bps)
+
+
+@pytest.mark.parametrize("order", [16, 17, 20, 24, 25, 31, 32])
+def test_plain_autocorrelation_loop_with_a_lane_per_subframe(order, monkeypatch):
+    """autoc4_kernel (round 5): from -l 16 up the reference runs the plain loop of lpc.c:133-157 (lag > 16), per lag a sequence of
+    additions in increasing sample order -- here with a lane per subframe, every layout from the candidate channels' planes; forced at
+    test size (FLACGPU_AUTOC2=1), stereo with mid/side / mono / 5.1 / 24-bit / loose and no mid/side / other block sizes / a pure
+    tone / wasted bits; same bytes as the oracle"""
+    monkeypatch.setenv("FLACGPU_AUTOC2", "1")
+    import flac_amd
+    cases = [(2, 40, 16, 4096, "music", {}), (1, 70, 16, 4096, "music", {}), (6, 12, 16, 4096, "music", {}), (2, 21, 24, 4096, "music", {}), (2, 20, 16, 4608, "music", {}),
+             (2, 25, 16, 1152, "music", {}), (2, 20, 16, 4096, "sine", {}), (2, 20, 16, 4096, "wasted", {}), (2, 30, 16, 4096, "mixed", dict(mid_side=0)),
+             (2, 30, 16, 4096, "music", dict(mid_side=1, loose_mid_side=1)), (2, 33, 16, 576, "music", {})]
+    for ch, nfr, bps, bs, fam, kw in cases[order % 3::3] + cases[:1]:
+        pcm = signals.FAMILIES[fam](bs * nfr + 55, ch, bps)
+        eng = flac_amd.FrameEngine(flac_amd.make_settings(ch, bps, 48000, 8, max_lpc_order=order, streamable_subset=0, blocksize=bs, **kw), device=0, max_batch_frames=nfr + 1)
+        try:
+            data, fb = eng.encode(pcm)
+            kernels = eng.last_batch_kernels()
+        finally:
+            eng.close()
+        okw = dict(max_lpc_order=order, blocksize=bs)
+        if "mid_side" in kw:
+            okw.update(mid_side=kw["mid_side"], loose=kw.get("loose_mid_side", 0))
+        o = po.oracle_encode(pcm, bps, 48000, 8, **okw)
+        assert "autoc3_kernel<IND>|autoc4_kernel" in kernels and "autoc2_kernel" not in kernels and "autoc3_kernel" not in kernels, sorted(kernels)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (order, ch, bps, bs, fam, kw)
