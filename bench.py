@@ -316,7 +316,7 @@ def main():
     # one call, N workers: `python bench.py --gpus 8` starts its eight ranks itself (and never prints n_gpus: 8 from fewer)
     from flac_amd.dist import ensure_ranks, check_world
     launched_by = "a launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "bench.py itself"
-    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+    if "WORLD_SIZE" not in os.environ and ((args.gpus or 1) > 1 or (args.gpus and os.environ.get("FLAC_AMD_FORCE_LAUNCH") == "1")):
         os.environ["FLACGPU_BENCH_SELF_LAUNCHED"] = "1"
     elif os.environ.get("FLACGPU_BENCH_SELF_LAUNCHED") == "1":
         launched_by = "bench.py --gpus %d (flac_amd.dist.ensure_ranks -> torch.distributed.run)" % (args.gpus or 1)

@@ -75,7 +75,9 @@ def ensure_ranks(nproc, script, argv, need_devices=True, env=None, _exec=None, m
             sys.stderr.write("flac_amd.dist: --gpus %d but the launcher started %d ranks (WORLD_SIZE)\n" % (int(nproc), world))
             raise SystemExit(EXIT_BAD_WORLD)
         return int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), world
-    if nproc is None or int(nproc) <= 1:
+    # (FLAC_AMD_FORCE_LAUNCH=1: go through the launcher even for one rank -- the tests' way to run the self-launch path, exec and
+    #  all, on a box with a single GPU)
+    if (nproc is None or int(nproc) <= 1) and not (env.get("FLAC_AMD_FORCE_LAUNCH") == "1" and nproc is not None):
         return 0, 0, 1
     nproc = int(nproc)
     if need_devices:
@@ -85,6 +87,7 @@ def ensure_ranks(nproc, script, argv, need_devices=True, env=None, _exec=None, m
             raise SystemExit(EXIT_BAD_WORLD)
     cmd = launch_command(nproc, script, argv, module=module)
     child_env = dict(env)
+    child_env.pop("FLAC_AMD_FORCE_LAUNCH", None)
     child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL across processes)
     child_env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // nproc)))
     sys.stdout.flush()

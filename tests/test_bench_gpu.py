@@ -76,3 +76,18 @@ def test_self_launched_ranks_on_the_devices_there_are():
     if n > 1:
         assert line["gather"]["world_size_seen"] == n and line["verified"]["ranks_checked"] == n and line["verified"]["ok"]
         assert line["encode_only"]["value"] > 0 and line["encode_only"]["verified"]["ranks_checked"] == n
+
+
+def test_the_self_launch_path_on_this_box():
+    """FLAC_AMD_FORCE_LAUNCH=1: `python bench.py --gpus 1` replaces itself by `python -m torch.distributed.run --nproc-per-node 1 ...`
+    even for one rank -- the exec, the launcher's environment, the process group over RCCL and rank 0's ONE line on the command's
+    stdout, end to end on hardware (N > 1 needs a box with N GPUs: the driver's run)"""
+    clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = _run_bench(["--gpus", "1", "--force-dist", "--frames", "768", "--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], dict(clean, FLAC_AMD_FORCE_LAUNCH="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and "flac_amd.dist.ensure_ranks" in line["launched_by"], line["launched_by"]
+    assert line["gather"]["world_size_seen"] == 1 and line["verified"]["ok"] and line["verified"]["ranks_checked"] == 1
+    assert line["encode_only"]["value"] > 0 and line["hostshm"]["value"] > 0

@@ -96,3 +96,17 @@ def test_bench_and_corpus_decide_through_ensure_ranks():
         assert "ensure_ranks(" in src, rel
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=_clean_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 3 and "--gpus 64" in r.stderr and not r.stdout.strip()
+
+
+def test_forced_launch_of_one_rank():
+    """FLAC_AMD_FORCE_LAUNCH=1 (the GPU test of the exec path on a one-GPU box): one rank still goes through the launcher; the
+    variable does not travel to the ranks"""
+    from flac_amd.dist import ensure_ranks
+    seen = {}
+    assert ensure_ranks(1, "/x/bench.py", ["--gpus", "1"], need_devices=False, env={"FLAC_AMD_FORCE_LAUNCH": "1"}, _exec=lambda c, e: seen.update(cmd=c, env=e) or "launched") == "launched"
+    assert seen["cmd"][seen["cmd"].index("--nproc-per-node") + 1] == "1" and "FLAC_AMD_FORCE_LAUNCH" not in seen["env"]
+    assert ensure_ranks(None, "/x/bench.py", [], env={"FLAC_AMD_FORCE_LAUNCH": "1"}) == (0, 0, 1)          # (no --gpus: nothing to launch)
+    r = subprocess.run([sys.executable, PROBE, "--gpus", "1"], env=dict(_clean_env(), FLAC_AMD_FORCE_LAUNCH="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
