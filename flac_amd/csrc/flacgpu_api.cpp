@@ -1114,7 +1114,7 @@ extern "C" const char *flacgpu_kernel_bit_name(uint32_t bit)
 {
 	static const char *const names[] = {"ff_kernel", "prep3_kernel", "prep2_kernel", "prep_kernel", "autoc3_kernel", "autoc2_kernel", "autoc_kernel", "model_kernel",
 		"evalg_kernel", "evalw_kernel", "eval_list_kernel", "eval_kernel", "pack_plan_kernel", "pack2_kernel", "pack_kernel", "fo_place_kernel", "scan_kernel", "compact_kernel",
-		"append_tail_kernel", "pack2_kernel<run18>", "autoc3_kernel<SETS>", "autoc3_kernel<PLANES>", "fused_output", "prep2_kernel<DECIDE>", "prep4_kernel", "autoc3_kernel<IND>|autoc4_kernel", "evalg1_kernel"};
+		"append_tail_kernel", "pack2_kernel<run18>", "autoc3_kernel<SETS>", "autoc3_kernel<PLANES>", "fused_output", "prep2_kernel<DECIDE>", "prep4_kernel", "autoc3_kernel<IND>", "autoc4_kernel"};
 	return bit < sizeof names / sizeof names[0] ? names[bit] : nullptr;
 }
 // frames that gave up waiting in the fused output (PackOut, flacgpu_kernels.hip) and were placed from their slots by fo_place_kernel:

@@ -658,7 +658,7 @@ hipError_t launch_autoc4(const DevParams &P, const int32_t *chan, const float *w
 	if(nmain == 0 || njobs == 0) return hipSuccess;
 	const uint32_t max_lpc = P.max_lpc_order >= P.blocksize ? P.blocksize - 1 : P.max_lpc_order;
 	const uint32_t lag = max_lpc + 1, ngroups = (nmain * P.ncand + A3_ITEMS - 1) / A3_ITEMS;
-	note_launch(K_AUTOC1);
+	note_launch(K_AUTOC4);
 	if(lag <= 17) hipLaunchKernelGGL(autoc4_kernel<17>, dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
 	else if(lag <= 25) hipLaunchKernelGGL(autoc4_kernel<25>, dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
 	else hipLaunchKernelGGL(autoc4_kernel<33>, dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);

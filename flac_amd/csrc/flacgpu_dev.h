@@ -142,7 +142,7 @@ enum : uint32_t {
 	K_FF = 1u << 0, K_PREP3 = 1u << 1, K_PREP2 = 1u << 2, K_PREP = 1u << 3, K_AUTOC3 = 1u << 4, K_AUTOC2 = 1u << 5, K_AUTOC = 1u << 6, K_MODEL = 1u << 7,
 	K_EVALG = 1u << 8, K_EVALW = 1u << 9, K_EVAL_LIST = 1u << 10, K_EVAL = 1u << 11, K_PACK_PLAN = 1u << 12, K_PACK2 = 1u << 13, K_PACK = 1u << 14,
 	K_FO_PLACE = 1u << 15, K_SCAN = 1u << 16, K_COMPACT = 1u << 17, K_APPEND_TAIL = 1u << 18, K_PACK2_RUN18 = 1u << 19, K_AUTOC3_SETS = 1u << 20,
-	K_AUTOC3_PLANES = 1u << 21, K_FUSED_OUTPUT = 1u << 22, K_PREP2_DECIDE = 1u << 23, K_PREP1 = 1u << 24, K_AUTOC1 = 1u << 25, K_EVALG1 = 1u << 26
+	K_AUTOC3_PLANES = 1u << 21, K_FUSED_OUTPUT = 1u << 22, K_PREP2_DECIDE = 1u << 23, K_PREP1 = 1u << 24, K_AUTOC1 = 1u << 25 /* autoc3_kernel<IND> */, K_AUTOC4 = 1u << 26
 };
 struct Tune {
 	int autoc3_mode;           // FLACGPU_AUTOC3: 0 never, 1 whenever it applies, 2 (default) when it fills the chip

@@ -214,5 +214,5 @@ def test_plain_autocorrelation_loop_with_a_lane_per_subframe(order, monkeypatch)
         if "mid_side" in kw:
             okw.update(mid_side=kw["mid_side"], loose=kw.get("loose_mid_side", 0))
         o = po.oracle_encode(pcm, bps, 48000, 8, **okw)
-        assert "autoc3_kernel<IND>|autoc4_kernel" in kernels and "autoc2_kernel" not in kernels and "autoc3_kernel" not in kernels, sorted(kernels)
+        assert "autoc4_kernel" in kernels and "autoc2_kernel" not in kernels and "autoc3_kernel" not in kernels, sorted(kernels)
         assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (order, ch, bps, bs, fam, kw)
