@@ -360,9 +360,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(level, kind, steps, warmup, use_dist, gather=None):
+    def measure(level, kind, steps, warmup, use_dist, gather=None, window=None):
         """K timed steps of one configuration; returns the numbers and what the verification needs"""
         gather = gather or args.gather
+        window = window or args.window
         block = block_of(level)
         settings = flac_amd.make_settings(CH, BPS, RATE, level, **search)
         eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=nframes)
@@ -392,9 +393,9 @@ def main():
                 torch.cuda.synchronize()
                 hcap = (int(d_ptot.item()) * 5 // 4 + 4095) & ~4095
                 del d_probe, d_pfb, d_ptot
-                gp = HostShmPipeline(cap, nframes, dev, window=args.window, host_cap_bytes=hcap)
+                gp = HostShmPipeline(cap, nframes, dev, window=window, host_cap_bytes=hcap)
             else:
-                gp = GatherPipeline(cap, nframes, dev, window=args.window)
+                gp = GatherPipeline(cap, nframes, dev, window=window)
             state = {"k": 0}
 
             def run(nsteps):
@@ -588,8 +589,10 @@ def main():
         # link into one shared pinned host buffer (`hostshm`).  Every rank's frames are checked in both.
         side_steps = max(args.window, args.steps // 2)
         eo = measure(LEVEL, main_kind, side_steps, 1, True, "none")
-        # the shared host buffer lives in /dev/shm: rank 0 looks whether the windows fit there and tells the others
-        need = 2 * args.window * world * ((int(m.get("gathered_bytes_last_step") or 0) // max(1, world)) * 5 // 4 + 4096) if rank == 0 else 0
+        # the shared host buffer lives in /dev/shm and every rank page-locks all of it: windows of two steps for this side figure
+        # (eight ranks x four slots x 8 x 240 MB = 7.7 GB instead of 15); rank 0 looks whether they fit and tells the others
+        hs_window = min(args.window, 2)
+        need = 2 * hs_window * world * ((int(m.get("gathered_bytes_last_step") or 0) // max(1, world)) * 5 // 4 + 4096) if rank == 0 else 0
         verdict = [None]
         if rank == 0:
             try:
@@ -599,7 +602,7 @@ def main():
             except OSError as e:
                 verdict[0] = "no /dev/shm: %s" % e
         dist.broadcast_object_list(verdict, src=0)
-        hs = measure(LEVEL, main_kind, side_steps, 1, True, "hostshm") if verdict[0] is None else None
+        hs = measure(LEVEL, main_kind, side_steps, 1, True, "hostshm", window=hs_window) if verdict[0] is None else None
         if rank == 0:
             def side_line(r, how):
                 wins = r.get("gather_windows") or []
