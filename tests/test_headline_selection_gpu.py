@@ -216,3 +216,50 @@ def test_plain_autocorrelation_loop_with_a_lane_per_subframe(order, monkeypatch)
         o = po.oracle_encode(pcm, bps, 48000, 8, **okw)
         assert "autoc4_kernel" in kernels and "autoc2_kernel" not in kernels and "autoc3_kernel" not in kernels, sorted(kernels)
         assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (order, ch, bps, bs, fam, kw)
+
+
+def _oracle_parallel_kw(pcm, bps, rate, level, block, nthreads=16, chunk=32, **okw):
+    nfr = pcm.shape[0] // block
+    jobs = [(f, min(f + chunk, nfr)) for f in range(0, nfr, chunk)]
+
+    def one(j):
+        lo, hi = j
+        o = po.oracle_encode(pcm[lo * block:hi * block], bps, rate, level, first_frame=lo, **okw)
+        return o["data"], np.asarray(o["frame_bytes"])
+    with ThreadPoolExecutor(nthreads) as ex:
+        parts = list(ex.map(one, jobs))
+    return b"".join(p[0] for p in parts), np.concatenate([p[1] for p in parts])
+
+
+OFF_THE_FAST_PATH = [
+    # name, channels, bps, rate, level, block, frames, engine kw, oracle kw, kernels that must have run
+    ("-8 -b 2304: general evaluation and pack bodies", 2, 16, 44100, 8, 2304, 3000, dict(blocksize=2304), dict(blocksize=2304), {"eval_kernel", "pack_kernel", "scan_kernel", "compact_kernel"}),
+    ("-8 -l 32: autoc4 + the general evaluation, model and pack", 2, 16, 44100, 8, 4096, 1200, dict(max_lpc_order=32, streamable_subset=0), dict(max_lpc_order=32), {"autoc4_kernel", "eval_kernel", "pack_kernel"}),
+    ("-8 -l 16: autoc4 + eval_kernel + pack2", 2, 16, 44100, 8, 4096, 2500, dict(max_lpc_order=16, streamable_subset=0), dict(max_lpc_order=16), {"autoc4_kernel", "eval_kernel", "pack2_kernel"}),
+    ("-2 on 24-bit: prep2 + eval_kernel + pack2", 2, 24, 96000, 2, 1152, 6000, {}, {}, {"prep2_kernel", "eval_kernel", "pack2_kernel"}),
+    ("-8 mono under the default selection", 1, 16, 44100, 8, 4096, 9000, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "evalg_kernel", "pack2_kernel"}),
+    ("-8 5.1 under the default selection", 6, 16, 48000, 8, 4096, 1800, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "evalg_kernel", "pack2_kernel"}),
+    ("-5 stereo without mid/side", 2, 16, 44100, 5, 4096, 5000, dict(mid_side=0), dict(mid_side=0), {"prep4_kernel", "evalg_kernel", "pack2_kernel"}),
+]
+
+
+@pytest.mark.parametrize("name,ch,bps,rate,level,block,nfr,ekw,okw,want", OFF_THE_FAST_PATH, ids=[c[0] for c in OFF_THE_FAST_PATH])
+def test_batches_of_thousands_of_frames_off_the_headline_path(name, ch, bps, rate, level, block, nfr, ekw, okw, want):
+    """VERDICT r04, thin spot (iii): what is not the headline's path -- the general evaluation / model / pack bodies, the kernels of the
+    other channel layouts, the plain autocorrelation loop -- saw test-sized batches only.  Here each runs a batch of thousands of
+    frames under the engine's own selection (no switches), every byte compared with the oracle (all frames, host threads), the
+    kernels that ran asserted."""
+    import flac_amd
+    base = signals.music(block * 96, ch, bps, seed=len(name)).astype(np.int64)
+    reps = -(-nfr // 96)
+    pcm = np.concatenate([(base * (1000 - 3 * (r % 150))) // 1000 + (r % 3) for r in range(reps)])[:nfr * block].astype(np.int32)
+    eng = flac_amd.FrameEngine(flac_amd.make_settings(ch, bps, rate, level, **ekw), device=0, max_batch_frames=nfr)
+    try:
+        data, fb = eng.encode(pcm)
+        kernels = eng.last_batch_kernels()
+    finally:
+        eng.close()
+    assert want <= kernels, (name, sorted(kernels))
+    odata, ofb = _oracle_parallel_kw(pcm, bps, rate, level, block, **okw)
+    assert np.array_equal(fb, ofb), name
+    assert data == odata, name
