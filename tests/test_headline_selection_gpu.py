@@ -105,7 +105,9 @@ def test_full_size_level8_batch_under_the_default_selection_equals_the_oracle_en
     odata, ofb = _oracle_parallel(pcm, 8, block)
     assert np.array_equal(fb, ofb) and np.array_equal(fb2, ofb)
     assert data == odata and data2 == odata
-    assert fell == (0, 0), fell                       # nothing gave up waiting in the fused output on an otherwise idle chip
+    # (frames that give up waiting in the fused output cost time, never bytes, and how many do depends on the order in which the chip
+    #  starts workgroups -- observed, not promised: none in every run so far, but not a parity condition)
+    assert fell[1] <= nfr, fell
 
 
 @pytest.mark.parametrize("level,nfr,block,want,never", [
