@@ -826,10 +826,12 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 	}
 	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u);
-	// wavefronts that own a channel (one per raw channel of a round; four with mid/side: L, R, M, S); the workgroup always has four, so
-	// that the staging of a frame is the work of 256 threads whatever the channel count (tune().no_fast1: round 4's shape, for A/B runs)
+	// wavefronts that own a channel (one per raw channel of a round; four with mid/side: L, R, M, S) = the workgroup.  (Round 5 tried
+	// four wavefronts always, so that 256 threads stage a frame whatever the channel count: mono at -0 went 0.164 -> 0.252 ms per 33 M
+	// samples -- the three idle wavefronts take the register file's room from nine more one-wavefront workgroups per CU.  What this
+	// kernel keeps from that round is the staging loop with four samples in flight per thread.)
 	const uint32_t active = stereo_ms ? 4u : nraw;
-	const uint32_t waves = tune().no_fast1 ? active : 4u;
+	const uint32_t waves = active;
 	const size_t lds = (size_t)nraw * p2_chan_bytes(P.blocksize, p2_chunk_len(P.blocksize));
 #define P2GO(W, NF) hipLaunchKernelGGL((prep2_kernel<W, NF, false>), dim3(nmain), dim3(64 * waves), lds, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft)
 	note_launch(K_PREP2);
