@@ -41,6 +41,7 @@ struct flacgpu_ctx {
 	uint8_t *d_slots;            // [max_batch][slot_bytes]
 	bool ff_ok;                  // ff_kernel (one kernel per batch: -0 .. -2 on 16-bit stereo) can take this stream
 	uint32_t *d_frame_bytes;     // [max_batch]
+	uint32_t *last_fb;           // where the last batch's frame lengths are: d_frame_bytes, or the caller's array
 	uint64_t *d_offsets;         // [max_batch+1]
 	uint64_t *d_total;
 	// the fused output (flacgpu_kernels.hip: PackOut): tagged frame lengths, segment totals and starts, arrival counters, the ticket
@@ -103,6 +104,9 @@ static Tune read_tune(int device)
 	auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
 	auto set = [](const char *name) { return getenv(name) ? 1 : 0; };
 	t.autoc3_mode = num("FLACGPU_AUTOC3", 2); t.autoc3_sets = num("FLACGPU_AUTOC3_SETS", 1); t.autoc3_planes = num("FLACGPU_AUTOC3_PLANES", 1);
+	t.autoc3_ind_sets = num("FLACGPU_AUTOC3_IND_SETS", 2);
+	t.event_fence = num("FLACGPU_EVENT_FENCE", 0);            // 1: the timing events with their system-scope fence (round 4's)
+	t.copy_results = num("FLACGPU_COPY_RESULTS", 0);          // 1: frame lengths / total copied to the caller's arrays behind the last kernel (round 4's)
 	t.autoc2_ungrouped = set("FLACGPU_AUTOC2_UNGROUPED");
 	{ const char *e = getenv("FLACGPU_AUTOC2"); t.autoc2_force = e ? atoi(e) + 1 : 0; }
 	t.no_ff = set("FLACGPU_NO_FF"); t.no_run18 = set("FLACGPU_NO_RUN18"); t.no_prep3 = set("FLACGPU_NO_PREP3"); t.no_prep_decide = set("FLACGPU_NO_PREP_DECIDE");
@@ -415,8 +419,11 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	bool ok = true;
 	ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
 	for(int r = 0; r < TIMING_RING && ok; r++) {
-		for(int i = 0; i < 5 && ok; i++) ok = hipEventCreate(&c->ev_ring[r][i]) == hipSuccess;
-		for(int i = 0; i < 3 && ok; i++) ok = hipEventCreate(&c->pev_ring[r][i]) == hipSuccess;
+		// (timing only: nothing synchronizes on these to READ memory -- without the system-scope fence a record stops costing the
+		//  stream a cache write-back + invalidate, ~6 us of idle chip per event and six events a batch: profiles/r05_p_timeline_*.txt)
+		const unsigned tflags = c->tune.event_fence ? 0u : hipEventDisableSystemFence;
+		for(int i = 0; i < 5 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_ring[r][i], tflags) == hipSuccess;
+		for(int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&c->pev_ring[r][i], tflags) == hipSuccess;
 	}
 	c->ev = c->ev_ring[0]; c->pev = c->pev_ring[0];
 	for(int i = 0; i < FLACGPU_MAX_SUBBATCHES && ok; i++) {
@@ -513,6 +520,11 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	c->tune.launched = 0;
 	struct KeepLaunched { flacgpu_ctx *c; ~KeepLaunched() { c->last_launched = c->tune.launched; } } keep_launched{c};
 	const DevParams &P = c->P;
+	// frame lengths and the stream's length are written where the caller wants them (they were copied there behind the last kernel:
+	// two more dispatches per batch -- a tenth of a -0 step)
+	uint32_t *const fb = d_fb_out && !c->tune.copy_results ? d_fb_out : c->d_frame_bytes;
+	uint64_t *const tot = d_total_out && !c->tune.copy_results ? d_total_out : c->d_total;
+	c->last_fb = fb;
 	if(tail_n) {
 		// The short last block has its own job schedule and windows.  Both live in one device copy each, and the sources are
 		// pageable host memory (this context; the caller's array): wait until an earlier batch that may still be reading the
@@ -535,7 +547,11 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	// parity tests of that path.
 	const int fuse = c->tune.no_fused ? 0 : 1;
 	PackOutArgs po = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-	if(fuse && nframes <= c->fo_frames) {
+	// ff_kernel (one kernel for the whole frame, flacgpu_kernels.hip) where it applies: not with the verify hints (the decoder wants
+	// the pack kernel's run starts), not with the debug stamps; one stream
+	const bool ff = c->ff_ok && !c->d_vhints && !c->ab.dbg;
+	// (ff_kernel places its frames itself only when asked to, launch_ff: otherwise the batch has no use for the fused output's words)
+	if(fuse && nframes <= c->fo_frames && !(ff && c->ff_lag < 0)) {
 		uint32_t epoch = c->fo_epoch + 1;
 		if(epoch >= (1u << 24) || c->fo_dirty) {
 			// the tags have gone round: start again from clean words (once in sixteen million batches) -- or the batch before ended in an
@@ -546,7 +562,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			c->fo_epoch = 0; epoch = 1; c->fo_last_fused = 0;
 		}
 		else if(c->fo_last_fused + 1 != epoch && hipMemsetAsync(c->d_fo_nfall, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-		po = PackOutArgs{d_out, out_cap, c->d_offsets, c->d_total, c->d_fo_fstate, c->d_fo_sstate, c->d_fo_sprefix, c->d_fo_scount, c->d_fo_fall, c->d_fo_nfall, epoch, c->fo_spin_limit, c->ff_lag > 0 ? (uint32_t)c->ff_lag : 0u};
+		po = PackOutArgs{d_out, out_cap, c->d_offsets, tot, c->d_fo_fstate, c->d_fo_sstate, c->d_fo_sprefix, c->d_fo_scount, c->d_fo_fall, c->d_fo_nfall, epoch, c->fo_spin_limit, c->ff_lag > 0 ? (uint32_t)c->ff_lag : 0u};
 		// The epoch is spent from here on, whether or not the launches below succeed: a kernel that tagged words with it may have run
 		// before a later launch fails, and the next batch must not take those words for its own.  An unused epoch costs
 		// nothing: the tags only have to differ from batch to batch.  (The arrival counters are zeroed by their last user; a batch
@@ -554,9 +570,6 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		c->fo_epoch = epoch;
 		c->fo_dirty = true;          // (until every launch of this batch has been enqueued)
 	}
-	// ff_kernel (one kernel for the whole frame, flacgpu_kernels.hip) where it applies: not with the verify hints (the decoder wants
-	// the pack kernel's run starts), not with the debug stamps; one stream
-	const bool ff = c->ff_ok && !c->d_vhints && !c->ab.dbg;
 	if(c->ab.dbg || nframes < 256 * nsub || ff) nsub = 1;
 	const bool lpc = P.max_analyses != 0;
 	if(ff) {
@@ -564,7 +577,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		// (every buffer is indexed by frame: the same launches on offset pointers) and then, with the fused output, behind the others
 		const uint32_t nmain = tail_n ? nframes - 1 : nframes;
 		const bool ffpo = po.out != nullptr && c->ff_lag >= 0;          // (the kernel places its frames itself only when asked to: launch_ff)
-		if(launch_ff(P, d_pcm, nmain, first, c->d_slots, c->d_frame_bytes, c->d_info, ffpo ? &po : nullptr, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(launch_ff(P, d_pcm, nmain, first, c->d_slots, fb, c->d_info, ffpo ? &po : nullptr, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		fused = ffpo && nmain != 0;
 		hipEvent_t after_main = c->ev[3];
 		if(tail_n) {
@@ -575,9 +588,9 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			B.prep += fc0; B.autoc += fc0 * P.max_jobs * AUTOC_STRIDE; B.cands += fc0 * ncs; B.valid += fc0 * ncs; B.chan += fc0 * P.chan_stride; B.left += fc0; B.left2 += fc0; B.dbg = nullptr;
 			if(launch_analyze(P, d_pcm + (size_t)nmain * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, 1, tail_n, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
 			                  c->d_decisions + fc0, nullptr, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-			if(launch_pack(P, B.chan, 1, tail_n, first + nmain, c->d_decisions + fc0, c->d_plan + (size_t)nmain * pack_plan_stride(P), c->d_slots + (size_t)nmain * P.slot_bytes, c->d_frame_bytes + nmain, c->d_info + nmain, nullptr, nullptr, nullptr, nullptr, nullptr, s) != hipSuccess)
+			if(launch_pack(P, B.chan, 1, tail_n, first + nmain, c->d_decisions + fc0, c->d_plan + (size_t)nmain * pack_plan_stride(P), c->d_slots + (size_t)nmain * P.slot_bytes, fb + nmain, c->d_info + nmain, nullptr, nullptr, nullptr, nullptr, nullptr, s) != hipSuccess)
 				return FLACGPU_ERR_LAUNCH;
-			if(fused && launch_append_tail(c->d_slots + (size_t)nmain * P.slot_bytes, c->d_frame_bytes, nmain, &po, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			if(fused && launch_append_tail(c->d_slots + (size_t)nmain * P.slot_bytes, fb, nmain, &po, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		}
 		c->hint_count = 0;
 		// (the kernel's time is booked under "prep", a short last block's under "pack", the two-kernel compaction's under its own name)
@@ -604,7 +617,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			const uint32_t tn = i + 1 == nsub ? tail_n : 0;
 			if(launch_analyze(P, d_pcm + (size_t)f0 * P.blocksize * P.channels, c->d_windows, c->d_tail_windows, nf, tn, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, B,
 			                  c->d_decisions + fc0, nullptr, ss) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_plan + (size_t)f0 * pack_plan_stride(P), c->d_slots + (size_t)f0 * P.slot_bytes, c->d_frame_bytes + f0, c->d_info + f0, nullptr, nullptr, nullptr, nullptr, nullptr, ss) != hipSuccess)
+			if(launch_pack(P, B.chan, nf, tn, first + f0, c->d_decisions + fc0, c->d_plan + (size_t)f0 * pack_plan_stride(P), c->d_slots + (size_t)f0 * P.slot_bytes, fb + f0, c->d_info + f0, nullptr, nullptr, nullptr, nullptr, nullptr, ss) != hipSuccess)
 				return FLACGPU_ERR_LAUNCH;
 			(void)hipEventRecord(c->sub_done[i], ss);
 			(void)hipStreamWaitEvent(s, c->sub_done[i], 0);
@@ -652,7 +665,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		{
 			uint32_t hinted = 0;
 			// (not with the debug stamps: they are indexed by workgroup, the fused output takes frames in dispatch order)
-			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_plan, c->d_slots, c->d_frame_bytes, c->d_info, c->ab.dbg, po.out && !c->ab.dbg ? &po : nullptr, &fused, c->d_vhints, &hinted, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+			if(launch_pack(P, c->ab.chan, nframes, tail_n, first, c->d_decisions, c->d_plan, c->d_slots, fb, c->d_info, c->ab.dbg, po.out && !c->ab.dbg ? &po : nullptr, &fused, c->d_vhints, &hinted, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 			c->hint_out = d_out; c->hint_nframes = nframes; c->hint_first = first; c->hint_count = hinted;
 		}
 		if(c->ab.dbg) {
@@ -675,12 +688,12 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	}
 	if(fused) { note_launch(K_FUSED_OUTPUT); c->fo_last_fused = po.epoch; }
 	if(!fused) {
-		if(launch_scan(c->d_frame_bytes, nframes, c->d_offsets, c->d_total, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-		if(launch_compact(c->d_slots, P.slot_bytes, c->d_frame_bytes, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(launch_scan(fb, nframes, c->d_offsets, tot, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(launch_compact(c->d_slots, P.slot_bytes, fb, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
 	(void)hipEventRecord(c->ev[3], s);
-	if(d_fb_out && hipMemcpyAsync(d_fb_out, c->d_frame_bytes, nframes * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
-	if(d_total_out && hipMemcpyAsync(d_total_out, c->d_total, sizeof(uint64_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(d_fb_out && fb != d_fb_out && hipMemcpyAsync(d_fb_out, fb, nframes * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+	if(d_total_out && tot != d_total_out && hipMemcpyAsync(d_total_out, tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	c->last_nframes = nframes;
 	c->timing_valid = true;
 	c->fo_dirty = false;
@@ -952,7 +965,7 @@ extern "C" int flacgpu_submit_batch_raw(flacgpu_ctx *c, const void *raw, const f
 	r = run_batch(c, c->d_pcm, nframes, first_frame_number, tail_n, tail_windows, a.d_out, a.d_out_bytes, a.d_fb, a.d_total, s);
 	if(r != FLACGPU_OK) return submit_drain(c, r);
 	if(c->verify_on) {
-		if(launch_verify(c->P, a.d_out, c->d_frame_bytes, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, c->d_vresult,
+		if(launch_verify(c->P, a.d_out, c->last_fb, c->d_offsets, nframes, tail_n, first_frame_number, c->d_pcm, c->d_vscratch, c->d_vdecoded, c->d_vfinfo, c->d_vstate, c->d_vresult,
 		                 c->d_vhints, hints_for(c, a.d_out, nframes, first_frame_number), c->d_vfstat, c->ab.dbg, s) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 		if(hipMemcpyAsync(a.d_vres, c->d_vresult, sizeof(flacgpu_verify_result), hipMemcpyDeviceToDevice, s) != hipSuccess) return submit_drain(c, FLACGPU_ERR_LAUNCH);
 	}

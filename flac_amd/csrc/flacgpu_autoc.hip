@@ -430,8 +430,9 @@ __device__ __forceinline__ void a3_store_ind(float *tile, uint32_t half, const A
 // lines -- 75 KB per frame instead of 42).
 // SRC: 0 stereo with a full mid/side search from the interleaved PCM, 1 the same from the left / right planes (PLANES), 2 independent
 // subframes from their planes (IND)
+// (independent subframes by sets: launched only while its wavefronts fit one per SIMD -- the whole register file is the wavefront's)
 template <int VARIANT, int LAG, bool SETS, int SRC>
-__global__ __launch_bounds__(64, 2) void autoc3_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
+__global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
                                                        uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
                                                        double *__restrict__ autoc_out)
 {
@@ -683,10 +684,17 @@ static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const int32_
 	const uint32_t ngroups = (nmain * P.ncand + A3_ITEMS - 1) / A3_ITEMS;
 	const int sets = tune().autoc3_sets;
 	if(!autoc3_ms(P)) {
-		// independent subframes from their planes.  A wavefront per job: the channels of a group are not one frame's, the sets' trick
-		// of sharing a frame's lines in the L2 does not apply -- and the many short wavefronts fill the chip better for few channels
-		note_launch(K_AUTOC3 | K_AUTOC3_PLANES | K_AUTOC1);
-		hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 2>), dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
+		// independent subframes from their planes.  A wavefront per job fills the chip better when the subframes are few (six short
+		// wavefronts per group at -8) -- until the jobs stop fitting one per SIMD: they are dispatched longest first and a SIMD that gets
+		// the whole-block job AND a half carries 1.5 sweeps of the block where a third of the SIMDs carry a third (mono, 16384 frames:
+		// 0.316 ms, the time of 1.5 sweeps).  A wavefront per SET (whole | halves | thirds: one sweep each, equal lengths) fits one per
+		// SIMD up to 341 groups: one sweep.
+		const int isets = tune().autoc3_ind_sets;
+		const uint32_t simds = 1024;
+		const bool by_sets = nsets >= 2 && nsets <= 8 && (isets == 1 || (isets == 2 && njobs * ngroups > simds && nsets * ngroups <= simds));
+		note_launch(K_AUTOC3 | K_AUTOC3_PLANES | K_AUTOC1 | (by_sets ? K_AUTOC3_SETS : 0u));
+		if(by_sets) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 2>), dim3(nsets * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
+		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 2>), dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
 		return;
 	}
 	// 16-bit input: the prep kernel's left and right planes are 16-bit pairs (ChanPrep::fmt = 1 whenever sbps <= 16) -- read those

@@ -231,6 +231,43 @@ def test_device_resident_entry_point():
     eng.close()
 
 
+@pytest.mark.parametrize("level,block", [(8, 4096), (5, 4096), (0, 1152), (2, 1152), (8, 2304)])
+@pytest.mark.parametrize("copy", [0, 1])
+def test_device_entry_writes_lengths_and_total_into_the_callers_arrays(level, block, copy, monkeypatch):
+    """round 5: the kernels write the frame lengths and the stream's length where the caller asked for them (FLACGPU_COPY_RESULTS=1:
+    round 4's two copies behind the last kernel) -- arrays in the middle of larger ones (4- and 8-byte aligned, nothing beyond the
+    batch's entries touched), two batches back to back into different arrays, a short last block, every preset family's last kernel
+    (fused output, scan + compact behind ff_kernel, the general pack kernel)"""
+    import torch
+    import flac_amd
+    if copy:
+        monkeypatch.setenv("FLACGPU_COPY_RESULTS", "1")
+    nfr, tail = 37, 333
+    pcm = signals.music(block * nfr + tail, 2, 16, seed=level + block)
+    eng = flac_amd.FrameEngine(flac_amd.make_settings(2, 16, 44100, level, blocksize=block), device=0, max_batch_frames=64)
+    try:
+        dev = torch.device("cuda", 0)
+        d_pcm = torch.from_numpy(pcm).to(dev)
+        cap = eng.max_output_bytes(nfr + 1)
+        outs = []
+        for k, first in enumerate((0, 1000)):
+            d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            d_fb = torch.full((nfr + 1 + 6,), -7, dtype=torch.int32, device=dev)
+            d_tot = torch.full((4,), -9, dtype=torch.int64, device=dev)
+            eng.encode_device(d_pcm.data_ptr(), nfr + 1, d_out.data_ptr(), cap, d_fb.data_ptr() + 4 * (1 + 2 * k), d_tot.data_ptr() + 8 * (1 + k), first_frame_number=first, tail=tail)
+            outs.append((d_out, d_fb, d_tot, first, 1 + 2 * k, 1 + k))
+        torch.cuda.synchronize()
+        for d_out, d_fb, d_tot, first, fo, to in outs:
+            o = po.oracle_encode(pcm, 16, 44100, level, blocksize=block, first_frame=first)
+            fb, tot = d_fb.cpu().numpy(), d_tot.cpu().numpy()
+            assert int(tot[to]) == len(o["data"]) and all(int(tot[i]) == -9 for i in range(4) if i != to), tot
+            assert np.array_equal(fb[fo:fo + nfr + 1].astype(np.uint32), o["frame_bytes"])
+            assert np.all(fb[:fo] == -7) and np.all(fb[fo + nfr + 1:] == -7), fb
+            assert d_out[:len(o["data"])].cpu().numpy().tobytes() == o["data"]
+    finally:
+        eng.close()
+
+
 # ---- input staging on the device (format_input of the reference's CLI, src/flac/encode.c:2352-2492) ---------------------
 RAW_FORMATS = [(8, False, True, 0), (8, False, False, 0), (16, False, False, 0), (16, True, False, 0), (16, False, True, 0),
                (24, False, False, 0), (24, True, False, 0), (24, True, True, 0), (32, False, False, 8), (32, True, True, 8),

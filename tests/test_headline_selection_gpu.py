@@ -160,6 +160,33 @@ def test_lane_per_subframe_autocorrelation_of_independent_channels(name, ch, bps
         assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (name, level, bs)
 
 
+@pytest.mark.parametrize("name,ch,bps,kw,fam", [l for l in LAYOUTS if l[0] in ("mono", "stereo, independent", "5.1", "8 channels, 24-bit", "mono, 24-bit with wasted bits")],
+                         ids=[l[0] for l in LAYOUTS if l[0] in ("mono", "stereo, independent", "5.1", "8 channels, 24-bit", "mono, 24-bit with wasted bits")])
+def test_independent_channels_with_a_wavefront_per_window_job_set(name, ch, bps, kw, fam, monkeypatch):
+    """autoc3_kernel<.., SETS, IND>: a wavefront sweeps the block once -- the whole-block job | the halves | the thirds (-8), the whole | the halves
+    (-6, -7) -- for 64 independent subframes; the engine picks it when a wavefront per JOB no longer fits one per SIMD and a wavefront
+    per SET still does (mono: 10923..21845 frames).  Forced here at test size, group counts that are not multiples of the XCD count."""
+    _force_autoc3(monkeypatch)
+    monkeypatch.setenv("FLACGPU_AUTOC3_IND_SETS", "1")
+    import flac_amd
+    for level, bs, nfr in ((8, 4096, 21), (6, 4096, 150), (7, 4608, 70), (8, 1152, 700), (8, 4096, 577)):
+        nfr = max(3, nfr // ch)
+        pcm = signals.FAMILIES[fam](bs * nfr + 77, ch, bps)
+        ekw = dict(kw, blocksize=bs)
+        okw = dict(blocksize=bs)
+        if "mid_side" in kw:
+            okw.update(mid_side=kw["mid_side"], loose=kw.get("loose_mid_side", 0))
+        eng = flac_amd.FrameEngine(flac_amd.make_settings(ch, bps, 48000, level, **ekw), device=0, max_batch_frames=nfr + 1)
+        try:
+            data, fb = eng.encode(pcm)
+            kernels = eng.last_batch_kernels()
+        finally:
+            eng.close()
+        assert {"autoc3_kernel<IND>", "autoc3_kernel<SETS>"} <= kernels, (name, level, bs, sorted(kernels))
+        o = po.oracle_encode(pcm, bps, 48000, level, **okw)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (name, level, bs)
+
+
 @pytest.mark.parametrize("ch,bps", [(1, 16), (2, 16), (6, 16), (8, 24), (3, 12), (1, 24)])
 def test_independent_channel_kernels_edge_signals(ch, bps, monkeypatch):
     """prep4_kernel / autoc3_kernel<IND> on the signals that exercise the prep decisions: constant and silent channels (CONSTANT, the
@@ -240,6 +267,7 @@ OFF_THE_FAST_PATH = [
     ("-8 -l 16: autoc4 + eval_kernel + pack2", 2, 16, 44100, 8, 4096, 2500, dict(max_lpc_order=16, streamable_subset=0), dict(max_lpc_order=16), {"autoc4_kernel", "eval_kernel", "pack2_kernel"}),
     ("-2 on 24-bit: prep2 + eval_kernel + pack2", 2, 24, 96000, 2, 1152, 6000, {}, {}, {"prep2_kernel", "eval_kernel", "pack2_kernel"}),
     ("-8 mono under the default selection", 1, 16, 44100, 8, 4096, 9000, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "evalg_kernel", "pack2_kernel"}),
+    ("-8 mono, 11264 frames: the size at which independent channels go a wavefront per window-job set", 1, 16, 44100, 8, 4096, 11264, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "autoc3_kernel<SETS>", "evalg_kernel", "pack2_kernel"}),
     ("-8 5.1 under the default selection", 6, 16, 48000, 8, 4096, 1800, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "evalg_kernel", "pack2_kernel"}),
     ("-5 stereo without mid/side", 2, 16, 44100, 5, 4096, 5000, dict(mid_side=0), dict(mid_side=0), {"prep4_kernel", "evalg_kernel", "pack2_kernel"}),
 ]
