@@ -119,6 +119,9 @@ int64_t flacgpu_encode_batch(flacgpu_ctx *ctx, const int32_t *pcm, uint32_t nfra
 
 /* Same, with every buffer already resident in DEVICE memory (HBM): d_pcm, d_out and
  * d_frame_bytes are device pointers; d_total_bytes (device, 8 bytes) receives the byte total.
+ * The kernels write both in place (round 5): d_frame_bytes needs 4-byte, d_total_bytes 8-byte alignment, nothing beyond the
+ * batch's nframes entries is touched, and their contents are undefined until the batch has completed on `stream` (either may be
+ * NULL: the engine then writes its own arrays, which no entry point exposes).
  * Asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream); returns 0 or
  * a negative code.  This is the entry bench.py times. */
 int flacgpu_encode_batch_device(flacgpu_ctx *ctx, const int32_t *d_pcm, uint32_t nframes,
