@@ -312,6 +312,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank pipeline (process group, windowed ordered gather) even with one rank")
     ap.add_argument("--no-clock", action="store_true", help="skip the engine-clock probe (outside the timed region)")
     ap.add_argument("--no-side-gathers", action="store_true", help="multi-rank rccl line: skip the encode-only (--gather none) and hostshm figures measured beside it in the same run")
+    ap.add_argument("--side-timeout", type=int, default=420, help="multi-rank rccl line: seconds the side figures may take before rank 0 prints the main line without them and exits 1")
     args = ap.parse_args()
     # one call, N workers: `python bench.py --gpus 8` starts its eight ranks itself (and never prints n_gpus: 8 from fewer)
     from flac_amd.dist import ensure_ranks, check_world
@@ -583,57 +584,8 @@ def main():
     m = measure(LEVEL, main_kind, args.steps, args.warmup, multi)
     extras = {}
     side = {}
-    if multi and args.gather == "rccl" and not args.no_side_gathers:
-        # the same job twice more in the same run, so that a sub-linear rccl figure splits into encode scaling and funnel without
-        # a second command: the frames stay where they were encoded (`encode_only`), and every rank copies them over its own PCIe
-        # link into one shared pinned host buffer (`hostshm`).  Every rank's frames are checked in both.
-        side_steps = max(args.window, args.steps // 2)
-        eo = measure(LEVEL, main_kind, side_steps, 1, True, "none")
-        # the shared host buffer lives in /dev/shm and every rank page-locks all of it: windows of two steps for this side figure
-        # (eight ranks x four slots x 8 x 240 MB = 7.7 GB instead of 15); rank 0 looks whether they fit and tells the others
-        hs_window = min(args.window, 2)
-        need = 2 * hs_window * world * ((int(m.get("gathered_bytes_last_step") or 0) // max(1, world)) * 5 // 4 + 4096) if rank == 0 else 0
-        verdict = [None]
-        if rank == 0:
-            try:
-                st = os.statvfs("/dev/shm")
-                free = st.f_bavail * st.f_frsize
-                verdict[0] = None if need + (256 << 20) <= free else "the windows need %d MB of /dev/shm, %d MB free" % (need >> 20, free >> 20)
-            except OSError as e:
-                verdict[0] = "no /dev/shm: %s" % e
-        dist.broadcast_object_list(verdict, src=0)
-        hs = measure(LEVEL, main_kind, side_steps, 1, True, "hostshm", window=hs_window) if verdict[0] is None else None
-        if rank == 0:
-            def side_line(r, how):
-                wins = r.get("gather_windows") or []
-                wms = [w["ms"] for w in wins if w["ms"] is not None]
-                return {"value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"], "how": how,
-                        "verified": {k: r["verified"][k] for k in ("ranks_checked", "ok", "ranks_failing", "crc16_frames_checked", "frames_compared_with_oracle")} if r.get("verified") else None,
-                        "rank0_transfer_ms_per_step": round(sum(wms) / max(1, sum(w["steps"] for w in wins)), 4) if wms else None}
-            side["encode_only"] = side_line(eo, "--gather none in the same run: every rank's frames stay in its HBM; rccl value / this = what the funnel into rank 0 costs")
-            side["hostshm"] = side_line(hs, "--gather hostshm in the same run: every rank copies its frames over its own PCIe link into one shared pinned host buffer") \
-                if hs is not None else {"skipped": verdict[0]}
-    if world == 1 and not multi and not args.no_extras and LEVEL == 8 and not args.hires and not args.white and not any(search.values()):
-        side_steps = max(3, args.steps // 2)
-        w = measure(8, "white", side_steps, 1, False)
-        l5 = measure(5, "music", side_steps, 1, False)
-        l0 = measure(0, "music", 4 * side_steps, 2, False)       # (0.2 ms steps: five of them are a millisecond, too short a stretch to time)
-        args.hires = True
-        RATE, BPS = 96000, 24
-        hr = measure(8, "music", max(3, side_steps // 2), 1, False)
-        args.hires = False
-        RATE, BPS = 44100, 16
-        if rank == 0:
-            for key, r, what in (("white_noise", w, "flac -8 on i.i.d. uniform 16-bit stereo white noise (SURVEY.md 8d config 3 (i)): the 32-bit side-channel path, the largest frames"),
-                                 ("level5", l5, "flac -5 (the tool's default preset) on the music-like signal"),
-                                 ("level0", l0, "flac -0 (fixed predictors only, 1152-sample blocks, no mid/side) on the music-like signal"),
-                                 ("hires", hr, "flac -8 on 96 kHz / 24-bit stereo (BASELINE.json config 4: the wide-sample residual path), 4096-sample blocks")):
-                extras[key] = {"what": what, "value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"],
-                               "compressed_bytes_per_sample": round(r["out_bps"], 4), "kernel_ms": {k: round(v, 4) for k, v in r["kernel_ms"].items()},
-                               "clock": r.get("clock"), "roofline": r["roofline"], "roofline_valu": r.get("roofline_valu"), "verified_frames": r.get("verified", {}).get("frames_compared_with_oracle"),
-                               "verified_ok": r.get("verified", {}).get("ok")}
-
-    if rank == 0:
+    def compose(extras, side):
+        """the bench line from the main measurement m (rank 0)"""
         sig = "white noise" if args.white else "music-like synthetic PCM"
         line = {
             "metric": ("encode Msamples/s at -8, 44.1k/16-bit stereo; bit-exact vs libFLAC" if not args.hires else "encode Msamples/s at -8, 96k/24-bit stereo (side measurement)")
@@ -682,16 +634,114 @@ def main():
                                       "if rank0_transfer_ms_per_step approaches ms_per_step the gather sets the pace"}
         line.update(extras)
         line.update(side)
+        return line
+
+    def side_figures():
+        """multi-rank rccl line: the encode-only and the shared-host-buffer figures of the same run (every rank calls this)"""
+        side = {}
+        side_steps = max(args.window, args.steps // 2)
+        eo = measure(LEVEL, main_kind, side_steps, 1, True, "none")
+        fault = os.environ.get("FLACGPU_BENCH_SIDE_FAULT")        # (tests/test_bench_gpu.py: what the line looks like when these figures fail)
+        if fault == "raise":
+            raise RuntimeError("injected fault")
+        if fault == "hang":
+            import threading
+            threading.Event().wait()
+        # the shared host buffer lives in /dev/shm and every rank page-locks all of it: windows of two steps for this side figure
+        # (eight ranks x four slots x 8 x 240 MB = 7.7 GB instead of 15); rank 0 looks whether they fit and tells the others
+        hs_window = min(args.window, 2)
+        need = 2 * hs_window * world * ((int(m.get("gathered_bytes_last_step") or 0) // max(1, world)) * 5 // 4 + 4096) if rank == 0 else 0
+        verdict = [None]
+        if rank == 0:
+            try:
+                st = os.statvfs("/dev/shm")
+                free = st.f_bavail * st.f_frsize
+                verdict[0] = None if need + (256 << 20) <= free else "the windows need %d MB of /dev/shm, %d MB free" % (need >> 20, free >> 20)
+            except OSError as e:
+                verdict[0] = "no /dev/shm: %s" % e
+        dist.broadcast_object_list(verdict, src=0)
+        hs = measure(LEVEL, main_kind, side_steps, 1, True, "hostshm", window=hs_window) if verdict[0] is None else None
+        if rank == 0:
+            def side_line(r, how):
+                wins = r.get("gather_windows") or []
+                wms = [w["ms"] for w in wins if w["ms"] is not None]
+                return {"value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"], "how": how,
+                        "verified": {k: r["verified"][k] for k in ("ranks_checked", "ok", "ranks_failing", "crc16_frames_checked", "frames_compared_with_oracle")} if r.get("verified") else None,
+                        "rank0_transfer_ms_per_step": round(sum(wms) / max(1, sum(w["steps"] for w in wins)), 4) if wms else None}
+            side["encode_only"] = side_line(eo, "--gather none in the same run: every rank's frames stay in its HBM; rccl value / this = what the funnel into rank 0 costs")
+            side["hostshm"] = side_line(hs, "--gather hostshm in the same run: every rank copies its frames over its own PCIe link into one shared pinned host buffer") \
+                if hs is not None else {"skipped": verdict[0]}
+        return side
+
+    emitted = [False]
+
+    def emit(line):
+        if not emitted[0]:
+            emitted[0] = True
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+    def bail(why):
+        """rank 0, multi-rank: the side figures failed, hung or another rank died -- the main measurement is complete and checked:
+        print its line (saying what happened to the side figures) and leave; the launcher takes the other ranks down"""
+        emit(compose({}, {"side_figures": {"error": why}}))
+        os._exit(1)
+
+    if multi and args.gather == "rccl" and not args.no_side_gathers:
+        # the same job twice more in the same run, so that a sub-linear rccl figure splits into encode scaling and funnel without
+        # a second command: the frames stay where they were encoded (`encode_only`), and every rank copies them over its own PCIe
+        # link into one shared pinned host buffer (`hostshm`).  Every rank's frames are checked in both.
+        # (the main line must not depend on them: if rank 0 fails here, or another rank dies and the launcher signals this one, or
+        #  nothing moves for --side-timeout seconds, rank 0 prints the main line with the reason and exits non-zero)
+        from flac_amd.dist import Watchdog
+        import contextlib
+        with (Watchdog(args.side_timeout, bail, "the encode-only / hostshm figures") if rank == 0 else contextlib.nullcontext()):
+            try:
+                side = side_figures()
+            except Exception as e:                   # (other ranks: the exception ends the process, the launcher ends the job)
+                if rank == 0:
+                    bail("%s: %s" % (type(e).__name__, e))
+                raise
+    if world == 1 and not multi and not args.no_extras and LEVEL == 8 and not args.hires and not args.white and not any(search.values()):
+        # (one GPU, no collectives: a side measurement that fails says so in the line instead of taking the main measurement with it)
+        try:
+            side_steps = max(3, args.steps // 2)
+            w = measure(8, "white", side_steps, 1, False)
+            l5 = measure(5, "music", side_steps, 1, False)
+            l0 = measure(0, "music", 4 * side_steps, 2, False)       # (0.2 ms steps: five of them are a millisecond, too short a stretch to time)
+            args.hires = True
+            RATE, BPS = 96000, 24
+            hr = measure(8, "music", max(3, side_steps // 2), 1, False)
+            args.hires = False
+            RATE, BPS = 44100, 16
+            if rank == 0:
+                for key, r, what in (("white_noise", w, "flac -8 on i.i.d. uniform 16-bit stereo white noise (SURVEY.md 8d config 3 (i)): the 32-bit side-channel path, the largest frames"),
+                                     ("level5", l5, "flac -5 (the tool's default preset) on the music-like signal"),
+                                     ("level0", l0, "flac -0 (fixed predictors only, 1152-sample blocks, no mid/side) on the music-like signal"),
+                                     ("hires", hr, "flac -8 on 96 kHz / 24-bit stereo (BASELINE.json config 4: the wide-sample residual path), 4096-sample blocks")):
+                    extras[key] = {"what": what, "value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"],
+                                   "compressed_bytes_per_sample": round(r["out_bps"], 4), "kernel_ms": {k: round(v, 4) for k, v in r["kernel_ms"].items()},
+                                   "clock": r.get("clock"), "roofline": r["roofline"], "roofline_valu": r.get("roofline_valu"), "verified_frames": r.get("verified", {}).get("frames_compared_with_oracle"),
+                                   "verified_ok": r.get("verified", {}).get("ok")}
+        except Exception as e:
+            args.hires = False
+            RATE, BPS = 44100, 16
+            extras["side_measurements_error"] = "%s: %s" % (type(e).__name__, e)
+
+    if rank == 0:
+        line = compose(extras, side)
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(LEVEL, search)
-            line["cpu_baseline"] = cb
-            line["speedup_vs_cpu_1thread"] = round(m["value"] / cb["value"], 2)
-            if "all_cores" in cb:
-                line["speedup_vs_cpu_allcores"] = round(m["value"] / cb["all_cores"]["value"], 2)
-                if cb["library_thread_pool"]["value"]:
-                    line["speedup_vs_cpu_library_pool"] = round(m["value"] / cb["library_thread_pool"]["value"], 2)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+            try:
+                cb = cpu_baseline(LEVEL, search)
+                line["cpu_baseline"] = cb
+                line["speedup_vs_cpu_1thread"] = round(m["value"] / cb["value"], 2)
+                if "all_cores" in cb:
+                    line["speedup_vs_cpu_allcores"] = round(m["value"] / cb["all_cores"]["value"], 2)
+                    if cb["library_thread_pool"]["value"]:
+                        line["speedup_vs_cpu_library_pool"] = round(m["value"] / cb["library_thread_pool"]["value"], 2)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        emit(line)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -106,6 +106,56 @@ def check_world(nproc, group=None):
     return world
 
 
+class Watchdog:
+    """Context manager around work whose failure must not take a finished result with it (bench.py: the side figures behind the
+    multi-rank line).  A thread calls on_fail(reason) -- which is expected not to return: print what there is, os._exit -- when
+    the block has not finished after `timeout` seconds, or when SIGTERM arrives (the launcher's way of ending the other ranks
+    after one has died).  The signal is seen through the interpreter's wake-up descriptor, written by the C-level handler the
+    moment the signal arrives: a main thread that sits in a collective or a device synchronisation never gets to run a Python
+    handler.  Main thread only (signal.set_wakeup_fd)."""
+
+    def __init__(self, timeout, on_fail, what="the guarded block"):
+        self.timeout, self.on_fail, self.what = float(timeout), on_fail, what
+
+    def __enter__(self):
+        import signal
+        import threading
+        self._signal = signal
+        self._rp, self._wp = os.pipe()
+        os.set_blocking(self._wp, False)
+        self._old_fd = signal.set_wakeup_fd(self._wp, warn_on_full_buffer=False)
+        self._old_term = signal.signal(signal.SIGTERM, lambda signum, frame: None)      # (a Python-level handler puts the C-level one in place)
+        self._done = threading.Event()
+        self._thread = threading.Thread(target=self._watch, daemon=True)
+        self._thread.start()
+        return self
+
+    def _watch(self):
+        import select
+        import time
+        deadline = time.monotonic() + self.timeout
+        while not self._done.is_set():
+            left = deadline - time.monotonic()
+            if left <= 0:
+                self.on_fail("%s did not finish within %d s" % (self.what, int(self.timeout)))
+                return
+            ready, _, _ = select.select([self._rp], [], [], min(left, 0.5))
+            if ready and not self._done.is_set():
+                got = os.read(self._rp, 64)
+                if bytes([self._signal.SIGTERM]) in got:
+                    self.on_fail("signal %d (another rank failed?) during %s" % (int(self._signal.SIGTERM), self.what))
+                    return
+
+    def __exit__(self, et, ev, tb):
+        self._done.set()
+        self._signal.set_wakeup_fd(self._old_fd)
+        self._signal.signal(self._signal.SIGTERM, self._old_term)
+        self._thread.join(timeout=2.0)
+        os.close(self._rp)
+        os.close(self._wp)
+        return False
+
+
 def shard_range(nframes, world, rank):
     """Contiguous frame range [lo, hi) of `rank`; earlier ranks take the remainder."""
     base, rem = divmod(nframes, world)

@@ -34,6 +34,24 @@ def test_multi_rank_line_checks_every_rank(gather):
         assert "encode_only" not in line
 
 
+@pytest.mark.parametrize("fault", ["raise", "hang"])
+def test_the_main_line_is_printed_when_the_side_figures_fail(fault):
+    """the multi-rank rccl line measures the encode-only and hostshm figures behind the main measurement: an exception there, or a
+    hang (another rank gone, a collective that never completes), must not cost the finished, verified main line -- rank 0 prints it
+    with the reason and exits 1 (flac_amd.dist.Watchdog)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29650 + os.getpid() % 300), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", FLACGPU_BENCH_SIDE_FAULT=fault)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--frames", "512", "--steps", "4", "--warmup", "1", "--window", "2",
+                        "--no-cpu-baseline", "--no-extras", "--side-timeout", "8"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["n_gpus"] == 1 and line["verified"]["ok"] and line["verified"]["ranks_checked"] == 1
+    why = line["side_figures"]["error"]
+    assert ("injected fault" in why) if fault == "raise" else ("did not finish within 8 s" in why), why
+    assert "encode_only" not in line
+
+
 def _run_bench(argv, env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=600)
     return r

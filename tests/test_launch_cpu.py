@@ -110,3 +110,52 @@ def test_forced_launch_of_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
+
+
+WATCHDOG_SCRIPT = r"""
+import os, sys, threading, time, json
+sys.path.insert(0, %r)
+from flac_amd.dist import Watchdog
+mode = sys.argv[1]
+def bail(why):
+    os.write(1, (json.dumps({"value": 123.0, "side_figures": {"error": why}}) + "\n").encode())
+    os._exit(1)
+with Watchdog(1.5 if mode == "timeout" else 30, bail, "the side figures"):
+    if mode == "ok":
+        time.sleep(0.2)
+    elif mode == "timeout":
+        lock = threading.Lock(); lock.acquire(); lock.acquire()          # a main thread that never comes back
+    elif mode == "sigterm":
+        os.write(1, b"READY\n")
+        lock = threading.Lock(); lock.acquire(); lock.acquire()
+if mode == "ok":
+    import signal
+    assert signal.getsignal(signal.SIGTERM) == signal.SIG_DFL
+    print(json.dumps({"value": 123.0, "side": "measured"}))
+"""
+
+
+@pytest.mark.parametrize("mode", ["ok", "timeout", "sigterm"])
+def test_the_main_line_survives_side_figures_that_hang_or_a_rank_that_dies(mode, tmp_path):
+    """bench.py, multi-rank: the encode-only / hostshm figures are measured behind the main line's measurement.  If they hang, or
+    another rank dies and the launcher sends SIGTERM, rank 0 -- possibly sitting in a collective that never returns, where no
+    Python signal handler runs -- must still print the main line (flac_amd.dist.Watchdog: a thread on the interpreter's wake-up
+    descriptor) and exit non-zero."""
+    import signal
+    import time
+    script = tmp_path / "w.py"
+    script.write_text(WATCHDOG_SCRIPT % ROOT)
+    p = subprocess.Popen([sys.executable, str(script), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=_clean_env())
+    if mode == "sigterm":
+        assert p.stdout.readline().strip() == b"READY"
+        time.sleep(0.3)
+        p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    lines = [json.loads(l) for l in out.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["value"] == 123.0, (out, err)
+    if mode == "ok":
+        assert p.returncode == 0 and lines[0]["side"] == "measured"
+    else:
+        assert p.returncode == 1
+        why = lines[0]["side_figures"]["error"]
+        assert ("did not finish within 1 s" in why) if mode == "timeout" else ("signal 15" in why), why
