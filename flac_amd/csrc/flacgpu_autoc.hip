@@ -685,10 +685,11 @@ static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const int32_
 	const int sets = tune().autoc3_sets;
 	if(!autoc3_ms(P)) {
 		// independent subframes from their planes.  A wavefront per job fills the chip better when the subframes are few (six short
-		// wavefronts per group at -8) -- until the jobs stop fitting one per SIMD: they are dispatched longest first and a SIMD that gets
-		// the whole-block job AND a half carries 1.5 sweeps of the block where a third of the SIMDs carry a third (mono, 16384 frames:
-		// 0.316 ms, the time of 1.5 sweeps).  A wavefront per SET (whole | halves | thirds: one sweep each, equal lengths) fits one per
-		// SIMD up to 341 groups: one sweep.
+		// wavefronts per group at -8).  Where the jobs no longer fit one per SIMD but the SETS (whole | halves | thirds: one sweep of the
+		// block each, equal lengths) still do -- 171..341 groups -- a wavefront per set, with the whole register file to itself (launch
+		// bounds 1: no spills, and the dispatcher cannot put two on one SIMD): mono's 16384 frames 0.320 -> 0.304 ms
+		// (profiles/r05_o_chan_rate_ind_sets_ab.txt).  The floor of either shape is one wavefront's sweep of the block ALONE on a SIMD,
+		// 0.27-0.30 ms (two per SIMD hide each other's LDS and conversion latencies: 0.21 ms per sweep in the stereo flavour).
 		const int isets = tune().autoc3_ind_sets;
 		const uint32_t simds = 1024;
 		const bool by_sets = nsets >= 2 && nsets <= 8 && (isets == 1 || (isets == 2 && njobs * ngroups > simds && nsets * ngroups <= simds));
