@@ -382,3 +382,21 @@ def test_blocks_longer_than_16384(ref, blocksize):
         r = po.ref_encode(pcm, bps, 44100, level, blocksize=blocksize, streamable_subset=0, **kw)
         o = po.oracle_encode(pcm, bps, 44100, level, blocksize=blocksize, **kw)
         assert o["data"] == _frames(r), (blocksize, fam, ch, bps, level)
+
+
+@pytest.mark.parametrize("ch", range(1, 9))
+def test_every_channel_count(ref, ch):
+    """1..8 channels (the frame header's channel assignment 0..7, stream_encoder_framing.c:245-391; the seeded sweeps draw from
+    1, 2, 3, 6, 8): independent channels whatever the preset asks of stereo, limit_min_bitrate's last-channel rule
+    (stream_encoder.c:3874-3879) with every other channel constant, 16- and 24-bit, a short last block"""
+    for bps, rate in ((16, 48000), (24, 96000)):
+        base = signals.music(4096 * 2 + 333, ch, bps, seed=10 * ch + bps)
+        flat = base.copy()
+        flat[:, :] = 5
+        flat[:, -1] = base[:, -1] if ch > 1 else 5
+        one_const = base.copy()
+        one_const[:, ch // 2] = -7
+        for level, pcm, kw in ((8, base, {}), (5, base, {}), (0, base, dict(blocksize=4096)), (8, flat, dict(limit_min_bitrate=1)),
+                               (5, one_const, dict(limit_min_bitrate=1)), (8, np.zeros_like(base), dict(limit_min_bitrate=1))):
+            r = po.ref_encode(pcm, bps, rate, level, **kw)
+            assert po.oracle_encode(pcm, bps, rate, level, **kw)["data"] == _frames(r), (ch, bps, level, kw)
