@@ -111,12 +111,21 @@ def adversarial_signal(rng, n, ch, bps):
     return np.stack(cols, axis=1).astype(np.int32)
 
 
-def adversarial_case(seed):
+def adversarial_case(seed, any_channel_count=False):
+    """any_channel_count: the channel count drawn from 1..8 instead of the sweep's 1, 2, 3, 6, 8 (a separate seed space: the cases of
+    the soaks on record stay what they were)"""
     import flac_amd
     from test_gpu_parity import _random_config
-    rng = np.random.default_rng(770000 + seed)
+    rng = np.random.default_rng((990000 if any_channel_count else 770000) + seed)
     while True:
         _, n, ch, bps, rate, kw = _random_config(rng)
+        if any_channel_count:
+            ch = int(rng.integers(1, 9))
+            kw.pop("mid_side", None)
+            kw.pop("loose_mid_side", None)
+            if ch == 2:
+                kw["mid_side"] = int(rng.integers(0, 2))
+                kw["loose_mid_side"] = int(rng.integers(0, 2)) if kw["mid_side"] else 0
         n = min(n, 3 * 4608 + 100)                  # (keeps the blocks longer than that to little more than one)
         n = max(n, 1)
         pcm = adversarial_signal(rng, n, ch, bps)
@@ -140,12 +149,13 @@ def ref_kwargs(kw):
     return rkw
 
 
+@pytest.mark.parametrize("any_channel_count", [False, True], ids=["the sweep's channel counts", "1..8 channels"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FLACGPU_ADV_SEEDS", "24"))))
-def test_adversarial_signals_oracle_vs_reference(seed):
+def test_adversarial_signals_oracle_vs_reference(seed, any_channel_count):
     from oracle_from_settings import oracle_encode_settings
     done = 0
     for sub in range(8):
-        pcm, ch, bps, rate, kw, s = adversarial_case(seed * 8 + sub)
+        pcm, ch, bps, rate, kw, s = adversarial_case(seed * 8 + sub, any_channel_count)
         try:
             r = po.ref_encode(pcm, bps, rate, 5, **ref_kwargs(kw))
         except RuntimeError:

@@ -42,3 +42,25 @@ def test_every_channel_count_gpu_vs_oracle(ch, forced, monkeypatch):
             assert v.status == 0, ("verify", ch, bps, level, kw, v.status, v.frame_number, v.channel, v.sample)
             o = po.oracle_encode(pcm, bps, rate, level, **okw)
             assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (ch, bps, level, kw, sorted(kernels))
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_adversarial_signals_with_any_channel_count_gpu_vs_oracle(seed, monkeypatch):
+    """the adversarial cases of tests/test_adversarial_cpu.py with the channel count drawn from 1..8 (there: oracle == reference on
+    40 000 such cases); like the test above, not yet run on hardware when committed"""
+    import flac_amd
+    from oracle_from_settings import oracle_encode_settings
+    from test_adversarial_cpu import adversarial_case
+    monkeypatch.setenv("FLACGPU_POISON", "1")
+    for sub in range(8):
+        pcm, ch, bps, rate, kw, s = adversarial_case(seed * 8 + sub, True)
+        eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=8)
+        try:
+            eng.set_verify(True)
+            data, fb = eng.encode(pcm)
+            v = eng.last_verify_result()
+            assert v.status == 0, ("verify", v.status, v.frame_number, v.channel, v.sample, seed, sub, ch, bps, rate, kw)
+        finally:
+            eng.close()
+        o = oracle_encode_settings(pcm, s)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (seed, sub, ch, bps, rate, kw)
