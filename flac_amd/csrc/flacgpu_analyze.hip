@@ -1338,12 +1338,13 @@ template <int MAXORD>
 static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint32_t nframes, uint32_t tail_n, const JobTable *jtm, const JobTable *jtt,
                                     const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
 {
-	static bool attr_set[64];
-	if(first_on_device(attr_set)) {
+	static AttrFlags attr_set;
+	if(AttrOnce once{attr_set}) {
 		hipError_t e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)eval_kernel<MAXORD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)eval_list_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
+		if(e != hipSuccess) return e;
+		once.ok();
 	}
 	if(P.max_analyses) {
 		note_launch(K_MODEL);
@@ -1429,10 +1430,11 @@ void sync_debug(const char *what, hipStream_t s)
 hipError_t launch_analyze(const DevParams &P, const int32_t *pcm, const float *win, const float *tailwin, uint32_t nframes, uint32_t tail_n,
                           const JobTable *jtm, const JobTable *jtt, uint32_t nsets_main, const AnalyzeBuffers &B, SubDecision *dec, hipEvent_t *pev, hipStream_t s)
 {
-	static bool attr_set[64];
-	if(first_on_device(attr_set)) {
+	static AttrFlags attr_set;
+	if(AttrOnce once{attr_set}) {
 		hipError_t e = hipFuncSetAttribute((const void *)prep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
+		if(e != hipSuccess) return e;
+		once.ok();
 	}
 	{
 		// frames of nominal length: one workgroup per frame (flacgpu_prep.hip); the short last block, and block sizes that

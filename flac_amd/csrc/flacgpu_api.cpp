@@ -125,6 +125,7 @@ Tune &tune()
 	static thread_local Tune dflt = read_tune(0);
 	return dflt;
 }
+std::mutex &attr_mutex() { static std::mutex m; return m; }
 // an entry point of a context runs under its switches
 struct TuneScope { Tune *prev; explicit TuneScope(Tune *t) : prev(g_tune) { g_tune = t; } ~TuneScope() { g_tune = prev; } };
 

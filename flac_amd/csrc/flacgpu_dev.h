@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include "flacgpu.h"
 
 namespace flacgpu {
@@ -158,8 +160,24 @@ struct Tune {
 };
 Tune &tune();
 inline void note_launch(uint32_t k) { tune().launched |= k; }
-// true exactly once per (call site's flag array, device): the hipFuncSetAttribute calls of a launch function
-inline bool first_on_device(bool (&done)[64]) { const int d = tune().device & 63; if(done[d]) return false; done[d] = true; return true; }
+// The hipFuncSetAttribute calls of a launch function, once per (call site, device) and safe against a second thread with another
+// context on the same device (the flag used to be set before the attributes were): `if(AttrOnce once{flags}) { ...set the
+// attributes, return on error...; once.ok(); }` -- the first thread runs the block holding the lock, the others wait for it; the flag
+// is set by ok() only, so a failed attempt is retried by the next launch.
+struct AttrFlags { std::atomic<bool> done[64]; };
+std::mutex &attr_mutex();
+struct AttrOnce {
+	AttrFlags &f; int d; bool first; std::unique_lock<std::mutex> lk;
+	explicit AttrOnce(AttrFlags &flags) : f(flags), d(tune().device & 63), first(false)
+	{
+		if(f.done[d].load(std::memory_order_acquire)) return;
+		lk = std::unique_lock<std::mutex>(attr_mutex());
+		first = !f.done[d].load(std::memory_order_relaxed);
+		if(!first) lk.unlock();
+	}
+	explicit operator bool() const { return first; }
+	void ok() { f.done[d].store(true, std::memory_order_release); }
+};
 
 void sync_debug(const char *what, hipStream_t s);
 size_t analyze_lds_bytes(const DevParams &P);

@@ -322,8 +322,9 @@ template <int MAXORD, int WPC>
 static hipError_t launch_evalg_t(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
 {
 	const uint32_t lds = evalg_lds_bytes<MAXORD>(P.blocksize, WPC);
-	static bool set[64];
-	if(first_on_device(set)) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<MAXORD, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) { set[tune().device & 63] = false; return e; } }
+	static AttrFlags set;
+	if(AttrOnce once{set}) { const hipError_t e = hipFuncSetAttribute((const void *)evalg_kernel<MAXORD, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); if(e != hipSuccess) return e;
+		once.ok(); }
 	note_launch(K_EVALG);
 	hipLaunchKernelGGL((evalg_kernel<MAXORD, WPC>), dim3(nframes * P.ncand), dim3(64 * WPC), lds, s, P, B.chan, nframes, tail_n, jt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
 	return hipGetLastError();

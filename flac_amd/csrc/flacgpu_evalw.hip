@@ -365,12 +365,13 @@ template <int MAXORD>
 static hipError_t launch_evalw_t(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec,
                                  const uint32_t *in_list, const uint32_t *in_count, uint32_t *out_list, uint32_t *out_count, hipStream_t s)
 {
-	static bool set[64];
-	if(first_on_device(set)) {
+	static AttrFlags set;
+	if(AttrOnce once{set}) {
 		hipError_t e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)evalw_kernel<MAXORD, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-		if(e != hipSuccess) { set[tune().device & 63] = false; return e; }
+		if(e != hipSuccess) return e;
+		once.ok();
 	}
 	note_launch(K_EVALW);
 	const uint32_t nchan = nframes * P.ncand;

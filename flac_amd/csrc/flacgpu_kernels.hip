@@ -2239,8 +2239,8 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
                                 const SubDecision *dec, uint8_t *plan, uint8_t *slots, uint32_t *fb, FrameInfo *info, unsigned long long *dbg, size_t lds, const PackOutArgs *po, bool *fused_out,
                                 uint32_t *hints, uint32_t *hinted_frames, hipStream_t s)
 {
-	static bool attr_set[64];
-	if(first_on_device(attr_set)) {
+	static AttrFlags attr_set;
+	if(AttrOnce once{attr_set}) {
 		hipError_t e = hipFuncSetAttribute((const void *)pack_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		if constexpr(MAXORD <= 16) {
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
@@ -2249,7 +2249,8 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, true, TPB / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, 64, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		}
-		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
+		if(e != hipSuccess) return e;
+		once.ok();
 	}
 	uint32_t f_lo = 0;
 	bool fused = false;

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 		A.diff = wave_or_u32(A.diff);
 		if(c == 3) A.mag = wave_or_u32(A.mag);
 #pragma unroll
-		for(int k = 0; k < 5; k++) A.e[k] = WIDE ? wave_sum_u50(A.e[k]) : (uint64_t)wave_sum_u32((uint32_t)A.e[k]);   // !WIDE: 2^30 at most
+		for(int k = 0; k < 5; k++) A.e[k] = WIDE ? wave_sum_u50(A.e[k]) : (uint64_t)wave_sum_u32((uint32_t)A.e[k]);   // !WIDE (bps <= 17, launch_prep2): 2^31 at most
 		if(lane == 0) {
 			Prep3Part &pt = part[wave];
 			pt.orv[c] = A.orv; pt.diff[c] = A.diff; pt.first[c] = first;
@@ -786,41 +786,47 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 		if(prep2_decides(P)) (void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
 		return hipSuccess;
 	}
-	static bool attr_set[64];
-	if(first_on_device(attr_set)) {
+	static AttrFlags attr_set;
+	if(AttrOnce once{attr_set}) {
 		hipError_t e = hipSuccess;
 #define P2ATTR(W, NF, DZ) if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep2_kernel<W, NF, DZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)
 		P2ATTR(false, 0, false); P2ATTR(false, 1152, false); P2ATTR(false, 4096, false); P2ATTR(true, 0, false); P2ATTR(true, 1152, false); P2ATTR(true, 4096, false);
 		P2ATTR(false, 0, true); P2ATTR(false, 1152, true);
 #undef P2ATTR
-		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
+		if(e != hipSuccess) return e;
+		once.ok();
 	}
 	if(prep4_applicable(P) && !tune().no_fast1 && !tune().no_prep4 && !prep2_decides(P)) {
-		static bool attr4[64];
-		if(first_on_device(attr4)) {
+		static AttrFlags attr4;
+		if(AttrOnce once{attr4}) {
 			// (at most four channels' tiles at a time: 68 KB; the kernel's static LDS -- the four partial records -- is 1.7 KB)
 			hipError_t e = hipFuncSetAttribute((const void *)prep4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-			if(e != hipSuccess) { attr4[tune().device & 63] = false; return e; }
+			if(e != hipSuccess) return e;
+		once.ok();
 		}
 		note_launch(K_PREP1);
 		// channels per round: all of them up to four, else the rounds as even as they come (5, 6 -> 3; 7, 8 -> 4)
 		const uint32_t C = P.channels, G = C <= 4 ? C : (C + 1) / 2;
 		const size_t lds4 = 4 * (size_t)G * p2_chan_bytes(P.blocksize / 4);
-		if(P.bps > 20) hipLaunchKernelGGL(prep4_kernel<true>, dim3(nmain), dim3(TPB), lds4, s, P, pcm, nmain, G, B.prep, B.cands, B.valid, B.chan);
+		// (the wavefront's sum of 1024 fourth differences: |d4| < 2^(bps+3), so 32 bits hold it up to 18-bit samples only -- ADVICE r05: at
+		//  20 bits a Nyquist alternation at half of full scale wrapped e[4] and fixed order 4 was guessed instead of 0)
+		if(P.bps > 18) hipLaunchKernelGGL(prep4_kernel<true>, dim3(nmain), dim3(TPB), lds4, s, P, pcm, nmain, G, B.prep, B.cands, B.valid, B.chan);
 		else hipLaunchKernelGGL(prep4_kernel<false>, dim3(nmain), dim3(TPB), lds4, s, P, pcm, nmain, G, B.prep, B.cands, B.valid, B.chan);
 		return hipGetLastError();
 	}
 	if(prep3_applicable(P) && !tune().no_prep3) {
-		static bool attr3[64];
-		if(first_on_device(attr3)) {
+		static AttrFlags attr3;
+		if(AttrOnce once{attr3}) {
 			hipError_t e = hipFuncSetAttribute((const void *)prep3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-			if(e != hipSuccess) { attr3[tune().device & 63] = false; return e; }
+			if(e != hipSuccess) return e;
+		once.ok();
 		}
 		note_launch(K_PREP3);
 		const size_t lds3 = 8 * (size_t)p2_chan_bytes(P.blocksize / 4);
-		if(P.bps > 20) hipLaunchKernelGGL(prep3_kernel<true>, dim3(nmain), dim3(TPB), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
+		// (the side channel has bps + 1 bits: its quarter's sum of fourth differences is below 2^(bps+14), 32 bits up to 17-bit input)
+		if(P.bps > 17) hipLaunchKernelGGL(prep3_kernel<true>, dim3(nmain), dim3(TPB), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
 		else hipLaunchKernelGGL(prep3_kernel<false>, dim3(nmain), dim3(TPB), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
 		return hipGetLastError();
 	}

@@ -366,10 +366,10 @@ template <int MAXORD>
 static hipError_t launch_hinted_t(const DevParams &P, const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, uint32_t nhinted, uint64_t first,
                                   const int32_t *pcm, const uint32_t *hints, uint32_t *fstat, VerifyState *state, unsigned long long *dbg, hipStream_t s)
 {
-	static bool attr_set[64];
+	static AttrFlags attr_set;
 	static uint32_t ahead_of[64];
 	uint32_t &ahead = ahead_of[tune().device & 63];
-	if(first_on_device(attr_set)) {
+	if(AttrOnce once{attr_set}) {
 		// workgroups resident at a time = the distance to the one that takes this one's place
 		int per_cu = 0, cus = 256;
 		hipDeviceProp_t prop;
@@ -379,7 +379,8 @@ static hipError_t launch_hinted_t(const DevParams &P, const uint8_t *frames, con
 		const char *e2 = getenv("FLACGPU_VERIFY_PREFETCH");
 		ahead = e2 ? (uint32_t)atoi(e2) : (uint32_t)(per_cu * cus);
 		const hipError_t e = hipFuncSetAttribute((const void *)verify_hinted_kernel<MAXORD>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		if(e != hipSuccess) { attr_set[tune().device & 63] = false; return e; }
+		if(e != hipSuccess) return e;
+		once.ok();
 	}
 	hipLaunchKernelGGL((verify_hinted_kernel<MAXORD>), dim3(nframes), dim3(TPB), hinted_lds_bytes(P), s, P, frames, fb, offsets, nframes, nhinted, first, pcm, hints, fstat, state, dbg, ahead);
 	if(dbg) {

@@ -164,3 +164,43 @@ def test_adversarial_signals_oracle_vs_reference(seed, any_channel_count):
         assert o["data"] == r["data"][r["header_bytes"]:], (seed, sub, ch, bps, rate, kw)
         done += 1
     assert done >= 4
+
+
+def edge_sum_cases():
+    """the fixed-predictor error sums of a quarter block at the edge of 32 bits -- a Nyquist alternation of +-A (|d4| = 16 A)
+    at 17..24 bits with A around the amplitude where 1024 fourth differences reach 2^32 (0.5 of full scale at 20 bits, a quarter at
+    21, ...), mono / stereo with and without mid/side / three and five channels, blocks of 4096 (fixed.c:222-424: the reference sums
+    in 64 bits from 28 - ilog2(n) bits up).  Yields (name, pcm, channels, bps, kwargs for make_settings)."""
+    n = 4096 * 3
+    sign = np.where(np.arange(n) % 2 == 0, 1, -1).astype(np.int64)
+    for bps in (17, 18, 19, 20, 21, 22, 24):
+        fs = 1 << (bps - 1)
+        wrap = (1 << 32) / (1024.0 * 16.0)                       # the amplitude at which a quarter's sum of |d4| is 2^32
+        for mult in (0.97, 1.0, 1.03, 1.06, 2.02, 0.51):
+            a = int(min(fs - 1, round(wrap * mult)))
+            if a < 1:
+                continue
+            for ch, ms in ((1, 0), (2, 0), (2, 1), (3, 0), (5, 0)):
+                cols = []
+                for c in range(ch):
+                    x = sign * a if c % 2 == 0 else -sign * (a - c)   # (the side channel of an anti-phase pair has twice the amplitude)
+                    cols.append(x)
+                pcm = np.stack(cols, axis=1).astype(np.int32)
+                kw = dict(blocksize=4096, streamable_subset=0)
+                if ch == 2:
+                    kw.update(mid_side=ms, loose_mid_side=0)
+                yield "bps%d a%d ch%d ms%d" % (bps, a, ch, ms), pcm, ch, bps, kw
+
+
+def test_fixed_sums_at_the_32_bit_edge_oracle_vs_reference():
+    import flac_amd
+    from oracle_from_settings import oracle_encode_settings
+    for name, pcm, ch, bps, kw in edge_sum_cases():
+        for level in (2, 5):
+            s = flac_amd.make_settings(ch, bps, 48000, level, **kw)
+            rkw = dict(blocksize=4096, streamable_subset=0)
+            if ch == 2:
+                rkw.update(mid_side=kw["mid_side"], loose_mid_side=0)
+            r = po.ref_encode(pcm, bps, 48000, level, **rkw)
+            o = oracle_encode_settings(pcm, s)
+            assert o["data"] == r["data"][r["header_bytes"]:], (name, level)
