@@ -253,7 +253,7 @@ struct StageParams {
 hipError_t launch_stage_raw(const StageParams &S, const void *d_raw, uint64_t nvalues, int32_t *d_pcm, uint32_t *d_err, hipStream_t s);
 // the self check (flacgpu_verify.hip, crc_check_kernel in flacgpu_kernels.hip)
 struct VerifyState { uint32_t first_bad; uint32_t hinted_ok; uint32_t pad[2]; };      // index of the first frame of the batch that failed (0xffffffff: none); frames the hinted pass verified
-hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s);
+hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s, uint8_t *per_frame_bad = nullptr);
 bool verify_hinted_covers(const DevParams &P);        // this configuration's frames can go through the thread-per-run verify pass
 size_t verify_decoded_bytes(const DevParams &P, uint32_t max_frames);     // the lane-interleaved buffer of decoded coded-channel samples
 // hints / nhinted: the pack kernel's run starts for the first nhinted frames (null / 0: none) -- those frames go through the

@@ -2148,15 +2148,19 @@ __device__ inline uint32_t gf16_xpow(uint64_t e)
 	while(e) { if(e & 1) r = gf16_mul(r, b); b = gf16_mul(b, b); e >>= 1; }
 	return r;
 }
+// per_frame_bad != null (the stream decoder, flacgpu_stream_decode.hip): frames of length 0xffffffff are none of this kernel's business,
+// and a footer that does not match sets per_frame_bad[f] instead of the batch's first bad frame
 __global__ __launch_bounds__(TPB) void crc_check_kernel(const uint8_t *__restrict__ frames, const uint32_t *__restrict__ frame_bytes,
-                                                        const uint64_t *__restrict__ offsets, uint32_t nframes, VerifyState *__restrict__ state)
+                                                        const uint64_t *__restrict__ offsets, uint32_t nframes, VerifyState *__restrict__ state,
+                                                        uint8_t *__restrict__ per_frame_bad)
 {
 	__shared__ uint16_t tab[4][256];
 	__shared__ uint32_t parts[TPB / 64];
 	const uint32_t f = blockIdx.x;
 	const int tid = (int)threadIdx.x;
 	const uint32_t len = frame_bytes[f];
-	if(len == 0xffffffffu || len < 3) { if(tid == 0) atomicMin(&state->first_bad, f); return; }          // (the same for every thread)
+	if(per_frame_bad && len == 0xffffffffu) return;
+	if(len == 0xffffffffu || len < 3) { if(tid == 0) { if(per_frame_bad) per_frame_bad[f] = 1; else atomicMin(&state->first_bad, f); } return; }          // (the same for every thread)
 	for(uint32_t w = (uint32_t)tid; w < 4 * 256 / 2; w += TPB) ((uint32_t *)tab)[w] = ((const uint32_t *)g_crc_tables.tab)[w];
 	__syncthreads();
 	const uint8_t *p = frames + offsets[f];
@@ -2206,7 +2210,7 @@ __global__ __launch_bounds__(TPB) void crc_check_kernel(const uint8_t *__restric
 		uint32_t crc = 0;
 		for(int w = 0; w < TPB / 64; w++) crc ^= parts[w];
 		crc = gf16_mul(crc & 0xffffu, g_crc_tables.xbyte[last_len]) ^ (crc >> 16);
-		if(crc != (((uint32_t)p[body] << 8) | p[body + 1])) atomicMin(&state->first_bad, f);
+		if(crc != (((uint32_t)p[body] << 8) | p[body + 1])) { if(per_frame_bad) per_frame_bad[f] = 1; else atomicMin(&state->first_bad, f); }
 	}
 }
 
@@ -2355,9 +2359,9 @@ hipError_t launch_append_tail(const uint8_t *slot, const uint32_t *fb, uint32_t 
 	hipLaunchKernelGGL(append_tail_kernel, dim3(1), dim3(TPB), 0, s, slot, fb, f, make_pack_out(po));
 	return hipGetLastError();
 }
-hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s)
+hipError_t launch_crc_check(const uint8_t *frames, const uint32_t *fb, const uint64_t *offsets, uint32_t nframes, VerifyState *state, hipStream_t s, uint8_t *per_frame_bad)
 {
-	hipLaunchKernelGGL(crc_check_kernel, dim3(nframes), dim3(TPB), 0, s, frames, fb, offsets, nframes, state);
+	hipLaunchKernelGGL(crc_check_kernel, dim3(nframes), dim3(TPB), 0, s, frames, fb, offsets, nframes, state, per_frame_bad);
 	return hipGetLastError();
 }
 hipError_t launch_scan(const uint32_t *fb, uint32_t nframes, uint64_t *offsets, uint64_t *total, hipStream_t s)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FLACGPU_ABI_VERSION 4
+#define FLACGPU_ABI_VERSION 5
 #define FLACGPU_MAX_CHANNELS 8
 #define FLACGPU_MAX_APODIZATIONS 32     /* FLAC__MAX_APODIZATION_FUNCTIONS */
 
@@ -187,6 +187,69 @@ int flacgpu_verify_batch_device(flacgpu_ctx *ctx, const uint8_t *d_frames, const
  * call returns; flacgpu_last_verify_result gives the verdict of the most recent batch (status 0 when verification is off). */
 int flacgpu_set_verify(flacgpu_ctx *ctx, uint32_t on);
 int flacgpu_last_verify_result(flacgpu_ctx *ctx, flacgpu_verify_result *out);
+
+/* ---- decoding streams the engine did NOT write (`flac -t`, `flac -d`): what the reference's
+ * FLAC__stream_decoder_process_until_end_of_stream (src/libFLAC/stream_decoder.c:1168) hands its client for a stream -- every
+ * sample of every write callback, every error callback in order -- for a byte range in DEVICE memory, PCM left in DEVICE memory.
+ * Frames are found by their sync codes (frame_sync_ :2321), headers checked with their CRC-8 (read_frame_header_ :2624), bodies
+ * decoded one lane per frame (read_subframe_* :2949-3360, lpc.c:978-1578, fixed.c:571-667), CRC-16 and sample bounds checked
+ * (read_frame_ :2373-2483), frames that are missing made up for with silence as the reference does (:2485-2554).  Any bytes are
+ * legal input; a damaged stream yields the reference's errors (one documented exception: FLACGPU_DECODE long_rice_codes).
+ * No FLAC__stream_decoder_* layer on top (out of scope) -- metadata is the caller's (flacgpu_probe_stream). ---- */
+typedef struct {
+	uint32_t has_streaminfo;         /* 0: the fields below are unknown (frames must then carry rate and sample size themselves) */
+	uint32_t min_blocksize, max_blocksize, sample_rate, channels, bits_per_sample;
+} flacgpu_stream_info;
+
+/* error callbacks, as FLAC__StreamDecoderErrorStatus + 1 (include/FLAC/stream_decoder.h:277-310) */
+enum {
+	FLACGPU_DECODE_LOST_SYNC = 1, FLACGPU_DECODE_BAD_HEADER = 2, FLACGPU_DECODE_FRAME_CRC_MISMATCH = 3, FLACGPU_DECODE_UNPARSEABLE_STREAM = 4,
+	FLACGPU_DECODE_BAD_METADATA = 5, FLACGPU_DECODE_OUT_OF_BOUNDS = 6, FLACGPU_DECODE_MISSING_FRAME = 7
+};
+typedef struct {
+	uint32_t status;                 /* FLACGPU_DECODE_* */
+	uint32_t pad;
+	uint64_t byte_offset;            /* the sync code the error belongs to, or where the search that skipped bytes began */
+} flacgpu_decode_event;
+
+typedef struct {
+	uint64_t samples;                /* inter-channel samples the client receives (= written to d_pcm), silence included */
+	uint64_t frames;                 /* frames decoded into them */
+	uint64_t silence_samples;        /* of `samples`: stand-ins for missing frames */
+	uint64_t candidates;             /* sync codes looked at */
+	uint64_t redecoded_frames;       /* frames decoded a second time, into a place other than the one their number implies (0 for a whole stream) */
+	uint32_t nevents;                /* error callbacks; the first max_events of them are in `events` */
+	uint32_t end_in_header;          /* the stream ended inside a frame header: the reference's process call returns false */
+	uint32_t format_changes;         /* good frames whose channel count / sample size is not the stream's: reported, not written */
+	uint32_t long_rice_codes;        /* frames given up for a Rice code whose unary part exceeds what a 32-bit residual allows.  The
+	                                    reference applies this limit only to codes that do not straddle a refill of its 8 KiB read
+	                                    buffer (bitreader_read_rice_signed_block.c); this decoder always.  Non-zero: the error list may
+	                                    differ from the reference's for those frames. */
+	uint32_t channels, bits_per_sample, sample_rate;   /* the stream's format: STREAMINFO, else the first good frame */
+	uint32_t errors_by_status[8];    /* count per FLACGPU_DECODE_* */
+	float ms_scan, ms_decode, ms_place, ms_total;       /* HIP-event times: sync scan; decode + CRC + finish; re-decodes + silence; all */
+} flacgpu_decode_result;
+
+typedef struct flacgpu_decoder flacgpu_decoder;
+int flacgpu_decoder_create(int device, flacgpu_decoder **out);    /* scratch buffers grow with use and are kept between calls */
+void flacgpu_decoder_destroy(flacgpu_decoder *dec);
+
+/* HOST: where the audio frames of a FLAC file begin and what its STREAMINFO says, from the file's first bytes (ID3v2 tags in front
+ * are stepped over; a stream that does not start with "fLaC" is taken as bare frames from byte 0).  total_samples, md5 (16 bytes) may
+ * be NULL.  FLACGPU_ERR_INPUT: the metadata runs past nbytes. */
+int flacgpu_probe_stream(const uint8_t *head, size_t nbytes, flacgpu_stream_info *si, uint64_t *first_frame_offset, uint64_t *total_samples, uint8_t *md5);
+
+/* Decode d_stream[first_frame_offset .. nbytes) (DEVICE memory; d_stream 4-byte aligned, its allocation extending to the next multiple
+ * of 4 bytes) into d_pcm (DEVICE, interleaved int32 [samples][channels], room for pcm_capacity_values int32 values -- the channel count is
+ * the stream's, which without STREAMINFO only the decode tells; NULL: verdict only).  si may be NULL.  events: host array [max_events] (may be NULL).  Synchronous.
+ * Returns 0, FLACGPU_ERR_OUTPUT_TOO_SMALL (result->samples x result->channels says what is needed; d_pcm's contents are then undefined) or another
+ * negative FLACGPU_ERR_*. */
+int flacgpu_decode_stream_device(flacgpu_decoder *dec, const uint8_t *d_stream, uint64_t nbytes, uint64_t first_frame_offset, const flacgpu_stream_info *si,
+                                 int32_t *d_pcm, uint64_t pcm_capacity_values, flacgpu_decode_result *result, flacgpu_decode_event *events, uint32_t max_events,
+                                 void *stream);
+/* int32 samples (DEVICE) -> the bytes a WAVE file and the MD5 of STREAMINFO hold: little endian, (bits_per_sample + 7) / 8 bytes each
+ * (what FLAC__MD5Accumulate is fed, src/libFLAC/md5.c:497; flacgpu_stage_raw_device's inverse).  Asynchronous on `stream`. */
+int flacgpu_pack_samples_device(int device, const int32_t *d_pcm, uint64_t nvalues, uint32_t bits_per_sample, uint8_t *d_out, void *stream);
 
 /* Diagnostics of the most recent batch: [nframes][channels] subframe choices and the channel
  * assignment per frame (0 independent, 1 left/side, 2 right/side, 3 mid/side). Host arrays. */

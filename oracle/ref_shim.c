@@ -159,3 +159,86 @@ int32_t ref_encode_file(const ref_cfg_t *cfg, const int32_t *pcm_interleaved, ui
 }
 
 const char *ref_vendor_string(void) { return FLAC__VENDOR_STRING; }
+
+/* ---- the reference's stream DECODER on a stream in memory (FLAC__stream_decoder_init_stream with every callback, so that the
+ * decoder can rewind after a damaged frame the way it does on a file, src/libFLAC/stream_decoder.c:2558-2587): what the client
+ * receives -- every sample of every write callback, every error callback in order -- for tests/test_stream_decode_*.py to hold the
+ * product's GPU stream decoder to.  Nothing here restates reference logic. ---- */
+#include "FLAC/stream_decoder.h"
+
+typedef struct {
+	const uint8_t *data; uint64_t len, pos;
+	int32_t *pcm; uint64_t cap, samples;         /* interleaved, inter-channel samples */
+	uint32_t channels, bps, rate;                /* of the first frame written */
+	uint32_t *ev; uint32_t max_ev, nev;
+	uint64_t frames, format_changes;
+	int overflow;
+} dec_capture_t;
+
+static FLAC__StreamDecoderReadStatus dec_read_cb(const FLAC__StreamDecoder *d, FLAC__byte buffer[], size_t *bytes, void *client)
+{
+	dec_capture_t *c = (dec_capture_t *)client; (void)d;
+	if(c->pos >= c->len) { *bytes = 0; return FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM; }
+	if(*bytes > c->len - c->pos) *bytes = (size_t)(c->len - c->pos);
+	memcpy(buffer, c->data + c->pos, *bytes);
+	c->pos += *bytes;
+	return FLAC__STREAM_DECODER_READ_STATUS_CONTINUE;
+}
+static FLAC__StreamDecoderSeekStatus dec_seek_cb(const FLAC__StreamDecoder *d, FLAC__uint64 off, void *client)
+{
+	dec_capture_t *c = (dec_capture_t *)client; (void)d;
+	if(off > c->len) return FLAC__STREAM_DECODER_SEEK_STATUS_ERROR;
+	c->pos = off; return FLAC__STREAM_DECODER_SEEK_STATUS_OK;
+}
+static FLAC__StreamDecoderTellStatus dec_tell_cb(const FLAC__StreamDecoder *d, FLAC__uint64 *off, void *client)
+{ (void)d; *off = ((dec_capture_t *)client)->pos; return FLAC__STREAM_DECODER_TELL_STATUS_OK; }
+static FLAC__StreamDecoderLengthStatus dec_length_cb(const FLAC__StreamDecoder *d, FLAC__uint64 *len, void *client)
+{ (void)d; *len = ((dec_capture_t *)client)->len; return FLAC__STREAM_DECODER_LENGTH_STATUS_OK; }
+static FLAC__bool dec_eof_cb(const FLAC__StreamDecoder *d, void *client)
+{ (void)d; return ((dec_capture_t *)client)->pos >= ((dec_capture_t *)client)->len; }
+static FLAC__StreamDecoderWriteStatus dec_write_cb(const FLAC__StreamDecoder *d, const FLAC__Frame *f, const FLAC__int32 *const buf[], void *client)
+{
+	dec_capture_t *c = (dec_capture_t *)client; (void)d;
+	if(c->channels == 0) { c->channels = f->header.channels; c->bps = f->header.bits_per_sample; c->rate = f->header.sample_rate; }
+	if(f->header.channels != c->channels || f->header.bits_per_sample != c->bps) { c->format_changes++; return FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE; }
+	if(c->samples + f->header.blocksize > c->cap) { c->overflow = 1; c->samples += f->header.blocksize; return FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE; }
+	for(uint32_t i = 0; i < f->header.blocksize; i++)
+		for(uint32_t ch = 0; ch < c->channels; ch++) c->pcm[(c->samples + i) * c->channels + ch] = buf[ch][i];
+	c->samples += f->header.blocksize;
+	c->frames++;
+	return FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE;
+}
+static void dec_meta_cb(const FLAC__StreamDecoder *d, const FLAC__StreamMetadata *m, void *client)
+{
+	dec_capture_t *c = (dec_capture_t *)client; (void)d;
+	if(m->type == FLAC__METADATA_TYPE_STREAMINFO) { c->channels = m->data.stream_info.channels; c->bps = m->data.stream_info.bits_per_sample; c->rate = m->data.stream_info.sample_rate; }
+}
+static void dec_error_cb(const FLAC__StreamDecoder *d, FLAC__StreamDecoderErrorStatus st, void *client)
+{
+	dec_capture_t *c = (dec_capture_t *)client; (void)d;
+	if(c->nev < c->max_ev) c->ev[c->nev] = (uint32_t)st + 1;
+	c->nev++;
+}
+
+/* result: samples, write callbacks taken, error callbacks, process_until_end_of_stream's return, finish's return (MD5), final state
+ * before finish, channels, bps, format changes, overflow */
+int ref_decode_stream(const uint8_t *stream, uint64_t nbytes, int md5_checking, int32_t *pcm, uint64_t cap_samples, uint32_t *ev_status, uint32_t max_events, uint64_t *result)
+{
+	dec_capture_t c;
+	memset(&c, 0, sizeof c);
+	c.data = stream; c.len = nbytes; c.pcm = pcm; c.cap = cap_samples; c.ev = ev_status; c.max_ev = max_events;
+	FLAC__StreamDecoder *d = FLAC__stream_decoder_new();
+	if(!d) return -1;
+	FLAC__stream_decoder_set_md5_checking(d, md5_checking ? true : false);
+	if(FLAC__stream_decoder_init_stream(d, dec_read_cb, dec_seek_cb, dec_tell_cb, dec_length_cb, dec_eof_cb, dec_write_cb, dec_meta_cb, dec_error_cb, &c) != FLAC__STREAM_DECODER_INIT_STATUS_OK) {
+		FLAC__stream_decoder_delete(d);
+		return -2;
+	}
+	const FLAC__bool ok = FLAC__stream_decoder_process_until_end_of_stream(d);
+	const uint32_t state = (uint32_t)FLAC__stream_decoder_get_state(d);
+	const FLAC__bool fin = FLAC__stream_decoder_finish(d);
+	FLAC__stream_decoder_delete(d);
+	result[0] = c.samples; result[1] = c.frames; result[2] = c.nev; result[3] = ok ? 1 : 0; result[4] = fin ? 1 : 0; result[5] = state;
+	result[6] = c.channels; result[7] = c.bps; result[8] = c.format_changes; result[9] = (uint64_t)c.overflow;
+	return 0;
+}

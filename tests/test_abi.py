@@ -73,7 +73,7 @@ def test_wider_searches_reach_the_engine_config():
     s = engine.make_settings(2, 16, 44100, 8, exhaustive=1, prec_search=1)
     cfg = engine.EngineConfig()
     assert engine.load_host().flacgpu_host_engine_config(C.byref(s), 0, 16, C.byref(cfg)) == 0
-    assert (cfg.abi_version, cfg.do_exhaustive_model_search, cfg.do_qlp_coeff_prec_search) == (4, 1, 1)
+    assert (cfg.abi_version, cfg.do_exhaustive_model_search, cfg.do_qlp_coeff_prec_search) == (5, 1, 1)
 
 
 def test_no_device_fails_loudly():

@@ -1,0 +1,135 @@
+"""-m gpu: the device stream decoder (flacgpu_decode_stream_device, flac_amd/csrc/flacgpu_stream_decode.hip) against the REFERENCE's
+decoder (oracle/_ref/libFLAC_ref.so: FLAC__stream_decoder_process_until_end_of_stream on the same bytes, oracle/ref_shim.c) on streams
+this engine did not write: files of the reference's own `flac` tool over presets, `-e -p -l 32 --lax`, block sizes 16..65535, 8..32 bits,
+1..8 channels -- samples and verdict must agree; on the same files damaged (flipped bits, false sync codes, cut, spliced, zeroed):
+the same error callbacks in the same order and the same samples, silence for missing frames included.  SURVEY.md 8f row 3
+(stream_decoder.c:2321 frame_sync_, :2373 read_frame_, :2624 read_frame_header_, :3299 read_residual_partitioned_rice_).
+Nothing here reads /root/reference: oracle/_ref travels to the GPU box prebuilt."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import signals
+import stream_decode_util as U
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not U.have_ref(), reason="oracle/_ref not built")]
+
+
+@pytest.fixture(scope="module")
+def dec():
+    import flac_amd
+    d = flac_amd.StreamDecoder(0)
+    yield d
+    d.close()
+
+
+def check(dec, stream, what, expect_pcm=None, allow_long_rice=True):
+    ref = U.ref_decode(stream)
+    got = dec.decode(stream)
+    v = U.same_verdict(ref, got)
+    if v and allow_long_rice and got["long_rice_codes"]:
+        return "skipped"
+    assert v is None, (what, v)
+    if expect_pcm is not None:
+        assert np.array_equal(got["pcm"], expect_pcm), what
+    return got
+
+
+CLEAN = [
+    (2, 16, 44100, ["-8"]), (2, 16, 44100, ["-5"]), (2, 16, 44100, ["-0"]), (2, 16, 44100, ["-2"]), (2, 16, 44100, ["-3"]),
+    (1, 16, 44100, ["-5"]), (2, 24, 96000, ["-8"]), (2, 8, 8000, ["-4"]), (2, 32, 48000, ["-5"]), (2, 32, 48000, ["-8", "-e"]),
+    (6, 16, 48000, ["-6"]), (8, 24, 48000, ["-5"]), (3, 16, 44100, ["-7"]), (5, 16, 44100, ["-1"]), (7, 16, 44100, ["-5"]), (4, 24, 44100, ["-8"]),
+    (2, 16, 44100, ["-8", "-e", "-p"]), (2, 16, 44100, ["--lax", "-l", "32", "-8"]), (2, 24, 96000, ["--lax", "-l", "32", "-e", "-p", "-5"]),
+    (2, 16, 44100, ["--lax", "-b", "16", "-l", "0"]), (2, 16, 44100, ["--lax", "-b", "65535", "-5"]), (2, 16, 44100, ["--lax", "-b", "1000", "-8"]),
+    (2, 16, 44100, ["-b", "192", "-l", "4"]), (2, 16, 12345, ["--lax", "-5"]), (2, 16, 44100, ["-5", "--no-padding", "--no-seektable"]),
+    (2, 16, 44100, ["-8", "-r", "0,0"]), (2, 16, 44100, ["-8", "-r", "8"]), (1, 8, 8000, ["-8", "--lax", "-b", "33"]),
+]
+
+
+def make_pcm(kind, n, ch, bps, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "music":
+        return signals.music(n, ch, bps, seed=seed)
+    if kind == "noise":
+        return rng.integers(-(1 << (bps - 1)), 1 << (bps - 1), size=(n, ch)).astype(np.int32)
+    if kind == "wasted":
+        return (signals.music(n, ch, bps, seed=seed) >> 3) << 3
+    pcm = np.zeros((n, ch), dtype=np.int32)
+    pcm[n // 2:] = 7
+    return pcm
+
+
+@pytest.mark.parametrize("case", range(len(CLEAN)))
+@pytest.mark.parametrize("kind", ["music", "noise", "wasted", "silence"])
+def test_reference_written_files_decode_as_the_reference_decodes_them(dec, case, kind):
+    import torch
+    ch, bps, rate, args = CLEAN[case]
+    rng = np.random.default_rng(100 + case)
+    bs = int(args[args.index("-b") + 1]) if "-b" in args else 4096
+    n = min(bs * 5 + int(rng.integers(1, max(2, bs))), 200000)
+    pcm = make_pcm(kind, n, ch, bps, case)
+    f = U.flac_encode_cli(pcm, bps, rate, args)
+    got = check(dec, f, (ch, bps, rate, args, kind), expect_pcm=pcm, allow_long_rice=False)
+    assert got["events"] == [] and got["redecoded"] == 0 and got["silence"] == 0
+    # the MD5 of STREAMINFO over the decoded samples (what FLAC__stream_decoder_finish compares, stream_decoder.c:670-676)
+    d_pcm = torch.from_numpy(np.ascontiguousarray(got["pcm"])).to("cuda:0")
+    bytes_per = (bps + 7) // 8
+    d_bytes = torch.empty(d_pcm.numel() * bytes_per, dtype=torch.uint8, device="cuda:0")
+    dec.pack_samples(d_pcm.data_ptr(), d_pcm.numel(), bps, d_bytes.data_ptr())
+    torch.cuda.synchronize()
+    assert hashlib.md5(d_bytes.cpu().numpy().tobytes()).digest() == got["md5"]
+
+
+def damage(rng, f, first):
+    b = bytearray(f)
+    n = len(b)
+    kind = int(rng.integers(0, 12))
+
+    def pos():
+        return int(rng.integers(first, n))
+    if kind == 0:
+        for _ in range(int(rng.integers(1, 4))):
+            b[pos()] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:
+        p = pos(); b[p:p + 2] = b'\xff\xf8'
+    elif kind == 2:
+        b = b[:pos()]
+    elif kind == 3:
+        p = pos(); q = min(n, p + int(rng.integers(1, 3000))); del b[p:q]
+    elif kind == 4:
+        p = pos(); b[p:p] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 200)), dtype=np.uint8))
+    elif kind == 5:
+        p = pos(); q = min(n, p + int(rng.integers(1, 64))); b[p:q] = b'\xff' * (q - p)
+    elif kind == 6:
+        p = pos(); q = min(n, p + int(rng.integers(1, 5000))); b[p:q] = bytes(q - p)
+    elif kind == 7:
+        p = pos(); b[p:p + 4] = bytes([0xff, 0xf8 | int(rng.integers(0, 2)), int(rng.integers(0, 256)), int(rng.integers(0, 256))])
+    elif kind == 8:
+        p = pos(); q = min(n, p + int(rng.integers(100, 20000))); b[q:q] = b[p:q]
+    elif kind == 9:
+        p = pos(); q = min(n, p + int(rng.integers(1, 100))); b[p:q] = bytes(rng.integers(0, 256, size=q - p, dtype=np.uint8))
+    elif kind == 10:
+        p = pos(); b = b[:first] + b[p:]
+    else:
+        for _ in range(int(rng.integers(2, 10))):
+            p = pos(); b[p:p + 2] = bytes([0xff, 0xf8 + int(rng.integers(0, 2))])
+    return bytes(b), kind
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FLACGPU_SD_SEEDS", "40"))))
+def test_damaged_streams_give_the_references_errors_and_samples(dec, seed):
+    rng = np.random.default_rng(5000 + seed)
+    ch, bps, rate, args = CLEAN[int(rng.integers(0, len(CLEAN)))]
+    bs = int(args[args.index("-b") + 1]) if "-b" in args else int(rng.choice([1152, 4096]))
+    n = min(bs * int(rng.integers(2, 9)) + int(rng.integers(0, 1000)), 150000)
+    pcm = make_pcm("music" if rng.random() < 0.7 else "noise", n, ch, bps, seed)
+    f = U.flac_encode_cli(pcm, bps, rate, args)
+    first = U.probe(f)[2]
+    skipped = 0
+    for d in range(8):
+        g, kind = damage(rng, f, first)
+        if check(dec, g, (seed, d, kind, ch, bps, rate, args)) == "skipped":
+            skipped += 1
+    assert skipped <= 4
