@@ -299,6 +299,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the white-noise and -5 side measurements")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the last step's frames (outside the timed region)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode_only side figure (the step's output decoded again as a bare stream, outside the timed region)")
     ap.add_argument("--hires", action="store_true", help="96 kHz / 24-bit stereo (BASELINE.json config 4): a side measurement")
     ap.add_argument("--white", action="store_true", help="white-noise corpus as the main measurement (side measurement)")
     ap.add_argument("--exhaustive", action="store_true", help="flac -8e: not the headline workload, a side measurement")
@@ -463,6 +464,36 @@ def main():
                                     "ms_per_batch_lane_per_frame": round(seq_ms, 4),
                                     "decode_Msamples_per_s": round(nframes * block / vms / 1e3, 1),
                                     "encode_plus_verify_Msamples_per_s": round(nframes * block / (vms + elapsed / steps * 1e3) / 1e3, 1)}
+        if rank == 0 and gp is None and not use_dist and not args.no_verify and not args.no_decode:
+            # side measurement, outside the timed region: the step's output taken as a stream nobody vouches for --
+            # no frame lengths, no input to compare with -- and decoded on the device: sync-code scan, a lane per frame, CRC-16,
+            # interleaved PCM in HBM (flacgpu_decode_stream_device); then compared with the step's input
+            try:
+                from flac_amd.stream_decoder import StreamDecoder, StreamInfo
+                sdec = StreamDecoder(local_rank)
+                tb = int(d_total.item())
+                info = StreamInfo(1, block, block, RATE, CH, BPS)
+                d_dec = torch.empty(nframes * block * CH, dtype=torch.int32, device=dev)
+                rc, r0, ev = sdec.decode_device(d_out.data_ptr(), tb, 0, info, d_dec.data_ptr(), d_dec.numel())      # (buffers grow on this one)
+                torch.cuda.synchronize()
+                walls, devms = [], []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    rc, r0, ev = sdec.decode_device(d_out.data_ptr(), tb, 0, info, d_dec.data_ptr(), d_dec.numel())
+                    torch.cuda.synchronize()
+                    walls.append((time.perf_counter() - t1) * 1e3)
+                    devms.append({"scan": r0.ms_scan, "decode": r0.ms_decode, "place": r0.ms_place, "total": r0.ms_total})
+                best = min(range(3), key=lambda k: walls[k])
+                same = bool(torch.equal(d_dec.view(-1), d_pcm.view(-1)))
+                res["decode_only"] = {"rc": int(rc), "samples": int(r0.samples), "frames": int(r0.frames), "errors": int(r0.nevents), "sync_codes": int(r0.candidates),
+                                      "redecoded_frames": int(r0.redecoded_frames), "pcm_equals_input": same,
+                                      "ms_wall": round(walls[best], 3), "ms_device": {k: round(v, 3) for k, v in devms[best].items()},
+                                      "Msamples_per_s": round(nframes * block / walls[best] / 1e3, 1), "stream_bytes": tb,
+                                      "what": "flacgpu_decode_stream_device on the step's %d bytes as a bare stream: frames found by sync code, nothing known but STREAMINFO's fields; wall time of the call (two host reads of the candidate table inside)" % tb}
+                sdec.close()
+                del d_dec
+            except Exception as e:
+                res["decode_only"] = {"error": repr(e)}
         verified = None
         if use_dist and not args.no_verify:
             # the multi-rank check, outside the timed region: EVERY rank's frames of the last step
@@ -622,6 +653,8 @@ def main():
             line["verified"] = m["verified"]
         if "device_verify" in m:
             line["device_verify"] = m["device_verify"]
+        if "decode_only" in m:
+            line["decode_only"] = m["decode_only"]
         if multi:
             wins = m.get("gather_windows") or []
             wms = [w["ms"] for w in wins if w["ms"] is not None]

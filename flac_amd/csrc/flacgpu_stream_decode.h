@@ -29,7 +29,8 @@ enum : uint8_t {
 	SD_OK = 0, SD_LOST_SYNC = 1, SD_BAD_HEADER = 2, SD_CRC_MISMATCH = 3, SD_UNPARSEABLE = 4, SD_BAD_METADATA = 5, SD_OUT_OF_BOUNDS = 6, SD_MISSING_FRAME = 7,
 	SD_EOS = 8,           // the stream ends inside (the reference's read callback reports END_OF_STREAM)
 	SD_RETRY = 9,         // internal: decode again with the instance that keeps 32 taps and multiplies in 32 bits
-	SD_NOT_DECODED = 10   // internal: header did not hold, nothing to decode
+	SD_NOT_DECODED = 10,  // internal: header did not hold, nothing to decode
+	SD_DEFERRED = 11      // internal: header holds but does not look like one of this stream's: decoded only if the search gets there
 };
 
 // the STREAMINFO fields the frame reader consults (stream_decoder.c:2706-2711, 2775-2780, 2808-2811, 2919-2934)

@@ -151,25 +151,21 @@ __global__ __launch_bounds__(1024) void sd_prefix_kernel(const uint32_t *__restr
 }
 
 // ---- the decode pass --------------------------------------------------------------------------------------------------------
-// One lane per candidate of the chunk [c0, c0 + count) -- or, with `list`, per entry of a list of candidate indices (frames decoded
-// again into their final place).  retry: take only candidates an earlier instance left at SD_RETRY.
+// One lane per entry of a list of candidate indices.  place == 0: the candidates' first decode -- status, length and what the CRC
+// kernel needs are recorded; place != 0: frames the walk found good decoded again for their samples only (status to lstat[]).
+// retry: take only candidates an earlier instance left at SD_RETRY.
 // decoded: [wavefront of the launch][Cmax][Nmax][64 lanes]; d_len / d_off: what crc_check_kernel reads (0xffffffff: nothing to check).
 template <int MAXORD, bool EXACT, typename ST>
 __global__ __launch_bounds__(64) void sd_decode_kernel(const uint8_t *__restrict__ stream, uint64_t nbytes, const StreamCand *__restrict__ cand, StreamBody *__restrict__ body,
-                                                       uint64_t c0, uint32_t count, const uint32_t *__restrict__ list, uint32_t Cmax, uint32_t Nmax, ST *__restrict__ decoded,
+                                                       uint32_t count, const uint32_t *__restrict__ list, uint32_t place, uint32_t Cmax, uint32_t Nmax, ST *__restrict__ decoded,
                                                        uint32_t *__restrict__ d_len, uint64_t *__restrict__ d_off, uint8_t *__restrict__ lstat, uint32_t retry)
 {
 	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
 	if(g >= count) return;
-	const uint64_t ci = list ? (uint64_t)list[g] : c0 + g;
+	const uint64_t ci = list[g];
 	const StreamCand K = cand[ci];
-	// (a list's entries are frames the walk found good: their status is known, only their samples are wanted again)
-	uint8_t *stp = list ? lstat + g : &body[ci].bstat;
-	if(retry) { if(*stp != SD_RETRY) return; }
-	else if(K.hstat != SD_OK) {
-		if(!list) { StreamBody B; B.spec = ~0ull; B.len = 0; B.bstat = SD_NOT_DECODED; B.oob_mask = 0; B.wrote = 0; B.pad_error = 0; body[ci] = B; d_len[g] = 0xffffffffu; d_off[g] = 0; }
-		return;
-	}
+	uint8_t *stp = place ? lstat + g : &body[ci].bstat;
+	if(retry && *stp != SD_RETRY) return;
 	ST *base = decoded + (size_t)blockIdx.x * Cmax * Nmax * 64 + threadIdx.x;
 	ST *row = base;
 	uint32_t cur = 0;
@@ -179,7 +175,7 @@ __global__ __launch_bounds__(64) void sd_decode_kernel(const uint8_t *__restrict
 	};
 	uint32_t len = 0, pad_error = 0;
 	const int st = sd_decode_frame<MAXORD, EXACT, ST>(stream + K.pos, nbytes - K.pos, stream + nbytes, K, sink, &len, &pad_error);
-	if(list) { *stp = (uint8_t)st; return; }
+	if(place) { *stp = (uint8_t)st; return; }
 	StreamBody B;
 	B.spec = ~0ull; B.len = st == SD_OK ? len : 0u; B.bstat = (uint8_t)st; B.oob_mask = 0; B.wrote = 0; B.pad_error = (uint8_t)pad_error;
 	body[ci] = B;
@@ -192,7 +188,7 @@ __global__ __launch_bounds__(64) void sd_decode_kernel(const uint8_t *__restrict
 // bounds check (a bit per offending channel into oob[]), and -- when the frame has the stream's format and its place lies inside the
 // output -- interleaved PCM at `spec` = the sample number its header implies minus spec_base (chunk mode), or at place[] (list mode).
 struct FinishArgs {
-	uint64_t c0; uint32_t count; const uint32_t *list; const uint64_t *place; const uint8_t *lstat;
+	uint32_t count; const uint32_t *list; const uint64_t *place; const uint8_t *lstat;      // place != null: frames decoded again into place
 	uint32_t Cmax, Nmax;
 	uint64_t spec_base, capacity;           // inter-channel samples
 	uint32_t out_channels, out_bps;
@@ -213,10 +209,10 @@ __global__ __launch_bounds__(TPB) void sd_finish_kernel(const FinishArgs A, cons
 		uint32_t n = 0, fmt = 0;
 		uint64_t outp = 0;
 		if(g < A.count) {
-			const uint64_t ci = A.list ? (uint64_t)A.list[g] : A.c0 + g;
+			const uint64_t ci = A.list[g];
 			const StreamCand K = cand[ci];
 			bool ok, wr;
-			if(A.list) { ok = A.lstat[g] == SD_OK; wr = ok; outp = A.place[g]; }
+			if(A.place) { ok = A.lstat[g] == SD_OK; wr = ok; outp = A.place[g]; }
 			else {
 				const StreamBody B = body[ci];
 				ok = K.hstat == SD_OK && B.bstat == SD_OK && !crcbad[g];
@@ -277,7 +273,7 @@ __global__ __launch_bounds__(TPB) void sd_finish_kernel(const FinishArgs A, cons
 			}
 		}
 	}
-	if(!A.list) {
+	if(!A.place) {
 #pragma unroll
 		for(int k = 0; k < 64 / (TPB / 64); k++) {
 			uint32_t v = oobacc[k];
@@ -382,13 +378,13 @@ namespace {
 struct ChunkPlan { uint32_t Cmax, Nmax; bool wide; uint32_t frames_per_chunk; };
 
 template <typename ST>
-hipError_t run_decode(flacgpu_decoder *d, const uint8_t *stream, uint64_t nbytes, uint64_t c0, uint32_t count, const uint32_t *list, const ChunkPlan &cp, hipStream_t s)
+hipError_t run_decode(flacgpu_decoder *d, const uint8_t *stream, uint64_t nbytes, uint32_t count, bool place, const ChunkPlan &cp, hipStream_t s)
 {
 	const uint32_t nwb = (count + 63) / 64;
-	hipLaunchKernelGGL((sd_decode_kernel<12, false, ST>), dim3(nwb), dim3(64), 0, s, stream, nbytes, (const StreamCand *)d->cand.p, (StreamBody *)d->body.p, c0, count, list, cp.Cmax, cp.Nmax, (ST *)d->decoded.p,
-	                   (uint32_t *)d->len.p, (uint64_t *)d->off.p, (uint8_t *)d->lstat.p, 0u);
-	hipLaunchKernelGGL((sd_decode_kernel<32, true, ST>), dim3(nwb), dim3(64), 0, s, stream, nbytes, (const StreamCand *)d->cand.p, (StreamBody *)d->body.p, c0, count, list, cp.Cmax, cp.Nmax, (ST *)d->decoded.p,
-	                   (uint32_t *)d->len.p, (uint64_t *)d->off.p, (uint8_t *)d->lstat.p, 1u);
+	hipLaunchKernelGGL((sd_decode_kernel<12, false, ST>), dim3(nwb), dim3(64), 0, s, stream, nbytes, (const StreamCand *)d->cand.p, (StreamBody *)d->body.p, count,
+	                   (const uint32_t *)d->list.p, place ? 1u : 0u, cp.Cmax, cp.Nmax, (ST *)d->decoded.p, (uint32_t *)d->len.p, (uint64_t *)d->off.p, (uint8_t *)d->lstat.p, 0u);
+	hipLaunchKernelGGL((sd_decode_kernel<32, true, ST>), dim3(nwb), dim3(64), 0, s, stream, nbytes, (const StreamCand *)d->cand.p, (StreamBody *)d->body.p, count,
+	                   (const uint32_t *)d->list.p, place ? 1u : 0u, cp.Cmax, cp.Nmax, (ST *)d->decoded.p, (uint32_t *)d->len.p, (uint64_t *)d->off.p, (uint8_t *)d->lstat.p, 1u);
 	return hipGetLastError();
 }
 template <typename ST>
@@ -419,7 +415,6 @@ extern "C" int flacgpu_decode_stream_device(flacgpu_decoder *d, const uint8_t *d
 	struct EvGuard { hipEvent_t *e; ~EvGuard() { for(int k = 0; k < 4; k++) (void)hipEventDestroy(e[k]); } } evg{ev};
 	std::vector<StreamCand> cand;
 	std::vector<StreamBody> body;
-	ChunkPlan cp = {1, 1, false, 0};
 	uint32_t last_byte = 0;
 	uint64_t ncand = 0;
 	(void)hipEventRecord(ev[0], s);
@@ -449,52 +444,92 @@ extern "C" int flacgpu_decode_stream_device(flacgpu_decoder *d, const uint8_t *d
 	}
 	else if(nbytes == 1) { uint8_t lb = 0; SD_CK(hipMemcpy(&lb, d_stream, 1, hipMemcpyDeviceToHost)); last_byte = lb; }
 	(void)hipEventRecord(ev[1], s);
-	// ---- what the decode passes need to know about the table: the widest frame, whether a 33-bit channel can occur, the format and
-	// the first sample number the output is laid out by
+	// ---- which candidates are decoded at once.  A sync code inside a frame's data passes the header's CRC-8 once in 256 times and
+	// then claims any block size and channel count; decoded with the rest it would set the scratch's shape (8 x 65535 samples per
+	// lane) and keep one lane busy long after its wavefront's other 63 are done.  In a stream whose frames are all there the search
+	// never reaches such a candidate.  So: the candidates that look like the stream's frames (STREAMINFO's format and block-size
+	// range; without STREAMINFO: the format of the first header that holds) are decoded now, the others are DEFERRED -- only if
+	// the walk reaches one of them are they decoded too, all of them, and the walk run again.
 	uint32_t out_channels = I.has_streaminfo ? I.channels : 0, out_bps = I.has_streaminfo ? I.bps : 0;
 	uint64_t spec_base = 0;
 	bool have_first = false;
 	for(const StreamCand &K : cand) {
 		if(K.hstat != SD_OK) continue;
-		cp.Cmax = std::max<uint32_t>(cp.Cmax, K.channels); cp.Nmax = std::max<uint32_t>(cp.Nmax, K.blocksize);
-		if(K.bps == 32 && K.ca != 0) cp.wide = true;
 		if(!have_first) { have_first = true; spec_base = sd_spec_sample(K, I); if(!out_channels) { out_channels = K.channels; out_bps = K.bps; } }
+		break;
 	}
 	body.resize((size_t)ncand);
-	std::vector<uint32_t> oob((size_t)ncand, 0);
-	const size_t elem = cp.wide ? 8 : 4;
-	if(ncand) {
-		// chunks of candidates sized so that the lane-interleaved scratch stays below 1 GiB
+	std::vector<uint32_t> main_list, deferred;
+	ChunkPlan cpm = {1, 1, false, 0}, cpd = {1, 1, false, 0};
+	for(size_t i = 0; i < (size_t)ncand; i++) {
+		const StreamCand &K = cand[i];
+		StreamBody &B = body[i];
+		B.spec = ~0ull; B.len = 0; B.bstat = SD_NOT_DECODED; B.oob_mask = 0; B.wrote = 0; B.pad_error = 0;
+		if(K.hstat != SD_OK) continue;
+		const bool plausible = K.channels == out_channels && K.bps == out_bps && (!I.has_streaminfo || K.blocksize <= I.max_blocksize);
+		ChunkPlan &cp = plausible ? cpm : cpd;
+		cp.Cmax = std::max<uint32_t>(cp.Cmax, K.channels); cp.Nmax = std::max<uint32_t>(cp.Nmax, K.blocksize);
+		if(K.bps == 32 && K.ca != 0) cp.wide = true;
+		(plausible ? main_list : deferred).push_back((uint32_t)i);
+		B.bstat = SD_DEFERRED;
+	}
+	if(ncand) SD_CK(hipMemcpyAsync(d->body.p, body.data(), (size_t)ncand * sizeof(StreamBody), hipMemcpyHostToDevice, s));
+	std::vector<uint32_t> oob_list;                                       // per list entry, filled chunk by chunk
+	// first decode of a list of candidates: decode, CRC-16, finish (speculative placement), statuses into d->body
+	auto first_decode = [&](const std::vector<uint32_t> &list, ChunkPlan &cp) -> int {
+		if(list.empty()) return FLACGPU_OK;
+		const size_t elem = cp.wide ? 8 : 4;
+		// chunks of candidates sized by the lane-interleaved scratch: as many wavefronts in one launch as a quarter of the free HBM
+		// (at most 32 GiB of the 288) holds -- a lane is a serial bit chain, what fills the chip is the number of frames in flight:
+		// 16384 frames are one wavefront per CU, a ten-hour stream's 390 000 are six per SIMD
 		const size_t per64 = (size_t)cp.Cmax * cp.Nmax * 64 * elem;
-		size_t wpc = ((size_t)1 << 30) / per64;
+		size_t budget = (size_t)1 << 30, mfree = 0, mtotal = 0;
+		if(hipMemGetInfo(&mfree, &mtotal) == hipSuccess) budget = std::max(budget, std::min<size_t>((size_t)32 << 30, mfree / 4));
+		if(d->decoded.bytes > budget) budget = d->decoded.bytes;          // (what an earlier call left is there to be used)
+		size_t wpc = budget / per64;
 		if(wpc < 1) wpc = 1;
-		if(wpc > 256) wpc = 256;                                          // 16384 candidates
-		const size_t total_wb = ((size_t)ncand + 63) / 64;
+		if(wpc > 8192) wpc = 8192;                                        // 524288 candidates
+		const size_t total_wb = (list.size() + 63) / 64;
 		if(wpc > total_wb) wpc = total_wb;
 		cp.frames_per_chunk = (uint32_t)(wpc * 64);
 		if(!d->decoded.need(wpc * per64) || !d->len.need((size_t)cp.frames_per_chunk * 4) || !d->off.need((size_t)cp.frames_per_chunk * 8) ||
-		   !d->crcbad.need(cp.frames_per_chunk) || !d->oob.need((size_t)cp.frames_per_chunk * 4) || !d->lstat.need(64)) return FLACGPU_ERR_ALLOC;
-		for(uint64_t c0 = 0; c0 < ncand; c0 += cp.frames_per_chunk) {
-			const uint32_t count = (uint32_t)std::min<uint64_t>(cp.frames_per_chunk, ncand - c0);
+		   !d->crcbad.need(cp.frames_per_chunk) || !d->oob.need((size_t)cp.frames_per_chunk * 4) || !d->lstat.need(64) || !d->list.need(list.size() * 4)) return FLACGPU_ERR_ALLOC;
+		oob_list.assign(list.size(), 0);
+		for(size_t l0 = 0; l0 < list.size(); l0 += cp.frames_per_chunk) {
+			const uint32_t count = (uint32_t)std::min<size_t>(cp.frames_per_chunk, list.size() - l0);
+			SD_CK(hipMemcpyAsync(d->list.p, list.data() + l0, (size_t)count * 4, hipMemcpyHostToDevice, s));
 			SD_CK(hipMemsetAsync(d->crcbad.p, 0, count, s));
 			SD_CK(hipMemsetAsync(d->oob.p, 0, (size_t)count * 4, s));
-			SD_CK(cp.wide ? run_decode<int64_t>(d, d_stream, nbytes, c0, count, nullptr, cp, s) : run_decode<int32_t>(d, d_stream, nbytes, c0, count, nullptr, cp, s));
+			SD_CK(cp.wide ? run_decode<int64_t>(d, d_stream, nbytes, count, false, cp, s) : run_decode<int32_t>(d, d_stream, nbytes, count, false, cp, s));
 			SD_CK(launch_crc_check(d_stream, (const uint32_t *)d->len.p, (const uint64_t *)d->off.p, count, d->d_vstate, s, (uint8_t *)d->crcbad.p));
 			FinishArgs A;
-			A.c0 = c0; A.count = count; A.list = nullptr; A.place = nullptr; A.lstat = nullptr; A.Cmax = cp.Cmax; A.Nmax = cp.Nmax; A.spec_base = spec_base;
+			A.count = count; A.list = (const uint32_t *)d->list.p; A.place = nullptr; A.lstat = nullptr; A.Cmax = cp.Cmax; A.Nmax = cp.Nmax; A.spec_base = spec_base;
 			A.capacity = d_pcm && out_channels ? pcm_capacity_values / out_channels : 0; A.out_channels = out_channels; A.out_bps = out_bps; A.I = I;
 			SD_CK(cp.wide ? run_finish<int64_t>(d, A, d_pcm, s) : run_finish<int32_t>(d, A, d_pcm, s));
-			SD_CK(hipMemcpyAsync(oob.data() + c0, d->oob.p, (size_t)count * 4, hipMemcpyDeviceToHost, s));
+			SD_CK(hipMemcpyAsync(oob_list.data() + l0, d->oob.p, (size_t)count * 4, hipMemcpyDeviceToHost, s));
 		}
-		SD_CK(hipMemcpyAsync(body.data(), d->body.p, (size_t)ncand * sizeof(StreamBody), hipMemcpyDeviceToHost, s));
-		(void)hipEventRecord(ev[2], s);
+		// (the statuses of the listed candidates come back with the whole table: 16 bytes per sync code)
+		std::vector<StreamBody> back((size_t)ncand);
+		SD_CK(hipMemcpyAsync(back.data(), d->body.p, (size_t)ncand * sizeof(StreamBody), hipMemcpyDeviceToHost, s));
 		SD_CK(hipStreamSynchronize(s));
-		for(size_t i = 0; i < (size_t)ncand; i++) if(oob[i] && body[i].bstat == SD_OK) { body[i].bstat = SD_OUT_OF_BOUNDS; body[i].oob_mask = (uint8_t)oob[i]; }
-	}
-	else (void)hipEventRecord(ev[2], s);
+		for(size_t k = 0; k < list.size(); k++) {
+			StreamBody &B = body[list[k]];
+			B = back[list[k]];
+			if(oob_list[k] && B.bstat == SD_OK) { B.bstat = SD_OUT_OF_BOUNDS; B.oob_mask = (uint8_t)oob_list[k]; }
+		}
+		return FLACGPU_OK;
+	};
+	{ const int r = first_decode(main_list, cpm); if(r != FLACGPU_OK) return r; }
+	(void)hipEventRecord(ev[2], s);
 	// ---- the walk
 	WalkResult W;
 	sd_walk(I, first_frame_offset, nbytes, last_byte, cand.data(), body.data(), (size_t)ncand, W);
+	if(W.need_deferred) {
+		result->deferred_decoded = deferred.size();
+		const int r = first_decode(deferred, cpd); if(r != FLACGPU_OK) return r;
+		W = WalkResult();
+		sd_walk(I, first_frame_offset, nbytes, last_byte, cand.data(), body.data(), (size_t)ncand, W);
+	}
 	result->samples = W.samples; result->frames = W.frames; result->silence_samples = W.silence_samples; result->candidates = ncand;
 	result->nevents = (uint32_t)W.events.size(); result->end_in_header = W.end_in_header; result->format_changes = W.format_changes;
 	result->long_rice_codes = W.long_rice_codes; result->channels = W.channels; result->bits_per_sample = W.bps; result->sample_rate = W.sample_rate;
@@ -523,20 +558,31 @@ extern "C" int flacgpu_decode_stream_device(flacgpu_decoder *d, const uint8_t *d
 		};
 		std::vector<uint32_t> list;
 		std::vector<uint64_t> place;
-		for(const WalkPlace &P : W.places) if(P.cand >= 0 && (!placed[(size_t)P.cand] || touches(P.out, P.out + P.n))) { list.push_back((uint32_t)P.cand); place.push_back(P.out); }
+		ChunkPlan cp = {1, 1, false, 0};
+		for(const WalkPlace &P : W.places) if(P.cand >= 0 && (!placed[(size_t)P.cand] || touches(P.out, P.out + P.n))) {
+			const StreamCand &K = cand[(size_t)P.cand];
+			list.push_back((uint32_t)P.cand); place.push_back(P.out);
+			cp.Cmax = std::max<uint32_t>(cp.Cmax, K.channels); cp.Nmax = std::max<uint32_t>(cp.Nmax, K.blocksize);
+			if(K.bps == 32 && K.ca != 0) cp.wide = true;
+		}
 		result->redecoded_frames = list.size();
+		if(!list.empty()) {
+			const size_t per64 = (size_t)cp.Cmax * cp.Nmax * 64 * (cp.wide ? 8 : 4);
+			size_t wpc = std::max<size_t>(1, std::min<size_t>(256, ((size_t)1 << 30) / per64));
+			cp.frames_per_chunk = (uint32_t)(wpc * 64);
+			if(!d->decoded.need(wpc * per64) || !d->len.need((size_t)cp.frames_per_chunk * 4) || !d->off.need((size_t)cp.frames_per_chunk * 8)) return FLACGPU_ERR_ALLOC;
+		}
 		for(size_t l0 = 0; l0 < list.size(); l0 += cp.frames_per_chunk) {
 			const uint32_t count = (uint32_t)std::min<size_t>(cp.frames_per_chunk, list.size() - l0);
 			if(!d->list.need((size_t)count * 4) || !d->place.need((size_t)count * 8) || !d->lstat.need(count)) return FLACGPU_ERR_ALLOC;
 			SD_CK(hipMemcpyAsync(d->list.p, list.data() + l0, (size_t)count * 4, hipMemcpyHostToDevice, s));
 			SD_CK(hipMemcpyAsync(d->place.p, place.data() + l0, (size_t)count * 8, hipMemcpyHostToDevice, s));
 			SD_CK(hipMemsetAsync(d->lstat.p, 0, count, s));
-			SD_CK(cp.wide ? run_decode<int64_t>(d, d_stream, nbytes, 0, count, (const uint32_t *)d->list.p, cp, s) : run_decode<int32_t>(d, d_stream, nbytes, 0, count, (const uint32_t *)d->list.p, cp, s));
+			SD_CK(cp.wide ? run_decode<int64_t>(d, d_stream, nbytes, count, true, cp, s) : run_decode<int32_t>(d, d_stream, nbytes, count, true, cp, s));
 			FinishArgs A;
-			A.c0 = 0; A.count = count; A.list = (const uint32_t *)d->list.p; A.place = (const uint64_t *)d->place.p; A.lstat = (const uint8_t *)d->lstat.p; A.Cmax = cp.Cmax; A.Nmax = cp.Nmax; A.spec_base = 0;
+			A.count = count; A.list = (const uint32_t *)d->list.p; A.place = (const uint64_t *)d->place.p; A.lstat = (const uint8_t *)d->lstat.p; A.Cmax = cp.Cmax; A.Nmax = cp.Nmax; A.spec_base = 0;
 			A.capacity = pcm_capacity_values / W.channels; A.out_channels = W.channels; A.out_bps = W.bps; A.I = I;
 			SD_CK(cp.wide ? run_finish<int64_t>(d, A, d_pcm, s) : run_finish<int32_t>(d, A, d_pcm, s));
-			SD_CK(hipStreamSynchronize(s));                               // (the host vectors behind the copies are reused)
 		}
 		for(const WalkPlace &P : W.places) if(P.cand < 0) SD_CK(hipMemsetAsync(d_pcm + P.out * W.channels, 0, (size_t)P.n * W.channels * 4, s));
 	}

@@ -32,6 +32,7 @@ struct WalkResult {
 	uint64_t frames = 0, silence_samples = 0;
 	uint32_t end_in_header = 0;    // the stream ended inside a frame header: process_until_end_of_stream returns false (:1186-1187)
 	uint32_t long_rice_codes = 0;  // frames the search reached that were given up for a Rice code longer than a 32-bit residual allows (flacgpu_stream_decode.h)
+	uint32_t need_deferred = 0;    // the search reached a candidate whose frame has not been decoded yet (SD_DEFERRED): decode those, walk again
 	uint32_t format_changes = 0;   // good frames whose channel count or sample width is not the stream's (they get no room in the output)
 	uint32_t channels = 0, bps = 0, sample_rate = 0;   // the stream's format: STREAMINFO, else the first good frame
 };
@@ -61,6 +62,7 @@ inline void sd_walk(const SdInfo &I, uint64_t first_pos, uint64_t nbytes, uint32
 		if(K.pos > pos) send(SD_LOST_SYNC, pos);
 		if(K.hstat == SD_EOS) { R.end_in_header = 1; break; }
 		if(K.hstat != SD_OK) { send(K.hstat, K.pos); pos = K.pos + K.resume; continue; }
+		if(B.bstat == SD_DEFERRED) { R.need_deferred = 1; return; }
 		// the header holds: its number becomes a sample number (:2917-2934)
 		uint32_t next_fixed = 0;
 		uint64_t sn;

@@ -25,7 +25,7 @@ class DecodeEvent(C.Structure):
 class DecodeResult(C.Structure):
     """flacgpu_decode_result"""
     _fields_ = [("samples", C.c_uint64), ("frames", C.c_uint64), ("silence_samples", C.c_uint64), ("candidates", C.c_uint64),
-                ("redecoded_frames", C.c_uint64), ("nevents", C.c_uint32), ("end_in_header", C.c_uint32), ("format_changes", C.c_uint32),
+                ("deferred_decoded", C.c_uint64), ("redecoded_frames", C.c_uint64), ("nevents", C.c_uint32), ("end_in_header", C.c_uint32), ("format_changes", C.c_uint32),
                 ("long_rice_codes", C.c_uint32), ("channels", C.c_uint32), ("bits_per_sample", C.c_uint32), ("sample_rate", C.c_uint32),
                 ("errors_by_status", C.c_uint32 * 8), ("ms_scan", C.c_float), ("ms_decode", C.c_float), ("ms_place", C.c_float),
                 ("ms_total", C.c_float)]
@@ -136,7 +136,7 @@ class StreamDecoder:
         return dict(pcm=pcm, events=[e[0] for e in events], event_offsets=[e[1] for e in events], nevents=int(res.nevents), ok=not bool(res.end_in_header),
                     samples=int(res.samples), frames=int(res.frames), silence=int(res.silence_samples), channels=int(res.channels),
                     bps=int(res.bits_per_sample), sample_rate=int(res.sample_rate), format_changes=int(res.format_changes),
-                    long_rice_codes=int(res.long_rice_codes), candidates=int(res.candidates), redecoded=int(res.redecoded_frames),
+                    long_rice_codes=int(res.long_rice_codes), candidates=int(res.candidates), redecoded=int(res.redecoded_frames), deferred_decoded=int(res.deferred_decoded),
                     ms=dict(scan=res.ms_scan, decode=res.ms_decode, place=res.ms_place, total=res.ms_total), md5=md5, total_samples=total)
 
     def pack_samples(self, d_pcm_ptr, nvalues, bps, d_out_ptr, stream=None):

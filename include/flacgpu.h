@@ -217,6 +217,8 @@ typedef struct {
 	uint64_t frames;                 /* frames decoded into them */
 	uint64_t silence_samples;        /* of `samples`: stand-ins for missing frames */
 	uint64_t candidates;             /* sync codes looked at */
+	uint64_t deferred_decoded;       /* sync codes inside frame data whose header happens to hold but does not look like this stream's, decoded after
+	                                    all because the search got to one (0 for a whole stream) */
 	uint64_t redecoded_frames;       /* frames decoded a second time, into a place other than the one their number implies (0 for a whole stream) */
 	uint32_t nevents;                /* error callbacks; the first max_events of them are in `events` */
 	uint32_t end_in_header;          /* the stream ended inside a frame header: the reference's process call returns false */
