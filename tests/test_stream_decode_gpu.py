@@ -133,3 +133,20 @@ def test_damaged_streams_give_the_references_errors_and_samples(dec, seed):
         if check(dec, g, (seed, d, kind, ch, bps, rate, args)) == "skipped":
             skipped += 1
     assert skipped <= 4
+
+
+@pytest.mark.parametrize("name", ["test_escape_coded_partitions_and_rice2", "test_variable_block_sizes_and_every_header_code", "test_reserved_and_broken_headers",
+                                  "test_frames_missing_silence_and_its_caps", "test_values_that_overflow_and_32_bit_wrap_around",
+                                  "test_orders_up_to_32_precisions_shifts_wasted_bits", "test_a_frame_hidden_in_verbatim_data_and_false_syncs_with_good_headers"])
+def test_hand_built_streams_on_the_device(dec, name, monkeypatch):
+    """The hand-built streams of tests/test_stream_decode_cpu.py (escape codes, RICE2, sample numbers and changing block sizes, every
+    header code, streams without STREAMINFO, missing frames and the caps on their silence, overflowing values, a frame hidden in
+    verbatim data, truncation at every byte) through the device decoder instead of the host build of its lane code."""
+    import test_stream_decode_cpu as T
+
+    def device_decode(stream, **kw):
+        r = dec.decode(stream)
+        r["retries"] = 1
+        return r
+    monkeypatch.setattr(U, "pin_decode", device_decode)
+    getattr(T, name)()
