@@ -150,3 +150,65 @@ def test_hand_built_streams_on_the_device(dec, name, monkeypatch):
         return r
     monkeypatch.setattr(U, "pin_decode", device_decode)
     getattr(T, name)()
+
+
+GEN = os.path.join(U.ROOT, "oracle", "_ref", "test_streams")
+
+
+@pytest.mark.skipif(not os.path.exists(GEN), reason="oracle/_ref/test_streams not built")
+def test_the_reference_generators_streams_round_trip_through_the_device_decoder(dec, tmp_path):
+    """The files of the reference's own stream generator (src/test_streams/main.c: sines, full-scale deflection, the rt-* files of
+    1 / 111 / 4777 samples at 8..32 bits and 1..4+ channels, `wacky` headers) encoded by the reference's `flac` with the options of
+    its test script (test/test_streams.sh:178-219) and decoded on the device: samples and verdict as the reference's decoder has them."""
+    import subprocess
+    subprocess.run([GEN], cwd=str(tmp_path), check=True, capture_output=True, timeout=300)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.dirname(U.FLAC_REF) + ":" + env.get("LD_LIBRARY_PATH", "")
+    wavs = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith(".wav"))
+    raws = [("sine16-%02d.raw" % k, 1 if k < 10 else 2, 16) for k in (0, 4, 3, 10, 14, 19)] + [("sine24-%02d.raw" % k, 1 if k < 10 else 2, 24) for k in (1, 12, 19)] + \
+           [("sine32-%02d.raw" % k, 1 if k < 10 else 2, 32) for k in (3, 15)] + [("sine8-%02d.raw" % k, 1 if k < 10 else 2, 8) for k in (2, 16)] + \
+           [("fsd%d-%02d.raw" % (b, k), 1, b) for b in (8, 16, 24, 32) for k in (1, 4, 7)]
+    done = 0
+    opts = [["-5"], ["-0", "-l", "16", "--lax", "-m", "-e", "-p"], ["-8", "-b", "1152"], ["--lax", "-l", "32", "-b", "4608"]]
+    for k, w in enumerate(wavs):
+        out = os.path.join(str(tmp_path), "o.flac")
+        r = subprocess.run([U.FLAC_REF, "--silent", "-f", "-o", out] + opts[k % len(opts)] + [os.path.join(str(tmp_path), w)], env=env, capture_output=True)
+        if r.returncode != 0:
+            continue                                     # (the wacky files the tool itself refuses)
+        check(dec, open(out, "rb").read(), w, allow_long_rice=False)
+        done += 1
+    for k, (name, ch, bps) in enumerate(raws):
+        out = os.path.join(str(tmp_path), "o.flac")
+        subprocess.check_call([U.FLAC_REF, "--silent", "-f", "-o", out, "--force-raw-format", "--endian=little", "--sign=signed", "--channels=%d" % ch, "--bps=%d" % bps,
+                               "--sample-rate=44100"] + opts[k % len(opts)] + [os.path.join(str(tmp_path), name)], env=env)
+        got = check(dec, open(out, "rb").read(), name, allow_long_rice=False)
+        assert got["events"] == []
+        done += 1
+    assert done >= 40
+
+
+def test_many_streams_decoded_and_their_md5_taken_on_the_device(dec):
+    """`flac -t` over a directory, on the device end to end: every file decoded (flacgpu_decode_stream_device), its samples narrowed to
+    the bytes the MD5 of STREAMINFO is over (flacgpu_pack_samples_device) and all digests taken by one launch, a lane per stream
+    (flacgpu_md5_many_device) -- each equal to the file's STREAMINFO (what FLAC__stream_decoder_finish checks, stream_decoder.c:670-676)."""
+    import torch
+    from flac_amd.engine import md5_many_device
+    files = []
+    for k, (ch, bps, rate, args) in enumerate(CLEAN[:12]):
+        pcm = make_pcm("music", 4096 * 3 + 17 * k, ch, bps, 40 + k)
+        files.append((U.flac_encode_cli(pcm, bps, rate, args), pcm, bps))
+    packed, offsets, lengths, want = [], [], [], []
+    total = sum(p.size * ((b + 7) // 8) for _, p, b in files)
+    d_bytes = torch.empty(total + 64, dtype=torch.uint8, device="cuda:0")
+    off = 0
+    for f, pcm, bps in files:
+        got = dec.decode(f)
+        assert got["events"] == [] and np.array_equal(got["pcm"], pcm)
+        d_pcm = torch.from_numpy(np.ascontiguousarray(got["pcm"])).to("cuda:0")
+        nb = d_pcm.numel() * ((bps + 7) // 8)
+        dec.pack_samples(d_pcm.data_ptr(), d_pcm.numel(), bps, d_bytes.data_ptr() + off)
+        torch.cuda.synchronize()
+        offsets.append(off); lengths.append(nb); want.append(got["md5"])
+        off += nb
+    digests = md5_many_device(d_bytes.data_ptr(), offsets, lengths, device=0)
+    assert digests == want
