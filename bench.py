@@ -299,6 +299,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the white-noise and -5 side measurements")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the last step's frames (outside the timed region)")
+    ap.add_argument("--timing-every", type=int, default=1, help="per-kernel HIP-event timing on every n-th step of the timed region (1: every step)")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode_only side figure (the step's output decoded again as a bare stream, outside the timed region)")
     ap.add_argument("--hires", action="store_true", help="96 kHz / 24-bit stereo (BASELINE.json config 4): a side measurement")
     ap.add_argument("--white", action="store_true", help="white-noise corpus as the main measurement (side measurement)")
@@ -369,6 +370,9 @@ def main():
         block = block_of(level)
         settings = flac_amd.make_settings(CH, BPS, RATE, level, **search)
         eng = flac_amd.FrameEngine(settings, device=local_rank, max_batch_frames=nframes)
+        # phase timing (HIP events on the engine's stream around its kernels) on every --timing-every-th step: instrumentation that
+        # costs the stream ~4.6 us per record; the per-kernel durations of the line are the averages over the steps that carry it
+        eng.set_phase_timing(args.timing_every)
         pcm_h = rank_pcm(rank, nframes, block, kind, args.hires)
         d_pcm = torch.from_numpy(pcm_h).to(dev)
         cap = eng.max_output_bytes(nframes)
@@ -422,7 +426,7 @@ def main():
         elapsed = time.perf_counter() - t0
         # per-kernel durations of the timed steps: HIP events the engine recorded on its stream around every launch (it keeps
         # the sets of its last 64 batches, so nothing had to sync inside the timed region)
-        phase_ms = [eng.last_phase_ms(back) for back in range(min(steps, 64))]
+        phase_ms = [ph for ph in (eng.last_phase_ms(back) for back in range(min(steps, 64))) if ph is not None]
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -538,7 +542,7 @@ def main():
                 # encode set the pace
                 res["gather_windows"] = gp.window_stats()[nwin_warm:]
                 res["gather_backend"] = gp.backend
-            kms = {k: float(np.mean([ph[k] for ph in phase_ms])) for k in phase_ms[0]}
+            kms = {k: float(np.mean([ph[k] for ph in phase_ms])) for k in phase_ms[0]} if phase_ms else {k: 0.0 for k in ("prep", "autoc", "model", "eval", "pack", "scan_compact")}
             samples_per_step = nframes * block
             out_bps = total_bytes / samples_per_step
             alg_bytes = samples_per_step * (4 * CH + out_bps)         # PCM read once + frames written once

@@ -25,6 +25,7 @@ struct flacgpu_ctx {
 	// HIP events of the last TIMING_RING batches (so that a caller can read per-kernel times of a run of batches
 	// afterwards, without a host sync in between); ev/pev point at the set of the current batch
 	hipEvent_t ev_ring[TIMING_RING][5], pev_ring[TIMING_RING][3];
+	bool timed_ring[TIMING_RING]; uint32_t timing_every;      // which of them carry events (flacgpu_set_phase_timing)
 	hipEvent_t seq_ring[TIMING_RING][7];   // the seven phase boundaries of each batch: which of its events closes which phase (an event record costs
 	                                       // the stream ~4 us, so phases that launch nothing share the event of the phase in front)
 	hipEvent_t *ev;              // start, after analyze, after pack, after compact, spare
@@ -110,7 +111,7 @@ static Tune read_tune(int device)
 	t.autoc2_ungrouped = set("FLACGPU_AUTOC2_UNGROUPED");
 	{ const char *e = getenv("FLACGPU_AUTOC2"); t.autoc2_force = e ? atoi(e) + 1 : 0; }
 	t.no_ff = set("FLACGPU_NO_FF"); t.no_run18 = set("FLACGPU_NO_RUN18"); t.no_prep3 = set("FLACGPU_NO_PREP3"); t.no_prep_decide = set("FLACGPU_NO_PREP_DECIDE");
-	t.no_evalg = set("FLACGPU_NO_EVALG"); t.no_fast1 = set("FLACGPU_NO_FAST1"); t.no_prep4 = set("FLACGPU_NO_PREP4");
+	t.no_evalg = set("FLACGPU_NO_EVALG"); t.no_fast1 = set("FLACGPU_NO_FAST1"); t.no_prep4 = set("FLACGPU_NO_PREP4"); t.no_flat = set("FLACGPU_NO_FLAT");
 	t.eval_wpc = num("FLACGPU_EVAL_WPC", 1) == 2 ? 2 : 1; t.evalw_wpc = num("FLACGPU_EVALW_WPC", 2) == 1 ? 1 : 2;
 	t.eval_waves = num("FLACGPU_EVAL_WAVES", 0); t.eval_cpw = num("FLACGPU_EVAL_CPW", 0); t.eval_prefetch = num("FLACGPU_EVAL_PREFETCH", -1);
 	t.sync_debug = set("FLACGPU_SYNC_DEBUG"); t.no_fused = set("FLACGPU_NO_FUSED_COMPACT"); t.no_copy_kernel = set("FLACGPU_NO_COPY_KERNEL");
@@ -173,6 +174,7 @@ extern "C" int flacgpu_batch_phase_ms(flacgpu_ctx *c, uint32_t batches_ago, floa
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	const size_t slot = (size_t)((c->batch_seq - 1 - batches_ago) % TIMING_RING);
 	hipEvent_t *seq = c->seq_ring[slot];
+	if(!c->timed_ring[slot]) { for(int i = 0; i < 6; i++) ms[i] = 0.0f; return 1; }      // that batch carried no events
 	if(hipEventSynchronize(seq[6]) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	for(int i = 0; i < 6; i++) {
 		ms[i] = 0.0f;
@@ -181,6 +183,12 @@ extern "C" int flacgpu_batch_phase_ms(flacgpu_ctx *c, uint32_t batches_ago, floa
 	return FLACGPU_OK;
 }
 extern "C" int flacgpu_last_batch_phase_ms(flacgpu_ctx *c, float ms[6]) { return flacgpu_batch_phase_ms(c, 0, ms); }
+extern "C" int flacgpu_set_phase_timing(flacgpu_ctx *c, uint32_t every)
+{
+	if(!c) return FLACGPU_ERR_BAD_ARG;
+	c->timing_every = every;
+	return FLACGPU_OK;
+}
 extern "C" int flacgpu_set_subbatches(flacgpu_ctx *c, uint32_t n)
 {
 	if(!c || n < 1 || n > (uint32_t)FLACGPU_MAX_SUBBATCHES) return FLACGPU_ERR_BAD_ARG;
@@ -433,6 +441,8 @@ extern "C" int flacgpu_create(const flacgpu_config *cfg, const float *windows, f
 	}
 	ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
 	c->nsub = 1;
+	c->timing_every = 1;                                             // (every batch, until the caller says otherwise: flacgpu_set_phase_timing)
+	if(const char *e = getenv("FLACGPU_TIMING_EVERY")) { const int v = atoi(e); if(v >= 0) c->timing_every = (uint32_t)v; }
 	if(const char *e = getenv("FLACGPU_SUBBATCHES")) { const int v = atoi(e); if(v >= 1 && v <= FLACGPU_MAX_SUBBATCHES) c->nsub = (uint32_t)v; }
 	const size_t B = cfg->max_batch_frames;
 	const size_t wbytes = (size_t)(P.num_apod ? P.num_apod : 1) * N * sizeof(float);
@@ -539,8 +549,12 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 	c->ev = c->ev_ring[c->batch_seq % TIMING_RING]; c->pev = c->pev_ring[c->batch_seq % TIMING_RING];
 	const size_t ring_slot = c->batch_seq % TIMING_RING;
 	hipEvent_t *seq = c->seq_ring[ring_slot];
+	// phase timing is instrumentation: every n-th batch carries the event records (flacgpu_set_phase_timing; an event record costs the
+	// stream ~4.6 us, six of them 1.4 % of a -8 step of 16384 frames and a fifth of a -0 step)
+	const bool timed = c->timing_every && (c->batch_seq % c->timing_every) == 0;
+	c->timed_ring[ring_slot] = timed;
 	c->batch_seq++;
-	(void)hipEventRecord(c->ev[0], s);
+	if(timed) (void)hipEventRecord(c->ev[0], s);
 	bool fused = false;
 	uint32_t nsub = c->nsub;
 	// The fused output (flacgpu_kernels.hip, PackOut): the pack kernels (pack2_kernel, ff_kernel) write every frame once, at its
@@ -582,7 +596,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		fused = ffpo && nmain != 0;
 		hipEvent_t after_main = c->ev[3];
 		if(tail_n) {
-			(void)hipEventRecord(c->pev[0], s);
+			if(timed) (void)hipEventRecord(c->pev[0], s);
 			after_main = c->pev[0];
 			const size_t fc0 = (size_t)nmain * P.ncand, ncs = P.ncslots;
 			AnalyzeBuffers B = c->ab;
@@ -598,8 +612,8 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		seq[0] = c->ev[0]; seq[1] = seq[2] = seq[3] = seq[4] = after_main;
 		if(fused) seq[5] = seq[6] = c->ev[3];
 		else {
-			if(tail_n) { (void)hipEventRecord(c->ev[2], s); seq[5] = c->ev[2]; }
-			else { (void)hipEventRecord(c->pev[0], s); seq[1] = seq[2] = seq[3] = seq[4] = seq[5] = c->pev[0]; }
+			if(tail_n) { if(timed) (void)hipEventRecord(c->ev[2], s); seq[5] = c->ev[2]; }
+			else { if(timed) (void)hipEventRecord(c->pev[0], s); seq[1] = seq[2] = seq[3] = seq[4] = seq[5] = c->pev[0]; }
 			seq[6] = c->ev[3];
 		}
 	}
@@ -625,11 +639,11 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		}
 		c->hint_count = 0;
 		// the per-kernel events of the single-stream path are not meaningful here: everything is booked under "pack"
-		(void)hipEventRecord(c->ev[2], s);
+		if(timed) (void)hipEventRecord(c->ev[2], s);
 		seq[0] = seq[1] = seq[2] = seq[3] = seq[4] = c->ev[0]; seq[5] = c->ev[2]; seq[6] = c->ev[3];
 	}
 	else {
-		if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, c->ab, c->d_decisions, c->pev, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
+		if(launch_analyze(P, d_pcm, c->d_windows, c->d_tail_windows, nframes, tail_n, c->d_jobtab, c->d_jobtab + 1, c->h_jobtab[0].nsets, c->ab, c->d_decisions, timed ? c->pev : nullptr, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		if(c->ab.dbg) {
 			// development aid: average shader cycles per phase of the eval workgroups of this launch
 			const size_t nwg = (size_t)nframes * P.ncand;
@@ -662,7 +676,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 			free(h);
 			(void)hipMemsetAsync(c->ab.dbg, 0, nwg * 16 * sizeof(unsigned long long), s);
 		}
-		(void)hipEventRecord(c->ev[1], s);
+		if(timed) (void)hipEventRecord(c->ev[1], s);
 		{
 			uint32_t hinted = 0;
 			// (not with the debug stamps: they are indexed by workgroup, the fused output takes frames in dispatch order)
@@ -685,14 +699,14 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
 		// without LPC analyses nothing is launched between the prep and the evaluation phase, and no event is recorded there
 		seq[0] = c->ev[0]; seq[1] = c->pev[0]; seq[2] = lpc ? c->pev[1] : c->pev[0]; seq[3] = lpc ? c->pev[2] : c->pev[0]; seq[4] = c->ev[1];
 		if(fused) seq[5] = seq[6] = c->ev[3];
-		else { (void)hipEventRecord(c->ev[2], s); seq[5] = c->ev[2]; seq[6] = c->ev[3]; }
+		else { if(timed) (void)hipEventRecord(c->ev[2], s); seq[5] = c->ev[2]; seq[6] = c->ev[3]; }
 	}
 	if(fused) { note_launch(K_FUSED_OUTPUT); c->fo_last_fused = po.epoch; }
 	if(!fused) {
 		if(launch_scan(fb, nframes, c->d_offsets, tot, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 		if(launch_compact(c->d_slots, P.slot_bytes, fb, c->d_offsets, d_out, out_cap, nframes, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	}
-	(void)hipEventRecord(c->ev[3], s);
+	if(timed) (void)hipEventRecord(c->ev[3], s);
 	if(d_fb_out && fb != d_fb_out && hipMemcpyAsync(d_fb_out, fb, nframes * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	if(d_total_out && tot != d_total_out && hipMemcpyAsync(d_total_out, tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return FLACGPU_ERR_LAUNCH;
 	c->last_nframes = nframes;

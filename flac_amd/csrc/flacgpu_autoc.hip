@@ -339,7 +339,7 @@ __device__ __forceinline__ void a3_fetch(const A2Job &J, const int2 *__restrict_
 }
 // any_wasted: some subframe of the wavefront has wasted bits (wave-uniform; without, the shifts and their counts are not issued)
 template <bool PLANES>
-__device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /* [16]: the four wasted-bits counts of a frame, a byte each */, bool any_wasted, uint32_t half, const A3Fetch &F, uint32_t col)
+__device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /* [16]: the four wasted-bits counts of a frame, a byte each */, bool any_wasted, uint32_t half, const A3Fetch &F, uint32_t col, bool tune_no_flat)
 {
 	if(any_wasted) {
 #pragma unroll
@@ -352,6 +352,23 @@ __device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /*
 			row[1 * A3_ST] = a2_value(r, (w4 >> 8) & 0xffu, F.wt);
 			row[2 * A3_ST] = a2_value((l + r) >> 1, (w4 >> 16) & 0xffu, F.wt);
 			row[3 * A3_ST] = a2_value(l - r, w4 >> 24, F.wt);
+		}
+	}
+	else if(__all((int)(F.wt == 1.0f)) && !tune_no_flat) {
+		// every column of this tile lies on the window's flat part (five sixths of a tukey(0.5 / 3) block, all of a partial window's
+		// middle): fma(x, 1.0f, +0) is x bit for bit -- (float) of an integer is never -0 -- so the 32 multiplies of the lane are not
+		// issued (round 6; wave-uniform: one compare and a branch per tile)
+#pragma unroll
+		for(int q = 0; q < 8; q++) {
+			const uint32_t fr = 2u * (uint32_t)q + half;
+			const int32_t l = F.v[q].x, r = F.v[q].y;
+			int32_t lr = l + r;
+			if(PLANES) asm("v_add_u32 %0, %1, %2" : "=v"(lr) : "v"(l), "v"(r));
+			float *row = tile + fr * 4u * A3_ST + col;
+			row[0 * A3_ST] = (float)l;
+			row[1 * A3_ST] = (float)r;
+			row[2 * A3_ST] = (float)(lr >> 1);
+			row[3 * A3_ST] = (float)(l - r);
 		}
 	}
 	else {
@@ -434,8 +451,9 @@ __device__ __forceinline__ void a3_store_ind(float *tile, uint32_t half, const A
 template <int VARIANT, int LAG, bool SETS, int SRC>
 __global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(const DevParams P, const int32_t *__restrict__ pcm, const float *__restrict__ windows,
                                                        uint32_t nmain, const JobTable *__restrict__ jt, const ChanPrep *__restrict__ preps,
-                                                       double *__restrict__ autoc_out)
+                                                       double *__restrict__ autoc_out, uint32_t no_flat_arg)
 {
+	const bool no_flat = no_flat_arg != 0;                          // (FLACGPU_NO_FLAT=1: the window multiply on every tile, for A/B runs)
 	__shared__ float tile[A3_ITEMS * A3_ST];
 	__shared__ uint32_t wasted4[A3_ITEMS / 4];
 	constexpr bool PLANES = SRC == 1, IND = SRC == 2;
@@ -500,7 +518,7 @@ __global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(
 #pragma unroll
 	for(int j = 0; j < LAG; j++) { acc[j][0] = 0.0; acc[j][1] = 0.0; acc[j][2] = 0.0; acc[j][3] = 0.0; }
 #define A3_FETCH(idx) do { if constexpr(IND) a3_fetch_ind(J, pcm, P.chan_stride, fc0, nfc, half, is16, kind, (idx), G); else a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (idx), F); } while(0)
-#define A3_STORE(col) do { if constexpr(IND) a3_store_ind(tile, half, G, (col)); else a3_store<PLANES>(tile, wasted4, any_wasted, half, F, (col)); } while(0)
+#define A3_STORE(col) do { if constexpr(IND) a3_store_ind(tile, half, G, (col)); else a3_store<PLANES>(tile, wasted4, any_wasted, half, F, (col), no_flat); } while(0)
 	double w[HB + A3_T];              // w[HB + c] = d[first sample of the tile + c]
 	A3Fetch F;
 	A3FetchInd G;
@@ -694,8 +712,8 @@ static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const int32_
 		const uint32_t simds = 1024;
 		const bool by_sets = nsets >= 2 && nsets <= 8 && (isets == 1 || (isets == 2 && njobs * ngroups > simds && nsets * ngroups <= simds));
 		note_launch(K_AUTOC3 | K_AUTOC3_PLANES | K_AUTOC1 | (by_sets ? K_AUTOC3_SETS : 0u));
-		if(by_sets) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 2>), dim3(nsets * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
-		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 2>), dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc);
+		if(by_sets) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 2>), dim3(nsets * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc, (uint32_t)tune().no_flat);
+		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 2>), dim3(njobs * ngroups), dim3(64), 0, s, P, chan, win, nmain, jt, preps, autoc, (uint32_t)tune().no_flat);
 		return;
 	}
 	// 16-bit input: the prep kernel's left and right planes are 16-bit pairs (ChanPrep::fmt = 1 whenever sbps <= 16) -- read those
@@ -704,11 +722,11 @@ static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const int32_
 	const int32_t *src = pl ? chan : pcm;
 	note_launch(K_AUTOC3 | (pl ? K_AUTOC3_PLANES : 0u) | (sets && nsets >= 2 && nsets <= 8 ? K_AUTOC3_SETS : 0u));
 	if(sets && nsets >= 2 && nsets <= 8) {
-		if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 1>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
-		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 0>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
+		if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 1>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc, (uint32_t)tune().no_flat);
+		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 0>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc, (uint32_t)tune().no_flat);
 	}
-	else if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 1>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
-	else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 0>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc);
+	else if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 1>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc, (uint32_t)tune().no_flat);
+	else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, false, 0>), dim3(njobs * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc, (uint32_t)tune().no_flat);
 }
 
 template <int VARIANT, int LAG>

@@ -838,6 +838,7 @@ static void *bringup_main(void *arg)
 	}
 	if(r == FLACGPU_OK) r = flacgpu_create(&p->bring_cfg, windows, &gpu);
 	p->windows = windows; p->wcount = windows ? (size_t)s->num_apodizations * s->blocksize : 0;     /* kept: the key of a parked engine */
+	if(r == FLACGPU_OK) (void)flacgpu_set_phase_timing(gpu, 0);      /* nobody reads per-kernel times through the libFLAC API: no event records */
 	if(r == FLACGPU_OK && s->verify) r = flacgpu_set_verify(gpu, 1);
 	const double t1 = now_s();
 	if(r == FLACGPU_OK)

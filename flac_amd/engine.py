@@ -397,9 +397,19 @@ class FrameEngine:
         """per-kernel ms of a recent batch (0 = the last): prep, autoc, model, eval, pack, scan+compact"""
         ms = (C.c_float * 6)()
         r = self.lib.flacgpu_batch_phase_ms(self.ctx, batches_ago, C.byref(ms))
+        if r == 1:
+            return None                                  # that batch carried no timing events (set_phase_timing)
         if r != 0:
             raise FlacGpuError("flacgpu_batch_phase_ms: %s" % self.lib.flacgpu_strerror(r).decode())
         return dict(zip(("prep", "autoc", "model", "eval", "pack", "scan_compact"), [float(v) for v in ms]))
+
+    def set_phase_timing(self, every):
+        """phase timing on every n-th batch (1: all, the default; 0: none): the event records are instrumentation, not work"""
+        self.lib.flacgpu_set_phase_timing.restype = C.c_int
+        self.lib.flacgpu_set_phase_timing.argtypes = [C.c_void_p, C.c_uint32]
+        r = self.lib.flacgpu_set_phase_timing(self.ctx, every)
+        if r != 0:
+            raise FlacGpuError("flacgpu_set_phase_timing: %s" % self.lib.flacgpu_strerror(r).decode())
 
     def last_kernel_ms(self):
         a, p, k = C.c_float(), C.c_float(), C.c_float()

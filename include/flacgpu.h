@@ -268,6 +268,10 @@ int flacgpu_last_batch_phase_ms(flacgpu_ctx *ctx, float ms[6]);
 /* The same for the batch launched `batches_ago` batches before the last one (0 = the last; the engine keeps the
  * events of its 64 most recent batches), so that a run of batches can be timed without a host sync in between. */
 int flacgpu_batch_phase_ms(flacgpu_ctx *ctx, uint32_t batches_ago, float ms[6]);
+/* The phase times are instrumentation: six event records per batch, ~4.6 us of the stream each (1.4 % of a -8 step of 16384 frames,
+ * a fifth of a -0 step).  every = 1 (default): each batch carries them; n: every n-th batch; 0: none.  flacgpu_batch_phase_ms
+ * returns 1 (and zeros) for a batch that carried none.  The libFLAC API layer, which never reads them, runs with 0. */
+int flacgpu_set_phase_timing(flacgpu_ctx *ctx, uint32_t every);
 /* Which kernels the most recent batch launched: a bit per kernel (family / flavour); flacgpu_kernel_bit_name(bit) names bit
  * `bit` (NULL past the last).  The engine picks kernels by stream shape and batch size; tests that pin a
  * selection -- "the full-size -8 batch runs autoc3_kernel<SETS,PLANES> and the fused output" -- assert on this. */

@@ -48,6 +48,7 @@ int flacgpu_config_check(const flacgpu_config *cfg) { return cfg && cfg->abi_ver
 size_t flacgpu_config_max_output_bytes(const flacgpu_config *cfg, uint32_t nframes) { (void)cfg; return (size_t)nframes * 32; }
 const char *flacgpu_strerror(int code) { (void)code; return "fake engine"; }
 int flacgpu_set_verify(flacgpu_ctx *ctx, uint32_t on) { ctx->verify = on; return FLACGPU_OK; }
+int flacgpu_set_phase_timing(flacgpu_ctx *ctx, uint32_t every) { (void)ctx; (void)every; return FLACGPU_OK; }
 int flacgpu_last_verify_result(flacgpu_ctx *ctx, flacgpu_verify_result *out) { (void)ctx; memset(out, 0, sizeof *out); return FLACGPU_OK; }
 
 int64_t flacgpu_encode_batch_raw(flacgpu_ctx *ctx, const void *raw, const flacgpu_raw_format *fmt, uint32_t nframes,
