@@ -190,6 +190,58 @@ def cpu_baseline(level, search=None):
 # ------------------------------------------------------------------------------------------------------------------
 # after the timed region: the frames of the last step, checked
 # ------------------------------------------------------------------------------------------------------------------
+def libflac_api_figures(pcm_h, nframes, block, level, d_out, total_bytes):
+    """FLAC__stream_encoder_process_interleaved through libFLACgpu.so from a C client, file-less write callback (src/libFLAC/
+    stream_encoder.c:2513, 2570, 3448, 3666-3686): rates, and two checks of what came out -- the frames of the whole stream equal the
+    device-path step's bytes (which the line's `verified` holds to the oracle), and the first 512 frames' stream equals, byte for
+    byte and metadata included, what the reference library writes for the same calls."""
+    import json as _json
+    import subprocess as _sp
+    import tempfile as _tf
+    tool = os.path.join(ROOT, "flac_amd", "lib", "api_bench")
+    ref_tool = os.path.join(ROOT, "oracle", "_ref", "api_bench_ref")
+    if not os.path.exists(tool):
+        return {"error": "flac_amd/lib/api_bench not built"}
+    n = nframes * block
+    d = _tf.mkdtemp(prefix="flacgpu_api_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out = {}
+    try:
+        src = os.path.join(d, "pcm.i32")
+        np.ascontiguousarray(pcm_h[:n], dtype=np.int32).tofile(src)
+
+        def run(binary, samples, md5, streams, reps, dump=None):
+            cmd = [binary, src, str(samples), "0", str(level), str(md5), str(streams), str(reps)] + ([dump] if dump else [])
+            r = _sp.run(cmd, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0 or not r.stdout.strip():
+                raise RuntimeError("%s: rc %d %s" % (os.path.basename(binary), r.returncode, r.stderr[-300:]))
+            return _json.loads(r.stdout.strip().splitlines()[-1])
+        dump = os.path.join(d, "gpu.flac")
+        a = run(tool, n, 0, 1, 3, dump)
+        stream = np.fromfile(dump, dtype=np.uint8)
+        head = len(stream) - total_bytes
+        frames_equal = bool(head > 0 and np.array_equal(stream[head:], d_out[:total_bytes].cpu().numpy()))
+        b = run(tool, n, 1, 1, 2)
+        k = max(2, min(16, usable_cpus()[0]))
+        c = run(tool, n, 1, k, 2)
+        out = {"one_stream_md5_off_Msamples_per_s": a["Msamples_per_s"], "one_stream_md5_on_Msamples_per_s": b["Msamples_per_s"],
+               "streams_at_once": k, "streams_at_once_md5_on_Msamples_per_s": c["Msamples_per_s"], "samples_per_stream": n,
+               "seconds": {"one_md5_off": a["seconds_best"], "one_md5_off_first_call_incl_runtime_start": a["seconds_first"], "one_md5_on": b["seconds_best"], "streams_md5_on": c["seconds_best"]},
+               "frames_equal_the_device_step": frames_equal, "streams_identical": bool(c["streams_identical"]),
+               "what": "libFLACgpu.so from one C thread per stream: FLAC__stream_encoder_init_stream (write/seek/tell callbacks to memory), process_interleaved in 1 Mi-sample calls from host memory, finish; best of the repetitions (the first includes the HIP runtime's start)"}
+        prefix = min(512 * block, n)
+        if os.path.exists(ref_tool):
+            g, r = os.path.join(d, "g.flac"), os.path.join(d, "r.flac")
+            run(tool, prefix, 1, 1, 1, g)
+            rr = run(ref_tool, prefix, 1, 1, 1, r)
+            out["prefix_file_equals_reference"] = bool(open(g, "rb").read() == open(r, "rb").read())
+            out["reference_same_call_Msamples_per_s"] = rr["Msamples_per_s"]
+        out["verified_ok"] = bool(frames_equal and out.get("prefix_file_equals_reference", False) and a["ok"] and b["ok"] and c["ok"] and c["streams_identical"])
+    finally:
+        import shutil as _sh
+        _sh.rmtree(d, ignore_errors=True)
+    return out
+
+
 def verify_step(pcm_h, out_bytes, fb, first_frame, level, block, nsample=96, search=None):
     """every CRC-16 recomputed on the host; `nsample` frames (the ends of the batch, the XCD remap boundaries, random ones)
     re-encoded by the oracle with their frame number and compared byte for byte"""
@@ -300,6 +352,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the white-noise and -5 side measurements")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the last step's frames (outside the timed region)")
     ap.add_argument("--timing-every", type=int, default=1, help="per-kernel HIP-event timing on every n-th step of the timed region (1: every step)")
+    ap.add_argument("--no-api", action="store_true", help="skip the libflac_api side figures (the libFLAC encoder API driven by a C client, outside the timed region)")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode_only side figure (the step's output decoded again as a bare stream, outside the timed region)")
     ap.add_argument("--hires", action="store_true", help="96 kHz / 24-bit stereo (BASELINE.json config 4): a side measurement")
     ap.add_argument("--white", action="store_true", help="white-noise corpus as the main measurement (side measurement)")
@@ -498,6 +551,14 @@ def main():
                 del d_dec
             except Exception as e:
                 res["decode_only"] = {"error": repr(e)}
+        if rank == 0 and gp is None and not use_dist and not args.no_verify and not args.no_api and level == LEVEL and kind == main_kind and not args.hires:
+            # side measurement, outside the timed region: the boundary north_star names -- FLAC__stream_encoder_* --
+            # driven by a C client (flac_amd/lib/api_bench <- flac_amd/csrc/tools/api_bench.c) on this step's PCM from host memory:
+            # one stream with MD5 off and on (the API's default), and K streams at once with MD5 on
+            try:
+                res["libflac_api"] = libflac_api_figures(pcm_h, nframes, block, level, d_out, int(d_total.item()))
+            except Exception as e:
+                res["libflac_api"] = {"error": repr(e)}
         verified = None
         if use_dist and not args.no_verify:
             # the multi-rank check, outside the timed region: EVERY rank's frames of the last step
@@ -659,6 +720,8 @@ def main():
             line["device_verify"] = m["device_verify"]
         if "decode_only" in m:
             line["decode_only"] = m["decode_only"]
+        if "libflac_api" in m:
+            line["libflac_api"] = m["libflac_api"]
         if multi:
             wins = m.get("gather_windows") or []
             wms = [w["ms"] for w in wins if w["ms"] is not None]

@@ -293,7 +293,7 @@ static int stage_pool_run(struct stage_pool *sp, int (*fn)(const void *, size_t,
 }
 
 /* ------------------------------------------------------------------------------------------------
- * One parked engine per process.  Creating an engine costs 30 ms in a warm process (device buffers, 17 streams, 500 events),
+ * Parked engines.  Creating an engine costs 30 ms in a warm process (device buffers, 17 streams, 500 events),
  * releasing it and its page-locked slots 40 ms: together as long as 130 M samples take to pass through it.  A program that
  * encodes one stream after another with the same settings -- `flac *.wav` is one -- gets the previous stream's engine and
  * slots back instead.  finish() parks them here when the stream ended without an engine error; init_*() takes them when the
@@ -310,10 +310,19 @@ struct engine_bundle {
 	int registered[2 * NSLOT];
 	size_t raw_bytes, out_cap;
 };
+/* Round 6: a pool, not one -- a program that encodes K streams at once (a thread and an encoder each: bench.py's libflac_api figure,
+ * a ripper's worker pool) parks K engines when they finish and gets K back for its next K streams; with one place to park, K - 1
+ * of them were created and destroyed per round, 70 ms each and one after the other inside the HIP runtime: 16 streams of 67 M
+ * samples took 1.97 s, 1.6 of them that.  A sequential program still holds exactly one.  FLACGPU_ENGINE_CACHE=n: at most n (default
+ * 16, 0: none). */
+#define PARK_MAX 16
 static pthread_mutex_t g_park_mu = PTHREAD_MUTEX_INITIALIZER;
-static struct engine_bundle g_park;
-static int g_park_valid;
-static int parking_enabled(void) { const char *v = getenv("FLACGPU_ENGINE_CACHE"); return !(v && atoi(v) == 0); }
+static struct engine_bundle g_park[PARK_MAX];
+static int g_park_valid[PARK_MAX];
+static unsigned g_park_clock, g_park_age[PARK_MAX];
+static int parking_limit(void) { const char *v = getenv("FLACGPU_ENGINE_CACHE"); int n = v ? atoi(v) : PARK_MAX; return n < 0 ? 0 : n > PARK_MAX ? PARK_MAX : n; }
+static int parking_enabled(void) { return parking_limit() > 0; }
+static int park_any(void) { int any = 0; for(int i = 0; i < PARK_MAX; i++) any |= g_park_valid[i]; return any; }      /* (under g_park_mu) */
 static void bundle_destroy(struct engine_bundle *b)
 {
 	for(int i = 0; i < NSLOT; i++) {
@@ -325,33 +334,49 @@ static void bundle_destroy(struct engine_bundle *b)
 	if(b->gpu) flacgpu_destroy(b->gpu);
 	memset(b, 0, sizeof *b);
 }
-/* the parked engine if it serves `cfg` (capacity: at least cfg->max_batch_frames) with these window tables */
+/* a parked engine that serves `cfg` (capacity: at least cfg->max_batch_frames) with these window tables */
 static int park_take(const flacgpu_config *cfg, const float *windows, size_t wcount, size_t raw_bytes, size_t out_cap, struct engine_bundle *out)
 {
 	int hit = 0;
 	pthread_mutex_lock(&g_park_mu);
-	if(g_park_valid) {
-		flacgpu_config a = g_park.cfg, b = *cfg;
-		const int roomy = a.max_batch_frames >= b.max_batch_frames && g_park.raw_bytes >= raw_bytes && g_park.out_cap >= out_cap;
+	for(int i = 0; i < PARK_MAX && !hit; i++) {
+		if(!g_park_valid[i]) continue;
+		flacgpu_config a = g_park[i].cfg, b = *cfg;
+		const int roomy = a.max_batch_frames >= b.max_batch_frames && g_park[i].raw_bytes >= raw_bytes && g_park[i].out_cap >= out_cap;
 		a.max_batch_frames = b.max_batch_frames = 0;
-		if(roomy && memcmp(&a, &b, sizeof a) == 0 && g_park.wcount == wcount && (wcount == 0 || memcmp(g_park.windows, windows, wcount * sizeof(float)) == 0)) {
-			*out = g_park;
-			g_park_valid = 0;
+		if(roomy && memcmp(&a, &b, sizeof a) == 0 && g_park[i].wcount == wcount && (wcount == 0 || memcmp(g_park[i].windows, windows, wcount * sizeof(float)) == 0)) {
+			*out = g_park[i];
+			g_park_valid[i] = 0;
 			hit = 1;
 		}
 	}
 	pthread_mutex_unlock(&g_park_mu);
 	return hit;
 }
+static int bundle_same_settings(const struct engine_bundle *x, const struct engine_bundle *y)
+{
+	flacgpu_config a = x->cfg, b = y->cfg;
+	a.max_batch_frames = b.max_batch_frames = 0;
+	return memcmp(&a, &b, sizeof a) == 0 && x->wcount == y->wcount && (x->wcount == 0 || memcmp(x->windows, y->windows, x->wcount * sizeof(float)) == 0);
+}
+/* engines of OTHER settings go when one is parked (a program that changes its settings from stream to stream holds one engine, as
+ * before); engines of the same settings gather, up to the limit: those are streams that ran side by side */
 static void park_put(struct engine_bundle *b)
 {
-	struct engine_bundle old;
-	int had;
+	struct engine_bundle gone[PARK_MAX];
+	int ngone = 0, slot = -1;
+	const int limit = parking_limit();
 	pthread_mutex_lock(&g_park_mu);
-	had = g_park_valid; old = g_park;
-	g_park = *b; g_park_valid = 1;
+	for(int i = 0; i < PARK_MAX; i++) if(g_park_valid[i] && (i >= limit || !bundle_same_settings(&g_park[i], b))) { gone[ngone++] = g_park[i]; g_park_valid[i] = 0; }
+	for(int i = 0; i < limit && slot < 0; i++) if(!g_park_valid[i]) slot = i;
+	if(slot < 0) {          /* full: the one parked longest makes room */
+		slot = 0;
+		for(int i = 1; i < limit; i++) if((int)(g_park_age[i] - g_park_age[slot]) < 0) slot = i;
+		gone[ngone++] = g_park[slot];
+	}
+	g_park[slot] = *b; g_park_valid[slot] = 1; g_park_age[slot] = ++g_park_clock;
 	pthread_mutex_unlock(&g_park_mu);
-	if(had) bundle_destroy(&old);
+	for(int i = 0; i < ngone; i++) bundle_destroy(&gone[i]);
 	memset(b, 0, sizeof *b);
 }
 
@@ -1123,7 +1148,7 @@ static FLAC__StreamEncoderInitStatus init_common(FLAC__StreamEncoder *e, FLAC__S
 			p->raw_bytes = (size_t)p->width * s->channels * ((size_t)p->batch_frames * s->blocksize + 1);
 			p->windows = 0; p->wcount = 0; p->engine_failed = 0;
 			pthread_mutex_lock(&g_park_mu);
-			const int maybe = g_park_valid && parking_enabled();
+			const int maybe = park_any() && parking_enabled();
 			pthread_mutex_unlock(&g_park_mu);
 			if(maybe) {
 				const size_t wcount = s->max_lpc_order > 0 ? (size_t)s->num_apodizations * s->blocksize : 0;
