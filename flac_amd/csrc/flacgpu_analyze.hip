@@ -629,82 +629,7 @@ __device__ __forceinline__ uint32_t owner_stride_words(uint32_t S, bool packed)
 	return w | 1u;
 }
 
-// Rice search over the partition orders for leaf sums held one per lane group (stream_encoder.c:4701-5075).
-// v: this lane's |residual| sum over its S samples; e = 6 - max_po: 2^e adjacent lanes form a leaf partition.
-__device__ __forceinline__ uint32_t rice_search_owner(uint64_t v, bool narrow, uint32_t e, uint32_t n, uint32_t order, uint32_t max_po, uint32_t min_po,
-                                                      uint32_t rice_limit, const uint32_t *divtab, uint8_t *kout, uint32_t *best_po_out, int lane)
-{
-	for(uint32_t m = 0; m < e; m++) v += shfl_xor_u64(v, 1 << m);
-	if(narrow) v = (uint32_t)v;
-	uint64_t vlev[7];
-	vlev[0] = v;
-#pragma unroll
-	for(int d = 1; d <= 6; d++) {
-		if((uint32_t)d <= max_po - min_po) v += shfl_xor_u64(v, 1 << (e + d - 1));
-		vlev[d] = v;
-	}
-	uint32_t klev[7];
-	uint64_t blev[7];
-	bool big = false;
-#pragma unroll
-	for(int d = 0; d <= 6; d++) {
-		klev[d] = 0; blev[d] = 0;
-		if((uint32_t)d <= max_po - min_po) {
-			const uint32_t po = max_po - (uint32_t)d;
-			const uint32_t g = e + (uint32_t)d;                        // log2 lanes per partition at this order
-			const uint32_t pidx = (uint32_t)lane >> g;
-			const bool rep = ((uint32_t)lane & ((1u << g) - 1u)) == 0;
-			const uint32_t o = pidx == 0 ? order : 0;
-			const uint32_t ns = (n >> po) - o;
-			const uint32_t div = divtab[po * (MAX_ORDER + 1) + o];
-			const uint64_t sum = vlev[d];
-			uint32_t k;
-			if(sum < 2 || (((sum - 1) * div) >> 18) == 0) k = 0;
-			else k = ilog2_u64(((sum - 1) * div) >> 18) + 1;
-			if(k >= rice_limit) k = rice_limit - 1;
-			uint64_t bb = 4 + (uint64_t)(1 + k) * ns + (k ? (sum >> (k - 1)) : (sum << 1)) - (ns >> 1);
-			if(bb > 0xffffffffull) bb = 0xffffffffull;
-			klev[d] = k;
-			blev[d] = rep ? bb : 0;
-			big |= rep && bb >= (1ull << 25);
-		}
-	}
-	if(!__any((int)big)) {
-		uint32_t t[7];
-#pragma unroll
-		for(int d = 0; d <= 6; d++) t[d] = (uint32_t)blev[d];
-#pragma unroll
-		for(int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-			for(int d = 0; d <= 6; d++) t[d] += __shfl_xor(t[d], off);
-		}
-#pragma unroll
-		for(int d = 0; d <= 6; d++) blev[d] = t[d];
-	}
-	else {
-#pragma unroll
-		for(int d = 0; d <= 6; d++) blev[d] = wave_reduce_add_u64(blev[d]);
-	}
-	uint32_t best_bits = 0, best_po = 0;
-#pragma unroll
-	for(int d = 0; d <= 6; d++) {
-		if((uint32_t)d <= max_po - min_po) {
-			const uint64_t tot = 6 + blev[d];
-			const uint32_t bits = tot >= 0xffffffffull ? 0xffffffffu : (uint32_t)tot;
-			if(best_bits == 0 || bits < best_bits) { best_bits = bits; best_po = max_po - (uint32_t)d; }
-		}
-	}
-	const uint32_t db = max_po - best_po;
-	uint32_t kk = 0;
-#pragma unroll
-	for(int d = 0; d <= 6; d++) if((uint32_t)d == db) kk = klev[d];
-	const uint32_t g = e + db;
-	if(((uint32_t)lane & ((1u << g) - 1u)) == 0) kout[(uint32_t)lane >> g] = (uint8_t)kk;
-	__builtin_amdgcn_wave_barrier();
-	*best_po_out = best_po;
-	return best_bits;
-}
-
+// (rice_search_owner, the same search on 64-bit leaf sums: flacgpu_devfn.h since round 6 -- the deciding prep kernel runs it on wide samples)
 // (rice_node_small / rice_search_nodes: flacgpu_devfn.h -- the prep kernel of the fixed-predictor presets runs them, too)
 // |residual| without forming the residual.  With p = sum >> shift (arithmetic) the reference's residual is x - p.
 // Start the wrapping tap sum at 2^31: (sum + 2^31) >> shift LOGICAL = p + 2^(31-shift) =: p + bias, exactly, and

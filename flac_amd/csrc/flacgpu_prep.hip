@@ -67,9 +67,12 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 	// DECIDE: [divisor table][per wavefront: chunk sums 5 x nchunks | the first chunk's extras 8 | Rice parameters 64 B] behind the staged channels
 	const uint32_t dz_base = (stereo_ms ? 2u : (C < 4 ? C : 4u)) * cbytes;
 	uint32_t *dz_divtab = (uint32_t *)(smem + dz_base);
-	const uint32_t dz_wbytes = (5 * nchunks + 8) * 4 + 64;
+	// (WIDE: a chunk's sum of fourth differences of 25-bit samples does not fit 32 bits: 64-bit chunk sums, the extras and parameters behind them)
+	constexpr uint32_t CSB = WIDE ? 8u : 4u;
+	const uint32_t dz_wbytes = 5 * nchunks * CSB + 8 * 4 + 64;
 	uint32_t *dz_csum = (uint32_t *)(smem + dz_base + P2_DIVTAB_BYTES + (size_t)wave * dz_wbytes);
-	uint32_t *dz_extra = dz_csum + 5 * nchunks;
+	uint64_t *dz_csum64 = (uint64_t *)dz_csum;
+	uint32_t *dz_extra = (uint32_t *)((unsigned char *)dz_csum + (size_t)5 * nchunks * CSB);
 	uint8_t *dz_kout = (uint8_t *)(dz_extra + 8);
 
 	for(uint32_t c0 = 0; c0 < C; c0 += G) {
@@ -181,17 +184,33 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 				}
 				if(DECIDE) {
 					uint32_t cs[5], ex[5] = {0, 0, 0, 0, 0};
-					if(mode == 3) prep2_chunk<WIDE, true, true, (int)CH>(x, ch == 0, first, A, cs, ex);
-					else prep2_chunk<WIDE, false, true, (int)CH>(x, ch == 0, first, A, cs, ex);
+					// A lane's chunk is summed in 32 bits wherever that cannot wrap: |d4| <= 16 max|x|, so 16 (18) of them stay below 2^32 for
+					// samples of up to 24 bits -- and for the 25-bit side channel at 16 per chunk (256 (2^24 - 1)), not at 18.  Only that one
+					// case adds every |difference| to the 64-bit totals (two instructions instead of one, twenty times per sample; until
+					// round 6 every channel of a > 20-bit stream paid that).
+					constexpr bool SIDE64 = WIDE && CH > 16;
+					uint64_t before[5];
+					if(SIDE64 && mode == 3) {
 #pragma unroll
-					for(int k = 0; k < 5; k++) dz_csum[(uint32_t)k * nchunks + ch] = cs[k];
+						for(int k = 0; k < 5; k++) before[k] = A.e[k];
+					}
+					if(mode == 3) prep2_chunk<SIDE64, true, true, (int)CH>(x, ch == 0, first, A, cs, ex);
+					else prep2_chunk<false, false, true, (int)CH>(x, ch == 0, first, A, cs, ex);
+					if(WIDE) {
+#pragma unroll
+						for(int k = 0; k < 5; k++) dz_csum64[(uint32_t)k * nchunks + ch] = (SIDE64 && mode == 3) ? A.e[k] - before[k] : (uint64_t)cs[k];
+					}
+					else {
+#pragma unroll
+						for(int k = 0; k < 5; k++) dz_csum[(uint32_t)k * nchunks + ch] = cs[k];
+					}
 					if(ch == 0) {
 #pragma unroll
 						for(int k = 0; k < 5; k++) dz_extra[k] = ex[k];
 					}
 				}
-				else if(mode == 3) prep2_chunk<WIDE, true, false, (int)CH>(x, ch == 0, first, A);
-				else prep2_chunk<WIDE, false, false, (int)CH>(x, ch == 0, first, A);
+				else if(mode == 3) prep2_chunk<(WIDE && CH > 16), true, false, (int)CH>(x, ch == 0, first, A);      // (see above: only the side channel at 18 per chunk)
+				else prep2_chunk<false, false, false, (int)CH>(x, ch == 0, first, A);
 			}
 			A.orv = wave_or_u32(A.orv);
 			A.diff = wave_or_u32(A.diff);
@@ -269,19 +288,29 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 				const uint32_t fmin = umin32(P.min_po, fmax), e = 6 - fmax, cpp = (n >> fmax) / CH;
 				__builtin_amdgcn_wave_barrier();                                       // this wavefront's chunk sums are in LDS
 				uint32_t v = 0;
+				uint64_t v64 = 0;
 				if(((uint32_t)lane & ((1u << e) - 1u)) == 0) {
 					const uint32_t pidx = (uint32_t)lane >> e;
-					const uint32_t *cs = dz_csum + fixed_order * nchunks + pidx * cpp;
 					uint64_t sum = 0;
-					for(uint32_t c = 0; c < cpp; c++) sum += cs[c];
+					if(WIDE) { const uint64_t *cs = dz_csum64 + fixed_order * nchunks + pidx * cpp; for(uint32_t c = 0; c < cpp; c++) sum += cs[c]; }
+					else { const uint32_t *cs = dz_csum + fixed_order * nchunks + pidx * cpp; for(uint32_t c = 0; c < cpp; c++) sum += cs[c]; }
 					if(pidx == 0) sum += dz_extra[fixed_order];
 					sum >>= wasted;
+					v64 = sum;
 					v = sum >= (1u << 23) ? (1u << 23) : (uint32_t)sum;
 				}
-				if(__any((int)(v >= (1u << 23)))) leave = true;
+				const bool bigleaf = __any((int)(v >= (1u << 23))) != 0;
+				if(bigleaf && !WIDE) leave = true;
 				else {
-					uint32_t po = 0;
-					const uint32_t rbits = rice_search_nodes(v, e, n, fixed_order, fmax, fmin, P.rice_limit, dz_divtab, dz_kout, &po, lane);
+					uint32_t po = 0, rbits;
+					if(!bigleaf) rbits = rice_search_nodes(v, e, n, fixed_order, fmax, fmin, P.rice_limit, dz_divtab, dz_kout, &po, lane);
+					else {
+						// leaf sums beyond the 32-bit node arithmetic (round 6: 17..24-bit input at -0..-2 used to go to eval_list_kernel's list
+						// here, every channel of it): the search on 64-bit sums, the leaf's lanes holding its sum between them
+						// (find_best_partition_order_ / set_partitioned_rice_, stream_encoder.c:4701-5075; :4814-4817 for `narrow`)
+						const bool narrow = (sbps + 4) < (32 - ilog2_u32(n >> fmax));
+						rbits = rice_search_owner(v64, narrow, e, n, fixed_order, fmax, fmin, P.rice_limit, dz_divtab, dz_kout, &po, lane);
+					}
 					const uint32_t est = sat_add_u32(hdr + fixed_order * sbps, rbits);
 					if(est > 0 && est < best_bits) { best_type = 2; best_bits = est; dpo = po; }
 				}
@@ -754,16 +783,19 @@ bool prep2_applicable(const DevParams &P)
 // prep2_kernel<.,.,true>: the presets whose only residual candidate is the guessed fixed order.  The leaf partitions must be whole
 // 16-sample chunks, the partition sums the reference's 32-bit ones (stream_encoder.c:4814), and eval_list_kernel (the lane-owner
 // evaluation) must be able to take what this kernel leaves behind.
+// the deciding kernel's wide flavour: chunk sums and leaf sums in 64 bits (17..24-bit input; the side channel has 25)
+static bool prep2_decide_wide(const DevParams &P) { return P.bps > 16; }
 static size_t prep2_decide_lds(const DevParams &P, uint32_t nraw, uint32_t waves)
 {
 	const uint32_t ch = p2_chunk_len(P.blocksize);
-	return (size_t)nraw * p2_chan_bytes(P.blocksize, ch) + P2_DIVTAB_BYTES + (size_t)waves * ((5 * (P.blocksize / ch) + 8) * 4 + 64);
+	return (size_t)nraw * p2_chan_bytes(P.blocksize, ch) + P2_DIVTAB_BYTES + (size_t)waves * (5 * (P.blocksize / ch) * (prep2_decide_wide(P) ? 8 : 4) + 8 * 4 + 64);
 }
 bool prep2_decides(const DevParams &P)
 {
 	const int off = tune().no_prep_decide;
 	if(off || !prep2_applicable(P) || prep3_applicable(P)) return false;
-	if(P.max_lpc_order != 0 || P.nfixed != 1 || P.ncslots != 1 || P.bps > 16 || P.tune_flags) return false;
+	if(P.max_lpc_order != 0 || P.nfixed != 1 || P.ncslots != 1 || P.bps > 24 || P.tune_flags) return false;
+	if(P.bps > 16 && tune().no_wide_decide) return false;
 	const uint32_t n = P.blocksize;
 	uint32_t fmax = 0;
 	{ uint32_t b = n; while(!(b & 1)) { fmax++; b >>= 1; } }
@@ -772,7 +804,8 @@ bool prep2_decides(const DevParams &P)
 	const uint32_t psize = n >> fmax;
 	uint32_t lg = 0;
 	while((2u << lg) <= psize) lg++;
-	if(!(psize % p2_chunk_len(n) == 0 && (P.bps + 1 + 4) < 32 - lg)) return false;
+	// (the 32-bit flavour: the partition sums are the reference's 32-bit ones, stream_encoder.c:4814; the wide one carries 64 bits)
+	if(!(psize % p2_chunk_len(n) == 0 && (prep2_decide_wide(P) || (P.bps + 1 + 4) < 32 - lg))) return false;
 	// the chunk sums of every wavefront behind the staged channels must still fit the LDS (6 channels x 8192 samples do not)
 	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;
 	const uint32_t nraw = stereo_ms ? 2u : (P.channels < 4 ? P.channels : 4u), waves = stereo_ms ? 4u : nraw;
@@ -791,7 +824,7 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 		hipError_t e = hipSuccess;
 #define P2ATTR(W, NF, DZ) if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep2_kernel<W, NF, DZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)
 		P2ATTR(false, 0, false); P2ATTR(false, 1152, false); P2ATTR(false, 4096, false); P2ATTR(true, 0, false); P2ATTR(true, 1152, false); P2ATTR(true, 4096, false);
-		P2ATTR(false, 0, true); P2ATTR(false, 1152, true);
+		P2ATTR(false, 0, true); P2ATTR(false, 1152, true); P2ATTR(true, 0, true); P2ATTR(true, 1152, true);
 #undef P2ATTR
 		if(e != hipSuccess) return e;
 		once.ok();
@@ -846,7 +879,11 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 		// (launch_model_eval then runs eval_list_kernel on what is left, and nothing else)
 		(void)hipMemsetAsync(B.nleft, 0, 2 * sizeof(uint32_t), s);
 		const size_t ldz = prep2_decide_lds(P, nraw, active);
-		if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
+		if(prep2_decide_wide(P)) {
+			if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<true, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
+			else hipLaunchKernelGGL((prep2_kernel<true, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
+		}
+		else if(P.blocksize == 1152) hipLaunchKernelGGL((prep2_kernel<false, 1152, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
 		else hipLaunchKernelGGL((prep2_kernel<false, 0, true>), dim3(nmain), dim3(64 * waves), ldz, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan, dec, B.left, B.nleft);
 		return hipGetLastError();
 	}
