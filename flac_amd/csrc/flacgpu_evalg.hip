@@ -115,7 +115,7 @@ struct EgSlot { uint32_t Q[7]; uint32_t shift, bias, order, npf, precision, ci; 
 // WPC wavefronts share a channel's image and split its candidates between them (each has its own search state; the better of their
 // first minima wins): an experiment in occupancy (the LDS image allows four one-wavefront channels per SIMD), opt-in, see launch_evalg.
 template <int MAXORD>
-__host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N, uint32_t wpc = 1) { return (N / 128) * EG_ROW + wpc * eg_tail_bytes<MAXORD>() + 64 + 128; }      // (+128: the half piece of a 16 k + 8 run loads four rows behind the image)
+__host__ __device__ inline uint32_t evalg_lds_bytes(uint32_t N, uint32_t wpc = 1) { return (N / 128) * EG_ROW + wpc * eg_tail_bytes<MAXORD>() + 64 + 128 + ((N / 64) % 8 ? 8 * EG_ROW : 0); }      // (+128: the half piece of a 16 k + 8 run loads four rows behind the image; runs of 16 k + 2 or + 4 samples: up to seven)
 constexpr int EG_PIECES_AHEAD = 8;        // 16-byte pieces of the planar channel a lane has in flight before its first use (8 = a 4096-sample block at WPC 1)
 
 // returns false when the channel is not this kernel's (the caller lists it)
@@ -146,7 +146,9 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 		for(int j = 0; j < MAXORD; j++) cq[j] = cd->q[j];
 	}
 	const uint4 *src = (const uint4 *)(chan + (size_t)fc * P.chan_stride);
-	const uint32_t nvec = n / 8, vps = S / 8;                                 // 16-byte pieces of the block, of a lane's run
+	// (runs that are no whole number of 16-byte pieces -- 18 or 36 samples: blocks of 1152 and 2304 -- are filled word by word below)
+	const bool by_words = (S % 8u) != 0;
+	const uint32_t nvec = by_words ? 0u : n / 8, vps = S / 8;                 // 16-byte pieces of the block, of a lane's run
 	uint4 pv[AHEAD];
 #pragma unroll
 	for(int i = 0; i < AHEAD; i++) { const uint32_t m = (uint32_t)tid + 64u * WPC * (uint32_t)i; if(m < nvec) pv[i] = src[m]; }
@@ -210,6 +212,15 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 				*(uint32_t *)(d) = pv[i].x; *(uint32_t *)(d + EG_ROW) = pv[i].y; *(uint32_t *)(d + 2 * EG_ROW) = pv[i].z; *(uint32_t *)(d + 3 * EG_ROW) = pv[i].w;
 			}
 		}
+		if(by_words) {
+			// word w of the block is word w % (S/2) of run w / (S/2)  (round 6: 1152- and 2304-sample blocks at the LPC presets)
+			const uint32_t wpr = S / 2, nwords = n / 2;
+			const uint32_t *srcw = (const uint32_t *)src;
+			for(uint32_t w = (uint32_t)tid; w < nwords; w += 64 * WPC) {
+				const uint32_t Lo = w / wpr, r = w - Lo * wpr;
+				*(uint32_t *)(smem + (Lo + 1) * 4 + r * EG_ROW) = srcw[w];
+			}
+		}
 		for(uint32_t m = (uint32_t)tid + 64u * WPC * AHEAD; m < nvec; m += 64 * WPC) {          // blocks of more than 4096 samples
 			const uint4 v = src[m];
 			const uint32_t Lo = spow2 ? m >> vlog : m / vps, r = m - Lo * vps;
@@ -265,12 +276,23 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 			v0 = fir16_dispatch<false>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
 			if(two) v1 = fir16_dispatch<false>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
 		}
-		if(S & 8u) {
-			// the half piece that ends the run (the words it loads behind the run are never used)
+		if(S & 15u) {
+			// the short piece that ends the run: 8 samples (4608-sample blocks), 4 (2304) or 2 (1152) -- the words it loads behind the run
+			// are never used
 			uint32_t AA[15], BB[14];
 			load_piece(own + (8 * npieces - 7) * EG_ROW, AA, BB);
-			v0 = fir16_dispatch<false, 8>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
-			if(two) v1 = fir16_dispatch<false, 8>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+			if((S & 15u) == 8u) {
+				v0 = fir16_dispatch<false, 8>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+				if(two) v1 = fir16_dispatch<false, 8>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+			}
+			else if((S & 15u) == 4u) {
+				v0 = fir16_dispatch<false, 4>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+				if(two) v1 = fir16_dispatch<false, 4>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+			}
+			else {
+				v0 = fir16_dispatch<false, 2>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+				if(two) v1 = fir16_dispatch<false, 2>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+			}
 		}
 		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_list_kernel's (nothing was written yet)
 		if(__any((int)((v0 | v1) >= (1u << 23)))) { if(WPC == 1) return false; leave = true; break; }
@@ -316,7 +338,8 @@ bool evalg_applicable(const DevParams &P)
 {
 	const int off = tune().no_evalg;
 	const uint32_t S = P.blocksize / 64;
-	return !off && P.blocksize % 64 == 0 && S >= 16 && S % 8 == 0 && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC && P.blocksize <= 16384;
+	const uint32_t tail = S % 16;                                           // a run's last piece: whole, or 8, 4 or 2 samples
+	return !off && P.blocksize % 64 == 0 && S >= 16 && (tail == 0 || tail == 8 || tail == 4 || tail == 2) && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC && P.blocksize <= 16384;
 }
 template <int MAXORD, int WPC>
 static hipError_t launch_evalg_t(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)

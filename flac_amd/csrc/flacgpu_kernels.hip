@@ -2227,6 +2227,14 @@ static bool pack2_applicable(const DevParams &P)
 	const uint32_t ps = P.blocksize >> P.max_po;
 	return P.blocksize % CHUNK == 0 && ps >= (uint32_t)CHUNK && ps % CHUNK == 0 && ((size_t)ps << P.max_po) == P.blocksize && !P.wide_samples && !P.img_global && !P.stream_sig;
 }
+// the one-wavefront instance whose threads own 18-sample runs (pack2_kernel<., false, 64, 18>): blocks that are a whole number of its
+// 1152-sample passes and whose Rice partitions are whole runs -- the presets' 1152 at any partition order down to 18 samples, 2304 at
+// its 36 (round 6: at the LPC presets these blocks went to the general pack_kernel, as long as everything else together)
+static bool pack2_run18_applicable(const DevParams &P)
+{
+	const uint32_t ps = P.blocksize >> P.max_po;
+	return P.blocksize % 1152u == 0 && ps >= 18u && ps % 18u == 0 && ((size_t)ps << P.max_po) == P.blocksize && !P.wide_samples && !P.img_global && !P.stream_sig;
+}
 static PackOut make_pack_out(const PackOutArgs *po)
 {
 	PackOut O;
@@ -2261,7 +2269,8 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 	if(hinted_frames) *hinted_frames = 0;
 	PackOut O = make_pack_out(nullptr);
 	if constexpr(MAXORD <= 16) {                  // predictors of more than 16 taps (-l 17..32) take the general kernel
-		if(pack2_applicable(P)) {
+		const bool run18_ok = pack2_run18_applicable(P) && !hints && !tune().no_run18;
+		if(pack2_applicable(P) || run18_ok) {
 			f_lo = tail_n ? nframes - 1 : nframes;
 			const size_t lds2 = ((sizeof(Pack2Shared) + 15) & ~(size_t)15) + P2_IMG_PAD + (size_t)P.slot_bytes + 16;
 			if(f_lo && po && po->out) {
@@ -2276,7 +2285,8 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			const bool no_run18 = tune().no_run18 != 0;
 			const uint32_t pstride = (uint32_t)pack_plan_stride(P);
 			if(f_lo) hipLaunchKernelGGL(pack_plan_kernel, dim3((f_lo + PLAN_FRAMES - 1) / PLAN_FRAMES), dim3(64), 0, s, P, make_hdr_const(P), f_lo, first, dec, plan, pstride, info);
-			const bool run18 = P.blocksize == 1152 && !hints && !no_run18 && (1152u >> P.max_po) % 18u == 0;
+			const bool run18 = run18_ok && (P.blocksize == 1152 || !pack2_applicable(P));      // (1152: always; larger blocks: where the 16-sample instances do not apply)
+			(void)no_run18;
 			if(f_lo) note_launch(K_PACK_PLAN | K_PACK2 | (run18 ? K_PACK2_RUN18 : 0u) | (fused ? K_FO_PLACE : 0u));
 			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
 			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
