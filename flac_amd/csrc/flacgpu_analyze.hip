@@ -1307,6 +1307,10 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		ahead = derived;
 	}
 	const bool pdz = prep2_applicable(P) && prep2_decides(P) && op && !B.dbg;
+	// (evalw_kernel fills its image in 16-byte pieces of a run and ends a run with a whole or a half piece: runs of 16 k or 16 k + 8
+	//  samples.  The 18- and 36-sample runs evalg_kernel takes since round 6 -- blocks of 1152 and 2304 -- are not its: what evalg_kernel
+	//  lists there goes straight to the lane-owner body, and a stream of more than 16 bits at such a block size keeps the general kernel)
+	const bool evalw_ok = ((P.blocksize / 64u) % 8u) == 0;
 	if(pdz) {
 		// the prep kernel has decided the frames of nominal length (flacgpu_prep.hip: DECIDE); the short last block and what it listed
 		// go through the lane-owner body
@@ -1315,16 +1319,16 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		const uint32_t grid = nframes * P.ncand < 1024u ? nframes * P.ncand : 1024u;
 		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(4 * 64), eval_layout(P, 4, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
 	}
-	else if(op && evalg_applicable(P) && !B.dbg && evalg_worthwhile(P)) {
+	else if(op && evalg_applicable(P) && !B.dbg && evalg_worthwhile(P) && (evalw_ok || P.bps <= 16)) {
 		// one wavefront per channel: 16-bit pairs (flacgpu_evalg.hip), then the 32-bit channels it listed (flacgpu_evalw.hip) -- or
 		// those straight away when the stream has more than 16 bits --, and what neither takes through the workgroup-per-channel
 		// body above, a fixed grid looping over the last list
 		const uint32_t *last_list, *last_count;
 		if(P.bps <= 16) {
 			hipError_t e = launch_evalg(P, nframes, tail_n, jtm, B, dec, s);
-			if(e == hipSuccess) e = launch_evalw(P, nframes, tail_n, jtm, B, dec, B.left, B.nleft, B.left2, B.nleft + 1, s);
+			if(e == hipSuccess && evalw_ok) e = launch_evalw(P, nframes, tail_n, jtm, B, dec, B.left, B.nleft, B.left2, B.nleft + 1, s);
 			if(e != hipSuccess) return e;
-			last_list = B.left2; last_count = B.nleft + 1;
+			last_list = evalw_ok ? B.left2 : B.left; last_count = evalw_ok ? B.nleft + 1 : B.nleft;
 		}
 		else {
 			const hipError_t e = launch_evalw(P, nframes, tail_n, jtm, B, dec, nullptr, nullptr, B.left, B.nleft, s);

@@ -262,10 +262,15 @@ def _oracle_parallel_kw(pcm, bps, rate, level, block, nthreads=16, chunk=32, **o
 
 OFF_THE_FAST_PATH = [
     # name, channels, bps, rate, level, block, frames, engine kw, oracle kw, kernels that must have run
-    ("-8 -b 2304: general evaluation and pack bodies", 2, 16, 44100, 8, 2304, 3000, dict(blocksize=2304), dict(blocksize=2304), {"eval_kernel", "pack_kernel", "scan_kernel", "compact_kernel"}),
-    ("-8 -l 32: autoc4 + the general evaluation, model and pack", 2, 16, 44100, 8, 4096, 1200, dict(max_lpc_order=32, streamable_subset=0), dict(max_lpc_order=32), {"autoc4_kernel", "eval_kernel", "pack_kernel"}),
+    # (round 6: 2304- and 1152-sample blocks take evalg_kernel and pack2_kernel's 18-sample-run instance; 3456 = 64 runs of 54 still has the
+    #  general evaluation body -- and the 18-sample-run pack instance, three passes of it; the general pack body: the -l 32 case below)
+    ("-8 -b 3456: general evaluation body, pack2<run18>", 2, 16, 44100, 8, 3456, 2000, dict(blocksize=3456, streamable_subset=0), dict(blocksize=3456), {"eval_kernel", "pack2_kernel<run18>"}),
+    ("-8 -b 2304: evalg + pack2<run18>", 2, 16, 44100, 8, 2304, 3000, dict(blocksize=2304), dict(blocksize=2304), {"evalg_kernel", "pack2_kernel<run18>", "fused_output"}),
+    ("-8 -b 1152: evalg + pack2<run18>", 2, 16, 44100, 8, 1152, 6000, dict(blocksize=1152), dict(blocksize=1152), {"evalg_kernel", "pack2_kernel<run18>", "fused_output"}),
+    ("-8 -l 32: autoc4 + the general evaluation, model and pack", 2, 16, 44100, 8, 4096, 1200, dict(max_lpc_order=32, streamable_subset=0), dict(max_lpc_order=32), {"autoc4_kernel", "eval_kernel", "pack_kernel", "scan_kernel", "compact_kernel"}),
     ("-8 -l 16: autoc4 + eval_kernel + pack2", 2, 16, 44100, 8, 4096, 2500, dict(max_lpc_order=16, streamable_subset=0), dict(max_lpc_order=16), {"autoc4_kernel", "eval_kernel", "pack2_kernel"}),
-    ("-2 on 24-bit: prep2 + eval_kernel + pack2", 2, 24, 96000, 2, 1152, 6000, {}, {}, {"prep2_kernel", "eval_kernel", "pack2_kernel"}),
+    ("-2 on 24-bit: the deciding prep kernel (wide) + pack2", 2, 24, 96000, 2, 1152, 6000, {}, {}, {"prep2_kernel<DECIDE>", "pack2_kernel"}),
+    ("-0 on 24-bit mono", 1, 24, 48000, 0, 1152, 6000, {}, {}, {"prep2_kernel<DECIDE>", "pack2_kernel"}),
     ("-8 mono under the default selection", 1, 16, 44100, 8, 4096, 9000, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "evalg_kernel", "pack2_kernel"}),
     ("-8 mono, 11264 frames: the size at which independent channels go a wavefront per window-job set", 1, 16, 44100, 8, 4096, 11264, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "autoc3_kernel<SETS>", "evalg_kernel", "pack2_kernel"}),
     ("-8 5.1 under the default selection", 6, 16, 48000, 8, 4096, 1800, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "evalg_kernel", "pack2_kernel"}),
