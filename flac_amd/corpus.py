@@ -326,7 +326,7 @@ def encode_tracks(eng, base, base_dev, F, total_samples, ntracks, dev, enc_strea
         offs_b = [lo * BLOCK * CH * 2 for lo, _ in ranges]
         lens_b = [max(0, (min(hi * BLOCK, total_samples) - lo * BLOCK)) * CH * 2 if hi > lo else 0 for lo, hi in ranges]
         # behind the encodes, on their stream (beside them, on a stream of its own, the two wavefronts of 120 chains took twice as long
-        # and the job with them: profiles/r04_q_md5_device_overlapped.txt)
+        # and the job with them: profiles/archive/r04_q_md5_device_overlapped.txt)
         enc_stream.synchronize()
         t_enc = time.perf_counter() - t0
         tm0 = time.perf_counter()
@@ -399,7 +399,7 @@ def main(argv=None):
     ap.add_argument("--md5", choices=("auto", "host", "device"), default="auto", help="--tracks: where the tracks' digests are computed -- device: one lane per track on the "
                     "staged sample bytes in HBM (flacgpu_md5.hip); host: AVX2, eight chains per pass, --md5-threads threads; auto: the device from 256 tracks up "
                     "(a chain is serial: 120 tracks are two wavefronts at ~30-50 MB/s per lane, 1.1-1.8 s for ten hours; 1000 tracks hash in 0.09 s -- "
-                    "profiles/r04_s_md5_device.txt)")
+                    "profiles/archive/r04_s_md5_device.txt)")
     ap.add_argument("--hours", type=float, default=10.0)
     ap.add_argument("--samples", type=int, default=0, help="corpus length in inter-channel samples (overrides --hours); a last short block is encoded as such")
     ap.add_argument("--batch-frames", type=int, default=16384)

@@ -140,7 +140,7 @@ __device__ __forceinline__ uint32_t fir16_w_dispatch(const int32_t (&x)[28], con
 // WPC = 2: two wavefronts share a channel's image and halve its candidates between them (each with its own search state; the better
 // of their first minima wins).  A 4096-sample image of 32-bit samples is 16.6 KB: one wavefront per image is 2.25 wavefronts per
 // SIMD, and the kernel -- a dependent chain of multiply-adds per sample, like flacgpu_evalg.hip's -- then issues at 0.64 of the
-// chip's rate (profiles/r04_a_pmc_counters_hires_before.txt); two per image are four per SIMD.  (The 16-bit kernel has the same
+// chip's rate (profiles/archive/r04_a_pmc_counters_hires_before.txt); two per image are four per SIMD.  (The 16-bit kernel has the same
 // option and does not need it: its images are half the size.)
 template <int MAXORD>
 __host__ __device__ inline uint32_t evalw_lds_bytes(uint32_t N, uint32_t wpc = 1) { return (N / 64) * EG_ROW + wpc * eg_tail_bytes<MAXORD>() + 64; }

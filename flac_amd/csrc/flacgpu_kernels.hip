@@ -284,7 +284,7 @@ __device__ __forceinline__ uint32_t frame_crc16_p2(const uint32_t *img, uint32_t
 // loop; the padding's factor x^(8 z) comes off at the end by its inverse (x is a unit modulo P: P(0) = 1).  A byte's table
 // address is one SDWA shift (v_lshlrev_b32 with a byte select; the tables sit at a fixed LDS address, which goes into the
 // instruction's offset field): 9 VALU instructions and 4 LDS reads per word where the round-3 form had 13 + predication
-// (profiles/r04_l_crc_ab.txt).
+// (profiles/archive/r04_l_crc_ab.txt).
 constexpr uint32_t crc_gfmul_c(uint32_t a, uint32_t b) { uint32_t r = 0; for(int i = 0; i < 16; i++) { r = crc_mulx(r); if(b & 0x8000u) r ^= a; b = (b << 1) & 0xffffu; } return r; }
 constexpr uint32_t CRC_XINV1 = 0xC002u;                   // x^-1 = x^15 + x^14 + x  (x * that = x^16 + x^15 + x^2 = 1 mod P)
 constexpr uint32_t crc_xinv8() { uint32_t r = 1; for(int i = 0; i < 8; i++) r = crc_gfmul_c(r, CRC_XINV1); return r; }
@@ -709,7 +709,7 @@ struct Pack2Shared {
 //     front of it in its own segment and the totals of the segments in front, 64 per step, nearest first.  The first frame of a
 //     segment leaves its offset behind as the segment's START: a walk that meets a known start stops there, so however long the
 //     batch, a frame looks at one or two rows of 64 totals.
-// What it buys depends on the kernel (profiles/r04_g_fused_ab.txt, r04_h_ff_lag_ab.txt): pack2_kernel (-3 .. -8: five workgroups
+// What it buys depends on the kernel (profiles/archive/r04_g_fused_ab.txt, r04_h_ff_lag_ab.txt): pack2_kernel (-3 .. -8: five workgroups
 // of four wavefronts per CU, a frame's length known four fifths through) 0.26 + 0.09 ms of scan and compaction -> 0.30 ms;
 // ff_kernel (-0 .. -2: one wavefront per frame, 26 us from load to store) 0.106 + 0.039 -> 0.157 ms -- a hop between two CUs is
 // 2-5 us under load (MI355X_MICROARCH.md, handoff-1to1), and a wavefront that waits for two of them at the end of 26 us is a SIMD
@@ -1804,7 +1804,7 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	// wavefront as a whole reads its 9216 bytes once; a 16-byte piece never straddles a cache line).  Round 3 loaded coalesced and
 	// transposed through an LDS tile: 18 loads, 18 address computations with a division by 18, 18 LDS writes, 22 LDS reads and
 	// two wavefront barriers -- a tenth of the kernel's instructions for a layout change the memory system does as well
-	// (profiles/r04_n_ff_direct_loads_ab.txt).  The four samples in front of a lane's run are its left neighbour's last four:
+	// (profiles/archive/r04_n_ff_direct_loads_ab.txt).  The four samples in front of a lane's run are its left neighbour's last four:
 	// a DPP shift by one lane (lane 0 gets zeros: the start of the block).
 	uint32_t w[FF_RUN + 4];
 	{
@@ -2340,7 +2340,7 @@ hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uin
 	// How the frames get to their places.  Default: every frame to its slot, scan_kernel + compact_kernel behind this one (the caller,
 	// with po == null).  FLACGPU_FF_LAG=n (opt-in, po != null): the kernel publishes its lengths and the wavefront of frame f places
 	// frame f - n, whose length, predecessors and bytes have been out for a dozen microseconds; the last n frames, and with n = 0 all
-	// of them, are fo_place_kernel's.  Measured (profiles/r04_h_ff_lag_ab.txt, 16384 frames, ms per step, two kernels / lag 2048 /
+	// of them, are fo_place_kernel's.  Measured (profiles/archive/r04_h_ff_lag_ab.txt, 16384 frames, ms per step, two kernels / lag 2048 /
 	// lag 0): -0 0.156 / 0.158 / 0.161, -1 0.164 / 0.165 / 0.169, -2 0.194 / 0.185 / 0.195 -- a kernel of one-wavefront workgroups
 	// that live 26 us pays for every extra round trip (the write-through slot stores, the loads of the frame it places) with a
 	// wavefront slot that is not computing; only -2, whose wavefronts live longer, comes out ahead.  And a wavefront that places its

@@ -9,7 +9,7 @@
 // are shorter idle at the end.  Throughput is the chain's latency times the number of streams: 30-70 MB/s per lane -- the ten-hour
 // corpus as 1000 tracks hashes in 0.09 s (70 GB/s), as 120 tracks (two wavefronts on an otherwise idle chip) in 1.1-1.8 s, which
 // four host threads of the AVX2 eight-chain routine beat (0.78 s): flac_amd/corpus.py picks by the number of tracks
-// (profiles/r04_s_md5_device.txt).
+// (profiles/archive/r04_s_md5_device.txt).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flacgpu.h"

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 			else {
 				// mono, 3..8 channels (up to four raw channels per round): a thread takes sample i of every channel of the round --
 				// neighbouring words of one line --, four samples in flight per thread (round 4: a rolled loop of single loads by one
-				// wavefront per channel: mono's prep took longer than stereo's four channels, profiles/r04_t_chan_rate.txt)
+				// wavefront per channel: mono's prep took longer than stereo's four channels, profiles/archive/r04_t_chan_rate.txt)
 				uint32_t a = a0;
 				int32_t *s0 = (int32_t *)smem, *s1 = (int32_t *)(smem + cbytes), *s2 = (int32_t *)(smem + 2 * (size_t)cbytes), *s3 = (int32_t *)(smem + 3 * (size_t)cbytes);
 #pragma unroll 4
