@@ -525,6 +525,7 @@ static int run_batch(flacgpu_ctx *c, const int32_t *d_pcm, uint32_t nframes, uin
                      uint64_t *d_total_out, hipStream_t s)
 {
 	if(!c || !d_pcm || !d_out || nframes == 0 || nframes > c->cfg.max_batch_frames) return FLACGPU_ERR_BAD_ARG;
+	if(((uintptr_t)d_fb_out & 3u) || ((uintptr_t)d_total_out & 7u)) return FLACGPU_ERR_BAD_ARG;      // (the kernels write them in place: include/flacgpu.h)
 	if(tail_n >= c->P.blocksize) tail_n = 0;
 	if(hipSetDevice(c->device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	TuneScope tune_scope(&c->tune);

@@ -156,8 +156,8 @@ using namespace flacgpu;
 // hipMalloc / hipFree -- a device-wide synchronisation -- per call.
 #include <mutex>
 namespace {
-struct Md5Scratch { void *p = nullptr; size_t cap = 0; };
-std::mutex g_md5_mu;
+// (a lock per device: calls for different devices do not wait for each other -- ADVICE r05; the scratch goes with the process)
+struct Md5Scratch { void *p = nullptr; size_t cap = 0; std::mutex mu; };
 Md5Scratch g_md5_scratch[64];
 }
 extern "C" int flacgpu_md5_many_device(int device, const void *d_base, const uint64_t *offsets, const uint64_t *lengths, uint32_t n, uint8_t *digests, void *stream)
@@ -167,8 +167,8 @@ extern "C" int flacgpu_md5_many_device(int device, const void *d_base, const uin
 	if(hipSetDevice(device) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
 	hipStream_t s = (hipStream_t)stream;
 	// one call per device at a time uses the scratch (the call is synchronous on its stream anyway)
-	std::lock_guard<std::mutex> lock(g_md5_mu);
 	Md5Scratch &sc = g_md5_scratch[device];
+	std::lock_guard<std::mutex> lock(sc.mu);
 	const size_t need = (size_t)n * 32;
 	if(sc.cap < need) {
 		if(sc.p) (void)hipFree(sc.p);

@@ -121,7 +121,9 @@ int64_t flacgpu_encode_batch(flacgpu_ctx *ctx, const int32_t *pcm, uint32_t nfra
  * d_frame_bytes are device pointers; d_total_bytes (device, 8 bytes) receives the byte total.
  * The kernels write both in place (round 5): d_frame_bytes needs 4-byte, d_total_bytes 8-byte alignment, nothing beyond the
  * batch's nframes entries is touched, and their contents are undefined until the batch has completed on `stream` (either may be
- * NULL: the engine then writes its own arrays, which no entry point exposes).
+ * NULL: the engine then writes its own arrays, which no entry point exposes).  Later kernels of the SAME batch read both back
+ * (offsets are built from the lengths): a caller that overwrites them while the batch is in flight corrupts that batch's layout.
+ * Misaligned pointers: FLACGPU_ERR_BAD_ARG.
  * Asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream); returns 0 or
  * a negative code.  This is the entry bench.py times. */
 int flacgpu_encode_batch_device(flacgpu_ctx *ctx, const int32_t *d_pcm, uint32_t nframes,
@@ -152,7 +154,7 @@ int flacgpu_stage_raw_device(flacgpu_ctx *ctx, const void *d_raw, const flacgpu_
  * src/libFLAC/md5.c:60-222 is the transform).  One lane per stream: worth it for a corpus of many streams, not for one.
  * offsets, lengths: host arrays [n]; digests: host [n][16].  Synchronous on `stream` (may be NULL).
  * d_base must be 4-byte aligned (FLACGPU_ERR_BAD_ARG otherwise; the ranges themselves may start anywhere); the ranges must
- * lie inside the caller's allocation. */
+ * lie inside the caller's allocation.  device: 0..63 (FLACGPU_ERR_BAD_ARG beyond: the per-device scratch is a fixed table). */
 int flacgpu_md5_many_device(int device, const void *d_base, const uint64_t *offsets, const uint64_t *lengths, uint32_t n,
                             uint8_t *digests, void *stream);
 
