@@ -212,3 +212,35 @@ def test_many_streams_decoded_and_their_md5_taken_on_the_device(dec):
         off += nb
     digests = md5_many_device(d_bytes.data_ptr(), offsets, lengths, device=0)
     assert digests == want
+
+
+def test_flac_t_of_a_directory_on_the_device_agrees_with_the_references_tool(tmp_path):
+    """python -m flac_amd.flactest (decode + MD5 of every file on the device) against `flac -t` of the reference's tool file by file:
+    good files of several formats, a file with a flipped bit in its audio, one cut short, one whose STREAMINFO carries another MD5."""
+    import subprocess
+    import sys
+    files, expect = [], []
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.dirname(U.FLAC_REF) + ":" + env.get("LD_LIBRARY_PATH", "")
+    for k, (ch, bps, rate, args) in enumerate(CLEAN[:10]):
+        pcm = make_pcm("music", 4096 * 4 + 33 * k, ch, bps, 70 + k)
+        f = bytearray(U.flac_encode_cli(pcm, bps, rate, args))
+        first = U.probe(bytes(f))[2]
+        if k == 3:
+            f[first + (len(f) - first) // 2] ^= 0x10
+        elif k == 5:
+            f = f[:first + (len(f) - first) * 2 // 3]
+        elif k == 7:
+            f[26 + 4] ^= 0xff                                   # a byte of STREAMINFO's MD5 (4 + 4 + 18 bytes in front of it)
+        path = os.path.join(str(tmp_path), "f%02d.flac" % k)
+        open(path, "wb").write(bytes(f))
+        files.append(path)
+        r = subprocess.run([U.FLAC_REF, "-t", "--silent", path], env=env, capture_output=True)
+        expect.append(r.returncode == 0)
+    assert expect.count(False) == 3
+    r = subprocess.run([sys.executable, "-m", "flac_amd.flactest", "--json"] + files, capture_output=True, text=True, cwd=U.ROOT)
+    import json
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [f["ok"] for f in got["files"]] == expect, [(f["path"][-8:], f["ok"], f["errors"], f["md5"]) for f in got["files"]]
+    assert r.returncode == 1
+    assert got["files"][7]["md5"] == "mismatch" and got["files"][7]["errors"] == []
