@@ -33,7 +33,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 RATE, BPS, CH = 44100, 16, 2
-FRAMES_PER_GPU = 16384         # 67.1 M inter-channel samples = 25 min of audio per GPU per step
+FRAMES_PER_GPU = 262144        # one GPU: 1.07 G inter-channel samples = 6.8 h of audio per step, 8.6 GB of int32 PCM resident (round 6: the
+                               # kernels of a 16384-frame step are 0.2 .. 0.9 ms each and run 4 .. 8 % slower than in a long batch -- profiles/r06_w_*;
+                               # 288 GB of HBM are there for this; rounds 1-5 used 16384: the line carries that figure too, `frames_16384`)
+FRAMES_PER_GPU_MULTI = 65536   # N > 1 ranks: rank 0 holds two windows of every rank's frames (8 ranks x 2 x 2 steps x 0.63 GB = 20 GB)
+FRAMES_SIDE = 65536            # the side measurements (other presets, white noise, 96 kHz / 24-bit)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # which kernels a phase of flacgpu_batch_phase_ms covers (the ones a workload does not launch are not in its counter pass)
 KERNEL_NAMES = {"prep": "ff_kernel+prep3_kernel+prep2_kernel+prep_kernel", "autoc": "autoc3_kernel+autoc2_kernel+autoc_kernel", "model": "model_kernel",
@@ -96,7 +100,13 @@ def rank_pcm(rank, nframes, block, kind, hires):
     regenerates after the timed region to check the frames it gathered from that rank"""
     if hires:
         import signals
-        return np.ascontiguousarray(signals.music(nframes * block, CH, BPS, seed=1234 + rank, rate=RATE))
+        base_frames = min(nframes, 16384)             # (the first 16384 frames are rounds 1-5's signal; more: the clip again with gains and offsets)
+        base = signals.music(base_frames * block, CH, BPS, seed=1234 + rank, rate=RATE)
+        reps = (nframes + base_frames - 1) // base_frames
+        if reps > 1:
+            lim = 1 << (BPS - 1)
+            base = np.concatenate([base if r == 0 else np.clip(np.rint(base * (1.0 - 0.07 * (r % 8))) + (r % 5) - 2, -lim, lim - 1).astype(np.int32) for r in range(reps)], axis=0)
+        return np.ascontiguousarray(base[: nframes * block])
     return synth_pcm(nframes, 1234 + rank, block, kind)
 
 
@@ -347,7 +357,7 @@ def main():
                     "(flac_amd.dist.ensure_ranks -> torch.distributed.run); under one, N must equal its WORLD_SIZE (else exit code 3)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default: %d on one GPU, %d per rank on several)" % (FRAMES_PER_GPU, FRAMES_PER_GPU_MULTI))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the white-noise and -5 side measurements")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the last step's frames (outside the timed region)")
@@ -407,7 +417,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         check_world(args.gpus)
 
-    nframes = args.frames
+    nframes_main = args.frames if args.frames else (FRAMES_PER_GPU_MULTI if (world > 1 or args.force_dist) else FRAMES_PER_GPU)
     search = dict(exhaustive=int(args.exhaustive), prec_search=int(args.prec_search))
 
     def sync():
@@ -416,8 +426,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(level, kind, steps, warmup, use_dist, gather=None, window=None):
+    def measure(level, kind, steps, warmup, use_dist, gather=None, window=None, frames=None):
         """K timed steps of one configuration; returns the numbers and what the verification needs"""
+        nframes = frames or nframes_main
         gather = gather or args.gather
         window = window or args.window
         block = block_of(level)
@@ -484,7 +495,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        res = {"elapsed": elapsed, "steps": steps, "block": block, "level": level, "kind": kind}
+        res = {"elapsed": elapsed, "steps": steps, "block": block, "level": level, "kind": kind, "nframes": nframes}
         if rank == 0 and gp is None and not use_dist and not args.no_clock:
             try:
                 res["clock"] = clock_probe(local_rank, run)
@@ -556,7 +567,8 @@ def main():
             # driven by a C client (flac_amd/lib/api_bench <- flac_amd/csrc/tools/api_bench.c) on this step's PCM from host memory:
             # one stream with MD5 off and on (the API's default), and K streams at once with MD5 on
             try:
-                res["libflac_api"] = libflac_api_figures(pcm_h, nframes, block, level, d_out, int(d_total.item()))
+                api_frames = min(nframes, 16384)                   # (67 M samples per stream, as in round 5: sixteen streams of the whole step would be 137 GB of host buffers)
+                res["libflac_api"] = libflac_api_figures(pcm_h, api_frames, block, level, d_out, int(d_fb[:api_frames].to(torch.int64).sum().item()))
             except Exception as e:
                 res["libflac_api"] = {"error": repr(e)}
         verified = None
@@ -608,7 +620,7 @@ def main():
             out_bps = total_bytes / samples_per_step
             alg_bytes = samples_per_step * (4 * CH + out_bps)         # PCM read once + frames written once
             dom = max(kms, key=kms.get)
-            achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
+            achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9 if kms[dom] else 0.0          # (--timing-every 0: no kernel times)
             traffic = valu_busy = traffic_step = None
             valu = {}
             pw, pkey, pstale = pmc_workload(level, kind, args.hires)
@@ -692,11 +704,11 @@ def main():
             "config": {"workload": "flac -%d%s%s (%s) on %s stereo, "
                                    "%d frames x %d samples per GPU per step, %s resident in HBM" % (LEVEL, "e" if args.exhaustive else "", "p" if args.prec_search else "",
                                    "max LPC order 12, subdivide_tukey(3), mid/side, partition order <= 6" if LEVEL == 8 else "the preset's settings, stream_encoder.c:117-140",
-                                   "96k/24-bit" if args.hires else "44.1k/16-bit", nframes, m["block"], sig),
-                       "frames_per_gpu_per_step": nframes, "blocksize": m["block"], "channels": CH, "bits_per_sample": BPS,
+                                   "96k/24-bit" if args.hires else "44.1k/16-bit", nframes_main, m["block"], sig),
+                       "frames_per_gpu_per_step": nframes_main, "blocksize": m["block"], "channels": CH, "bits_per_sample": BPS,
                        "samples_are": "inter-channel (x2 for channel-samples)",
                        "input": "every step encodes the SAME resident batch again (%.0f MB of int32 PCM per GPU: larger than the 256 MB Infinity Cache, so it streams from "
-                                "HBM every step, but it is one buffer, not a corpus)" % (nframes * m["block"] * CH * 4 / 1e6),
+                                "HBM every step, but it is one buffer, not a corpus)" % (nframes_main * m["block"] * CH * 4 / 1e6),
                        "parallelism": ("frame-shard x%d, no gather: every rank's frames stay in its HBM (encode-only scaling; the difference to the rccl line is the funnel)" % world
                                        if args.gather == "none" else
                                        "frame-shard x%d + ordered RCCL gather of every step's frames to rank 0 (sizes exchanged once per window of %d steps, "
@@ -805,21 +817,30 @@ def main():
     if world == 1 and not multi and not args.no_extras and LEVEL == 8 and not args.hires and not args.white and not any(search.values()):
         # (one GPU, no collectives: a side measurement that fails says so in the line instead of taking the main measurement with it)
         try:
-            side_steps = max(3, args.steps // 2)
-            w = measure(8, "white", side_steps, 1, False)
-            l5 = measure(5, "music", side_steps, 1, False)
-            l0 = measure(0, "music", 4 * side_steps, 2, False)       # (0.2 ms steps: five of them are a millisecond, too short a stretch to time)
+            # (the first tens of milliseconds behind an idle stretch run 3 % (-8) to 11 % (-5) below the steady state, profiles/r06_w_*:
+            #  three warm-up steps and at least 60 ms of timed steps for every side figure)
+            side_steps = max(6, args.steps)
+            fside = min(FRAMES_SIDE, nframes_main)
+            w = measure(8, "white", side_steps, 3, False, frames=fside)
+            l5 = measure(5, "music", 2 * side_steps, 3, False, frames=fside)
+            l0 = measure(0, "music", 4 * side_steps, 3, False, frames=min(4 * fside, nframes_main))       # (1152-sample blocks: four times the frames are the same samples)
+            # the step of rounds 1-5 (16384 frames = 67 M samples, 2 ms at -8): the same kernels in short launches, at that round's step count
+            small = measure(8, "music", 20, 2, False, frames=16384) if nframes_main > 16384 else None
             args.hires = True
             RATE, BPS = 96000, 24
-            hr = measure(8, "music", max(3, side_steps // 2), 1, False)
+            hr = measure(8, "music", side_steps, 3, False, frames=fside)
             args.hires = False
             RATE, BPS = 44100, 16
             if rank == 0:
+                if small is not None:
+                    extras["frames_16384"] = {"what": "the main measurement's workload in steps of 16384 frames (the step of rounds 1-5: BENCH_r01..r05 are this figure)",
+                                              "value": round(small["value"], 3), "unit": "Msamples/s", "ms_per_step": round(small["ms_per_step"], 4), "steps": small["steps"],
+                                              "kernel_ms": {k: round(v, 4) for k, v in small["kernel_ms"].items()}, "verified_ok": small.get("verified", {}).get("ok")}
                 for key, r, what in (("white_noise", w, "flac -8 on i.i.d. uniform 16-bit stereo white noise (SURVEY.md 8d config 3 (i)): the 32-bit side-channel path, the largest frames"),
                                      ("level5", l5, "flac -5 (the tool's default preset) on the music-like signal"),
                                      ("level0", l0, "flac -0 (fixed predictors only, 1152-sample blocks, no mid/side) on the music-like signal"),
                                      ("hires", hr, "flac -8 on 96 kHz / 24-bit stereo (BASELINE.json config 4: the wide-sample residual path), 4096-sample blocks")):
-                    extras[key] = {"what": what, "value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"],
+                    extras[key] = {"what": what, "value": round(r["value"], 3), "unit": "Msamples/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"], "frames_per_step": r.get("nframes"),
                                    "compressed_bytes_per_sample": round(r["out_bps"], 4), "kernel_ms": {k: round(v, 4) for k, v in r["kernel_ms"].items()},
                                    "clock": r.get("clock"), "roofline": r["roofline"], "roofline_valu": r.get("roofline_valu"), "verified_frames": r.get("verified", {}).get("frames_compared_with_oracle"),
                                    "verified_ok": r.get("verified", {}).get("ok")}
