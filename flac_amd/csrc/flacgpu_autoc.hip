@@ -309,12 +309,6 @@ __global__ __launch_bounds__(TPB, (VARIANT == 8 && SRC != 0) ? 4 : AUTOC2_WAVES_
 constexpr int A3_T = 32;             // new samples per tile = 4 chain steps
 constexpr int A3_ST = 41;            // words per subframe row (>= 40: head + tail of the finish)
 constexpr int A3_ITEMS = 64;         // subframes per wavefront
-// Round 6: autoc3_kernel's tile holds DOUBLES (row stride 33: the 64 lanes reading "their" sample as 8 bytes cover the 32 banks in
-// quarter-wavefronts).  The chain reads its operands as they are -- the 8 conversions per 8-sample step and subframe (of 164 VALU
-// instructions) are gone from it -- and the fill converts once per sample either way: on the window's flat part the integer goes
-// straight to a double (v_cvt_f64_i32: the value (double)(float)x has whenever |x| < 2^24, int_exact), on the slopes the float
-// product is widened there instead of in the chain.  The head / tail rows of the finish stay floats in the same memory.
-constexpr int A3_DST = 33;           // doubles per subframe row
 struct A3Fetch { int2 v[8]; float wt; };
 // PLANES: left and right come from the planar channels the prep kernel left behind (16-bit input: 16-bit pairs, wasted bits
 // shifted out -- a quarter of the interleaved 32-bit PCM's bytes per frame and sweep) instead of from the PCM
@@ -344,22 +338,20 @@ __device__ __forceinline__ void a3_fetch(const A2Job &J, const int2 *__restrict_
 	}
 }
 // any_wasted: some subframe of the wavefront has wasted bits (wave-uniform; without, the shifts and their counts are not issued)
-// T / ST: element type and row stride of the tile (double, A3_DST: the chain's tile; float, 2 * A3_DST: the same memory as the finish reads it)
-template <bool PLANES, typename T, int ST>
-__device__ __forceinline__ void a3_store(T *tile, const uint32_t *wasted4 /* [16]: the four wasted-bits counts of a frame, a byte each */, bool any_wasted, uint32_t half, const A3Fetch &F, uint32_t col, bool tune_no_flat, bool int_exact)
+template <bool PLANES>
+__device__ __forceinline__ void a3_store(float *tile, const uint32_t *wasted4 /* [16]: the four wasted-bits counts of a frame, a byte each */, bool any_wasted, uint32_t half, const A3Fetch &F, uint32_t col, bool tune_no_flat)
 {
-	constexpr int A3_ST = ST;
 	if(any_wasted) {
 #pragma unroll
 		for(int q = 0; q < 8; q++) {
 			const uint32_t fr = 2u * (uint32_t)q + half, w4 = wasted4[fr];
 			// (a plane's samples come without their channel's wasted bits: put the zeros back for mid and side)
 			const int32_t l = PLANES ? (int32_t)((uint32_t)F.v[q].x << (w4 & 0xffu)) : F.v[q].x, r = PLANES ? (int32_t)((uint32_t)F.v[q].y << ((w4 >> 8) & 0xffu)) : F.v[q].y;
-			T *row = tile + fr * 4u * A3_ST + col;
-			row[0 * A3_ST] = (T)a2_value(l, w4 & 0xffu, F.wt);
-			row[1 * A3_ST] = (T)a2_value(r, (w4 >> 8) & 0xffu, F.wt);
-			row[2 * A3_ST] = (T)a2_value((l + r) >> 1, (w4 >> 16) & 0xffu, F.wt);
-			row[3 * A3_ST] = (T)a2_value(l - r, w4 >> 24, F.wt);
+			float *row = tile + fr * 4u * A3_ST + col;
+			row[0 * A3_ST] = a2_value(l, w4 & 0xffu, F.wt);
+			row[1 * A3_ST] = a2_value(r, (w4 >> 8) & 0xffu, F.wt);
+			row[2 * A3_ST] = a2_value((l + r) >> 1, (w4 >> 16) & 0xffu, F.wt);
+			row[3 * A3_ST] = a2_value(l - r, w4 >> 24, F.wt);
 		}
 	}
 	else if(__all((int)(F.wt == 1.0f)) && !tune_no_flat) {
@@ -372,20 +364,11 @@ __device__ __forceinline__ void a3_store(T *tile, const uint32_t *wasted4 /* [16
 			const int32_t l = F.v[q].x, r = F.v[q].y;
 			int32_t lr = l + r;
 			if(PLANES) asm("v_add_u32 %0, %1, %2" : "=v"(lr) : "v"(l), "v"(r));
-			T *row = tile + fr * 4u * A3_ST + col;
-			if(sizeof(T) == 8 && (PLANES || int_exact)) {
-				// (16-bit planes, or input of at most 24 bits: every value is below 2^24 in magnitude and (float) of it is the integer itself)
-				row[0 * A3_ST] = (T)l;
-				row[1 * A3_ST] = (T)r;
-				row[2 * A3_ST] = (T)(lr >> 1);
-				row[3 * A3_ST] = (T)(l - r);
-			}
-			else {
-				row[0 * A3_ST] = (T)(float)l;
-				row[1 * A3_ST] = (T)(float)r;
-				row[2 * A3_ST] = (T)(float)(lr >> 1);
-				row[3 * A3_ST] = (T)(float)(l - r);
-			}
+			float *row = tile + fr * 4u * A3_ST + col;
+			row[0 * A3_ST] = (float)l;
+			row[1 * A3_ST] = (float)r;
+			row[2 * A3_ST] = (float)(lr >> 1);
+			row[3 * A3_ST] = (float)(l - r);
 		}
 	}
 	else {
@@ -395,11 +378,11 @@ __device__ __forceinline__ void a3_store(T *tile, const uint32_t *wasted4 /* [16
 			const int32_t l = F.v[q].x, r = F.v[q].y;
 			int32_t lr = l + r;
 			if(PLANES) asm("v_add_u32 %0, %1, %2" : "=v"(lr) : "v"(l), "v"(r));      // (the compiler, knowing both fit 16 bits, builds the mid sample from four 16-bit operations instead of an add and a shift)
-			T *row = tile + fr * 4u * A3_ST + col;
-			row[0 * A3_ST] = (T)a2_value(l, 0u, F.wt);
-			row[1 * A3_ST] = (T)a2_value(r, 0u, F.wt);
-			row[2 * A3_ST] = (T)a2_value(lr >> 1, 0u, F.wt);
-			row[3 * A3_ST] = (T)a2_value(l - r, 0u, F.wt);
+			float *row = tile + fr * 4u * A3_ST + col;
+			row[0 * A3_ST] = a2_value(l, 0u, F.wt);
+			row[1 * A3_ST] = a2_value(r, 0u, F.wt);
+			row[2 * A3_ST] = a2_value(lr >> 1, 0u, F.wt);
+			row[3 * A3_ST] = a2_value(l - r, 0u, F.wt);
 		}
 	}
 }
@@ -443,11 +426,10 @@ __device__ __forceinline__ void a3_fetch_ind(const A2Job &J, const int32_t *__re
 		}
 	}
 }
-template <typename T = float, int ST = A3_ST>
-__device__ __forceinline__ void a3_store_ind(T *tile, uint32_t half, const A3FetchInd &F, uint32_t col)
+__device__ __forceinline__ void a3_store_ind(float *tile, uint32_t half, const A3FetchInd &F, uint32_t col)
 {
 #pragma unroll
-	for(int q = 0; q < 32; q++) tile[(2u * (uint32_t)q + half) * ST + col] = (T)a2_value(F.v[q], 0u, F.wt);
+	for(int q = 0; q < 32; q++) tile[(2u * (uint32_t)q + half) * A3_ST + col] = a2_value(F.v[q], 0u, F.wt);
 }
 // one chain step (lpc_intrin_fma.c:46,61) / two steps of the lag-12 routine as compiled (:54), for the four vector lanes l:
 // W(c) = d[first sample of the step + c] of this lane's subframe
@@ -472,12 +454,8 @@ __global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(
                                                        double *__restrict__ autoc_out, uint32_t no_flat_arg)
 {
 	const bool no_flat = no_flat_arg != 0;                          // (FLACGPU_NO_FLAT=1: the window multiply on every tile, for A/B runs)
-	__shared__ double tiled[A3_ITEMS * A3_DST];
+	__shared__ float tile[A3_ITEMS * A3_ST];
 	__shared__ uint32_t wasted4[A3_ITEMS / 4];
-	float *const tile = (float *)tiled;                             // (the finish's view: rows of 2 * A3_DST floats, head and tail in the first 40)
-	constexpr int A3_FST = 2 * A3_DST;
-	static_assert(A3_FST >= 40 && A3_DST >= A3_T, "a row holds a tile of doubles, and the 16 + 24 floats of the finish");
-	const bool int_exact = P.bps <= 24;
 	constexpr bool PLANES = SRC == 1, IND = SRC == 2;
 	const int lane = (int)threadIdx.x;
 	const uint32_t nfc = nmain * (IND ? P.ncand : 4u), ngroups = (nfc + A3_ITEMS - 1) / A3_ITEMS;
@@ -522,8 +500,7 @@ __global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(
 		}
 	}
 	const int2 *pcm2 = (const int2 *)pcm;
-	const float *row = tile + lane * A3_FST;
-	const double *rowd = tiled + lane * A3_DST;
+	const float *row = tile + lane * A3_ST;
 	__builtin_amdgcn_wave_barrier();
 
 #pragma unroll 1
@@ -541,8 +518,7 @@ __global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(
 #pragma unroll
 	for(int j = 0; j < LAG; j++) { acc[j][0] = 0.0; acc[j][1] = 0.0; acc[j][2] = 0.0; acc[j][3] = 0.0; }
 #define A3_FETCH(idx) do { if constexpr(IND) a3_fetch_ind(J, pcm, P.chan_stride, fc0, nfc, half, is16, kind, (idx), G); else a3_fetch<PLANES>(J, pcm2, N, f0, nmain, half, (idx), F); } while(0)
-#define A3_STORE(col) do { if constexpr(IND) a3_store_ind<double, A3_DST>(tiled, half, G, (col)); else a3_store<PLANES, double, A3_DST>(tiled, wasted4, any_wasted, half, F, (col), no_flat, int_exact); } while(0)
-#define A3_STORE_F(col) do { if constexpr(IND) a3_store_ind<float, A3_FST>(tile, half, G, (col)); else a3_store<PLANES, float, A3_FST>(tile, wasted4, any_wasted, half, F, (col), no_flat, int_exact); } while(0)
+#define A3_STORE(col) do { if constexpr(IND) a3_store_ind(tile, half, G, (col)); else a3_store<PLANES>(tile, wasted4, any_wasted, half, F, (col), no_flat); } while(0)
 	double w[HB + A3_T];              // w[HB + c] = d[first sample of the tile + c]
 	A3Fetch F;
 	A3FetchInd G;
@@ -553,7 +529,7 @@ __global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(
 	A3_FETCH((int32_t)L + (int32_t)sl);
 	__builtin_amdgcn_wave_barrier();
 #pragma unroll
-	for(int u = 0; u < HB; u++) w[A3_T + u] = rowd[16 - HB + u];
+	for(int u = 0; u < HB; u++) w[A3_T + u] = (double)row[16 - HB + u];
 	for(uint32_t t = 0; t < ntiles; t++) {
 		__builtin_amdgcn_wave_barrier();
 		A3_STORE(sl);
@@ -570,7 +546,7 @@ __global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(
 #pragma unroll
 			for(int kk = 0; kk < 4; kk += 2) {
 #pragma unroll
-				for(int u = 0; u < 16; u++) w[HB + 8 * kk + u] = rowd[8 * kk + u];
+				for(int u = 0; u < 16; u++) w[HB + 8 * kk + u] = (double)row[8 * kk + u];
 				if((uint32_t)kk + 2 <= ksteps && k0 + (uint32_t)kk + 2 <= 2 * npairs12) { A3_PAIR(8 * kk); }
 				else {
 					if((uint32_t)kk < ksteps) { A3_STEP(8 * kk); }
@@ -582,7 +558,7 @@ __global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(
 #pragma unroll
 			for(int kk = 0; kk < 4; kk++) {
 #pragma unroll
-				for(int u = 0; u < 8; u++) w[HB + 8 * kk + u] = rowd[8 * kk + u];
+				for(int u = 0; u < 8; u++) w[HB + 8 * kk + u] = (double)row[8 * kk + u];
 				if((uint32_t)kk < ksteps) { A3_STEP(8 * kk); }
 			}
 		}
@@ -593,14 +569,13 @@ __global__ __launch_bounds__(64, (SETS && SRC == 2) ? 1 : 2) void autoc3_kernel(
 	const uint32_t tail_lo = nd - 24;               // nd > 32
 	{
 		A3_FETCH(sl < 16 ? (int32_t)sl : (int32_t)(tail_lo + (sl - 16)));
-		A3_STORE_F(sl);
+		A3_STORE(sl);
 		A3_FETCH((int32_t)(tail_lo + 16 + (sl & 7u)));
-		if(sl < 8) A3_STORE_F(32 + sl);
+		if(sl < 8) A3_STORE(32 + sl);
 	}
 	__builtin_amdgcn_wave_barrier();
 #undef A3_FETCH
 #undef A3_STORE
-#undef A3_STORE_F
 	const uint32_t max_lpc = P.max_lpc_order >= N ? N - 1 : P.max_lpc_order;
 	const uint32_t lag = max_lpc + 1;
 	double *out = autoc_out + ((size_t)(fc < nfc ? fc : nfc - 1) * P.max_jobs + jb) * AUTOC_STRIDE;

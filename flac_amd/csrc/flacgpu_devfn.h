@@ -523,8 +523,9 @@ struct Prep2Acc {
 // PARTS (the presets without an LPC search, prep2_kernel<.,.,true>): cs[k] = this chunk's sum for order k, as added to A.e[k];
 // ex[k] = what the residual of order k has IN FRONT of sample 4 (samples k..3: the predictor estimate skips them, the residual
 // of the chosen order does not, stream_encoder.c:4100 vs :4456)
-template <bool WIDE, bool MAG = false, bool PARTS = false, int CH = CHUNK>
-__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[CH + 4], bool first_chunk, int32_t first, Prep2Acc &A, uint32_t *cs = nullptr, uint32_t *ex = nullptr)
+template <bool WIDE, bool MAG = false, bool PARTS = false, int CH = CHUNK, bool FUSE = false>
+__device__ __forceinline__ void prep2_chunk(const int32_t (&x)[CH + 4], bool first_chunk, int32_t first, Prep2Acc &A, uint32_t *cs = nullptr, uint32_t *ex = nullptr,
+                                            bool maybe_first = true /* wave-uniform: false = no lane of this wavefront holds the block's first chunk */)
 {
 	constexpr uint32_t M = 0x80000000u;
 	uint32_t s[5] = {0, 0, 0, 0, 0};
@@ -538,16 +539,26 @@ __device__ __forceinline__ void prep2_chunk(const int32_t (&x)[CH + 4], bool fir
 		if(MAG) A.mag |= (uint32_t)(a0 ^ (a0 >> 31));
 		const uint32_t xb = (uint32_t)a0 ^ M;
 		const int32_t d1 = a0 - x[t + 3], d2 = d1 - d1p, d3 = d2 - d2p;
-		uint32_t t0 = sad_u32(xb, M, 0), t1 = sad_u32(xb, xbp, 0), t2 = sad_u32((uint32_t)d1 ^ M, (uint32_t)d1p ^ M, 0),
-		         t3 = sad_u32((uint32_t)d2 ^ M, (uint32_t)d2p ^ M, 0), t4 = sad_u32((uint32_t)d3 ^ M, (uint32_t)d3p ^ M, 0);
-		if(t < 4) {
-			if(first_chunk) {
-				if(PARTS) { ex[0] += t0; if(t >= 1) ex[1] += t1; if(t >= 2) ex[2] += t2; if(t >= 3) ex[3] += t3; }
-				t0 = t1 = t2 = t3 = t4 = 0;                                        // the sums start at sample 4 (stream_encoder.c:4100)
-			}
+		if(FUSE && !WIDE && (t >= 4 || !maybe_first)) {
+			// (round 6, FUSE: the running sum is the instruction's own third operand -- |a - b| + c -- instead of a sum formed behind it:
+			//  five additions per sample and channel less, a seventh of this loop; the same 32-bit sums.  prep3_kernel: -10 % instructions,
+			//  -2.5 % time (it is HBM bound next to that), -5 +1.1 %; ff_kernel, whose lanes run five chains of eighteen dependent
+			//  v_sad_u32 that way, got 2.5 % SLOWER and keeps the sums apart: profiles/r06_z_*)
+			s[0] = sad_u32(xb, M, s[0]); s[1] = sad_u32(xb, xbp, s[1]); s[2] = sad_u32((uint32_t)d1 ^ M, (uint32_t)d1p ^ M, s[2]);
+			s[3] = sad_u32((uint32_t)d2 ^ M, (uint32_t)d2p ^ M, s[3]); s[4] = sad_u32((uint32_t)d3 ^ M, (uint32_t)d3p ^ M, s[4]);
 		}
-		if(WIDE) { A.e[0] += t0; A.e[1] += t1; A.e[2] += t2; A.e[3] += t3; A.e[4] += t4; }
-		else { s[0] += t0; s[1] += t1; s[2] += t2; s[3] += t3; s[4] += t4; }
+		else {
+			uint32_t t0 = sad_u32(xb, M, 0), t1 = sad_u32(xb, xbp, 0), t2 = sad_u32((uint32_t)d1 ^ M, (uint32_t)d1p ^ M, 0),
+			         t3 = sad_u32((uint32_t)d2 ^ M, (uint32_t)d2p ^ M, 0), t4 = sad_u32((uint32_t)d3 ^ M, (uint32_t)d3p ^ M, 0);
+			if(t < 4) {
+				if(first_chunk) {
+					if(PARTS) { ex[0] += t0; if(t >= 1) ex[1] += t1; if(t >= 2) ex[2] += t2; if(t >= 3) ex[3] += t3; }
+					t0 = t1 = t2 = t3 = t4 = 0;                                        // the sums start at sample 4 (stream_encoder.c:4100)
+				}
+			}
+			if(WIDE) { A.e[0] += t0; A.e[1] += t1; A.e[2] += t2; A.e[3] += t3; A.e[4] += t4; }
+			else { s[0] += t0; s[1] += t1; s[2] += t2; s[3] += t3; s[4] += t4; }
+		}
 		d1p = d1; d2p = d2; d3p = d3; xbp = xb;
 	}
 	if(!WIDE) {

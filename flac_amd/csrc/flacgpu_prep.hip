@@ -475,8 +475,8 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 		//  samples -- the side channel of a 24-bit stream -- is below 2^28, sixteen of them below 2^32; only the totals across lanes
 		//  and wavefronts need more.  Round 3 added every |difference| in 64 bits for such streams: two instructions instead of one,
 		//  twenty times per sample and channel)
-		if(c == 3) prep2_chunk<false, true>(x, first_chunk, first, A);
-		else prep2_chunk<false>(x, first_chunk, first, A);
+		if(c == 3) prep2_chunk<false, true, false, CHUNK, true>(x, first_chunk, first, A, nullptr, nullptr, wave == 0);
+		else prep2_chunk<false, false, false, CHUNK, true>(x, first_chunk, first, A, nullptr, nullptr, wave == 0);
 		A.orv = wave_or_u32(A.orv);
 		A.diff = wave_or_u32(A.diff);
 		if(c == 3) A.mag = wave_or_u32(A.mag);
