@@ -1319,7 +1319,7 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		const uint32_t grid = nframes * P.ncand < 1024u ? nframes * P.ncand : 1024u;
 		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(4 * 64), eval_layout(P, 4, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, B.left, B.nleft);
 	}
-	else if(op && evalg_applicable(P) && !B.dbg && evalg_worthwhile(P) && (evalw_ok || P.bps <= 16)) {
+	else if(op && evalg_applicable(P) && !B.dbg && evalg_worthwhile(P) && (evalw_ok || P.bps <= 16) && (P.max_lpc_order <= 12 || P.bps <= 16)) {      // (13..16 taps: evalg_kernel<32> has them, evalw_kernel stops at 12)
 		// one wavefront per channel: 16-bit pairs (flacgpu_evalg.hip), then the 32-bit channels it listed (flacgpu_evalw.hip) -- or
 		// those straight away when the stream has more than 16 bits --, and what neither takes through the workgroup-per-channel
 		// body above, a fixed grid looping over the last list
@@ -1339,6 +1339,15 @@ static hipError_t launch_model_eval(const DevParams &P, const int32_t *pcm, uint
 		const uint32_t lw = 4u;
 		const uint32_t grid = nframes * P.ncand < 1024u ? nframes * P.ncand : 1024u;
 		hipLaunchKernelGGL((eval_list_kernel<MAXORD>), dim3(grid), dim3(lw * 64), eval_layout(P, lw, 1, false).total, s, P, B.chan, nframes, tail_n, jtm, jtt, B.prep, B.cands, B.valid, dec, last_list, last_count);
+	}
+	else if(!op && P.bps <= 16 && P.max_lpc_order > 12 && evalg_applicable(P) && !B.dbg && evalg_worthwhile(P)) {
+		// predictors of 17..32 taps on 16-bit input (round 6): the wavefront-per-channel kernel takes what its 32-bit chain is exact for
+		// (and the channels without residual candidates); the general kernel below skips what it marked (ChanPrep::handled)
+		const hipError_t e = launch_evalg(P, nframes, tail_n, jtm, B, dec, s);
+		if(e != hipSuccess) return e;
+		// (the short last block is not that kernel's: its channels without a residual candidate are decided by the one-wavefront form
+		//  of the general kernel, as in the branch below)
+		if(tail_n) { note_launch(K_EVAL); hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u); }
 	}
 	else if(op) { note_launch(K_EVAL); hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * (P.ncand / cpw)), dim3(waves * 64), lds, s, P, B.chan, nframes, tail_n, cpw, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, (uint32_t)ahead); }
 	else { note_launch(K_EVAL); hipLaunchKernelGGL((eval_kernel<MAXORD, 0>), dim3(nframes * P.ncand), dim3(64), eval_layout(P, 1, 1, false).total /* VARIANT 0 lays out as such */, s, P, B.chan, nframes, tail_n, 1u, jtm, jtt, B.prep, B.cands, B.valid, dec, B.dbg, 0u); }

@@ -111,7 +111,7 @@ static Tune read_tune(int device)
 	t.autoc2_ungrouped = set("FLACGPU_AUTOC2_UNGROUPED");
 	{ const char *e = getenv("FLACGPU_AUTOC2"); t.autoc2_force = e ? atoi(e) + 1 : 0; }
 	t.no_ff = set("FLACGPU_NO_FF"); t.no_run18 = set("FLACGPU_NO_RUN18"); t.no_prep3 = set("FLACGPU_NO_PREP3"); t.no_prep_decide = set("FLACGPU_NO_PREP_DECIDE");
-	t.no_evalg = set("FLACGPU_NO_EVALG"); t.no_fast1 = set("FLACGPU_NO_FAST1"); t.no_prep4 = set("FLACGPU_NO_PREP4"); t.no_flat = set("FLACGPU_NO_FLAT"); t.no_wide_decide = set("FLACGPU_NO_WIDE_DECIDE");
+	t.no_evalg = set("FLACGPU_NO_EVALG"); t.no_fast1 = set("FLACGPU_NO_FAST1"); t.no_prep4 = set("FLACGPU_NO_PREP4"); t.no_flat = set("FLACGPU_NO_FLAT"); t.no_wide_decide = set("FLACGPU_NO_WIDE_DECIDE"); t.no_evalg32 = set("FLACGPU_NO_EVALG32");
 	t.eval_wpc = num("FLACGPU_EVAL_WPC", 1) == 2 ? 2 : 1; t.evalw_wpc = num("FLACGPU_EVALW_WPC", 2) == 1 ? 1 : 2;
 	t.eval_waves = num("FLACGPU_EVAL_WAVES", 0); t.eval_cpw = num("FLACGPU_EVAL_CPW", 0); t.eval_prefetch = num("FLACGPU_EVAL_PREFETCH", -1);
 	t.sync_debug = set("FLACGPU_SYNC_DEBUG"); t.no_fused = set("FLACGPU_NO_FUSED_COMPACT"); t.no_copy_kernel = set("FLACGPU_NO_COPY_KERNEL");
@@ -164,7 +164,7 @@ void build_job_table(const DevParams &P, uint32_t n, JobTable *jt)
 	}
 	jt->njobs = nj; jt->nanalyses = na; jt->wnd_floats = woff; jt->nsets = ns;
 	for(uint32_t m = 0; m < 7; m++)
-		for(uint32_t o = 0; o < 13; o++) { const uint32_t full = (n / 64u) << m; jt->eg_div[m][o] = full > o ? (0x40000u / (full - o)) << 13 : 0u; }
+		for(uint32_t o = 0; o <= (uint32_t)MAX_ORDER; o++) { const uint32_t full = (n / 64u) << m; jt->eg_div[m][o] = full > o ? (0x40000u / (full - o)) << 13 : 0u; }
 }
 }
 

@@ -96,7 +96,7 @@ struct JobTable {
 	// S = n / 64 samples, `o` of them warm-up samples, (0x40000 / (ns)) << 13 with ns = (S << m) - o -- the integer reciprocal of
 	// set_partitioned_rice_ (stream_encoder.c:5020), a function of the block size alone: built here, once, instead of 91 integer
 	// divisions per channel in the kernels (round 5)
-	uint32_t eg_div[7][13];
+	uint32_t eg_div[7][MAX_ORDER + 1];
 };
 void build_job_table(const DevParams &P, uint32_t n, JobTable *jt);
 
@@ -152,7 +152,7 @@ struct Tune {
 	int event_fence, copy_results;      // (host side, flacgpu_api.cpp)
 	int autoc3_ind_sets;          // FLACGPU_AUTOC3_IND_SETS: independent channels, a wavefront per window-job SET: 0 never, 1 always, 2 by the batch's size
 	int autoc2_force;          // FLACGPU_AUTOC2: 0 decide per batch, 1 never, 2 always
-	int no_ff, no_run18, no_prep3, no_prep4, no_prep_decide, no_evalg, no_fast1, no_flat, no_wide_decide;
+	int no_ff, no_run18, no_prep3, no_prep4, no_prep_decide, no_evalg, no_fast1, no_flat, no_wide_decide, no_evalg32;
 	int eval_wpc, evalw_wpc, eval_waves, eval_cpw, eval_prefetch /* -1: derive */;
 	int sync_debug, no_fused, no_copy_kernel, cands_global;
 	int device;                // the context's device: index of the per-device "attributes set" flags

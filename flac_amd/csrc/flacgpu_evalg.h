@@ -187,9 +187,9 @@ __device__ __forceinline__ void eg_pair_search(EgSearch &R, unsigned char *smem,
 }
 // the decision: first minimum in the reference's evaluation order (verbatim -> constant | fixed -> LPC); lane c holds candidate c's
 // order / precision / shift / taps (cq[0..MAXORD))
-template <int MAXORD>
+template <int MAXORD, int NQ>
 __device__ __forceinline__ void eg_decide(const EgSearch &R, const DevParams &P, const ChanPrep &pr, uint32_t n, const uint8_t *kbest, uint32_t c_order, uint32_t c_prec, uint32_t c_shift,
-                                          const int32_t (&cq)[13], SubDecision *dec, ChanPrep *prep_out, int lane)
+                                          const int32_t (&cq)[NQ], SubDecision *dec, ChanPrep *prep_out, int lane)
 {
 	const uint32_t wasted = pr.wasted, sbps = pr.sbps, hdr = 8 + wasted;
 	const uint32_t best_ci = R.best_ci;

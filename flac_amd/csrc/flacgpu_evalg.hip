@@ -28,8 +28,13 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "flacgpu_evalg.h"
+#include "flacgpu_evalg_chain.h"
 
 namespace flacgpu {
+
+// pairs of folded taps a kernel instance provides for: 7 (predictors of at most 12 taps + the sample: every preset), 17 (-l 13..32,
+// round 6).  The window of a 16-sample piece is NPM words of history in front of its 8.
+template <int MAXORD> constexpr int eg_npm() { return MAXORD <= 12 ? 7 : 17; }
 
 // ---- the FIR of one candidate over one 16-sample piece of every lane's run ------------------------------------------
 // AA[j]: the word holding samples (2j - 14, 2j - 13) relative to the piece start, BB[m] = samples (2m - 13, 2m - 12).
@@ -37,9 +42,10 @@ namespace flacgpu {
 // sample.  Sample s of the piece: pairs p = 0..NPF-1 are (x[s-2p], x[s-2p-1]) = AA[(s+13)/2 - p] for odd s,
 // BB[s/2 + 6 - p] for even s.  NPF dependent v_dot2_i32_i16 and the logical shift are ONE asm statement (between separate
 // statements the compiler pads every dependent pair with an s_nop, flacgpu_devfn.h: dot2_chain_lshr).
-template <int NPF>
-__device__ __forceinline__ uint32_t dot2_chain_s(const uint32_t (&W)[NPF], const uint32_t (&Q)[7], uint32_t sum0, uint32_t shift)
+template <int NPF, int NQ>
+__device__ __forceinline__ uint32_t dot2_chain_s(const uint32_t (&W)[NPF], const uint32_t (&Q)[NQ], uint32_t sum0, uint32_t shift)
 {
+	if constexpr(NPF >= 8) return dot2_chain_long<NPF, NQ>(W, Q, sum0, shift);
 	uint32_t d;
 	if constexpr(NPF == 1) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_lshrrev_b32 %0, %4, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "s"(shift));
 	if constexpr(NPF == 2) asm("v_dot2_i32_i16 %0, %2, %3, %1\n\tv_dot2_i32_i16 %0, %4, %5, %0\n\tv_lshrrev_b32 %0, %6, %0" : "=&v"(d) : "v"(sum0), "v"(W[0]), "s"(Q[0]), "v"(W[1]), "s"(Q[1]), "s"(shift));
@@ -56,60 +62,72 @@ __device__ __forceinline__ uint32_t sad_u32_s(uint32_t a, uint32_t b_uniform, ui
 	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
 	return d;
 }
-// FIRST: the piece that opens the block -- lane 0's first `order` samples are warm-up, not residual
+// PC: the piece's number when it is one of the first (lane 0's first `order` samples are warm-up, not residual: pieces 0 and, from 17
+// taps up, 1), -1 for every other piece
 // NV: samples of the piece that belong to the lane's run (16; 8 for the half piece that ends a run of 16 k + 8 samples: blocks of
 // 4608 samples)
-template <int NPF, bool FIRST, int NV = 16>
-__device__ __forceinline__ uint32_t fir16_folded(const uint32_t (&AA)[15], const uint32_t (&BB)[14], const uint32_t (&Q)[7], uint32_t shift, uint32_t bias, uint32_t order,
+// AA[j]: the word holding samples (2 j - 2 NPM, 2 j - 2 NPM + 1) relative to the piece start, BB[m] = samples (2 m - 2 NPM + 1, 2 m - 2 NPM + 2)
+template <int NPF, int PC, int NV, int NPM>
+__device__ __forceinline__ uint32_t fir16_folded(const uint32_t (&AA)[NPM + 8], const uint32_t (&BB)[NPM + 7], const uint32_t (&Q)[NPM], uint32_t shift, uint32_t bias, uint32_t order,
                                                  bool lane0, uint32_t sum0, uint32_t acc)
 {
 #pragma unroll
 	for(int s = 0; s < NV; s++) {
 		uint32_t W[NPF];
 #pragma unroll
-		for(int p = 0; p < NPF; p++) W[p] = (s & 1) ? AA[(s + 13) / 2 - p] : BB[s / 2 + 6 - p];
-		uint32_t pb = dot2_chain_s<NPF>(W, Q, sum0, shift);
-		if(FIRST && s < 2 * NPF - 1) { if(lane0 && (uint32_t)s < order) pb = bias; }
+		for(int p = 0; p < NPF; p++) W[p] = (s & 1) ? AA[(s + 2 * NPM - 1) / 2 - p] : BB[s / 2 + NPM - 1 - p];
+		uint32_t pb = dot2_chain_s<NPF, NPM>(W, Q, sum0, shift);
+		if(PC >= 0 && 16 * PC + s < 2 * NPF - 1) { if(lane0 && (uint32_t)(16 * PC + s) < order) pb = bias; }
 		acc = sad_u32_s(pb, bias, acc);
 	}
 	return acc;
 }
-template <bool FIRST, int NV = 16>
-__device__ __forceinline__ uint32_t fir16_dispatch(uint32_t npf, const uint32_t (&AA)[15], const uint32_t (&BB)[14], const uint32_t (&Q)[7], uint32_t shift, uint32_t bias,
+template <int PC, int NV, int NPM>
+__device__ __forceinline__ uint32_t fir16_dispatch(uint32_t npf, const uint32_t (&AA)[NPM + 8], const uint32_t (&BB)[NPM + 7], const uint32_t (&Q)[NPM], uint32_t shift, uint32_t bias,
                                                    uint32_t order, bool lane0, uint32_t sum0, uint32_t acc)
 {
-	switch(npf) {
-	case 1: return fir16_folded<1, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 2: return fir16_folded<2, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 3: return fir16_folded<3, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 4: return fir16_folded<4, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 5: return fir16_folded<5, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	case 6: return fir16_folded<6, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
-	default: return fir16_folded<7, FIRST, NV>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+#define EG_CASE(n) case n: return fir16_folded<n, PC, NV, NPM>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+	if constexpr(NPM == 7) {
+		switch(npf) {
+		EG_CASE(1) EG_CASE(2) EG_CASE(3) EG_CASE(4) EG_CASE(5) EG_CASE(6)
+		default: return fir16_folded<7, PC, NV, NPM>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+		}
 	}
+	else {
+		switch(npf) {
+		EG_CASE(1) EG_CASE(2) EG_CASE(3) EG_CASE(4) EG_CASE(5) EG_CASE(6) EG_CASE(7) EG_CASE(8) EG_CASE(9) EG_CASE(10) EG_CASE(11) EG_CASE(12)
+		EG_CASE(13) EG_CASE(14) EG_CASE(15) EG_CASE(16)
+		default: return fir16_folded<17, PC, NV, NPM>(AA, BB, Q, shift, bias, order, lane0, sum0, acc);
+		}
+	}
+#undef EG_CASE
 }
-// base: byte address of word (first sample of the piece - 14 samples) in the lane's column; rows at immediate offsets
-__device__ __forceinline__ void load_piece(const unsigned char *base, uint32_t (&AA)[15], uint32_t (&BB)[14])
+// base: byte address of word (first sample of the piece - 2 NPM samples) in the lane's column; rows at immediate offsets
+template <int NPM>
+__device__ __forceinline__ void load_piece(const unsigned char *base, uint32_t (&AA)[NPM + 8], uint32_t (&BB)[NPM + 7])
 {
 #pragma unroll
-	for(int j = 0; j < 15; j++) AA[j] = *(const uint32_t *)(base + j * EG_ROW);
+	for(int j = 0; j < NPM + 8; j++) AA[j] = *(const uint32_t *)(base + j * EG_ROW);
 #pragma unroll
-	for(int m = 0; m < 14; m++) BB[m] = __builtin_amdgcn_alignbit(AA[m + 1], AA[m], 16);
+	for(int m = 0; m < NPM + 7; m++) BB[m] = __builtin_amdgcn_alignbit(AA[m + 1], AA[m], 16);
 }
-// the piece that opens the block: the 7 words in front of the run come from the previous lane's column
-__device__ __forceinline__ void load_piece_first(const unsigned char *own /* word 0 of the run */, const unsigned char *hist /* word (run words - 7) of the previous column */,
-                                                 uint32_t (&AA)[15], uint32_t (&BB)[14])
+// one of the pieces that open the block (piece PC, 8 PC < NPM): the words in front of the run come from the previous lane's column
+template <int NPM, int PC>
+__device__ __forceinline__ void load_piece_head(const unsigned char *own /* word 0 of the run */, const unsigned char *prev_end /* word `run words` of the previous column: one past its last */,
+                                                uint32_t (&AA)[NPM + 8], uint32_t (&BB)[NPM + 7])
 {
 #pragma unroll
-	for(int j = 0; j < 7; j++) AA[j] = *(const uint32_t *)(hist + j * EG_ROW);
+	for(int j = 0; j < NPM + 8; j++) {
+		constexpr int dummy = 0; (void)dummy;
+		const int w = 8 * PC - NPM + j;                      // word of the run (negative: of the previous lane's run, counted from its end)
+		AA[j] = w < 0 ? *(const uint32_t *)(prev_end + w * (int)EG_ROW) : *(const uint32_t *)(own + w * (int)EG_ROW);
+	}
 #pragma unroll
-	for(int j = 7; j < 15; j++) AA[j] = *(const uint32_t *)(own + (j - 7) * EG_ROW);
-#pragma unroll
-	for(int m = 0; m < 14; m++) BB[m] = __builtin_amdgcn_alignbit(AA[m + 1], AA[m], 16);
+	for(int m = 0; m < NPM + 7; m++) BB[m] = __builtin_amdgcn_alignbit(AA[m + 1], AA[m], 16);
 }
 
 // one slot of the pair: a residual candidate's folded taps and scalars, all wave-uniform
-struct EgSlot { uint32_t Q[7]; uint32_t shift, bias, order, npf, precision, ci; };
+template <int NPM> struct EgSlot { uint32_t Q[NPM]; uint32_t shift, bias, order, npf, precision, ci; };
 
 // LDS of one wavefront: [image (S/2 rows of 65 words)][prefix sums | divisor table | best parameters (flacgpu_evalg.h)]
 // WPC wavefronts share a channel's image and split its candidates between them (each has its own search state; the better of their
@@ -127,6 +145,8 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	const int lane = tid & 63;
 	const uint32_t wave = WPC > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) : 0u;
 	constexpr int AHEAD = EG_PIECES_AHEAD / WPC;
+	constexpr int NPM = eg_npm<MAXORD>(), NQ = 2 * NPM - 1;               // folded tap pairs; taps of a candidate record a lane holds (13 | 33)
+	static_assert(MAXORD < NQ, "a record holds the predictor's taps");
 	const uint32_t n = P.blocksize, S = n / 64;
 	const uint32_t aslots = P.norders * P.nprec, cstride = P.ncslots;
 	// ---- every load from HBM goes out before the first use: one round trip, not three ------------------------------------
@@ -134,9 +154,9 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	const uint32_t nanalyses = jt->nanalyses;
 	int c_vflag = 0;
 	uint32_t c_order = 0, c_shift = 0, c_prec = 0, c_wide = 0;
-	int32_t cq[13];
+	int32_t cq[NQ];
 #pragma unroll
-	for(int j = 0; j < 13; j++) cq[j] = 0;
+	for(int j = 0; j < NQ; j++) cq[j] = 0;
 	if((uint32_t)lane < cstride) {                                            // lane c holds candidate c (cstride <= EG_MAXC)
 		const size_t ix = (size_t)fc * cstride + (uint32_t)lane;
 		c_vflag = valid[ix];
@@ -173,22 +193,25 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	if(pr.fmt != 1 || !narrow || frame_max_po > 6) return false;
 
 	// ---- candidate records: folded taps, and whether this kernel's arithmetic is exact for them --------------------------------
-	uint32_t Qv[7];
+	uint32_t Qv[NPM];
 	const bool c_valid = (uint32_t)lane < nan && c_vflag != 0;
 	bool c_ok = true;
 	{
-		int32_t t[14];
+		int32_t t[2 * NPM];
 		uint32_t abs_sum = 0;
 #pragma unroll
-		for(int j = 0; j < 13; j++) {
+		for(int j = 0; j < NQ; j++) {
 			const int32_t q = (uint32_t)j < c_order ? cq[j] : 0;
 			t[j + 1] = q;
 			abs_sum += (uint32_t)(q < 0 ? -q : q);
 		}
 		t[0] = -(int32_t)(1u << (c_shift & 15u));
 #pragma unroll
-		for(int p = 0; p < 7; p++) Qv[p] = ((uint32_t)t[2 * p] << 16) | ((uint32_t)t[2 * p + 1] & 0xffffu);
-		if(c_valid) c_ok = c_wide == 0 && c_order <= (uint32_t)MAXORD && c_shift <= 15u
+		for(int p = 0; p < NPM; p++) Qv[p] = ((uint32_t)t[2 * p] << 16) | ((uint32_t)t[2 * p + 1] & 0xffffu);
+		// (from 13 taps up the reference runs the 64-bit routine on 16-bit input -- bps + precision + ilog2(order) > 32, lpc.c:942-976 --:
+		//  where the bound below holds, the sum it forms fits 32 bits and the chain here forms the same integer; the overflow-checked
+		//  flavour, wide == 2, stays out)
+		if(c_valid) c_ok = (MAXORD <= 12 ? c_wide == 0 : c_wide <= 1) && c_order <= (uint32_t)MAXORD && c_shift <= 15u
 		                   && (((uint64_t)abs_sum + (1u << (c_shift & 15u))) << (sbps - 1)) < (1ull << 31);
 	}
 	if(__any((int)!c_ok)) return false;
@@ -202,7 +225,7 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	{
 		const bool spow2 = (vps & (vps - 1)) == 0;
 		const uint32_t vlog = ilog2_u32(vps);
-		if(tid < 8) *(uint32_t *)(smem + (rows - 8 + (uint32_t)tid) * EG_ROW) = 0;      // column 0: lane 0's history
+		if(tid < NPM + 1) *(uint32_t *)(smem + (rows - (NPM + 1) + (uint32_t)tid) * EG_ROW) = 0;      // column 0: lane 0's history
 #pragma unroll
 		for(int i = 0; i < AHEAD; i++) {
 			const uint32_t m = (uint32_t)tid + 64u * WPC * (uint32_t)i;
@@ -231,7 +254,7 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	eg_search_setup<MAXORD>(R, smem, tail_off, S, frame_max_po, frame_min_po, P.rice_limit, lane, jt);
 	(void)img_bytes;
 	const unsigned char *own = smem + ((uint32_t)lane + 1) * 4;                      // word 0 of this lane's run
-	const unsigned char *hist = smem + (uint32_t)lane * 4 + (rows - 7) * EG_ROW;     // 7 words in front of it: the previous column's last
+	const unsigned char *prev_end = smem + (uint32_t)lane * 4 + rows * EG_ROW;       // one past the previous column's last word: the words in front of the run lie below it
 	const uint32_t npieces = S / 16;                                                   // whole 16-sample pieces of a run; S % 16 == 8: a half piece behind them
 	const uint32_t sum0 = 0x80000000u;
 	if(WPC > 1) {
@@ -247,14 +270,14 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 
 	// ---- the candidates, two at a time ----------------------------------------------------------------------------------------
 	while(vmask) {
-		EgSlot A, B;
+		EgSlot<NPM> A, B;
 		const uint32_t ci0 = (uint32_t)__builtin_ctzll(vmask);
 		vmask &= vmask - 1;
 		const bool two = vmask != 0;
 		const uint32_t ci1 = two ? (uint32_t)__builtin_ctzll(vmask) : ci0;
 		if(two) vmask &= vmask - 1;
 #pragma unroll
-		for(int p = 0; p < 7; p++) { A.Q[p] = rdlane(Qv[p], ci0); B.Q[p] = rdlane(Qv[p], ci1); }
+		for(int p = 0; p < NPM; p++) { A.Q[p] = rdlane(Qv[p], ci0); B.Q[p] = rdlane(Qv[p], ci1); }
 		A.shift = rdlane(c_shift, ci0); B.shift = rdlane(c_shift, ci1);
 		A.order = rdlane(c_order, ci0); B.order = rdlane(c_order, ci1);
 		A.precision = rdlane(c_prec, ci0); B.precision = rdlane(c_prec, ci1);
@@ -264,35 +287,53 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 
 		uint32_t v0 = 0, v1 = 0;
 		{
-			uint32_t AA[15], BB[14];
-			load_piece_first(own, hist, AA, BB);
-			v0 = fir16_dispatch<true>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, lane == 0, sum0, v0);
-			if(two) v1 = fir16_dispatch<true>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, lane == 0, sum0, v1);
+			uint32_t AA[NPM + 8], BB[NPM + 7];
+			load_piece_head<NPM, 0>(own, prev_end, AA, BB);
+			v0 = fir16_dispatch<0, 16, NPM>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, lane == 0, sum0, v0);
+			if(two) v1 = fir16_dispatch<0, 16, NPM>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, lane == 0, sum0, v1);
+		}
+		if constexpr(NPM > 8) {
+			// (17 pairs: the windows of pieces 1 and 2 still reach in front of the run, and warm-up samples 16..31 lie in piece 1; runs of
+			//  at least 48 samples, evalg_applicable)
+			{
+				uint32_t AA[NPM + 8], BB[NPM + 7];
+				load_piece_head<NPM, 1>(own, prev_end, AA, BB);
+				v0 = fir16_dispatch<1, 16, NPM>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, lane == 0, sum0, v0);
+				if(two) v1 = fir16_dispatch<1, 16, NPM>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, lane == 0, sum0, v1);
+			}
+			{
+				uint32_t AA[NPM + 8], BB[NPM + 7];
+				load_piece_head<NPM, 2>(own, prev_end, AA, BB);
+				v0 = fir16_dispatch<-1, 16, NPM>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+				if(two) v1 = fir16_dispatch<-1, 16, NPM>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+			}
 		}
 #pragma unroll 1
-		for(uint32_t c = 1; c < npieces; c++) {
-			uint32_t AA[15], BB[14];
-			load_piece(own + (8 * c - 7) * EG_ROW, AA, BB);
-			v0 = fir16_dispatch<false>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
-			if(two) v1 = fir16_dispatch<false>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+		for(uint32_t c = NPM > 8 ? 3 : 1; c < npieces; c++) {
+			uint32_t AA[NPM + 8], BB[NPM + 7];
+			load_piece<NPM>(own + (int)(8 * c - NPM) * (int)EG_ROW, AA, BB);
+			v0 = fir16_dispatch<-1, 16, NPM>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+			if(two) v1 = fir16_dispatch<-1, 16, NPM>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
 		}
+		if constexpr(NPM == 7) {
 		if(S & 15u) {
 			// the short piece that ends the run: 8 samples (4608-sample blocks), 4 (2304) or 2 (1152) -- the words it loads behind the run
 			// are never used
-			uint32_t AA[15], BB[14];
-			load_piece(own + (8 * npieces - 7) * EG_ROW, AA, BB);
+			uint32_t AA[NPM + 8], BB[NPM + 7];
+			load_piece<NPM>(own + (int)(8 * npieces - NPM) * (int)EG_ROW, AA, BB);
 			if((S & 15u) == 8u) {
-				v0 = fir16_dispatch<false, 8>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
-				if(two) v1 = fir16_dispatch<false, 8>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+				v0 = fir16_dispatch<-1, 8, NPM>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+				if(two) v1 = fir16_dispatch<-1, 8, NPM>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
 			}
 			else if((S & 15u) == 4u) {
-				v0 = fir16_dispatch<false, 4>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
-				if(two) v1 = fir16_dispatch<false, 4>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+				v0 = fir16_dispatch<-1, 4, NPM>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+				if(two) v1 = fir16_dispatch<-1, 4, NPM>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
 			}
 			else {
-				v0 = fir16_dispatch<false, 2>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
-				if(two) v1 = fir16_dispatch<false, 2>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
+				v0 = fir16_dispatch<-1, 2, NPM>(A.npf, AA, BB, A.Q, A.shift, A.bias, A.order, false, sum0, v0);
+				if(two) v1 = fir16_dispatch<-1, 2, NPM>(B.npf, AA, BB, B.Q, B.shift, B.bias, B.order, false, sum0, v1);
 			}
+		}
 		}
 		// sums that leave the 32-bit arithmetic of the node passes: the channel is eval_list_kernel's (nothing was written yet)
 		if(__any((int)((v0 | v1) >= (1u << 23)))) { if(WPC == 1) return false; leave = true; break; }
@@ -313,12 +354,13 @@ __device__ __forceinline__ bool evalg_body(const DevParams &P, const int32_t *__
 	}       // any
 	else if(WPC > 1 && wave != 0) return true;                                    // a channel without candidates: wavefront 0 decides it
 
-	eg_decide<MAXORD>(R, P, pr, n, kbest, c_order, c_prec, c_shift, cq, decisions + fc, preps + fc, lane);
+	eg_decide<MAXORD, NQ>(R, P, pr, n, kbest, c_order, c_prec, c_shift, cq, decisions + fc, preps + fc, lane);
 	return true;
 }
 
 template <int MAXORD, int WPC>
-__global__ __launch_bounds__(64 * WPC, EVALG_WAVES_PER_SIMD) void evalg_kernel(const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
+__global__ __launch_bounds__(64 * WPC, MAXORD > 12 ? 3 : EVALG_WAVES_PER_SIMD) void evalg_kernel(      // (17 tap pairs: a window of 49 words and 50 registers of records)
+                                                                          const DevParams P, const int32_t *__restrict__ chan, uint32_t nframes, uint32_t tail_n,
                                                                           const JobTable *__restrict__ jt, ChanPrep *__restrict__ preps, const Candidate *__restrict__ cands,
                                                                           const int *__restrict__ valid, SubDecision *__restrict__ decisions,
                                                                           uint32_t *__restrict__ left, uint32_t *__restrict__ nleft)
@@ -339,7 +381,10 @@ bool evalg_applicable(const DevParams &P)
 	const int off = tune().no_evalg;
 	const uint32_t S = P.blocksize / 64;
 	const uint32_t tail = S % 16;                                           // a run's last piece: whole, or 8, 4 or 2 samples
-	return !off && P.blocksize % 64 == 0 && S >= 16 && (tail == 0 || tail == 8 || tail == 4 || tail == 2) && P.max_lpc_order <= 12 && !P.wide_samples && !P.stream_sig && P.ncslots <= (uint32_t)EG_MAXC && P.blocksize <= 16384;
+	if(off || P.blocksize % 64 != 0 || P.wide_samples || P.stream_sig || P.ncslots > (uint32_t)EG_MAXC || P.blocksize > 16384) return false;
+	// predictors of 13..32 taps (round 6): runs of whole pieces, three of them at least (the windows of the first three reach in front of the run)
+	if(P.max_lpc_order > 12) return P.max_lpc_order <= 32 && S >= 48 && tail == 0 && !tune().no_evalg32;
+	return S >= 16 && (tail == 0 || tail == 8 || tail == 4 || tail == 2);
 }
 template <int MAXORD, int WPC>
 static hipError_t launch_evalg_t(const DevParams &P, uint32_t nframes, uint32_t tail_n, const JobTable *jt, const AnalyzeBuffers &B, SubDecision *dec, hipStream_t s)
@@ -360,6 +405,7 @@ hipError_t launch_evalg(const DevParams &P, uint32_t nframes, uint32_t tail_n, c
 	// kernel's idle quarter is not a lack of wavefronts
 	const int wpc = tune().eval_wpc;
 	const bool two = wpc == 2 && P.ncslots >= 4;
+	if(P.max_lpc_order > 12) return launch_evalg_t<32, 1>(P, nframes, tail_n, jt, B, dec, s);
 	if(P.max_lpc_order <= 8) return two ? launch_evalg_t<8, 2>(P, nframes, tail_n, jt, B, dec, s) : launch_evalg_t<8, 1>(P, nframes, tail_n, jt, B, dec, s);
 	return two ? launch_evalg_t<12, 2>(P, nframes, tail_n, jt, B, dec, s) : launch_evalg_t<12, 1>(P, nframes, tail_n, jt, B, dec, s);
 }
