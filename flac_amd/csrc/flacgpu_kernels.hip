@@ -1513,15 +1513,17 @@ struct FFShared {
 	uint32_t rec[4][12];                                   // their decision records (FFDec, word by word), between the decision loop and the frame
 };
 struct FFDec { uint32_t which, type, order, wasted, sbps, bits, po, rice2; int32_t constant; };
-// x^(416 m) mod P, m = 0..127: the span shifts of frame_crc16_p2<64, 13> (52-byte spans)
-struct FFSpan { uint16_t x[FF_XSPAN]; };
+// x^(416 m) mod P, m = 0..255: the span shifts of frame_crc16_p2<64, 13> (52-byte spans).  The first FF_XSPAN of them are copied to
+// LDS; the frames of 17..24-bit input (up to 7.5 KB: 145 spans) read the rest here
+constexpr uint32_t FF_XSPAN_ALL = 256;
+struct FFSpan { uint16_t x[FF_XSPAN_ALL]; };
 constexpr FFSpan make_ff_span()
 {
 	FFSpan t{};
 	uint32_t xs = 1;
 	for(int r = 0; r < 52; r++) xs = crc_mulx8(xs);                          // x^416
 	uint32_t c = 1;
-	for(uint32_t m = 0; m < FF_XSPAN; m++) {
+	for(uint32_t m = 0; m < FF_XSPAN_ALL; m++) {
 		t.x[m] = (uint16_t)c;
 		uint32_t r = 0, b = xs;
 		for(int i = 0; i < 16; i++) { r = crc_mulx(r); if(b & 0x8000u) r ^= c; b = (b << 1) & 0xffffu; }
@@ -1537,13 +1539,22 @@ __device__ const FFDiv g_ff_div_tab = make_ff_div();
 #define g_ff_div g_ff_div_tab.v
 __host__ __device__ inline uint32_t ff_tile_bytes(uint32_t slot_bytes) { const uint32_t img = (slot_bytes + 8 + 15) & ~15u; return img > (uint32_t)FF_TILE_BYTES ? img : (uint32_t)FF_TILE_BYTES; }
 
+// A lane's window: its 18 samples of both channels and the four in front of them.  Up to 16 bits per sample it stays packed, left
+// in the low and right in the high half of a word: 22 registers instead of 44 across the kernel.  WIDE (round 6: 17..24-bit input,
+// which the reference serves by the same code with its wide sums, stream_encoder.c:4098-4108, fixed.c:301): a register per sample
+// and channel.
+template <bool WIDE> struct FFWin;
+template <> struct FFWin<false> { uint32_t w[FF_RUN + 4]; };
+template <> struct FFWin<true> { int32_t a[FF_RUN + 4], b[FF_RUN + 4]; };
+template <bool WIDE> __device__ __forceinline__ int32_t ff_left(const FFWin<WIDE> &W, int k) { if constexpr(WIDE) return W.a[k]; else return (int32_t)(int16_t)(W.w[k] & 0xffffu); }
+template <bool WIDE> __device__ __forceinline__ int32_t ff_right(const FFWin<WIDE> &W, int k) { if constexpr(WIDE) return W.b[k]; else return (int32_t)W.w[k] >> 16; }
 // the candidate channel `which` (0 left, 1 right, 2 mid, 3 side) of this lane's window
-// (the window stays packed, left in the low and right in the high half of a word: 22 registers instead of 44 across the kernel)
-__device__ __forceinline__ void ff_channel(const uint32_t (&w)[FF_RUN + 4], uint32_t which, int32_t (&x)[FF_RUN + 4])
+template <bool WIDE>
+__device__ __forceinline__ void ff_channel(const FFWin<WIDE> &W, uint32_t which, int32_t (&x)[FF_RUN + 4])
 {
 #pragma unroll
 	for(int k = 0; k < FF_RUN + 4; k++) {
-		const int32_t a = (int32_t)(int16_t)(w[k] & 0xffffu), b = (int32_t)w[k] >> 16;
+		const int32_t a = ff_left<WIDE>(W, k), b = ff_right<WIDE>(W, k);
 		x[k] = which == 0 ? a : which == 1 ? b : which == 2 ? ((a + b) >> 1) : (a - b);
 	}
 }
@@ -1582,7 +1593,7 @@ __device__ __noinline__ uint64_t ff_rice_search_wide(uint32_t v, uint32_t n, uin
 }
 
 // statistics and decision of one candidate channel (CPO: the partition order range when it is the presets' 0..3, else -1)
-template <int CPO>
+template <int CPO, bool WIDE>
 __device__ __forceinline__ void ff_decide(const DevParams &P, uint32_t which, const int32_t (&x)[FF_RUN + 4], bool disable_constant, FFShared *sh, uint32_t *leaf, int lane, FFDec &D, uint32_t &alleq)
 {
 	constexpr uint32_t n = FF_N;
@@ -1592,11 +1603,18 @@ __device__ __forceinline__ void ff_decide(const DevParams &P, uint32_t which, co
 	for(int k = 0; k < 5; k++) A.e[k] = 0;
 	const int32_t first = (int32_t)__builtin_amdgcn_readfirstlane(x[4]);          // sample 0 of the block (lane 0's first own sample)
 	uint32_t cs[5], ex[5] = {0, 0, 0, 0, 0};
-	prep2_chunk<false, false, true, FF_RUN>(x, lane == 0, first, A, cs, ex);
+	if constexpr(WIDE) {
+		// |d4| <= 16 max|x|: a lane's eighteen stay below 2^32 for samples of up to 24 bits, not for the 25-bit side channel -- that one
+		// adds every |difference| to the 64-bit sums (prep2_kernel<true, ., true> draws the same line)
+		if(which == 3) prep2_chunk<true, false, true, FF_RUN>(x, lane == 0, first, A, cs, ex);
+		else prep2_chunk<false, false, true, FF_RUN>(x, lane == 0, first, A, cs, ex);
+	}
+	else prep2_chunk<false, false, true, FF_RUN>(x, lane == 0, first, A, cs, ex);
 	const uint32_t orv = wave_or_u32(A.orv), diff = wave_or_u32(A.diff);
 	uint64_t e[5];
 #pragma unroll
-	for(int k = 0; k < 5; k++) e[k] = wave_sum_u32((uint32_t)A.e[k]);            // < 2^31: 1152 fourth differences of 17-bit samples
+	for(int k = 0; k < 5; k++) e[k] = WIDE ? wave_sum_u50(A.e[k])               // < 2^39: 1152 fourth differences of 25-bit samples
+	                                       : wave_sum_u32((uint32_t)A.e[k]);    // < 2^31: 1152 fourth differences of 17-bit samples
 	alleq = diff == 0 ? 1u : 0u;
 	uint32_t wasted = orv ? (uint32_t)(__ffs((int)orv) - 1) : 0;
 	if(wasted > P.bps) wasted = P.bps;
@@ -1638,17 +1656,33 @@ __device__ __forceinline__ void ff_decide(const DevParams &P, uint32_t which, co
 		const uint32_t fmin = umin32(P.min_po, fmax), ee = 6 - fmax;
 		// this lane's 18 samples are one of the 64 leaves of the search: the chunk sum of the chosen order (what the residual has in front
 		// of sample 4 added on lane 0), shifted like the signal
-		uint32_t v = fixed_order == 0 ? cs[0] : fixed_order == 1 ? cs[1] : fixed_order == 2 ? cs[2] : fixed_order == 3 ? cs[3] : cs[4];
-		if(lane == 0) v += fixed_order == 0 ? ex[0] : fixed_order == 1 ? ex[1] : fixed_order == 2 ? ex[2] : fixed_order == 3 ? ex[3] : ex[4];
-		v >>= wasted;
 		uint32_t po = 0, rbits;
-		// (a leaf partition is 2^ee lanes: rice_search_nodes wants its sum below 2^23)
-		if(__any((int)(v >= ((1u << 23) >> ee)))) {
-			const uint64_t r = ff_rice_search_wide(v, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, leaf, sh->kout[which], lane);
-			rbits = (uint32_t)r; po = (uint32_t)(r >> 32);
+		if constexpr(WIDE) {
+			// (A.e[] is this lane's sum in both flavours of the chunk: the lane has one chunk)
+			uint64_t v64 = fixed_order == 0 ? A.e[0] : fixed_order == 1 ? A.e[1] : fixed_order == 2 ? A.e[2] : fixed_order == 3 ? A.e[3] : A.e[4];
+			if(lane == 0) v64 += fixed_order == 0 ? ex[0] : fixed_order == 1 ? ex[1] : fixed_order == 2 ? ex[2] : fixed_order == 3 ? ex[3] : ex[4];
+			v64 >>= wasted;
+			// rice_search_nodes is exact while no partition sum reaches 2^31 (its (sum << 1) >> k is the one place that could wrap; the
+			// parameter and the bit counts are far from it): every lane below 2^25 guarantees that.  Beyond: the same search on 64-bit
+			// sums, the leaf's lanes holding its sum between them (rice_search_owner; `narrow`: stream_encoder.c:4814-4817)
+			if(__any((int)(v64 >= (1ull << 25)))) {
+				const bool narrow = (sbps + 4) < (32 - ilog2_u32(n >> fmax));
+				rbits = rice_search_owner(v64, narrow, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
+			}
+			else rbits = rice_search_nodes((uint32_t)v64, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
 		}
-		else if(CPO == 3) rbits = rice_search_nodes<3, 3>(v, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
-		else rbits = rice_search_nodes(v, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
+		else {
+			uint32_t v = fixed_order == 0 ? cs[0] : fixed_order == 1 ? cs[1] : fixed_order == 2 ? cs[2] : fixed_order == 3 ? cs[3] : cs[4];
+			if(lane == 0) v += fixed_order == 0 ? ex[0] : fixed_order == 1 ? ex[1] : fixed_order == 2 ? ex[2] : fixed_order == 3 ? ex[3] : ex[4];
+			v >>= wasted;
+			// (a leaf partition is 2^ee lanes: rice_search_nodes wants its sum below 2^23)
+			if(__any((int)(v >= ((1u << 23) >> ee)))) {
+				const uint64_t r = ff_rice_search_wide(v, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, leaf, sh->kout[which], lane);
+				rbits = (uint32_t)r; po = (uint32_t)(r >> 32);
+			}
+			else if(CPO == 3) rbits = rice_search_nodes<3, 3>(v, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
+			else rbits = rice_search_nodes(v, ee, n, fixed_order, fmax, fmin, P.rice_limit, sh->divtab, sh->kout[which], &po, lane);
+		}
 		const uint32_t est = sat_add_u32(hdr + fixed_order * sbps, rbits);
 		if(est > 0 && est < D.bits) { D.type = 2; D.bits = est; D.po = po; D.order = fixed_order; }
 	}
@@ -1669,17 +1703,19 @@ __device__ __forceinline__ void ff_decide(const DevParams &P, uint32_t which, co
 #define FF_WAVES 4           // (the LDS allows four wavefronts per SIMD)
 #endif
 // ff_channel with the channel a scalar register: a branch per flavour instead of three selects per word
-__device__ __forceinline__ void ff_channel_u(const uint32_t (&w)[FF_RUN + 4], uint32_t which, int32_t (&x)[FF_RUN + 4])
+template <bool WIDE>
+__device__ __forceinline__ void ff_channel_u(const FFWin<WIDE> &w, uint32_t which, int32_t (&x)[FF_RUN + 4])
 {
-	if(which == 0) ff_channel(w, 0, x);
-	else if(which == 1) ff_channel(w, 1, x);
-	else if(which == 2) ff_channel(w, 2, x);
-	else ff_channel(w, 3, x);
+	if(which == 0) ff_channel<WIDE>(w, 0, x);
+	else if(which == 1) ff_channel<WIDE>(w, 1, x);
+	else if(which == 2) ff_channel<WIDE>(w, 2, x);
+	else ff_channel<WIDE>(w, 3, x);
 }
 // one subframe's share of the frame, before a bit of it is written: the folded residuals u (FIXED), the lane's Rice parameter,
 // where in the subframe's residual section the lane's codes start, and the subframe's length in bits (everything but u uniform)
 struct FFSub { uint32_t k, excl, end, bits; bool starts; };
-__device__ __forceinline__ void ff_subframe_sizes(const uint32_t (&w)[FF_RUN + 4], const FFDec &d, const FFShared *sh, int lane, uint32_t (&u)[FF_RUN], FFSub &S)
+template <bool WIDE>
+__device__ __forceinline__ void ff_subframe_sizes(const FFWin<WIDE> &w, const FFDec &d, const FFShared *sh, int lane, uint32_t (&u)[FF_RUN], FFSub &S)
 {
 	constexpr uint32_t n = FF_N;
 	S.k = 0; S.excl = 0; S.end = 0; S.starts = false;
@@ -1687,7 +1723,7 @@ __device__ __forceinline__ void ff_subframe_sizes(const uint32_t (&w)[FF_RUN + 4
 	if(d.type == 1) { S.bits = 8 + d.wasted + n * d.sbps; return; }
 	// the residual of the fixed predictor of this order = the order-th difference (fixed.c:470) of the shifted channel
 	int32_t dd[FF_RUN + 4];
-	ff_channel_u(w, d.which, dd);
+	ff_channel_u<WIDE>(w, d.which, dd);
 	if(d.wasted) {
 #pragma unroll
 		for(int t = 0; t < FF_RUN + 4; t++) dd[t] >>= d.wasted;
@@ -1720,7 +1756,8 @@ __device__ __forceinline__ void ff_subframe_sizes(const uint32_t (&w)[FF_RUN + 4
 	S.bits = 8 + d.wasted + d.order * d.sbps + 6 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 // ... and its bits, at bit `pos` of the zeroed frame image (stream_encoder_framing.c:393-594, bitwriter.c:575-706)
-__device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t img_abs /* LDS byte address of img */, uint32_t cap_words, uint32_t pos, const uint32_t (&w)[FF_RUN + 4], const FFDec &d, const uint32_t (&u)[FF_RUN], const FFSub &S, int lane)
+template <bool WIDE>
+__device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t img_abs /* LDS byte address of img */, uint32_t cap_words, uint32_t pos, const FFWin<WIDE> &w, const FFDec &d, const uint32_t (&u)[FF_RUN], const FFSub &S, int lane)
 {
 	const uint32_t type = d.type, order = d.order, wasted = d.wasted, sbps = d.sbps;
 	const uint32_t type_bits = type == 0 ? 0x00u : type == 1 ? 0x02u : (0x10u | (order << 1));
@@ -1736,7 +1773,7 @@ __device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t img_ab
 	}
 	if(type == 1) {
 		int32_t x[FF_RUN + 4];
-		ff_channel_u(w, d.which, x);
+		ff_channel_u<WIDE>(w, d.which, x);
 #pragma unroll
 		for(int t = 0; t < FF_RUN; t++) or_bits(img, cap_words, pos + ((uint32_t)lane * FF_RUN + (uint32_t)t) * sbps, (uint32_t)(x[t + 4] >> wasted) & smask, sbps);
 		return;
@@ -1746,8 +1783,7 @@ __device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t img_ab
 #pragma unroll
 		for(int i = 0; i < 4; i++) {
 			if((uint32_t)i < order) {
-				const uint32_t wi = w[4 + i];
-				const int32_t a = (int32_t)(int16_t)(wi & 0xffffu), b = (int32_t)wi >> 16;
+				const int32_t a = ff_left<WIDE>(w, 4 + i), b = ff_right<WIDE>(w, 4 + i);
 				const int32_t xv = d.which == 0 ? a : d.which == 1 ? b : d.which == 2 ? ((a + b) >> 1) : (a - b);
 				or_bits(img, cap_words, pos + (uint32_t)i * sbps, (uint32_t)(xv >> wasted) & smask, sbps);
 			}
@@ -1785,8 +1821,8 @@ __device__ __forceinline__ void ff_subframe_write(uint32_t *img, uint32_t img_ab
 	}
 }
 
-template <int MS, int CPO>       // DevParams::ms_mode; partition orders 0..CPO known at compile time (3: what -0 .. -2 set), or -1
-__global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint64_t first_frame_number,
+template <int MS, int CPO, bool WIDE = false>    // DevParams::ms_mode; partition orders 0..CPO known at compile time (3: what -0 .. -2 set), or -1; WIDE: 17..24-bit input
+__global__ __launch_bounds__(64, WIDE ? 3 : FF_WAVES) void ff_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint64_t first_frame_number,
                                                  uint8_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, FrameInfo *__restrict__ info, const PackOut O)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1806,7 +1842,7 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	// two wavefront barriers -- a tenth of the kernel's instructions for a layout change the memory system does as well
 	// (profiles/archive/r04_n_ff_direct_loads_ab.txt).  The four samples in front of a lane's run are its left neighbour's last four:
 	// a DPP shift by one lane (lane 0 gets zeros: the start of the block).
-	uint32_t w[FF_RUN + 4];
+	FFWin<WIDE> w;
 	{
 		const fo_u4 *p = (const fo_u4 *)(pcm + (size_t)f * n * 2) + (uint32_t)lane * (FF_RUN / 2);
 		fo_u4 v[FF_RUN / 2];
@@ -1821,14 +1857,29 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 		for(int k = 0; k < 8; k++) ((uint32_t *)sh->crc_tab)[(uint32_t)lane + 64u * (uint32_t)k] = tv[k];
 		((uint32_t *)sh->xspan)[lane] = xv;
 		if(lane < 35) { const uint32_t po = (uint32_t)lane / 5u, o = (uint32_t)lane - po * 5u; sh->divtab[po * (MAX_ORDER + 1) + o] = g_ff_div[lane]; }
-		// left in the low half, right in the high half of a word: one byte permute per sample
+		if constexpr(WIDE) {
+			// (the loaded words are the window)
 #pragma unroll
-		for(int k = 0; k < FF_RUN / 2; k++) {
-			w[4 + 2 * k] = __builtin_amdgcn_perm(v[k].y, v[k].x, 0x05040100u);
-			w[4 + 2 * k + 1] = __builtin_amdgcn_perm(v[k].w, v[k].z, 0x05040100u);
+			for(int k = 0; k < FF_RUN / 2; k++) {
+				w.a[4 + 2 * k] = (int32_t)v[k].x; w.b[4 + 2 * k] = (int32_t)v[k].y;
+				w.a[4 + 2 * k + 1] = (int32_t)v[k].z; w.b[4 + 2 * k + 1] = (int32_t)v[k].w;
+			}
+#pragma unroll
+			for(int k = 0; k < 4; k++) {
+				w.a[k] = __builtin_amdgcn_update_dpp(0, w.a[FF_RUN + k], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+				w.b[k] = __builtin_amdgcn_update_dpp(0, w.b[FF_RUN + k], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+			}
 		}
+		else {
+			// left in the low half, right in the high half of a word: one byte permute per sample
 #pragma unroll
-		for(int k = 0; k < 4; k++) w[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[FF_RUN + k], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+			for(int k = 0; k < FF_RUN / 2; k++) {
+				w.w[4 + 2 * k] = __builtin_amdgcn_perm(v[k].y, v[k].x, 0x05040100u);
+				w.w[4 + 2 * k + 1] = __builtin_amdgcn_perm(v[k].w, v[k].z, 0x05040100u);
+			}
+#pragma unroll
+			for(int k = 0; k < 4; k++) w.w[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w.w[FF_RUN + k], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+		}
 	}
 	__builtin_amdgcn_wave_barrier();
 
@@ -1843,7 +1894,8 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 #pragma unroll
 		for(int t = 0; t < FF_RUN; t++) {
 			if(t > 0 || lane > 0) {
-				const int32_t pl = ((int32_t)(int16_t)(w[t + 4] & 0xffffu)) - ((int32_t)(int16_t)(w[t + 3] & 0xffffu)), pr = ((int32_t)w[t + 4] >> 16) - ((int32_t)w[t + 3] >> 16);
+				// (24-bit samples: |pl|, |pr| < 2^25, eighteen times 3 * 2^25 stay below 2^32)
+				const int32_t pl = ff_left<WIDE>(w, t + 4) - ff_left<WIDE>(w, t + 3), pr = ff_right<WIDE>(w, t + 4) - ff_right<WIDE>(w, t + 3);
 				lr += (uint32_t)(abs(pl) + abs(pr));
 				ms += (uint32_t)(abs((pl + pr) >> 1) + abs(pl - pr));
 			}
@@ -1853,10 +1905,17 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 		if(P.limit_min_bitrate) {
 			// (the all-equal flag of the left channel decides whether the second subframe may be CONSTANT, stream_encoder.c:3874-3879)
 			uint32_t dl = 0;
+			if constexpr(WIDE) {
 #pragma unroll
-			for(int t = 0; t < FF_RUN; t++) dl |= (w[t + 4] ^ w[4]) & 0xffffu;
-			const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[4]);
-			dl |= (w[4] ^ fl) & 0xffffu;
+				for(int t = 0; t < FF_RUN; t++) dl |= (uint32_t)(w.a[t + 4] ^ w.a[4]);
+				dl |= (uint32_t)(w.a[4] ^ __builtin_amdgcn_readfirstlane(w.a[4]));
+			}
+			else {
+#pragma unroll
+				for(int t = 0; t < FF_RUN; t++) dl |= (w.w[t + 4] ^ w.w[4]) & 0xffffu;
+				const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.w[4]);
+				dl |= (w.w[4] ^ fl) & 0xffffu;
+			}
 			alleq_l = wave_or_u32(dl) == 0 ? 1u : 0u;
 		}
 		li = use_ms ? 2 : 0; ri = use_ms ? 3 : 1;
@@ -1876,13 +1935,19 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 			}
 			// (the window is the same in every pass, and so are its unpacked halves, their mean and their difference: the compiler
 			//  would keep all four, 88 registers, across the loop -- the empty asm makes the words look new in every pass)
+			if constexpr(WIDE) {
 #pragma unroll
-			for(int k = 0; k < FF_RUN + 4; k++) asm volatile("" : "+v"(w[k]));
+				for(int k = 0; k < FF_RUN + 4; k++) { asm volatile("" : "+v"(w.a[k])); asm volatile("" : "+v"(w.b[k])); }
+			}
+			else {
+#pragma unroll
+				for(int k = 0; k < FF_RUN + 4; k++) asm volatile("" : "+v"(w.w[k]));
+			}
 			int32_t x[FF_RUN + 4];
-			ff_channel_u(w, which, x);
+			ff_channel_u<WIDE>(w, which, x);
 			FFDec D;
 			uint32_t alleq = 0;
-			ff_decide<CPO>(P, which, x, dc, sh, leaf, lane, D, alleq);
+			ff_decide<CPO, WIDE>(P, which, x, dc, sh, leaf, lane, D, alleq);
 			if(ci == 0 && MS != 2) alleq_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)alleq);
 			if(lane == 0) {
 				uint32_t *rec = sh->rec[ci];
@@ -1919,8 +1984,8 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 	const uint32_t pos0 = 8 * frame_header_len(P, n, frame_number);
 	uint32_t uL[FF_RUN], uR[FF_RUN];
 	FFSub SL, SR;
-	ff_subframe_sizes(w, DL, sh, lane, uL, SL);
-	ff_subframe_sizes(w, DR, sh, lane, uR, SR);
+	ff_subframe_sizes<WIDE>(w, DL, sh, lane, uL, SL);
+	ff_subframe_sizes<WIDE>(w, DR, sh, lane, uR, SR);
 	const uint32_t pos = pos0 + SL.bits + SR.bits;
 	const uint32_t body_bytes = (pos + 7) >> 3, total_bytes = body_bytes + 2;
 	const bool overflow = total_bytes > P.slot_bytes;
@@ -1944,8 +2009,8 @@ __global__ __launch_bounds__(64, FF_WAVES) void ff_kernel(const DevParams P, con
 		if(lane < 4) img[lane] = lane == 0 ? hw[0] : lane == 1 ? hw[1] : lane == 2 ? hw[2] : hw[3];
 		__builtin_amdgcn_wave_barrier();
 	}
-	ff_subframe_write(img, IMG_OFF, cap_words, pos0, w, DL, uL, SL, lane);
-	ff_subframe_write(img, IMG_OFF, cap_words, pos0 + SL.bits, w, DR, uR, SR, lane);
+	ff_subframe_write<WIDE>(img, IMG_OFF, cap_words, pos0, w, DL, uL, SL, lane);
+	ff_subframe_write<WIDE>(img, IMG_OFF, cap_words, pos0 + SL.bits, w, DR, uR, SR, lane);
 	if(lane == 0 && info) {
 #pragma unroll
 		for(int s = 0; s < 2; s++) {
@@ -2330,8 +2395,9 @@ hipError_t launch_pack(const DevParams &P, const int32_t *chan, uint32_t nframes
 bool ff_applicable(const DevParams &P)
 {
 	const bool off = tune().no_ff != 0;
-	return !off && P.channels == 2 && P.bps <= 16 && P.blocksize == FF_N && P.ncand == (P.ms_mode == 1 ? 4u : 2u) && prep2_decides(P) && pack2_applicable(P)
-	       && (1152u >> P.max_po) % 18u == 0 && P.slot_bytes <= 52 * FF_XSPAN - 64;      // (every span shift of a frame in the LDS table)
+	if(P.bps > 16 && (P.bps > 24 || tune().no_wide_ff)) return false;         // (17..24 bits: ff_kernel<., ., true>, round 6)
+	return !off && P.channels == 2 && P.blocksize == FF_N && P.ncand == (P.ms_mode == 1 ? 4u : 2u) && prep2_decides(P) && pack2_applicable(P)
+	       && (1152u >> P.max_po) % 18u == 0 && P.slot_bytes <= 52 * (P.bps <= 16 ? FF_XSPAN : FF_XSPAN_ALL) - 64;      // (every span shift of a 16-bit frame in the LDS table, of a wider one in the global table)
 }
 hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uint64_t first, uint8_t *slots, uint32_t *fb, FrameInfo *info, const PackOutArgs *po, hipStream_t s)
 {
@@ -2350,7 +2416,8 @@ hipError_t launch_ff(const DevParams &P, const int32_t *pcm, uint32_t nmain, uin
 	PackOut O = Oplace;
 	if(po && po->out) { O.lag = po->lag < nmain ? po->lag : 0u; if(!O.lag) O.out = nullptr; }       // (lag 0: publish only)
 	const bool preset_po = P.max_po == 3 && P.min_po == 0;               // (stream_encoder.c:117-133: what the presets -0 .. -2 set)
-#define FFGO(MS_) do { if(preset_po) hipLaunchKernelGGL((ff_kernel<MS_, 3>), dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O); \
+#define FFGO(MS_) do { if(P.bps > 16) hipLaunchKernelGGL((ff_kernel<MS_, -1, true>), dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O); \
+                       else if(preset_po) hipLaunchKernelGGL((ff_kernel<MS_, 3>), dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O); \
                        else hipLaunchKernelGGL((ff_kernel<MS_, -1>), dim3(nmain), dim3(64), lds, s, P, pcm, nmain, first, slots, fb, info, O); } while(0)
 	if(P.ms_mode == 0) FFGO(0);
 	else if(P.ms_mode == 1) FFGO(1);

@@ -268,8 +268,9 @@ OFF_THE_FAST_PATH = [
     ("-8 -b 2304: evalg + pack2<run18>", 2, 16, 44100, 8, 2304, 3000, dict(blocksize=2304), dict(blocksize=2304), {"evalg_kernel", "pack2_kernel<run18>", "fused_output"}),
     ("-8 -b 1152: evalg + pack2<run18>", 2, 16, 44100, 8, 1152, 6000, dict(blocksize=1152), dict(blocksize=1152), {"evalg_kernel", "pack2_kernel<run18>", "fused_output"}),
     ("-8 -l 32: autoc4 + the general evaluation, model and pack", 2, 16, 44100, 8, 4096, 1200, dict(max_lpc_order=32, streamable_subset=0), dict(max_lpc_order=32), {"autoc4_kernel", "eval_kernel", "pack_kernel", "scan_kernel", "compact_kernel"}),
-    ("-8 -l 16: autoc4 + eval_kernel + pack2", 2, 16, 44100, 8, 4096, 2500, dict(max_lpc_order=16, streamable_subset=0), dict(max_lpc_order=16), {"autoc4_kernel", "eval_kernel", "pack2_kernel"}),
-    ("-2 on 24-bit: the deciding prep kernel (wide) + pack2", 2, 24, 96000, 2, 1152, 6000, {}, {}, {"prep2_kernel<DECIDE>", "pack2_kernel"}),
+    # (round 6: 13..32 taps on evalg_kernel<32>; 17..24-bit stereo at -0..-2 in ff_kernel<., ., WIDE>)
+    ("-8 -l 16: autoc4 + evalg_kernel<32> + pack2", 2, 16, 44100, 8, 4096, 2500, dict(max_lpc_order=16, streamable_subset=0), dict(max_lpc_order=16), {"autoc4_kernel", "evalg_kernel", "pack2_kernel"}),
+    ("-2 on 24-bit: the one-kernel frame (wide)", 2, 24, 96000, 2, 1152, 6000, {}, {}, {"ff_kernel", "scan_kernel", "compact_kernel"}),
     ("-0 on 24-bit mono", 1, 24, 48000, 0, 1152, 6000, {}, {}, {"prep2_kernel<DECIDE>", "pack2_kernel"}),
     ("-8 mono under the default selection", 1, 16, 44100, 8, 4096, 9000, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "evalg_kernel", "pack2_kernel"}),
     ("-8 mono, 11264 frames: the size at which independent channels go a wavefront per window-job set", 1, 16, 44100, 8, 4096, 11264, {}, {}, {"prep4_kernel", "autoc3_kernel<IND>", "autoc3_kernel<SETS>", "evalg_kernel", "pack2_kernel"}),
