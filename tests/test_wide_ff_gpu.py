@@ -143,3 +143,34 @@ def test_a_large_batch_of_wide_frames_and_the_verify_pass(monkeypatch):
         for b in fr[:-2]:
             c = ((c << 8) & 0xffff) ^ int(crc_tab[(c >> 8) ^ int(b)])
         assert c == (int(fr[-2]) << 8 | int(fr[-1])), f
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FLACGPU_FF_SEEDS", "60"))))
+def test_adversarial_signals_on_the_one_kernel_frame(seed, monkeypatch):
+    """The adversarial signals of tests/test_adversarial_cpu.py (resonances, exact polynomials, impulses, full-scale patterns, random
+    walks, related channels, wasted bits -- the oracle is held to the reference on them there) as stereo in 1152-sample blocks at the
+    presets without an LPC search, 8..24 bits, WITHOUT the verify pass (which would take the frames away from ff_kernel: the seeded
+    sweep and tests/test_adversarial_gpu.py run with it on), random subframe switches and partition order ranges."""
+    import flac_amd
+    from oracle_from_settings import oracle_encode_settings
+    from test_adversarial_cpu import adversarial_signal
+    monkeypatch.setenv("FLACGPU_POISON", "1")
+    rng = np.random.default_rng(424200 + seed)
+    for sub in range(6):
+        bps = int(rng.choice([8, 12, 16, 16, 17, 18, 20, 21, 23, 24, 24, 24]))
+        level = int(rng.integers(0, 3))
+        n = 1152 * int(rng.integers(1, 9)) + (int(rng.integers(0, 1152)) if rng.random() < 0.5 else 0)
+        kw = dict(streamable_subset=0, limit_min_bitrate=int(rng.random() < 0.3))
+        if rng.random() < 0.3:
+            kw["disable"] = tuple(int(rng.random() < 0.4) for _ in range(3))
+        if rng.random() < 0.4:
+            hi = int(rng.integers(0, 4))
+            kw["max_partition_order"], kw["min_partition_order"] = hi, int(rng.integers(0, hi + 1))
+        pcm = adversarial_signal(rng, n, 2, bps)
+        s = flac_amd.make_settings(2, bps, int(rng.choice([44100, 48000, 96000, 12345])), level, **kw)
+        batch = int(rng.integers(1, 12))
+        data, fb, ks = _encode(s, pcm, batch=batch)
+        o = oracle_encode_settings(pcm, s)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (seed, sub, bps, level, n, kw)
+        # (the record is the last batch's: it has whole blocks in it when the batch holds more than the short last block)
+        assert "ff_kernel" in ks or "disable" in kw or (n % 1152 and (n // 1152) % batch == 0), (seed, sub, bps, level, n, kw, batch, ks)
