@@ -103,3 +103,86 @@ def test_the_references_test_streams_sh_passes_on_the_drop_in_and_leaves_the_ref
     # (the wrapper's log carries one line per encode: the digest of what it wrote and its command line)
     print("test_streams.sh: %d of %d encodes%s, all files equal; digest of the log %s" % (len(glog), len(rlog), "" if g.returncode == 0 else " (budget of %d s)" % budget,
                                                                                        hashlib.sha256("\n".join(glog).encode()).hexdigest()[:16]))
+
+
+# ---- test/test_flac.sh: the tool's own suite --------------------------------------------------------------------------------------
+FLAC_SH = os.path.join(REFDIR, "shell", "test", "test_flac.sh")
+METAFLAC = os.path.join(REFDIR, "dropin", "metaflac")
+
+# in front of the tool on PATH: runs it, then records the SHA-256 of every regular file of the working directory the call created
+# or changed (what an encode wrote -- by name, by -o, or through the shell's redirection of -c --, and what a decode wrote), with the
+# command line.  `--ogg` is refused like a tool built without Ogg support refuses it: the drop-in writes Ogg FLAC, but its decoder
+# half is the reference's, which needs libogg (not in this image), and the script decodes what it encodes.
+WRAPPER2 = """#!/bin/sh
+case " $* " in *" --ogg "*) exit 1 ;; esac
+marker="$HASH_LOG.marker"
+: > "$marker"
+"$REAL_FLAC" "$@"
+rc=$?
+for f in $(find . -maxdepth 1 -type f -cnewer "$marker" | sort); do
+  echo "$(sha256sum < "$f" | cut -d' ' -f1) $f rc=$rc $*" >> "$HASH_LOG"
+done
+exit $rc
+"""
+
+
+def _run_flac_sh(tmp, which, libdir, inputs_from, budget=None):
+    top = os.path.join(tmp, which)
+    d = os.path.join(top, "test")
+    os.makedirs(d)
+    bindir = os.path.join(top, "bin")
+    os.makedirs(bindir)
+    staged = os.path.join(REFDIR, "shell", "test")
+    shutil.copy(FLAC_SH, os.path.join(d, "test_flac.sh"))
+    for sub in ("cuesheets", "foreign-metadata-test-files", "flac-to-flac-metadata-test-files"):
+        shutil.copytree(os.path.join(staged, sub), os.path.join(d, sub))
+    open(os.path.join(d, "common.sh"), "w").write(COMMON + "top_srcdir=%s\nECHO_N=-n\nECHO_C=\n" % top)
+    w = os.path.join(bindir, "flac")
+    open(w, "w").write(WRAPPER2)
+    os.chmod(w, 0o755)
+    os.symlink(GEN, os.path.join(bindir, "test_streams"))
+    os.symlink(METAFLAC, os.path.join(bindir, "metaflac"))
+    # the generator's streams (its noise is seeded by the clock): generated once by the caller, the same files for both runs -- the
+    # script generates only when wacky1.wav is missing (:71-73)
+    for f in os.listdir(inputs_from):
+        shutil.copy2(os.path.join(inputs_from, f), d)
+    env = dict(os.environ)
+    env.update(PATH=bindir + ":" + env.get("PATH", ""), LD_LIBRARY_PATH=libdir + ":" + env.get("LD_LIBRARY_PATH", ""), REAL_FLAC=FLAC,
+               HASH_LOG=os.path.join(top, "hashes.log"), FLAC__TEST_LEVEL=os.environ.get("FLACGPU_SHELL_TEST_LEVEL", "1"), top_srcdir=top)
+    cmd = ["sh", "-e", "./test_flac.sh"]
+    if budget:
+        cmd = ["timeout", "-s", "TERM", str(budget)] + cmd
+    r = subprocess.run(cmd, cwd=d, env=env, capture_output=True, text=True, timeout=3000)
+    log = open(env["HASH_LOG"]).read().replace(top, "$TOP").splitlines() if os.path.exists(env["HASH_LOG"]) else []
+    return r, log, d
+
+
+
+@pytest.mark.skipif(not (os.path.exists(FLAC_SH) and os.path.exists(METAFLAC)), reason="oracle/_ref/shell/test or dropin/metaflac not built")
+def test_the_references_test_flac_sh_passes_on_the_drop_in_and_leaves_the_references_files(tmp_path):
+    """test/test_flac.sh (:75-1392: overwrite protection, fractional block sizes, --skip / --until on encode and decode in every
+    container the tool reads, --cue, --input-size, piped input with a fixed-up STREAMINFO, several files at once, foreign metadata
+    round trips, FLAC-to-FLAC re-encoding with its metadata rules, --limit-min-bitrate, --ignore-chunk-sizes, over-long files) with
+    `flac` = the reference's tool on this project's libFLAC.so.14, then on the reference's: exit status 0 both times, and every file a
+    `flac` call wrote -- encodes and decodes alike -- the same bytes in both runs (second half).  1699 files from some
+    1500 calls: 5.3 minutes on the GPU box (profiles/r06_ag_shell_test_flac_full.log); the default run gives the drop-in side
+    FLACGPU_SHELL_BUDGET seconds (60) and compares what it wrote until then, FLACGPU_SHELL_SUITE=full runs it to its end."""
+    tmp = str(tmp_path)
+    full = os.environ.get("FLACGPU_SHELL_SUITE", "1") == "full"
+    budget = None if full else int(os.environ.get("FLACGPU_SHELL_BUDGET", "60"))
+    gen = os.path.join(tmp, "streams")
+    os.makedirs(gen)
+    subprocess.run([GEN], cwd=gen, check=True, capture_output=True, timeout=600)
+    g, glog, gdir = _run_flac_sh(tmp, "gpu", os.path.join(ROOT, "flac_amd", "lib"), gen, budget=budget)
+    assert g.returncode == 0 or (budget and g.returncode == 124), (g.returncode, g.stdout[-2500:], g.stderr[-1500:])
+    r, rlog, _ = _run_flac_sh(tmp, "ref", os.path.join(REFDIR, "dropin"), gen)
+    assert r.returncode == 0, (r.stdout[-2500:], r.stderr[-1500:])
+    if g.returncode == 0:
+        assert len(glog) == len(rlog) and len(glog) > 300, (len(glog), len(rlog))
+    else:
+        assert 50 < len(glog) <= len(rlog) + 2, (len(glog), len(rlog))
+        glog = glog[:-2]                 # (the call that was under way when the budget ran out may have left a partial file)
+    diff = [(a, b) for a, b in zip(glog, rlog) if a != b]
+    assert not diff, (len(diff), diff[:3])
+    print("test_flac.sh: %d of %d files written by flac calls%s, all equal; digest of the log %s" % (len(glog), len(rlog), "" if g.returncode == 0 else " (budget of %d s)" % budget,
+                                                                                                hashlib.sha256("\n".join(glog).encode()).hexdigest()[:16]))
