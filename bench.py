@@ -45,6 +45,42 @@ KERNEL_NAMES = {"prep": "ff_kernel+prep3_kernel+prep2_kernel+prep_kernel", "auto
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md: 2.4 GHz peak engine clock.  A SIMD issues one wave64 VALU instruction per 4 cycles
 VALU_ISSUE_PEAK = SIMDS * CLOCK_GHZ / 4      # G wavefront-instructions per second, the whole chip
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
+UBENCH_FILE = os.path.join(ROOT, "profiles", "ubench_cycles.json")   # shader cycles per wavefront-instruction per class (scripts/ubench_cycles.hip)
+# The hardware's INT32 class holds the integer ARITHMETIC (v_dot2 / v_sad / v_perm / v_mad / dpp adds, 2 cycles at best, and plain adds,
+# 1 cycle); shifts, logic and moves are in none of the class counters ("other", priced at the fast rate).  Where an ISA account of the
+# kernel gives the split of INT32 it is used, elsewhere the floor is a range (all fast .. all slow).
+INT32_SLOW_SHARE = {"evalg_kernel": 0.897}      # profiles/r05_evalg_isa_histogram.txt: dot2 3.831 + sad 0.625 + shifted-word 0.136 of the 5.12 INT32 instructions per sample
+# wavefronts per SIMD a kernel runs with (registers / LDS): which column of the microbenchmark its floor is read from
+KERNEL_WAVES = {"evalg_kernel": 4, "evalw_kernel": 4, "autoc3_kernel": 2, "autoc2_kernel": 4, "prep3_kernel": 5, "pack2_kernel": 5, "ff_kernel": 4, "model_kernel": 4}
+
+
+def mix_floor(name, entry):
+    """What ONE kernel's instruction mix costs at best: cycles a SIMD needs per wavefront-instruction when nothing but
+    the kernel's arithmetic is in the loop -- the class mix the hardware counted for it (SQ_INSTS_VALU_<class> of the committed counter
+    pass) priced with the rate each class reaches alone (profiles/ubench_cycles.json: measured inside the kernel with s_memtime, no
+    assumed clock), at eight wavefronts per SIMD and at the occupancy the kernel runs with.  A SIMD of this chip is 32 lanes wide (a
+    wave64 instruction issues over 2 cycles) but ONE wavefront issues at most every 4.8-5.1 cycles, every 8.4 when the instruction
+    waits for the one before it: the rate a SIMD reaches grows with its wavefronts up to eight."""
+    cl = entry.get("valu_class_per_sample")
+    try:
+        with open(UBENCH_FILE) as fh:
+            ub = json.load(fh)["classes"]
+    except Exception:
+        return None
+    if not cl or not sum(cl.values()):
+        return None
+    tot = sum(cl.values())
+    out = {}
+    for key in ("w8", "w%d" % KERNEL_WAVES.get(name, 4)):
+        c = lambda n: ub[n][key]
+        fast = (c("v_add_u32") + c("v_lshrrev_b32") + c("v_xor_b32") + c("v_mov_b32")) / 4
+        slow = (c("v_dot2_i32_i16") + c("v_sad_u32") + c("v_perm_b32") + c("v_mad_i32_i24")) / 4
+        fixed = (cl.get("int64", 0) * c("v_mad_i64_i32") + cl.get("fma_f64", 0) * c("v_fma_f64") + cl.get("add_f64", 0) * c("v_add_f64") + cl.get("mul_f64", 0) * c("v_mul_f64")
+                 + cl.get("cvt", 0) * c("v_cvt_f64_i32") + (cl.get("fma_f32", 0) + cl.get("add_f32", 0)) * c("v_fma_f32") + cl.get("other", 0) * fast)
+        i32 = cl.get("int32", 0)
+        lo, hi = (fixed + i32 * fast) / tot, (fixed + i32 * slow) / tot
+        out[key] = lo + (hi - lo) * INT32_SLOW_SHARE[name] if name in INT32_SLOW_SHARE else (lo, hi)
+    return out
 
 
 def block_of(level):
@@ -663,13 +699,39 @@ def main():
                 if ck.get("mhz_mean"):
                     # the same against the clock the chip really held under this workload (clock_probe): the peak above assumes 2.4 GHz
                     peak_m = SIMDS * ck["mhz_mean"] / 1000.0 / 4
+                    # ... and against what each kernel's own instruction mix costs at best (mix_floor): cycles per wavefront-instruction
+                    # achieved at the measured clock, next to the mix's floor at eight wavefronts per SIMD and at the kernel's occupancy
+                    mf = {}
+                    for ph, v in valu.items():
+                        names = [nm for nm in v["kernel"].split("+") if nm in K and K[nm].get("valu_class_per_sample")]
+                        if not names:
+                            continue
+                        nm = max(names, key=lambda x: K[x].get("valu_wave_insts_per_sample", 0.0))
+                        fl = mix_floor(nm, K[nm])
+                        if not fl:
+                            continue
+                        ach_c = SIMDS * ck["mhz_mean"] * 1e6 * (v["ms"] * 1e-3) / (v["wave_insts_per_sample"] * samples_per_step)
+                        wk = "w%d" % KERNEL_WAVES.get(nm, 4)
+                        rnd = lambda x: [round(x[0], 3), round(x[1], 3)] if isinstance(x, tuple) else round(x, 3)
+                        frac = lambda x: [round(x[0] / ach_c, 3), round(min(1.0, x[1] / ach_c), 3)] if isinstance(x, tuple) else round(x / ach_c, 3)
+                        mf[ph] = {"kernel": nm, "cycles_per_wave_instruction": round(ach_c, 3), "waves_per_simd": KERNEL_WAVES.get(nm, 4),
+                                  "floor_at_8_waves": rnd(fl["w8"]), "floor_at_this_occupancy": rnd(fl[wk]),
+                                  "frac_of_floor_at_8_waves": frac(fl["w8"]), "frac_of_floor_at_this_occupancy": frac(fl[wk]),
+                                  "classes_per_sample": K[nm]["valu_class_per_sample"]}
+                    if mf:
+                        res["roofline_valu"]["mix_floor"] = dict(mf, how="floor = sum over the hardware's VALU classes (SQ_INSTS_VALU_<class> of the committed counter pass) of share x the cycles "
+                                                                 "per wavefront-instruction the class reaches alone (profiles/ubench_cycles.json: s_memtime inside the kernel, eight independent "
+                                                                 "registers, W wavefronts per SIMD); the INT32 class holds the 1-cycle (add / shift / xor / mov) and the 2-cycle (dot2 / sad / perm / "
+                                                                 "mad) integer instructions: [all fast, all slow] unless an ISA account gives the split (evalg_kernel).  A SIMD is 32 lanes wide; the 4 "
+                                                                 "cycles per instruction of `peak` are what these kernels' occupancies (2-5 wavefronts per SIMD) reach, not the chip's limit")
                     res["roofline_valu"]["at_measured_clock"] = {
                         "clock_mhz": ck["mhz_mean"], "peak": round(peak_m, 1),
                         "whole_step_frac_of_issue_peak": round(tot_i * samples_per_step / (elapsed / steps) / 1e9 / peak_m, 4),
                         "per_kernel_frac": {k: round(v["achieved_Ginst_per_s"] / peak_m, 4) for k, v in valu.items()},
                         "cycles_per_wave_instruction_whole_step": round(SIMDS * ck["mhz_mean"] * 1e6 * (elapsed / steps) / (tot_i * samples_per_step), 3),
-                        "note": "4 cycles per wave64 instruction is the full-rate figure; per-class rates measured on this chip (scripts/ubench_valu.hip) "
-                                "are 3.0-3.4 for add / shift / xor / mov and 4.2-5.4 for dot2 / sad / perm / fp64 at an ASSUMED 2.4 GHz -- scale those by clock_mhz / 2400"}
+                        "note": "4 cycles per wave64 instruction is the yardstick of rounds 3-5, kept for comparison: scripts/ubench_cycles.hip (round 6, cycles counted inside "
+                                "the kernel) measures 1.0-1.2 cycles for add / shift / xor / mov and 2.0 for dot2 / sad / perm / mad / fp64 at eight wavefronts per SIMD, 1.2-1.9 "
+                                "and 3.0-3.5 at four -- see mix_floor"}
             if verified is not None:
                 res["verified"] = verified
             elif not args.no_verify:

@@ -6,10 +6,11 @@
 #   bench[:args]     bench.py [args] -> bench<i>.json          (":" separates, "," stands for a blank inside args)
 #   env:K=V          export K=V for the steps that follow (env:-K unsets)
 #   prof[:args]      rocprofv3 --kernel-trace --stats of bench.py --steps 5 --warmup 2 --no-cpu-baseline [args]
-#   pmc[:args]       the PMC passes (SQ instruction counters, FETCH_SIZE, WRITE_SIZE) at the bench's own batch size: the kernels
+#   pmc[:args]       the PMC passes (SQ instruction counters, FETCH_SIZE, WRITE_SIZE, the VALU instruction classes) at the bench's own batch size: the kernels
 #                    the bench line runs (launch_autoc2 picks by the number of wavefronts)
 #   ab:<rounds>[:args]  alternate flac_amd/lib (A) and build/alt_lib (B) engines, scripts/gpu_ab.sh
 #   sh:<file>        run another script of scripts/
+#   ubench           flac_amd/lib/ubench_cycles (scripts/ubench_cycles.hip, built here): shader cycles per wavefront-instruction per class -> ubench_cycles.json
 set -u
 TAG=${1:-visit}; shift || true
 OUT=gpurun_out/$TAG
@@ -41,7 +42,8 @@ for step in "$@"; do
       j=0
       for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
                  "SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE GRBM_COUNT" \
-                 "FETCH_SIZE" "WRITE_SIZE"; do
+                 "FETCH_SIZE" "WRITE_SIZE" \
+                 "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32"; do
         j=$((j+1))
         timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$j -o p$j -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-verify --no-clock $arg > $OUT/pmc$j.json 2> $OUT/pmc$j.err
         echo "[$i] pmc pass $j rc=$? : $SET"
@@ -53,6 +55,7 @@ for step in "$@"; do
     abn) r=${arg%% *}; rest=""; [ "$r" != "$arg" ] && rest=${arg#* }; bash scripts/gpu_abn.sh $r $rest 2>&1 | tee $OUT/abn_$i.txt ;;
     ab) r=${arg%% *}; rest=""; [ "$r" != "$arg" ] && rest=${arg#* }; bash scripts/gpu_ab.sh $r $rest 2>&1 | tee $OUT/ab_$i.txt ;;
     sh) bash scripts/$arg 2>&1 | tee $OUT/sh_$i.txt ;;
+    ubench) timeout 300 flac_amd/lib/ubench_cycles $OUT/ubench_cycles.json 2>&1 | tee $OUT/ubench_cycles.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -19,7 +19,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COUNTERS = "FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|SQ_INSTS_SALU|SQ_INSTS_LDS|SQ_ACTIVE_INST_VALU|GRBM_GUI_ACTIVE|SQ_WAVE_CYCLES|SQ_WAIT_INST_ANY|SQ_WAVES"
+CLASSES = ("INT32", "INT64", "FMA_F64", "ADD_F64", "MUL_F64", "CVT", "FMA_F32", "ADD_F32")     # SQ_INSTS_VALU_<class>: the hardware's own instruction classes
+COUNTERS = "FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|SQ_INSTS_SALU|SQ_INSTS_LDS|SQ_ACTIVE_INST_VALU|GRBM_GUI_ACTIVE|SQ_WAVE_CYCLES|SQ_WAIT_INST_ANY|SQ_WAVES|" + "|".join("SQ_INSTS_VALU_" + c for c in CLASSES)
 
 
 def blob_hash(path):
@@ -54,6 +55,12 @@ def parse(src, frames, blocksize):
         e = {"fetch_kb": v["FETCH_SIZE"], "write_kb": v["WRITE_SIZE"], "hbm_bytes_per_frame": round(hbm / frames, 1)}
         if "SQ_INSTS_VALU" in v:
             e["valu_wave_insts_per_sample"] = round(v["SQ_INSTS_VALU"] / (frames * blocksize), 4)
+        if "SQ_INSTS_VALU" in v and any("SQ_INSTS_VALU_" + c in v for c in CLASSES):
+            # the class mix of the kernel's VALU instructions (round 6, VERDICT r05 #8: the issue roofline against per-class measured
+            # cycles, scripts/ubench_cycles.hip); "other" = what the class counters do not claim (moves, lane exchange, bit operations ...)
+            cl = {c.lower(): round(v.get("SQ_INSTS_VALU_" + c, 0.0) / (frames * blocksize), 4) for c in CLASSES}
+            cl["other"] = round(max(0.0, v["SQ_INSTS_VALU"] - sum(v.get("SQ_INSTS_VALU_" + c, 0.0) for c in CLASSES)) / (frames * blocksize), 4)
+            e["valu_class_per_sample"] = cl
         if "SQ_INSTS_SALU" in v:
             e["salu_insts_per_sample"] = round(v["SQ_INSTS_SALU"] / (frames * blocksize), 4)
         if "SQ_INSTS_LDS" in v:
