@@ -49,7 +49,7 @@ UBENCH_FILE = os.path.join(ROOT, "profiles", "ubench_cycles.json")   # shader cy
 # The hardware's INT32 class holds the integer ARITHMETIC (v_dot2 / v_sad / v_perm / v_mad / dpp adds, 2 cycles at best, and plain adds,
 # 1 cycle); shifts, logic and moves are in none of the class counters ("other", priced at the fast rate).  Where an ISA account of the
 # kernel gives the split of INT32 it is used, elsewhere the floor is a range (all fast .. all slow).
-INT32_SLOW_SHARE = {"evalg_kernel": 0.897}      # profiles/r05_evalg_isa_histogram.txt: dot2 3.831 + sad 0.625 + shifted-word 0.136 of the 5.12 INT32 instructions per sample
+INT32_SLOW_SHARE = {"evalg_kernel": 0.897}      # profiles/archive/r05_evalg_isa_histogram.txt: dot2 3.831 + sad 0.625 + shifted-word 0.136 of the 5.12 INT32 instructions per sample
 # wavefronts per SIMD a kernel runs with (registers / LDS): which column of the microbenchmark its floor is read from
 KERNEL_WAVES = {"evalg_kernel": 4, "evalw_kernel": 4, "autoc3_kernel": 2, "autoc2_kernel": 4, "prep3_kernel": 5, "pack2_kernel": 5, "ff_kernel": 4, "model_kernel": 4}
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ISA-level account of evalg_kernel<12,1>: where its wavefront-instructions go.
 
-    python scripts/isa_histogram.py > profiles/r05_evalg_isa_histogram.txt
+    python scripts/isa_histogram.py > profiles/archive/r05_evalg_isa_histogram.txt
 
 Compiles flac_amd/csrc/flacgpu_evalg.hip for gfx950 to assembly with comment-only markers (`; MARK name`, inserted into a scratch copy
 of the source at the boundaries of the kernel's phases), walks the kernel's control-flow graph from its entry carrying "the last
@@ -143,13 +143,13 @@ how to read this
    wavefronts x 7066 VALU)), i.e. it is bound by the NUMBER of VALU instructions, and three other wavefronts of the SIMD issue into
    the slot a padded wavefront leaves.  Folding the whole piece into one asm statement needs 33 operands (limit 30).
  * the shifted sample words (v_perm_b32, 13 per pair and piece) are 2 % of the VALU work, the Rice search 11 %, set-up 5-6 %.
-what was done with it (round 5), same-box A/B in profiles/r05_b_ab_evalg.txt
+what was done with it (round 5), same-box A/B in profiles/archive/r05_b_ab_evalg.txt
  * rice_pass took ilog2 as the exponent of (float)x and the compiler, seeing a 64-bit product behind x, built the float with its
    64-bit sequence (v_lshlrev_b64, v_min, v_or, v_cvt, v_ldexp, v_frexp_exp): 31 - clz(2 x + 1) is three instructions -- the search
    105 -> 90 VALU per pair;  the divisor table of the search (91 integer divisions per channel) now comes from the host (JobTable).
  * together -0.10 VALU per sample (model 6.79 -> 6.69) and -0.3 % of the kernel's time (0.8664 -> 0.8634 ms): the instructions
    that are not the FIR's are too few to matter.  <= 6.3 VALU per sample needs fewer dot2 / shift / sad per candidate-sample, i.e. a
-   different formulation of the FIR -- the int8 MFMA split is measured in profiles/r05_mfma_fir_ubench.txt.
+   different formulation of the FIR -- the int8 MFMA split is measured in profiles/archive/r05_mfma_fir_ubench.txt.
 """
 
 

@@ -1,7 +1,7 @@
 """CPU: oracle against the real reference on signals built to reach the corners of the arithmetic rather than to sound like music --
 test infrastructure pinning test infrastructure: the oracle is what the GPU path is held to, so it is held to the reference on more
 than the nine signal families of the sweep (tests/test_random_cpu.py).  Seeded: FLACGPU_ADV_SEEDS (default 24; 2000 seeds = 16 000 cases ran
-clean when this file was written, and 1000 of them on the GPU: profiles/r05_soak_seeded_sweep.txt).
+clean when this file was written, and 1000 of them on the GPU: profiles/archive/r05_soak_seeded_sweep.txt).
 
 What the generators aim at (reference file:line):
   * resonances on and next to the unit circle, growing and decaying exponentials -- coefficients of 2^k and more: the negative-shift

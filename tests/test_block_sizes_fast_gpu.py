@@ -1,7 +1,7 @@
 """-m gpu: 1152- and 2304-sample blocks at the LPC presets on the fast kernels (round 6: evalg_kernel's runs of 16 k + 2 / + 4 samples,
 pack2_kernel's 18-sample-run instance at any block that is whole passes of it) against the oracle, with the kernel record -- these
 shapes used to run on the general evaluation and pack kernels, 3.5x / 2.4x slower per sample than 4096-sample blocks
-(profiles/r05_j_order_rate_autoc4.txt).  The reference's presets put 1152 at -0..-2 only, but `-b 1152` / `-b 2304` at any level are
+(profiles/archive/r05_j_order_rate_autoc4.txt).  The reference's presets put 1152 at -0..-2 only, but `-b 1152` / `-b 2304` at any level are
 what its test script and users of low-latency streams ask for (test/test_streams.sh:172-219, stream_encoder.c:748-753)."""
 import numpy as np
 import pytest
