@@ -102,6 +102,9 @@ __global__ __launch_bounds__(256, 8) void k(uint64_t *cyc, uint64_t *real, uint3
 	}
 	if((threadIdx.x & 63) == 0) {
 		cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0; real[blockIdx.x * 4 + (threadIdx.x >> 6)] = r1 - r0;
+		// absolute start and end on the 100 MHz counter (one counter for the chip): the host checks that the W wavefronts of a SIMD really
+		// ran side by side -- a SIMD's rate from the span between its first start and its last end, next to the per-wavefront figure
+		real[(1 << 16) + 2 * (blockIdx.x * 4 + (threadIdx.x >> 6))] = r0; real[(1 << 16) + 2 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + 1] = r1;
 		// where the wavefront ran: HW_ID (SIMD, compute unit, shader array, shader engine) and the XCC -- the host counts wavefronts per SIMD
 		uint32_t hw, xcc;
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 8) void k(uint64_t *cyc, uint64_t *real, uint3
 	if(x == 0x12345678u) sink[0] = x;
 }
 
-struct Res { double cyc_per_inst, mhz, waves_per_simd_seen; int simds_seen; };
+struct Res { double cyc_per_inst, mhz, waves_per_simd_seen; int simds_seen; double span_cyc_per_inst, event_cyc_per_inst; };
 template <int OP>
 static Res run(int waves_per_simd, uint64_t *d_cyc, uint64_t *d_real, uint32_t *d_sink)
 {
@@ -120,8 +123,15 @@ static Res run(int waves_per_simd, uint64_t *d_cyc, uint64_t *d_real, uint32_t *
 	const int wgs = prop.multiProcessorCount * waves_per_simd, blocks = wgs * 4;
 	hipLaunchKernelGGL(k<OP>, dim3(wgs), dim3(256), 0, 0, d_cyc, d_real, d_sink, 64);         // warm-up
 	hipDeviceSynchronize();
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	hipEventRecord(e0);
 	hipLaunchKernelGGL(k<OP>, dim3(wgs), dim3(256), 0, 0, d_cyc, d_real, d_sink, ITER);
+	hipEventRecord(e1);
 	hipDeviceSynchronize();
+	float ev_ms = 0;
+	hipEventElapsedTime(&ev_ms, e0, e1);
+	hipEventDestroy(e0); hipEventDestroy(e1);
 	std::vector<uint64_t> c(blocks), r(blocks);
 	hipMemcpy(c.data(), d_cyc, blocks * 8, hipMemcpyDeviceToHost);
 	hipMemcpy(r.data(), d_real, blocks * 8, hipMemcpyDeviceToHost);
@@ -133,19 +143,38 @@ static Res run(int waves_per_simd, uint64_t *d_cyc, uint64_t *d_real, uint32_t *
 	std::sort(hw.begin(), hw.end());
 	int simds = 0, most = 0, run_ = 0;
 	for(int i = 0; i < blocks; i++) { if(i == 0 || hw[i] != hw[i - 1]) { simds++; run_ = 0; } run_++; if(run_ > most) most = run_; }
-	return Res{per[blocks / 2], mhz[blocks / 2], (double)most, simds};
+	// per SIMD: (last end - first start) of its wavefronts on the 100 MHz counter, in shader cycles at the median clock, per instruction
+	std::vector<uint64_t> ab(2 * blocks);
+	hipMemcpy(ab.data(), d_real + (1 << 16), 2 * blocks * 8, hipMemcpyDeviceToHost);
+	std::vector<uint32_t> hw2(blocks);
+	hipMemcpy(hw2.data(), d_sink + 1, blocks * 4, hipMemcpyDeviceToHost);
+	std::vector<std::pair<uint32_t, int>> order(blocks);
+	for(int i = 0; i < blocks; i++) order[i] = {hw2[i], i};
+	std::sort(order.begin(), order.end());
+	std::vector<double> spans;
+	for(int i = 0; i < blocks;) {
+		int j = i; uint64_t lo = ~0ull, hi = 0; int n = 0;
+		while(j < blocks && order[j].first == order[i].first) { const int w = order[j].second; if(ab[2 * w] < lo) lo = ab[2 * w]; if(ab[2 * w + 1] > hi) hi = ab[2 * w + 1]; n++; j++; }
+		spans.push_back((double)(hi - lo) / 100.0 * mhz[blocks / 2] / ((double)n * ITER * UNR * REP));
+		i = j;
+	}
+	std::sort(spans.begin(), spans.end());
+	// ... and the whole launch between two HIP events (launch overhead included), at the median clock
+	const double ev = (double)ev_ms * 1e3 * mhz[blocks / 2] / ((double)waves_per_simd * ITER * UNR * REP);
+	return Res{per[blocks / 2], mhz[blocks / 2], (double)most, simds, spans[spans.size() / 2], ev};
 }
 
 int main(int argc, char **argv)
 {
 	uint64_t *d_cyc, *d_real; uint32_t *d_sink;
-	hipMalloc(&d_cyc, 1 << 20); hipMalloc(&d_real, 1 << 20); hipMalloc(&d_sink, 1 << 20);
+	hipMalloc(&d_cyc, 1 << 20); hipMalloc(&d_real, 1 << 21); hipMalloc(&d_sink, 1 << 20);
 	FILE *js = argc > 1 ? fopen(argv[1], "w") : nullptr;
 	if(js) fprintf(js, "{\"what\": \"shader cycles a SIMD spends per wavefront-instruction (s_memtime inside the kernel, median over all wavefronts), W wavefronts per SIMD running the same loop\", \"classes\": {\n");
 	printf("%-36s %12s %12s %28s %28s %28s\n", "instruction", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD: cycles (MHz)", "5 waves/SIMD", "8 waves/SIMD");
 	bool first = true;
 #define ROW(OP) do { Res r1 = run<OP>(1, d_cyc, d_real, d_sink), r2 = run<OP>(2, d_cyc, d_real, d_sink), r4 = run<OP>(4, d_cyc, d_real, d_sink), r5 = run<OP>(5, d_cyc, d_real, d_sink), r8 = run<OP>(8, d_cyc, d_real, d_sink); \
-		printf("%-36s %12.3f %12.3f %18.3f (%7.1f) %18.3f (%7.1f) %18.3f (%7.1f)   placement at 2 / 8 waves: %d / %d SIMDs seen, at most %.0f / %.0f wavefronts on one\n", NAMES[OP], r1.cyc_per_inst, r2.cyc_per_inst, r4.cyc_per_inst, r4.mhz, r5.cyc_per_inst, r5.mhz, r8.cyc_per_inst, r8.mhz, r2.simds_seen, r8.simds_seen, r2.waves_per_simd_seen, r8.waves_per_simd_seen); \
+		printf("%-36s %12.3f %12.3f %18.3f (%7.1f) %18.3f (%7.1f) %18.3f (%7.1f)   placement at 2 / 8 waves: %d / %d SIMDs seen, at most %.0f / %.0f wavefronts on one; from first start to last end of a SIMD's wavefronts: %.3f %.3f %.3f %.3f %.3f\n", NAMES[OP], r1.cyc_per_inst, r2.cyc_per_inst, r4.cyc_per_inst, r4.mhz, r5.cyc_per_inst, r5.mhz, r8.cyc_per_inst, r8.mhz, r2.simds_seen, r8.simds_seen, r2.waves_per_simd_seen, r8.waves_per_simd_seen, r1.span_cyc_per_inst, r2.span_cyc_per_inst, r4.span_cyc_per_inst, r5.span_cyc_per_inst, r8.span_cyc_per_inst); \
+		printf("%-36s     the launch between two HIP events: %.3f %.3f %.3f %.3f %.3f\n", "", r1.event_cyc_per_inst, r2.event_cyc_per_inst, r4.event_cyc_per_inst, r5.event_cyc_per_inst, r8.event_cyc_per_inst); \
 		if(js) { fprintf(js, "%s  \"%s\": {\"w1\": %.4f, \"w2\": %.4f, \"w4\": %.4f, \"w5\": %.4f, \"w8\": %.4f, \"mhz_w8\": %.1f}", first ? "" : ",\n", NAMES[OP], r1.cyc_per_inst, r2.cyc_per_inst, r4.cyc_per_inst, r5.cyc_per_inst, r8.cyc_per_inst, r8.mhz); first = false; } } while(0)
 	ROW(ADD); ROW(LSHR); ROW(XOR); ROW(MOV); ROW(ADD3); ROW(DOT2); ROW(SAD); ROW(PERM); ROW(ALIGNBIT); ROW(MAD24); ROW(MADLO); ROW(MAD64);
 	ROW(FMA64); ROW(ADD64); ROW(MUL64); ROW(CVT_F64_I32); ROW(FMA32); ROW(DPP_ADD); ROW(READLANE); ROW(CNDMASK); ROW(BFE); ROW(MED3);
