@@ -46,9 +46,10 @@ SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md: 2.4 GHz
 VALU_ISSUE_PEAK = SIMDS * CLOCK_GHZ / 4      # G wavefront-instructions per second, the whole chip
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
 UBENCH_FILE = os.path.join(ROOT, "profiles", "ubench_cycles.json")   # shader cycles per wavefront-instruction per class (scripts/ubench_cycles.hip)
-# The hardware's INT32 class holds the integer ARITHMETIC (v_dot2 / v_sad / v_perm / v_mad / dpp adds, 2 cycles at best, and plain adds,
-# 1 cycle); shifts, logic and moves are in none of the class counters ("other", priced at the fast rate).  Where an ISA account of the
-# kernel gives the split of INT32 it is used, elsewhere the floor is a range (all fast .. all slow).
+# The hardware's INT32 class holds the integer ARITHMETIC (v_dot2 / v_sad / v_perm / v_mad / dpp adds: 4.1-4.4 cycles per wave64
+# instruction, a quarter of the lanes per cycle; and plain adds: 2.2-2.4, half of them); shifts, logic and moves are in none of the class
+# counters ("other", priced at the fast rate).  Where an ISA account of the kernel gives the split of INT32 it is used, elsewhere the
+# floor is a range (all fast .. all slow).
 INT32_SLOW_SHARE = {"evalg_kernel": 0.897}      # profiles/archive/r05_evalg_isa_histogram.txt: dot2 3.831 + sad 0.625 + shifted-word 0.136 of the 5.12 INT32 instructions per sample
 # wavefronts per SIMD a kernel runs with (registers / LDS): which column of the microbenchmark its floor is read from
 KERNEL_WAVES = {"evalg_kernel": 4, "evalw_kernel": 4, "autoc3_kernel": 2, "autoc2_kernel": 4, "prep3_kernel": 5, "pack2_kernel": 5, "ff_kernel": 4, "model_kernel": 4}
@@ -57,10 +58,11 @@ KERNEL_WAVES = {"evalg_kernel": 4, "evalw_kernel": 4, "autoc3_kernel": 2, "autoc
 def mix_floor(name, entry):
     """What ONE kernel's instruction mix costs at best: cycles a SIMD needs per wavefront-instruction when nothing but
     the kernel's arithmetic is in the loop -- the class mix the hardware counted for it (SQ_INSTS_VALU_<class> of the committed counter
-    pass) priced with the rate each class reaches alone (profiles/ubench_cycles.json: measured inside the kernel with s_memtime, no
-    assumed clock), at eight wavefronts per SIMD and at the occupancy the kernel runs with.  A SIMD of this chip is 32 lanes wide (a
-    wave64 instruction issues over 2 cycles) but ONE wavefront issues at most every 4.8-5.1 cycles, every 8.4 when the instruction
-    waits for the one before it: the rate a SIMD reaches grows with its wavefronts up to eight."""
+    pass) priced with the rate each class reaches alone (profiles/ubench_cycles.json: from the first start to the last end of a SIMD's
+    wavefronts, at the clock measured inside the loop; HIP events agree), at eight wavefronts per SIMD and at the occupancy the kernel
+    runs with.  On this chip add / shift / logic / move / fp32 issue a wave64 instruction over 2.2-2.4 cycles, everything else these
+    kernels use (dot2, sad, perm, mad, add3, bfe, DPP, fp64, conversions) over 4.1-4.4; one wavefront alone issues every 4.8-5.1
+    cycles, every 8.4 in a dependent chain."""
     cl = entry.get("valu_class_per_sample")
     try:
         with open(UBENCH_FILE) as fh:
@@ -720,18 +722,16 @@ def main():
                                   "classes_per_sample": K[nm]["valu_class_per_sample"]}
                     if mf:
                         res["roofline_valu"]["mix_floor"] = dict(mf, how="floor = sum over the hardware's VALU classes (SQ_INSTS_VALU_<class> of the committed counter pass) of share x the cycles "
-                                                                 "per wavefront-instruction the class reaches alone (profiles/ubench_cycles.json: s_memtime inside the kernel, eight independent "
-                                                                 "registers, W wavefronts per SIMD); the INT32 class holds the 1-cycle (add / shift / xor / mov) and the 2-cycle (dot2 / sad / perm / "
-                                                                 "mad) integer instructions: [all fast, all slow] unless an ISA account gives the split (evalg_kernel).  A SIMD is 32 lanes wide; the 4 "
-                                                                 "cycles per instruction of `peak` are what these kernels' occupancies (2-5 wavefronts per SIMD) reach, not the chip's limit")
+                                                                 "per wavefront-instruction the class reaches alone (profiles/ubench_cycles.json: first start to last end of a SIMD's W wavefronts, clock "
+                                                                 "measured inside the loop); the INT32 class holds the 2.3-cycle plain adds and the 4.2-cycle dot2 / sad / perm / mad: [all fast, all slow] "
+                                                                 "unless an ISA account gives the split (evalg_kernel); shifts, logic and moves ('other') issue in 2.3 cycles, fp64 and conversions in 4.1-4.5")
                     res["roofline_valu"]["at_measured_clock"] = {
                         "clock_mhz": ck["mhz_mean"], "peak": round(peak_m, 1),
                         "whole_step_frac_of_issue_peak": round(tot_i * samples_per_step / (elapsed / steps) / 1e9 / peak_m, 4),
                         "per_kernel_frac": {k: round(v["achieved_Ginst_per_s"] / peak_m, 4) for k, v in valu.items()},
                         "cycles_per_wave_instruction_whole_step": round(SIMDS * ck["mhz_mean"] * 1e6 * (elapsed / steps) / (tot_i * samples_per_step), 3),
-                        "note": "4 cycles per wave64 instruction is the yardstick of rounds 3-5, kept for comparison: scripts/ubench_cycles.hip (round 6, cycles counted inside "
-                                "the kernel) measures 1.0-1.2 cycles for add / shift / xor / mov and 2.0 for dot2 / sad / perm / mad / fp64 at eight wavefronts per SIMD, 1.2-1.9 "
-                                "and 3.0-3.5 at four -- see mix_floor"}
+                        "note": "4 cycles per wave64 instruction is the yardstick of rounds 3-5: scripts/ubench_cycles.hip (round 6, cycles counted inside the kernel, HIP events "
+                                "agree) measures 4.1-4.4 for dot2 / sad / perm / mad / fp64 and 2.2-2.4 for add / shift / logic / move -- a kernel's own floor is in mix_floor"}
             if verified is not None:
                 res["verified"] = verified
             elif not args.no_verify:

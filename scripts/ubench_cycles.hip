@@ -1,10 +1,15 @@
 // scripts/ubench_cycles.hip -- shader cycles a SIMD spends per wavefront-instruction, per instruction class, measured INSIDE the
-// kernel with s_memtime (which ticks with the shader clock on this part; the 100 MHz s_memrealtime is read beside it, so the
-// clock the measurement ran at is reported and the cycle figure does not depend on an assumed frequency -- round 2's
-// ubench_valu.hip timed with HIP events and divided by an assumed 2.4 GHz).  Every SIMD of the chip holds W wavefronts that run
-// the same loop of N instructions of one class over 8 independent registers; SIMD-cycles per wavefront-instruction =
-// (a wavefront's own elapsed cycles) / (W * N), the median over all wavefronts.  VERDICT r05 #8: the VALU roofline against
-// per-class measured cycles.     hipcc --offload-arch=gfx950 -O3 -o /tmp/ubc scripts/ubench_cycles.hip && /tmp/ubc [json path]
+// kernel (round 2's ubench_valu.hip timed with HIP events and divided by an assumed 2.4 GHz).  Every SIMD of the chip gets W
+// wavefronts (workgroups of four wavefronts, W per compute unit; HW_ID of every wavefront is recorded and the host checks that each
+// of the 1024 SIMDs got exactly W) that run the same loop of N instructions of one class.  Three figures per class and W:
+//   * SIMD: (last end - first start of the SIMD's wavefronts, on the chip-wide 100 MHz s_memrealtime) x the clock the loop ran at
+//     (s_memtime ticks with the shader clock; its ratio to s_memrealtime inside the same loop) / (W x N) -- THE figure;
+//   * events: the whole launch between two HIP events, same conversion -- agrees with it to a few per cent;
+//   * own: a wavefront's own elapsed s_memtime / N -- the interval between ITS instructions.  NOT a SIMD rate: the wavefronts of a
+//     SIMD do not all start together, and own / W understates the SIMD's cycles per instruction by up to 2x (this file's first
+//     version reported that and concluded "2 cycles per v_dot2 at eight wavefronts": wrong, retracted in DESIGN.md section 7).
+// the VALU roofline against per-class measured cycles.
+//     hipcc --offload-arch=gfx950 -O3 -o /tmp/ubc scripts/ubench_cycles.hip && /tmp/ubc [json path]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -169,13 +174,14 @@ int main(int argc, char **argv)
 	uint64_t *d_cyc, *d_real; uint32_t *d_sink;
 	hipMalloc(&d_cyc, 1 << 20); hipMalloc(&d_real, 1 << 21); hipMalloc(&d_sink, 1 << 20);
 	FILE *js = argc > 1 ? fopen(argv[1], "w") : nullptr;
-	if(js) fprintf(js, "{\"what\": \"shader cycles a SIMD spends per wavefront-instruction (s_memtime inside the kernel, median over all wavefronts), W wavefronts per SIMD running the same loop\", \"classes\": {\n");
-	printf("%-36s %12s %12s %28s %28s %28s\n", "instruction", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD: cycles (MHz)", "5 waves/SIMD", "8 waves/SIMD");
+	if(js) fprintf(js, "{\"what\": \"shader cycles a SIMD spends per wavefront-instruction with W wavefronts running the same loop: from the first start to the last end of the SIMD's wavefronts (s_memrealtime) at the clock measured inside the loop (s_memtime / s_memrealtime), median over the 1024 SIMDs; events_w8: the launch between two HIP events; own_interval: cycles between ONE wavefront's own instructions\", \"classes\": {\n");
+	printf("%-58s %34s | %20s | %20s | %4s  %s\n", "cycles per wavefront-instruction", "a SIMD, W = 1 2 4 5 8 (first start to last end)", "HIP events, W = 2 4 8", "a wavefront's own, W = 1 4 8", "MHz", "SIMDs seen, most wavefronts on one (W = 2 / 8)");
 	bool first = true;
 #define ROW(OP) do { Res r1 = run<OP>(1, d_cyc, d_real, d_sink), r2 = run<OP>(2, d_cyc, d_real, d_sink), r4 = run<OP>(4, d_cyc, d_real, d_sink), r5 = run<OP>(5, d_cyc, d_real, d_sink), r8 = run<OP>(8, d_cyc, d_real, d_sink); \
-		printf("%-36s %12.3f %12.3f %18.3f (%7.1f) %18.3f (%7.1f) %18.3f (%7.1f)   placement at 2 / 8 waves: %d / %d SIMDs seen, at most %.0f / %.0f wavefronts on one; from first start to last end of a SIMD's wavefronts: %.3f %.3f %.3f %.3f %.3f\n", NAMES[OP], r1.cyc_per_inst, r2.cyc_per_inst, r4.cyc_per_inst, r4.mhz, r5.cyc_per_inst, r5.mhz, r8.cyc_per_inst, r8.mhz, r2.simds_seen, r8.simds_seen, r2.waves_per_simd_seen, r8.waves_per_simd_seen, r1.span_cyc_per_inst, r2.span_cyc_per_inst, r4.span_cyc_per_inst, r5.span_cyc_per_inst, r8.span_cyc_per_inst); \
-		printf("%-36s     the launch between two HIP events: %.3f %.3f %.3f %.3f %.3f\n", "", r1.event_cyc_per_inst, r2.event_cyc_per_inst, r4.event_cyc_per_inst, r5.event_cyc_per_inst, r8.event_cyc_per_inst); \
-		if(js) { fprintf(js, "%s  \"%s\": {\"w1\": %.4f, \"w2\": %.4f, \"w4\": %.4f, \"w5\": %.4f, \"w8\": %.4f, \"mhz_w8\": %.1f}", first ? "" : ",\n", NAMES[OP], r1.cyc_per_inst, r2.cyc_per_inst, r4.cyc_per_inst, r5.cyc_per_inst, r8.cyc_per_inst, r8.mhz); first = false; } } while(0)
+		printf("%-58s %6.2f %6.2f %6.2f %6.2f %6.2f | %6.2f %6.2f %6.2f | %6.2f %6.2f %6.2f | %4.0f  %d/%d %.0f/%.0f\n", NAMES[OP], r1.span_cyc_per_inst, r2.span_cyc_per_inst, r4.span_cyc_per_inst, r5.span_cyc_per_inst, r8.span_cyc_per_inst, \
+		       r2.event_cyc_per_inst, r4.event_cyc_per_inst, r8.event_cyc_per_inst, r1.cyc_per_inst, 4 * r4.cyc_per_inst, 8 * r8.cyc_per_inst, r8.mhz, r2.simds_seen, r8.simds_seen, r2.waves_per_simd_seen, r8.waves_per_simd_seen); \
+		if(js) { fprintf(js, "%s  \"%s\": {\"w1\": %.4f, \"w2\": %.4f, \"w4\": %.4f, \"w5\": %.4f, \"w8\": %.4f, \"events_w8\": %.4f, \"own_interval_w1\": %.4f, \"own_interval_w8\": %.4f, \"mhz_w8\": %.1f}", first ? "" : ",\n", NAMES[OP], \
+		                 r1.span_cyc_per_inst, r2.span_cyc_per_inst, r4.span_cyc_per_inst, r5.span_cyc_per_inst, r8.span_cyc_per_inst, r8.event_cyc_per_inst, r1.cyc_per_inst, 8 * r8.cyc_per_inst, r8.mhz); first = false; } } while(0)
 	ROW(ADD); ROW(LSHR); ROW(XOR); ROW(MOV); ROW(ADD3); ROW(DOT2); ROW(SAD); ROW(PERM); ROW(ALIGNBIT); ROW(MAD24); ROW(MADLO); ROW(MAD64);
 	ROW(FMA64); ROW(ADD64); ROW(MUL64); ROW(CVT_F64_I32); ROW(FMA32); ROW(DPP_ADD); ROW(READLANE); ROW(CNDMASK); ROW(BFE); ROW(MED3);
 	ROW(DOT2_C1); ROW(DOT2_C2); ROW(DOT2_C4); ROW(DOT2_BLK7); ROW(ADD_C1); ROW(ADD_C2); ROW(FMA64_C1); ROW(FMA64_C2); ROW(FMA64_C4); ROW(DOT2_SGPR); ROW(DOT2_SGPR_C2); ROW(EVALG_LIKE);
