@@ -1118,8 +1118,13 @@ __global__ __launch_bounds__(64) void pack_plan_kernel(const DevParams P, const 
 
 // HINTS / NT / RUN: see above
 template <int MAXORD, bool HINTS, int NT, int RUN = CHUNK>
+// Workgroups per CU (wavefronts per SIMD) the register budget is set for.  Round 3 settled on five ("without a spill"); round 6's
+// stamps show a workgroup's wall time is 45 % barriers and first-touch latencies, which more workgroups side by side hide: six for
+// predictors of up to 12 taps (80 registers, one spilled in the -8 instance), seven for up to 8 (72, none) -- pack 0.889 -> 0.838 ms
+// per 65536 frames at -8, 0.895 -> 0.806 at -5, same box (profiles/r06_ap_abn_pack2_waves_*.txt; seven at 12 taps spills 12 and loses).
+// The 17.6 KB image of a 16-bit stereo frame allows seven; longer predictors keep five.
 #ifndef PACK2_WAVES
-#define PACK2_WAVES 5
+#define PACK2_WAVES (MAXORD <= 8 ? 7 : MAXORD <= 12 ? 6 : 5)
 #endif
 __global__ __launch_bounds__(NT, NT == 64 ? 4 : PACK2_WAVES) void pack2_kernel(      // (one-wavefront workgroups: the LDS image allows four per SIMD, no more)
                                                     const DevParams P, const int32_t *__restrict__ chan,
