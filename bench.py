@@ -52,7 +52,12 @@ UBENCH_FILE = os.path.join(ROOT, "profiles", "ubench_cycles.json")   # shader cy
 # floor is a range (all fast .. all slow).
 INT32_SLOW_SHARE = {"evalg_kernel": 0.897}      # profiles/archive/r05_evalg_isa_histogram.txt: dot2 3.831 + sad 0.625 + shifted-word 0.136 of the 5.12 INT32 instructions per sample
 # wavefronts per SIMD a kernel runs with (registers / LDS): which column of the microbenchmark its floor is read from
-KERNEL_WAVES = {"evalg_kernel": 4, "evalw_kernel": 4, "autoc3_kernel": 2, "autoc2_kernel": 4, "prep3_kernel": 5, "pack2_kernel": 5, "ff_kernel": 4, "model_kernel": 4}
+KERNEL_WAVES = {"evalg_kernel": 4, "evalw_kernel": 4, "autoc3_kernel": 2, "autoc2_kernel": 4, "prep3_kernel": 6, "pack2_kernel": 6, "ff_kernel": 4, "model_kernel": 4}
+
+
+def ubench_key(w):
+    """the microbenchmark's column for w wavefronts per SIMD: measured at 1, 2, 4, 5, 8 -- the largest one not above w"""
+    return "w%d" % max(x for x in (1, 2, 4, 5, 8) if x <= max(1, w))
 
 
 def mix_floor(name, entry):
@@ -73,7 +78,7 @@ def mix_floor(name, entry):
         return None
     tot = sum(cl.values())
     out = {}
-    for key in ("w8", "w%d" % KERNEL_WAVES.get(name, 4)):
+    for key in ("w8", ubench_key(KERNEL_WAVES.get(name, 4))):
         c = lambda n: ub[n][key]
         fast = (c("v_add_u32") + c("v_lshrrev_b32") + c("v_xor_b32") + c("v_mov_b32")) / 4
         slow = (c("v_dot2_i32_i16") + c("v_sad_u32") + c("v_perm_b32") + c("v_mad_i32_i24")) / 4
@@ -713,7 +718,7 @@ def main():
                         if not fl:
                             continue
                         ach_c = SIMDS * ck["mhz_mean"] * 1e6 * (v["ms"] * 1e-3) / (v["wave_insts_per_sample"] * samples_per_step)
-                        wk = "w%d" % KERNEL_WAVES.get(nm, 4)
+                        wk = ubench_key(KERNEL_WAVES.get(nm, 4))
                         rnd = lambda x: [round(x[0], 3), round(x[1], 3)] if isinstance(x, tuple) else round(x, 3)
                         frac = lambda x: [round(x[0] / ach_c, 3), round(min(1.0, x[1] / ach_c), 3)] if isinstance(x, tuple) else round(x / ach_c, 3)
                         mf[ph] = {"kernel": nm, "cycles_per_wave_instruction": round(ach_c, 3), "waves_per_simd": KERNEL_WAVES.get(nm, 4),
