@@ -52,7 +52,7 @@ UBENCH_FILE = os.path.join(ROOT, "profiles", "ubench_cycles.json")   # shader cy
 # floor is a range (all fast .. all slow).
 INT32_SLOW_SHARE = {"evalg_kernel": 0.897}      # profiles/archive/r05_evalg_isa_histogram.txt: dot2 3.831 + sad 0.625 + shifted-word 0.136 of the 5.12 INT32 instructions per sample
 # wavefronts per SIMD a kernel runs with (registers / LDS): which column of the microbenchmark its floor is read from
-KERNEL_WAVES = {"evalg_kernel": 4, "evalw_kernel": 4, "autoc3_kernel": 2, "autoc2_kernel": 4, "prep3_kernel": 6, "pack2_kernel": 6, "ff_kernel": 4, "model_kernel": 4}
+KERNEL_WAVES = {"evalg_kernel": 4, "evalw_kernel": 4, "autoc3_kernel": 2, "autoc2_kernel": 4, "prep3_kernel": 4, "pack2_kernel": 6, "ff_kernel": 4, "model_kernel": 4}
 
 
 def ubench_key(w):
