@@ -387,7 +387,9 @@ __global__ __launch_bounds__(TPB, P2_WAVES) void prep2_kernel(const DevParams P,
 // prep3_kernel: stereo frames of 4096 samples with a mid/side search (what the presets from -4 up encode)
 // ---------------------------------------------------------------------------------------------------------
 // Same results as prep2_kernel, different split of the work: wavefront w owns the QUARTER [w*N/4, (w+1)*N/4) of the
-// frame for ALL candidate channels.  It stages its own quarter (coalesced loads -> its own transposed LDS tile, no
+// frame for ALL candidate channels.  (Round 6: <., NW, CH> -- NW wavefronts, each a PART of 64 chunks of CH samples: blocks of
+// NW x 64 x CH samples, i.e. 1024, 2048, 4096, 8192 with chunks of 16 and 1152, 2304, 4608 with chunks of 18 -- the block sizes
+// of `-b` on the LPC presets ran prep2_kernel, 2.7x this kernel's time per sample: VERDICT r05 #7's -8 -b 1152.)  It stages its own quarter (coalesced loads -> its own transposed LDS tile, no
 // workgroup barrier in front of the compute), reads left and right ONCE for the four channels derived from them, and
 // the workgroup meets only twice: to add up the four partial statistics and to learn the wasted bits before the planar
 // channels are written.
@@ -399,59 +401,58 @@ struct Prep3Part {
 };
 struct Prep3Out { uint32_t wasted[4]; int32_t slot[4]; uint32_t fmt[4]; };
 
-template <bool WIDE>
-__global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
+template <bool WIDE, int NW = 4, int CH = CHUNK>
+__global__ __launch_bounds__(64 * NW, 4) void prep3_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain,
                                                        ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
                                                        int32_t *__restrict__ chan)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	__shared__ Prep3Part part[TPB / 64];
+	__shared__ Prep3Part part[NW];
 	__shared__ Prep3Out outp;
 	const int tid = (int)threadIdx.x, lane = tid & 63;
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
-	constexpr uint32_t N = 4096, Q = N / 4;                               // prep3_applicable(): 1024 = one 16-sample chunk per lane; a
+	constexpr uint32_t Q = 64 * CH, N = NW * Q;                           // prep3_applicable(): one CH-sample chunk per lane; a
 	                                                                      // constant tile stride folds every LDS address into an offset
 	const uint32_t f = blockIdx.x;
 	const uint32_t q0 = wave * Q;
 	const int2 *p = (const int2 *)(pcm + (size_t)f * N * 2) + q0;
-	constexpr uint32_t TS = ((Q / CHUNK - 1 + 31) / 32) * 32 + 2, cbytes = CHUNK * TS * 4;     // p2_ts(Q), p2_chan_bytes(Q)
+	constexpr uint32_t TS = ((Q / CH - 1 + 31) / 32) * 32 + 2, cbytes = CH * TS * 4;     // p2_ts(Q, CH), p2_chan_bytes(Q, CH)
 	int32_t *sa = (int32_t *)(smem + (size_t)wave * 2 * cbytes), *sb = (int32_t *)(smem + (size_t)wave * 2 * cbytes + cbytes);
 	const uint32_t cstride = P.ncslots;
 
-	// ---- stage this quarter: sample q0 + i -> row i%16, column i/16 + 1; column 0 = the four samples in front ---------
+	// ---- stage this quarter: sample q0 + i -> row i%CH, column i/CH + 1; column 0 = the four samples in front ---------
 	{
-		int2 v[16];
-		for(uint32_t i0 = 0; i0 < Q; i0 += 64 * 16) {
+		int2 v[CH];
 #pragma unroll
-			for(int r = 0; r < 16; r++) v[r] = p[i0 + (uint32_t)lane + 64u * (uint32_t)r];
+		for(int r = 0; r < CH; r++) v[r] = p[(uint32_t)lane + 64u * (uint32_t)r];
 #pragma unroll
-			for(int r = 0; r < 16; r++) {
-				const uint32_t i = i0 + (uint32_t)lane + 64u * (uint32_t)r;
-				const uint32_t a = (i & 15u) * TS + (i >> 4) + 1;
-				sa[a] = v[r].x; sb[a] = v[r].y;
-			}
+		for(int r = 0; r < CH; r++) {
+			const uint32_t i = (uint32_t)lane + 64u * (uint32_t)r;
+			const uint32_t col = CH == 16 ? i >> 4 : i / (uint32_t)CH, row = i - col * (uint32_t)CH;
+			const uint32_t a = row * TS + col + 1;
+			sa[a] = v[r].x; sb[a] = v[r].y;
 		}
-		if(lane < CHUNK) {
+		if(lane < CH) {
 			int2 h = make_int2(0, 0);
-			if(lane >= 12 && wave) h = p[lane - 16];
+			if(lane >= CH - 4 && wave) h = p[lane - CH];
 			sa[(uint32_t)lane * TS] = h.x; sb[(uint32_t)lane * TS] = h.y;
 		}
 	}
 	__builtin_amdgcn_wave_barrier();
 
-	// ---- statistics of the four channels over this quarter: one 16-sample chunk per lane ------------------------------
-	int32_t a[20], b[20];
+	// ---- statistics of the four channels over this quarter: one CH-sample chunk per lane ------------------------------
+	int32_t a[CH + 4], b[CH + 4];
 	{
 		const int32_t *pa = sa + lane, *pb = sb + lane;
 #pragma unroll
-		for(int k = 0; k < 20; k++) { a[k] = k < 4 ? pa[(12 + k) * TS] : pa[(k - 4) * TS + 1]; b[k] = k < 4 ? pb[(12 + k) * TS] : pb[(k - 4) * TS + 1]; }
+		for(int k = 0; k < CH + 4; k++) { a[k] = k < 4 ? pa[(CH - 4 + k) * TS] : pa[(k - 4) * TS + 1]; b[k] = k < 4 ? pb[(CH - 4 + k) * TS] : pb[(k - 4) * TS + 1]; }
 	}
 	const bool first_chunk = wave == 0 && lane == 0;
 	if(P.ms_mode == 2) {
 		// loose mid/side (stream_encoder.c:3778-3807), bps < 25
 		uint64_t lr_sum = 0, ms_sum = 0;
 #pragma unroll
-		for(int t = 0; t < CHUNK; t++) {
+		for(int t = 0; t < CH; t++) {
 			if(t > 0 || !first_chunk) {
 				const int32_t pl = a[t + 4] - a[t + 3], pr = b[t + 4] - b[t + 3];
 				lr_sum += (uint64_t)(uint32_t)(abs(pl) + abs(pr));
@@ -463,9 +464,9 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 	}
 #pragma unroll
 	for(int c = 0; c < 4; c++) {
-		int32_t x[20];
+		int32_t x[CH + 4];
 #pragma unroll
-		for(int k = 0; k < 20; k++) x[k] = c == 0 ? a[k] : c == 1 ? b[k] : c == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
+		for(int k = 0; k < CH + 4; k++) x[k] = c == 0 ? a[k] : c == 1 ? b[k] : c == 2 ? ((a[k] + b[k]) >> 1) : (a[k] - b[k]);
 		const int32_t first = __builtin_amdgcn_readfirstlane(x[4]);      // this quarter's first sample
 		Prep2Acc A;
 		A.orv = 0; A.diff = 0; A.mag = 0;
@@ -475,13 +476,14 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 		//  samples -- the side channel of a 24-bit stream -- is below 2^28, sixteen of them below 2^32; only the totals across lanes
 		//  and wavefronts need more.  Round 3 added every |difference| in 64 bits for such streams: two instructions instead of one,
 		//  twenty times per sample and channel)
-		if(c == 3) prep2_chunk<false, true, false, CHUNK, true>(x, first_chunk, first, A, nullptr, nullptr, wave == 0);
-		else prep2_chunk<false, false, false, CHUNK, true>(x, first_chunk, first, A, nullptr, nullptr, wave == 0);
+		// (eighteen fourth differences of a 25-bit side channel do not: that one chunk flavour adds in 64 bits, as prep2_kernel's does)
+		if(c == 3) prep2_chunk<(WIDE && CH > 16), true, false, CH, true>(x, first_chunk, first, A, nullptr, nullptr, wave == 0);
+		else prep2_chunk<false, false, false, CH, true>(x, first_chunk, first, A, nullptr, nullptr, wave == 0);
 		A.orv = wave_or_u32(A.orv);
 		A.diff = wave_or_u32(A.diff);
 		if(c == 3) A.mag = wave_or_u32(A.mag);
 #pragma unroll
-		for(int k = 0; k < 5; k++) A.e[k] = WIDE ? wave_sum_u50(A.e[k]) : (uint64_t)wave_sum_u32((uint32_t)A.e[k]);   // !WIDE (bps <= 17, launch_prep2): 2^31 at most
+		for(int k = 0; k < 5; k++) A.e[k] = WIDE ? wave_sum_u50(A.e[k]) : (uint64_t)wave_sum_u32((uint32_t)A.e[k]);   // !WIDE (bps <= 17, launch_prep2): 1152 x 2^21 at most
 		if(lane == 0) {
 			Prep3Part &pt = part[wave];
 			pt.orv[c] = A.orv; pt.diff[c] = A.diff; pt.first[c] = first;
@@ -493,14 +495,17 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 	}
 	__syncthreads();
 
-	// ---- wavefront c decides channel c (every lane holds the totals) ----------------------------------------------------
-	{
-		const uint32_t c = wave, which = wave;                      // 0 left, 1 right, 2 mid, 3 side
+	// ---- wavefront c decides channel c (every lane holds the totals; fewer than four wavefronts: c, c + NW, ...) -----------------
+#pragma unroll 1
+	for(uint32_t c = wave; c < 4; c += NW) {
+		const uint32_t which = c;                                   // 0 left, 1 right, 2 mid, 3 side
 		uint32_t orv = 0, diff = 0, mag = 0;
 		uint64_t e[5] = {0, 0, 0, 0, 0}, lr = 0, ms = 0;
 		bool alleq0 = true;                                         // the LEFT channel is constant (limit_min_bitrate)
 		const int32_t f0 = part[0].first[c];
-		for(int w = 0; w < TPB / 64; w++) {
+		constexpr int UW = NW > 4 ? 2 : NW;                         // (eight parts' sums asked for at once: 25 registers spilled)
+#pragma unroll UW
+		for(int w = 0; w < NW; w++) {
 			orv |= part[w].orv[c]; mag |= part[w].mag;
 			diff |= part[w].diff[c] | (uint32_t)(part[w].first[c] ^ f0);
 			for(int k = 0; k < 5; k++) e[k] += part[w].e[c][k];
@@ -550,25 +555,36 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 
 	// ---- planar channels of this quarter, shifted, straight from the registers ----------------------------------------
 	{
-		const uint32_t base = q0 + (uint32_t)lane * CHUNK;
+		const uint32_t base = q0 + (uint32_t)lane * CH;
 		// the quarter is read again from the LDS tile (conflict-free, behind the barrier) rather than kept in registers across
 		// the decision phase: holding a[], b[] alive there cost 23 spilled VGPRs = 23 KB of scratch written and read per frame
-		int32_t ra[CHUNK], rb[CHUNK];
+		int32_t ra[CH], rb[CH];
 		{
 			const int32_t *pa = sa + lane, *pb = sb + lane;
 #pragma unroll
-			for(int k = 0; k < CHUNK; k++) { ra[k] = pa[k * TS + 1]; rb[k] = pb[k * TS + 1]; }
+			for(int k = 0; k < CH; k++) { ra[k] = pa[k * TS + 1]; rb[k] = pb[k * TS + 1]; }
 		}
 #pragma unroll
 		for(int c = 0; c < 4; c++) {
 			const int32_t slot = outp.slot[c];
 			if(slot < 0) continue;
 			const uint32_t wasted = outp.wasted[c];
-			int32_t x[CHUNK];
+			int32_t x[CH];
 #pragma unroll
-			for(int k = 0; k < CHUNK; k++) x[k] = (c == 0 ? ra[k] : c == 1 ? rb[k] : c == 2 ? ((ra[k] + rb[k]) >> 1) : (ra[k] - rb[k])) >> wasted;
+			for(int k = 0; k < CH; k++) x[k] = (c == 0 ? ra[k] : c == 1 ? rb[k] : c == 2 ? ((ra[k] + rb[k]) >> 1) : (ra[k] - rb[k])) >> wasted;
 			uint32_t *dst = (uint32_t *)(chan + ((size_t)f * P.ncand + (uint32_t)slot) * (size_t)N);
-			if(outp.fmt[c]) {
+			if constexpr(CH != CHUNK) {
+				// 18 samples: nine words of pairs (or eighteen words) at a 36-byte (72-byte) lane stride: plain word stores
+				if(outp.fmt[c]) {
+#pragma unroll
+					for(int j = 0; j < CH / 2; j++) dst[base / 2 + j] = ((uint32_t)x[2 * j] & 0xffffu) | ((uint32_t)x[2 * j + 1] << 16);
+				}
+				else {
+#pragma unroll
+					for(int j = 0; j < CH; j++) dst[base + j] = (uint32_t)x[j];
+				}
+			}
+			else if(outp.fmt[c]) {
 				uint4 w0, w1;
 				w0.x = ((uint32_t)x[0] & 0xffffu) | ((uint32_t)x[1] << 16); w0.y = ((uint32_t)x[2] & 0xffffu) | ((uint32_t)x[3] << 16);
 				w0.z = ((uint32_t)x[4] & 0xffffu) | ((uint32_t)x[5] << 16); w0.w = ((uint32_t)x[6] & 0xffffu) | ((uint32_t)x[7] << 16);
@@ -585,7 +601,19 @@ __global__ __launch_bounds__(TPB, 4) void prep3_kernel(const DevParams P, const 
 		}
 	}
 }
-bool prep3_applicable(const DevParams &P) { return P.channels == 2 && P.ms_mode != 0 && P.blocksize == 4096 && !P.wide_samples; }
+// NW x 64 x CH samples: 4096 as ever; round 6: 1024, 2048, 8192 (chunks of 16) and 1152, 2304, 4608 (chunks of 18) where an LPC search
+// follows (without one the deciding prep2_kernel / ff_kernel own these sizes: prep2_decides)
+static bool prep3_shape(uint32_t n, uint32_t &nw, uint32_t &ch)
+{
+	for(uint32_t c = 16; c <= 18; c += 2) for(uint32_t w = 1; w <= 8; w *= 2) if(n == w * 64 * c && !(c == 18 && w == 8)) { nw = w; ch = c; return true; }
+	return false;
+}
+bool prep3_applicable(const DevParams &P)
+{
+	uint32_t nw, ch;
+	if(!(P.channels == 2 && P.ms_mode != 0 && !P.wide_samples && prep3_shape(P.blocksize, nw, ch))) return false;
+	return P.blocksize == 4096 || (P.max_lpc_order != 0 && !tune().no_prep3n);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // prep4_kernel (round 5): frames of 4096 samples of 1..8 INDEPENDENT channels -- mono, stereo without a mid/side search, 3..8
@@ -849,18 +877,28 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 		return hipGetLastError();
 	}
 	if(prep3_applicable(P) && !tune().no_prep3) {
+		uint32_t nw = 4, ch = 16;
+		(void)prep3_shape(P.blocksize, nw, ch);
 		static AttrFlags attr3;
 		if(AttrOnce once{attr3}) {
-			hipError_t e = hipFuncSetAttribute((const void *)prep3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			hipError_t e = hipSuccess;
+			// (what the instance asks for, no more: the eight-wavefront one has 1.9 KB of static LDS beside it, and 159 KB + that is over the CU's)
+#define P3ATTR(W, NWV, CHV) if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep3_kernel<W, NWV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NWV * p2_chan_bytes(64 * CHV, CHV)))
+			P3ATTR(false, 1, 16); P3ATTR(false, 2, 16); P3ATTR(false, 4, 16); P3ATTR(false, 8, 16); P3ATTR(false, 1, 18); P3ATTR(false, 2, 18); P3ATTR(false, 4, 18);
+			P3ATTR(true, 1, 16); P3ATTR(true, 2, 16); P3ATTR(true, 4, 16); P3ATTR(true, 8, 16); P3ATTR(true, 1, 18); P3ATTR(true, 2, 18); P3ATTR(true, 4, 18);
+#undef P3ATTR
 			if(e != hipSuccess) return e;
 		once.ok();
 		}
 		note_launch(K_PREP3);
-		const size_t lds3 = 8 * (size_t)p2_chan_bytes(P.blocksize / 4);
-		// (the side channel has bps + 1 bits: its quarter's sum of fourth differences is below 2^(bps+14), 32 bits up to 17-bit input)
-		if(P.bps > 17) hipLaunchKernelGGL(prep3_kernel<true>, dim3(nmain), dim3(TPB), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
-		else hipLaunchKernelGGL(prep3_kernel<false>, dim3(nmain), dim3(TPB), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan);
+		const size_t lds3 = 2 * (size_t)nw * p2_chan_bytes(64 * ch, ch);
+		// (the side channel has bps + 1 bits: its part's sum of fourth differences is below 2^(bps+14) -- 1152 of them: 1.125 x that --, 32 bits up to 17-bit input)
+		const bool wide = P.bps > 17;
+#define P3GO(NWV, CHV) do { if(wide) hipLaunchKernelGGL((prep3_kernel<true, NWV, CHV>), dim3(nmain), dim3(64 * NWV), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan); \
+		                    else hipLaunchKernelGGL((prep3_kernel<false, NWV, CHV>), dim3(nmain), dim3(64 * NWV), lds3, s, P, pcm, nmain, B.prep, B.cands, B.valid, B.chan); } while(0)
+		if(ch == 16) { if(nw == 1) P3GO(1, 16); else if(nw == 2) P3GO(2, 16); else if(nw == 4) P3GO(4, 16); else P3GO(8, 16); }
+		else { if(nw == 1) P3GO(1, 18); else if(nw == 2) P3GO(2, 18); else P3GO(4, 18); }
+#undef P3GO
 		return hipGetLastError();
 	}
 	const bool stereo_ms = P.channels == 2 && P.ms_mode != 0;

@@ -15,7 +15,8 @@ import signals  # noqa: E402
 
 NF = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for name, kw in (("-8 (-l 12)", {}), ("-8 -l 13", dict(max_lpc_order=13, streamable_subset=0)), ("-8 -l 16", dict(max_lpc_order=16, streamable_subset=0)), ("-8 -l 32", dict(max_lpc_order=32, streamable_subset=0)),
-                 ("-8 -b 2304", dict(blocksize=2304)), ("-8 -b 1152", dict(blocksize=1152)), ("-8 -b 8192 --lax", dict(blocksize=8192, streamable_subset=0))):
+                 ("-8 -b 2304", dict(blocksize=2304)), ("-8 -b 1152", dict(blocksize=1152)), ("-8 -b 8192 --lax", dict(blocksize=8192, streamable_subset=0)),
+                 ("-8 -b 4608", dict(blocksize=4608)), ("-8 -b 2048", dict(blocksize=2048)), ("-8 -b 1024", dict(blocksize=1024))):
     N = kw.get("blocksize", 4096)
     nf = NF * 4096 // N
     base = signals.music(64 * N, 2, 16, seed=5)
