@@ -628,22 +628,23 @@ bool prep3_applicable(const DevParams &P)
 struct Prep4Part { uint32_t orv[FLACGPU_MAX_CHANNELS], diff[FLACGPU_MAX_CHANNELS]; int32_t first[FLACGPU_MAX_CHANNELS]; uint64_t e[FLACGPU_MAX_CHANNELS][5]; };
 struct Prep4Out { uint32_t wasted[FLACGPU_MAX_CHANNELS], fmt[FLACGPU_MAX_CHANNELS]; };
 
-template <bool WIDE>
-__global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint32_t G,
+// (round 6: <., NW, CH> as prep3_kernel -- blocks of NW x 64 x CH samples)
+template <bool WIDE, int NW = 4, int CH = CHUNK>
+__global__ __launch_bounds__(64 * NW, 4) void prep4_kernel(const DevParams P, const int32_t *__restrict__ pcm, uint32_t nmain, uint32_t G,
                                                        ChanPrep *__restrict__ preps, Candidate *__restrict__ cands, int *__restrict__ valid,
                                                        int32_t *__restrict__ chan)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	__shared__ Prep4Part part[TPB / 64];
+	__shared__ Prep4Part part[NW];
 	__shared__ Prep4Out outp;
 	const int tid = (int)threadIdx.x, lane = tid & 63;
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
-	constexpr uint32_t N = 4096, Q = N / 4;
+	constexpr uint32_t Q = 64 * CH, N = NW * Q;
 	const uint32_t C = P.channels;
 	const uint32_t f = blockIdx.x;
 	const uint32_t q0 = wave * Q;
 	const int32_t *p = pcm + ((size_t)f * N + q0) * C;                      // this quarter: Q * C consecutive words
-	constexpr uint32_t TS = ((Q / CHUNK - 1 + 31) / 32) * 32 + 2, cbytes = CHUNK * TS * 4;     // p2_ts(Q), p2_chan_bytes(Q)
+	constexpr uint32_t TS = ((Q / CH - 1 + 31) / 32) * 32 + 2, cbytes = CH * TS * 4;     // p2_ts(Q, CH), p2_chan_bytes(Q, CH)
 	unsigned char *tiles = smem + (size_t)wave * G * cbytes;               // [G] tiles of this wavefront
 	const uint32_t cstride = P.ncslots;
 	const bool first_chunk = wave == 0 && lane == 0;
@@ -659,26 +660,28 @@ __global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const 
 		{
 			const uint32_t nwords = Q * ng;
 			const uint32_t ginv = ng > 1 ? 0xffffffffu / ng + 1u : 0u;           // ceil(2^32 / ng)
-			for(uint32_t m0 = 0; m0 < nwords; m0 += 64 * 16) {
-				int32_t v[16];
+			constexpr int RB = CH == 16 ? 16 : CH / 2;                              // loads in flight per lane (eighteen at once spilled 14 registers)
+			for(uint32_t m0 = 0; m0 < nwords; m0 += 64 * RB) {
+				int32_t v[RB];
 #pragma unroll
-				for(int r = 0; r < 16; r++) {
-					const uint32_t m = m0 + (uint32_t)lane + 64u * (uint32_t)r;   // (Q * ng is a multiple of 1024)
-					const uint32_t i = ng == 1 ? m : __umulhi(m, ginv), c = m - i * ng;      // m / ng (m < 4096: the reciprocal is exact)
+				for(int r = 0; r < RB; r++) {
+					const uint32_t m = m0 + (uint32_t)lane + 64u * (uint32_t)r;   // (Q * ng is a whole number of passes of 64 x RB words)
+					const uint32_t i = ng == 1 ? m : __umulhi(m, ginv), c = m - i * ng;      // m / ng (m < 4608: the reciprocal is exact)
 					v[r] = p[i * C + cg + c];
 				}
 #pragma unroll
-				for(int r = 0; r < 16; r++) {
+				for(int r = 0; r < RB; r++) {
 					const uint32_t m = m0 + (uint32_t)lane + 64u * (uint32_t)r;
 					const uint32_t i = ng == 1 ? m : __umulhi(m, ginv), c = m - i * ng;
-					((int32_t *)(tiles + (size_t)c * cbytes))[(i & 15u) * TS + (i >> 4) + 1] = v[r];
+					const uint32_t col = CH == 16 ? i >> 4 : i / (uint32_t)CH, row = i - col * (uint32_t)CH;
+					((int32_t *)(tiles + (size_t)c * cbytes))[row * TS + col + 1] = v[r];
 				}
 			}
-			// column 0 = the four samples in front of the quarter (rows 12..15), zeros in front of the block
-			for(uint32_t t = (uint32_t)lane; t < CHUNK * ng; t += 64) {
-				const uint32_t c = t / CHUNK, r = t - c * CHUNK;
+			// column 0 = the four samples in front of the quarter (rows CH - 4 .. CH - 1), zeros in front of the block
+			for(uint32_t t = (uint32_t)lane; t < (uint32_t)CH * ng; t += 64) {
+				const uint32_t c = t / (uint32_t)CH, r = t - c * (uint32_t)CH;
 				int32_t h = 0;
-				if(r >= 12 && wave) h = p[((int32_t)r - 16) * (int32_t)C + (int32_t)(cg + c)];
+				if(r >= (uint32_t)CH - 4 && wave) h = p[((int32_t)r - CH) * (int32_t)C + (int32_t)(cg + c)];
 				((int32_t *)(tiles + (size_t)c * cbytes))[r * TS] = h;
 			}
 		}
@@ -689,15 +692,15 @@ __global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const 
 		for(uint32_t cl = 0; cl < ng; cl++) {
 			const uint32_t c = cg + cl;
 			const int32_t *pa = (const int32_t *)(tiles + (size_t)cl * cbytes) + lane;
-			int32_t x[20];
+			int32_t x[CH + 4];
 #pragma unroll
-			for(int k = 0; k < 20; k++) x[k] = k < 4 ? pa[(12 + k) * TS] : pa[(k - 4) * TS + 1];
+			for(int k = 0; k < CH + 4; k++) x[k] = k < 4 ? pa[(CH - 4 + k) * TS] : pa[(k - 4) * TS + 1];
 			const int32_t first = __builtin_amdgcn_readfirstlane(x[4]);      // this quarter's first sample
 			Prep2Acc A;
 			A.orv = 0; A.diff = 0; A.mag = 0;
 #pragma unroll
 			for(int k = 0; k < 5; k++) A.e[k] = 0;
-			prep2_chunk<false>(x, first_chunk, first, A);                      // (a lane's sixteen differences fit 32 bits at any width served here)
+			prep2_chunk<false, false, false, CH>(x, first_chunk, first, A);    // (a lane's sixteen or eighteen differences fit 32 bits at any width served here: 18 x 2^27)
 			A.orv = wave_or_u32(A.orv);
 			A.diff = wave_or_u32(A.diff);
 #pragma unroll
@@ -712,11 +715,13 @@ __global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const 
 		__syncthreads();
 
 		// ---- wavefront w decides the round's channels cg + w (every lane holds the totals) -------------------------------------------
-		for(uint32_t c = cg + wave; c < cg + ng; c += TPB / 64) {
+		for(uint32_t c = cg + wave; c < cg + ng; c += NW) {
 			uint32_t orv = 0, diff = 0;
 			uint64_t e[5] = {0, 0, 0, 0, 0};
 			const int32_t f0 = part[0].first[c];
-			for(int w = 0; w < TPB / 64; w++) {
+			constexpr int UW = NW > 4 ? 2 : NW;
+#pragma unroll UW
+			for(int w = 0; w < NW; w++) {
 				orv |= part[w].orv[c];
 				diff |= part[w].diff[c] | (uint32_t)(part[w].first[c] ^ f0);
 				for(int k = 0; k < 5; k++) e[k] += part[w].e[c][k];
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const 
 				// (the last channel is in the last round: the records of all the others are there)
 				bool others_constant = true;
 				for(uint32_t o = 0; o + 1 < C; o++)
-					for(int w = 0; w < TPB / 64; w++) others_constant = others_constant && part[w].diff[o] == 0 && part[w].first[o] == part[0].first[o];
+					for(int w = 0; w < NW; w++) others_constant = others_constant && part[w].diff[o] == 0 && part[w].first[o] == part[0].first[o];
 				if(others_constant) disable_constant = true;
 			}
 			uint32_t flags = 0, fixed_order = 0;
@@ -767,17 +772,27 @@ __global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const 
 
 		// ---- planar channels of this quarter, shifted: the tiles are read again (conflict-free, behind the barrier) -----------------
 		{
-			const uint32_t base = q0 + (uint32_t)lane * CHUNK;
+			const uint32_t base = q0 + (uint32_t)lane * CH;
 #pragma unroll 1
 			for(uint32_t cl = 0; cl < ng; cl++) {
 				const uint32_t c = cg + cl;
 				const int32_t *pa = (const int32_t *)(tiles + (size_t)cl * cbytes) + lane;
 				const uint32_t wasted = outp.wasted[c];
-				int32_t x[CHUNK];
+				int32_t x[CH];
 #pragma unroll
-				for(int k = 0; k < CHUNK; k++) x[k] = pa[k * TS + 1] >> wasted;
+				for(int k = 0; k < CH; k++) x[k] = pa[k * TS + 1] >> wasted;
 				uint32_t *dst = (uint32_t *)(chan + ((size_t)f * P.ncand + c) * (size_t)N);
-				if(outp.fmt[c]) {
+				if constexpr(CH != CHUNK) {
+					if(outp.fmt[c]) {
+#pragma unroll
+						for(int j2 = 0; j2 < CH / 2; j2++) dst[base / 2 + j2] = ((uint32_t)x[2 * j2] & 0xffffu) | ((uint32_t)x[2 * j2 + 1] << 16);
+					}
+					else {
+#pragma unroll
+						for(int j2 = 0; j2 < CH; j2++) dst[base + j2] = (uint32_t)x[j2];
+					}
+				}
+				else if(outp.fmt[c]) {
 					uint4 w0, w1;
 					w0.x = ((uint32_t)x[0] & 0xffffu) | ((uint32_t)x[1] << 16); w0.y = ((uint32_t)x[2] & 0xffffu) | ((uint32_t)x[3] << 16);
 					w0.z = ((uint32_t)x[4] & 0xffffu) | ((uint32_t)x[5] << 16); w0.w = ((uint32_t)x[6] & 0xffffu) | ((uint32_t)x[7] << 16);
@@ -797,7 +812,12 @@ __global__ __launch_bounds__(TPB, 4) void prep4_kernel(const DevParams P, const 
 }
 // every channel a candidate channel of its own (no mid/side: ncand == channels), the block size the tiles are built for, and the whole
 // frame in the workgroup's LDS (8 channels: 135 KB)
-bool prep4_applicable(const DevParams &P) { return P.ms_mode == 0 && P.ncand == P.channels && P.blocksize == 4096 && !P.wide_samples && !P.stream_sig; }
+bool prep4_applicable(const DevParams &P)
+{
+	uint32_t nw, ch;
+	if(!(P.ms_mode == 0 && P.ncand == P.channels && !P.wide_samples && !P.stream_sig && prep3_shape(P.blocksize, nw, ch))) return false;
+	return P.blocksize == 4096 || !tune().no_prep3n;                  // (round 6: the other sizes of prep3_shape)
+}
 
 
 // the kernel above serves frames of nominal length when every lane run is whole and the AVX2 short-tail quirk of
@@ -858,22 +878,34 @@ hipError_t launch_prep2(const DevParams &P, const int32_t *pcm, uint32_t nmain, 
 		once.ok();
 	}
 	if(prep4_applicable(P) && !tune().no_fast1 && !tune().no_prep4 && !prep2_decides(P)) {
+		uint32_t nw = 4, ch = 16;
+		(void)prep3_shape(P.blocksize, nw, ch);
+		// channels per round: all of them up to four, else the rounds as even as they come (5, 6 -> 3; 7, 8 -> 4); the eight-wavefront
+		// instance two at most (its tiles are 34 KB per channel of a round)
+		const uint32_t C = P.channels;
+		uint32_t G = C <= 4 ? C : (C + 1) / 2;
+		if(nw == 8 && G > 2) G = 2;
+		const size_t lds4 = (size_t)nw * G * p2_chan_bytes(64 * ch, ch);
 		static AttrFlags attr4;
 		if(AttrOnce once{attr4}) {
-			// (at most four channels' tiles at a time: 68 KB; the kernel's static LDS -- the four partial records -- is 1.7 KB)
-			hipError_t e = hipFuncSetAttribute((const void *)prep4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+			// (at most four channels' tiles at a time: 68 KB, 76 KB with 18-sample chunks; the kernel's static LDS -- the partial records -- is 1.7 KB, 3.4 with eight wavefronts)
+			hipError_t e = hipSuccess;
+#define P4ATTR(W, NWV, CHV) if(e == hipSuccess) e = hipFuncSetAttribute((const void *)prep4_kernel<W, NWV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+			P4ATTR(false, 1, 16); P4ATTR(false, 2, 16); P4ATTR(false, 4, 16); P4ATTR(false, 8, 16); P4ATTR(false, 1, 18); P4ATTR(false, 2, 18); P4ATTR(false, 4, 18);
+			P4ATTR(true, 1, 16); P4ATTR(true, 2, 16); P4ATTR(true, 4, 16); P4ATTR(true, 8, 16); P4ATTR(true, 1, 18); P4ATTR(true, 2, 18); P4ATTR(true, 4, 18);
+#undef P4ATTR
 			if(e != hipSuccess) return e;
 		once.ok();
 		}
 		note_launch(K_PREP1);
-		// channels per round: all of them up to four, else the rounds as even as they come (5, 6 -> 3; 7, 8 -> 4)
-		const uint32_t C = P.channels, G = C <= 4 ? C : (C + 1) / 2;
-		const size_t lds4 = 4 * (size_t)G * p2_chan_bytes(P.blocksize / 4);
-		// (the wavefront's sum of 1024 fourth differences: |d4| < 2^(bps+3), so 32 bits hold it up to 18-bit samples only -- ADVICE r05: at
+		// (the wavefront's sum of 1024 (1152) fourth differences: |d4| < 2^(bps+3), so 32 bits hold it up to 18-bit samples only -- ADVICE r05: at
 		//  20 bits a Nyquist alternation at half of full scale wrapped e[4] and fixed order 4 was guessed instead of 0)
-		if(P.bps > 18) hipLaunchKernelGGL(prep4_kernel<true>, dim3(nmain), dim3(TPB), lds4, s, P, pcm, nmain, G, B.prep, B.cands, B.valid, B.chan);
-		else hipLaunchKernelGGL(prep4_kernel<false>, dim3(nmain), dim3(TPB), lds4, s, P, pcm, nmain, G, B.prep, B.cands, B.valid, B.chan);
+		const bool wide = P.bps > 18;
+#define P4GO(NWV, CHV) do { if(wide) hipLaunchKernelGGL((prep4_kernel<true, NWV, CHV>), dim3(nmain), dim3(64 * NWV), lds4, s, P, pcm, nmain, G, B.prep, B.cands, B.valid, B.chan); \
+		                    else hipLaunchKernelGGL((prep4_kernel<false, NWV, CHV>), dim3(nmain), dim3(64 * NWV), lds4, s, P, pcm, nmain, G, B.prep, B.cands, B.valid, B.chan); } while(0)
+		if(ch == 16) { if(nw == 1) P4GO(1, 16); else if(nw == 2) P4GO(2, 16); else if(nw == 4) P4GO(4, 16); else P4GO(8, 16); }
+		else { if(nw == 1) P4GO(1, 18); else if(nw == 2) P4GO(2, 18); else P4GO(4, 18); }
+#undef P4GO
 		return hipGetLastError();
 	}
 	if(prep3_applicable(P) && !tune().no_prep3) {

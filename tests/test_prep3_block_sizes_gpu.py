@@ -97,3 +97,90 @@ def test_prep3_other_sizes_many_frames(blocksize, level, monkeypatch):
     assert "prep3_kernel" in ks and "prep2_kernel" not in ks, ks
     o = oracle_encode_settings(pcm, s)
     assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"]
+
+
+# ---- prep4_kernel<., NW, CH>: independent channels (mono, stereo without a mid/side search, 3..8 channels) at the same block sizes ----
+def _check4(pcm, s, what, frames=16):
+    import flac_amd
+    from oracle_from_settings import oracle_encode_settings
+    nb = (len(pcm) // s.blocksize) * s.blocksize
+    eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=frames)
+    try:
+        data, fb = eng.encode(pcm[:nb])
+        ks = eng.last_batch_kernels()
+    finally:
+        eng.close()
+    o = oracle_encode_settings(pcm[:nb], s)
+    assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], what
+    assert "prep4_kernel" in ks and "prep2_kernel" not in ks, (what, ks)
+    eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=frames)
+    try:
+        data, fb = eng.encode(pcm)
+    finally:
+        eng.close()
+    o = oracle_encode_settings(pcm, s)
+    assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (what, "with the last block")
+
+
+@pytest.mark.parametrize("blocksize", SIZES)
+@pytest.mark.parametrize("ch,bps,level", [(1, 16, 8), (1, 24, 5), (2, 16, 3), (3, 16, 5), (5, 20, 8), (6, 24, 5), (7, 16, 3), (8, 16, 8), (8, 24, 3)])
+def test_prep4_at_other_block_sizes(blocksize, ch, bps, level, monkeypatch):
+    """rounds of 1..4 channels (two at most with eight wavefronts), uneven last rounds (5 = 3 + 2, 7 = 4 + 3), every sample width's sums"""
+    import flac_amd
+    monkeypatch.setenv("FLACGPU_POISON", "1")
+    kw = dict(mid_side=0) if ch == 2 else {}
+    s = flac_amd.make_settings(ch, bps, 48000, level, blocksize=blocksize, streamable_subset=0, **kw)
+    rng = np.random.default_rng(blocksize * 10 + ch)
+    n = blocksize * 5 + 33
+    fs = 1 << (bps - 1)
+    const = np.tile(np.arange(ch, dtype=np.int32) * 100 - 50, (n, 1))
+    lastc = signals.music(n, ch, bps, seed=4).copy()
+    if ch > 1:
+        lastc[:, :-1] = 7                                            # every channel but the last constant
+    for name, pcm in (("music", signals.music(n, ch, bps, seed=level)), ("noise", rng.integers(-fs, fs, size=(n, ch)).astype(np.int32)),
+                      ("wasted", (signals.music(n, ch, bps, seed=9) >> 3) << 3), ("constant", const), ("all but the last constant", lastc)):
+        _check4(pcm, s, (name, blocksize, ch, bps, level))
+    # limit_min_bitrate (stream_encoder.c:3874-3879): the last channel of an all-constant frame is not CONSTANT -- the rule reads the other channels' records
+    s2 = flac_amd.make_settings(ch, bps, 48000, level, blocksize=blocksize, streamable_subset=0, limit_min_bitrate=1, **kw)
+    _check4(const, s2, ("limit_min_bitrate, all constant", blocksize, ch, bps, level))
+    _check4(lastc, s2, ("limit_min_bitrate, all but the last constant", blocksize, ch, bps, level))
+
+
+@pytest.mark.parametrize("blocksize", SIZES)
+def test_prep4_other_sizes_sums_at_the_32_bit_edge(blocksize, monkeypatch):
+    import flac_amd
+    monkeypatch.setenv("FLACGPU_POISON", "1")
+    q = 64 * (18 if blocksize % 1152 == 0 else 16)
+    n = blocksize * 3
+    sign = np.where(np.arange(n) % 2 == 0, 1, -1).astype(np.int64)
+    for bps in (17, 18, 19, 20, 24):
+        fs = 1 << (bps - 1)
+        wrap = (1 << 32) / (q * 16.0)
+        for mult in (0.51, 0.97, 1.03, 2.02, 1e9):
+            a = int(min(fs - 1, round(wrap * mult)))
+            if a < 1:
+                continue
+            for ch in (1, 3):
+                pcm = np.stack([sign * a if c % 2 == 0 else -sign * (a - c) for c in range(ch)], axis=1).astype(np.int32)
+                s = flac_amd.make_settings(ch, bps, 48000, 5, blocksize=blocksize, streamable_subset=0)
+                _check4(pcm, s, ("edge", blocksize, bps, a, ch))
+
+
+@pytest.mark.parametrize("blocksize,ch,level", [(1152, 1, 8), (4608, 6, 5), (8192, 2, 8), (2048, 1, 5)])
+def test_prep4_other_sizes_many_frames(blocksize, ch, level, monkeypatch):
+    import flac_amd
+    from oracle_from_settings import oracle_encode_settings
+    monkeypatch.setenv("FLACGPU_POISON", "1")
+    kw = dict(mid_side=0) if ch == 2 else {}
+    s = flac_amd.make_settings(ch, 16, 48000, level, blocksize=blocksize, streamable_subset=0, **kw)
+    nframes = 1200000 // (blocksize * ch)
+    pcm = signals.music(nframes * blocksize, ch, 16, seed=blocksize)
+    eng = flac_amd.FrameEngine(s, device=0, max_batch_frames=nframes)
+    try:
+        data, fb = eng.encode(pcm)
+        ks = eng.last_batch_kernels()
+    finally:
+        eng.close()
+    assert "prep4_kernel" in ks and "prep2_kernel" not in ks, ks
+    o = oracle_encode_settings(pcm, s)
+    assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"]
