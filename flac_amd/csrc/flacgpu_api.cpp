@@ -110,7 +110,7 @@ static Tune read_tune(int device)
 	t.copy_results = num("FLACGPU_COPY_RESULTS", 0);          // 1: frame lengths / total copied to the caller's arrays behind the last kernel (round 4's)
 	t.autoc2_ungrouped = set("FLACGPU_AUTOC2_UNGROUPED");
 	{ const char *e = getenv("FLACGPU_AUTOC2"); t.autoc2_force = e ? atoi(e) + 1 : 0; }
-	t.no_ff = set("FLACGPU_NO_FF"); t.no_run18 = set("FLACGPU_NO_RUN18"); t.no_prep3 = set("FLACGPU_NO_PREP3"); t.no_prep3n = set("FLACGPU_NO_PREP3N"); t.no_prep_decide = set("FLACGPU_NO_PREP_DECIDE");
+	t.no_ff = set("FLACGPU_NO_FF"); t.no_run18 = set("FLACGPU_NO_RUN18"); t.no_run18w = set("FLACGPU_NO_RUN18W"); t.no_prep3 = set("FLACGPU_NO_PREP3"); t.no_prep3n = set("FLACGPU_NO_PREP3N"); t.no_prep_decide = set("FLACGPU_NO_PREP_DECIDE");
 	t.no_evalg = set("FLACGPU_NO_EVALG"); t.no_fast1 = set("FLACGPU_NO_FAST1"); t.no_prep4 = set("FLACGPU_NO_PREP4"); t.no_flat = set("FLACGPU_NO_FLAT"); t.no_wide_decide = set("FLACGPU_NO_WIDE_DECIDE"); t.no_evalg32 = set("FLACGPU_NO_EVALG32"); t.no_wide_ff = set("FLACGPU_NO_WIDE_FF");
 	t.eval_wpc = num("FLACGPU_EVAL_WPC", 1) == 2 ? 2 : 1; t.evalw_wpc = num("FLACGPU_EVALW_WPC", 2) == 1 ? 1 : 2;
 	t.eval_waves = num("FLACGPU_EVAL_WAVES", 0); t.eval_cpw = num("FLACGPU_EVAL_CPW", 0); t.eval_prefetch = num("FLACGPU_EVAL_PREFETCH", -1);

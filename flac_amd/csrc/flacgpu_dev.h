@@ -152,7 +152,7 @@ struct Tune {
 	int event_fence, copy_results;      // (host side, flacgpu_api.cpp)
 	int autoc3_ind_sets;          // FLACGPU_AUTOC3_IND_SETS: independent channels, a wavefront per window-job SET: 0 never, 1 always, 2 by the batch's size
 	int autoc2_force;          // FLACGPU_AUTOC2: 0 decide per batch, 1 never, 2 always
-	int no_ff, no_run18, no_prep3, no_prep3n, no_prep4, no_prep_decide, no_evalg, no_fast1, no_flat, no_wide_decide, no_evalg32, no_wide_ff;
+	int no_ff, no_run18, no_run18w, no_prep3, no_prep3n, no_prep4, no_prep_decide, no_evalg, no_fast1, no_flat, no_wide_decide, no_evalg32, no_wide_ff;
 	int eval_wpc, evalw_wpc, eval_waves, eval_cpw, eval_prefetch /* -1: derive */;
 	int sync_debug, no_fused, no_copy_kernel, cands_global;
 	int device;                // the context's device: index of the per-device "attributes set" flags

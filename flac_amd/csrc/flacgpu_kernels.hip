@@ -2330,6 +2330,8 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, TPB / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, true, TPB / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, 64, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, 128, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pack2_kernel<MAXORD, false, 256, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 		}
 		if(e != hipSuccess) return e;
 		once.ok();
@@ -2358,7 +2360,12 @@ static hipError_t launch_pack_t(const DevParams &P, const int32_t *chan, uint32_
 			const bool run18 = run18_ok && (P.blocksize == 1152 || !pack2_applicable(P));      // (1152: always; larger blocks: where the 16-sample instances do not apply)
 			(void)no_run18;
 			if(f_lo) note_launch(K_PACK_PLAN | K_PACK2 | (run18 ? K_PACK2_RUN18 : 0u) | (fused ? K_FO_PLACE : 0u));
-			if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
+			// (round 6: blocks of two / four and more 1152-sample passes -- 2304; 4608, 3456 ... -- on two / four wavefronts: the one-wavefront
+			//  instance walked them pass by pass, 5.1 at -b 4608 packed at 2.2x the time per sample of -b 4096; FLACGPU_NO_RUN18W=1: as before)
+			const uint32_t passes18 = P.blocksize / 1152u;
+			if(f_lo && run18 && passes18 >= 4 && !tune().no_run18w) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 256, 18>), dim3(f_lo), dim3(256), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
+			else if(f_lo && run18 && passes18 >= 2 && !tune().no_run18w) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 128, 18>), dim3(f_lo), dim3(128), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
+			else if(f_lo && run18) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, 64, 18>), dim3(f_lo), dim3(64), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
 			else if(f_lo && hints && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
 			else if(f_lo && hints) hipLaunchKernelGGL((pack2_kernel<MAXORD, true, TPB>), dim3(f_lo), dim3(TPB), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
 			else if(f_lo && half) hipLaunchKernelGGL((pack2_kernel<MAXORD, false, TPB / 2>), dim3(f_lo), dim3(TPB / 2), lds2, s, P, chan, f_lo, plan, pstride, dec, slots, fb, dbg, O, hints);
