@@ -478,7 +478,7 @@ def _random_config(rng):
     """one legal encoder configuration + signal, drawn over the whole range the engine accepts"""
     bps = int(rng.choice([8, 12, 16, 16, 16, 20, 24, 24, 32, int(rng.integers(4, 33))]))
     ch = int(rng.choice([1, 2, 2, 2, 3, 6, 8]))
-    blocksize = int(rng.choice([16, 17, 64, 192, 576, 1000, 1152, 2304, 4096, 4096, 4096, 4608, 8192, 16384, int(rng.integers(16, 5000)),
+    blocksize = int(rng.choice([16, 17, 64, 192, 576, 1000, 1024, 1152, 2048, 2304, 4096, 4096, 4096, 4608, 8192, 16384, int(rng.integers(16, 5000)),
                                 int(rng.choice([16385, 32768, 65535, int(rng.integers(16385, 65536))]))]))
     lpc = int(rng.choice([0, 1, 4, 6, 8, 12, 12, 15, 16, 20, 32, int(rng.integers(0, 33))]))
     lpc = min(lpc, blocksize)
