@@ -11,7 +11,7 @@ oracle/_ref/shell (a build output; the GPU box has no /root/reference); `common.
 is written here.
 The script is 1228 encodes at FLAC__TEST_LEVEL=0, each a process that starts the HIP runtime (0.2 s) and an engine: 8.6 minutes on the
 GPU box (profiles/r06_j_shell_suite_full.log: exit status 0, 1228 files equal).  The suite's default run therefore gives the drop-in
-side FLACGPU_SHELL_BUDGET seconds (default 100) and holds what it got through by then to the reference's files -- a third of the
+side FLACGPU_SHELL_BUDGET seconds (default 60) and holds what it got through by then to the reference's files -- a fifth of the
 script; FLACGPU_SHELL_SUITE=full runs it to its end and demands exit status 0; FLACGPU_SHELL_SUITE=0 skips."""
 import hashlib
 import os
@@ -86,7 +86,7 @@ def _run(tmp, which, libdir, inputs_from=None, budget=None):
 def test_the_references_test_streams_sh_passes_on_the_drop_in_and_leaves_the_references_files(tmp_path):
     tmp = str(tmp_path)
     full = os.environ.get("FLACGPU_SHELL_SUITE", "1") == "full"
-    budget = None if full else int(os.environ.get("FLACGPU_SHELL_BUDGET", "100"))
+    budget = None if full else int(os.environ.get("FLACGPU_SHELL_BUDGET", "60"))
     g, glog, gdir = _run(tmp, "gpu", os.path.join(ROOT, "flac_amd", "lib"), budget=budget)
     # (124: the budget ran out -- what was encoded until then is compared; anything else must be the script's own success)
     assert g.returncode == 0 or (budget and g.returncode == 124), (g.returncode, g.stdout[-1500:], g.stderr[-1500:])
