@@ -299,3 +299,30 @@ def test_batches_of_thousands_of_frames_off_the_headline_path(name, ch, bps, rat
     odata, ofb = _oracle_parallel_kw(pcm, bps, rate, level, block, **okw)
     assert np.array_equal(fb, ofb), name
     assert data == odata, name
+
+
+@pytest.mark.parametrize("ch,bps,level,kw", [(1, 16, 8, {}), (3, 16, 5, {}), (2, 24, 8, dict(mid_side=0)), (1, 16, 8, dict(max_lpc_order=16, streamable_subset=0))])
+def test_the_last_group_of_independent_subframes_is_whole(ch, bps, level, kw, monkeypatch):
+    """round 6: autoc3_kernel<IND> / autoc4_kernel start the batch's last group of 64 rows 64 rows before the end (a partial group took
+    the slow fetch in every window job).  Subframe counts around the multiples of 64 -- fewer than a group, a whole number of groups, one
+    row more, one row less -- against the oracle with the kernel asserted; rows shared with the group before are computed twice."""
+    _force_autoc3(monkeypatch)
+    monkeypatch.setenv("FLACGPU_POISON", "1")
+    import flac_amd
+    from oracle_from_settings import oracle_encode_settings
+    N = 1024
+    want = "autoc4_kernel" if kw.get("max_lpc_order") == 16 else "autoc3_kernel<IND>"
+    st = flac_amd.make_settings(ch, bps, 48000, level, blocksize=N, **kw)
+    for rows in (1, 63, 64, 65, 127, 128, 129, 190):
+        nframes = (rows + ch - 1) // ch
+        pcm = signals.music(nframes * N, ch, bps, seed=rows)
+        eng = flac_amd.FrameEngine(st, device=0, max_batch_frames=nframes)
+        try:
+            data, fb = eng.encode(pcm)
+            kernels = eng.last_batch_kernels()
+        finally:
+            eng.close()
+        o = oracle_encode_settings(pcm, st)
+        assert np.array_equal(fb, o["frame_bytes"]) and data == o["data"], (rows, ch, bps, level, kw, sorted(kernels))
+        if nframes * ch >= 2:
+            assert want in kernels, (rows, sorted(kernels))
