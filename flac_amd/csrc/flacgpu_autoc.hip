@@ -726,8 +726,14 @@ static void launch_autoc3_t(const DevParams &P, const int32_t *pcm, const int32_
 	const int planes = tune().autoc3_planes;
 	const bool pl = planes && chan && P.bps <= 16;
 	const int32_t *src = pl ? chan : pcm;
-	note_launch(K_AUTOC3 | (pl ? K_AUTOC3_PLANES : 0u) | (sets && nsets >= 2 && nsets <= 8 ? K_AUTOC3_SETS : 0u));
-	if(sets && nsets >= 2 && nsets <= 8) {
+	// By SETS (a wavefront sweeps the block once per set: equal wavefronts, a PCM line fetched once per group) or by JOBS (six wavefronts
+	// of three lengths per group at -8, longest first).  Equal wavefronts that do not fill the chip's 2048 slots a whole number of times
+	// leave SIMDs idle while the ones with two wavefronts finish: 8192 frames = 1536 wavefronts took one full round, 0.425 ms, for 0.75
+	// of work; by jobs 0.319 ms (the step +10 %), 12288 frames 0.610 -> 0.504 (+6 %), equal at 16384, by sets ahead from 32768 frames on
+	// (profiles/r06_ay_ab_autoc3_sets_by_batch.txt).  FLACGPU_AUTOC3_SETS = 0: never by sets, 2: always, 1: by sets from 1.5 rounds up.
+	const bool by_sets = sets && nsets >= 2 && nsets <= 8 && (sets == 2 || nsets * ngroups >= 3072u);
+	note_launch(K_AUTOC3 | (pl ? K_AUTOC3_PLANES : 0u) | (by_sets ? K_AUTOC3_SETS : 0u));
+	if(by_sets) {
 		if(pl) hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 1>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc, (uint32_t)tune().no_flat);
 		else hipLaunchKernelGGL((autoc3_kernel<VARIANT, LAG, true, 0>), dim3(nsets * ngroups), dim3(64), 0, s, P, src, win, nmain, jt, preps, autoc, (uint32_t)tune().no_flat);
 	}

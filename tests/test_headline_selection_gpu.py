@@ -28,11 +28,13 @@ with open(os.path.join(os.path.dirname(__file__), "golden", "frames.json")) as f
 SEEN = {"autoc3": 0, "engines": 0}
 
 
-def _force_autoc3(monkeypatch):
+def _force_autoc3(monkeypatch, sets=None):
     """the streaming autocorrelation kernels whatever the batch size (FLACGPU_AUTOC2=1: launch_analyze otherwise gives batches of fewer
     than 640 wavefronts to the wavefront-per-job kernel), and of the two the lane-per-subframe one wherever it applies (FLACGPU_AUTOC3=1)"""
     monkeypatch.setenv("FLACGPU_AUTOC2", "1")
     monkeypatch.setenv("FLACGPU_AUTOC3", "1")
+    if sets is not None:
+        monkeypatch.setenv("FLACGPU_AUTOC3_SETS", str(sets))     # 2: a wavefront per window-job SET whatever the batch size (round 6: small batches go by jobs)
 
 
 def _encode(pcm, bps, rate, level, max_batch=2048, **kw):
@@ -47,7 +49,7 @@ def _encode(pcm, bps, rate, level, max_batch=2048, **kw):
 
 @pytest.mark.parametrize("case", golden_cases(), ids=case_key)
 def test_reference_golden_with_the_lane_per_subframe_autocorrelation(case, monkeypatch):
-    _force_autoc3(monkeypatch)
+    _force_autoc3(monkeypatch, sets=2 if case["level"] % 2 == 0 else 0)       # (both grids: by sets at the even presets, by jobs at the odd ones)
     want = GOLDEN[case_key(case)]
     data, fb, kernels = _encode(case_pcm(case), case["bps"], case["rate"], case["level"], **case_search(case))
     SEEN["engines"] += 1
@@ -99,8 +101,10 @@ def test_full_size_level8_batch_under_the_default_selection_equals_the_oracle_en
         fell = eng.fused_fallbacks()
     finally:
         eng.close()
-    want_kernels = {"prep3_kernel", "autoc3_kernel", "autoc3_kernel<SETS>", "autoc3_kernel<PLANES>", "model_kernel", "evalg_kernel", "pack_plan_kernel", "pack2_kernel", "fused_output"}
-    assert want_kernels <= kernels, sorted(kernels)
+    # (round 6: a batch of this size -- 344 groups x 3 sets = 1032 wavefronts, half a round of the chip's 2048 slots -- goes a wavefront per
+    #  JOB; by sets from 1.5 rounds up: tests/test_large_batch_gpu.py asserts that one)
+    want_kernels = {"prep3_kernel", "autoc3_kernel", "autoc3_kernel<PLANES>", "model_kernel", "evalg_kernel", "pack_plan_kernel", "pack2_kernel", "fused_output"}
+    assert want_kernels <= kernels and "autoc3_kernel<SETS>" not in kernels, sorted(kernels)
     assert not ({"autoc2_kernel", "autoc_kernel", "prep2_kernel", "prep_kernel", "pack_kernel", "scan_kernel", "compact_kernel"} & kernels), sorted(kernels)
     odata, ofb = _oracle_parallel(pcm, 8, block)
     assert np.array_equal(fb, ofb) and np.array_equal(fb2, ofb)

@@ -75,3 +75,5 @@ def test_one_launch_equals_batches_of_16384(level, bps, nframes):
     # the kernels the bench's step runs are the ones that ran here
     if level >= 5 and bps == 16:
         assert {"prep3_kernel", "autoc3_kernel", "evalg_kernel", "pack2_kernel"} <= kernels, sorted(kernels)
+        if level == 8:
+            assert "autoc3_kernel<SETS>" in kernels, sorted(kernels)      # (three window-job sets: a wavefront per set from 1.5 rounds of the chip's slots up)
